@@ -1,0 +1,184 @@
+/* libmggan_hip.so -- C ABI of the MI355X (gfx950) hot path of MG-GAN training.
+ *
+ * The reference (selflein/MG-GAN) has no FFI of its own: its boundary for this
+ * path is the Python class surface mggan.model.* (SURVEY.md 8b).  This header is
+ * the drop-in boundary underneath that surface: every entry point below replaces
+ * the implicit ATen/cuDNN/cuBLAS launches behind one reference call site, cited
+ * per function as file:line under /root/reference/mggan.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every pointer is a DEVICE pointer to
+ *     contiguous f32 / int32 / int64 memory owned by the caller (PyTorch-ROCm
+ *     tensors are storage only).  No allocation, no ownership transfer.
+ *   - every call is asynchronous on `stream`; returns 0 or a negative code, text
+ *     via mggan_last_error().  No global mutable state besides that error string.
+ *   - "ld*" = row stride in floats, so outputs can be written straight into column
+ *     slices of wider buffers (no concatenation kernels).
+ *   - gradients of parameters are ACCUMULATED (+=) into caller-zeroed buffers;
+ *     reductions are two-phase and deterministic (no float atomics).
+ */
+#ifndef MGGAN_HIP_H
+#define MGGAN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mggan_stream_t; /* == hipStream_t */
+
+const char* mggan_last_error(void);
+int mggan_version(void);
+
+/* ---- dense layers: nn.Linear (+activation) forward / input grad / weight grad -------
+ * reference: utils.py:134-149 (make_mlp), discriminators.py:46-56,76-108,
+ *            standard.py:91-105, social.py:13,39-45, cnn.py:102-107
+ * act: 0 none, 1 LeakyReLU(slope) (slope 0 == ReLU), 2 sigmoid, 3 sigmoid*(1-2e-7)+1e-7 (D output) */
+int mggan_linear_fwd(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int rows, int K,
+                     int N, int act, float slope, mggan_stream_t stream);
+/* dZ = dY * act'(Y)  (Y = activation OUTPUT) */
+int mggan_act_bwd(const float* dY, int lddy, const float* Y, int ldy, float* dZ, int lddz, int rows, int N, int act,
+                  float slope, mggan_stream_t stream);
+/* dX (rows x K) (+)= dZ (rows x N) . W (N x K, row stride ldw) */
+int mggan_linear_bwd_data(const float* dZ, int lddz, const float* W, int ldw, float* dX, int lddx, int rows, int K,
+                          int N, int accumulate, mggan_stream_t stream);
+/* dW[g] (N x K, row stride lddw) += dZ_g^T X_g ; db[g] (N) += colsum(dZ_g).  Rows may be
+ * split in n_groups contiguous segments seg[0..n_groups] (device int32, multiplied by
+ * seg_scale) with per-group outputs w_stride / b_stride floats apart (per-generator
+ * decoder weights).  seg == NULL, n_groups <= 1: one group over all rows. */
+int mggan_wgrad_splits(int rows, int K, int N, int n_groups);
+size_t mggan_wgrad_workspace_bytes(int rows, int K, int N, int n_groups);
+int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, int lddw, float* db, int rows, int K,
+                int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, void* workspace,
+                size_t workspace_bytes, mggan_stream_t stream);
+int mggan_transpose(const float* W, float* WT, int N, int K, mggan_stream_t stream);
+/* dst[ped][c] (+)= sum_k src[inv[k*b+ped]][c] : adjoint of "repeat over samples" */
+int mggan_gather_sum(const float* src, int ld_src, const int* inv, float* dst, int ld_dst, int b, int K, int ncols,
+                     int accumulate, mggan_stream_t stream);
+
+/* ---- LSTM trajectory encoder / decoder rollouts ---------------------------------------
+ * reference: common_modules.py:48-66 (TrajectoryEncoder), :97-131 (RelativeDecoder),
+ *            standard.py:91-94,227-265 (enc_h_to_dec_h, forward_all), :190-214 (gather)
+ * mggan_lstm_fold: per group (generator), fold Linear(2,E) into the gate weights and lay
+ * the weights out for the rollout kernels.  Block layout (floats):
+ *   A[4H][2] | bias[4H] | WhhT[H][4H] | dec: W1T[H+S][H/2] | b1[H/2] | W2[2][H/2] | b2[2] */
+int mggan_lstm_prep_size(int H, int S, int dec);
+int mggan_lstm_fold(const float* W_emb, const float* b_emb, const float* W_ih, const float* b_ih, const float* b_hh,
+                    const float* W_hh, const float* W1, const float* b1, const float* W2, const float* b2,
+                    long param_stride, int n_groups, int H, int E, int S, int dec, float* prep, int prep_stride,
+                    mggan_stream_t stream);
+/* chain rule back from (dA[4H][2] | dbias[4H]) to embedding / W_ih / b_ih / b_hh grads */
+int mggan_lstm_unfold_grads(const float* W_emb, const float* b_emb, const float* W_ih, float* dW_emb, float* db_emb,
+                            float* dW_ih, float* db_ih, float* db_hh, long param_stride, int n_groups, int H, int E,
+                            const float* dprep, int dprep_stride, mggan_stream_t stream);
+/* x (T,b,2) -> h_T (b, ld_hout).  Save buffers (all or none): Gt (b,T,4H) gates after
+ * activation, Cs (b,T,H), Hp (b,T,H) = h_{t-1}, Din (b,T,2). */
+int mggan_lstm_encoder_fwd(const float* x, int T, int b, int H, const float* prep, float* hout, int ld_hout, float* Gt,
+                           float* Cs, float* Hp, float* Din, mggan_stream_t stream);
+/* dh_T -> dPre (b,T,4H): gradient of the gate pre-activations (weight grads follow via mggan_wgrad) */
+int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, const float* W_hh, const float* prep,
+                           const float* Gt, const float* Cs, float* dPre, mggan_stream_t stream);
+/* R rollout rows sorted by generator; row r: pedestrian row_ped[r], noise slot row_slot[r],
+ * generator row_gen[r], output position row_pos[r] in (T, Rout, 2). */
+int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const float* prep, int prep_stride,
+                              const int* row_gen, const int* row_ped, const int* row_slot, const int* row_pos,
+                              const float* enc_h, int ld_enc, const float* noise, const float* soc, int ld_soc,
+                              const float* xy0, const float* dxdy0, const float* We2dT, const float* be2d,
+                              float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Hp, float* Hc,
+                              float* Din, float* Aact, float* E2Din, float* SocR, mggan_stream_t stream);
+int mggan_decoder_rollout_bwd(int R, int T, int H, int EIN, int Z, const int* row_gen, const int* row_pos,
+                              const float* W_hh, const float* W1, const float* W2, long param_stride,
+                              const float* We2d, const float* prep, int prep_stride, const float* Gt, const float* Cs,
+                              const float* Aact, const float* gabs, const float* grel, int Rout, float* dPre,
+                              float* dU, float* gD, float* dH0, float* dQ, float* dEnc, float* dSocR,
+                              mggan_stream_t stream);
+
+/* ---- social attention over in-scene ordered pairs ---------------------------------------
+ * reference: social.py:67-104 (features), :33-48 (embedding MLP), :14-30 (attention pooling),
+ *            discriminators.py:179-184 (D-side call; only sample block 0 carries features)
+ * pair p = (pair_i[p], pair_j[p]); per pedestrian: ped_prow = index of pair (i, first j of its
+ * scene), ped_s0 = first pedestrian of its scene, ped_n = scene size.
+ * vc (b x 65) = Wh [W3 | b3] from the generic GEMM; sigma_ij = l2_ij . vc_j[:64] + vc_j[64]. */
+int mggan_social_w3b(const float* W3, const float* b3, float* W3b, int F, mggan_stream_t stream);
+int mggan_social_pairs_fwd(int P, const int* pair_i, const int* pair_j, const float* xy_last, const float* dxdy_last,
+                           const float* W1, const float* b1, const float* W2, const float* b2, const float* vc,
+                           float* feat, float* l1, float* l2, float* sigma, mggan_stream_t stream);
+int mggan_social_softmax_fwd(int b, int H, const int* ped_prow, const int* ped_s0, const int* ped_n,
+                             const float* sigma, const float* h, int ld_h, float* att, float* S, int ld_s,
+                             mggan_stream_t stream);
+int mggan_social_softmax_bwd(int b, int H, const int* ped_prow, const int* ped_s0, const int* ped_n, const float* att,
+                             const float* h, int ld_h, const float* dS, int ld_ds, float* dsigma, float* dh, int ld_dh,
+                             int accumulate_dh, mggan_stream_t stream);
+int mggan_social_pairs_bwd(int P, int b, const int* pair_j, const int* ped_prow, const int* ped_s0, const int* ped_n,
+                           const float* dsigma, const float* vc, const float* l1, const float* l2, const float* W2,
+                           float* dz2, float* dz1, float* dvc, mggan_stream_t stream);
+
+/* ---- scene CNN + physical attention -----------------------------------------------------
+ * reference: cnn.py:119-160 (Conv_Blocks), :275-282 (CNN.forward), :109-116 (AttentionGlobal.forward)
+ * img (B,4,33,33) -> y1 raw (B,C,33,33) -> [BN+ReLU+pool] -> y2 raw (B,C,16,16) -> [BN+ReLU+pool]
+ * -> attention over channels -> out (B,64).  part = per-image (sum, sumsq) per channel (B,2C);
+ * mggan_bn_reduce folds them to f64 sums (all-reduce point for multi-GPU), mggan_bn_finalize
+ * turns sums into scale/shift (+ running-stat update, stat = mean | invstd). */
+int mggan_cnn_bwd_grid(int B);
+int mggan_conv1_fwd(const float* img, int B, int C, const float* W, const float* bias, float* y1, float* part,
+                    mggan_stream_t stream);
+int mggan_bn_reduce(const float* part, int B, int W, double* sums, mggan_stream_t stream);
+int mggan_bn_finalize(const double* sums, double count, int C, int training, const float* gamma, const float* beta,
+                      float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps,
+                      float* scale, float* shift, float* stat, mggan_stream_t stream);
+/* sums: (sum g, sum g*xhat) over the GLOBAL batch (after the all-reduce); local_sums: this rank's share */
+int mggan_bn_bwd_finalize(const double* sums, const double* local_sums, double count, int C, const float* gamma,
+                          const float* stat, float* coef, float* dgamma, float* dbeta, mggan_stream_t stream);
+int mggan_conv2_fwd(const float* y1, int B, int C, const float* scale1, const float* shift1, const float* W,
+                    const float* bias, float* y2, float* part, mggan_stream_t stream);
+int mggan_scene_attention_fwd(const float* y2, int B, int C, const float* scale2, const float* shift2, const float* Wa,
+                              const float* ba, const float* Wb, const float* bb, float* out, int ld_out,
+                              mggan_stream_t stream);
+int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2, const float* shift2,
+                              const float* stat2, const float* Wa, const float* ba, const float* Wb, const float* bb,
+                              const float* dout, int ld_dout, float* ds, float* hact, float* dz, float* vsave,
+                              float* G2, float* part, mggan_stream_t stream);
+int mggan_conv2_bwd(const float* y1, int B, int C, const float* scale1, const float* shift1, const float* stat1,
+                    const float* y2, const float* G2, const float* stat2, const float* coef2, const float* W,
+                    float* G1c, unsigned char* code1, float* part1, float* dW, float* db, float* workspace,
+                    size_t workspace_bytes, mggan_stream_t stream);
+int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float* stat1, const float* coef1,
+                    const float* G1c, const unsigned char* code1, float* dW, float* db, float* workspace,
+                    size_t workspace_bytes, mggan_stream_t stream);
+
+/* ---- losses (+ gradients), clipping, AdamW ----------------------------------------------
+ * reference: abstract_train.py:62-67, utils.py:18-25, train.py:58-75,92-113,181-200,626-639,
+ *            train.py:131-135,209-213,656-658, abstract_train.py:45-50 */
+/* p = D output rows; loss_r = w_r*scale*BCE(p_r,label), w_r = inv_count[row_gen[r]] (or 1); dp = dloss/dp */
+int mggan_bce_rows(int rows, const float* p, float label, float scale, const int* row_gen, const float* inv_count,
+                   float* loss_rows, float* dp, mggan_stream_t stream);
+int mggan_scale(float* x, long n, const float* scalar, mggan_stream_t stream);
+/* classifier input of the discriminator (discriminators.py:141,185,196): rows k*b+ped =
+ * [soc (sample block 0 only) | in_enc | pred_enc | scene], and its adjoint */
+int mggan_d_assemble_fwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, const float* soc0,
+                         const float* in_enc, const float* pred_enc, const float* scene, float* X,
+                         mggan_stream_t stream);
+int mggan_d_assemble_bwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, const float* dX, float* dsoc0,
+                         float* din_enc, float* dpred_enc, float* dscene, mggan_stream_t stream);
+int mggan_ce_rows(int rows, int g, const float* logits, int ld, const int* target, const float* inv_count, float scale,
+                  float* loss_rows, float* dlogits, int ldd, mggan_stream_t stream);
+int mggan_l2_min_scene(int S, int T, int K, int b, const int* scenes, const int* ped_scene, const float* gen_abs,
+                       const float* gt, float grad_scale, float* scene_loss, int* scene_arg, float* gabs,
+                       mggan_stream_t stream);
+int mggan_pm_ml_loss(int b, int T, int E, int g, const float* gen_abs, const float* gt, const float* logits, float sigma,
+                     float scale, float* loss_rows, float* dlogits, float* probs, mggan_stream_t stream);
+int mggan_sum(const float* x, long n, float alpha, float* out, int accumulate, mggan_stream_t stream);
+int mggan_colmean(const float* x, int rows, int g, float scale, float* out, mggan_stream_t stream);
+int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count, mggan_stream_t stream);
+int mggan_inv_counts(const int* counts, int g, float* inv_count, mggan_stream_t stream);
+/* flat parameter buffer + segment table: elem_seg[i] = segment of element i (-1 = padding),
+ * active[s] = segment takes part in this step (grad not None), seg_step[s] = Adam step count */
+int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, const int* elem_seg, int nseg,
+                     const unsigned char* active, int* seg_step, float max_norm, double lr, double beta1, double beta2,
+                     double eps, double weight_decay, double* workspace, float* norm_out, mggan_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

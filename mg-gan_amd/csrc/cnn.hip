@@ -1,0 +1,680 @@
+// Scene CNN + physical (channel-softmax) attention for MG-GAN on gfx950.
+//
+// Replaces (file:line under /root/reference/mggan/model/modules/cnn.py):
+//   Conv_Blocks  :119-160   Conv2d(3x3,p1) -> BatchNorm2d -> ReLU -> MaxPool2d(2)   (x2, C = 16 in G, 8 in D)
+//   CNN.forward  :275-282   (B,4,33,33) -> (B,C,16,16) -> (B,C,8,8)
+//   AttentionGlobal.forward :109-116  per position: MLP C->32->C (LeakyReLU .01), softmax over CHANNELS, sum_c a_c x_c
+// BatchNorm runs in train mode on the hot path (abstract_train.py:111-112): batch statistics
+// sit between conv and ReLU, so each block is "conv + per-image partial sums" -> tiny
+// reduce/finalize -> the NEXT kernel applies scale/shift + ReLU + 2x2 max-pool in its prologue
+// while staging its input tile into LDS (the normalised / pooled activations never touch HBM).
+// Direct convolution, register-tiled: one workgroup per image, wave w owns a group of output
+// channels (weights become wave-uniform -> scalar loads), lane owns a 1x4 strip of positions
+// and reads its 3x6 input patch with one b128 + one b64 LDS read per row.
+#include "common.h"
+#include "../../include/mggan_hip.h"
+
+#define IH 33
+#define IPIX (IH * IH)
+#define IMG_LD 40     // padded row stride of the 35-row input image in LDS
+#define IMG_PLANE (35 * IMG_LD)
+#define A1_LD 20      // padded row stride of the 18x18 (16x16 + halo) tiles
+#define A1_PLANE (18 * A1_LD)
+#define HID 32
+
+__device__ __forceinline__ void load6(const float* p, float r[6]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float2 b = *reinterpret_cast<const float2*>(p + 4);
+  r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y;
+}
+
+__device__ __forceinline__ void stage_image(const float* __restrict__ img, float* imgp) {
+  for (int idx = threadIdx.x; idx < 4 * IMG_PLANE; idx += 256) {
+    const int ci = idx / IMG_PLANE, rem = idx % IMG_PLANE, yy = rem / IMG_LD, xx = rem % IMG_LD;
+    float v = 0.f;
+    if (yy >= 1 && yy <= IH && xx >= 1 && xx <= IH) v = img[(ci * IH + (yy - 1)) * IH + (xx - 1)];
+    imgp[idx] = v;
+  }
+}
+
+// ---------------- conv1: (4,33,33) -> raw (C,33,33) + per-image (sum, sumsq) ----------------
+template <int C>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ y1,
+                                                        float* __restrict__ part) {
+  constexpr int COT = C / 4;
+  __shared__ __attribute__((aligned(16))) float imgp[4 * IMG_PLANE];
+  const int b = blockIdx.x;
+  stage_image(img + (size_t)b * 4 * IPIX, imgp);
+  __syncthreads();
+  const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pg = threadIdx.x & 63;
+  float sum[COT], sq[COT];
+#pragma unroll
+  for (int co = 0; co < COT; ++co) sum[co] = sq[co] = 0.f;
+  for (int s = pg; s < IH * 9; s += 64) {
+    const int y = s / 9, x0 = (s % 9) * 4;
+    float acc[COT][4];
+#pragma unroll
+    for (int co = 0; co < COT; ++co) {
+      const float bv = bias[cg * COT + co];
+#pragma unroll
+      for (int px = 0; px < 4; ++px) acc[co][px] = bv;
+    }
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        float r[6];
+        load6(&imgp[ci * IMG_PLANE + (y + ky) * IMG_LD + x0], r);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int co = 0; co < COT; ++co) {
+            const float w = W[((cg * COT + co) * 4 + ci) * 9 + ky * 3 + kx];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) acc[co][px] = fmaf(w, r[px + kx], acc[co][px]);
+          }
+      }
+#pragma unroll
+    for (int co = 0; co < COT; ++co) {
+      float* o = y1 + (((size_t)b * C + cg * COT + co) * IH + y) * IH + x0;
+#pragma unroll
+      for (int px = 0; px < 4; ++px)
+        if (x0 + px < IH) {
+          const float v = acc[co][px];
+          o[px] = v;
+          sum[co] += v;
+          sq[co] = fmaf(v, v, sq[co]);
+        }
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < COT; ++co) {
+    const float s = wave_sum(sum[co]), q = wave_sum(sq[co]);
+    if (pg == 0) {
+      part[(size_t)b * 2 * C + cg * COT + co] = s;
+      part[(size_t)b * 2 * C + C + cg * COT + co] = q;
+    }
+  }
+}
+
+// sums[col] = sum_b part[b][col]   (f64 accumulation; one block per column)
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ part, int B, int W, double* sums) {
+  __shared__ double red[256];
+  const int col = blockIdx.x;
+  double acc = 0.0;
+  for (int r = threadIdx.x; r < B; r += 256) acc += (double)part[(size_t)r * W + col];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[col] = red[0];
+}
+
+// train: batch statistics -> scale/shift (+ running-stat update, cnn.py BN_1 momentum 0.1, eps 1e-5)
+// eval : running statistics -> scale/shift.   stat[0..C) = mean, stat[C..2C) = invstd.
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, int C, int training,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* run_mean,
+                                   float* run_var, long long* nbt, float momentum, float eps, float* scale,
+                                   float* shift, float* stat) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    const double m = sums[c] / count;
+    double v = sums[C + c] / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    if (c == 0) *nbt += 1;
+  } else {
+    mean = run_mean[c];
+    var = run_var[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  stat[c] = mean;
+  stat[C + c] = invstd;
+}
+
+// sums = (sum g, sum g*xhat) -> coef[0..C)=gamma*invstd, [C..2C)=mean(g), [2C..3C)=mean(g*xhat); dgamma/dbeta +=
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ local,
+                                       double count, int C,
+                                       const float* __restrict__ gamma, const float* __restrict__ stat, float* coef,
+                                       float* dgamma, float* dbeta) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  coef[c] = gamma[c] * stat[C + c];
+  coef[C + c] = (float)(sums[c] / count);
+  coef[2 * C + c] = (float)(sums[C + c] / count);
+  // parameter grads use this rank's LOCAL sums (the gradient all-reduce adds the ranks up)
+  dbeta[c] += (float)local[c];
+  dgamma[c] += (float)local[C + c];
+}
+
+// a1 = maxpool2(relu(y1*scale+shift)) for pooled position (py,px), channel c; returns argmax code / raw value
+__device__ __forceinline__ float pool_bn_relu(const float* __restrict__ base, int ld, float sc, float sh, int& code,
+                                              float& raw) {
+  const float v[4] = {base[0], base[1], base[ld], base[ld + 1]};
+  float best = fmaxf(fmaf(v[0], sc, sh), 0.f);
+  code = 0;
+  raw = v[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const float z = fmaxf(fmaf(v[k], sc, sh), 0.f);
+    if (z > best) { best = z; code = k; raw = v[k]; }
+  }
+  return best;
+}
+
+// ---------------- conv2: BN1+ReLU+pool prologue, (C,16,16) -> raw (C,16,16) + partial stats ----------------
+template <int C>
+__global__ __launch_bounds__(256) void conv2_fwd_kernel(const float* __restrict__ y1, const float* __restrict__ scale1,
+                                                        const float* __restrict__ shift1, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ y2,
+                                                        float* __restrict__ part) {
+  constexpr int COT = C / 4;
+  __shared__ __attribute__((aligned(16))) float a1p[C * A1_PLANE];
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < C * A1_PLANE; i += 256) a1p[i] = 0.f;
+  __syncthreads();
+  {
+    const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+      int code; float raw;
+      const float* base = y1 + (((size_t)b * C + c) * IH + 2 * py) * IH + 2 * px;
+      a1p[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = pool_bn_relu(base, IH, scale1[c], shift1[c], code, raw);
+    }
+  }
+  __syncthreads();
+  const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pg = threadIdx.x & 63;
+  const int py = pg >> 2, x0 = (pg & 3) * 4;
+  float acc[COT][4];
+#pragma unroll
+  for (int co = 0; co < COT; ++co) {
+    const float bv = bias[cg * COT + co];
+#pragma unroll
+    for (int px = 0; px < 4; ++px) acc[co][px] = bv;
+  }
+#pragma unroll 2
+  for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      float r[6];
+      load6(&a1p[ci * A1_PLANE + (py + ky) * A1_LD + x0], r);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int co = 0; co < COT; ++co) {
+          const float w = W[((cg * COT + co) * C + ci) * 9 + ky * 3 + kx];
+#pragma unroll
+          for (int px = 0; px < 4; ++px) acc[co][px] = fmaf(w, r[px + kx], acc[co][px]);
+        }
+    }
+#pragma unroll
+  for (int co = 0; co < COT; ++co) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int px = 0; px < 4; ++px) { s += acc[co][px]; q = fmaf(acc[co][px], acc[co][px], q); }
+    *reinterpret_cast<float4*>(y2 + (((size_t)b * C + cg * COT + co) * 16 + py) * 16 + x0) =
+        make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (pg == 0) {
+      part[(size_t)b * 2 * C + cg * COT + co] = s;
+      part[(size_t)b * 2 * C + C + cg * COT + co] = q;
+    }
+  }
+}
+
+// ---------------- attention head: BN2+ReLU+pool prologue, 64 positions per image ----------------
+template <int C, bool BWD>
+__global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restrict__ y2, const float* __restrict__ scale2,
+                                                   const float* __restrict__ shift2, const float* __restrict__ Wa,
+                                                   const float* __restrict__ ba, const float* __restrict__ Wb,
+                                                   const float* __restrict__ bb, float* out, int ld_out,
+                                                   // backward only
+                                                   const float* __restrict__ dout, int ld_dout,
+                                                   const float* __restrict__ stat2, float* ds_s, float* hact,
+                                                   float* dz_s, float* vsave, float* G2, float* part) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), pos = threadIdx.x & 63;
+  if (b >= B) return;  // whole waves leave together
+  const int py = pos >> 3, px = pos & 7;
+  float v[C], raw[C];
+  int code[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float* base = y2 + (((size_t)b * C + c) * 16 + 2 * py) * 16 + 2 * px;
+    v[c] = pool_bn_relu(base, 16, scale2[c], shift2[c], code[c], raw[c]);
+  }
+  float hid[HID];
+#pragma unroll
+  for (int k = 0; k < HID; ++k) {
+    float s = ba[k];
+#pragma unroll
+    for (int c = 0; c < C; ++c) s = fmaf(Wa[k * C + c], v[c], s);
+    hid[k] = s > 0.f ? s : 0.01f * s;  // nn.LeakyReLU() default slope, cnn.py:19-20
+  }
+  float sc[C], mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float s = bb[c];
+#pragma unroll
+    for (int k = 0; k < HID; ++k) s = fmaf(Wb[c * HID + k], hid[k], s);
+    sc[c] = s;
+    mx = fmaxf(mx, s);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { sc[c] = __expf(sc[c] - mx); den += sc[c]; }
+  const float inv = 1.f / den;
+  float o = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { sc[c] *= inv; o = fmaf(sc[c], v[c], o); }
+  if (!BWD) {
+    out[(size_t)b * ld_out + pos] = o;
+    return;
+  }
+  // ---- backward: out = sum_c a_c v_c, a = softmax(s) ----
+  const float go = dout[(size_t)b * ld_dout + pos];
+  const size_t row = (size_t)b * 64 + pos;
+  float dv[C], dsv[C], dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { dv[c] = go * sc[c]; dot = fmaf(sc[c], go * v[c], dot); }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    dsv[c] = sc[c] * (go * v[c] - dot);
+    ds_s[row * C + c] = dsv[c];
+    vsave[row * C + c] = v[c];
+  }
+#pragma unroll
+  for (int k = 0; k < HID; ++k) {
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) d = fmaf(Wb[c * HID + k], dsv[c], d);
+    d *= hid[k] > 0.f ? 1.f : 0.01f;
+    dz_s[row * HID + k] = d;
+    hact[row * HID + k] = hid[k];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dv[c] = fmaf(Wa[k * C + c], d, dv[c]);
+  }
+  // route through max-pool + ReLU to the raw conv2 output grid; partial sums for the BN backward
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float g = v[c] > 0.f ? dv[c] : 0.f;
+    float* gb = G2 + (((size_t)b * C + c) * 16 + 2 * py) * 16 + 2 * px;
+    gb[0] = code[c] == 0 ? g : 0.f;
+    gb[1] = code[c] == 1 ? g : 0.f;
+    gb[16] = code[c] == 2 ? g : 0.f;
+    gb[17] = code[c] == 3 ? g : 0.f;
+    const float xh = (raw[c] - stat2[c]) * stat2[C + c];
+    const float s1 = wave_sum(g), s2 = wave_sum(g * xh);
+    if (pos == 0) {
+      part[(size_t)b * 2 * C + c] = s1;
+      part[(size_t)b * 2 * C + C + c] = s2;
+    }
+  }
+}
+
+// ---------------- conv2 backward: BN2 bwd + weight grad + input grad routed through pool1/ReLU ----------------
+template <int C>
+__global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __restrict__ y1,
+                                                        const float* __restrict__ scale1,
+                                                        const float* __restrict__ shift1,
+                                                        const float* __restrict__ stat1, const float* __restrict__ y2,
+                                                        const float* __restrict__ G2, const float* __restrict__ stat2,
+                                                        const float* __restrict__ coef2, const float* __restrict__ W,
+                                                        float* G1c, unsigned char* code1, float* part1, float* wpart) {
+  constexpr int COT = C / 4, PAIRS = C * C, NQ = 256 / PAIRS, ROWS = 16 / NQ, WLEN = PAIRS * 9 + C;
+  __shared__ __attribute__((aligned(16))) float dyp[C * A1_PLANE];
+  __shared__ __attribute__((aligned(16))) float a1p[C * A1_PLANE];
+  __shared__ float y1r[C * 256];
+  for (int i = threadIdx.x; i < C * A1_PLANE; i += 256) { dyp[i] = 0.f; a1p[i] = 0.f; }
+  const int pair = threadIdx.x % PAIRS, rq = threadIdx.x / PAIRS;
+  const int wco = pair / C, wci = pair % C;
+  float wacc[9], bacc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wacc[k] = 0.f;
+  const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pg = threadIdx.x & 63;
+  const int ty = pg >> 2, x0 = (pg & 3) * 4;
+
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    {
+      const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
+#pragma unroll 2
+      for (int c = 0; c < C; ++c) {
+        int code; float raw;
+        const float* base = y1 + (((size_t)b * C + c) * IH + 2 * py) * IH + 2 * px;
+        a1p[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = pool_bn_relu(base, IH, scale1[c], shift1[c], code, raw);
+        y1r[c * 256 + threadIdx.x] = raw;
+        const size_t gi = ((size_t)b * C + c) * 256 + threadIdx.x;
+        code1[gi] = (unsigned char)code;
+        const float xh = (y2[gi] - stat2[c]) * stat2[C + c];
+        dyp[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (G2[gi] - coef2[C + c] - xh * coef2[2 * C + c]);
+      }
+    }
+    __syncthreads();
+    // (1) weight gradient: dW[co][ci][ky][kx] += sum_{y,x} dy[co][y][x] * a1p[ci][y+ky][x+kx]
+    for (int y = rq * ROWS; y < (rq + 1) * ROWS; ++y) {
+      float dy[16];
+#pragma unroll
+      for (int x = 0; x < 16; x += 4) {
+        // interior starts at column 1 -> unaligned for b128; read scalars
+        dy[x] = dyp[wco * A1_PLANE + (y + 1) * A1_LD + x + 1];
+        dy[x + 1] = dyp[wco * A1_PLANE + (y + 1) * A1_LD + x + 2];
+        dy[x + 2] = dyp[wco * A1_PLANE + (y + 1) * A1_LD + x + 3];
+        dy[x + 3] = dyp[wco * A1_PLANE + (y + 1) * A1_LD + x + 4];
+      }
+      if (wci == 0) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) bacc += dy[x];
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        float ar[20];
+#pragma unroll
+        for (int x = 0; x < 20; x += 4) {
+          const float4 t4 = *reinterpret_cast<const float4*>(&a1p[wci * A1_PLANE + (y + ky) * A1_LD + x]);
+          ar[x] = t4.x; ar[x + 1] = t4.y; ar[x + 2] = t4.z; ar[x + 3] = t4.w;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int x = 0; x < 16; ++x) wacc[ky * 3 + kx] = fmaf(dy[x], ar[x + kx], wacc[ky * 3 + kx]);
+      }
+    }
+    // (2) input gradient (flipped kernel), tile = COT input channels x 4 positions
+    float acc[COT][4];
+#pragma unroll
+    for (int ci = 0; ci < COT; ++ci)
+#pragma unroll
+      for (int px = 0; px < 4; ++px) acc[ci][px] = 0.f;
+#pragma unroll 2
+    for (int co = 0; co < C; ++co)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        float r[6];
+        load6(&dyp[co * A1_PLANE + (ty + ky) * A1_LD + x0], r);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int ci = 0; ci < COT; ++ci) {
+            const float w = W[((co * C) + cg * COT + ci) * 9 + (2 - ky) * 3 + (2 - kx)];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) acc[ci][px] = fmaf(w, r[px + kx], acc[ci][px]);
+          }
+      }
+#pragma unroll
+    for (int ci = 0; ci < COT; ++ci) {
+      const int c = cg * COT + ci;
+      float g[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        const bool on = a1p[c * A1_PLANE + (ty + 1) * A1_LD + x0 + px + 1] > 0.f;
+        g[px] = on ? acc[ci][px] : 0.f;
+        const float xh = (y1r[c * 256 + ty * 16 + x0 + px] - stat1[c]) * stat1[C + c];
+        s1 += g[px];
+        s2 = fmaf(g[px], xh, s2);
+      }
+      *reinterpret_cast<float4*>(G1c + (((size_t)b * C + c) * 16 + ty) * 16 + x0) = make_float4(g[0], g[1], g[2], g[3]);
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      if (pg == 0) {
+        part1[(size_t)b * 2 * C + c] = s1;
+        part1[(size_t)b * 2 * C + C + c] = s2;
+      }
+    }
+  }
+  float* wp = wpart + ((size_t)blockIdx.x * NQ + rq) * WLEN;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wp[pair * 9 + k] = wacc[k];
+  if (wci == 0) wp[PAIRS * 9 + wco] = bacc;
+}
+
+// ---------------- conv1 backward: BN1 bwd + weight grad (the image needs no gradient) ----------------
+template <int C>
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(int B, const float* __restrict__ img,
+                                                        const float* __restrict__ y1, const float* __restrict__ stat1,
+                                                        const float* __restrict__ coef1, const float* __restrict__ G1c,
+                                                        const unsigned char* __restrict__ code1, float* wpart) {
+  constexpr int PAIRS = C * 4, NQ = 256 / PAIRS, RPQ = (IH + NQ - 1) / NQ, DLD = 36, WLEN = PAIRS * 9 + C;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* imgp = smem;                  // 4*IMG_PLANE
+  float* dy1 = smem + 4 * IMG_PLANE;   // C*33*36
+  for (int i = threadIdx.x; i < C * IH * DLD; i += 256) dy1[i] = 0.f;
+  const int pair = threadIdx.x % PAIRS, rq = threadIdx.x / PAIRS;
+  const int wco = pair / 4, wci = pair % 4;
+  float wacc[9], bacc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wacc[k] = 0.f;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    stage_image(img + (size_t)b * 4 * IPIX, imgp);
+    for (int idx = threadIdx.x; idx < C * IPIX; idx += 256) {
+      const int c = idx / IPIX, rem = idx % IPIX, y = rem / IH, x = rem % IH;
+      const float xh = (y1[(size_t)b * C * IPIX + idx] - stat1[c]) * stat1[C + c];
+      float g = 0.f;
+      if (y < 32 && x < 32) {
+        const size_t pi = (((size_t)b * C + c) * 16 + (y >> 1)) * 16 + (x >> 1);
+        if (code1[pi] == ((y & 1) * 2 + (x & 1))) g = G1c[pi];
+      }
+      dy1[(c * IH + y) * DLD + x] = coef1[c] * (g - coef1[C + c] - xh * coef1[2 * C + c]);
+    }
+    __syncthreads();
+    const int yend = min(IH, (rq + 1) * RPQ);
+    for (int y = rq * RPQ; y < yend; ++y) {
+      float dy[DLD];
+#pragma unroll
+      for (int x = 0; x < DLD; x += 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(&dy1[(wco * IH + y) * DLD + x]);
+        dy[x] = t4.x; dy[x + 1] = t4.y; dy[x + 2] = t4.z; dy[x + 3] = t4.w;
+      }
+      if (wci == 0) {
+#pragma unroll
+        for (int x = 0; x < IH; ++x) bacc += dy[x];
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        float ar[IMG_LD];
+#pragma unroll
+        for (int x = 0; x < IMG_LD; x += 4) {
+          const float4 t4 = *reinterpret_cast<const float4*>(&imgp[wci * IMG_PLANE + (y + ky) * IMG_LD + x]);
+          ar[x] = t4.x; ar[x + 1] = t4.y; ar[x + 2] = t4.z; ar[x + 3] = t4.w;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int x = 0; x < IH; ++x) wacc[ky * 3 + kx] = fmaf(dy[x], ar[x + kx], wacc[ky * 3 + kx]);
+      }
+    }
+  }
+  float* wp = wpart + ((size_t)blockIdx.x * NQ + rq) * WLEN;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wp[pair * 9 + k] = wacc[k];
+  if (wci == 0) wp[PAIRS * 9 + wco] = bacc;
+}
+
+// dst[o] += sum_z P[z][o]
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ P, int nP, int len, float* dst) {
+  __shared__ float red[4][64];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (o < len)
+    for (int z = zl; z < nP; z += 4) s += P[(size_t)z * len + o];
+  red[zl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (zl == 0 && o < len)
+    dst[o] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+static int persistent_grid(int B) { return B < 256 ? B : 256; }
+
+extern "C" {
+
+int mggan_cnn_bwd_grid(int B) { return persistent_grid(B); }
+
+int mggan_conv1_fwd(const float* img, int B, int C, const float* W, const float* bias, float* y1, float* part,
+                    hipStream_t stream) {
+  MG_CHECK_ARG(C == 8 || C == 16, "conv1_fwd: channels %d not built (8 or 16)", C);
+  if (B == 0) return MGGAN_OK;
+  MG_CHECK_ARG(img && W && bias && y1 && part, "conv1_fwd: null pointer");
+  if (C == 16) hipLaunchKernelGGL((conv1_fwd_kernel<16>), dim3(B), dim3(256), 0, stream, img, W, bias, y1, part);
+  else hipLaunchKernelGGL((conv1_fwd_kernel<8>), dim3(B), dim3(256), 0, stream, img, W, bias, y1, part);
+  MG_LAUNCH_CHECK("conv1_fwd");
+  return MGGAN_OK;
+}
+
+int mggan_bn_reduce(const float* part, int B, int W, double* sums, hipStream_t stream) {
+  MG_CHECK_ARG(part && sums && W > 0, "bn_reduce: bad arguments");
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3(W), dim3(256), 0, stream, part, B, W, sums);
+  MG_LAUNCH_CHECK("bn_reduce");
+  return MGGAN_OK;
+}
+
+int mggan_bn_finalize(const double* sums, double count, int C, int training, const float* gamma, const float* beta,
+                      float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps,
+                      float* scale, float* shift, float* stat, hipStream_t stream) {
+  MG_CHECK_ARG(gamma && beta && run_mean && run_var && scale && shift && stat && C <= 64, "bn_finalize: bad arguments");
+  MG_CHECK_ARG(!training || (sums && num_batches_tracked), "bn_finalize: training needs sums and the batch counter");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, count, C, training, gamma, beta, run_mean,
+                     run_var, num_batches_tracked, momentum, eps, scale, shift, stat);
+  MG_LAUNCH_CHECK("bn_finalize");
+  return MGGAN_OK;
+}
+
+int mggan_bn_bwd_finalize(const double* sums, const double* local_sums, double count, int C, const float* gamma,
+                          const float* stat, float* coef, float* dgamma, float* dbeta, hipStream_t stream) {
+  MG_CHECK_ARG(sums && local_sums && gamma && stat && coef && dgamma && dbeta && C <= 64,
+               "bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, local_sums, count, C, gamma, stat, coef,
+                     dgamma, dbeta);
+  MG_LAUNCH_CHECK("bn_bwd_finalize");
+  return MGGAN_OK;
+}
+
+int mggan_conv2_fwd(const float* y1, int B, int C, const float* scale1, const float* shift1, const float* W,
+                    const float* bias, float* y2, float* part, hipStream_t stream) {
+  MG_CHECK_ARG(C == 8 || C == 16, "conv2_fwd: channels %d not built (8 or 16)", C);
+  if (B == 0) return MGGAN_OK;
+  MG_CHECK_ARG(y1 && scale1 && shift1 && W && bias && y2 && part, "conv2_fwd: null pointer");
+  if (C == 16)
+    hipLaunchKernelGGL((conv2_fwd_kernel<16>), dim3(B), dim3(256), 0, stream, y1, scale1, shift1, W, bias, y2, part);
+  else
+    hipLaunchKernelGGL((conv2_fwd_kernel<8>), dim3(B), dim3(256), 0, stream, y1, scale1, shift1, W, bias, y2, part);
+  MG_LAUNCH_CHECK("conv2_fwd");
+  return MGGAN_OK;
+}
+
+int mggan_scene_attention_fwd(const float* y2, int B, int C, const float* scale2, const float* shift2, const float* Wa,
+                              const float* ba, const float* Wb, const float* bb, float* out, int ld_out,
+                              hipStream_t stream) {
+  MG_CHECK_ARG(C == 8 || C == 16, "scene_attention_fwd: channels %d not built (8 or 16)", C);
+  if (B == 0) return MGGAN_OK;
+  MG_CHECK_ARG(y2 && scale2 && shift2 && Wa && ba && Wb && bb && out, "scene_attention_fwd: null pointer");
+  if (C == 16)
+    hipLaunchKernelGGL((attn_kernel<16, false>), dim3(cdiv(B, 4)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
+                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  else
+    hipLaunchKernelGGL((attn_kernel<8, false>), dim3(cdiv(B, 4)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
+                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  MG_LAUNCH_CHECK("scene_attention_fwd");
+  return MGGAN_OK;
+}
+
+int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2, const float* shift2,
+                              const float* stat2, const float* Wa, const float* ba, const float* Wb, const float* bb,
+                              const float* dout, int ld_dout, float* ds, float* hact, float* dz, float* vsave,
+                              float* G2, float* part, hipStream_t stream) {
+  MG_CHECK_ARG(C == 8 || C == 16, "scene_attention_bwd: channels %d not built (8 or 16)", C);
+  if (B == 0) return MGGAN_OK;
+  MG_CHECK_ARG(y2 && scale2 && shift2 && stat2 && Wa && ba && Wb && bb && dout && ds && hact && dz && vsave && G2 && part,
+               "scene_attention_bwd: null pointer");
+  if (C == 16)
+    hipLaunchKernelGGL((attn_kernel<16, true>), dim3(cdiv(B, 4)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
+                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, ds, hact, dz, vsave, G2, part);
+  else
+    hipLaunchKernelGGL((attn_kernel<8, true>), dim3(cdiv(B, 4)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
+                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, ds, hact, dz, vsave, G2, part);
+  MG_LAUNCH_CHECK("scene_attention_bwd");
+  return MGGAN_OK;
+}
+
+/* workspace: mggan_cnn_bwd_grid(B) * (256/(C*C)) * (C*C*9 + C) floats */
+int mggan_conv2_bwd(const float* y1, int B, int C, const float* scale1, const float* shift1, const float* stat1,
+                    const float* y2, const float* G2, const float* stat2, const float* coef2, const float* W,
+                    float* G1c, unsigned char* code1, float* part1, float* dW, float* db, float* workspace,
+                    size_t workspace_bytes, hipStream_t stream) {
+  MG_CHECK_ARG(C == 8 || C == 16, "conv2_bwd: channels %d not built (8 or 16)", C);
+  if (B == 0) return MGGAN_OK;
+  MG_CHECK_ARG(y1 && scale1 && shift1 && stat1 && y2 && G2 && stat2 && coef2 && W && G1c && code1 && part1 && dW && db &&
+                   workspace,
+               "conv2_bwd: null pointer");
+  const int grid = persistent_grid(B), NQ = 256 / (C * C), wlen = C * C * 9 + C;
+  const size_t need = (size_t)grid * NQ * wlen * sizeof(float);
+  if (workspace_bytes < need) {
+    mggan_set_error("conv2_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return MGGAN_ERR_WORKSPACE;
+  }
+  if (C == 16)
+    hipLaunchKernelGGL((conv2_bwd_kernel<16>), dim3(grid), dim3(256), 0, stream, B, y1, scale1, shift1, stat1, y2, G2,
+                       stat2, coef2, W, G1c, code1, part1, workspace);
+  else
+    hipLaunchKernelGGL((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, y1, scale1, shift1, stat1, y2, G2,
+                       stat2, coef2, W, G1c, code1, part1, workspace);
+  MG_LAUNCH_CHECK("conv2_bwd");
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(256), 0, stream, workspace, grid * NQ, wlen, dW);
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, stream, workspace + C * C * 9, grid * NQ, wlen,
+                     db);
+  MG_LAUNCH_CHECK("conv2_bwd reduce");
+  return MGGAN_OK;
+}
+
+/* workspace: mggan_cnn_bwd_grid(B) * (256/(4*C)) * (4*C*9 + C) floats */
+int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float* stat1, const float* coef1,
+                    const float* G1c, const unsigned char* code1, float* dW, float* db, float* workspace,
+                    size_t workspace_bytes, hipStream_t stream) {
+  MG_CHECK_ARG(C == 8 || C == 16, "conv1_bwd: channels %d not built (8 or 16)", C);
+  if (B == 0) return MGGAN_OK;
+  MG_CHECK_ARG(img && y1 && stat1 && coef1 && G1c && code1 && dW && db && workspace, "conv1_bwd: null pointer");
+  const int grid = persistent_grid(B), NQ = 256 / (4 * C), wlen = 4 * C * 9 + C;
+  const size_t need = (size_t)grid * NQ * wlen * sizeof(float);
+  if (workspace_bytes < need) {
+    mggan_set_error("conv1_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return MGGAN_ERR_WORKSPACE;
+  }
+  const size_t lds = (size_t)(4 * IMG_PLANE + C * IH * 36) * sizeof(float);
+  if (C == 16) {
+    static bool attr16 = false;
+    if (!attr16) {
+      hipFuncSetAttribute((const void*)conv1_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr16 = true;
+    }
+    hipLaunchKernelGGL((conv1_bwd_kernel<16>), dim3(grid), dim3(256), lds, stream, B, img, y1, stat1, coef1, G1c, code1,
+                       workspace);
+  } else {
+    static bool attr8 = false;
+    if (!attr8) {
+      hipFuncSetAttribute((const void*)conv1_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr8 = true;
+    }
+    hipLaunchKernelGGL((conv1_bwd_kernel<8>), dim3(grid), dim3(256), lds, stream, B, img, y1, stat1, coef1, G1c, code1,
+                       workspace);
+  }
+  MG_LAUNCH_CHECK("conv1_bwd");
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(4 * C * 9, 64)), dim3(256), 0, stream, workspace, grid * NQ, wlen, dW);
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, stream, workspace + 4 * C * 9, grid * NQ, wlen,
+                     db);
+  MG_LAUNCH_CHECK("conv1_bwd reduce");
+  return MGGAN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// Shared host/device helpers for libmggan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define MGGAN_OK 0
+#define MGGAN_ERR_ARG (-1)
+#define MGGAN_ERR_LAUNCH (-2)
+#define MGGAN_ERR_WORKSPACE (-3)
+
+void mggan_set_error(const char* fmt, ...);
+
+#define MG_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      mggan_set_error(__VA_ARGS__);        \
+      return MGGAN_ERR_ARG;                \
+    }                                      \
+  } while (0)
+
+#define MG_LAUNCH_CHECK(name)                                              \
+  do {                                                                     \
+    hipError_t e_ = hipGetLastError();                                     \
+    if (e_ != hipSuccess) {                                                \
+      mggan_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return MGGAN_ERR_LAUNCH;                                             \
+    }                                                                      \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// activation codes shared with the Python side
+#define ACT_NONE 0
+#define ACT_LEAKY 1    // slope 0 == ReLU
+#define ACT_SIGMOID 2
+#define ACT_SIGMOID_EPS 3  // sigmoid(x)*(1-2e-7)+1e-7 : D output, discriminators.py:83-84,203-204
+#define MG_D_EPS 1e-7f
+
+__device__ __forceinline__ float mg_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float mg_tanh(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); accurate to ~2 ulp with __expf, saturates cleanly
+  float e = __expf(2.0f * x);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+__device__ __forceinline__ float mg_act(float x, int act, float slope) {
+  if (act == ACT_LEAKY) return x > 0.f ? x : x * slope;
+  if (act == ACT_SIGMOID) return mg_sigmoid(x);
+  if (act == ACT_SIGMOID_EPS) return mg_sigmoid(x) * (1.f - 2.f * MG_D_EPS) + MG_D_EPS;
+  return x;
+}
+// derivative expressed through the OUTPUT y of the activation
+__device__ __forceinline__ float mg_act_grad_from_out(float y, int act, float slope) {
+  if (act == ACT_LEAKY) return y > 0.f ? 1.f : slope;
+  if (act == ACT_SIGMOID) return y * (1.f - y);
+  if (act == ACT_SIGMOID_EPS) {
+    const float s = (y - MG_D_EPS) / (1.f - 2.f * MG_D_EPS);
+    return (1.f - 2.f * MG_D_EPS) * s * (1.f - s);
+  }
+  return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,260 @@
+// Generic f32 GEMM family for the small dense layers of MG-GAN (linear forward,
+// input-gradient, weight-gradient) plus the elementwise/reduction helpers they
+// need.  Replaces the implicit ATen/cuBLAS launches behind nn.Linear on the
+// reference hot path (reference call sites
+// mggan/utils.py:134-149 make_mlp, model/modules/discriminators.py:46-56,76-108,
+// model/modules/standard.py:91-105).
+//
+// One LDS-tiled, register-blocked kernel: 64x64 output tile per 256-thread
+// workgroup (4 waves), 4x4 outputs per lane, K chunked by 16 through LDS in a
+// k-major image so that every inner-loop LDS read is a conflict-free
+// ds_read_b128.  Operands may be stored k-major or k-minor, which covers
+//   forward      Y  = X  W^T      (A k-minor, B k-minor)
+//   input grad   dX = dZ W        (A k-minor, B k-major)
+//   weight grad  dW = dZ^T X      (A k-major, B k-major; split over rows, two-phase
+//                                  deterministic reduction, bias grad via a ones column)
+#include "common.h"
+#include "../../include/mggan_hip.h"
+
+#define BM 64
+#define BN 64
+#define BK 16
+#define LDT 68  // padded LDS leading dimension (multiple of 4 -> aligned b128 reads)
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, K;        // C is MxN, reduction length K
+  int lda, ldb, ldc;
+  int act;
+  float slope;
+  int accumulate;     // C += result
+  // split-K / grouped (weight-grad) mode
+  int splits;         // >0: write partial sums P[z][M*Naug] instead of C
+  int ones_col;       // B gets a virtual column N-1 == 1.0 (bias grad); real N-1 columns
+  const int* seg;     // optional group row offsets (n_groups+1), scaled by seg_scale
+  int seg_scale;
+  int n_groups;
+};
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[BK][LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int k_begin = 0, k_end = g.K;
+  if (g.splits > 0) {
+    int z = blockIdx.z;
+    int grp = z / g.splits, sp = z % g.splits;
+    int r0 = 0, r1 = g.K;
+    if (g.seg) { r0 = g.seg[grp] * g.seg_scale; r1 = g.seg[grp + 1] * g.seg_scale; }
+    int len = r1 - r0;
+    int chunk = ((len + g.splits - 1) / g.splits + BK - 1) / BK * BK;
+    k_begin = r0 + sp * chunk;
+    k_end = min(r1, k_begin + chunk);
+  }
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int e = tid + 256 * i;
+      // ---- A tile -> As[kd][m]
+      {
+        int kd, m;
+        if (A_KM) { kd = e >> 6; m = e & 63; } else { m = e >> 4; kd = e & 15; }
+        int gk = k0 + kd, gm = m0 + m;
+        float v = 0.f;
+        if (gk < k_end && gm < g.M) v = A_KM ? g.A[(size_t)gk * g.lda + gm] : g.A[(size_t)gm * g.lda + gk];
+        As[kd][m] = v;
+      }
+      // ---- B tile -> Bs[kd][n]
+      {
+        int kd, n;
+        if (B_KM) { kd = e >> 6; n = e & 63; } else { n = e >> 4; kd = e & 15; }
+        int gk = k0 + kd, gn = n0 + n;
+        float v = 0.f;
+        if (gk < k_end && gn < g.N) {
+          if (g.ones_col && gn == g.N - 1) v = 1.0f;
+          else v = B_KM ? g.B[(size_t)gk * g.ldb + gn] : g.B[(size_t)gn * g.ldb + gk];
+        }
+        Bs[kd][n] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kd = 0; kd < BK; ++kd) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[kd][4 * ty]);
+      const float4 b = *reinterpret_cast<const float4*>(&Bs[kd][4 * tx]);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  if (g.splits > 0) {
+    float* P = g.C + (size_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int gm = m0 + 4 * ty + i;
+      if (gm >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int gn = n0 + 4 * tx + j;
+        if (gn < g.N) P[(size_t)gm * g.N + gn] = acc[i][j];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int gm = m0 + 4 * ty + i;
+    if (gm >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int gn = n0 + 4 * tx + j;
+      if (gn >= g.N) continue;
+      float v = acc[i][j];
+      if (g.bias) v += g.bias[gn];
+      v = mg_act(v, g.act, g.slope);
+      float* c = g.C + (size_t)gm * g.ldc + gn;
+      *c = g.accumulate ? (*c + v) : v;
+    }
+  }
+}
+
+// dW[grp][m*lddw + n] += sum_z P[grp*splits+z][m*Naug+n];  column Naug-1 -> db[grp][m]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ P, float* dW, float* db, int M,
+                                                           int Naug, int has_bias, int lddw, int splits,
+                                                           long w_stride, long b_stride) {
+  __shared__ float red[4][64];
+  const int grp = blockIdx.y;
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int zl = threadIdx.x >> 6;
+  const int total = M * Naug;
+  float s = 0.f;
+  if (o < total) {
+    const float* p = P + ((size_t)grp * splits) * total + o;
+    for (int z = zl; z < splits; z += 4) s += p[(size_t)z * total];
+  }
+  red[zl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (zl == 0 && o < total) {
+    s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    int m = o / Naug, n = o % Naug;
+    if (has_bias && n == Naug - 1) {
+      if (db) db[grp * b_stride + m] += s;
+    } else {
+      dW[grp * w_stride + (size_t)m * lddw + n] += s;
+    }
+  }
+}
+
+// dZ = dY * act'(Y)
+__global__ void act_bwd_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ Y, int ldy,
+                               float* __restrict__ dZ, int lddz, int rows, int N, int act, float slope) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * N) return;
+  int r = (int)(i / N), n = (int)(i % N);
+  dZ[(size_t)r * lddz + n] = dY[(size_t)r * lddy + n] * mg_act_grad_from_out(Y[(size_t)r * ldy + n], act, slope);
+}
+
+extern "C" {
+
+int mggan_linear_fwd(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int rows, int K,
+                     int N, int act, float slope, hipStream_t stream) {
+  MG_CHECK_ARG(X && W && Y && rows >= 0 && K > 0 && N > 0, "linear_fwd: bad arguments");
+  if (rows == 0) return MGGAN_OK;
+  GemmArgs g = {};
+  g.A = X; g.B = W; g.C = Y; g.bias = bias;
+  g.M = rows; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy;
+  g.act = act; g.slope = slope;
+  dim3 grid(cdiv(N, BN), cdiv(rows, BM), 1);
+  hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  MG_LAUNCH_CHECK("linear_fwd");
+  return MGGAN_OK;
+}
+
+int mggan_act_bwd(const float* dY, int lddy, const float* Y, int ldy, float* dZ, int lddz, int rows, int N, int act,
+                  float slope, hipStream_t stream) {
+  MG_CHECK_ARG(dY && Y && dZ, "act_bwd: null pointer");
+  long n = (long)rows * N;
+  if (n == 0) return MGGAN_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, dY, lddy, Y, ldy, dZ, lddz, rows, N, act,
+                     slope);
+  MG_LAUNCH_CHECK("act_bwd");
+  return MGGAN_OK;
+}
+
+int mggan_linear_bwd_data(const float* dZ, int lddz, const float* W, int ldw, float* dX, int lddx, int rows, int K,
+                          int N, int accumulate, hipStream_t stream) {
+  MG_CHECK_ARG(dZ && W && dX && K > 0 && N > 0, "linear_bwd_data: bad arguments");
+  if (rows == 0) return MGGAN_OK;
+  GemmArgs g = {};
+  g.A = dZ; g.B = W; g.C = dX;
+  g.M = rows; g.N = K; g.K = N; g.lda = lddz; g.ldb = ldw; g.ldc = lddx;
+  g.accumulate = accumulate;
+  dim3 grid(cdiv(K, BN), cdiv(rows, BM), 1);
+  hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, stream, g);
+  MG_LAUNCH_CHECK("linear_bwd_data");
+  return MGGAN_OK;
+}
+
+size_t mggan_wgrad_workspace_bytes(int rows, int K, int N, int n_groups) {
+  int splits = mggan_wgrad_splits(rows, K, N, n_groups);
+  return (size_t)splits * (n_groups > 0 ? n_groups : 1) * N * (K + 1) * sizeof(float);
+}
+
+int mggan_wgrad_splits(int rows, int K, int N, int n_groups) {
+  int ng = n_groups > 0 ? n_groups : 1;
+  int tiles = cdiv(N, BM) * cdiv(K + 1, BN) * ng;
+  int per_group_rows = rows / ng + 1;
+  int by_rows = cdiv(per_group_rows, 256);   // at least 256 rows per split
+  int by_fill = cdiv(1024, tiles);           // about 4 workgroups per CU overall
+  int s = by_rows < by_fill ? by_rows : by_fill;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return s;
+}
+
+int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, int lddw, float* db, int rows, int K,
+                int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, void* workspace,
+                size_t workspace_bytes, hipStream_t stream) {
+  MG_CHECK_ARG(dZ && X && dW && K > 0 && N > 0, "wgrad: bad arguments");
+  if (rows == 0) return MGGAN_OK;
+  const int ng = n_groups > 0 ? n_groups : 1;
+  MG_CHECK_ARG(ng == 1 || seg, "wgrad: grouped mode needs segment offsets");
+  const int splits = mggan_wgrad_splits(rows, K, N, n_groups);
+  const int Naug = K + 1;
+  size_t need = (size_t)splits * ng * N * Naug * sizeof(float);
+  if (workspace_bytes < need || !workspace) {
+    mggan_set_error("wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return MGGAN_ERR_WORKSPACE;
+  }
+  GemmArgs g = {};
+  g.A = dZ; g.B = X; g.C = (float*)workspace;
+  g.M = N; g.N = Naug; g.K = rows; g.lda = lddz; g.ldb = ldx; g.ldc = Naug;
+  g.splits = splits; g.ones_col = 1; g.seg = seg; g.seg_scale = seg_scale > 0 ? seg_scale : 1; g.n_groups = ng;
+  dim3 grid(cdiv(Naug, BN), cdiv(N, BM), splits * ng);
+  hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
+  MG_LAUNCH_CHECK("wgrad");
+  dim3 rgrid(cdiv((long)N * Naug, 64), ng, 1);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, (const float*)workspace, dW, db, N, Naug, 1,
+                     lddw, splits, w_stride, b_stride);
+  MG_LAUNCH_CHECK("wgrad_reduce");
+  return MGGAN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,414 @@
+// GAN losses (+ their gradients), gradient-norm clipping and AdamW for MG-GAN on gfx950.
+//
+// Replaces (file:line under /root/reference/mggan):
+//   BCE with scalar smoothed labels       abstract_train.py:62-67 (phi_1..3, 'NS'), utils.py:18-25
+//   D output epsilon-affine               model/modules/discriminators.py:203-204 (p = sigmoid(z)(1-2e-7)+1e-7)
+//   1/count(generator) re-weighting, CE   model/train.py:92-113,181-186
+//   per-scene min-over-K L2               model/train.py:58-75
+//   PM-network 'ml' target                model/train.py:626-639
+//   clip_grad_norm_ + AdamW               model/train.py:131-135,209-213,656-658; abstract_train.py:45-50
+// All reductions are fixed-order (deterministic); every loss kernel also emits the gradient
+// w.r.t. its input so logits never round-trip through autograd.
+#include "common.h"
+#include "../../include/mggan_hip.h"
+
+// ---- BCE on the discriminator output ---------------------------------------------------
+// p: D output per row (already sigmoid + eps-affine). loss_r = w_r*scale*BCE(p,y); dp = dloss_r/dp.
+__global__ void bce_rows_kernel(int rows, const float* __restrict__ p_in, float y, float scale,
+                                const int* __restrict__ row_gen, const float* __restrict__ inv_count,
+                                float* loss_rows, float* dp) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float p = p_in[r];
+  const float w = (row_gen ? inv_count[row_gen[r]] : 1.f) * scale;
+  const float lp = fmaxf(__logf(p), -100.f), lq = fmaxf(__logf(1.f - p), -100.f);  // BCELoss log clamp
+  loss_rows[r] = -w * (y * lp + (1.f - y) * lq);
+  if (dp) dp[r] = -w * (y / p - (1.f - y) / (1.f - p));
+}
+
+__global__ void scale_kernel(float* x, long n, const float* __restrict__ s) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= *s;
+}
+
+// X[k*b+ped] = [ soc0[ped] if k==0 else 0 | in_enc[ped] | pred_enc[k*b+ped] | scene[ped] ]
+__global__ void d_assemble_kernel(int b, int K, int ws, int wi, int wp, int wc, const float* __restrict__ soc0,
+                                  const float* __restrict__ in_enc, const float* __restrict__ pred_enc,
+                                  const float* __restrict__ scene, float* X) {
+  const int W = ws + wi + wp + wc;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)K * b * W) return;
+  const int c = (int)(i % W);
+  const long r = i / W;
+  const int ped = (int)(r % b), k = (int)(r / b);
+  float v;
+  if (c < ws) v = k == 0 ? soc0[(size_t)ped * ws + c] : 0.f;
+  else if (c < ws + wi) v = in_enc[(size_t)ped * wi + (c - ws)];
+  else if (c < ws + wi + wp) v = pred_enc[(size_t)r * wp + (c - ws - wi)];
+  else v = scene[(size_t)ped * wc + (c - ws - wi - wp)];
+  X[i] = v;
+}
+
+// adjoint: dsoc0[ped] = dX[ped][:ws]; din_enc[ped] = sum_k dX[k*b+ped][ws:ws+wi]; dpred = copy; dscene = sum_k
+__global__ void d_assemble_bwd_kernel(int b, int K, int ws, int wi, int wp, int wc, const float* __restrict__ dX,
+                                      float* dsoc0, float* din_enc, float* dpred_enc, float* dscene) {
+  const int W = ws + wi + wp + wc;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)b * W) return;
+  const int c = (int)(i % W), ped = (int)(i / W);
+  if (c < ws) {
+    if (dsoc0) dsoc0[(size_t)ped * ws + c] = dX[(size_t)ped * W + c];
+  } else if (c >= ws + wi && c < ws + wi + wp) {
+    if (dpred_enc)
+      for (int k = 0; k < K; ++k) dpred_enc[((size_t)k * b + ped) * wp + (c - ws - wi)] = dX[((size_t)k * b + ped) * W + c];
+  } else {
+    float* dst = c < ws + wi ? din_enc : dscene;
+    if (!dst) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += dX[((size_t)k * b + ped) * W + c];
+    if (c < ws + wi) dst[(size_t)ped * wi + (c - ws)] = s;
+    else dst[(size_t)ped * wc + (c - ws - wi - wp)] = s;
+  }
+}
+
+// ---- cross entropy per row (generator-id head) ------------------------------------------
+__global__ void ce_rows_kernel(int rows, int g, const float* __restrict__ logits, int ld, const int* __restrict__ target,
+                               const float* __restrict__ inv_count, float scale, float* loss_rows, float* dlogits,
+                               int ldd) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* l = logits + (size_t)r * ld;
+  const int t = target[r];
+  float mx = -INFINITY;
+  for (int c = 0; c < g; ++c) mx = fmaxf(mx, l[c]);
+  float den = 0.f;
+  for (int c = 0; c < g; ++c) den += __expf(l[c] - mx);
+  const float lse = mx + __logf(den);
+  const float w = (inv_count ? inv_count[t] : 1.f) * scale;
+  loss_rows[r] = w * (lse - l[t]);
+  if (dlogits)
+    for (int c = 0; c < g; ++c) dlogits[(size_t)r * ldd + c] = w * (__expf(l[c] - lse) - (c == t ? 1.f : 0.f));
+}
+
+// ---- per-scene min-over-K L2 (train.py:58-75) -------------------------------------------
+// one wave per scene; lane k accumulates sum_ped sum_t |abs - gt|; first minimum wins.
+__global__ __launch_bounds__(64) void l2_scene_kernel(int S, int T, int K, int b, const int* __restrict__ scenes,
+                                                      const float* __restrict__ gen_abs, const float* __restrict__ gt,
+                                                      float* scene_loss, int* scene_arg) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int p0 = scenes[2 * s], p1 = scenes[2 * s + 1];
+  float best = INFINITY;
+  int bestk = 0;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int k = k0 + lane;
+    float acc = INFINITY;
+    if (k < K) {
+      acc = 0.f;
+      for (int ped = p0; ped < p1; ++ped)
+        for (int t = 0; t < T; ++t) {
+          const float* a = gen_abs + (((size_t)t * K + k) * b + ped) * 2;
+          const float dx = a[0] - gt[((size_t)t * b + ped) * 2], dy = a[1] - gt[((size_t)t * b + ped) * 2 + 1];
+          acc += sqrtf(dx * dx + dy * dy);
+        }
+    }
+    float v = acc;
+    int vi = k;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(vi, o, 64);
+      if (ov < v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+    }
+    if (v < best) { best = v; bestk = vi; }
+  }
+  if (lane == 0) { scene_loss[s] = best; scene_arg[s] = bestk; }
+}
+
+// gabs[t][k][ped] = scale * (abs-gt)/|abs-gt| if k == argmin(scene(ped)) else 0
+__global__ void l2_grad_kernel(int T, int K, int b, const int* __restrict__ ped_scene, const int* __restrict__ scene_arg,
+                               const float* __restrict__ gen_abs, const float* __restrict__ gt, float scale,
+                               float* gabs) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)T * K * b) return;
+  const int ped = (int)(i % b), k = (int)((i / b) % K), t = (int)(i / ((long)b * K));
+  float gx = 0.f, gy = 0.f;
+  if (scene_arg[ped_scene[ped]] == k) {
+    const float dx = gen_abs[i * 2] - gt[((size_t)t * b + ped) * 2], dy = gen_abs[i * 2 + 1] - gt[((size_t)t * b + ped) * 2 + 1];
+    const float n = sqrtf(dx * dx + dy * dy);
+    if (n > 0.f) { gx = scale * dx / n; gy = scale * dy / n; }
+  }
+  gabs[i * 2] = gx;
+  gabs[i * 2 + 1] = gy;
+}
+
+// ---- PM-network 'ml' loss (train.py:626-639) ---------------------------------------------
+// gen_abs (T,E,g,b,2); target = softmax_g( mean_E sum_{t,xy} log N(err; 0, sigma) ); loss_r = -sum target*log_softmax(logits)
+__global__ void pm_ml_kernel(int b, int T, int E, int g, const float* __restrict__ gen_abs, const float* __restrict__ gt,
+                             const float* __restrict__ logits, float sigma, float scale, float* loss_rows,
+                             float* dlogits, float* probs) {
+  const int ped = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ped >= b) return;
+  const float inv2s = 1.f / (2.f * sigma * sigma);
+  const float cst = -__logf(sigma) - 0.91893853320467274178f;  // -log(sigma) - 0.5 log(2 pi)
+  float lp[16], lg[16];
+  float mxp = -INFINITY, mxl = -INFINITY;
+  for (int gi = 0; gi < g; ++gi) {
+    float acc = 0.f;
+    for (int e = 0; e < E; ++e)
+      for (int t = 0; t < T; ++t) {
+        const float* a = gen_abs + ((((size_t)t * E + e) * g + gi) * b + ped) * 2;
+        const float dx = a[0] - gt[((size_t)t * b + ped) * 2], dy = a[1] - gt[((size_t)t * b + ped) * 2 + 1];
+        acc += (-dx * dx * inv2s + cst) + (-dy * dy * inv2s + cst);
+      }
+    lp[gi] = acc / (float)E;
+    lg[gi] = logits[(size_t)ped * g + gi];
+    mxp = fmaxf(mxp, lp[gi]);
+    mxl = fmaxf(mxl, lg[gi]);
+  }
+  float dp = 0.f, dl = 0.f;
+  for (int gi = 0; gi < g; ++gi) { dp += __expf(lp[gi] - mxp); dl += __expf(lg[gi] - mxl); }
+  const float lsel = mxl + __logf(dl);
+  float loss = 0.f;
+  for (int gi = 0; gi < g; ++gi) {
+    const float tgt = __expf(lp[gi] - mxp) / dp;
+    const float sm = __expf(lg[gi] - lsel);
+    loss -= tgt * (lg[gi] - lsel);
+    dlogits[(size_t)ped * g + gi] = scale * (sm - tgt);
+    if (probs) probs[(size_t)ped * g + gi] = sm;
+  }
+  loss_rows[ped] = scale * loss;
+}
+
+// ---- fixed-order sum: out[slot] (+)= alpha * sum_i x[i] -------------------------------------
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, long n, float alpha, float* out,
+                                                   int accumulate) {
+  __shared__ double red[1024];
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) acc += (double)x[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float v = alpha * (float)red[0];
+    *out = accumulate ? (*out + v) : v;
+  }
+}
+
+// column means of a (rows x g) matrix -> out[g]  (probs/Gen i probability metric, train.py:597-600)
+__global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ x, int rows, int g, float scale,
+                                                      float* out) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
+  double acc = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) acc += (double)x[(size_t)r * g + c];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = scale * (float)(red[0] / rows);
+}
+
+// ---- clip_grad_norm_ + AdamW over a flat parameter buffer with a segment table ---------------
+#define NORM_BLOCKS 256
+__global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float* __restrict__ grad, long n,
+                                                               const int* __restrict__ elem_seg,
+                                                               const unsigned char* __restrict__ active,
+                                                               double* partial) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)NORM_BLOCKS * 256) {
+    const int sg = elem_seg[i];
+    if (sg >= 0 && active[sg]) acc += (double)grad[i] * (double)grad[i];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* param, float* grad, float* m, float* v, long n,
+                                                    const int* __restrict__ elem_seg,
+                                                    const unsigned char* __restrict__ active,
+                                                    const int* __restrict__ seg_step, const double* __restrict__ partial,
+                                                    float max_norm, double lr, double beta1, double beta2,
+                                                    double eps_d, double wd, float* norm_out) {
+  __shared__ double red[256];
+  red[threadIdx.x] = threadIdx.x < NORM_BLOCKS ? partial[threadIdx.x] : 0.0;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float total = (float)sqrt(red[0]);
+  float coef = 1.f;
+  if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.f);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int sg = elem_seg[i];
+    if (sg < 0 || !active[sg]) continue;
+    const int t = seg_step[sg] + 1;
+    const float g = grad[i] * coef;
+    grad[i] = g;  // clip_grad_norm_ scales .grad in place
+    // torch.optim.AdamW single-tensor path: scalar factors in double, tensor math in f32
+    float p = param[i] * (float)(1.0 - lr * wd);
+    const float mi = m[i] + (g - m[i]) * (float)(1.0 - beta1);          // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * (float)beta2 + g * g * (float)(1.0 - beta2);  // mul_(beta2).addcmul_
+    m[i] = mi;
+    v[i] = vi;
+    const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+    const float denom = sqrtf(vi) / (float)sqrt(bc2) + (float)eps_d;
+    p -= (float)(lr / bc1) * (mi / denom);
+    param[i] = p;
+  }
+}
+
+__global__ void adam_inc_kernel(int nseg, const unsigned char* __restrict__ active, int* seg_step) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nseg && active[i]) seg_step[i] += 1;
+}
+
+// counts of generator ids (int32 atomics: exact, order independent) and their reciprocals
+__global__ void count_kernel(const int* __restrict__ idx, int n, int* counts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&counts[idx[i]], 1);
+}
+__global__ void inv_count_kernel(const int* __restrict__ counts, int g, float* inv) {
+  const int i = threadIdx.x;
+  if (i < g) inv[i] = counts[i] > 0 ? 1.f / (float)counts[i] : 0.f;
+}
+
+extern "C" {
+
+int mggan_bce_rows(int rows, const float* p, float label, float scale, const int* row_gen, const float* inv_count,
+                   float* loss_rows, float* dp, hipStream_t stream) {
+  if (rows == 0) return MGGAN_OK;
+  MG_CHECK_ARG(p && loss_rows && ((row_gen == nullptr) == (inv_count == nullptr)), "bce_rows: bad arguments");
+  hipLaunchKernelGGL(bce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rows, p, label, scale, row_gen,
+                     inv_count, loss_rows, dp);
+  MG_LAUNCH_CHECK("bce_rows");
+  return MGGAN_OK;
+}
+
+int mggan_scale(float* x, long n, const float* scalar, hipStream_t stream) {
+  if (n == 0) return MGGAN_OK;
+  MG_CHECK_ARG(x && scalar, "scale: null pointer");
+  hipLaunchKernelGGL(scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, n, scalar);
+  MG_LAUNCH_CHECK("scale");
+  return MGGAN_OK;
+}
+
+int mggan_d_assemble_fwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, const float* soc0,
+                         const float* in_enc, const float* pred_enc, const float* scene, float* X,
+                         hipStream_t stream) {
+  MG_CHECK_ARG(soc0 && in_enc && pred_enc && scene && X, "d_assemble_fwd: null pointer");
+  const long n = (long)K * b * (w_soc + w_in + w_pred + w_scene);
+  if (n == 0) return MGGAN_OK;
+  hipLaunchKernelGGL(d_assemble_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, w_soc, w_in, w_pred, w_scene,
+                     soc0, in_enc, pred_enc, scene, X);
+  MG_LAUNCH_CHECK("d_assemble_fwd");
+  return MGGAN_OK;
+}
+
+int mggan_d_assemble_bwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, const float* dX, float* dsoc0,
+                         float* din_enc, float* dpred_enc, float* dscene, hipStream_t stream) {
+  MG_CHECK_ARG(dX, "d_assemble_bwd: null pointer");
+  const long n = (long)b * (w_soc + w_in + w_pred + w_scene);
+  if (n == 0) return MGGAN_OK;
+  hipLaunchKernelGGL(d_assemble_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, w_soc, w_in, w_pred, w_scene,
+                     dX, dsoc0, din_enc, dpred_enc, dscene);
+  MG_LAUNCH_CHECK("d_assemble_bwd");
+  return MGGAN_OK;
+}
+
+int mggan_ce_rows(int rows, int g, const float* logits, int ld, const int* target, const float* inv_count, float scale,
+                  float* loss_rows, float* dlogits, int ldd, hipStream_t stream) {
+  if (rows == 0) return MGGAN_OK;
+  MG_CHECK_ARG(logits && target && loss_rows && g > 0, "ce_rows: bad arguments");
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rows, g, logits, ld, target,
+                     inv_count, scale, loss_rows, dlogits, ldd);
+  MG_LAUNCH_CHECK("ce_rows");
+  return MGGAN_OK;
+}
+
+int mggan_l2_min_scene(int S, int T, int K, int b, const int* scenes, const int* ped_scene, const float* gen_abs,
+                       const float* gt, float grad_scale, float* scene_loss, int* scene_arg, float* gabs,
+                       hipStream_t stream) {
+  if (S == 0) return MGGAN_OK;
+  MG_CHECK_ARG(scenes && ped_scene && gen_abs && gt && scene_loss && scene_arg, "l2_min_scene: null pointer");
+  hipLaunchKernelGGL(l2_scene_kernel, dim3(S), dim3(64), 0, stream, S, T, K, b, scenes, gen_abs, gt, scene_loss,
+                     scene_arg);
+  MG_LAUNCH_CHECK("l2_scene");
+  if (gabs) {
+    hipLaunchKernelGGL(l2_grad_kernel, dim3(cdiv((long)T * K * b, 256)), dim3(256), 0, stream, T, K, b, ped_scene,
+                       scene_arg, gen_abs, gt, grad_scale, gabs);
+    MG_LAUNCH_CHECK("l2_grad");
+  }
+  return MGGAN_OK;
+}
+
+int mggan_pm_ml_loss(int b, int T, int E, int g, const float* gen_abs, const float* gt, const float* logits, float sigma,
+                     float scale, float* loss_rows, float* dlogits, float* probs, hipStream_t stream) {
+  if (b == 0) return MGGAN_OK;
+  MG_CHECK_ARG(gen_abs && gt && logits && loss_rows && dlogits && g <= 16, "pm_ml_loss: bad arguments (g <= 16)");
+  hipLaunchKernelGGL(pm_ml_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, T, E, g, gen_abs, gt, logits, sigma,
+                     scale, loss_rows, dlogits, probs);
+  MG_LAUNCH_CHECK("pm_ml_loss");
+  return MGGAN_OK;
+}
+
+int mggan_sum(const float* x, long n, float alpha, float* out, int accumulate, hipStream_t stream) {
+  MG_CHECK_ARG(out && (x || n == 0), "sum: null pointer");
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, stream, x, n, alpha, out, accumulate);
+  MG_LAUNCH_CHECK("sum");
+  return MGGAN_OK;
+}
+
+int mggan_colmean(const float* x, int rows, int g, float scale, float* out, hipStream_t stream) {
+  MG_CHECK_ARG(x && out && rows > 0 && g > 0, "colmean: bad arguments");
+  hipLaunchKernelGGL(colmean_kernel, dim3(g), dim3(256), 0, stream, x, rows, g, scale, out);
+  MG_LAUNCH_CHECK("colmean");
+  return MGGAN_OK;
+}
+
+int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count, hipStream_t stream) {
+  MG_CHECK_ARG(idx && counts && inv_count && g <= 256, "gen_counts: bad arguments");
+  hipMemsetAsync(counts, 0, sizeof(int) * g, stream);
+  if (n > 0) hipLaunchKernelGGL(count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, idx, n, counts);
+  hipLaunchKernelGGL(inv_count_kernel, dim3(1), dim3(256), 0, stream, counts, g, inv_count);
+  MG_LAUNCH_CHECK("gen_counts");
+  return MGGAN_OK;
+}
+
+int mggan_inv_counts(const int* counts, int g, float* inv_count, hipStream_t stream) {
+  MG_CHECK_ARG(counts && inv_count && g <= 256, "inv_counts: bad arguments");
+  hipLaunchKernelGGL(inv_count_kernel, dim3(1), dim3(256), 0, stream, counts, g, inv_count);
+  MG_LAUNCH_CHECK("inv_counts");
+  return MGGAN_OK;
+}
+
+/* workspace: 256 doubles */
+int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, const int* elem_seg, int nseg,
+                     const unsigned char* active, int* seg_step, float max_norm, double lr, double beta1, double beta2,
+                     double eps, double weight_decay, double* workspace, float* norm_out, hipStream_t stream) {
+  MG_CHECK_ARG(param && grad && m && v && elem_seg && active && seg_step && workspace, "clip_adamw: null pointer");
+  if (n == 0) return MGGAN_OK;
+  hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, grad, n, elem_seg, active,
+                     workspace);
+  int blocks = cdiv(n, 256 * 4);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, m, v, n, elem_seg, active, seg_step,
+                     workspace, max_norm, lr, beta1, beta2, eps, weight_decay, norm_out);
+  hipLaunchKernelGGL(adam_inc_kernel, dim3(cdiv(nseg, 256)), dim3(256), 0, stream, nseg, active, seg_step);
+  MG_LAUNCH_CHECK("clip_adamw");
+  return MGGAN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,565 @@
+// Time-step-fused LSTM rollouts for MG-GAN on gfx950.
+//
+// Replaces, on the reference hot path (file:line under /root/reference/mggan):
+//   TrajectoryEncoder.forward     model/modules/common_modules.py:48-66  (Linear(2,E) + nn.LSTM over T=7)
+//   RelativeDecoder.forward       model/modules/common_modules.py:97-131 (12 x {Linear(2,E); LSTM cell; hidden2pos; xy+=dxdy})
+//   enc_h_to_dec_h                model/modules/standard.py:91-94,244-252 (h0 = Linear(136,32)([enc_h|noise]), c0 = 0)
+//   selected-rollout gather       model/modules/standard.py:190-214 (folded: one row per selected (ped, sample))
+//
+// Design (CDNA4): one lane per (row, hidden unit); the four gate rows of W_hh for
+// that unit live in VGPRs for the whole sequence (weights are read from HBM/L2 once
+// per workgroup, never per step), h_t is exchanged through LDS (one 128-byte row per
+// trajectory, broadcast ds_read_b128), c_t stays in a register, all T steps and
+// (decoder) the hidden2pos head + autoregressive feedback run inside ONE launch.
+// The input embedding Linear(2,E) is folded algebraically into the gate weights
+// (A = W_ih W_emb, 4H x 2) by a tiny prep kernel each step; its gradient is
+// un-folded by the chain rule in mggan_lstm_unfold_grads.
+// Rows are pre-bucketed by generator so that a workgroup's lanes load one
+// generator's weights (L1-resident) and weight-gradient GEMMs see contiguous segments.
+#include "common.h"
+#include "../../include/mggan_hip.h"
+
+// ---- layout of one prepared (folded/transposed) weight block, in floats -----------
+//  A[4H][2] | bias[4H] | WhhT[H][4H] | (decoder only) W1T[H+S][H/2] | b1[H/2] | W2[2][H/2] | b2[2]
+__host__ __device__ inline int prep_off_A(int H) { return 0; }
+__host__ __device__ inline int prep_off_bias(int H) { return 8 * H; }
+__host__ __device__ inline int prep_off_whhT(int H) { return 12 * H; }
+__host__ __device__ inline int prep_off_w1T(int H) { return 12 * H + 4 * H * H; }
+__host__ __device__ inline int prep_size(int H, int S, int dec) {
+  int n = 12 * H + 4 * H * H;
+  if (dec) n += (H + S) * (H / 2) + H / 2 + 2 * (H / 2) + 2;
+  return (n + 3) / 4 * 4;
+}
+
+struct FoldArgs {
+  const float *W_emb, *b_emb, *W_ih, *b_ih, *b_hh, *W_hh, *W1, *b1, *W2, *b2;
+  long param_stride;  // floats between consecutive generators' parameter blocks
+  float* prep;
+  int prep_stride, H, E, S, dec;
+};
+
+__global__ __launch_bounds__(256) void lstm_fold_kernel(FoldArgs a) {
+  const int grp = blockIdx.x;
+  const long po = (long)grp * a.param_stride;
+  const int H = a.H, E = a.E, G4 = 4 * a.H;
+  float* P = a.prep + (size_t)grp * a.prep_stride;
+  for (int m = threadIdx.x; m < G4; m += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, sb = a.b_ih[po + m] + a.b_hh[po + m];
+    for (int e = 0; e < E; ++e) {
+      float w = a.W_ih[po + (size_t)m * E + e];
+      s0 = fmaf(w, a.W_emb[po + e * 2 + 0], s0);
+      s1 = fmaf(w, a.W_emb[po + e * 2 + 1], s1);
+      sb = fmaf(w, a.b_emb[po + e], sb);
+    }
+    P[prep_off_A(H) + m * 2 + 0] = s0;
+    P[prep_off_A(H) + m * 2 + 1] = s1;
+    P[prep_off_bias(H) + m] = sb;
+  }
+  for (int i = threadIdx.x; i < H * G4; i += blockDim.x) {
+    int k = i / G4, m = i % G4;
+    P[prep_off_whhT(H) + i] = a.W_hh[po + (size_t)m * H + k];
+  }
+  if (a.dec) {
+    const int Hh = H / 2, IN = H + a.S;
+    float* w1T = P + prep_off_w1T(H);
+    for (int i = threadIdx.x; i < IN * Hh; i += blockDim.x) {
+      int k = i / Hh, m = i % Hh;
+      w1T[i] = a.W1[po + (size_t)m * IN + k];
+    }
+    float* b1 = w1T + IN * Hh;
+    float* w2 = b1 + Hh;
+    float* b2 = w2 + 2 * Hh;
+    for (int i = threadIdx.x; i < Hh; i += blockDim.x) b1[i] = a.b1[po + i];
+    for (int i = threadIdx.x; i < 2 * Hh; i += blockDim.x) w2[i] = a.W2[po + i];
+    if (threadIdx.x < 2) b2[threadIdx.x] = a.b2[po + threadIdx.x];
+  }
+}
+
+struct UnfoldArgs {
+  const float *W_emb, *b_emb, *W_ih;       // parameters (group 0)
+  float *dW_emb, *db_emb, *dW_ih, *db_ih, *db_hh;  // gradients (group 0), accumulated
+  long param_stride;
+  const float* dprep;  // per group: dA[4H][2] | dbias[4H]
+  int dprep_stride, H, E;
+};
+
+__global__ __launch_bounds__(256) void lstm_unfold_kernel(UnfoldArgs a) {
+  const int grp = blockIdx.x;
+  const long po = (long)grp * a.param_stride;
+  const int E = a.E, G4 = 4 * a.H;
+  const float* dA = a.dprep + (size_t)grp * a.dprep_stride;
+  const float* dB = dA + 2 * G4;
+  for (int i = threadIdx.x; i < G4 * E; i += blockDim.x) {
+    int m = i / E, e = i % E;
+    float v = dA[m * 2] * a.W_emb[po + e * 2] + dA[m * 2 + 1] * a.W_emb[po + e * 2 + 1] + dB[m] * a.b_emb[po + e];
+    a.dW_ih[po + i] += v;
+  }
+  for (int m = threadIdx.x; m < G4; m += blockDim.x) {
+    a.db_ih[po + m] += dB[m];
+    a.db_hh[po + m] += dB[m];
+  }
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, sb = 0.f;
+    for (int m = 0; m < G4; ++m) {
+      float w = a.W_ih[po + (size_t)m * E + e];
+      s0 = fmaf(w, dA[m * 2], s0);
+      s1 = fmaf(w, dA[m * 2 + 1], s1);
+      sb = fmaf(w, dB[m], sb);
+    }
+    a.dW_emb[po + e * 2] += s0;
+    a.dW_emb[po + e * 2 + 1] += s1;
+    a.db_emb[po + e] += sb;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+struct SeqArgs {
+  int R, T, b;
+  const float* prep;
+  int prep_stride;
+  const int* row_gen;   // NULL -> group 0
+  // encoder
+  const float* x;       // (T,b,2) time-major (encoder input; row r == pedestrian r)
+  float* hout;          // (R, ld_hout)
+  int ld_hout;
+  // decoder
+  const int *row_ped, *row_slot, *row_pos;
+  const float *enc_h, *noise, *soc, *xy0, *dxdy0, *We2dT, *be2d;
+  int ld_enc, ld_soc, Z, EIN;  // EIN = encoder feature width fed to enc_h_to_dec_h (128)
+  float *out_abs, *out_rel;    // (T, Rout, 2) written at row_pos
+  int Rout;
+  // saved for backward (all NULL in no-grad mode)
+  float *Gt, *Cs, *Hp, *Hc, *Din, *Aact, *E2Din, *SocR;
+};
+
+template <int H, bool DEC>
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
+  constexpr int RT = 256 / H, G4 = 4 * H, Hh = H / 2, S = H;
+  __shared__ __attribute__((aligned(16))) float hbuf[RT][H];
+  __shared__ __attribute__((aligned(16))) float abuf[RT][Hh];
+  __shared__ __attribute__((aligned(16))) float xin[DEC ? RT : 1][DEC ? 160 : 4];
+  const int rr = threadIdx.x / H, j = threadIdx.x % H;
+  const int r = blockIdx.x * RT + rr;
+  const bool valid = r < p.R;
+  const int rc = valid ? r : p.R - 1;
+  const int grp = p.row_gen ? p.row_gen[rc] : 0;
+  const float* P = p.prep + (size_t)grp * p.prep_stride;
+  const float* WT = P + prep_off_whhT(H);
+  const bool save = p.Gt != nullptr;
+
+  float whh[4][H], a0[4], a1[4], bs[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int k = 0; k < H; ++k) whh[q][k] = WT[k * G4 + q * H + j];
+    a0[q] = P[prep_off_A(H) + (q * H + j) * 2];
+    a1[q] = P[prep_off_A(H) + (q * H + j) * 2 + 1];
+    bs[q] = P[prep_off_bias(H) + q * H + j];
+  }
+
+  float hj = 0.f, c = 0.f, d0 = 0.f, d1 = 0.f, x0 = 0.f, x1 = 0.f;
+  float w1h[DEC ? H : 1], w2a[DEC ? Hh : 1], w2b[DEC ? Hh : 1];
+  float qv = 0.f, b20 = 0.f, b21 = 0.f;
+  int pos = 0;
+  if (DEC) {
+    const int ped = p.row_ped[rc], slot = p.row_slot[rc];
+    pos = p.row_pos[rc];
+    const int IN = p.EIN + p.Z;
+    for (int k = j; k < IN; k += H) {
+      float v = k < p.EIN ? p.enc_h[(size_t)ped * p.ld_enc + k] : p.noise[((size_t)slot * p.b + ped) * p.Z + (k - p.EIN)];
+      xin[rr][k] = v;
+      if (save && valid) p.E2Din[(size_t)r * IN + k] = v;
+    }
+    const float sv = p.soc[(size_t)ped * p.ld_soc + j];
+    abuf[rr][0] = 0.f;  // touch
+    __syncthreads();
+    // h0 = W_e2d [enc_h | noise] + b   (standard.py:247-252)
+    float h0 = p.be2d[j];
+    for (int k = 0; k < IN; ++k) h0 = fmaf(p.We2dT[k * H + j], xin[rr][k], h0);
+    hj = h0;
+    // time-invariant social half of hidden2pos: q = W1[:,H:] soc + b1
+    const float* w1T = P + prep_off_w1T(H);
+    const float* b1 = w1T + (H + S) * Hh;
+    const float* w2 = b1 + Hh;
+    const float* b2 = w2 + 2 * Hh;
+    __syncthreads();
+    hbuf[rr][j] = sv;  // reuse hbuf as the social row for the q product
+    if (save && valid) p.SocR[(size_t)r * S + j] = sv;
+    __syncthreads();
+    if (j < Hh) {
+      qv = b1[j];
+#pragma unroll
+      for (int k = 0; k < S; ++k) qv = fmaf(w1T[(H + k) * Hh + j], hbuf[rr][k], qv);
+#pragma unroll
+      for (int k = 0; k < H; ++k) w1h[k] = w1T[k * Hh + j];
+    }
+#pragma unroll
+    for (int m = 0; m < Hh; ++m) { w2a[m] = w2[m]; w2b[m] = w2[Hh + m]; }
+    b20 = b2[0]; b21 = b2[1];
+    const int pd = p.row_ped[rc];
+    d0 = p.dxdy0[pd * 2]; d1 = p.dxdy0[pd * 2 + 1];
+    x0 = p.xy0[pd * 2];   x1 = p.xy0[pd * 2 + 1];
+    __syncthreads();
+  }
+  hbuf[rr][j] = hj;
+  __syncthreads();
+  float hv[H];
+#pragma unroll
+  for (int k = 0; k < H; k += 4) {
+    float4 t4 = *reinterpret_cast<const float4*>(&hbuf[rr][k]);
+    hv[k] = t4.x; hv[k + 1] = t4.y; hv[k + 2] = t4.z; hv[k + 3] = t4.w;
+  }
+
+  for (int t = 0; t < p.T; ++t) {
+    const size_t rt = (size_t)r * p.T + t;
+    if (!DEC) {
+      d0 = p.x[((size_t)t * p.b + rc) * 2];
+      d1 = p.x[((size_t)t * p.b + rc) * 2 + 1];
+    }
+    if (save && valid) {
+      p.Hp[rt * H + j] = hj;
+      if (j == 0) { p.Din[rt * 2] = d0; p.Din[rt * 2 + 1] = d1; }
+    }
+    float pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float s = fmaf(a1[q], d1, fmaf(a0[q], d0, bs[q]));
+#pragma unroll
+      for (int k = 0; k < H; ++k) s = fmaf(whh[q][k], hv[k], s);
+      pre[q] = s;
+    }
+    const float gi = mg_sigmoid(pre[0]), gf = mg_sigmoid(pre[1]), gg = mg_tanh(pre[2]), go = mg_sigmoid(pre[3]);
+    c = fmaf(gf, c, gi * gg);
+    hj = go * mg_tanh(c);
+    if (save && valid) {
+      p.Gt[rt * G4 + 0 * H + j] = gi;
+      p.Gt[rt * G4 + 1 * H + j] = gf;
+      p.Gt[rt * G4 + 2 * H + j] = gg;
+      p.Gt[rt * G4 + 3 * H + j] = go;
+      p.Cs[rt * H + j] = c;
+      if (DEC) p.Hc[rt * H + j] = hj;
+    }
+    __syncthreads();
+    hbuf[rr][j] = hj;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < H; k += 4) {
+      float4 t4 = *reinterpret_cast<const float4*>(&hbuf[rr][k]);
+      hv[k] = t4.x; hv[k + 1] = t4.y; hv[k + 2] = t4.z; hv[k + 3] = t4.w;
+    }
+    if (DEC) {
+      if (j < Hh) {
+        float u = qv;
+#pragma unroll
+        for (int k = 0; k < H; ++k) u = fmaf(w1h[k], hv[k], u);
+        const float av = u > 0.f ? u : 0.01f * u;  // LeakyReLU(0.01), utils.py:143-144
+        abuf[rr][j] = av;
+        if (save && valid) p.Aact[rt * Hh + j] = av;
+      }
+      __syncthreads();
+      float n0 = b20, n1 = b21;
+#pragma unroll
+      for (int m = 0; m < Hh; ++m) {
+        const float av = abuf[rr][m];
+        n0 = fmaf(w2a[m], av, n0);
+        n1 = fmaf(w2b[m], av, n1);
+      }
+      d0 = n0; d1 = n1;
+      x0 += n0; x1 += n1;
+      if (valid && j == 0) {
+        const size_t o = ((size_t)t * p.Rout + pos) * 2;
+        *reinterpret_cast<float2*>(&p.out_abs[o]) = make_float2(x0, x1);
+        *reinterpret_cast<float2*>(&p.out_rel[o]) = make_float2(d0, d1);
+      }
+    }
+  }
+  if (!DEC && valid) p.hout[(size_t)r * p.ld_hout + j] = hj;
+}
+
+struct SeqBwdArgs {
+  int R, T;
+  const int* row_gen;
+  // raw parameters of group 0 + stride
+  const float *W_hh, *W1, *W2, *We2d;  // W1 (H/2 x (H+S)), W2 (2 x H/2), We2d (H x (EIN+Z))
+  long param_stride;
+  const float* prep;   // folded A lives here
+  int prep_stride;
+  const float *Gt, *Cs, *Aact;
+  // encoder: gradient of h_T
+  const float* dhT;
+  int ld_dhT;
+  // decoder: gradients of the outputs
+  const float *gabs, *grel;  // (T,Rout,2), may be NULL (treated as zero)
+  const int* row_pos;
+  int Rout, EIN, Z;
+  // outputs
+  float *dPre, *dU, *gD, *dH0, *dQ, *dEnc, *dSocR;
+};
+
+template <int H, bool DEC>
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
+  constexpr int RT = 256 / H, G4 = 4 * H, Hh = H / 2, S = H;
+  __shared__ __attribute__((aligned(16))) float dpbuf[RT][G4];
+  __shared__ __attribute__((aligned(16))) float dubuf[RT][Hh];
+  const int rr = threadIdx.x / H, j = threadIdx.x % H;
+  const int r = blockIdx.x * RT + rr;
+  const bool valid = r < p.R;
+  const int rc = valid ? r : p.R - 1;
+  const int grp = p.row_gen ? p.row_gen[rc] : 0;
+  const long po = (long)grp * p.param_stride;
+  const float* P = p.prep + (size_t)grp * p.prep_stride;
+
+  float whc[G4];  // column j of W_hh: dh_prev[j] = sum_m W_hh[m][j] dpre[m]
+#pragma unroll
+  for (int m = 0; m < G4; ++m) whc[m] = p.W_hh[po + (size_t)m * H + j];
+  float a0[4], a1[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    a0[q] = P[prep_off_A(H) + (q * H + j) * 2];
+    a1[q] = P[prep_off_A(H) + (q * H + j) * 2 + 1];
+  }
+  float w1c[DEC ? Hh : 1], w20 = 0.f, w21 = 0.f;
+  int pos = 0;
+  if (DEC) {
+#pragma unroll
+    for (int m = 0; m < Hh; ++m) w1c[m] = p.W1[po + (size_t)m * (H + S) + j];
+    if (j < Hh) { w20 = p.W2[po + j]; w21 = p.W2[po + Hh + j]; }
+    pos = p.row_pos[rc];
+  }
+  float dh = 0.f, dc = 0.f, dd0 = 0.f, dd1 = 0.f, s0 = 0.f, s1 = 0.f, dqacc = 0.f;
+  if (!DEC) dh = p.dhT[(size_t)rc * p.ld_dhT + j];
+
+  for (int t = p.T - 1; t >= 0; --t) {
+    const size_t rt = (size_t)rc * p.T + t;
+    if (DEC) {
+      const size_t o = ((size_t)t * p.Rout + pos) * 2;
+      if (p.gabs) { s0 += p.gabs[o]; s1 += p.gabs[o + 1]; }
+      float g0 = s0 + dd0, g1 = s1 + dd1;
+      if (p.grel) { g0 += p.grel[o]; g1 += p.grel[o + 1]; }
+      if (valid && j == 0) { p.gD[rt * 2] = g0; p.gD[rt * 2 + 1] = g1; }
+      if (j < Hh) {
+        const float av = p.Aact[rt * Hh + j];
+        const float du = (w20 * g0 + w21 * g1) * (av > 0.f ? 1.f : 0.01f);
+        dubuf[rr][j] = du;
+        dqacc += du;
+        if (valid) p.dU[rt * Hh + j] = du;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < Hh; ++m) dh = fmaf(w1c[m], dubuf[rr][m], dh);
+    }
+    const float gi = p.Gt[rt * G4 + j], gf = p.Gt[rt * G4 + H + j], gg = p.Gt[rt * G4 + 2 * H + j],
+                go = p.Gt[rt * G4 + 3 * H + j];
+    const float cc = p.Cs[rt * H + j];
+    const float cprev = t > 0 ? p.Cs[(rt - 1) * H + j] : 0.f;
+    const float tc = mg_tanh(cc);
+    const float dO = dh * tc;
+    dc = fmaf(dh * go, 1.f - tc * tc, dc);
+    const float dpi = dc * gg * gi * (1.f - gi);
+    const float dpf = dc * cprev * gf * (1.f - gf);
+    const float dpg = dc * gi * (1.f - gg * gg);
+    const float dpo = dO * go * (1.f - go);
+    dc = dc * gf;
+    if (valid) {
+      p.dPre[rt * G4 + j] = dpi;
+      p.dPre[rt * G4 + H + j] = dpf;
+      p.dPre[rt * G4 + 2 * H + j] = dpg;
+      p.dPre[rt * G4 + 3 * H + j] = dpo;
+    }
+    dpbuf[rr][j] = dpi;
+    dpbuf[rr][H + j] = dpf;
+    dpbuf[rr][2 * H + j] = dpg;
+    dpbuf[rr][3 * H + j] = dpo;
+    __syncthreads();
+    float nh = 0.f;
+#pragma unroll
+    for (int m = 0; m < G4; m += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(&dpbuf[rr][m]);
+      nh = fmaf(whc[m], v.x, nh);
+      nh = fmaf(whc[m + 1], v.y, nh);
+      nh = fmaf(whc[m + 2], v.z, nh);
+      nh = fmaf(whc[m + 3], v.w, nh);
+    }
+    dh = nh;
+    if (DEC) {
+      float p0 = a0[0] * dpi + a0[1] * dpf + a0[2] * dpg + a0[3] * dpo;
+      float p1 = a1[0] * dpi + a1[1] * dpf + a1[2] * dpg + a1[3] * dpo;
+#pragma unroll
+      for (int o = H / 2; o > 0; o >>= 1) {
+        p0 += __shfl_xor(p0, o, 64);
+        p1 += __shfl_xor(p1, o, 64);
+      }
+      dd0 = p0; dd1 = p1;
+    }
+    __syncthreads();
+  }
+  if (DEC) {
+    // dH0, dQ, d(social row) = W1[:,H:]^T dQ, d(enc_h row) = W_e2d[:, :EIN]^T dH0
+    if (valid) p.dH0[(size_t)r * H + j] = dh;
+    if (j < Hh) {
+      dubuf[rr][j] = dqacc;
+      if (valid) p.dQ[(size_t)r * Hh + j] = dqacc;
+    }
+    dpbuf[rr][j] = dh;
+    __syncthreads();
+    float ds = 0.f;
+#pragma unroll
+    for (int m = 0; m < Hh; ++m) ds = fmaf(p.W1[po + (size_t)m * (H + S) + H + j], dubuf[rr][m], ds);
+    if (valid) p.dSocR[(size_t)r * S + j] = ds;
+    const int IN = p.EIN + p.Z;
+    for (int k = j; k < p.EIN; k += H) {
+      float de = 0.f;
+#pragma unroll 8
+      for (int jj = 0; jj < H; ++jj) de = fmaf(p.We2d[(size_t)jj * IN + k], dpbuf[rr][jj], de);
+      if (valid) p.dEnc[(size_t)r * p.EIN + k] = de;
+    }
+  }
+}
+
+// dst[ped][c] (+)= sum_k src[inv[k*b + ped]][c]
+__global__ void gather_sum_kernel(const float* __restrict__ src, int lds_, const int* __restrict__ inv, float* dst,
+                                  int ldd, int b, int K, int ncols, int accumulate) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)b * ncols) return;
+  int ped = (int)(i / ncols), c = (int)(i % ncols);
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += src[(size_t)inv[(size_t)k * b + ped] * lds_ + c];
+  float* d = dst + (size_t)ped * ldd + c;
+  *d = accumulate ? (*d + s) : s;
+}
+
+// WT[k][n] = W[n][k]
+__global__ void transpose_kernel(const float* __restrict__ W, float* __restrict__ WT, int N, int K) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * K) return;
+  int n = i / K, k = i % K;
+  WT[(size_t)k * N + n] = W[i];
+}
+
+extern "C" {
+
+int mggan_lstm_prep_size(int H, int S, int dec) { return prep_size(H, S, dec); }
+
+int mggan_lstm_fold(const float* W_emb, const float* b_emb, const float* W_ih, const float* b_ih, const float* b_hh,
+                    const float* W_hh, const float* W1, const float* b1, const float* W2, const float* b2,
+                    long param_stride, int n_groups, int H, int E, int S, int dec, float* prep, int prep_stride,
+                    hipStream_t stream) {
+  MG_CHECK_ARG(W_emb && b_emb && W_ih && b_ih && b_hh && W_hh && prep, "lstm_fold: null pointer");
+  MG_CHECK_ARG(!dec || (W1 && b1 && W2 && b2), "lstm_fold: decoder head pointers missing");
+  MG_CHECK_ARG(prep_stride >= prep_size(H, S, dec), "lstm_fold: prep stride too small");
+  FoldArgs a = {W_emb, b_emb, W_ih, b_ih, b_hh, W_hh, W1, b1, W2, b2, param_stride, prep, prep_stride, H, E, S, dec};
+  hipLaunchKernelGGL(lstm_fold_kernel, dim3(n_groups), dim3(256), 0, stream, a);
+  MG_LAUNCH_CHECK("lstm_fold");
+  return MGGAN_OK;
+}
+
+int mggan_lstm_unfold_grads(const float* W_emb, const float* b_emb, const float* W_ih, float* dW_emb, float* db_emb,
+                            float* dW_ih, float* db_ih, float* db_hh, long param_stride, int n_groups, int H, int E,
+                            const float* dprep, int dprep_stride, hipStream_t stream) {
+  MG_CHECK_ARG(W_emb && b_emb && W_ih && dW_emb && db_emb && dW_ih && db_ih && db_hh && dprep,
+               "lstm_unfold_grads: null pointer");
+  UnfoldArgs a = {W_emb, b_emb, W_ih, dW_emb, db_emb, dW_ih, db_ih, db_hh, param_stride, dprep, dprep_stride, H, E};
+  hipLaunchKernelGGL(lstm_unfold_kernel, dim3(n_groups), dim3(256), 0, stream, a);
+  MG_LAUNCH_CHECK("lstm_unfold_grads");
+  return MGGAN_OK;
+}
+
+int mggan_lstm_encoder_fwd(const float* x, int T, int b, int H, const float* prep, float* hout, int ld_hout, float* Gt,
+                           float* Cs, float* Hp, float* Din, hipStream_t stream) {
+  MG_CHECK_ARG(x && prep && hout && T > 0 && b >= 0, "lstm_encoder_fwd: bad arguments");
+  MG_CHECK_ARG(H == 32 || H == 64, "lstm_encoder_fwd: hidden size %d not built (32 or 64)", H);
+  MG_CHECK_ARG((Gt == nullptr) == (Cs == nullptr) && (Gt == nullptr) == (Hp == nullptr) &&
+                   (Gt == nullptr) == (Din == nullptr),
+               "lstm_encoder_fwd: save buffers must be all set or all NULL");
+  if (b == 0) return MGGAN_OK;
+  SeqArgs p = {};
+  p.R = b; p.T = T; p.b = b; p.prep = prep; p.prep_stride = 0; p.x = x; p.hout = hout; p.ld_hout = ld_hout;
+  p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Din = Din;
+  if (H == 32) hipLaunchKernelGGL((lstm_fwd_kernel<32, false>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((lstm_fwd_kernel<64, false>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
+  MG_LAUNCH_CHECK("lstm_encoder_fwd");
+  return MGGAN_OK;
+}
+
+int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, const float* W_hh, const float* prep,
+                           const float* Gt, const float* Cs, float* dPre, hipStream_t stream) {
+  MG_CHECK_ARG(dhT && W_hh && prep && Gt && Cs && dPre, "lstm_encoder_bwd: null pointer");
+  MG_CHECK_ARG(H == 32 || H == 64, "lstm_encoder_bwd: hidden size %d not built (32 or 64)", H);
+  if (b == 0) return MGGAN_OK;
+  SeqBwdArgs p = {};
+  p.R = b; p.T = T; p.W_hh = W_hh; p.prep = prep; p.Gt = Gt; p.Cs = Cs; p.dhT = dhT; p.ld_dhT = ld_dhT; p.dPre = dPre;
+  if (H == 32) hipLaunchKernelGGL((lstm_bwd_kernel<32, false>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((lstm_bwd_kernel<64, false>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
+  MG_LAUNCH_CHECK("lstm_encoder_bwd");
+  return MGGAN_OK;
+}
+
+int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const float* prep, int prep_stride,
+                              const int* row_gen, const int* row_ped, const int* row_slot, const int* row_pos,
+                              const float* enc_h, int ld_enc, const float* noise, const float* soc, int ld_soc,
+                              const float* xy0, const float* dxdy0, const float* We2dT, const float* be2d,
+                              float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Hp, float* Hc,
+                              float* Din, float* Aact, float* E2Din, float* SocR, hipStream_t stream) {
+  MG_CHECK_ARG(prep && row_gen && row_ped && row_slot && row_pos && enc_h && noise && soc && xy0 && dxdy0 && We2dT &&
+                   be2d && out_abs && out_rel,
+               "decoder_rollout_fwd: null pointer");
+  MG_CHECK_ARG(H == 32, "decoder_rollout_fwd: decoder_h_dim %d not built (32)", H);
+  MG_CHECK_ARG(EIN + Z <= 160, "decoder_rollout_fwd: enc_h + noise width %d exceeds 160", EIN + Z);
+  const bool s = Gt != nullptr;
+  MG_CHECK_ARG(s == (Cs != nullptr) && s == (Hp != nullptr) && s == (Hc != nullptr) && s == (Din != nullptr) &&
+                   s == (Aact != nullptr) && s == (E2Din != nullptr) && s == (SocR != nullptr),
+               "decoder_rollout_fwd: save buffers must be all set or all NULL");
+  if (R == 0) return MGGAN_OK;
+  SeqArgs p = {};
+  p.R = R; p.T = T; p.b = b; p.prep = prep; p.prep_stride = prep_stride; p.row_gen = row_gen;
+  p.row_ped = row_ped; p.row_slot = row_slot; p.row_pos = row_pos;
+  p.enc_h = enc_h; p.noise = noise; p.soc = soc; p.xy0 = xy0; p.dxdy0 = dxdy0; p.We2dT = We2dT; p.be2d = be2d;
+  p.ld_enc = ld_enc; p.ld_soc = ld_soc; p.Z = Z; p.EIN = EIN;
+  p.out_abs = out_abs; p.out_rel = out_rel; p.Rout = Rout;
+  p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Hc = Hc; p.Din = Din; p.Aact = Aact; p.E2Din = E2Din; p.SocR = SocR;
+  hipLaunchKernelGGL((lstm_fwd_kernel<32, true>), dim3(cdiv(R, 8)), dim3(256), 0, stream, p);
+  MG_LAUNCH_CHECK("decoder_rollout_fwd");
+  return MGGAN_OK;
+}
+
+int mggan_decoder_rollout_bwd(int R, int T, int H, int EIN, int Z, const int* row_gen, const int* row_pos,
+                              const float* W_hh, const float* W1, const float* W2, long param_stride,
+                              const float* We2d, const float* prep, int prep_stride, const float* Gt, const float* Cs,
+                              const float* Aact, const float* gabs, const float* grel, int Rout, float* dPre,
+                              float* dU, float* gD, float* dH0, float* dQ, float* dEnc, float* dSocR,
+                              hipStream_t stream) {
+  MG_CHECK_ARG(row_gen && row_pos && W_hh && W1 && W2 && We2d && prep && Gt && Cs && Aact && dPre && dU && gD && dH0 &&
+                   dQ && dEnc && dSocR,
+               "decoder_rollout_bwd: null pointer");
+  MG_CHECK_ARG(H == 32, "decoder_rollout_bwd: decoder_h_dim %d not built (32)", H);
+  if (R == 0) return MGGAN_OK;
+  SeqBwdArgs p = {};
+  p.R = R; p.T = T; p.row_gen = row_gen; p.W_hh = W_hh; p.W1 = W1; p.W2 = W2; p.We2d = We2d;
+  p.param_stride = param_stride; p.prep = prep; p.prep_stride = prep_stride;
+  p.Gt = Gt; p.Cs = Cs; p.Aact = Aact; p.gabs = gabs; p.grel = grel; p.row_pos = row_pos; p.Rout = Rout;
+  p.EIN = EIN; p.Z = Z;
+  p.dPre = dPre; p.dU = dU; p.gD = gD; p.dH0 = dH0; p.dQ = dQ; p.dEnc = dEnc; p.dSocR = dSocR;
+  hipLaunchKernelGGL((lstm_bwd_kernel<32, true>), dim3(cdiv(R, 8)), dim3(256), 0, stream, p);
+  MG_LAUNCH_CHECK("decoder_rollout_bwd");
+  return MGGAN_OK;
+}
+
+int mggan_gather_sum(const float* src, int ld_src, const int* inv, float* dst, int ld_dst, int b, int K, int ncols,
+                     int accumulate, hipStream_t stream) {
+  MG_CHECK_ARG(src && inv && dst, "gather_sum: null pointer");
+  long n = (long)b * ncols;
+  if (n == 0) return MGGAN_OK;
+  hipLaunchKernelGGL(gather_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, src, ld_src, inv, dst, ld_dst, b, K,
+                     ncols, accumulate);
+  MG_LAUNCH_CHECK("gather_sum");
+  return MGGAN_OK;
+}
+
+int mggan_transpose(const float* W, float* WT, int N, int K, hipStream_t stream) {
+  MG_CHECK_ARG(W && WT, "transpose: null pointer");
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv((long)N * K, 256)), dim3(256), 0, stream, W, WT, N, K);
+  MG_LAUNCH_CHECK("transpose");
+  return MGGAN_OK;
+}
+
+}  // extern "C"

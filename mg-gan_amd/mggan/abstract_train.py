@@ -1,0 +1,191 @@
+"""Training driver with the reference's surface (/root/reference/mggan/abstract_train.py:25-296):
+MultiGeneratorGAN.{train, save, load, load_from_path} and the optimizer / schedule setup.
+One iteration = discriminator step -> generator step -> PM-network step (:136-159)."""
+import abc
+import math
+from argparse import Namespace
+from collections import defaultdict
+from pathlib import Path
+from statistics import mean
+
+import numpy as np
+import torch
+
+from mggan.data_utils.data_loaders import get_dataloader
+from mggan.logging import Experiment
+from mggan.model.config import get_parser
+from mggan.optim import FlatAdamW, CosineAnnealingLR
+from mggan.parallel import DistContext
+from mggan.rng import HostRNG, DeviceRNG
+
+# Set seeds for reproducibility (abstract_train.py:14-15)
+torch.random.manual_seed(145325)
+np.random.seed(435346)
+
+
+class MultiGeneratorGAN(abc.ABC):
+    def __init__(self, generator, discriminator, config, writer):
+        self.writer = writer
+        self.config = config
+        if not config.gpus:
+            raise RuntimeError("the MI355X build has no CPU compute path: pass --gpus 0 (use the oracle for CPU runs)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible; the hot path runs only on the GPU (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.D = discriminator.to(self.device).flatten_parameters_()
+        self.G = generator.to(self.device).flatten_parameters_()
+        self.l2_weight = self.config.l2_loss_weight
+        self.gan_type = self.config.gan_type
+        if self.config.gan_obj != "NS":
+            raise ValueError("Objective not supported on the HIP path (only 'NS', the reference default)")
+
+        self.log_dir = Path(self.writer.get_data_path(self.writer.name, self.writer.version))
+        self.model_save_dir = self.log_dir / "checkpoints"
+        self.model_save_dir.mkdir(exist_ok=True, parents=True)
+
+        self.optimizerD = FlatAdamW(self.D, lr=self.config.d_lr, betas=(config.beta1, 0.999))
+        self.optimizerG = FlatAdamW(self.G, lr=self.config.g_lr, betas=(config.beta1, 0.999))
+        self.lr_schedulerD = CosineAnnealingLR(self.optimizerD, config.epochs, eta_min=0)
+        self.lr_schedulerG = CosineAnnealingLR(self.optimizerG, config.epochs, eta_min=0)
+        self.epoch = 0
+
+        self.rng = DeviceRNG() if getattr(config, "rng", "host") == "device" else HostRNG()
+        self.G.rng = self.rng
+        self.dist = DistContext()
+        self.dist.attach(self.G, self.D)
+
+    def to_device(self, batch):
+        return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def train_iteration(self, batch, metrics):
+        """Loop body of abstract_train.py:114-168 for one collated batch (already on the device)."""
+        in_xy, in_dxdy = batch["in_xy"], batch["in_dxdy"]
+        b = in_xy.size(1)
+        sub_batches = batch["seq_start_end"] if "seq_start_end" in batch else list(zip(range(b), range(1, b + 1)))
+        gt_xy, gt_dxdy = batch["gt_xy"], batch["gt_dxdy"]
+        loss_mask = batch.get("loss_mask")
+        if loss_mask is None:
+            loss_mask = ~gt_xy.isnan().any(2).any(0)
+        if not bool(loss_mask.all()):
+            gt_dxdy, gt_xy = gt_dxdy[:, loss_mask], gt_xy[:, loss_mask]
+        img = batch["features"] if "features" in batch else None
+        args = (in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, metrics, loss_mask, img)
+        for _ in range(self.config.num_unrolling_steps + 1):
+            self.discriminator_step(*args)
+        self.generator_step(*args)
+        self.net_chooser_step(*args)
+
+    def train(self):
+        cfg = self.config
+        kw = dict(synthetic_scenes=getattr(cfg, "synthetic_scenes", 64), synthetic_peds=getattr(cfg, "synthetic_peds", 0))
+        train_loader = get_dataloader(dataset=cfg.dataset, phase="train", augment=cfg.augment,
+                                      batch_size=cfg.batch_size, workers=cfg.workers, shuffle=True, **kw)
+        val_loader = get_dataloader(dataset=cfg.dataset, phase="val", augment=False, batch_size=cfg.batch_size,
+                                    workers=cfg.workers, shuffle=False, **kw)
+        track_metric = "val/ADE k=20"
+        min_track_metric = math.inf
+        for epoch in range(cfg.epochs):
+            self.epoch += 1
+            self.D.train()
+            self.G.train()
+            metrics = defaultdict(list)
+            for batch in train_loader:
+                batch = self.to_device(batch)
+                batch["loss_mask"] = torch.ones(batch["in_xy"].size(1), dtype=torch.bool, device=self.device) \
+                    if not torch.isnan(batch["gt_xy"]).any() else None
+                self.train_iteration(batch, metrics)
+
+            if self.epoch % cfg.val_every == 0:
+                self.D.eval()
+                self.G.eval()
+                with torch.no_grad():
+                    m = self.check_accuracy(val_loader, vis=True, prefix="val/", num_k=cfg.top_k_test)
+                    for k, v in m.items():
+                        metrics["val/{}".format(k)].append(v)
+                cur = mean(metrics[track_metric])
+                if cur < min_track_metric:
+                    print('Saving best model... "{}: Before: {}, After: {}'.format(track_metric, min_track_metric, cur))
+                    min_track_metric = cur
+                    self.save(checkpoint_name="checkpoint_best.pth")
+
+            metrics = {k: float(np.mean(v)) for k, v in metrics.items()}
+            self.writer.log(metrics, epoch)
+            if self.epoch % cfg.save_every == 0:
+                self.save()
+            self.l2_weight *= cfg.l2_decay_rate
+            self.lr_schedulerD.step()
+            self.lr_schedulerG.step()
+            self.writer.save()
+        return metrics
+
+    def save(self, checkpoint_name=None):
+        save_obj = {"generator": self.G.state_dict(), "discriminator": self.D.state_dict(),
+                    "gen_opt": self.optimizerG.state_dict(), "disc_opt": self.optimizerD.state_dict()}
+        if not checkpoint_name:
+            checkpoint_name = "checkpoint_{}.pth".format(self.epoch)
+        torch.save(save_obj, self.model_save_dir / checkpoint_name)
+
+    @classmethod
+    def load(cls, log_path, exp_name, version, checkpoint):
+        import csv
+
+        version_dir = Path(log_path) / exp_name / "version_{}".format(version)
+        checkpoint_dir = version_dir / "checkpoints"
+        if checkpoint == "latest":
+            epochs = [int(p.stem.split("_")[1]) for p in checkpoint_dir.iterdir() if p.stem.split("_")[1] != "best"]
+            checkpoint = max(epochs)
+        state_dicts = torch.load(checkpoint_dir / "checkpoint_{}.pth".format(checkpoint), map_location="cpu")
+        defaults = {a.dest: a.default for a in get_parser()._actions if not a.required and a.dest != "help"}
+        with open(version_dir / "meta_tags.csv") as f:
+            for row in csv.DictReader(f):
+                defaults[row["key"]] = _convert(row["value"])
+        config = Namespace(**defaults)
+        g, d = cls.construct_model(config)
+        m = cls(g, d, config, Experiment(log_path, name=exp_name, version=version))
+        m.G.load_state_dict(state_dicts["generator"], strict=False)
+        m.D.load_state_dict(state_dicts["discriminator"], strict=False)
+        try:
+            m.optimizerD.load_state_dict(state_dicts["disc_opt"])
+            m.optimizerG.load_state_dict(state_dicts["gen_opt"])
+        except Exception as e:  # same tolerance as the reference (abstract_train.py:278-283)
+            print("Could not restore optimizers.", str(e))
+        return m, config
+
+    @classmethod
+    def load_from_path(cls, version_path, checkpoint="best"):
+        version_path = Path(version_path)
+        assert "version" in version_path.stem, "Input path should point to model version directory."
+        return cls.load(version_path.parent.parent, version_path.parent.name, int(version_path.stem.split("_")[1]),
+                        checkpoint)
+
+    @abc.abstractmethod
+    def generator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None):
+        pass
+
+    @abc.abstractmethod
+    def discriminator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None):
+        pass
+
+    @abc.abstractmethod
+    def net_chooser_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, metrics, loss_mask, img):
+        pass
+
+    @abc.abstractmethod
+    def check_accuracy(self, loader, vis=False, prefix="", num_k=20):
+        pass
+
+
+def _convert(val):
+    if isinstance(val, str):
+        if val.lower() == "true":
+            return True
+        if val.lower() == "false":
+            return False
+        if val == "None" or val == "":
+            return None
+    for c in (int, float, str):
+        try:
+            return c(val)
+        except (ValueError, TypeError):
+            pass
+    return val

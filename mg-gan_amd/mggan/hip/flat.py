@@ -1,0 +1,115 @@
+"""Flat parameter / gradient storage for the HIP modules.
+
+All parameters of a root module (generator or discriminator) live in ONE f32
+buffer (nn.Parameters are views into it, state_dict keys unchanged), with a
+twin gradient buffer.  This is what lets
+  * clip_grad_norm_ + AdamW run as one fused launch over the whole model,
+  * the per-generator decoder weights be addressed as base + g * stride,
+  * a multi-GPU gradient all-reduce be ONE RCCL call per optimizer step.
+Backward kernels accumulate parameter gradients straight into the twin buffer;
+`p.grad` is attached as a view of it (zeroed on first touch after zero_grad()).
+"""
+import torch
+from torch import nn
+
+ALIGN = 4  # floats (16 B) -> every tensor can be read with float4 loads
+
+
+class FlatModule(nn.Module):
+    """Mixin for root modules (MultiGenerator, MultiDiscriminatorTrajectory)."""
+
+    _flat = None
+
+    def flat_is_current(self):
+        f = self._flat
+        if f is None:
+            return False
+        base = f.data_ptr()
+        for p, off in self._flat_items:
+            if p.data_ptr() != base + 4 * off:
+                return False
+        return True
+
+    def ensure_flat(self):
+        if not self.flat_is_current():
+            self.flatten_parameters_()
+        return self
+
+    def flatten_parameters_(self):
+        named = list(self.named_parameters())
+        if not named:
+            return self
+        dev = named[0][1].device
+        off, table = 0, []
+        for name, p in named:
+            assert p.dtype == torch.float32, name
+            table.append((name, p, off, p.numel()))
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        elem_seg = torch.full((off,), -1, dtype=torch.int32)
+        with torch.no_grad():
+            for si, (name, p, o, n) in enumerate(table):
+                flat[o:o + n].copy_(p.data.reshape(-1))
+                p.data = flat[o:o + n].view(p.shape)
+                if p.grad is not None:
+                    grad[o:o + n].copy_(p.grad.reshape(-1))
+                    p.grad = grad[o:o + n].view(p.shape)
+                elem_seg[o:o + n] = si
+        self._flat, self._flat_grad = flat, grad
+        self._flat_items = [(p, o) for _, p, o, _ in table]
+        self._flat_names = [name for name, _, _, _ in table]
+        self._flat_seg = {name: si for si, (name, _, _, _) in enumerate(table)}
+        self._flat_off = {id(p): (o, n) for _, p, o, n in table}
+        self._elem_seg = elem_seg.to(dev)
+        self._touched = set()
+        self._mask_cache = {}
+        for m in self.modules():
+            if m is not self:
+                object.__setattr__(m, "_flat_root", self)
+        return self
+
+    # ---- gradient buffer access -------------------------------------------------
+    def grad_ptr(self, p):
+        """device pointer of p's slot in the flat gradient buffer; attaches p.grad on first touch."""
+        o, n = self._flat_off[id(p)]
+        self._touched.add(id(p))
+        if p.grad is None:
+            view = self._flat_grad[o:o + n].view(p.shape)
+            view.zero_()
+            p.grad = view
+        return self._flat_grad.data_ptr() + 4 * o
+
+    def zero_grad_flat(self):
+        """Trainer fast path: one memset, every p.grad stays attached."""
+        self._flat_grad.zero_()
+        self._touched.clear()
+        for p, o in self._flat_items:
+            if p.grad is None:
+                n = p.numel()
+                p.grad = self._flat_grad[o:o + n].view(p.shape)
+
+    def touched_mask(self):
+        """uint8 mask over parameter segments that received a gradient since the last zero_grad_flat()
+        (== the reference's `p.grad is not None` set that AdamW / clip_grad_norm_ act on)."""
+        key = tuple(1 if id(p) in self._touched else 0 for p, _ in self._flat_items)
+        m = self._mask_cache.get(key)
+        if m is None:
+            m = torch.tensor(key, dtype=torch.uint8).to(self._flat.device)
+            self._mask_cache[key] = m
+        return m
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none)
+        if self._flat is not None:
+            self._touched.clear()
+
+
+def root_of(module):
+    r = getattr(module, "_flat_root", None)
+    if r is None:
+        if not isinstance(module, FlatModule):
+            raise RuntimeError("{} is not attached to a flattened root module".format(type(module).__name__))
+        r = module
+    r.ensure_flat()
+    return r

@@ -1,0 +1,565 @@
+"""torch.autograd.Function wrappers over the C ABI (include/mggan_hip.h).
+
+Each Function is one coarse stage of the reference forward pass; its forward and
+backward are sequences of HIP kernel launches on the current stream.  PyTorch
+tensors are storage only.  Parameter gradients are accumulated by the kernels
+into the root module's flat gradient buffer (hip/flat.py), so backward returns
+None for parameter inputs.
+"""
+import torch
+from torch.autograd import Function
+
+from .lib import lib
+from .flat import root_of
+
+ACT_NONE, ACT_LEAKY, ACT_SIGMOID, ACT_SIGMOID_EPS = 0, 1, 2, 3
+F32 = torch.float32
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _empty(*shape, like=None, dtype=F32):
+    return torch.empty(*shape, dtype=dtype, device=like.device)
+
+
+def _rows2d(t):
+    """(rows, cols) view with unit inner stride -> (tensor, ld)."""
+    assert t.dim() == 2 and t.dtype == F32 and t.is_cuda, (t.shape, t.dtype, t.device)
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+
+
+def _want(*params):
+    return torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params)
+
+
+def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scale=1, n_groups=0, w_stride=0,
+          b_stride=0):
+    """dW += dz^T x, db += colsum(dz)  (deterministic split reduction)."""
+    if rows == 0:
+        return
+    nbytes = lib.mggan_wgrad_workspace_bytes(rows, K, N, n_groups)
+    ws = torch.empty(nbytes // 4, dtype=F32, device=dz.device if torch.is_tensor(dz) else x.device)
+    lib.mggan_wgrad(_p(dz) if torch.is_tensor(dz) else dz, lddz, _p(x) if torch.is_tensor(x) else x, ldx, dW_ptr, lddw,
+                    db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, ws.data_ptr(), nbytes, _s())
+
+
+# ------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = act(x W^T + b)   (nn.Linear + activation; reference utils.py:134-149)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, slope, owner):
+        x, ldx = _rows2d(x)
+        rows, K = x.shape
+        N = W.shape[0]
+        y = _empty(rows, N, like=x)
+        lib.mggan_linear_fwd(_p(x), ldx, _p(W), _p(b), _p(y), N, rows, K, N, act, float(slope), _s())
+        ctx.act, ctx.slope, ctx.owner, ctx.ldx = act, slope, owner, ldx
+        ctx.save_for_backward(x, W, b, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, b, y = ctx.saved_tensors
+        rows, K = x.shape
+        N = W.shape[0]
+        dy, lddy = _rows2d(dy)
+        if ctx.act != ACT_NONE:
+            dz = _empty(rows, N, like=x)
+            lib.mggan_act_bwd(_p(dy), lddy, _p(y), N, _p(dz), N, rows, N, ctx.act, float(ctx.slope), _s())
+            lddz = N
+        else:
+            dz, lddz = dy, lddy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty(rows, K, like=x)
+            lib.mggan_linear_bwd_data(_p(dz), lddz, _p(W), K, _p(dx), K, rows, K, N, 0, _s())
+        if W.requires_grad:
+            root = root_of(ctx.owner)
+            wgrad(dz, lddz, x, ctx.ldx, root.grad_ptr(W), K, root.grad_ptr(b) if b is not None else 0, rows, K, N)
+        return dx, None, None, None, None, None
+
+
+def linear(x, layer, act=ACT_NONE, slope=0.0):
+    lead = x.shape[:-1]
+    y = LinearFn.apply(x.reshape(-1, x.shape[-1]), layer.weight, layer.bias, act, slope, layer)
+    return y.reshape(*lead, -1)
+
+
+# ------------------------------------------------------------------------------------------
+class LstmEncoderFn(Function):
+    """Linear(2,E) + nn.LSTM over T steps -> h_T   (common_modules.py:48-66)."""
+
+    @staticmethod
+    def forward(ctx, x, emb_w, emb_b, w_ih, w_hh, b_ih, b_hh, owner):
+        T, b, _ = x.shape
+        H, E = w_hh.shape[1], emb_w.shape[0]
+        x = x.contiguous()
+        psz = lib.mggan_lstm_prep_size(H, 0, 0)
+        prep = _empty(psz, like=x)
+        lib.mggan_lstm_fold(_p(emb_w), _p(emb_b), _p(w_ih), _p(b_ih), _p(b_hh), _p(w_hh), 0, 0, 0, 0, 0, 1, H, E, 0, 0,
+                            _p(prep), psz, _s())
+        save = _want(emb_w, w_ih, w_hh)
+        Gt = _empty(b, T, 4 * H, like=x) if save else None
+        Cs = _empty(b, T, H, like=x) if save else None
+        Hp = _empty(b, T, H, like=x) if save else None
+        Din = _empty(b, T, 2, like=x) if save else None
+        hout = _empty(b, H, like=x)
+        lib.mggan_lstm_encoder_fwd(_p(x), T, b, H, _p(prep), _p(hout), H, _p(Gt), _p(Cs), _p(Hp), _p(Din), _s())
+        if save:
+            ctx.dims, ctx.owner = (T, b, H, E), owner
+            ctx.save_for_backward(emb_w, emb_b, w_ih, w_hh, b_ih, b_hh, prep, Gt, Cs, Hp, Din)
+        return hout
+
+    @staticmethod
+    def backward(ctx, dh):
+        emb_w, emb_b, w_ih, w_hh, b_ih, b_hh, prep, Gt, Cs, Hp, Din = ctx.saved_tensors
+        T, b, H, E = ctx.dims
+        root = root_of(ctx.owner)
+        dh, ld = _rows2d(dh)
+        dPre = _empty(b, T, 4 * H, like=dh)
+        lib.mggan_lstm_encoder_bwd(_p(dh), ld, T, b, H, _p(w_hh), _p(prep), _p(Gt), _p(Cs), _p(dPre), _s())
+        rows = b * T
+        wgrad(dPre, 4 * H, Hp, H, root.grad_ptr(w_hh), H, 0, rows, H, 4 * H)
+        dprep = torch.zeros(12 * H, dtype=F32, device=dh.device)
+        wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, rows, 2, 4 * H)
+        lib.mggan_lstm_unfold_grads(_p(emb_w), _p(emb_b), _p(w_ih), root.grad_ptr(emb_w), root.grad_ptr(emb_b),
+                                    root.grad_ptr(w_ih), root.grad_ptr(b_ih), root.grad_ptr(b_hh), 0, 1, H, E,
+                                    _p(dprep), 12 * H, _s())
+        return (None,) * 8
+
+
+# ------------------------------------------------------------------------------------------
+class SceneTables:
+    """Device-side index tables of one batch's scene structure (built once per batch)."""
+
+    def __init__(self, seq_start_end, b, device):
+        import numpy as np
+
+        sse = [(int(s), int(e)) for s, e in seq_start_end]
+        ped_s0 = np.zeros(b, np.int32)
+        ped_n = np.ones(b, np.int32)
+        ped_prow = np.zeros(b, np.int32)
+        ped_scene = np.zeros(b, np.int32)
+        pi, pj, P = [], [], 0
+        for si, (s, e) in enumerate(sse):
+            n = e - s
+            ped_scene[s:e] = si
+            ped_s0[s:e] = s
+            ped_n[s:e] = n
+            if n > 1:
+                ii, jj = np.meshgrid(np.arange(s, e), np.arange(s, e), indexing="ij")
+                pi.append(ii.reshape(-1))
+                pj.append(jj.reshape(-1))
+                ped_prow[s:e] = P + np.arange(n) * n
+                P += n * n
+        self.P, self.b, self.S = P, b, len(sse)
+        cat = (lambda l: np.concatenate(l).astype(np.int32)) if pi else (lambda l: np.zeros(0, np.int32))
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.pair_i, self.pair_j = to(cat(pi)), to(cat(pj))
+        self.ped_s0, self.ped_n, self.ped_prow, self.ped_scene = to(ped_s0), to(ped_n), to(ped_prow), to(ped_scene)
+        self.scenes = to(np.asarray(sse, np.int32).reshape(-1, 2))
+        self.seq_start_end = sse
+
+
+_TABLE_CACHE = {}
+
+
+def scene_tables(seq_start_end, b, device):
+    key = (id(seq_start_end), b, str(device))
+    hit = _TABLE_CACHE.get(key)
+    if hit is not None and hit[0] is seq_start_end:
+        return hit[1]
+    t = SceneTables(seq_start_end, b, device)
+    if len(_TABLE_CACHE) > 64:
+        _TABLE_CACHE.clear()
+    _TABLE_CACHE[key] = (seq_start_end, t)
+    return t
+
+
+class SocialAttentionFn(Function):
+    """SocialFeatures -> EmbedSocialFeatures -> AttentionPooling over in-scene pairs (social.py:7-123)."""
+
+    @staticmethod
+    def forward(ctx, xy_last, dxdy_last, h, tb, w1, b1, w2, b2, w3, b3, wat, bat, owner):
+        h, ld_h = _rows2d(h)
+        b, Hh = h.shape
+        Fd = wat.shape[0]
+        xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
+        st = _s()
+        Wh = _empty(b, Fd, like=h)
+        lib.mggan_linear_fwd(_p(h), ld_h, _p(wat), _p(bat), _p(Wh), Fd, b, Hh, Fd, ACT_NONE, 0.0, st)
+        W3b = _empty(Fd, 65, like=h)
+        lib.mggan_social_w3b(_p(w3), _p(b3), _p(W3b), Fd, st)
+        vc = _empty(b, 65, like=h)
+        lib.mggan_linear_bwd_data(_p(Wh), Fd, _p(W3b), 65, _p(vc), 65, b, 65, Fd, 0, st)
+        save = _want(h, w1, wat)
+        P = tb.P
+        sigma = _empty(max(P, 1), like=h)
+        feat = _empty(max(P, 1), 3, like=h) if save else None
+        l1 = _empty(max(P, 1), 32, like=h) if save else None
+        l2 = _empty(max(P, 1), 64, like=h) if save else None
+        lib.mggan_social_pairs_fwd(P, _p(tb.pair_i), _p(tb.pair_j), _p(xy_last), _p(dxdy_last), _p(w1), _p(b1), _p(w2),
+                                   _p(b2), _p(vc), _p(feat), _p(l1), _p(l2), _p(sigma), st)
+        att = _empty(max(P, 1), like=h)
+        S = _empty(b, Hh, like=h)
+        lib.mggan_social_softmax_fwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(sigma), _p(h), ld_h,
+                                     _p(att), _p(S), Hh, st)
+        if save:
+            ctx.tb, ctx.owner, ctx.ld_h = tb, owner, ld_h
+            ctx.save_for_backward(h, w2, wat, W3b, Wh, vc, feat, l1, l2, att, w1, b1, b2, w3, b3, bat)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        h, w2, wat, W3b, Wh, vc, feat, l1, l2, att, w1, b1, b2, w3, b3, bat = ctx.saved_tensors
+        tb, ld_h = ctx.tb, ctx.ld_h
+        root = root_of(ctx.owner)
+        b, Hh = h.shape
+        Fd, P = wat.shape[0], tb.P
+        st = _s()
+        dS, ld_ds = _rows2d(dS)
+        dsigma = _empty(max(P, 1), like=h)
+        dh = _empty(b, Hh, like=h)
+        lib.mggan_social_softmax_bwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(att), _p(h), ld_h, _p(dS),
+                                     ld_ds, _p(dsigma), _p(dh), Hh, 0, st)
+        dz2 = _empty(max(P, 1), 64, like=h)
+        dz1 = _empty(max(P, 1), 32, like=h)
+        dvc = _empty(b, 65, like=h)
+        lib.mggan_social_pairs_bwd(P, b, _p(tb.pair_j), _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(dsigma), _p(vc),
+                                   _p(l1), _p(l2), _p(w2), _p(dz2), _p(dz1), _p(dvc), st)
+        if w1.requires_grad:
+            wgrad(dz2, 64, l1, 32, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64)
+            wgrad(dz1, 32, feat, 3, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32)
+        # dWh = dvc [W3|b3]^T ; d[W3|b3] = Wh^T dvc
+        dWh = _empty(b, Fd, like=h)
+        lib.mggan_linear_fwd(_p(dvc), 65, _p(W3b), 0, _p(dWh), Fd, b, 65, Fd, ACT_NONE, 0.0, st)
+        if w3.requires_grad:
+            wgrad(Wh, Fd, dvc, 65, root.grad_ptr(w3), 64, 0, b, 64, Fd)
+            wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, 65, root.grad_ptr(b3), 1, 0, b, 1, Fd)
+            wgrad(dWh, Fd, h, ld_h, root.grad_ptr(wat), Hh, root.grad_ptr(bat), b, Hh, Fd)
+        lib.mggan_linear_bwd_data(_p(dWh), Fd, _p(wat), Hh, _p(dh), Hh, b, Hh, Fd, 1, st)
+        return (None, None, dh if ctx.needs_input_grad[2] else None) + (None,) * 10
+
+
+# ------------------------------------------------------------------------------------------
+class SceneAttentionFn(Function):
+    """CNN (2 x Conv-BN-ReLU-MaxPool) + channel-softmax attention -> (B,64)  (cnn.py:109-282)."""
+
+    @staticmethod
+    def forward(ctx, img, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb, bb, bn1, bn2, training, owner, sync):
+        img = img.contiguous()
+        B, C = img.shape[0], c1w.shape[0]
+        st = _s()
+        y1 = _empty(B, C, 33, 33, like=img)
+        part = _empty(max(B, 1), 2 * C, like=img)
+        lib.mggan_conv1_fwd(_p(img), B, C, _p(c1w), _p(c1b), _p(y1), _p(part), st)
+        n_img = float(B)
+
+        def finalize(bn, gamma, beta, hw):
+            sums = None
+            n = n_img
+            if training:
+                sums = torch.empty(2 * C, dtype=torch.float64, device=img.device)
+                lib.mggan_bn_reduce(_p(part), B, 2 * C, _p(sums), st)
+                if sync is not None:
+                    n = sync.all_reduce_stats(sums, n_img)
+            scale, shift, stat = _empty(C, like=img), _empty(C, like=img), _empty(2 * C, like=img)
+            lib.mggan_bn_finalize(_p(sums), n * hw, C, 1 if training else 0, _p(gamma), _p(beta), _p(bn.running_mean),
+                                  _p(bn.running_var), _p(bn.num_batches_tracked), float(bn.momentum), float(bn.eps),
+                                  _p(scale), _p(shift), _p(stat), st)
+            return scale, shift, stat, n * hw
+
+        sc1, sh1, stat1, cnt1 = finalize(bn1, g1, be1, 33 * 33)
+        y2 = _empty(B, C, 16, 16, like=img)
+        lib.mggan_conv2_fwd(_p(y1), B, C, _p(sc1), _p(sh1), _p(c2w), _p(c2b), _p(y2), _p(part), st)
+        sc2, sh2, stat2, cnt2 = finalize(bn2, g2, be2, 16 * 16)
+        out = _empty(B, 64, like=img)
+        lib.mggan_scene_attention_fwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(wa), _p(ba), _p(wb), _p(bb), _p(out), 64, st)
+        if _want(c1w, wa):
+            if not training:
+                raise RuntimeError("scene attention backward is only implemented for train-mode BatchNorm "
+                                   "(the reference never differentiates in eval mode)")
+            ctx.owner, ctx.sync, ctx.counts = owner, sync, (cnt1, cnt2)
+            ctx.save_for_backward(img, y1, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa,
+                                  ba, wb, bb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (img, y1, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb,
+         bb) = ctx.saved_tensors
+        root, sync = root_of(ctx.owner), ctx.sync
+        cnt1, cnt2 = ctx.counts
+        B, C = img.shape[0], c1w.shape[0]
+        st = _s()
+        dout, ld = _rows2d(dout)
+        rows = B * 64
+        ds, vs = _empty(rows, C, like=img), _empty(rows, C, like=img)
+        hact, dz = _empty(rows, 32, like=img), _empty(rows, 32, like=img)
+        G2 = _empty(B, C, 16, 16, like=img)
+        part = _empty(B, 2 * C, like=img)
+        lib.mggan_scene_attention_bwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(stat2), _p(wa), _p(ba), _p(wb), _p(bb), _p(dout),
+                                      ld, _p(ds), _p(hact), _p(dz), _p(vs), _p(G2), _p(part), st)
+        wgrad(ds, C, hact, 32, root.grad_ptr(wb), 32, root.grad_ptr(bb), rows, 32, C)
+        wgrad(dz, 32, vs, C, root.grad_ptr(wa), C, root.grad_ptr(ba), rows, C, 32)
+
+        def bn_bwd(gamma, beta, stat, cnt):
+            sums = torch.empty(2 * C, dtype=torch.float64, device=img.device)
+            lib.mggan_bn_reduce(_p(part), B, 2 * C, _p(sums), st)
+            local = sums
+            if sync is not None:
+                local = sums.clone()
+                sync.all_reduce_(sums)
+            coef = _empty(3 * C, like=img)
+            lib.mggan_bn_bwd_finalize(_p(sums), _p(local), cnt, C, _p(gamma), _p(stat), _p(coef), root.grad_ptr(gamma),
+                                      root.grad_ptr(beta), st)
+            return coef
+
+        coef2 = bn_bwd(g2, be2, stat2, cnt2)
+        G1c = _empty(B, C, 16, 16, like=img)
+        code1 = torch.empty(B, C, 16, 16, dtype=torch.uint8, device=img.device)
+        grid = lib.mggan_cnn_bwd_grid(B)
+        nb = grid * (256 // (C * C)) * (C * C * 9 + C) * 4
+        ws = torch.empty(nb // 4, dtype=F32, device=img.device)
+        lib.mggan_conv2_bwd(_p(y1), B, C, _p(sc1), _p(sh1), _p(stat1), _p(y2), _p(G2), _p(stat2), _p(coef2), _p(c2w),
+                            _p(G1c), _p(code1), _p(part), root.grad_ptr(c2w), root.grad_ptr(c2b), _p(ws), nb, st)
+        coef1 = bn_bwd(g1, be1, stat1, cnt1)
+        nb = grid * (256 // (4 * C)) * (4 * C * 9 + C) * 4
+        ws = torch.empty(nb // 4, dtype=F32, device=img.device)
+        lib.mggan_conv1_bwd(_p(img), B, C, _p(y1), _p(stat1), _p(coef1), _p(G1c), _p(code1), root.grad_ptr(c1w),
+                            root.grad_ptr(c1b), _p(ws), nb, st)
+        return (None,) * 18
+
+
+# ------------------------------------------------------------------------------------------
+class RolloutRows:
+    """Row tables of one decoder launch: rows sorted by generator (host-side bookkeeping that
+    replaces get_selection_indices + the index gather of standard.py:190-214)."""
+
+    def __init__(self, gen, ped, slot, n_gens, b, device):
+        import numpy as np
+
+        gen = np.asarray(gen, np.int64).reshape(-1)
+        R = gen.shape[0]
+        order = np.argsort(gen, kind="stable").astype(np.int32)
+        inv = np.empty(R, np.int32)
+        inv[order] = np.arange(R, dtype=np.int32)
+        seg = np.zeros(n_gens + 1, np.int32)
+        seg[1:] = np.cumsum(np.bincount(gen, minlength=n_gens))
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(device)
+        self.R, self.b, self.K = R, b, R // max(b, 1)
+        self.row_gen, self.row_ped, self.row_slot = to(gen[order]), to(np.asarray(ped)[order]), to(np.asarray(slot)[order])
+        self.row_pos, self.inv, self.seg = to(order), to(inv), to(seg)
+        self.counts = np.diff(seg)
+
+
+class DecoderRolloutFn(Function):
+    """enc_h_to_dec_h + per-generator RelativeDecoder rollouts for the selected rows
+    (standard.py:227-265, common_modules.py:97-131)."""
+
+    @staticmethod
+    def forward(ctx, enc_h, soc, noise, xy0, dxdy0, rows, e2d_w, e2d_b, g0, n_gens, stride, T, owner):
+        enc_h, ld_enc = _rows2d(enc_h)
+        soc, ld_soc = _rows2d(soc)
+        noise, xy0, dxdy0 = noise.contiguous(), xy0.contiguous(), dxdy0.contiguous()
+        b, EIN = enc_h.shape
+        Z = noise.shape[-1]
+        H, E, S = g0["w_hh"].shape[1], g0["emb_w"].shape[0], soc.shape[1]
+        assert S == H, "social width must equal decoder_h_dim (both 32 by default)"
+        R = rows.R
+        st = _s()
+        ctx.set_materialize_grads(False)
+        psz = lib.mggan_lstm_prep_size(H, S, 1)
+        prep = _empty(n_gens, psz, like=enc_h)
+        lib.mggan_lstm_fold(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), _p(g0["b_ih"]), _p(g0["b_hh"]),
+                            _p(g0["w_hh"]), _p(g0["w1"]), _p(g0["b1"]), _p(g0["w2"]), _p(g0["b2"]), stride, n_gens, H, E,
+                            S, 1, _p(prep), psz, st)
+        e2dT = _empty(EIN + Z, H, like=enc_h)
+        lib.mggan_transpose(_p(e2d_w), _p(e2dT), H, EIN + Z, st)
+        save = _want(enc_h, soc, e2d_w, g0["w_hh"])
+        mk = (lambda *s: _empty(*s, like=enc_h)) if save else (lambda *s: None)
+        Gt, Cs, Hp, Hc = mk(R, T, 4 * H), mk(R, T, H), mk(R, T, H), mk(R, T, H)
+        Din, Aact, E2Din, SocR = mk(R, T, 2), mk(R, T, H // 2), mk(R, EIN + Z), mk(R, S)
+        out_abs, out_rel = _empty(T, R, 2, like=enc_h), _empty(T, R, 2, like=enc_h)
+        lib.mggan_decoder_rollout_fwd(R, T, b, H, EIN, Z, _p(prep), psz, _p(rows.row_gen), _p(rows.row_ped),
+                                      _p(rows.row_slot), _p(rows.row_pos), _p(enc_h), ld_enc, _p(noise) or _p(enc_h), _p(soc), ld_soc,
+                                      _p(xy0), _p(dxdy0), _p(e2dT), _p(e2d_b), _p(out_abs), _p(out_rel), R, _p(Gt),
+                                      _p(Cs), _p(Hp), _p(Hc), _p(Din), _p(Aact), _p(E2Din), _p(SocR), st)
+        if save:
+            ctx.meta = (rows, g0, n_gens, stride, T, owner, (b, EIN, Z, H, E, S, psz))
+            ctx.save_for_backward(e2d_w, e2d_b, prep, Gt, Cs, Hp, Hc, Din, Aact, E2Din, SocR)
+        return out_abs, out_rel
+
+    @staticmethod
+    def backward(ctx, gabs, grel):
+        e2d_w, e2d_b, prep, Gt, Cs, Hp, Hc, Din, Aact, E2Din, SocR = ctx.saved_tensors
+        rows, g0, n_gens, stride, T, owner, (b, EIN, Z, H, E, S, psz) = ctx.meta
+        root = root_of(owner)
+        R, Hh = rows.R, H // 2
+        st = _s()
+        dev = prep.device
+        gabs = None if gabs is None else gabs.contiguous()
+        grel = None if grel is None else grel.contiguous()
+        mk = lambda *s: torch.empty(*s, dtype=F32, device=dev)
+        dPre, dU, gD, dH0, dQ = mk(R, T, 4 * H), mk(R, T, Hh), mk(R, T, 2), mk(R, H), mk(R, Hh)
+        dEnc, dSocR = mk(R, EIN), mk(R, S)
+        lib.mggan_decoder_rollout_bwd(R, T, H, EIN, Z, _p(rows.row_gen), _p(rows.row_pos), _p(g0["w_hh"]), _p(g0["w1"]),
+                                      _p(g0["w2"]), stride, _p(e2d_w), _p(prep), psz, _p(Gt), _p(Cs), _p(Aact), _p(gabs),
+                                      _p(grel), R, _p(dPre), _p(dU), _p(gD), _p(dH0), _p(dQ), _p(dEnc), _p(dSocR), st)
+        if g0["w_hh"].requires_grad:
+            gp = root.grad_ptr
+            seg, ng = rows.seg, n_gens
+            wgrad(dPre, 4 * H, Hp, H, gp(g0["w_hh"]), H, 0, R * T, H, 4 * H, seg, T, ng, stride, stride)
+            dprep = torch.zeros(n_gens, 12 * H, dtype=F32, device=dev)
+            wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, R * T, 2, 4 * H, seg, T, ng,
+                  12 * H, 12 * H)
+            # touch every gradient slot of every generator so that p.grad is attached (zero if no rows)
+            for p in owner.generator_parameters():
+                gp(p)
+            lib.mggan_lstm_unfold_grads(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), gp(g0["emb_w"]),
+                                        gp(g0["emb_b"]), gp(g0["w_ih"]), gp(g0["b_ih"]), gp(g0["b_hh"]), stride, ng, H,
+                                        E, _p(dprep), 12 * H, st)
+            wgrad(dU, Hh, Hc, H, gp(g0["w1"]), H + S, gp(g0["b1"]), R * T, H, Hh, seg, T, ng, stride, stride)
+            wgrad(dQ, Hh, SocR, S, gp(g0["w1"]) + 4 * H, H + S, 0, R, S, Hh, seg, 1, ng, stride, stride)
+            wgrad(gD, 2, Aact, Hh, gp(g0["w2"]), Hh, gp(g0["b2"]), R * T, Hh, 2, seg, T, ng, stride, stride)
+        if e2d_w.requires_grad:
+            wgrad(dH0, H, E2Din, EIN + Z, root.grad_ptr(e2d_w), EIN + Z, root.grad_ptr(e2d_b), R, EIN + Z, H)
+        d_enc = d_soc = None
+        if ctx.needs_input_grad[0]:
+            d_enc = mk(b, EIN)
+            lib.mggan_gather_sum(_p(dEnc), EIN, _p(rows.inv), _p(d_enc), EIN, b, rows.K, EIN, 0, st)
+        if ctx.needs_input_grad[1]:
+            d_soc = mk(b, S)
+            lib.mggan_gather_sum(_p(dSocR), S, _p(rows.inv), _p(d_soc), S, b, rows.K, S, 0, st)
+        return (d_enc, d_soc) + (None,) * 11
+
+
+# ------------------------------------------------------------------------------------------
+class DAssembleFn(Function):
+    """classifier_inp rows k*b+ped = [soc (block 0 only) | in_enc | pred_enc | scene]
+    (discriminators.py:141,179-196; SURVEY A.1: list-repeat of seq_start_end leaves the social
+    features of sample blocks >= 1 at zero)."""
+
+    @staticmethod
+    def forward(ctx, soc0, in_enc, pred_enc, scene, K):
+        soc0, in_enc, pred_enc, scene = (t.contiguous() for t in (soc0, in_enc, pred_enc, scene))
+        b = in_enc.shape[0]
+        ws, wi, wp, wc = soc0.shape[1], in_enc.shape[1], pred_enc.shape[1], scene.shape[1]
+        X = _empty(K * b, ws + wi + wp + wc, like=in_enc)
+        lib.mggan_d_assemble_fwd(b, K, ws, wi, wp, wc, _p(soc0), _p(in_enc), _p(pred_enc), _p(scene), _p(X), _s())
+        ctx.dims = (b, K, ws, wi, wp, wc)
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        b, K, ws, wi, wp, wc = ctx.dims
+        dX = dX.contiguous()
+        need = ctx.needs_input_grad
+        mk = lambda n, r, c: torch.empty(r, c, dtype=F32, device=dX.device) if n else None
+        dsoc, din, dpred, dsc = mk(need[0], b, ws), mk(need[1], b, wi), mk(need[2], K * b, wp), mk(need[3], b, wc)
+        lib.mggan_d_assemble_bwd(b, K, ws, wi, wp, wc, _p(dX), _p(dsoc), _p(din), _p(dpred), _p(dsc), _s())
+        return dsoc, din, dpred, dsc, None
+
+
+# ---------------------------------------- losses -------------------------------------------
+def _scaled(grad, g):
+    """grad *= g (g: 0-dim device tensor from autograd) without a host sync."""
+    if g is None:
+        return None
+    g = g.reshape(1).to(F32)
+    lib.mggan_scale(_p(grad), grad.numel(), _p(g), _s())
+    return grad
+
+
+class BceMeanFn(Function):
+    """mean over rows of w_r * BCE(p_r, label)  (abstract_train.py:62-67 'NS'; train.py:92-97 re-weighting)."""
+
+    @staticmethod
+    def forward(ctx, p_rows, label, row_gen, inv_count, out, norm=None):
+        p_rows = p_rows.contiguous()
+        rows = p_rows.numel()
+        loss_rows = _empty(rows, like=p_rows)
+        dp = _empty(rows, like=p_rows)
+        lib.mggan_bce_rows(rows, _p(p_rows), float(label), 1.0 / float(norm or max(rows, 1)), _p(row_gen), _p(inv_count),
+                           _p(loss_rows), _p(dp), _s())
+        lib.mggan_sum(_p(loss_rows), rows, 1.0, _p(out), 0, _s())
+        ctx.dp, ctx.shape = dp, p_rows.shape
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _scaled(ctx.dp, g).view(ctx.shape), None, None, None, None, None
+
+
+class CeMeanFn(Function):
+    """mean over rows of w_r * cross_entropy(logits_r, target_r)  (train.py:105-111,184)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, inv_count, out, norm=None):
+        logits = logits.contiguous()
+        rows, g = logits.shape
+        loss_rows = _empty(rows, like=logits)
+        dl = _empty(rows, g, like=logits)
+        lib.mggan_ce_rows(rows, g, _p(logits), g, _p(target), _p(inv_count), 1.0 / float(norm or max(rows, 1)),
+                          _p(loss_rows), _p(dl), g, _s())
+        lib.mggan_sum(_p(loss_rows), rows, 1.0, _p(out), 0, _s())
+        ctx.dl = dl
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _scaled(ctx.dl, g), None, None, None, None
+
+
+class L2MinSceneFn(Function):
+    """sum_scenes min_k sum_{ped,t} |abs - gt| / b   (train.py:58-75)."""
+
+    @staticmethod
+    def forward(ctx, gen_abs, gt, tb, b_norm, out):
+        gen_abs, gt = gen_abs.contiguous(), gt.contiguous()
+        T, K, b, _ = gen_abs.shape
+        scene_loss = _empty(tb.S, like=gen_abs)
+        scene_arg = torch.empty(tb.S, dtype=torch.int32, device=gen_abs.device)
+        gabs = _empty(T, K, b, 2, like=gen_abs)
+        lib.mggan_l2_min_scene(tb.S, T, K, b, _p(tb.scenes), _p(tb.ped_scene), _p(gen_abs), _p(gt), 1.0 / b_norm,
+                               _p(scene_loss), _p(scene_arg), _p(gabs), _s())
+        lib.mggan_sum(_p(scene_loss), tb.S, 1.0 / b_norm, _p(out), 0, _s())
+        ctx.gabs = gabs
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _scaled(ctx.gabs, g), None, None, None, None
+
+
+class PmMlFn(Function):
+    """PM-network 'ml' objective (train.py:626-639): target = softmax_g(mean_E sum log N(err;0,sigma))."""
+
+    @staticmethod
+    def forward(ctx, logits, gen_abs, gt, sigma, out, probs_out, norm=None):
+        logits, gen_abs, gt = logits.contiguous(), gen_abs.contiguous(), gt.contiguous()
+        T, E, g, b, _ = gen_abs.shape
+        loss_rows = _empty(b, like=logits)
+        dl = _empty(b, g, like=logits)
+        probs = _empty(b, g, like=logits)
+        n = float(norm or b)
+        lib.mggan_pm_ml_loss(b, T, E, g, _p(gen_abs), _p(gt), _p(logits), float(sigma), 1.0 / n, _p(loss_rows), _p(dl),
+                             _p(probs), _s())
+        lib.mggan_sum(_p(loss_rows), b, 1.0, _p(out), 0, _s())
+        if probs_out is not None:
+            lib.mggan_colmean(_p(probs), b, g, float(b) / n, _p(probs_out), _s())
+        ctx.dl = dl
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _scaled(ctx.dl, g), None, None, None, None, None, None

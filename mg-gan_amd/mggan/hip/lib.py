@@ -1,0 +1,95 @@
+"""Loader for libmggan_hip.so.  Argument types are derived from the C header
+(include/mggan_hip.h), which is the single source of truth for the ABI."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmggan_hip.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "..", "include", "mggan_hip.h"))
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _ctype(decl):
+    d = decl.strip()
+    if "*" in d:
+        return ctypes.c_void_p
+    if "mggan_stream_t" in d:
+        return ctypes.c_void_p
+    base = d.rsplit(" ", 1)[0] if " " in d else d
+    base = base.replace("const", "").strip()
+    return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+            "size_t": ctypes.c_size_t, "long long": ctypes.c_longlong}[base]
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes])} for every function declared in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"(const char\*|int|size_t)\s+(mggan_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        res = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}[ret]
+        argtypes = [] if args in ("", "void") else [_ctype(a) for a in args.split(",")]
+        out[name] = (res, argtypes)
+    return out
+
+
+# functions whose int return value is data, not a status code
+_VALUE_RETURNING = {"mggan_version", "mggan_wgrad_splits", "mggan_lstm_prep_size", "mggan_cnn_bwd_grid"}
+
+_lib = None
+
+
+class _Lib:
+    """Attribute access returns a checked wrapper: non-zero status -> HipError."""
+
+    def __init__(self, cdll):
+        self._c = cdll
+        self._w = {}
+        self.decls = parse_header()
+        for name, (res, argtypes) in self.decls.items():
+            fn = getattr(cdll, name)  # AttributeError here == header/library mismatch
+            fn.argtypes = argtypes
+            fn.restype = res
+
+    def __getattr__(self, name):
+        w = self._w.get(name)
+        if w is not None:
+            return w
+        res, _ = self.decls[name]
+        fn = getattr(self._c, name)
+        if res is not ctypes.c_int or name in _VALUE_RETURNING:
+            w = fn
+        else:
+            last_error = self._c.mggan_last_error
+
+            def w(*args, _fn=fn, _name=name):
+                rc = _fn(*args)
+                if rc != 0:
+                    raise HipError("{} failed ({}): {}".format(_name, rc, last_error().decode()))
+
+        self._w[name] = w
+        return w
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(
+                "libmggan_hip.so not found at {} -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C mg-gan_amd/csrc`; there is no CPU fallback".format(LIB_PATH))
+        _lib = _Lib(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+class _LazyLib:
+    def __getattr__(self, name):
+        return getattr(load(), name)
+
+
+lib = _LazyLib()

@@ -1,0 +1,100 @@
+"""MultiDiscriminatorTrajectory with the reference's class surface
+(/root/reference/mggan/model/modules/discriminators.py:12-219), gan_type 'mgan' / 'gan'."""
+import torch
+import torch.nn as nn
+
+from mggan.hip.flat import FlatModule
+from mggan.hip import functions as HF
+from mggan.model.modules.cnn import AttentionGlobal
+from mggan.model.modules.social import SocialAttention
+from mggan.model.modules.common_modules import TrajectoryEncoder
+
+
+class MultiDiscriminatorTrajectory(FlatModule):
+    def __init__(self, num_gens, num_discs, unbound_output, h_dim, inp_format, pred_len, gan_type, global_disc,
+                 scene_dim, pool_type="sgan"):
+        super().__init__()
+        assert inp_format in ("rel", "abs", "abs_rel")
+        assert gan_type in ("probgan", "mgan", "infogan", "gan")
+        if (inp_format != "rel" or gan_type not in ("mgan", "gan") or not global_disc or pool_type != "sways"
+                or unbound_output or num_discs != 1 or scene_dim <= 0):
+            raise ValueError("HIP MultiDiscriminatorTrajectory implements the default hot path: inp_format='rel', "
+                             "gan_type mgan/gan, global_disc, pool_type='sways', NS/MM objective, one discriminator")
+        self.inp_format = inp_format
+        self.unbound_output = unbound_output
+        self.n_ds = num_discs
+        self.gan_type = gan_type
+        self.global_disc = global_disc
+        self.inp_size = 2
+        self.in_encoder = TrajectoryEncoder(hidden_size=h_dim, inp_size=self.inp_size, num_layers=1, embedding_dim=h_dim,
+                                            return_hc=False)
+        self.in_encoder_fc = nn.Sequential(nn.Linear(h_dim, h_dim // 2), nn.LeakyReLU(0.2),
+                                           nn.Linear(h_dim // 2, h_dim // 2))
+        self.pred_encoder = nn.Sequential(nn.Linear(pred_len * self.inp_size, h_dim), nn.LeakyReLU(0.2),
+                                          nn.Linear(h_dim, h_dim // 2))
+        self.social = SocialAttention(h_dim, h_dim)
+        h_dim *= 2
+        self.scene_encoder = AttentionGlobal(noise_attention_dim=0, PhysFeature=True, num_layers=2, channels_cnn=8)
+        h_dim += scene_dim
+        self.discs = nn.ModuleList()
+        for _ in range(num_discs):
+            self.discs.append(nn.Sequential(nn.Linear(h_dim, h_dim // 2), nn.LeakyReLU(0.2), nn.Linear(h_dim // 2, 1),
+                                            nn.Sigmoid()))
+        if gan_type == "mgan":
+            self.gen_id_reconstructor = nn.Sequential(nn.Linear(h_dim, h_dim // 2), nn.LeakyReLU(0.2),
+                                                      nn.Linear(h_dim // 2, num_gens))
+        self.eps = 1e-7
+        self.len_hist = 1.0
+
+    def encode(self, in_xy, in_dxdy, pred_xy, pred_dxdy, mask=None):
+        """(in_enc (b,h/2), pred_enc (K*b_m,h/2)) -> enc (K*b, h) as the reference returns it."""
+        in_enc, pred_enc = self._encode_parts(in_dxdy, pred_dxdy)
+        n_samples = pred_dxdy.shape[1]
+        if mask is not None and not bool(mask.all()):
+            pad = pred_enc.new_zeros(in_dxdy.size(1) * n_samples, pred_enc.size(1))
+            pred_enc = pad.index_copy(0, mask.repeat(n_samples).nonzero().flatten(), pred_enc)
+        return torch.cat([in_enc.repeat(n_samples, 1), pred_enc], dim=1)
+
+    def _encode_parts(self, in_dxdy, pred_dxdy):
+        fc, pe = self.in_encoder_fc, self.pred_encoder
+        h = self.in_encoder(in_dxdy)
+        in_enc = HF.linear(HF.linear(h, fc[0], HF.ACT_LEAKY, 0.2), fc[2])
+        _, n_samples, b, _ = pred_dxdy.shape
+        x = pred_dxdy.permute(1, 2, 0, 3).reshape(n_samples * b, -1)
+        pred_enc = HF.linear(HF.linear(x, pe[0], HF.ACT_LEAKY, 0.2), pe[2])
+        return in_enc, pred_enc
+
+    def forward(self, in_xy, in_dxdy, pred_xy, pred_dxdy, seq_start_end, return_all=False, img=None, mask=None):
+        """Returns output (b_m, K) and, for gan_type 'mgan', branch_out (b_m, K, num_gens)."""
+        if img is None:
+            raise ValueError("img is mandatory: scene_dim=64 is hard-wired into the model (SURVEY A.6)")
+        self.ensure_flat()
+        if pred_xy.dim() == 3:
+            pred_xy, pred_dxdy = pred_xy.unsqueeze(1), pred_dxdy.unsqueeze(1)
+        pred_len, n_samples, b, _ = pred_xy.shape
+        full_b = in_xy.size(1)
+        masked = mask is not None and not bool(mask.all())
+
+        in_enc, pred_enc = self._encode_parts(in_dxdy, pred_dxdy)
+        if not masked:
+            # social features only for sample block 0: `seq_start_end * n_samples` is LIST repetition (A.1)
+            enc0 = torch.cat([in_enc, pred_enc[:full_b]], dim=1)
+            soc0 = self.social(in_xy, in_dxdy, enc0, seq_start_end)
+            scene = self.scene_encoder(img)
+            classifier_inp = HF.DAssembleFn.apply(soc0, in_enc, pred_enc, scene, n_samples)
+        else:
+            enc = self.encode(in_xy, in_dxdy, pred_xy, pred_dxdy, mask)
+            soc = self.social(in_xy.repeat(1, n_samples, 1), in_dxdy.repeat(1, n_samples, 1), enc,
+                              seq_start_end * n_samples)
+            classifier_inp = torch.cat([soc, enc], dim=1)[mask.repeat(n_samples)]
+            scene = self.scene_encoder(img[mask]).repeat(n_samples, 1)
+            classifier_inp = torch.cat([classifier_inp, scene], 1)
+
+        d = self.discs[0]
+        y = HF.linear(HF.linear(classifier_inp, d[0], HF.ACT_LEAKY, 0.2), d[2], HF.ACT_SIGMOID_EPS)
+        output = y.reshape(n_samples, b).t()  # mean over the single discriminator is the identity
+        if self.gan_type == "gan":
+            return output
+        r = self.gen_id_reconstructor
+        branch_out = HF.linear(HF.linear(classifier_inp, r[0], HF.ACT_LEAKY, 0.2), r[2])
+        return output, branch_out.reshape(n_samples, b, -1).transpose(0, 1)

@@ -1,0 +1,47 @@
+"""Social attention (Social-Ways style) with the reference's surface
+(/root/reference/mggan/model/modules/social.py), computed over in-scene pairs
+only by csrc/social.hip."""
+import torch
+from torch import nn
+
+from mggan.hip.flat import FlatModule
+from mggan.hip import functions as HF
+
+
+class AttentionPooling(nn.Module):
+    def __init__(self, h_dim, f_dim):
+        super().__init__()
+        self.f_dim = f_dim
+        self.h_dim = h_dim
+        self.W = nn.Linear(h_dim, f_dim, bias=True)
+
+
+class EmbedSocialFeatures(nn.Module):
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.fc = nn.Sequential(nn.Linear(input_size, 32), nn.ReLU(), nn.Linear(32, 64), nn.ReLU(),
+                                nn.Linear(64, hidden_size))
+
+
+class SocialAttention(FlatModule):
+    def __init__(self, social_feat_size, hidden_size):
+        super().__init__()
+        self.feature_embedder = EmbedSocialFeatures(3, social_feat_size)
+        self.attention = AttentionPooling(hidden_size, social_feat_size)
+
+    def forward(self, in_xy, in_dxdy, enc_h, sub_batches):
+        """in_xy (T,N,2), in_dxdy (T-1,N,2), enc_h (N,h) -> (N,h).  Only rows covered by
+        sub_batches receive features (the discriminator passes a list repeated K times that
+        still indexes the first b rows)."""
+        HF.root_of(self)
+        fc, W = self.feature_embedder.fc, self.attention.W
+        b = max(int(e) for _, e in sub_batches) if len(sub_batches) else 0
+        N = enc_h.shape[0]
+        tb = HF.scene_tables(sub_batches, b, enc_h.device)
+        S = HF.SocialAttentionFn.apply(in_xy[-1, :b], in_dxdy[-1, :b], enc_h[:b], tb, fc[0].weight, fc[0].bias,
+                                       fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, W.weight, W.bias, self)
+        if N > b:
+            S = torch.cat([S, S.new_zeros(N - b, S.shape[1])], 0)
+        return S

@@ -1,0 +1,155 @@
+"""MultiGenerator with the reference's class surface
+(/root/reference/mggan/model/modules/standard.py:17-265): trajectory encoder + scene
+attention + social attention trunk, `num_gens` LSTM decoders, PM-network (`net_chooser`).
+
+MI355X design differences (results identical): instead of running every
+generator for `max occurrence` noise slots and gathering (standard.py:190-214), exactly
+one rollout per selected (pedestrian, sample) is launched, rows bucketed by generator."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from mggan.utils import make_mlp, get_selection_indices
+from mggan.rng import HostRNG
+from mggan.hip.flat import FlatModule
+from mggan.hip import functions as HF
+from mggan.model.modules.cnn import AttentionGlobal
+from mggan.model.modules.social import SocialAttention
+from mggan.model.modules.common_modules import TrajectoryEncoder, RelativeDecoder, get_input, GeneratorOutput
+
+
+class MultiGenerator(FlatModule):
+    def __init__(self, z_size, encoder_h_dim, decoder_h_dim, social_feat_size, num_gens, pred_len, embedding_dim,
+                 inp_format, num_social_modules, pool_type, scene_dim, use_pinet, learn_prior=False):
+        super().__init__()
+        assert inp_format in ("rel", "abs", "abs_rel")
+        assert num_social_modules in (0, 1, num_gens)
+        assert pool_type in ("sways", "sgan")
+        if inp_format != "rel" or pool_type != "sways" or social_feat_size <= 0 or scene_dim <= 0:
+            raise ValueError("HIP MultiGenerator implements the default hot path: inp_format='rel', "
+                             "pool_type='sways', social and scene features enabled")
+        self.use_pinet = use_pinet
+        self.inp_format = inp_format
+        self.z_size = z_size
+        self.embedding_dim = embedding_dim
+        self.social_feat_size = social_feat_size
+        self.n_social_modules = num_social_modules
+        self.pool_type = pool_type
+        self.decoder_h_dim = decoder_h_dim
+        self.encoder_h_dim = encoder_h_dim
+        self.scene_dim = scene_dim
+
+        self.encoder = TrajectoryEncoder(inp_size=2, hidden_size=encoder_h_dim, embedding_dim=embedding_dim,
+                                         num_layers=1)
+        self.scene_encoder = AttentionGlobal(noise_attention_dim=0, PhysFeature=True, num_layers=2, channels_cnn=16)
+        self.social = SocialAttention(social_feat_size, encoder_h_dim)
+
+        self.gs = nn.ModuleList()
+        for i in range(num_gens):
+            decoder = RelativeDecoder(pred_len=pred_len, embedding_dim=embedding_dim, h_dim=decoder_h_dim,
+                                      num_layers=1, social_feat_size=social_feat_size, z_size=z_size, dropout=0.0,
+                                      inp_format=inp_format)
+            setattr(self, "G_{}".format(i), decoder)
+            self.gs.append(decoder)
+
+        self.n_gs = len(self.gs)
+        self.pred_len = pred_len
+        self.enc_h_to_dec_h = make_mlp([encoder_h_dim + z_size + scene_dim + social_feat_size, decoder_h_dim],
+                                       batch_norm=False)
+        assert not (use_pinet and learn_prior), "Using conditional distribution already, `learn_prior` has no effect"
+        self.net_chooser = nn.Sequential(
+            nn.Linear(encoder_h_dim + scene_dim + social_feat_size, encoder_h_dim // 2), nn.ReLU(),
+            nn.Linear(encoder_h_dim // 2, encoder_h_dim // 2), nn.ReLU(),
+            nn.Linear(encoder_h_dim // 2, num_gens))
+        self.net_prior = nn.Parameter(torch.zeros(1, self.n_gs), requires_grad=learn_prior)
+        self.rng = HostRNG()
+
+    # -- helpers ---------------------------------------------------------------------------
+    def generator_parameters(self):
+        return [p for g in self.gs for p in g.parameters()]
+
+    def _gen_stride(self):
+        if self.n_gs == 1:
+            return 0
+        d0, d1 = self.gs[0].param_dict(), self.gs[1].param_dict()
+        strides = {(d1[k].data_ptr() - d0[k].data_ptr()) // 4 for k in d0}
+        assert len(strides) == 1, "per-generator parameter blocks must be laid out with a constant stride"
+        return strides.pop()
+
+    def trunk(self, in_xy, in_dxdy, sub_batches, img):
+        enc = self.encoder(get_input(in_xy, in_dxdy, self.inp_format))
+        scene = self.scene_encoder(img)
+        soc = self.social(in_xy, in_dxdy, enc, sub_batches)
+        return torch.cat([enc, scene, soc], -1), soc
+
+    def _chooser(self, enc_h):
+        nc = self.net_chooser
+        x = HF.linear(enc_h, nc[0], HF.ACT_LEAKY, 0.0)
+        x = HF.linear(x, nc[2], HF.ACT_LEAKY, 0.0)
+        return HF.linear(x, nc[4])
+
+    def _rollout(self, rows, in_xy, in_dxdy, enc_h, social_feats, noise):
+        e2d = self.enc_h_to_dec_h[0]
+        return HF.DecoderRolloutFn.apply(enc_h, social_feats, noise, in_xy[-1], in_dxdy[-1], rows, e2d.weight, e2d.bias,
+                                         self.gs[0].param_dict(), self.n_gs, self._gen_stride(), self.pred_len, self)
+
+    # -- reference surface -------------------------------------------------------------------
+    def forward(self, in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=None, num_samples=5, mask=None):
+        """Returns (GeneratorOutput(rel, abs), net_chooser_out (b_m, g), sampled_gen_idxs (b_m, K) int64).
+        abs/rel: (pred_len, K, b_m, 2) or (pred_len, K, g, b_m, 2) when all_gen_out."""
+        if img is None:
+            raise ValueError("img is mandatory: scene_dim=64 is hard-wired into the model (SURVEY A.6)")
+        self.ensure_flat()
+        batch_size = in_xy.size(1)
+        dev = in_xy.device
+        enc_h, social_feats = self.trunk(in_xy, in_dxdy, sub_batches, img)
+
+        if noise is not None:
+            assert noise.shape == (num_samples, batch_size, self.z_size)
+            noise = noise.to(dev)
+        else:
+            noise = self.rng.noise(num_samples, self.z_size, sub_batches, dev)
+
+        if mask is not None and not bool(mask.all()):
+            in_xy, in_dxdy = in_xy[:, mask], in_dxdy[:, mask]
+            enc_h, social_feats, noise = enc_h[mask], social_feats[mask], noise[:, mask]
+            batch_size = int(mask.sum())
+        b, g, K = batch_size, self.n_gs, num_samples
+        ped = np.tile(np.arange(b), K)
+
+        if all_gen_out:
+            with torch.no_grad():
+                rows = HF.RolloutRows(np.tile(np.repeat(np.arange(g), b), K), np.tile(np.arange(b), K * g),
+                                      np.repeat(np.arange(K), g * b), g, b, dev)
+                pa, pr = self._rollout(rows, in_xy, in_dxdy, enc_h.detach(), social_feats.detach(), noise)
+            net_chooser_out, sampled_gen_idxs = self.get_samples(enc_h, num_samples)
+            shape = (self.pred_len, K, g, b, 2)
+            return GeneratorOutput(pr.view(shape), pa.view(shape)), net_chooser_out, sampled_gen_idxs
+
+        with torch.no_grad():
+            net_chooser_out, sampled_gen_idxs = self.get_samples(enc_h, num_samples)
+        idx_host = sampled_gen_idxs.cpu()
+        offsets = get_selection_indices(idx_host)  # noise slot = occurrence offset, NOT the sample index (A.4)
+        rows = HF.RolloutRows(idx_host.t().reshape(-1).numpy(), ped, offsets.t().reshape(-1).numpy(), g, b, dev)
+        pa, pr = self._rollout(rows, in_xy, in_dxdy, enc_h, social_feats, noise)
+        shape = (self.pred_len, K, b, 2)
+        return GeneratorOutput(pr.view(shape), pa.view(shape)), net_chooser_out, sampled_gen_idxs
+
+    def get_samples(self, enc_h, num_samples=5):
+        """Returns (logits (b, g), generator indexes (b, num_samples))."""
+        if self.use_pinet:
+            net_chooser_out = self._chooser(enc_h)
+        else:
+            net_chooser_out = self.net_prior.expand(enc_h.size(0), -1)
+        sampled = self.rng.sample_generators(net_chooser_out, num_samples).to(enc_h.device)
+        return net_chooser_out, sampled
+
+    def forward_all(self, in_xy, in_dxdy, enc_h, noise, social_feats):
+        """Every generator on every (sample, pedestrian): two tensors (pred_len, n_samples, num_gens, b, 2)."""
+        n, b, _ = noise.shape
+        g = self.n_gs
+        rows = HF.RolloutRows(np.tile(np.repeat(np.arange(g), b), n), np.tile(np.arange(b), n * g),
+                              np.repeat(np.arange(n), g * b), g, b, enc_h.device)
+        pa, pr = self._rollout(rows, in_xy, in_dxdy, enc_h, social_feats, noise)
+        shape = (self.pred_len, n, g, b, 2)
+        return pa.view(shape), pr.view(shape)

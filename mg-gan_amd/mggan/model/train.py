@@ -1,0 +1,248 @@
+"""PiNetMultiGeneratorGAN: the three optimisation steps of MG-GAN with the reference's surface
+(/root/reference/mggan/model/train.py:18-289,578-662) on hand-written HIP kernels.
+
+    python mg-gan_amd/mggan/model/train.py --name test --num_gens 4 --dataset synthetic --epochs 2
+"""
+import os
+import random
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+if __name__ == "__main__":  # allow running the file directly like the reference's README
+    sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+
+import numpy as np
+import torch
+
+from mggan.abstract_train import MultiGeneratorGAN
+from mggan.evaluation import evaluate_ade_fde
+from mggan.hip import functions as HF
+from mggan.hip.lib import lib
+from mggan.logging import Experiment
+from mggan.model.config import get_parser
+from mggan.model.model_factory import construct_model
+from mggan.utils import to_numpy
+
+# slots of the device-side metric buffer (one D2H copy per step instead of one .item() per metric)
+M_REAL, M_FAKE, M_CE_D, M_L2, M_ADV, M_CLF, M_PM, M_PROBS = 0, 1, 2, 3, 4, 5, 6, 8
+
+
+class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
+    def __init__(self, generator, discriminator, config, writer):
+        super().__init__(generator, discriminator, config, writer)
+        assert self.gan_type in ("mgan", "gan"), self.gan_type
+        if config.weighting_target not in ("ml", "none"):
+            raise ValueError("HIP path implements weighting_target 'ml' (default) and 'none'")
+        if config.l2_loss_type not in ("min_g_z", "min_z", "min_g_min_z", "none"):
+            raise ValueError("HIP path implements the per-scene min-over-samples L2 (not 'mse')")
+        dev = self.device
+        self._m = torch.zeros(M_PROBS + 64, dtype=torch.float32, device=dev)
+        self._one = torch.ones((), device=dev)
+        self._w = {k: torch.full((), float(v), device=dev) for k, v in
+                   (("l2", config.l2_loss_weight), ("clf", config.clf_loss_weight), ("pi", config.pi_net_loss_weight))}
+        self.defer_metrics = False  # True: steps only enqueue work; fetch with flush_metrics()
+        self._pending = []
+
+    # ---- metric plumbing ---------------------------------------------------------------
+    def _emit(self, train_metrics, items):
+        """items: list of (key, slot | (slot_a, slot_b) summed)."""
+        snap = self._m.clone()
+        if self.dist.enabled:
+            self.dist.all_reduce_(snap)
+        self._pending.append((train_metrics, items, snap))
+        if not self.defer_metrics:
+            self.flush_metrics()
+
+    def flush_metrics(self):
+        for train_metrics, items, snap in self._pending:
+            v = snap.cpu().numpy()
+            for key, slot in items:
+                train_metrics[key].append(float(v[slot] if isinstance(slot, int) else v[slot[0]] + v[slot[1]]))
+        self._pending = []
+
+    def _global(self, n):
+        return n * self.dist.world_size if self.dist.enabled else n
+
+    def _gen_weights(self, gen_idxs):
+        """Batch-global 1/count(generator) weights (train.py:94-96) + int32 row targets in (k*b+ped) order."""
+        g = self.G.n_gs
+        row_gen = gen_idxs.t().reshape(-1).to(torch.int32)
+        counts = torch.empty(g, dtype=torch.int32, device=self.device)
+        inv = torch.empty(g, dtype=torch.float32, device=self.device)
+        st = torch.cuda.current_stream().cuda_stream
+        lib.mggan_gen_counts(row_gen.data_ptr(), row_gen.numel(), g, counts.data_ptr(), inv.data_ptr(), st)
+        if self.dist.enabled:
+            self.dist.all_reduce_(counts)
+            lib.mggan_inv_counts(counts.data_ptr(), g, inv.data_ptr(), st)
+        return row_gen, inv
+
+    # ---- the three steps -----------------------------------------------------------------
+    def discriminator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None):
+        m = self._m
+        real_result = self.D(in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, img=img, mask=loss_mask)
+        if isinstance(real_result, tuple):
+            real_result = real_result[0]
+        n_real = self._global(real_result.numel())
+        label_real, _ = self.rng.labels()
+        real_loss = HF.BceMeanFn.apply(real_result.t().reshape(-1), label_real, None, None, m[M_REAL:M_REAL + 1], n_real)
+
+        noise = self.rng.noise(1, self.config.noise_dim, sub_batches, self.device)
+        with torch.no_grad():
+            gen_out, _, gen_labels_gt = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
+                                               num_samples=1, mask=loss_mask)
+        disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask)
+        losses = [real_loss]
+        items = []
+        if self.gan_type == "mgan":
+            disc_out, branch_out = disc_out
+            rows = branch_out.transpose(0, 1).reshape(-1, branch_out.shape[-1])
+            target = gen_labels_gt.t().reshape(-1).to(torch.int32)
+            ce_loss = HF.CeMeanFn.apply(rows, target, None, m[M_CE_D:M_CE_D + 1], self._global(rows.shape[0]))
+            losses.append(ce_loss)
+            items.append(("train/info_mgan_disc_loss", M_CE_D))
+        _, label_fake = self.rng.labels()
+        fake_loss = HF.BceMeanFn.apply(disc_out.t().reshape(-1), label_fake, None, None, m[M_FAKE:M_FAKE + 1],
+                                       self._global(disc_out.numel()))
+        losses.append(fake_loss)
+        items.append(("train/discr_loss", (M_FAKE, M_REAL)))
+
+        self.optimizerD.zero_grad()
+        torch.autograd.backward(losses, [self._one] * len(losses))
+        self.dist.all_reduce_grads(self.D)
+        self.optimizerD.step(self.config.clipping_threshold_d)
+        self._emit(train_metrics, items)
+
+    def generator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None):
+        m, cfg = self._m, self.config
+        b = in_xy.size(1)
+        noise = self.rng.noise(cfg.num_samples, cfg.noise_dim, sub_batches, self.device)
+        gen_out, _, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
+                                      mask=loss_mask, num_samples=cfg.num_samples)
+        losses, grads, items = [], [], []
+        if cfg.l2_loss_type != "none":
+            tb = HF.scene_tables(sub_batches, gen_out.abs.shape[2], self.device)
+            min_l2 = HF.L2MinSceneFn.apply(gen_out.abs, gt_xy, tb, self._global(b), m[M_L2:M_L2 + 1])
+            losses.append(min_l2)
+            grads.append(self._w["l2"])
+            items.append(("train/L2_loss", M_L2))
+
+        # adversarial pass: D's weights get no gradient here (the reference discards them: D.zero_grad()
+        # precedes backward and the next discriminator step zeroes them again, train.py:128,207)
+        d_params = list(self.D.parameters())
+        flags = [p.requires_grad for p in d_params]
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask)
+        finally:
+            for p, f in zip(d_params, flags):
+                p.requires_grad_(f)
+        branch_out = None
+        if isinstance(disc_out, tuple):
+            disc_out, branch_out = disc_out
+        label_real, _ = self.rng.labels()
+        row_gen, inv_count = self._gen_weights(gen_idxs)
+        n_rows = self._global(disc_out.numel())
+        adv_loss = HF.BceMeanFn.apply(disc_out.t().reshape(-1), label_real, row_gen, inv_count, m[M_ADV:M_ADV + 1],
+                                      n_rows)
+        losses.append(adv_loss)
+        grads.append(self._one)
+        items.append(("train/gen_loss", M_ADV))
+        if self.gan_type == "mgan":
+            rows = branch_out.transpose(0, 1).reshape(-1, branch_out.shape[-1])
+            clf = HF.CeMeanFn.apply(rows, row_gen, inv_count, m[M_CLF:M_CLF + 1], n_rows)
+            losses.append(clf)
+            grads.append(self._w["clf"])
+            items.append(("train/info_mgan_loss", M_CLF))
+
+        self.optimizerG.zero_grad()
+        torch.autograd.backward(losses, grads)
+        self.dist.all_reduce_grads(self.G)
+        self.optimizerG.step(cfg.clipping_threshold_g)
+        self._emit(train_metrics, items)
+
+    def net_chooser_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, metrics, mask, img):
+        cfg = self.config
+        if cfg.weighting_target == "none":
+            return
+        m, g = self._m, self.G.n_gs
+        gen_out, net_chooser_weights, _ = self.G(in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=img,
+                                                 num_samples=cfg.num_expectation_samples, mask=mask)
+        loss = HF.PmMlFn.apply(net_chooser_weights, gen_out.abs, gt_xy, cfg.sigma, m[M_PM:M_PM + 1],
+                               m[M_PROBS:M_PROBS + g], self._global(net_chooser_weights.shape[0]))
+        self.optimizerG.zero_grad()
+        torch.autograd.backward([loss], [self._w["pi"]])
+        self.dist.all_reduce_grads(self.G)
+        self.optimizerG.step(0.0)
+        items = [("probs/Gen {} probability".format(i), M_PROBS + i) for i in range(g)]
+        self._emit(metrics, items + [("train/net_chooser_loss", M_PM)])
+
+    # ---- prediction / evaluation -----------------------------------------------------------
+    def predict(self, in_dxdy, in_xy, sub_batches, img=None, num=20, noise=None, mask=None):
+        """-> (abs (pred_len,num,b,2), rel, probs (b,g) numpy, gen_idxs (b,num) numpy)   (train.py:259-289)."""
+        self.G.eval()
+        with torch.no_grad():
+            preds, net_chooser_out, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False,
+                                                      img=img, num_samples=num, mask=mask)
+            probs = torch.softmax(net_chooser_out, 1)
+        assert preds.abs.shape[1] == num
+        return preds.abs, preds.rel, to_numpy(probs), to_numpy(gen_idxs)
+
+    def get_predict_func(self, strategy):
+        if strategy != "sampling":
+            raise NotImplementedError("only the 'sampling' strategy (predict) is on the hot path (SURVEY f1)")
+        return self.predict
+
+    def get_predictions(self, loader, num_preds=20, strategy="sampling"):
+        self.D.eval()
+        self.G.eval()
+        pred_func = self.get_predict_func(strategy)
+        all_preds = []
+        for batch in loader:
+            batch = self.to_device(batch)
+            in_xy, in_dxdy = batch["in_xy"], batch["in_dxdy"]
+            b = in_dxdy.size(1)
+            sub_batches = batch["seq_start_end"] if "seq_start_end" in batch else list(zip(range(b), range(1, b + 1)))
+            preds, _, _, _ = pred_func(in_dxdy, in_xy, sub_batches, img=batch.get("features"), num=num_preds)
+            all_preds.append(to_numpy(preds))
+        return np.concatenate(all_preds, 2)
+
+    def check_accuracy(self, loader, vis=False, prefix="", num_k=20, predict_strategy="sampling", debug=False, **kw):
+        preds = self.get_predictions(loader, num_preds=num_k, strategy=predict_strategy)
+        gts, sse, off = [], [], 0
+        for batch in loader:
+            gts.append(batch["gt_xy"].permute(1, 0, 2))
+            sse += [(s + off, e + off) for s, e in batch["seq_start_end"]]
+            off += batch["gt_xy"].shape[1]
+
+        class _DS:
+            pred_traj = torch.cat(gts, 0)
+            seq_start_end = sse
+
+        return evaluate_ade_fde(_DS, preds, [num_k])
+
+    @staticmethod
+    def construct_model(config):
+        return construct_model(config)
+
+
+if __name__ == "__main__":
+    args = get_parser().parse_args()
+    if args.checkpoint:
+        output_dir = Path(args.checkpoint)
+        assert output_dir.is_dir()
+        model, config = PiNetMultiGeneratorGAN.load_from_path(output_dir)
+        config.gpus = True
+        config.val_every = 1
+    else:
+        output_dir = Path(args.log_dir) / args.experiment
+        output_dir.mkdir(exist_ok=True, parents=True)
+        print(str(output_dir.resolve()))
+        logger = Experiment(output_dir.resolve(), name=args.name, debug=args.debug,
+                            version=random.randint(10 ** 10, (10 ** 11) - 1))
+        G, D = construct_model(config=args)
+        logger.argparse(args)
+        model = PiNetMultiGeneratorGAN(G, D, args, logger)
+        logger.save()
+    model.train()

@@ -1,0 +1,78 @@
+"""Fused clip_grad_norm_ + AdamW over a root module's flat parameter buffer
+(reference: torch.optim.AdamW(lr, betas=(beta1, 0.999)) + nn.utils.clip_grad_norm_,
+/root/reference/mggan/abstract_train.py:45-50, model/train.py:131-135,209-213,656-658)
+and the per-epoch cosine schedule (abstract_train.py:52-57,199-200)."""
+import math
+
+import torch
+
+from mggan.hip.lib import lib
+
+
+class FlatAdamW:
+    def __init__(self, root, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.root = root.ensure_flat()
+        self.base_lr = self.lr = lr
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        f = root._flat
+        self.exp_avg = torch.zeros_like(f)
+        self.exp_avg_sq = torch.zeros_like(f)
+        self.nseg = len(root._flat_items)
+        self.seg_step = torch.zeros(self.nseg, dtype=torch.int32, device=f.device)
+        self._ws = torch.zeros(256, dtype=torch.float64, device=f.device)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=f.device)
+        self._flat_id = f.data_ptr()
+
+    def zero_grad(self):
+        self.root.zero_grad_flat()
+
+    def step(self, max_norm=0.0):
+        """Clip the gradients of the touched parameters to `max_norm` (0 = no clipping), then AdamW-update them.
+        Parameters that received no gradient since zero_grad() are skipped, like `p.grad is None` in torch."""
+        r = self.root
+        if r._flat.data_ptr() != self._flat_id:
+            raise RuntimeError("the module's flat parameter buffer was rebuilt after the optimizer was created")
+        mask = r.touched_mask()
+        st = torch.cuda.current_stream().cuda_stream
+        lib.mggan_clip_adamw(r._flat.data_ptr(), r._flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                             self.exp_avg_sq.data_ptr(), r._flat.numel(), r._elem_seg.data_ptr(), self.nseg,
+                             mask.data_ptr(), self.seg_step.data_ptr(), float(max_norm), float(self.lr),
+                             float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                             self._ws.data_ptr(), self.grad_norm.data_ptr(), st)
+
+    # torch.optim-compatible checkpoint surface (abstract_train.py:235-244 saves optimizer state_dicts)
+    def state_dict(self):
+        state = {}
+        steps = self.seg_step.cpu()
+        for i, (p, o) in enumerate(self.root._flat_items):
+            if int(steps[i]) == 0:
+                continue
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(steps[i])), "exp_avg": self.exp_avg[o:o + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "params": list(range(self.nseg))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        steps = torch.zeros(self.nseg, dtype=torch.int32)
+        for i, st in sd["state"].items():
+            p, o = self.root._flat_items[int(i)]
+            n = p.numel()
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps[int(i)] = int(st["step"])
+        self.seg_step.copy_(steps)
+        self.lr = sd["param_groups"][0]["lr"]
+
+
+class CosineAnnealingLR:
+    """torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max, eta_min=0), stepped once per epoch."""
+
+    def __init__(self, optimizer, T_max, eta_min=0.0):
+        self.opt, self.T_max, self.eta_min, self.epoch = optimizer, T_max, eta_min, 0
+
+    def step(self):
+        self.epoch += 1
+        base = self.opt.base_lr
+        self.opt.lr = self.eta_min + (base - self.eta_min) * (1 + math.cos(math.pi * self.epoch / self.T_max)) / 2

@@ -1,0 +1,90 @@
+"""Scene-sharded data parallelism for the training steps: one process per GPU,
+`torch.distributed` (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in CPU tests).
+
+The per-scene work is independent (social attention, min-over-K L2 and noise are per scene),
+so each rank takes a contiguous range of scenes; weights and optimizer state are replicated.
+What couples the ranks:
+  C1  parameter gradients    -> ONE all-reduce(sum) of the flat gradient buffer per optimizer step
+  C2  BatchNorm statistics   -> all-reduce of the f64 per-channel sums (forward and backward)
+  C3  batch-global counters  -> generator-id counts and loss normalisers
+All messages are <= 360 KB: latency-bound, so they are kept to one collective each.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_scenes(seq_start_end, rank, world_size):
+    """Contiguous scene range for `rank`, balanced by pedestrian count.
+    Returns (scene_slice, ped_start, ped_end, local_seq_start_end)."""
+    sse = [(int(s), int(e)) for s, e in seq_start_end]
+    total = sum(e - s for s, e in sse)
+    bounds, acc, nxt = [0], 0, 1
+    for i, (s, e) in enumerate(sse):
+        acc += e - s
+        while nxt < world_size and acc >= total * nxt / world_size:
+            bounds.append(i + 1)
+            nxt += 1
+    while len(bounds) < world_size:
+        bounds.append(len(sse))
+    bounds.append(len(sse))
+    lo, hi = bounds[rank], max(bounds[rank], bounds[rank + 1])
+    if lo >= hi:
+        return slice(lo, lo), 0, 0, []
+    p0, p1 = sse[lo][0], sse[hi - 1][1]
+    return slice(lo, hi), p0, p1, [[s - p0, e - p0] for s, e in sse[lo:hi]]
+
+
+def shard_batch(batch, rank, world_size):
+    """Slice a collated batch (reference schema, trajectories_scene.py:68-78) to this rank's scenes."""
+    _, p0, p1, local = shard_scenes(batch["seq_start_end"], rank, world_size)
+    out = {"seq_start_end": local}
+    for k in ("in_xy", "in_dxdy", "gt_xy", "gt_dxdy"):
+        out[k] = batch[k][:, p0:p1].contiguous()
+    out["features"] = batch["features"][p0:p1].contiguous()
+    return out
+
+
+class DistContext:
+    """Collective hooks used by the modules / trainer.  world_size == 1 -> every hook is the identity."""
+
+    def __init__(self, group=None):
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.world_size = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+
+    def all_reduce_(self, t):
+        if self.enabled:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_reduce_stats(self, sums, n_local):
+        """BatchNorm: sums (2C,) f64 and the local image count -> global sums in place, global count returned."""
+        if not self.enabled:
+            return n_local
+        buf = torch.cat([sums, sums.new_tensor([float(n_local)])])
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        sums.copy_(buf[:-1])
+        return float(buf[-1].item())
+
+    def global_count(self, n_local):
+        if not self.enabled:
+            return n_local
+        t = torch.tensor([float(n_local)], dtype=torch.float64, device=self._dev)
+        dist.all_reduce(t, group=self.group)
+        return float(t.item())
+
+    _dev = "cpu"
+
+    def all_reduce_grads(self, root):
+        """C1: one collective over the whole flat gradient buffer."""
+        if self.enabled:
+            dist.all_reduce(root._flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def attach(self, *roots):
+        for r in roots:
+            for m in r.modules():
+                if hasattr(m, "sync") and m.__class__.__name__ == "AttentionGlobal":
+                    m.sync = self if self.enabled else None
+            if r._flat is not None:
+                self._dev = r._flat.device

@@ -1,0 +1,80 @@
+"""Sources of randomness for the training steps.
+
+HostRNG   -- the reference's draw order on the HOST generators (torch CPU global generator +
+             numpy global), SURVEY App. B.  Seed-comparable with the reference; needs the
+             PM-network logits on the host for Categorical sampling (one small D2H per G call).
+DeviceRNG -- same distributions drawn on the GPU (torch.cuda generator) with no host sync;
+             statistically equivalent, not seed-identical.  Used by bench.py (`--rng device`).
+ReplayRNG -- replays recorded draws (golden fixtures / parity tests).
+"""
+import numpy as np
+import torch
+
+from mggan.utils import get_gan_label_scalars, get_global_noise
+
+
+class HostRNG:
+    on_device = False
+
+    def labels(self):
+        return get_gan_label_scalars()
+
+    def noise(self, num_samples, dim, sub_batches, device):
+        return torch.stack([get_global_noise(dim, sub_batches, "gaussian") for _ in range(num_samples)]).to(device)
+
+    def sample_generators(self, logits, num_samples):
+        """Categorical(logits=...).sample((K,)).T on the CPU generator (standard.py:223-224)."""
+        lg = logits.detach().float().cpu()
+        probs = torch.softmax(lg - lg.logsumexp(-1, keepdim=True), -1)
+        return torch.multinomial(probs, num_samples, True)
+
+
+class DeviceRNG:
+    on_device = True
+
+    def __init__(self, seed=0):
+        self.seed = seed
+        self._gen = None
+        self._np = np.random.RandomState(seed)
+
+    def _g(self, device):
+        if self._gen is None:
+            self._gen = torch.Generator(device=device)
+            self._gen.manual_seed(self.seed)
+        return self._gen
+
+    def labels(self):
+        fake = self._np.uniform(0, 0.1)
+        real = self._np.uniform(0.9, 1.0)
+        return float(real), float(fake)
+
+    def noise(self, num_samples, dim, sub_batches, device):
+        lens = torch.tensor([int(e) - int(s) for s, e in sub_batches], device=device)
+        per_scene = torch.randn(num_samples, len(sub_batches), dim, device=device, generator=self._g(device))
+        return per_scene.repeat_interleave(lens, dim=1)
+
+    def sample_generators(self, logits, num_samples):
+        probs = torch.softmax(logits.detach().float(), -1)
+        return torch.multinomial(probs, num_samples, True, generator=self._g(logits.device))
+
+
+class ReplayRNG:
+    """Feeds recorded draws in call order: labels -> list of (real,fake); noise / gen_idxs -> lists."""
+    on_device = False
+
+    def __init__(self, labels=(), noise=(), gen_idxs=()):
+        self._labels, self._noise, self._idx = list(labels), list(noise), list(gen_idxs)
+
+    def labels(self):
+        r, f = self._labels.pop(0)
+        return float(r), float(f)
+
+    def noise(self, num_samples, dim, sub_batches, device):
+        n = self._noise.pop(0)
+        assert n.shape[0] == num_samples and n.shape[-1] == dim, (n.shape, num_samples, dim)
+        return n.to(device)
+
+    def sample_generators(self, logits, num_samples):
+        idx = self._idx.pop(0)
+        assert idx.shape[1] == num_samples
+        return idx

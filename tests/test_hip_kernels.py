@@ -1,0 +1,137 @@
+"""GPU: C-ABI primitives (generic GEMM family, reductions, optimizer) against plain torch math."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda")
+
+
+def _lib():
+    from mggan.hip import lib
+    return lib
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("rows,K,N,act", [(7, 3, 32, 1), (300, 136, 32, 0), (1000, 192, 96, 1), (65, 96, 1, 3),
+                                          (129, 16, 4, 0), (64, 24, 64, 2)])
+def test_linear_fwd_bwd_wgrad(rows, K, N, act):
+    lib, dev = _lib(), _dev()
+    g = torch.Generator().manual_seed(rows + K)
+    ldx = K + 5
+    Xf = torch.randn(rows, ldx, generator=g)
+    W, bias = torch.randn(N, K, generator=g) * 0.3, torch.randn(N, generator=g)
+    X = Xf[:, :K]
+    slope = 0.2
+    pre = X.double() @ W.double().t() + bias.double()
+    ref = {0: pre, 1: torch.where(pre > 0, pre, pre * slope), 2: torch.sigmoid(pre),
+           3: torch.sigmoid(pre) * (1 - 2e-7) + 1e-7}[act]
+    Xd, Wd, bd = Xf.to(dev), W.to(dev), bias.to(dev)
+    Y = torch.empty(rows, N, device=dev)
+    lib.mggan_linear_fwd(Xd.data_ptr(), ldx, Wd.data_ptr(), bd.data_ptr(), Y.data_ptr(), N, rows, K, N, act, slope, st())
+    np.testing.assert_allclose(Y.cpu().numpy(), ref.float().numpy(), rtol=2e-5, atol=2e-5)
+    dY = torch.randn(rows, N, generator=g)
+    yr = ref.float()
+    dact = {0: torch.ones_like(yr), 1: torch.where(yr > 0, 1.0, slope), 2: yr * (1 - yr), 3: yr * (1 - yr)}[act]
+    dZ_ref = dY * dact
+    dZ = torch.empty(rows, N, device=dev)
+    lib.mggan_act_bwd(dY.to(dev).data_ptr(), N, Y.data_ptr(), N, dZ.data_ptr(), N, rows, N, act, slope, st())
+    np.testing.assert_allclose(dZ.cpu().numpy(), dZ_ref.numpy(), rtol=1e-4, atol=1e-6)
+    dX = torch.full((rows, K), 1.0, device=dev)
+    lib.mggan_linear_bwd_data(dZ.data_ptr(), N, Wd.data_ptr(), K, dX.data_ptr(), K, rows, K, N, 1, st())
+    np.testing.assert_allclose(dX.cpu().numpy(), (dZ_ref.double() @ W.double()).float().numpy() + 1.0, rtol=1e-4,
+                               atol=1e-4)
+    dW = torch.full((N, K), 0.5, device=dev)
+    db = torch.zeros(N, device=dev)
+    nb = lib.mggan_wgrad_workspace_bytes(rows, K, N, 0)
+    ws = torch.empty(nb // 4, device=dev)
+    lib.mggan_wgrad(dZ.data_ptr(), N, Xd.data_ptr(), ldx, dW.data_ptr(), K, db.data_ptr(), rows, K, N, 0, 1, 0, 0, 0,
+                    ws.data_ptr(), nb, st())
+    dW_ref = dZ_ref.double().t() @ X.double()
+    np.testing.assert_allclose(dW.cpu().numpy(), dW_ref.float().numpy() + 0.5, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), dZ_ref.double().sum(0).float().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_wgrad_grouped_segments():
+    lib, dev = _lib(), _dev()
+    g = torch.Generator().manual_seed(3)
+    T, K, N, ng = 12, 32, 128, 4
+    seg = torch.tensor([0, 5, 5, 40, 97], dtype=torch.int32)  # one empty group
+    R = int(seg[-1])
+    dZ, X = torch.randn(R * T, N, generator=g), torch.randn(R * T, K, generator=g)
+    stride = N * K + 64
+    dW = torch.zeros(ng * stride, device=dev)
+    db = torch.zeros(ng * stride, device=dev)
+    nb = lib.mggan_wgrad_workspace_bytes(R * T, K, N, ng)
+    ws = torch.empty(nb // 4, device=dev)
+    lib.mggan_wgrad(dZ.to(dev).data_ptr(), N, X.to(dev).data_ptr(), K, dW.data_ptr(), K, db.data_ptr(), R * T, K, N,
+                    seg.to(dev).data_ptr(), T, ng, stride, stride, ws.data_ptr(), nb, st())
+    for gi in range(ng):
+        a, b = int(seg[gi]) * T, int(seg[gi + 1]) * T
+        ref = dZ[a:b].double().t() @ X[a:b].double()
+        np.testing.assert_allclose(dW[gi * stride:gi * stride + N * K].view(N, K).cpu().numpy(), ref.float().numpy(),
+                                   rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(db[gi * stride:gi * stride + N].cpu().numpy(), dZ[a:b].double().sum(0).float().numpy(),
+                                   rtol=1e-4, atol=2e-4)
+
+
+def test_gather_sum_and_transpose():
+    lib, dev = _lib(), _dev()
+    g = torch.Generator().manual_seed(5)
+    b, K, C = 13, 6, 40
+    src = torch.randn(K * b, C, generator=g)
+    inv = torch.randperm(K * b, generator=g).to(torch.int32)
+    dst = torch.zeros(b, C, device=dev)
+    lib.mggan_gather_sum(src.to(dev).data_ptr(), C, inv.to(dev).data_ptr(), dst.data_ptr(), C, b, K, C, 0, st())
+    ref = src[inv.long()].view(K, b, C).sum(0)
+    np.testing.assert_allclose(dst.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    W = torch.randn(32, 136, generator=g)
+    WT = torch.empty(136, 32, device=dev)
+    lib.mggan_transpose(W.to(dev).data_ptr(), WT.data_ptr(), 32, 136, st())
+    assert torch.equal(WT.cpu(), W.t().contiguous())
+
+
+def test_clip_adamw_matches_torch_and_skips_untouched():
+    """Fused clip+AdamW vs torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW over 3 steps; a parameter
+    without gradient is left bit-identical."""
+    from mggan.hip.flat import FlatModule
+    from mggan.optim import FlatAdamW
+
+    dev = _dev()
+
+    class M(FlatModule):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(7, 5)
+            self.b = torch.nn.Linear(5, 3)
+            self.c = torch.nn.Parameter(torch.randn(11))
+
+    torch.manual_seed(0)
+    m = M().to(dev).flatten_parameters_()
+    ref = M()
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    opt = FlatAdamW(m, lr=1e-2, betas=(0.5, 0.999))
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, betas=(0.5, 0.999))
+    g = torch.Generator().manual_seed(1)
+    for it in range(3):
+        opt.zero_grad()
+        ropt.zero_grad()
+        for (n, p), (_, rp) in zip(m.named_parameters(), ref.named_parameters()):
+            if n == "c" and it != 1:
+                continue  # untouched in steps 0 and 2
+            gr = torch.randn(p.shape, generator=g) * (50.0 if it == 0 else 0.1)
+            ptr = m.grad_ptr(p)
+            p.grad.copy_(gr.to(dev))
+            rp.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 10.0)
+        ropt.step()
+        opt.step(10.0)
+        for (n, p), (_, rp) in zip(m.named_parameters(), ref.named_parameters()):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), rp.detach().numpy(), rtol=2e-5, atol=1e-6, err_msg=n)

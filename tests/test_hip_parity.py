@@ -1,0 +1,205 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, behind the reference's class surface)
+against the golden vectors produced by the real reference and against the CPU oracle.
+Tolerances: SURVEY A.12 (outputs/losses rtol 1e-3; gradients and post-step weights relL2 1e-3)."""
+import copy
+from collections import defaultdict
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, assert_grad_close, batch_from, check_param_grads, rel_l2, sd_from
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build(golden, which="0"):
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+
+    g = int(golden["meta/num_gens"])
+    cfg = get_parser().parse_args(["--num_gens", str(g)])
+    G, D = construct_model(cfg)
+    G.load_state_dict(sd_from(golden, "G" + which), strict=True)
+    D.load_state_dict(sd_from(golden, "D" + which), strict=True)
+    G, D = G.to(DEV).flatten_parameters_(), D.to(DEV).flatten_parameters_()
+    G.train()
+    D.train()
+    return G, D, cfg
+
+
+def T(golden, k):
+    return torch.from_numpy(golden[k].copy()).to(DEV)
+
+
+def test_extension_is_loaded():
+    from mggan.hip import lib, LIB_PATH
+    import os
+
+    assert os.path.exists(LIB_PATH)
+    assert lib.mggan_version() >= 100
+
+
+def test_encoders(golden):
+    G, D, _ = build(golden)
+    bt = batch_from(golden, DEV)
+    for name, enc in (("u_genc", G.encoder), ("u_denc", D.in_encoder)):
+        y = enc(bt["in_dxdy"])
+        assert_close(y, golden[name + "/out"], what=name)
+        (y * T(golden, name + "/cot")).sum().backward()
+        check_param_grads(golden, name + "/grad", enc)
+
+
+def test_scene_attention(golden):
+    G, D, _ = build(golden)
+    bt = batch_from(golden, DEV)
+    for name, mod in (("u_gscene", G.scene_encoder), ("u_dscene", D.scene_encoder)):
+        y = mod(bt["features"])
+        assert_close(y, golden[name + "/out"], what=name)
+        (y * T(golden, name + "/cot")).sum().backward()
+        check_param_grads(golden, name + "/grad", mod)
+        for k, v in mod.state_dict().items():
+            assert_close(v, golden["{}/after/{}".format(name, k)], what=name + k)
+        mod.eval()
+        with torch.no_grad():
+            assert_close(mod(bt["features"]), golden[name + "/out_eval"], what=name + " eval")
+
+
+def test_social_attention(golden):
+    G, D, _ = build(golden)
+    bt = batch_from(golden, DEV)
+    for name, mod in (("u_gsoc", G.social), ("u_dsoc", D.social)):
+        h = T(golden, name + "/h").requires_grad_()
+        y = mod(bt["in_xy"], bt["in_dxdy"], h, bt["seq_start_end"])
+        assert_close(y, golden[name + "/out"], what=name)
+        (y * T(golden, name + "/cot")).sum().backward()
+        assert_grad_close(h.grad, golden[name + "/grad_h"], name + " dh")
+        check_param_grads(golden, name + "/grad", mod)
+
+
+def test_decoder_rollout(golden):
+    G, _, _ = build(golden)
+    bt = batch_from(golden, DEV)
+    dec = G.gs[G.n_gs - 1]
+    h0 = T(golden, "u_dec/h0").requires_grad_()
+    soc = T(golden, "u_dec/soc").requires_grad_()
+    pa, pr = dec(bt["in_xy"][-1].repeat(2, 1), bt["in_dxdy"][-1].repeat(2, 1), None, soc,
+                 (h0.unsqueeze(0), torch.zeros_like(h0).unsqueeze(0)))
+    assert_close(pa, golden["u_dec/abs"], what="abs")
+    assert_close(pr, golden["u_dec/rel"], what="rel")
+    ((pa * T(golden, "u_dec/cot_abs")).sum() + (pr * T(golden, "u_dec/cot_rel")).sum()).backward()
+    assert_grad_close(h0.grad, golden["u_dec/grad_h0"], "dh0")
+    assert_grad_close(soc.grad, golden["u_dec/grad_soc"], "dsoc")
+    check_param_grads(golden, "u_dec/grad", dec)
+
+
+def test_discriminator_forward_backward(golden):
+    _, D, _ = build(golden)
+    bt = batch_from(golden, DEV)
+    pdx = T(golden, "u_D/pred_dxdy").requires_grad_()
+    mask = torch.ones(bt["in_xy"].shape[1], dtype=torch.bool, device=DEV)
+    o, br = D(bt["in_xy"], bt["in_dxdy"], T(golden, "u_D/pred_xy"), pdx, bt["seq_start_end"], img=bt["features"],
+              mask=mask)
+    assert_close(o, golden["u_D/out"], what="out")
+    assert_close(br, golden["u_D/branch"], what="branch")
+    ((o * T(golden, "u_D/cot_out")).sum() + (br * T(golden, "u_D/cot_branch")).sum()).backward()
+    assert_grad_close(pdx.grad, golden["u_D/grad_pred_dxdy"], "dpred")
+    check_param_grads(golden, "u_D/grad", D)
+
+
+def test_generator_forward_backward(golden):
+    from mggan.rng import ReplayRNG
+
+    G, _, _ = build(golden)
+    bt = batch_from(golden, DEV)
+    idx = torch.from_numpy(golden["u_G/gen_idxs"].copy())
+    K = idx.shape[1]
+    G.rng = ReplayRNG(gen_idxs=[idx])
+    go, logits, gi = G(bt["in_xy"], bt["in_dxdy"], bt["seq_start_end"], noise=T(golden, "u_G/noise"), all_gen_out=False,
+                       img=bt["features"], num_samples=K)
+    assert_close(logits, golden["u_G/logits"], what="logits")
+    assert_close(go.abs, golden["u_G/abs"], what="abs")
+    assert_close(go.rel, golden["u_G/rel"], what="rel")
+    ((go.abs * T(golden, "u_G/cot_abs")).sum() + (go.rel * T(golden, "u_G/cot_rel")).sum()).backward()
+    check_param_grads(golden, "u_G/grad", G)
+
+    G, _, _ = build(golden)
+    E = golden["u_Gall/noise"].shape[0]
+    G.rng = ReplayRNG(gen_idxs=[torch.zeros(bt["in_xy"].shape[1], E, dtype=torch.long)])
+    go, logits, _ = G(bt["in_xy"], bt["in_dxdy"], bt["seq_start_end"], noise=T(golden, "u_Gall/noise"),
+                      all_gen_out=True, img=bt["features"], num_samples=E)
+    assert_close(go.abs, golden["u_Gall/abs"], what="abs all")
+    assert_close(go.rel, golden["u_Gall/rel"], what="rel all")
+    assert_close(logits, golden["u_Gall/logits"], what="logits all")
+    (logits * T(golden, "u_Gall/cot_logits")).sum().backward()
+    check_param_grads(golden, "u_Gall/grad", G)
+
+
+def make_trainer(golden, which="0"):
+    from mggan.logging import Experiment
+    from mggan.model.train import PiNetMultiGeneratorGAN
+
+    G, D, cfg = build(golden, which)
+    tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+    return tr
+
+
+def replay_for(golden, p, step):
+    from mggan.rng import ReplayRNG
+
+    lab = golden.get(p + "/labels")
+    labels = [] if lab is None else [tuple(r) for r in lab]
+    return ReplayRNG(labels=labels, noise=[torch.from_numpy(golden[p + "/noise"].copy())],
+                     gen_idxs=[torch.from_numpy(golden[p + "/gen_idxs"].copy())])
+
+
+def test_three_training_iterations(golden):
+    """D/G/PM steps with the recorded draws against the real reference: every logged loss (rtol 1e-3),
+    every parameter gradient of iteration 1 (relL2 1e-3), parameters after iterations 1 and 3 (relL2 1e-3),
+    BatchNorm num_batches_tracked exactly."""
+    tr = make_trainer(golden)
+    bt = batch_from(golden, DEV)
+    mask = torch.ones(bt["in_xy"].shape[1], dtype=torch.bool, device=DEV)
+    args = (bt["in_xy"], bt["in_dxdy"], bt["gt_xy"], bt["gt_dxdy"], bt["seq_start_end"])
+    for it in range(1, 4):
+        for step, fn, mod in (("d", tr.discriminator_step, tr.D), ("g", tr.generator_step, tr.G),
+                              ("pm", tr.net_chooser_step, tr.G)):
+            p = "s{}_{}".format(it, step)
+            tr.rng = tr.G.rng = replay_for(golden, p, step)
+            m = defaultdict(list)
+            fn(*args, m, mask, bt["features"])
+            for k, v in m.items():
+                ref = float(golden[p + "/metric/" + k])
+                assert abs(v[0] - ref) <= 1e-3 * abs(ref) + 1e-6, (p, k, v[0], ref)
+            assert len(m) == sum(1 for k in golden if k.startswith(p + "/metric/")), (p, sorted(m))
+            if it == 1:
+                touched = {n: q.grad for n, q in mod.named_parameters() if id(q) in mod._touched}
+                check_param_grads(golden, p + "/grad", mod, grads=touched)
+        if it in (1, 3):
+            for mod, pre in ((tr.G, "G"), (tr.D, "D")):
+                ref = sd_from(golden, pre + str(it))
+                sd = {k: v.cpu() for k, v in mod.state_dict().items()}
+                fl = [k for k in ref if ref[k].is_floating_point()]
+                a = torch.cat([sd[k].flatten().double() for k in fl]).numpy()
+                r = torch.cat([ref[k].flatten().double() for k in fl]).numpy()
+                assert rel_l2(a, r) <= 1e-3, (pre, it, rel_l2(a, r))
+                for k in ref:
+                    if not ref[k].is_floating_point():
+                        assert int(sd[k]) == int(ref[k]), k
+
+
+def test_predict_and_ade_fde(golden):
+    from mggan.metrics import compute_metrics_from_batch
+    from mggan.rng import ReplayRNG
+
+    tr = make_trainer(golden, "3")
+    bt = batch_from(golden, DEV)
+    tr.rng = tr.G.rng = ReplayRNG(gen_idxs=[torch.from_numpy(golden["e/gen_idxs"].copy())])
+    pa, pr, probs, gidx = tr.predict(bt["in_dxdy"], bt["in_xy"], bt["seq_start_end"], img=bt["features"], num=20,
+                                     noise=T(golden, "e/noise"))
+    assert_close(pa, golden["e/abs"], what="predict")
+    np.testing.assert_allclose(probs, golden["e/probs"], rtol=1e-3, atol=1e-5)
+    m = compute_metrics_from_batch(pa.cpu(), bt["gt_xy"].cpu(), bt["seq_start_end"], mode="raw")
+    for k in ("ADE", "FDE", "Mode"):
+        np.testing.assert_allclose(m[k], golden["e/" + k], rtol=1e-3)
