@@ -503,13 +503,14 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(int B, const float* __re
   if (wci == 0) wp[PAIRS * 9 + wco] = bacc;
 }
 
-// dst[o] += sum_z P[z][o]
-__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ P, int nP, int len, float* dst) {
+// dst[o] += sum_z P[z*stride + o], o < len
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ P, int nP, int stride, int len,
+                                                          float* dst) {
   __shared__ float red[4][64];
   const int o = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
   float s = 0.f;
   if (o < len)
-    for (int z = zl; z < nP; z += 4) s += P[(size_t)z * len + o];
+    for (int z = zl; z < nP; z += 4) s += P[(size_t)z * stride + o];
   red[zl][threadIdx.x & 63] = s;
   __syncthreads();
   if (zl == 0 && o < len)
@@ -631,9 +632,10 @@ int mggan_conv2_bwd(const float* y1, int B, int C, const float* scale1, const fl
     hipLaunchKernelGGL((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, y1, scale1, shift1, stat1, y2, G2,
                        stat2, coef2, W, G1c, code1, part1, workspace);
   MG_LAUNCH_CHECK("conv2_bwd");
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(256), 0, stream, workspace, grid * NQ, wlen, dW);
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(256), 0, stream, workspace, grid * NQ, wlen,
+                     C * C * 9, dW);
   hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, stream, workspace + C * C * 9, grid * NQ, wlen,
-                     db);
+                     C, db);
   MG_LAUNCH_CHECK("conv2_bwd reduce");
   return MGGAN_OK;
 }
@@ -670,9 +672,10 @@ int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float
                        workspace);
   }
   MG_LAUNCH_CHECK("conv1_bwd");
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(4 * C * 9, 64)), dim3(256), 0, stream, workspace, grid * NQ, wlen, dW);
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(4 * C * 9, 64)), dim3(256), 0, stream, workspace, grid * NQ, wlen,
+                     4 * C * 9, dW);
   hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, stream, workspace + 4 * C * 9, grid * NQ, wlen,
-                     db);
+                     C, db);
   MG_LAUNCH_CHECK("conv1_bwd reduce");
   return MGGAN_OK;
 }

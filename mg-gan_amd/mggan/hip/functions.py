@@ -36,8 +36,9 @@ def _rows2d(t):
     return t, (t.stride(0) if t.shape[0] > 1 else t.shape[1])
 
 
-def _want(*params):
-    return torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params)
+def want_grad(*tensors):
+    """Evaluated at the call site (autograd.Function.forward always runs with grad mode off)."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scale=1, n_groups=0, w_stride=0,
@@ -99,7 +100,7 @@ class LstmEncoderFn(Function):
     """Linear(2,E) + nn.LSTM over T steps -> h_T   (common_modules.py:48-66)."""
 
     @staticmethod
-    def forward(ctx, x, emb_w, emb_b, w_ih, w_hh, b_ih, b_hh, owner):
+    def forward(ctx, x, emb_w, emb_b, w_ih, w_hh, b_ih, b_hh, owner, save):
         T, b, _ = x.shape
         H, E = w_hh.shape[1], emb_w.shape[0]
         x = x.contiguous()
@@ -107,7 +108,6 @@ class LstmEncoderFn(Function):
         prep = _empty(psz, like=x)
         lib.mggan_lstm_fold(_p(emb_w), _p(emb_b), _p(w_ih), _p(b_ih), _p(b_hh), _p(w_hh), 0, 0, 0, 0, 0, 1, H, E, 0, 0,
                             _p(prep), psz, _s())
-        save = _want(emb_w, w_ih, w_hh)
         Gt = _empty(b, T, 4 * H, like=x) if save else None
         Cs = _empty(b, T, H, like=x) if save else None
         Hp = _empty(b, T, H, like=x) if save else None
@@ -134,7 +134,7 @@ class LstmEncoderFn(Function):
         lib.mggan_lstm_unfold_grads(_p(emb_w), _p(emb_b), _p(w_ih), root.grad_ptr(emb_w), root.grad_ptr(emb_b),
                                     root.grad_ptr(w_ih), root.grad_ptr(b_ih), root.grad_ptr(b_hh), 0, 1, H, E,
                                     _p(dprep), 12 * H, _s())
-        return (None,) * 8
+        return (None,) * 9
 
 
 # ------------------------------------------------------------------------------------------
@@ -189,7 +189,7 @@ class SocialAttentionFn(Function):
     """SocialFeatures -> EmbedSocialFeatures -> AttentionPooling over in-scene pairs (social.py:7-123)."""
 
     @staticmethod
-    def forward(ctx, xy_last, dxdy_last, h, tb, w1, b1, w2, b2, w3, b3, wat, bat, owner):
+    def forward(ctx, xy_last, dxdy_last, h, tb, w1, b1, w2, b2, w3, b3, wat, bat, owner, save):
         h, ld_h = _rows2d(h)
         b, Hh = h.shape
         Fd = wat.shape[0]
@@ -201,7 +201,6 @@ class SocialAttentionFn(Function):
         lib.mggan_social_w3b(_p(w3), _p(b3), _p(W3b), Fd, st)
         vc = _empty(b, 65, like=h)
         lib.mggan_linear_bwd_data(_p(Wh), Fd, _p(W3b), 65, _p(vc), 65, b, 65, Fd, 0, st)
-        save = _want(h, w1, wat)
         P = tb.P
         sigma = _empty(max(P, 1), like=h)
         feat = _empty(max(P, 1), 3, like=h) if save else None
@@ -247,7 +246,7 @@ class SocialAttentionFn(Function):
             wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, 65, root.grad_ptr(b3), 1, 0, b, 1, Fd)
             wgrad(dWh, Fd, h, ld_h, root.grad_ptr(wat), Hh, root.grad_ptr(bat), b, Hh, Fd)
         lib.mggan_linear_bwd_data(_p(dWh), Fd, _p(wat), Hh, _p(dh), Hh, b, Hh, Fd, 1, st)
-        return (None, None, dh if ctx.needs_input_grad[2] else None) + (None,) * 10
+        return (None, None, dh if ctx.needs_input_grad[2] else None) + (None,) * 11
 
 
 # ------------------------------------------------------------------------------------------
@@ -255,7 +254,7 @@ class SceneAttentionFn(Function):
     """CNN (2 x Conv-BN-ReLU-MaxPool) + channel-softmax attention -> (B,64)  (cnn.py:109-282)."""
 
     @staticmethod
-    def forward(ctx, img, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb, bb, bn1, bn2, training, owner, sync):
+    def forward(ctx, img, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb, bb, bn1, bn2, training, owner, sync, save):
         img = img.contiguous()
         B, C = img.shape[0], c1w.shape[0]
         st = _s()
@@ -284,7 +283,7 @@ class SceneAttentionFn(Function):
         sc2, sh2, stat2, cnt2 = finalize(bn2, g2, be2, 16 * 16)
         out = _empty(B, 64, like=img)
         lib.mggan_scene_attention_fwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(wa), _p(ba), _p(wb), _p(bb), _p(out), 64, st)
-        if _want(c1w, wa):
+        if save:
             if not training:
                 raise RuntimeError("scene attention backward is only implemented for train-mode BatchNorm "
                                    "(the reference never differentiates in eval mode)")
@@ -337,7 +336,7 @@ class SceneAttentionFn(Function):
         ws = torch.empty(nb // 4, dtype=F32, device=img.device)
         lib.mggan_conv1_bwd(_p(img), B, C, _p(y1), _p(stat1), _p(coef1), _p(G1c), _p(code1), root.grad_ptr(c1w),
                             root.grad_ptr(c1b), _p(ws), nb, st)
-        return (None,) * 18
+        return (None,) * 19
 
 
 # ------------------------------------------------------------------------------------------
@@ -367,7 +366,8 @@ class DecoderRolloutFn(Function):
     (standard.py:227-265, common_modules.py:97-131)."""
 
     @staticmethod
-    def forward(ctx, enc_h, soc, noise, xy0, dxdy0, rows, e2d_w, e2d_b, g0, n_gens, stride, T, owner):
+    def forward(ctx, enc_h, soc, noise, xy0, dxdy0, rows, e2d_w, e2d_b, anchor, g0, n_gens, stride, T, owner, save):
+        # `anchor` (= the first generator's W_hh) makes the per-generator weights visible to autograd
         enc_h, ld_enc = _rows2d(enc_h)
         soc, ld_soc = _rows2d(soc)
         noise, xy0, dxdy0 = noise.contiguous(), xy0.contiguous(), dxdy0.contiguous()
@@ -385,7 +385,6 @@ class DecoderRolloutFn(Function):
                             S, 1, _p(prep), psz, st)
         e2dT = _empty(EIN + Z, H, like=enc_h)
         lib.mggan_transpose(_p(e2d_w), _p(e2dT), H, EIN + Z, st)
-        save = _want(enc_h, soc, e2d_w, g0["w_hh"])
         mk = (lambda *s: _empty(*s, like=enc_h)) if save else (lambda *s: None)
         Gt, Cs, Hp, Hc = mk(R, T, 4 * H), mk(R, T, H), mk(R, T, H), mk(R, T, H)
         Din, Aact, E2Din, SocR = mk(R, T, 2), mk(R, T, H // 2), mk(R, EIN + Z), mk(R, S)
@@ -418,13 +417,14 @@ class DecoderRolloutFn(Function):
         if g0["w_hh"].requires_grad:
             gp = root.grad_ptr
             seg, ng = rows.seg, n_gens
+            # attach (and zero on first touch) every generator's gradient slots BEFORE any kernel writes into
+            # them: all decoders are in the graph, a generator without rows gets a zero gradient
+            for p in owner.generator_parameters():
+                gp(p)
             wgrad(dPre, 4 * H, Hp, H, gp(g0["w_hh"]), H, 0, R * T, H, 4 * H, seg, T, ng, stride, stride)
             dprep = torch.zeros(n_gens, 12 * H, dtype=F32, device=dev)
             wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, R * T, 2, 4 * H, seg, T, ng,
                   12 * H, 12 * H)
-            # touch every gradient slot of every generator so that p.grad is attached (zero if no rows)
-            for p in owner.generator_parameters():
-                gp(p)
             lib.mggan_lstm_unfold_grads(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), gp(g0["emb_w"]),
                                         gp(g0["emb_b"]), gp(g0["w_ih"]), gp(g0["b_ih"]), gp(g0["b_hh"]), stride, ng, H,
                                         E, _p(dprep), 12 * H, st)
@@ -440,7 +440,7 @@ class DecoderRolloutFn(Function):
         if ctx.needs_input_grad[1]:
             d_soc = mk(b, S)
             lib.mggan_gather_sum(_p(dSocR), S, _p(rows.inv), _p(d_soc), S, b, rows.K, S, 0, st)
-        return (d_enc, d_soc) + (None,) * 11
+        return (d_enc, d_soc) + (None,) * 13
 
 
 # ------------------------------------------------------------------------------------------

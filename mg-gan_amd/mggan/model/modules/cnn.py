@@ -117,4 +117,4 @@ class AttentionGlobal(FlatModule):
         return HF.SceneAttentionFn.apply(features, b1.Conv_1.weight, b1.Conv_1.bias, b1.BN_1.weight, b1.BN_1.bias,
                                          b2.Conv_1.weight, b2.Conv_1.bias, b2.BN_1.weight, b2.BN_1.bias, a[0].weight,
                                          a[0].bias, a[2].weight, a[2].bias, b1.BN_1, b2.BN_1, self.training, self,
-                                         self.sync)
+                                         self.sync, HF.want_grad(a[0].weight))

@@ -44,7 +44,7 @@ class TrajectoryEncoder(FlatModule):
         L = self.encoder
         HF.root_of(self)
         return HF.LstmEncoderFn.apply(inp, self.embedding.weight, self.embedding.bias, L.weight_ih_l0, L.weight_hh_l0,
-                                      L.bias_ih_l0, L.bias_hh_l0, self)
+                                      L.bias_ih_l0, L.bias_hh_l0, self, HF.want_grad(L.weight_hh_l0))
 
 
 class RelativeDecoder(FlatModule):
@@ -82,5 +82,6 @@ class RelativeDecoder(FlatModule):
         ar = torch.arange(R)
         rows = HF.RolloutRows(torch.zeros(R, dtype=torch.long), ar, torch.zeros(R, dtype=torch.long), 1, R, dev)
         noise0 = torch.zeros(1, R, 0, device=dev)
-        return HF.DecoderRolloutFn.apply(h0, social_feats, noise0, xy, dxdy, rows, eye, zb, self.param_dict(), 1, 0,
-                                         self.pred_len, self)
+        save = HF.want_grad(h0, social_feats, self.decoder.weight_hh_l0)
+        return HF.DecoderRolloutFn.apply(h0, social_feats, noise0, xy, dxdy, rows, eye, zb, self.decoder.weight_hh_l0,
+                                         self.param_dict(), 1, 0, self.pred_len, self, save)

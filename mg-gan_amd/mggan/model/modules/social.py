@@ -41,7 +41,8 @@ class SocialAttention(FlatModule):
         N = enc_h.shape[0]
         tb = HF.scene_tables(sub_batches, b, enc_h.device)
         S = HF.SocialAttentionFn.apply(in_xy[-1, :b], in_dxdy[-1, :b], enc_h[:b], tb, fc[0].weight, fc[0].bias,
-                                       fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, W.weight, W.bias, self)
+                                       fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, W.weight, W.bias, self,
+                                       HF.want_grad(enc_h, W.weight))
         if N > b:
             S = torch.cat([S, S.new_zeros(N - b, S.shape[1])], 0)
         return S

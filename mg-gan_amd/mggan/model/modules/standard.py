@@ -90,8 +90,10 @@ class MultiGenerator(FlatModule):
 
     def _rollout(self, rows, in_xy, in_dxdy, enc_h, social_feats, noise):
         e2d = self.enc_h_to_dec_h[0]
+        w_hh = self.gs[0].decoder.weight_hh_l0
         return HF.DecoderRolloutFn.apply(enc_h, social_feats, noise, in_xy[-1], in_dxdy[-1], rows, e2d.weight, e2d.bias,
-                                         self.gs[0].param_dict(), self.n_gs, self._gen_stride(), self.pred_len, self)
+                                         w_hh, self.gs[0].param_dict(), self.n_gs, self._gen_stride(), self.pred_len,
+                                         self, HF.want_grad(enc_h, social_feats, w_hh))
 
     # -- reference surface -------------------------------------------------------------------
     def forward(self, in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=None, num_samples=5, mask=None):

@@ -42,7 +42,8 @@ def test_linear_fwd_bwd_wgrad(rows, K, N, act):
     dact = {0: torch.ones_like(yr), 1: torch.where(yr > 0, 1.0, slope), 2: yr * (1 - yr), 3: yr * (1 - yr)}[act]
     dZ_ref = dY * dact
     dZ = torch.empty(rows, N, device=dev)
-    lib.mggan_act_bwd(dY.to(dev).data_ptr(), N, Y.data_ptr(), N, dZ.data_ptr(), N, rows, N, act, slope, st())
+    dYd = dY.to(dev)
+    lib.mggan_act_bwd(dYd.data_ptr(), N, Y.data_ptr(), N, dZ.data_ptr(), N, rows, N, act, slope, st())
     np.testing.assert_allclose(dZ.cpu().numpy(), dZ_ref.numpy(), rtol=1e-4, atol=1e-6)
     dX = torch.full((rows, K), 1.0, device=dev)
     lib.mggan_linear_bwd_data(dZ.data_ptr(), N, Wd.data_ptr(), K, dX.data_ptr(), K, rows, K, N, 1, st())
@@ -71,8 +72,9 @@ def test_wgrad_grouped_segments():
     db = torch.zeros(ng * stride, device=dev)
     nb = lib.mggan_wgrad_workspace_bytes(R * T, K, N, ng)
     ws = torch.empty(nb // 4, device=dev)
-    lib.mggan_wgrad(dZ.to(dev).data_ptr(), N, X.to(dev).data_ptr(), K, dW.data_ptr(), K, db.data_ptr(), R * T, K, N,
-                    seg.to(dev).data_ptr(), T, ng, stride, stride, ws.data_ptr(), nb, st())
+    dZd, Xd, segd = dZ.to(dev), X.to(dev), seg.to(dev)
+    lib.mggan_wgrad(dZd.data_ptr(), N, Xd.data_ptr(), K, dW.data_ptr(), K, db.data_ptr(), R * T, K, N,
+                    segd.data_ptr(), T, ng, stride, stride, ws.data_ptr(), nb, st())
     for gi in range(ng):
         a, b = int(seg[gi]) * T, int(seg[gi + 1]) * T
         ref = dZ[a:b].double().t() @ X[a:b].double()
@@ -89,12 +91,14 @@ def test_gather_sum_and_transpose():
     src = torch.randn(K * b, C, generator=g)
     inv = torch.randperm(K * b, generator=g).to(torch.int32)
     dst = torch.zeros(b, C, device=dev)
-    lib.mggan_gather_sum(src.to(dev).data_ptr(), C, inv.to(dev).data_ptr(), dst.data_ptr(), C, b, K, C, 0, st())
+    srcd, invd = src.to(dev), inv.to(dev)
+    lib.mggan_gather_sum(srcd.data_ptr(), C, invd.data_ptr(), dst.data_ptr(), C, b, K, C, 0, st())
     ref = src[inv.long()].view(K, b, C).sum(0)
     np.testing.assert_allclose(dst.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
     W = torch.randn(32, 136, generator=g)
     WT = torch.empty(136, 32, device=dev)
-    lib.mggan_transpose(W.to(dev).data_ptr(), WT.data_ptr(), 32, 136, st())
+    Wd = W.to(dev)
+    lib.mggan_transpose(Wd.data_ptr(), WT.data_ptr(), 32, 136, st())
     assert torch.equal(WT.cpu(), W.t().contiguous())
 
 
