@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- MG-GAN train-step trajectories/sec on MI355X (BASELINE.json metric).
+
+One "step" = one full iteration of the reference loop body (abstract_train.py:114-168):
+discriminator step + generator step + PM-network step, each with forward, backward, gradient
+clipping and an AdamW update, on a synthetic batch already resident in HBM.
+Workload at N=1: BASELINE.json configs[1] -- 64 scenes x 20 pedestrians, num_gens=4, K=20 samples.
+N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns 64 scenes of a
+N*64-scene global batch (weak scaling); gradients / BatchNorm statistics / generator counts are
+all-reduced over RCCL.  value = N * b_local * steps / max-over-ranks(time).
+
+Prints ONE JSON line (rank 0) with `roofline` for the dominant C-ABI entry (timed live with HIP
+events on the launch stream) and `cpu_baseline` (the CPU oracle, block-diagonal mode, timed on
+this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mg-gan_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+F32_PEAK_TFLOPS = 157.3  # MI355X dense f32 (vector == f32-MFMA rate), MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_of(name, a):
+    """Algorithmic FLOPs (2*MAC, reference operator shapes) of one C-ABI call."""
+    if name == "mggan_linear_fwd":
+        return 2.0 * a[6] * a[7] * a[8]
+    if name == "mggan_linear_bwd_data":
+        return 2.0 * a[6] * a[7] * a[8]
+    if name == "mggan_wgrad":
+        return 2.0 * a[7] * a[8] * a[9]
+    if name == "mggan_lstm_encoder_fwd":
+        T, b, H = a[1], a[2], a[3]
+        E = H // 2 if H == 32 else H
+        return float(T) * b * (2 * 2 * E + 2 * (E + H) * 4 * H)
+    if name == "mggan_lstm_encoder_bwd":
+        T, b, H = a[2], a[3], a[4]
+        return float(T) * b * 2 * (4 * H * H)
+    if name == "mggan_decoder_rollout_fwd":
+        R, T, H, EIN, Z = a[0], a[1], a[3], a[4], a[5]
+        return float(R) * (2 * (EIN + Z) * H + T * (2 * 2 * 16 + 2 * (16 + H) * 4 * H + 2 * (2 * H * (H // 2) + (H // 2) * 2)))
+    if name == "mggan_decoder_rollout_bwd":
+        R, T, H, EIN = a[0], a[1], a[2], a[3]
+        return float(R) * (T * 2 * (4 * H * H + 2 * 4 * H + H * (H // 2) + (H // 2) * 2) + 2 * (EIN * H + H * (H // 2)))
+    if name == "mggan_conv1_fwd":
+        return float(a[1]) * 2 * 33 * 33 * a[2] * 36
+    if name == "mggan_conv2_fwd":
+        return float(a[1]) * 2 * 256 * a[2] * a[2] * 9
+    if name == "mggan_conv2_bwd":
+        return float(a[1]) * 2 * 2 * 256 * a[2] * a[2] * 9
+    if name == "mggan_conv1_bwd":
+        return float(a[1]) * 2 * 33 * 33 * a[2] * 36
+    if name == "mggan_scene_attention_fwd":
+        return float(a[1]) * 64 * 2 * (a[2] * 32 * 2)
+    if name == "mggan_scene_attention_bwd":
+        return float(a[1]) * 64 * 2 * (a[2] * 32 * 2) * 3
+    if name == "mggan_social_pairs_fwd":
+        return float(a[0]) * 2 * (96 + 2048 + 64)
+    if name == "mggan_social_pairs_bwd":
+        return float(a[0]) * 2 * (64 + 2048)
+    return 0.0
+
+
+def build_trainer(num_gens, rng, device):
+    from mggan.logging import Experiment
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.model.train import PiNetMultiGeneratorGAN
+
+    cfg = get_parser().parse_args(["--num_gens", str(num_gens), "--rng", rng, "--epochs", "500"])
+    torch.manual_seed(145325)
+    np.random.seed(435346)
+    import io
+    import contextlib
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        G, D = construct_model(cfg)
+    tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+    tr.G.train()
+    tr.D.train()
+    return tr
+
+
+def cpu_baseline(sizes, num_gens, iters):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mggan_oracle as O
+    from mggan.data_utils import synthetic
+
+    threads = torch.get_num_threads()
+    torch.manual_seed(145325)
+    np.random.seed(435346)
+    G, D = O.construct_oracle(num_gens)
+    tr = O.OracleTrainer(G, D, mode="block")
+    batch = synthetic.make_batch(sizes, seed=0)
+    m = defaultdict(list)
+    tr.iteration(batch, m)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        tr.iteration(batch, m)
+    dt = (time.perf_counter() - t0) / iters
+    b = batch["in_xy"].shape[1]
+    return {"value": b / dt, "unit": "trajectories/s", "cores": threads, "kind": "port",
+            "sample": "{} full iterations (D+G+PM steps) of the same {}-scene x {}-ped, num_gens={} workload on the CPU "
+                      "oracle (oracle/mggan_oracle.py, block-diagonal mode, torch CPU {} threads, nproc={}); "
+                      "{:.2f} s/iteration".format(iters, len(sizes), sizes[0], num_gens, threads, os.cpu_count(), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scenes", type=int, default=64)
+    ap.add_argument("--peds", type=int, default=20)
+    ap.add_argument("--num_gens", type=int, default=4)
+    ap.add_argument("--rng", choices=["host", "device"], default="device")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from mggan.data_utils import synthetic
+    from mggan.hip import lib as hiplib_mod  # noqa: F401
+    from mggan.hip.lib import start_trace, stop_trace
+
+    tr = build_trainer(args.num_gens, args.rng, dev)
+    sizes = synthetic.scene_sizes(args.scenes, args.peds)
+    batch = tr.to_device(synthetic.make_batch(sizes, seed=rank))
+    b = batch["in_xy"].shape[1]
+    batch["loss_mask"] = torch.ones(b, dtype=torch.bool, device=dev)
+    tr.defer_metrics = True
+    metrics = defaultdict(list)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_iteration(batch, metrics)
+    tr.flush_metrics()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train_iteration(batch, metrics)
+    tr.flush_metrics()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- live per-entry timing (HIP events on the launch stream) for the roofline block ----
+    start_trace()
+    n_prof = 3
+    for _ in range(n_prof):
+        tr.train_iteration(batch, metrics)
+    tr.flush_metrics()
+    trace = stop_trace()
+    rows = []
+    for name, (calls, ms, arglist) in trace.items():
+        fl = sum(flops_of(name, a) for a in arglist)
+        rows.append((ms / n_prof, name, calls // n_prof, fl / n_prof))
+    rows.sort(reverse=True)
+    gpu_ms = sum(r[0] for r in rows)
+    top = rows[0]
+    per_launch_flops = top[3] / max(top[2], 1)
+    per_launch_s = top[0] / max(top[2], 1) * 1e-3
+    achieved = per_launch_flops / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
+    total_flops = sum(r[3] for r in rows)
+    roofline = {"bound": "mfma", "kernel": top[1], "achieved": round(achieved, 3), "peak": F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / F32_PEAK_TFLOPS, 5), "traffic": None,
+                "launches_per_step": top[2], "avg_launch_ms": round(per_launch_s * 1e3, 4),
+                "note": "f32 (exact) -- peak is the dense f32 vector/MFMA rate; achieved = algorithmic FLOPs "
+                        "(SURVEY App. D shapes) / HIP-event time of this C-ABI entry"}
+    breakdown = [{"entry": n, "ms_per_step": round(ms, 4), "calls": c, "gflop": round(fl / 1e9, 3)}
+                 for ms, n, c, fl in rows[:12]]
+
+    if rank == 0:
+        out = {
+            "metric": "train-step trajectories/sec", "value": round(world * b * args.steps / dt, 2),
+            "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "{} scenes x {} peds per GPU, num_gens={}, num_samples=20, D+G+PM steps "
+                                   "(BASELINE configs[1])".format(args.scenes, args.peds, args.num_gens),
+                       "b_per_gpu": b, "parallelism": "dp{}".format(world), "rng": args.rng,
+                       "last_losses": {k: round(v[-1], 6) for k, v in sorted(metrics.items()) if "probs" not in k}},
+            "roofline": roofline,
+            "iteration_flops_algorithmic_g": round(total_flops / 1e9, 2),
+            "iteration_tflops": round(total_flops / (dt / args.steps) / 1e12, 3),
+            "gpu_ms_per_step_sum_of_entries": round(gpu_ms, 3),
+            "breakdown": breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sizes, args.num_gens, args.cpu_iters)
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

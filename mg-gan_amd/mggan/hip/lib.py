@@ -50,6 +50,7 @@ class _Lib:
     def __init__(self, cdll):
         self._c = cdll
         self._w = {}
+        self.trace = None  # list of (name, args, start_event, end_event) while profiling is on
         self.decls = parse_header()
         for name, (res, argtypes) in self.decls.items():
             fn = getattr(cdll, name)  # AttributeError here == header/library mismatch
@@ -60,6 +61,8 @@ class _Lib:
         w = self._w.get(name)
         if w is not None:
             return w
+        if name not in self.decls:
+            raise AttributeError(name)
         res, _ = self.decls[name]
         fn = getattr(self._c, name)
         if res is not ctypes.c_int or name in _VALUE_RETURNING:
@@ -68,7 +71,16 @@ class _Lib:
             last_error = self._c.mggan_last_error
 
             def w(*args, _fn=fn, _name=name):
+                tr = self.trace
+                if tr is not None:
+                    import torch
+
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 rc = _fn(*args)
+                if tr is not None:
+                    e1.record()
+                    tr.append((_name, args, e0, e1))
                 if rc != 0:
                     raise HipError("{} failed ({}): {}".format(_name, rc, last_error().decode()))
 
@@ -89,7 +101,29 @@ def load():
 
 class _LazyLib:
     def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
         return getattr(load(), name)
+
+
+def start_trace():
+    """Bracket every C-ABI call with HIP events on the current stream (all launches go to torch's current
+    stream, so torch.cuda.Event sees them)."""
+    load().trace = []
+
+
+def stop_trace():
+    """-> {entry: (calls, total_ms, [args...])}"""
+    import torch
+
+    l = load()
+    tr, l.trace = l.trace, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, args, e0, e1 in tr or []:
+        c, t, a = out.get(name, (0, 0.0, []))
+        out[name] = (c + 1, t + e0.elapsed_time(e1), a + [args])
+    return out
 
 
 lib = _LazyLib()
