@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 --kernel-trace result (rocpd sqlite .db) into a per-kernel table:
+    python tools/rocprof_summary.py gpurun_out/prof_x/x_results.db > profiles/rNN_x_kernel_stats.txt
+"""
+import sqlite3
+import sys
+
+
+def main(path, top=60):
+    c = sqlite3.connect(path)
+    tot, n = c.execute("select sum(end-start)/1e3, count(*) from rocpd_kernel_dispatch").fetchone()
+    print("# rocprofv3 --kernel-trace summary of {}".format(path))
+    print("# total kernel time {:.1f} us over {} dispatches".format(tot, n))
+    print("# {:<88s} {:>7s} {:>11s} {:>9s} {:>8s} {:>9s} {:>6s}".format("kernel", "calls", "total_us", "avg_us", "min_us",
+                                                                         "max_us", "pct"))
+    q = ("select s.kernel_name, count(*), sum(d.end-d.start)/1e3, avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3, "
+         "max(d.end-d.start)/1e3 from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+         "group by s.kernel_name order by 3 desc limit {}".format(top))
+    for r in c.execute(q):
+        print("  {:<88s} {:>7d} {:>11.1f} {:>9.2f} {:>8.2f} {:>9.2f} {:>5.1f}%".format(r[0][:88], r[1], r[2], r[3], r[4],
+                                                                                       r[5], 100 * r[2] / tot))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 60)
