@@ -95,7 +95,8 @@ def cpu_baseline(sizes, num_gens, iters):
     import mggan_oracle as O
     from mggan.data_utils import synthetic
 
-    threads = torch.get_num_threads()
+    threads = min(16, os.cpu_count() or 1)  # more threads are slower for these small operators
+    torch.set_num_threads(threads)
     torch.manual_seed(145325)
     np.random.seed(435346)
     G, D = O.construct_oracle(num_gens)
@@ -138,6 +139,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # host-side bookkeeping is a handful of tiny torch CPU ops: a large OpenMP team only adds fork/join latency
+    torch.set_num_threads(min(4, os.cpu_count() or 1))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

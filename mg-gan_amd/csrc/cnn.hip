@@ -347,10 +347,10 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
   const int ty = pg >> 2, x0 = (pg & 3) * 4;
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    __syncthreads();
+    lds_barrier();
     {
       const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
-#pragma unroll 2
+#pragma unroll 8
       for (int c = 0; c < C; ++c) {
         int code; float raw;
         const float* base = y1 + (((size_t)b * C + c) * IH + 2 * py) * IH + 2 * px;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
         dyp[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (G2[gi] - coef2[C + c] - xh * coef2[2 * C + c]);
       }
     }
-    __syncthreads();
+    lds_barrier();
     // (1) weight gradient: dW[co][ci][ky][kx] += sum_{y,x} dy[co][y][x] * a1p[ci][y+ky][x+kx]
     for (int y = rq * ROWS; y < (rq + 1) * ROWS; ++y) {
       float dy[16];
@@ -441,80 +441,119 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
 }
 
 // ---------------- conv1 backward: BN1 bwd + weight grad (the image needs no gradient) ----------------
+// Channels are processed 8 at a time so that a workgroup needs 60 KB of LDS (two workgroups per CU);
+// the dy1 tile is built cell-wise (one lane per pooled cell, loads of several channels in flight).
 template <int C>
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(int B, const float* __restrict__ img,
                                                         const float* __restrict__ y1, const float* __restrict__ stat1,
                                                         const float* __restrict__ coef1, const float* __restrict__ G1c,
                                                         const unsigned char* __restrict__ code1, float* wpart) {
-  constexpr int PAIRS = C * 4, NQ = 256 / PAIRS, RPQ = (IH + NQ - 1) / NQ, DLD = 36, WLEN = PAIRS * 9 + C;
+  constexpr int CH = 8, NP = C / CH, PAIRS = CH * 4, NQ = 256 / PAIRS, RPQ = (IH + NQ - 1) / NQ, DLD = 36;
+  constexpr int WLEN = C * 4 * 9 + C;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* imgp = smem;                  // 4*IMG_PLANE
-  float* dy1 = smem + 4 * IMG_PLANE;   // C*33*36
-  for (int i = threadIdx.x; i < C * IH * DLD; i += 256) dy1[i] = 0.f;
+  float* dy1 = smem + 4 * IMG_PLANE;   // CH*33*36
+  for (int i = threadIdx.x; i < CH * IH * DLD; i += 256) dy1[i] = 0.f;
   const int pair = threadIdx.x % PAIRS, rq = threadIdx.x / PAIRS;
-  const int wco = pair / 4, wci = pair % 4;
-  float wacc[9], bacc = 0.f;
+  const int lco = pair / 4, wci = pair % 4;
+  float wacc[NP][9], bacc[NP];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) wacc[k] = 0.f;
+  for (int q = 0; q < NP; ++q) {
+    bacc[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wacc[q][k] = 0.f;
+  }
+  const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    __syncthreads();
+    lds_barrier();
     stage_image(img + (size_t)b * 4 * IPIX, imgp);
-    for (int idx = threadIdx.x; idx < C * IPIX; idx += 256) {
-      const int c = idx / IPIX, rem = idx % IPIX, y = rem / IH, x = rem % IH;
-      const float xh = (y1[(size_t)b * C * IPIX + idx] - stat1[c]) * stat1[C + c];
-      float g = 0.f;
-      if (y < 32 && x < 32) {
-        const size_t pi = (((size_t)b * C + c) * 16 + (y >> 1)) * 16 + (x >> 1);
-        if (code1[pi] == ((y & 1) * 2 + (x & 1))) g = G1c[pi];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      if (q > 0) lds_barrier();
+      // interior 32x32: one lane per pooled cell
+#pragma unroll 4
+      for (int lc = 0; lc < CH; ++lc) {
+        const int c = q * CH + lc;
+        const size_t pi = ((size_t)b * C + c) * 256 + threadIdx.x;
+        const float* yb = y1 + (((size_t)b * C + c) * IH + 2 * py) * IH + 2 * px;
+        const float v0 = yb[0], v1 = yb[1], v2 = yb[IH], v3 = yb[IH + 1];
+        const float g = G1c[pi];
+        const int code = code1[pi];
+        const float mean = stat1[c], inv = stat1[C + c], cs = coef1[c], m1 = coef1[C + c], m2 = coef1[2 * C + c];
+        float* d = dy1 + (lc * IH + 2 * py) * DLD + 2 * px;
+        d[0] = cs * ((code == 0 ? g : 0.f) - m1 - (v0 - mean) * inv * m2);
+        d[1] = cs * ((code == 1 ? g : 0.f) - m1 - (v1 - mean) * inv * m2);
+        d[DLD] = cs * ((code == 2 ? g : 0.f) - m1 - (v2 - mean) * inv * m2);
+        d[DLD + 1] = cs * ((code == 3 ? g : 0.f) - m1 - (v3 - mean) * inv * m2);
       }
-      dy1[(c * IH + y) * DLD + x] = coef1[c] * (g - coef1[C + c] - xh * coef1[2 * C + c]);
-    }
-    __syncthreads();
-    const int yend = min(IH, (rq + 1) * RPQ);
-    for (int y = rq * RPQ; y < yend; ++y) {
-      float dy[DLD];
-#pragma unroll
-      for (int x = 0; x < DLD; x += 4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(&dy1[(wco * IH + y) * DLD + x]);
-        dy[x] = t4.x; dy[x + 1] = t4.y; dy[x + 2] = t4.z; dy[x + 3] = t4.w;
+      // border row 32 / column 32 (never pooled: g = 0)
+      for (int idx = threadIdx.x; idx < CH * 65; idx += 256) {
+        const int lc = idx / 65, e = idx % 65, c = q * CH + lc;
+        const int y = e < 33 ? 32 : e - 33, x = e < 33 ? e : 32;
+        const float v = y1[(((size_t)b * C + c) * IH + y) * IH + x];
+        dy1[(lc * IH + y) * DLD + x] = coef1[c] * (-coef1[C + c] - (v - stat1[c]) * stat1[C + c] * coef1[2 * C + c]);
       }
-      if (wci == 0) {
+      lds_barrier();
+      const int yend = min(IH, (rq + 1) * RPQ);
+      for (int y = rq * RPQ; y < yend; ++y) {
+        float dy[DLD];
 #pragma unroll
-        for (int x = 0; x < IH; ++x) bacc += dy[x];
-      }
+        for (int x = 0; x < DLD; x += 4) {
+          const float4 t4 = *reinterpret_cast<const float4*>(&dy1[(lco * IH + y) * DLD + x]);
+          dy[x] = t4.x; dy[x + 1] = t4.y; dy[x + 2] = t4.z; dy[x + 3] = t4.w;
+        }
+        if (wci == 0) {
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        float ar[IMG_LD];
-#pragma unroll
-        for (int x = 0; x < IMG_LD; x += 4) {
-          const float4 t4 = *reinterpret_cast<const float4*>(&imgp[wci * IMG_PLANE + (y + ky) * IMG_LD + x]);
-          ar[x] = t4.x; ar[x + 1] = t4.y; ar[x + 2] = t4.z; ar[x + 3] = t4.w;
+          for (int x = 0; x < IH; ++x) bacc[q] += dy[x];
         }
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int ky = 0; ky < 3; ++ky) {
+          float ar[IMG_LD];
 #pragma unroll
-          for (int x = 0; x < IH; ++x) wacc[ky * 3 + kx] = fmaf(dy[x], ar[x + kx], wacc[ky * 3 + kx]);
+          for (int x = 0; x < IMG_LD; x += 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&imgp[wci * IMG_PLANE + (y + ky) * IMG_LD + x]);
+            ar[x] = t4.x; ar[x + 1] = t4.y; ar[x + 2] = t4.z; ar[x + 3] = t4.w;
+          }
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int x = 0; x < IH; ++x) wacc[q][ky * 3 + kx] = fmaf(dy[x], ar[x + kx], wacc[q][ky * 3 + kx]);
+        }
       }
     }
   }
   float* wp = wpart + ((size_t)blockIdx.x * NQ + rq) * WLEN;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) wp[pair * 9 + k] = wacc[k];
-  if (wci == 0) wp[PAIRS * 9 + wco] = bacc;
+  for (int q = 0; q < NP; ++q) {
+    const int co = q * CH + lco;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wp[(co * 4 + wci) * 9 + k] = wacc[q][k];
+    if (wci == 0) wp[C * 36 + co] = bacc[q];
+  }
 }
 
-// dst[o] += sum_z P[z*stride + o], o < len
-__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ P, int nP, int stride, int len,
-                                                          float* dst) {
-  __shared__ float red[4][64];
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
+// dst[o] += sum_z P[z*stride + o], o < len   (64 outputs x 16 z-lanes per block, fixed order)
+__global__ __launch_bounds__(1024) void partial_sum_kernel(const float* __restrict__ P, int nP, int stride, int len,
+                                                           float* dst) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + lane;
   float s = 0.f;
-  if (o < len)
-    for (int z = zl; z < nP; z += 4) s += P[(size_t)z * stride + o];
-  red[zl][threadIdx.x & 63] = s;
+  if (o < len) {
+    float s0 = 0.f, s1 = 0.f;
+    int z = zl;
+    for (; z + 16 < nP; z += 32) { s0 += P[(size_t)z * stride + o]; s1 += P[(size_t)(z + 16) * stride + o]; }
+    if (z < nP) s0 += P[(size_t)z * stride + o];
+    s = s0 + s1;
+  }
+  red[zl][lane] = s;
   __syncthreads();
-  if (zl == 0 && o < len)
-    dst[o] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (zl == 0 && o < len) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][lane];
+    dst[o] += t;
+  }
 }
 
 static int persistent_grid(int B) { return B < 256 ? B : 256; }
@@ -632,28 +671,28 @@ int mggan_conv2_bwd(const float* y1, int B, int C, const float* scale1, const fl
     hipLaunchKernelGGL((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, y1, scale1, shift1, stat1, y2, G2,
                        stat2, coef2, W, G1c, code1, part1, workspace);
   MG_LAUNCH_CHECK("conv2_bwd");
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(256), 0, stream, workspace, grid * NQ, wlen,
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(1024), 0, stream, workspace, grid * NQ, wlen,
                      C * C * 9, dW);
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, stream, workspace + C * C * 9, grid * NQ, wlen,
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, workspace + C * C * 9, grid * NQ, wlen,
                      C, db);
   MG_LAUNCH_CHECK("conv2_bwd reduce");
   return MGGAN_OK;
 }
 
-/* workspace: mggan_cnn_bwd_grid(B) * (256/(4*C)) * (4*C*9 + C) floats */
+/* workspace: mggan_cnn_bwd_grid(B) * 8 * (4*C*9 + C) floats */
 int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float* stat1, const float* coef1,
                     const float* G1c, const unsigned char* code1, float* dW, float* db, float* workspace,
                     size_t workspace_bytes, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv1_bwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(img && y1 && stat1 && coef1 && G1c && code1 && dW && db && workspace, "conv1_bwd: null pointer");
-  const int grid = persistent_grid(B), NQ = 256 / (4 * C), wlen = 4 * C * 9 + C;
+  const int grid = persistent_grid(B) * 2, NQ = 8, wlen = 4 * C * 9 + C;
   const size_t need = (size_t)grid * NQ * wlen * sizeof(float);
   if (workspace_bytes < need) {
     mggan_set_error("conv1_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
     return MGGAN_ERR_WORKSPACE;
   }
-  const size_t lds = (size_t)(4 * IMG_PLANE + C * IH * 36) * sizeof(float);
+  const size_t lds = (size_t)(4 * IMG_PLANE + 8 * IH * 36) * sizeof(float);
   if (C == 16) {
     static bool attr16 = false;
     if (!attr16) {
@@ -672,9 +711,9 @@ int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float
                        workspace);
   }
   MG_LAUNCH_CHECK("conv1_bwd");
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(4 * C * 9, 64)), dim3(256), 0, stream, workspace, grid * NQ, wlen,
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(4 * C * 9, 64)), dim3(1024), 0, stream, workspace, grid * NQ, wlen,
                      4 * C * 9, dW);
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, stream, workspace + 4 * C * 9, grid * NQ, wlen,
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, workspace + 4 * C * 9, grid * NQ, wlen,
                      C, db);
   MG_LAUNCH_CHECK("conv1_bwd reduce");
   return MGGAN_OK;

@@ -60,6 +60,13 @@ __device__ __forceinline__ float mg_act_grad_from_out(float y, int act, float sl
   return 1.f;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
+// store (s_waitcnt vmcnt(0)), which costs a full HBM write round trip per barrier in kernels that stream
+// their saved activations out inside a time loop.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -18,7 +18,7 @@
 
 #define BM 64
 #define BN 64
-#define BK 16
+#define BK 32
 #define LDT 68  // padded LDS leading dimension (multiple of 4 -> aligned b128 reads)
 
 struct GemmArgs {
@@ -38,6 +38,36 @@ struct GemmArgs {
   int seg_scale;
   int n_groups;
 };
+
+// Global -> register fetch of one BMxBK (A) and BNxBK (B) tile; 8 + 8 elements per lane.
+template <bool A_KM, bool B_KM>
+__device__ __forceinline__ void gemm_fetch(const GemmArgs& g, int m0, int n0, int k0, int k_end, float ra[8],
+                                           float rb[8]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = tid + 256 * i;
+    {
+      int kd, m;
+      if (A_KM) { kd = e >> 6; m = e & 63; } else { m = e >> 5; kd = e & 31; }
+      const int gk = k0 + kd, gm = m0 + m;
+      float v = 0.f;
+      if (gk < k_end && gm < g.M) v = A_KM ? g.A[(size_t)gk * g.lda + gm] : g.A[(size_t)gm * g.lda + gk];
+      ra[i] = v;
+    }
+    {
+      int kd, n;
+      if (B_KM) { kd = e >> 6; n = e & 63; } else { n = e >> 5; kd = e & 31; }
+      const int gk = k0 + kd, gn = n0 + n;
+      float v = 0.f;
+      if (gk < k_end && gn < g.N) {
+        if (g.ones_col && gn == g.N - 1) v = 1.0f;
+        else v = B_KM ? g.B[(size_t)gk * g.ldb + gn] : g.B[(size_t)gn * g.ldb + gk];
+      }
+      rb[i] = v;
+    }
+  }
+}
 
 template <bool A_KM, bool B_KM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -63,33 +93,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
+  // software pipeline: the global loads of tile k+1 are in flight while tile k is multiplied
+  float ra[8], rb[8];
+  if (k_begin < k_end) gemm_fetch<A_KM, B_KM>(g, m0, n0, k_begin, k_end, ra, rb);
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int e = tid + 256 * i;
-      // ---- A tile -> As[kd][m]
-      {
-        int kd, m;
-        if (A_KM) { kd = e >> 6; m = e & 63; } else { m = e >> 4; kd = e & 15; }
-        int gk = k0 + kd, gm = m0 + m;
-        float v = 0.f;
-        if (gk < k_end && gm < g.M) v = A_KM ? g.A[(size_t)gk * g.lda + gm] : g.A[(size_t)gm * g.lda + gk];
-        As[kd][m] = v;
-      }
-      // ---- B tile -> Bs[kd][n]
-      {
-        int kd, n;
-        if (B_KM) { kd = e >> 6; n = e & 63; } else { n = e >> 4; kd = e & 15; }
-        int gk = k0 + kd, gn = n0 + n;
-        float v = 0.f;
-        if (gk < k_end && gn < g.N) {
-          if (g.ones_col && gn == g.N - 1) v = 1.0f;
-          else v = B_KM ? g.B[(size_t)gk * g.ldb + gn] : g.B[(size_t)gn * g.ldb + gk];
-        }
-        Bs[kd][n] = v;
-      }
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i;
+      if (A_KM) As[e >> 6][e & 63] = ra[i]; else As[e & 31][e >> 5] = ra[i];
+      if (B_KM) Bs[e >> 6][e & 63] = rb[i]; else Bs[e & 31][e >> 5] = rb[i];
     }
     __syncthreads();
+    if (k0 + BK < k_end) gemm_fetch<A_KM, B_KM>(g, m0, n0, k0 + BK, k_end, ra, rb);
 #pragma unroll
     for (int kd = 0; kd < BK; ++kd) {
       const float4 a = *reinterpret_cast<const float4*>(&As[kd][4 * ty]);
@@ -136,28 +151,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }
 
 // dW[grp][m*lddw + n] += sum_z P[grp*splits+z][m*Naug+n];  column Naug-1 -> db[grp][m]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ P, float* dW, float* db, int M,
-                                                           int Naug, int has_bias, int lddw, int splits,
-                                                           long w_stride, long b_stride) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ P, float* dW, float* db, int M,
+                                                            int Naug, int has_bias, int lddw, int splits,
+                                                            long w_stride, long b_stride) {
+  __shared__ float red[16][64];
   const int grp = blockIdx.y;
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int zl = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + lane;
   const int total = M * Naug;
   float s = 0.f;
   if (o < total) {
     const float* p = P + ((size_t)grp * splits) * total + o;
-    for (int z = zl; z < splits; z += 4) s += p[(size_t)z * total];
+    float s0 = 0.f, s1 = 0.f;
+    int z = zl;
+    for (; z + 16 < splits; z += 32) { s0 += p[(size_t)z * total]; s1 += p[(size_t)(z + 16) * total]; }
+    if (z < splits) s0 += p[(size_t)z * total];
+    s = s0 + s1;
   }
-  red[zl][threadIdx.x & 63] = s;
+  red[zl][lane] = s;
   __syncthreads();
   if (zl == 0 && o < total) {
-    s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][lane];
     int m = o / Naug, n = o % Naug;
     if (has_bias && n == Naug - 1) {
-      if (db) db[grp * b_stride + m] += s;
+      if (db) db[grp * b_stride + m] += t;
     } else {
-      dW[grp * w_stride + (size_t)m * lddw + n] += s;
+      dW[grp * w_stride + (size_t)m * lddw + n] += t;
     }
   }
 }
@@ -218,14 +239,15 @@ size_t mggan_wgrad_workspace_bytes(int rows, int K, int N, int n_groups) {
 }
 
 int mggan_wgrad_splits(int rows, int K, int N, int n_groups) {
+  // short dependent chains: 128-256 rows (4-8 pipelined k-steps) per workgroup, up to ~4 workgroups per CU
   int ng = n_groups > 0 ? n_groups : 1;
   int tiles = cdiv(N, BM) * cdiv(K + 1, BN) * ng;
   int per_group_rows = rows / ng + 1;
-  int by_rows = cdiv(per_group_rows, 256);   // at least 256 rows per split
-  int by_fill = cdiv(1024, tiles);           // about 4 workgroups per CU overall
-  int s = by_rows < by_fill ? by_rows : by_fill;
+  int s = cdiv(per_group_rows, 256);
+  if (s * tiles < 512) s = cdiv(per_group_rows, 128);
+  int cap = cdiv(2048, tiles);
+  if (s > cap) s = cap;
   if (s < 1) s = 1;
-  if (s > 256) s = 256;
   return s;
 }
 
@@ -251,7 +273,7 @@ int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, i
   hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
   MG_LAUNCH_CHECK("wgrad");
   dim3 rgrid(cdiv((long)N * Naug, 64), ng, 1);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, (const float*)workspace, dW, db, N, Naug, 1,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(1024), 0, stream, (const float*)workspace, dW, db, N, Naug, 1,
                      lddw, splits, w_stride, b_stride);
   MG_LAUNCH_CHECK("wgrad_reduce");
   return MGGAN_OK;

@@ -276,9 +276,13 @@ __global__ void adam_inc_kernel(int nseg, const unsigned char* __restrict__ acti
 }
 
 // counts of generator ids (int32 atomics: exact, order independent) and their reciprocals
-__global__ void count_kernel(const int* __restrict__ idx, int n, int* counts) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) atomicAdd(&counts[idx[i]], 1);
+__global__ __launch_bounds__(256) void count_kernel(const int* __restrict__ idx, int n, int g, int* counts) {
+  __shared__ int hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) atomicAdd(&hist[idx[i]], 1);
+  __syncthreads();
+  if (threadIdx.x < g && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], hist[threadIdx.x]);
 }
 __global__ void inv_count_kernel(const int* __restrict__ counts, int g, float* inv) {
   const int i = threadIdx.x;
@@ -381,7 +385,10 @@ int mggan_colmean(const float* x, int rows, int g, float scale, float* out, hipS
 int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count, hipStream_t stream) {
   MG_CHECK_ARG(idx && counts && inv_count && g <= 256, "gen_counts: bad arguments");
   hipMemsetAsync(counts, 0, sizeof(int) * g, stream);
-  if (n > 0) hipLaunchKernelGGL(count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, idx, n, counts);
+  if (n > 0) {
+    int blocks = cdiv(n, 2048);
+    hipLaunchKernelGGL(count_kernel, dim3(blocks > 64 ? 64 : blocks), dim3(256), 0, stream, idx, n, g, counts);
+  }
   hipLaunchKernelGGL(inv_count_kernel, dim3(1), dim3(256), 0, stream, counts, g, inv_count);
   MG_LAUNCH_CHECK("gen_counts");
   return MGGAN_OK;

@@ -42,8 +42,9 @@ __global__ __launch_bounds__(256) void lstm_fold_kernel(FoldArgs a) {
   const int grp = blockIdx.x;
   const long po = (long)grp * a.param_stride;
   const int H = a.H, E = a.E, G4 = 4 * a.H;
+  const int t0 = blockIdx.y * blockDim.x + threadIdx.x, nt = gridDim.y * blockDim.x;
   float* P = a.prep + (size_t)grp * a.prep_stride;
-  for (int m = threadIdx.x; m < G4; m += blockDim.x) {
+  for (int m = t0; m < G4; m += nt) {
     float s0 = 0.f, s1 = 0.f, sb = a.b_ih[po + m] + a.b_hh[po + m];
     for (int e = 0; e < E; ++e) {
       float w = a.W_ih[po + (size_t)m * E + e];
@@ -55,23 +56,23 @@ __global__ __launch_bounds__(256) void lstm_fold_kernel(FoldArgs a) {
     P[prep_off_A(H) + m * 2 + 1] = s1;
     P[prep_off_bias(H) + m] = sb;
   }
-  for (int i = threadIdx.x; i < H * G4; i += blockDim.x) {
+  for (int i = t0; i < H * G4; i += nt) {
     int k = i / G4, m = i % G4;
     P[prep_off_whhT(H) + i] = a.W_hh[po + (size_t)m * H + k];
   }
   if (a.dec) {
     const int Hh = H / 2, IN = H + a.S;
     float* w1T = P + prep_off_w1T(H);
-    for (int i = threadIdx.x; i < IN * Hh; i += blockDim.x) {
+    for (int i = t0; i < IN * Hh; i += nt) {
       int k = i / Hh, m = i % Hh;
       w1T[i] = a.W1[po + (size_t)m * IN + k];
     }
     float* b1 = w1T + IN * Hh;
     float* w2 = b1 + Hh;
     float* b2 = w2 + 2 * Hh;
-    for (int i = threadIdx.x; i < Hh; i += blockDim.x) b1[i] = a.b1[po + i];
-    for (int i = threadIdx.x; i < 2 * Hh; i += blockDim.x) w2[i] = a.W2[po + i];
-    if (threadIdx.x < 2) b2[threadIdx.x] = a.b2[po + threadIdx.x];
+    for (int i = t0; i < Hh; i += nt) b1[i] = a.b1[po + i];
+    for (int i = t0; i < 2 * Hh; i += nt) w2[i] = a.W2[po + i];
+    if (t0 < 2) b2[t0] = a.b2[po + t0];
   }
 }
 
@@ -87,18 +88,19 @@ __global__ __launch_bounds__(256) void lstm_unfold_kernel(UnfoldArgs a) {
   const int grp = blockIdx.x;
   const long po = (long)grp * a.param_stride;
   const int E = a.E, G4 = 4 * a.H;
+  const int t0 = blockIdx.y * blockDim.x + threadIdx.x, nt = gridDim.y * blockDim.x;
   const float* dA = a.dprep + (size_t)grp * a.dprep_stride;
   const float* dB = dA + 2 * G4;
-  for (int i = threadIdx.x; i < G4 * E; i += blockDim.x) {
+  for (int i = t0; i < G4 * E; i += nt) {
     int m = i / E, e = i % E;
     float v = dA[m * 2] * a.W_emb[po + e * 2] + dA[m * 2 + 1] * a.W_emb[po + e * 2 + 1] + dB[m] * a.b_emb[po + e];
     a.dW_ih[po + i] += v;
   }
-  for (int m = threadIdx.x; m < G4; m += blockDim.x) {
+  for (int m = t0; m < G4; m += nt) {
     a.db_ih[po + m] += dB[m];
     a.db_hh[po + m] += dB[m];
   }
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+  for (int e = t0; e < E; e += nt) {
     float s0 = 0.f, s1 = 0.f, sb = 0.f;
     for (int m = 0; m < G4; ++m) {
       float w = a.W_ih[po + (size_t)m * E + e];
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
   __shared__ __attribute__((aligned(16))) float hbuf[RT][H];
   __shared__ __attribute__((aligned(16))) float abuf[RT][Hh];
   __shared__ __attribute__((aligned(16))) float xin[DEC ? RT : 1][DEC ? 160 : 4];
+  __shared__ __attribute__((aligned(16))) float we2d[DEC ? 160 * H : 4];  // W_e2d^T staged once per workgroup
   const int rr = threadIdx.x / H, j = threadIdx.x % H;
   const int r = blockIdx.x * RT + rr;
   const bool valid = r < p.R;
@@ -171,21 +174,22 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
       if (save && valid) p.E2Din[(size_t)r * IN + k] = v;
     }
     const float sv = p.soc[(size_t)ped * p.ld_soc + j];
-    abuf[rr][0] = 0.f;  // touch
-    __syncthreads();
+    for (int i = threadIdx.x; i < IN * H; i += 256) we2d[i] = p.We2dT[i];
+    lds_barrier();
     // h0 = W_e2d [enc_h | noise] + b   (standard.py:247-252)
     float h0 = p.be2d[j];
-    for (int k = 0; k < IN; ++k) h0 = fmaf(p.We2dT[k * H + j], xin[rr][k], h0);
+#pragma unroll 8
+    for (int k = 0; k < IN; ++k) h0 = fmaf(we2d[k * H + j], xin[rr][k], h0);
     hj = h0;
     // time-invariant social half of hidden2pos: q = W1[:,H:] soc + b1
     const float* w1T = P + prep_off_w1T(H);
     const float* b1 = w1T + (H + S) * Hh;
     const float* w2 = b1 + Hh;
     const float* b2 = w2 + 2 * Hh;
-    __syncthreads();
+    lds_barrier();
     hbuf[rr][j] = sv;  // reuse hbuf as the social row for the q product
     if (save && valid) p.SocR[(size_t)r * S + j] = sv;
-    __syncthreads();
+    lds_barrier();
     if (j < Hh) {
       qv = b1[j];
 #pragma unroll
@@ -199,10 +203,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
     const int pd = p.row_ped[rc];
     d0 = p.dxdy0[pd * 2]; d1 = p.dxdy0[pd * 2 + 1];
     x0 = p.xy0[pd * 2];   x1 = p.xy0[pd * 2 + 1];
-    __syncthreads();
+    lds_barrier();
   }
   hbuf[rr][j] = hj;
-  __syncthreads();
+  lds_barrier();
   float hv[H];
 #pragma unroll
   for (int k = 0; k < H; k += 4) {
@@ -239,9 +243,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
       p.Cs[rt * H + j] = c;
       if (DEC) p.Hc[rt * H + j] = hj;
     }
-    __syncthreads();
+    lds_barrier();
     hbuf[rr][j] = hj;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < H; k += 4) {
       float4 t4 = *reinterpret_cast<const float4*>(&hbuf[rr][k]);
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
         abuf[rr][j] = av;
         if (save && valid) p.Aact[rt * Hh + j] = av;
       }
-      __syncthreads();
+      lds_barrier();
       float n0 = b20, n1 = b21;
 #pragma unroll
       for (int m = 0; m < Hh; ++m) {
@@ -329,29 +333,42 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
   float dh = 0.f, dc = 0.f, dd0 = 0.f, dd1 = 0.f, s0 = 0.f, s1 = 0.f, dqacc = 0.f;
   if (!DEC) dh = p.dhT[(size_t)rc * p.ld_dhT + j];
 
-  for (int t = p.T - 1; t >= 0; --t) {
+  // software pipeline over time: the saved activations / incoming gradients of step t-1 are fetched
+  // while step t is being computed (occupancy is one wave per SIMD, so latency must be hidden in-wave)
+  float n_gi, n_gf, n_gg, n_go, n_cc, n_cp, n_av = 0.f, n_ga0 = 0.f, n_ga1 = 0.f, n_gr0 = 0.f, n_gr1 = 0.f;
+  auto fetch = [&](int t) {
     const size_t rt = (size_t)rc * p.T + t;
+    n_gi = p.Gt[rt * G4 + j]; n_gf = p.Gt[rt * G4 + H + j]; n_gg = p.Gt[rt * G4 + 2 * H + j];
+    n_go = p.Gt[rt * G4 + 3 * H + j];
+    n_cc = p.Cs[rt * H + j];
+    n_cp = t > 0 ? p.Cs[(rt - 1) * H + j] : 0.f;
     if (DEC) {
       const size_t o = ((size_t)t * p.Rout + pos) * 2;
-      if (p.gabs) { s0 += p.gabs[o]; s1 += p.gabs[o + 1]; }
-      float g0 = s0 + dd0, g1 = s1 + dd1;
-      if (p.grel) { g0 += p.grel[o]; g1 += p.grel[o + 1]; }
+      if (p.gabs) { n_ga0 = p.gabs[o]; n_ga1 = p.gabs[o + 1]; }
+      if (p.grel) { n_gr0 = p.grel[o]; n_gr1 = p.grel[o + 1]; }
+      if (j < Hh) n_av = p.Aact[rt * Hh + j];
+    }
+  };
+  fetch(p.T - 1);
+  for (int t = p.T - 1; t >= 0; --t) {
+    const size_t rt = (size_t)rc * p.T + t;
+    const float gi = n_gi, gf = n_gf, gg = n_gg, go = n_go, cc = n_cc, cprev = n_cp;
+    const float av = n_av, ga0 = n_ga0, ga1 = n_ga1, gr0 = n_gr0, gr1 = n_gr1;
+    if (t > 0) fetch(t - 1);
+    if (DEC) {
+      s0 += ga0; s1 += ga1;
+      const float g0 = s0 + dd0 + gr0, g1 = s1 + dd1 + gr1;
       if (valid && j == 0) { p.gD[rt * 2] = g0; p.gD[rt * 2 + 1] = g1; }
       if (j < Hh) {
-        const float av = p.Aact[rt * Hh + j];
         const float du = (w20 * g0 + w21 * g1) * (av > 0.f ? 1.f : 0.01f);
         dubuf[rr][j] = du;
         dqacc += du;
         if (valid) p.dU[rt * Hh + j] = du;
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int m = 0; m < Hh; ++m) dh = fmaf(w1c[m], dubuf[rr][m], dh);
     }
-    const float gi = p.Gt[rt * G4 + j], gf = p.Gt[rt * G4 + H + j], gg = p.Gt[rt * G4 + 2 * H + j],
-                go = p.Gt[rt * G4 + 3 * H + j];
-    const float cc = p.Cs[rt * H + j];
-    const float cprev = t > 0 ? p.Cs[(rt - 1) * H + j] : 0.f;
     const float tc = mg_tanh(cc);
     const float dO = dh * tc;
     dc = fmaf(dh * go, 1.f - tc * tc, dc);
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
     dpbuf[rr][H + j] = dpf;
     dpbuf[rr][2 * H + j] = dpg;
     dpbuf[rr][3 * H + j] = dpo;
-    __syncthreads();
+    lds_barrier();
     float nh = 0.f;
 #pragma unroll
     for (int m = 0; m < G4; m += 4) {
@@ -391,7 +408,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
       }
       dd0 = p0; dd1 = p1;
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (DEC) {
     // dH0, dQ, d(social row) = W1[:,H:]^T dQ, d(enc_h row) = W_e2d[:, :EIN]^T dH0
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
       if (valid) p.dQ[(size_t)r * Hh + j] = dqacc;
     }
     dpbuf[rr][j] = dh;
-    __syncthreads();
+    lds_barrier();
     float ds = 0.f;
 #pragma unroll
     for (int m = 0; m < Hh; ++m) ds = fmaf(p.W1[po + (size_t)m * (H + S) + H + j], dubuf[rr][m], ds);
@@ -448,7 +465,7 @@ int mggan_lstm_fold(const float* W_emb, const float* b_emb, const float* W_ih, c
   MG_CHECK_ARG(!dec || (W1 && b1 && W2 && b2), "lstm_fold: decoder head pointers missing");
   MG_CHECK_ARG(prep_stride >= prep_size(H, S, dec), "lstm_fold: prep stride too small");
   FoldArgs a = {W_emb, b_emb, W_ih, b_ih, b_hh, W_hh, W1, b1, W2, b2, param_stride, prep, prep_stride, H, E, S, dec};
-  hipLaunchKernelGGL(lstm_fold_kernel, dim3(n_groups), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(lstm_fold_kernel, dim3(n_groups, 8), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("lstm_fold");
   return MGGAN_OK;
 }
@@ -459,7 +476,7 @@ int mggan_lstm_unfold_grads(const float* W_emb, const float* b_emb, const float*
   MG_CHECK_ARG(W_emb && b_emb && W_ih && dW_emb && db_emb && dW_ih && db_ih && db_hh && dprep,
                "lstm_unfold_grads: null pointer");
   UnfoldArgs a = {W_emb, b_emb, W_ih, dW_emb, db_emb, dW_ih, db_ih, db_hh, param_stride, dprep, dprep_stride, H, E};
-  hipLaunchKernelGGL(lstm_unfold_kernel, dim3(n_groups), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(lstm_unfold_kernel, dim3(n_groups, 8), dim3(64), 0, stream, a);
   MG_LAUNCH_CHECK("lstm_unfold_grads");
   return MGGAN_OK;
 }

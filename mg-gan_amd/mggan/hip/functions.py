@@ -332,7 +332,7 @@ class SceneAttentionFn(Function):
         lib.mggan_conv2_bwd(_p(y1), B, C, _p(sc1), _p(sh1), _p(stat1), _p(y2), _p(G2), _p(stat2), _p(coef2), _p(c2w),
                             _p(G1c), _p(code1), _p(part), root.grad_ptr(c2w), root.grad_ptr(c2b), _p(ws), nb, st)
         coef1 = bn_bwd(g1, be1, stat1, cnt1)
-        nb = grid * (256 // (4 * C)) * (4 * C * 9 + C) * 4
+        nb = 2 * grid * 8 * (4 * C * 9 + C) * 4
         ws = torch.empty(nb // 4, dtype=F32, device=img.device)
         lib.mggan_conv1_bwd(_p(img), B, C, _p(y1), _p(stat1), _p(coef1), _p(G1c), _p(code1), root.grad_ptr(c1w),
                             root.grad_ptr(c1b), _p(ws), nb, st)
