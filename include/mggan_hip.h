@@ -151,8 +151,17 @@ int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float
  * reference: abstract_train.py:62-67, utils.py:18-25, train.py:58-75,92-113,181-200,626-639,
  *            train.py:131-135,209-213,656-658, abstract_train.py:45-50 */
 /* p = D output rows; loss_r = w_r*scale*BCE(p_r,label), w_r = inv_count[row_gen[r]] (or 1); dp = dloss/dp */
-int mggan_bce_rows(int rows, const float* p, float label, float scale, const int* row_gen, const float* inv_count,
-                   float* loss_rows, float* dp, mggan_stream_t stream);
+/* label: host scalar, or (label_u != NULL) drawn on the device as label_lo + (label_hi-label_lo) * *label_u */
+int mggan_bce_rows(int rows, const float* p, float label, const float* label_u, float label_lo, float label_hi,
+                   float scale, const int* row_gen, const float* inv_count, float* loss_rows, float* dp,
+                   mggan_stream_t stream);
+/* device-side replacement of get_selection_indices + gather bookkeeping (utils.py:234-248,
+ * standard.py:190-214): idx (b,K) int64 generator ids -> rollout rows stably sorted by generator.
+ * row r: generator row_gen[r], pedestrian row_ped[r], noise slot row_slot[r] (occurrence offset),
+ * output position row_pos[r] = k*b+ped; inv = inverse permutation; seg[g+1] = segment offsets;
+ * row_gen_pos (optional) = generator id per output position. */
+int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, int* row_ped, int* row_slot,
+                      int* row_pos, int* inv, int* seg, int* row_gen_pos, mggan_stream_t stream);
 int mggan_scale(float* x, long n, const float* scalar, mggan_stream_t stream);
 /* classifier input of the discriminator (discriminators.py:141,185,196): rows k*b+ped =
  * [soc (sample block 0 only) | in_enc | pred_enc | scene], and its adjoint */

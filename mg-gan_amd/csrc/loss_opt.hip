@@ -14,11 +14,12 @@
 
 // ---- BCE on the discriminator output ---------------------------------------------------
 // p: D output per row (already sigmoid + eps-affine). loss_r = w_r*scale*BCE(p,y); dp = dloss_r/dp.
-__global__ void bce_rows_kernel(int rows, const float* __restrict__ p_in, float y, float scale,
-                                const int* __restrict__ row_gen, const float* __restrict__ inv_count,
-                                float* loss_rows, float* dp) {
+__global__ void bce_rows_kernel(int rows, const float* __restrict__ p_in, float y, const float* __restrict__ y_u,
+                                float y_lo, float y_hi, float scale, const int* __restrict__ row_gen,
+                                const float* __restrict__ inv_count, float* loss_rows, float* dp) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
+  if (y_u) y = y_lo + (y_hi - y_lo) * (*y_u);  // smoothed label drawn on the device: U(y_lo, y_hi)
   const float p = p_in[r];
   const float w = (row_gen ? inv_count[row_gen[r]] : 1.f) * scale;
   const float lp = fmaxf(__logf(p), -100.f), lq = fmaxf(__logf(1.f - p), -100.f);  // BCELoss log clamp
@@ -289,14 +290,82 @@ __global__ void inv_count_kernel(const int* __restrict__ counts, int g, float* i
   if (i < g) inv[i] = counts[i] > 0 ? 1.f / (float)counts[i] : 0.f;
 }
 
+// ---- device-side row bookkeeping for the selected rollouts (replaces get_selection_indices +
+// the index gather of standard.py:190-214, utils.py:234-248) ---------------------------------
+// idx (b, K) generator ids.  Output rows are stably sorted by generator: row r <-> output position
+// pos = k*b + ped; row_slot = number of earlier samples of the same pedestrian with the same generator.
+#define BR_THREADS 512
+#define BR_MAXG 16
+__global__ __launch_bounds__(BR_THREADS) void bucket_rows_kernel(const long long* __restrict__ idx, int b, int K, int g,
+                                                                 int* row_gen, int* row_ped, int* row_slot,
+                                                                 int* row_pos, int* inv, int* seg, int* row_gen_pos) {
+  __shared__ int cnt[BR_THREADS][BR_MAXG + 1];
+  __shared__ int base[BR_MAXG + 1];
+  const int R = b * K, t = threadIdx.x;
+  const int per = (R + BR_THREADS - 1) / BR_THREADS;
+  const int lo = min(R, t * per), hi = min(R, lo + per);
+  int local[BR_MAXG];
+#pragma unroll
+  for (int q = 0; q < BR_MAXG; ++q) local[q] = 0;
+  for (int pos = lo; pos < hi; ++pos) {
+    const int ped = pos % b, k = pos / b;
+    const int gi = (int)idx[(size_t)ped * K + k];
+#pragma unroll
+    for (int q = 0; q < BR_MAXG; ++q) local[q] += (q == gi);
+  }
+#pragma unroll
+  for (int q = 0; q < BR_MAXG; ++q) cnt[t][q] = local[q];
+  __syncthreads();
+  // exclusive scan over threads, one lane per generator (g <= 16, 1024 entries each: short serial loop)
+  if (t < g) {
+    int run = 0;
+    for (int i = 0; i < BR_THREADS; ++i) { const int c = cnt[i][t]; cnt[i][t] = run; run += c; }
+    base[t] = run;  // total of generator t
+  }
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int q = 0; q < g; ++q) { const int c = base[q]; base[q] = run; seg[q] = run; run += c; }
+    seg[g] = run;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < BR_MAXG; ++q) local[q] = 0;
+  for (int pos = lo; pos < hi; ++pos) {
+    const int ped = pos % b, k = pos / b;
+    const int gi = (int)idx[(size_t)ped * K + k];
+    int slot = 0;
+    for (int kk = 0; kk < k; ++kk) slot += ((int)idx[(size_t)ped * K + kk] == gi);
+    int off = 0;
+#pragma unroll
+    for (int q = 0; q < BR_MAXG; ++q) {
+      if (q == gi) { off = local[q]; local[q] += 1; }
+    }
+    const int r = base[gi] + cnt[t][gi] + off;
+    row_gen[r] = gi; row_ped[r] = ped; row_slot[r] = slot; row_pos[r] = pos; inv[pos] = r;
+    if (row_gen_pos) row_gen_pos[pos] = gi;
+  }
+}
+
 extern "C" {
 
-int mggan_bce_rows(int rows, const float* p, float label, float scale, const int* row_gen, const float* inv_count,
-                   float* loss_rows, float* dp, hipStream_t stream) {
+int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, int* row_ped, int* row_slot,
+                      int* row_pos, int* inv, int* seg, int* row_gen_pos, hipStream_t stream) {
+  MG_CHECK_ARG(idx && row_gen && row_ped && row_slot && row_pos && inv && seg, "bucket_rows: null pointer");
+  MG_CHECK_ARG(g >= 1 && g <= BR_MAXG, "bucket_rows: num_gens %d exceeds %d", g, BR_MAXG);
+  hipLaunchKernelGGL(bucket_rows_kernel, dim3(1), dim3(BR_THREADS), 0, stream, idx, b, K, g, row_gen, row_ped, row_slot,
+                     row_pos, inv, seg, row_gen_pos);
+  MG_LAUNCH_CHECK("bucket_rows");
+  return MGGAN_OK;
+}
+
+int mggan_bce_rows(int rows, const float* p, float label, const float* label_u, float label_lo, float label_hi,
+                   float scale, const int* row_gen, const float* inv_count, float* loss_rows, float* dp,
+                   hipStream_t stream) {
   if (rows == 0) return MGGAN_OK;
   MG_CHECK_ARG(p && loss_rows && ((row_gen == nullptr) == (inv_count == nullptr)), "bce_rows: bad arguments");
-  hipLaunchKernelGGL(bce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rows, p, label, scale, row_gen,
-                     inv_count, loss_rows, dp);
+  hipLaunchKernelGGL(bce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rows, p, label, label_u, label_lo,
+                     label_hi, scale, row_gen, inv_count, loss_rows, dp);
   MG_LAUNCH_CHECK("bce_rows");
   return MGGAN_OK;
 }

@@ -63,10 +63,13 @@ class MultiGeneratorGAN(abc.ABC):
         b = in_xy.size(1)
         sub_batches = batch["seq_start_end"] if "seq_start_end" in batch else list(zip(range(b), range(1, b + 1)))
         gt_xy, gt_dxdy = batch["gt_xy"], batch["gt_dxdy"]
-        loss_mask = batch.get("loss_mask")
-        if loss_mask is None:
+        if "loss_mask" in batch:  # None == every pedestrian valid (no device sync, HIP-graph capturable)
+            loss_mask = batch["loss_mask"]
+        else:
             loss_mask = ~gt_xy.isnan().any(2).any(0)
-        if not bool(loss_mask.all()):
+            if bool(loss_mask.all()):
+                loss_mask = None
+        if loss_mask is not None:
             gt_dxdy, gt_xy = gt_dxdy[:, loss_mask], gt_xy[:, loss_mask]
         img = batch["features"] if "features" in batch else None
         args = (in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, metrics, loss_mask, img)
@@ -74,6 +77,44 @@ class MultiGeneratorGAN(abc.ABC):
             self.discriminator_step(*args)
         self.generator_step(*args)
         self.net_chooser_step(*args)
+
+    def capture_iteration(self, batch, warmup=3):
+        """Capture one full D+G+PM iteration on `batch` into a HIP graph (needs --rng device: no host
+        sync anywhere in the iteration).  Returns replay(metrics) which re-runs the iteration on the
+        same static batch tensors (copy new data into them to change the input)."""
+        if not getattr(self.rng, "on_device", False):
+            raise RuntimeError("graph capture needs the device RNG (--rng device): the host RNG path reads the "
+                               "PM-network logits back to the CPU")
+        if self.dist.enabled:
+            raise RuntimeError("graph capture is single-GPU for now")
+        batch = dict(batch)
+        batch["loss_mask"] = None
+        keep, self.defer_metrics = self.defer_metrics, True
+        scratch = defaultdict(list)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.train_iteration(batch, scratch)
+        torch.cuda.current_stream().wait_stream(side)
+        self.flush_metrics()
+        graph = torch.cuda.CUDAGraph()
+        captured = defaultdict(list)
+        with torch.cuda.graph(graph):
+            self.train_iteration(batch, captured)
+        pending, self._pending = self._pending, []
+        self.defer_metrics = keep
+
+        def replay(metrics=None, fetch=True):
+            graph.replay()
+            if metrics is not None and fetch:
+                for _, items, snap in pending:
+                    v = snap.cpu().numpy()
+                    for key, slot in items:
+                        metrics[key].append(float(v[slot] if isinstance(slot, int) else v[slot[0]] + v[slot[1]]))
+
+        replay.graph = graph
+        return replay
 
     def train(self):
         cfg = self.config
@@ -91,8 +132,6 @@ class MultiGeneratorGAN(abc.ABC):
             metrics = defaultdict(list)
             for batch in train_loader:
                 batch = self.to_device(batch)
-                batch["loss_mask"] = torch.ones(batch["in_xy"].size(1), dtype=torch.bool, device=self.device) \
-                    if not torch.isnan(batch["gt_xy"]).any() else None
                 self.train_iteration(batch, metrics)
 
             if self.epoch % cfg.val_every == 0:

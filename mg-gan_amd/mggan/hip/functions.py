@@ -358,7 +358,23 @@ class RolloutRows:
         self.R, self.b, self.K = R, b, R // max(b, 1)
         self.row_gen, self.row_ped, self.row_slot = to(gen[order]), to(np.asarray(ped)[order]), to(np.asarray(slot)[order])
         self.row_pos, self.inv, self.seg = to(order), to(inv), to(seg)
-        self.counts = np.diff(seg)
+        self.row_gen_pos = to(gen)
+
+
+def device_rollout_rows(idx, n_gens):
+    """RolloutRows built on the GPU from sampled generator ids (b, K) int64 -- no host round trip."""
+    b, K = idx.shape
+    R = b * K
+    dev = idx.device
+    rows = RolloutRows.__new__(RolloutRows)
+    mk = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+    rows.R, rows.b, rows.K = R, b, K
+    rows.row_gen, rows.row_ped, rows.row_slot, rows.row_pos, rows.inv = mk(R), mk(R), mk(R), mk(R), mk(R)
+    rows.seg, rows.row_gen_pos = mk(n_gens + 1), mk(R)
+    idx = idx.contiguous()
+    lib.mggan_bucket_rows(_p(idx), b, K, n_gens, _p(rows.row_gen), _p(rows.row_ped), _p(rows.row_slot),
+                          _p(rows.row_pos), _p(rows.inv), _p(rows.seg), _p(rows.row_gen_pos), _s())
+    return rows
 
 
 class DecoderRolloutFn(Function):
@@ -489,7 +505,12 @@ class BceMeanFn(Function):
         rows = p_rows.numel()
         loss_rows = _empty(rows, like=p_rows)
         dp = _empty(rows, like=p_rows)
-        lib.mggan_bce_rows(rows, _p(p_rows), float(label), 1.0 / float(norm or max(rows, 1)), _p(row_gen), _p(inv_count),
+        if isinstance(label, tuple):  # (u (1,) device tensor, lo, hi): label = lo + (hi-lo)*u drawn on the GPU
+            lab, lab_u, lo, hi = 0.0, _p(label[0]), float(label[1]), float(label[2])
+        else:
+            lab, lab_u, lo, hi = float(label), 0, 0.0, 0.0
+        lib.mggan_bce_rows(rows, _p(p_rows), lab, lab_u, lo, hi, 1.0 / float(norm or max(rows, 1)), _p(row_gen),
+                           _p(inv_count),
                            _p(loss_rows), _p(dp), _s())
         lib.mggan_sum(_p(loss_rows), rows, 1.0, _p(out), 0, _s())
         ctx.dp, ctx.shape = dp, p_rows.shape

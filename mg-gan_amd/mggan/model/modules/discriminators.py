@@ -73,7 +73,7 @@ class MultiDiscriminatorTrajectory(FlatModule):
             pred_xy, pred_dxdy = pred_xy.unsqueeze(1), pred_dxdy.unsqueeze(1)
         pred_len, n_samples, b, _ = pred_xy.shape
         full_b = in_xy.size(1)
-        masked = mask is not None and not bool(mask.all())
+        masked = mask is not None and not bool(mask.all())  # pass mask=None (all valid) to avoid the sync
 
         in_enc, pred_enc = self._encode_parts(in_dxdy, pred_dxdy)
         if not masked:

@@ -76,6 +76,20 @@ class MultiGenerator(FlatModule):
         assert len(strides) == 1, "per-generator parameter blocks must be laid out with a constant stride"
         return strides.pop()
 
+    def _all_rows(self, n, b, dev):
+        """Row table of "every generator on every (sample, pedestrian)": static per shape, cached."""
+        key = (n, b, str(dev))
+        cache = self.__dict__.setdefault("_all_rows_cache", {})
+        rows = cache.get(key)
+        if rows is None:
+            g = self.n_gs
+            rows = HF.RolloutRows(np.tile(np.repeat(np.arange(g), b), n), np.tile(np.arange(b), n * g),
+                                  np.repeat(np.arange(n), g * b), g, b, dev)
+            if len(cache) > 16:
+                cache.clear()
+            cache[key] = rows
+        return rows
+
     def trunk(self, in_xy, in_dxdy, sub_batches, img):
         enc = self.encoder(get_input(in_xy, in_dxdy, self.inp_format))
         scene = self.scene_encoder(img)
@@ -112,7 +126,7 @@ class MultiGenerator(FlatModule):
         else:
             noise = self.rng.noise(num_samples, self.z_size, sub_batches, dev)
 
-        if mask is not None and not bool(mask.all()):
+        if mask is not None and not bool(mask.all()):  # pass mask=None (all valid) to avoid this device sync
             in_xy, in_dxdy = in_xy[:, mask], in_dxdy[:, mask]
             enc_h, social_feats, noise = enc_h[mask], social_feats[mask], noise[:, mask]
             batch_size = int(mask.sum())
@@ -121,18 +135,21 @@ class MultiGenerator(FlatModule):
 
         if all_gen_out:
             with torch.no_grad():
-                rows = HF.RolloutRows(np.tile(np.repeat(np.arange(g), b), K), np.tile(np.arange(b), K * g),
-                                      np.repeat(np.arange(K), g * b), g, b, dev)
-                pa, pr = self._rollout(rows, in_xy, in_dxdy, enc_h.detach(), social_feats.detach(), noise)
+                pa, pr = self._rollout(self._all_rows(K, b, dev), in_xy, in_dxdy, enc_h.detach(),
+                                       social_feats.detach(), noise)
             net_chooser_out, sampled_gen_idxs = self.get_samples(enc_h, num_samples)
             shape = (self.pred_len, K, g, b, 2)
             return GeneratorOutput(pr.view(shape), pa.view(shape)), net_chooser_out, sampled_gen_idxs
 
         with torch.no_grad():
             net_chooser_out, sampled_gen_idxs = self.get_samples(enc_h, num_samples)
-        idx_host = sampled_gen_idxs.cpu()
-        offsets = get_selection_indices(idx_host)  # noise slot = occurrence offset, NOT the sample index (A.4)
-        rows = HF.RolloutRows(idx_host.t().reshape(-1).numpy(), ped, offsets.t().reshape(-1).numpy(), g, b, dev)
+        if sampled_gen_idxs.is_cuda and getattr(self.rng, "on_device", False):
+            rows = HF.device_rollout_rows(sampled_gen_idxs, g)  # no host round trip
+        else:
+            idx_host = sampled_gen_idxs.cpu()
+            offsets = get_selection_indices(idx_host)  # noise slot = occurrence offset, NOT the sample index (A.4)
+            rows = HF.RolloutRows(idx_host.t().reshape(-1).numpy(), ped, offsets.t().reshape(-1).numpy(), g, b, dev)
+        self.last_rows = rows
         pa, pr = self._rollout(rows, in_xy, in_dxdy, enc_h, social_feats, noise)
         shape = (self.pred_len, K, b, 2)
         return GeneratorOutput(pr.view(shape), pa.view(shape)), net_chooser_out, sampled_gen_idxs
@@ -150,8 +167,6 @@ class MultiGenerator(FlatModule):
         """Every generator on every (sample, pedestrian): two tensors (pred_len, n_samples, num_gens, b, 2)."""
         n, b, _ = noise.shape
         g = self.n_gs
-        rows = HF.RolloutRows(np.tile(np.repeat(np.arange(g), b), n), np.tile(np.arange(b), n * g),
-                              np.repeat(np.arange(n), g * b), g, b, enc_h.device)
-        pa, pr = self._rollout(rows, in_xy, in_dxdy, enc_h, social_feats, noise)
+        pa, pr = self._rollout(self._all_rows(n, b, enc_h.device), in_xy, in_dxdy, enc_h, social_feats, noise)
         shape = (self.pred_len, n, g, b, 2)
         return pa.view(shape), pr.view(shape)

@@ -67,7 +67,11 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
     def _gen_weights(self, gen_idxs):
         """Batch-global 1/count(generator) weights (train.py:94-96) + int32 row targets in (k*b+ped) order."""
         g = self.G.n_gs
-        row_gen = gen_idxs.t().reshape(-1).to(torch.int32)
+        rows = getattr(self.G, "last_rows", None)
+        if rows is not None and rows.R == gen_idxs.numel():
+            row_gen = rows.row_gen_pos  # produced by the row-bucketing step of this very forward pass
+        else:
+            row_gen = gen_idxs.t().reshape(-1).to(torch.int32)
         counts = torch.empty(g, dtype=torch.int32, device=self.device)
         inv = torch.empty(g, dtype=torch.float32, device=self.device)
         st = torch.cuda.current_stream().cuda_stream
@@ -97,7 +101,9 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         if self.gan_type == "mgan":
             disc_out, branch_out = disc_out
             rows = branch_out.transpose(0, 1).reshape(-1, branch_out.shape[-1])
-            target = gen_labels_gt.t().reshape(-1).to(torch.int32)
+            rows_d = getattr(self.G, "last_rows", None)
+            target = rows_d.row_gen_pos if rows_d is not None and rows_d.R == gen_labels_gt.numel() \
+                else gen_labels_gt.t().reshape(-1).to(torch.int32)
             ce_loss = HF.CeMeanFn.apply(rows, target, None, m[M_CE_D:M_CE_D + 1], self._global(rows.shape[0]))
             losses.append(ce_loss)
             items.append(("train/info_mgan_disc_loss", M_CE_D))

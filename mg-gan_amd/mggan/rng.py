@@ -30,32 +30,35 @@ class HostRNG:
 
 
 class DeviceRNG:
+    """Everything is drawn by the default CUDA generator (capturable in a HIP graph, no host sync)."""
     on_device = True
 
     def __init__(self, seed=0):
-        self.seed = seed
-        self._gen = None
-        self._np = np.random.RandomState(seed)
-
-    def _g(self, device):
-        if self._gen is None:
-            self._gen = torch.Generator(device=device)
-            self._gen.manual_seed(self.seed)
-        return self._gen
+        torch.cuda.manual_seed(seed)
+        self._lens = {}
 
     def labels(self):
-        fake = self._np.uniform(0, 0.1)
-        real = self._np.uniform(0.9, 1.0)
-        return float(real), float(fake)
+        """-> ((u, 0.9, 1.0), (u', 0.0, 0.1)): smoothed labels real ~ U(.9,1), fake ~ U(0,.1) as device draws."""
+        u = torch.rand(2, device="cuda")
+        return (u[0:1], 0.9, 1.0), (u[1:2], 0.0, 0.1)
 
     def noise(self, num_samples, dim, sub_batches, device):
-        lens = torch.tensor([int(e) - int(s) for s, e in sub_batches], device=device)
-        per_scene = torch.randn(num_samples, len(sub_batches), dim, device=device, generator=self._g(device))
-        return per_scene.repeat_interleave(lens, dim=1)
+        key = (id(sub_batches), len(sub_batches))
+        lens = self._lens.get(key)
+        if lens is None or lens[0] is not sub_batches:
+            t = torch.tensor([int(e) - int(s) for s, e in sub_batches], device=device)
+            total = int(t.sum())
+            scene_of = torch.repeat_interleave(torch.arange(len(sub_batches), device=device), t, output_size=total)
+            lens = (sub_batches, scene_of)
+            if len(self._lens) > 64:
+                self._lens.clear()
+            self._lens[key] = lens
+        per_scene = torch.randn(num_samples, len(sub_batches), dim, device=device)
+        return per_scene[:, lens[1]]  # one draw per scene, repeated for its pedestrians (utils.py:160-165)
 
     def sample_generators(self, logits, num_samples):
         probs = torch.softmax(logits.detach().float(), -1)
-        return torch.multinomial(probs, num_samples, True, generator=self._g(logits.device))
+        return torch.multinomial(probs, num_samples, True)
 
 
 class ReplayRNG:
