@@ -49,9 +49,10 @@ int mggan_linear_bwd_data(const float* dZ, int lddz, const float* W, int ldw, fl
  * decoder weights).  seg == NULL, n_groups <= 1: one group over all rows. */
 int mggan_wgrad_splits(int rows, int K, int N, int n_groups);
 size_t mggan_wgrad_workspace_bytes(int rows, int K, int N, int n_groups);
+/* feature_major != 0: dZ is stored [N][lddz] and X [K][ldx] (element (row, f) at p[f*ld + row]) */
 int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, int lddw, float* db, int rows, int K,
-                int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, void* workspace,
-                size_t workspace_bytes, mggan_stream_t stream);
+                int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, int feature_major,
+                void* workspace, size_t workspace_bytes, mggan_stream_t stream);
 int mggan_transpose(const float* W, float* WT, int N, int K, mggan_stream_t stream);
 /* dst[ped][c] (+)= sum_k src[inv[k*b+ped]][c] : adjoint of "repeat over samples" */
 int mggan_gather_sum(const float* src, int ld_src, const int* inv, float* dst, int ld_dst, int b, int K, int ncols,

@@ -285,15 +285,15 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
   }
   // ---- backward: out = sum_c a_c v_c, a = softmax(s) ----
   const float go = dout[(size_t)b * ld_dout + pos];
-  const size_t row = (size_t)b * 64 + pos;
+  const size_t row = (size_t)b * 64 + pos, NR = (size_t)B * 64;  // saved arrays are [feature][NR]
   float dv[C], dsv[C], dot = 0.f;
 #pragma unroll
   for (int c = 0; c < C; ++c) { dv[c] = go * sc[c]; dot = fmaf(sc[c], go * v[c], dot); }
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     dsv[c] = sc[c] * (go * v[c] - dot);
-    ds_s[row * C + c] = dsv[c];
-    vsave[row * C + c] = v[c];
+    ds_s[c * NR + row] = dsv[c];
+    vsave[c * NR + row] = v[c];
   }
 #pragma unroll
   for (int k = 0; k < HID; ++k) {
@@ -301,8 +301,8 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
 #pragma unroll
     for (int c = 0; c < C; ++c) d = fmaf(Wb[c * HID + k], dsv[c], d);
     d *= hid[k] > 0.f ? 1.f : 0.01f;
-    dz_s[row * HID + k] = d;
-    hact[row * HID + k] = hid[k];
+    dz_s[k * NR + row] = d;
+    hact[k * NR + row] = hid[k];
 #pragma unroll
     for (int c = 0; c < C; ++c) dv[c] = fmaf(Wa[k * C + c], d, dv[c]);
   }
@@ -434,10 +434,23 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
       }
     }
   }
-  float* wp = wpart + ((size_t)blockIdx.x * NQ + rq) * WLEN;
+  // fold the NQ row-group partials in LDS (fixed order) -> one partial row per workgroup
+  lds_barrier();
+  float* red = dyp;  // reuse (>= NQ * WLEN floats)
+  {
+    float* rp = red + rq * WLEN;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) wp[pair * 9 + k] = wacc[k];
-  if (wci == 0) wp[PAIRS * 9 + wco] = bacc;
+    for (int k = 0; k < 9; ++k) rp[pair * 9 + k] = wacc[k];
+    if (wci == 0) rp[PAIRS * 9 + wco] = bacc;
+  }
+  lds_barrier();
+  float* wp = wpart + (size_t)blockIdx.x * WLEN;
+  for (int i = threadIdx.x; i < WLEN; i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) t += red[q * WLEN + i];
+    wp[i] = t;
+  }
 }
 
 // ---------------- conv1 backward: BN1 bwd + weight grad (the image needs no gradient) ----------------
@@ -522,13 +535,25 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(int B, const float* __re
       }
     }
   }
-  float* wp = wpart + ((size_t)blockIdx.x * NQ + rq) * WLEN;
+  lds_barrier();
+  float* red = dy1;  // reuse (>= NQ * WLEN floats: 8 * 592 <= 9504)
+  {
+    float* rp = red + rq * WLEN;
 #pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    const int co = q * CH + lco;
+    for (int q = 0; q < NP; ++q) {
+      const int co = q * CH + lco;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wp[(co * 4 + wci) * 9 + k] = wacc[q][k];
-    if (wci == 0) wp[C * 36 + co] = bacc[q];
+      for (int k = 0; k < 9; ++k) rp[(co * 4 + wci) * 9 + k] = wacc[q][k];
+      if (wci == 0) rp[C * 36 + co] = bacc[q];
+    }
+  }
+  lds_barrier();
+  float* wp = wpart + (size_t)blockIdx.x * WLEN;
+  for (int i = threadIdx.x; i < WLEN; i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) t += red[q * WLEN + i];
+    wp[i] = t;
   }
 }
 
@@ -671,9 +696,9 @@ int mggan_conv2_bwd(const float* y1, int B, int C, const float* scale1, const fl
     hipLaunchKernelGGL((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, y1, scale1, shift1, stat1, y2, G2,
                        stat2, coef2, W, G1c, code1, part1, workspace);
   MG_LAUNCH_CHECK("conv2_bwd");
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(1024), 0, stream, workspace, grid * NQ, wlen,
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(1024), 0, stream, workspace, grid, wlen,
                      C * C * 9, dW);
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, workspace + C * C * 9, grid * NQ, wlen,
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, workspace + C * C * 9, grid, wlen,
                      C, db);
   MG_LAUNCH_CHECK("conv2_bwd reduce");
   return MGGAN_OK;
@@ -711,9 +736,9 @@ int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float
                        workspace);
   }
   MG_LAUNCH_CHECK("conv1_bwd");
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(4 * C * 9, 64)), dim3(1024), 0, stream, workspace, grid * NQ, wlen,
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(4 * C * 9, 64)), dim3(1024), 0, stream, workspace, grid, wlen,
                      4 * C * 9, dW);
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, workspace + 4 * C * 9, grid * NQ, wlen,
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, workspace + 4 * C * 9, grid, wlen,
                      C, db);
   MG_LAUNCH_CHECK("conv1_bwd reduce");
   return MGGAN_OK;

@@ -252,8 +252,8 @@ int mggan_wgrad_splits(int rows, int K, int N, int n_groups) {
 }
 
 int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, int lddw, float* db, int rows, int K,
-                int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, void* workspace,
-                size_t workspace_bytes, hipStream_t stream) {
+                int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, int feature_major,
+                void* workspace, size_t workspace_bytes, hipStream_t stream) {
   MG_CHECK_ARG(dZ && X && dW && K > 0 && N > 0, "wgrad: bad arguments");
   if (rows == 0) return MGGAN_OK;
   const int ng = n_groups > 0 ? n_groups : 1;
@@ -270,7 +270,9 @@ int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, i
   g.M = N; g.N = Naug; g.K = rows; g.lda = lddz; g.ldb = ldx; g.ldc = Naug;
   g.splits = splits; g.ones_col = 1; g.seg = seg; g.seg_scale = seg_scale > 0 ? seg_scale : 1; g.n_groups = ng;
   dim3 grid(cdiv(Naug, BN), cdiv(N, BM), splits * ng);
-  hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
+  // feature_major: operands stored [feature][row] (written coalesced by one-lane-per-row kernels)
+  if (feature_major) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
   MG_LAUNCH_CHECK("wgrad");
   dim3 rgrid(cdiv((long)N * Naug, 64), ng, 1);
   hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(1024), 0, stream, (const float*)workspace, dW, db, N, Naug, 1,

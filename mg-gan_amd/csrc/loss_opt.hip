@@ -302,25 +302,42 @@ __global__ __launch_bounds__(BR_THREADS) void bucket_rows_kernel(const long long
   __shared__ int cnt[BR_THREADS][BR_MAXG + 1];
   __shared__ int base[BR_MAXG + 1];
   const int R = b * K, t = threadIdx.x;
+  // phase A: one lane per pedestrian walks its K samples once: generator id and occurrence offset per
+  // output position (slot is parked in inv[pos] until phase C overwrites it)
+  for (int ped = t; ped < b; ped += BR_THREADS) {
+    int seen[BR_MAXG];
+#pragma unroll
+    for (int q = 0; q < BR_MAXG; ++q) seen[q] = 0;
+    for (int k = 0; k < K; ++k) {
+      const int gi = (int)idx[(size_t)ped * K + k];
+      int slot = 0;
+#pragma unroll
+      for (int q = 0; q < BR_MAXG; ++q) {
+        if (q == gi) { slot = seen[q]; seen[q] += 1; }
+      }
+      row_gen_pos[k * b + ped] = gi;
+      inv[k * b + ped] = slot;
+    }
+  }
+  __syncthreads();
+  // phase B: stable counting sort of the positions by generator
   const int per = (R + BR_THREADS - 1) / BR_THREADS;
   const int lo = min(R, t * per), hi = min(R, lo + per);
   int local[BR_MAXG];
 #pragma unroll
   for (int q = 0; q < BR_MAXG; ++q) local[q] = 0;
   for (int pos = lo; pos < hi; ++pos) {
-    const int ped = pos % b, k = pos / b;
-    const int gi = (int)idx[(size_t)ped * K + k];
+    const int gi = row_gen_pos[pos];
 #pragma unroll
     for (int q = 0; q < BR_MAXG; ++q) local[q] += (q == gi);
   }
 #pragma unroll
   for (int q = 0; q < BR_MAXG; ++q) cnt[t][q] = local[q];
   __syncthreads();
-  // exclusive scan over threads, one lane per generator (g <= 16, 1024 entries each: short serial loop)
   if (t < g) {
     int run = 0;
     for (int i = 0; i < BR_THREADS; ++i) { const int c = cnt[i][t]; cnt[i][t] = run; run += c; }
-    base[t] = run;  // total of generator t
+    base[t] = run;
   }
   __syncthreads();
   if (t == 0) {
@@ -329,21 +346,18 @@ __global__ __launch_bounds__(BR_THREADS) void bucket_rows_kernel(const long long
     seg[g] = run;
   }
   __syncthreads();
+  // phase C: scatter
 #pragma unroll
   for (int q = 0; q < BR_MAXG; ++q) local[q] = 0;
   for (int pos = lo; pos < hi; ++pos) {
-    const int ped = pos % b, k = pos / b;
-    const int gi = (int)idx[(size_t)ped * K + k];
-    int slot = 0;
-    for (int kk = 0; kk < k; ++kk) slot += ((int)idx[(size_t)ped * K + kk] == gi);
+    const int gi = row_gen_pos[pos], slot = inv[pos];
     int off = 0;
 #pragma unroll
     for (int q = 0; q < BR_MAXG; ++q) {
       if (q == gi) { off = local[q]; local[q] += 1; }
     }
     const int r = base[gi] + cnt[t][gi] + off;
-    row_gen[r] = gi; row_ped[r] = ped; row_slot[r] = slot; row_pos[r] = pos; inv[pos] = r;
-    if (row_gen_pos) row_gen_pos[pos] = gi;
+    row_gen[r] = gi; row_ped[r] = pos % b; row_slot[r] = slot; row_pos[r] = pos; inv[pos] = r;
   }
 }
 
@@ -351,7 +365,7 @@ extern "C" {
 
 int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, int* row_ped, int* row_slot,
                       int* row_pos, int* inv, int* seg, int* row_gen_pos, hipStream_t stream) {
-  MG_CHECK_ARG(idx && row_gen && row_ped && row_slot && row_pos && inv && seg, "bucket_rows: null pointer");
+  MG_CHECK_ARG(idx && row_gen && row_ped && row_slot && row_pos && inv && seg && row_gen_pos, "bucket_rows: null pointer");
   MG_CHECK_ARG(g >= 1 && g <= BR_MAXG, "bucket_rows: num_gens %d exceeds %d", g, BR_MAXG);
   hipLaunchKernelGGL(bucket_rows_kernel, dim3(1), dim3(BR_THREADS), 0, stream, idx, b, K, g, row_gen, row_ped, row_slot,
                      row_pos, inv, seg, row_gen_pos);

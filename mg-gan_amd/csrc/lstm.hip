@@ -100,17 +100,18 @@ __global__ __launch_bounds__(256) void lstm_unfold_kernel(UnfoldArgs a) {
     a.db_ih[po + m] += dB[m];
     a.db_hh[po + m] += dB[m];
   }
-  for (int e = t0; e < E; e += nt) {
-    float s0 = 0.f, s1 = 0.f, sb = 0.f;
-    for (int m = 0; m < G4; ++m) {
-      float w = a.W_ih[po + (size_t)m * E + e];
-      s0 = fmaf(w, dA[m * 2], s0);
-      s1 = fmaf(w, dA[m * 2 + 1], s1);
-      sb = fmaf(w, dB[m], sb);
+  // dW_emb[e][c] = sum_m W_ih[m][e] dA[m][c], db_emb[e] = sum_m W_ih[m][e] dB[m]: one wave per (e, c|bias)
+  const int wave = (blockIdx.y * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.y * blockDim.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  for (int o = wave; o < 3 * E; o += nw) {
+    const int e = o / 3, c = o % 3;
+    float s = 0.f;
+    for (int m = lane; m < G4; m += 64) s = fmaf(a.W_ih[po + (size_t)m * E + e], c < 2 ? dA[m * 2 + c] : dB[m], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+      if (c < 2) a.dW_emb[po + e * 2 + c] += s;
+      else a.db_emb[po + e] += s;
     }
-    a.dW_emb[po + e * 2] += s0;
-    a.dW_emb[po + e * 2 + 1] += s1;
-    a.db_emb[po + e] += sb;
   }
 }
 
@@ -476,7 +477,7 @@ int mggan_lstm_unfold_grads(const float* W_emb, const float* b_emb, const float*
   MG_CHECK_ARG(W_emb && b_emb && W_ih && dW_emb && db_emb && dW_ih && db_ih && db_hh && dprep,
                "lstm_unfold_grads: null pointer");
   UnfoldArgs a = {W_emb, b_emb, W_ih, dW_emb, db_emb, dW_ih, db_ih, db_hh, param_stride, dprep, dprep_stride, H, E};
-  hipLaunchKernelGGL(lstm_unfold_kernel, dim3(n_groups, 8), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(lstm_unfold_kernel, dim3(n_groups, 12), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("lstm_unfold_grads");
   return MGGAN_OK;
 }

@@ -34,14 +34,19 @@ __device__ __forceinline__ void pair_features(const float* __restrict__ xy, cons
   f[2] = sqrtf(cx * cx + cy * cy);
 }
 
+// 64 pairs per workgroup; wave w computes hidden units [16w, 16w+16) of layer 2 for all 64 pairs
+// (its weights are wave-uniform -> scalar loads), the four partial scores meet in LDS.
 __global__ __launch_bounds__(256) void social_pairs_fwd_kernel(
     int P, const int* __restrict__ pair_i, const int* __restrict__ pair_j, const float* __restrict__ xy,
     const float* __restrict__ dxy, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ vc, float* feat, float* l1s,
     float* l2s, float* sigma) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  const int i = pair_i[p], j = pair_j[p];
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = blockIdx.x * 64 + lane;
+  const bool ok = p < P;
+  const int pc = ok ? p : P - 1;
+  const int i = pair_i[pc], j = pair_j[pc];
   float f[3];
   pair_features(xy, dxy, i, j, f);
   float l1[L1];
@@ -54,24 +59,33 @@ __global__ __launch_bounds__(256) void social_pairs_fwd_kernel(
     l1[k] = fmaxf(s, 0.f);
   }
   const float* v = vc + (size_t)j * (L2 + 1);
-  float sg = v[L2];
+  float sg = 0.f;
   const bool save = l1s != nullptr;
 #pragma unroll 4
-  for (int m = 0; m < L2; ++m) {
+  for (int mm = 0; mm < L2 / 4; ++mm) {
+    const int m = w * (L2 / 4) + mm;
     float s = b2[m];
 #pragma unroll
     for (int k = 0; k < L1; ++k) s = fmaf(W2[m * L1 + k], l1[k], s);
     s = fmaxf(s, 0.f);
-    if (save) l2s[(size_t)p * L2 + m] = s;
+    if (save && ok) l2s[(size_t)m * P + p] = s;  // feature-major: coalesced across the pair lanes
     sg = fmaf(s, v[m], sg);
   }
-  sigma[p] = (i == j) ? -1000.0f : sg;  // social.py:25
-  if (save) {
-    feat[(size_t)p * 3 + 0] = f[0];
-    feat[(size_t)p * 3 + 1] = f[1];
-    feat[(size_t)p * 3 + 2] = f[2];
+  part[w][lane] = sg;
+  if (save && ok) {
+    if (w == 0) {
+      feat[p] = f[0];
+      feat[(size_t)P + p] = f[1];
+      feat[(size_t)2 * P + p] = f[2];
+    }
 #pragma unroll
-    for (int k = 0; k < L1; ++k) l1s[(size_t)p * L1 + k] = l1[k];
+    for (int k = 0; k < L1; ++k)  // static register index; wave w stores rows [8w, 8w+8)
+      if ((k >> 3) == w) l1s[(size_t)k * P + p] = l1[k];
+  }
+  __syncthreads();
+  if (w == 0 && ok) {
+    const float tot = v[L2] + (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    sigma[p] = (i == j) ? -1000.0f : tot;  // social.py:25
   }
 }
 
@@ -149,49 +163,61 @@ __global__ __launch_bounds__(256) void social_dh_kernel(int b, const int* __rest
   *d = accumulate ? (*d + acc) : acc;
 }
 
-// per pair: dz2 = dsigma * v_j * relu'(l2), dz1 = (W2^T dz2) * relu'(l1)
+// per pair: dz2 = dsigma * v_j * relu'(l2), dz1 = (W2^T dz2) * relu'(l1); wave w owns hidden units
+// [16w, 16w+16) of layer 2, the four partial W2^T dz2 vectors are summed through LDS.
 __global__ __launch_bounds__(256) void social_pairs_bwd_kernel(int P, const int* __restrict__ pair_j,
                                                                const float* __restrict__ dsigma,
                                                                const float* __restrict__ vc,
                                                                const float* __restrict__ l1s,
                                                                const float* __restrict__ l2s,
                                                                const float* __restrict__ W2, float* dz2, float* dz1) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  const float dsg = dsigma[p];
-  const float* v = vc + (size_t)pair_j[p] * (L2 + 1);
+  __shared__ float part[4][L1][64];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = blockIdx.x * 64 + lane;
+  const bool ok = p < P;
+  const int pc = ok ? p : P - 1;
+  const float dsg = dsigma[pc];
+  const float* v = vc + (size_t)pair_j[pc] * (L2 + 1);
   float d1[L1];
 #pragma unroll
   for (int k = 0; k < L1; ++k) d1[k] = 0.f;
 #pragma unroll 4
-  for (int m = 0; m < L2; ++m) {
-    const float z = l2s[(size_t)p * L2 + m] > 0.f ? dsg * v[m] : 0.f;
-    dz2[(size_t)p * L2 + m] = z;
+  for (int mm = 0; mm < L2 / 4; ++mm) {
+    const int m = w * (L2 / 4) + mm;
+    const float z = l2s[(size_t)m * P + pc] > 0.f ? dsg * v[m] : 0.f;
+    if (ok) dz2[(size_t)m * P + p] = z;
 #pragma unroll
     for (int k = 0; k < L1; ++k) d1[k] = fmaf(W2[m * L1 + k], z, d1[k]);
   }
 #pragma unroll
-  for (int k = 0; k < L1; ++k) dz1[(size_t)p * L1 + k] = l1s[(size_t)p * L1 + k] > 0.f ? d1[k] : 0.f;
+  for (int k = 0; k < L1; ++k) part[w][k][lane] = d1[k];
+  __syncthreads();
+#pragma unroll
+  for (int kk = 0; kk < L1 / 4; ++kk) {
+    const int k = w * (L1 / 4) + kk;
+    const float t = (part[0][k][lane] + part[1][k][lane]) + (part[2][k][lane] + part[3][k][lane]);
+    if (ok) dz1[(size_t)k * P + p] = l1s[(size_t)k * P + p] > 0.f ? t : 0.f;
+  }
 }
 
 // dvc[j][m] = sum_i dsigma_ij * (m < 64 ? l2_ij[m] : 1)
-__global__ __launch_bounds__(256) void social_dvc_kernel(int b, const int* __restrict__ prow,
+__global__ __launch_bounds__(256) void social_dvc_kernel(int b, int P, const int* __restrict__ prow,
                                                          const int* __restrict__ s0a, const int* __restrict__ na,
                                                          const float* __restrict__ dsigma,
                                                          const float* __restrict__ l2s, float* dvc) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)b * (L2 + 1)) return;
-  const int j = (int)(t / (L2 + 1)), m = (int)(t % (L2 + 1));
+  const int m = (int)(t / b), j = (int)(t % b);  // lanes run over pedestrians: l2s[m][pair] reads are coalesced
   const int n = na[j];
   float acc = 0.f;
   if (n > 1) {
     const int s0 = s0a[j], lj = j - s0;
     for (int i = 0; i < n; ++i) {
       const int p = prow[s0 + i] + lj;
-      acc = fmaf(dsigma[p], m < L2 ? l2s[(size_t)p * L2 + m] : 1.0f, acc);
+      acc = fmaf(dsigma[p], m < L2 ? l2s[(size_t)m * P + p] : 1.0f, acc);
     }
   }
-  dvc[t] = acc;
+  dvc[(size_t)j * (L2 + 1) + m] = acc;
 }
 
 // W3b[f][0..63] = W3[f][:], W3b[f][64] = b3[f]
@@ -220,7 +246,7 @@ int mggan_social_pairs_fwd(int P, const int* pair_i, const int* pair_j, const fl
                "social_pairs_fwd: null pointer");
   MG_CHECK_ARG((feat == nullptr) == (l1 == nullptr) && (l1 == nullptr) == (l2 == nullptr),
                "social_pairs_fwd: save buffers must be all set or all NULL");
-  hipLaunchKernelGGL(social_pairs_fwd_kernel, dim3(cdiv(P, 256)), dim3(256), 0, stream, P, pair_i, pair_j, xy_last,
+  hipLaunchKernelGGL(social_pairs_fwd_kernel, dim3(cdiv(P, 64)), dim3(256), 0, stream, P, pair_i, pair_j, xy_last,
                      dxdy_last, W1, b1, W2, b2, vc, feat, l1, l2, sigma);
   MG_LAUNCH_CHECK("social_pairs_fwd");
   return MGGAN_OK;
@@ -262,13 +288,13 @@ int mggan_social_pairs_bwd(int P, int b, const int* pair_j, const int* ped_prow,
   MG_CHECK_ARG(ped_prow && ped_s0 && ped_n && dvc, "social_pairs_bwd: null pointer");
   if (P > 0) {
     MG_CHECK_ARG(pair_j && dsigma && vc && l1 && l2 && W2 && dz2 && dz1, "social_pairs_bwd: null pointer");
-    hipLaunchKernelGGL(social_pairs_bwd_kernel, dim3(cdiv(P, 256)), dim3(256), 0, stream, P, pair_j, dsigma, vc, l1, l2,
+    hipLaunchKernelGGL(social_pairs_bwd_kernel, dim3(cdiv(P, 64)), dim3(256), 0, stream, P, pair_j, dsigma, vc, l1, l2,
                        W2, dz2, dz1);
     MG_LAUNCH_CHECK("social_pairs_bwd");
   }
   if (b > 0) {
-    hipLaunchKernelGGL(social_dvc_kernel, dim3(cdiv((long)b * (L2 + 1), 256)), dim3(256), 0, stream, b, ped_prow, ped_s0,
-                       ped_n, dsigma, l2, dvc);
+    hipLaunchKernelGGL(social_dvc_kernel, dim3(cdiv((long)b * (L2 + 1), 256)), dim3(256), 0, stream, b, P, ped_prow,
+                       ped_s0, ped_n, dsigma, l2, dvc);
     MG_LAUNCH_CHECK("social_dvc");
   }
   return MGGAN_OK;

@@ -73,9 +73,14 @@ class MultiGeneratorGAN(abc.ABC):
             gt_dxdy, gt_xy = gt_dxdy[:, loss_mask], gt_xy[:, loss_mask]
         img = batch["features"] if "features" in batch else None
         args = (in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, metrics, loss_mask, img)
+        shared = None
+        if getattr(self, "share_trunk", False) and loss_mask is None and self.config.num_unrolling_steps == 0:
+            # G is not updated between the no-grad generator call of the D step and the G step: one trunk
+            # forward (with its backward graph) serves both; BatchNorm running stats still move twice (A.8)
+            shared = {"g_trunk": self.G.trunk(in_xy, in_dxdy, sub_batches, img, passes=2)}
         for _ in range(self.config.num_unrolling_steps + 1):
-            self.discriminator_step(*args)
-        self.generator_step(*args)
+            self.discriminator_step(*args, shared=shared)
+        self.generator_step(*args, shared=shared)
         self.net_chooser_step(*args)
 
     def capture_iteration(self, batch, warmup=3):
@@ -198,11 +203,13 @@ class MultiGeneratorGAN(abc.ABC):
                         checkpoint)
 
     @abc.abstractmethod
-    def generator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None):
+    def generator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None,
+                       shared=None):
         pass
 
     @abc.abstractmethod
-    def discriminator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None):
+    def discriminator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None,
+                           shared=None):
         pass
 
     @abc.abstractmethod

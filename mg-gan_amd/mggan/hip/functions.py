@@ -42,14 +42,14 @@ def want_grad(*tensors):
 
 
 def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scale=1, n_groups=0, w_stride=0,
-          b_stride=0):
+          b_stride=0, fm=0):
     """dW += dz^T x, db += colsum(dz)  (deterministic split reduction)."""
     if rows == 0:
         return
     nbytes = lib.mggan_wgrad_workspace_bytes(rows, K, N, n_groups)
     ws = torch.empty(nbytes // 4, dtype=F32, device=dz.device if torch.is_tensor(dz) else x.device)
     lib.mggan_wgrad(_p(dz) if torch.is_tensor(dz) else dz, lddz, _p(x) if torch.is_tensor(x) else x, ldx, dW_ptr, lddw,
-                    db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, ws.data_ptr(), nbytes, _s())
+                    db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, fm, ws.data_ptr(), nbytes, _s())
 
 
 # ------------------------------------------------------------------------------------------
@@ -203,9 +203,9 @@ class SocialAttentionFn(Function):
         lib.mggan_linear_bwd_data(_p(Wh), Fd, _p(W3b), 65, _p(vc), 65, b, 65, Fd, 0, st)
         P = tb.P
         sigma = _empty(max(P, 1), like=h)
-        feat = _empty(max(P, 1), 3, like=h) if save else None
-        l1 = _empty(max(P, 1), 32, like=h) if save else None
-        l2 = _empty(max(P, 1), 64, like=h) if save else None
+        feat = _empty(3, max(P, 1), like=h) if save else None      # feature-major [feature][pair]
+        l1 = _empty(32, max(P, 1), like=h) if save else None
+        l2 = _empty(64, max(P, 1), like=h) if save else None
         lib.mggan_social_pairs_fwd(P, _p(tb.pair_i), _p(tb.pair_j), _p(xy_last), _p(dxdy_last), _p(w1), _p(b1), _p(w2),
                                    _p(b2), _p(vc), _p(feat), _p(l1), _p(l2), _p(sigma), st)
         att = _empty(max(P, 1), like=h)
@@ -230,14 +230,14 @@ class SocialAttentionFn(Function):
         dh = _empty(b, Hh, like=h)
         lib.mggan_social_softmax_bwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(att), _p(h), ld_h, _p(dS),
                                      ld_ds, _p(dsigma), _p(dh), Hh, 0, st)
-        dz2 = _empty(max(P, 1), 64, like=h)
-        dz1 = _empty(max(P, 1), 32, like=h)
+        dz2 = _empty(64, max(P, 1), like=h)
+        dz1 = _empty(32, max(P, 1), like=h)
         dvc = _empty(b, 65, like=h)
         lib.mggan_social_pairs_bwd(P, b, _p(tb.pair_j), _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(dsigma), _p(vc),
                                    _p(l1), _p(l2), _p(w2), _p(dz2), _p(dz1), _p(dvc), st)
         if w1.requires_grad:
-            wgrad(dz2, 64, l1, 32, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64)
-            wgrad(dz1, 32, feat, 3, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32)
+            wgrad(dz2, P, l1, P, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64, fm=1)
+            wgrad(dz1, P, feat, P, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32, fm=1)
         # dWh = dvc [W3|b3]^T ; d[W3|b3] = Wh^T dvc
         dWh = _empty(b, Fd, like=h)
         lib.mggan_linear_fwd(_p(dvc), 65, _p(W3b), 0, _p(dWh), Fd, b, 65, Fd, ACT_NONE, 0.0, st)
@@ -254,7 +254,8 @@ class SceneAttentionFn(Function):
     """CNN (2 x Conv-BN-ReLU-MaxPool) + channel-softmax attention -> (B,64)  (cnn.py:109-282)."""
 
     @staticmethod
-    def forward(ctx, img, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb, bb, bn1, bn2, training, owner, sync, save):
+    def forward(ctx, img, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb, bb, bn1, bn2, training, owner, sync, save,
+                stat_updates=1):
         img = img.contiguous()
         B, C = img.shape[0], c1w.shape[0]
         st = _s()
@@ -272,9 +273,12 @@ class SceneAttentionFn(Function):
                 if sync is not None:
                     n = sync.all_reduce_stats(sums, n_img)
             scale, shift, stat = _empty(C, like=img), _empty(C, like=img), _empty(2 * C, like=img)
-            lib.mggan_bn_finalize(_p(sums), n * hw, C, 1 if training else 0, _p(gamma), _p(beta), _p(bn.running_mean),
-                                  _p(bn.running_var), _p(bn.num_batches_tracked), float(bn.momentum), float(bn.eps),
-                                  _p(scale), _p(shift), _p(stat), st)
+            # stat_updates > 1: this one forward stands for several identical reference forwards (shared
+            # history context) -> the running statistics take the momentum update that many times (A.8)
+            for _ in range(stat_updates if training else 1):
+                lib.mggan_bn_finalize(_p(sums), n * hw, C, 1 if training else 0, _p(gamma), _p(beta),
+                                      _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked),
+                                      float(bn.momentum), float(bn.eps), _p(scale), _p(shift), _p(stat), st)
             return scale, shift, stat, n * hw
 
         sc1, sh1, stat1, cnt1 = finalize(bn1, g1, be1, 33 * 33)
@@ -302,14 +306,14 @@ class SceneAttentionFn(Function):
         st = _s()
         dout, ld = _rows2d(dout)
         rows = B * 64
-        ds, vs = _empty(rows, C, like=img), _empty(rows, C, like=img)
-        hact, dz = _empty(rows, 32, like=img), _empty(rows, 32, like=img)
+        ds, vs = _empty(C, rows, like=img), _empty(C, rows, like=img)        # feature-major [feature][row]
+        hact, dz = _empty(32, rows, like=img), _empty(32, rows, like=img)
         G2 = _empty(B, C, 16, 16, like=img)
         part = _empty(B, 2 * C, like=img)
         lib.mggan_scene_attention_bwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(stat2), _p(wa), _p(ba), _p(wb), _p(bb), _p(dout),
                                       ld, _p(ds), _p(hact), _p(dz), _p(vs), _p(G2), _p(part), st)
-        wgrad(ds, C, hact, 32, root.grad_ptr(wb), 32, root.grad_ptr(bb), rows, 32, C)
-        wgrad(dz, 32, vs, C, root.grad_ptr(wa), C, root.grad_ptr(ba), rows, C, 32)
+        wgrad(ds, rows, hact, rows, root.grad_ptr(wb), 32, root.grad_ptr(bb), rows, 32, C, fm=1)
+        wgrad(dz, rows, vs, rows, root.grad_ptr(wa), C, root.grad_ptr(ba), rows, C, 32, fm=1)
 
         def bn_bwd(gamma, beta, stat, cnt):
             sums = torch.empty(2 * C, dtype=torch.float64, device=img.device)
@@ -336,7 +340,7 @@ class SceneAttentionFn(Function):
         ws = torch.empty(nb // 4, dtype=F32, device=img.device)
         lib.mggan_conv1_bwd(_p(img), B, C, _p(y1), _p(stat1), _p(coef1), _p(G1c), _p(code1), root.grad_ptr(c1w),
                             root.grad_ptr(c1b), _p(ws), nb, st)
-        return (None,) * 19
+        return (None,) * 20
 
 
 # ------------------------------------------------------------------------------------------

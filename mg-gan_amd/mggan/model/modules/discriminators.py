@@ -55,16 +55,31 @@ class MultiDiscriminatorTrajectory(FlatModule):
             pred_enc = pad.index_copy(0, mask.repeat(n_samples).nonzero().flatten(), pred_enc)
         return torch.cat([in_enc.repeat(n_samples, 1), pred_enc], dim=1)
 
-    def _encode_parts(self, in_dxdy, pred_dxdy):
-        fc, pe = self.in_encoder_fc, self.pred_encoder
+    def history_context(self, in_dxdy, img, passes=1):
+        """(in_enc (b,h/2), scene (b,64)): everything that depends only on the observed history and the
+        image crop.  The real and the fake pass of one discriminator step share it (identical inputs and
+        weights), autograd sums their cotangents, so the history LSTM and the scene CNN run forward and
+        backward once instead of twice; `passes` keeps the BatchNorm running-stat count of the reference."""
+        self.ensure_flat()
+        fc = self.in_encoder_fc
         h = self.in_encoder(in_dxdy)
         in_enc = HF.linear(HF.linear(h, fc[0], HF.ACT_LEAKY, 0.2), fc[2])
+        return in_enc, self.scene_encoder(img, stat_updates=passes)
+
+    def _encode_parts(self, in_dxdy, pred_dxdy, context=None):
+        fc, pe = self.in_encoder_fc, self.pred_encoder
+        if context is not None:
+            in_enc = context[0]
+        else:
+            h = self.in_encoder(in_dxdy)
+            in_enc = HF.linear(HF.linear(h, fc[0], HF.ACT_LEAKY, 0.2), fc[2])
         _, n_samples, b, _ = pred_dxdy.shape
         x = pred_dxdy.permute(1, 2, 0, 3).reshape(n_samples * b, -1)
         pred_enc = HF.linear(HF.linear(x, pe[0], HF.ACT_LEAKY, 0.2), pe[2])
         return in_enc, pred_enc
 
-    def forward(self, in_xy, in_dxdy, pred_xy, pred_dxdy, seq_start_end, return_all=False, img=None, mask=None):
+    def forward(self, in_xy, in_dxdy, pred_xy, pred_dxdy, seq_start_end, return_all=False, img=None, mask=None,
+                context=None):
         """Returns output (b_m, K) and, for gan_type 'mgan', branch_out (b_m, K, num_gens)."""
         if img is None:
             raise ValueError("img is mandatory: scene_dim=64 is hard-wired into the model (SURVEY A.6)")
@@ -75,12 +90,14 @@ class MultiDiscriminatorTrajectory(FlatModule):
         full_b = in_xy.size(1)
         masked = mask is not None and not bool(mask.all())  # pass mask=None (all valid) to avoid the sync
 
-        in_enc, pred_enc = self._encode_parts(in_dxdy, pred_dxdy)
+        if context is not None and masked:
+            raise ValueError("a shared history context needs mask=None (all pedestrians valid)")
+        in_enc, pred_enc = self._encode_parts(in_dxdy, pred_dxdy, context)
         if not masked:
             # social features only for sample block 0: `seq_start_end * n_samples` is LIST repetition (A.1)
             enc0 = torch.cat([in_enc, pred_enc[:full_b]], dim=1)
             soc0 = self.social(in_xy, in_dxdy, enc0, seq_start_end)
-            scene = self.scene_encoder(img)
+            scene = context[1] if context is not None else self.scene_encoder(img)
             classifier_inp = HF.DAssembleFn.apply(soc0, in_enc, pred_enc, scene, n_samples)
         else:
             enc = self.encode(in_xy, in_dxdy, pred_xy, pred_dxdy, mask)

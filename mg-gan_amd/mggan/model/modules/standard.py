@@ -90,9 +90,13 @@ class MultiGenerator(FlatModule):
             cache[key] = rows
         return rows
 
-    def trunk(self, in_xy, in_dxdy, sub_batches, img):
+    def trunk(self, in_xy, in_dxdy, sub_batches, img, passes=1):
+        """-> (enc_h (b,128) = [lstm | scene | social], social (b,32)).  `passes` > 1: the result stands
+        for that many identical reference forwards (the no-grad generator call of the discriminator step and
+        the generator step see the same weights) -> BatchNorm running stats are updated that many times."""
+        self.ensure_flat()
         enc = self.encoder(get_input(in_xy, in_dxdy, self.inp_format))
-        scene = self.scene_encoder(img)
+        scene = self.scene_encoder(img, stat_updates=passes)
         soc = self.social(in_xy, in_dxdy, enc, sub_batches)
         return torch.cat([enc, scene, soc], -1), soc
 
@@ -110,7 +114,8 @@ class MultiGenerator(FlatModule):
                                          self, HF.want_grad(enc_h, social_feats, w_hh))
 
     # -- reference surface -------------------------------------------------------------------
-    def forward(self, in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=None, num_samples=5, mask=None):
+    def forward(self, in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=None, num_samples=5, mask=None,
+                trunk=None):
         """Returns (GeneratorOutput(rel, abs), net_chooser_out (b_m, g), sampled_gen_idxs (b_m, K) int64).
         abs/rel: (pred_len, K, b_m, 2) or (pred_len, K, g, b_m, 2) when all_gen_out."""
         if img is None:
@@ -118,7 +123,7 @@ class MultiGenerator(FlatModule):
         self.ensure_flat()
         batch_size = in_xy.size(1)
         dev = in_xy.device
-        enc_h, social_feats = self.trunk(in_xy, in_dxdy, sub_batches, img)
+        enc_h, social_feats = trunk if trunk is not None else self.trunk(in_xy, in_dxdy, sub_batches, img)
 
         if noise is not None:
             assert noise.shape == (num_samples, batch_size, self.z_size)

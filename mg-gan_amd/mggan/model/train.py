@@ -42,6 +42,10 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self._w = {k: torch.full((), float(v), device=dev) for k, v in
                    (("l2", config.l2_loss_weight), ("clf", config.clf_loss_weight), ("pi", config.pi_net_loss_weight))}
         self.defer_metrics = False  # True: steps only enqueue work; fetch with flush_metrics()
+        # legitimate de-duplications (same results): D's history context once per D step, and the
+        # generator trunk once for {no-grad G call of the D step, G step} (G's weights do not change in between)
+        self.share_context = True
+        self.share_trunk = True
         self._pending = []
 
     # ---- metric plumbing ---------------------------------------------------------------
@@ -82,9 +86,13 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         return row_gen, inv
 
     # ---- the three steps -----------------------------------------------------------------
-    def discriminator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None):
+    def discriminator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None,
+                           shared=None):
         m = self._m
-        real_result = self.D(in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, img=img, mask=loss_mask)
+        # history LSTM + scene CNN of D are identical in the real and the fake pass: run them once
+        ctx = self.D.history_context(in_dxdy, img, passes=2) if (loss_mask is None and self.share_context) else None
+        g_trunk = None if shared is None else shared.get("g_trunk")
+        real_result = self.D(in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, img=img, mask=loss_mask, context=ctx)
         if isinstance(real_result, tuple):
             real_result = real_result[0]
         n_real = self._global(real_result.numel())
@@ -94,8 +102,9 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         noise = self.rng.noise(1, self.config.noise_dim, sub_batches, self.device)
         with torch.no_grad():
             gen_out, _, gen_labels_gt = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
-                                               num_samples=1, mask=loss_mask)
-        disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask)
+                                               num_samples=1, mask=loss_mask,
+                                               trunk=None if g_trunk is None else tuple(t.detach() for t in g_trunk))
+        disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask, context=ctx)
         losses = [real_loss]
         items = []
         if self.gan_type == "mgan":
@@ -119,12 +128,14 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self.optimizerD.step(self.config.clipping_threshold_d)
         self._emit(train_metrics, items)
 
-    def generator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None):
+    def generator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None,
+                       shared=None):
         m, cfg = self._m, self.config
         b = in_xy.size(1)
         noise = self.rng.noise(cfg.num_samples, cfg.noise_dim, sub_batches, self.device)
         gen_out, _, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
-                                      mask=loss_mask, num_samples=cfg.num_samples)
+                                      mask=loss_mask, num_samples=cfg.num_samples,
+                                      trunk=None if shared is None else shared.get("g_trunk"))
         losses, grads, items = [], [], []
         if cfg.l2_loss_type != "none":
             tb = HF.scene_tables(sub_batches, gen_out.abs.shape[2], self.device)

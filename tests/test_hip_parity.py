@@ -203,3 +203,41 @@ def test_predict_and_ade_fde(golden):
     m = compute_metrics_from_batch(pa.cpu(), bt["gt_xy"].cpu(), bt["seq_start_end"], mode="raw")
     for k in ("ADE", "FDE", "Mode"):
         np.testing.assert_allclose(m[k], golden["e/" + k], rtol=1e-3)
+
+
+def test_shared_context_iteration_matches_reference(golden):
+    """train_iteration with the de-duplicated history context / generator trunk (mask=None fast path)
+    reproduces the reference's three iterations: losses, parameters (relL2 1e-3) and BatchNorm counters."""
+    from mggan.rng import ReplayRNG
+
+    tr = make_trainer(golden)
+    assert tr.share_context and tr.share_trunk
+    bt = batch_from(golden, DEV)
+    bt["loss_mask"] = None
+    for it in range(1, 4):
+        labels, noise, idxs = [], [], []
+        for step in ("d", "g", "pm"):
+            p = "s{}_{}".format(it, step)
+            lab = golden.get(p + "/labels")
+            labels += [] if lab is None else [tuple(r) for r in lab]
+            noise.append(torch.from_numpy(golden[p + "/noise"].copy()))
+            idxs.append(torch.from_numpy(golden[p + "/gen_idxs"].copy()))
+        tr.rng = tr.G.rng = ReplayRNG(labels=labels, noise=noise, gen_idxs=idxs)
+        m = defaultdict(list)
+        tr.train_iteration(bt, m)
+        for step in ("d", "g", "pm"):
+            p = "s{}_{}".format(it, step)
+            for key in [k for k in golden if k.startswith(p + "/metric/")]:
+                name, ref = key.split("/metric/")[1], float(golden[key])
+                assert abs(m[name][0] - ref) <= 1e-3 * abs(ref) + 1e-6, (p, name, m[name][0], ref)
+        if it in (1, 3):
+            for mod, pre in ((tr.G, "G"), (tr.D, "D")):
+                ref = sd_from(golden, pre + str(it))
+                sd = {k: v.cpu() for k, v in mod.state_dict().items()}
+                fl = [k for k in ref if ref[k].is_floating_point()]
+                a = torch.cat([sd[k].flatten().double() for k in fl]).numpy()
+                r = torch.cat([ref[k].flatten().double() for k in fl]).numpy()
+                assert rel_l2(a, r) <= 1e-3, (pre, it, rel_l2(a, r))
+                for k in ref:
+                    if not ref[k].is_floating_point():
+                        assert int(sd[k]) == int(ref[k]), k
