@@ -308,6 +308,7 @@ __global__ __launch_bounds__(BR_THREADS) void bucket_rows_kernel(const long long
     int seen[BR_MAXG];
 #pragma unroll
     for (int q = 0; q < BR_MAXG; ++q) seen[q] = 0;
+#pragma unroll 4
     for (int k = 0; k < K; ++k) {
       const int gi = (int)idx[(size_t)ped * K + k];
       int slot = 0;
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(BR_THREADS) void bucket_rows_kernel(const long long
   int local[BR_MAXG];
 #pragma unroll
   for (int q = 0; q < BR_MAXG; ++q) local[q] = 0;
+#pragma unroll 8
   for (int pos = lo; pos < hi; ++pos) {
     const int gi = row_gen_pos[pos];
 #pragma unroll
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(BR_THREADS) void bucket_rows_kernel(const long long
   __syncthreads();
   if (t < g) {
     int run = 0;
+#pragma unroll 16
     for (int i = 0; i < BR_THREADS; ++i) { const int c = cnt[i][t]; cnt[i][t] = run; run += c; }
     base[t] = run;
   }
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(BR_THREADS) void bucket_rows_kernel(const long long
   // phase C: scatter
 #pragma unroll
   for (int q = 0; q < BR_MAXG; ++q) local[q] = 0;
+#pragma unroll 4
   for (int pos = lo; pos < hi; ++pos) {
     const int gi = row_gen_pos[pos], slot = inv[pos];
     int off = 0;

@@ -41,13 +41,65 @@ def want_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+# Weight-gradient GEMMs are off the critical path of a backward pass (nothing consumes them before the
+# optimizer step).  When enabled (the trainer does), they are issued on a side stream so that they overlap
+# the latency-bound input-gradient chain; `join_side_stream()` (called before clip+AdamW / gradient
+# all-reduce) makes the main stream wait for them.  Inside a HIP-graph capture this becomes a parallel branch.
+_SIDE = {"on": False, "stream": None, "keep": [], "dirty": False}
+
+
+def enable_side_stream(on=True):
+    _SIDE["on"] = bool(on)
+
+
+def _side_stream():
+    if _SIDE["stream"] is None:
+        _SIDE["stream"] = torch.cuda.Stream()
+    return _SIDE["stream"]
+
+
+class side_stream:
+    """Context: kernels launched inside run on the side stream, ordered after everything already queued on
+    the main stream.  Tensors passed in `keep` stay referenced until join_side_stream()."""
+
+    def __init__(self, *keep):
+        self.keep = keep
+
+    def __enter__(self):
+        if not _SIDE["on"]:
+            self.ctx = None
+            return self
+        side = _side_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        _SIDE["keep"].extend(self.keep)
+        _SIDE["dirty"] = True
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_side_stream():
+    if _SIDE["dirty"]:
+        torch.cuda.current_stream().wait_stream(_side_stream())
+        _SIDE["keep"].clear()
+        _SIDE["dirty"] = False
+
+
 def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scale=1, n_groups=0, w_stride=0,
           b_stride=0, fm=0):
-    """dW += dz^T x, db += colsum(dz)  (deterministic split reduction)."""
+    """dW += dz^T x, db += colsum(dz)  (deterministic split reduction).  Call inside `with side_stream(...)`
+    to take it off the critical path."""
     if rows == 0:
         return
     nbytes = lib.mggan_wgrad_workspace_bytes(rows, K, N, n_groups)
     ws = torch.empty(nbytes // 4, dtype=F32, device=dz.device if torch.is_tensor(dz) else x.device)
+    if _SIDE["dirty"]:
+        _SIDE["keep"].append(ws)
     lib.mggan_wgrad(_p(dz) if torch.is_tensor(dz) else dz, lddz, _p(x) if torch.is_tensor(x) else x, ldx, dW_ptr, lddw,
                     db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, fm, ws.data_ptr(), nbytes, _s())
 
@@ -85,7 +137,8 @@ class LinearFn(Function):
             lib.mggan_linear_bwd_data(_p(dz), lddz, _p(W), K, _p(dx), K, rows, K, N, 0, _s())
         if W.requires_grad:
             root = root_of(ctx.owner)
-            wgrad(dz, lddz, x, ctx.ldx, root.grad_ptr(W), K, root.grad_ptr(b) if b is not None else 0, rows, K, N)
+            with side_stream(dz, x):
+                wgrad(dz, lddz, x, ctx.ldx, root.grad_ptr(W), K, root.grad_ptr(b) if b is not None else 0, rows, K, N)
         return dx, None, None, None, None, None
 
 
@@ -128,12 +181,13 @@ class LstmEncoderFn(Function):
         dPre = _empty(b, T, 4 * H, like=dh)
         lib.mggan_lstm_encoder_bwd(_p(dh), ld, T, b, H, _p(w_hh), _p(prep), _p(Gt), _p(Cs), _p(dPre), _s())
         rows = b * T
-        wgrad(dPre, 4 * H, Hp, H, root.grad_ptr(w_hh), H, 0, rows, H, 4 * H)
+        gp = [root.grad_ptr(t) for t in (w_hh, emb_w, emb_b, w_ih, b_ih, b_hh)]
         dprep = torch.zeros(12 * H, dtype=F32, device=dh.device)
-        wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, rows, 2, 4 * H)
-        lib.mggan_lstm_unfold_grads(_p(emb_w), _p(emb_b), _p(w_ih), root.grad_ptr(emb_w), root.grad_ptr(emb_b),
-                                    root.grad_ptr(w_ih), root.grad_ptr(b_ih), root.grad_ptr(b_hh), 0, 1, H, E,
-                                    _p(dprep), 12 * H, _s())
+        with side_stream(dPre, Hp, Din, dprep):
+            wgrad(dPre, 4 * H, Hp, H, gp[0], H, 0, rows, H, 4 * H)
+            wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, rows, 2, 4 * H)
+            lib.mggan_lstm_unfold_grads(_p(emb_w), _p(emb_b), _p(w_ih), gp[1], gp[2], gp[3], gp[4], gp[5], 0, 1, H, E,
+                                        _p(dprep), 12 * H, _s())
         return (None,) * 9
 
 
@@ -236,15 +290,17 @@ class SocialAttentionFn(Function):
         lib.mggan_social_pairs_bwd(P, b, _p(tb.pair_j), _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(dsigma), _p(vc),
                                    _p(l1), _p(l2), _p(w2), _p(dz2), _p(dz1), _p(dvc), st)
         if w1.requires_grad:
-            wgrad(dz2, P, l1, P, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64, fm=1)
-            wgrad(dz1, P, feat, P, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32, fm=1)
+            with side_stream(dz2, dz1, l1, feat):
+                wgrad(dz2, P, l1, P, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64, fm=1)
+                wgrad(dz1, P, feat, P, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32, fm=1)
         # dWh = dvc [W3|b3]^T ; d[W3|b3] = Wh^T dvc
         dWh = _empty(b, Fd, like=h)
         lib.mggan_linear_fwd(_p(dvc), 65, _p(W3b), 0, _p(dWh), Fd, b, 65, Fd, ACT_NONE, 0.0, st)
         if w3.requires_grad:
-            wgrad(Wh, Fd, dvc, 65, root.grad_ptr(w3), 64, 0, b, 64, Fd)
-            wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, 65, root.grad_ptr(b3), 1, 0, b, 1, Fd)
-            wgrad(dWh, Fd, h, ld_h, root.grad_ptr(wat), Hh, root.grad_ptr(bat), b, Hh, Fd)
+            with side_stream(Wh, dvc, dWh, h):
+                wgrad(Wh, Fd, dvc, 65, root.grad_ptr(w3), 64, 0, b, 64, Fd)
+                wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, 65, root.grad_ptr(b3), 1, 0, b, 1, Fd)
+                wgrad(dWh, Fd, h, ld_h, root.grad_ptr(wat), Hh, root.grad_ptr(bat), b, Hh, Fd)
         lib.mggan_linear_bwd_data(_p(dWh), Fd, _p(wat), Hh, _p(dh), Hh, b, Hh, Fd, 1, st)
         return (None, None, dh if ctx.needs_input_grad[2] else None) + (None,) * 11
 
@@ -312,8 +368,9 @@ class SceneAttentionFn(Function):
         part = _empty(B, 2 * C, like=img)
         lib.mggan_scene_attention_bwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(stat2), _p(wa), _p(ba), _p(wb), _p(bb), _p(dout),
                                       ld, _p(ds), _p(hact), _p(dz), _p(vs), _p(G2), _p(part), st)
-        wgrad(ds, rows, hact, rows, root.grad_ptr(wb), 32, root.grad_ptr(bb), rows, 32, C, fm=1)
-        wgrad(dz, rows, vs, rows, root.grad_ptr(wa), C, root.grad_ptr(ba), rows, C, 32, fm=1)
+        with side_stream(ds, hact, dz, vs):
+            wgrad(ds, rows, hact, rows, root.grad_ptr(wb), 32, root.grad_ptr(bb), rows, 32, C, fm=1)
+            wgrad(dz, rows, vs, rows, root.grad_ptr(wa), C, root.grad_ptr(ba), rows, C, 32, fm=1)
 
         def bn_bwd(gamma, beta, stat, cnt):
             sums = torch.empty(2 * C, dtype=torch.float64, device=img.device)
@@ -441,18 +498,22 @@ class DecoderRolloutFn(Function):
             # them: all decoders are in the graph, a generator without rows gets a zero gradient
             for p in owner.generator_parameters():
                 gp(p)
-            wgrad(dPre, 4 * H, Hp, H, gp(g0["w_hh"]), H, 0, R * T, H, 4 * H, seg, T, ng, stride, stride)
+            ptr = {k: gp(v) for k, v in g0.items()}
             dprep = torch.zeros(n_gens, 12 * H, dtype=F32, device=dev)
-            wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, R * T, 2, 4 * H, seg, T, ng,
-                  12 * H, 12 * H)
-            lib.mggan_lstm_unfold_grads(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), gp(g0["emb_w"]),
-                                        gp(g0["emb_b"]), gp(g0["w_ih"]), gp(g0["b_ih"]), gp(g0["b_hh"]), stride, ng, H,
-                                        E, _p(dprep), 12 * H, st)
-            wgrad(dU, Hh, Hc, H, gp(g0["w1"]), H + S, gp(g0["b1"]), R * T, H, Hh, seg, T, ng, stride, stride)
-            wgrad(dQ, Hh, SocR, S, gp(g0["w1"]) + 4 * H, H + S, 0, R, S, Hh, seg, 1, ng, stride, stride)
-            wgrad(gD, 2, Aact, Hh, gp(g0["w2"]), Hh, gp(g0["b2"]), R * T, Hh, 2, seg, T, ng, stride, stride)
+            with side_stream(dPre, Hp, Din, dU, Hc, dQ, SocR, gD, Aact, dprep, prep):
+                wgrad(dPre, 4 * H, Hp, H, ptr["w_hh"], H, 0, R * T, H, 4 * H, seg, T, ng, stride, stride)
+                wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, R * T, 2, 4 * H, seg, T,
+                      ng, 12 * H, 12 * H)
+                lib.mggan_lstm_unfold_grads(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), ptr["emb_w"],
+                                            ptr["emb_b"], ptr["w_ih"], ptr["b_ih"], ptr["b_hh"], stride, ng, H, E,
+                                            _p(dprep), 12 * H, _s())
+                wgrad(dU, Hh, Hc, H, ptr["w1"], H + S, ptr["b1"], R * T, H, Hh, seg, T, ng, stride, stride)
+                wgrad(dQ, Hh, SocR, S, ptr["w1"] + 4 * H, H + S, 0, R, S, Hh, seg, 1, ng, stride, stride)
+                wgrad(gD, 2, Aact, Hh, ptr["w2"], Hh, ptr["b2"], R * T, Hh, 2, seg, T, ng, stride, stride)
         if e2d_w.requires_grad:
-            wgrad(dH0, H, E2Din, EIN + Z, root.grad_ptr(e2d_w), EIN + Z, root.grad_ptr(e2d_b), R, EIN + Z, H)
+            pw, pb = root.grad_ptr(e2d_w), root.grad_ptr(e2d_b)
+            with side_stream(dH0, E2Din):
+                wgrad(dH0, H, E2Din, EIN + Z, pw, EIN + Z, pb, R, EIN + Z, H)
         d_enc = d_soc = None
         if ctx.needs_input_grad[0]:
             d_enc = mk(b, EIN)

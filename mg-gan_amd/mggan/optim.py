@@ -32,6 +32,9 @@ class FlatAdamW:
         r = self.root
         if r._flat.data_ptr() != self._flat_id:
             raise RuntimeError("the module's flat parameter buffer was rebuilt after the optimizer was created")
+        from mggan.hip.functions import join_side_stream
+
+        join_side_stream()  # weight-gradient GEMMs issued on the side stream must have landed
         mask = r.touched_mask()
         st = torch.cuda.current_stream().cuda_stream
         lib.mggan_clip_adamw(r._flat.data_ptr(), r._flat_grad.data_ptr(), self.exp_avg.data_ptr(),

@@ -79,6 +79,9 @@ class DistContext:
     def all_reduce_grads(self, root):
         """C1: one collective over the whole flat gradient buffer."""
         if self.enabled:
+            from mggan.hip.functions import join_side_stream
+
+            join_side_stream()
             dist.all_reduce(root._flat_grad, op=dist.ReduceOp.SUM, group=self.group)
 
     def attach(self, *roots):
