@@ -53,6 +53,12 @@ size_t mggan_wgrad_workspace_bytes(int rows, int K, int N, int n_groups);
 int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, int lddw, float* db, int rows, int K,
                 int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, int feature_major,
                 void* workspace, size_t workspace_bytes, mggan_stream_t stream);
+/* Deferred reduction: mggan_wgrad with dW == NULL only writes its partial sums into `workspace`
+ * ([groups*splits][N*(K+1)]); mggan_grad_reduce_multi then folds MANY such partial buffers into the
+ * gradient buffers in one launch.  descs = host array of n structs
+ *   { const float* P; float* dW; float* db; long w_stride, b_stride;
+ *     int M, Naug, has_bias, lddw, splits, groups, p_stride, block0(ignored); }                          */
+int mggan_grad_reduce_multi(const void* descs, int n, mggan_stream_t stream);
 int mggan_transpose(const float* W, float* WT, int N, int K, mggan_stream_t stream);
 /* dst[ped][c] (+)= sum_k src[inv[k*b+ped]][c] : adjoint of "repeat over samples" */
 int mggan_gather_sum(const float* src, int ld_src, const int* inv, float* dst, int ld_dst, int b, int K, int ncols,

@@ -680,8 +680,7 @@ int mggan_conv2_bwd(const float* y1, int B, int C, const float* scale1, const fl
                     size_t workspace_bytes, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv2_bwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
-  MG_CHECK_ARG(y1 && scale1 && shift1 && stat1 && y2 && G2 && stat2 && coef2 && W && G1c && code1 && part1 && dW && db &&
-                   workspace,
+  MG_CHECK_ARG(y1 && scale1 && shift1 && stat1 && y2 && G2 && stat2 && coef2 && W && G1c && code1 && part1 && workspace,
                "conv2_bwd: null pointer");
   const int grid = persistent_grid(B), NQ = 256 / (C * C), wlen = C * C * 9 + C;
   const size_t need = (size_t)grid * NQ * wlen * sizeof(float);
@@ -696,6 +695,7 @@ int mggan_conv2_bwd(const float* y1, int B, int C, const float* scale1, const fl
     hipLaunchKernelGGL((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, y1, scale1, shift1, stat1, y2, G2,
                        stat2, coef2, W, G1c, code1, part1, workspace);
   MG_LAUNCH_CHECK("conv2_bwd");
+  if (!dW) return MGGAN_OK;  // deferred reduce of the [grid][C*C*9 + C] partial rows
   hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(1024), 0, stream, workspace, grid, wlen,
                      C * C * 9, dW);
   hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, workspace + C * C * 9, grid, wlen,
@@ -710,7 +710,7 @@ int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float
                     size_t workspace_bytes, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv1_bwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
-  MG_CHECK_ARG(img && y1 && stat1 && coef1 && G1c && code1 && dW && db && workspace, "conv1_bwd: null pointer");
+  MG_CHECK_ARG(img && y1 && stat1 && coef1 && G1c && code1 && workspace, "conv1_bwd: null pointer");
   const int grid = persistent_grid(B) * 2, NQ = 8, wlen = 4 * C * 9 + C;
   const size_t need = (size_t)grid * NQ * wlen * sizeof(float);
   if (workspace_bytes < need) {
@@ -736,6 +736,7 @@ int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float
                        workspace);
   }
   MG_LAUNCH_CHECK("conv1_bwd");
+  if (!dW) return MGGAN_OK;  // deferred reduce of the [grid][4*C*9 + C] partial rows
   hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(4 * C * 9, 64)), dim3(1024), 0, stream, workspace, grid, wlen,
                      4 * C * 9, dW);
   hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, workspace + 4 * C * 9, grid, wlen,

@@ -183,6 +183,59 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
+// ---- deferred, batched reduction of many weight-gradient partial buffers in ONE launch ----------
+// (a backward pass produces ~20 independent partial buffers; reducing each with its own launch costs
+// more in launch latency than in work)
+#define MG_MAX_REDUCE 24
+struct ReduceDesc {
+  const float* P;   // partials: [groups*splits][p_stride]
+  float* dW;
+  float* db;
+  long w_stride, b_stride;
+  int M, Naug, has_bias, lddw, splits, groups, p_stride, block0;  // block0: first block of this descriptor
+};
+struct ReduceBatch {
+  ReduceDesc d[MG_MAX_REDUCE];
+  int n;
+};
+
+__global__ __launch_bounds__(1024) void grad_reduce_multi_kernel(ReduceBatch bt) {
+  __shared__ float red[16][64];
+  int di = 0;
+#pragma unroll 1
+  for (int i = 1; i < bt.n; ++i)
+    if ((int)blockIdx.x >= bt.d[i].block0) di = i;
+  const ReduceDesc& D = bt.d[di];
+  const int total = D.M * D.Naug;
+  const int bpg = (total + 63) / 64;  // blocks per group
+  const int rel = blockIdx.x - D.block0;
+  const int grp = rel / bpg;
+  const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const int o = (rel % bpg) * 64 + lane;
+  float s = 0.f;
+  if (o < total) {
+    const float* p = D.P + ((size_t)grp * D.splits) * D.p_stride + o;
+    float s0 = 0.f, s1 = 0.f;
+    int z = zl;
+    for (; z + 16 < D.splits; z += 32) { s0 += p[(size_t)z * D.p_stride]; s1 += p[(size_t)(z + 16) * D.p_stride]; }
+    if (z < D.splits) s0 += p[(size_t)z * D.p_stride];
+    s = s0 + s1;
+  }
+  red[zl][lane] = s;
+  __syncthreads();
+  if (zl == 0 && o < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][lane];
+    const int m = o / D.Naug, n = o % D.Naug;
+    if (D.has_bias && n == D.Naug - 1) {
+      if (D.db) D.db[grp * D.b_stride + m] += t;
+    } else {
+      D.dW[grp * D.w_stride + (size_t)m * D.lddw + n] += t;
+    }
+  }
+}
+
 // dZ = dY * act'(Y)
 __global__ void act_bwd_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ Y, int ldy,
                                float* __restrict__ dZ, int lddz, int rows, int N, int act, float slope) {
@@ -251,10 +304,29 @@ int mggan_wgrad_splits(int rows, int K, int N, int n_groups) {
   return s;
 }
 
+int mggan_grad_reduce_multi(const void* descs, int n, hipStream_t stream) {
+  MG_CHECK_ARG(descs || n == 0, "grad_reduce_multi: null descriptor array");
+  const ReduceDesc* in = (const ReduceDesc*)descs;
+  for (int i0 = 0; i0 < n; i0 += MG_MAX_REDUCE) {
+    ReduceBatch bt;
+    bt.n = n - i0 < MG_MAX_REDUCE ? n - i0 : MG_MAX_REDUCE;
+    int blocks = 0;
+    for (int i = 0; i < bt.n; ++i) {
+      bt.d[i] = in[i0 + i];
+      MG_CHECK_ARG(bt.d[i].P && bt.d[i].dW && bt.d[i].splits > 0 && bt.d[i].groups > 0, "grad_reduce_multi: bad descriptor");
+      bt.d[i].block0 = blocks;
+      blocks += cdiv((long)bt.d[i].M * bt.d[i].Naug, 64) * bt.d[i].groups;
+    }
+    hipLaunchKernelGGL(grad_reduce_multi_kernel, dim3(blocks), dim3(1024), 0, stream, bt);
+    MG_LAUNCH_CHECK("grad_reduce_multi");
+  }
+  return MGGAN_OK;
+}
+
 int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, int lddw, float* db, int rows, int K,
                 int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, int feature_major,
                 void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  MG_CHECK_ARG(dZ && X && dW && K > 0 && N > 0, "wgrad: bad arguments");
+  MG_CHECK_ARG(dZ && X && K > 0 && N > 0, "wgrad: bad arguments");
   if (rows == 0) return MGGAN_OK;
   const int ng = n_groups > 0 ? n_groups : 1;
   MG_CHECK_ARG(ng == 1 || seg, "wgrad: grouped mode needs segment offsets");
@@ -274,6 +346,7 @@ int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, i
   if (feature_major) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
   else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
   MG_LAUNCH_CHECK("wgrad");
+  if (!dW) return MGGAN_OK;  // deferred: the caller reduces the partials later (mggan_grad_reduce_multi)
   dim3 rgrid(cdiv((long)N * Naug, 64), ng, 1);
   hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(1024), 0, stream, (const float*)workspace, dW, db, N, Naug, 1,
                      lddw, splits, w_stride, b_stride);

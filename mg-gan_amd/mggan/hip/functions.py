@@ -6,6 +6,8 @@ tensors are storage only.  Parameter gradients are accumulated by the kernels
 into the root module's flat gradient buffer (hip/flat.py), so backward returns
 None for parameter inputs.
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -90,8 +92,54 @@ def join_side_stream():
         _SIDE["dirty"] = False
 
 
+class _ReduceDesc(ctypes.Structure):
+    _fields_ = [("P", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("w_stride", ctypes.c_long),
+                ("b_stride", ctypes.c_long), ("M", ctypes.c_int), ("Naug", ctypes.c_int), ("has_bias", ctypes.c_int),
+                ("lddw", ctypes.c_int), ("splits", ctypes.c_int), ("groups", ctypes.c_int), ("p_stride", ctypes.c_int),
+                ("block0", ctypes.c_int)]
+
+
+# Deferred gradient reduction: inside the trainer's backward every weight-gradient kernel only leaves its
+# partial sums behind; ONE batched launch per optimizer step folds them all into the flat gradient buffer.
+_DEFER = {"on": False, "descs": [], "keep": []}
+
+
+def defer_grad_reduce(on=True):
+    _DEFER["on"] = bool(on)
+
+
+def _queue_reduce(P, dW, db, M, Naug, has_bias, lddw, splits, groups, p_stride, w_stride=0, b_stride=0, keep=()):
+    _DEFER["descs"].append(_ReduceDesc(P, dW, db or None, w_stride, b_stride, M, Naug, has_bias, lddw, splits, groups,
+                                       p_stride, 0))
+    _DEFER["keep"].extend(keep)
+
+
+def flush_grad_reduces():
+    """Batched reduce.  Two partial buffers that accumulate into the SAME gradient tensor (e.g. the real and
+    the fake pass of a discriminator step) must not share a launch: batches are cut at such conflicts."""
+    d = _DEFER["descs"]
+    if not d:
+        return
+    batch, seen = [], set()
+
+    def launch():
+        if batch:
+            arr = (_ReduceDesc * len(batch))(*batch)
+            lib.mggan_grad_reduce_multi(ctypes.addressof(arr), len(batch), _s())
+
+    for desc in d:
+        keys = {desc.dW} | ({desc.db} if desc.db else set())
+        if (keys & seen) or len(batch) == 24:
+            launch()
+            batch, seen = [], set()
+        batch.append(desc)
+        seen |= keys
+    launch()
+    _DEFER["descs"], _DEFER["keep"] = [], []
+
+
 def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scale=1, n_groups=0, w_stride=0,
-          b_stride=0, fm=0):
+          b_stride=0, fm=0, now=False):
     """dW += dz^T x, db += colsum(dz)  (deterministic split reduction).  Call inside `with side_stream(...)`
     to take it off the critical path."""
     if rows == 0:
@@ -100,8 +148,14 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
     ws = torch.empty(nbytes // 4, dtype=F32, device=dz.device if torch.is_tensor(dz) else x.device)
     if _SIDE["dirty"]:
         _SIDE["keep"].append(ws)
-    lib.mggan_wgrad(_p(dz) if torch.is_tensor(dz) else dz, lddz, _p(x) if torch.is_tensor(x) else x, ldx, dW_ptr, lddw,
-                    db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, fm, ws.data_ptr(), nbytes, _s())
+    defer = _DEFER["on"] and not _SIDE["dirty"] and not now  # now=True: the result is consumed right away
+    lib.mggan_wgrad(_p(dz) if torch.is_tensor(dz) else dz, lddz, _p(x) if torch.is_tensor(x) else x, ldx,
+                    0 if defer else dW_ptr, lddw, db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, fm,
+                    ws.data_ptr(), nbytes, _s())
+    if defer:
+        ng = max(n_groups, 1)
+        _queue_reduce(ws.data_ptr(), dW_ptr, db_ptr, N, K + 1, 1, lddw, lib.mggan_wgrad_splits(rows, K, N, n_groups), ng,
+                      N * (K + 1), w_stride, b_stride, keep=(ws,))
 
 
 # ------------------------------------------------------------------------------------------
@@ -185,7 +239,7 @@ class LstmEncoderFn(Function):
         dprep = torch.zeros(12 * H, dtype=F32, device=dh.device)
         with side_stream(dPre, Hp, Din, dprep):
             wgrad(dPre, 4 * H, Hp, H, gp[0], H, 0, rows, H, 4 * H)
-            wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, rows, 2, 4 * H)
+            wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, rows, 2, 4 * H, now=True)
             lib.mggan_lstm_unfold_grads(_p(emb_w), _p(emb_b), _p(w_ih), gp[1], gp[2], gp[3], gp[4], gp[5], 0, 1, H, E,
                                         _p(dprep), 12 * H, _s())
         return (None,) * 9
@@ -390,13 +444,24 @@ class SceneAttentionFn(Function):
         grid = lib.mggan_cnn_bwd_grid(B)
         nb = grid * (256 // (C * C)) * (C * C * 9 + C) * 4
         ws = torch.empty(nb // 4, dtype=F32, device=img.device)
+        defer = _DEFER["on"]
+        pw, pb = root.grad_ptr(c2w), root.grad_ptr(c2b)
         lib.mggan_conv2_bwd(_p(y1), B, C, _p(sc1), _p(sh1), _p(stat1), _p(y2), _p(G2), _p(stat2), _p(coef2), _p(c2w),
-                            _p(G1c), _p(code1), _p(part), root.grad_ptr(c2w), root.grad_ptr(c2b), _p(ws), nb, st)
+                            _p(G1c), _p(code1), _p(part), 0 if defer else pw, 0 if defer else pb, _p(ws), nb, st)
+        if defer:
+            wl = C * C * 9 + C
+            _queue_reduce(ws.data_ptr(), pw, 0, 1, C * C * 9, 0, C * C * 9, grid, 1, wl, keep=(ws,))
+            _queue_reduce(ws.data_ptr() + 4 * C * C * 9, pb, 0, 1, C, 0, C, grid, 1, wl)
         coef1 = bn_bwd(g1, be1, stat1, cnt1)
         nb = 2 * grid * 8 * (4 * C * 9 + C) * 4
         ws = torch.empty(nb // 4, dtype=F32, device=img.device)
-        lib.mggan_conv1_bwd(_p(img), B, C, _p(y1), _p(stat1), _p(coef1), _p(G1c), _p(code1), root.grad_ptr(c1w),
-                            root.grad_ptr(c1b), _p(ws), nb, st)
+        pw, pb = root.grad_ptr(c1w), root.grad_ptr(c1b)
+        lib.mggan_conv1_bwd(_p(img), B, C, _p(y1), _p(stat1), _p(coef1), _p(G1c), _p(code1), 0 if defer else pw,
+                            0 if defer else pb, _p(ws), nb, st)
+        if defer:
+            wl = 4 * C * 9 + C
+            _queue_reduce(ws.data_ptr(), pw, 0, 1, 4 * C * 9, 0, 4 * C * 9, 2 * grid, 1, wl, keep=(ws,))
+            _queue_reduce(ws.data_ptr() + 4 * 4 * C * 9, pb, 0, 1, C, 0, C, 2 * grid, 1, wl)
         return (None,) * 20
 
 
@@ -503,7 +568,7 @@ class DecoderRolloutFn(Function):
             with side_stream(dPre, Hp, Din, dU, Hc, dQ, SocR, gD, Aact, dprep, prep):
                 wgrad(dPre, 4 * H, Hp, H, ptr["w_hh"], H, 0, R * T, H, 4 * H, seg, T, ng, stride, stride)
                 wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, R * T, 2, 4 * H, seg, T,
-                      ng, 12 * H, 12 * H)
+                      ng, 12 * H, 12 * H, now=True)
                 lib.mggan_lstm_unfold_grads(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), ptr["emb_w"],
                                             ptr["emb_b"], ptr["w_ih"], ptr["b_ih"], ptr["b_hh"], stride, ng, H, E,
                                             _p(dprep), 12 * H, _s())

@@ -89,11 +89,14 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
 
     def _backward(self, losses, grads):
         HF.enable_side_stream(self.overlap_wgrad)
+        HF.defer_grad_reduce(True)  # weight-grad kernels leave partial sums; one batched reduce below
         try:
             torch.autograd.backward(losses, grads)
         finally:
             HF.enable_side_stream(False)
+            HF.defer_grad_reduce(False)
         HF.join_side_stream()
+        HF.flush_grad_reduces()
 
     # ---- the three steps -----------------------------------------------------------------
     def discriminator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None,
