@@ -40,9 +40,11 @@ int mggan_linear_fwd(const float* X, int ldx, const float* W, const float* bias,
 /* dZ = dY * act'(Y)  (Y = activation OUTPUT) */
 int mggan_act_bwd(const float* dY, int lddy, const float* Y, int ldy, float* dZ, int lddz, int rows, int N, int act,
                   float slope, mggan_stream_t stream);
-/* dX (rows x K) (+)= dZ (rows x N) . W (N x K, row stride ldw) */
+/* dX (rows x K) (+)= dZ (rows x N) . W (N x K, row stride ldw).  If Yact != NULL the activation derivative is
+ * fused into the operand load: dZ = dY * act'(Yact) with dY passed as `dZ` (no separate mggan_act_bwd launch). */
 int mggan_linear_bwd_data(const float* dZ, int lddz, const float* W, int ldw, float* dX, int lddx, int rows, int K,
-                          int N, int accumulate, mggan_stream_t stream);
+                          int N, int accumulate, const float* Yact, int ld_yact, int act, float slope,
+                          mggan_stream_t stream);
 /* dW[g] (N x K, row stride lddw) += dZ_g^T X_g ; db[g] (N) += colsum(dZ_g).  Rows may be
  * split in n_groups contiguous segments seg[0..n_groups] (device int32, multiplied by
  * seg_scale) with per-group outputs w_stride / b_stride floats apart (per-generator
@@ -52,7 +54,8 @@ size_t mggan_wgrad_workspace_bytes(int rows, int K, int N, int n_groups);
 /* feature_major != 0: dZ is stored [N][lddz] and X [K][ldx] (element (row, f) at p[f*ld + row]) */
 int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, int lddw, float* db, int rows, int K,
                 int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, int feature_major,
-                void* workspace, size_t workspace_bytes, mggan_stream_t stream);
+                const float* Yact, int ld_yact, int act, float slope, void* workspace, size_t workspace_bytes,
+                mggan_stream_t stream);
 /* Deferred reduction: mggan_wgrad with dW == NULL only writes its partial sums into `workspace`
  * ([groups*splits][N*(K+1)]); mggan_grad_reduce_multi then folds MANY such partial buffers into the
  * gradient buffers in one launch.  descs = host array of n structs
@@ -134,6 +137,13 @@ int mggan_bn_reduce(const float* part, int B, int W, double* sums, mggan_stream_
 int mggan_bn_finalize(const double* sums, double count, int C, int training, const float* gamma, const float* beta,
                       float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps,
                       float* scale, float* shift, float* stat, mggan_stream_t stream);
+/* single-GPU fast path: mggan_bn_reduce + mggan_bn_finalize (x `updates` running-stat updates) in ONE launch,
+ * and the same for the backward statistics */
+int mggan_bn_stats_finalize(const float* part, int B, double count, int C, const float* gamma, const float* beta,
+                            float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps,
+                            int updates, float* scale, float* shift, float* stat, mggan_stream_t stream);
+int mggan_bn_bwd_stats_finalize(const float* part, int B, double count, int C, const float* gamma, const float* stat,
+                                float* coef, float* dgamma, float* dbeta, mggan_stream_t stream);
 /* sums: (sum g, sum g*xhat) over the GLOBAL batch (after the all-reduce); local_sums: this rank's share */
 int mggan_bn_bwd_finalize(const double* sums, const double* local_sums, double count, int C, const float* gamma,
                           const float* stat, float* coef, float* dgamma, float* dbeta, mggan_stream_t stream);

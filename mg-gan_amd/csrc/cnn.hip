@@ -144,6 +144,80 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   stat[C + c] = invstd;
 }
 
+// Single-GPU fast path: column sums of the per-image partials AND the finalize step in one launch.
+// 1024 threads: 32 row-groups x (up to) 32 columns, f64 accumulation, fixed order.
+__device__ __forceinline__ void bn_colsum_block(const float* __restrict__ part, int B, int W, double* colsum /*LDS [W]*/,
+                                                double* red /*LDS [32][32]*/) {
+  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  double acc = 0.0;
+  if (col < W) {
+    // 8 independent loads in flight per lane (a single block must hide the HBM latency by itself)
+    int r = rg;
+    for (; r + 7 * 32 < B; r += 8 * 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(r + u * 32) * W + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; r < B; r += 32) acc += (double)part[(size_t)r * W + col];
+  }
+  red[rg * 32 + col] = acc;
+  __syncthreads();
+  if (threadIdx.x < W) {
+    double t = 0.0;
+    for (int i = 0; i < 32; ++i) t += red[i * 32 + threadIdx.x];
+    colsum[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ part, int B, double count,
+                                                                 int C, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* run_mean,
+                                                                 float* run_var, long long* nbt, float momentum,
+                                                                 float eps, int updates, float* scale, float* shift,
+                                                                 float* stat) {
+  __shared__ double red[32 * 32], sums[32];
+  bn_colsum_block(part, B, 2 * C, sums, red);
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const double m = sums[c] / count;
+  double v = sums[C + c] / count - m * m;
+  if (v < 0.0) v = 0.0;
+  const float mean = (float)m, var = (float)v;
+  const float unb = (float)(count > 1.0 ? v * count / (count - 1.0) : v);
+  float rm = run_mean[c], rv = run_var[c];
+  for (int u = 0; u < updates; ++u) {
+    rm = (1.f - momentum) * rm + momentum * mean;
+    rv = (1.f - momentum) * rv + momentum * unb;
+  }
+  run_mean[c] = rm;
+  run_var[c] = rv;
+  if (c == 0) *nbt += updates;
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  stat[c] = mean;
+  stat[C + c] = invstd;
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_stats_finalize_kernel(const float* __restrict__ part, int B, double count,
+                                                                     int C, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ stat, float* coef,
+                                                                     float* dgamma, float* dbeta) {
+  __shared__ double red[32 * 32], sums[32];
+  bn_colsum_block(part, B, 2 * C, sums, red);
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  coef[c] = gamma[c] * stat[C + c];
+  coef[C + c] = (float)(sums[c] / count);
+  coef[2 * C + c] = (float)(sums[C + c] / count);
+  dbeta[c] += (float)sums[c];
+  dgamma[c] += (float)sums[C + c];
+}
+
 // sums = (sum g, sum g*xhat) -> coef[0..C)=gamma*invstd, [C..2C)=mean(g), [2C..3C)=mean(g*xhat); dgamma/dbeta +=
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ local,
                                        double count, int C,
@@ -613,6 +687,26 @@ int mggan_bn_finalize(const double* sums, double count, int C, int training, con
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, count, C, training, gamma, beta, run_mean,
                      run_var, num_batches_tracked, momentum, eps, scale, shift, stat);
   MG_LAUNCH_CHECK("bn_finalize");
+  return MGGAN_OK;
+}
+
+int mggan_bn_stats_finalize(const float* part, int B, double count, int C, const float* gamma, const float* beta,
+                            float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps,
+                            int updates, float* scale, float* shift, float* stat, hipStream_t stream) {
+  MG_CHECK_ARG(part && gamma && beta && run_mean && run_var && num_batches_tracked && scale && shift && stat && C <= 16,
+               "bn_stats_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(1024), 0, stream, part, B, count, C, gamma, beta, run_mean,
+                     run_var, num_batches_tracked, momentum, eps, updates, scale, shift, stat);
+  MG_LAUNCH_CHECK("bn_stats_finalize");
+  return MGGAN_OK;
+}
+
+int mggan_bn_bwd_stats_finalize(const float* part, int B, double count, int C, const float* gamma, const float* stat,
+                                float* coef, float* dgamma, float* dbeta, hipStream_t stream) {
+  MG_CHECK_ARG(part && gamma && stat && coef && dgamma && dbeta && C <= 16, "bn_bwd_stats_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_stats_finalize_kernel, dim3(1), dim3(1024), 0, stream, part, B, count, C, gamma, stat, coef,
+                     dgamma, dbeta);
+  MG_LAUNCH_CHECK("bn_bwd_stats_finalize");
   return MGGAN_OK;
 }
 

@@ -37,10 +37,14 @@ struct GemmArgs {
   const int* seg;     // optional group row offsets (n_groups+1), scaled by seg_scale
   int seg_scale;
   int n_groups;
+  // optional fused activation derivative on the A operand: A(row, n) *= act'(Yact[row*ld_yact + n])
+  const float* Yact;
+  int ld_yact, act_a;
+  float slope_a;
 };
 
 // Global -> register fetch of one BMxBK (A) and BNxBK (B) tile; 8 + 8 elements per lane.
-template <bool A_KM, bool B_KM>
+template <bool A_KM, bool B_KM, bool ACT>
 __device__ __forceinline__ void gemm_fetch(const GemmArgs& g, int m0, int n0, int k0, int k_end, float ra[8],
                                            float rb[8]) {
   const int tid = threadIdx.x;
@@ -52,7 +56,13 @@ __device__ __forceinline__ void gemm_fetch(const GemmArgs& g, int m0, int n0, in
       if (A_KM) { kd = e >> 6; m = e & 63; } else { m = e >> 5; kd = e & 31; }
       const int gk = k0 + kd, gm = m0 + m;
       float v = 0.f;
-      if (gk < k_end && gm < g.M) v = A_KM ? g.A[(size_t)gk * g.lda + gm] : g.A[(size_t)gm * g.lda + gk];
+      if (gk < k_end && gm < g.M) {
+        v = A_KM ? g.A[(size_t)gk * g.lda + gm] : g.A[(size_t)gm * g.lda + gk];
+        if (ACT) {  // (row, feature) = (gk, gm) for k-major A (weight grad), (gm, gk) for k-minor A (input grad)
+          const float y = A_KM ? g.Yact[(size_t)gk * g.ld_yact + gm] : g.Yact[(size_t)gm * g.ld_yact + gk];
+          v *= mg_act_grad_from_out(y, g.act_a, g.slope_a);
+        }
+      }
       ra[i] = v;
     }
     {
@@ -69,7 +79,7 @@ __device__ __forceinline__ void gemm_fetch(const GemmArgs& g, int m0, int n0, in
   }
 }
 
-template <bool A_KM, bool B_KM>
+template <bool A_KM, bool B_KM, bool ACT = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BK][LDT];
   __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   // software pipeline: the global loads of tile k+1 are in flight while tile k is multiplied
   float ra[8], rb[8];
-  if (k_begin < k_end) gemm_fetch<A_KM, B_KM>(g, m0, n0, k_begin, k_end, ra, rb);
+  if (k_begin < k_end) gemm_fetch<A_KM, B_KM, ACT>(g, m0, n0, k_begin, k_end, ra, rb);
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       if (B_KM) Bs[e >> 6][e & 63] = rb[i]; else Bs[e & 31][e >> 5] = rb[i];
     }
     __syncthreads();
-    if (k0 + BK < k_end) gemm_fetch<A_KM, B_KM>(g, m0, n0, k0 + BK, k_end, ra, rb);
+    if (k0 + BK < k_end) gemm_fetch<A_KM, B_KM, ACT>(g, m0, n0, k0 + BK, k_end, ra, rb);
 #pragma unroll
     for (int kd = 0; kd < BK; ++kd) {
       const float4 a = *reinterpret_cast<const float4*>(&As[kd][4 * ty]);
@@ -273,7 +283,8 @@ int mggan_act_bwd(const float* dY, int lddy, const float* Y, int ldy, float* dZ,
 }
 
 int mggan_linear_bwd_data(const float* dZ, int lddz, const float* W, int ldw, float* dX, int lddx, int rows, int K,
-                          int N, int accumulate, hipStream_t stream) {
+                          int N, int accumulate, const float* Yact, int ld_yact, int act, float slope,
+                          hipStream_t stream) {
   MG_CHECK_ARG(dZ && W && dX && K > 0 && N > 0, "linear_bwd_data: bad arguments");
   if (rows == 0) return MGGAN_OK;
   GemmArgs g = {};
@@ -281,7 +292,12 @@ int mggan_linear_bwd_data(const float* dZ, int lddz, const float* W, int ldw, fl
   g.M = rows; g.N = K; g.K = N; g.lda = lddz; g.ldb = ldw; g.ldc = lddx;
   g.accumulate = accumulate;
   dim3 grid(cdiv(K, BN), cdiv(rows, BM), 1);
-  hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, stream, g);
+  if (Yact && act != ACT_NONE) {
+    g.Yact = Yact; g.ld_yact = ld_yact; g.act_a = act; g.slope_a = slope;
+    hipLaunchKernelGGL((gemm_kernel<false, true, true>), grid, dim3(256), 0, stream, g);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, stream, g);
+  }
   MG_LAUNCH_CHECK("linear_bwd_data");
   return MGGAN_OK;
 }
@@ -325,7 +341,8 @@ int mggan_grad_reduce_multi(const void* descs, int n, hipStream_t stream) {
 
 int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, int lddw, float* db, int rows, int K,
                 int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, int feature_major,
-                void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                const float* Yact, int ld_yact, int act, float slope, void* workspace, size_t workspace_bytes,
+                hipStream_t stream) {
   MG_CHECK_ARG(dZ && X && K > 0 && N > 0, "wgrad: bad arguments");
   if (rows == 0) return MGGAN_OK;
   const int ng = n_groups > 0 ? n_groups : 1;
@@ -341,9 +358,14 @@ int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, i
   g.A = dZ; g.B = X; g.C = (float*)workspace;
   g.M = N; g.N = Naug; g.K = rows; g.lda = lddz; g.ldb = ldx; g.ldc = Naug;
   g.splits = splits; g.ones_col = 1; g.seg = seg; g.seg_scale = seg_scale > 0 ? seg_scale : 1; g.n_groups = ng;
+  if (Yact && act != ACT_NONE) {
+    MG_CHECK_ARG(!feature_major, "wgrad: fused activation derivative needs row-major operands");
+    g.Yact = Yact; g.ld_yact = ld_yact; g.act_a = act; g.slope_a = slope;
+  }
   dim3 grid(cdiv(Naug, BN), cdiv(N, BM), splits * ng);
   // feature_major: operands stored [feature][row] (written coalesced by one-lane-per-row kernels)
   if (feature_major) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  else if (g.Yact) hipLaunchKernelGGL((gemm_kernel<true, true, true>), grid, dim3(256), 0, stream, g);
   else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
   MG_LAUNCH_CHECK("wgrad");
   if (!dW) return MGGAN_OK;  // deferred: the caller reduces the partials later (mggan_grad_reduce_multi)

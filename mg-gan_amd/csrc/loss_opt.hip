@@ -219,8 +219,12 @@ __global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float* __restrict__ grad, long n,
                                                                const int* __restrict__ elem_seg,
                                                                const unsigned char* __restrict__ active,
-                                                               double* partial) {
+                                                               double* partial, int nseg, int* seg_step) {
   __shared__ double red[256];
+  // Adam step counters of the touched tensors advance here (the update kernel that follows reads them)
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nseg; i += 256)
+      if (active[i]) seg_step[i] += 1;
   double acc = 0.0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)NORM_BLOCKS * 256) {
     const int sg = elem_seg[i];
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, float* grad, f
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int sg = elem_seg[i];
     if (sg < 0 || !active[sg]) continue;
-    const int t = seg_step[sg] + 1;
+    const int t = seg_step[sg];  // already advanced by gradnorm_partial_kernel
     const float g = grad[i] * coef;
     grad[i] = g;  // clip_grad_norm_ scales .grad in place
     // torch.optim.AdamW single-tensor path: scalar factors in double, tensor math in f32
@@ -495,12 +499,11 @@ int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, cons
   MG_CHECK_ARG(param && grad && m && v && elem_seg && active && seg_step && workspace, "clip_adamw: null pointer");
   if (n == 0) return MGGAN_OK;
   hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, grad, n, elem_seg, active,
-                     workspace);
+                     workspace, nseg, seg_step);
   int blocks = cdiv(n, 256 * 4);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, m, v, n, elem_seg, active, seg_step,
                      workspace, max_norm, lr, beta1, beta2, eps, weight_decay, norm_out);
-  hipLaunchKernelGGL(adam_inc_kernel, dim3(cdiv(nseg, 256)), dim3(256), 0, stream, nseg, active, seg_step);
   MG_LAUNCH_CHECK("clip_adamw");
   return MGGAN_OK;
 }

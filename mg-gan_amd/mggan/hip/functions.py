@@ -139,7 +139,7 @@ def flush_grad_reduces():
 
 
 def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scale=1, n_groups=0, w_stride=0,
-          b_stride=0, fm=0, now=False):
+          b_stride=0, fm=0, now=False, yact=None, ld_yact=0, act=0, slope=0.0):
     """dW += dz^T x, db += colsum(dz)  (deterministic split reduction).  Call inside `with side_stream(...)`
     to take it off the critical path."""
     if rows == 0:
@@ -151,7 +151,7 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
     defer = _DEFER["on"] and not _SIDE["dirty"] and not now  # now=True: the result is consumed right away
     lib.mggan_wgrad(_p(dz) if torch.is_tensor(dz) else dz, lddz, _p(x) if torch.is_tensor(x) else x, ldx,
                     0 if defer else dW_ptr, lddw, db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, fm,
-                    ws.data_ptr(), nbytes, _s())
+                    _p(yact), ld_yact, act, float(slope), ws.data_ptr(), nbytes, _s())
     if defer:
         ng = max(n_groups, 1)
         _queue_reduce(ws.data_ptr(), dW_ptr, db_ptr, N, K + 1, 1, lddw, lib.mggan_wgrad_splits(rows, K, N, n_groups), ng,
@@ -179,6 +179,8 @@ class LinearFn(Function):
         rows, K = x.shape
         N = W.shape[0]
         dy, lddy = _rows2d(dy)
+        # (the C ABI can fuse dY*act'(Y) into the GEMM operand loads, but measured on MI355X the extra operand
+        # stream costs ~11 us per GEMM against ~5 us for this elementwise launch, so it stays separate)
         if ctx.act != ACT_NONE:
             dz = _empty(rows, N, like=x)
             lib.mggan_act_bwd(_p(dy), lddy, _p(y), N, _p(dz), N, rows, N, ctx.act, float(ctx.slope), _s())
@@ -188,7 +190,7 @@ class LinearFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _empty(rows, K, like=x)
-            lib.mggan_linear_bwd_data(_p(dz), lddz, _p(W), K, _p(dx), K, rows, K, N, 0, _s())
+            lib.mggan_linear_bwd_data(_p(dz), lddz, _p(W), K, _p(dx), K, rows, K, N, 0, 0, 0, 0, 0.0, _s())
         if W.requires_grad:
             root = root_of(ctx.owner)
             with side_stream(dz, x):
@@ -308,7 +310,7 @@ class SocialAttentionFn(Function):
         W3b = _empty(Fd, 65, like=h)
         lib.mggan_social_w3b(_p(w3), _p(b3), _p(W3b), Fd, st)
         vc = _empty(b, 65, like=h)
-        lib.mggan_linear_bwd_data(_p(Wh), Fd, _p(W3b), 65, _p(vc), 65, b, 65, Fd, 0, st)
+        lib.mggan_linear_bwd_data(_p(Wh), Fd, _p(W3b), 65, _p(vc), 65, b, 65, Fd, 0, 0, 0, 0, 0.0, st)
         P = tb.P
         sigma = _empty(max(P, 1), like=h)
         feat = _empty(3, max(P, 1), like=h) if save else None      # feature-major [feature][pair]
@@ -355,7 +357,7 @@ class SocialAttentionFn(Function):
                 wgrad(Wh, Fd, dvc, 65, root.grad_ptr(w3), 64, 0, b, 64, Fd)
                 wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, 65, root.grad_ptr(b3), 1, 0, b, 1, Fd)
                 wgrad(dWh, Fd, h, ld_h, root.grad_ptr(wat), Hh, root.grad_ptr(bat), b, Hh, Fd)
-        lib.mggan_linear_bwd_data(_p(dWh), Fd, _p(wat), Hh, _p(dh), Hh, b, Hh, Fd, 1, st)
+        lib.mggan_linear_bwd_data(_p(dWh), Fd, _p(wat), Hh, _p(dh), Hh, b, Hh, Fd, 1, 0, 0, 0, 0.0, st)
         return (None, None, dh if ctx.needs_input_grad[2] else None) + (None,) * 11
 
 
@@ -377,6 +379,12 @@ class SceneAttentionFn(Function):
         def finalize(bn, gamma, beta, hw):
             sums = None
             n = n_img
+            if training and sync is None:  # single GPU: column sums + finalize (+ repeated stat updates) in one launch
+                scale, shift, stat = _empty(C, like=img), _empty(C, like=img), _empty(2 * C, like=img)
+                lib.mggan_bn_stats_finalize(_p(part), B, n * hw, C, _p(gamma), _p(beta), _p(bn.running_mean),
+                                            _p(bn.running_var), _p(bn.num_batches_tracked), float(bn.momentum),
+                                            float(bn.eps), stat_updates, _p(scale), _p(shift), _p(stat), st)
+                return scale, shift, stat, n * hw
             if training:
                 sums = torch.empty(2 * C, dtype=torch.float64, device=img.device)
                 lib.mggan_bn_reduce(_p(part), B, 2 * C, _p(sums), st)
@@ -427,6 +435,11 @@ class SceneAttentionFn(Function):
             wgrad(dz, rows, vs, rows, root.grad_ptr(wa), C, root.grad_ptr(ba), rows, C, 32, fm=1)
 
         def bn_bwd(gamma, beta, stat, cnt):
+            if sync is None:
+                coef = _empty(3 * C, like=img)
+                lib.mggan_bn_bwd_stats_finalize(_p(part), B, cnt, C, _p(gamma), _p(stat), _p(coef), root.grad_ptr(gamma),
+                                                root.grad_ptr(beta), st)
+                return coef
             sums = torch.empty(2 * C, dtype=torch.float64, device=img.device)
             lib.mggan_bn_reduce(_p(part), B, 2 * C, _p(sums), st)
             local = sums
@@ -617,10 +630,20 @@ class DAssembleFn(Function):
 
 
 # ---------------------------------------- losses -------------------------------------------
+_UNIT_GRADS = set()
+
+
+def register_unit_grad(t):
+    """Tell the loss Functions that this device scalar is exactly 1.0 (skips the scaling launch)."""
+    _UNIT_GRADS.add(t.data_ptr())
+
+
 def _scaled(grad, g):
     """grad *= g (g: 0-dim device tensor from autograd) without a host sync."""
     if g is None:
         return None
+    if g.data_ptr() in _UNIT_GRADS:
+        return grad
     g = g.reshape(1).to(F32)
     lib.mggan_scale(_p(grad), grad.numel(), _p(g), _s())
     return grad

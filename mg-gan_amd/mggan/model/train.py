@@ -39,7 +39,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         dev = self.device
         self._m = torch.zeros(M_PROBS + 64, dtype=torch.float32, device=dev)
         self._one = torch.ones((), device=dev)
-        self._w = {k: torch.full((), float(v), device=dev) for k, v in
+        HF.register_unit_grad(self._one)
+        self._w = {k: (self._one if float(v) == 1.0 else torch.full((), float(v), device=dev)) for k, v in
                    (("l2", config.l2_loss_weight), ("clf", config.clf_loss_weight), ("pi", config.pi_net_loss_weight))}
         self.defer_metrics = False  # True: steps only enqueue work; fetch with flush_metrics()
         # legitimate de-duplications (same results): D's history context once per D step, and the

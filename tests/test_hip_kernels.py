@@ -46,7 +46,7 @@ def test_linear_fwd_bwd_wgrad(rows, K, N, act):
     lib.mggan_act_bwd(dYd.data_ptr(), N, Y.data_ptr(), N, dZ.data_ptr(), N, rows, N, act, slope, st())
     np.testing.assert_allclose(dZ.cpu().numpy(), dZ_ref.numpy(), rtol=1e-4, atol=1e-6)
     dX = torch.full((rows, K), 1.0, device=dev)
-    lib.mggan_linear_bwd_data(dZ.data_ptr(), N, Wd.data_ptr(), K, dX.data_ptr(), K, rows, K, N, 1, st())
+    lib.mggan_linear_bwd_data(dZ.data_ptr(), N, Wd.data_ptr(), K, dX.data_ptr(), K, rows, K, N, 1, 0, 0, 0, 0.0, st())
     np.testing.assert_allclose(dX.cpu().numpy(), (dZ_ref.double() @ W.double()).float().numpy() + 1.0, rtol=1e-4,
                                atol=1e-4)
     dW = torch.full((N, K), 0.5, device=dev)
@@ -54,15 +54,26 @@ def test_linear_fwd_bwd_wgrad(rows, K, N, act):
     nb = lib.mggan_wgrad_workspace_bytes(rows, K, N, 0)
     ws = torch.empty(nb // 4, device=dev)
     lib.mggan_wgrad(dZ.data_ptr(), N, Xd.data_ptr(), ldx, dW.data_ptr(), K, db.data_ptr(), rows, K, N, 0, 1, 0, 0, 0,
-                    0, ws.data_ptr(), nb, st())
+                    0, 0, 0, 0, 0.0, ws.data_ptr(), nb, st())
     dW_ref = dZ_ref.double().t() @ X.double()
     np.testing.assert_allclose(dW.cpu().numpy(), dW_ref.float().numpy() + 0.5, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(db.cpu().numpy(), dZ_ref.double().sum(0).float().numpy(), rtol=1e-4, atol=1e-4)
+    # fused activation derivative (dY and Y in, no act_bwd launch) gives the same input / weight gradients
+    if act != 0:
+        dX3 = torch.zeros(rows, K, device=dev)
+        lib.mggan_linear_bwd_data(dYd.data_ptr(), N, Wd.data_ptr(), K, dX3.data_ptr(), K, rows, K, N, 0, Y.data_ptr(), N,
+                                  act, slope, st())
+        np.testing.assert_allclose(dX3.cpu().numpy(), (dZ_ref.double() @ W.double()).float().numpy(), rtol=1e-4, atol=1e-4)
+        dW3, db3 = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+        lib.mggan_wgrad(dYd.data_ptr(), N, Xd.data_ptr(), ldx, dW3.data_ptr(), K, db3.data_ptr(), rows, K, N, 0, 1, 0, 0,
+                        0, 0, Y.data_ptr(), N, act, slope, ws.data_ptr(), nb, st())
+        np.testing.assert_allclose(dW3.cpu().numpy(), dW_ref.float().numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(db3.cpu().numpy(), dZ_ref.double().sum(0).float().numpy(), rtol=1e-4, atol=1e-4)
     # feature-major operands ([feature][row]) give the same result
     dZt, Xt = dZ.t().contiguous(), Xd[:, :K].t().contiguous()
     dW2, db2 = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
     lib.mggan_wgrad(dZt.data_ptr(), rows, Xt.data_ptr(), rows, dW2.data_ptr(), K, db2.data_ptr(), rows, K, N, 0, 1, 0, 0,
-                    0, 1, ws.data_ptr(), nb, st())
+                    0, 1, 0, 0, 0, 0.0, ws.data_ptr(), nb, st())
     np.testing.assert_allclose(dW2.cpu().numpy(), dW_ref.float().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(db2.cpu().numpy(), dZ_ref.double().sum(0).float().numpy(), rtol=1e-4, atol=1e-4)
 
@@ -81,7 +92,7 @@ def test_wgrad_grouped_segments():
     ws = torch.empty(nb // 4, device=dev)
     dZd, Xd, segd = dZ.to(dev), X.to(dev), seg.to(dev)
     lib.mggan_wgrad(dZd.data_ptr(), N, Xd.data_ptr(), K, dW.data_ptr(), K, db.data_ptr(), R * T, K, N,
-                    segd.data_ptr(), T, ng, stride, stride, 0, ws.data_ptr(), nb, st())
+                    segd.data_ptr(), T, ng, stride, stride, 0, 0, 0, 0, 0.0, ws.data_ptr(), nb, st())
     for gi in range(ng):
         a, b = int(seg[gi]) * T, int(seg[gi + 1]) * T
         ref = dZ[a:b].double().t() @ X[a:b].double()
