@@ -135,11 +135,18 @@ struct SeqArgs {
   float *Gt, *Cs, *Hp, *Hc, *Din, *Aact, *E2Din, *SocR;
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// Instruction-issue bound kernel (SQ_ACTIVE_INST ~ wave cycles at one wave per SIMD), so the step loop is
+// written for few instructions and <= 256 registers (two waves per SIMD):
+//  * the four gates are two packed pairs (i,f) / (g,o): one v_pk_fma_f32 does two gate MACs per lane;
+//  * hidden2pos: all 32 lanes of a row work (two halves of the K range, combined with one shuffle);
+//  * dxdy = W2 a + b2 is a 16-lane shuffle reduction of per-lane products (no LDS round trip, no barrier).
 template <int H, bool DEC>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
   constexpr int RT = 256 / H, G4 = 4 * H, Hh = H / 2, S = H;
   __shared__ __attribute__((aligned(16))) float hbuf[RT][H];
-  __shared__ __attribute__((aligned(16))) float abuf[RT][Hh];
   __shared__ __attribute__((aligned(16))) float xin[DEC ? RT : 1][DEC ? 160 : 4];
   __shared__ __attribute__((aligned(16))) float we2d[DEC ? 160 * H : 4];  // W_e2d^T staged once per workgroup
   const int rr = threadIdx.x / H, j = threadIdx.x % H;
@@ -151,19 +158,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
   const float* WT = P + prep_off_whhT(H);
   const bool save = p.Gt != nullptr;
 
-  float whh[4][H], a0[4], a1[4], bs[4];
+  v2f wp[2][H], ap0[2], ap1[2], bp[2];  // pair 0 = gates (i,f), pair 1 = gates (g,o)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < 2; ++q) {
 #pragma unroll
-    for (int k = 0; k < H; ++k) whh[q][k] = WT[k * G4 + q * H + j];
-    a0[q] = P[prep_off_A(H) + (q * H + j) * 2];
-    a1[q] = P[prep_off_A(H) + (q * H + j) * 2 + 1];
-    bs[q] = P[prep_off_bias(H) + q * H + j];
+    for (int k = 0; k < H; ++k) wp[q][k] = v2f{WT[k * G4 + (2 * q) * H + j], WT[k * G4 + (2 * q + 1) * H + j]};
+    ap0[q] = v2f{P[prep_off_A(H) + ((2 * q) * H + j) * 2], P[prep_off_A(H) + ((2 * q + 1) * H + j) * 2]};
+    ap1[q] = v2f{P[prep_off_A(H) + ((2 * q) * H + j) * 2 + 1], P[prep_off_A(H) + ((2 * q + 1) * H + j) * 2 + 1]};
+    bp[q] = v2f{P[prep_off_bias(H) + (2 * q) * H + j], P[prep_off_bias(H) + (2 * q + 1) * H + j]};
   }
 
   float hj = 0.f, c = 0.f, d0 = 0.f, d1 = 0.f, x0 = 0.f, x1 = 0.f;
-  float w1h[DEC ? H : 1], w2a[DEC ? Hh : 1], w2b[DEC ? Hh : 1];
-  float qv = 0.f, b20 = 0.f, b21 = 0.f;
+  float w1q[DEC ? Hh : 1];
+  float qv = 0.f, w20 = 0.f, w21 = 0.f, b20 = 0.f, b21 = 0.f;
+  const int um = j & (Hh - 1), uhalf = j / Hh;  // hidden2pos unit / K-half owned by this lane (H == 2*Hh)
   int pos = 0;
   if (DEC) {
     const int ped = p.row_ped[rc], slot = p.row_slot[rc];
@@ -178,10 +186,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
     for (int i = threadIdx.x; i < IN * H; i += 256) we2d[i] = p.We2dT[i];
     lds_barrier();
     // h0 = W_e2d [enc_h | noise] + b   (standard.py:247-252)
-    float h0 = p.be2d[j];
-#pragma unroll 8
-    for (int k = 0; k < IN; ++k) h0 = fmaf(we2d[k * H + j], xin[rr][k], h0);
-    hj = h0;
+    float h0 = p.be2d[j], h1 = 0.f, h2 = 0.f, h3 = 0.f;
+    int k = 0;
+    for (; k + 3 < IN; k += 4) {
+      h0 = fmaf(we2d[k * H + j], xin[rr][k], h0);
+      h1 = fmaf(we2d[(k + 1) * H + j], xin[rr][k + 1], h1);
+      h2 = fmaf(we2d[(k + 2) * H + j], xin[rr][k + 2], h2);
+      h3 = fmaf(we2d[(k + 3) * H + j], xin[rr][k + 3], h3);
+    }
+    for (; k < IN; ++k) h0 = fmaf(we2d[k * H + j], xin[rr][k], h0);
+    hj = (h0 + h1) + (h2 + h3);
     // time-invariant social half of hidden2pos: q = W1[:,H:] soc + b1
     const float* w1T = P + prep_off_w1T(H);
     const float* b1 = w1T + (H + S) * Hh;
@@ -191,19 +205,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
     hbuf[rr][j] = sv;  // reuse hbuf as the social row for the q product
     if (save && valid) p.SocR[(size_t)r * S + j] = sv;
     lds_barrier();
-    if (j < Hh) {
-      qv = b1[j];
+    qv = b1[um];
 #pragma unroll
-      for (int k = 0; k < S; ++k) qv = fmaf(w1T[(H + k) * Hh + j], hbuf[rr][k], qv);
+    for (int kk = 0; kk < S; ++kk) qv = fmaf(w1T[(H + kk) * Hh + um], hbuf[rr][kk], qv);
 #pragma unroll
-      for (int k = 0; k < H; ++k) w1h[k] = w1T[k * Hh + j];
-    }
-#pragma unroll
-    for (int m = 0; m < Hh; ++m) { w2a[m] = w2[m]; w2b[m] = w2[Hh + m]; }
+    for (int kk = 0; kk < Hh; ++kk) w1q[kk] = w1T[(uhalf * Hh + kk) * Hh + um];
+    w20 = w2[um]; w21 = w2[Hh + um];
     b20 = b2[0]; b21 = b2[1];
-    const int pd = p.row_ped[rc];
-    d0 = p.dxdy0[pd * 2]; d1 = p.dxdy0[pd * 2 + 1];
-    x0 = p.xy0[pd * 2];   x1 = p.xy0[pd * 2 + 1];
+    d0 = p.dxdy0[ped * 2]; d1 = p.dxdy0[ped * 2 + 1];
+    x0 = p.xy0[ped * 2];   x1 = p.xy0[ped * 2 + 1];
     lds_barrier();
   }
   hbuf[rr][j] = hj;
@@ -225,15 +235,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
       p.Hp[rt * H + j] = hj;
       if (j == 0) { p.Din[rt * 2] = d0; p.Din[rt * 2 + 1] = d1; }
     }
-    float pre[4];
+    v2f acc[2][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float s = fmaf(a1[q], d1, fmaf(a0[q], d0, bs[q]));
-#pragma unroll
-      for (int k = 0; k < H; ++k) s = fmaf(whh[q][k], hv[k], s);
-      pre[q] = s;
+    for (int q = 0; q < 2; ++q) {
+      acc[q][0] = pk_fma(ap0[q], v2f{d0, d0}, bp[q]);
+      acc[q][1] = ap1[q] * v2f{d1, d1};
     }
-    const float gi = mg_sigmoid(pre[0]), gf = mg_sigmoid(pre[1]), gg = mg_tanh(pre[2]), go = mg_sigmoid(pre[3]);
+#pragma unroll
+    for (int k = 0; k < H; k += 2) {
+      const v2f ha = v2f{hv[k], hv[k]}, hb = v2f{hv[k + 1], hv[k + 1]};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        acc[q][0] = pk_fma(wp[q][k], ha, acc[q][0]);
+        acc[q][1] = pk_fma(wp[q][k + 1], hb, acc[q][1]);
+      }
+    }
+    const v2f pif = acc[0][0] + acc[0][1], pgo = acc[1][0] + acc[1][1];
+    const float gi = mg_sigmoid(pif.x), gf = mg_sigmoid(pif.y), gg = mg_tanh(pgo.x), go = mg_sigmoid(pgo.y);
     c = fmaf(gf, c, gi * gg);
     hj = go * mg_tanh(c);
     if (save && valid) {
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
       p.Cs[rt * H + j] = c;
       if (DEC) p.Hc[rt * H + j] = hj;
     }
-    lds_barrier();
+    lds_barrier();  // every lane of the row has consumed the previous h
     hbuf[rr][j] = hj;
     lds_barrier();
 #pragma unroll
@@ -253,22 +271,29 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
       hv[k] = t4.x; hv[k + 1] = t4.y; hv[k + 2] = t4.z; hv[k + 3] = t4.w;
     }
     if (DEC) {
-      if (j < Hh) {
-        float u = qv;
+      // u = W1[:, :H] h + q : lane (um, uhalf) sums its half of the K range, the halves meet via one shuffle
+      float u0 = 0.f, u1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < H; ++k) u = fmaf(w1h[k], hv[k], u);
-        const float av = u > 0.f ? u : 0.01f * u;  // LeakyReLU(0.01), utils.py:143-144
-        abuf[rr][j] = av;
-        if (save && valid) p.Aact[rt * Hh + j] = av;
+      for (int kk = 0; kk < Hh; kk += 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(&hbuf[rr][uhalf * Hh + kk]);
+        u0 = fmaf(w1q[kk], t4.x, u0);
+        u1 = fmaf(w1q[kk + 1], t4.y, u1);
+        u0 = fmaf(w1q[kk + 2], t4.z, u0);
+        u1 = fmaf(w1q[kk + 3], t4.w, u1);
       }
-      lds_barrier();
-      float n0 = b20, n1 = b21;
+      float u = u0 + u1;
+      u += __shfl_xor(u, Hh, 64);
+      u += qv;
+      const float av = u > 0.f ? u : 0.01f * u;  // LeakyReLU(0.01), utils.py:143-144
+      if (save && valid && j < Hh) p.Aact[rt * Hh + j] = av;
+      // dxdy = W2 a + b2: 16-lane butterfly over the per-lane products (both halves hold the same values)
+      float n0 = w20 * av, n1 = w21 * av;
 #pragma unroll
-      for (int m = 0; m < Hh; ++m) {
-        const float av = abuf[rr][m];
-        n0 = fmaf(w2a[m], av, n0);
-        n1 = fmaf(w2b[m], av, n1);
+      for (int o = Hh / 2; o > 0; o >>= 1) {
+        n0 += __shfl_xor(n0, o, 64);
+        n1 += __shfl_xor(n1, o, 64);
       }
+      n0 += b20; n1 += b21;
       d0 = n0; d1 = n1;
       x0 += n0; x1 += n1;
       if (valid && j == 0) {
@@ -314,9 +339,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
   const long po = (long)grp * p.param_stride;
   const float* P = p.prep + (size_t)grp * p.prep_stride;
 
-  float whc[G4];  // column j of W_hh: dh_prev[j] = sum_m W_hh[m][j] dpre[m]
+  v2f whc[G4 / 2];  // column j of W_hh in packed pairs: dh_prev[j] = sum_m W_hh[m][j] dpre[m]
 #pragma unroll
-  for (int m = 0; m < G4; ++m) whc[m] = p.W_hh[po + (size_t)m * H + j];
+  for (int m = 0; m < G4; m += 2) whc[m / 2] = v2f{p.W_hh[po + (size_t)m * H + j], p.W_hh[po + (size_t)(m + 1) * H + j]};
   float a0[4], a1[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -367,8 +392,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
         if (valid) p.dU[rt * Hh + j] = du;
       }
       lds_barrier();
+      float e0 = 0.f, e1 = 0.f;
 #pragma unroll
-      for (int m = 0; m < Hh; ++m) dh = fmaf(w1c[m], dubuf[rr][m], dh);
+      for (int m = 0; m < Hh; m += 2) {
+        e0 = fmaf(w1c[m], dubuf[rr][m], e0);
+        e1 = fmaf(w1c[m + 1], dubuf[rr][m + 1], e1);
+      }
+      dh += e0 + e1;
     }
     const float tc = mg_tanh(cc);
     const float dO = dh * tc;
@@ -389,16 +419,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
     dpbuf[rr][2 * H + j] = dpg;
     dpbuf[rr][3 * H + j] = dpo;
     lds_barrier();
-    float nh = 0.f;
+    v2f nh0 = v2f{0.f, 0.f}, nh1 = v2f{0.f, 0.f};  // packed FMAs: two MACs per instruction
 #pragma unroll
     for (int m = 0; m < G4; m += 4) {
       const float4 v = *reinterpret_cast<const float4*>(&dpbuf[rr][m]);
-      nh = fmaf(whc[m], v.x, nh);
-      nh = fmaf(whc[m + 1], v.y, nh);
-      nh = fmaf(whc[m + 2], v.z, nh);
-      nh = fmaf(whc[m + 3], v.w, nh);
+      nh0 = pk_fma(whc[m / 2], v2f{v.x, v.y}, nh0);
+      nh1 = pk_fma(whc[m / 2 + 1], v2f{v.z, v.w}, nh1);
     }
-    dh = nh;
+    dh = (nh0.x + nh0.y) + (nh1.x + nh1.y);
     if (DEC) {
       float p0 = a0[0] * dpi + a0[1] * dpf + a0[2] * dpg + a0[3] * dpo;
       float p1 = a1[0] * dpi + a1[1] * dpf + a1[2] * dpg + a1[3] * dpo;
