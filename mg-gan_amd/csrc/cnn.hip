@@ -310,6 +310,9 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const float* __restrict_
 }
 
 // ---------------- attention head: BN2+ReLU+pool prologue, 64 positions per image ----------------
+// One lane per position (wave = image).  The 2*32*C MLP weights are staged in LDS and the hidden layer is
+// walked with a rolled loop (hidden unit k: recompute h_k, use it, forget it): keeping all of it in
+// registers / scalar registers made the compiler spill ~1k SGPRs through v_writelane (12.6k instructions).
 template <int C, bool BWD>
 __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restrict__ y2, const float* __restrict__ scale2,
                                                    const float* __restrict__ shift2, const float* __restrict__ Wa,
@@ -319,6 +322,15 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
                                                    const float* __restrict__ dout, int ld_dout,
                                                    const float* __restrict__ stat2, float* ds_s, float* hact,
                                                    float* dz_s, float* vsave, float* G2, float* part) {
+  __shared__ __attribute__((aligned(16))) float wa[HID][C];   // Wa[k][c]
+  __shared__ __attribute__((aligned(16))) float wbT[HID][C];  // Wb[c][k] transposed
+  __shared__ float bas[HID];
+  for (int i = threadIdx.x; i < HID * C; i += 256) {
+    wa[i / C][i % C] = Wa[i];
+    wbT[i % HID][i / HID] = Wb[i];
+  }
+  if (threadIdx.x < HID) bas[threadIdx.x] = ba[threadIdx.x];
+  __syncthreads();
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6), pos = threadIdx.x & 63;
   if (b >= B) return;  // whole waves leave together
   const int py = pos >> 3, px = pos & 7;
@@ -329,23 +341,22 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
     const float* base = y2 + (((size_t)b * C + c) * 16 + 2 * py) * 16 + 2 * px;
     v[c] = pool_bn_relu(base, 16, scale2[c], shift2[c], code[c], raw[c]);
   }
-  float hid[HID];
+  float sc[C];
 #pragma unroll
+  for (int c = 0; c < C; ++c) sc[c] = bb[c];
+#pragma unroll 2
   for (int k = 0; k < HID; ++k) {
-    float s = ba[k];
+    float h0 = bas[k], h1 = 0.f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) s = fmaf(Wa[k * C + c], v[c], s);
-    hid[k] = s > 0.f ? s : 0.01f * s;  // nn.LeakyReLU() default slope, cnn.py:19-20
+    for (int c = 0; c < C; c += 2) { h0 = fmaf(wa[k][c], v[c], h0); h1 = fmaf(wa[k][c + 1], v[c + 1], h1); }
+    float h = h0 + h1;
+    h = h > 0.f ? h : 0.01f * h;  // nn.LeakyReLU() default slope, cnn.py:19-20
+#pragma unroll
+    for (int c = 0; c < C; ++c) sc[c] = fmaf(wbT[k][c], h, sc[c]);
   }
-  float sc[C], mx = -INFINITY;
+  float mx = -INFINITY;
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    float s = bb[c];
-#pragma unroll
-    for (int k = 0; k < HID; ++k) s = fmaf(Wb[c * HID + k], hid[k], s);
-    sc[c] = s;
-    mx = fmaxf(mx, s);
-  }
+  for (int c = 0; c < C; ++c) mx = fmaxf(mx, sc[c]);
   float den = 0.f;
 #pragma unroll
   for (int c = 0; c < C; ++c) { sc[c] = __expf(sc[c] - mx); den += sc[c]; }
@@ -369,26 +380,30 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
     ds_s[c * NR + row] = dsv[c];
     vsave[c * NR + row] = v[c];
   }
-#pragma unroll
+#pragma unroll 2
   for (int k = 0; k < HID; ++k) {
-    float d = 0.f;
+    float h0 = bas[k], h1 = 0.f, d0 = 0.f, d1 = 0.f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) d = fmaf(Wb[c * HID + k], dsv[c], d);
-    d *= hid[k] > 0.f ? 1.f : 0.01f;
+    for (int c = 0; c < C; c += 2) {
+      h0 = fmaf(wa[k][c], v[c], h0);
+      h1 = fmaf(wa[k][c + 1], v[c + 1], h1);
+      d0 = fmaf(wbT[k][c], dsv[c], d0);
+      d1 = fmaf(wbT[k][c + 1], dsv[c + 1], d1);
+    }
+    const float hp = h0 + h1;
+    const float d = (d0 + d1) * (hp > 0.f ? 1.f : 0.01f);
     dz_s[k * NR + row] = d;
-    hact[k * NR + row] = hid[k];
+    hact[k * NR + row] = hp > 0.f ? hp : 0.01f * hp;
 #pragma unroll
-    for (int c = 0; c < C; ++c) dv[c] = fmaf(Wa[k * C + c], d, dv[c]);
+    for (int c = 0; c < C; ++c) dv[c] = fmaf(wa[k][c], d, dv[c]);
   }
   // route through max-pool + ReLU to the raw conv2 output grid; partial sums for the BN backward
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const float g = v[c] > 0.f ? dv[c] : 0.f;
     float* gb = G2 + (((size_t)b * C + c) * 16 + 2 * py) * 16 + 2 * px;
-    gb[0] = code[c] == 0 ? g : 0.f;
-    gb[1] = code[c] == 1 ? g : 0.f;
-    gb[16] = code[c] == 2 ? g : 0.f;
-    gb[17] = code[c] == 3 ? g : 0.f;
+    *reinterpret_cast<float2*>(gb) = make_float2(code[c] == 0 ? g : 0.f, code[c] == 1 ? g : 0.f);
+    *reinterpret_cast<float2*>(gb + 16) = make_float2(code[c] == 2 ? g : 0.f, code[c] == 3 ? g : 0.f);
     const float xh = (raw[c] - stat2[c]) * stat2[C + c];
     const float s1 = wave_sum(g), s2 = wave_sum(g * xh);
     if (pos == 0) {
@@ -655,7 +670,7 @@ __global__ __launch_bounds__(1024) void partial_sum_kernel(const float* __restri
   }
 }
 
-static int persistent_grid(int B) { return B < 256 ? B : 256; }
+static int persistent_grid(int B) { return B < 512 ? B : 512; }  // two workgroups per CU
 
 extern "C" {
 
