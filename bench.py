@@ -70,7 +70,7 @@ def flops_of(name, a):
     return 0.0
 
 
-def build_trainer(num_gens, rng, device):
+def build_trainer(num_gens, rng, device, seed=0):
     from mggan.logging import Experiment
     from mggan.model.config import get_parser
     from mggan.model.model_factory import construct_model
@@ -85,6 +85,8 @@ def build_trainer(num_gens, rng, device):
     with contextlib.redirect_stdout(io.StringIO()):
         G, D = construct_model(cfg)
     tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+    if rng == "device":
+        torch.cuda.manual_seed(1234 + seed)  # replicas share the weights, every rank draws its own noise
     tr.G.train()
     tr.D.train()
     return tr
@@ -149,7 +151,8 @@ def main():
     from mggan.hip import lib as hiplib_mod  # noqa: F401
     from mggan.hip.lib import start_trace, stop_trace
 
-    tr = build_trainer(args.num_gens, args.rng, dev)
+    tr = build_trainer(args.num_gens, args.rng, dev, seed=rank)
+    tr.dist.equal_shards = True  # every rank holds the same number of scenes/pedestrians
     sizes = synthetic.scene_sizes(args.scenes, args.peds)
     batch = tr.to_device(synthetic.make_batch(sizes, seed=rank))
     b = batch["in_xy"].shape[1]

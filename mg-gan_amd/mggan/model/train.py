@@ -69,7 +69,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self._pending = []
 
     def _global(self, n):
-        return n * self.dist.world_size if self.dist.enabled else n
+        """Row count over all ranks (loss normalisers are means over the GLOBAL batch)."""
+        return self.dist.global_count(n) if self.dist.enabled else n
 
     def _gen_weights(self, gen_idxs):
         """Batch-global 1/count(generator) weights (train.py:94-96) + int32 row targets in (k*b+ped) order."""

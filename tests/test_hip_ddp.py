@@ -1,0 +1,97 @@
+"""GPU: the data-parallel HIP trainer (scene sharding + flat-gradient all-reduce + BatchNorm-statistics
+all-reduce + global generator counts) equals the single-process trainer.  Two ranks share the one GPU of
+the test box, so the process group uses gloo (RCCL refuses two ranks on one device); the code path through
+mggan.parallel.DistContext is the one bench.py --gpus N runs over RCCL."""
+import os
+import socket
+from collections import defaultdict
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _draws(sizes, g, K, seed):
+    gen = torch.Generator().manual_seed(seed)
+    b, S = sum(sizes), len(sizes)
+    rep = torch.tensor(sizes)
+    out = {"labels": [(0.95, 0.05), (0.93, 0.07), (0.97, 0.02)]}
+    out["noise"] = [torch.randn(k, S, 8, generator=gen).repeat_interleave(rep, dim=1) for k in (1, K, 1)]
+    out["idx"] = [torch.randint(0, g, (b, k), generator=gen) for k in (1, K, 1)]
+    return out
+
+
+def _run(rank, world, port, sizes, q):
+    import sys
+
+    for p in (os.path.join(ROOT, "mg-gan_amd"), ROOT):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    import bench
+    from mggan.data_utils import synthetic
+    from mggan.parallel import shard_batch, shard_scenes
+    from mggan.rng import ReplayRNG
+
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    dev = torch.device("cuda", 0)
+    g, K = 2, 20
+    tr = bench.build_trainer(g, "host", dev)
+    full = synthetic.make_batch(sizes, seed=9)
+    dr = _draws(sizes, g, K, 5)
+    _, p0, p1, _ = shard_scenes(full["seq_start_end"], rank, world)
+    batch = tr.to_device(shard_batch(full, rank, world))
+    batch["loss_mask"] = None
+    m = defaultdict(list)
+    for it in range(2):
+        tr.rng = tr.G.rng = ReplayRNG(labels=list(dr["labels"]), noise=[n[:, p0:p1] for n in dr["noise"]],
+                                      gen_idxs=[i[p0:p1] for i in dr["idx"]])
+        tr.train_iteration(batch, m)
+    flat = torch.cat([tr.G._flat.cpu(), tr.D._flat.cpu()])
+    bn = float(tr.G.scene_encoder.CNN.encoder.ConvBlock_1.Block.BN_1.running_var.sum().cpu())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    q.put((rank, flat.numpy(), bn, {k: v for k, v in m.items() if "probs" not in k}))
+
+
+def _launch(world, sizes):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, sizes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_ranks_match_single_process():
+    sizes = [3, 2, 4, 1, 3, 5]  # ranks get 9 pedestrians each (3 scenes each)
+    single = _launch(1, sizes)[0]
+    two = _launch(2, sizes)
+    for r in two:
+        rel = np.linalg.norm(r[1] - single[1]) / np.linalg.norm(single[1])
+        assert rel <= 1e-3, rel                    # replicas stay in lock-step with the single-process run
+        assert abs(r[2] - single[2]) <= 1e-3 * abs(single[2])  # BatchNorm running stats from GLOBAL statistics
+        for k, v in single[3].items():              # logged losses are global means on every rank
+            np.testing.assert_allclose(r[3][k], v, rtol=2e-3, atol=1e-6, err_msg=k)
+    assert np.array_equal(two[0][1], two[1][1])    # bit-identical replicas
