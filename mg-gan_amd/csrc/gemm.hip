@@ -79,12 +79,32 @@ __device__ __forceinline__ void gemm_fetch(const GemmArgs& g, int m0, int n0, in
   }
 }
 
+// LDS images for the MFMA fragments (v_mfma_f32_16x16x4_f32: lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]):
+//  * k-major operand (stored [k][m] in memory): LDS [k][LDK], LDK = 80 (== 16 mod 32): the two k rows a
+//    32-lane half reads land on disjoint bank halves; stores are row-contiguous (conflict-free);
+//  * k-minor operand (stored [m][k] in memory): LDS [m][LDM], LDM = 34: fragment reads hit bank 2i+k
+//    (conflict-free per half), stores are row-contiguous.  No transposing stores anywhere.
+#define LDK 80
+#define LDM 34
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool KM>
+__device__ __forceinline__ void lds_put(float* T, int e, float v) {
+  if (KM) T[(e >> 6) * LDK + (e & 63)] = v;   // (kd = e>>6, m = e&63)
+  else T[(e >> 5) * LDM + (e & 31)] = v;      // (m = e>>5, kd = e&31)
+}
+template <bool KM>
+__device__ __forceinline__ float lds_frag(const float* T, int m, int k) {  // element (m, k) of the tile
+  return KM ? T[k * LDK + m] : T[m * LDM + k];
+}
+
 template <bool A_KM, bool B_KM, bool ACT = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[BK][LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
-  const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
+  __shared__ __attribute__((aligned(16))) float As[A_KM ? BK * LDK : BM * LDM];
+  __shared__ __attribute__((aligned(16))) float Bs[B_KM ? BK * LDK : BN * LDM];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 32, wn = (w & 1) * 32;   // this wave's 32x32 quadrant of the 64x64 tile
+  const int fi = lane & 15, fk = lane >> 4;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   int k_begin = 0, k_end = g.K;
   if (g.splits > 0) {
@@ -97,67 +117,60 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     k_begin = r0 + sp * chunk;
     k_end = min(r1, k_begin + chunk);
   }
-  float acc[4][4];
+  f32x4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // software pipeline: the global loads of tile k+1 are in flight while tile k is multiplied
+  // software pipeline: the global loads of tile k+1 are in flight while tile k is multiplied on the matrix
+  // cores (exact f32 MFMA: bitwise a k-ordered fmaf chain)
   float ra[8], rb[8];
   if (k_begin < k_end) gemm_fetch<A_KM, B_KM, ACT>(g, m0, n0, k_begin, k_end, ra, rb);
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int e = tid + 256 * i;
-      if (A_KM) As[e >> 6][e & 63] = ra[i]; else As[e & 31][e >> 5] = ra[i];
-      if (B_KM) Bs[e >> 6][e & 63] = rb[i]; else Bs[e & 31][e >> 5] = rb[i];
+      lds_put<A_KM>(As, tid + 256 * i, ra[i]);
+      lds_put<B_KM>(Bs, tid + 256 * i, rb[i]);
     }
     __syncthreads();
     if (k0 + BK < k_end) gemm_fetch<A_KM, B_KM, ACT>(g, m0, n0, k0 + BK, k_end, ra, rb);
 #pragma unroll
-    for (int kd = 0; kd < BK; ++kd) {
-      const float4 a = *reinterpret_cast<const float4*>(&As[kd][4 * ty]);
-      const float4 b = *reinterpret_cast<const float4*>(&Bs[kd][4 * tx]);
-      const float av[4] = {a.x, a.y, a.z, a.w};
-      const float bv[4] = {b.x, b.y, b.z, b.w};
+    for (int kk = 0; kk < BK; kk += 4) {
+      float a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 2; ++i) {
+        a[i] = lds_frag<A_KM>(As, wm + 16 * i + fi, kk + fk);
+        b[i] = lds_frag<B_KM>(Bs, wn + 16 * i + fi, kk + fk);
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 
-  if (g.splits > 0) {
-    float* P = g.C + (size_t)blockIdx.z * g.M * g.N;
+  // C/D fragment: lane l, register r <-> row (l>>4)*4 + r, column l&15 of each 16x16 tile
+  float* P = g.splits > 0 ? g.C + (size_t)blockIdx.z * g.M * g.N : nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int gm = m0 + 4 * ty + i;
-      if (gm >= g.M) continue;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int gn = n0 + 4 * tx + j;
-        if (gn < g.N) P[(size_t)gm * g.N + gn] = acc[i][j];
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gm = m0 + wm + 16 * i + fk * 4 + r, gn = n0 + wn + 16 * j + fi;
+        if (gm >= g.M || gn >= g.N) continue;
+        float v = acc[i][j][r];
+        if (P) {
+          P[(size_t)gm * g.N + gn] = v;
+        } else {
+          if (g.bias) v += g.bias[gn];
+          v = mg_act(v, g.act, g.slope);
+          float* c = g.C + (size_t)gm * g.ldc + gn;
+          *c = g.accumulate ? (*c + v) : v;
+        }
       }
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int gm = m0 + 4 * ty + i;
-    if (gm >= g.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int gn = n0 + 4 * tx + j;
-      if (gn >= g.N) continue;
-      float v = acc[i][j];
-      if (g.bias) v += g.bias[gn];
-      v = mg_act(v, g.act, g.slope);
-      float* c = g.C + (size_t)gm * g.ldc + gn;
-      *c = g.accumulate ? (*c + v) : v;
-    }
-  }
 }
 
 // dW[grp][m*lddw + n] += sum_z P[grp*splits+z][m*Naug+n];  column Naug-1 -> db[grp][m]
