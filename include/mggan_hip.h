@@ -176,9 +176,9 @@ int mggan_bce_rows(int rows, const float* p, float label, const float* label_u, 
  * standard.py:190-214): idx (b,K) int64 generator ids -> rollout rows stably sorted by generator.
  * row r: generator row_gen[r], pedestrian row_ped[r], noise slot row_slot[r] (occurrence offset),
  * output position row_pos[r] = k*b+ped; inv = inverse permutation; seg[g+1] = segment offsets;
- * row_gen_pos (optional) = generator id per output position. */
+ * row_gen_pos = generator id per output position; blk_cnt = scratch, 16 * ceil(b*K/1024) ints. */
 int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, int* row_ped, int* row_slot,
-                      int* row_pos, int* inv, int* seg, int* row_gen_pos, mggan_stream_t stream);
+                      int* row_pos, int* inv, int* seg, int* row_gen_pos, int* blk_cnt, mggan_stream_t stream);
 int mggan_scale(float* x, long n, const float* scalar, mggan_stream_t stream);
 /* classifier input of the discriminator (discriminators.py:141,185,196): rows k*b+ped =
  * [soc (sample block 0 only) | in_enc | pred_enc | scene], and its adjoint */

@@ -298,73 +298,82 @@ __global__ void inv_count_kernel(const int* __restrict__ counts, int g, float* i
 // the index gather of standard.py:190-214, utils.py:234-248) ---------------------------------
 // idx (b, K) generator ids.  Output rows are stably sorted by generator: row r <-> output position
 // pos = k*b + ped; row_slot = number of earlier samples of the same pedestrian with the same generator.
-#define BR_THREADS 512
 #define BR_MAXG 16
-__global__ __launch_bounds__(BR_THREADS) void bucket_rows_kernel(const long long* __restrict__ idx, int b, int K, int g,
-                                                                 int* row_gen, int* row_ped, int* row_slot,
-                                                                 int* row_pos, int* inv, int* seg, int* row_gen_pos) {
-  __shared__ int cnt[BR_THREADS][BR_MAXG + 1];
-  __shared__ int base[BR_MAXG + 1];
-  const int R = b * K, t = threadIdx.x;
-  // phase A: one lane per pedestrian walks its K samples once: generator id and occurrence offset per
-  // output position (slot is parked in inv[pos] until phase C overwrites it)
-  for (int ped = t; ped < b; ped += BR_THREADS) {
-    int seen[BR_MAXG];
+#define BR_BLOCK 1024  // positions per workgroup in the counting / scatter passes
+
+// pass 1: one lane per pedestrian walks its K samples: generator id per output position, occurrence offset
+// (noise slot) parked in inv[pos]
+__global__ __launch_bounds__(256) void bucket_slots_kernel(const long long* __restrict__ idx, int b, int K,
+                                                           int* row_gen_pos, int* inv) {
+  const int ped = blockIdx.x * 256 + threadIdx.x;
+  if (ped >= b) return;
+  int seen[BR_MAXG];
 #pragma unroll
-    for (int q = 0; q < BR_MAXG; ++q) seen[q] = 0;
+  for (int q = 0; q < BR_MAXG; ++q) seen[q] = 0;
 #pragma unroll 4
-    for (int k = 0; k < K; ++k) {
-      const int gi = (int)idx[(size_t)ped * K + k];
-      int slot = 0;
-#pragma unroll
-      for (int q = 0; q < BR_MAXG; ++q) {
-        if (q == gi) { slot = seen[q]; seen[q] += 1; }
-      }
-      row_gen_pos[k * b + ped] = gi;
-      inv[k * b + ped] = slot;
-    }
-  }
-  __syncthreads();
-  // phase B: stable counting sort of the positions by generator
-  const int per = (R + BR_THREADS - 1) / BR_THREADS;
-  const int lo = min(R, t * per), hi = min(R, lo + per);
-  int local[BR_MAXG];
-#pragma unroll
-  for (int q = 0; q < BR_MAXG; ++q) local[q] = 0;
-#pragma unroll 8
-  for (int pos = lo; pos < hi; ++pos) {
-    const int gi = row_gen_pos[pos];
-#pragma unroll
-    for (int q = 0; q < BR_MAXG; ++q) local[q] += (q == gi);
-  }
-#pragma unroll
-  for (int q = 0; q < BR_MAXG; ++q) cnt[t][q] = local[q];
-  __syncthreads();
-  if (t < g) {
-    int run = 0;
-#pragma unroll 16
-    for (int i = 0; i < BR_THREADS; ++i) { const int c = cnt[i][t]; cnt[i][t] = run; run += c; }
-    base[t] = run;
-  }
-  __syncthreads();
-  if (t == 0) {
-    int run = 0;
-    for (int q = 0; q < g; ++q) { const int c = base[q]; base[q] = run; seg[q] = run; run += c; }
-    seg[g] = run;
-  }
-  __syncthreads();
-  // phase C: scatter
-#pragma unroll
-  for (int q = 0; q < BR_MAXG; ++q) local[q] = 0;
-#pragma unroll 4
-  for (int pos = lo; pos < hi; ++pos) {
-    const int gi = row_gen_pos[pos], slot = inv[pos];
-    int off = 0;
+  for (int k = 0; k < K; ++k) {
+    const int gi = (int)idx[(size_t)ped * K + k];
+    int slot = 0;
 #pragma unroll
     for (int q = 0; q < BR_MAXG; ++q) {
-      if (q == gi) { off = local[q]; local[q] += 1; }
+      if (q == gi) { slot = seen[q]; seen[q] += 1; }
     }
-    const int r = base[gi] + cnt[t][gi] + off;
+    row_gen_pos[k * b + ped] = gi;
+    inv[k * b + ped] = slot;
+  }
+}
+
+// pass 2: per block of 1024 consecutive positions, number of rows of every generator
+__global__ __launch_bounds__(BR_BLOCK) void bucket_count_kernel(const int* __restrict__ row_gen_pos, int R, int g,
+                                                                int* blk_cnt) {
+  __shared__ int hist[BR_MAXG];
+  if (threadIdx.x < BR_MAXG) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int pos = blockIdx.x * BR_BLOCK + threadIdx.x;
+  if (pos < R) atomicAdd(&hist[row_gen_pos[pos]], 1);  // integer LDS atomics: exact, order independent
+  __syncthreads();
+  if (threadIdx.x < g) blk_cnt[blockIdx.x * BR_MAXG + threadIdx.x] = hist[threadIdx.x];
+}
+
+// pass 3: exclusive scan over blocks per generator + segment offsets (one small workgroup)
+__global__ __launch_bounds__(64) void bucket_scan_kernel(int nblk, int g, int* blk_cnt, int* seg) {
+  __shared__ int tot[BR_MAXG];
+  const int q = threadIdx.x;
+  if (q < g) {
+    int run = 0;
+    for (int i = 0; i < nblk; ++i) { const int c = blk_cnt[i * BR_MAXG + q]; blk_cnt[i * BR_MAXG + q] = run; run += c; }
+    tot[q] = run;
+  }
+  __syncthreads();
+  if (q == 0) {
+    int run = 0;
+    for (int i = 0; i < g; ++i) { seg[i] = run; run += tot[i]; }
+    seg[g] = run;
+  }
+}
+
+// pass 4: stable scatter.  Rank of a position among the same-generator positions of its block: wave ballot +
+// prefix over the block's waves.
+__global__ __launch_bounds__(BR_BLOCK) void bucket_scatter_kernel(const int* __restrict__ row_gen_pos, int R, int b, int g,
+                                                                  const int* __restrict__ blk_cnt,
+                                                                  const int* __restrict__ seg, int* row_gen,
+                                                                  int* row_ped, int* row_slot, int* row_pos, int* inv) {
+  __shared__ int wcnt[BR_BLOCK / 64][BR_MAXG];
+  const int pos = blockIdx.x * BR_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool ok = pos < R;
+  const int gi = ok ? row_gen_pos[pos] : -1;
+  int rank = 0;
+  for (int q = 0; q < g; ++q) {
+    const unsigned long long m = __ballot(gi == q);
+    if (gi == q) rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wv][q] = __popcll(m);
+  }
+  __syncthreads();
+  if (ok) {
+    int before = 0;
+    for (int i = 0; i < wv; ++i) before += wcnt[i][gi];
+    const int r = seg[gi] + blk_cnt[blockIdx.x * BR_MAXG + gi] + before + rank;
+    const int slot = inv[pos];
     row_gen[r] = gi; row_ped[r] = pos % b; row_slot[r] = slot; row_pos[r] = pos; inv[pos] = r;
   }
 }
@@ -372,11 +381,17 @@ __global__ __launch_bounds__(BR_THREADS) void bucket_rows_kernel(const long long
 extern "C" {
 
 int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, int* row_ped, int* row_slot,
-                      int* row_pos, int* inv, int* seg, int* row_gen_pos, hipStream_t stream) {
-  MG_CHECK_ARG(idx && row_gen && row_ped && row_slot && row_pos && inv && seg && row_gen_pos, "bucket_rows: null pointer");
+                      int* row_pos, int* inv, int* seg, int* row_gen_pos, int* blk_cnt, hipStream_t stream) {
+  MG_CHECK_ARG(idx && row_gen && row_ped && row_slot && row_pos && inv && seg && row_gen_pos && blk_cnt,
+               "bucket_rows: null pointer");
   MG_CHECK_ARG(g >= 1 && g <= BR_MAXG, "bucket_rows: num_gens %d exceeds %d", g, BR_MAXG);
-  hipLaunchKernelGGL(bucket_rows_kernel, dim3(1), dim3(BR_THREADS), 0, stream, idx, b, K, g, row_gen, row_ped, row_slot,
-                     row_pos, inv, seg, row_gen_pos);
+  const int R = b * K, nblk = cdiv(R, BR_BLOCK);
+  if (R == 0) return MGGAN_OK;
+  hipLaunchKernelGGL(bucket_slots_kernel, dim3(cdiv(b, 256)), dim3(256), 0, stream, idx, b, K, row_gen_pos, inv);
+  hipLaunchKernelGGL(bucket_count_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, g, blk_cnt);
+  hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(64), 0, stream, nblk, g, blk_cnt, seg);
+  hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, b, g, blk_cnt, seg,
+                     row_gen, row_ped, row_slot, row_pos, inv);
   MG_LAUNCH_CHECK("bucket_rows");
   return MGGAN_OK;
 }

@@ -511,8 +511,9 @@ def device_rollout_rows(idx, n_gens):
     rows.row_gen, rows.row_ped, rows.row_slot, rows.row_pos, rows.inv = mk(R), mk(R), mk(R), mk(R), mk(R)
     rows.seg, rows.row_gen_pos = mk(n_gens + 1), mk(R)
     idx = idx.contiguous()
+    blk = mk(16 * ((R + 1023) // 1024))
     lib.mggan_bucket_rows(_p(idx), b, K, n_gens, _p(rows.row_gen), _p(rows.row_ped), _p(rows.row_slot),
-                          _p(rows.row_pos), _p(rows.inv), _p(rows.seg), _p(rows.row_gen_pos), _s())
+                          _p(rows.row_pos), _p(rows.inv), _p(rows.seg), _p(rows.row_gen_pos), _p(blk), _s())
     return rows
 
 
