@@ -172,6 +172,9 @@ int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float
 int mggan_bce_rows(int rows, const float* p, float label, const float* label_u, float label_lo, float label_hi,
                    float scale, const int* row_gen, const float* inv_count, float* loss_rows, float* dp,
                    mggan_stream_t stream);
+/* Categorical(logits=...).sample((K,)).T on the device (standard.py:217-225): inverse CDF from uniforms u (b,K) */
+int mggan_sample_categorical(int b, int K, int g, const float* logits, const float* u, long long* idx,
+                             mggan_stream_t stream);
 /* device-side replacement of get_selection_indices + gather bookkeeping (utils.py:234-248,
  * standard.py:190-214): idx (b,K) int64 generator ids -> rollout rows stably sorted by generator.
  * row r: generator row_gen[r], pedestrian row_ped[r], noise slot row_slot[r] (occurrence offset),

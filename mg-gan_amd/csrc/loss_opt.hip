@@ -378,7 +378,36 @@ __global__ __launch_bounds__(BR_BLOCK) void bucket_scatter_kernel(const int* __r
   }
 }
 
+// Categorical(logits).sample((K,)).T by inverse CDF from caller-provided uniforms u (b,K) in [0,1):
+// one lane per pedestrian (standard.py:217-225 on the device, no host round trip)
+__global__ void sample_categorical_kernel(int b, int K, int g, const float* __restrict__ logits,
+                                          const float* __restrict__ u, long long* idx) {
+  const int ped = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ped >= b) return;
+  float cdf[BR_MAXG];
+  float mx = -INFINITY;
+  for (int i = 0; i < g; ++i) mx = fmaxf(mx, logits[(size_t)ped * g + i]);
+  float run = 0.f;
+  for (int i = 0; i < g; ++i) { run += __expf(logits[(size_t)ped * g + i] - mx); cdf[i] = run; }
+  for (int k = 0; k < K; ++k) {
+    const float x = u[(size_t)ped * K + k] * run;
+    int pick = g - 1;
+    for (int i = g - 2; i >= 0; --i)
+      if (x < cdf[i]) pick = i;
+    idx[(size_t)ped * K + k] = pick;
+  }
+}
+
 extern "C" {
+
+int mggan_sample_categorical(int b, int K, int g, const float* logits, const float* u, long long* idx,
+                             hipStream_t stream) {
+  if (b == 0) return MGGAN_OK;
+  MG_CHECK_ARG(logits && u && idx && g >= 1 && g <= BR_MAXG, "sample_categorical: bad arguments (num_gens <= 16)");
+  hipLaunchKernelGGL(sample_categorical_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, K, g, logits, u, idx);
+  MG_LAUNCH_CHECK("sample_categorical");
+  return MGGAN_OK;
+}
 
 int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, int* row_ped, int* row_slot,
                       int* row_pos, int* inv, int* seg, int* row_gen_pos, int* blk_cnt, hipStream_t stream) {

@@ -47,3 +47,17 @@ def test_graph_replay_trains_like_eager():
     # the graph run logged only its 3 replays; they must look like training (finite, D loss near 2*ln2 early on)
     assert 0.2 < losses["graph"]["train/discr_loss"][-1] < 3.0
     assert abs(losses["graph"]["train/discr_loss"][-1] - losses["eager"]["train/discr_loss"][-1]) < 0.5
+
+
+def test_device_categorical_sampler_statistics():
+    """Inverse-CDF sampler: empirical frequencies follow softmax(logits); indices in range."""
+    from mggan.rng import DeviceRNG
+
+    rng = DeviceRNG(seed=3)
+    logits = torch.tensor([[0.0, 1.0, -1.0, 0.5]] * 4096, device="cuda")
+    idx = rng.sample_generators(logits, 20)
+    assert idx.shape == (4096, 20) and idx.dtype == torch.int64
+    assert int(idx.min()) >= 0 and int(idx.max()) <= 3
+    freq = torch.bincount(idx.flatten(), minlength=4).float() / idx.numel()
+    ref = torch.softmax(logits[0], 0)
+    assert float((freq.cpu() - ref.cpu()).abs().max()) < 0.01
