@@ -95,7 +95,7 @@ class MultiDiscriminatorTrajectory(FlatModule):
         in_enc, pred_enc = self._encode_parts(in_dxdy, pred_dxdy, context)
         if not masked:
             # social features only for sample block 0: `seq_start_end * n_samples` is LIST repetition (A.1)
-            enc0 = torch.cat([in_enc, pred_enc[:full_b]], dim=1)
+            enc0 = torch.cat([in_enc, pred_enc if n_samples == 1 else pred_enc[:full_b]], dim=1)
             soc0 = self.social(in_xy, in_dxdy, enc0, seq_start_end)
             scene = context[1] if context is not None else self.scene_encoder(img)
             classifier_inp = HF.DAssembleFn.apply(soc0, in_enc, pred_enc, scene, n_samples)

@@ -40,7 +40,10 @@ class SocialAttention(FlatModule):
         b = max(int(e) for _, e in sub_batches) if len(sub_batches) else 0
         N = enc_h.shape[0]
         tb = HF.scene_tables(sub_batches, b, enc_h.device)
-        S = HF.SocialAttentionFn.apply(in_xy[-1, :b], in_dxdy[-1, :b], enc_h[:b], tb, fc[0].weight, fc[0].bias,
+        xy_l, dxy_l, h = in_xy[-1], in_dxdy[-1], enc_h
+        if N != b:  # (identity slices would still cost a zero-fill + copy each in autograd's slice backward)
+            xy_l, dxy_l, h = xy_l[:b], dxy_l[:b], h[:b]
+        S = HF.SocialAttentionFn.apply(xy_l, dxy_l, h, tb, fc[0].weight, fc[0].bias,
                                        fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, W.weight, W.bias, self,
                                        HF.want_grad(enc_h, W.weight))
         if N > b:
