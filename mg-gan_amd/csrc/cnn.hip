@@ -542,6 +542,130 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
   }
 }
 
+// ---------------- conv2 backward on the matrix cores (C = 16) ----------------
+// Same staging as conv2_bwd_kernel; both GEMM-shaped parts run on exact-f32 MFMA (16x16x4):
+//   weight grad  dW[co][(tap,ci)] += sum_pos dy[co][pos] * a1[ci][pos+tap]   M=co(16), N=(tap,ci)(9 tiles), K=pos
+//   input grad   da1[pos][ci]      = sum_{tap,co} dy[co][pos+tap'] * Wflip   M=pos (16 rows of 16), N=ci, K=(tap,co)
+// LDS planes are 361 floats apart (== 9 mod 32): a 16-lane fragment read that walks channels hits 16
+// distinct banks.  Wave w owns image rows 4w..4w+3 in both products; the wave-private weight-grad
+// accumulators persist over the workgroup's images and meet in LDS once at the end.
+#define C2_PLANE 361
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float* __restrict__ y1,
+                                                            const float* __restrict__ scale1,
+                                                            const float* __restrict__ shift1,
+                                                            const float* __restrict__ stat1,
+                                                            const float* __restrict__ y2, const float* __restrict__ G2,
+                                                            const float* __restrict__ stat2,
+                                                            const float* __restrict__ coef2, const float* __restrict__ W,
+                                                            float* G1c, unsigned char* code1, float* part1,
+                                                            float* wpart) {
+  constexpr int C = 16, WLEN = C * C * 9 + C;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dyp = smem;                       // [C][18][20] padded planes, stride C2_PLANE
+  float* a1p = dyp + C * C2_PLANE;         // same layout
+  float* y1r = a1p + C * C2_PLANE;         // [C][256] raw conv1 value at the pooling argmax
+  float* wf = y1r + C * 256;               // [tap'][co][ci] = W[co][ci][8 - tap'] (flipped kernel), 2304
+  float* red = wf + 9 * C * C;             // [4][32] cross-wave statistics
+  for (int i = threadIdx.x; i < 2 * C * C2_PLANE; i += 256) dyp[i] = 0.f;  // dyp and a1p (halos stay zero)
+  for (int i = threadIdx.x; i < 9 * C * C; i += 256) {
+    const int tp = i / (C * C), co = (i / C) % C, ci = i % C;
+    wf[i] = W[(co * C + ci) * 9 + (8 - tp)];
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  f32x4_t wacc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wacc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bacc = 0.f;
+
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    lds_barrier();
+    {
+      const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
+#pragma unroll 8
+      for (int c = 0; c < C; ++c) {
+        int code; float raw;
+        const float* base = y1 + (((size_t)b * C + c) * IH + 2 * py) * IH + 2 * px;
+        a1p[c * C2_PLANE + (py + 1) * A1_LD + px + 1] = pool_bn_relu(base, IH, scale1[c], shift1[c], code, raw);
+        y1r[c * 256 + threadIdx.x] = raw;
+        const size_t gi = ((size_t)b * C + c) * 256 + threadIdx.x;
+        code1[gi] = (unsigned char)code;
+        const float xh = (y2[gi] - stat2[c]) * stat2[C + c];
+        dyp[c * C2_PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (G2[gi] - coef2[C + c] - xh * coef2[2 * C + c]);
+      }
+    }
+    lds_barrier();
+    // ---- (1) weight gradient: K runs over this wave's 64 positions (rows 4w..4w+3), 4 positions per MFMA
+#pragma unroll 1
+    for (int ks = 0; ks < 16; ++ks) {
+      const int y = 4 * w + (ks >> 2), x0 = (ks & 3) * 4;
+      // A[i = co][k = position x0+fk]
+      const float a = dyp[fi * C2_PLANE + (y + 1) * A1_LD + x0 + 1 + fk];
+      bacc += a;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        // B[k = position][j = ci] for tap t = (ky,kx): a1 value at (y+ky, x+kx) in padded coordinates
+        const float bv = a1p[fi * C2_PLANE + (y + t / 3) * A1_LD + x0 + fk + t % 3];
+        wacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, wacc[t], 0, 0, 0);
+      }
+    }
+    // ---- (2) input gradient for rows 4w..4w+3: M = 16 x-positions of one row, N = ci, K = (tap', co)
+    float s1 = 0.f, s2 = 0.f;  // BN1-backward partial sums for channel ci = fi
+#pragma unroll 1
+    for (int ry = 0; ry < 4; ++ry) {
+      const int y = 4 * w + ry;
+      f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+        for (int c4 = 0; c4 < C; c4 += 4) {
+          const int co = c4 + fk;
+          // A[i = x][k = (tp, co)] = dy[co] at padded (y + tp/3, x + tp%3);  B[k][j = ci] = wf[tp][co][ci]
+          const float a = dyp[co * C2_PLANE + (y + tp / 3) * A1_LD + fi + tp % 3];
+          const float bv = wf[(tp * C + co) * C + fi];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+        }
+      }
+      // D fragment: register r <-> x = 4*fk + r, column = ci = fi
+      float g[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = 4 * fk + r;
+        const bool on = a1p[fi * C2_PLANE + (y + 1) * A1_LD + x + 1] > 0.f;
+        g[r] = on ? acc[r] : 0.f;
+        const float xh = (y1r[fi * 256 + y * 16 + x] - stat1[fi]) * stat1[C + fi];
+        s1 += g[r];
+        s2 = fmaf(g[r], xh, s2);
+      }
+      *reinterpret_cast<float4*>(G1c + (((size_t)b * C + fi) * 16 + y) * 16 + 4 * fk) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+    // per-channel statistics: fold the 4 lane groups, then the 4 waves
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (lane < 16) { red[w * 32 + lane] = s1; red[w * 32 + 16 + lane] = s2; }
+    lds_barrier();
+    if (threadIdx.x < 32) {
+      const float t = (red[threadIdx.x] + red[32 + threadIdx.x]) + (red[64 + threadIdx.x] + red[96 + threadIdx.x]);
+      part1[(size_t)b * 2 * C + threadIdx.x] = t;  // [0,16) = sum g, [16,32) = sum g*xhat
+    }
+  }
+  // ---- fold the four waves' weight-gradient fragments; wacc[t][r] of lane l is dW[co = 4*fk + r][ci = fi][tap t]
+  lds_barrier();
+  float* fold = dyp;  // reuse: [4][WLEN]
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fold[w * WLEN + ((4 * fk + r) * C + fi) * 9 + t] = wacc[t][r];
+  bacc += __shfl_xor(bacc, 16, 64);
+  bacc += __shfl_xor(bacc, 32, 64);  // lanes 0..15: sum over this wave's positions of dy[co = lane]
+  if (lane < 16) fold[w * WLEN + C * C * 9 + lane] = bacc;
+  lds_barrier();
+  float* wp = wpart + (size_t)blockIdx.x * WLEN;
+  for (int i = threadIdx.x; i < WLEN; i += 256)
+    wp[i] = (fold[i] + fold[WLEN + i]) + (fold[2 * WLEN + i] + fold[3 * WLEN + i]);
+}
+
 // ---------------- conv1 backward: BN1 bwd + weight grad (the image needs no gradient) ----------------
 // Channels are processed 8 at a time so that a workgroup needs 60 KB of LDS (two workgroups per CU);
 // the dy1 tile is built cell-wise (one lane per pooled cell, loads of several channels in flight).
@@ -797,10 +921,16 @@ int mggan_conv2_bwd(const float* y1, int B, int C, const float* scale1, const fl
     mggan_set_error("conv2_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
     return MGGAN_ERR_WORKSPACE;
   }
-  if (C == 16)
-    hipLaunchKernelGGL((conv2_bwd_kernel<16>), dim3(grid), dim3(256), 0, stream, B, y1, scale1, shift1, stat1, y2, G2,
+  if (C == 16) {
+    const size_t lds = (size_t)(2 * 16 * C2_PLANE + 16 * 256 + 9 * 256 + 128) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute((const void*)conv2_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL(conv2_bwd_mfma_kernel, dim3(grid), dim3(256), lds, stream, B, y1, scale1, shift1, stat1, y2, G2,
                        stat2, coef2, W, G1c, code1, part1, workspace);
-  else
+  } else
     hipLaunchKernelGGL((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, y1, scale1, shift1, stat1, y2, G2,
                        stat2, coef2, W, G1c, code1, part1, workspace);
   MG_LAUNCH_CHECK("conv2_bwd");
