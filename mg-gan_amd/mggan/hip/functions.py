@@ -466,15 +466,15 @@ class SceneAttentionFn(Function):
             _queue_reduce(ws.data_ptr(), pw, 0, 1, C * C * 9, 0, C * C * 9, grid, 1, wl, keep=(ws,))
             _queue_reduce(ws.data_ptr() + 4 * C * C * 9, pb, 0, 1, C, 0, C, grid, 1, wl)
         coef1 = bn_bwd(g1, be1, stat1, cnt1)
-        nb = 2 * grid * 8 * (4 * C * 9 + C) * 4
+        nb = grid * 8 * (4 * C * 9 + C) * 4
         ws = torch.empty(nb // 4, dtype=F32, device=img.device)
         pw, pb = root.grad_ptr(c1w), root.grad_ptr(c1b)
         lib.mggan_conv1_bwd(_p(img), B, C, _p(y1), _p(stat1), _p(coef1), _p(G1c), _p(code1), 0 if defer else pw,
                             0 if defer else pb, _p(ws), nb, st)
         if defer:
             wl = 4 * C * 9 + C
-            _queue_reduce(ws.data_ptr(), pw, 0, 1, 4 * C * 9, 0, 4 * C * 9, 2 * grid, 1, wl, keep=(ws,))
-            _queue_reduce(ws.data_ptr() + 4 * 4 * C * 9, pb, 0, 1, C, 0, C, 2 * grid, 1, wl)
+            _queue_reduce(ws.data_ptr(), pw, 0, 1, 4 * C * 9, 0, 4 * C * 9, grid, 1, wl, keep=(ws,))
+            _queue_reduce(ws.data_ptr() + 4 * 4 * C * 9, pb, 0, 1, C, 0, C, grid, 1, wl)
         return (None,) * 20
 
 
