@@ -207,6 +207,19 @@ int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, cons
                      const unsigned char* active, int* seg_step, float max_norm, double lr, double beta1, double beta2,
                      double eps, double weight_decay, double* workspace, float* norm_out, mggan_stream_t stream);
 
+/* Fused decoder backward: BPTT + in-kernel per-generator weight gradients (dW_hh and dW1[:, :H] on MFMA).
+ * n_gens*NW persistent workgroups; workgroup (g, w) leaves one partial block of `wlen` floats at
+ * wpart[(g*NW + w) * wlen] laid out as [W_hh | A | bias | W1h | b1 | W2 | b2] (offsets from
+ * mggan_decoder_bwd_fused_layout); reduce them with mggan_grad_reduce_multi (groups = n_gens, splits = NW). */
+int mggan_decoder_bwd_fused_layout(int* wlen, int* off_A, int* off_bias, int* off_W1, int* off_b1, int* off_W2,
+                                   int* off_b2);
+int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, int Z, const int* seg, const int* row_pos,
+                                    const float* W_hh, const float* W1, const float* W2, long param_stride,
+                                    const float* We2d, const float* prep, int prep_stride, const float* Gt,
+                                    const float* Cs, const float* Hp, const float* Hc, const float* Din,
+                                    const float* Aact, const float* gabs, const float* grel, int Rout, float* dH0,
+                                    float* dQ, float* dEnc, float* dSocR, float* wpart, mggan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -462,6 +462,244 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Fused decoder backward: BPTT over the 12 steps AND the per-generator weight gradients in one launch.
+// The un-fused path writes the gate gradients (512 B per row and step, 157 MB at 25,600 rows) and two
+// weight-gradient GEMMs read them back: HBM-bound.  Here a workgroup is persistent over the 8-row tiles of
+// ONE generator; per step the rank-8 updates
+//     dW_hh[128x32] += dPre^T[128x8] h_{t-1}[8x32]      dW1[:, :32][16x32] += dU^T[16x8] h_t[8x32]
+// run on the matrix cores (exact-f32 16x16x4 MFMA) straight from the LDS tiles the recurrence already
+// needs; dA / dbias / dW2 / db1 / db2 are lane-local FMAs.  Each workgroup leaves ONE partial block
+//     [ W_hh 4096 | A 256 | bias 128 | W1h 512 | b1 16 | W2 32 | b2 2 (+2 pad) ]
+// which the batched gradient reduce folds per generator.
+#define DF_WLEN 5044
+#define DF_OFF_A 4096
+#define DF_OFF_B 4352
+#define DF_OFF_W1 4480
+#define DF_OFF_B1 4992
+#define DF_OFF_W2 5008
+#define DF_OFF_B2 5040
+#define DPLD 144  // dpbuf row stride (== 16 mod 32: conflict-free MFMA fragment reads, 16-B aligned rows)
+#define HLD 48    // h tile row stride (== 16 mod 32)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct DecFusedArgs {
+  int T, NW, Rout, EIN, Z;
+  const int* seg;        // generator segment offsets into the sorted rows (g+1)
+  const int* row_pos;
+  const float *W_hh, *W1, *W2, *We2d;
+  long param_stride;
+  const float* prep;
+  int prep_stride;
+  const float *Gt, *Cs, *Hp, *Hc, *Din, *Aact, *gabs, *grel;
+  float *dH0, *dQ, *dEnc, *dSocR, *wpart;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void decoder_bwd_fused_kernel(DecFusedArgs p) {
+  constexpr int H = 32, G4 = 128, Hh = 16, S = 32, RT = 8;
+  __shared__ __attribute__((aligned(16))) float dpbuf[RT * DPLD];
+  __shared__ __attribute__((aligned(16))) float dubuf[RT * Hh];
+  __shared__ __attribute__((aligned(16))) float hbuf[2][RT * HLD];
+  __shared__ float w1s[Hh * H];     // W1[:, :H] (m-major): lane j reads w1s[m*H + j]
+  __shared__ float as_[8 * H];      // folded input weights: as_[(2q + c)*H + j] = A[q*H + j][c]
+  __shared__ float fold[RT * 64];  // end-of-kernel reduction over the 8 tile rows (A 256 | bias 128 | W2 32 | b1 16 | b2 2)
+  const int gi = blockIdx.x / p.NW, wi = blockIdx.x % p.NW;
+  const int rr = threadIdx.x / H, j = threadIdx.x % H;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  const long po = (long)gi * p.param_stride;
+  const float* P = p.prep + (size_t)gi * p.prep_stride;
+  const int seg0 = p.seg[gi], seg1 = p.seg[gi + 1];
+  const int ntiles = (seg1 - seg0 + RT - 1) / RT;
+
+  v2f whc[G4 / 2];  // column j of W_hh (packed pairs)
+#pragma unroll
+  for (int m = 0; m < G4; m += 2) whc[m / 2] = v2f{p.W_hh[po + (size_t)m * H + j], p.W_hh[po + (size_t)(m + 1) * H + j]};
+  float w20 = 0.f, w21 = 0.f;
+  for (int i = threadIdx.x; i < Hh * H; i += 256) w1s[i] = p.W1[po + (size_t)(i / H) * (H + S) + (i % H)];
+  {
+    const int q = threadIdx.x / 64, c = (threadIdx.x / H) & 1;
+    as_[threadIdx.x] = P[prep_off_A(H) + (q * H + j) * 2 + c];
+  }
+  // B-tile columns 32..47 of both h tiles: [din0, din1, 1, 0...] (the constant part is written once)
+  for (int i = threadIdx.x; i < 2 * RT * 16; i += 256) {
+    const int bsel = i / (RT * 16), row = (i / 16) % RT, col = i % 16;
+    hbuf[bsel][row * HLD + H + col] = col == 2 ? 1.f : 0.f;
+  }
+  if (j < Hh) { w20 = p.W2[po + j]; w21 = p.W2[po + Hh + j]; }
+
+  // accumulators that live across all tiles of this workgroup
+  f32x4 accW[2][3], accU = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) accW[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float accW2[2] = {0.f, 0.f}, accb1 = 0.f, accb2[2] = {0.f, 0.f};
+
+  for (int tile = wi; tile < ntiles; tile += p.NW) {
+    const int r = seg0 + tile * RT + rr;
+    const bool valid = r < seg1;
+    const int rc = valid ? r : seg1 - 1;
+    const float vm = valid ? 1.f : 0.f;  // rows past the segment end contribute nothing
+    const int pos = p.row_pos[rc];
+    float dh = 0.f, dc = 0.f, dd0 = 0.f, dd1 = 0.f, s0 = 0.f, s1 = 0.f, dqacc = 0.f;
+    float n_gi, n_gf, n_gg, n_go, n_cc, n_cp, n_hp, n_d0, n_d1, n_av = 0.f, n_ga0 = 0.f, n_ga1 = 0.f, n_gr0 = 0.f,
+                                                                       n_gr1 = 0.f;
+    auto fetch = [&](int t) {
+      const size_t rt = (size_t)rc * p.T + t;
+      n_gi = p.Gt[rt * G4 + j]; n_gf = p.Gt[rt * G4 + H + j]; n_gg = p.Gt[rt * G4 + 2 * H + j];
+      n_go = p.Gt[rt * G4 + 3 * H + j];
+      n_cc = p.Cs[rt * H + j];
+      n_cp = t > 0 ? p.Cs[(rt - 1) * H + j] : 0.f;
+      n_hp = p.Hp[rt * H + j];
+      n_d0 = p.Din[rt * 2]; n_d1 = p.Din[rt * 2 + 1];
+      const size_t o = ((size_t)t * p.Rout + pos) * 2;
+      if (p.gabs) { n_ga0 = p.gabs[o]; n_ga1 = p.gabs[o + 1]; }
+      if (p.grel) { n_gr0 = p.grel[o]; n_gr1 = p.grel[o + 1]; }
+      if (j < Hh) n_av = p.Aact[rt * Hh + j];
+    };
+    lds_barrier();  // previous tile's LDS traffic is finished
+    hbuf[(p.T - 1) & 1 ^ 1][rr * HLD + j] = p.Hc[((size_t)rc * p.T + p.T - 1) * H + j];  // h_{T-1}
+    fetch(p.T - 1);
+    for (int t = p.T - 1; t >= 0; --t) {
+      const int cur = (t & 1) ^ 1, prv = t & 1;  // hbuf[cur] = h_t, hbuf[prv] <- h_{t-1}
+      const float gi_ = n_gi, gf = n_gf, gg = n_gg, go = n_go, cc = n_cc, cprev = n_cp, hp = n_hp;
+      const float din0 = n_d0, din1 = n_d1, av = n_av, ga0 = n_ga0, ga1 = n_ga1, gr0 = n_gr0, gr1 = n_gr1;
+      if (t > 0) fetch(t - 1);
+      s0 += ga0; s1 += ga1;
+      const float g0 = (s0 + dd0 + gr0) * vm, g1 = (s1 + dd1 + gr1) * vm;
+      if (j == 0) { accb2[0] += g0; accb2[1] += g1; }
+      if (j < Hh) {
+        const float du = (w20 * g0 + w21 * g1) * (av > 0.f ? 1.f : 0.01f);
+        dubuf[rr * Hh + j] = du;
+        dqacc += du;
+        accW2[0] = fmaf(g0, av, accW2[0]);
+        accW2[1] = fmaf(g1, av, accW2[1]);
+      }
+      hbuf[prv][rr * HLD + j] = hp;
+      if (j < 2) hbuf[prv][rr * HLD + H + j] = j ? din1 : din0;
+      lds_barrier();
+      {  // dW1[:, :H] += dU^T h_t : wave w -> N tile (w & 1), K half (w >> 1)
+        const int nt = w & 1, kk = w >> 1;
+        const float a = dubuf[(4 * kk + fk) * Hh + fi];
+        const float bv = hbuf[cur][(4 * kk + fk) * HLD + 16 * nt + fi];
+        accU = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, accU, 0, 0, 0);
+      }
+      float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+      for (int m = 0; m < Hh; m += 2) {
+        e0 = fmaf(w1s[m * H + j], dubuf[rr * Hh + m], e0);
+        e1 = fmaf(w1s[(m + 1) * H + j], dubuf[rr * Hh + m + 1], e1);
+      }
+      dh += e0 + e1;
+      const float tc = mg_tanh(cc);
+      const float dO = dh * tc;
+      dc = fmaf(dh * go, 1.f - tc * tc, dc);
+      const float dpi = dc * gg * gi_ * (1.f - gi_) * vm;
+      const float dpf = dc * cprev * gf * (1.f - gf) * vm;
+      const float dpg = dc * gi_ * (1.f - gg * gg) * vm;
+      const float dpo = dO * go * (1.f - go) * vm;
+      dc = dc * gf;
+      dpbuf[rr * DPLD + j] = dpi;
+      dpbuf[rr * DPLD + H + j] = dpf;
+      dpbuf[rr * DPLD + 2 * H + j] = dpg;
+      dpbuf[rr * DPLD + 3 * H + j] = dpo;
+      lds_barrier();
+      // [dW_hh | dA | dbias] += dPre^T [h_{t-1} | din | 1]: wave w owns gate-row tiles 2w, 2w+1, K = the 8 tile rows
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        float a[2], bv[3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = dpbuf[(4 * kk + fk) * DPLD + 16 * (2 * w + i) + fi];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bv[n] = hbuf[prv][(4 * kk + fk) * HLD + 16 * n + fi];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) accW[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[n], accW[i][n], 0, 0, 0);
+      }
+      v2f nh0 = v2f{0.f, 0.f}, nh1 = v2f{0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < G4; m += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(&dpbuf[rr * DPLD + m]);
+        nh0 = pk_fma(whc[m / 2], v2f{v.x, v.y}, nh0);
+        nh1 = pk_fma(whc[m / 2 + 1], v2f{v.z, v.w}, nh1);
+      }
+      dh = (nh0.x + nh0.y) + (nh1.x + nh1.y);
+      float p0 = as_[0 * H + j] * dpi + as_[2 * H + j] * dpf + as_[4 * H + j] * dpg + as_[6 * H + j] * dpo;
+      float p1 = as_[1 * H + j] * dpi + as_[3 * H + j] * dpf + as_[5 * H + j] * dpg + as_[7 * H + j] * dpo;
+#pragma unroll
+      for (int o = H / 2; o > 0; o >>= 1) {
+        p0 += __shfl_xor(p0, o, 64);
+        p1 += __shfl_xor(p1, o, 64);
+      }
+      dd0 = p0; dd1 = p1;
+      lds_barrier();
+    }
+    // per-row outputs of this tile: dH0, dQ, d(social row), d(enc_h row)
+    if (valid) p.dH0[(size_t)r * H + j] = dh;
+    if (j < Hh) {
+      dubuf[rr * Hh + j] = dqacc;
+      if (valid) p.dQ[(size_t)r * Hh + j] = dqacc;
+      accb1 += dqacc * vm;
+    }
+    dpbuf[rr * DPLD + j] = dh;
+    lds_barrier();
+    float ds = 0.f;
+#pragma unroll
+    for (int m = 0; m < Hh; ++m) ds = fmaf(p.W1[po + (size_t)m * (H + S) + H + j], dubuf[rr * Hh + m], ds);
+    if (valid) p.dSocR[(size_t)r * S + j] = ds;
+    const int IN = p.EIN + p.Z;
+    for (int k = j; k < p.EIN; k += H) {
+      float de = 0.f;
+#pragma unroll 8
+      for (int jj = 0; jj < H; ++jj) de = fmaf(p.We2d[(size_t)jj * IN + k], dpbuf[rr * DPLD + jj], de);
+      if (valid) p.dEnc[(size_t)r * p.EIN + k] = de;
+    }
+  }
+
+  // ---- this workgroup's partial block ----
+  float* wp = p.wpart + (size_t)blockIdx.x * DF_WLEN;
+  // W_hh: accW[i][n][r] of lane l is dW_hh[m = 16*(2w+i) + 4*fk + r][k = 16*n + fi]  (each tile has one owner wave)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) wp[(16 * (2 * w + i) + 4 * fk + r4) * H + 16 * n + fi] = accW[i][n][r4];
+  if (fi < 3) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int m = 16 * (2 * w + i) + 4 * fk + r4;
+        if (fi < 2) wp[DF_OFF_A + m * 2 + fi] = accW[i][2][r4];
+        else wp[DF_OFF_B + m] = accW[i][2][r4];
+      }
+  }
+  lds_barrier();
+  // W1h: tile (w & 1) is shared by waves w and w ^ 2 (K halves): sum them through LDS
+  float* u = dpbuf;  // [4][256]
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) u[w * 256 + (4 * fk + r4) * 16 + fi] = accU[r4];
+  // lane-local accumulators (W2, b1, b2) -> fold over the 8 tile rows
+  float* f = fold + rr * 64;
+  if (j < Hh) { f[j] = accW2[0]; f[Hh + j] = accW2[1]; f[32 + j] = accb1; }
+  if (j == 0) { f[48] = accb2[0]; f[49] = accb2[1]; }
+  lds_barrier();
+  if (threadIdx.x < 50) {
+    const int i = threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < RT; ++q) t += fold[q * 64 + i];
+    wp[i < 32 ? DF_OFF_W2 + i : i < 48 ? DF_OFF_B1 + (i - 32) : DF_OFF_B2 + (i - 48)] = t;
+  }
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    // i = m*32 + k: tile nt = k / 16 held by waves nt and nt + 2
+    const int m = i / 32, k = i % 32, nt = k / 16;
+    wp[DF_OFF_W1 + i] = u[nt * 256 + m * 16 + (k & 15)] + u[(nt + 2) * 256 + m * 16 + (k & 15)];
+  }
+}
+
 // dst[ped][c] (+)= sum_k src[inv[k*b + ped]][c]
 __global__ void gather_sum_kernel(const float* __restrict__ src, int lds_, const int* __restrict__ inv, float* dst,
                                   int ldd, int b, int K, int ncols, int accumulate) {
@@ -587,6 +825,33 @@ int mggan_decoder_rollout_bwd(int R, int T, int H, int EIN, int Z, const int* ro
   p.dPre = dPre; p.dU = dU; p.gD = gD; p.dH0 = dH0; p.dQ = dQ; p.dEnc = dEnc; p.dSocR = dSocR;
   hipLaunchKernelGGL((lstm_bwd_kernel<32, true>), dim3(cdiv(R, 8)), dim3(256), 0, stream, p);
   MG_LAUNCH_CHECK("decoder_rollout_bwd");
+  return MGGAN_OK;
+}
+
+int mggan_decoder_bwd_fused_layout(int* wlen, int* off_A, int* off_bias, int* off_W1, int* off_b1, int* off_W2,
+                                   int* off_b2) {
+  *wlen = DF_WLEN; *off_A = DF_OFF_A; *off_bias = DF_OFF_B; *off_W1 = DF_OFF_W1; *off_b1 = DF_OFF_B1;
+  *off_W2 = DF_OFF_W2; *off_b2 = DF_OFF_B2;
+  return MGGAN_OK;
+}
+
+int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, int Z, const int* seg, const int* row_pos,
+                                    const float* W_hh, const float* W1, const float* W2, long param_stride,
+                                    const float* We2d, const float* prep, int prep_stride, const float* Gt,
+                                    const float* Cs, const float* Hp, const float* Hc, const float* Din,
+                                    const float* Aact, const float* gabs, const float* grel, int Rout, float* dH0,
+                                    float* dQ, float* dEnc, float* dSocR, float* wpart, hipStream_t stream) {
+  MG_CHECK_ARG(seg && row_pos && W_hh && W1 && W2 && We2d && prep && Gt && Cs && Hp && Hc && Din && Aact && dH0 && dQ &&
+                   dEnc && dSocR && wpart,
+               "decoder_rollout_bwd_fused: null pointer");
+  MG_CHECK_ARG(H == 32 && NW > 0 && n_gens > 0, "decoder_rollout_bwd_fused: decoder_h_dim %d not built (32)", H);
+  DecFusedArgs p = {};
+  p.T = T; p.NW = NW; p.Rout = Rout; p.EIN = EIN; p.Z = Z; p.seg = seg; p.row_pos = row_pos;
+  p.W_hh = W_hh; p.W1 = W1; p.W2 = W2; p.We2d = We2d; p.param_stride = param_stride; p.prep = prep;
+  p.prep_stride = prep_stride; p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Hc = Hc; p.Din = Din; p.Aact = Aact;
+  p.gabs = gabs; p.grel = grel; p.dH0 = dH0; p.dQ = dQ; p.dEnc = dEnc; p.dSocR = dSocR; p.wpart = wpart;
+  hipLaunchKernelGGL(decoder_bwd_fused_kernel, dim3(n_gens * NW), dim3(256), 0, stream, p);
+  MG_LAUNCH_CHECK("decoder_rollout_bwd_fused");
   return MGGAN_OK;
 }
 

@@ -517,6 +517,18 @@ def device_rollout_rows(idx, n_gens):
     return rows
 
 
+_FUSED_LAYOUT = {}
+
+
+def _fused_layout():
+    """Offsets (in floats) inside one partial block of mggan_decoder_rollout_bwd_fused."""
+    if not _FUSED_LAYOUT:
+        v = [ctypes.c_int() for _ in range(7)]
+        lib.mggan_decoder_bwd_fused_layout(*[ctypes.byref(x) for x in v])
+        _FUSED_LAYOUT.update(zip(("wlen", "A", "bias", "W1", "b1", "W2", "b2"), (x.value for x in v)))
+    return _FUSED_LAYOUT
+
+
 class DecoderRolloutFn(Function):
     """enc_h_to_dec_h + per-generator RelativeDecoder rollouts for the selected rows
     (standard.py:227-265, common_modules.py:97-131)."""
@@ -565,30 +577,43 @@ class DecoderRolloutFn(Function):
         gabs = None if gabs is None else gabs.contiguous()
         grel = None if grel is None else grel.contiguous()
         mk = lambda *s: torch.empty(*s, dtype=F32, device=dev)
-        dPre, dU, gD, dH0, dQ = mk(R, T, 4 * H), mk(R, T, Hh), mk(R, T, 2), mk(R, H), mk(R, Hh)
-        dEnc, dSocR = mk(R, EIN), mk(R, S)
-        lib.mggan_decoder_rollout_bwd(R, T, H, EIN, Z, _p(rows.row_gen), _p(rows.row_pos), _p(g0["w_hh"]), _p(g0["w1"]),
-                                      _p(g0["w2"]), stride, _p(e2d_w), _p(prep), psz, _p(Gt), _p(Cs), _p(Aact), _p(gabs),
-                                      _p(grel), R, _p(dPre), _p(dU), _p(gD), _p(dH0), _p(dQ), _p(dEnc), _p(dSocR), st)
-        if g0["w_hh"].requires_grad:
+        dH0, dQ, dEnc, dSocR = mk(R, H), mk(R, Hh), mk(R, EIN), mk(R, S)
+        # persistent workgroups per generator; each leaves one partial block of weight gradients
+        NW = max(1, min(-(-R // (8 * n_gens)), 512 // n_gens))
+        lay = _fused_layout()
+        wpart = mk(n_gens * NW, lay["wlen"])
+        train_w = g0["w_hh"].requires_grad
+        if train_w:
             gp = root.grad_ptr
-            seg, ng = rows.seg, n_gens
             # attach (and zero on first touch) every generator's gradient slots BEFORE any kernel writes into
             # them: all decoders are in the graph, a generator without rows gets a zero gradient
             for p in owner.generator_parameters():
                 gp(p)
             ptr = {k: gp(v) for k, v in g0.items()}
+        lib.mggan_decoder_rollout_bwd_fused(n_gens, NW, T, H, EIN, Z, _p(rows.seg), _p(rows.row_pos), _p(g0["w_hh"]),
+                                            _p(g0["w1"]), _p(g0["w2"]), stride, _p(e2d_w), _p(prep), psz, _p(Gt), _p(Cs),
+                                            _p(Hp), _p(Hc), _p(Din), _p(Aact), _p(gabs), _p(grel), R, _p(dH0), _p(dQ),
+                                            _p(dEnc), _p(dSocR), _p(wpart), st)
+        if train_w:
+            ng, wl, P = n_gens, lay["wlen"], wpart.data_ptr()
             dprep = torch.zeros(n_gens, 12 * H, dtype=F32, device=dev)
-            with side_stream(dPre, Hp, Din, dU, Hc, dQ, SocR, gD, Aact, dprep, prep):
-                wgrad(dPre, 4 * H, Hp, H, ptr["w_hh"], H, 0, R * T, H, 4 * H, seg, T, ng, stride, stride)
-                wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, R * T, 2, 4 * H, seg, T,
-                      ng, 12 * H, 12 * H, now=True)
-                lib.mggan_lstm_unfold_grads(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), ptr["emb_w"],
-                                            ptr["emb_b"], ptr["w_ih"], ptr["b_ih"], ptr["b_hh"], stride, ng, H, E,
-                                            _p(dprep), 12 * H, _s())
-                wgrad(dU, Hh, Hc, H, ptr["w1"], H + S, ptr["b1"], R * T, H, Hh, seg, T, ng, stride, stride)
-                wgrad(dQ, Hh, SocR, S, ptr["w1"] + 4 * H, H + S, 0, R, S, Hh, seg, 1, ng, stride, stride)
-                wgrad(gD, 2, Aact, Hh, ptr["w2"], Hh, ptr["b2"], R * T, Hh, 2, seg, T, ng, stride, stride)
+            now = (_ReduceDesc * 2)(
+                _ReduceDesc(P + 4 * lay["A"], dprep.data_ptr(), None, 12 * H, 0, 4 * H, 2, 0, 2, NW, ng, wl, 0),
+                _ReduceDesc(P + 4 * lay["bias"], dprep.data_ptr() + 4 * 8 * H, None, 12 * H, 0, 1, 4 * H, 0, 4 * H, NW, ng,
+                            wl, 0))
+            lib.mggan_grad_reduce_multi(ctypes.addressof(now), 2, st)
+            lib.mggan_lstm_unfold_grads(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), ptr["emb_w"], ptr["emb_b"],
+                                        ptr["w_ih"], ptr["b_ih"], ptr["b_hh"], stride, ng, H, E, _p(dprep), 12 * H, st)
+            parts = [(0, ptr["w_hh"], 4 * H, H, H), (lay["W1"], ptr["w1"], Hh, H, H + S), (lay["b1"], ptr["b1"], 1, Hh, Hh),
+                     (lay["W2"], ptr["w2"], 2, Hh, Hh), (lay["b2"], ptr["b2"], 1, 2, 2)]
+            if _DEFER["on"]:
+                for i, (off, dst, M, N, ld) in enumerate(parts):
+                    _queue_reduce(P + 4 * off, dst, 0, M, N, 0, ld, NW, ng, wl, stride, 0, keep=(wpart,) if i == 0 else ())
+            else:
+                arr = (_ReduceDesc * len(parts))(*[_ReduceDesc(P + 4 * off, dst, None, stride, 0, M, N, 0, ld, NW, ng, wl, 0)
+                                                  for off, dst, M, N, ld in parts])
+                lib.mggan_grad_reduce_multi(ctypes.addressof(arr), len(parts), st)
+            wgrad(dQ, Hh, SocR, S, ptr["w1"] + 4 * H, H + S, 0, R, S, Hh, rows.seg, 1, ng, stride, stride)
         if e2d_w.requires_grad:
             pw, pb = root.grad_ptr(e2d_w), root.grad_ptr(e2d_b)
             with side_stream(dH0, E2Din):
