@@ -463,6 +463,209 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
 }
 
 // ------------------------------------------------------------------------------------
+// Decoder rollout, matrix-core form.  A workgroup of four waves owns a tile of 16 rollout rows of one
+// generator for all T steps.  Per step ONE matrix phase with B = h_t (read from a 2 KB LDS tile):
+//     [ W_hh ; W1[:, :H] ] . h_t^T   ->   G_{t+1} = W_hh h_t  (gate pre-activations of the NEXT step, without
+//                                         the rank-2 input term)  and  u_t = W1[:, :H] h_t + q  (hidden2pos)
+// on v_mfma_f32_16x16x4_f32 (exact f32).  Wave w owns hidden units 8w .. 8w+7.  The rows of its two gate
+// M-tiles are permuted so that D register r of lane (fi = lane & 15, fk = lane >> 4) of tile mt is gate r
+// (i, f, g, o) of unit 8w + 4mt + fk for tile row fi: the cell update is lane-local (two units per lane), the
+// autoregressive input enters as two FMAs per gate (A = W_ih W_emb folded), and dxdy = W2 u + b2 is four FMAs
+// plus two cross-lane adds.  The u tile is computed by every wave (8 MFMAs) instead of a second exchange.
+// Saved for backward, in the lane layout the backward kernel reads back with one 16-byte load per unit:
+//     Gt (R,T,H,4) = gates (i,f,g,o) after activation;  Cs (R,T,H,2) = (c_t, h_t);  Hp (R,H) = h_0.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define DEC_HLD 36  // LDS h tile row stride in floats (16-byte aligned rows, conflict-light)
+
+struct DecFwdArgs {
+  int T, b, NW, Rout, EIN, Z, ld_enc, ld_soc;
+  const int* seg;
+  const float* prep;
+  int prep_stride;
+  const int *row_ped, *row_slot, *row_pos;
+  const float *enc_h, *noise, *soc, *xy0, *dxdy0, *We2dT, *be2d;
+  float *out_abs, *out_rel;
+  float *Gt, *Cs, *Hp, *Din, *Aact, *E2Din, *SocR;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void decoder_fwd_mfma_kernel(DecFwdArgs p) {
+  constexpr int H = 32, G4 = 128, Hh = 16;
+  __shared__ __attribute__((aligned(16))) float hs[2][16 * DEC_HLD];
+  const int gi = blockIdx.x / p.NW, wi = blockIdx.x % p.NW;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  const float* P = p.prep + (size_t)gi * p.prep_stride;
+  const float* WT = P + prep_off_whhT(H);
+  const float* w1T = P + prep_off_w1T(H);
+  const float* b1 = w1T + 2 * H * Hh;
+  const float* w2 = b1 + Hh;
+  const float* b2 = w2 + 2 * Hh;
+  const int seg0 = p.seg[gi], seg1 = p.seg[gi + 1];
+  const int ntiles = (seg1 - seg0 + 15) / 16;
+  const bool save = p.Gt != nullptr;
+  const int IN = p.EIN + p.Z;
+
+  for (int tile = wi; tile < ntiles; tile += p.NW) {
+    const int r = seg0 + tile * 16 + fi;
+    const bool valid = r < seg1;
+    const int rc = valid ? r : seg1 - 1;
+    const int ped = p.row_ped[rc], slot = p.row_slot[rc], pos = p.row_pos[rc];
+    const bool sv = save && valid, sv0 = sv && w == 0;
+    // ---- h0 = W_e2d [enc_h | noise] + b_e2d (standard.py:247-252): wave w -> units 8w .. 8w+7 (M rows 0..7) ----
+    f32x4 hacc = f32x4{0.f, 0.f, 0.f, 0.f}, hacc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto e2d_block = [&](int kb, f32x4& x4, f32x4& a4) {  // loads of one 16-wide K block (this lane's quad)
+      const int kq = 16 * kb + 4 * fk;
+      const bool kin = kq + 3 < IN;
+      x4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kq + 3 < p.EIN) x4 = *reinterpret_cast<const f32x4*>(p.enc_h + (size_t)ped * p.ld_enc + kq);
+      else if (kq >= p.EIN && kin)
+        x4 = *reinterpret_cast<const f32x4*>(p.noise + ((size_t)slot * p.b + ped) * p.Z + (kq - p.EIN));
+      if (sv0 && kin) *reinterpret_cast<f32x4*>(p.E2Din + (size_t)r * IN + kq) = x4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a4[q] = (kin && fi < 8) ? p.We2dT[(size_t)(kq + q) * H + 8 * w + fi] : 0.f;
+    };
+    for (int kb0 = 0; kb0 * 16 < IN; kb0 += 3) {  // three blocks of loads in flight, then their 12 MFMAs
+      f32x4 xs[3], as[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) e2d_block(kb0 + i, xs[i], as[i]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; q += 2) {
+          hacc = MFMA16(as[i][q], xs[i][q], hacc);
+          hacc2 = MFMA16(as[i][q + 1], xs[i][q + 1], hacc2);
+        }
+    }
+    hacc += hacc2;
+    // A operands (lane = (M row fi, K index fk) of the 16x4 fragment); K index of step ks is 8 fk + ks.  Loaded per
+    // tile, after the h0 phase, so that its loads in flight and these 60 registers are not live together
+    float Wg[2][8], Wu[8];
+  #pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+  #pragma unroll
+      for (int mt = 0; mt < 2; ++mt) Wg[mt][ks] = WT[(8 * fk + ks) * G4 + (fi & 3) * H + 8 * w + 4 * mt + (fi >> 2)];
+      Wu[ks] = w1T[(8 * fk + ks) * Hh + fi];
+    }
+    // per-lane coefficients of its D values: gate r of unit uj[mt]
+    int uj[2];
+    float ca0[2][4], ca1[2][4], cb[2][4], w2r[2][4], b1r[4];
+  #pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      uj[mt] = 8 * w + 4 * mt + fk;
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = q * H + uj[mt];
+        ca0[mt][q] = P[prep_off_A(H) + m * 2];
+        ca1[mt][q] = P[prep_off_A(H) + m * 2 + 1];
+        cb[mt][q] = P[prep_off_bias(H) + m];
+      }
+    }
+  #pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      w2r[0][q] = w2[4 * fk + q];
+      w2r[1][q] = w2[Hh + 4 * fk + q];
+      b1r[q] = b1[4 * fk + q];
+    }
+    const float b20 = b2[0], b21 = b2[1];
+    lds_barrier();  // the previous tile's last reads of hs[0] are done
+    if (fk < 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hacc[q] += p.be2d[8 * w + 4 * fk + q];
+      *reinterpret_cast<f32x4*>(&hs[0][fi * DEC_HLD + 8 * w + 4 * fk]) = hacc;
+      if (sv) *reinterpret_cast<f32x4*>(p.Hp + (size_t)r * H + 8 * w + 4 * fk) = hacc;
+    }
+    // ---- time-invariant social half of hidden2pos: q = W1[:, H:] soc + b1 (every wave) ----
+    f32x4 qv = f32x4{b1r[0], b1r[1], b1r[2], b1r[3]};
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.soc + (size_t)ped * p.ld_soc + 16 * hh + 4 * fk);
+      if (sv0) *reinterpret_cast<f32x4*>(p.SocR + (size_t)r * H + 16 * hh + 4 * fk) = s4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) qv = MFMA16(w1T[(H + 16 * hh + 4 * fk + q) * Hh + fi], s4[q], qv);
+    }
+    float d0 = p.dxdy0[ped * 2], d1 = p.dxdy0[ped * 2 + 1];
+    float x0 = p.xy0[ped * 2], x1 = p.xy0[ped * 2 + 1];
+    float c[2] = {0.f, 0.f};
+    lds_barrier();
+    f32x4 G[2];
+    {
+      const f32x4 ha = *reinterpret_cast<const f32x4*>(&hs[0][fi * DEC_HLD + 8 * fk]);
+      const f32x4 hb = *reinterpret_cast<const f32x4*>(&hs[0][fi * DEC_HLD + 8 * fk + 4]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        G[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) G[mt] = MFMA16(Wg[mt][ks], ha[ks], G[mt]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) G[mt] = MFMA16(Wg[mt][4 + ks], hb[ks], G[mt]);
+      }
+    }
+
+    for (int t = 0; t < p.T; ++t) {
+      const size_t rt = (size_t)r * p.T + t;
+      float* hw = hs[(t + 1) & 1];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        f32x4 g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = fmaf(ca1[mt][q], d1, fmaf(ca0[mt][q], d0, G[mt][q] + cb[mt][q]));
+        g[0] = mg_sigmoid(g[0]); g[1] = mg_sigmoid(g[1]); g[2] = mg_tanh(g[2]); g[3] = mg_sigmoid(g[3]);
+        c[mt] = fmaf(g[1], c[mt], g[0] * g[2]);
+        const float hn = g[3] * mg_tanh(c[mt]);
+        hw[fi * DEC_HLD + uj[mt]] = hn;
+        if (sv) {
+          *reinterpret_cast<f32x4*>(p.Gt + (rt * H + uj[mt]) * 4) = g;
+          *reinterpret_cast<float2*>(p.Cs + (rt * H + uj[mt]) * 2) = float2{c[mt], hn};
+        }
+      }
+      if (sv0 && fk == 0) *reinterpret_cast<float2*>(p.Din + rt * 2) = float2{d0, d1};
+      lds_barrier();
+      const f32x4 ha = *reinterpret_cast<const f32x4*>(&hw[fi * DEC_HLD + 8 * fk]);
+      const f32x4 hb = *reinterpret_cast<const f32x4*>(&hw[fi * DEC_HLD + 8 * fk + 4]);
+      // u = LeakyReLU(W1[:, :H] h + q): lane (fi, fk) holds units m = 4 fk + r of row fi
+      f32x4 ua = qv, ub = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        ua = MFMA16(Wu[ks], ha[ks], ua);
+        ub = MFMA16(Wu[4 + ks], hb[ks], ub);
+      }
+      if (t + 1 < p.T) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) G[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) G[mt] = MFMA16(Wg[mt][ks], ha[ks], G[mt]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) G[mt] = MFMA16(Wg[mt][4 + ks], hb[ks], G[mt]);
+      }
+      f32x4 av;
+      float n0 = 0.f, n1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float u = ua[q] + ub[q];
+        av[q] = u > 0.f ? u : 0.01f * u;  // LeakyReLU(0.01), utils.py:143-144
+        n0 = fmaf(w2r[0][q], av[q], n0);
+        n1 = fmaf(w2r[1][q], av[q], n1);
+      }
+      if (sv0) *reinterpret_cast<f32x4*>(p.Aact + rt * Hh + 4 * fk) = av;
+      n0 += __shfl_xor(n0, 16, 64); n1 += __shfl_xor(n1, 16, 64);
+      n0 += __shfl_xor(n0, 32, 64); n1 += __shfl_xor(n1, 32, 64);
+      n0 += b20; n1 += b21;
+      d0 = n0; d1 = n1;
+      x0 += n0; x1 += n1;
+      if (valid && w == 0 && fk == 0) {
+        const size_t o = ((size_t)t * p.Rout + pos) * 2;
+        *reinterpret_cast<float2*>(p.out_abs + o) = float2{x0, x1};
+        *reinterpret_cast<float2*>(p.out_rel + o) = float2{n0, n1};
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Fused decoder backward: BPTT over the 12 steps AND the per-generator weight gradients in one launch.
 // The un-fused path writes the gate gradients (512 B per row and step, 157 MB at 25,600 rows) and two
 // weight-gradient GEMMs read them back: HBM-bound.  Here a workgroup is persistent over the 8-row tiles of
@@ -481,8 +684,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
 #define DF_OFF_B2 5040
 #define DPLD 144  // dpbuf row stride (== 16 mod 32: conflict-free MFMA fragment reads, 16-B aligned rows)
 #define HLD 48    // h tile row stride (== 16 mod 32)
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 struct DecFusedArgs {
   int T, NW, Rout, EIN, Z;
   const int* seg;        // generator segment offsets into the sorted rows (g+1)
@@ -491,7 +692,7 @@ struct DecFusedArgs {
   long param_stride;
   const float* prep;
   int prep_stride;
-  const float *Gt, *Cs, *Hp, *Hc, *Din, *Aact, *gabs, *grel;
+  const float *Gt, *Cs, *Hp, *Din, *Aact, *gabs, *grel;
   float *dH0, *dQ, *dEnc, *dSocR, *wpart;
 };
 
@@ -546,11 +747,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                                        n_gr1 = 0.f;
     auto fetch = [&](int t) {
       const size_t rt = (size_t)rc * p.T + t;
-      n_gi = p.Gt[rt * G4 + j]; n_gf = p.Gt[rt * G4 + H + j]; n_gg = p.Gt[rt * G4 + 2 * H + j];
-      n_go = p.Gt[rt * G4 + 3 * H + j];
-      n_cc = p.Cs[rt * H + j];
-      n_cp = t > 0 ? p.Cs[(rt - 1) * H + j] : 0.f;
-      n_hp = p.Hp[rt * H + j];
+      const float4 g4 = *reinterpret_cast<const float4*>(p.Gt + (rt * H + j) * 4);
+      n_gi = g4.x; n_gf = g4.y; n_gg = g4.z; n_go = g4.w;
+      n_cc = p.Cs[(rt * H + j) * 2];
+      const float2 ch = t > 0 ? *reinterpret_cast<const float2*>(p.Cs + ((rt - 1) * H + j) * 2)
+                              : float2{0.f, p.Hp[(size_t)rc * H + j]};
+      n_cp = ch.x; n_hp = ch.y;
       n_d0 = p.Din[rt * 2]; n_d1 = p.Din[rt * 2 + 1];
       const size_t o = ((size_t)t * p.Rout + pos) * 2;
       if (p.gabs) { n_ga0 = p.gabs[o]; n_ga1 = p.gabs[o + 1]; }
@@ -558,7 +760,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (j < Hh) n_av = p.Aact[rt * Hh + j];
     };
     lds_barrier();  // previous tile's LDS traffic is finished
-    hbuf[(p.T - 1) & 1 ^ 1][rr * HLD + j] = p.Hc[((size_t)rc * p.T + p.T - 1) * H + j];  // h_{T-1}
+    hbuf[(p.T - 1) & 1 ^ 1][rr * HLD + j] = p.Cs[(((size_t)rc * p.T + p.T - 1) * H + j) * 2 + 1];  // h_{T-1}
     fetch(p.T - 1);
     for (int t = p.T - 1; t >= 0; --t) {
       const int cur = (t & 1) ^ 1, prv = t & 1;  // hbuf[cur] = h_t, hbuf[prv] <- h_{t-1}
@@ -779,52 +981,33 @@ int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, co
 }
 
 int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const float* prep, int prep_stride,
-                              const int* row_gen, const int* row_ped, const int* row_slot, const int* row_pos,
+                              const int* seg, int n_gens, const int* row_ped, const int* row_slot, const int* row_pos,
                               const float* enc_h, int ld_enc, const float* noise, const float* soc, int ld_soc,
                               const float* xy0, const float* dxdy0, const float* We2dT, const float* be2d,
-                              float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Hp, float* Hc,
-                              float* Din, float* Aact, float* E2Din, float* SocR, hipStream_t stream) {
-  MG_CHECK_ARG(prep && row_gen && row_ped && row_slot && row_pos && enc_h && noise && soc && xy0 && dxdy0 && We2dT &&
-                   be2d && out_abs && out_rel,
+                              float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Hp, float* Din,
+                              float* Aact, float* E2Din, float* SocR, hipStream_t stream) {
+  MG_CHECK_ARG(prep && seg && row_ped && row_slot && row_pos && enc_h && noise && soc && xy0 && dxdy0 && We2dT && be2d &&
+                   out_abs && out_rel,
                "decoder_rollout_fwd: null pointer");
   MG_CHECK_ARG(H == 32, "decoder_rollout_fwd: decoder_h_dim %d not built (32)", H);
-  MG_CHECK_ARG(EIN + Z <= 160, "decoder_rollout_fwd: enc_h + noise width %d exceeds 160", EIN + Z);
+  MG_CHECK_ARG(EIN % 4 == 0 && Z % 4 == 0 && ld_enc % 4 == 0 && ld_soc % 4 == 0 && n_gens > 0,
+               "decoder_rollout_fwd: widths must be multiples of 4 (enc %d, noise %d)", EIN, Z);
   const bool s = Gt != nullptr;
-  MG_CHECK_ARG(s == (Cs != nullptr) && s == (Hp != nullptr) && s == (Hc != nullptr) && s == (Din != nullptr) &&
-                   s == (Aact != nullptr) && s == (E2Din != nullptr) && s == (SocR != nullptr),
+  MG_CHECK_ARG(s == (Cs != nullptr) && s == (Hp != nullptr) && s == (Din != nullptr) && s == (Aact != nullptr) &&
+                   s == (E2Din != nullptr) && s == (SocR != nullptr),
                "decoder_rollout_fwd: save buffers must be all set or all NULL");
   if (R == 0) return MGGAN_OK;
-  SeqArgs p = {};
-  p.R = R; p.T = T; p.b = b; p.prep = prep; p.prep_stride = prep_stride; p.row_gen = row_gen;
-  p.row_ped = row_ped; p.row_slot = row_slot; p.row_pos = row_pos;
+  DecFwdArgs p = {};
+  p.T = T; p.b = b; p.Rout = Rout; p.EIN = EIN; p.Z = Z; p.ld_enc = ld_enc; p.ld_soc = ld_soc; p.seg = seg;
+  p.prep = prep; p.prep_stride = prep_stride; p.row_ped = row_ped; p.row_slot = row_slot; p.row_pos = row_pos;
   p.enc_h = enc_h; p.noise = noise; p.soc = soc; p.xy0 = xy0; p.dxdy0 = dxdy0; p.We2dT = We2dT; p.be2d = be2d;
-  p.ld_enc = ld_enc; p.ld_soc = ld_soc; p.Z = Z; p.EIN = EIN;
-  p.out_abs = out_abs; p.out_rel = out_rel; p.Rout = Rout;
-  p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Hc = Hc; p.Din = Din; p.Aact = Aact; p.E2Din = E2Din; p.SocR = SocR;
-  hipLaunchKernelGGL((lstm_fwd_kernel<32, true>), dim3(cdiv(R, 8)), dim3(256), 0, stream, p);
+  p.out_abs = out_abs; p.out_rel = out_rel;
+  p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Din = Din; p.Aact = Aact; p.E2Din = E2Din; p.SocR = SocR;
+  // one workgroup per 16-row tile, NW workgroups per generator (sized for an even split of R)
+  const int per_gen = cdiv(cdiv(R, n_gens), 16);
+  p.NW = per_gen < 1 ? 1 : (per_gen > 2048 / n_gens ? (2048 / n_gens > 0 ? 2048 / n_gens : 1) : per_gen);
+  hipLaunchKernelGGL(decoder_fwd_mfma_kernel, dim3(n_gens * p.NW), dim3(256), 0, stream, p);
   MG_LAUNCH_CHECK("decoder_rollout_fwd");
-  return MGGAN_OK;
-}
-
-int mggan_decoder_rollout_bwd(int R, int T, int H, int EIN, int Z, const int* row_gen, const int* row_pos,
-                              const float* W_hh, const float* W1, const float* W2, long param_stride,
-                              const float* We2d, const float* prep, int prep_stride, const float* Gt, const float* Cs,
-                              const float* Aact, const float* gabs, const float* grel, int Rout, float* dPre,
-                              float* dU, float* gD, float* dH0, float* dQ, float* dEnc, float* dSocR,
-                              hipStream_t stream) {
-  MG_CHECK_ARG(row_gen && row_pos && W_hh && W1 && W2 && We2d && prep && Gt && Cs && Aact && dPre && dU && gD && dH0 &&
-                   dQ && dEnc && dSocR,
-               "decoder_rollout_bwd: null pointer");
-  MG_CHECK_ARG(H == 32, "decoder_rollout_bwd: decoder_h_dim %d not built (32)", H);
-  if (R == 0) return MGGAN_OK;
-  SeqBwdArgs p = {};
-  p.R = R; p.T = T; p.row_gen = row_gen; p.W_hh = W_hh; p.W1 = W1; p.W2 = W2; p.We2d = We2d;
-  p.param_stride = param_stride; p.prep = prep; p.prep_stride = prep_stride;
-  p.Gt = Gt; p.Cs = Cs; p.Aact = Aact; p.gabs = gabs; p.grel = grel; p.row_pos = row_pos; p.Rout = Rout;
-  p.EIN = EIN; p.Z = Z;
-  p.dPre = dPre; p.dU = dU; p.gD = gD; p.dH0 = dH0; p.dQ = dQ; p.dEnc = dEnc; p.dSocR = dSocR;
-  hipLaunchKernelGGL((lstm_bwd_kernel<32, true>), dim3(cdiv(R, 8)), dim3(256), 0, stream, p);
-  MG_LAUNCH_CHECK("decoder_rollout_bwd");
   return MGGAN_OK;
 }
 
@@ -838,17 +1021,17 @@ int mggan_decoder_bwd_fused_layout(int* wlen, int* off_A, int* off_bias, int* of
 int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, int Z, const int* seg, const int* row_pos,
                                     const float* W_hh, const float* W1, const float* W2, long param_stride,
                                     const float* We2d, const float* prep, int prep_stride, const float* Gt,
-                                    const float* Cs, const float* Hp, const float* Hc, const float* Din,
+                                    const float* Cs, const float* Hp, const float* Din,
                                     const float* Aact, const float* gabs, const float* grel, int Rout, float* dH0,
                                     float* dQ, float* dEnc, float* dSocR, float* wpart, hipStream_t stream) {
-  MG_CHECK_ARG(seg && row_pos && W_hh && W1 && W2 && We2d && prep && Gt && Cs && Hp && Hc && Din && Aact && dH0 && dQ &&
+  MG_CHECK_ARG(seg && row_pos && W_hh && W1 && W2 && We2d && prep && Gt && Cs && Hp && Din && Aact && dH0 && dQ &&
                    dEnc && dSocR && wpart,
                "decoder_rollout_bwd_fused: null pointer");
   MG_CHECK_ARG(H == 32 && NW > 0 && n_gens > 0, "decoder_rollout_bwd_fused: decoder_h_dim %d not built (32)", H);
   DecFusedArgs p = {};
   p.T = T; p.NW = NW; p.Rout = Rout; p.EIN = EIN; p.Z = Z; p.seg = seg; p.row_pos = row_pos;
   p.W_hh = W_hh; p.W1 = W1; p.W2 = W2; p.We2d = We2d; p.param_stride = param_stride; p.prep = prep;
-  p.prep_stride = prep_stride; p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Hc = Hc; p.Din = Din; p.Aact = Aact;
+  p.prep_stride = prep_stride; p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Din = Din; p.Aact = Aact;
   p.gabs = gabs; p.grel = grel; p.dH0 = dH0; p.dQ = dQ; p.dEnc = dEnc; p.dSocR = dSocR; p.wpart = wpart;
   hipLaunchKernelGGL(decoder_bwd_fused_kernel, dim3(n_gens * NW), dim3(256), 0, stream, p);
   MG_LAUNCH_CHECK("decoder_rollout_bwd_fused");

@@ -554,21 +554,22 @@ class DecoderRolloutFn(Function):
         e2dT = _empty(EIN + Z, H, like=enc_h)
         lib.mggan_transpose(_p(e2d_w), _p(e2dT), H, EIN + Z, st)
         mk = (lambda *s: _empty(*s, like=enc_h)) if save else (lambda *s: None)
-        Gt, Cs, Hp, Hc = mk(R, T, 4 * H), mk(R, T, H), mk(R, T, H), mk(R, T, H)
+        # Gt (R,T,H,4) gates i,f,g,o; Cs (R,T,H,2) = (c_t, h_t); Hp (R,H) = h_0
+        Gt, Cs, Hp = mk(R, T, H, 4), mk(R, T, H, 2), mk(R, H)
         Din, Aact, E2Din, SocR = mk(R, T, 2), mk(R, T, H // 2), mk(R, EIN + Z), mk(R, S)
         out_abs, out_rel = _empty(T, R, 2, like=enc_h), _empty(T, R, 2, like=enc_h)
-        lib.mggan_decoder_rollout_fwd(R, T, b, H, EIN, Z, _p(prep), psz, _p(rows.row_gen), _p(rows.row_ped),
+        lib.mggan_decoder_rollout_fwd(R, T, b, H, EIN, Z, _p(prep), psz, _p(rows.seg), n_gens, _p(rows.row_ped),
                                       _p(rows.row_slot), _p(rows.row_pos), _p(enc_h), ld_enc, _p(noise) or _p(enc_h), _p(soc), ld_soc,
                                       _p(xy0), _p(dxdy0), _p(e2dT), _p(e2d_b), _p(out_abs), _p(out_rel), R, _p(Gt),
-                                      _p(Cs), _p(Hp), _p(Hc), _p(Din), _p(Aact), _p(E2Din), _p(SocR), st)
+                                      _p(Cs), _p(Hp), _p(Din), _p(Aact), _p(E2Din), _p(SocR), st)
         if save:
             ctx.meta = (rows, g0, n_gens, stride, T, owner, (b, EIN, Z, H, E, S, psz))
-            ctx.save_for_backward(e2d_w, e2d_b, prep, Gt, Cs, Hp, Hc, Din, Aact, E2Din, SocR)
+            ctx.save_for_backward(e2d_w, e2d_b, prep, Gt, Cs, Hp, Din, Aact, E2Din, SocR)
         return out_abs, out_rel
 
     @staticmethod
     def backward(ctx, gabs, grel):
-        e2d_w, e2d_b, prep, Gt, Cs, Hp, Hc, Din, Aact, E2Din, SocR = ctx.saved_tensors
+        e2d_w, e2d_b, prep, Gt, Cs, Hp, Din, Aact, E2Din, SocR = ctx.saved_tensors
         rows, g0, n_gens, stride, T, owner, (b, EIN, Z, H, E, S, psz) = ctx.meta
         root = root_of(owner)
         R, Hh = rows.R, H // 2
@@ -592,7 +593,7 @@ class DecoderRolloutFn(Function):
             ptr = {k: gp(v) for k, v in g0.items()}
         lib.mggan_decoder_rollout_bwd_fused(n_gens, NW, T, H, EIN, Z, _p(rows.seg), _p(rows.row_pos), _p(g0["w_hh"]),
                                             _p(g0["w1"]), _p(g0["w2"]), stride, _p(e2d_w), _p(prep), psz, _p(Gt), _p(Cs),
-                                            _p(Hp), _p(Hc), _p(Din), _p(Aact), _p(gabs), _p(grel), R, _p(dH0), _p(dQ),
+                                            _p(Hp), _p(Din), _p(Aact), _p(gabs), _p(grel), R, _p(dH0), _p(dQ),
                                             _p(dEnc), _p(dSocR), _p(wpart), st)
         if train_w:
             ng, wl, P = n_gens, lay["wlen"], wpart.data_ptr()
