@@ -902,6 +902,263 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// Matrix-core form of the fused backward, in the lane layout of decoder_fwd_mfma_kernel: four waves per
+// 16-row tile, wave w owns hidden units 8w .. 8w+7, lane (fi = lane & 15, fk = lane >> 4) holds the cell
+// state gradients of units 8w + fk and 8w + 4 + fk of tile row fi.  Per step, ONE barrier:
+//   1. du = W2^T g . LeakyReLU'(u)  (lane-local, units m = 4 fk + r)      dh += W1[:, :H]^T du      (4 MFMAs)
+//   2. gate gradients dPre for the lane's two units (VALU) -> LDS tile dps[row][unit*4 + gate]
+//   3. barrier; then with B = dPre^T read back as eight 16-byte LDS loads:
+//        [ W_hh^T (own 8 units) ; A^T ] . dPre^T  ->  dh_{t-1} of the own units and d(dxdy_t)       (32 MFMAs)
+//      (M rows 4 fk + {0,1} = the lane's two units, rows 4 fk + {2,3} = the two input components: every lane
+//      gets the complete sums in its D registers, no partial exchange)
+//   4. weight gradients with K = the 16 tile rows: [dW_hh | dA | dbias] += dPre^T [h_{t-1} | dxdy | 1]
+//      (wave w: position tiles 2w, 2w+1 x three column tiles, 24 MFMAs), dW1[:, :H] += du^T h_t (2 MFMAs)
+// The LDS tiles are multi-buffered over t so that the single barrier per step is enough.
+#define DB_RS 132  // dPre tile row stride (== 4 mod 32: conflict-free 16-byte row reads)
+#define DB_HS 48   // h tile row stride (== 16 mod 32: conflict-free transposed reads); cols 32,33 = dxdy, 34 = 1
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void decoder_bwd_mfma_kernel(DecFusedArgs p) {
+  constexpr int H = 32, Hh = 16, S = 32;
+  __shared__ __attribute__((aligned(16))) float dps[2][16 * DB_RS];
+  __shared__ __attribute__((aligned(16))) float hts[3][16 * DB_HS];
+  __shared__ __attribute__((aligned(16))) float dus[2][16 * Hh];
+  __shared__ float red[16 * 52];
+  const int gi = blockIdx.x / p.NW, wi = blockIdx.x % p.NW;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  const long po = (long)gi * p.param_stride;
+  const float* P = p.prep + (size_t)gi * p.prep_stride;
+  const float* Whh = p.W_hh + po;
+  const float* W1 = p.W1 + po;
+  const int seg0 = p.seg[gi], seg1 = p.seg[gi + 1];
+  const int ntiles = (seg1 - seg0 + 15) / 16;
+  const int IN = p.EIN + p.Z;
+  const int uj[2] = {8 * w + fk, 8 * w + 4 + fk};
+  const int sel = fi & 3, us = 8 * w + 4 * (sel & 1) + (fi >> 2);  // A-operand row role of this lane
+
+  // A operands.  Position p = unit*4 + gate in the dPre tile <-> original gate row (p & 3)*H + (p >> 2).
+  float Ah[32], Aw1[4], w2c[2][4];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) {
+    const int pp = 16 * (ks >> 2) + 4 * fk + (ks & 3), m = (pp & 3) * H + (pp >> 2);
+    Ah[ks] = sel < 2 ? Whh[(size_t)m * H + us] : P[prep_off_A(H) + m * 2 + (sel - 2)];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) Aw1[ks] = sel < 2 ? W1[(size_t)(4 * fk + ks) * (H + S) + us] : 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    w2c[0][q] = p.W2[po + 4 * fk + q];
+    w2c[1][q] = p.W2[po + Hh + 4 * fk + q];
+  }
+  // constant part of the h tiles: column 34 = 1 (bias), 35..47 = 0
+  for (int i = threadIdx.x; i < 3 * 16 * 16; i += 256) {
+    const int bsel = i / 256, row = (i / 16) % 16, col = i % 16;
+    hts[bsel][row * DB_HS + H + col] = col == 2 ? 1.f : 0.f;
+  }
+
+  f32x4 accW[2][3], accU = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) accW[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float accW2[2][4], accb1[4], accb2[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) accW2[0][q] = accW2[1][q] = accb1[q] = 0.f;
+
+  for (int tile = wi; tile < ntiles; tile += p.NW) {
+    const int r = seg0 + tile * 16 + fi;
+    const bool valid = r < seg1;
+    const int rc = valid ? r : seg1 - 1;
+    const float vm = valid ? 1.f : 0.f;  // rows past the segment end contribute nothing
+    const int pos = p.row_pos[rc];
+    const size_t r0 = (size_t)rc * p.T;
+    float dh[2] = {0.f, 0.f}, dc[2] = {0.f, 0.f}, dd0 = 0.f, dd1 = 0.f, s0 = 0.f, s1 = 0.f;
+    f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
+    // prefetch registers of the next step
+    f32x4 n_g[2], n_av;
+    float2 n_ch[2], n_din, n_ga = float2{0.f, 0.f}, n_gr = float2{0.f, 0.f};
+    float cc[2];
+    auto fetch = [&](int t) {
+      const size_t rt = r0 + t;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        n_g[mt] = *reinterpret_cast<const f32x4*>(p.Gt + (rt * H + uj[mt]) * 4);
+        n_ch[mt] = t > 0 ? *reinterpret_cast<const float2*>(p.Cs + ((rt - 1) * H + uj[mt]) * 2)
+                         : float2{0.f, p.Hp[(size_t)rc * H + uj[mt]]};  // (c_{t-1}, h_{t-1})
+      }
+      n_av = *reinterpret_cast<const f32x4*>(p.Aact + rt * Hh + 4 * fk);
+      n_din = *reinterpret_cast<const float2*>(p.Din + rt * 2);
+      const size_t o = ((size_t)t * p.Rout + pos) * 2;
+      if (p.gabs) n_ga = *reinterpret_cast<const float2*>(p.gabs + o);
+      if (p.grel) n_gr = *reinterpret_cast<const float2*>(p.grel + o);
+    };
+    lds_barrier();  // the previous tile's last LDS reads are done
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float2 ch = *reinterpret_cast<const float2*>(p.Cs + ((r0 + p.T - 1) * H + uj[mt]) * 2);
+      cc[mt] = ch.x;
+      hts[p.T % 3][fi * DB_HS + uj[mt]] = ch.y;  // h_{T-1}
+    }
+    fetch(p.T - 1);
+
+    for (int t = p.T - 1; t >= 0; --t) {
+      float* dpw = dps[t & 1];
+      float* duw = dus[t & 1];
+      float* htw = hts[t % 3];              // receives h_{t-1}
+      const float* htc = hts[(t + 1) % 3];  // holds h_t
+      const f32x4 g4[2] = {n_g[0], n_g[1]}, av = n_av;
+      const float2 ch[2] = {n_ch[0], n_ch[1]}, din = n_din, ga = n_ga, gr = n_gr;
+      if (t > 0) fetch(t - 1);
+      s0 += ga.x; s1 += ga.y;
+      const float g0 = (s0 + dd0 + gr.x) * vm, g1 = (s1 + dd1 + gr.y) * vm;
+      f32x4 du;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        du[q] = fmaf(w2c[0][q], g0, w2c[1][q] * g1) * (av[q] > 0.f ? 1.f : 0.01f);
+        accW2[0][q] = fmaf(g0, av[q], accW2[0][q]);
+        accW2[1][q] = fmaf(g1, av[q], accW2[1][q]);
+      }
+      dq += du;
+      accb2[0] += g0; accb2[1] += g1;
+      if (w == 0) {
+        *reinterpret_cast<f32x4*>(&duw[fi * Hh + 4 * fk]) = du;
+        if (fk == 0) *reinterpret_cast<float2*>(&htw[fi * DB_HS + H]) = din;
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) htw[fi * DB_HS + uj[mt]] = ch[mt].y;
+      // dh += W1[:, :H]^T du  (rows 4 fk + {0,1} of the M tile are this lane's units)
+      f32x4 a1 = f32x4{dh[0], dh[1], 0.f, 0.f}, a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+      a1 = MFMA16(Aw1[0], du[0], a1);
+      a2 = MFMA16(Aw1[1], du[1], a2);
+      a1 = MFMA16(Aw1[2], du[2], a1);
+      a2 = MFMA16(Aw1[3], du[3], a2);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const float dhv = a1[mt] + a2[mt];
+        const float gi_ = g4[mt][0], gf = g4[mt][1], gg = g4[mt][2], go = g4[mt][3];
+        const float tc = mg_tanh(cc[mt]);
+        const float dO = dhv * tc;
+        const float dcv = fmaf(dhv * go, 1.f - tc * tc, dc[mt]);
+        f32x4 dp;
+        dp[0] = dcv * gg * gi_ * (1.f - gi_) * vm;
+        dp[1] = dcv * ch[mt].x * gf * (1.f - gf) * vm;
+        dp[2] = dcv * gi_ * (1.f - gg * gg) * vm;
+        dp[3] = dO * go * (1.f - go) * vm;
+        dc[mt] = dcv * gf;
+        cc[mt] = ch[mt].x;
+        *reinterpret_cast<f32x4*>(&dpw[fi * DB_RS + uj[mt] * 4]) = dp;
+      }
+      lds_barrier();
+      // [dh_{t-1} (own units) ; d dxdy_t] = [W_hh^T ; A^T] dPre^T, K = 128 gate rows in tile-position order
+      f32x4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&dpw[fi * DB_RS + 16 * j + 4 * fk]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = MFMA16(Ah[4 * j + q], b4[q], acc[q]);
+      }
+      // weight gradients, K = the 16 tile rows
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        float a[2], bv[3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = dpw[(4 * ks + fk) * DB_RS + 16 * (2 * w + i) + fi];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bv[n] = htw[(4 * ks + fk) * DB_HS + 16 * n + fi];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) accW[i][n] = MFMA16(a[i], bv[n], accW[i][n]);
+      }
+      {  // dW1[:, :H] += du^T h_t : wave w -> column tile (w & 1), K half (w >> 1)
+        const int nt = w & 1, kh = w >> 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int ks = 2 * kh + kk;
+          accU = MFMA16(duw[(4 * ks + fk) * Hh + fi], htc[(4 * ks + fk) * DB_HS + 16 * nt + fi], accU);
+        }
+      }
+      const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      dh[0] = sum[0]; dh[1] = sum[1]; dd0 = sum[2]; dd1 = sum[3];
+    }
+    // ---- per-row outputs of this tile: dH0, dQ, d(enc_h row), d(social row) ----
+    float* h0t = hts[2];  // h_{-1} slot of the t = 0 step is hts[0]; hts[2] held h_1 (last read at t = 1)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (valid) p.dH0[(size_t)r * H + uj[mt]] = dh[mt];
+      h0t[fi * DB_HS + uj[mt]] = dh[mt];
+    }
+    if (w == 0 && valid) *reinterpret_cast<f32x4*>(p.dQ + (size_t)r * Hh + 4 * fk) = dq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accb1[q] += dq[q];
+    if (w < 2) {  // dSocR^T [S x rows] = W1[:, H:]^T dQ^T : wave w -> social columns 16 w .. 16 w + 15
+      f32x4 ds = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ds = MFMA16(W1[(size_t)(4 * fk + ks) * (H + S) + H + 16 * w + fi], dq[ks], ds);
+      if (valid) *reinterpret_cast<f32x4*>(p.dSocR + (size_t)r * S + 16 * w + 4 * fk) = ds;
+    }
+    lds_barrier();
+    {  // dEnc^T [EIN x rows] = W_e2d[:, :EIN]^T dH0^T : wave w -> 16-column tiles w, w + 4, ...
+      const f32x4 ha = *reinterpret_cast<const f32x4*>(&h0t[fi * DB_HS + 8 * fk]);
+      const f32x4 hb = *reinterpret_cast<const f32x4*>(&h0t[fi * DB_HS + 8 * fk + 4]);
+      for (int ct = w; ct * 16 < p.EIN; ct += 4) {
+        const int col = 16 * ct + fi;
+        const bool cin = col < p.EIN;
+        f32x4 de = f32x4{0.f, 0.f, 0.f, 0.f}, de2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          de = MFMA16(cin ? p.We2d[(size_t)(8 * fk + ks) * IN + col] : 0.f, ha[ks], de);
+          de2 = MFMA16(cin ? p.We2d[(size_t)(8 * fk + 4 + ks) * IN + col] : 0.f, hb[ks], de2);
+        }
+        de += de2;
+        if (valid && 16 * ct + 4 * fk + 3 < p.EIN) *reinterpret_cast<f32x4*>(p.dEnc + (size_t)r * p.EIN + 16 * ct + 4 * fk) = de;
+      }
+    }
+  }
+
+  // ---- this workgroup's partial block ----
+  float* wp = p.wpart + (size_t)blockIdx.x * DF_WLEN;
+  // accW[i][n][q] of lane (fi, fk): tile position pp = 16 (2w + i) + 4 fk + q, column 16 n + fi
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pp = 16 * (2 * w + i) + 4 * fk + q, m = (pp & 3) * H + (pp >> 2);
+      wp[m * H + fi] = accW[i][0][q];
+      wp[m * H + 16 + fi] = accW[i][1][q];
+      if (fi < 2) wp[DF_OFF_A + m * 2 + fi] = accW[i][2][q];
+      else if (fi == 2) wp[DF_OFF_B + m] = accW[i][2][q];
+    }
+  lds_barrier();
+  // W1h: column tile (w & 1) is shared by waves w and w ^ 2 (K halves): sum them through LDS
+  float* u = dps[0];  // [4][256]
+#pragma unroll
+  for (int q = 0; q < 4; ++q) u[w * 256 + (4 * fk + q) * 16 + fi] = accU[q];
+  if (w == 0) {  // lane-local accumulators (W2, b1, b2) -> fold over the 16 tile rows
+    float* f = red + fi * 52;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f[4 * fk + q] = accW2[0][q];
+      f[Hh + 4 * fk + q] = accW2[1][q];
+      f[32 + 4 * fk + q] = accb1[q];
+    }
+    if (fk == 0) { f[48] = accb2[0]; f[49] = accb2[1]; }
+  }
+  lds_barrier();
+  if (threadIdx.x < 50) {
+    const int i = threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q * 52 + i];
+    wp[i < 32 ? DF_OFF_W2 + i : i < 48 ? DF_OFF_B1 + (i - 32) : DF_OFF_B2 + (i - 48)] = t;
+  }
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int m = i / 32, k = i % 32, nt = k / 16;
+    wp[DF_OFF_W1 + i] = u[nt * 256 + m * 16 + (k & 15)] + u[(nt + 2) * 256 + m * 16 + (k & 15)];
+  }
+}
+
 // dst[ped][c] (+)= sum_k src[inv[k*b + ped]][c]
 __global__ void gather_sum_kernel(const float* __restrict__ src, int lds_, const int* __restrict__ inv, float* dst,
                                   int ldd, int b, int K, int ncols, int accumulate) {
@@ -1033,7 +1290,7 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
   p.W_hh = W_hh; p.W1 = W1; p.W2 = W2; p.We2d = We2d; p.param_stride = param_stride; p.prep = prep;
   p.prep_stride = prep_stride; p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Din = Din; p.Aact = Aact;
   p.gabs = gabs; p.grel = grel; p.dH0 = dH0; p.dQ = dQ; p.dEnc = dEnc; p.dSocR = dSocR; p.wpart = wpart;
-  hipLaunchKernelGGL(decoder_bwd_fused_kernel, dim3(n_gens * NW), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(decoder_bwd_mfma_kernel, dim3(n_gens * NW), dim3(256), 0, stream, p);
   MG_LAUNCH_CHECK("decoder_rollout_bwd_fused");
   return MGGAN_OK;
 }

@@ -580,7 +580,8 @@ class DecoderRolloutFn(Function):
         mk = lambda *s: torch.empty(*s, dtype=F32, device=dev)
         dH0, dQ, dEnc, dSocR = mk(R, H), mk(R, Hh), mk(R, EIN), mk(R, S)
         # persistent workgroups per generator; each leaves one partial block of weight gradients
-        NW = max(1, min(-(-R // (8 * n_gens)), 512 // n_gens))
+        # (16-row tiles; about two resident workgroups per CU, each looping over its generator's tiles)
+        NW = max(1, min(-(-R // (16 * n_gens)), 512 // n_gens))
         lay = _fused_layout()
         wpart = mk(n_gens * NW, lay["wlen"])
         train_w = g0["w_hh"].requires_grad
