@@ -56,6 +56,13 @@ int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, i
                 int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, int feature_major,
                 const float* Yact, int ld_yact, int act, float slope, void* workspace, size_t workspace_bytes,
                 mggan_stream_t stream);
+/* Many independent weight gradients (partial-sum phase of mggan_wgrad with dW == NULL) in one launch per
+ * operand layout.  descs: array of n structures
+ *   { const float* dZ; const float* X; float* workspace; const int* seg;
+ *     int rows, K, N, lddz, ldx, seg_scale, n_groups, feature_major; }
+ * with the meaning of the mggan_wgrad arguments of the same names; each workspace must hold
+ * mggan_wgrad_workspace_bytes(rows, K, N, n_groups).  Fold the partials with mggan_grad_reduce_multi. */
+int mggan_wgrad_multi(const void* descs, int n, mggan_stream_t stream);
 /* Deferred reduction: mggan_wgrad with dW == NULL only writes its partial sums into `workspace`
  * ([groups*splits][N*(K+1)]); mggan_grad_reduce_multi then folds MANY such partial buffers into the
  * gradient buffers in one launch.  descs = host array of n structs

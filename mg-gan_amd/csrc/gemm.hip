@@ -98,17 +98,17 @@ __device__ __forceinline__ float lds_frag(const float* T, int m, int k) {  // el
   return KM ? T[k * LDK + m] : T[m * LDM + k];
 }
 
-template <bool A_KM, bool B_KM, bool ACT = false>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+template <bool A_KM, bool B_KM, bool ACT>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz) {
   __shared__ __attribute__((aligned(16))) float As[A_KM ? BK * LDK : BM * LDM];
   __shared__ __attribute__((aligned(16))) float Bs[B_KM ? BK * LDK : BN * LDM];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * 32, wn = (w & 1) * 32;   // this wave's 32x32 quadrant of the 64x64 tile
   const int fi = lane & 15, fk = lane >> 4;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   int k_begin = 0, k_end = g.K;
   if (g.splits > 0) {
-    int z = blockIdx.z;
+    int z = bz;
     int grp = z / g.splits, sp = z % g.splits;
     int r0 = 0, r1 = g.K;
     if (g.seg) { r0 = g.seg[grp] * g.seg_scale; r1 = g.seg[grp + 1] * g.seg_scale; }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 
   // C/D fragment: lane l, register r <-> row (l>>4)*4 + r, column l&15 of each 16x16 tile
-  float* P = g.splits > 0 ? g.C + (size_t)blockIdx.z * g.M * g.N : nullptr;
+  float* P = g.splits > 0 ? g.C + (size_t)bz * g.M * g.N : nullptr;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -171,6 +171,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
           *c = g.accumulate ? (*c + v) : v;
         }
       }
+}
+
+template <bool A_KM, bool B_KM, bool ACT = false>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  gemm_tile<A_KM, B_KM, ACT>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- many independent weight-gradient GEMMs (partial-sum mode) in ONE launch --------------------
+// A training step has ~20 weight gradients, most of them a handful of workgroups and a few microseconds of
+// work: launched one by one they are pure launch latency.  The batch kernel maps a flat block index to
+// (problem, tile, split); the partial sums are folded by grad_reduce_multi_kernel afterwards.
+#define MG_MAX_GEMM_BATCH 16
+struct GemmBatch {
+  GemmArgs a[MG_MAX_GEMM_BATCH];
+  int blk0[MG_MAX_GEMM_BATCH];  // first flat block of each problem
+  int gx[MG_MAX_GEMM_BATCH], gy[MG_MAX_GEMM_BATCH];
+  int n;
+};
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_multi_kernel(GemmBatch bt) {
+  int di = 0;
+#pragma unroll 1
+  for (int i = 1; i < bt.n; ++i)
+    if ((int)blockIdx.x >= bt.blk0[i]) di = i;
+  const int rel = blockIdx.x - bt.blk0[di];
+  const int gx = bt.gx[di], gy = bt.gy[di];
+  gemm_tile<A_KM, B_KM, false>(bt.a[di], rel % gx, (rel / gx) % gy, rel / (gx * gy));
 }
 
 // dW[grp][m*lddw + n] += sum_z P[grp*splits+z][m*Naug+n];  column Naug-1 -> db[grp][m]
@@ -386,6 +414,51 @@ int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, i
   hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(1024), 0, stream, (const float*)workspace, dW, db, N, Naug, 1,
                      lddw, splits, w_stride, b_stride);
   MG_LAUNCH_CHECK("wgrad_reduce");
+  return MGGAN_OK;
+}
+
+struct WgradDesc {  // mirrors the ctypes structure in mggan/hip/functions.py
+  const float* dZ;
+  const float* X;
+  float* workspace;
+  const int* seg;
+  int rows, K, N, lddz, ldx, seg_scale, n_groups, feature_major;
+};
+
+int mggan_wgrad_multi(const void* descs, int n, hipStream_t stream) {
+  MG_CHECK_ARG(descs || n == 0, "wgrad_multi: null descriptor array");
+  const WgradDesc* d = (const WgradDesc*)descs;
+  for (int fm = 0; fm < 2; ++fm) {
+    GemmBatch bt;
+    bt.n = 0;
+    int blocks = 0;
+    auto launch = [&]() {
+      if (bt.n == 0) return;
+      if (fm) hipLaunchKernelGGL((gemm_multi_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, bt);
+      else hipLaunchKernelGGL((gemm_multi_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, bt);
+      bt.n = 0;
+      blocks = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+      if ((d[i].feature_major != 0) != (fm != 0) || d[i].rows == 0) continue;
+      MG_CHECK_ARG(d[i].dZ && d[i].X && d[i].workspace && d[i].K > 0 && d[i].N > 0, "wgrad_multi: bad descriptor %d", i);
+      const int ng = d[i].n_groups > 0 ? d[i].n_groups : 1;
+      MG_CHECK_ARG(ng == 1 || d[i].seg, "wgrad_multi: grouped mode needs segment offsets");
+      GemmArgs g = {};
+      g.A = d[i].dZ; g.B = d[i].X; g.C = d[i].workspace;
+      g.M = d[i].N; g.N = d[i].K + 1; g.K = d[i].rows; g.lda = d[i].lddz; g.ldb = d[i].ldx; g.ldc = g.N;
+      g.splits = mggan_wgrad_splits(d[i].rows, d[i].K, d[i].N, d[i].n_groups);
+      g.ones_col = 1; g.seg = d[i].seg; g.seg_scale = d[i].seg_scale > 0 ? d[i].seg_scale : 1; g.n_groups = ng;
+      bt.a[bt.n] = g;
+      bt.blk0[bt.n] = blocks;
+      bt.gx[bt.n] = cdiv(g.N, BN);
+      bt.gy[bt.n] = cdiv(g.M, BM);
+      blocks += bt.gx[bt.n] * bt.gy[bt.n] * g.splits * ng;
+      if (++bt.n == MG_MAX_GEMM_BATCH) launch();
+    }
+    launch();
+    MG_LAUNCH_CHECK("wgrad_multi");
+  }
   return MGGAN_OK;
 }
 

@@ -101,7 +101,14 @@ class _ReduceDesc(ctypes.Structure):
 
 # Deferred gradient reduction: inside the trainer's backward every weight-gradient kernel only leaves its
 # partial sums behind; ONE batched launch per optimizer step folds them all into the flat gradient buffer.
-_DEFER = {"on": False, "descs": [], "keep": []}
+class _WgradDesc(ctypes.Structure):
+    _fields_ = [("dZ", ctypes.c_void_p), ("X", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("seg", ctypes.c_void_p),
+                ("rows", ctypes.c_int), ("K", ctypes.c_int), ("N", ctypes.c_int), ("lddz", ctypes.c_int),
+                ("ldx", ctypes.c_int), ("seg_scale", ctypes.c_int), ("n_groups", ctypes.c_int),
+                ("feature_major", ctypes.c_int)]
+
+
+_DEFER = {"on": False, "descs": [], "keep": [], "gemms": []}
 
 
 def defer_grad_reduce(on=True):
@@ -120,6 +127,10 @@ def flush_grad_reduces():
     d = _DEFER["descs"]
     if not d:
         return
+    gm = _DEFER["gemms"]
+    if gm:  # the queued weight-gradient GEMMs (partial sums), one launch per operand layout and 16 problems
+        arr = (_WgradDesc * len(gm))(*gm)
+        lib.mggan_wgrad_multi(ctypes.addressof(arr), len(gm), _s())
     batch, seen = [], set()
 
     def launch():
@@ -135,7 +146,7 @@ def flush_grad_reduces():
         batch.append(desc)
         seen |= keys
     launch()
-    _DEFER["descs"], _DEFER["keep"] = [], []
+    _DEFER["descs"], _DEFER["keep"], _DEFER["gemms"] = [], [], []
 
 
 def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scale=1, n_groups=0, w_stride=0,
@@ -149,13 +160,21 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
     if _SIDE["dirty"]:
         _SIDE["keep"].append(ws)
     defer = _DEFER["on"] and not _SIDE["dirty"] and not now  # now=True: the result is consumed right away
-    lib.mggan_wgrad(_p(dz) if torch.is_tensor(dz) else dz, lddz, _p(x) if torch.is_tensor(x) else x, ldx,
-                    0 if defer else dW_ptr, lddw, db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, fm,
-                    _p(yact), ld_yact, act, float(slope), ws.data_ptr(), nbytes, _s())
+    pz, px = (_p(dz) if torch.is_tensor(dz) else dz), (_p(x) if torch.is_tensor(x) else x)
+    if defer and yact is None:
+        # neither the GEMM nor its reduction runs now: both are queued (operands kept alive) and go out in the
+        # batched launches of flush_grad_reduces() at the end of the backward pass
+        _DEFER["gemms"].append(_WgradDesc(pz, px, ws.data_ptr(), _p(seg) or None, rows, K, N, lddz, ldx, seg_scale, n_groups,
+                                          fm))
+        keep = (ws, dz, x, seg)
+    else:
+        lib.mggan_wgrad(pz, lddz, px, ldx, 0 if defer else dW_ptr, lddw, db_ptr, rows, K, N, _p(seg), seg_scale, n_groups,
+                        w_stride, b_stride, fm, _p(yact), ld_yact, act, float(slope), ws.data_ptr(), nbytes, _s())
+        keep = (ws,)
     if defer:
         ng = max(n_groups, 1)
         _queue_reduce(ws.data_ptr(), dW_ptr, db_ptr, N, K + 1, 1, lddw, lib.mggan_wgrad_splits(rows, K, N, n_groups), ng,
-                      N * (K + 1), w_stride, b_stride, keep=(ws,))
+                      N * (K + 1), w_stride, b_stride, keep=keep)
 
 
 # ------------------------------------------------------------------------------------------
