@@ -30,6 +30,25 @@ F32_PEAK_TFLOPS = 157.3  # MI355X dense f32 (vector == f32-MFMA rate), MI355X_MI
 HBM_PEAK_GBS = 8000.0
 
 
+def kernel_of(name, a):
+    """C-ABI entry -> the HIP kernel that does its work, named as tools/hbm_traffic.py and the rocprofv3
+    summaries under profiles/ name it."""
+    fixed = {
+        "mggan_decoder_rollout_bwd_fused": "decoder_bwd_mfma_kernel",
+        "mggan_decoder_rollout_fwd": "decoder_fwd_mfma_kernel",
+        "mggan_wgrad_multi": "gemm_multi_kernel<true,true>",
+        "mggan_wgrad": "gemm_kernel<true,true,false>",
+        "mggan_linear_fwd": "gemm_kernel<false,false,false>",
+        "mggan_linear_bwd_data": "gemm_kernel<false,true,false>",
+        "mggan_conv2_bwd": "conv2_bwd_mfma_kernel",
+    }
+    if name in fixed:
+        return fixed[name]
+    if name in ("mggan_conv1_bwd", "mggan_conv1_fwd", "mggan_conv2_fwd"):
+        return "{}_kernel<{}>".format(name[len("mggan_"):], a[2])
+    return name
+
+
 def flops_of(name, a):
     """Algorithmic FLOPs (2*MAC, reference operator shapes) of one C-ABI call."""
     if name == "mggan_linear_fwd":
@@ -38,6 +57,11 @@ def flops_of(name, a):
         return 2.0 * a[6] * a[7] * a[8]
     if name == "mggan_wgrad":
         return 2.0 * a[7] * a[8] * a[9]
+    if name == "mggan_wgrad_multi":  # a batch of weight gradients: the launcher notes the FLOPs of each batch
+        from mggan.hip import functions as HF
+
+        notes = HF.TRACE_NOTES["wgrad_multi_flops"]
+        return notes.pop(0) if notes else 0.0
     if name == "mggan_lstm_encoder_fwd":
         T, b, H = a[1], a[2], a[3]
         E = H // 2 if H == 32 else H
@@ -160,6 +184,7 @@ def main():
     b = batch["in_xy"].shape[1]
     batch["loss_mask"] = None  # synthetic data has no NaN ground truth: every pedestrian is valid
     tr.defer_metrics = True
+    tr.zero_grads_in_step = True  # AdamW zeroes what it consumed: no separate memset per step
     metrics = defaultdict(list)
     use_graph = args.rng == "device" and world == 1 and not args.no_graph
     if use_graph:
@@ -205,21 +230,33 @@ def main():
     rows = []
     for name, (calls, ms, arglist) in trace.items():
         fl = sum(flops_of(name, a) for a in arglist)
-        rows.append((ms / n_prof, name, calls // n_prof, fl / n_prof))
+        rows.append((ms / n_prof, name, calls // n_prof, fl / n_prof, kernel_of(name, arglist[0])))
     rows.sort(reverse=True)
     gpu_ms = sum(r[0] for r in rows)
-    top = rows[0]
-    per_launch_flops = top[3] / max(top[2], 1)
-    per_launch_s = top[0] / max(top[2], 1) * 1e-3
-    achieved = per_launch_flops / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
     total_flops = sum(r[3] for r in rows)
-    roofline = {"bound": "mfma", "kernel": top[1], "achieved": round(achieved, 3), "peak": F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / F32_PEAK_TFLOPS, 5), "traffic": None,
-                "launches_per_step": top[2], "avg_launch_ms": round(per_launch_s * 1e3, 4),
-                "note": "f32 (exact) -- peak is the dense f32 vector/MFMA rate; achieved = algorithmic FLOPs "
-                        "(SURVEY App. D shapes) / HIP-event time of this C-ABI entry"}
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    traffic_tab = {}
+    if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
+        with open(tpath) as fh:
+            traffic_tab = json.load(fh)
+
+    def roof(row):
+        ms, name, calls, fl, symbol = row
+        per_launch_s = ms / max(calls, 1) * 1e-3
+        achieved = fl / max(calls, 1) / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
+        return {"bound": "mfma", "kernel": symbol, "entry": name, "achieved": round(achieved, 3),
+                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_PEAK_TFLOPS, 5),
+                "traffic": traffic_tab.get(symbol, {}).get("bytes_per_launch"), "launches_per_step": calls,
+                "avg_launch_ms": round(per_launch_s * 1e3, 4)}
+
+    # the dominant kernel = the one with the largest share of the step's GPU time (summed over its launches)
+    roofline = roof(rows[0])
+    roofline["note"] = ("f32 (exact) -- peak is the dense f32 vector/MFMA rate; achieved = algorithmic FLOPs per launch "
+                        "(SURVEY App. D shapes) / average HIP-event duration of a launch of this kernel; traffic = HBM "
+                        "bytes per launch from the rocprofv3 --pmc passes committed under profiles/")
+    roofline_top = [roof(r) for r in rows[:6]]
     breakdown = [{"entry": n, "ms_per_step": round(ms, 4), "calls": c, "gflop": round(fl / 1e9, 3)}
-                 for ms, n, c, fl in rows[:12]]
+                 for ms, n, c, fl, _ in rows[:12]]
 
     if rank == 0:
         out = {
@@ -233,6 +270,7 @@ def main():
                        "launch": "hipGraph replay of the whole iteration" if use_graph else "eager",
                        "last_losses": {k: round(v[-1], 6) for k, v in sorted(metrics.items()) if "probs" not in k}},
             "roofline": roofline,
+            "roofline_top_kernels": roofline_top,
             "iteration_flops_algorithmic_g": round(total_flops / 1e9, 2),
             "iteration_tflops": round(total_flops / (dt / args.steps) / 1e12, 3),
             "gpu_ms_per_step_sum_of_entries": round(gpu_ms, 3),

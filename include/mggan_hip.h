@@ -67,7 +67,9 @@ int mggan_wgrad_multi(const void* descs, int n, mggan_stream_t stream);
  * ([groups*splits][N*(K+1)]); mggan_grad_reduce_multi then folds MANY such partial buffers into the
  * gradient buffers in one launch.  descs = host array of n structs
  *   { const float* P; float* dW; float* db; long w_stride, b_stride;
- *     int M, Naug, has_bias, lddw, splits, groups, p_stride, block0(ignored); }                          */
+ *     int M, Naug, has_bias, lddw, splits, groups, p_stride, block0(ignored); }
+ * has_bias bit 0: the last partial column is the bias gradient (-> db); bit 1: store (=) instead of
+ * accumulate (+=), for scratch destinations that were not zeroed. */
 int mggan_grad_reduce_multi(const void* descs, int n, mggan_stream_t stream);
 int mggan_transpose(const float* W, float* WT, int N, int K, mggan_stream_t stream);
 /* dst[ped][c] (+)= sum_k src[inv[k*b+ped]][c] : adjoint of "repeat over samples" */
@@ -102,7 +104,7 @@ int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, co
 int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const float* prep, int prep_stride,
                               const int* seg, int n_gens, const int* row_ped, const int* row_slot, const int* row_pos,
                               const float* enc_h, int ld_enc, const float* noise, const float* soc, int ld_soc,
-                              const float* xy0, const float* dxdy0, const float* We2dT, const float* be2d,
+                              const float* xy0, const float* dxdy0, const float* We2d, const float* be2d,
                               float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Hp, float* Din,
                               float* Aact, float* E2Din, float* SocR, mggan_stream_t stream);
 /* ---- social attention over in-scene ordered pairs ---------------------------------------
@@ -203,10 +205,13 @@ int mggan_colmean(const float* x, int rows, int g, float scale, float* out, mgga
 int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count, mggan_stream_t stream);
 int mggan_inv_counts(const int* counts, int g, float* inv_count, mggan_stream_t stream);
 /* flat parameter buffer + segment table: elem_seg[i] = segment of element i (-1 = padding),
- * active[s] = segment takes part in this step (grad not None), seg_step[s] = Adam step count */
+ * active[s] = segment takes part in this step (grad not None), seg_step[s] = Adam step count.
+ * zero_grad != 0: the consumed gradients are left at 0 instead of their clipped values (saves the caller's
+ * memset before the next backward pass). */
 int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, const int* elem_seg, int nseg,
                      const unsigned char* active, int* seg_step, float max_norm, double lr, double beta1, double beta2,
-                     double eps, double weight_decay, double* workspace, float* norm_out, mggan_stream_t stream);
+                     double eps, double weight_decay, int zero_grad, double* workspace, float* norm_out,
+                     mggan_stream_t stream);
 
 /* Fused decoder backward: BPTT + in-kernel per-generator weight gradients (dW_hh and dW1[:, :H] on MFMA).
  * n_gens*NW persistent workgroups; workgroup (g, w) leaves one partial block of `wlen` floats at

@@ -243,7 +243,8 @@ struct ReduceDesc {
   float* dW;
   float* db;
   long w_stride, b_stride;
-  int M, Naug, has_bias, lddw, splits, groups, p_stride, block0;  // block0: first block of this descriptor
+  int M, Naug, has_bias, lddw, splits, groups, p_stride, block0;  // has_bias: bit 0 = last column is the bias
+                                                                  // gradient, bit 1 = overwrite; block0: first block
 };
 struct ReduceBatch {
   ReduceDesc d[MG_MAX_REDUCE];
@@ -279,10 +280,15 @@ __global__ __launch_bounds__(1024) void grad_reduce_multi_kernel(ReduceBatch bt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += red[i][lane];
     const int m = o / D.Naug, n = o % D.Naug;
-    if (D.has_bias && n == D.Naug - 1) {
-      if (D.db) D.db[grp * D.b_stride + m] += t;
+    const bool overwrite = (D.has_bias & 2) != 0;  // bit 1: '=' instead of '+=' (scratch destinations)
+    if ((D.has_bias & 1) && n == D.Naug - 1) {
+      if (D.db) {
+        float* q = D.db + grp * D.b_stride + m;
+        *q = overwrite ? t : *q + t;
+      }
     } else {
-      D.dW[grp * D.w_stride + (size_t)m * D.lddw + n] += t;
+      float* q = D.dW + grp * D.w_stride + (size_t)m * D.lddw + n;
+      *q = overwrite ? t : *q + t;
     }
   }
 }

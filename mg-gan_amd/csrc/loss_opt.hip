@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, float* grad, f
                                                     const unsigned char* __restrict__ active,
                                                     const int* __restrict__ seg_step, const double* __restrict__ partial,
                                                     float max_norm, double lr, double beta1, double beta2,
-                                                    double eps_d, double wd, float* norm_out) {
+                                                    double eps_d, double wd, int zero_grad, float* norm_out) {
   __shared__ double red[256];
   red[threadIdx.x] = threadIdx.x < NORM_BLOCKS ? partial[threadIdx.x] : 0.0;
   __syncthreads();
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, float* grad, f
     if (sg < 0 || !active[sg]) continue;
     const int t = seg_step[sg];  // already advanced by gradnorm_partial_kernel
     const float g = grad[i] * coef;
-    grad[i] = g;  // clip_grad_norm_ scales .grad in place
+    grad[i] = zero_grad ? 0.f : g;  // clip_grad_norm_ scales .grad in place; or leave it zeroed for the next step
     // torch.optim.AdamW single-tensor path: scalar factors in double, tensor math in f32
     float p = param[i] * (float)(1.0 - lr * wd);
     const float mi = m[i] + (g - m[i]) * (float)(1.0 - beta1);          // exp_avg.lerp_(grad, 1-beta1)
@@ -539,7 +539,8 @@ int mggan_inv_counts(const int* counts, int g, float* inv_count, hipStream_t str
 /* workspace: 256 doubles */
 int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, const int* elem_seg, int nseg,
                      const unsigned char* active, int* seg_step, float max_norm, double lr, double beta1, double beta2,
-                     double eps, double weight_decay, double* workspace, float* norm_out, hipStream_t stream) {
+                     double eps, double weight_decay, int zero_grad, double* workspace, float* norm_out,
+                     hipStream_t stream) {
   MG_CHECK_ARG(param && grad && m && v && elem_seg && active && seg_step && workspace, "clip_adamw: null pointer");
   if (n == 0) return MGGAN_OK;
   hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, grad, n, elem_seg, active,
@@ -547,7 +548,7 @@ int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, cons
   int blocks = cdiv(n, 256 * 4);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, m, v, n, elem_seg, active, seg_step,
-                     workspace, max_norm, lr, beta1, beta2, eps, weight_decay, norm_out);
+                     workspace, max_norm, lr, beta1, beta2, eps, weight_decay, zero_grad, norm_out);
   MG_LAUNCH_CHECK("clip_adamw");
   return MGGAN_OK;
 }

@@ -116,45 +116,32 @@ __global__ __launch_bounds__(256) void lstm_unfold_kernel(UnfoldArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// Trajectory encoder (T = 7 observed steps, row r == pedestrian r).  One lane per (row, hidden unit); the
+// four gate rows of W_hh for that unit live in VGPRs for the whole sequence, h_t is exchanged through LDS
+// (one row per trajectory, broadcast ds_read_b128), c_t stays in a register.
 struct SeqArgs {
   int R, T, b;
   const float* prep;
-  int prep_stride;
-  const int* row_gen;   // NULL -> group 0
-  // encoder
-  const float* x;       // (T,b,2) time-major (encoder input; row r == pedestrian r)
-  float* hout;          // (R, ld_hout)
+  const float* x;  // (T,b,2) time-major
+  float* hout;     // (R, ld_hout)
   int ld_hout;
-  // decoder
-  const int *row_ped, *row_slot, *row_pos;
-  const float *enc_h, *noise, *soc, *xy0, *dxdy0, *We2dT, *be2d;
-  int ld_enc, ld_soc, Z, EIN;  // EIN = encoder feature width fed to enc_h_to_dec_h (128)
-  float *out_abs, *out_rel;    // (T, Rout, 2) written at row_pos
-  int Rout;
-  // saved for backward (all NULL in no-grad mode)
-  float *Gt, *Cs, *Hp, *Hc, *Din, *Aact, *E2Din, *SocR;
+  float *Gt, *Cs, *Hp, *Din;  // saved for backward (all NULL in no-grad mode)
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-// Instruction-issue bound kernel (SQ_ACTIVE_INST ~ wave cycles at one wave per SIMD), so the step loop is
-// written for few instructions and <= 256 registers (two waves per SIMD):
-//  * the four gates are two packed pairs (i,f) / (g,o): one v_pk_fma_f32 does two gate MACs per lane;
-//  * hidden2pos: all 32 lanes of a row work (two halves of the K range, combined with one shuffle);
-//  * dxdy = W2 a + b2 is a 16-lane shuffle reduction of per-lane products (no LDS round trip, no barrier).
-template <int H, bool DEC>
+// Instruction-issue bound, so the step loop is written for few instructions and <= 256 registers (two waves
+// per SIMD): the four gates are two packed pairs (i,f) / (g,o), one v_pk_fma_f32 does two gate MACs per lane.
+template <int H>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
-  constexpr int RT = 256 / H, G4 = 4 * H, Hh = H / 2, S = H;
+  constexpr int RT = 256 / H, G4 = 4 * H;
   __shared__ __attribute__((aligned(16))) float hbuf[RT][H];
-  __shared__ __attribute__((aligned(16))) float xin[DEC ? RT : 1][DEC ? 160 : 4];
-  __shared__ __attribute__((aligned(16))) float we2d[DEC ? 160 * H : 4];  // W_e2d^T staged once per workgroup
   const int rr = threadIdx.x / H, j = threadIdx.x % H;
   const int r = blockIdx.x * RT + rr;
   const bool valid = r < p.R;
   const int rc = valid ? r : p.R - 1;
-  const int grp = p.row_gen ? p.row_gen[rc] : 0;
-  const float* P = p.prep + (size_t)grp * p.prep_stride;
+  const float* P = p.prep;
   const float* WT = P + prep_off_whhT(H);
   const bool save = p.Gt != nullptr;
 
@@ -167,70 +154,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
     ap1[q] = v2f{P[prep_off_A(H) + ((2 * q) * H + j) * 2 + 1], P[prep_off_A(H) + ((2 * q + 1) * H + j) * 2 + 1]};
     bp[q] = v2f{P[prep_off_bias(H) + (2 * q) * H + j], P[prep_off_bias(H) + (2 * q + 1) * H + j]};
   }
-
-  float hj = 0.f, c = 0.f, d0 = 0.f, d1 = 0.f, x0 = 0.f, x1 = 0.f;
-  float w1q[DEC ? Hh : 1];
-  float qv = 0.f, w20 = 0.f, w21 = 0.f, b20 = 0.f, b21 = 0.f;
-  const int um = j & (Hh - 1), uhalf = j / Hh;  // hidden2pos unit / K-half owned by this lane (H == 2*Hh)
-  int pos = 0;
-  if (DEC) {
-    const int ped = p.row_ped[rc], slot = p.row_slot[rc];
-    pos = p.row_pos[rc];
-    const int IN = p.EIN + p.Z;
-    for (int k = j; k < IN; k += H) {
-      float v = k < p.EIN ? p.enc_h[(size_t)ped * p.ld_enc + k] : p.noise[((size_t)slot * p.b + ped) * p.Z + (k - p.EIN)];
-      xin[rr][k] = v;
-      if (save && valid) p.E2Din[(size_t)r * IN + k] = v;
-    }
-    const float sv = p.soc[(size_t)ped * p.ld_soc + j];
-    for (int i = threadIdx.x; i < IN * H; i += 256) we2d[i] = p.We2dT[i];
-    lds_barrier();
-    // h0 = W_e2d [enc_h | noise] + b   (standard.py:247-252)
-    float h0 = p.be2d[j], h1 = 0.f, h2 = 0.f, h3 = 0.f;
-    int k = 0;
-    for (; k + 3 < IN; k += 4) {
-      h0 = fmaf(we2d[k * H + j], xin[rr][k], h0);
-      h1 = fmaf(we2d[(k + 1) * H + j], xin[rr][k + 1], h1);
-      h2 = fmaf(we2d[(k + 2) * H + j], xin[rr][k + 2], h2);
-      h3 = fmaf(we2d[(k + 3) * H + j], xin[rr][k + 3], h3);
-    }
-    for (; k < IN; ++k) h0 = fmaf(we2d[k * H + j], xin[rr][k], h0);
-    hj = (h0 + h1) + (h2 + h3);
-    // time-invariant social half of hidden2pos: q = W1[:,H:] soc + b1
-    const float* w1T = P + prep_off_w1T(H);
-    const float* b1 = w1T + (H + S) * Hh;
-    const float* w2 = b1 + Hh;
-    const float* b2 = w2 + 2 * Hh;
-    lds_barrier();
-    hbuf[rr][j] = sv;  // reuse hbuf as the social row for the q product
-    if (save && valid) p.SocR[(size_t)r * S + j] = sv;
-    lds_barrier();
-    qv = b1[um];
-#pragma unroll
-    for (int kk = 0; kk < S; ++kk) qv = fmaf(w1T[(H + kk) * Hh + um], hbuf[rr][kk], qv);
-#pragma unroll
-    for (int kk = 0; kk < Hh; ++kk) w1q[kk] = w1T[(uhalf * Hh + kk) * Hh + um];
-    w20 = w2[um]; w21 = w2[Hh + um];
-    b20 = b2[0]; b21 = b2[1];
-    d0 = p.dxdy0[ped * 2]; d1 = p.dxdy0[ped * 2 + 1];
-    x0 = p.xy0[ped * 2];   x1 = p.xy0[ped * 2 + 1];
-    lds_barrier();
-  }
-  hbuf[rr][j] = hj;
-  lds_barrier();
+  float hj = 0.f, c = 0.f;
   float hv[H];
 #pragma unroll
-  for (int k = 0; k < H; k += 4) {
-    float4 t4 = *reinterpret_cast<const float4*>(&hbuf[rr][k]);
-    hv[k] = t4.x; hv[k + 1] = t4.y; hv[k + 2] = t4.z; hv[k + 3] = t4.w;
-  }
+  for (int k = 0; k < H; ++k) hv[k] = 0.f;
 
   for (int t = 0; t < p.T; ++t) {
     const size_t rt = (size_t)r * p.T + t;
-    if (!DEC) {
-      d0 = p.x[((size_t)t * p.b + rc) * 2];
-      d1 = p.x[((size_t)t * p.b + rc) * 2 + 1];
-    }
+    const float d0 = p.x[((size_t)t * p.b + rc) * 2], d1 = p.x[((size_t)t * p.b + rc) * 2 + 1];
     if (save && valid) {
       p.Hp[rt * H + j] = hj;
       if (j == 0) { p.Din[rt * 2] = d0; p.Din[rt * 2 + 1] = d1; }
@@ -260,7 +191,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
       p.Gt[rt * G4 + 2 * H + j] = gg;
       p.Gt[rt * G4 + 3 * H + j] = go;
       p.Cs[rt * H + j] = c;
-      if (DEC) p.Hc[rt * H + j] = hj;
     }
     lds_barrier();  // every lane of the row has consumed the previous h
     hbuf[rr][j] = hj;
@@ -270,136 +200,47 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
       float4 t4 = *reinterpret_cast<const float4*>(&hbuf[rr][k]);
       hv[k] = t4.x; hv[k + 1] = t4.y; hv[k + 2] = t4.z; hv[k + 3] = t4.w;
     }
-    if (DEC) {
-      // u = W1[:, :H] h + q : lane (um, uhalf) sums its half of the K range, the halves meet via one shuffle
-      float u0 = 0.f, u1 = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < Hh; kk += 4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(&hbuf[rr][uhalf * Hh + kk]);
-        u0 = fmaf(w1q[kk], t4.x, u0);
-        u1 = fmaf(w1q[kk + 1], t4.y, u1);
-        u0 = fmaf(w1q[kk + 2], t4.z, u0);
-        u1 = fmaf(w1q[kk + 3], t4.w, u1);
-      }
-      float u = u0 + u1;
-      u += __shfl_xor(u, Hh, 64);
-      u += qv;
-      const float av = u > 0.f ? u : 0.01f * u;  // LeakyReLU(0.01), utils.py:143-144
-      if (save && valid && j < Hh) p.Aact[rt * Hh + j] = av;
-      // dxdy = W2 a + b2: 16-lane butterfly over the per-lane products (both halves hold the same values)
-      float n0 = w20 * av, n1 = w21 * av;
-#pragma unroll
-      for (int o = Hh / 2; o > 0; o >>= 1) {
-        n0 += __shfl_xor(n0, o, 64);
-        n1 += __shfl_xor(n1, o, 64);
-      }
-      n0 += b20; n1 += b21;
-      d0 = n0; d1 = n1;
-      x0 += n0; x1 += n1;
-      if (valid && j == 0) {
-        const size_t o = ((size_t)t * p.Rout + pos) * 2;
-        *reinterpret_cast<float2*>(&p.out_abs[o]) = make_float2(x0, x1);
-        *reinterpret_cast<float2*>(&p.out_rel[o]) = make_float2(d0, d1);
-      }
-    }
   }
-  if (!DEC && valid) p.hout[(size_t)r * p.ld_hout + j] = hj;
+  if (valid) p.hout[(size_t)r * p.ld_hout + j] = hj;
 }
 
 struct SeqBwdArgs {
   int R, T;
-  const int* row_gen;
-  // raw parameters of group 0 + stride
-  const float *W_hh, *W1, *W2, *We2d;  // W1 (H/2 x (H+S)), W2 (2 x H/2), We2d (H x (EIN+Z))
-  long param_stride;
-  const float* prep;   // folded A lives here
-  int prep_stride;
-  const float *Gt, *Cs, *Aact;
-  // encoder: gradient of h_T
-  const float* dhT;
+  const float* W_hh;
+  const float *Gt, *Cs;
+  const float* dhT;  // gradient of h_T
   int ld_dhT;
-  // decoder: gradients of the outputs
-  const float *gabs, *grel;  // (T,Rout,2), may be NULL (treated as zero)
-  const int* row_pos;
-  int Rout, EIN, Z;
-  // outputs
-  float *dPre, *dU, *gD, *dH0, *dQ, *dEnc, *dSocR;
+  float* dPre;       // (R,T,4H) gate pre-activation gradients (weight gradients follow as GEMMs)
 };
 
-template <int H, bool DEC>
+template <int H>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
-  constexpr int RT = 256 / H, G4 = 4 * H, Hh = H / 2, S = H;
+  constexpr int RT = 256 / H, G4 = 4 * H;
   __shared__ __attribute__((aligned(16))) float dpbuf[RT][G4];
-  __shared__ __attribute__((aligned(16))) float dubuf[RT][Hh];
   const int rr = threadIdx.x / H, j = threadIdx.x % H;
   const int r = blockIdx.x * RT + rr;
   const bool valid = r < p.R;
   const int rc = valid ? r : p.R - 1;
-  const int grp = p.row_gen ? p.row_gen[rc] : 0;
-  const long po = (long)grp * p.param_stride;
-  const float* P = p.prep + (size_t)grp * p.prep_stride;
 
   v2f whc[G4 / 2];  // column j of W_hh in packed pairs: dh_prev[j] = sum_m W_hh[m][j] dpre[m]
 #pragma unroll
-  for (int m = 0; m < G4; m += 2) whc[m / 2] = v2f{p.W_hh[po + (size_t)m * H + j], p.W_hh[po + (size_t)(m + 1) * H + j]};
-  float a0[4], a1[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    a0[q] = P[prep_off_A(H) + (q * H + j) * 2];
-    a1[q] = P[prep_off_A(H) + (q * H + j) * 2 + 1];
-  }
-  float w1c[DEC ? Hh : 1], w20 = 0.f, w21 = 0.f;
-  int pos = 0;
-  if (DEC) {
-#pragma unroll
-    for (int m = 0; m < Hh; ++m) w1c[m] = p.W1[po + (size_t)m * (H + S) + j];
-    if (j < Hh) { w20 = p.W2[po + j]; w21 = p.W2[po + Hh + j]; }
-    pos = p.row_pos[rc];
-  }
-  float dh = 0.f, dc = 0.f, dd0 = 0.f, dd1 = 0.f, s0 = 0.f, s1 = 0.f, dqacc = 0.f;
-  if (!DEC) dh = p.dhT[(size_t)rc * p.ld_dhT + j];
+  for (int m = 0; m < G4; m += 2) whc[m / 2] = v2f{p.W_hh[(size_t)m * H + j], p.W_hh[(size_t)(m + 1) * H + j]};
+  float dh = p.dhT[(size_t)rc * p.ld_dhT + j], dc = 0.f;
 
-  // software pipeline over time: the saved activations / incoming gradients of step t-1 are fetched
-  // while step t is being computed (occupancy is one wave per SIMD, so latency must be hidden in-wave)
-  float n_gi, n_gf, n_gg, n_go, n_cc, n_cp, n_av = 0.f, n_ga0 = 0.f, n_ga1 = 0.f, n_gr0 = 0.f, n_gr1 = 0.f;
+  // software pipeline over time: the saved activations of step t-1 are fetched while step t is computed
+  float n_gi, n_gf, n_gg, n_go, n_cc, n_cp;
   auto fetch = [&](int t) {
     const size_t rt = (size_t)rc * p.T + t;
     n_gi = p.Gt[rt * G4 + j]; n_gf = p.Gt[rt * G4 + H + j]; n_gg = p.Gt[rt * G4 + 2 * H + j];
     n_go = p.Gt[rt * G4 + 3 * H + j];
     n_cc = p.Cs[rt * H + j];
     n_cp = t > 0 ? p.Cs[(rt - 1) * H + j] : 0.f;
-    if (DEC) {
-      const size_t o = ((size_t)t * p.Rout + pos) * 2;
-      if (p.gabs) { n_ga0 = p.gabs[o]; n_ga1 = p.gabs[o + 1]; }
-      if (p.grel) { n_gr0 = p.grel[o]; n_gr1 = p.grel[o + 1]; }
-      if (j < Hh) n_av = p.Aact[rt * Hh + j];
-    }
   };
   fetch(p.T - 1);
   for (int t = p.T - 1; t >= 0; --t) {
     const size_t rt = (size_t)rc * p.T + t;
     const float gi = n_gi, gf = n_gf, gg = n_gg, go = n_go, cc = n_cc, cprev = n_cp;
-    const float av = n_av, ga0 = n_ga0, ga1 = n_ga1, gr0 = n_gr0, gr1 = n_gr1;
     if (t > 0) fetch(t - 1);
-    if (DEC) {
-      s0 += ga0; s1 += ga1;
-      const float g0 = s0 + dd0 + gr0, g1 = s1 + dd1 + gr1;
-      if (valid && j == 0) { p.gD[rt * 2] = g0; p.gD[rt * 2 + 1] = g1; }
-      if (j < Hh) {
-        const float du = (w20 * g0 + w21 * g1) * (av > 0.f ? 1.f : 0.01f);
-        dubuf[rr][j] = du;
-        dqacc += du;
-        if (valid) p.dU[rt * Hh + j] = du;
-      }
-      lds_barrier();
-      float e0 = 0.f, e1 = 0.f;
-#pragma unroll
-      for (int m = 0; m < Hh; m += 2) {
-        e0 = fmaf(w1c[m], dubuf[rr][m], e0);
-        e1 = fmaf(w1c[m + 1], dubuf[rr][m + 1], e1);
-      }
-      dh += e0 + e1;
-    }
     const float tc = mg_tanh(cc);
     const float dO = dh * tc;
     dc = fmaf(dh * go, 1.f - tc * tc, dc);
@@ -427,38 +268,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
       nh1 = pk_fma(whc[m / 2 + 1], v2f{v.z, v.w}, nh1);
     }
     dh = (nh0.x + nh0.y) + (nh1.x + nh1.y);
-    if (DEC) {
-      float p0 = a0[0] * dpi + a0[1] * dpf + a0[2] * dpg + a0[3] * dpo;
-      float p1 = a1[0] * dpi + a1[1] * dpf + a1[2] * dpg + a1[3] * dpo;
-#pragma unroll
-      for (int o = H / 2; o > 0; o >>= 1) {
-        p0 += __shfl_xor(p0, o, 64);
-        p1 += __shfl_xor(p1, o, 64);
-      }
-      dd0 = p0; dd1 = p1;
-    }
     lds_barrier();
-  }
-  if (DEC) {
-    // dH0, dQ, d(social row) = W1[:,H:]^T dQ, d(enc_h row) = W_e2d[:, :EIN]^T dH0
-    if (valid) p.dH0[(size_t)r * H + j] = dh;
-    if (j < Hh) {
-      dubuf[rr][j] = dqacc;
-      if (valid) p.dQ[(size_t)r * Hh + j] = dqacc;
-    }
-    dpbuf[rr][j] = dh;
-    lds_barrier();
-    float ds = 0.f;
-#pragma unroll
-    for (int m = 0; m < Hh; ++m) ds = fmaf(p.W1[po + (size_t)m * (H + S) + H + j], dubuf[rr][m], ds);
-    if (valid) p.dSocR[(size_t)r * S + j] = ds;
-    const int IN = p.EIN + p.Z;
-    for (int k = j; k < p.EIN; k += H) {
-      float de = 0.f;
-#pragma unroll 8
-      for (int jj = 0; jj < H; ++jj) de = fmaf(p.We2d[(size_t)jj * IN + k], dpbuf[rr][jj], de);
-      if (valid) p.dEnc[(size_t)r * p.EIN + k] = de;
-    }
   }
 }
 
@@ -484,7 +294,7 @@ struct DecFwdArgs {
   const float* prep;
   int prep_stride;
   const int *row_ped, *row_slot, *row_pos;
-  const float *enc_h, *noise, *soc, *xy0, *dxdy0, *We2dT, *be2d;
+  const float *enc_h, *noise, *soc, *xy0, *dxdy0, *We2d, *be2d;
   float *out_abs, *out_rel;
   float *Gt, *Cs, *Hp, *Din, *Aact, *E2Din, *SocR;
 };
@@ -521,8 +331,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       else if (kq >= p.EIN && kin)
         x4 = *reinterpret_cast<const f32x4*>(p.noise + ((size_t)slot * p.b + ped) * p.Z + (kq - p.EIN));
       if (sv0 && kin) *reinterpret_cast<f32x4*>(p.E2Din + (size_t)r * IN + kq) = x4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) a4[q] = (kin && fi < 8) ? p.We2dT[(size_t)(kq + q) * H + 8 * w + fi] : 0.f;
+      // A rows = this wave's units: W_e2d[8w + fi][kq .. kq+3] (row-major parameter, one 16-byte load)
+      a4 = (kin && fi < 8) ? *reinterpret_cast<const f32x4*>(p.We2d + (size_t)(8 * w + fi) * IN + kq)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     for (int kb0 = 0; kb0 * 16 < IN; kb0 += 3) {  // three blocks of loads in flight, then their 12 MFMAs
       f32x4 xs[3], as[3];
@@ -695,212 +506,6 @@ struct DecFusedArgs {
   const float *Gt, *Cs, *Hp, *Din, *Aact, *gabs, *grel;
   float *dH0, *dQ, *dEnc, *dSocR, *wpart;
 };
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void decoder_bwd_fused_kernel(DecFusedArgs p) {
-  constexpr int H = 32, G4 = 128, Hh = 16, S = 32, RT = 8;
-  __shared__ __attribute__((aligned(16))) float dpbuf[RT * DPLD];
-  __shared__ __attribute__((aligned(16))) float dubuf[RT * Hh];
-  __shared__ __attribute__((aligned(16))) float hbuf[2][RT * HLD];
-  __shared__ float w1s[Hh * H];     // W1[:, :H] (m-major): lane j reads w1s[m*H + j]
-  __shared__ float as_[8 * H];      // folded input weights: as_[(2q + c)*H + j] = A[q*H + j][c]
-  __shared__ float fold[RT * 64];  // end-of-kernel reduction over the 8 tile rows (A 256 | bias 128 | W2 32 | b1 16 | b2 2)
-  const int gi = blockIdx.x / p.NW, wi = blockIdx.x % p.NW;
-  const int rr = threadIdx.x / H, j = threadIdx.x % H;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
-  const long po = (long)gi * p.param_stride;
-  const float* P = p.prep + (size_t)gi * p.prep_stride;
-  const int seg0 = p.seg[gi], seg1 = p.seg[gi + 1];
-  const int ntiles = (seg1 - seg0 + RT - 1) / RT;
-
-  v2f whc[G4 / 2];  // column j of W_hh (packed pairs)
-#pragma unroll
-  for (int m = 0; m < G4; m += 2) whc[m / 2] = v2f{p.W_hh[po + (size_t)m * H + j], p.W_hh[po + (size_t)(m + 1) * H + j]};
-  float w20 = 0.f, w21 = 0.f;
-  for (int i = threadIdx.x; i < Hh * H; i += 256) w1s[i] = p.W1[po + (size_t)(i / H) * (H + S) + (i % H)];
-  {
-    const int q = threadIdx.x / 64, c = (threadIdx.x / H) & 1;
-    as_[threadIdx.x] = P[prep_off_A(H) + (q * H + j) * 2 + c];
-  }
-  // B-tile columns 32..47 of both h tiles: [din0, din1, 1, 0...] (the constant part is written once)
-  for (int i = threadIdx.x; i < 2 * RT * 16; i += 256) {
-    const int bsel = i / (RT * 16), row = (i / 16) % RT, col = i % 16;
-    hbuf[bsel][row * HLD + H + col] = col == 2 ? 1.f : 0.f;
-  }
-  if (j < Hh) { w20 = p.W2[po + j]; w21 = p.W2[po + Hh + j]; }
-
-  // accumulators that live across all tiles of this workgroup
-  f32x4 accW[2][3], accU = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) accW[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float accW2[2] = {0.f, 0.f}, accb1 = 0.f, accb2[2] = {0.f, 0.f};
-
-  for (int tile = wi; tile < ntiles; tile += p.NW) {
-    const int r = seg0 + tile * RT + rr;
-    const bool valid = r < seg1;
-    const int rc = valid ? r : seg1 - 1;
-    const float vm = valid ? 1.f : 0.f;  // rows past the segment end contribute nothing
-    const int pos = p.row_pos[rc];
-    float dh = 0.f, dc = 0.f, dd0 = 0.f, dd1 = 0.f, s0 = 0.f, s1 = 0.f, dqacc = 0.f;
-    float n_gi, n_gf, n_gg, n_go, n_cc, n_cp, n_hp, n_d0, n_d1, n_av = 0.f, n_ga0 = 0.f, n_ga1 = 0.f, n_gr0 = 0.f,
-                                                                       n_gr1 = 0.f;
-    auto fetch = [&](int t) {
-      const size_t rt = (size_t)rc * p.T + t;
-      const float4 g4 = *reinterpret_cast<const float4*>(p.Gt + (rt * H + j) * 4);
-      n_gi = g4.x; n_gf = g4.y; n_gg = g4.z; n_go = g4.w;
-      n_cc = p.Cs[(rt * H + j) * 2];
-      const float2 ch = t > 0 ? *reinterpret_cast<const float2*>(p.Cs + ((rt - 1) * H + j) * 2)
-                              : float2{0.f, p.Hp[(size_t)rc * H + j]};
-      n_cp = ch.x; n_hp = ch.y;
-      n_d0 = p.Din[rt * 2]; n_d1 = p.Din[rt * 2 + 1];
-      const size_t o = ((size_t)t * p.Rout + pos) * 2;
-      if (p.gabs) { n_ga0 = p.gabs[o]; n_ga1 = p.gabs[o + 1]; }
-      if (p.grel) { n_gr0 = p.grel[o]; n_gr1 = p.grel[o + 1]; }
-      if (j < Hh) n_av = p.Aact[rt * Hh + j];
-    };
-    lds_barrier();  // previous tile's LDS traffic is finished
-    hbuf[(p.T - 1) & 1 ^ 1][rr * HLD + j] = p.Cs[(((size_t)rc * p.T + p.T - 1) * H + j) * 2 + 1];  // h_{T-1}
-    fetch(p.T - 1);
-    for (int t = p.T - 1; t >= 0; --t) {
-      const int cur = (t & 1) ^ 1, prv = t & 1;  // hbuf[cur] = h_t, hbuf[prv] <- h_{t-1}
-      const float gi_ = n_gi, gf = n_gf, gg = n_gg, go = n_go, cc = n_cc, cprev = n_cp, hp = n_hp;
-      const float din0 = n_d0, din1 = n_d1, av = n_av, ga0 = n_ga0, ga1 = n_ga1, gr0 = n_gr0, gr1 = n_gr1;
-      if (t > 0) fetch(t - 1);
-      s0 += ga0; s1 += ga1;
-      const float g0 = (s0 + dd0 + gr0) * vm, g1 = (s1 + dd1 + gr1) * vm;
-      if (j == 0) { accb2[0] += g0; accb2[1] += g1; }
-      if (j < Hh) {
-        const float du = (w20 * g0 + w21 * g1) * (av > 0.f ? 1.f : 0.01f);
-        dubuf[rr * Hh + j] = du;
-        dqacc += du;
-        accW2[0] = fmaf(g0, av, accW2[0]);
-        accW2[1] = fmaf(g1, av, accW2[1]);
-      }
-      hbuf[prv][rr * HLD + j] = hp;
-      if (j < 2) hbuf[prv][rr * HLD + H + j] = j ? din1 : din0;
-      lds_barrier();
-      {  // dW1[:, :H] += dU^T h_t : wave w -> N tile (w & 1), K half (w >> 1)
-        const int nt = w & 1, kk = w >> 1;
-        const float a = dubuf[(4 * kk + fk) * Hh + fi];
-        const float bv = hbuf[cur][(4 * kk + fk) * HLD + 16 * nt + fi];
-        accU = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, accU, 0, 0, 0);
-      }
-      float e0 = 0.f, e1 = 0.f;
-#pragma unroll
-      for (int m = 0; m < Hh; m += 2) {
-        e0 = fmaf(w1s[m * H + j], dubuf[rr * Hh + m], e0);
-        e1 = fmaf(w1s[(m + 1) * H + j], dubuf[rr * Hh + m + 1], e1);
-      }
-      dh += e0 + e1;
-      const float tc = mg_tanh(cc);
-      const float dO = dh * tc;
-      dc = fmaf(dh * go, 1.f - tc * tc, dc);
-      const float dpi = dc * gg * gi_ * (1.f - gi_) * vm;
-      const float dpf = dc * cprev * gf * (1.f - gf) * vm;
-      const float dpg = dc * gi_ * (1.f - gg * gg) * vm;
-      const float dpo = dO * go * (1.f - go) * vm;
-      dc = dc * gf;
-      dpbuf[rr * DPLD + j] = dpi;
-      dpbuf[rr * DPLD + H + j] = dpf;
-      dpbuf[rr * DPLD + 2 * H + j] = dpg;
-      dpbuf[rr * DPLD + 3 * H + j] = dpo;
-      lds_barrier();
-      // [dW_hh | dA | dbias] += dPre^T [h_{t-1} | din | 1]: wave w owns gate-row tiles 2w, 2w+1, K = the 8 tile rows
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        float a[2], bv[3];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = dpbuf[(4 * kk + fk) * DPLD + 16 * (2 * w + i) + fi];
-#pragma unroll
-        for (int n = 0; n < 3; ++n) bv[n] = hbuf[prv][(4 * kk + fk) * HLD + 16 * n + fi];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int n = 0; n < 3; ++n) accW[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[n], accW[i][n], 0, 0, 0);
-      }
-      v2f nh0 = v2f{0.f, 0.f}, nh1 = v2f{0.f, 0.f};
-#pragma unroll
-      for (int m = 0; m < G4; m += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(&dpbuf[rr * DPLD + m]);
-        nh0 = pk_fma(whc[m / 2], v2f{v.x, v.y}, nh0);
-        nh1 = pk_fma(whc[m / 2 + 1], v2f{v.z, v.w}, nh1);
-      }
-      dh = (nh0.x + nh0.y) + (nh1.x + nh1.y);
-      float p0 = as_[0 * H + j] * dpi + as_[2 * H + j] * dpf + as_[4 * H + j] * dpg + as_[6 * H + j] * dpo;
-      float p1 = as_[1 * H + j] * dpi + as_[3 * H + j] * dpf + as_[5 * H + j] * dpg + as_[7 * H + j] * dpo;
-#pragma unroll
-      for (int o = H / 2; o > 0; o >>= 1) {
-        p0 += __shfl_xor(p0, o, 64);
-        p1 += __shfl_xor(p1, o, 64);
-      }
-      dd0 = p0; dd1 = p1;
-      lds_barrier();
-    }
-    // per-row outputs of this tile: dH0, dQ, d(social row), d(enc_h row)
-    if (valid) p.dH0[(size_t)r * H + j] = dh;
-    if (j < Hh) {
-      dubuf[rr * Hh + j] = dqacc;
-      if (valid) p.dQ[(size_t)r * Hh + j] = dqacc;
-      accb1 += dqacc * vm;
-    }
-    dpbuf[rr * DPLD + j] = dh;
-    lds_barrier();
-    float ds = 0.f;
-#pragma unroll
-    for (int m = 0; m < Hh; ++m) ds = fmaf(p.W1[po + (size_t)m * (H + S) + H + j], dubuf[rr * Hh + m], ds);
-    if (valid) p.dSocR[(size_t)r * S + j] = ds;
-    const int IN = p.EIN + p.Z;
-    for (int k = j; k < p.EIN; k += H) {
-      float de = 0.f;
-#pragma unroll 8
-      for (int jj = 0; jj < H; ++jj) de = fmaf(p.We2d[(size_t)jj * IN + k], dpbuf[rr * DPLD + jj], de);
-      if (valid) p.dEnc[(size_t)r * p.EIN + k] = de;
-    }
-  }
-
-  // ---- this workgroup's partial block ----
-  float* wp = p.wpart + (size_t)blockIdx.x * DF_WLEN;
-  // W_hh: accW[i][n][r] of lane l is dW_hh[m = 16*(2w+i) + 4*fk + r][k = 16*n + fi]  (each tile has one owner wave)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) wp[(16 * (2 * w + i) + 4 * fk + r4) * H + 16 * n + fi] = accW[i][n][r4];
-  if (fi < 3) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int m = 16 * (2 * w + i) + 4 * fk + r4;
-        if (fi < 2) wp[DF_OFF_A + m * 2 + fi] = accW[i][2][r4];
-        else wp[DF_OFF_B + m] = accW[i][2][r4];
-      }
-  }
-  lds_barrier();
-  // W1h: tile (w & 1) is shared by waves w and w ^ 2 (K halves): sum them through LDS
-  float* u = dpbuf;  // [4][256]
-#pragma unroll
-  for (int r4 = 0; r4 < 4; ++r4) u[w * 256 + (4 * fk + r4) * 16 + fi] = accU[r4];
-  // lane-local accumulators (W2, b1, b2) -> fold over the 8 tile rows
-  float* f = fold + rr * 64;
-  if (j < Hh) { f[j] = accW2[0]; f[Hh + j] = accW2[1]; f[32 + j] = accb1; }
-  if (j == 0) { f[48] = accb2[0]; f[49] = accb2[1]; }
-  lds_barrier();
-  if (threadIdx.x < 50) {
-    const int i = threadIdx.x;
-    float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < RT; ++q) t += fold[q * 64 + i];
-    wp[i < 32 ? DF_OFF_W2 + i : i < 48 ? DF_OFF_B1 + (i - 32) : DF_OFF_B2 + (i - 48)] = t;
-  }
-  for (int i = threadIdx.x; i < 512; i += 256) {
-    // i = m*32 + k: tile nt = k / 16 held by waves nt and nt + 2
-    const int m = i / 32, k = i % 32, nt = k / 16;
-    wp[DF_OFF_W1 + i] = u[nt * 256 + m * 16 + (k & 15)] + u[(nt + 2) * 256 + m * 16 + (k & 15)];
-  }
-}
 
 // Matrix-core form of the fused backward, in the lane layout of decoder_fwd_mfma_kernel: four waves per
 // 16-row tile, wave w owns hidden units 8w .. 8w+7, lane (fi = lane & 15, fk = lane >> 4) holds the cell
@@ -1216,10 +821,10 @@ int mggan_lstm_encoder_fwd(const float* x, int T, int b, int H, const float* pre
                "lstm_encoder_fwd: save buffers must be all set or all NULL");
   if (b == 0) return MGGAN_OK;
   SeqArgs p = {};
-  p.R = b; p.T = T; p.b = b; p.prep = prep; p.prep_stride = 0; p.x = x; p.hout = hout; p.ld_hout = ld_hout;
+  p.R = b; p.T = T; p.b = b; p.prep = prep; p.x = x; p.hout = hout; p.ld_hout = ld_hout;
   p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Din = Din;
-  if (H == 32) hipLaunchKernelGGL((lstm_fwd_kernel<32, false>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((lstm_fwd_kernel<64, false>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
+  if (H == 32) hipLaunchKernelGGL((lstm_fwd_kernel<32>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((lstm_fwd_kernel<64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
   MG_LAUNCH_CHECK("lstm_encoder_fwd");
   return MGGAN_OK;
 }
@@ -1230,9 +835,9 @@ int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, co
   MG_CHECK_ARG(H == 32 || H == 64, "lstm_encoder_bwd: hidden size %d not built (32 or 64)", H);
   if (b == 0) return MGGAN_OK;
   SeqBwdArgs p = {};
-  p.R = b; p.T = T; p.W_hh = W_hh; p.prep = prep; p.Gt = Gt; p.Cs = Cs; p.dhT = dhT; p.ld_dhT = ld_dhT; p.dPre = dPre;
-  if (H == 32) hipLaunchKernelGGL((lstm_bwd_kernel<32, false>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((lstm_bwd_kernel<64, false>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
+  p.R = b; p.T = T; p.W_hh = W_hh; p.Gt = Gt; p.Cs = Cs; p.dhT = dhT; p.ld_dhT = ld_dhT; p.dPre = dPre;
+  if (H == 32) hipLaunchKernelGGL((lstm_bwd_kernel<32>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((lstm_bwd_kernel<64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
   MG_LAUNCH_CHECK("lstm_encoder_bwd");
   return MGGAN_OK;
 }
@@ -1240,10 +845,10 @@ int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, co
 int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const float* prep, int prep_stride,
                               const int* seg, int n_gens, const int* row_ped, const int* row_slot, const int* row_pos,
                               const float* enc_h, int ld_enc, const float* noise, const float* soc, int ld_soc,
-                              const float* xy0, const float* dxdy0, const float* We2dT, const float* be2d,
+                              const float* xy0, const float* dxdy0, const float* We2d, const float* be2d,
                               float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Hp, float* Din,
                               float* Aact, float* E2Din, float* SocR, hipStream_t stream) {
-  MG_CHECK_ARG(prep && seg && row_ped && row_slot && row_pos && enc_h && noise && soc && xy0 && dxdy0 && We2dT && be2d &&
+  MG_CHECK_ARG(prep && seg && row_ped && row_slot && row_pos && enc_h && noise && soc && xy0 && dxdy0 && We2d && be2d &&
                    out_abs && out_rel,
                "decoder_rollout_fwd: null pointer");
   MG_CHECK_ARG(H == 32, "decoder_rollout_fwd: decoder_h_dim %d not built (32)", H);
@@ -1257,7 +862,7 @@ int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const 
   DecFwdArgs p = {};
   p.T = T; p.b = b; p.Rout = Rout; p.EIN = EIN; p.Z = Z; p.ld_enc = ld_enc; p.ld_soc = ld_soc; p.seg = seg;
   p.prep = prep; p.prep_stride = prep_stride; p.row_ped = row_ped; p.row_slot = row_slot; p.row_pos = row_pos;
-  p.enc_h = enc_h; p.noise = noise; p.soc = soc; p.xy0 = xy0; p.dxdy0 = dxdy0; p.We2dT = We2dT; p.be2d = be2d;
+  p.enc_h = enc_h; p.noise = noise; p.soc = soc; p.xy0 = xy0; p.dxdy0 = dxdy0; p.We2d = We2d; p.be2d = be2d;
   p.out_abs = out_abs; p.out_rel = out_rel;
   p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Din = Din; p.Aact = Aact; p.E2Din = E2Din; p.SocR = SocR;
   // one workgroup per 16-row tile, NW workgroups per generator (sized for an even split of R)

@@ -74,6 +74,7 @@ class FlatModule(nn.Module):
         """device pointer of p's slot in the flat gradient buffer; attaches p.grad on first touch."""
         o, n = self._flat_off[id(p)]
         self._touched.add(id(p))
+        self._grad_clean = False
         if p.grad is None:
             view = self._flat_grad[o:o + n].view(p.shape)
             view.zero_()
@@ -81,8 +82,10 @@ class FlatModule(nn.Module):
         return self._flat_grad.data_ptr() + 4 * o
 
     def zero_grad_flat(self):
-        """Trainer fast path: one memset, every p.grad stays attached."""
-        self._flat_grad.zero_()
+        """Trainer fast path: one memset, every p.grad stays attached.  The memset is skipped when the last
+        optimizer step already left the buffer zeroed (FlatAdamW.step(zero_grad=True)) and nothing wrote since."""
+        if not getattr(self, "_grad_clean", False):
+            self._flat_grad.zero_()
         self._touched.clear()
         for p, o in self._flat_items:
             if p.grad is None:

@@ -11,7 +11,7 @@ import ctypes
 import torch
 from torch.autograd import Function
 
-from .lib import lib
+from .lib import lib, load as _load_lib
 from .flat import root_of
 
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID, ACT_SIGMOID_EPS = 0, 1, 2, 3
@@ -109,6 +109,7 @@ class _WgradDesc(ctypes.Structure):
 
 
 _DEFER = {"on": False, "descs": [], "keep": [], "gemms": []}
+TRACE_NOTES = {"wgrad_multi_flops": []}
 
 
 def defer_grad_reduce(on=True):
@@ -130,6 +131,8 @@ def flush_grad_reduces():
     gm = _DEFER["gemms"]
     if gm:  # the queued weight-gradient GEMMs (partial sums), one launch per operand layout and 16 problems
         arr = (_WgradDesc * len(gm))(*gm)
+        if _load_lib().trace is not None:  # bench.py's per-entry trace: algorithmic FLOPs of this batch
+            TRACE_NOTES["wgrad_multi_flops"].append(sum(2.0 * g.rows * g.K * g.N for g in gm))
         lib.mggan_wgrad_multi(ctypes.addressof(arr), len(gm), _s())
     batch, seen = [], set()
 
@@ -150,7 +153,7 @@ def flush_grad_reduces():
 
 
 def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scale=1, n_groups=0, w_stride=0,
-          b_stride=0, fm=0, now=False, yact=None, ld_yact=0, act=0, slope=0.0):
+          b_stride=0, fm=0, now=False, yact=None, ld_yact=0, act=0, slope=0.0, overwrite=False):
     """dW += dz^T x, db += colsum(dz)  (deterministic split reduction).  Call inside `with side_stream(...)`
     to take it off the critical path."""
     if rows == 0:
@@ -167,6 +170,13 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
         _DEFER["gemms"].append(_WgradDesc(pz, px, ws.data_ptr(), _p(seg) or None, rows, K, N, lddz, ldx, seg_scale, n_groups,
                                           fm))
         keep = (ws, dz, x, seg)
+    elif overwrite:  # partial sums now, then a storing (not accumulating) reduction: the destination is scratch
+        lib.mggan_wgrad(pz, lddz, px, ldx, 0, lddw, db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, fm,
+                        _p(yact), ld_yact, act, float(slope), ws.data_ptr(), nbytes, _s())
+        one = (_ReduceDesc * 1)(_ReduceDesc(ws.data_ptr(), dW_ptr, db_ptr or None, w_stride, b_stride, N, K + 1, 3, lddw,
+                                            lib.mggan_wgrad_splits(rows, K, N, n_groups), max(n_groups, 1), N * (K + 1), 0))
+        lib.mggan_grad_reduce_multi(ctypes.addressof(one), 1, _s())
+        return
     else:
         lib.mggan_wgrad(pz, lddz, px, ldx, 0 if defer else dW_ptr, lddw, db_ptr, rows, K, N, _p(seg), seg_scale, n_groups,
                         w_stride, b_stride, fm, _p(yact), ld_yact, act, float(slope), ws.data_ptr(), nbytes, _s())
@@ -257,10 +267,11 @@ class LstmEncoderFn(Function):
         lib.mggan_lstm_encoder_bwd(_p(dh), ld, T, b, H, _p(w_hh), _p(prep), _p(Gt), _p(Cs), _p(dPre), _s())
         rows = b * T
         gp = [root.grad_ptr(t) for t in (w_hh, emb_w, emb_b, w_ih, b_ih, b_hh)]
-        dprep = torch.zeros(12 * H, dtype=F32, device=dh.device)
+        dprep = _empty(12 * H, like=dh)  # [dA (4H,2) | dbias (4H)], written (not accumulated) by the reduction
         with side_stream(dPre, Hp, Din, dprep):
             wgrad(dPre, 4 * H, Hp, H, gp[0], H, 0, rows, H, 4 * H)
-            wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, rows, 2, 4 * H, now=True)
+            wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, rows, 2, 4 * H, now=True,
+                  overwrite=True)
             lib.mggan_lstm_unfold_grads(_p(emb_w), _p(emb_b), _p(w_ih), gp[1], gp[2], gp[3], gp[4], gp[5], 0, 1, H, E,
                                         _p(dprep), 12 * H, _s())
         return (None,) * 9
@@ -570,8 +581,6 @@ class DecoderRolloutFn(Function):
         lib.mggan_lstm_fold(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), _p(g0["b_ih"]), _p(g0["b_hh"]),
                             _p(g0["w_hh"]), _p(g0["w1"]), _p(g0["b1"]), _p(g0["w2"]), _p(g0["b2"]), stride, n_gens, H, E,
                             S, 1, _p(prep), psz, st)
-        e2dT = _empty(EIN + Z, H, like=enc_h)
-        lib.mggan_transpose(_p(e2d_w), _p(e2dT), H, EIN + Z, st)
         mk = (lambda *s: _empty(*s, like=enc_h)) if save else (lambda *s: None)
         # Gt (R,T,H,4) gates i,f,g,o; Cs (R,T,H,2) = (c_t, h_t); Hp (R,H) = h_0
         Gt, Cs, Hp = mk(R, T, H, 4), mk(R, T, H, 2), mk(R, H)
@@ -579,7 +588,7 @@ class DecoderRolloutFn(Function):
         out_abs, out_rel = _empty(T, R, 2, like=enc_h), _empty(T, R, 2, like=enc_h)
         lib.mggan_decoder_rollout_fwd(R, T, b, H, EIN, Z, _p(prep), psz, _p(rows.seg), n_gens, _p(rows.row_ped),
                                       _p(rows.row_slot), _p(rows.row_pos), _p(enc_h), ld_enc, _p(noise) or _p(enc_h), _p(soc), ld_soc,
-                                      _p(xy0), _p(dxdy0), _p(e2dT), _p(e2d_b), _p(out_abs), _p(out_rel), R, _p(Gt),
+                                      _p(xy0), _p(dxdy0), _p(e2d_w), _p(e2d_b), _p(out_abs), _p(out_rel), R, _p(Gt),
                                       _p(Cs), _p(Hp), _p(Din), _p(Aact), _p(E2Din), _p(SocR), st)
         if save:
             ctx.meta = (rows, g0, n_gens, stride, T, owner, (b, EIN, Z, H, E, S, psz))
@@ -617,10 +626,10 @@ class DecoderRolloutFn(Function):
                                             _p(dEnc), _p(dSocR), _p(wpart), st)
         if train_w:
             ng, wl, P = n_gens, lay["wlen"], wpart.data_ptr()
-            dprep = torch.zeros(n_gens, 12 * H, dtype=F32, device=dev)
+            dprep = mk(n_gens, 12 * H)  # scratch: the reduction stores into it (has_bias bit 1)
             now = (_ReduceDesc * 2)(
-                _ReduceDesc(P + 4 * lay["A"], dprep.data_ptr(), None, 12 * H, 0, 4 * H, 2, 0, 2, NW, ng, wl, 0),
-                _ReduceDesc(P + 4 * lay["bias"], dprep.data_ptr() + 4 * 8 * H, None, 12 * H, 0, 1, 4 * H, 0, 4 * H, NW, ng,
+                _ReduceDesc(P + 4 * lay["A"], dprep.data_ptr(), None, 12 * H, 0, 4 * H, 2, 2, 2, NW, ng, wl, 0),
+                _ReduceDesc(P + 4 * lay["bias"], dprep.data_ptr() + 4 * 8 * H, None, 12 * H, 0, 1, 4 * H, 2, 4 * H, NW, ng,
                             wl, 0))
             lib.mggan_grad_reduce_multi(ctypes.addressof(now), 2, st)
             lib.mggan_lstm_unfold_grads(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), ptr["emb_w"], ptr["emb_b"],

@@ -95,6 +95,11 @@ def load():
             raise HipError(
                 "libmggan_hip.so not found at {} -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C mg-gan_amd/csrc`; there is no CPU fallback".format(LIB_PATH))
+        # torch ships its own libamdhip64: it has to be in the process first so that this library binds to the
+        # SAME HIP runtime as the tensors it is handed (loaded the other way round, /opt/rocm's runtime comes in
+        # next to torch's and every launch fails with "no ROCm-capable device is detected")
+        import torch  # noqa: F401
+
         _lib = _Lib(ctypes.CDLL(LIB_PATH))
     return _lib
 

@@ -49,6 +49,9 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self.share_trunk = True
         # weight-gradient GEMMs on a side stream during backward, joined in optimizer.step
         self.overlap_wgrad = os.environ.get("MGGAN_OVERLAP_WGRAD", "0") == "1"  # measured: no gain inside a hipGraph (5.5 vs 5.3 ms)
+        # True: AdamW leaves the gradients it consumed at zero (p.grad reads 0 after a step instead of the clipped
+        # gradient), which removes the memset at the start of the next step; same parameter updates
+        self.zero_grads_in_step = False
         self._pending = []
 
     # ---- metric plumbing ---------------------------------------------------------------
@@ -140,7 +143,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self.optimizerD.zero_grad()
         self._backward(losses, [self._one] * len(losses))
         self.dist.all_reduce_grads(self.D)
-        self.optimizerD.step(self.config.clipping_threshold_d)
+        self.optimizerD.step(self.config.clipping_threshold_d, zero_grad=self.zero_grads_in_step)
         self._emit(train_metrics, items)
 
     def generator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None,
@@ -191,7 +194,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self.optimizerG.zero_grad()
         self._backward(losses, grads)
         self.dist.all_reduce_grads(self.G)
-        self.optimizerG.step(cfg.clipping_threshold_g)
+        self.optimizerG.step(cfg.clipping_threshold_g, zero_grad=self.zero_grads_in_step)
         self._emit(train_metrics, items)
 
     def net_chooser_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, metrics, mask, img):
@@ -206,7 +209,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self.optimizerG.zero_grad()
         self._backward([loss], [self._w["pi"]])
         self.dist.all_reduce_grads(self.G)
-        self.optimizerG.step(0.0)
+        self.optimizerG.step(0.0, zero_grad=self.zero_grads_in_step)
         items = [("probs/Gen {} probability".format(i), M_PROBS + i) for i in range(g)]
         self._emit(metrics, items + [("train/net_chooser_loss", M_PM)])
 

@@ -26,9 +26,11 @@ class FlatAdamW:
     def zero_grad(self):
         self.root.zero_grad_flat()
 
-    def step(self, max_norm=0.0):
+    def step(self, max_norm=0.0, zero_grad=False):
         """Clip the gradients of the touched parameters to `max_norm` (0 = no clipping), then AdamW-update them.
-        Parameters that received no gradient since zero_grad() are skipped, like `p.grad is None` in torch."""
+        Parameters that received no gradient since zero_grad() are skipped, like `p.grad is None` in torch.
+        zero_grad=True leaves the consumed gradients at zero (instead of their clipped values), which turns the
+        next zero_grad() into bookkeeping only."""
         r = self.root
         if r._flat.data_ptr() != self._flat_id:
             raise RuntimeError("the module's flat parameter buffer was rebuilt after the optimizer was created")
@@ -41,7 +43,9 @@ class FlatAdamW:
                              self.exp_avg_sq.data_ptr(), r._flat.numel(), r._elem_seg.data_ptr(), self.nseg,
                              mask.data_ptr(), self.seg_step.data_ptr(), float(max_norm), float(self.lr),
                              float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                             self._ws.data_ptr(), self.grad_norm.data_ptr(), st)
+                             1 if zero_grad else 0, self._ws.data_ptr(), self.grad_norm.data_ptr(), st)
+        if zero_grad:
+            r._grad_clean = True  # every gradient written since the last memset has been consumed and zeroed
 
     # torch.optim-compatible checkpoint surface (abstract_train.py:235-244 saves optimizer state_dicts)
     def state_dict(self):
