@@ -165,8 +165,15 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # MGGAN_DIST_BACKEND=gloo lets two ranks share ONE GPU (RCCL refuses that): a functional check of the
+        # sharded path on a single-GPU box, never a measurement
+        backend = os.environ.get("MGGAN_DIST_BACKEND", "nccl")
+        local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     # host-side bookkeeping is a handful of tiny torch CPU ops: a large OpenMP team only adds fork/join latency
     torch.set_num_threads(min(4, os.cpu_count() or 1))
@@ -186,7 +193,7 @@ def main():
     tr.defer_metrics = True
     tr.zero_grads_in_step = True  # AdamW zeroes what it consumed: no separate memset per step
     metrics = defaultdict(list)
-    use_graph = args.rng == "device" and world == 1 and not args.no_graph
+    use_graph = args.rng == "device" and not args.no_graph
     if use_graph:
         replay = tr.capture_iteration(batch)
 
@@ -267,7 +274,9 @@ def main():
             "config": {"workload": "{} scenes x {} peds per GPU, num_gens={}, num_samples=20, D+G+PM steps "
                                    "(BASELINE configs[1])".format(args.scenes, args.peds, args.num_gens),
                        "b_per_gpu": b, "parallelism": "dp{}".format(world), "rng": args.rng,
-                       "launch": "hipGraph replay of the whole iteration" if use_graph else "eager",
+                       "launch": ("eager" if not use_graph else "hipGraph replay of the whole iteration" if world == 1
+                                  else "{} hipGraph segments per iteration, RCCL collectives between them".format(
+                                      replay.graph.n_graphs)),
                        "last_losses": {k: round(v[-1], 6) for k, v in sorted(metrics.items()) if "probs" not in k}},
             "roofline": roofline,
             "roofline_top_kernels": roofline_top,

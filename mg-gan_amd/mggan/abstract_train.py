@@ -90,8 +90,6 @@ class MultiGeneratorGAN(abc.ABC):
         if not getattr(self.rng, "on_device", False):
             raise RuntimeError("graph capture needs the device RNG (--rng device): the host RNG path reads the "
                                "PM-network logits back to the CPU")
-        if self.dist.enabled:
-            raise RuntimeError("graph capture is single-GPU for now")
         batch = dict(batch)
         batch["loss_mask"] = None
         keep, self.defer_metrics = self.defer_metrics, True
@@ -103,20 +101,39 @@ class MultiGeneratorGAN(abc.ABC):
                 self.train_iteration(batch, scratch)
         torch.cuda.current_stream().wait_stream(side)
         self.flush_metrics()
-        graph = torch.cuda.CUDAGraph()
         captured = defaultdict(list)
-        with torch.cuda.graph(graph):
-            self.train_iteration(batch, captured)
+        if self.dist.enabled:
+            # sharded iteration: the collectives cut the capture into graph segments and stay eager calls
+            # between them (parallel.SegmentRecorder)
+            from mggan.parallel import SegmentRecorder
+
+            if not self.dist.equal_shards:
+                raise RuntimeError("graph capture of a sharded iteration needs equal shards (dist.equal_shards)")
+            rec = SegmentRecorder()
+            torch.cuda.synchronize()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.dist.recorder = rec
+                rec.begin()
+                try:
+                    self.train_iteration(batch, captured)
+                finally:
+                    rec.end()
+                    self.dist.recorder = None
+            torch.cuda.current_stream().wait_stream(side)
+            run, graph = rec.replay, rec
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.train_iteration(batch, captured)
+            run = graph.replay
         pending, self._pending = self._pending, []
         self.defer_metrics = keep
 
         def replay(metrics=None, fetch=True):
-            graph.replay()
+            run()
             if metrics is not None and fetch:
-                for _, items, snap in pending:
-                    v = snap.cpu().numpy()
-                    for key, slot in items:
-                        metrics[key].append(float(v[slot] if isinstance(slot, int) else v[slot[0]] + v[slot[1]]))
+                self._fetch([(metrics, items, snap) for _, items, snap in pending])
 
         replay.graph = graph
         return replay

@@ -57,18 +57,22 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
     # ---- metric plumbing ---------------------------------------------------------------
     def _emit(self, train_metrics, items):
         """items: list of (key, slot | (slot_a, slot_b) summed)."""
-        snap = self._m.clone()
-        if self.dist.enabled:
-            self.dist.all_reduce_(snap)
-        self._pending.append((train_metrics, items, snap))
+        self._pending.append((train_metrics, items, self._m.clone()))
         if not self.defer_metrics:
             self.flush_metrics()
 
-    def flush_metrics(self):
-        for train_metrics, items, snap in self._pending:
+    def _fetch(self, pending):
+        """One D2H copy per pending snapshot; sharded runs sum the per-rank partial means first (the loss
+        kernels already divide by the GLOBAL row count)."""
+        for train_metrics, items, snap in pending:
+            if self.dist.enabled:
+                snap = self.dist.all_reduce_(snap.clone())
             v = snap.cpu().numpy()
             for key, slot in items:
                 train_metrics[key].append(float(v[slot] if isinstance(slot, int) else v[slot[0]] + v[slot[1]]))
+
+    def flush_metrics(self):
+        self._fetch(self._pending)
         self._pending = []
 
     def _global(self, n):

@@ -53,15 +53,37 @@ class DistContext:
         self.world_size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
 
+    recorder = None  # a SegmentRecorder while an iteration is being captured into HIP graphs
+
+    def _collective(self, t):
+        """Sum `t` over the ranks in place.  While an iteration is being captured the collective CUTS the graph:
+        the kernels queued so far become one graph segment, the collective itself stays an eager call that is
+        replayed between the segments (so the capture does not depend on the backend being capturable)."""
+        group = self.group
+
+        def run():
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+        if self.recorder is not None:
+            self.recorder.cut(run)
+        else:
+            run()
+
     def all_reduce_(self, t):
         if self.enabled:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._collective(t)
         return t
 
     def all_reduce_stats(self, sums, n_local):
         """BatchNorm: sums (2C,) f64 and the local image count -> global sums in place, global count returned."""
         if not self.enabled:
             return n_local
+        if self.equal_shards:  # every rank holds n_local images: no count exchange, no host read-back
+            self._collective(sums)
+            return float(n_local) * self.world_size
+        if self.recorder is not None:
+            raise RuntimeError("graph capture of a sharded iteration needs equal shards (the global image count of "
+                               "unequal shards is read back to the host)")
         buf = torch.cat([sums, sums.new_tensor([float(n_local)])])
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         sums.copy_(buf[:-1])
@@ -72,6 +94,8 @@ class DistContext:
             return n_local
         if self.equal_shards:
             return n_local * self.world_size
+        if self.recorder is not None:
+            raise RuntimeError("graph capture of a sharded iteration needs equal shards")
         t = torch.tensor([float(n_local)], dtype=torch.float64, device=self._dev)
         dist.all_reduce(t, group=self.group)
         return float(t.item())
@@ -86,7 +110,7 @@ class DistContext:
             from mggan.hip.functions import join_side_stream
 
             join_side_stream()
-            dist.all_reduce(root._flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self._collective(root._flat_grad)
 
     def attach(self, *roots):
         for r in roots:
@@ -95,3 +119,43 @@ class DistContext:
                     m.sync = self if self.enabled else None
             if r._flat is not None:
                 self._dev = r._flat.device
+
+
+class SegmentRecorder:
+    """Captures one iteration as a chain  graph_0, call_0, graph_1, call_1, ..., graph_n  where the calls are
+    the eager collectives that cut the capture (DistContext._collective).  All segments share one memory pool
+    and are replayed strictly in capture order, so a tensor produced in one segment is valid in the next.
+    Capture mode "relaxed": a cut can come from the autograd engine's worker thread (BatchNorm statistics in a
+    backward pass), and HIP only lets another thread end a capture that was begun relaxed."""
+
+    def __init__(self, error_mode="relaxed"):
+        self.items = []  # ("graph", CUDAGraph) | ("call", fn)
+        self.pool = torch.cuda.graph_pool_handle()
+        self.error_mode = error_mode
+        self._g = None
+
+    def begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._g.capture_begin(pool=self.pool, capture_error_mode=self.error_mode)
+
+    def end(self):
+        self._g.capture_end()
+        self.items.append(("graph", self._g))
+        self._g = None
+
+    def cut(self, fn):
+        self.end()
+        fn()  # keeps the ranks' collective sequence in lock-step during capture (the data is not meaningful yet)
+        self.items.append(("call", fn))
+        self.begin()
+
+    def replay(self):
+        for kind, x in self.items:
+            if kind == "graph":
+                x.replay()
+            else:
+                x()
+
+    @property
+    def n_graphs(self):
+        return sum(1 for k, _ in self.items if k == "graph")

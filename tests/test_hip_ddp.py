@@ -77,7 +77,7 @@ def _launch(world, sizes):
     procs = [ctx.Process(target=_run, args=(r, world, port, sizes, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -95,3 +95,59 @@ def test_two_ranks_match_single_process():
         for k, v in single[3].items():              # logged losses are global means on every rank
             np.testing.assert_allclose(r[3][k], v, rtol=2e-3, atol=1e-6, err_msg=k)
     assert np.array_equal(two[0][1], two[1][1])    # bit-identical replicas
+
+
+def _run_graph(rank, world, port, sizes, q):
+    """Sharded iteration captured as HIP-graph segments with the collectives replayed eagerly between them."""
+    import sys
+
+    for p in (os.path.join(ROOT, "mg-gan_amd"), ROOT):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    import bench
+    from mggan.data_utils import synthetic
+    from mggan.parallel import shard_batch
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    dev = torch.device("cuda", 0)
+    tr = bench.build_trainer(2, "device", dev, seed=rank)
+    tr.dist.equal_shards = True
+    full = synthetic.make_batch(sizes, seed=9)
+    batch = tr.to_device(shard_batch(full, rank, world))
+    batch["loss_mask"] = None
+    tr.defer_metrics = True
+    m = defaultdict(list)
+    replay = tr.capture_iteration(batch, warmup=2)
+    for i in range(3):
+        replay(m, True)
+    torch.cuda.synchronize()
+    flat = torch.cat([tr.G._flat.cpu(), tr.D._flat.cpu()])
+    steps = int(tr.optimizerD.seg_step.max().cpu())
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, flat.numpy(), replay.graph.n_graphs, steps, {k: v for k, v in m.items() if "probs" not in k}))
+
+
+def test_two_ranks_graph_segments():
+    sizes = [3, 3, 3, 3]  # equal shards: 6 pedestrians per rank
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_graph, args=(r, 2, port, sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, f0, n0, s0, m0), (_, f1, n1, s1, m1) = res
+    assert n0 == n1 and n0 > 10            # the collectives cut the iteration into graph segments
+    assert s0 == s1 == 2 + 3               # 2 eager warm-up iterations + 3 replays (capturing executes nothing)
+    assert np.isfinite(f0).all() and np.array_equal(f0, f1)  # replicas stay bit-identical through the replays
+    for k, v in m0.items():
+        assert len(v) == 3 and np.isfinite(v).all(), k
+        np.testing.assert_allclose(v, m1[k], rtol=1e-6)      # logged losses are global means on every rank
+    assert 0.2 < m0["train/discr_loss"][-1] < 3.0
