@@ -41,6 +41,7 @@ def kernel_of(name, a):
         "mggan_linear_fwd": "gemm_kernel<false,false,false>",
         "mggan_linear_bwd_data": "gemm_kernel<false,true,false>",
         "mggan_conv2_bwd": "conv2_bwd_mfma_kernel",
+        "mggan_mlp_chain": "mlp_chain_kernel",
     }
     if name in fixed:
         return fixed[name]
@@ -61,6 +62,11 @@ def flops_of(name, a):
         from mggan.hip import functions as HF
 
         notes = HF.TRACE_NOTES["wgrad_multi_flops"]
+        return notes.pop(0) if notes else 0.0
+    if name == "mggan_mlp_chain":  # fused MLP chain: the launcher notes the FLOPs of every launch
+        from mggan.hip import functions as HF
+
+        notes = HF.TRACE_NOTES["mlp_chain_flops"]
         return notes.pop(0) if notes else 0.0
     if name == "mggan_lstm_encoder_fwd":
         T, b, H = a[1], a[2], a[3]

@@ -38,6 +38,19 @@ int mggan_version(void);
 int mggan_linear_fwd(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int rows, int K,
                      int N, int act, float slope, mggan_stream_t stream);
 /* dZ = dY * act'(Y)  (Y = activation OUTPUT) */
+/* A chain of up to three dense stages on 32-row tiles in ONE launch (replaces the nn.Sequential MLP stacks
+ * built by the reference's utils.make_mlp, utils.py:134-149: discriminator heads, pred_encoder,
+ * in_encoder_fc, PM-network).  `args` points to a host structure
+ *   { const float* X; const float* in_mul; float* in_store;
+ *     int ldx, rows, K0, ld_in_mul, in_mul_act, ld_in_store, n; float in_mul_slope;
+ *     struct { const float* W; const float* bias; const float* mul_src; float* out;
+ *              int K, N, ldw, trans, act, mul_act, ld_mul, ld_out, accumulate; float slope, mul_slope; } s[3]; }
+ * Stage i: out_i[r][c] = act_i(sum_k in_i[r][k] * (trans ? W[k][c] : W[c][k]) + bias[c]) * act'_mul(mul_src[r][c]);
+ * in_0 = X (* act'(in_mul), optionally copied to in_store), in_{i+1} = out_i; widths <= 192.  Forward pass:
+ * trans = 0, `out` of the inner stages = the saved hidden activations.  Backward pass: in_mul = the saved
+ * output of the last activation, stages run last-to-first with trans = 1 and mul_src = the saved hidden
+ * activations; in_store / out hold the gate gradients the weight-gradient GEMMs (mggan_wgrad*) read. */
+int mggan_mlp_chain(const void* args, mggan_stream_t stream);
 int mggan_act_bwd(const float* dY, int lddy, const float* Y, int ldy, float* dZ, int lddz, int rows, int N, int act,
                   float slope, mggan_stream_t stream);
 /* dX (rows x K) (+)= dZ (rows x N) . W (N x K, row stride ldw).  If Yact != NULL the activation derivative is

@@ -7,6 +7,7 @@ into the root module's flat gradient buffer (hip/flat.py), so backward returns
 None for parameter inputs.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -92,6 +93,60 @@ def join_side_stream():
         _SIDE["dirty"] = False
 
 
+# Independent sub-graphs of a step (the scene CNN next to the trajectory LSTM / social attention chain; the
+# discriminator's history context next to the generator rollouts) are issued on a second stream: the small
+# latency-bound kernels of one branch fill the gaps of the other.  Autograd replays every backward node on
+# the stream of its forward, so the backward pass inherits the same two-branch shape; inside a HIP-graph
+# capture the fork/join events become graph edges.  A branch ALWAYS starts by waiting for the main stream, and
+# every step ends joined, so memory freed by one stream is never re-used by the other before it is ordered.
+_BR = {"on": os.environ.get("MGGAN_BRANCH", "1") == "1", "stream": None, "dirty": False}
+
+
+def enable_branches(on=True):
+    join_branch()
+    _BR["on"] = bool(on)
+
+
+class branch:
+    """Context: launches inside go to the branch stream (no-op when disabled or already on it)."""
+
+    def __enter__(self):
+        self.ctx = None
+        if not _BR["on"]:
+            return self
+        if _BR["stream"] is None:
+            _BR["stream"] = torch.cuda.Stream()
+        side, cur = _BR["stream"], torch.cuda.current_stream()
+        if cur == side:
+            return self
+        side.wait_stream(cur)
+        _BR["dirty"] = True
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_branch(*tensors, force=False):
+    """The current stream waits for the branch stream; `tensors` (branch results consumed from here on) are
+    registered with the consuming stream so the allocator keeps them until that stream is done with them."""
+    side = _BR["stream"]
+    if side is None or not (_BR["dirty"] or force):
+        return
+    cur = torch.cuda.current_stream()
+    if cur == side:
+        return
+    cur.wait_stream(side)
+    for t in tensors:
+        if t is not None:
+            t.record_stream(cur)
+    _BR["dirty"] = False
+
+
 class _ReduceDesc(ctypes.Structure):
     _fields_ = [("P", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("w_stride", ctypes.c_long),
                 ("b_stride", ctypes.c_long), ("M", ctypes.c_int), ("Naug", ctypes.c_int), ("has_bias", ctypes.c_int),
@@ -109,7 +164,7 @@ class _WgradDesc(ctypes.Structure):
 
 
 _DEFER = {"on": False, "descs": [], "keep": [], "gemms": []}
-TRACE_NOTES = {"wgrad_multi_flops": []}
+TRACE_NOTES = {"wgrad_multi_flops": [], "mlp_chain_flops": []}
 
 
 def defer_grad_reduce(on=True):
@@ -230,6 +285,131 @@ class LinearFn(Function):
 def linear(x, layer, act=ACT_NONE, slope=0.0):
     lead = x.shape[:-1]
     y = LinearFn.apply(x.reshape(-1, x.shape[-1]), layer.weight, layer.bias, act, slope, layer)
+    return y.reshape(*lead, -1)
+
+
+class _McStage(ctypes.Structure):  # mirrors csrc/mlp.hip:McStage
+    _fields_ = [("W", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("mul_src", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("K", ctypes.c_int), ("N", ctypes.c_int), ("ldw", ctypes.c_int), ("trans", ctypes.c_int),
+                ("act", ctypes.c_int), ("mul_act", ctypes.c_int), ("ld_mul", ctypes.c_int), ("ld_out", ctypes.c_int),
+                ("accumulate", ctypes.c_int), ("slope", ctypes.c_float), ("mul_slope", ctypes.c_float)]
+
+
+class _McArgs(ctypes.Structure):
+    _fields_ = [("X", ctypes.c_void_p), ("in_mul", ctypes.c_void_p), ("in_store", ctypes.c_void_p),
+                ("ldx", ctypes.c_int), ("rows", ctypes.c_int), ("K0", ctypes.c_int), ("ld_in_mul", ctypes.c_int),
+                ("in_mul_act", ctypes.c_int), ("ld_in_store", ctypes.c_int), ("n", ctypes.c_int),
+                ("in_mul_slope", ctypes.c_float), ("s", _McStage * 3)]
+
+
+MLP_MAX_WIDTH = 192
+
+
+class MlpChainFn(Function):
+    """act_n(... act_1(x W_1^T + b_1) ...) for 2-3 Linear layers in ONE launch per direction
+    (nn.Sequential stacks of utils.make_mlp, utils.py:134-149; csrc/mlp.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, spec, owner, save, *wb):
+        # spec: tuple of (act, slope) per layer; wb = (W_1, b_1, W_2, b_2, ...); save: a backward pass will follow
+        x, ldx = _rows2d(x)
+        rows, K0 = x.shape
+        n = len(spec)
+        Ws, bs = wb[0::2], wb[1::2]
+        a = _McArgs()
+        a.X, a.ldx, a.rows, a.K0, a.n = _p(x), ldx, rows, K0, n
+        outs = []
+        for i, ((act, slope), W, b) in enumerate(zip(spec, Ws, bs)):
+            N, K = W.shape
+            keep = i == n - 1 or save  # hidden activations only leave the chip when a backward pass needs them
+            y = _empty(rows, N, like=x) if keep else None
+            outs.append(y)
+            st = a.s[i]
+            st.W, st.bias, st.out = _p(W), _p(b), _p(y)
+            st.K, st.N, st.ldw, st.trans, st.act, st.slope, st.ld_out = K, N, K, 0, act, float(slope), N
+        if _load_lib().trace is not None:
+            TRACE_NOTES["mlp_chain_flops"].append(2.0 * rows * sum(W.shape[0] * W.shape[1] for W in Ws))
+        lib.mggan_mlp_chain(ctypes.addressof(a), _s())
+        if save:
+            ctx.spec, ctx.owner, ctx.ldx, ctx.n = spec, owner, ldx, n
+            ctx.save_for_backward(x, *outs, *wb)
+        return outs[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, spec = ctx.n, ctx.spec
+        sv = ctx.saved_tensors
+        x, outs, wb = sv[0], sv[1:1 + n], sv[1 + n:]
+        Ws, bs = wb[0::2], wb[1::2]
+        rows = x.shape[0]
+        dy, lddy = _rows2d(dy)
+        need_dx = ctx.needs_input_grad[0]
+        train_w = Ws[0].requires_grad
+        # gate gradients dz_l (l = n-1 .. 0): dz_{n-1} = dy * act'(y); dz_{l-1} = (dz_l W_l) * act'(h_{l-1})
+        a = _McArgs()
+        a.X, a.ldx, a.rows, a.K0 = _p(dy), lddy, rows, Ws[-1].shape[0]
+        dz = [None] * n
+        act_last = spec[-1][0]
+        if act_last != ACT_NONE:
+            a.in_mul, a.ld_in_mul, a.in_mul_act, a.in_mul_slope = _p(outs[-1]), outs[-1].shape[1], act_last, float(spec[-1][1])
+            if train_w:
+                dz[-1] = _empty(rows, Ws[-1].shape[0], like=x)
+                a.in_store, a.ld_in_store = _p(dz[-1]), Ws[-1].shape[0]
+        elif train_w:
+            dz[-1] = dy
+        k = 0
+        dx = None
+        for l in range(n - 1, -1, -1):  # stage k: dz_l (rows, N_l) -> (rows, K_l) through W_l
+            if l == 0 and not need_dx:
+                break
+            N, K = Ws[l].shape
+            st = a.s[k]
+            st.W, st.K, st.N, st.ldw, st.trans, st.act = _p(Ws[l]), N, K, K, 1, ACT_NONE
+            if l > 0:
+                st.mul_src, st.ld_mul, st.mul_act, st.mul_slope = _p(outs[l - 1]), K, spec[l - 1][0], float(spec[l - 1][1])
+                if train_w:
+                    dz[l - 1] = _empty(rows, K, like=x)
+                    st.out, st.ld_out = _p(dz[l - 1]), K
+            else:
+                dx = _empty(rows, K, like=x)
+                st.out, st.ld_out = _p(dx), K
+            k += 1
+        a.n = k
+        if k > 0:
+            if _load_lib().trace is not None:
+                TRACE_NOTES["mlp_chain_flops"].append(2.0 * rows * sum(a.s[i].K * a.s[i].N for i in range(k)))
+            lib.mggan_mlp_chain(ctypes.addressof(a), _s())
+        if train_w:
+            root = root_of(ctx.owner)
+            lddz_last = lddy if dz[-1] is dy else Ws[-1].shape[0]
+            with side_stream(*[t for t in dz if t is not None], x, *outs):
+                for l in range(n):
+                    N, K = Ws[l].shape
+                    inp, ldi = (x, ctx.ldx) if l == 0 else (outs[l - 1], K)
+                    wgrad(dz[l], lddz_last if l == n - 1 else N, inp, ldi, root.grad_ptr(Ws[l]), K,
+                          root.grad_ptr(bs[l]) if bs[l] is not None else 0, rows, K, N)
+        return (dx, None, None, None) + (None,) * len(wb)
+
+
+# Above this many rows the stack runs as one GEMM launch per layer: a weight-stationary chain keeps one wave per
+# SIMD resident (the weight images fill the LDS) and measured 40 us against 35 us for 25,600 x 192 x 96 x 1; below
+# it the chain wins by the launches it removes (9.7 us against 13.5 us for 1,280 x 64 x 32 x 32).
+MLP_FUSE_MAX_ROWS = int(os.environ.get("MGGAN_MLP_FUSE_MAX_ROWS", "8192"))
+
+
+def mlp(x, layers, owner=None):
+    """layers: [(nn.Linear, act, slope), ...] applied in order as one fused chain (2-3 layers, widths <= 192)."""
+    lead = x.shape[:-1]
+    if x.numel() // max(x.shape[-1], 1) > MLP_FUSE_MAX_ROWS:
+        for lin, act, slope in layers:
+            x = linear(x, lin, act, slope)
+        return x
+    spec = tuple((act, slope) for _, act, slope in layers)
+    wb = []
+    for lin, _, _ in layers:
+        wb += [lin.weight, lin.bias]
+    y = MlpChainFn.apply(x.reshape(-1, x.shape[-1]), spec, owner if owner is not None else layers[0][0],
+                         want_grad(x, wb[0]), *wb)
     return y.reshape(*lead, -1)
 
 

@@ -62,9 +62,11 @@ class MultiDiscriminatorTrajectory(FlatModule):
         backward once instead of twice; `passes` keeps the BatchNorm running-stat count of the reference."""
         self.ensure_flat()
         fc = self.in_encoder_fc
+        with HF.branch():  # scene CNN || history LSTM; joined by forward() right before the classifier input
+            scene = self.scene_encoder(img, stat_updates=passes)
         h = self.in_encoder(in_dxdy)
-        in_enc = HF.linear(HF.linear(h, fc[0], HF.ACT_LEAKY, 0.2), fc[2])
-        return in_enc, self.scene_encoder(img, stat_updates=passes)
+        in_enc = HF.mlp(h, [(fc[0], HF.ACT_LEAKY, 0.2), (fc[2], HF.ACT_NONE, 0.0)])
+        return in_enc, scene
 
     def _encode_parts(self, in_dxdy, pred_dxdy, context=None):
         fc, pe = self.in_encoder_fc, self.pred_encoder
@@ -72,10 +74,10 @@ class MultiDiscriminatorTrajectory(FlatModule):
             in_enc = context[0]
         else:
             h = self.in_encoder(in_dxdy)
-            in_enc = HF.linear(HF.linear(h, fc[0], HF.ACT_LEAKY, 0.2), fc[2])
+            in_enc = HF.mlp(h, [(fc[0], HF.ACT_LEAKY, 0.2), (fc[2], HF.ACT_NONE, 0.0)])
         _, n_samples, b, _ = pred_dxdy.shape
         x = pred_dxdy.permute(1, 2, 0, 3).reshape(n_samples * b, -1)
-        pred_enc = HF.linear(HF.linear(x, pe[0], HF.ACT_LEAKY, 0.2), pe[2])
+        pred_enc = HF.mlp(x, [(pe[0], HF.ACT_LEAKY, 0.2), (pe[2], HF.ACT_NONE, 0.0)])
         return in_enc, pred_enc
 
     def forward(self, in_xy, in_dxdy, pred_xy, pred_dxdy, seq_start_end, return_all=False, img=None, mask=None,
@@ -98,6 +100,7 @@ class MultiDiscriminatorTrajectory(FlatModule):
             enc0 = torch.cat([in_enc, pred_enc if n_samples == 1 else pred_enc[:full_b]], dim=1)
             soc0 = self.social(in_xy, in_dxdy, enc0, seq_start_end)
             scene = context[1] if context is not None else self.scene_encoder(img)
+            HF.join_branch(scene)
             classifier_inp = HF.DAssembleFn.apply(soc0, in_enc, pred_enc, scene, n_samples)
         else:
             enc = self.encode(in_xy, in_dxdy, pred_xy, pred_dxdy, mask)
@@ -108,10 +111,10 @@ class MultiDiscriminatorTrajectory(FlatModule):
             classifier_inp = torch.cat([classifier_inp, scene], 1)
 
         d = self.discs[0]
-        y = HF.linear(HF.linear(classifier_inp, d[0], HF.ACT_LEAKY, 0.2), d[2], HF.ACT_SIGMOID_EPS)
+        y = HF.mlp(classifier_inp, [(d[0], HF.ACT_LEAKY, 0.2), (d[2], HF.ACT_SIGMOID_EPS, 0.0)])
         output = y.reshape(n_samples, b).t()  # mean over the single discriminator is the identity
         if self.gan_type == "gan":
             return output
         r = self.gen_id_reconstructor
-        branch_out = HF.linear(HF.linear(classifier_inp, r[0], HF.ACT_LEAKY, 0.2), r[2])
+        branch_out = HF.mlp(classifier_inp, [(r[0], HF.ACT_LEAKY, 0.2), (r[2], HF.ACT_NONE, 0.0)])
         return output, branch_out.reshape(n_samples, b, -1).transpose(0, 1)

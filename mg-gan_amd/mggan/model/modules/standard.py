@@ -95,16 +95,16 @@ class MultiGenerator(FlatModule):
         for that many identical reference forwards (the no-grad generator call of the discriminator step and
         the generator step see the same weights) -> BatchNorm running stats are updated that many times."""
         self.ensure_flat()
+        with HF.branch():  # scene CNN || trajectory LSTM + social attention
+            scene = self.scene_encoder(img, stat_updates=passes)
         enc = self.encoder(get_input(in_xy, in_dxdy, self.inp_format))
-        scene = self.scene_encoder(img, stat_updates=passes)
         soc = self.social(in_xy, in_dxdy, enc, sub_batches)
+        HF.join_branch(scene)
         return torch.cat([enc, scene, soc], -1), soc
 
     def _chooser(self, enc_h):
         nc = self.net_chooser
-        x = HF.linear(enc_h, nc[0], HF.ACT_LEAKY, 0.0)
-        x = HF.linear(x, nc[2], HF.ACT_LEAKY, 0.0)
-        return HF.linear(x, nc[4])
+        return HF.mlp(enc_h, [(nc[0], HF.ACT_LEAKY, 0.0), (nc[2], HF.ACT_LEAKY, 0.0), (nc[4], HF.ACT_NONE, 0.0)])
 
     def _rollout(self, rows, in_xy, in_dxdy, enc_h, social_feats, noise):
         e2d = self.enc_h_to_dec_h[0]

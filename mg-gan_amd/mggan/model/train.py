@@ -105,6 +105,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             HF.enable_side_stream(False)
             HF.defer_grad_reduce(False)
         HF.join_side_stream()
+        HF.join_branch(force=True)  # backward nodes ran on the streams of their forwards
         HF.flush_grad_reduces()
 
     # ---- the three steps -----------------------------------------------------------------
@@ -154,18 +155,6 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                        shared=None):
         m, cfg = self._m, self.config
         b = in_xy.size(1)
-        noise = self.rng.noise(cfg.num_samples, cfg.noise_dim, sub_batches, self.device)
-        gen_out, _, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
-                                      mask=loss_mask, num_samples=cfg.num_samples,
-                                      trunk=None if shared is None else shared.get("g_trunk"))
-        losses, grads, items = [], [], []
-        if cfg.l2_loss_type != "none":
-            tb = HF.scene_tables(sub_batches, gen_out.abs.shape[2], self.device)
-            min_l2 = HF.L2MinSceneFn.apply(gen_out.abs, gt_xy, tb, self._global(b), m[M_L2:M_L2 + 1])
-            losses.append(min_l2)
-            grads.append(self._w["l2"])
-            items.append(("train/L2_loss", M_L2))
-
         # adversarial pass: D's weights get no gradient here (the reference discards them: D.zero_grad()
         # precedes backward and the next discriminator step zeroes them again, train.py:128,207)
         d_params = list(self.D.parameters())
@@ -173,7 +162,28 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         for p in d_params:
             p.requires_grad_(False)
         try:
-            disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask)
+            ctx_d = None
+            if loss_mask is None and self.share_context:
+                # D's history LSTM + scene CNN depend on neither G nor (in this step) any gradient: they run on the
+                # branch stream next to the generator's forward pass
+                with HF.branch(), torch.no_grad():
+                    ctx_d = self.D.history_context(in_dxdy, img, passes=1)
+            noise = self.rng.noise(cfg.num_samples, cfg.noise_dim, sub_batches, self.device)
+            gen_out, _, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
+                                          mask=loss_mask, num_samples=cfg.num_samples,
+                                          trunk=None if shared is None else shared.get("g_trunk"))
+            losses, grads, items = [], [], []
+            if cfg.l2_loss_type != "none":
+                tb = HF.scene_tables(sub_batches, gen_out.abs.shape[2], self.device)
+                min_l2 = HF.L2MinSceneFn.apply(gen_out.abs, gt_xy, tb, self._global(b), m[M_L2:M_L2 + 1])
+                losses.append(min_l2)
+                grads.append(self._w["l2"])
+                items.append(("train/L2_loss", M_L2))
+
+            if ctx_d is not None:
+                HF.join_branch(*ctx_d)
+            disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask,
+                              context=ctx_d)
         finally:
             for p, f in zip(d_params, flags):
                 p.requires_grad_(f)

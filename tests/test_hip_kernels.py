@@ -157,3 +157,66 @@ def test_clip_adamw_matches_torch_and_skips_untouched():
         opt.step(10.0)
         for (n, p), (_, rp) in zip(m.named_parameters(), ref.named_parameters()):
             np.testing.assert_allclose(p.detach().cpu().numpy(), rp.detach().numpy(), rtol=2e-5, atol=1e-6, err_msg=n)
+
+
+@pytest.mark.parametrize("rows,dims,acts,train_w,need_dx", [
+    (1000, (192, 96, 1), ((1, 0.2), (3, 0.0)), True, True),     # discriminator head (sigmoid-eps output)
+    (77, (192, 96, 4), ((1, 0.2), (0, 0.0)), False, True),       # generator-id head, frozen weights (G step)
+    (1280, (24, 64, 32), ((1, 0.2), (0, 0.0)), True, False),     # pred_encoder on leaf inputs
+    (33, (128, 16, 16, 8), ((1, 0.0), (1, 0.0), (0, 0.0)), True, True),  # PM-network (3 layers, ReLU)
+    (1, (65, 64, 33), ((0, 0.0), (2, 0.0)), True, True),         # odd widths, a single row
+])
+def test_mlp_chain_matches_torch(rows, dims, acts, train_w, need_dx):
+    """mggan_mlp_chain (forward and backward chains) == the same nn.Sequential in float64 on the CPU, and
+    bit-identical to the one-layer GEMM launches it replaces."""
+    import torch.nn as nn
+    from mggan.hip import functions as HF
+    from mggan.hip.flat import FlatModule
+
+    dev = _dev()
+    torch.manual_seed(rows + sum(dims))
+
+    class Net(FlatModule):
+        def __init__(self):
+            super().__init__()
+            self.layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+
+    net = Net()
+    ref = [nn.Linear(a, b).double() for a, b in zip(dims[:-1], dims[1:])]
+    for r, l in zip(ref, net.layers):
+        r.load_state_dict({k: v.double() for k, v in l.state_dict().items()})
+    net = net.to(dev).flatten_parameters_()
+    for p in net.parameters():
+        p.requires_grad_(train_w)
+    x = torch.randn(rows, dims[0] + 3)[:, :dims[0]]  # strided rows
+    xd = x.to(dev).requires_grad_(need_dx)
+    xr = x.double().requires_grad_(True)
+
+    def act_ref(v, a, s):
+        return {0: v, 1: torch.where(v > 0, v, v * s), 2: torch.sigmoid(v), 3: torch.sigmoid(v) * (1 - 2e-7) + 1e-7}[a]
+
+    h = xr
+    for l, (a, s) in zip(ref, acts):
+        h = act_ref(l(h), a, s)
+    layers = [(l, a, s) for l, (a, s) in zip(net.layers, acts)]
+    y = HF.mlp(xd, layers)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), h.detach().float().numpy(), rtol=2e-5, atol=2e-5)
+    y1 = xd.detach()
+    for l, a, s in layers:  # the unfused launches: same MFMA order -> same bits
+        y1 = HF.linear(y1, l, a, s)
+    assert torch.equal(y1.detach(), y.detach())
+    if not (train_w or need_dx):
+        return
+    dy = torch.randn(rows, dims[-1])
+    h.backward(dy.double())
+    net.zero_grad_flat()
+    HF.defer_grad_reduce(False)
+    y.backward(dy.to(dev))
+    if need_dx:
+        np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.float().numpy(), rtol=1e-4, atol=1e-5)
+    for l, r in zip(net.layers, ref):
+        if train_w:
+            np.testing.assert_allclose(l.weight.grad.cpu().numpy(), r.weight.grad.float().numpy(), rtol=1e-4, atol=2e-5)
+            np.testing.assert_allclose(l.bias.grad.cpu().numpy(), r.bias.grad.float().numpy(), rtol=1e-4, atol=2e-5)
+        else:
+            assert l.weight.grad is None or float(l.weight.grad.abs().max()) == 0.0
