@@ -142,7 +142,7 @@ int mggan_social_pairs_bwd(int P, int b, const int* pair_j, const int* ped_prow,
 
 /* ---- scene CNN + physical attention -----------------------------------------------------
  * reference: cnn.py:119-160 (Conv_Blocks), :275-282 (CNN.forward), :109-116 (AttentionGlobal.forward)
- * img (B,4,33,33) -> y1 raw (B,C,33,33) -> [BN+ReLU+pool] -> y2 raw (B,C,16,16) -> [BN+ReLU+pool]
+ * img (B,4,33,33) -> y1 raw (B,C,33,36: rows padded to 36 floats) -> [BN+ReLU+pool] -> y2 raw (B,C,16,16) -> [BN+ReLU+pool]
  * -> attention over channels -> out (B,64).  part = per-image (sum, sumsq) per channel (B,2C);
  * mggan_bn_reduce folds them to f64 sums (all-reduce point for multi-GPU), mggan_bn_finalize
  * turns sums into scale/shift (+ running-stat update, stat = mean | invstd). */

@@ -16,6 +16,7 @@
 
 #define IH 33
 #define IPIX (IH * IH)
+#define Y1_LD 36    // row stride of the raw conv1 output (33 + 3 pad): 1x4 strips are aligned 16-byte stores
 #define IMG_LD 40     // padded row stride of the 35-row input image in LDS
 #define IMG_PLANE (35 * IMG_LD)
 #define A1_LD 20      // padded row stride of the 18x18 (16x16 + halo) tiles
@@ -28,12 +29,28 @@ __device__ __forceinline__ void load6(const float* p, float r[6]) {
   r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y;
 }
 
+// (4,33,33) image -> zero-haloed LDS planes.  All 4,356 pixels are requested first (contiguous, coalesced,
+// 18 loads per thread in flight), the halo is cleared while they fly, then the interior lands.
+template <bool ZERO>
 __device__ __forceinline__ void stage_image(const float* __restrict__ img, float* imgp) {
-  for (int idx = threadIdx.x; idx < 4 * IMG_PLANE; idx += 256) {
-    const int ci = idx / IMG_PLANE, rem = idx % IMG_PLANE, yy = rem / IMG_LD, xx = rem % IMG_LD;
-    float v = 0.f;
-    if (yy >= 1 && yy <= IH && xx >= 1 && xx <= IH) v = img[(ci * IH + (yy - 1)) * IH + (xx - 1)];
-    imgp[idx] = v;
+  constexpr int NPIX = 4 * IPIX, PER = (NPIX + 255) / 256;
+  float v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    v[u] = img[e < NPIX ? e : 0];
+  }
+  if (ZERO) {
+    for (int i = threadIdx.x; i < 4 * IMG_PLANE; i += 256) imgp[i] = 0.f;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    if (e < NPIX) {
+      const int ci = e / IPIX, rem = e - ci * IPIX, y = rem / IH, x = rem - y * IH;
+      imgp[ci * IMG_PLANE + (y + 1) * IMG_LD + x + 1] = v[u];
+    }
   }
 }
 
@@ -45,7 +62,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   constexpr int COT = C / 4;
   __shared__ __attribute__((aligned(16))) float imgp[4 * IMG_PLANE];
   const int b = blockIdx.x;
-  stage_image(img + (size_t)b * 4 * IPIX, imgp);
+  stage_image<true>(img + (size_t)b * 4 * IPIX, imgp);
   __syncthreads();
   const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pg = threadIdx.x & 63;
   float sum[COT], sq[COT];
@@ -77,12 +94,12 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       }
 #pragma unroll
     for (int co = 0; co < COT; ++co) {
-      float* o = y1 + (((size_t)b * C + cg * COT + co) * IH + y) * IH + x0;
+      float* o = y1 + (((size_t)b * C + cg * COT + co) * IH + y) * Y1_LD + x0;
+      *reinterpret_cast<float4*>(o) = make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);  // pad columns: unused
 #pragma unroll
       for (int px = 0; px < 4; ++px)
         if (x0 + px < IH) {
           const float v = acc[co][px];
-          o[px] = v;
           sum[co] += v;
           sq[co] = fmaf(v, v, sq[co]);
         }
@@ -236,7 +253,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, const do
 // a1 = maxpool2(relu(y1*scale+shift)) for pooled position (py,px), channel c; returns argmax code / raw value
 __device__ __forceinline__ float pool_bn_relu(const float* __restrict__ base, int ld, float sc, float sh, int& code,
                                               float& raw) {
-  const float v[4] = {base[0], base[1], base[ld], base[ld + 1]};
+  const float2 lo = *reinterpret_cast<const float2*>(base), hi = *reinterpret_cast<const float2*>(base + ld);
+  const float v[4] = {lo.x, lo.y, hi.x, hi.y};
   float best = fmaxf(fmaf(v[0], sc, sh), 0.f);
   code = 0;
   raw = v[0];
@@ -264,8 +282,8 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const float* __restrict_
 #pragma unroll 4
     for (int c = 0; c < C; ++c) {
       int code; float raw;
-      const float* base = y1 + (((size_t)b * C + c) * IH + 2 * py) * IH + 2 * px;
-      a1p[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = pool_bn_relu(base, IH, scale1[c], shift1[c], code, raw);
+      const float* base = y1 + (((size_t)b * C + c) * IH + 2 * py) * Y1_LD + 2 * px;
+      a1p[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = pool_bn_relu(base, Y1_LD, scale1[c], shift1[c], code, raw);
     }
   }
   __syncthreads();
@@ -442,8 +460,8 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
 #pragma unroll 8
       for (int c = 0; c < C; ++c) {
         int code; float raw;
-        const float* base = y1 + (((size_t)b * C + c) * IH + 2 * py) * IH + 2 * px;
-        a1p[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = pool_bn_relu(base, IH, scale1[c], shift1[c], code, raw);
+        const float* base = y1 + (((size_t)b * C + c) * IH + 2 * py) * Y1_LD + 2 * px;
+        a1p[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = pool_bn_relu(base, Y1_LD, scale1[c], shift1[c], code, raw);
         y1r[c * 256 + threadIdx.x] = raw;
         const size_t gi = ((size_t)b * C + c) * 256 + threadIdx.x;
         code1[gi] = (unsigned char)code;
@@ -586,8 +604,8 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
 #pragma unroll 8
       for (int c = 0; c < C; ++c) {
         int code; float raw;
-        const float* base = y1 + (((size_t)b * C + c) * IH + 2 * py) * IH + 2 * px;
-        a1p[c * C2_PLANE + (py + 1) * A1_LD + px + 1] = pool_bn_relu(base, IH, scale1[c], shift1[c], code, raw);
+        const float* base = y1 + (((size_t)b * C + c) * IH + 2 * py) * Y1_LD + 2 * px;
+        a1p[c * C2_PLANE + (py + 1) * A1_LD + px + 1] = pool_bn_relu(base, Y1_LD, scale1[c], shift1[c], code, raw);
         y1r[c * 256 + threadIdx.x] = raw;
         const size_t gi = ((size_t)b * C + c) * 256 + threadIdx.x;
         code1[gi] = (unsigned char)code;
@@ -680,6 +698,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(int B, const float* __re
   float* imgp = smem;                  // 4*IMG_PLANE
   float* dy1 = smem + 4 * IMG_PLANE;   // CH*33*36
   for (int i = threadIdx.x; i < CH * IH * DLD; i += 256) dy1[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * IMG_PLANE; i += 256) imgp[i] = 0.f;  // halo stays zero for every image
   const int pair = threadIdx.x % PAIRS, rq = threadIdx.x / PAIRS;
   const int lco = pair / 4, wci = pair % 4;
   float wacc[NP][9], bacc[NP];
@@ -692,7 +711,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(int B, const float* __re
   const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     lds_barrier();
-    stage_image(img + (size_t)b * 4 * IPIX, imgp);
+    stage_image<false>(img + (size_t)b * 4 * IPIX, imgp);
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       if (q > 0) lds_barrier();
@@ -701,8 +720,9 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(int B, const float* __re
       for (int lc = 0; lc < CH; ++lc) {
         const int c = q * CH + lc;
         const size_t pi = ((size_t)b * C + c) * 256 + threadIdx.x;
-        const float* yb = y1 + (((size_t)b * C + c) * IH + 2 * py) * IH + 2 * px;
-        const float v0 = yb[0], v1 = yb[1], v2 = yb[IH], v3 = yb[IH + 1];
+        const float* yb = y1 + (((size_t)b * C + c) * IH + 2 * py) * Y1_LD + 2 * px;
+        const float2 ylo = *reinterpret_cast<const float2*>(yb), yhi = *reinterpret_cast<const float2*>(yb + Y1_LD);
+        const float v0 = ylo.x, v1 = ylo.y, v2 = yhi.x, v3 = yhi.y;
         const float g = G1c[pi];
         const int code = code1[pi];
         const float mean = stat1[c], inv = stat1[C + c], cs = coef1[c], m1 = coef1[C + c], m2 = coef1[2 * C + c];
@@ -716,7 +736,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(int B, const float* __re
       for (int idx = threadIdx.x; idx < CH * 65; idx += 256) {
         const int lc = idx / 65, e = idx % 65, c = q * CH + lc;
         const int y = e < 33 ? 32 : e - 33, x = e < 33 ? e : 32;
-        const float v = y1[(((size_t)b * C + c) * IH + y) * IH + x];
+        const float v = y1[(((size_t)b * C + c) * IH + y) * Y1_LD + x];
         dy1[(lc * IH + y) * DLD + x] = coef1[c] * (-coef1[C + c] - (v - stat1[c]) * stat1[C + c] * coef1[2 * C + c]);
       }
       lds_barrier();

@@ -581,7 +581,7 @@ class SceneAttentionFn(Function):
         img = img.contiguous()
         B, C = img.shape[0], c1w.shape[0]
         st = _s()
-        y1 = _empty(B, C, 33, 33, like=img)
+        y1 = _empty(B, C, 33, 36, like=img)  # raw conv1 output, rows padded to 36 floats (csrc/cnn.hip:Y1_LD)
         part = _empty(max(B, 1), 2 * C, like=img)
         lib.mggan_conv1_fwd(_p(img), B, C, _p(c1w), _p(c1b), _p(y1), _p(part), st)
         n_img = float(B)
