@@ -115,6 +115,102 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   }
 }
 
+// ---------------- conv1 on the matrix cores ----------------
+// Implicit GEMM over FLAT output positions p = y*36 + x (the padded row stride of y1 is also the row stride of
+// the zero-haloed LDS image, so the patch of position p for tap (ky,kx) sits at p + ky*36 + kx: one linear
+// address space, no div/mod in the loop).  Per 16-position tile: D(16 pos x 16 co) += A(16 pos x 4 k) B(4 k x 16 co)
+// for the 9 k-steps of K = 36 = (ci,ky,kx) on v_mfma_f32_16x16x4_f32 (exact f32).  B = the weights (9 registers
+// per lane for the whole image), A = one ds_read_b32 per k-step (16 consecutive floats per tap; the plane stride
+// 1274 == 26 mod 32 keeps the two taps of a half-wave on disjoint banks when the channel changes).  The D
+// fragment holds 4 consecutive positions of one channel per lane: one aligned 16-byte store.  The VALU kernel
+// above spends 3 of 4 VALU slots on operand shuffling (SQ_INSTS_VALU 5.9k per wave for 1.4k packed FMAs).
+#define C1_LD 36
+#define C1_PLANE 1274
+typedef float c1_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int C>
+__global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __restrict__ img, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, float* __restrict__ y1,
+                                                             float* __restrict__ part) {
+  constexpr int NPOS = IH * Y1_LD, NT = (NPOS + 15) / 16;  // 1188 flat positions, 75 tiles
+  constexpr int NPIX = 4 * IPIX, PER = (NPIX + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float imgp[4 * C1_PLANE];
+  __shared__ float red[4][2][16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fi = lane & 15, fk = lane >> 4;
+  {
+    const float* src = img + (size_t)b * NPIX;
+    float v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + 256 * u;
+      v[u] = src[e < NPIX ? e : 0];
+    }
+    for (int i = tid; i < 4 * C1_PLANE; i += 256) imgp[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + 256 * u;
+      if (e < NPIX) {
+        const int ci = e / IPIX, rem = e - ci * IPIX, y = rem / IH, x = rem - y * IH;
+        imgp[ci * C1_PLANE + (y + 1) * C1_LD + x + 1] = v[u];
+      }
+    }
+  }
+  float bw[9];
+  int offs[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) {
+    const int k = 4 * s + fk, ci = k / 9, t = k - ci * 9, ky = t / 3, kx = t - ky * 3;
+    bw[s] = fi < C ? W[fi * 36 + k] : 0.f;
+    offs[s] = ci * C1_PLANE + ky * C1_LD + kx + fi;
+  }
+  const float bv = fi < C ? bias[fi] : 0.f;
+  float sum = 0.f, sq = 0.f;
+  __syncthreads();
+  float* yout = y1 + ((size_t)b * C + fi) * NPOS + 4 * fk;
+#pragma unroll 1
+  for (int t = w; t < NT; t += 8) {  // two independent tiles per pass keep the matrix pipe fed
+    const int p0 = 16 * t, p1 = 16 * (t + 4);
+    const bool two = t + 4 < NT;
+    c1_f32x4 a0 = {bv, bv, bv, bv}, a1 = {bv, bv, bv, bv};
+    float x0[9], x1[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      x0[s] = imgp[p0 + offs[s]];
+      x1[s] = imgp[(two ? p1 : p0) + offs[s]];
+    }
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[s], bw[s], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[s], bw[s], a1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && !two) break;
+      const c1_f32x4 acc = h ? a1 : a0;
+      const int q = (h ? p1 : p0) + 4 * fk;  // first of this lane's 4 flat positions
+      if (fi < C && q < NPOS) {
+        *reinterpret_cast<float4*>(yout + (h ? p1 : p0)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        const int col = q % Y1_LD;  // multiple of 4: only col 32 has pad positions (r >= 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < IH) {
+            sum += acc[r];
+            sq = fmaf(acc[r], acc[r], sq);
+          }
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 16, 64); sq += __shfl_xor(sq, 16, 64);
+  sum += __shfl_xor(sum, 32, 64); sq += __shfl_xor(sq, 32, 64);
+  if (fk == 0) { red[w][0][fi] = sum; red[w][1][fi] = sq; }
+  __syncthreads();
+  if (tid < 2 * C) {
+    const int which = tid / C, c = tid - which * C;
+    part[(size_t)b * 2 * C + tid] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+  }
+}
+
 // sums[col] = sum_b part[b][col]   (f64 accumulation; one block per column)
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ part, int B, int W, double* sums) {
   __shared__ double red[256];
@@ -830,8 +926,8 @@ int mggan_conv1_fwd(const float* img, int B, int C, const float* W, const float*
   MG_CHECK_ARG(C == 8 || C == 16, "conv1_fwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(img && W && bias && y1 && part, "conv1_fwd: null pointer");
-  if (C == 16) hipLaunchKernelGGL((conv1_fwd_kernel<16>), dim3(B), dim3(256), 0, stream, img, W, bias, y1, part);
-  else hipLaunchKernelGGL((conv1_fwd_kernel<8>), dim3(B), dim3(256), 0, stream, img, W, bias, y1, part);
+  if (C == 16) hipLaunchKernelGGL((conv1_fwd_mfma_kernel<16>), dim3(B), dim3(256), 0, stream, img, W, bias, y1, part);
+  else hipLaunchKernelGGL((conv1_fwd_mfma_kernel<8>), dim3(B), dim3(256), 0, stream, img, W, bias, y1, part);
   MG_LAUNCH_CHECK("conv1_fwd");
   return MGGAN_OK;
 }
