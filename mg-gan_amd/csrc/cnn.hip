@@ -805,22 +805,63 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(int B, const float* __re
     for (int k = 0; k < 9; ++k) wacc[q][k] = 0.f;
   }
   const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
+  // Software pipeline: everything pass (b, q) needs from global memory (the raw conv1 outputs of the 2x2
+  // window of this lane's pooled cell, its gradient and argmax code for 8 channels, the 65 border positions,
+  // and for q == 0 the image) is requested BEFORE the product phase of the previous pass and lands in LDS
+  // after it: the loads fly under ~300 FMAs per lane instead of stalling the two resident workgroups.
+  constexpr int NPIX = 4 * IPIX, PER = (NPIX + 255) / 256, NBORD = (CH * 65 + 255) / 256;
+  float2 r_lo[CH], r_hi[CH];
+  float r_g[CH], r_b[NBORD], r_img[PER];
+  int r_code[CH];
+  auto fetch = [&](int b, int q, bool with_img) {
+#pragma unroll
+    for (int lc = 0; lc < CH; ++lc) {
+      const int c = q * CH + lc;
+      const size_t pi = ((size_t)b * C + c) * 256 + threadIdx.x;
+      const float* yb = y1 + (((size_t)b * C + c) * IH + 2 * py) * Y1_LD + 2 * px;
+      r_lo[lc] = *reinterpret_cast<const float2*>(yb);
+      r_hi[lc] = *reinterpret_cast<const float2*>(yb + Y1_LD);
+      r_g[lc] = G1c[pi];
+      r_code[lc] = code1[pi];
+    }
+#pragma unroll
+    for (int u = 0; u < NBORD; ++u) {
+      const int idx = threadIdx.x + 256 * u, ic = idx < CH * 65 ? idx : 0;
+      const int lc = ic / 65, e = ic - lc * 65, c = q * CH + lc;
+      const int y = e < 33 ? 32 : e - 33, x = e < 33 ? e : 32;
+      r_b[u] = y1[(((size_t)b * C + c) * IH + y) * Y1_LD + x];
+    }
+    if (with_img) {
+      const float* src = img + (size_t)b * NPIX;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        r_img[u] = src[e < NPIX ? e : 0];
+      }
+    }
+  };
+  if ((int)blockIdx.x < B) fetch(blockIdx.x, 0, true);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    lds_barrier();
-    stage_image<false>(img + (size_t)b * 4 * IPIX, imgp);
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      if (q > 0) lds_barrier();
+      lds_barrier();  // the previous product phase is done with dy1 (and, for q == 0, with the image)
+      if (q == 0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int e = threadIdx.x + 256 * u;
+          if (e < NPIX) {
+            const int ci = e / IPIX, rem = e - ci * IPIX, y = rem / IH, x = rem - y * IH;
+            imgp[ci * IMG_PLANE + (y + 1) * IMG_LD + x + 1] = r_img[u];
+          }
+        }
+      }
       // interior 32x32: one lane per pooled cell
-#pragma unroll 4
+#pragma unroll
       for (int lc = 0; lc < CH; ++lc) {
         const int c = q * CH + lc;
-        const size_t pi = ((size_t)b * C + c) * 256 + threadIdx.x;
-        const float* yb = y1 + (((size_t)b * C + c) * IH + 2 * py) * Y1_LD + 2 * px;
-        const float2 ylo = *reinterpret_cast<const float2*>(yb), yhi = *reinterpret_cast<const float2*>(yb + Y1_LD);
-        const float v0 = ylo.x, v1 = ylo.y, v2 = yhi.x, v3 = yhi.y;
-        const float g = G1c[pi];
-        const int code = code1[pi];
+        const float v0 = r_lo[lc].x, v1 = r_lo[lc].y, v2 = r_hi[lc].x, v3 = r_hi[lc].y;
+        const float g = r_g[lc];
+        const int code = r_code[lc];
         const float mean = stat1[c], inv = stat1[C + c], cs = coef1[c], m1 = coef1[C + c], m2 = coef1[2 * C + c];
         float* d = dy1 + (lc * IH + 2 * py) * DLD + 2 * px;
         d[0] = cs * ((code == 0 ? g : 0.f) - m1 - (v0 - mean) * inv * m2);
@@ -829,13 +870,21 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(int B, const float* __re
         d[DLD + 1] = cs * ((code == 3 ? g : 0.f) - m1 - (v3 - mean) * inv * m2);
       }
       // border row 32 / column 32 (never pooled: g = 0)
-      for (int idx = threadIdx.x; idx < CH * 65; idx += 256) {
-        const int lc = idx / 65, e = idx % 65, c = q * CH + lc;
-        const int y = e < 33 ? 32 : e - 33, x = e < 33 ? e : 32;
-        const float v = y1[(((size_t)b * C + c) * IH + y) * Y1_LD + x];
-        dy1[(lc * IH + y) * DLD + x] = coef1[c] * (-coef1[C + c] - (v - stat1[c]) * stat1[C + c] * coef1[2 * C + c]);
+#pragma unroll
+      for (int u = 0; u < NBORD; ++u) {
+        const int idx = threadIdx.x + 256 * u;
+        if (idx < CH * 65) {
+          const int lc = idx / 65, e = idx - lc * 65, c = q * CH + lc;
+          const int y = e < 33 ? 32 : e - 33, x = e < 33 ? e : 32;
+          dy1[(lc * IH + y) * DLD + x] = coef1[c] * (-coef1[C + c] - (r_b[u] - stat1[c]) * stat1[C + c] * coef1[2 * C + c]);
+        }
       }
       lds_barrier();
+      {  // next pass's operands: in flight during this pass's products
+        const bool last_q = q == NP - 1;
+        const int nb = last_q ? b + (int)gridDim.x : b, nq = last_q ? 0 : q + 1;
+        if (nb < B) fetch(nb, nq, last_q);
+      }
       const int yend = min(IH, (rq + 1) * RPQ);
       for (int y = rq * RPQ; y < yend; ++y) {
         float dy[DLD];

@@ -92,37 +92,47 @@ __global__ void ce_rows_kernel(int rows, int g, const float* __restrict__ logits
 }
 
 // ---- per-scene min-over-K L2 (train.py:58-75) -------------------------------------------
-// one wave per scene; lane k accumulates sum_ped sum_t |abs - gt|; first minimum wins.
-__global__ __launch_bounds__(64) void l2_scene_kernel(int S, int T, int K, int b, const int* __restrict__ scenes,
-                                                      const float* __restrict__ gen_abs, const float* __restrict__ gt,
-                                                      float* scene_loss, int* scene_arg) {
-  const int s = blockIdx.x, lane = threadIdx.x;
+// One 256-thread workgroup per scene: eight 32-lane groups take the samples k round-robin, the lanes of a
+// group take the scene's pedestrians (contiguous 8-byte reads), each lane sums its |abs - gt| over the T steps,
+// a fixed-order shuffle tree adds the pedestrians.  Wave 0 then takes the first minimum over k.
+#define L2_MAXK 256
+__global__ __launch_bounds__(256) void l2_scene_kernel(int S, int T, int K, int b, const int* __restrict__ scenes,
+                                                       const float* __restrict__ gen_abs, const float* __restrict__ gt,
+                                                       float* scene_loss, int* scene_arg) {
+  __shared__ float ksum[L2_MAXK];
+  const int s = blockIdx.x, grp = threadIdx.x >> 5, l = threadIdx.x & 31;
   const int p0 = scenes[2 * s], p1 = scenes[2 * s + 1];
-  float best = INFINITY;
-  int bestk = 0;
-  for (int k0 = 0; k0 < K; k0 += 64) {
-    const int k = k0 + lane;
-    float acc = INFINITY;
-    if (k < K) {
-      acc = 0.f;
-      for (int ped = p0; ped < p1; ++ped)
-        for (int t = 0; t < T; ++t) {
-          const float* a = gen_abs + (((size_t)t * K + k) * b + ped) * 2;
-          const float dx = a[0] - gt[((size_t)t * b + ped) * 2], dy = a[1] - gt[((size_t)t * b + ped) * 2 + 1];
-          acc += sqrtf(dx * dx + dy * dy);
-        }
-    }
-    float v = acc;
-    int vi = k;
+  for (int k = grp; k < K; k += 8) {
+    float acc = 0.f;
+    for (int ped = p0 + l; ped < p1; ped += 32)
+      for (int t = 0; t < T; ++t) {
+        const float2 a = *reinterpret_cast<const float2*>(gen_abs + (((size_t)t * K + k) * b + ped) * 2);
+        const float2 g = *reinterpret_cast<const float2*>(gt + ((size_t)t * b + ped) * 2);
+        const float dx = a.x - g.x, dy = a.y - g.y;
+        acc += sqrtf(dx * dx + dy * dy);
+      }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(v, o, 64);
-      const int oi = __shfl_xor(vi, o, 64);
-      if (ov < v || (ov == v && oi < vi)) { v = ov; vi = oi; }
-    }
-    if (v < best) { best = v; bestk = vi; }
+    for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (l == 0) ksum[k] = acc;
   }
-  if (lane == 0) { scene_loss[s] = best; scene_arg[s] = bestk; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    float best = INFINITY;
+    int bestk = 0;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      float v = k0 + lane < K ? ksum[k0 + lane] : INFINITY;
+      int vi = k0 + lane;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(vi, o, 64);
+        if (ov < v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+      }
+      if (v < best) { best = v; bestk = vi; }
+    }
+    if (lane == 0) { scene_loss[s] = best; scene_arg[s] = bestk; }
+  }
 }
 
 // gabs[t][k][ped] = scale * (abs-gt)/|abs-gt| if k == argmin(scene(ped)) else 0
@@ -482,7 +492,8 @@ int mggan_l2_min_scene(int S, int T, int K, int b, const int* scenes, const int*
                        hipStream_t stream) {
   if (S == 0) return MGGAN_OK;
   MG_CHECK_ARG(scenes && ped_scene && gen_abs && gt && scene_loss && scene_arg, "l2_min_scene: null pointer");
-  hipLaunchKernelGGL(l2_scene_kernel, dim3(S), dim3(64), 0, stream, S, T, K, b, scenes, gen_abs, gt, scene_loss,
+  MG_CHECK_ARG(K <= L2_MAXK, "l2_min_scene: %d samples per pedestrian not built (<= %d)", K, L2_MAXK);
+  hipLaunchKernelGGL(l2_scene_kernel, dim3(S), dim3(256), 0, stream, S, T, K, b, scenes, gen_abs, gt, scene_loss,
                      scene_arg);
   MG_LAUNCH_CHECK("l2_scene");
   if (gabs) {
