@@ -99,7 +99,7 @@ def join_side_stream():
 # the stream of its forward, so the backward pass inherits the same two-branch shape; inside a HIP-graph
 # capture the fork/join events become graph edges.  A branch ALWAYS starts by waiting for the main stream, and
 # every step ends joined, so memory freed by one stream is never re-used by the other before it is ordered.
-_BR = {"on": os.environ.get("MGGAN_BRANCH", "1") == "1", "stream": None, "dirty": False}
+_BR = {"on": os.environ.get("MGGAN_BRANCH", "1") == "1", "streams": {}, "dirty": set()}
 
 
 def enable_branches(on=True):
@@ -108,19 +108,23 @@ def enable_branches(on=True):
 
 
 class branch:
-    """Context: launches inside go to the branch stream (no-op when disabled or already on it)."""
+    """Context: launches inside go to branch stream `which` (no-op when disabled or already on a branch)."""
+
+    def __init__(self, which=0):
+        self.which = which
 
     def __enter__(self):
         self.ctx = None
         if not _BR["on"]:
             return self
-        if _BR["stream"] is None:
-            _BR["stream"] = torch.cuda.Stream()
-        side, cur = _BR["stream"], torch.cuda.current_stream()
-        if cur == side:
+        side = _BR["streams"].get(self.which)
+        if side is None:
+            side = _BR["streams"][self.which] = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        if any(cur == s for s in _BR["streams"].values()):
             return self
         side.wait_stream(cur)
-        _BR["dirty"] = True
+        _BR["dirty"].add(self.which)
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         return self
@@ -131,20 +135,20 @@ class branch:
         return False
 
 
-def join_branch(*tensors, force=False):
-    """The current stream waits for the branch stream; `tensors` (branch results consumed from here on) are
-    registered with the consuming stream so the allocator keeps them until that stream is done with them."""
-    side = _BR["stream"]
-    if side is None or not (_BR["dirty"] or force):
-        return
+def join_branch(*tensors, which=None, force=False):
+    """The current stream waits for branch stream `which` (None: all of them); `tensors` (branch results consumed
+    from here on) are registered with the consuming stream so the allocator keeps them until it is done."""
     cur = torch.cuda.current_stream()
-    if cur == side:
-        return
-    cur.wait_stream(side)
+    for w, side in list(_BR["streams"].items()):
+        if which is not None and w != which:
+            continue
+        if not (w in _BR["dirty"] or force) or cur == side:
+            continue
+        cur.wait_stream(side)
+        _BR["dirty"].discard(w)
     for t in tensors:
-        if t is not None:
+        if t is not None and torch.is_tensor(t):
             t.record_stream(cur)
-    _BR["dirty"] = False
 
 
 class _ReduceDesc(ctypes.Structure):

@@ -112,28 +112,31 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
     def discriminator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None,
                            shared=None):
         m = self._m
+        g_trunk = None if shared is None else shared.get("g_trunk")
+        # the fake trajectories (no-grad generator call: PM-network, sampling, row bucketing, rollout) depend on
+        # nothing the real pass computes: they are produced on a branch stream beside it.  (The label scalars
+        # come from the numpy generator, noise and sampling from torch's: reordering the two is seed-neutral.)
+        with HF.branch(1), torch.no_grad():
+            noise = self.rng.noise(1, self.config.noise_dim, sub_batches, self.device)
+            gen_out, _, gen_labels_gt = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
+                                               num_samples=1, mask=loss_mask,
+                                               trunk=None if g_trunk is None else tuple(t.detach() for t in g_trunk))
+            rows_d = getattr(self.G, "last_rows", None)
         # history LSTM + scene CNN of D are identical in the real and the fake pass: run them once
         ctx = self.D.history_context(in_dxdy, img, passes=2) if (loss_mask is None and self.share_context) else None
-        g_trunk = None if shared is None else shared.get("g_trunk")
         real_result = self.D(in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, img=img, mask=loss_mask, context=ctx)
         if isinstance(real_result, tuple):
             real_result = real_result[0]
         n_real = self._global(real_result.numel())
         label_real, _ = self.rng.labels()
         real_loss = HF.BceMeanFn.apply(real_result.t().reshape(-1), label_real, None, None, m[M_REAL:M_REAL + 1], n_real)
-
-        noise = self.rng.noise(1, self.config.noise_dim, sub_batches, self.device)
-        with torch.no_grad():
-            gen_out, _, gen_labels_gt = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
-                                               num_samples=1, mask=loss_mask,
-                                               trunk=None if g_trunk is None else tuple(t.detach() for t in g_trunk))
+        HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, None if rows_d is None else rows_d.row_gen_pos, which=1)
         disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask, context=ctx)
         losses = [real_loss]
         items = []
         if self.gan_type == "mgan":
             disc_out, branch_out = disc_out
             rows = branch_out.transpose(0, 1).reshape(-1, branch_out.shape[-1])
-            rows_d = getattr(self.G, "last_rows", None)
             target = rows_d.row_gen_pos if rows_d is not None and rows_d.R == gen_labels_gt.numel() \
                 else gen_labels_gt.t().reshape(-1).to(torch.int32)
             ce_loss = HF.CeMeanFn.apply(rows, target, None, m[M_CE_D:M_CE_D + 1], self._global(rows.shape[0]))
