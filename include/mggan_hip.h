@@ -200,12 +200,14 @@ int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, i
                       int* row_pos, int* inv, int* seg, int* row_gen_pos, int* blk_cnt, mggan_stream_t stream);
 int mggan_scale(float* x, long n, const float* scalar, mggan_stream_t stream);
 /* classifier input of the discriminator (discriminators.py:141,185,196): rows k*b+ped =
- * [soc (sample block 0 only) | in_enc | pred_enc | scene], and its adjoint */
-int mggan_d_assemble_fwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, const float* soc0,
+ * [soc | in_enc | pred_enc | scene], and its adjoint.  soc_all = 0: social features exist for sample block 0 only
+ * (soc0 has b rows; the list-repetition quirk of one K-sample call); soc_all = 1: soc0 has K*b rows
+ * (K independent single-sample calls batched into one pass, e.g. the real and the fake pass of a D step). */
+int mggan_d_assemble_fwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, int soc_all, const float* soc0,
                          const float* in_enc, const float* pred_enc, const float* scene, float* X,
                          mggan_stream_t stream);
-int mggan_d_assemble_bwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, const float* dX, float* dsoc0,
-                         float* din_enc, float* dpred_enc, float* dscene, mggan_stream_t stream);
+int mggan_d_assemble_bwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, int soc_all, const float* dX,
+                         float* dsoc0, float* din_enc, float* dpred_enc, float* dscene, mggan_stream_t stream);
 int mggan_ce_rows(int rows, int g, const float* logits, int ld, const int* target, const float* inv_count, float scale,
                   float* loss_rows, float* dlogits, int ldd, mggan_stream_t stream);
 int mggan_l2_min_scene(int S, int T, int K, int b, const int* scenes, const int* ped_scene, const float* gen_abs,

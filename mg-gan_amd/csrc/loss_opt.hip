@@ -33,9 +33,9 @@ __global__ void scale_kernel(float* x, long n, const float* __restrict__ s) {
 }
 
 // X[k*b+ped] = [ soc0[ped] if k==0 else 0 | in_enc[ped] | pred_enc[k*b+ped] | scene[ped] ]
-__global__ void d_assemble_kernel(int b, int K, int ws, int wi, int wp, int wc, const float* __restrict__ soc0,
-                                  const float* __restrict__ in_enc, const float* __restrict__ pred_enc,
-                                  const float* __restrict__ scene, float* X) {
+__global__ void d_assemble_kernel(int b, int K, int ws, int wi, int wp, int wc, int soc_all,
+                                  const float* __restrict__ soc0, const float* __restrict__ in_enc,
+                                  const float* __restrict__ pred_enc, const float* __restrict__ scene, float* X) {
   const int W = ws + wi + wp + wc;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)K * b * W) return;
@@ -43,7 +43,7 @@ __global__ void d_assemble_kernel(int b, int K, int ws, int wi, int wp, int wc, 
   const long r = i / W;
   const int ped = (int)(r % b), k = (int)(r / b);
   float v;
-  if (c < ws) v = k == 0 ? soc0[(size_t)ped * ws + c] : 0.f;
+  if (c < ws) v = soc_all ? soc0[(size_t)r * ws + c] : (k == 0 ? soc0[(size_t)ped * ws + c] : 0.f);
   else if (c < ws + wi) v = in_enc[(size_t)ped * wi + (c - ws)];
   else if (c < ws + wi + wp) v = pred_enc[(size_t)r * wp + (c - ws - wi)];
   else v = scene[(size_t)ped * wc + (c - ws - wi - wp)];
@@ -51,14 +51,17 @@ __global__ void d_assemble_kernel(int b, int K, int ws, int wi, int wp, int wc, 
 }
 
 // adjoint: dsoc0[ped] = dX[ped][:ws]; din_enc[ped] = sum_k dX[k*b+ped][ws:ws+wi]; dpred = copy; dscene = sum_k
-__global__ void d_assemble_bwd_kernel(int b, int K, int ws, int wi, int wp, int wc, const float* __restrict__ dX,
-                                      float* dsoc0, float* din_enc, float* dpred_enc, float* dscene) {
+__global__ void d_assemble_bwd_kernel(int b, int K, int ws, int wi, int wp, int wc, int soc_all,
+                                      const float* __restrict__ dX, float* dsoc0, float* din_enc, float* dpred_enc,
+                                      float* dscene) {
   const int W = ws + wi + wp + wc;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)b * W) return;
   const int c = (int)(i % W), ped = (int)(i / W);
   if (c < ws) {
-    if (dsoc0) dsoc0[(size_t)ped * ws + c] = dX[(size_t)ped * W + c];
+    if (dsoc0)
+      for (int k = 0; k < (soc_all ? K : 1); ++k)
+        dsoc0[((size_t)k * b + ped) * ws + c] = dX[((size_t)k * b + ped) * W + c];
   } else if (c >= ws + wi && c < ws + wi + wp) {
     if (dpred_enc)
       for (int k = 0; k < K; ++k) dpred_enc[((size_t)k * b + ped) * wp + (c - ws - wi)] = dX[((size_t)k * b + ped) * W + c];
@@ -454,25 +457,25 @@ int mggan_scale(float* x, long n, const float* scalar, hipStream_t stream) {
   return MGGAN_OK;
 }
 
-int mggan_d_assemble_fwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, const float* soc0,
+int mggan_d_assemble_fwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, int soc_all, const float* soc0,
                          const float* in_enc, const float* pred_enc, const float* scene, float* X,
                          hipStream_t stream) {
   MG_CHECK_ARG(soc0 && in_enc && pred_enc && scene && X, "d_assemble_fwd: null pointer");
   const long n = (long)K * b * (w_soc + w_in + w_pred + w_scene);
   if (n == 0) return MGGAN_OK;
   hipLaunchKernelGGL(d_assemble_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, w_soc, w_in, w_pred, w_scene,
-                     soc0, in_enc, pred_enc, scene, X);
+                     soc_all, soc0, in_enc, pred_enc, scene, X);
   MG_LAUNCH_CHECK("d_assemble_fwd");
   return MGGAN_OK;
 }
 
-int mggan_d_assemble_bwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, const float* dX, float* dsoc0,
-                         float* din_enc, float* dpred_enc, float* dscene, hipStream_t stream) {
+int mggan_d_assemble_bwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, int soc_all, const float* dX,
+                         float* dsoc0, float* din_enc, float* dpred_enc, float* dscene, hipStream_t stream) {
   MG_CHECK_ARG(dX, "d_assemble_bwd: null pointer");
   const long n = (long)b * (w_soc + w_in + w_pred + w_scene);
   if (n == 0) return MGGAN_OK;
   hipLaunchKernelGGL(d_assemble_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, w_soc, w_in, w_pred, w_scene,
-                     dX, dsoc0, din_enc, dpred_enc, dscene);
+                     soc_all, dX, dsoc0, din_enc, dpred_enc, dscene);
   MG_LAUNCH_CHECK("d_assemble_bwd");
   return MGGAN_OK;
 }

@@ -844,29 +844,34 @@ class DecoderRolloutFn(Function):
 
 # ------------------------------------------------------------------------------------------
 class DAssembleFn(Function):
-    """classifier_inp rows k*b+ped = [soc (block 0 only) | in_enc | pred_enc | scene]
-    (discriminators.py:141,179-196; SURVEY A.1: list-repeat of seq_start_end leaves the social
-    features of sample blocks >= 1 at zero)."""
+    """classifier_inp rows k*b+ped = [soc | in_enc | pred_enc | scene]
+    (discriminators.py:141,179-196).  soc_all=False: soc0 (b rows) belongs to sample block 0 only and the other
+    blocks get zeros (list-repeat of seq_start_end); soc_all=True: soc0 has K*b rows (K independent
+    single-sample passes batched into one)."""
 
     @staticmethod
-    def forward(ctx, soc0, in_enc, pred_enc, scene, K):
+    def forward(ctx, soc0, in_enc, pred_enc, scene, K, soc_all=False):
         soc0, in_enc, pred_enc, scene = (t.contiguous() for t in (soc0, in_enc, pred_enc, scene))
         b = in_enc.shape[0]
         ws, wi, wp, wc = soc0.shape[1], in_enc.shape[1], pred_enc.shape[1], scene.shape[1]
+        assert soc0.shape[0] == (K * b if soc_all else b), (soc0.shape, K, b, soc_all)
         X = _empty(K * b, ws + wi + wp + wc, like=in_enc)
-        lib.mggan_d_assemble_fwd(b, K, ws, wi, wp, wc, _p(soc0), _p(in_enc), _p(pred_enc), _p(scene), _p(X), _s())
-        ctx.dims = (b, K, ws, wi, wp, wc)
+        lib.mggan_d_assemble_fwd(b, K, ws, wi, wp, wc, 1 if soc_all else 0, _p(soc0), _p(in_enc), _p(pred_enc), _p(scene),
+                                 _p(X), _s())
+        ctx.dims = (b, K, ws, wi, wp, wc, soc_all)
         return X
 
     @staticmethod
     def backward(ctx, dX):
-        b, K, ws, wi, wp, wc = ctx.dims
+        b, K, ws, wi, wp, wc, soc_all = ctx.dims
         dX = dX.contiguous()
         need = ctx.needs_input_grad
         mk = lambda n, r, c: torch.empty(r, c, dtype=F32, device=dX.device) if n else None
-        dsoc, din, dpred, dsc = mk(need[0], b, ws), mk(need[1], b, wi), mk(need[2], K * b, wp), mk(need[3], b, wc)
-        lib.mggan_d_assemble_bwd(b, K, ws, wi, wp, wc, _p(dX), _p(dsoc), _p(din), _p(dpred), _p(dsc), _s())
-        return dsoc, din, dpred, dsc, None
+        dsoc, din = mk(need[0], K * b if soc_all else b, ws), mk(need[1], b, wi)
+        dpred, dsc = mk(need[2], K * b, wp), mk(need[3], b, wc)
+        lib.mggan_d_assemble_bwd(b, K, ws, wi, wp, wc, 1 if soc_all else 0, _p(dX), _p(dsoc), _p(din), _p(dpred), _p(dsc),
+                                 _s())
+        return dsoc, din, dpred, dsc, None, None
 
 
 # ---------------------------------------- losses -------------------------------------------

@@ -80,6 +80,38 @@ class MultiDiscriminatorTrajectory(FlatModule):
         pred_enc = HF.mlp(x, [(pe[0], HF.ACT_LEAKY, 0.2), (pe[2], HF.ACT_NONE, 0.0)])
         return in_enc, pred_enc
 
+    def forward_pair(self, in_xy, in_dxdy, real_dxdy, fake_dxdy, seq_start_end, context):
+        """The real and the fake single-sample pass of one discriminator step as ONE pass over 2b rows (rows
+        [0,b) = real, [b,2b) = fake).  Every operator after the shared history context is row-wise or per
+        scene, so the results equal two forward() calls; the latency-bound kernel chain runs once instead of twice.
+        -> (out_real (b,1), out_fake (b,1), branch_fake (b,1,g) | None)"""
+        self.ensure_flat()
+        in_enc, scene = context
+        b = in_xy.size(1)
+        pe = self.pred_encoder
+        x = torch.cat([real_dxdy.reshape(real_dxdy.shape[0], b, 2).permute(1, 0, 2).reshape(b, -1),
+                       fake_dxdy.reshape(fake_dxdy.shape[0], b, 2).permute(1, 0, 2).reshape(b, -1)], 0)
+        pred_enc = HF.mlp(x, [(pe[0], HF.ACT_LEAKY, 0.2), (pe[2], HF.ACT_NONE, 0.0)])
+        enc0 = torch.cat([in_enc.repeat(2, 1), pred_enc], dim=1)
+        cache = self.__dict__.setdefault("_pair_scenes", {})
+        hit = cache.get(id(seq_start_end))
+        if hit is None or hit[0] is not seq_start_end:
+            if len(cache) > 16:
+                cache.clear()
+            hit = (seq_start_end, [[int(s), int(e)] for s, e in seq_start_end] +
+                   [[int(s) + b, int(e) + b] for s, e in seq_start_end])
+            cache[id(seq_start_end)] = hit
+        soc = self.social(in_xy[-1:].repeat(1, 2, 1), in_dxdy[-1:].repeat(1, 2, 1), enc0, hit[1])
+        HF.join_branch(scene)
+        classifier_inp = HF.DAssembleFn.apply(soc, in_enc, pred_enc, scene, 2, True)
+        d = self.discs[0]
+        y = HF.mlp(classifier_inp, [(d[0], HF.ACT_LEAKY, 0.2), (d[2], HF.ACT_SIGMOID_EPS, 0.0)])
+        branch = None
+        if self.gan_type == "mgan":
+            r = self.gen_id_reconstructor
+            branch = HF.mlp(classifier_inp[b:], [(r[0], HF.ACT_LEAKY, 0.2), (r[2], HF.ACT_NONE, 0.0)]).reshape(b, 1, -1)
+        return y[:b], y[b:], branch
+
     def forward(self, in_xy, in_dxdy, pred_xy, pred_dxdy, seq_start_end, return_all=False, img=None, mask=None,
                 context=None):
         """Returns output (b_m, K) and, for gan_type 'mgan', branch_out (b_m, K, num_gens)."""

@@ -124,14 +124,23 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             rows_d = getattr(self.G, "last_rows", None)
         # history LSTM + scene CNN of D are identical in the real and the fake pass: run them once
         ctx = self.D.history_context(in_dxdy, img, passes=2) if (loss_mask is None and self.share_context) else None
-        real_result = self.D(in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, img=img, mask=loss_mask, context=ctx)
-        if isinstance(real_result, tuple):
-            real_result = real_result[0]
+        pair = ctx is not None and getattr(self, "pair_passes", True)
+        if pair:
+            # real and fake pass batched into one 2b-row pass (same results: every operator is row-wise / per scene)
+            HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, None if rows_d is None else rows_d.row_gen_pos, which=1)
+            real_result, disc_out, branch_out = self.D.forward_pair(in_xy, in_dxdy, gt_dxdy, gen_out.rel, sub_batches, ctx)
+            if self.gan_type == "mgan":
+                disc_out = (disc_out, branch_out)
+        else:
+            real_result = self.D(in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, img=img, mask=loss_mask, context=ctx)
+            if isinstance(real_result, tuple):
+                real_result = real_result[0]
         n_real = self._global(real_result.numel())
         label_real, _ = self.rng.labels()
         real_loss = HF.BceMeanFn.apply(real_result.t().reshape(-1), label_real, None, None, m[M_REAL:M_REAL + 1], n_real)
-        HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, None if rows_d is None else rows_d.row_gen_pos, which=1)
-        disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask, context=ctx)
+        if not pair:
+            HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, None if rows_d is None else rows_d.row_gen_pos, which=1)
+            disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask, context=ctx)
         losses = [real_loss]
         items = []
         if self.gan_type == "mgan":
