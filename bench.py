@@ -40,12 +40,15 @@ def kernel_of(name, a):
         "mggan_wgrad": "gemm_kernel<true,true,false>",
         "mggan_linear_fwd": "gemm_kernel<false,false,false>",
         "mggan_linear_bwd_data": "gemm_kernel<false,true,false>",
-        "mggan_conv2_bwd": "conv2_bwd_mfma_kernel",
-        "mggan_mlp_chain": "mlp_chain_kernel",
+        "mggan_mlp_chain": "mlp_chain_kernel<2>",  # 32-row tiles: the trainer only fuses stacks below 8192 rows
     }
     if name in fixed:
         return fixed[name]
-    if name in ("mggan_conv1_bwd", "mggan_conv1_fwd", "mggan_conv2_fwd"):
+    if name == "mggan_conv1_fwd":
+        return "conv1_fwd_mfma_kernel<{}>".format(a[2])
+    if name == "mggan_conv2_bwd":
+        return "conv2_bwd_mfma_kernel" if a[2] == 16 else "conv2_bwd_kernel<8>"
+    if name in ("mggan_conv1_bwd", "mggan_conv2_fwd"):
         return "{}_kernel<{}>".format(name[len("mggan_"):], a[2])
     return name
 
@@ -241,9 +244,16 @@ def main():
     tr.flush_metrics()
     trace = stop_trace()
     rows = []
-    for name, (calls, ms, arglist) in trace.items():
-        fl = sum(flops_of(name, a) for a in arglist)
-        rows.append((ms / n_prof, name, calls // n_prof, fl / n_prof, kernel_of(name, arglist[0])))
+    for name, (calls, ms_list, arglist) in trace.items():
+        # one row per HIP kernel: an entry such as mggan_conv1_bwd launches a different template per channel count
+        by_kernel = {}
+        for a, ms in zip(arglist, ms_list):
+            r = by_kernel.setdefault(kernel_of(name, a), [0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += ms
+            r[2] += flops_of(name, a)
+        for sym, (c, ms, fl) in by_kernel.items():
+            rows.append((ms / n_prof, name, c // n_prof, fl / n_prof, sym))
     rows.sort(reverse=True)
     gpu_ms = sum(r[0] for r in rows)
     total_flops = sum(r[3] for r in rows)

@@ -118,7 +118,7 @@ def start_trace():
 
 
 def stop_trace():
-    """-> {entry: (calls, total_ms, [args...])}"""
+    """-> {entry: (calls, [ms per call], [args per call])}"""
     import torch
 
     l = load()
@@ -126,8 +126,8 @@ def stop_trace():
     torch.cuda.synchronize()
     out = {}
     for name, args, e0, e1 in tr or []:
-        c, t, a = out.get(name, (0, 0.0, []))
-        out[name] = (c + 1, t + e0.elapsed_time(e1), a + [args])
+        c, t, a = out.get(name, (0, [], []))
+        out[name] = (c + 1, t + [e0.elapsed_time(e1)], a + [args])
     return out
 
 

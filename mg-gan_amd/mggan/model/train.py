@@ -6,6 +6,8 @@
 import os
 import random
 import sys
+from functools import partial
+from math import ceil
 from collections import defaultdict
 from pathlib import Path
 
@@ -22,7 +24,8 @@ from mggan.hip.lib import lib
 from mggan.logging import Experiment
 from mggan.model.config import get_parser
 from mggan.model.model_factory import construct_model
-from mggan.utils import to_numpy
+from mggan.utils import (expected_sample_idxs, get_selection_indices, thresholded_generators, to_numpy,
+                         uniform_sample_idxs)
 
 # slots of the device-side metric buffer (one D2H copy per step instead of one .item() per metric)
 M_REAL, M_FAKE, M_CE_D, M_L2, M_ADV, M_CLF, M_PM, M_PROBS = 0, 1, 2, 3, 4, 5, 6, 8
@@ -250,9 +253,91 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         assert preds.abs.shape[1] == num
         return preds.abs, preds.rel, to_numpy(probs), to_numpy(gen_idxs)
 
+    # The strategies below run every generator (`all_gen_out=True`, kernels of the hot path in eval mode) and
+    # then pick `num` of the (noise sample, generator) pairs per pedestrian; the picking rules are host logic in
+    # mggan/utils.py, the picking itself is one gather on the device.
+    def _all_generators(self, in_dxdy, in_xy, sub_batches, img, n_samples, noise, mask):
+        self.G.eval()
+        with torch.no_grad():
+            preds, logits, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=True, img=img,
+                                             num_samples=n_samples, mask=mask)
+            return preds, torch.softmax(logits, 1), gen_idxs
+
+    @staticmethod
+    def _pick(preds, gen, slot):
+        """preds.abs/.rel (T, n, g, b, 2); gen/slot (b, num) -> two tensors (T, num, b, 2)."""
+        dev = preds.abs.device
+        gen, slot = gen.to(dev), slot.to(dev)
+        ped = torch.arange(gen.shape[0], device=dev)[:, None]
+        return (preds.abs[:, slot, gen, ped].transpose(1, 2).contiguous(),
+                preds.rel[:, slot, gen, ped].transpose(1, 2).contiguous())
+
+    def predict_expected(self, in_dxdy, in_xy, sub_batches, img=None, num=20, noise=None, mask=None):
+        """Number of predictions per generator proportional to the PM-network probability (train.py:291-352)."""
+        preds, probs, _ = self._all_generators(in_dxdy, in_xy, sub_batches, img, num, noise, mask)
+        probs = to_numpy(probs)
+        gen = torch.from_numpy(expected_sample_idxs(probs, num))
+        out_xy, out_dxdy = self._pick(preds, gen, get_selection_indices(gen))
+        return out_xy, out_dxdy, probs, to_numpy(gen)
+
+    def predict_uniform(self, in_dxdy, in_xy, sub_batches, img=None, num=20, noise=None, eps=0.0, mask=None):
+        """Generators over the probability threshold, best first, in turn (train.py:354-408)."""
+        preds, probs, _ = self._all_generators(in_dxdy, in_xy, sub_batches, img, num * self.G.n_gs, noise, mask)
+        gen, slot = uniform_sample_idxs(probs, eps, num)
+        out_xy, out_dxdy = self._pick(preds, gen, slot)
+        return out_xy, out_dxdy, to_numpy(probs), to_numpy(gen)
+
+    def predict_smart_sampling(self, in_dxdy, in_xy, sub_batches, img=None, num=20, noise=None, eps=0.0, mask=None):
+        """Uniform sampling among the generators over the threshold (train.py:410-461)."""
+        preds, probs, _ = self._all_generators(in_dxdy, in_xy, sub_batches, img, num * self.G.n_gs, noise, mask)
+        over = thresholded_generators(probs, eps).float()
+        gen = self.rng.sample_generators(torch.log(over), num).cpu()  # Categorical(probs=over).sample((num,)).T
+        out_xy, out_dxdy = self._pick(preds, gen, get_selection_indices(gen))
+        return out_xy, out_dxdy, to_numpy(probs), to_numpy(gen)
+
+    def predict_rejection(self, in_dxdy, in_xy, sub_batches, img=None, num=20, noise=None, sigma=1e-3, N=10,
+                          truncation_ratio=0.7, debug=False, mask=None):
+        """Keep the `num` samples with the smallest estimated Jacobian norm |dG/dz| (train.py:463-545,
+        'Learning disconnected manifolds: no GAN's land'); single generator only."""
+        assert self.config.num_gens == 1, "Only implemented for single generator"
+        assert 0.0 < truncation_ratio <= 1.0
+        b = in_xy.shape[1]
+        total = num + ceil((1 - truncation_ratio) * num)
+        if noise is None:
+            noise = self.rng.noise(total, self.config.noise_dim, sub_batches, self.device)
+        noise = noise.to(self.device)
+        preds, probs, gen_idxs = self._all_generators(in_dxdy, in_xy, sub_batches, img, total, noise, mask)
+        vec = preds.abs.permute(3, 1, 2, 0, 4).reshape(b, total, -1)
+        jac = torch.zeros(b, total, device=self.device)
+        for _ in range(N):
+            eps_i = self.rng.randn(total, b, self.config.noise_dim).to(self.device) * sigma ** 2
+            preds_eps, _, _ = self._all_generators(in_dxdy, in_xy, sub_batches, img, total, noise + eps_i, mask)
+            vec_eps = preds_eps.abs.permute(3, 1, 2, 0, 4).reshape(b, total, -1)
+            jac += ((vec_eps - vec) ** 2).sum(-1) / sigma ** 2
+        keep = torch.sort(jac / N, dim=1)[1][:, :num]
+        gen_idxs = gen_idxs.to(self.device)
+        if debug:
+            gen_idxs = torch.ones_like(gen_idxs)
+            gen_idxs[torch.arange(b, device=self.device)[:, None], keep] = 0
+            return preds.abs.squeeze(2), preds.rel.squeeze(2), to_numpy(probs), to_numpy(gen_idxs)
+        out_xy, out_dxdy = self._pick(preds, torch.zeros_like(keep), keep)
+        return out_xy, out_dxdy, to_numpy(probs), to_numpy(gen_idxs[torch.arange(b, device=self.device)[:, None], keep])
+
     def get_predict_func(self, strategy):
-        if strategy != "sampling":
-            raise NotImplementedError("only the 'sampling' strategy (predict) is on the hot path (SURVEY f1)")
+        assert strategy in ("uniform_expected", "sampling", "expected", "rejection", "smart_expected", "smart_sampling",
+                            "uniform_sampling")
+        if strategy == "expected":
+            return self.predict_expected
+        if strategy == "rejection":
+            return self.predict_rejection
+        if strategy == "uniform_expected":
+            return self.predict_uniform
+        if strategy == "smart_expected":
+            return partial(self.predict_uniform, eps=1.0 / self.G.n_gs)
+        if strategy == "smart_sampling":
+            return partial(self.predict_smart_sampling, eps=1.0 / self.G.n_gs ** 2)
+        if strategy == "uniform_sampling":
+            return partial(self.predict_smart_sampling, eps=0.0)
         return self.predict
 
     def get_predictions(self, loader, num_preds=20, strategy="sampling"):

@@ -22,6 +22,9 @@ class HostRNG:
     def noise(self, num_samples, dim, sub_batches, device):
         return torch.stack([get_global_noise(dim, sub_batches, "gaussian") for _ in range(num_samples)]).to(device)
 
+    def randn(self, *shape):
+        return torch.randn(*shape)
+
     def sample_generators(self, logits, num_samples):
         """Categorical(logits=...).sample((K,)).T on the CPU generator (standard.py:223-224)."""
         lg = logits.detach().float().cpu()
@@ -56,6 +59,9 @@ class DeviceRNG:
         per_scene = torch.randn(num_samples, len(sub_batches), dim, device=device)
         return per_scene[:, lens[1]]  # one draw per scene, repeated for its pedestrians (utils.py:160-165)
 
+    def randn(self, *shape):
+        return torch.randn(*shape, device="cuda")
+
     def sample_generators(self, logits, num_samples):
         """Inverse-CDF categorical sampling in one HIP launch (torch.multinomial costs ~12 tiny kernels)."""
         from mggan.hip.lib import lib
@@ -84,6 +90,9 @@ class ReplayRNG:
         n = self._noise.pop(0)
         assert n.shape[0] == num_samples and n.shape[-1] == dim, (n.shape, num_samples, dim)
         return n.to(device)
+
+    def randn(self, *shape):
+        return torch.randn(*shape)
 
     def sample_generators(self, logits, num_samples):
         idx = self._idx.pop(0)

@@ -70,3 +70,55 @@ def get_selection_indices(sampled_gen_idxs):
     same = idx[:, :, None] == idx[:, None, :]
     lower = torch.tril(torch.ones(idx.shape[1], idx.shape[1], dtype=torch.bool, device=idx.device), -1)
     return (same & lower[None]).sum(-1)
+
+
+# ---- generator-selection rules of the prediction strategies (model/train.py:291-470 of the reference) ----
+def expected_sample_idxs(probs, num):
+    """'expected' strategy (train.py:301-338): every generator gets round(p * num) of the `num` predictions, the
+    rounding remainder is handed out (or taken back) one by one in descending order of the counts, and the
+    predictions are listed round-robin over that order.  probs (b, g) numpy -> (b, num) int64 generator ids."""
+    probs = np.asarray(probs)
+    expected = np.round(probs * num).astype(int)
+    order = np.argsort(-expected, axis=-1)
+    missing = num - expected.sum(1)
+    for r, miss in enumerate(missing):
+        n = abs(int(miss))
+        uniq, counts = np.unique(np.tile(order[r], n)[:n], return_counts=True)
+        expected[r, uniq] += np.sign(miss) * counts
+    assert (expected.sum(1) == num).all()
+    out = np.zeros((probs.shape[0], num), dtype=np.int64)
+    for r in range(probs.shape[0]):
+        left, ids = expected[r].copy(), []
+        for _ in range(num):
+            for g in order[r]:
+                if left[g] > 0:
+                    ids.append(g)
+                    left[g] -= 1
+        out[r] = ids[:num]
+    return out
+
+
+def thresholded_generators(probs, eps):
+    """Generators whose probability exceeds eps, per pedestrian; nobody over the threshold -> everybody
+    (train.py:372-376,430-433).  probs (b, g) tensor -> bool (b, g)."""
+    over = probs > eps
+    over[over.sum(1) < 1] = True
+    return over
+
+
+def uniform_sample_idxs(probs, eps, num):
+    """'uniform_expected' / 'smart_expected' (train.py:378-399): the generators over the threshold, in descending
+    order of probability, repeated until `num` predictions are listed.  -> (gen (b, num), slot (b, num)) int64:
+    prediction j of pedestrian r is generator gen[r, j] run on noise sample slot[r, j]."""
+    over = thresholded_generators(probs, eps)
+    b, g = probs.shape
+    gen = torch.zeros(b, num, dtype=torch.int64)
+    slot = torch.zeros(b, num, dtype=torch.int64)
+    ids = torch.arange(g)
+    for r in range(b):
+        sel = over[r].cpu()
+        order = ids[sel][torch.argsort(-probs[r].cpu()[sel])]
+        m = order.numel()
+        j = torch.arange(num)
+        gen[r], slot[r] = order[j % m], j // m
+    return gen, slot
