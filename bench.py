@@ -287,8 +287,10 @@ def main():
             "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "{} scenes x {} peds per GPU, num_gens={}, num_samples=20, D+G+PM steps "
-                                   "(BASELINE configs[1])".format(args.scenes, args.peds, args.num_gens),
+            "config": {"workload": "{} scenes x {} peds per GPU, num_gens={}, num_samples=20, D+G+PM steps ({})".format(
+                           args.scenes, args.peds, args.num_gens,
+                           {(64, 20, 4): "BASELINE configs[1]", (256, 32, 8): "BASELINE configs[2]"}.get(
+                               (args.scenes, args.peds, args.num_gens), "custom shape")),
                        "b_per_gpu": b, "parallelism": "dp{}".format(world), "rng": args.rng,
                        "launch": ("eager" if not use_graph else "hipGraph replay of the whole iteration" if world == 1
                                   else "{} hipGraph segments per iteration, RCCL collectives between them".format(
