@@ -53,12 +53,6 @@ class MultiGeneratorGAN(abc.ABC):
         self.G.rng = self.rng
         self.dist = DistContext()
         self.dist.attach(self.G, self.D)
-        if self.dist.enabled:
-            # a collective inside a branch (BatchNorm statistics) would cut a graph capture while the branch
-            # stream is still forked: sharded runs keep everything on one stream
-            from mggan.hip import functions as HF
-
-            HF.enable_branches(False)
 
     def to_device(self, batch):
         return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}

@@ -107,6 +107,10 @@ def enable_branches(on=True):
     _BR["on"] = bool(on)
 
 
+def branch_streams():
+    return _BR["streams"].values()
+
+
 class branch:
     """Context: launches inside go to branch stream `which` (no-op when disabled or already on a branch)."""
 

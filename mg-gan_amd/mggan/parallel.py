@@ -133,13 +133,27 @@ class SegmentRecorder:
         self.pool = torch.cuda.graph_pool_handle()
         self.error_mode = error_mode
         self._g = None
+        self.origin = None  # the stream every segment is captured on; branch streams fork from / join into it
 
     def begin(self):
-        self._g = torch.cuda.CUDAGraph()
-        self._g.capture_begin(pool=self.pool, capture_error_mode=self.error_mode)
+        if self.origin is None:
+            self.origin = torch.cuda.current_stream()
+        with torch.cuda.stream(self.origin):
+            self._g = torch.cuda.CUDAGraph()
+            self._g.capture_begin(pool=self.pool, capture_error_mode=self.error_mode)
+        cur = torch.cuda.current_stream()
+        if cur != self.origin:  # the cut came from inside a branch: the branch stream forks into the new segment
+            cur.wait_stream(self.origin)
 
     def end(self):
-        self._g.capture_end()
+        from mggan.hip.functions import branch_streams
+
+        cur = torch.cuda.current_stream()
+        for s in list(branch_streams()) + [cur]:  # a capture can only end with every fork joined
+            if s != self.origin:
+                self.origin.wait_stream(s)
+        with torch.cuda.stream(self.origin):
+            self._g.capture_end()
         self.items.append(("graph", self._g))
         self._g = None
 
