@@ -3,6 +3,7 @@ MultiGeneratorGAN.{train, save, load, load_from_path} and the optimizer / schedu
 One iteration = discriminator step -> generator step -> PM-network step (:136-159)."""
 import abc
 import math
+import os
 from argparse import Namespace
 from collections import defaultdict
 from pathlib import Path
@@ -53,6 +54,13 @@ class MultiGeneratorGAN(abc.ABC):
         self.G.rng = self.rng
         self.dist = DistContext()
         self.dist.attach(self.G, self.D)
+        if self.dist.enabled and os.environ.get("MGGAN_BRANCH_SHARDED", "0") != "1":
+            # sharded runs are replayed as ~19 short graph segments (one per collective); forks that have to be
+            # joined at every cut measured slower than one stream (3.49 vs 3.24 ms per iteration with dummy
+            # collectives on one MI355X), so the branch streams stay off unless asked for
+            from mggan.hip import functions as HF
+
+            HF.enable_branches(False)
 
     def to_device(self, batch):
         return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
