@@ -1,0 +1,132 @@
+"""GPU, BASELINE.json sizes: the HIP path against the CPU oracle on one full D+G+PM iteration at configs[1]
+(64 scenes x 20 pedestrians, 4 generators, 20 samples), plus size-independent properties at that size:
+bit-identical repeats (no float atomics, fixed-order reductions) and scene-order equivariance of the forward."""
+from collections import defaultdict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _draws(sizes, g, K, gen):
+    b, S = sum(sizes), len(sizes)
+    rep = torch.tensor(sizes)
+    steps = []
+    for k in (1, K, 1):
+        noise = torch.randn(k, S, 8, generator=gen).repeat_interleave(rep, dim=1)
+        idx = torch.randint(0, g, (b, k), generator=gen)
+        steps.append((noise, idx))
+    return steps
+
+
+def _trainers(g, seed=3):
+    import mggan_oracle as O
+    from mggan.logging import Experiment
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.model.train import PiNetMultiGeneratorGAN
+
+    cfg = get_parser().parse_args(["--num_gens", str(g)])
+    torch.manual_seed(seed)
+    G, D = construct_model(cfg)
+    Go, Do = O.construct_oracle(g)
+    Go.load_state_dict(G.state_dict())
+    Do.load_state_dict(D.state_dict())
+    tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+    for m in (tr.G, tr.D, Go, Do):
+        m.train()
+    return tr, O.OracleTrainer(Go, Do, mode="block")
+
+
+def _iteration(tr, batch, steps, labels):
+    from mggan.rng import ReplayRNG
+
+    m = defaultdict(list)
+    dbatch = tr.to_device(batch)
+    dbatch["loss_mask"] = None
+    tr.rng = tr.G.rng = ReplayRNG(labels=[labels[0], labels[1], labels[2]], noise=[s[0] for s in steps],
+                                  gen_idxs=[s[1] for s in steps])
+    tr.train_iteration(dbatch, m)
+    return m
+
+
+def test_configs1_iteration_matches_oracle():
+    from mggan.data_utils import synthetic
+
+    g, K = 4, 20
+    sizes = synthetic.scene_sizes(64, 20)
+    batch = synthetic.make_batch(sizes, seed=1)
+    steps = _draws(sizes, g, K, torch.Generator().manual_seed(5))
+    labels = [(0.95, 0.05), (0.93, 0.07), (0.97, 0.02)]
+    tr, tro = _trainers(g)
+    torch.set_num_threads(16)
+    m_gpu = _iteration(tr, batch, steps, labels)
+    # the oracle takes its draws per step
+    m_cpu = defaultdict(list)
+    b = sum(sizes)
+    mask = torch.ones(b, dtype=torch.bool)
+    cpu_args = (batch["in_xy"], batch["in_dxdy"], batch["gt_xy"], batch["gt_dxdy"], batch["seq_start_end"])
+    for (step, (noise, idx)), lab in zip(zip(("discriminator_step", "generator_step", "net_chooser_step"), steps),
+                                         ((labels[0], labels[1]), (labels[2], labels[2]), (labels[2], labels[2]))):
+        draws = {"noise": noise, "gen_idxs": idx, "labels": lab[0], "labels1": lab[0], "labels2": lab[1]}
+        getattr(tro, step)(*cpu_args, m_cpu, mask, batch["features"], draws=draws)
+    for key, v in m_cpu.items():  # losses: rtol 1e-3 (SURVEY A.12 ii)
+        assert abs(m_gpu[key][0] - v[0]) <= 1e-3 * abs(v[0]) + 1e-6, (key, m_gpu[key][0], v[0])
+    for mod, ref in ((tr.G, tro.G), (tr.D, tro.D)):  # post-step parameters: relL2 1e-3 (A.12 iv)
+        a = torch.cat([p.detach().cpu().flatten() for p in mod.parameters()]).double()
+        r = torch.cat([p.detach().flatten() for p in ref.parameters()]).double()
+        assert float((a - r).norm() / r.norm()) <= 1e-3
+
+
+def test_configs1_iteration_is_bit_reproducible():
+    from mggan.data_utils import synthetic
+
+    g, K = 4, 20
+    sizes = synthetic.scene_sizes(64, 20)
+    batch = synthetic.make_batch(sizes, seed=2)
+    labels = [(0.95, 0.05), (0.93, 0.07), (0.97, 0.02)]
+    outs = []
+    for _ in range(2):
+        tr, _ = _trainers(g, seed=7)
+        steps = _draws(sizes, g, K, torch.Generator().manual_seed(9))
+        m = _iteration(tr, batch, steps, labels)
+        outs.append((torch.cat([tr.G._flat, tr.D._flat]).cpu(), {k: v[0] for k, v in m.items()}))
+    assert torch.equal(outs[0][0], outs[1][0])  # every reduction is fixed-order: two runs agree to the bit
+    assert outs[0][1] == outs[1][1]
+
+
+def test_generator_is_equivariant_to_scene_order():
+    """Scenes are independent in the generator (social attention, noise and rollouts are per scene / per
+    pedestrian): feeding the scenes in reverse order permutes the predictions and nothing else."""
+    from mggan.data_utils import synthetic
+    from mggan.rng import ReplayRNG
+
+    g, K = 4, 20
+    sizes = [20] * 64
+    batch = synthetic.make_batch(sizes, seed=4)
+    tr, _ = _trainers(g, seed=11)
+    tr.G.eval()  # BatchNorm statistics of the whole batch do not depend on the order, running stats even less
+    b = sum(sizes)
+    gen = torch.Generator().manual_seed(13)
+    noise = torch.randn(K, len(sizes), 8, generator=gen).repeat_interleave(torch.tensor(sizes), dim=1)
+    idx = torch.randint(0, g, (b, K), generator=gen)
+    perm = torch.arange(b).view(len(sizes), 20).flip(0).reshape(-1)  # pedestrian order after reversing the scenes
+    outs = []
+    for order in (None, perm):
+        bt = {k: v for k, v in batch.items()}
+        n, i = noise, idx
+        if order is not None:
+            for k in ("in_xy", "in_dxdy"):
+                bt[k] = batch[k][:, order]
+            bt["features"] = batch["features"][order]
+            n, i = noise[:, order], idx[order]
+        d = tr.to_device(bt)
+        tr.rng = tr.G.rng = ReplayRNG(gen_idxs=[i])
+        with torch.no_grad():
+            out, logits, _ = tr.G(d["in_xy"], d["in_dxdy"], bt["seq_start_end"], noise=n.cuda(), all_gen_out=False,
+                                  img=d["features"], num_samples=K)
+        outs.append((out.abs.cpu(), logits.cpu()))
+    np.testing.assert_allclose(outs[1][0].numpy(), outs[0][0][:, :, perm].numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(outs[1][1].numpy(), outs[0][1][perm].numpy(), rtol=1e-5, atol=1e-6)
