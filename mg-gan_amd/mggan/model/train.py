@@ -189,7 +189,14 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                                           trunk=None if shared is None else shared.get("g_trunk"))
             losses, grads, items = [], [], []
             if cfg.l2_loss_type != "none":
-                tb = HF.scene_tables(sub_batches, gen_out.abs.shape[2], self.device)
+                bm = gen_out.abs.shape[2]
+                sse = sub_batches
+                if bm != b:
+                    # masked batch: the reference slices the MASKED predictions with the UNMASKED scene bounds
+                    # (train.py:67-68; python slices clip at the end) and still divides by the unmasked b (:73)
+                    sse = [[min(int(s0), bm), min(int(e0), bm)] for s0, e0 in sub_batches]
+                    sse = [se for se in sse if se[1] > se[0]]
+                tb = HF.scene_tables(sse, bm, self.device)
                 min_l2 = HF.L2MinSceneFn.apply(gen_out.abs, gt_xy, tb, self._global(b), m[M_L2:M_L2 + 1])
                 losses.append(min_l2)
                 grads.append(self._w["l2"])
