@@ -241,6 +241,14 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
                                     const float* Aact, const float* gabs, const float* grel, int Rout, float* dH0,
                                     float* dQ, float* dEnc, float* dSocR, float* wpart, mggan_stream_t stream);
 
+/* ---- input pipeline: per-pedestrian scene crops cut on the GPU -----------------------------
+ * Replaces the per-pedestrian PIL crop loop of BaseTrajectories.py:254-288 / trajectories_scene.py:349-356.
+ * atlas = the u8 RGB "small" scene images (H,W,3) packed back to back in device memory; pedestrian p reads the
+ * image at byte offset img_off[p] of size img_hw[2p] x img_hw[2p+1], window centre centers[2p] (x), [2p+1] (y);
+ * out (n,4,2m+1,2m+1): channels 0-2 = -1 + v*2/256 (0 outside the image), channel 3 = one-hot centre. */
+int mggan_crop_patches(const unsigned char* atlas, const long long* img_off, const int* img_hw, const int* centers,
+                       int n, int margin, float* out, mggan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,6 @@
-"""get_dataloader (surface of /root/reference/mggan/data_utils/data_loaders.py:10).  The on-disk
-datasets (ETH/UCY/SDD text + jpg) are host-side I/O outside this build's scope; the
-'synthetic' dataset yields batches with the reference's collate schema."""
+"""get_dataloader (surface of /root/reference/mggan/data_utils/data_loaders.py:10-100): the on-disk datasets
+(ETH/UCY, GOFP, SDD: tab-separated text + one jpg per scene, mggan/data_utils/trajectories_scene.py) and the
+built-in 'synthetic' dataset, both with the reference's collate schema."""
 import torch
 
 from mggan.data_utils import synthetic
@@ -22,11 +22,34 @@ class SyntheticScenes(torch.utils.data.Dataset):
 
 
 def get_dataloader(dataset, phase, augment=False, batch_size=8, workers=0, shuffle=False, synthetic_scenes=64,
-                   synthetic_peds=0):
+                   synthetic_peds=0, crop_device=None):
+    """crop_device: a HIP device -> the image crops of un-augmented on-disk datasets are cut on the GPU from scene
+    images resident in HBM (mggan/data_utils/device_crops.py); `features` then arrives on that device."""
+    assert phase in ("train", "val", "test")
     if dataset != "synthetic":
-        raise NotImplementedError(
-            "dataset '{}' needs the reference's on-disk loaders (data/datasets/<name>/...), which are out of scope "
-            "for the MI355X hot-path build; use --dataset synthetic".format(dataset))
+        from mggan.data_utils.trajectories_scene import TrajectoryDatasetEval, seq_collate_scene
+
+        if phase in ("val", "test") and augment:
+            print("No augmentation during validation or testing.")
+            augment = False
+        # metres per pixel of the crop source per dataset family (data_loaders.py:60-95)
+        if dataset == "stanford":
+            name, small = "stanford", 0.7
+        elif dataset.lower() in ("eth", "hotel", "zara1", "zara2", "univ", "gofp"):
+            name, small = dataset.lower(), 0.5
+        else:
+            raise NotImplementedError("dataset '{}' (on disk: eth, hotel, univ, zara1, zara2, gofp, stanford; or "
+                                      "'synthetic')".format(dataset))
+        ds = TrajectoryDatasetEval(dataset_name=name, phase=phase, margin_in=16, margin_out=16, load_occupancy=False,
+                                   scaling_small=small, data_augmentation=int(augment))
+        if crop_device is not None and not (augment and phase == "train"):
+            from mggan.data_utils.device_crops import DeviceCropDataset
+
+            dds = DeviceCropDataset(ds, crop_device)
+            return torch.utils.data.DataLoader(dds, batch_size=batch_size, shuffle=shuffle, num_workers=0,
+                                               collate_fn=dds.collate, drop_last=False)
+        return torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=shuffle, num_workers=workers,
+                                           collate_fn=seq_collate_scene, drop_last=False)
     n_batches = max(1, synthetic_scenes // max(batch_size, 1))
     ds = SyntheticScenes(n_batches if phase == "train" else max(1, n_batches // 4), batch_size,
                          synthetic_peds if synthetic_peds > 0 else None, seed={"train": 0, "val": 7, "test": 13}[phase])

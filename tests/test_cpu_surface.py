@@ -192,7 +192,7 @@ def test_synthetic_batch_schema():
     batch = next(iter(get_dataloader("synthetic", "train", batch_size=4, synthetic_scenes=8, synthetic_peds=3)))
     assert batch["in_xy"].shape[1] == 12
     with pytest.raises(NotImplementedError):
-        get_dataloader("eth", "train")
+        get_dataloader("no_such_dataset", "train")
 
 
 def test_cosine_schedule_matches_torch():

@@ -1,0 +1,77 @@
+"""On-disk dataset loader against what the reference's loader produced from the same files
+(tests/golden/golden_loader.npz, made by tests/golden/make_golden_loader.py): sequence extraction, scaling,
+NaN padding of inactive pedestrians, image rescaling, the per-pedestrian crops, augmentation draws, collation."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def loader_golden(tmp_path_factory):
+    g = dict(np.load(os.path.join(GOLDEN, "golden_loader.npz")))
+    root = tmp_path_factory.mktemp("datasets")
+    for k, v in g.items():
+        if k.startswith("file/"):
+            path = root / k[len("file/"):]
+            path.parent.mkdir(parents=True, exist_ok=True)
+            path.write_bytes(v.tobytes())
+    os.environ["MGGAN_DATA_ROOT"] = str(root)
+    yield g
+    os.environ.pop("MGGAN_DATA_ROOT", None)
+
+
+@pytest.mark.parametrize("name,small", [("eth", 0.5), ("gofp", 0.5), ("stanford", 0.7)])
+@pytest.mark.parametrize("phase,aug", [("test", 0), ("train", 1)])
+def test_dataset_matches_reference(loader_golden, name, small, phase, aug):
+    from mggan.data_utils.trajectories_scene import TrajectoryDatasetEval, seq_collate_scene
+
+    g = loader_golden
+    ds = TrajectoryDatasetEval(dataset_name=name, phase=phase, margin_in=16, margin_out=16, load_occupancy=False,
+                               scaling_small=small, data_augmentation=aug)
+    p = "{}/{}/".format(name, phase)
+    np.testing.assert_array_equal(np.array(ds.seq_start_end), g[p + "seq_start_end"])
+    np.testing.assert_array_equal(ds.ped_ids, g[p + "ped_ids"])
+    assert list(ds.scene_list) == list(g[p + "scenes"])
+    np.testing.assert_allclose(ds.trajectory, g[p + "trajectory"], rtol=1e-12, atol=0, equal_nan=True)
+    np.random.seed(123)  # the augmentation draws come from numpy's global generator
+    batch = seq_collate_scene([ds[i] for i in range(min(3, len(ds)))])
+    assert batch["seq_start_end"] == g[p + "batch/seq_start_end"].tolist()
+    for k in ("in_xy", "gt_xy", "in_dxdy", "gt_dxdy"):
+        np.testing.assert_allclose(batch[k].numpy(), g[p + "batch/" + k], rtol=1e-6, atol=1e-6, equal_nan=True, err_msg=k)
+    # same decoded JPEG, same Pillow filters, same crop boxes: the crops agree to the bit
+    np.testing.assert_array_equal(batch["features"].numpy(), g[p + "batch/features"])
+    assert batch["features"].shape[1:] == (4, 33, 33)
+    assert float(batch["features"][:, 3].sum()) == batch["features"].shape[0]  # one-hot centre channel
+
+
+def test_get_dataloader_on_disk(loader_golden):
+    from mggan.data_utils.data_loaders import get_dataloader
+
+    loader = get_dataloader("eth", "test", batch_size=4)
+    batch = next(iter(loader))
+    b = batch["in_xy"].shape[1]
+    assert batch["in_xy"].shape == (8, b, 2) and batch["gt_xy"].shape == (12, b, 2)
+    assert batch["in_dxdy"].shape == (7, b, 2) and batch["features"].shape == (b, 4, 33, 33)
+    assert batch["seq_start_end"][-1][1] == b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["eth", "gofp", "stanford"])
+def test_device_crops_match_host_crops(loader_golden, name):
+    """mggan_crop_patches (scene images resident in HBM, one launch per batch) == the per-pedestrian PIL crops."""
+    from mggan.data_utils.data_loaders import get_dataloader
+
+    host = next(iter(get_dataloader(name, "test", batch_size=5)))
+    dev = next(iter(get_dataloader(name, "test", batch_size=5, crop_device="cuda")))
+    assert dev["features"].is_cuda and dev["features"].shape == host["features"].shape
+    assert torch.equal(dev["features"].cpu(), host["features"])
+    for k in ("in_xy", "gt_xy", "in_dxdy", "gt_dxdy"):
+        np.testing.assert_array_equal(dev[k].numpy(), host[k].numpy())
+    assert dev["seq_start_end"] == host["seq_start_end"]
+    g = loader_golden["{}/test/batch/features".format(name)]
+    n = min(len(g), dev["features"].shape[0])
+    np.testing.assert_array_equal(dev["features"].cpu().numpy()[:n], g[:n])  # and == the reference's crops
