@@ -183,11 +183,17 @@ int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float
 /* ---- losses (+ gradients), clipping, AdamW ----------------------------------------------
  * reference: abstract_train.py:62-67, utils.py:18-25, train.py:58-75,92-113,181-200,626-639,
  *            train.py:131-135,209-213,656-658, abstract_train.py:45-50 */
-/* p = D output rows; loss_r = w_r*scale*BCE(p_r,label), w_r = inv_count[row_gen[r]] (or 1); dp = dloss/dp */
+/* p = D output rows; loss_r = w_r*scale*L(p_r,label), w_r = inv_count[row_gen[r]] (or 1); dp = dloss/dp.
+ * kind 0: L = BCELoss (objectives 'NS' and, with a negative scale on the generator side, 'MM'); kind 1: L = (p-label)^2
+ * ('LS'); abstract_train.py:62-75 */
 /* label: host scalar, or (label_u != NULL) drawn on the device as label_lo + (label_hi-label_lo) * *label_u */
-int mggan_bce_rows(int rows, const float* p, float label, const float* label_u, float label_lo, float label_hi,
-                   float scale, const int* row_gen, const float* inv_count, float* loss_rows, float* dp,
+int mggan_bce_rows(int rows, int kind, const float* p, float label, const float* label_u, float label_lo,
+                   float label_hi, float scale, const int* row_gen, const float* inv_count, float* loss_rows, float* dp,
                    mggan_stream_t stream);
+/* PM-network targets 'l2' (mode 0) / 'endpoint' (mode 1), train.py:616-624,641-647: target[ped] = the generator
+ * whose best of E samples is closest to the ground truth; gen_abs (T,E,g,b,2), gt (T,b,2) */
+int mggan_pm_target(int b, int T, int E, int g, int mode, const float* gen_abs, const float* gt, int* target,
+                    mggan_stream_t stream);
 /* Categorical(logits=...).sample((K,)).T on the device (standard.py:217-225): inverse CDF from uniforms u (b,K) */
 int mggan_sample_categorical(int b, int K, int g, const float* logits, const float* u, long long* idx,
                              mggan_stream_t stream);

@@ -14,7 +14,7 @@
 
 // ---- BCE on the discriminator output ---------------------------------------------------
 // p: D output per row (already sigmoid + eps-affine). loss_r = w_r*scale*BCE(p,y); dp = dloss_r/dp.
-__global__ void bce_rows_kernel(int rows, const float* __restrict__ p_in, float y, const float* __restrict__ y_u,
+__global__ void bce_rows_kernel(int rows, int kind, const float* __restrict__ p_in, float y, const float* __restrict__ y_u,
                                 float y_lo, float y_hi, float scale, const int* __restrict__ row_gen,
                                 const float* __restrict__ inv_count, float* loss_rows, float* dp) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -22,6 +22,11 @@ __global__ void bce_rows_kernel(int rows, const float* __restrict__ p_in, float 
   if (y_u) y = y_lo + (y_hi - y_lo) * (*y_u);  // smoothed label drawn on the device: U(y_lo, y_hi)
   const float p = p_in[r];
   const float w = (row_gen ? inv_count[row_gen[r]] : 1.f) * scale;
+  if (kind == 1) {  // least-squares objective (abstract_train.py:72-75): MSELoss(reduction='none')
+    loss_rows[r] = w * (p - y) * (p - y);
+    if (dp) dp[r] = w * 2.f * (p - y);
+    return;
+  }
   const float lp = fmaxf(__logf(p), -100.f), lq = fmaxf(__logf(1.f - p), -100.f);  // BCELoss log clamp
   loss_rows[r] = -w * (y * lp + (1.f - y) * lq);
   if (dp) dp[r] = -w * (y / p - (1.f - y) / (1.f - p));
@@ -153,6 +158,32 @@ __global__ void l2_grad_kernel(int T, int K, int b, const int* __restrict__ ped_
   }
   gabs[i * 2] = gx;
   gabs[i * 2 + 1] = gy;
+}
+
+// ---- PM-network 'l2' / 'endpoint' targets (train.py:616-624,641-647) ---------------------------------
+// target[ped] = argmin_g min_E dist(g, e), dist = mean_t |abs - gt| ('l2', mode 0) or |abs[T-1] - gt[T-1]|
+// ('endpoint', mode 1); first minimum wins like torch.argmin.  gen_abs (T,E,g,b,2).
+__global__ void pm_target_kernel(int b, int T, int E, int g, int mode, const float* __restrict__ gen_abs,
+                                 const float* __restrict__ gt, int* __restrict__ target) {
+  const int ped = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ped >= b) return;
+  float best = INFINITY;
+  int arg = 0;
+  for (int gi = 0; gi < g; ++gi) {
+    float dmin = INFINITY;
+    for (int e = 0; e < E; ++e) {
+      float d = 0.f;
+      for (int t = mode ? T - 1 : 0; t < T; ++t) {
+        const float* a = gen_abs + ((((size_t)t * E + e) * g + gi) * b + ped) * 2;
+        const float dx = a[0] - gt[((size_t)t * b + ped) * 2], dy = a[1] - gt[((size_t)t * b + ped) * 2 + 1];
+        d += sqrtf(dx * dx + dy * dy);
+      }
+      if (!mode) d /= (float)T;
+      dmin = fminf(dmin, d);
+    }
+    if (dmin < best) { best = dmin; arg = gi; }
+  }
+  target[ped] = arg;
 }
 
 // ---- PM-network 'ml' loss (train.py:626-639) ---------------------------------------------
@@ -438,12 +469,13 @@ int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, i
   return MGGAN_OK;
 }
 
-int mggan_bce_rows(int rows, const float* p, float label, const float* label_u, float label_lo, float label_hi,
-                   float scale, const int* row_gen, const float* inv_count, float* loss_rows, float* dp,
+int mggan_bce_rows(int rows, int kind, const float* p, float label, const float* label_u, float label_lo,
+                   float label_hi, float scale, const int* row_gen, const float* inv_count, float* loss_rows, float* dp,
                    hipStream_t stream) {
   if (rows == 0) return MGGAN_OK;
-  MG_CHECK_ARG(p && loss_rows && ((row_gen == nullptr) == (inv_count == nullptr)), "bce_rows: bad arguments");
-  hipLaunchKernelGGL(bce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rows, p, label, label_u, label_lo,
+  MG_CHECK_ARG(p && loss_rows && ((row_gen == nullptr) == (inv_count == nullptr)) && (kind == 0 || kind == 1),
+               "bce_rows: bad arguments");
+  hipLaunchKernelGGL(bce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rows, kind, p, label, label_u, label_lo,
                      label_hi, scale, row_gen, inv_count, loss_rows, dp);
   MG_LAUNCH_CHECK("bce_rows");
   return MGGAN_OK;
@@ -514,6 +546,15 @@ int mggan_pm_ml_loss(int b, int T, int E, int g, const float* gen_abs, const flo
   hipLaunchKernelGGL(pm_ml_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, T, E, g, gen_abs, gt, logits, sigma,
                      scale, loss_rows, dlogits, probs);
   MG_LAUNCH_CHECK("pm_ml_loss");
+  return MGGAN_OK;
+}
+
+int mggan_pm_target(int b, int T, int E, int g, int mode, const float* gen_abs, const float* gt, int* target,
+                    hipStream_t stream) {
+  if (b == 0) return MGGAN_OK;
+  MG_CHECK_ARG(gen_abs && gt && target && (mode == 0 || mode == 1), "pm_target: bad arguments");
+  hipLaunchKernelGGL(pm_target_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, T, E, g, mode, gen_abs, gt, target);
+  MG_LAUNCH_CHECK("pm_target");
   return MGGAN_OK;
 }
 

@@ -37,8 +37,9 @@ class MultiGeneratorGAN(abc.ABC):
         self.G = generator.to(self.device).flatten_parameters_()
         self.l2_weight = self.config.l2_loss_weight
         self.gan_type = self.config.gan_type
-        if self.config.gan_obj != "NS":
-            raise ValueError("Objective not supported on the HIP path (only 'NS', the reference default)")
+        if self.config.gan_obj not in ("NS", "MM", "LS"):
+            raise ValueError("Objective not supported on the HIP path ('NS' (default), 'MM', 'LS'; 'W' needs the "
+                             "unbounded discriminator output)")
 
         self.log_dir = Path(self.writer.get_data_path(self.writer.name, self.writer.version))
         self.model_save_dir = self.log_dir / "checkpoints"

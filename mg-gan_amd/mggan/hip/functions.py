@@ -902,7 +902,8 @@ class BceMeanFn(Function):
     """mean over rows of w_r * BCE(p_r, label)  (abstract_train.py:62-67 'NS'; train.py:92-97 re-weighting)."""
 
     @staticmethod
-    def forward(ctx, p_rows, label, row_gen, inv_count, out, norm=None):
+    def forward(ctx, p_rows, label, row_gen, inv_count, out, norm=None, kind=0, sign=1.0):
+        # kind 0: BCE ('NS'; 'MM' on the generator side with sign = -1), kind 1: squared error ('LS')
         p_rows = p_rows.contiguous()
         rows = p_rows.numel()
         loss_rows = _empty(rows, like=p_rows)
@@ -911,7 +912,7 @@ class BceMeanFn(Function):
             lab, lab_u, lo, hi = 0.0, _p(label[0]), float(label[1]), float(label[2])
         else:
             lab, lab_u, lo, hi = float(label), 0, 0.0, 0.0
-        lib.mggan_bce_rows(rows, _p(p_rows), lab, lab_u, lo, hi, 1.0 / float(norm or max(rows, 1)), _p(row_gen),
+        lib.mggan_bce_rows(rows, kind, _p(p_rows), lab, lab_u, lo, hi, float(sign) / float(norm or max(rows, 1)), _p(row_gen),
                            _p(inv_count),
                            _p(loss_rows), _p(dp), _s())
         lib.mggan_sum(_p(loss_rows), rows, 1.0, _p(out), 0, _s())
@@ -920,7 +921,7 @@ class BceMeanFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _scaled(ctx.dp, g).view(ctx.shape), None, None, None, None, None
+        return _scaled(ctx.dp, g).view(ctx.shape), None, None, None, None, None, None, None
 
 
 class CeMeanFn(Function):

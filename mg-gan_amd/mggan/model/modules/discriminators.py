@@ -17,9 +17,9 @@ class MultiDiscriminatorTrajectory(FlatModule):
         assert inp_format in ("rel", "abs", "abs_rel")
         assert gan_type in ("probgan", "mgan", "infogan", "gan")
         if (inp_format != "rel" or gan_type not in ("mgan", "gan") or not global_disc or pool_type != "sways"
-                or unbound_output or num_discs != 1 or scene_dim <= 0):
+                or num_discs != 1 or scene_dim <= 0):
             raise ValueError("HIP MultiDiscriminatorTrajectory implements the default hot path: inp_format='rel', "
-                             "gan_type mgan/gan, global_disc, pool_type='sways', NS/MM objective, one discriminator")
+                             "gan_type mgan/gan, global_disc, pool_type='sways', one discriminator")
         self.inp_format = inp_format
         self.unbound_output = unbound_output
         self.n_ds = num_discs
@@ -37,14 +37,18 @@ class MultiDiscriminatorTrajectory(FlatModule):
         self.scene_encoder = AttentionGlobal(noise_attention_dim=0, PhysFeature=True, num_layers=2, channels_cnn=8)
         h_dim += scene_dim
         self.discs = nn.ModuleList()
-        for _ in range(num_discs):
-            self.discs.append(nn.Sequential(nn.Linear(h_dim, h_dim // 2), nn.LeakyReLU(0.2), nn.Linear(h_dim // 2, 1),
-                                            nn.Sigmoid()))
+        for _ in range(num_discs):  # raw scores for the 'LS' / 'W' objectives (discriminators.py:76-85)
+            layers = [nn.Linear(h_dim, h_dim // 2), nn.LeakyReLU(0.2), nn.Linear(h_dim // 2, 1)]
+            self.discs.append(nn.Sequential(*(layers if unbound_output else layers + [nn.Sigmoid()])))
         if gan_type == "mgan":
             self.gen_id_reconstructor = nn.Sequential(nn.Linear(h_dim, h_dim // 2), nn.LeakyReLU(0.2),
                                                       nn.Linear(h_dim // 2, num_gens))
         self.eps = 1e-7
         self.len_hist = 1.0
+
+    def _out_act(self):
+        """Sigmoid + the eps squeeze of discriminators.py:83-84,203-204, or the raw score when unbound."""
+        return HF.ACT_NONE if self.unbound_output else HF.ACT_SIGMOID_EPS
 
     def encode(self, in_xy, in_dxdy, pred_xy, pred_dxdy, mask=None):
         """(in_enc (b,h/2), pred_enc (K*b_m,h/2)) -> enc (K*b, h) as the reference returns it."""
@@ -105,7 +109,7 @@ class MultiDiscriminatorTrajectory(FlatModule):
         HF.join_branch(scene)
         classifier_inp = HF.DAssembleFn.apply(soc, in_enc, pred_enc, scene, 2, True)
         d = self.discs[0]
-        y = HF.mlp(classifier_inp, [(d[0], HF.ACT_LEAKY, 0.2), (d[2], HF.ACT_SIGMOID_EPS, 0.0)])
+        y = HF.mlp(classifier_inp, [(d[0], HF.ACT_LEAKY, 0.2), (d[2], self._out_act(), 0.0)])
         branch = None
         if self.gan_type == "mgan":
             r = self.gen_id_reconstructor
@@ -143,7 +147,7 @@ class MultiDiscriminatorTrajectory(FlatModule):
             classifier_inp = torch.cat([classifier_inp, scene], 1)
 
         d = self.discs[0]
-        y = HF.mlp(classifier_inp, [(d[0], HF.ACT_LEAKY, 0.2), (d[2], HF.ACT_SIGMOID_EPS, 0.0)])
+        y = HF.mlp(classifier_inp, [(d[0], HF.ACT_LEAKY, 0.2), (d[2], self._out_act(), 0.0)])
         output = y.reshape(n_samples, b).t()  # mean over the single discriminator is the identity
         if self.gan_type == "gan":
             return output

@@ -35,8 +35,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
     def __init__(self, generator, discriminator, config, writer):
         super().__init__(generator, discriminator, config, writer)
         assert self.gan_type in ("mgan", "gan"), self.gan_type
-        if config.weighting_target not in ("ml", "none"):
-            raise ValueError("HIP path implements weighting_target 'ml' (default) and 'none'")
+        if config.weighting_target not in ("ml", "l2", "endpoint", "none"):
+            raise ValueError("HIP path implements weighting_target 'ml' (default), 'l2', 'endpoint' and 'none'")
         if config.l2_loss_type not in ("min_g_z", "min_z", "min_g_min_z", "none"):
             raise ValueError("HIP path implements the per-scene min-over-samples L2 (not 'mse')")
         dev = self.device
@@ -140,7 +140,9 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                 real_result = real_result[0]
         n_real = self._global(real_result.numel())
         label_real, _ = self.rng.labels()
-        real_loss = HF.BceMeanFn.apply(real_result.t().reshape(-1), label_real, None, None, m[M_REAL:M_REAL + 1], n_real)
+        kind = 1 if self.config.gan_obj == "LS" else 0  # phi_1 / phi_2: squared error for 'LS', BCE for 'NS' and 'MM'
+        real_loss = HF.BceMeanFn.apply(real_result.t().reshape(-1), label_real, None, None, m[M_REAL:M_REAL + 1], n_real,
+                                       kind)
         if not pair:
             HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, None if rows_d is None else rows_d.row_gen_pos, which=1)
             disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask, context=ctx)
@@ -156,7 +158,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             items.append(("train/info_mgan_disc_loss", M_CE_D))
         _, label_fake = self.rng.labels()
         fake_loss = HF.BceMeanFn.apply(disc_out.t().reshape(-1), label_fake, None, None, m[M_FAKE:M_FAKE + 1],
-                                       self._global(disc_out.numel()))
+                                       self._global(disc_out.numel()), kind)
         losses.append(fake_loss)
         items.append(("train/discr_loss", (M_FAKE, M_REAL)))
 
@@ -212,11 +214,14 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         branch_out = None
         if isinstance(disc_out, tuple):
             disc_out, branch_out = disc_out
-        label_real, _ = self.rng.labels()
+        label_real, label_fake = self.rng.labels()
         row_gen, inv_count = self._gen_weights(gen_idxs)
         n_rows = self._global(disc_out.numel())
-        adv_loss = HF.BceMeanFn.apply(disc_out.t().reshape(-1), label_real, row_gen, inv_count, m[M_ADV:M_ADV + 1],
-                                      n_rows)
+        # phi_3 (abstract_train.py:62-75): 'NS' BCE(d, real), 'LS' (d - real)^2, 'MM' -BCE(d, fake)
+        obj = cfg.gan_obj
+        adv_loss = HF.BceMeanFn.apply(disc_out.t().reshape(-1), label_fake if obj == "MM" else label_real, row_gen,
+                                      inv_count, m[M_ADV:M_ADV + 1], n_rows, 1 if obj == "LS" else 0,
+                                      -1.0 if obj == "MM" else 1.0)
         losses.append(adv_loss)
         grads.append(self._one)
         items.append(("train/gen_loss", M_ADV))
@@ -240,8 +245,20 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         m, g = self._m, self.G.n_gs
         gen_out, net_chooser_weights, _ = self.G(in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=img,
                                                  num_samples=cfg.num_expectation_samples, mask=mask)
-        loss = HF.PmMlFn.apply(net_chooser_weights, gen_out.abs, gt_xy, cfg.sigma, m[M_PM:M_PM + 1],
-                               m[M_PROBS:M_PROBS + g], self._global(net_chooser_weights.shape[0]))
+        n_pm = self._global(net_chooser_weights.shape[0])
+        if cfg.weighting_target == "ml":
+            loss = HF.PmMlFn.apply(net_chooser_weights, gen_out.abs, gt_xy, cfg.sigma, m[M_PM:M_PM + 1],
+                                   m[M_PROBS:M_PROBS + g], n_pm)
+        else:  # 'l2' / 'endpoint' (train.py:616-624,641-647): cross entropy against the closest generator
+            T_, E_, _, b_, _ = gen_out.abs.shape
+            target = torch.empty(b_, dtype=torch.int32, device=self.device)
+            lib.mggan_pm_target(b_, T_, E_, g, 1 if cfg.weighting_target == "endpoint" else 0,
+                                gen_out.abs.contiguous().data_ptr(), gt_xy.contiguous().data_ptr(), target.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+            probs = torch.softmax(net_chooser_weights.detach(), 1).contiguous()  # logged mean generator probabilities
+            lib.mggan_colmean(probs.data_ptr(), b_, g, float(b_) / n_pm, m[M_PROBS:M_PROBS + g].data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+            loss = HF.CeMeanFn.apply(net_chooser_weights, target, None, m[M_PM:M_PM + 1], n_pm)
         self.optimizerG.zero_grad()
         self._backward([loss], [self._w["pi"]])
         self.dist.all_reduce_grads(self.G)

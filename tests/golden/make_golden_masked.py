@@ -5,7 +5,9 @@ Pins SURVEY A.10 (the L2 term slices the masked predictions with the unmasked sc
 unmasked b).
 
 Run in the build container only (needs /root/reference):
-    python tests/golden/make_golden_masked.py        -> tests/golden/golden_masked_g2.npz"""
+    python tests/golden/make_golden_masked.py [masked] [variants]
+        -> tests/golden/golden_masked_g2.npz, golden_{obj_ls,obj_mm,wt_l2,wt_endpoint}_g2.npz
+(`variants`: one unmasked iteration each under --gan_obj LS / MM and --weighting_target l2 / endpoint)."""
 import importlib.util
 import os
 import sys
@@ -32,27 +34,30 @@ def t2n(t):
     return t.detach().cpu().numpy().copy()
 
 
-def main(num_gens=2, sizes=(2, 3, 1, 4), seed=21):
+def main(tag="masked_g2", extra=(), nan=True, num_gens=2, sizes=(2, 3, 1, 4), seed=21, keep_init=True):
     out = {}
-    args = ref_config.get_parser().parse_args(["--gpus", "", "--num_gens", str(num_gens)])
+    args = ref_config.get_parser().parse_args(["--gpus", "", "--num_gens", str(num_gens)] + list(extra))
     torch.manual_seed(seed)
     np.random.seed(seed + 1)
     G, D = ref_train.construct_model(args)
     model = ref_train.PiNetMultiGeneratorGAN(G, D, args, test_tube.Experiment())
     G.train()
     D.train()
-    for pre, mod in (("G0", G), ("D0", D)):
-        for k, v in mod.state_dict().items():
-            out["{}/{}".format(pre, k)] = t2n(v)
+    if keep_init:  # (the variants re-create the initial state from the seed: seeded init is bit-identical)
+        for pre, mod in (("G0", G), ("D0", D)):
+            for k, v in mod.state_dict().items():
+                out["{}/{}".format(pre, k)] = t2n(v)
     batch = synth.make_batch(list(sizes), seed=seed + 2)
-    batch["gt_xy"][5:, 3] = float("nan")    # pedestrian 3 (second scene) leaves after 5 predicted steps
-    batch["gt_dxdy"][5:, 3] = float("nan")
-    batch["gt_xy"][9:, 8] = float("nan")    # pedestrian 8 (last scene)
-    batch["gt_dxdy"][9:, 8] = float("nan")
+    if nan:
+        batch["gt_xy"][5:, 3] = float("nan")    # pedestrian 3 (second scene) leaves after 5 predicted steps
+        batch["gt_dxdy"][5:, 3] = float("nan")
+        batch["gt_xy"][9:, 8] = float("nan")    # pedestrian 8 (last scene)
+        batch["gt_dxdy"][9:, 8] = float("nan")
     sub = batch["seq_start_end"]
     in_xy, in_dxdy, gt_xy, gt_dxdy, img = (batch[k] for k in ("in_xy", "in_dxdy", "gt_xy", "gt_dxdy", "features"))
     mask = ~gt_xy.isnan().any(2).any(0)     # abstract_train.py:127
     out["meta/num_gens"], out["meta/scenes"] = np.int64(num_gens), np.array(sub, dtype=np.int64)
+    out["meta/seed"], out["meta/args"] = np.int64(seed), np.array(list(extra))
     for k in ("in_xy", "in_dxdy", "gt_xy", "gt_dxdy", "features"):
         out["in/" + k] = t2n(batch[k])
     out["in/mask"] = t2n(mask)
@@ -101,11 +106,19 @@ def main(num_gens=2, sizes=(2, 3, 1, 4), seed=21):
     for pre, mod in (("G1", G), ("D1", D)):
         for k, v in mod.state_dict().items():
             out["{}/{}".format(pre, k)] = t2n(v)
-    path = os.path.join(HERE, "golden_masked_g2.npz")
+    ref_train.get_gan_labels = orig_labels
+    ref_standard.get_global_noise = orig_noise
+    path = os.path.join(HERE, "golden_{}.npz".format(tag))
     np.savez_compressed(path, **out)
-    print("bytes", os.path.getsize(path))
+    print(tag, "bytes", os.path.getsize(path))
 
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    main()
+    which = sys.argv[1:] or ["masked", "variants"]
+    if "masked" in which:
+        main()
+    if "variants" in which:  # other GAN objectives and PM-network targets, one unmasked iteration each
+        for tag, extra in (("obj_ls_g2", ["--gan_obj", "LS"]), ("obj_mm_g2", ["--gan_obj", "MM"]),
+                           ("wt_l2_g2", ["--weighting_target", "l2"]), ("wt_endpoint_g2", ["--weighting_target", "endpoint"])):
+            main(tag, extra, nan=False, keep_init=False)

@@ -1,0 +1,74 @@
+"""Other GAN objectives and PM-network targets (--gan_obj LS / MM, --weighting_target l2 / endpoint):
+one D+G+PM iteration against golden vectors from the real reference (tests/golden/make_golden_masked.py variants);
+the initial state is re-created from the seed (seeded initialisation is bit-identical to the reference's)."""
+import os
+from collections import defaultdict
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from test_masked import STEPS, _batch, _check
+
+VARIANTS = ["obj_ls_g2", "obj_mm_g2", "wt_l2_g2", "wt_endpoint_g2"]
+
+
+def _load(tag):
+    g = dict(np.load(os.path.join(GOLDEN, "golden_{}.npz".format(tag))))
+    return g, [str(a) for a in g["meta/args"]]
+
+
+def _opts(args):
+    return {args[i].lstrip("-"): args[i + 1] for i in range(0, len(args), 2)}
+
+
+@pytest.mark.parametrize("tag", VARIANTS)
+def test_oracle_variant_iteration(tag):
+    import mggan_oracle as O
+
+    g, args = _load(tag)
+    torch.manual_seed(int(g["meta/seed"]))
+    np.random.seed(int(g["meta/seed"]) + 1)
+    o = _opts(args)
+    G, D = O.construct_oracle(int(g["meta/num_gens"]), gan_obj=o.get("gan_obj", "NS"))
+    G.train()
+    D.train()
+    tr = O.OracleTrainer(G, D, mode="block", gan_obj=o.get("gan_obj", "NS"), weighting_target=o.get("weighting_target", "ml"))
+    bt, mask = _batch(g)
+    a = (bt["in_xy"], bt["in_dxdy"], bt["gt_xy"], bt["gt_dxdy"], bt["seq_start_end"])
+    m = defaultdict(list)
+    for s, fn in STEPS:
+        lab = g.get("s_{}/labels".format(s))
+        dr = {"noise": torch.from_numpy(g["s_{}/noise".format(s)].copy()),
+              "gen_idxs": torch.from_numpy(g["s_{}/gen_idxs".format(s)].copy())}
+        if lab is not None:
+            dr.update(labels=tuple(lab[0]), labels1=tuple(lab[0]), labels2=tuple(lab[-1]))
+        getattr(tr, fn)(*a, m, mask, bt["features"], draws=dr)
+    _check(g, m, G, D)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", VARIANTS)
+def test_hip_variant_iteration(tag):
+    from mggan.logging import Experiment
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.model.train import PiNetMultiGeneratorGAN
+    from mggan.rng import ReplayRNG
+
+    g, args = _load(tag)
+    cfg = get_parser().parse_args(["--num_gens", str(int(g["meta/num_gens"]))] + args)
+    torch.manual_seed(int(g["meta/seed"]))
+    np.random.seed(int(g["meta/seed"]) + 1)
+    G, D = construct_model(cfg)
+    tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+    tr.G.train()
+    tr.D.train()
+    bt, _ = _batch(g, "cuda")
+    labels = [tuple(r) for s, _ in STEPS if "s_{}/labels".format(s) in g for r in g["s_{}/labels".format(s)]]
+    tr.rng = tr.G.rng = ReplayRNG(labels=labels, noise=[torch.from_numpy(g["s_{}/noise".format(s)].copy()) for s, _ in STEPS],
+                                  gen_idxs=[torch.from_numpy(g["s_{}/gen_idxs".format(s)].copy()) for s, _ in STEPS])
+    m = defaultdict(list)
+    tr.train_iteration(bt, m)
+    _check(g, m, tr.G, tr.D)
