@@ -203,9 +203,19 @@ def main():
     tr.zero_grads_in_step = True  # AdamW zeroes what it consumed: no separate memset per step
     metrics = defaultdict(list)
     use_graph = args.rng == "device" and not args.no_graph
+    replay = None
     if use_graph:
-        replay = tr.capture_iteration(batch)
-
+        try:
+            replay = tr.capture_iteration(batch)
+        except Exception as exc:  # noqa: BLE001
+            if world == 1:
+                raise
+            # every rank runs the same program on the same shapes, so they all end up here together
+            print("[bench] rank {}: graph-segment capture failed ({}: {}); launching eagerly".format(
+                rank, type(exc).__name__, exc), file=sys.stderr)
+            tr.dist.recorder = None
+            use_graph = False
+    if use_graph:
         def run_step(fetch):
             replay(metrics, fetch)
     else:
