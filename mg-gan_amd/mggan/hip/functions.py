@@ -262,6 +262,9 @@ class LinearFn(Function):
         y = _empty(rows, N, like=x)
         lib.mggan_linear_fwd(_p(x), ldx, _p(W), _p(b), _p(y), N, rows, K, N, act, float(slope), _s())
         ctx.act, ctx.slope, ctx.owner, ctx.ldx = act, slope, owner, ldx
+        # whether the weights train is decided when the forward pass runs (the generator step freezes D around its
+        # forward: the reference discards those gradients, so they are never computed)
+        ctx.train_w = W.requires_grad
         ctx.save_for_backward(x, W, b, y)
         return y
 
@@ -283,7 +286,7 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = _empty(rows, K, like=x)
             lib.mggan_linear_bwd_data(_p(dz), lddz, _p(W), K, _p(dx), K, rows, K, N, 0, 0, 0, 0, 0.0, _s())
-        if W.requires_grad:
+        if ctx.train_w:
             root = root_of(ctx.owner)
             with side_stream(dz, x):
                 wgrad(dz, lddz, x, ctx.ldx, root.grad_ptr(W), K, root.grad_ptr(b) if b is not None else 0, rows, K, N)
@@ -339,7 +342,7 @@ class MlpChainFn(Function):
             TRACE_NOTES["mlp_chain_flops"].append(2.0 * rows * sum(W.shape[0] * W.shape[1] for W in Ws))
         lib.mggan_mlp_chain(ctypes.addressof(a), _s())
         if save:
-            ctx.spec, ctx.owner, ctx.ldx, ctx.n = spec, owner, ldx, n
+            ctx.spec, ctx.owner, ctx.ldx, ctx.n, ctx.train_w = spec, owner, ldx, n, Ws[0].requires_grad
             ctx.save_for_backward(x, *outs, *wb)
         return outs[-1]
 
@@ -352,7 +355,7 @@ class MlpChainFn(Function):
         rows = x.shape[0]
         dy, lddy = _rows2d(dy)
         need_dx = ctx.needs_input_grad[0]
-        train_w = Ws[0].requires_grad
+        train_w = ctx.train_w
         # gate gradients dz_l (l = n-1 .. 0): dz_{n-1} = dy * act'(y); dz_{l-1} = (dz_l W_l) * act'(h_{l-1})
         a = _McArgs()
         a.X, a.ldx, a.rows, a.K0 = _p(dy), lddy, rows, Ws[-1].shape[0]
@@ -542,6 +545,7 @@ class SocialAttentionFn(Function):
                                      _p(att), _p(S), Hh, st)
         if save:
             ctx.tb, ctx.owner, ctx.ld_h = tb, owner, ld_h
+            ctx.train_w1, ctx.train_w3 = w1.requires_grad, w3.requires_grad
             ctx.save_for_backward(h, w2, wat, W3b, Wh, vc, feat, l1, l2, att, w1, b1, b2, w3, b3, bat)
         return S
 
@@ -563,14 +567,14 @@ class SocialAttentionFn(Function):
         dvc = _empty(b, 65, like=h)
         lib.mggan_social_pairs_bwd(P, b, _p(tb.pair_j), _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(dsigma), _p(vc),
                                    _p(l1), _p(l2), _p(w2), _p(dz2), _p(dz1), _p(dvc), st)
-        if w1.requires_grad:
+        if ctx.train_w1:
             with side_stream(dz2, dz1, l1, feat):
                 wgrad(dz2, P, l1, P, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64, fm=1)
                 wgrad(dz1, P, feat, P, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32, fm=1)
         # dWh = dvc [W3|b3]^T ; d[W3|b3] = Wh^T dvc
         dWh = _empty(b, Fd, like=h)
         lib.mggan_linear_fwd(_p(dvc), 65, _p(W3b), 0, _p(dWh), Fd, b, 65, Fd, ACT_NONE, 0.0, st)
-        if w3.requires_grad:
+        if ctx.train_w3:
             with side_stream(Wh, dvc, dWh, h):
                 wgrad(Wh, Fd, dvc, 65, root.grad_ptr(w3), 64, 0, b, 64, Fd)
                 wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, 65, root.grad_ptr(b3), 1, 0, b, 1, Fd)
