@@ -1128,8 +1128,10 @@ int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float
   }
   const size_t lds = (size_t)(4 * IMG_PLANE + 8 * IH * 36) * sizeof(float);
   if (C == 16) {
-    // (an MFMA variant of this kernel -- dW as a 16 x 36 x 1089 implicit GEMM, image in two row halves -- was
-    //  measured at 131 us vs 101 us for this VALU kernel: the cost is in staging dy1, not in the products)
+    // (MFMA variants of this kernel were measured twice and lost: dW as a 16 x 36 x 1089 implicit GEMM with the
+    //  image in two row halves, 131 us; the flat-position form of conv1_fwd_mfma with all 16 channels of dy1 in a
+    //  78 KB LDS tile, one workgroup per CU and the next image's operands prefetched under the products, 134 us
+    //  (C = 8: 102 us) -- against 96 us (65 us) for this VALU kernel)
     static bool attr16 = false;
     if (!attr16) {
       hipFuncSetAttribute((const void*)conv1_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
