@@ -40,7 +40,7 @@ def kernel_of(name, a):
         "mggan_wgrad": "gemm_kernel<true,true,false>",
         "mggan_linear_fwd": "gemm_kernel<false,false,false>",
         "mggan_linear_bwd_data": "gemm_kernel<false,true,false>",
-        "mggan_mlp_chain": "mlp_chain_kernel<2>",  # 32-row tiles: the trainer only fuses stacks below 8192 rows
+        "mggan_mlp_chain": "mlp_chain_kernel",
     }
     if name in fixed:
         return fixed[name]

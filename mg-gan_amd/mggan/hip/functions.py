@@ -402,9 +402,9 @@ class MlpChainFn(Function):
         return (dx, None, None, None) + (None,) * len(wb)
 
 
-# Above this many rows the stack runs as one GEMM launch per layer: a weight-stationary chain keeps one wave per
-# SIMD resident (the weight images fill the LDS) and measured 40 us against 35 us for 25,600 x 192 x 96 x 1; below
-# it the chain wins by the launches it removes (9.7 us against 13.5 us for 1,280 x 64 x 32 x 32).
+# Above this many rows the stack runs as one GEMM launch per layer: the chain wins by the launches and round trips
+# it removes (6.7 us against 13.5 us for 1,280 x 64 x 32 x 32), at 25,600 rows it only ties the GEMMs forward (35.7 vs
+# 35.2 us) and loses backward.
 MLP_FUSE_MAX_ROWS = int(os.environ.get("MGGAN_MLP_FUSE_MAX_ROWS", "8192"))
 
 
