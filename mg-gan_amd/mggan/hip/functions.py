@@ -526,12 +526,18 @@ class SocialAttentionFn(Function):
         Fd = wat.shape[0]
         xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
         st = _s()
-        Wh = _empty(b, Fd, like=h)
-        lib.mggan_linear_fwd(_p(h), ld_h, _p(wat), _p(bat), _p(Wh), Fd, b, Hh, Fd, ACT_NONE, 0.0, st)
         W3b = _empty(Fd, 65, like=h)
         lib.mggan_social_w3b(_p(w3), _p(b3), _p(W3b), Fd, st)
-        vc = _empty(b, 65, like=h)
-        lib.mggan_linear_bwd_data(_p(Wh), Fd, _p(W3b), 65, _p(vc), 65, b, 65, Fd, 0, 0, 0, 0, 0.0, st)
+        # Wh = h W_at^T + b_at and vc = Wh [W3 | b3] as one two-stage chain launch
+        Wh, vc = _empty(b, Fd, like=h), _empty(b, 65, like=h)
+        a = _McArgs()
+        a.X, a.ldx, a.rows, a.K0, a.n = _p(h), ld_h, b, Hh, 2
+        s0, s1 = a.s[0], a.s[1]
+        s0.W, s0.bias, s0.out, s0.K, s0.N, s0.ldw, s0.trans, s0.act, s0.ld_out = _p(wat), _p(bat), _p(Wh), Hh, Fd, Hh, 0, ACT_NONE, Fd
+        s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out = _p(W3b), _p(vc), Fd, 65, 65, 1, ACT_NONE, 65
+        if _load_lib().trace is not None:
+            TRACE_NOTES["mlp_chain_flops"].append(2.0 * b * (Hh * Fd + Fd * 65))
+        lib.mggan_mlp_chain(ctypes.addressof(a), st)
         P = tb.P
         sigma = _empty(max(P, 1), like=h)
         feat = _empty(3, max(P, 1), like=h) if save else None      # feature-major [feature][pair]
@@ -571,15 +577,21 @@ class SocialAttentionFn(Function):
             with side_stream(dz2, dz1, l1, feat):
                 wgrad(dz2, P, l1, P, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64, fm=1)
                 wgrad(dz1, P, feat, P, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32, fm=1)
-        # dWh = dvc [W3|b3]^T ; d[W3|b3] = Wh^T dvc
+        # dWh = dvc [W3|b3]^T and dh += dWh W_at as one two-stage chain launch; d[W3|b3] = Wh^T dvc
         dWh = _empty(b, Fd, like=h)
-        lib.mggan_linear_fwd(_p(dvc), 65, _p(W3b), 0, _p(dWh), Fd, b, 65, Fd, ACT_NONE, 0.0, st)
+        a = _McArgs()
+        a.X, a.ldx, a.rows, a.K0, a.n = _p(dvc), 65, b, 65, 2
+        s0, s1 = a.s[0], a.s[1]
+        s0.W, s0.out, s0.K, s0.N, s0.ldw, s0.trans, s0.act, s0.ld_out = _p(W3b), _p(dWh), 65, Fd, 65, 0, ACT_NONE, Fd
+        s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out, s1.accumulate = _p(wat), _p(dh), Fd, Hh, Hh, 1, ACT_NONE, Hh, 1
+        if _load_lib().trace is not None:
+            TRACE_NOTES["mlp_chain_flops"].append(2.0 * b * (65 * Fd + Fd * Hh))
+        lib.mggan_mlp_chain(ctypes.addressof(a), st)
         if ctx.train_w3:
             with side_stream(Wh, dvc, dWh, h):
                 wgrad(Wh, Fd, dvc, 65, root.grad_ptr(w3), 64, 0, b, 64, Fd)
                 wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, 65, root.grad_ptr(b3), 1, 0, b, 1, Fd)
                 wgrad(dWh, Fd, h, ld_h, root.grad_ptr(wat), Hh, root.grad_ptr(bat), b, Hh, Fd)
-        lib.mggan_linear_bwd_data(_p(dWh), Fd, _p(wat), Hh, _p(dh), Hh, b, Hh, Fd, 1, 0, 0, 0, 0.0, st)
         return (None, None, dh if ctx.needs_input_grad[2] else None) + (None,) * 11
 
 
