@@ -194,6 +194,10 @@ int mggan_bce_rows(int rows, int kind, const float* p, float label, const float*
  * whose best of E samples is closest to the ground truth; gen_abs (T,E,g,b,2), gt (T,b,2) */
 int mggan_pm_target(int b, int T, int E, int g, int mode, const float* gen_abs, const float* gt, int* target,
                     mggan_stream_t stream);
+/* PM-network target 'mgan' as the reference computes it (train.py:606-614; the target softmax runs over a singleton
+ * axis): loss_r = scale * (-target_weight * sum_j log p_j + reg * sum_j p_j log p_j), p = softmax(logits (b,g)) */
+int mggan_pm_mgan_loss(int b, int g, const float* logits, float target_weight, float reg, float scale, float* loss_rows,
+                       float* dlogits, float* probs, mggan_stream_t stream);
 /* Categorical(logits=...).sample((K,)).T on the device (standard.py:217-225): inverse CDF from uniforms u (b,K) */
 int mggan_sample_categorical(int b, int K, int g, const float* logits, const float* u, long long* idx,
                              mggan_stream_t stream);

@@ -186,6 +186,35 @@ __global__ void pm_target_kernel(int b, int T, int E, int g, int mode, const flo
   target[ped] = arg;
 }
 
+// ---- PM-network 'mgan' target (train.py:606-614) ------------------------------------------------------
+// As written in the reference the target softmax runs over the singleton sample axis of branch_out (b,1,g), so
+// every target is 1 and the product broadcasts over the batch: loss = -(1/g) sum_{r,j} log p_rj - reg * mean_r H(p_r),
+// reg = 0.9^epoch, p = softmax(logits).  Per row: loss_r = -tw sum_j log p_j + reg sum_j p_j log p_j with tw = b/g;
+// dlogits_k = scale * [ tw (g p_k - 1) + reg p_k (log p_k - sum_j p_j log p_j) ].
+__global__ void pm_mgan_kernel(int b, int g, const float* __restrict__ logits, float tw, float reg, float scale,
+                               float* loss_rows, float* dlogits, float* probs) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= b) return;
+  const float* z = logits + (size_t)r * g;
+  float mx = -INFINITY;
+  for (int j = 0; j < g; ++j) mx = fmaxf(mx, z[j]);
+  float den = 0.f;
+  for (int j = 0; j < g; ++j) den += __expf(z[j] - mx);
+  const float lden = __logf(den);
+  float slog = 0.f, plogp = 0.f;
+  for (int j = 0; j < g; ++j) {
+    const float lp = z[j] - mx - lden, p = __expf(lp);
+    slog += lp;
+    plogp = fmaf(p, lp, plogp);
+  }
+  loss_rows[r] = scale * (-tw * slog + reg * plogp);
+  for (int j = 0; j < g; ++j) {
+    const float lp = z[j] - mx - lden, p = __expf(lp);
+    if (probs) probs[(size_t)r * g + j] = p;
+    dlogits[(size_t)r * g + j] = scale * (tw * ((float)g * p - 1.f) + reg * p * (lp - plogp));
+  }
+}
+
 // ---- PM-network 'ml' loss (train.py:626-639) ---------------------------------------------
 // gen_abs (T,E,g,b,2); target = softmax_g( mean_E sum_{t,xy} log N(err; 0, sigma) ); loss_r = -sum target*log_softmax(logits)
 __global__ void pm_ml_kernel(int b, int T, int E, int g, const float* __restrict__ gen_abs, const float* __restrict__ gt,
@@ -546,6 +575,16 @@ int mggan_pm_ml_loss(int b, int T, int E, int g, const float* gen_abs, const flo
   hipLaunchKernelGGL(pm_ml_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, T, E, g, gen_abs, gt, logits, sigma,
                      scale, loss_rows, dlogits, probs);
   MG_LAUNCH_CHECK("pm_ml_loss");
+  return MGGAN_OK;
+}
+
+int mggan_pm_mgan_loss(int b, int g, const float* logits, float target_weight, float reg, float scale, float* loss_rows,
+                       float* dlogits, float* probs, hipStream_t stream) {
+  if (b == 0) return MGGAN_OK;
+  MG_CHECK_ARG(logits && loss_rows && dlogits && g > 0, "pm_mgan_loss: bad arguments");
+  hipLaunchKernelGGL(pm_mgan_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, g, logits, target_weight, reg, scale,
+                     loss_rows, dlogits, probs);
+  MG_LAUNCH_CHECK("pm_mgan_loss");
   return MGGAN_OK;
 }
 

@@ -1003,3 +1003,26 @@ class PmMlFn(Function):
     @staticmethod
     def backward(ctx, g):
         return _scaled(ctx.dl, g), None, None, None, None, None, None
+
+
+class PmMganFn(Function):
+    """PM-network 'mgan' objective as the reference computes it (train.py:606-614): the softmax that should turn the
+    discriminator's generator-id logits into targets runs over the singleton sample axis, every target is 1 and the
+    product broadcasts over the batch -> -(1/g) sum_{r,j} log p_rj - 0.9^epoch * mean_r H(p_r)."""
+
+    @staticmethod
+    def forward(ctx, logits, reg, out, probs_out, norm=None):
+        logits = logits.contiguous()
+        b, g = logits.shape
+        n = float(norm or b)
+        loss_rows, dl, probs = _empty(b, like=logits), _empty(b, g, like=logits), _empty(b, g, like=logits)
+        lib.mggan_pm_mgan_loss(b, g, _p(logits), n / g, float(reg), 1.0 / n, _p(loss_rows), _p(dl), _p(probs), _s())
+        lib.mggan_sum(_p(loss_rows), b, 1.0, _p(out), 0, _s())
+        if probs_out is not None:
+            lib.mggan_colmean(_p(probs), b, g, float(b) / n, _p(probs_out), _s())
+        ctx.dl = dl
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _scaled(ctx.dl, g), None, None, None, None

@@ -35,8 +35,9 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
     def __init__(self, generator, discriminator, config, writer):
         super().__init__(generator, discriminator, config, writer)
         assert self.gan_type in ("mgan", "gan"), self.gan_type
-        if config.weighting_target not in ("ml", "l2", "endpoint", "none"):
-            raise ValueError("HIP path implements weighting_target 'ml' (default), 'l2', 'endpoint' and 'none'")
+        if config.weighting_target not in ("ml", "l2", "endpoint", "mgan", "none"):
+            raise ValueError("HIP path implements weighting_target 'ml' (default), 'l2', 'endpoint', 'mgan' and 'none' "
+                             "('disc_scores' raises NotImplementedError in the reference too)")
         if config.l2_loss_type not in ("min_g_z", "min_z", "min_g_min_z", "none"):
             raise ValueError("HIP path implements the per-scene min-over-samples L2 (not 'mse')")
         dev = self.device
@@ -249,6 +250,14 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         if cfg.weighting_target == "ml":
             loss = HF.PmMlFn.apply(net_chooser_weights, gen_out.abs, gt_xy, cfg.sigma, m[M_PM:M_PM + 1],
                                    m[M_PROBS:M_PROBS + g], n_pm)
+        elif cfg.weighting_target == "mgan":
+            assert self.gan_type == "mgan"
+            # the reference runs D on the real trajectories here (train.py:608-610); with its target softmax over a
+            # singleton axis (see PmMganFn) the only trace D's forward leaves is one more update of the BatchNorm
+            # running statistics of its scene encoder
+            with torch.no_grad():
+                self.D.scene_encoder(img if mask is None or bool(mask.all()) else img[mask])
+            loss = HF.PmMganFn.apply(net_chooser_weights, 0.9 ** self.epoch, m[M_PM:M_PM + 1], m[M_PROBS:M_PROBS + g], n_pm)
         else:  # 'l2' / 'endpoint' (train.py:616-624,641-647): cross entropy against the closest generator
             T_, E_, _, b_, _ = gen_out.abs.shape
             target = torch.empty(b_, dtype=torch.int32, device=self.device)

@@ -6,7 +6,7 @@ unmasked b).
 
 Run in the build container only (needs /root/reference):
     python tests/golden/make_golden_masked.py [masked] [variants]
-        -> tests/golden/golden_masked_g2.npz, golden_{obj_ls,obj_mm,wt_l2,wt_endpoint}_g2.npz
+        -> tests/golden/golden_masked_g2.npz, golden_{obj_ls,obj_mm,wt_l2,wt_endpoint,wt_mgan}_g2.npz
 (`variants`: one unmasked iteration each under --gan_obj LS / MM and --weighting_target l2 / endpoint)."""
 import importlib.util
 import os
@@ -120,5 +120,6 @@ if __name__ == "__main__":
         main()
     if "variants" in which:  # other GAN objectives and PM-network targets, one unmasked iteration each
         for tag, extra in (("obj_ls_g2", ["--gan_obj", "LS"]), ("obj_mm_g2", ["--gan_obj", "MM"]),
-                           ("wt_l2_g2", ["--weighting_target", "l2"]), ("wt_endpoint_g2", ["--weighting_target", "endpoint"])):
+                           ("wt_l2_g2", ["--weighting_target", "l2"]), ("wt_endpoint_g2", ["--weighting_target", "endpoint"]),
+                           ("wt_mgan_g2", ["--weighting_target", "mgan"])):
             main(tag, extra, nan=False, keep_init=False)

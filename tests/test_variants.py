@@ -11,7 +11,7 @@ import torch
 from conftest import GOLDEN
 from test_masked import STEPS, _batch, _check
 
-VARIANTS = ["obj_ls_g2", "obj_mm_g2", "wt_l2_g2", "wt_endpoint_g2"]
+VARIANTS = ["obj_ls_g2", "obj_mm_g2", "wt_l2_g2", "wt_endpoint_g2", "wt_mgan_g2"]
 
 
 def _load(tag):
