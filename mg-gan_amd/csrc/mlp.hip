@@ -4,14 +4,14 @@
 // (model/modules/standard.py:99-105), all built by utils.make_mlp (utils.py:134-149).
 //
 // One launch runs the whole chain; a workgroup of four waves owns 16 rows.  The activations of the tile live in
-// a 12.5 KB LDS buffer that is rewritten in place between stages; the WEIGHTS never touch LDS: they are a few
+// two 12.5 KB LDS buffers (ping-pong between stages); the WEIGHTS never touch LDS: they are a few
 // tens of KB and L2-resident, and every wave fetches the B fragments of its own 16-column tiles straight into
 // registers with 16-byte loads along k (the k index inside a 16-wide super-step is permuted so that lane
 // (n, fk) needs 4 consecutive floats: k = 16 S + 4 fk + i for step i of super-step S; A uses the same
 // permutation, so the sum is over the same set).  Products on v_mfma_f32_16x16x4_f32 (exact f32).  A first
 // version kept all weights of the chain as fragment images in LDS (weight-stationary persistent workgroups,
 // 80-130 KB): one workgroup per CU, and its launches sat behind the scene-CNN kernels of the other stream until a
-// CU had that much LDS free (17-22 us per launch in the training step, up to 83 us); this one needs 13 KB.
+// CU had that much LDS free (17-22 us per launch in the training step, up to 83 us); this one needs 25 KB.
 // The backward pass is the same kernel: its stages use the weights transposed (dX = dZ W), the activation
 // derivative enters as an elementwise factor taken from the saved forward output, and the gate gradients dZ_l
 // every stage produces are stored for the weight-gradient GEMMs.
@@ -21,8 +21,6 @@
 #define MC_ROWS 16
 #define MC_LDX 196     // activation row stride (floats): 16-byte aligned rows, 4 mod 32
 #define MC_MAXD 192
-#define MC_MAXS 12     // 16-wide k super-steps of the widest stage
-#define MC_MAXT 3      // 16-column tiles per wave (192 / 16 / 4 waves)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -46,17 +44,18 @@ struct McArgs {
   McStage s[3];
 };
 
-// B fragments of one 16-column tile: b[S] holds W-elements (k = 16 S + 4 fk + i, n = n0 + fi), i = 0..3
-__device__ __forceinline__ void mc_load_b(const McStage& S, int n0, int fi, int fk, int KS, f32x4* b) {
+// B fragments of one 16-column tile for the 2 super-steps of chunk c: b[s] holds the W elements
+// (k = 16 (2c + s) + 4 fk + i, n = n0 + fi), i = 0..3; zero outside the matrix
+__device__ __forceinline__ void mc_load_b(const McStage& S, int n0, int fi, int fk, int c, f32x4* b) {
   const int n = n0 + fi, K = S.K, N = S.N;
   if (!S.trans) {
     const bool vec = (S.ldw & 3) == 0 && (((size_t)S.W & 15) == 0);
     const float* row = S.W + (size_t)(n < N ? n : 0) * S.ldw;
 #pragma unroll
-    for (int s = 0; s < MC_MAXS; ++s) {
-      const int k0 = 16 * s + 4 * fk;
+    for (int s = 0; s < 2; ++s) {
+      const int k0 = 16 * (2 * c + s) + 4 * fk;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (s < KS && n < N) {
+      if (n < N && k0 < K) {
         if (vec && k0 + 3 < K) {
           const float4 t = *reinterpret_cast<const float4*>(row + k0);
           v = f32x4{t.x, t.y, t.z, t.w};
@@ -70,25 +69,32 @@ __device__ __forceinline__ void mc_load_b(const McStage& S, int n0, int fi, int 
     }
   } else {
 #pragma unroll
-    for (int s = 0; s < MC_MAXS; ++s) {
+    for (int s = 0; s < 2; ++s) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int k = 16 * s + 4 * fk + i;
-        if (s < KS && k < K && n < N) v[i] = S.W[(size_t)k * S.ldw + n];
+        const int k = 16 * (2 * c + s) + 4 * fk + i;
+        if (k < K && n < N) v[i] = S.W[(size_t)k * S.ldw + n];
       }
       b[s] = v;
     }
   }
 }
 
+// The kernel is meant to slip in beside the long kernels of the other stream, so it stays small in every
+// resource: 25 KB of LDS and ~128 VGPRs (k is walked in chunks of two 16-wide super-steps, the next chunk's
+// fragments requested while the current one is multiplied) -- a version that held the whole K of A and B in
+// registers (332 VGPRs: one wave per SIMD) waited for a free SIMD behind the scene-CNN kernels like the
+// LDS-heavy one before it.
 __global__ __launch_bounds__(256) void mlp_chain_kernel(McArgs a) {
-  __shared__ __attribute__((aligned(16))) float act[MC_ROWS * MC_LDX];
+  __shared__ __attribute__((aligned(16))) float tiles[2][MC_ROWS * MC_LDX];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fi = lane & 15, fk = lane >> 4;
   const int r0 = blockIdx.x * MC_ROWS;
+  float* act = tiles[0];
+  float* nxt = tiles[1];
 
   {  // input tile, zero-padded to a multiple of 16 columns and to 16 rows; optional x *= act'(y) (+ copy out)
-    const int K0 = a.K0, KP = (K0 + 15) & ~15;
+    const int K0 = a.K0, KP = (K0 + 31) & ~31;  // products walk k in chunks of 32: pad with zeros
     const bool vec = (a.ldx & 3) == 0 && (K0 & 3) == 0 && (((size_t)a.X & 15) == 0) && !a.in_mul;
     if (vec) {  // <= 3 quads per thread, all requested before the first LDS store
       const int qn = KP >> 2, total = MC_ROWS * qn;
@@ -120,25 +126,20 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(McArgs a) {
     }
   }
 
-  f32x4 bcur[MC_MAXS];
 #pragma unroll 1
   for (int si = 0; si < a.n; ++si) {
     const McStage& S = a.s[si];
-    const int N = S.N, KS = (S.K + 15) >> 4, ntt = (N + 15) >> 4;
+    const int N = S.N, NC = (S.K + 31) >> 5, ntt = (N + 15) >> 4;  // chunks of 32 k, 16-column tiles
     const bool last = si == a.n - 1;
-    __syncthreads();  // the tile holds this stage's input
-    f32x4 av[MC_MAXS];
-#pragma unroll
-    for (int s = 0; s < MC_MAXS; ++s)
-      av[s] = s < KS ? *reinterpret_cast<const f32x4*>(&act[fi * MC_LDX + 16 * s + 4 * fk]) : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bnext[MC_MAXS];
-    if (si == 0 && w < ntt) mc_load_b(S, 16 * w, fi, fk, KS, bcur);  // later stages: requested during the previous one
-    __syncthreads();  // every wave holds its A fragments: the outputs may overwrite the tile
+    __syncthreads();  // `act` holds this stage's input (and nobody still reads `nxt`)
+    const float* arow = &act[fi * MC_LDX + 4 * fk];
 #pragma unroll 1
     for (int j = w; j < ntt; j += 4) {
-      const bool more = j + 4 < ntt;
-      if (more) mc_load_b(S, 16 * (j + 4), fi, fk, KS, bnext);  // in flight during this tile's products
       const int col = 16 * j + fi;
+      f32x4 av[2], bv[2], an[2], bn[2];
+      mc_load_b(S, 16 * j, fi, fk, 0, bv);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) av[s] = *reinterpret_cast<const f32x4*>(arow + 16 * s);
       // saved activation for the derivative factor (rows 4 fk + r of this lane's D registers)
       float mulv[4] = {1.f, 1.f, 1.f, 1.f};
       if (S.mul_src) {
@@ -152,14 +153,25 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(McArgs a) {
       }
       const float bias = (S.bias && col < N) ? S.bias[col] : 0.f;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the MFMA latency
+#pragma unroll 1
+      for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) {  // next chunk's fragments: in flight during this chunk's products
+          mc_load_b(S, 16 * j, fi, fk, c + 1, bn);
 #pragma unroll
-      for (int s = 0; s < MC_MAXS; ++s)
-        if (s < KS) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][0], bcur[s][0], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][1], bcur[s][1], acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][2], bcur[s][2], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][3], bcur[s][3], acc1, 0, 0, 0);
+          for (int s = 0; s < 2; ++s) an[s] = *reinterpret_cast<const f32x4*>(arow + 32 * (c + 1) + 16 * s);
         }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {  // (super-steps past K multiply zero-padded columns by zero weights)
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][0], bv[s][0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][1], bv[s][1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][2], bv[s][2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][3], bv[s][3], acc1, 0, 0, 0);
+        }
+        if (c + 1 < NC) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) { av[s] = an[s]; bv[s] = bn[s]; }
+        }
+      }
       // D fragment: lane l, register r <-> row (l>>4)*4 + r, column l&15 of the 16x16 tile
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -172,17 +184,19 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(McArgs a) {
             *o = S.accumulate ? (*o + v) : v;
           }
         }
-        if (!last) act[row * MC_LDX + col] = v;  // columns N..16*ntt become the zero padding of the next K
-      }
-      if (more) {
-#pragma unroll
-        for (int s = 0; s < MC_MAXS; ++s) bcur[s] = bnext[s];
+        if (!last) nxt[row * MC_LDX + col] = v;
       }
     }
-    if (!last) {  // the weights of the next stage do not depend on this one: fetch them under its tail
-      const McStage& Sn = a.s[si + 1];
-      if (w < ((Sn.N + 15) >> 4)) mc_load_b(Sn, 16 * w, fi, fk, (Sn.K + 15) >> 4, bcur);
+    if (!last) {  // zero the padding of the next stage's K: columns 16*ntt .. next multiple of 32
+      const int c0 = 16 * ntt, c1 = (c0 + 31) & ~31;
+      for (int e = tid; e < MC_ROWS * (c1 - c0); e += 256) {
+        const int r = e / (c1 - c0), c = c0 + e - r * (c1 - c0);
+        if (c < MC_LDX) nxt[r * MC_LDX + c] = 0.f;
+      }
     }
+    float* t = act;
+    act = nxt;
+    nxt = t;
   }
 }
 
