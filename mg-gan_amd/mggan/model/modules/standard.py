@@ -115,7 +115,7 @@ class MultiGenerator(FlatModule):
 
     # -- reference surface -------------------------------------------------------------------
     def forward(self, in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=None, num_samples=5, mask=None,
-                trunk=None):
+                trunk=None, logits=None):
         """Returns (GeneratorOutput(rel, abs), net_chooser_out (b_m, g), sampled_gen_idxs (b_m, K) int64).
         abs/rel: (pred_len, K, b_m, 2) or (pred_len, K, g, b_m, 2) when all_gen_out."""
         if img is None:
@@ -146,8 +146,8 @@ class MultiGenerator(FlatModule):
             shape = (self.pred_len, K, g, b, 2)
             return GeneratorOutput(pr.view(shape), pa.view(shape)), net_chooser_out, sampled_gen_idxs
 
-        with torch.no_grad():
-            net_chooser_out, sampled_gen_idxs = self.get_samples(enc_h, num_samples)
+        with torch.no_grad():  # `logits`: the PM-network output of the same trunk and weights, computed by an earlier call
+            net_chooser_out, sampled_gen_idxs = self.get_samples(enc_h, num_samples, logits=logits)
         if sampled_gen_idxs.is_cuda and getattr(self.rng, "on_device", False):
             rows = HF.device_rollout_rows(sampled_gen_idxs, g)  # no host round trip
         else:
@@ -159,9 +159,11 @@ class MultiGenerator(FlatModule):
         shape = (self.pred_len, K, b, 2)
         return GeneratorOutput(pr.view(shape), pa.view(shape)), net_chooser_out, sampled_gen_idxs
 
-    def get_samples(self, enc_h, num_samples=5):
+    def get_samples(self, enc_h, num_samples=5, logits=None):
         """Returns (logits (b, g), generator indexes (b, num_samples))."""
-        if self.use_pinet:
+        if logits is not None:
+            net_chooser_out = logits
+        elif self.use_pinet:
             net_chooser_out = self._chooser(enc_h)
         else:
             net_chooser_out = self.net_prior.expand(enc_h.size(0), -1)

@@ -122,16 +122,18 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         # come from the numpy generator, noise and sampling from torch's: reordering the two is seed-neutral.)
         with HF.branch(1), torch.no_grad():
             noise = self.rng.noise(1, self.config.noise_dim, sub_batches, self.device)
-            gen_out, _, gen_labels_gt = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
-                                               num_samples=1, mask=loss_mask,
-                                               trunk=None if g_trunk is None else tuple(t.detach() for t in g_trunk))
+            gen_out, g_logits, gen_labels_gt = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
+                                                      num_samples=1, mask=loss_mask,
+                                                      trunk=None if g_trunk is None else tuple(t.detach() for t in g_trunk))
+            if shared is not None and g_trunk is not None:
+                shared["g_logits"] = g_logits  # same trunk, same weights in the generator step: not recomputed there
             rows_d = getattr(self.G, "last_rows", None)
         # history LSTM + scene CNN of D are identical in the real and the fake pass: run them once
         ctx = self.D.history_context(in_dxdy, img, passes=2) if (loss_mask is None and self.share_context) else None
         pair = ctx is not None and getattr(self, "pair_passes", True)
         if pair:
             # real and fake pass batched into one 2b-row pass (same results: every operator is row-wise / per scene)
-            HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, None if rows_d is None else rows_d.row_gen_pos, which=1)
+            HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, g_logits, None if rows_d is None else rows_d.row_gen_pos, which=1)
             real_result, disc_out, branch_out = self.D.forward_pair(in_xy, in_dxdy, gt_dxdy, gen_out.rel, sub_batches, ctx)
             if self.gan_type == "mgan":
                 disc_out = (disc_out, branch_out)
@@ -145,7 +147,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         real_loss = HF.BceMeanFn.apply(real_result.t().reshape(-1), label_real, None, None, m[M_REAL:M_REAL + 1], n_real,
                                        kind)
         if not pair:
-            HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, None if rows_d is None else rows_d.row_gen_pos, which=1)
+            HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, g_logits, None if rows_d is None else rows_d.row_gen_pos, which=1)
             disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask, context=ctx)
         losses = [real_loss]
         items = []
@@ -189,7 +191,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             noise = self.rng.noise(cfg.num_samples, cfg.noise_dim, sub_batches, self.device)
             gen_out, _, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
                                           mask=loss_mask, num_samples=cfg.num_samples,
-                                          trunk=None if shared is None else shared.get("g_trunk"))
+                                          trunk=None if shared is None else shared.get("g_trunk"),
+                                          logits=None if shared is None else shared.get("g_logits"))
             losses, grads, items = [], [], []
             if cfg.l2_loss_type != "none":
                 bm = gen_out.abs.shape[2]
