@@ -195,21 +195,24 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                                           logits=None if shared is None else shared.get("g_logits"))
             losses, grads, items = [], [], []
             if cfg.l2_loss_type != "none":
-                bm = gen_out.abs.shape[2]
-                sse = sub_batches
-                if bm != b:
-                    # masked batch: the reference slices the MASKED predictions with the UNMASKED scene bounds
-                    # (train.py:67-68; python slices clip at the end) and still divides by the unmasked b (:73)
-                    sse = [[min(int(s0), bm), min(int(e0), bm)] for s0, e0 in sub_batches]
-                    sse = [se for se in sse if se[1] > se[0]]
-                tb = HF.scene_tables(sse, bm, self.device)
-                min_l2 = HF.L2MinSceneFn.apply(gen_out.abs, gt_xy, tb, self._global(b), m[M_L2:M_L2 + 1])
-                losses.append(min_l2)
-                grads.append(self._w["l2"])
-                items.append(("train/L2_loss", M_L2))
+                # min-over-samples L2 (three small launches) beside the discriminator pass on the predictions; autograd
+                # runs its backward on the same branch stream
+                with HF.branch(1):
+                    bm = gen_out.abs.shape[2]
+                    sse = sub_batches
+                    if bm != b:
+                        # masked batch: the reference slices the MASKED predictions with the UNMASKED scene bounds
+                        # (train.py:67-68; python slices clip at the end) and still divides by the unmasked b (:73)
+                        sse = [[min(int(s0), bm), min(int(e0), bm)] for s0, e0 in sub_batches]
+                        sse = [se for se in sse if se[1] > se[0]]
+                    tb = HF.scene_tables(sse, bm, self.device)
+                    min_l2 = HF.L2MinSceneFn.apply(gen_out.abs, gt_xy, tb, self._global(b), m[M_L2:M_L2 + 1])
+                    losses.append(min_l2)
+                    grads.append(self._w["l2"])
+                    items.append(("train/L2_loss", M_L2))
 
             if ctx_d is not None:
-                HF.join_branch(*ctx_d)
+                HF.join_branch(*ctx_d, which=0)
             disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask,
                               context=ctx_d)
         finally:
