@@ -102,6 +102,10 @@ def flops_of(name, a):
         return float(a[0]) * 2 * (96 + 2048 + 64)
     if name == "mggan_social_pairs_bwd":
         return float(a[0]) * 2 * (64 + 2048)
+    if name == "mggan_social_attention_fwd":
+        return float(a[2]) * 2 * (96 + 2048 + 64 + a[3])
+    if name == "mggan_social_attention_bwd":
+        return float(a[2]) * 2 * (64 + 2048 + 3 * a[4] + 65)
     return 0.0
 
 

@@ -140,6 +140,22 @@ int mggan_social_pairs_bwd(int P, int b, const int* pair_j, const int* ped_prow,
                            const float* dsigma, const float* vc, const float* l1, const float* l2, const float* W2,
                            float* dz2, float* dz1, float* dvc, mggan_stream_t stream);
 
+/* Fused launches of the same math over pedestrian-aligned tiles: tiles[t] = {ped0, ped1, first pair, pair count},
+ * consecutive pedestrians whose pairs are contiguous and number <= 64 (host-built once per batch; a scene of more
+ * than 64 pedestrians needs the unfused entry points above).  _fwd = pairs_fwd + softmax_fwd in one launch (sigma
+ * never reaches HBM), _bwd = softmax_bwd + pairs_bwd in one launch plus one launch for both column reductions. */
+int mggan_social_attention_fwd(int n_tiles, const int* tiles, int P, int H, const int* pair_i, const int* pair_j,
+                               const int* ped_prow, const int* ped_s0, const int* ped_n, const float* xy_last,
+                               const float* dxdy_last, const float* W1, const float* b1, const float* W2,
+                               const float* b2, const float* vc, const float* h, int ld_h, float* feat, float* l1,
+                               float* l2, float* att, float* S, int ld_s, mggan_stream_t stream);
+int mggan_social_attention_bwd(int n_tiles, const int* tiles, int P, int b, int H, const int* pair_i,
+                               const int* pair_j, const int* ped_prow, const int* ped_s0, const int* ped_n,
+                               const float* att, const float* h, int ld_h, const float* dS, int ld_ds,
+                               const float* vc, const float* l1, const float* l2, const float* W2, float* dsigma,
+                               float* dz2, float* dz1, float* dvc, float* dh, int ld_dh, int accumulate_dh,
+                               mggan_stream_t stream);
+
 /* ---- scene CNN + physical attention -----------------------------------------------------
  * reference: cnn.py:119-160 (Conv_Blocks), :275-282 (CNN.forward), :109-116 (AttentionGlobal.forward)
  * img (B,4,33,33) -> y1 raw (B,C,33,36: rows padded to 36 floats) -> [BN+ReLU+pool] -> y2 raw (B,C,16,16) -> [BN+ReLU+pool]

@@ -220,6 +220,192 @@ __global__ __launch_bounds__(256) void social_dvc_kernel(int b, int P, const int
   dvc[(size_t)j * (L2 + 1) + m] = acc;
 }
 
+// ---- fused launches over pedestrian-aligned tiles ------------------------------------------------
+// A tile is a run of consecutive pedestrians whose in-scene pairs are contiguous in the pair list and
+// number at most 64 (tile = {ped0, ped1, first pair, pair count}, built on the host once per batch).
+// Every pair of a pedestrian then sits in the same workgroup, so its softmax row never leaves LDS:
+// forward = pair MLP + scores + softmax + pooling in one launch, backward = softmax adjoint + pair MLP
+// adjoint in one launch, and the two column reductions (dh, dvc) share a third.
+
+template <int H>
+__global__ __launch_bounds__(256) void social_fwd_fused_kernel(
+    const int4* __restrict__ tiles, int P, const int* __restrict__ pair_i, const int* __restrict__ pair_j,
+    const int* __restrict__ prow, const int* __restrict__ s0a, const int* __restrict__ na,
+    const float* __restrict__ xy, const float* __restrict__ dxy, const float* __restrict__ W1,
+    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+    const float* __restrict__ vc, const float* __restrict__ h, int ld_h, float* feat, float* l1s, float* l2s,
+    float* att, float* S, int ld_s) {
+  __shared__ float part[4][64];
+  __shared__ float sg_s[64], a_s[64];
+  const int4 tl = tiles[blockIdx.x];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p0 = tl.z, np = tl.w;
+  if (np > 0) {  // workgroup-uniform
+    const bool ok = lane < np;
+    const int p = p0 + (ok ? lane : 0);
+    const int i = pair_i[p], j = pair_j[p];
+    float f[3];
+    pair_features(xy, dxy, i, j, f);
+    float l1[L1];
+#pragma unroll
+    for (int k = 0; k < L1; ++k) {
+      float s = b1[k];
+      s = fmaf(W1[k * 3 + 0], f[0], s);
+      s = fmaf(W1[k * 3 + 1], f[1], s);
+      s = fmaf(W1[k * 3 + 2], f[2], s);
+      l1[k] = fmaxf(s, 0.f);
+    }
+    const float* v = vc + (size_t)j * (L2 + 1);
+    float sg = 0.f;
+    const bool save = l1s != nullptr;
+#pragma unroll 4
+    for (int mm = 0; mm < L2 / 4; ++mm) {
+      const int m = w * (L2 / 4) + mm;
+      float s = b2[m];
+#pragma unroll
+      for (int k = 0; k < L1; ++k) s = fmaf(W2[m * L1 + k], l1[k], s);
+      s = fmaxf(s, 0.f);
+      if (save && ok) l2s[(size_t)m * P + p] = s;
+      sg = fmaf(s, v[m], sg);
+    }
+    part[w][lane] = sg;
+    if (save && ok) {
+      if (w == 0) {
+        feat[p] = f[0];
+        feat[(size_t)P + p] = f[1];
+        feat[(size_t)2 * P + p] = f[2];
+      }
+#pragma unroll
+      for (int k = 0; k < L1; ++k)
+        if ((k >> 3) == w) l1s[(size_t)k * P + p] = l1[k];
+    }
+    __syncthreads();
+    const float tot = v[L2] + (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const float sc = (i == j) ? -1000.0f : tot;  // social.py:25
+    if (w == 0) sg_s[lane] = sc;
+    __syncthreads();
+    // every wave walks its lanes' softmax rows (same values in all four; wave 0 publishes)
+    const int seg0 = prow[i] - p0, n = na[i];
+    float mx = -INFINITY;
+    for (int jj = 0; jj < n; ++jj) mx = fmaxf(mx, sg_s[seg0 + jj]);
+    float den = 0.f;
+    for (int jj = 0; jj < n; ++jj) den += __expf(sg_s[seg0 + jj] - mx);
+    const float a = __expf(sc - mx) * (1.0f / den);
+    if (w == 0) {
+      a_s[lane] = a;
+      if (ok) att[p] = a;
+    }
+    __syncthreads();
+  }
+  const int k = threadIdx.x % H;
+  for (int q = tl.x + threadIdx.x / H; q < tl.y; q += 256 / H) {
+    const int n = na[q];
+    float acc = 0.f;
+    if (n > 1) {  // social.py:19-20: a lone pedestrian pools nothing
+      const int seg0 = prow[q] - p0, s0 = s0a[q];
+      for (int jj = 0; jj < n; ++jj) acc = fmaf(a_s[seg0 + jj], h[(size_t)(s0 + jj) * ld_h + k], acc);
+    }
+    S[(size_t)q * ld_s + k] = acc;
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void social_bwd_fused_kernel(
+    const int4* __restrict__ tiles, int P, const int* __restrict__ pair_i, const int* __restrict__ pair_j,
+    const int* __restrict__ prow, const int* __restrict__ na, const float* __restrict__ att,
+    const float* __restrict__ h, int ld_h, const float* __restrict__ dS, int ld_ds, const float* __restrict__ vc,
+    const float* __restrict__ l1s, const float* __restrict__ l2s, const float* __restrict__ W2, float* dsigma,
+    float* dz2, float* dz1) {
+  __shared__ float part[4][L1][64];
+  __shared__ float dpart[4][64];
+  __shared__ float ad_s[64];
+  const int4 tl = tiles[blockIdx.x];
+  const int p0 = tl.z, np = tl.w;
+  if (np == 0) return;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool ok = lane < np;
+  const int p = p0 + (ok ? lane : 0);
+  const int i = pair_i[p], j = pair_j[p];
+  // da_ij = dS_i . h_j, wave w sums its quarter of the hidden units
+  {
+    const float* a = dS + (size_t)i * ld_ds + w * (H / 4);
+    const float* bq = h + (size_t)j * ld_h + w * (H / 4);
+    float d = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < H / 4; ++kk) d = fmaf(a[kk], bq[kk], d);
+    dpart[w][lane] = d;
+  }
+  const float a_ij = att[p];
+  __syncthreads();
+  const float da = (dpart[0][lane] + dpart[1][lane]) + (dpart[2][lane] + dpart[3][lane]);
+  if (w == 0) ad_s[lane] = a_ij * da;
+  __syncthreads();
+  const int seg0 = prow[i] - p0, n = na[i];
+  float dot = 0.f;
+  for (int jj = 0; jj < n; ++jj) dot += ad_s[seg0 + jj];
+  const float dsg = a_ij * (da - dot);
+  if (w == 0 && ok) dsigma[p] = dsg;
+  const float* v = vc + (size_t)j * (L2 + 1);
+  float d1[L1];
+#pragma unroll
+  for (int k = 0; k < L1; ++k) d1[k] = 0.f;
+#pragma unroll 4
+  for (int mm = 0; mm < L2 / 4; ++mm) {
+    const int m = w * (L2 / 4) + mm;
+    const float z = l2s[(size_t)m * P + p] > 0.f ? dsg * v[m] : 0.f;
+    if (ok) dz2[(size_t)m * P + p] = z;
+#pragma unroll
+    for (int k = 0; k < L1; ++k) d1[k] = fmaf(W2[m * L1 + k], z, d1[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < L1; ++k) part[w][k][lane] = d1[k];
+  __syncthreads();
+#pragma unroll
+  for (int kk = 0; kk < L1 / 4; ++kk) {
+    const int k = w * (L1 / 4) + kk;
+    const float t = (part[0][k][lane] + part[1][k][lane]) + (part[2][k][lane] + part[3][k][lane]);
+    if (ok) dz1[(size_t)k * P + p] = l1s[(size_t)k * P + p] > 0.f ? t : 0.f;
+  }
+}
+
+// the two reductions over i for a fixed neighbour j in one launch: workgroups [0, nb_dh) do
+// dh_j = sum_i a_ij dS_i, the rest dvc_j = sum_i dsigma_ij [l2_ij | 1]
+template <int H>
+__global__ __launch_bounds__(256) void social_dh_dvc_kernel(int b, int P, int nb_dh, const int* __restrict__ prow,
+                                                            const int* __restrict__ s0a, const int* __restrict__ na,
+                                                            const float* __restrict__ att,
+                                                            const float* __restrict__ dS, int ld_ds, float* dh,
+                                                            int ld_dh, int accumulate,
+                                                            const float* __restrict__ dsigma,
+                                                            const float* __restrict__ l2s, float* dvc) {
+  if ((int)blockIdx.x < nb_dh) {
+    const int j = blockIdx.x * (256 / H) + threadIdx.x / H, k = threadIdx.x % H;
+    if (j >= b) return;
+    const int n = na[j];
+    float acc = 0.f;
+    if (n > 1) {
+      const int s0 = s0a[j], lj = j - s0;
+      for (int i = 0; i < n; ++i) acc = fmaf(att[prow[s0 + i] + lj], dS[(size_t)(s0 + i) * ld_ds + k], acc);
+    }
+    float* d = dh + (size_t)j * ld_dh + k;
+    *d = accumulate ? (*d + acc) : acc;
+    return;
+  }
+  const long t = (long)(blockIdx.x - nb_dh) * 256 + threadIdx.x;
+  if (t >= (long)b * (L2 + 1)) return;
+  const int m = (int)(t / b), j = (int)(t % b);
+  const int n = na[j];
+  float acc = 0.f;
+  if (n > 1) {
+    const int s0 = s0a[j], lj = j - s0;
+    for (int i = 0; i < n; ++i) {
+      const int p = prow[s0 + i] + lj;
+      acc = fmaf(dsigma[p], m < L2 ? l2s[(size_t)m * P + p] : 1.0f, acc);
+    }
+  }
+  dvc[(size_t)j * (L2 + 1) + m] = acc;
+}
+
 // W3b[f][0..63] = W3[f][:], W3b[f][64] = b3[f]
 __global__ void social_w3b_kernel(const float* __restrict__ W3, const float* __restrict__ b3, float* W3b, int F) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -297,6 +483,65 @@ int mggan_social_pairs_bwd(int P, int b, const int* pair_j, const int* ped_prow,
                        ped_s0, ped_n, dsigma, l2, dvc);
     MG_LAUNCH_CHECK("social_dvc");
   }
+  return MGGAN_OK;
+}
+
+int mggan_social_attention_fwd(int n_tiles, const int* tiles, int P, int H, const int* pair_i, const int* pair_j,
+                               const int* ped_prow, const int* ped_s0, const int* ped_n, const float* xy_last,
+                               const float* dxdy_last, const float* W1, const float* b1, const float* W2,
+                               const float* b2, const float* vc, const float* h, int ld_h, float* feat, float* l1,
+                               float* l2, float* att, float* S, int ld_s, hipStream_t stream) {
+  MG_CHECK_ARG(H == 32 || H == 64, "social_attention_fwd: hidden size %d not built (32 or 64)", H);
+  MG_CHECK_ARG(n_tiles >= 0 && P >= 0, "social_attention_fwd: negative size");
+  if (n_tiles == 0) return MGGAN_OK;
+  MG_CHECK_ARG(tiles && ped_prow && ped_s0 && ped_n && h && S, "social_attention_fwd: null pointer");
+  MG_CHECK_ARG(P == 0 || (pair_i && pair_j && xy_last && dxdy_last && W1 && b1 && W2 && b2 && vc && att),
+               "social_attention_fwd: null pointer");
+  MG_CHECK_ARG((feat == nullptr) == (l1 == nullptr) && (l1 == nullptr) == (l2 == nullptr),
+               "social_attention_fwd: save buffers must be all set or all NULL");
+  const int4* t4 = reinterpret_cast<const int4*>(tiles);
+  if (H == 32)
+    hipLaunchKernelGGL((social_fwd_fused_kernel<32>), dim3(n_tiles), dim3(256), 0, stream, t4, P, pair_i, pair_j,
+                       ped_prow, ped_s0, ped_n, xy_last, dxdy_last, W1, b1, W2, b2, vc, h, ld_h, feat, l1, l2, att, S,
+                       ld_s);
+  else
+    hipLaunchKernelGGL((social_fwd_fused_kernel<64>), dim3(n_tiles), dim3(256), 0, stream, t4, P, pair_i, pair_j,
+                       ped_prow, ped_s0, ped_n, xy_last, dxdy_last, W1, b1, W2, b2, vc, h, ld_h, feat, l1, l2, att, S,
+                       ld_s);
+  MG_LAUNCH_CHECK("social_attention_fwd");
+  return MGGAN_OK;
+}
+
+int mggan_social_attention_bwd(int n_tiles, const int* tiles, int P, int b, int H, const int* pair_i,
+                               const int* pair_j, const int* ped_prow, const int* ped_s0, const int* ped_n,
+                               const float* att, const float* h, int ld_h, const float* dS, int ld_ds,
+                               const float* vc, const float* l1, const float* l2, const float* W2, float* dsigma,
+                               float* dz2, float* dz1, float* dvc, float* dh, int ld_dh, int accumulate_dh,
+                               hipStream_t stream) {
+  MG_CHECK_ARG(H == 32 || H == 64, "social_attention_bwd: hidden size %d not built (32 or 64)", H);
+  MG_CHECK_ARG(n_tiles >= 0 && P >= 0 && b >= 0, "social_attention_bwd: negative size");
+  if (b == 0) return MGGAN_OK;
+  MG_CHECK_ARG(tiles && ped_prow && ped_s0 && ped_n && h && dS && dh && dvc, "social_attention_bwd: null pointer");
+  const int4* t4 = reinterpret_cast<const int4*>(tiles);
+  if (P > 0) {
+    MG_CHECK_ARG(pair_i && pair_j && att && vc && l1 && l2 && W2 && dsigma && dz2 && dz1,
+                 "social_attention_bwd: null pointer");
+    if (H == 32)
+      hipLaunchKernelGGL((social_bwd_fused_kernel<32>), dim3(n_tiles), dim3(256), 0, stream, t4, P, pair_i, pair_j,
+                         ped_prow, ped_n, att, h, ld_h, dS, ld_ds, vc, l1, l2, W2, dsigma, dz2, dz1);
+    else
+      hipLaunchKernelGGL((social_bwd_fused_kernel<64>), dim3(n_tiles), dim3(256), 0, stream, t4, P, pair_i, pair_j,
+                         ped_prow, ped_n, att, h, ld_h, dS, ld_ds, vc, l1, l2, W2, dsigma, dz2, dz1);
+    MG_LAUNCH_CHECK("social_attention_bwd");
+  }
+  const int nb_dh = cdiv(b, 256 / H), nb_dvc = cdiv((long)b * (L2 + 1), 256);
+  if (H == 32)
+    hipLaunchKernelGGL((social_dh_dvc_kernel<32>), dim3(nb_dh + nb_dvc), dim3(256), 0, stream, b, P, nb_dh, ped_prow,
+                       ped_s0, ped_n, att, dS, ld_ds, dh, ld_dh, accumulate_dh, dsigma, l2, dvc);
+  else
+    hipLaunchKernelGGL((social_dh_dvc_kernel<64>), dim3(nb_dh + nb_dvc), dim3(256), 0, stream, b, P, nb_dh, ped_prow,
+                       ped_s0, ped_n, att, dS, ld_ds, dh, ld_dh, accumulate_dh, dsigma, l2, dvc);
+  MG_LAUNCH_CHECK("social_dh_dvc");
   return MGGAN_OK;
 }
 

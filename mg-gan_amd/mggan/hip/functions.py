@@ -493,12 +493,28 @@ class SceneTables:
                 ped_prow[s:e] = P + np.arange(n) * n
                 P += n * n
         self.P, self.b, self.S = P, b, len(sse)
+        # tiles of the fused social kernels: runs of consecutive pedestrians with <= 64 pairs between them
+        # ({ped0, ped1, first pair, pair count}); None when a scene is too large for one tile
+        self.tiles, self.n_tiles = None, 0
+        if b and int(ped_n.max()) <= 64:
+            tl, q0, p0, cnt = [], 0, 0, 0
+            for q in range(b):
+                nq = int(ped_n[q]) if ped_n[q] > 1 else 0
+                if cnt + nq > 64 or q - q0 >= 64:
+                    tl.append((q0, q, p0, cnt))
+                    q0, p0, cnt = q, p0 + cnt, 0
+                cnt += nq
+            tl.append((q0, b, p0, cnt))
+            self.tiles_host = np.asarray(tl, np.int32)
+            self.n_tiles = len(tl)
         cat = (lambda l: np.concatenate(l).astype(np.int32)) if pi else (lambda l: np.zeros(0, np.int32))
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.pair_i, self.pair_j = to(cat(pi)), to(cat(pj))
         self.ped_s0, self.ped_n, self.ped_prow, self.ped_scene = to(ped_s0), to(ped_n), to(ped_prow), to(ped_scene)
         self.scenes = to(np.asarray(sse, np.int32).reshape(-1, 2))
         self.seq_start_end = sse
+        if self.n_tiles:
+            self.tiles = to(self.tiles_host)
 
 
 _TABLE_CACHE = {}
@@ -539,16 +555,22 @@ class SocialAttentionFn(Function):
             TRACE_NOTES["mlp_chain_flops"].append(2.0 * b * (Hh * Fd + Fd * 65))
         lib.mggan_mlp_chain(ctypes.addressof(a), st)
         P = tb.P
-        sigma = _empty(max(P, 1), like=h)
         feat = _empty(3, max(P, 1), like=h) if save else None      # feature-major [feature][pair]
         l1 = _empty(32, max(P, 1), like=h) if save else None
         l2 = _empty(64, max(P, 1), like=h) if save else None
-        lib.mggan_social_pairs_fwd(P, _p(tb.pair_i), _p(tb.pair_j), _p(xy_last), _p(dxdy_last), _p(w1), _p(b1), _p(w2),
-                                   _p(b2), _p(vc), _p(feat), _p(l1), _p(l2), _p(sigma), st)
         att = _empty(max(P, 1), like=h)
         S = _empty(b, Hh, like=h)
-        lib.mggan_social_softmax_fwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(sigma), _p(h), ld_h,
-                                     _p(att), _p(S), Hh, st)
+        if tb.tiles is not None:  # pair MLP, scores, softmax and pooling in one launch
+            lib.mggan_social_attention_fwd(tb.n_tiles, _p(tb.tiles), P, Hh, _p(tb.pair_i), _p(tb.pair_j),
+                                           _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(xy_last), _p(dxdy_last),
+                                           _p(w1), _p(b1), _p(w2), _p(b2), _p(vc), _p(h), ld_h, _p(feat), _p(l1), _p(l2),
+                                           _p(att), _p(S), Hh, st)
+        else:  # a scene of more than 64 pedestrians does not fit a tile
+            sigma = _empty(max(P, 1), like=h)
+            lib.mggan_social_pairs_fwd(P, _p(tb.pair_i), _p(tb.pair_j), _p(xy_last), _p(dxdy_last), _p(w1), _p(b1),
+                                       _p(w2), _p(b2), _p(vc), _p(feat), _p(l1), _p(l2), _p(sigma), st)
+            lib.mggan_social_softmax_fwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(sigma), _p(h), ld_h,
+                                         _p(att), _p(S), Hh, st)
         if save:
             ctx.tb, ctx.owner, ctx.ld_h = tb, owner, ld_h
             ctx.train_w1, ctx.train_w3 = w1.requires_grad, w3.requires_grad
@@ -566,13 +588,19 @@ class SocialAttentionFn(Function):
         dS, ld_ds = _rows2d(dS)
         dsigma = _empty(max(P, 1), like=h)
         dh = _empty(b, Hh, like=h)
-        lib.mggan_social_softmax_bwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(att), _p(h), ld_h, _p(dS),
-                                     ld_ds, _p(dsigma), _p(dh), Hh, 0, st)
         dz2 = _empty(64, max(P, 1), like=h)
         dz1 = _empty(32, max(P, 1), like=h)
         dvc = _empty(b, 65, like=h)
-        lib.mggan_social_pairs_bwd(P, b, _p(tb.pair_j), _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(dsigma), _p(vc),
-                                   _p(l1), _p(l2), _p(w2), _p(dz2), _p(dz1), _p(dvc), st)
+        if tb.tiles is not None:
+            lib.mggan_social_attention_bwd(tb.n_tiles, _p(tb.tiles), P, b, Hh, _p(tb.pair_i), _p(tb.pair_j),
+                                           _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(att), _p(h), ld_h, _p(dS),
+                                           ld_ds, _p(vc), _p(l1), _p(l2), _p(w2), _p(dsigma), _p(dz2), _p(dz1), _p(dvc),
+                                           _p(dh), Hh, 0, st)
+        else:
+            lib.mggan_social_softmax_bwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(att), _p(h), ld_h,
+                                         _p(dS), ld_ds, _p(dsigma), _p(dh), Hh, 0, st)
+            lib.mggan_social_pairs_bwd(P, b, _p(tb.pair_j), _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(dsigma),
+                                       _p(vc), _p(l1), _p(l2), _p(w2), _p(dz2), _p(dz1), _p(dvc), st)
         if ctx.train_w1:
             with side_stream(dz2, dz1, l1, feat):
                 wgrad(dz2, P, l1, P, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64, fm=1)

@@ -220,3 +220,48 @@ def test_mlp_chain_matches_torch(rows, dims, acts, train_w, need_dx):
             np.testing.assert_allclose(l.bias.grad.cpu().numpy(), r.bias.grad.float().numpy(), rtol=1e-4, atol=2e-5)
         else:
             assert l.weight.grad is None or float(l.weight.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("H,sizes", [(32, [1, 2, 20, 1, 1, 7, 33, 64, 3, 5, 1]), (64, [20] * 7 + [1] * 70 + [13, 2]),
+                                     (32, [1, 1, 1])])
+def test_social_attention_tiles_match_the_unfused_launches(H, sizes):
+    """The tile-fused social attention (one forward launch, two backward launches) against the per-stage entry
+    points on ragged scenes: lone pedestrians, a scene that fills a tile, tiles that end mid-batch."""
+    from mggan.hip import functions as HF
+    from mggan.model.modules.social import SocialAttention
+
+    dev = _dev()
+    torch.manual_seed(5)
+    mod = SocialAttention(16, H).to(dev)
+    mod.flatten_parameters_()
+    b = sum(sizes)
+    sse, s = [], 0
+    for n in sizes:
+        sse.append([s, s + n])
+        s += n
+    xy = torch.randn(8, b, 2, device=dev) * 3
+    dxy = torch.randn(7, b, 2, device=dev)
+    h0 = torch.randn(b, H, device=dev)
+    cot = torch.randn(b, H, device=dev)
+    tb = HF.scene_tables(sse, b, dev)
+    assert tb.tiles is not None and int(tb.tiles_host[:, 3].max()) <= 64
+    assert int(tb.tiles_host[:, 3].sum()) == tb.P and int(tb.tiles_host[-1, 1]) == b
+    res = []
+    for fused in (True, False):
+        saved = tb.tiles
+        if not fused:
+            tb.tiles = None
+        try:
+            mod.zero_grad()
+            h = h0.clone().requires_grad_()
+            y = mod(xy, dxy, h, sse)
+            (y * cot).sum().backward()
+            torch.cuda.synchronize()
+            res.append((y.detach().clone(), h.grad.clone(), [p.grad.clone() for p in mod.parameters()]))
+        finally:
+            tb.tiles = saved
+    (y1, g1, p1), (y0, g0, p0) = res
+    assert torch.equal(y1, y0)  # same operations in the same order
+    torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5)
+    for a, c in zip(p1, p0):
+        torch.testing.assert_close(a, c, rtol=1e-4, atol=1e-5)
