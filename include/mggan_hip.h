@@ -30,6 +30,8 @@ typedef struct ihipStream_t* mggan_stream_t; /* == hipStream_t */
 
 const char* mggan_last_error(void);
 int mggan_version(void);
+/* Measurement aid: *slot = the device's 100 MHz wall clock when the stream (or the captured graph) gets here. */
+int mggan_timestamp(unsigned long long* slot, mggan_stream_t stream);
 
 /* ---- dense layers: nn.Linear (+activation) forward / input grad / weight grad -------
  * reference: utils.py:134-149 (make_mlp), discriminators.py:46-56,76-108,
@@ -206,6 +208,18 @@ int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float
 int mggan_bce_rows(int rows, int kind, const float* p, float label, const float* label_u, float label_lo,
                    float label_hi, float scale, const int* row_gen, const float* inv_count, float* loss_rows, float* dp,
                    mggan_stream_t stream);
+/* All adversarial loss terms of one optimizer step in ONE launch (abstract_train.py:62-75 phi_1/phi_2/phi_3,
+ * train.py:92-111 generator re-weighting and classifier CE, :184 discriminator-side CE): term A = BCE/MSE over rows
+ * [0,nA) of p (optionally weighted 1/count(generator of the row), sign +-1), term B = BCE/MSE over rows [nA,nA+nB),
+ * term C = cross entropy over nC rows of g logits.  Each term's mean goes to out[q] (when not NULL), total =
+ * A + B + grad_c*C, and the gradients of `total` wrt p and the logits are left in dp / dlogits.  `args` points to
+ *   { const float* p; const float* label_u[2]; const int* row_gen; const int* seg; const float* inv_count;
+ *     const float* logits; const int* target; float* dp; float* dlogits; float* out[3]; float* total;
+ *     double* partial; unsigned* ticket;   (96 doubles of scratch; one word that is zero before the first call)
+ *     float label[2], lo[2], hi[2], scale[3], sign_a, grad_c; int nA, nB, nC, g, ld, kind, weighted_c; }
+ * label_u[q] != NULL: the smoothed label of term q is lo + (hi-lo)*u drawn on the device; counts per generator come
+ * from seg (g+1 offsets of the generator-sorted rows) or from inv_count. */
+int mggan_gan_losses(const void* args, mggan_stream_t stream);
 /* PM-network targets 'l2' (mode 0) / 'endpoint' (mode 1), train.py:616-624,641-647: target[ped] = the generator
  * whose best of E samples is closest to the ground truth; gen_abs (T,E,g,b,2), gt (T,b,2) */
 int mggan_pm_target(int b, int T, int E, int g, int mode, const float* gen_abs, const float* gt, int* target,

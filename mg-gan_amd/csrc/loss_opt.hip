@@ -99,6 +99,118 @@ __global__ void ce_rows_kernel(int rows, int g, const float* __restrict__ logits
     for (int c = 0; c < g; ++c) dlogits[(size_t)r * ldd + c] = w * (__expf(l[c] - lse) - (c == t ? 1.f : 0.f));
 }
 
+// ---- all adversarial losses of one optimizer step in ONE launch ---------------------------------
+// The discriminator step has three loss terms (real BCE, fake BCE, generator-id CE), the generator step two
+// (adversarial BCE, classifier CE with 1/count(generator) row weights); as separate rows + sum launches they are
+// 6-8 dependent few-microsecond kernels on the critical chain.  Up to GAN_LOSS_MAX_WG 1024-thread workgroups take
+// the rows grid-strided and accumulate the per-term sums in double; the last workgroup to finish adds the
+// per-workgroup sums in index order, so the result is deterministic.
+#define GAN_LOSS_MAX_WG 32
+struct GanLossArgs {
+  const float* p;         // (nA + nB) discriminator outputs: rows [0,nA) term A, [nA,nA+nB) term B
+  const float* label_u[2];  // device uniform draw per term (label = lo + (hi-lo)*u) or NULL -> label[]
+  const int* row_gen;     // generator id per row (terms A and C weighting) or NULL
+  const int* seg;         // g+1 segment offsets of the rows sorted by generator (count_q = seg[q+1]-seg[q]) or NULL
+  const float* inv_count; // 1/count per generator (used when seg == NULL) or NULL
+  const float* logits;    // (nC x g) classifier logits, row stride ld
+  const int* target;      // nC class ids
+  float* dp;              // (nA + nB) gradient wrt p
+  float* dlogits;         // (nC x g) gradient wrt logits (already times grad_c)
+  float* out[3];          // where each term's value goes (NULL: term absent)
+  float* total;           // A + B + grad_c * C
+  double* partial;        // 3 * GAN_LOSS_MAX_WG doubles of scratch
+  unsigned* ticket;       // one zero-initialised word; the kernel leaves it at zero again
+  float label[2], lo[2], hi[2], scale[3], sign_a, grad_c;
+  int nA, nB, nC, g, ld, kind, weighted_c;
+};
+
+__device__ __forceinline__ float bce_term(int kind, float p, float y, float w, float* dp) {
+  if (kind == 1) {  // least-squares objective (abstract_train.py:72-75)
+    *dp = w * 2.f * (p - y);
+    return w * (p - y) * (p - y);
+  }
+  const float lp = fmaxf(__logf(p), -100.f), lq = fmaxf(__logf(1.f - p), -100.f);  // BCELoss log clamp
+  *dp = -w * (y / p - (1.f - y) / (1.f - p));
+  return -w * (y * lp + (1.f - y) * lq);
+}
+
+__global__ __launch_bounds__(1024) void gan_losses_kernel(GanLossArgs a) {
+  __shared__ double red[3][1024];
+  __shared__ float invc[256];
+  __shared__ int last;
+  const int t = threadIdx.x;
+  const bool weighted = a.row_gen != nullptr;
+  if (weighted && t < a.g) {
+    if (a.seg) {
+      const int c = a.seg[t + 1] - a.seg[t];
+      invc[t] = c > 0 ? 1.f / (float)c : 0.f;
+    } else {
+      invc[t] = a.inv_count[t];
+    }
+  }
+  __syncthreads();
+  double acc[3] = {0.0, 0.0, 0.0};
+  float y[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) y[q] = a.label_u[q] ? a.lo[q] + (a.hi[q] - a.lo[q]) * (*a.label_u[q]) : a.label[q];
+  const int first = blockIdx.x * 1024 + t, step = gridDim.x * 1024;
+  for (int r = first; r < a.nA; r += step) {
+    const float w = (weighted ? invc[a.row_gen[r]] : 1.f) * a.scale[0] * a.sign_a;
+    float d;
+    acc[0] += (double)bce_term(a.kind, a.p[r], y[0], w, &d);
+    a.dp[r] = d;
+  }
+  for (int r = first; r < a.nB; r += step) {
+    float d;
+    acc[1] += (double)bce_term(a.kind, a.p[a.nA + r], y[1], a.scale[1], &d);
+    a.dp[a.nA + r] = d;
+  }
+  for (int r = first; r < a.nC; r += step) {
+    const float* l = a.logits + (size_t)r * a.ld;
+    const int tg = a.target[r];
+    float mx = -INFINITY;
+    for (int c = 0; c < a.g; ++c) mx = fmaxf(mx, l[c]);
+    float den = 0.f;
+    for (int c = 0; c < a.g; ++c) den += __expf(l[c] - mx);
+    const float lse = mx + __logf(den);
+    const float w = (a.weighted_c ? invc[tg] : 1.f) * a.scale[2];
+    acc[2] += (double)(w * (lse - l[tg]));
+    for (int c = 0; c < a.g; ++c)
+      a.dlogits[(size_t)r * a.g + c] = a.grad_c * (w * (__expf(l[c] - lse) - (c == tg ? 1.f : 0.f)));
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) red[q][t] = acc[q];
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (t < o) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) red[q][t] += red[q][t + o];
+    }
+    __syncthreads();
+  }
+  // per-workgroup sums meet in `partial`; the workgroup that takes the last ticket adds them in index order
+  // (a fixed order: the result does not depend on which workgroup finishes last) and re-arms the ticket
+  if (t == 0) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a.partial[blockIdx.x * 3 + q] = red[q][0];
+    __threadfence();
+    last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last || t != 0) return;
+  __threadfence();
+  double tot[3] = {0.0, 0.0, 0.0};
+  for (unsigned b = 0; b < gridDim.x; ++b)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) tot[q] += ((volatile double*)a.partial)[b * 3 + q];
+  const float A = (float)tot[0], B = (float)tot[1], C = (float)tot[2];
+  if (a.out[0]) *a.out[0] = A;
+  if (a.out[1]) *a.out[1] = B;
+  if (a.out[2]) *a.out[2] = C;
+  *a.total = (a.nA ? A : 0.f) + (a.nB ? B : 0.f) + (a.nC ? a.grad_c * C : 0.f);
+  *a.ticket = 0u;
+}
+
 // ---- per-scene min-over-K L2 (train.py:58-75) -------------------------------------------
 // One 256-thread workgroup per scene: eight 32-lane groups take the samples k round-robin, the lanes of a
 // group take the scene's pedestrians (contiguous 8-byte reads), each lane sums its |abs - gt| over the T steps,
@@ -507,6 +619,24 @@ int mggan_bce_rows(int rows, int kind, const float* p, float label, const float*
   hipLaunchKernelGGL(bce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rows, kind, p, label, label_u, label_lo,
                      label_hi, scale, row_gen, inv_count, loss_rows, dp);
   MG_LAUNCH_CHECK("bce_rows");
+  return MGGAN_OK;
+}
+
+int mggan_gan_losses(const void* args, hipStream_t stream) {
+  MG_CHECK_ARG(args, "gan_losses: null argument block");
+  const GanLossArgs a = *static_cast<const GanLossArgs*>(args);
+  MG_CHECK_ARG(a.nA >= 0 && a.nB >= 0 && a.nC >= 0 && (a.kind == 0 || a.kind == 1), "gan_losses: bad sizes");
+  MG_CHECK_ARG(a.total && a.partial && a.ticket && (a.nA + a.nB == 0 || (a.p && a.dp)), "gan_losses: null pointer");
+  MG_CHECK_ARG(a.nC == 0 || (a.logits && a.target && a.dlogits && a.g > 0 && a.g <= 256 && a.ld >= a.g),
+               "gan_losses: bad classifier term");
+  MG_CHECK_ARG(!a.row_gen || ((a.seg || a.inv_count) && a.g > 0 && a.g <= 256), "gan_losses: row weights need counts");
+  MG_CHECK_ARG(!a.weighted_c || a.row_gen, "gan_losses: weighted classifier term needs counts");
+  int rows = a.nA > a.nB ? a.nA : a.nB;
+  if (a.nC > rows) rows = a.nC;
+  int wgs = cdiv(rows, 2048);  // two rows of every term per thread
+  wgs = wgs < 1 ? 1 : (wgs > GAN_LOSS_MAX_WG ? GAN_LOSS_MAX_WG : wgs);
+  hipLaunchKernelGGL(gan_losses_kernel, dim3(wgs), dim3(1024), 0, stream, a);
+  MG_LAUNCH_CHECK("gan_losses");
   return MGGAN_OK;
 }
 

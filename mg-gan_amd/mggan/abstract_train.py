@@ -133,8 +133,13 @@ class MultiGeneratorGAN(abc.ABC):
             run, graph = rec.replay, rec
         else:
             graph = torch.cuda.CUDAGraph()
+            dot = os.environ.get("MGGAN_GRAPH_DOT")  # debugging aid: dump the captured graph's nodes and edges
+            if dot:
+                graph.enable_debug_mode()
             with torch.cuda.graph(graph):
                 self.train_iteration(batch, captured)
+            if dot:
+                graph.debug_dump(dot)
             run = graph.replay
         pending, self._pending = self._pending, []
         self.defer_metrics = keep

@@ -39,6 +39,30 @@ def _rows2d(t):
     return t, (t.stride(0) if t.shape[0] > 1 else t.shape[1])
 
 
+# Time marks (MGGAN_MARKS=1): a one-lane kernel stores the device clock at the point of the call, on whatever
+# stream is current -- also inside a captured graph, where each replay refreshes the slots.
+_MARKS = {"on": os.environ.get("MGGAN_MARKS", "0") == "1", "buf": None, "names": []}
+
+
+def mark(name):
+    if not _MARKS["on"]:
+        return
+    if _MARKS["buf"] is None:
+        _MARKS["buf"] = torch.zeros(512, dtype=torch.int64, device="cuda")
+    i = len(_MARKS["names"])
+    _MARKS["names"].append(name)
+    lib.mggan_timestamp(_MARKS["buf"].data_ptr() + 8 * i, _s())
+
+
+def read_marks():
+    """-> [(name, microseconds since the first mark)] in time order."""
+    if _MARKS["buf"] is None:
+        return []
+    t = _MARKS["buf"][:len(_MARKS["names"])].cpu().tolist()
+    t0 = min(t)
+    return sorted(((n, (v - t0) / 100.0) for n, v in zip(_MARKS["names"], t)), key=lambda x: x[1])
+
+
 def want_grad(*tensors):
     """Evaluated at the call site (autograd.Function.forward always runs with grad mode off)."""
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
@@ -316,6 +340,79 @@ class _McArgs(ctypes.Structure):
 MLP_MAX_WIDTH = 192
 
 
+def _chain_fwd(x, ldx, rows, spec, Ws, bs, save):
+    """One launch: act_n(... act_1(x W_1^T + b_1) ...) -> per-layer outputs (hidden ones only when `save`)."""
+    n = len(spec)
+    K0 = Ws[0].shape[1]
+    a = _McArgs()
+    a.X, a.ldx, a.rows, a.K0, a.n = _p(x), ldx, rows, K0, n
+    outs = []
+    for i, ((act, slope), W, b) in enumerate(zip(spec, Ws, bs)):
+        N, K = W.shape
+        keep = i == n - 1 or save  # hidden activations only leave the chip when a backward pass needs them
+        y = _empty(rows, N, like=x) if keep else None
+        outs.append(y)
+        st = a.s[i]
+        st.W, st.bias, st.out = _p(W), _p(b), _p(y)
+        st.K, st.N, st.ldw, st.trans, st.act, st.slope, st.ld_out = K, N, K, 0, act, float(slope), N
+    if _load_lib().trace is not None:
+        TRACE_NOTES["mlp_chain_flops"].append(2.0 * rows * sum(W.shape[0] * W.shape[1] for W in Ws))
+    lib.mggan_mlp_chain(ctypes.addressof(a), _s())
+    return outs
+
+
+def _chain_bwd(dy, lddy, x, ldx, rows, outs, spec, Ws, bs, need_dx, train_w, owner, dx_into=None):
+    """Adjoint of _chain_fwd in one launch (+ the weight-gradient GEMMs, queued or on the side stream).
+    dx_into = (pointer, row stride, accumulate): where the input gradient goes (default: a fresh tensor)."""
+    n = len(spec)
+    # gate gradients dz_l (l = n-1 .. 0): dz_{n-1} = dy * act'(y); dz_{l-1} = (dz_l W_l) * act'(h_{l-1})
+    a = _McArgs()
+    a.X, a.ldx, a.rows, a.K0 = _p(dy), lddy, rows, Ws[-1].shape[0]
+    dz = [None] * n
+    act_last = spec[-1][0]
+    if act_last != ACT_NONE:
+        a.in_mul, a.ld_in_mul, a.in_mul_act, a.in_mul_slope = _p(outs[-1]), outs[-1].shape[1], act_last, float(spec[-1][1])
+        if train_w:
+            dz[-1] = _empty(rows, Ws[-1].shape[0], like=x)
+            a.in_store, a.ld_in_store = _p(dz[-1]), Ws[-1].shape[0]
+    elif train_w:
+        dz[-1] = dy
+    k = 0
+    dx = None
+    for l in range(n - 1, -1, -1):  # stage k: dz_l (rows, N_l) -> (rows, K_l) through W_l
+        if l == 0 and not need_dx:
+            break
+        N, K = Ws[l].shape
+        st = a.s[k]
+        st.W, st.K, st.N, st.ldw, st.trans, st.act = _p(Ws[l]), N, K, K, 1, ACT_NONE
+        if l > 0:
+            st.mul_src, st.ld_mul, st.mul_act, st.mul_slope = _p(outs[l - 1]), K, spec[l - 1][0], float(spec[l - 1][1])
+            if train_w:
+                dz[l - 1] = _empty(rows, K, like=x)
+                st.out, st.ld_out = _p(dz[l - 1]), K
+        elif dx_into is not None:
+            st.out, st.ld_out, st.accumulate = dx_into[0], dx_into[1], int(dx_into[2])
+        else:
+            dx = _empty(rows, K, like=x)
+            st.out, st.ld_out = _p(dx), K
+        k += 1
+    a.n = k
+    if k > 0:
+        if _load_lib().trace is not None:
+            TRACE_NOTES["mlp_chain_flops"].append(2.0 * rows * sum(a.s[i].K * a.s[i].N for i in range(k)))
+        lib.mggan_mlp_chain(ctypes.addressof(a), _s())
+    if train_w:
+        root = root_of(owner)
+        lddz_last = lddy if dz[-1] is dy else Ws[-1].shape[0]
+        with side_stream(*[t for t in dz if t is not None], x, *outs):
+            for l in range(n):
+                N, K = Ws[l].shape
+                inp, ldi = (x, ldx) if l == 0 else (outs[l - 1], K)
+                wgrad(dz[l], lddz_last if l == n - 1 else N, inp, ldi, root.grad_ptr(Ws[l]), K,
+                      root.grad_ptr(bs[l]) if bs[l] is not None else 0, rows, K, N)
+    return dx
+
+
 class MlpChainFn(Function):
     """act_n(... act_1(x W_1^T + b_1) ...) for 2-3 Linear layers in ONE launch per direction
     (nn.Sequential stacks of utils.make_mlp, utils.py:134-149; csrc/mlp.hip)."""
@@ -324,23 +421,10 @@ class MlpChainFn(Function):
     def forward(ctx, x, spec, owner, save, *wb):
         # spec: tuple of (act, slope) per layer; wb = (W_1, b_1, W_2, b_2, ...); save: a backward pass will follow
         x, ldx = _rows2d(x)
-        rows, K0 = x.shape
+        rows = x.shape[0]
         n = len(spec)
         Ws, bs = wb[0::2], wb[1::2]
-        a = _McArgs()
-        a.X, a.ldx, a.rows, a.K0, a.n = _p(x), ldx, rows, K0, n
-        outs = []
-        for i, ((act, slope), W, b) in enumerate(zip(spec, Ws, bs)):
-            N, K = W.shape
-            keep = i == n - 1 or save  # hidden activations only leave the chip when a backward pass needs them
-            y = _empty(rows, N, like=x) if keep else None
-            outs.append(y)
-            st = a.s[i]
-            st.W, st.bias, st.out = _p(W), _p(b), _p(y)
-            st.K, st.N, st.ldw, st.trans, st.act, st.slope, st.ld_out = K, N, K, 0, act, float(slope), N
-        if _load_lib().trace is not None:
-            TRACE_NOTES["mlp_chain_flops"].append(2.0 * rows * sum(W.shape[0] * W.shape[1] for W in Ws))
-        lib.mggan_mlp_chain(ctypes.addressof(a), _s())
+        outs = _chain_fwd(x, ldx, rows, spec, Ws, bs, save)
         if save:
             ctx.spec, ctx.owner, ctx.ldx, ctx.n, ctx.train_w = spec, owner, ldx, n, Ws[0].requires_grad
             ctx.save_for_backward(x, *outs, *wb)
@@ -352,54 +436,53 @@ class MlpChainFn(Function):
         sv = ctx.saved_tensors
         x, outs, wb = sv[0], sv[1:1 + n], sv[1 + n:]
         Ws, bs = wb[0::2], wb[1::2]
-        rows = x.shape[0]
         dy, lddy = _rows2d(dy)
-        need_dx = ctx.needs_input_grad[0]
-        train_w = ctx.train_w
-        # gate gradients dz_l (l = n-1 .. 0): dz_{n-1} = dy * act'(y); dz_{l-1} = (dz_l W_l) * act'(h_{l-1})
-        a = _McArgs()
-        a.X, a.ldx, a.rows, a.K0 = _p(dy), lddy, rows, Ws[-1].shape[0]
-        dz = [None] * n
-        act_last = spec[-1][0]
-        if act_last != ACT_NONE:
-            a.in_mul, a.ld_in_mul, a.in_mul_act, a.in_mul_slope = _p(outs[-1]), outs[-1].shape[1], act_last, float(spec[-1][1])
-            if train_w:
-                dz[-1] = _empty(rows, Ws[-1].shape[0], like=x)
-                a.in_store, a.ld_in_store = _p(dz[-1]), Ws[-1].shape[0]
-        elif train_w:
-            dz[-1] = dy
-        k = 0
-        dx = None
-        for l in range(n - 1, -1, -1):  # stage k: dz_l (rows, N_l) -> (rows, K_l) through W_l
-            if l == 0 and not need_dx:
-                break
-            N, K = Ws[l].shape
-            st = a.s[k]
-            st.W, st.K, st.N, st.ldw, st.trans, st.act = _p(Ws[l]), N, K, K, 1, ACT_NONE
-            if l > 0:
-                st.mul_src, st.ld_mul, st.mul_act, st.mul_slope = _p(outs[l - 1]), K, spec[l - 1][0], float(spec[l - 1][1])
-                if train_w:
-                    dz[l - 1] = _empty(rows, K, like=x)
-                    st.out, st.ld_out = _p(dz[l - 1]), K
-            else:
-                dx = _empty(rows, K, like=x)
-                st.out, st.ld_out = _p(dx), K
-            k += 1
-        a.n = k
-        if k > 0:
-            if _load_lib().trace is not None:
-                TRACE_NOTES["mlp_chain_flops"].append(2.0 * rows * sum(a.s[i].K * a.s[i].N for i in range(k)))
-            lib.mggan_mlp_chain(ctypes.addressof(a), _s())
-        if train_w:
-            root = root_of(ctx.owner)
-            lddz_last = lddy if dz[-1] is dy else Ws[-1].shape[0]
-            with side_stream(*[t for t in dz if t is not None], x, *outs):
-                for l in range(n):
-                    N, K = Ws[l].shape
-                    inp, ldi = (x, ctx.ldx) if l == 0 else (outs[l - 1], K)
-                    wgrad(dz[l], lddz_last if l == n - 1 else N, inp, ldi, root.grad_ptr(Ws[l]), K,
-                          root.grad_ptr(bs[l]) if bs[l] is not None else 0, rows, K, N)
+        dx = _chain_bwd(dy, lddy, x, ctx.ldx, x.shape[0], outs, spec, Ws, bs, ctx.needs_input_grad[0], ctx.train_w,
+                        ctx.owner)
         return (dx, None, None, None) + (None,) * len(wb)
+
+
+class TwoHeadsFn(Function):
+    """Two MLP heads on one input: head A over all rows, head B over rows [row0, rows) (the discriminator's
+    real/fake score and its generator-id classifier on the fake half of a pair pass, discriminators.py:186-199).
+    As two autograd nodes the heads cost a slice backward (zero-fill + copy) and a gradient add; here head B's
+    input gradient accumulates into head A's inside its own launch."""
+
+    @staticmethod
+    def forward(ctx, x, row0, spec_a, spec_b, owner_a, owner_b, save, *wb):
+        x, ldx = _rows2d(x)
+        rows, K = x.shape
+        na, nb = len(spec_a), len(spec_b)
+        wa, wbb = wb[:2 * na], wb[2 * na:]
+        outs_a = _chain_fwd(x, ldx, rows, spec_a, wa[0::2], wa[1::2], save)
+        xb = x[row0:]
+        outs_b = _chain_fwd(xb, ldx, rows - row0, spec_b, wbb[0::2], wbb[1::2], save)
+        if save:
+            ctx.cfg = (row0, spec_a, spec_b, owner_a, owner_b, ldx, wa[0].requires_grad, wbb[0].requires_grad)
+            ctx.save_for_backward(x, *outs_a, *outs_b, *wb)
+        return outs_a[-1], outs_b[-1]
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        row0, spec_a, spec_b, owner_a, owner_b, ldx, train_a, train_b = ctx.cfg
+        na, nb = len(spec_a), len(spec_b)
+        sv = ctx.saved_tensors
+        x, outs_a, outs_b, wb = sv[0], sv[1:1 + na], sv[1 + na:1 + na + nb], sv[1 + na + nb:]
+        wa, wbb = wb[:2 * na], wb[2 * na:]
+        rows, K = x.shape
+        need_dx = ctx.needs_input_grad[0]
+        dx = None
+        if dya is None:
+            dx = torch.zeros(rows, K, dtype=F32, device=x.device) if need_dx else None
+        else:
+            dya, ld = _rows2d(dya)
+            dx = _chain_bwd(dya, ld, x, ldx, rows, outs_a, spec_a, wa[0::2], wa[1::2], need_dx, train_a, owner_a)
+        if dyb is not None:
+            dyb, ld = _rows2d(dyb)
+            into = (dx.data_ptr() + 4 * row0 * K, K, 1) if need_dx else None
+            _chain_bwd(dyb, ld, x[row0:], ldx, rows - row0, outs_b, spec_b, wbb[0::2], wbb[1::2], need_dx, train_b,
+                       owner_b, dx_into=into)
+        return (dx,) + (None,) * (6 + len(wb))
 
 
 # Above this many rows the stack runs as one GEMM launch per layer: the chain wins by the launches and round trips
@@ -422,6 +505,16 @@ def mlp(x, layers, owner=None):
     y = MlpChainFn.apply(x.reshape(-1, x.shape[-1]), spec, owner if owner is not None else layers[0][0],
                          want_grad(x, wb[0]), *wb)
     return y.reshape(*lead, -1)
+
+
+def two_heads(x, layers_a, layers_b, row0):
+    """-> (head_a(x), head_b(x[row0:])) through TwoHeadsFn (both stacks small enough for the fused chain)."""
+    spec_a = tuple((act, slope) for _, act, slope in layers_a)
+    spec_b = tuple((act, slope) for _, act, slope in layers_b)
+    wb = []
+    for lin, _, _ in list(layers_a) + list(layers_b):
+        wb += [lin.weight, lin.bias]
+    return TwoHeadsFn.apply(x, row0, spec_a, spec_b, layers_a[0][0], layers_b[0][0], want_grad(x, *wb[0::2]), *wb)
 
 
 # ------------------------------------------------------------------------------------------
@@ -966,6 +1059,83 @@ class BceMeanFn(Function):
     @staticmethod
     def backward(ctx, g):
         return _scaled(ctx.dp, g).view(ctx.shape), None, None, None, None, None, None, None
+
+
+class _GanLossArgs(ctypes.Structure):  # mirrors csrc/loss_opt.hip:GanLossArgs
+    _fields_ = [("p", ctypes.c_void_p), ("label_u", ctypes.c_void_p * 2), ("row_gen", ctypes.c_void_p),
+                ("seg", ctypes.c_void_p), ("inv_count", ctypes.c_void_p), ("logits", ctypes.c_void_p),
+                ("target", ctypes.c_void_p), ("dp", ctypes.c_void_p), ("dlogits", ctypes.c_void_p),
+                ("out", ctypes.c_void_p * 3), ("total", ctypes.c_void_p), ("partial", ctypes.c_void_p),
+                ("ticket", ctypes.c_void_p),
+                ("label", ctypes.c_float * 2), ("lo", ctypes.c_float * 2), ("hi", ctypes.c_float * 2),
+                ("scale", ctypes.c_float * 3), ("sign_a", ctypes.c_float), ("grad_c", ctypes.c_float),
+                ("nA", ctypes.c_int), ("nB", ctypes.c_int), ("nC", ctypes.c_int), ("g", ctypes.c_int),
+                ("ld", ctypes.c_int), ("kind", ctypes.c_int), ("weighted_c", ctypes.c_int)]
+
+
+_LOSS_SCRATCH = {}
+
+
+def _loss_scratch():
+    """Per-stream scratch of mggan_gan_losses: (96 doubles, one ticket word the kernel always leaves at zero)."""
+    key = _s()
+    hit = _LOSS_SCRATCH.get(key)
+    if hit is None:
+        hit = _LOSS_SCRATCH[key] = (torch.zeros(96, dtype=torch.float64, device="cuda"),
+                                    torch.zeros(1, dtype=torch.int32, device="cuda"))
+    return hit
+
+
+class GanLossesFn(Function):
+    """Every adversarial loss term of one optimizer step as ONE launch and ONE autograd node
+    (abstract_train.py:62-75, train.py:92-111,184): term A over rows [0,nA) of p, term B over the next nB rows,
+    term C = cross entropy over the classifier logits.  -> A + B + grad_c * C; the terms go to `outs`."""
+
+    @staticmethod
+    def forward(ctx, p, logits, o):
+        # o: dict(nA, nB, labels=(lab_a, lab_b), norms=(nA, nB, nC) global row counts, kind, sign_a, grad_c,
+        #         row_gen, seg, inv_count, target, weighted_c, outs=(tA, tB, tC) one-element tensors or None)
+        p = p.contiguous()
+        a = _GanLossArgs()
+        a.nA, a.nB = int(o["nA"]), int(o.get("nB", 0))
+        assert p.numel() == a.nA + a.nB
+        dp = _empty(p.numel(), like=p)
+        a.p, a.dp = _p(p), _p(dp)
+        for q, lab in enumerate(o["labels"]):
+            if isinstance(lab, tuple):  # (u (1,) device tensor, lo, hi): label = lo + (hi-lo)*u drawn on the GPU
+                a.label_u[q], a.lo[q], a.hi[q] = _p(lab[0]), float(lab[1]), float(lab[2])
+            elif lab is not None:
+                a.label[q] = float(lab)
+        norms = o["norms"]
+        a.scale[0] = 1.0 / float(norms[0] or max(a.nA, 1))
+        a.scale[1] = 1.0 / float(norms[1] or max(a.nB, 1))
+        a.kind, a.sign_a, a.grad_c = int(o.get("kind", 0)), float(o.get("sign_a", 1.0)), float(o.get("grad_c", 1.0))
+        row_gen = o.get("row_gen")
+        a.row_gen, a.seg, a.inv_count = _p(row_gen), _p(o.get("seg")), _p(o.get("inv_count"))
+        dl = None
+        if logits is not None:
+            logits = logits.contiguous()
+            a.nC, a.g = logits.shape
+            a.ld = a.g
+            dl = _empty(a.nC, a.g, like=p)
+            a.logits, a.dlogits, a.target = _p(logits), _p(dl), _p(o["target"])
+            a.scale[2] = 1.0 / float(norms[2] or max(a.nC, 1))
+            a.weighted_c = int(bool(o.get("weighted_c", False)))
+        elif row_gen is not None:
+            a.g = int(o["g"])
+        for q, t in enumerate(o["outs"]):
+            a.out[q] = _p(t)
+        total = _empty(1, like=p)
+        a.total = _p(total)
+        partial, ticket = _loss_scratch()
+        a.partial, a.ticket = _p(partial), _p(ticket)
+        lib.mggan_gan_losses(ctypes.addressof(a), _s())
+        ctx.dp, ctx.dl, ctx.shape = dp, dl, p.shape
+        return total.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _scaled(ctx.dp, g).view(ctx.shape), (_scaled(ctx.dl, g) if ctx.dl is not None else None), None
 
 
 class CeMeanFn(Function):

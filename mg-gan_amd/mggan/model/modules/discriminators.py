@@ -67,9 +67,13 @@ class MultiDiscriminatorTrajectory(FlatModule):
         self.ensure_flat()
         fc = self.in_encoder_fc
         with HF.branch():  # scene CNN || history LSTM; joined by forward() right before the classifier input
+            HF.mark("Dctx.cnn.begin")
             scene = self.scene_encoder(img, stat_updates=passes)
+            HF.mark("Dctx.cnn.end")
+        HF.mark("Dctx.lstm.begin")
         h = self.in_encoder(in_dxdy)
         in_enc = HF.mlp(h, [(fc[0], HF.ACT_LEAKY, 0.2), (fc[2], HF.ACT_NONE, 0.0)])
+        HF.mark("Dctx.lstm.end")
         return in_enc, scene
 
     def _encode_parts(self, in_dxdy, pred_dxdy, context=None):
@@ -88,7 +92,7 @@ class MultiDiscriminatorTrajectory(FlatModule):
         """The real and the fake single-sample pass of one discriminator step as ONE pass over 2b rows (rows
         [0,b) = real, [b,2b) = fake).  Every operator after the shared history context is row-wise or per
         scene, so the results equal two forward() calls; the latency-bound kernel chain runs once instead of twice.
-        -> (out_real (b,1), out_fake (b,1), branch_fake (b,1,g) | None)"""
+        -> (out (2b,1): real rows then fake rows, branch_fake (b,1,g) | None)"""
         self.ensure_flat()
         in_enc, scene = context
         b = in_xy.size(1)
@@ -109,12 +113,12 @@ class MultiDiscriminatorTrajectory(FlatModule):
         HF.join_branch(scene)
         classifier_inp = HF.DAssembleFn.apply(soc, in_enc, pred_enc, scene, 2, True)
         d = self.discs[0]
-        y = HF.mlp(classifier_inp, [(d[0], HF.ACT_LEAKY, 0.2), (d[2], self._out_act(), 0.0)])
-        branch = None
-        if self.gan_type == "mgan":
-            r = self.gen_id_reconstructor
-            branch = HF.mlp(classifier_inp[b:], [(r[0], HF.ACT_LEAKY, 0.2), (r[2], HF.ACT_NONE, 0.0)]).reshape(b, 1, -1)
-        return y[:b], y[b:], branch
+        head = [(d[0], HF.ACT_LEAKY, 0.2), (d[2], self._out_act(), 0.0)]
+        if self.gan_type != "mgan":
+            return HF.mlp(classifier_inp, head), None
+        r = self.gen_id_reconstructor
+        y, branch = HF.two_heads(classifier_inp, head, [(r[0], HF.ACT_LEAKY, 0.2), (r[2], HF.ACT_NONE, 0.0)], b)
+        return y, branch.reshape(b, 1, -1)
 
     def forward(self, in_xy, in_dxdy, pred_xy, pred_dxdy, seq_start_end, return_all=False, img=None, mask=None,
                 context=None):

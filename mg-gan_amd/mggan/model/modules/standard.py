@@ -96,9 +96,12 @@ class MultiGenerator(FlatModule):
         the generator step see the same weights) -> BatchNorm running stats are updated that many times."""
         self.ensure_flat()
         with HF.branch():  # scene CNN || trajectory LSTM + social attention
+            HF.mark("trunk.cnn.begin")
             scene = self.scene_encoder(img, stat_updates=passes)
+            HF.mark("trunk.cnn.end")
         enc = self.encoder(get_input(in_xy, in_dxdy, self.inp_format))
         soc = self.social(in_xy, in_dxdy, enc, sub_batches)
+        HF.mark("trunk.soc.end")
         HF.join_branch(scene)
         return torch.cat([enc, scene, soc], -1), soc
 

@@ -120,7 +120,9 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         # the fake trajectories (no-grad generator call: PM-network, sampling, row bucketing, rollout) depend on
         # nothing the real pass computes: they are produced on a branch stream beside it.  (The label scalars
         # come from the numpy generator, noise and sampling from torch's: reordering the two is seed-neutral.)
+        HF.mark("D.begin")
         with HF.branch(1), torch.no_grad():
+            HF.mark("D.fake.begin")
             noise = self.rng.noise(1, self.config.noise_dim, sub_batches, self.device)
             gen_out, g_logits, gen_labels_gt = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
                                                       num_samples=1, mask=loss_mask,
@@ -128,47 +130,65 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             if shared is not None and g_trunk is not None:
                 shared["g_logits"] = g_logits  # same trunk, same weights in the generator step: not recomputed there
             rows_d = getattr(self.G, "last_rows", None)
+            HF.mark("D.fake.end")
         # history LSTM + scene CNN of D are identical in the real and the fake pass: run them once
         ctx = self.D.history_context(in_dxdy, img, passes=2) if (loss_mask is None and self.share_context) else None
         pair = ctx is not None and getattr(self, "pair_passes", True)
+        kind = 1 if self.config.gan_obj == "LS" else 0  # phi_1 / phi_2: squared error for 'LS', BCE for 'NS' and 'MM'
+        join_fake = lambda: HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, g_logits,
+                                           None if rows_d is None else rows_d.row_gen_pos, which=1)
+        ce_target = lambda: rows_d.row_gen_pos if rows_d is not None and rows_d.R == gen_labels_gt.numel() \
+            else gen_labels_gt.t().reshape(-1).to(torch.int32)
+        items = []
         if pair:
-            # real and fake pass batched into one 2b-row pass (same results: every operator is row-wise / per scene)
-            HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, g_logits, None if rows_d is None else rows_d.row_gen_pos, which=1)
-            real_result, disc_out, branch_out = self.D.forward_pair(in_xy, in_dxdy, gt_dxdy, gen_out.rel, sub_batches, ctx)
-            if self.gan_type == "mgan":
-                disc_out = (disc_out, branch_out)
+            # real and fake pass batched into one 2b-row pass (same results: every operator is row-wise / per scene),
+            # and the two or three loss terms as one launch / one autograd node
+            HF.mark("D.ctx.end")
+            join_fake()
+            HF.mark("D.pair.begin")
+            y, branch_out = self.D.forward_pair(in_xy, in_dxdy, gt_dxdy, gen_out.rel, sub_batches, ctx)
+            HF.mark("D.pair.end")
+            b = in_xy.size(1)
+            label_real, _ = self.rng.labels()
+            _, label_fake = self.rng.labels()
+            mgan = self.gan_type == "mgan"
+            n_b = self._global(b)
+            losses = [HF.GanLossesFn.apply(y.reshape(-1), branch_out.reshape(b, -1) if mgan else None, dict(
+                nA=b, nB=b, labels=(label_real, label_fake), norms=(n_b, n_b, n_b), kind=kind,
+                target=ce_target() if mgan else None,
+                outs=(m[M_REAL:M_REAL + 1], m[M_FAKE:M_FAKE + 1], m[M_CE_D:M_CE_D + 1] if mgan else None)))]
+            if mgan:
+                items.append(("train/info_mgan_disc_loss", M_CE_D))
         else:
             real_result = self.D(in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, img=img, mask=loss_mask, context=ctx)
             if isinstance(real_result, tuple):
                 real_result = real_result[0]
-        n_real = self._global(real_result.numel())
-        label_real, _ = self.rng.labels()
-        kind = 1 if self.config.gan_obj == "LS" else 0  # phi_1 / phi_2: squared error for 'LS', BCE for 'NS' and 'MM'
-        real_loss = HF.BceMeanFn.apply(real_result.t().reshape(-1), label_real, None, None, m[M_REAL:M_REAL + 1], n_real,
-                                       kind)
-        if not pair:
-            HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, g_logits, None if rows_d is None else rows_d.row_gen_pos, which=1)
+            n_real = self._global(real_result.numel())
+            label_real, _ = self.rng.labels()
+            real_loss = HF.BceMeanFn.apply(real_result.t().reshape(-1), label_real, None, None, m[M_REAL:M_REAL + 1],
+                                           n_real, kind)
+            join_fake()
             disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask, context=ctx)
-        losses = [real_loss]
-        items = []
-        if self.gan_type == "mgan":
-            disc_out, branch_out = disc_out
-            rows = branch_out.transpose(0, 1).reshape(-1, branch_out.shape[-1])
-            target = rows_d.row_gen_pos if rows_d is not None and rows_d.R == gen_labels_gt.numel() \
-                else gen_labels_gt.t().reshape(-1).to(torch.int32)
-            ce_loss = HF.CeMeanFn.apply(rows, target, None, m[M_CE_D:M_CE_D + 1], self._global(rows.shape[0]))
-            losses.append(ce_loss)
-            items.append(("train/info_mgan_disc_loss", M_CE_D))
-        _, label_fake = self.rng.labels()
-        fake_loss = HF.BceMeanFn.apply(disc_out.t().reshape(-1), label_fake, None, None, m[M_FAKE:M_FAKE + 1],
-                                       self._global(disc_out.numel()), kind)
-        losses.append(fake_loss)
+            losses = [real_loss]
+            if self.gan_type == "mgan":
+                disc_out, branch_out = disc_out
+                rows = branch_out.transpose(0, 1).reshape(-1, branch_out.shape[-1])
+                ce_loss = HF.CeMeanFn.apply(rows, ce_target(), None, m[M_CE_D:M_CE_D + 1], self._global(rows.shape[0]))
+                losses.append(ce_loss)
+                items.append(("train/info_mgan_disc_loss", M_CE_D))
+            _, label_fake = self.rng.labels()
+            fake_loss = HF.BceMeanFn.apply(disc_out.t().reshape(-1), label_fake, None, None, m[M_FAKE:M_FAKE + 1],
+                                           self._global(disc_out.numel()), kind)
+            losses.append(fake_loss)
         items.append(("train/discr_loss", (M_FAKE, M_REAL)))
 
+        HF.mark("D.loss.end")
         self.optimizerD.zero_grad()
         self._backward(losses, [self._one] * len(losses))
+        HF.mark("D.bwd.end")
         self.dist.all_reduce_grads(self.D)
         self.optimizerD.step(self.config.clipping_threshold_d, zero_grad=self.zero_grads_in_step)
+        HF.mark("D.opt.end")
         self._emit(train_metrics, items)
 
     def generator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None,
@@ -187,12 +207,15 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                 # D's history LSTM + scene CNN depend on neither G nor (in this step) any gradient: they run on the
                 # branch stream next to the generator's forward pass
                 with HF.branch(), torch.no_grad():
+                    HF.mark("G.dctx.begin")
                     ctx_d = self.D.history_context(in_dxdy, img, passes=1)
+                    HF.mark("G.dctx.end")
             noise = self.rng.noise(cfg.num_samples, cfg.noise_dim, sub_batches, self.device)
             gen_out, _, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
                                           mask=loss_mask, num_samples=cfg.num_samples,
                                           trunk=None if shared is None else shared.get("g_trunk"),
                                           logits=None if shared is None else shared.get("g_logits"))
+            HF.mark("G.gen.end")
             losses, grads, items = [], [], []
             if cfg.l2_loss_type != "none":
                 # min-over-samples L2 (three small launches) beside the discriminator pass on the predictions; autograd
@@ -210,39 +233,49 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                     losses.append(min_l2)
                     grads.append(self._w["l2"])
                     items.append(("train/L2_loss", M_L2))
+                    HF.mark("G.l2.end")
 
             if ctx_d is not None:
                 HF.join_branch(*ctx_d, which=0)
+            HF.mark("G.dpass.begin")
             disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask,
                               context=ctx_d)
         finally:
             for p, f in zip(d_params, flags):
                 p.requires_grad_(f)
+        HF.mark("G.dpass.end")
         branch_out = None
         if isinstance(disc_out, tuple):
             disc_out, branch_out = disc_out
         label_real, label_fake = self.rng.labels()
-        row_gen, inv_count = self._gen_weights(gen_idxs)
         n_rows = self._global(disc_out.numel())
-        # phi_3 (abstract_train.py:62-75): 'NS' BCE(d, real), 'LS' (d - real)^2, 'MM' -BCE(d, fake)
+        # phi_3 (abstract_train.py:62-75): 'NS' BCE(d, real), 'LS' (d - real)^2, 'MM' -BCE(d, fake); rows weighted by
+        # 1/count(generator) (train.py:92-97); classifier CE with the same weights (train.py:105-111)
         obj = cfg.gan_obj
-        adv_loss = HF.BceMeanFn.apply(disc_out.t().reshape(-1), label_fake if obj == "MM" else label_real, row_gen,
-                                      inv_count, m[M_ADV:M_ADV + 1], n_rows, 1 if obj == "LS" else 0,
-                                      -1.0 if obj == "MM" else 1.0)
-        losses.append(adv_loss)
+        mgan = self.gan_type == "mgan"
+        rows_g = getattr(self.G, "last_rows", None)
+        o = dict(nA=disc_out.numel(), labels=(label_fake if obj == "MM" else label_real, None), norms=(n_rows, 0, n_rows),
+                 kind=1 if obj == "LS" else 0, sign_a=-1.0 if obj == "MM" else 1.0, grad_c=float(cfg.clf_loss_weight),
+                 weighted_c=True, g=self.G.n_gs, outs=(m[M_ADV:M_ADV + 1], None, m[M_CLF:M_CLF + 1] if mgan else None))
+        if rows_g is not None and rows_g.R == gen_idxs.numel() and not self.dist.enabled:
+            o["row_gen"], o["seg"] = rows_g.row_gen_pos, rows_g.seg  # counts = segment lengths of the bucketed rows
+        else:
+            o["row_gen"], o["inv_count"] = self._gen_weights(gen_idxs)
+        o["target"] = o["row_gen"]
+        logits = branch_out.transpose(0, 1).reshape(-1, branch_out.shape[-1]) if mgan else None
+        losses.append(HF.GanLossesFn.apply(disc_out.t().reshape(-1), logits, o))
         grads.append(self._one)
         items.append(("train/gen_loss", M_ADV))
-        if self.gan_type == "mgan":
-            rows = branch_out.transpose(0, 1).reshape(-1, branch_out.shape[-1])
-            clf = HF.CeMeanFn.apply(rows, row_gen, inv_count, m[M_CLF:M_CLF + 1], n_rows)
-            losses.append(clf)
-            grads.append(self._w["clf"])
+        if mgan:
             items.append(("train/info_mgan_loss", M_CLF))
 
+        HF.mark("G.loss.end")
         self.optimizerG.zero_grad()
         self._backward(losses, grads)
+        HF.mark("G.bwd.end")
         self.dist.all_reduce_grads(self.G)
         self.optimizerG.step(cfg.clipping_threshold_g, zero_grad=self.zero_grads_in_step)
+        HF.mark("G.opt.end")
         self._emit(train_metrics, items)
 
     def net_chooser_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, metrics, mask, img):
@@ -250,6 +283,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         if cfg.weighting_target == "none":
             return
         m, g = self._m, self.G.n_gs
+        HF.mark("PM.begin")
         gen_out, net_chooser_weights, _ = self.G(in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=img,
                                                  num_samples=cfg.num_expectation_samples, mask=mask)
         n_pm = self._global(net_chooser_weights.shape[0])
@@ -274,10 +308,13 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             lib.mggan_colmean(probs.data_ptr(), b_, g, float(b_) / n_pm, m[M_PROBS:M_PROBS + g].data_ptr(),
                               torch.cuda.current_stream().cuda_stream)
             loss = HF.CeMeanFn.apply(net_chooser_weights, target, None, m[M_PM:M_PM + 1], n_pm)
+        HF.mark("PM.loss.end")
         self.optimizerG.zero_grad()
         self._backward([loss], [self._w["pi"]])
+        HF.mark("PM.bwd.end")
         self.dist.all_reduce_grads(self.G)
         self.optimizerG.step(0.0, zero_grad=self.zero_grads_in_step)
+        HF.mark("PM.opt.end")
         items = [("probs/Gen {} probability".format(i), M_PROBS + i) for i in range(g)]
         self._emit(metrics, items + [("train/net_chooser_loss", M_PM)])
 
