@@ -195,7 +195,7 @@ class _WgradDesc(ctypes.Structure):
                 ("feature_major", ctypes.c_int)]
 
 
-_DEFER = {"on": False, "descs": [], "keep": [], "gemms": []}
+_DEFER = {"on": False, "descs": [], "keep": [], "gemms": [], "events": {}}
 TRACE_NOTES = {"wgrad_multi_flops": [], "mlp_chain_flops": []}
 
 
@@ -209,18 +209,32 @@ def _queue_reduce(P, dW, db, M, Naug, has_bias, lddw, splits, groups, p_stride, 
     _DEFER["keep"].extend(keep)
 
 
+def flush_wgrad_gemms():
+    """Launch the queued weight-gradient GEMMs (partial sums; one launch per operand layout and 16 problems) on
+    the current stream.  Called BEFORE the branch streams are joined: the GEMMs need the branch streams only up to
+    the points where those queued their operands (events recorded then), so they run beside the rest of a branch's
+    backward (the scene CNN's convolution adjoints) instead of after it."""
+    gm = _DEFER["gemms"]
+    if not gm:
+        return
+    cur = torch.cuda.current_stream()
+    for ev in _DEFER["events"].values():
+        cur.wait_event(ev)
+    _DEFER["events"] = {}
+    arr = (_WgradDesc * len(gm))(*gm)
+    if _load_lib().trace is not None:  # bench.py's per-entry trace: algorithmic FLOPs of this batch
+        TRACE_NOTES["wgrad_multi_flops"].append(sum(2.0 * g.rows * g.K * g.N for g in gm))
+    lib.mggan_wgrad_multi(ctypes.addressof(arr), len(gm), _s())
+    _DEFER["gemms"] = []
+
+
 def flush_grad_reduces():
     """Batched reduce.  Two partial buffers that accumulate into the SAME gradient tensor (e.g. the real and
     the fake pass of a discriminator step) must not share a launch: batches are cut at such conflicts."""
     d = _DEFER["descs"]
     if not d:
         return
-    gm = _DEFER["gemms"]
-    if gm:  # the queued weight-gradient GEMMs (partial sums), one launch per operand layout and 16 problems
-        arr = (_WgradDesc * len(gm))(*gm)
-        if _load_lib().trace is not None:  # bench.py's per-entry trace: algorithmic FLOPs of this batch
-            TRACE_NOTES["wgrad_multi_flops"].append(sum(2.0 * g.rows * g.K * g.N for g in gm))
-        lib.mggan_wgrad_multi(ctypes.addressof(arr), len(gm), _s())
+    flush_wgrad_gemms()
     batch, seen = [], set()
 
     def launch():
@@ -236,7 +250,7 @@ def flush_grad_reduces():
         batch.append(desc)
         seen |= keys
     launch()
-    _DEFER["descs"], _DEFER["keep"], _DEFER["gemms"] = [], [], []
+    _DEFER["descs"], _DEFER["keep"] = [], []
 
 
 def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scale=1, n_groups=0, w_stride=0,
@@ -257,6 +271,11 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
         _DEFER["gemms"].append(_WgradDesc(pz, px, ws.data_ptr(), _p(seg) or None, rows, K, N, lddz, ldx, seg_scale, n_groups,
                                           fm))
         keep = (ws, dz, x, seg)
+        cur = torch.cuda.current_stream()
+        if any(cur == st for st in _BR["streams"].values()):  # queued from a branch stream: operands ready from here on
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            _DEFER["events"][cur.cuda_stream] = ev
     elif overwrite:  # partial sums now, then a storing (not accumulating) reduction: the destination is scratch
         lib.mggan_wgrad(pz, lddz, px, ldx, 0, lddw, db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, fm,
                         _p(yact), ld_yact, act, float(slope), ws.data_ptr(), nbytes, _s())
@@ -485,10 +504,10 @@ class TwoHeadsFn(Function):
         return (dx,) + (None,) * (6 + len(wb))
 
 
-# Above this many rows the stack runs as one GEMM launch per layer: the chain wins by the launches and round trips
-# it removes (6.7 us against 13.5 us for 1,280 x 64 x 32 x 32), at 25,600 rows it only ties the GEMMs forward (35.7 vs
-# 35.2 us) and loses backward.
-MLP_FUSE_MAX_ROWS = int(os.environ.get("MGGAN_MLP_FUSE_MAX_ROWS", "8192"))
+# Above this many rows the stack runs as one GEMM launch per layer.  Kernel for kernel the chain only ties the
+# GEMMs at 25,600 rows (35.7 vs 35.2 us forward), but inside the iteration graph every launch it removes is a
+# dependent hop less on the critical chain: 2.38 ms/iter with the 25,600-row discriminator pass fused, 2.40 without.
+MLP_FUSE_MAX_ROWS = int(os.environ.get("MGGAN_MLP_FUSE_MAX_ROWS", "32768"))
 
 
 def mlp(x, layers, owner=None):
@@ -507,8 +526,10 @@ def mlp(x, layers, owner=None):
     return y.reshape(*lead, -1)
 
 
-def two_heads(x, layers_a, layers_b, row0):
-    """-> (head_a(x), head_b(x[row0:])) through TwoHeadsFn (both stacks small enough for the fused chain)."""
+def two_heads(x, layers_a, layers_b, row0=0):
+    """-> (head_a(x), head_b(x[row0:])): one autograd node (TwoHeadsFn) when the fused chain applies."""
+    if x.shape[0] > MLP_FUSE_MAX_ROWS:
+        return mlp(x, layers_a), mlp(x[row0:] if row0 else x, layers_b)
     spec_a = tuple((act, slope) for _, act, slope in layers_a)
     spec_b = tuple((act, slope) for _, act, slope in layers_b)
     wb = []

@@ -1,5 +1,7 @@
 """MultiDiscriminatorTrajectory with the reference's class surface
 (/root/reference/mggan/model/modules/discriminators.py:12-219), gan_type 'mgan' / 'gan'."""
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -59,21 +61,24 @@ class MultiDiscriminatorTrajectory(FlatModule):
             pred_enc = pad.index_copy(0, mask.repeat(n_samples).nonzero().flatten(), pred_enc)
         return torch.cat([in_enc.repeat(n_samples, 1), pred_enc], dim=1)
 
-    def history_context(self, in_dxdy, img, passes=1):
+    def history_context(self, in_dxdy, img, passes=1, lstm_branch=None):
         """(in_enc (b,h/2), scene (b,64)): everything that depends only on the observed history and the
         image crop.  The real and the fake pass of one discriminator step share it (identical inputs and
         weights), autograd sums their cotangents, so the history LSTM and the scene CNN run forward and
-        backward once instead of twice; `passes` keeps the BatchNorm running-stat count of the reference."""
+        backward once instead of twice; `passes` keeps the BatchNorm running-stat count of the reference.
+        The scene CNN goes to branch stream 0; the history LSTM stays on the caller's stream or goes to branch
+        stream `lstm_branch` (the caller joins both before it uses the results)."""
         self.ensure_flat()
         fc = self.in_encoder_fc
         with HF.branch():  # scene CNN || history LSTM; joined by forward() right before the classifier input
             HF.mark("Dctx.cnn.begin")
             scene = self.scene_encoder(img, stat_updates=passes)
             HF.mark("Dctx.cnn.end")
-        HF.mark("Dctx.lstm.begin")
-        h = self.in_encoder(in_dxdy)
-        in_enc = HF.mlp(h, [(fc[0], HF.ACT_LEAKY, 0.2), (fc[2], HF.ACT_NONE, 0.0)])
-        HF.mark("Dctx.lstm.end")
+        with HF.branch(lstm_branch) if lstm_branch is not None else contextlib.nullcontext():
+            HF.mark("Dctx.lstm.begin")
+            h = self.in_encoder(in_dxdy)
+            in_enc = HF.mlp(h, [(fc[0], HF.ACT_LEAKY, 0.2), (fc[2], HF.ACT_NONE, 0.0)])
+            HF.mark("Dctx.lstm.end")
         return in_enc, scene
 
     def _encode_parts(self, in_dxdy, pred_dxdy, context=None):
@@ -151,10 +156,10 @@ class MultiDiscriminatorTrajectory(FlatModule):
             classifier_inp = torch.cat([classifier_inp, scene], 1)
 
         d = self.discs[0]
-        y = HF.mlp(classifier_inp, [(d[0], HF.ACT_LEAKY, 0.2), (d[2], self._out_act(), 0.0)])
-        output = y.reshape(n_samples, b).t()  # mean over the single discriminator is the identity
+        head = [(d[0], HF.ACT_LEAKY, 0.2), (d[2], self._out_act(), 0.0)]
         if self.gan_type == "gan":
-            return output
+            return HF.mlp(classifier_inp, head).reshape(n_samples, b).t()
         r = self.gen_id_reconstructor
-        branch_out = HF.mlp(classifier_inp, [(r[0], HF.ACT_LEAKY, 0.2), (r[2], HF.ACT_NONE, 0.0)])
+        y, branch_out = HF.two_heads(classifier_inp, head, [(r[0], HF.ACT_LEAKY, 0.2), (r[2], HF.ACT_NONE, 0.0)])
+        output = y.reshape(n_samples, b).t()  # mean over the single discriminator is the identity
         return output, branch_out.reshape(n_samples, b, -1).transpose(0, 1)

@@ -50,6 +50,9 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         # legitimate de-duplications (same results): D's history context once per D step, and the
         # generator trunk once for {no-grad G call of the D step, G step} (G's weights do not change in between)
         self.share_context = True
+        # branch stream of D's history LSTM in the generator step: 0 = behind D's scene CNN on the same stream,
+        # 2 = a third stream (measured slower: the rollout forward next to it loses more than the LSTM gains)
+        self.g_step_lstm_branch = int(os.environ.get("MGGAN_G_LSTM_BRANCH", "0"))
         self.share_trunk = True
         # weight-gradient GEMMs on a side stream during backward, joined in optimizer.step
         self.overlap_wgrad = os.environ.get("MGGAN_OVERLAP_WGRAD", "0") == "1"  # measured: no gain inside a hipGraph (5.5 vs 5.3 ms)
@@ -57,6 +60,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         # gradient), which removes the memset at the start of the next step; same parameter updates
         self.zero_grads_in_step = False
         self._pending = []
+        self._bwd_stream = None
 
     # ---- metric plumbing ---------------------------------------------------------------
     def _emit(self, train_metrics, items):
@@ -104,11 +108,32 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         HF.enable_side_stream(self.overlap_wgrad)
         HF.defer_grad_reduce(True)  # weight-grad kernels leave partial sums; one batched reduce below
         try:
-            torch.autograd.backward(losses, grads)
+            if HF._BR["on"]:
+                # autograd ends a backward pass by making the CALLER's stream wait for every stream its nodes ran
+                # on.  Called from a throw-away stream, that wait lands there and the main stream stays where its
+                # own last backward node left it: the weight-gradient GEMMs below then run beside the tail of the
+                # branch streams (the scene CNN's convolution adjoints) instead of behind it.
+                main = torch.cuda.current_stream()
+                if self._bwd_stream is None:
+                    self._bwd_stream = torch.cuda.Stream()
+                self._bwd_stream.wait_stream(main)
+                with torch.cuda.stream(self._bwd_stream):
+                    torch.autograd.backward(losses, grads)
+            else:
+                torch.autograd.backward(losses, grads)
         finally:
             HF.enable_side_stream(False)
             HF.defer_grad_reduce(False)
         HF.join_side_stream()
+        HF.mark("bwd.main.end")
+        HF.flush_wgrad_gemms()  # beside what is left of the branch streams' backward (the scene CNN's convolutions)
+        HF.mark("bwd.gemms.end")
+        if HF._MARKS["on"]:
+            for w, side in HF._BR["streams"].items():
+                with torch.cuda.stream(side):
+                    HF.mark("bwd.branch{}.end".format(w))
+        if HF._BR["on"]:
+            torch.cuda.current_stream().wait_stream(self._bwd_stream)
         HF.join_branch(force=True)  # backward nodes ran on the streams of their forwards
         HF.flush_grad_reduces()
 
@@ -204,12 +229,10 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         try:
             ctx_d = None
             if loss_mask is None and self.share_context:
-                # D's history LSTM + scene CNN depend on neither G nor (in this step) any gradient: they run on the
-                # branch stream next to the generator's forward pass
-                with HF.branch(), torch.no_grad():
-                    HF.mark("G.dctx.begin")
-                    ctx_d = self.D.history_context(in_dxdy, img, passes=1)
-                    HF.mark("G.dctx.end")
+                # D's history LSTM + scene CNN depend on neither G nor (in this step) any gradient: they run on
+                # branch streams (CNN on 0, LSTM on 2) next to the generator's forward pass
+                with torch.no_grad():
+                    ctx_d = self.D.history_context(in_dxdy, img, passes=1, lstm_branch=self.g_step_lstm_branch)
             noise = self.rng.noise(cfg.num_samples, cfg.noise_dim, sub_batches, self.device)
             gen_out, _, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
                                           mask=loss_mask, num_samples=cfg.num_samples,
@@ -236,7 +259,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                     HF.mark("G.l2.end")
 
             if ctx_d is not None:
-                HF.join_branch(*ctx_d, which=0)
+                HF.join_branch(ctx_d[1], which=0)
+                HF.join_branch(ctx_d[0], which=self.g_step_lstm_branch)
             HF.mark("G.dpass.begin")
             disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask,
                               context=ctx_d)
