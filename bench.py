@@ -173,10 +173,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("MGGAN_FORCE_DIST", "0") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # MGGAN_DIST_BACKEND=gloo lets two ranks share ONE GPU (RCCL refuses that): a functional check of the
         # sharded path on a single-GPU box, never a measurement
@@ -208,11 +211,54 @@ def main():
     metrics = defaultdict(list)
     use_graph = args.rng == "device" and not args.no_graph
     replay = None
-    if use_graph:
+    sharded = tr.dist.enabled
+    if use_graph and sharded and os.environ.get("MGGAN_GRAPH_COLLECTIVES", "auto") != "0":
+        # first choice for a sharded run: the RCCL collectives captured INSIDE one graph.  The attempt is
+        # checked (two replays must leave every rank with identical weights) and bounded in time; if it fails,
+        # a fresh trainer is built and the capture is cut into segments around eager collectives instead.
+        import threading
+
+        from mggan.parallel import replicas_in_sync
+
+        import torch.distributed as dist
+
+        warm = torch.zeros(1, device=dev)
+        dist.all_reduce(warm)  # first collective of the process: RCCL loads its kernels here, however long that takes
+        torch.cuda.synchronize()
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(float(os.environ.get("MGGAN_GRAPH_TRIAL_TIMEOUT", "300"))):
+                print("[bench] rank {}: graph with captured collectives did not finish in time; rerun with "
+                      "MGGAN_GRAPH_COLLECTIVES=0".format(rank), file=sys.stderr, flush=True)
+                os._exit(17)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            replay = tr.capture_iteration(batch)
+            if tr.graph_collectives:
+                for _ in range(2):
+                    replay(metrics, False)
+                torch.cuda.synchronize()
+                if not replicas_in_sync(tr.G, tr.D):
+                    raise RuntimeError("ranks diverged after replaying the captured collectives")
+        except Exception as exc:  # noqa: BLE001
+            print("[bench] rank {}: one-graph capture with RCCL inside failed ({}: {}); cutting the capture into "
+                  "segments".format(rank, type(exc).__name__, exc), file=sys.stderr)
+            replay = None
+            os.environ["MGGAN_GRAPH_COLLECTIVES"] = "0"
+            torch.cuda.synchronize()
+            tr = build_trainer(args.num_gens, args.rng, dev, seed=rank)
+            tr.dist.equal_shards = True
+            tr.defer_metrics = True
+            tr.zero_grads_in_step = True
+        finally:
+            done.set()
+    if use_graph and replay is None:
         try:
             replay = tr.capture_iteration(batch)
         except Exception as exc:  # noqa: BLE001
-            if world == 1:
+            if not sharded:
                 raise
             # every rank runs the same program on the same shapes, so they all end up here together
             print("[bench] rank {}: graph-segment capture failed ({}: {}); launching eagerly".format(
@@ -306,7 +352,9 @@ def main():
                            {(64, 20, 4): "BASELINE configs[1]", (256, 32, 8): "BASELINE configs[2]"}.get(
                                (args.scenes, args.peds, args.num_gens), "custom shape")),
                        "b_per_gpu": b, "parallelism": "dp{}".format(world), "rng": args.rng,
-                       "launch": ("eager" if not use_graph else "hipGraph replay of the whole iteration" if world == 1
+                       "launch": ("eager" if not use_graph else "hipGraph replay of the whole iteration" if not sharded
+                                  else "hipGraph replay of the whole iteration, RCCL collectives captured inside it"
+                                  if getattr(tr, "graph_collectives", False)
                                   else "{} hipGraph segments per iteration, RCCL collectives between them".format(
                                       replay.graph.n_graphs)),
                        "last_losses": {k: round(v[-1], 6) for k, v in sorted(metrics.items()) if "probs" not in k}},
@@ -321,7 +369,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sizes, args.num_gens, args.cpu_iters)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or sharded:
         import torch.distributed as dist
 
         dist.destroy_process_group()

@@ -101,6 +101,18 @@ class MultiGeneratorGAN(abc.ABC):
                                "PM-network logits back to the CPU")
         batch = dict(batch)
         batch["loss_mask"] = None
+        in_graph = False
+        if self.dist.enabled:
+            # RCCL collectives can be captured: the sharded iteration is then ONE graph like the single-GPU one
+            # (branch streams on, no cut per collective).  MGGAN_GRAPH_COLLECTIVES: auto (default: probe the
+            # backend), 1 (insist), 0 (always cut the capture into segments around eager collectives).
+            from mggan.hip import functions as HF
+            from mggan.parallel import graph_collectives_ok
+
+            want = os.environ.get("MGGAN_GRAPH_COLLECTIVES", "auto")
+            in_graph = want == "1" or (want == "auto" and graph_collectives_ok(self.device, self.dist.group))
+            HF.enable_branches(in_graph or os.environ.get("MGGAN_BRANCH_SHARDED", "0") == "1")
+        self.graph_collectives = in_graph
         keep, self.defer_metrics = self.defer_metrics, True
         scratch = defaultdict(list)
         side = torch.cuda.Stream()
@@ -111,7 +123,7 @@ class MultiGeneratorGAN(abc.ABC):
         torch.cuda.current_stream().wait_stream(side)
         self.flush_metrics()
         captured = defaultdict(list)
-        if self.dist.enabled:
+        if self.dist.enabled and not in_graph:
             # sharded iteration: the collectives cut the capture into graph segments and stay eager calls
             # between them (parallel.SegmentRecorder)
             from mggan.parallel import SegmentRecorder
@@ -136,7 +148,8 @@ class MultiGeneratorGAN(abc.ABC):
             dot = os.environ.get("MGGAN_GRAPH_DOT")  # debugging aid: dump the captured graph's nodes and edges
             if dot:
                 graph.enable_debug_mode()
-            with torch.cuda.graph(graph):
+            # (thread_local: RCCL's watchdog thread may query events while this thread captures)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if in_graph else "global"):
                 self.train_iteration(batch, captured)
             if dot:
                 graph.debug_dump(dot)

@@ -9,6 +9,8 @@ What couples the ranks:
   C3  batch-global counters  -> generator-id counts and loss normalisers
 All messages are <= 360 KB: latency-bound, so they are kept to one collective each.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -48,7 +50,10 @@ class DistContext:
     """Collective hooks used by the modules / trainer.  world_size == 1 -> every hook is the identity."""
 
     def __init__(self, group=None):
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # MGGAN_FORCE_DIST=1: run the collective hooks with a single rank too (exercises the RCCL code path,
+        # including its capture into a HIP graph, on a one-GPU box)
+        self.enabled = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or os.environ.get("MGGAN_FORCE_DIST", "0") == "1")
         self.group = group
         self.world_size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
@@ -119,6 +124,57 @@ class DistContext:
                     m.sync = self if self.enabled else None
             if r._flat is not None:
                 self._dev = r._flat.device
+
+
+def graph_collectives_ok(device, group=None):
+    """Can this backend's all-reduce be captured into a HIP graph and replayed?  RCCL can (the collective becomes
+    graph nodes on its internal stream); gloo cannot.  Checked by doing it: one small all-reduce captured, replayed
+    three times, results compared with the expected sums.  Every rank takes the same decision (the verdict itself
+    is all-reduced eagerly)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
+        return False
+    ok = 1.0
+    try:
+        world = dist.get_world_size(group)
+        x = torch.zeros(256, dtype=torch.float32, device=device)
+        y = torch.zeros(256, dtype=torch.float32, device=device)
+        dist.all_reduce(y, group=group)  # communicator set up outside the capture
+        torch.cuda.synchronize(device)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            g.capture_begin(capture_error_mode="thread_local")
+            y.copy_(x)
+            dist.all_reduce(y, group=group)
+            y.mul_(2.0)
+            g.capture_end()
+        torch.cuda.current_stream(device).wait_stream(side)
+        for i in range(3):
+            x.fill_(float(i + 1))
+            g.replay()
+            torch.cuda.synchronize(device)
+            if not torch.allclose(y, torch.full_like(y, 2.0 * world * (i + 1))):
+                ok = 0.0
+    except Exception:  # noqa: BLE001 -- any failure means "use the segmented path"
+        ok = 0.0
+    try:
+        torch.cuda.synchronize(device)
+    except Exception:  # noqa: BLE001
+        ok = 0.0
+    v = torch.tensor([ok], dtype=torch.float32, device=device)
+    dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+    return bool(v.item() > 0.5)
+
+
+def replicas_in_sync(*roots, group=None):
+    """Data-parallel invariant: after any number of optimizer steps every rank holds the same weights.
+    (max - min over the ranks of each flat parameter buffer's checksum must be exactly zero.)"""
+    sums = torch.stack([r._flat.double().sum() for r in roots] + [r._flat.double().abs().sum() for r in roots])
+    hi, lo = sums.clone(), sums.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    return bool(torch.isfinite(hi).all()) and bool((hi == lo).all())
 
 
 class SegmentRecorder:

@@ -151,3 +151,55 @@ def test_two_ranks_graph_segments():
         assert len(v) == 3 and np.isfinite(v).all(), k
         np.testing.assert_allclose(v, m1[k], rtol=1e-6)      # logged losses are global means on every rank
     assert 0.2 < m0["train/discr_loss"][-1] < 3.0
+
+
+def _run_one_graph(port, sizes, q):
+    """One rank, RCCL backend, collective hooks forced on: the all-reduces are captured inside the iteration graph."""
+    import sys
+
+    for p in (os.path.join(ROOT, "mg-gan_amd"), ROOT):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MGGAN_FORCE_DIST="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    import bench
+    from mggan.data_utils import synthetic
+    from mggan.parallel import graph_collectives_ok, replicas_in_sync
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    ok = graph_collectives_ok(dev)
+    tr = bench.build_trainer(2, "device", dev, seed=0)
+    assert tr.dist.enabled
+    tr.dist.equal_shards = True
+    batch = tr.to_device(synthetic.make_batch(sizes, seed=9))
+    batch["loss_mask"] = None
+    tr.defer_metrics = True
+    m = defaultdict(list)
+    replay = tr.capture_iteration(batch, warmup=2)
+    for _ in range(3):
+        replay(m, True)
+    torch.cuda.synchronize()
+    sync = replicas_in_sync(tr.G, tr.D)
+    flat = torch.cat([tr.G._flat.cpu(), tr.D._flat.cpu()])
+    one_graph = isinstance(replay.graph, torch.cuda.CUDAGraph)
+    dist.destroy_process_group()
+    q.put((ok, tr.graph_collectives, one_graph, sync, flat.numpy(), {k: v for k, v in m.items() if "probs" not in k}))
+
+
+def test_rccl_collectives_inside_one_graph():
+    """RCCL all-reduces are capturable: the sharded iteration is then ONE HIP graph (no segment per collective)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_run_one_graph, args=(_free_port(), [3, 3, 3, 3], q))
+    p.start()
+    ok, in_graph, one_graph, sync, flat, m = q.get(timeout=900)  # (a cold box pages librccl.so in first: minutes)
+    p.join(60)
+    assert p.exitcode == 0
+    assert ok and in_graph and one_graph and sync
+    assert np.isfinite(flat).all()
+    for k, v in m.items():
+        assert len(v) == 3 and np.isfinite(v).all(), k
+    assert 0.2 < m["train/discr_loss"][-1] < 3.0
