@@ -128,10 +128,9 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         HF.mark("bwd.main.end")
         HF.flush_wgrad_gemms()  # beside what is left of the branch streams' backward (the scene CNN's convolutions)
         HF.mark("bwd.gemms.end")
-        if HF._MARKS["on"]:
-            for w, side in HF._BR["streams"].items():
-                with torch.cuda.stream(side):
-                    HF.mark("bwd.branch{}.end".format(w))
+        if HF._MARKS["on"] and 0 in HF._BR["streams"]:
+            with torch.cuda.stream(HF._BR["streams"][0]):
+                HF.mark("bwd.branch0.end")
         if HF._BR["on"]:
             torch.cuda.current_stream().wait_stream(self._bwd_stream)
         HF.join_branch(force=True)  # backward nodes ran on the streams of their forwards

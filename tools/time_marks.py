@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Where one iteration's time goes, measured without a profiler: MGGAN_MARKS=1 makes the trainer drop one-lane
+timestamp kernels (mggan_timestamp: the device's 100 MHz wall clock) at the step boundaries and the fork / join
+points of its stream graph; they are captured into the iteration's HIP graph and read back after a replay.
+(rocprofv3 --kernel-trace serialises parts of a multi-stream graph and stretches the iteration by ~15 %;
+the marks cost ~2 us each.)      python tools/time_marks.py [scenes] [peds] [num_gens]"""
+import os
+import sys
+import time
+from collections import defaultdict
+
+os.environ["MGGAN_MARKS"] = "1"
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [R, os.path.join(R, "mg-gan_amd")]
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from mggan.data_utils import synthetic  # noqa: E402
+from mggan.hip import functions as HF  # noqa: E402
+
+
+def main(scenes=64, peds=20, num_gens=4):
+    dev = torch.device("cuda", 0)
+    tr = bench.build_trainer(num_gens, "device", dev)
+    batch = tr.to_device(synthetic.make_batch(synthetic.scene_sizes(scenes, peds), seed=0))
+    batch["loss_mask"] = None
+    tr.defer_metrics = True
+    tr.zero_grads_in_step = True
+    m = defaultdict(list)
+    HF._MARKS["on"] = False
+    for _ in range(3):
+        tr.train_iteration(batch, m)
+    torch.cuda.synchronize()
+    HF._MARKS["on"] = True
+    replay = tr.capture_iteration(batch, warmup=0)
+    HF._MARKS["on"] = False
+    for _ in range(10):
+        replay(m, False)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(50):
+        replay(m, False)
+    torch.cuda.synchronize()
+    print("# {} scenes x {} pedestrians, {} generators: {:.3f} ms per iteration with the marks in the graph".format(
+        scenes, peds, num_gens, (time.perf_counter() - t) / 50 * 1e3))
+    print("# microseconds since the first mark of the iteration; one replay")
+    replay(m, False)
+    replay(m, False)
+    torch.cuda.synchronize()
+    for name, us in HF.read_marks():
+        print("{:9.1f}  {}".format(us, name))
+
+
+if __name__ == "__main__":
+    main(*[int(a) for a in sys.argv[1:4]])
