@@ -212,9 +212,9 @@ def main():
     use_graph = args.rng == "device" and not args.no_graph
     replay = None
     sharded = tr.dist.enabled
-    if use_graph and sharded and os.environ.get("MGGAN_GRAPH_COLLECTIVES", "auto") != "0":
-        # first choice for a sharded run: the RCCL collectives captured INSIDE one graph.  The attempt is
-        # checked (two replays must leave every rank with identical weights) and bounded in time; if it fails,
+    if use_graph and sharded and os.environ.get("MGGAN_GRAPH_COLLECTIVES", "0") != "0":
+        # opt-in (MGGAN_GRAPH_COLLECTIVES=1|auto, experimental): the RCCL collectives captured INSIDE one graph.  The
+        # attempt is checked (two replays must leave every rank with identical weights) and bounded in time; if it fails,
         # a fresh trainer is built and the capture is cut into segments around eager collectives instead.
         import threading
 

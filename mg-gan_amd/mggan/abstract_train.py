@@ -104,12 +104,15 @@ class MultiGeneratorGAN(abc.ABC):
         in_graph = False
         if self.dist.enabled:
             # RCCL collectives can be captured: the sharded iteration is then ONE graph like the single-GPU one
-            # (branch streams on, no cut per collective).  MGGAN_GRAPH_COLLECTIVES: auto (default: probe the
-            # backend), 1 (insist), 0 (always cut the capture into segments around eager collectives).
+            # (branch streams on, no cut per collective).  EXPERIMENTAL, opt-in with MGGAN_GRAPH_COLLECTIVES=1
+            # ("auto": probe the backend first): with torch 2.10 / RCCL 2.26 the process group's watchdog thread
+            # intermittently queries an event that was recorded inside the capture and aborts the process
+            # (hipErrorCapturedEvent, about one run in three on one MI355X), so the default stays the segmented
+            # capture around eager collectives.
             from mggan.hip import functions as HF
             from mggan.parallel import graph_collectives_ok
 
-            want = os.environ.get("MGGAN_GRAPH_COLLECTIVES", "auto")
+            want = os.environ.get("MGGAN_GRAPH_COLLECTIVES", "0")
             in_graph = want == "1" or (want == "auto" and graph_collectives_ok(self.device, self.dist.group))
             HF.enable_branches(in_graph or os.environ.get("MGGAN_BRANCH_SHARDED", "0") == "1")
         self.graph_collectives = in_graph
