@@ -145,12 +145,14 @@ int mggan_social_pairs_bwd(int P, int b, const int* pair_j, const int* ped_prow,
 /* Fused launches of the same math over pedestrian-aligned tiles: tiles[t] = {ped0, ped1, first pair, pair count},
  * consecutive pedestrians whose pairs are contiguous and number <= 64 (host-built once per batch; a scene of more
  * than 64 pedestrians needs the unfused entry points above).  _fwd = pairs_fwd + softmax_fwd in one launch (sigma
- * never reaches HBM), _bwd = softmax_bwd + pairs_bwd in one launch plus one launch for both column reductions. */
+ * never reaches HBM), _bwd = softmax_bwd + pairs_bwd in one launch plus one launch for both column reductions.
+ * xy_mod > 0: the pedestrian rows repeat with that period (xy_last / dxdy_last hold one period: the real and the fake
+ * half of a discriminator pair pass share the observed positions). */
 int mggan_social_attention_fwd(int n_tiles, const int* tiles, int P, int H, const int* pair_i, const int* pair_j,
                                const int* ped_prow, const int* ped_s0, const int* ped_n, const float* xy_last,
                                const float* dxdy_last, const float* W1, const float* b1, const float* W2,
                                const float* b2, const float* vc, const float* h, int ld_h, float* feat, float* l1,
-                               float* l2, float* att, float* S, int ld_s, mggan_stream_t stream);
+                               float* l2, float* att, float* S, int ld_s, int xy_mod, mggan_stream_t stream);
 int mggan_social_attention_bwd(int n_tiles, const int* tiles, int P, int b, int H, const int* pair_i,
                                const int* pair_j, const int* ped_prow, const int* ped_s0, const int* ped_n,
                                const float* att, const float* h, int ld_h, const float* dS, int ld_ds,
@@ -248,6 +250,10 @@ int mggan_d_assemble_fwd(int b, int K, int w_soc, int w_in, int w_pred, int w_sc
                          mggan_stream_t stream);
 int mggan_d_assemble_bwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, int soc_all, const float* dX,
                          float* dsoc0, float* din_enc, float* dpred_enc, float* dscene, mggan_stream_t stream);
+/* Time-major steps -> one row per trajectory: out[r][2t+c] = a[t][r][c] for r < n, and (b != NULL) out[n+r][2t+c] =
+ * b[t][r][c] -- the input of the discriminator's pred_encoder (discriminators.py:129-131 permute + reshape; the real and
+ * the fake trajectories of a pair pass in one launch) */
+int mggan_steps_to_rows(const float* a, const float* b, int T, int n, float* out, mggan_stream_t stream);
 int mggan_ce_rows(int rows, int g, const float* logits, int ld, const int* target, const float* inv_count, float scale,
                   float* loss_rows, float* dlogits, int ldd, mggan_stream_t stream);
 int mggan_l2_min_scene(int S, int T, int K, int b, const int* scenes, const int* ped_scene, const float* gen_abs,

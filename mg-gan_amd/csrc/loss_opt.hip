@@ -32,6 +32,17 @@ __global__ void bce_rows_kernel(int rows, int kind, const float* __restrict__ p_
   if (dp) dp[r] = -w * (y / p - (1.f - y) / (1.f - p));
 }
 
+// out[r][2t+c] = (r < n ? a : b)[t][r mod n][c]
+__global__ void steps_to_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, int T, int n, int rows,
+                                     float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * T) return;
+  const int r = (int)(i / T), t = (int)(i % T);
+  const float* src = r < n ? a : b;
+  const float2 v = *reinterpret_cast<const float2*>(src + ((size_t)t * n + (r < n ? r : r - n)) * 2);
+  *reinterpret_cast<float2*>(out + ((size_t)r * T + t) * 2) = v;
+}
+
 __global__ void scale_kernel(float* x, long n, const float* __restrict__ s) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= *s;
@@ -563,6 +574,67 @@ __global__ __launch_bounds__(BR_BLOCK) void bucket_scatter_kernel(const int* __r
   }
 }
 
+// The four passes in ONE workgroup for small row counts (the single-sample rollouts of the discriminator step:
+// three dependent launches less on its critical chain).  Same stable order as the multi-pass version.
+__global__ __launch_bounds__(BR_BLOCK) void bucket_small_kernel(const long long* __restrict__ idx, int b, int K, int g,
+                                                                int* row_gen_pos, int* inv, int* seg, int* row_gen,
+                                                                int* row_ped, int* row_slot, int* row_pos) {
+  __shared__ int hist[BR_MAXG], base[BR_MAXG], wcnt[BR_BLOCK / 64][BR_MAXG];
+  const int R = b * K, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t < BR_MAXG) hist[t] = 0;
+  __syncthreads();
+  for (int ped = t; ped < b; ped += BR_BLOCK) {
+    int seen[BR_MAXG];
+#pragma unroll
+    for (int q = 0; q < BR_MAXG; ++q) seen[q] = 0;
+    for (int k = 0; k < K; ++k) {
+      const int gi = (int)idx[(size_t)ped * K + k];
+      int slot = 0;
+#pragma unroll
+      for (int q = 0; q < BR_MAXG; ++q) {
+        if (q == gi) { slot = seen[q]; seen[q] += 1; }
+      }
+      row_gen_pos[k * b + ped] = gi;
+      inv[k * b + ped] = slot;
+      atomicAdd(&hist[gi], 1);
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int i = 0; i < g; ++i) { seg[i] = run; base[i] = run; run += hist[i]; }
+    seg[g] = run;
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < R; c0 += BR_BLOCK) {
+    const int pos = c0 + t;
+    const bool ok = pos < R;
+    const int gi = ok ? row_gen_pos[pos] : -1;
+    int rank = 0;
+    for (int q = 0; q < g; ++q) {
+      const unsigned long long m = __ballot(gi == q);
+      if (gi == q) rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wcnt[wv][q] = __popcll(m);
+    }
+    __syncthreads();
+    if (ok) {
+      int before = 0;
+      for (int i = 0; i < wv; ++i) before += wcnt[i][gi];
+      const int r = base[gi] + before + rank;
+      const int slot = inv[pos];
+      row_gen[r] = gi; row_ped[r] = pos % b; row_slot[r] = slot; row_pos[r] = pos; inv[pos] = r;
+    }
+    __syncthreads();
+    if (t < g) {
+      int tot = 0;
+      for (int i = 0; i < BR_BLOCK / 64; ++i) tot += wcnt[i][t];
+      base[t] += tot;
+    }
+    __syncthreads();
+  }
+}
+
 // Categorical(logits).sample((K,)).T by inverse CDF from caller-provided uniforms u (b,K) in [0,1):
 // one lane per pedestrian (standard.py:217-225 on the device, no host round trip)
 __global__ void sample_categorical_kernel(int b, int K, int g, const float* __restrict__ logits,
@@ -601,6 +673,12 @@ int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, i
   MG_CHECK_ARG(g >= 1 && g <= BR_MAXG, "bucket_rows: num_gens %d exceeds %d", g, BR_MAXG);
   const int R = b * K, nblk = cdiv(R, BR_BLOCK);
   if (R == 0) return MGGAN_OK;
+  if (R <= 4 * BR_BLOCK) {
+    hipLaunchKernelGGL(bucket_small_kernel, dim3(1), dim3(BR_BLOCK), 0, stream, idx, b, K, g, row_gen_pos, inv, seg,
+                       row_gen, row_ped, row_slot, row_pos);
+    MG_LAUNCH_CHECK("bucket_rows");
+    return MGGAN_OK;
+  }
   hipLaunchKernelGGL(bucket_slots_kernel, dim3(cdiv(b, 256)), dim3(256), 0, stream, idx, b, K, row_gen_pos, inv);
   hipLaunchKernelGGL(bucket_count_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, g, blk_cnt);
   hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(64), 0, stream, nblk, g, blk_cnt, seg);
@@ -637,6 +715,16 @@ int mggan_gan_losses(const void* args, hipStream_t stream) {
   wgs = wgs < 1 ? 1 : (wgs > GAN_LOSS_MAX_WG ? GAN_LOSS_MAX_WG : wgs);
   hipLaunchKernelGGL(gan_losses_kernel, dim3(wgs), dim3(1024), 0, stream, a);
   MG_LAUNCH_CHECK("gan_losses");
+  return MGGAN_OK;
+}
+
+int mggan_steps_to_rows(const float* a, const float* b, int T, int n, float* out, hipStream_t stream) {
+  MG_CHECK_ARG(T >= 0 && n >= 0, "steps_to_rows: negative size");
+  const int rows = b ? 2 * n : n;
+  if ((long)rows * T == 0) return MGGAN_OK;
+  MG_CHECK_ARG(a && out, "steps_to_rows: null pointer");
+  hipLaunchKernelGGL(steps_to_rows_kernel, dim3(cdiv((long)rows * T, 256)), dim3(256), 0, stream, a, b, T, n, rows, out);
+  MG_LAUNCH_CHECK("steps_to_rows");
   return MGGAN_OK;
 }
 

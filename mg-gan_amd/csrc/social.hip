@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void social_fwd_fused_kernel(
     const float* __restrict__ xy, const float* __restrict__ dxy, const float* __restrict__ W1,
     const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
     const float* __restrict__ vc, const float* __restrict__ h, int ld_h, float* feat, float* l1s, float* l2s,
-    float* att, float* S, int ld_s) {
+    float* att, float* S, int ld_s, int xy_mod) {
   __shared__ float part[4][64];
   __shared__ float sg_s[64], a_s[64];
   const int4 tl = tiles[blockIdx.x];
@@ -245,7 +245,9 @@ __global__ __launch_bounds__(256) void social_fwd_fused_kernel(
     const int p = p0 + (ok ? lane : 0);
     const int i = pair_i[p], j = pair_j[p];
     float f[3];
-    pair_features(xy, dxy, i, j, f);
+    // xy_mod > 0: pedestrian rows repeat with that period (the real and the fake half of a pair pass share the
+    // observed positions), so the position tables hold one period only
+    pair_features(xy, dxy, xy_mod > 0 ? i % xy_mod : i, xy_mod > 0 ? j % xy_mod : j, f);
     float l1[L1];
 #pragma unroll
     for (int k = 0; k < L1; ++k) {
@@ -490,9 +492,9 @@ int mggan_social_attention_fwd(int n_tiles, const int* tiles, int P, int H, cons
                                const int* ped_prow, const int* ped_s0, const int* ped_n, const float* xy_last,
                                const float* dxdy_last, const float* W1, const float* b1, const float* W2,
                                const float* b2, const float* vc, const float* h, int ld_h, float* feat, float* l1,
-                               float* l2, float* att, float* S, int ld_s, hipStream_t stream) {
+                               float* l2, float* att, float* S, int ld_s, int xy_mod, hipStream_t stream) {
   MG_CHECK_ARG(H == 32 || H == 64, "social_attention_fwd: hidden size %d not built (32 or 64)", H);
-  MG_CHECK_ARG(n_tiles >= 0 && P >= 0, "social_attention_fwd: negative size");
+  MG_CHECK_ARG(n_tiles >= 0 && P >= 0 && xy_mod >= 0, "social_attention_fwd: negative size");
   if (n_tiles == 0) return MGGAN_OK;
   MG_CHECK_ARG(tiles && ped_prow && ped_s0 && ped_n && h && S, "social_attention_fwd: null pointer");
   MG_CHECK_ARG(P == 0 || (pair_i && pair_j && xy_last && dxdy_last && W1 && b1 && W2 && b2 && vc && att),
@@ -503,11 +505,11 @@ int mggan_social_attention_fwd(int n_tiles, const int* tiles, int P, int H, cons
   if (H == 32)
     hipLaunchKernelGGL((social_fwd_fused_kernel<32>), dim3(n_tiles), dim3(256), 0, stream, t4, P, pair_i, pair_j,
                        ped_prow, ped_s0, ped_n, xy_last, dxdy_last, W1, b1, W2, b2, vc, h, ld_h, feat, l1, l2, att, S,
-                       ld_s);
+                       ld_s, xy_mod);
   else
     hipLaunchKernelGGL((social_fwd_fused_kernel<64>), dim3(n_tiles), dim3(256), 0, stream, t4, P, pair_i, pair_j,
                        ped_prow, ped_s0, ped_n, xy_last, dxdy_last, W1, b1, W2, b2, vc, h, ld_h, feat, l1, l2, att, S,
-                       ld_s);
+                       ld_s, xy_mod);
   MG_LAUNCH_CHECK("social_attention_fwd");
   return MGGAN_OK;
 }

@@ -82,6 +82,8 @@ class MultiGeneratorGAN(abc.ABC):
             gt_dxdy, gt_xy = gt_dxdy[:, loss_mask], gt_xy[:, loss_mask]
         img = batch["features"] if "features" in batch else None
         args = (in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, metrics, loss_mask, img)
+        if hasattr(self.rng, "begin_iteration"):
+            self.rng.begin_iteration()
         shared = None
         if getattr(self, "share_trunk", False) and loss_mask is None and self.config.num_unrolling_steps == 0:
             # G is not updated between the no-grad generator call of the D step and the G step: one trunk

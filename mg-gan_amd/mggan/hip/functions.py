@@ -526,6 +526,15 @@ def mlp(x, layers, owner=None):
     return y.reshape(*lead, -1)
 
 
+def steps_to_rows(a, b=None):
+    """(T, n, 2) time-major steps [and a second set] -> (n [+ n], 2T) rows, one launch; inputs carry no gradient."""
+    T, n = a.shape[0], a.shape[-2]
+    a = a.reshape(T, n, 2).contiguous()
+    out = _empty(2 * n if b is not None else n, 2 * T, like=a)
+    lib.mggan_steps_to_rows(_p(a), _p(b.reshape(T, n, 2).contiguous()) if b is not None else 0, T, n, _p(out), _s())
+    return out
+
+
 def two_heads(x, layers_a, layers_b, row0=0):
     """-> (head_a(x), head_b(x[row0:])): one autograd node (TwoHeadsFn) when the fused chain applies."""
     if x.shape[0] > MLP_FUSE_MAX_ROWS:
@@ -650,7 +659,7 @@ class SocialAttentionFn(Function):
     """SocialFeatures -> EmbedSocialFeatures -> AttentionPooling over in-scene pairs (social.py:7-123)."""
 
     @staticmethod
-    def forward(ctx, xy_last, dxdy_last, h, tb, w1, b1, w2, b2, w3, b3, wat, bat, owner, save):
+    def forward(ctx, xy_last, dxdy_last, h, tb, w1, b1, w2, b2, w3, b3, wat, bat, owner, save, xy_mod=0):
         h, ld_h = _rows2d(h)
         b, Hh = h.shape
         Fd = wat.shape[0]
@@ -678,8 +687,11 @@ class SocialAttentionFn(Function):
             lib.mggan_social_attention_fwd(tb.n_tiles, _p(tb.tiles), P, Hh, _p(tb.pair_i), _p(tb.pair_j),
                                            _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(xy_last), _p(dxdy_last),
                                            _p(w1), _p(b1), _p(w2), _p(b2), _p(vc), _p(h), ld_h, _p(feat), _p(l1), _p(l2),
-                                           _p(att), _p(S), Hh, st)
+                                           _p(att), _p(S), Hh, int(xy_mod), st)
         else:  # a scene of more than 64 pedestrians does not fit a tile
+            if xy_mod:
+                rep_n = b // xy_mod
+                xy_last, dxdy_last = xy_last.repeat(rep_n, 1), dxdy_last.repeat(rep_n, 1)
             sigma = _empty(max(P, 1), like=h)
             lib.mggan_social_pairs_fwd(P, _p(tb.pair_i), _p(tb.pair_j), _p(xy_last), _p(dxdy_last), _p(w1), _p(b1),
                                        _p(w2), _p(b2), _p(vc), _p(feat), _p(l1), _p(l2), _p(sigma), st)
@@ -734,7 +746,7 @@ class SocialAttentionFn(Function):
                 wgrad(Wh, Fd, dvc, 65, root.grad_ptr(w3), 64, 0, b, 64, Fd)
                 wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, 65, root.grad_ptr(b3), 1, 0, b, 1, Fd)
                 wgrad(dWh, Fd, h, ld_h, root.grad_ptr(wat), Hh, root.grad_ptr(bat), b, Hh, Fd)
-        return (None, None, dh if ctx.needs_input_grad[2] else None) + (None,) * 11
+        return (None, None, dh if ctx.needs_input_grad[2] else None) + (None,) * 12
 
 
 # ------------------------------------------------------------------------------------------

@@ -102,8 +102,11 @@ class MultiDiscriminatorTrajectory(FlatModule):
         in_enc, scene = context
         b = in_xy.size(1)
         pe = self.pred_encoder
-        x = torch.cat([real_dxdy.reshape(real_dxdy.shape[0], b, 2).permute(1, 0, 2).reshape(b, -1),
-                       fake_dxdy.reshape(fake_dxdy.shape[0], b, 2).permute(1, 0, 2).reshape(b, -1)], 0)
+        if real_dxdy.requires_grad or fake_dxdy.requires_grad:
+            x = torch.cat([real_dxdy.reshape(real_dxdy.shape[0], b, 2).permute(1, 0, 2).reshape(b, -1),
+                           fake_dxdy.reshape(fake_dxdy.shape[0], b, 2).permute(1, 0, 2).reshape(b, -1)], 0)
+        else:  # (the discriminator step: both sets are constants) one launch instead of two permutes + cat
+            x = HF.steps_to_rows(real_dxdy, fake_dxdy)
         pred_enc = HF.mlp(x, [(pe[0], HF.ACT_LEAKY, 0.2), (pe[2], HF.ACT_NONE, 0.0)])
         enc0 = torch.cat([in_enc.repeat(2, 1), pred_enc], dim=1)
         cache = self.__dict__.setdefault("_pair_scenes", {})
@@ -114,7 +117,7 @@ class MultiDiscriminatorTrajectory(FlatModule):
             hit = (seq_start_end, [[int(s), int(e)] for s, e in seq_start_end] +
                    [[int(s) + b, int(e) + b] for s, e in seq_start_end])
             cache[id(seq_start_end)] = hit
-        soc = self.social(in_xy[-1:].repeat(1, 2, 1), in_dxdy[-1:].repeat(1, 2, 1), enc0, hit[1])
+        soc = self.social(in_xy[-1:], in_dxdy[-1:], enc0, hit[1], xy_mod=b)
         HF.join_branch(scene)
         classifier_inp = HF.DAssembleFn.apply(soc, in_enc, pred_enc, scene, 2, True)
         d = self.discs[0]

@@ -31,10 +31,11 @@ class SocialAttention(FlatModule):
         self.feature_embedder = EmbedSocialFeatures(3, social_feat_size)
         self.attention = AttentionPooling(hidden_size, social_feat_size)
 
-    def forward(self, in_xy, in_dxdy, enc_h, sub_batches):
+    def forward(self, in_xy, in_dxdy, enc_h, sub_batches, xy_mod=0):
         """in_xy (T,N,2), in_dxdy (T-1,N,2), enc_h (N,h) -> (N,h).  Only rows covered by
         sub_batches receive features (the discriminator passes a list repeated K times that
-        still indexes the first b rows)."""
+        still indexes the first b rows).  xy_mod > 0: enc_h / sub_batches cover several
+        repetitions of the xy_mod pedestrians that in_xy / in_dxdy describe (pair pass)."""
         HF.root_of(self)
         fc, W = self.feature_embedder.fc, self.attention.W
         b = max(int(e) for _, e in sub_batches) if len(sub_batches) else 0
@@ -42,10 +43,12 @@ class SocialAttention(FlatModule):
         tb = HF.scene_tables(sub_batches, b, enc_h.device)
         xy_l, dxy_l, h = in_xy[-1], in_dxdy[-1], enc_h
         if N != b:  # (identity slices would still cost a zero-fill + copy each in autograd's slice backward)
-            xy_l, dxy_l, h = xy_l[:b], dxy_l[:b], h[:b]
+            h = h[:b]
+            if not xy_mod:
+                xy_l, dxy_l = xy_l[:b], dxy_l[:b]
         S = HF.SocialAttentionFn.apply(xy_l, dxy_l, h, tb, fc[0].weight, fc[0].bias,
                                        fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, W.weight, W.bias, self,
-                                       HF.want_grad(enc_h, W.weight))
+                                       HF.want_grad(enc_h, W.weight), xy_mod)
         if N > b:
             S = torch.cat([S, S.new_zeros(N - b, S.shape[1])], 0)
         return S

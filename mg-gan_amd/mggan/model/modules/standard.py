@@ -118,7 +118,7 @@ class MultiGenerator(FlatModule):
 
     # -- reference surface -------------------------------------------------------------------
     def forward(self, in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=None, num_samples=5, mask=None,
-                trunk=None, logits=None):
+                trunk=None, logits=None, need_samples=True):
         """Returns (GeneratorOutput(rel, abs), net_chooser_out (b_m, g), sampled_gen_idxs (b_m, K) int64).
         abs/rel: (pred_len, K, b_m, 2) or (pred_len, K, g, b_m, 2) when all_gen_out."""
         if img is None:
@@ -145,7 +145,11 @@ class MultiGenerator(FlatModule):
             with torch.no_grad():
                 pa, pr = self._rollout(self._all_rows(K, b, dev), in_xy, in_dxdy, enc_h.detach(),
                                        social_feats.detach(), noise)
-            net_chooser_out, sampled_gen_idxs = self.get_samples(enc_h, num_samples)
+            if need_samples or not getattr(self.rng, "on_device", False):
+                net_chooser_out, sampled_gen_idxs = self.get_samples(enc_h, num_samples)
+            else:  # caller ignores the draw and the device generator owes nobody a seed-compatible stream
+                net_chooser_out, sampled_gen_idxs = self._chooser(enc_h) if self.use_pinet else \
+                    self.net_prior.expand(enc_h.size(0), -1), None
             shape = (self.pred_len, K, g, b, 2)
             return GeneratorOutput(pr.view(shape), pa.view(shape)), net_chooser_out, sampled_gen_idxs
 

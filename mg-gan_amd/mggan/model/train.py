@@ -308,7 +308,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         m, g = self._m, self.G.n_gs
         HF.mark("PM.begin")
         gen_out, net_chooser_weights, _ = self.G(in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=img,
-                                                 num_samples=cfg.num_expectation_samples, mask=mask)
+                                                 num_samples=cfg.num_expectation_samples, mask=mask, need_samples=False)
         n_pm = self._global(net_chooser_weights.shape[0])
         if cfg.weighting_target == "ml":
             loss = HF.PmMlFn.apply(net_chooser_weights, gen_out.abs, gt_xy, cfg.sigma, m[M_PM:M_PM + 1],

@@ -40,9 +40,18 @@ class DeviceRNG:
         torch.cuda.manual_seed(seed)
         self._lens = {}
 
+    def begin_iteration(self):
+        """One launch draws the label uniforms of a whole iteration (three labels() calls)."""
+        self._pool, self._used = torch.rand(8, device="cuda"), 0
+
+    _pool, _used = None, 0
+
     def labels(self):
         """-> ((u, 0.9, 1.0), (u', 0.0, 0.1)): smoothed labels real ~ U(.9,1), fake ~ U(0,.1) as device draws."""
-        u = torch.rand(2, device="cuda")
+        if self._pool is None or self._used + 2 > self._pool.numel():
+            self.begin_iteration()
+        u = self._pool[self._used:self._used + 2]
+        self._used += 2
         return (u[0:1], 0.9, 1.0), (u[1:2], 0.0, 0.1)
 
     def noise(self, num_samples, dim, sub_batches, device):

@@ -12,7 +12,8 @@ def test_bucket_rows_matches_host_tables():
     from mggan.hip.functions import RolloutRows, device_rollout_rows
     from mggan.utils import get_selection_indices
 
-    for b, K, g, seed in ((7, 20, 4, 0), (1280, 20, 4, 1), (33, 5, 1, 2), (513, 20, 8, 3)):
+    for b, K, g, seed in ((7, 20, 4, 0), (1280, 20, 4, 1), (33, 5, 1, 2), (513, 20, 8, 3), (1280, 1, 4, 4),
+                          (2000, 2, 8, 5)):
         idx = torch.randint(0, g, (b, K), generator=torch.Generator().manual_seed(seed))
         off = get_selection_indices(idx)
         host = RolloutRows(idx.t().reshape(-1).numpy(), np.tile(np.arange(b), K), off.t().reshape(-1).numpy(), g, b, "cpu")
