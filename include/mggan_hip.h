@@ -160,6 +160,22 @@ int mggan_social_attention_bwd(int n_tiles, const int* tiles, int P, int b, int 
                                float* dz2, float* dz1, float* dvc, float* dh, int ld_dh, int accumulate_dh,
                                mggan_stream_t stream);
 
+/* ---- Social-GAN pooling (--pool_type sgan) ------------------------------------------------
+ * reference: social_gan.py:199-229 (PoolHiddenNet.forward): per scene, every pedestrian i and every j of its scene
+ * (itself included): X = [Linear(2,E)(p_j - p_i) | h_j] -> mlp_pre_pool (mggan_mlp_chain) -> max over j.
+ * pair p: output row pair_o[p], position rows pair_i[p] / pair_j[p] (modulo xy_mod when > 0), hidden row pair_j[p];
+ * the pairs of output row o are [ped_prow[o], ped_prow[o] + ped_n[o]); hid_ptr / hid_pairs = CSR list of the pairs
+ * that read each hidden row (for the deterministic adjoint of the gather). */
+int mggan_pool_pairs_fwd(int P, const int* pair_i, const int* pair_j, const float* xy_last, int xy_mod,
+                         const float* We, const float* be, int E, const float* h, int ld_h, int H, float* X, float* rel,
+                         mggan_stream_t stream);
+int mggan_pool_gather_bwd(int b, int H, int E, const int* hid_ptr, const int* hid_pairs, const float* dX, float* dh,
+                          int ld_dh, mggan_stream_t stream);
+int mggan_segment_max_fwd(int rows, int B, const int* ped_prow, const int* ped_n, const float* Y, float* out, int* arg,
+                          mggan_stream_t stream);
+int mggan_segment_max_bwd(int P, int B, const int* pair_o, const int* ped_prow, const float* dOut, int ld_dout,
+                          const int* arg, float* dY, mggan_stream_t stream);
+
 /* ---- scene CNN + physical attention -----------------------------------------------------
  * reference: cnn.py:119-160 (Conv_Blocks), :275-282 (CNN.forward), :109-116 (AttentionGlobal.forward)
  * img (B,4,33,33) -> y1 raw (B,C,33,36: rows padded to 36 floats) -> [BN+ReLU+pool] -> y2 raw (B,C,16,16) -> [BN+ReLU+pool]
@@ -244,7 +260,9 @@ int mggan_scale(float* x, long n, const float* scalar, mggan_stream_t stream);
 /* classifier input of the discriminator (discriminators.py:141,185,196): rows k*b+ped =
  * [soc | in_enc | pred_enc | scene], and its adjoint.  soc_all = 0: social features exist for sample block 0 only
  * (soc0 has b rows; the list-repetition quirk of one K-sample call); soc_all = 1: soc0 has K*b rows
- * (K independent single-sample calls batched into one pass, e.g. the real and the fake pass of a D step). */
+ * (K independent single-sample calls batched into one pass, e.g. the real and the fake pass of a D step);
+ * soc_all = 2: soc0 has b rows and EVERY sample block gets them (PoolHiddenNet walks the K-times repeated scene list
+ * and concatenates K copies of the block-0 result, social_gan.py:212-228). */
 int mggan_d_assemble_fwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, int soc_all, const float* soc0,
                          const float* in_enc, const float* pred_enc, const float* scene, float* X,
                          mggan_stream_t stream);

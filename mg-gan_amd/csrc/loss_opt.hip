@@ -59,7 +59,7 @@ __global__ void d_assemble_kernel(int b, int K, int ws, int wi, int wp, int wc, 
   const long r = i / W;
   const int ped = (int)(r % b), k = (int)(r / b);
   float v;
-  if (c < ws) v = soc_all ? soc0[(size_t)r * ws + c] : (k == 0 ? soc0[(size_t)ped * ws + c] : 0.f);
+  if (c < ws) v = soc_all == 1 ? soc0[(size_t)r * ws + c] : ((k == 0 || soc_all == 2) ? soc0[(size_t)ped * ws + c] : 0.f);
   else if (c < ws + wi) v = in_enc[(size_t)ped * wi + (c - ws)];
   else if (c < ws + wi + wp) v = pred_enc[(size_t)r * wp + (c - ws - wi)];
   else v = scene[(size_t)ped * wc + (c - ws - wi - wp)];
@@ -75,9 +75,14 @@ __global__ void d_assemble_bwd_kernel(int b, int K, int ws, int wi, int wp, int 
   if (i >= (long)b * W) return;
   const int c = (int)(i % W), ped = (int)(i / W);
   if (c < ws) {
-    if (dsoc0)
+    if (dsoc0 && soc_all == 2) {
+      float s = 0.f;
+      for (int k = 0; k < K; ++k) s += dX[((size_t)k * b + ped) * W + c];
+      dsoc0[(size_t)ped * ws + c] = s;
+    } else if (dsoc0) {
       for (int k = 0; k < (soc_all ? K : 1); ++k)
         dsoc0[((size_t)k * b + ped) * ws + c] = dX[((size_t)k * b + ped) * W + c];
+    }
   } else if (c >= ws + wi && c < ws + wi + wp) {
     if (dpred_enc)
       for (int k = 0; k < K; ++k) dpred_enc[((size_t)k * b + ped) * wp + (c - ws - wi)] = dX[((size_t)k * b + ped) * W + c];

@@ -750,6 +750,104 @@ class SocialAttentionFn(Function):
 
 
 # ------------------------------------------------------------------------------------------
+class PoolTables:
+    """Pair lists of the Social-GAN pooling for one scene LIST (entries may repeat: the discriminator passes the list
+    K times, social_gan.py:212-228 walks it entry by entry): output rows in list order."""
+
+    def __init__(self, seq_start_end, device):
+        import numpy as np
+
+        po, pi, pj, prow, pn = [], [], [], [], []
+        P = rows = 0
+        hmax = 0
+        for s, e in seq_start_end:
+            s, e = int(s), int(e)
+            n = e - s
+            if n <= 0:
+                continue
+            ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+            po.append(rows + ii.reshape(-1))
+            pi.append(s + ii.reshape(-1))
+            pj.append(s + jj.reshape(-1))
+            prow.append(P + np.arange(n) * n)
+            pn.append(np.full(n, n))
+            P += n * n
+            rows += n
+            hmax = max(hmax, e)
+        cat = lambda l: np.concatenate(l).astype(np.int32) if l else np.zeros(0, np.int32)
+        pair_j = cat(pj)
+        order = np.argsort(pair_j, kind="stable").astype(np.int32)  # pairs grouped by the hidden row they read
+        hid_ptr = np.zeros(hmax + 1, np.int32)
+        np.add.at(hid_ptr, pair_j + 1, 1)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.P, self.rows, self.h_rows = P, rows, hmax
+        self.pair_o, self.pair_i, self.pair_j = to(cat(po)), to(cat(pi)), to(pair_j)
+        self.ped_prow, self.ped_n = to(cat(prow)), to(cat(pn))
+        self.hid_ptr, self.hid_pairs = to(np.cumsum(hid_ptr).astype(np.int32)), to(order)
+        self.key = seq_start_end
+
+
+_POOL_CACHE = {}
+
+
+def pool_tables(seq_start_end, device):
+    key = (id(seq_start_end), len(seq_start_end), str(device))
+    hit = _POOL_CACHE.get(key)
+    if hit is not None and hit.key is seq_start_end:
+        return hit
+    t = PoolTables(seq_start_end, device)
+    if len(_POOL_CACHE) > 64:
+        _POOL_CACHE.clear()
+    _POOL_CACHE[key] = t
+    return t
+
+
+class PoolHiddenFn(Function):
+    """PoolHiddenNet.forward (social_gan.py:199-229): [Linear(2,E)(p_j - p_i) | h_j] -> Linear -> ReLU -> Linear ->
+    max over the scene.  Pair rows by one launch, the MLP as one fused chain, the maximum by one launch."""
+
+    @staticmethod
+    def forward(ctx, xy_last, h, tb, we, be, w1, b1, w2, b2, owner, save, xy_mod=0):
+        h, ld_h = _rows2d(h)
+        H, E, B = h.shape[1], we.shape[0], w2.shape[0]
+        xy_last = xy_last.contiguous()
+        P = tb.P
+        st = _s()
+        X, rel = _empty(max(P, 1), E + H, like=h), _empty(max(P, 1), 2, like=h)
+        lib.mggan_pool_pairs_fwd(P, _p(tb.pair_i), _p(tb.pair_j), _p(xy_last), int(xy_mod), _p(we), _p(be), E, _p(h), ld_h,
+                                 H, _p(X), _p(rel), st)
+        spec = ((ACT_LEAKY, 0.0), (ACT_NONE, 0.0))  # ReLU = leaky slope 0
+        outs = _chain_fwd(X, E + H, P, spec, (w1, w2), (b1, b2), save) if P else [None, _empty(0, B, like=h)]
+        out = _empty(tb.rows, B, like=h)
+        arg = torch.empty(tb.rows, B, dtype=torch.int32, device=h.device)
+        lib.mggan_segment_max_fwd(tb.rows, B, _p(tb.ped_prow), _p(tb.ped_n), _p(outs[-1]), _p(out), _p(arg), st)
+        if save:
+            ctx.tb, ctx.owner, ctx.spec, ctx.dims = tb, owner, spec, (H, E, B, h.shape[0])
+            ctx.train_w = w1.requires_grad
+            ctx.save_for_backward(X, rel, outs[0], outs[1], arg, we, be, w1, b1, w2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        X, rel, y0, y1, arg, we, be, w1, b1, w2, b2 = ctx.saved_tensors
+        tb, (H, E, B, hr) = ctx.tb, ctx.dims
+        P = tb.P
+        st = _s()
+        dout, ld = _rows2d(dout)
+        dY = _empty(max(P, 1), B, like=X)
+        lib.mggan_segment_max_bwd(P, B, _p(tb.pair_o), _p(tb.ped_prow), _p(dout), ld, _p(arg), _p(dY), st)
+        dX = _chain_bwd(dY, B, X, E + H, P, (y0, y1), ctx.spec, (w1, w2), (b1, b2), True, ctx.train_w, ctx.owner)
+        dh = None
+        if ctx.needs_input_grad[1]:
+            dh = torch.zeros(hr, H, dtype=F32, device=X.device) if tb.h_rows < hr else _empty(hr, H, like=X)
+            lib.mggan_pool_gather_bwd(tb.h_rows, H, E, _p(tb.hid_ptr), _p(tb.hid_pairs), _p(dX), _p(dh), H, st)
+        if ctx.train_w:
+            root = root_of(ctx.owner)
+            with side_stream(dX, rel):
+                wgrad(dX, E + H, rel, 2, root.grad_ptr(we), 2, root.grad_ptr(be), P, 2, E)
+        return (None, dh) + (None,) * 10
+
+
 class SceneAttentionFn(Function):
     """CNN (2 x Conv-BN-ReLU-MaxPool) + channel-softmax attention -> (B,64)  (cnn.py:109-282)."""
 
@@ -1028,9 +1126,10 @@ class DAssembleFn(Function):
         soc0, in_enc, pred_enc, scene = (t.contiguous() for t in (soc0, in_enc, pred_enc, scene))
         b = in_enc.shape[0]
         ws, wi, wp, wc = soc0.shape[1], in_enc.shape[1], pred_enc.shape[1], scene.shape[1]
-        assert soc0.shape[0] == (K * b if soc_all else b), (soc0.shape, K, b, soc_all)
+        soc_all = int(soc_all)  # 0: block 0 only, 1: soc0 has K*b rows, 2: soc0 (b rows) broadcast to every block
+        assert soc0.shape[0] == (K * b if soc_all == 1 else b), (soc0.shape, K, b, soc_all)
         X = _empty(K * b, ws + wi + wp + wc, like=in_enc)
-        lib.mggan_d_assemble_fwd(b, K, ws, wi, wp, wc, 1 if soc_all else 0, _p(soc0), _p(in_enc), _p(pred_enc), _p(scene),
+        lib.mggan_d_assemble_fwd(b, K, ws, wi, wp, wc, soc_all, _p(soc0), _p(in_enc), _p(pred_enc), _p(scene),
                                  _p(X), _s())
         ctx.dims = (b, K, ws, wi, wp, wc, soc_all)
         return X
@@ -1041,9 +1140,9 @@ class DAssembleFn(Function):
         dX = dX.contiguous()
         need = ctx.needs_input_grad
         mk = lambda n, r, c: torch.empty(r, c, dtype=F32, device=dX.device) if n else None
-        dsoc, din = mk(need[0], K * b if soc_all else b, ws), mk(need[1], b, wi)
+        dsoc, din = mk(need[0], K * b if soc_all == 1 else b, ws), mk(need[1], b, wi)
         dpred, dsc = mk(need[2], K * b, wp), mk(need[3], b, wc)
-        lib.mggan_d_assemble_bwd(b, K, ws, wi, wp, wc, 1 if soc_all else 0, _p(dX), _p(dsoc), _p(din), _p(dpred), _p(dsc),
+        lib.mggan_d_assemble_bwd(b, K, ws, wi, wp, wc, soc_all, _p(dX), _p(dsoc), _p(din), _p(dpred), _p(dsc),
                                  _s())
         return dsoc, din, dpred, dsc, None, None
 

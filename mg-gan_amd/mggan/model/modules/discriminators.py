@@ -9,6 +9,7 @@ from mggan.hip.flat import FlatModule
 from mggan.hip import functions as HF
 from mggan.model.modules.cnn import AttentionGlobal
 from mggan.model.modules.social import SocialAttention
+from mggan.model.modules.social_gan import PoolHiddenNet
 from mggan.model.modules.common_modules import TrajectoryEncoder
 
 
@@ -18,10 +19,11 @@ class MultiDiscriminatorTrajectory(FlatModule):
         super().__init__()
         assert inp_format in ("rel", "abs", "abs_rel")
         assert gan_type in ("probgan", "mgan", "infogan", "gan")
-        if (inp_format != "rel" or gan_type not in ("mgan", "gan") or not global_disc or pool_type != "sways"
-                or num_discs != 1 or scene_dim <= 0):
+        if (inp_format != "rel" or gan_type not in ("mgan", "gan") or not global_disc
+                or pool_type not in ("sways", "sgan") or num_discs != 1 or scene_dim <= 0):
             raise ValueError("HIP MultiDiscriminatorTrajectory implements the default hot path: inp_format='rel', "
-                             "gan_type mgan/gan, global_disc, pool_type='sways', one discriminator")
+                             "gan_type mgan/gan, global_disc, pool_type sways/sgan, one discriminator")
+        self.pool_type = pool_type
         self.inp_format = inp_format
         self.unbound_output = unbound_output
         self.n_ds = num_discs
@@ -34,7 +36,10 @@ class MultiDiscriminatorTrajectory(FlatModule):
                                            nn.Linear(h_dim // 2, h_dim // 2))
         self.pred_encoder = nn.Sequential(nn.Linear(pred_len * self.inp_size, h_dim), nn.LeakyReLU(0.2),
                                           nn.Linear(h_dim, h_dim // 2))
-        self.social = SocialAttention(h_dim, h_dim)
+        if pool_type == "sways":
+            self.social = SocialAttention(h_dim, h_dim)
+        else:  # discriminators.py:62-67
+            self.social = PoolHiddenNet(embedding_dim=16, h_dim=h_dim, mlp_dim=h_dim, bottleneck_dim=h_dim)
         h_dim *= 2
         self.scene_encoder = AttentionGlobal(noise_attention_dim=0, PhysFeature=True, num_layers=2, channels_cnn=8)
         h_dim += scene_dim
@@ -149,7 +154,10 @@ class MultiDiscriminatorTrajectory(FlatModule):
             soc0 = self.social(in_xy, in_dxdy, enc0, seq_start_end)
             scene = context[1] if context is not None else self.scene_encoder(img)
             HF.join_branch(scene)
-            classifier_inp = HF.DAssembleFn.apply(soc0, in_enc, pred_enc, scene, n_samples)
+            # sways: only sample block 0 carries social features (A.1); sgan: PoolHiddenNet walks the repeated list
+            # and returns K copies of the block-0 result (mode 2 broadcasts it)
+            classifier_inp = HF.DAssembleFn.apply(soc0, in_enc, pred_enc, scene, n_samples,
+                                                  2 if self.pool_type == "sgan" else False)
         else:
             enc = self.encode(in_xy, in_dxdy, pred_xy, pred_dxdy, mask)
             soc = self.social(in_xy.repeat(1, n_samples, 1), in_dxdy.repeat(1, n_samples, 1), enc,

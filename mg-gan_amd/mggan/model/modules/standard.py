@@ -14,6 +14,7 @@ from mggan.rng import HostRNG
 from mggan.hip.flat import FlatModule
 from mggan.hip import functions as HF
 from mggan.model.modules.cnn import AttentionGlobal
+from mggan.model.modules.social_gan import PoolHiddenNet
 from mggan.model.modules.social import SocialAttention
 from mggan.model.modules.common_modules import TrajectoryEncoder, RelativeDecoder, get_input, GeneratorOutput
 
@@ -25,9 +26,11 @@ class MultiGenerator(FlatModule):
         assert inp_format in ("rel", "abs", "abs_rel")
         assert num_social_modules in (0, 1, num_gens)
         assert pool_type in ("sways", "sgan")
-        if inp_format != "rel" or pool_type != "sways" or social_feat_size <= 0 or scene_dim <= 0:
+        if inp_format != "rel" or social_feat_size <= 0 or scene_dim <= 0:
             raise ValueError("HIP MultiGenerator implements the default hot path: inp_format='rel', "
-                             "pool_type='sways', social and scene features enabled")
+                             "social and scene features enabled")
+        if pool_type == "sgan" and social_feat_size != encoder_h_dim:
+            raise ValueError("pool_type 'sgan' pools to encoder_h_dim features; social_feat_size must equal it")
         self.use_pinet = use_pinet
         self.inp_format = inp_format
         self.z_size = z_size
@@ -42,7 +45,11 @@ class MultiGenerator(FlatModule):
         self.encoder = TrajectoryEncoder(inp_size=2, hidden_size=encoder_h_dim, embedding_dim=embedding_dim,
                                          num_layers=1)
         self.scene_encoder = AttentionGlobal(noise_attention_dim=0, PhysFeature=True, num_layers=2, channels_cnn=16)
-        self.social = SocialAttention(social_feat_size, encoder_h_dim)
+        if pool_type == "sways":
+            self.social = SocialAttention(social_feat_size, encoder_h_dim)
+        else:  # standard.py:66-71
+            self.social = PoolHiddenNet(embedding_dim=embedding_dim, h_dim=encoder_h_dim, mlp_dim=social_feat_size,
+                                        bottleneck_dim=encoder_h_dim)
 
         self.gs = nn.ModuleList()
         for i in range(num_gens):

@@ -5,8 +5,8 @@ Pins SURVEY A.10 (the L2 term slices the masked predictions with the unmasked sc
 unmasked b).
 
 Run in the build container only (needs /root/reference):
-    python tests/golden/make_golden_masked.py [masked] [variants]
-        -> tests/golden/golden_masked_g2.npz, golden_{obj_ls,obj_mm,wt_l2,wt_endpoint,wt_mgan}_g2.npz
+    python tests/golden/make_golden_masked.py [masked] [variants] [sgan]
+        -> tests/golden/golden_masked_g2.npz, golden_{obj_ls,obj_mm,wt_l2,wt_endpoint,wt_mgan,pool_sgan}_g2.npz
 (`variants`: one unmasked iteration each under --gan_obj LS / MM and --weighting_target l2 / endpoint)."""
 import importlib.util
 import os
@@ -123,3 +123,5 @@ if __name__ == "__main__":
                            ("wt_l2_g2", ["--weighting_target", "l2"]), ("wt_endpoint_g2", ["--weighting_target", "endpoint"]),
                            ("wt_mgan_g2", ["--weighting_target", "mgan"])):
             main(tag, extra, nan=False, keep_init=False)
+    if "sgan" in which:  # Social-GAN pooling in G and D (social_gan.py:157-229) instead of the attention
+        main("pool_sgan_g2", ["--pool_type", "sgan"], nan=False, keep_init=False)

@@ -11,7 +11,7 @@ import torch
 from conftest import GOLDEN
 from test_masked import STEPS, _batch, _check
 
-VARIANTS = ["obj_ls_g2", "obj_mm_g2", "wt_l2_g2", "wt_endpoint_g2", "wt_mgan_g2"]
+VARIANTS = ["obj_ls_g2", "obj_mm_g2", "wt_l2_g2", "wt_endpoint_g2", "wt_mgan_g2", "pool_sgan_g2"]
 
 
 def _load(tag):
@@ -31,7 +31,7 @@ def test_oracle_variant_iteration(tag):
     torch.manual_seed(int(g["meta/seed"]))
     np.random.seed(int(g["meta/seed"]) + 1)
     o = _opts(args)
-    G, D = O.construct_oracle(int(g["meta/num_gens"]), gan_obj=o.get("gan_obj", "NS"))
+    G, D = O.construct_oracle(int(g["meta/num_gens"]), gan_obj=o.get("gan_obj", "NS"), pool_type=o.get("pool_type", "sways"))
     G.train()
     D.train()
     tr = O.OracleTrainer(G, D, mode="block", gan_obj=o.get("gan_obj", "NS"), weighting_target=o.get("weighting_target", "ml"))
