@@ -10,14 +10,19 @@ def construct_model(config):
     config.use_pinet = config.weighting_target != "none" and not config.unconditional
     pred_len = 12
     scene_dim = 8 * 8
-    if config.experiment != "multi_generator":
-        raise ValueError("Requested model not implemented on the HIP path (only 'multi_generator').")
-    G = MultiGenerator(z_size=config.noise_dim, inp_format=config.inp_format, encoder_h_dim=config.h_dim,
-                       decoder_h_dim=config.decoder_h_dim,
-                       social_feat_size=config.h_dim if config.n_social_modules > 0 else 0,
-                       embedding_dim=int(config.decoder_h_dim // 2), num_gens=config.num_gens, pred_len=pred_len,
-                       pool_type=config.pool_type, num_social_modules=config.n_social_modules, scene_dim=scene_dim,
-                       use_pinet=config.use_pinet, learn_prior=config.unconditional)
+    if config.experiment not in ("multi_generator", "discrete"):
+        raise ValueError("Requested model not implemented on the HIP path ('multi_generator' and 'discrete' are).")
+    common = dict(z_size=config.noise_dim, inp_format=config.inp_format, encoder_h_dim=config.h_dim,
+                  decoder_h_dim=config.decoder_h_dim, social_feat_size=config.h_dim if config.n_social_modules > 0 else 0,
+                  num_gens=config.num_gens, pred_len=pred_len, pool_type=config.pool_type,
+                  num_social_modules=config.n_social_modules, scene_dim=scene_dim, use_pinet=config.use_pinet,
+                  learn_prior=config.unconditional)
+    if config.experiment == "discrete":  # model_factory.py:50-66
+        from mggan.model.modules.standard_discrete import DiscreteLatentGenerator
+
+        G = DiscreteLatentGenerator(embedding_dim=16, **common)
+    else:
+        G = MultiGenerator(embedding_dim=int(config.decoder_h_dim // 2), **common)
     D = MultiDiscriminatorTrajectory(num_discs=num_discs, num_gens=config.num_gens, unbound_output=unbound_output,
                                      h_dim=config.h_dim * 2, pred_len=pred_len, inp_format=config.inp_format,
                                      gan_type=config.gan_type, scene_dim=scene_dim, global_disc=config.global_disc,

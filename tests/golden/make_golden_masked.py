@@ -23,6 +23,7 @@ import _refload  # noqa: E402
 ref_train, ref_config = _refload.load_reference()
 import test_tube  # noqa: E402  (stub)
 import mggan.model.modules.standard as ref_standard  # noqa: E402
+import mggan.model.modules.standard_discrete as ref_discrete  # noqa: E402
 
 _spec = importlib.util.spec_from_file_location(
     "_synth", os.path.join(HERE, "..", "..", "mg-gan_amd", "mggan", "data_utils", "synthetic.py"))
@@ -79,6 +80,7 @@ def main(tag="masked_g2", extra=(), nan=True, num_gens=2, sizes=(2, 3, 1, 4), se
         return n
 
     ref_standard.get_global_noise = noise_std
+    ref_discrete.get_global_noise = noise_std
     orig_fwd = G.forward
 
     def fwd(*a, **kw):
@@ -108,6 +110,7 @@ def main(tag="masked_g2", extra=(), nan=True, num_gens=2, sizes=(2, 3, 1, 4), se
             out["{}/{}".format(pre, k)] = t2n(v)
     ref_train.get_gan_labels = orig_labels
     ref_standard.get_global_noise = orig_noise
+    ref_discrete.get_global_noise = orig_noise
     path = os.path.join(HERE, "golden_{}.npz".format(tag))
     np.savez_compressed(path, **out)
     print(tag, "bytes", os.path.getsize(path))
@@ -123,5 +126,7 @@ if __name__ == "__main__":
                            ("wt_l2_g2", ["--weighting_target", "l2"]), ("wt_endpoint_g2", ["--weighting_target", "endpoint"]),
                            ("wt_mgan_g2", ["--weighting_target", "mgan"])):
             main(tag, extra, nan=False, keep_init=False)
+    if "discrete" in which:  # one decoder conditioned on an embedded generator id (standard_discrete.py)
+        main("discrete_g2", ["--experiment", "discrete"], nan=False, keep_init=False)
     if "sgan" in which:  # Social-GAN pooling in G and D (social_gan.py:157-229) instead of the attention
         main("pool_sgan_g2", ["--pool_type", "sgan"], nan=False, keep_init=False)

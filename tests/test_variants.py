@@ -11,7 +11,7 @@ import torch
 from conftest import GOLDEN
 from test_masked import STEPS, _batch, _check
 
-VARIANTS = ["obj_ls_g2", "obj_mm_g2", "wt_l2_g2", "wt_endpoint_g2", "wt_mgan_g2", "pool_sgan_g2"]
+VARIANTS = ["obj_ls_g2", "obj_mm_g2", "wt_l2_g2", "wt_endpoint_g2", "wt_mgan_g2", "pool_sgan_g2", "discrete_g2"]
 
 
 def _load(tag):
@@ -31,7 +31,8 @@ def test_oracle_variant_iteration(tag):
     torch.manual_seed(int(g["meta/seed"]))
     np.random.seed(int(g["meta/seed"]) + 1)
     o = _opts(args)
-    G, D = O.construct_oracle(int(g["meta/num_gens"]), gan_obj=o.get("gan_obj", "NS"), pool_type=o.get("pool_type", "sways"))
+    G, D = O.construct_oracle(int(g["meta/num_gens"]), gan_obj=o.get("gan_obj", "NS"), pool_type=o.get("pool_type", "sways"),
+                               experiment=o.get("experiment", "multi_generator"))
     G.train()
     D.train()
     tr = O.OracleTrainer(G, D, mode="block", gan_obj=o.get("gan_obj", "NS"), weighting_target=o.get("weighting_target", "ml"))
@@ -72,3 +73,20 @@ def test_hip_variant_iteration(tag):
     m = defaultdict(list)
     tr.train_iteration(bt, m)
     _check(g, m, tr.G, tr.D)
+
+
+@pytest.mark.parametrize("tag", ["pool_sgan_g2", "discrete_g2"])
+def test_variant_state_dict_surface(tag):
+    """CPU: the variant models expose the reference's state_dict keys and shapes (checkpoint compatibility)."""
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+
+    g, args = _load(tag)
+    cfg = get_parser().parse_args(["--num_gens", str(int(g["meta/num_gens"]))] + args)
+    G, D = construct_model(cfg)
+    for pre, mod in (("G1", G), ("D1", D)):
+        ref = {k[len(pre) + 1:]: v.shape for k, v in g.items() if k.startswith(pre + "/")}
+        sd = mod.state_dict()
+        assert list(sd.keys()) == list(ref.keys())
+        for k, shp in ref.items():
+            assert tuple(sd[k].shape) == tuple(shp), k
