@@ -81,6 +81,11 @@ class DiscreteLatentGenerator(MultiGenerator):
                                          e2d.bias, w_hh, self.decoder.param_dict(), 1, 0, self.pred_len, self,
                                          HF.want_grad(enc_rows, soc_rows, w_hh))
 
+    def forward_all(self, in_xy, in_dxdy, enc_h, noise, social_feats):
+        """The decoder on the current batch (standard_discrete.py:236-257): enc_h (b, enc + z) already carries the
+        embedded generator id, noise (b, z) -> (abs, rel), each (pred_len, b, 2)."""
+        return self._roll(in_xy, in_dxdy, enc_h, social_feats, noise, 1)
+
     def forward(self, in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=None, num_samples=5, mask=None,
                 trunk=None, logits=None, need_samples=True):
         """Returns (GeneratorOutput(rel, abs), net_chooser_out (b_m, g), sampled_gen_idxs (b_m, K) int64)."""
