@@ -279,6 +279,12 @@ int mggan_l2_min_scene(int S, int T, int K, int b, const int* scenes, const int*
                        mggan_stream_t stream);
 int mggan_pm_ml_loss(int b, int T, int E, int g, const float* gen_abs, const float* gt, const float* logits, float sigma,
                      float scale, float* loss_rows, float* dlogits, float* probs, mggan_stream_t stream);
+/* the same plus the reductions the trainer needs, in ONE launch: *out = sum of the loss rows, probs_out[g] =
+ * probs_scale * column means of the generator probabilities; partial = 17 * 64 doubles of scratch, ticket = one word
+ * that is zero before the first call (the kernel leaves it at zero) */
+int mggan_pm_ml_loss_mean(int b, int T, int E, int g, const float* gen_abs, const float* gt, const float* logits,
+                          float sigma, float scale, float* loss_rows, float* dlogits, float* probs, double* partial,
+                          unsigned* ticket, float* out, float* probs_out, float probs_scale, mggan_stream_t stream);
 int mggan_sum(const float* x, long n, float alpha, float* out, int accumulate, mggan_stream_t stream);
 int mggan_colmean(const float* x, int rows, int g, float scale, float* out, mggan_stream_t stream);
 int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count, mggan_stream_t stream);

@@ -345,40 +345,95 @@ __global__ void pm_mgan_kernel(int b, int g, const float* __restrict__ logits, f
 
 // ---- PM-network 'ml' loss (train.py:626-639) ---------------------------------------------
 // gen_abs (T,E,g,b,2); target = softmax_g( mean_E sum_{t,xy} log N(err; 0, sigma) ); loss_r = -sum target*log_softmax(logits)
-__global__ void pm_ml_kernel(int b, int T, int E, int g, const float* __restrict__ gen_abs, const float* __restrict__ gt,
-                             const float* __restrict__ logits, float sigma, float scale, float* loss_rows,
-                             float* dlogits, float* probs) {
-  const int ped = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ped >= b) return;
+// Lane = (pedestrian, generator): the T*E error terms of one generator per lane (the loads that dominate), the
+// softmax pair per pedestrian by its first lane.  With `partial` / `ticket` the launch also finishes the job: the mean
+// loss (out) and the mean generator probabilities (probs_out[g]) come from per-workgroup f64 sums that the last
+// workgroup adds in index order (deterministic); otherwise only the per-row values are written.
+#define PM_MAX_WG 64
+__global__ __launch_bounds__(256) void pm_ml_kernel(int b, int T, int E, int g, int G2, const float* __restrict__ gen_abs,
+                                                    const float* __restrict__ gt, const float* __restrict__ logits,
+                                                    float sigma, float scale, float* loss_rows, float* dlogits,
+                                                    float* probs, double* partial, unsigned* ticket, float* out,
+                                                    float* probs_out, float probs_scale) {
+  __shared__ float s_lp[256];
+  __shared__ double red[17][256];  // [value][pedestrian slot of this workgroup]
+  __shared__ int last;
   const float inv2s = 1.f / (2.f * sigma * sigma);
   const float cst = -__logf(sigma) - 0.91893853320467274178f;  // -log(sigma) - 0.5 log(2 pi)
-  float lp[16], lg[16];
-  float mxp = -INFINITY, mxl = -INFINITY;
-  for (int gi = 0; gi < g; ++gi) {
-    float acc = 0.f;
-    for (int e = 0; e < E; ++e)
-      for (int t = 0; t < T; ++t) {
-        const float* a = gen_abs + ((((size_t)t * E + e) * g + gi) * b + ped) * 2;
-        const float dx = a[0] - gt[((size_t)t * b + ped) * 2], dy = a[1] - gt[((size_t)t * b + ped) * 2 + 1];
-        acc += (-dx * dx * inv2s + cst) + (-dy * dy * inv2s + cst);
+  const int per = 256 / G2;  // pedestrians per workgroup pass
+  const int slot = threadIdx.x / G2, gi = threadIdx.x % G2;
+  double wsum[17];
+#pragma unroll
+  for (int q = 0; q < 17; ++q) wsum[q] = 0.0;
+  for (int p0 = blockIdx.x * per; p0 < b; p0 += gridDim.x * per) {
+    const int ped = p0 + slot;
+    const bool ok = slot < per && ped < b && gi < g;
+    float lp = 0.f;
+    if (ok) {
+      float acc = 0.f;
+      for (int e = 0; e < E; ++e)
+        for (int t = 0; t < T; ++t) {
+          const float2 a = *reinterpret_cast<const float2*>(gen_abs + ((((size_t)t * E + e) * g + gi) * b + ped) * 2);
+          const float2 y = *reinterpret_cast<const float2*>(gt + ((size_t)t * b + ped) * 2);
+          const float dx = a.x - y.x, dy = a.y - y.y;
+          acc += (-dx * dx * inv2s + cst) + (-dy * dy * inv2s + cst);
+        }
+      lp = acc / (float)E;
+    }
+    __syncthreads();
+    s_lp[threadIdx.x] = lp;
+    __syncthreads();
+    if (ok && gi == 0) {
+      const float* lps = s_lp + slot * G2;
+      float lg[16];
+      float mxp = -INFINITY, mxl = -INFINITY;
+      for (int q = 0; q < g; ++q) {
+        lg[q] = logits[(size_t)ped * g + q];
+        mxp = fmaxf(mxp, lps[q]);
+        mxl = fmaxf(mxl, lg[q]);
       }
-    lp[gi] = acc / (float)E;
-    lg[gi] = logits[(size_t)ped * g + gi];
-    mxp = fmaxf(mxp, lp[gi]);
-    mxl = fmaxf(mxl, lg[gi]);
+      float dp = 0.f, dl = 0.f;
+      for (int q = 0; q < g; ++q) { dp += __expf(lps[q] - mxp); dl += __expf(lg[q] - mxl); }
+      const float lsel = mxl + __logf(dl);
+      float loss = 0.f;
+      for (int q = 0; q < g; ++q) {
+        const float tgt = __expf(lps[q] - mxp) / dp;
+        const float sm = __expf(lg[q] - lsel);
+        loss -= tgt * (lg[q] - lsel);
+        dlogits[(size_t)ped * g + q] = scale * (sm - tgt);
+        if (probs) probs[(size_t)ped * g + q] = sm;
+        wsum[1 + q] += (double)sm;
+      }
+      loss_rows[ped] = scale * loss;
+      wsum[0] += (double)(scale * loss);
+    }
   }
-  float dp = 0.f, dl = 0.f;
-  for (int gi = 0; gi < g; ++gi) { dp += __expf(lp[gi] - mxp); dl += __expf(lg[gi] - mxl); }
-  const float lsel = mxl + __logf(dl);
-  float loss = 0.f;
-  for (int gi = 0; gi < g; ++gi) {
-    const float tgt = __expf(lp[gi] - mxp) / dp;
-    const float sm = __expf(lg[gi] - lsel);
-    loss -= tgt * (lg[gi] - lsel);
-    dlogits[(size_t)ped * g + gi] = scale * (sm - tgt);
-    if (probs) probs[(size_t)ped * g + gi] = sm;
+  if (!partial) return;
+  // workgroup sums in pedestrian-slot order, then the cross-workgroup sums by the last workgroup in index order
+  if (gi == 0 && slot < per) {
+#pragma unroll
+    for (int q = 0; q < 17; ++q) red[q][slot] = wsum[q];
   }
-  loss_rows[ped] = scale * loss;
+  __syncthreads();
+  if (threadIdx.x <= (unsigned)g) {
+    double t = 0.0;
+    for (int sl = 0; sl < per; ++sl) t += red[threadIdx.x][sl];
+    partial[(size_t)blockIdx.x * 17 + threadIdx.x] = t;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x <= (unsigned)g) {
+    const int q = threadIdx.x;
+    double t = 0.0;
+    for (unsigned w = 0; w < gridDim.x; ++w) t += ((volatile double*)partial)[(size_t)w * 17 + q];
+    if (q == 0) *out = (float)t;
+    else if (probs_out) probs_out[q - 1] = probs_scale * (float)(t / (double)b);
+  }
+  if (threadIdx.x == 0) *ticket = 0u;
 }
 
 // ---- fixed-order sum: out[slot] (+)= alpha * sum_i x[i] -------------------------------------
@@ -795,9 +850,34 @@ int mggan_pm_ml_loss(int b, int T, int E, int g, const float* gen_abs, const flo
                      float scale, float* loss_rows, float* dlogits, float* probs, hipStream_t stream) {
   if (b == 0) return MGGAN_OK;
   MG_CHECK_ARG(gen_abs && gt && logits && loss_rows && dlogits && g <= 16, "pm_ml_loss: bad arguments (g <= 16)");
-  hipLaunchKernelGGL(pm_ml_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, T, E, g, gen_abs, gt, logits, sigma,
-                     scale, loss_rows, dlogits, probs);
+  int G2 = 1;
+  while (G2 < g) G2 *= 2;
+  const int per = 256 / G2;
+  hipLaunchKernelGGL(pm_ml_kernel, dim3(cdiv(b, per)), dim3(256), 0, stream, b, T, E, g, G2, gen_abs, gt, logits, sigma,
+                     scale, loss_rows, dlogits, probs, (double*)nullptr, (unsigned*)nullptr, (float*)nullptr,
+                     (float*)nullptr, 0.f);
   MG_LAUNCH_CHECK("pm_ml_loss");
+  return MGGAN_OK;
+}
+
+int mggan_pm_ml_loss_mean(int b, int T, int E, int g, const float* gen_abs, const float* gt, const float* logits,
+                          float sigma, float scale, float* loss_rows, float* dlogits, float* probs, double* partial,
+                          unsigned* ticket, float* out, float* probs_out, float probs_scale, hipStream_t stream) {
+  MG_CHECK_ARG(out, "pm_ml_loss_mean: null pointer");
+  if (b == 0) {
+    hipMemsetAsync(out, 0, sizeof(float), stream);
+    return MGGAN_OK;
+  }
+  MG_CHECK_ARG(gen_abs && gt && logits && loss_rows && dlogits && partial && ticket && g <= 16,
+               "pm_ml_loss_mean: bad arguments (g <= 16)");
+  int G2 = 1;
+  while (G2 < g) G2 *= 2;
+  const int per = 256 / G2;
+  int wgs = cdiv(b, per);
+  if (wgs > PM_MAX_WG) wgs = PM_MAX_WG;
+  hipLaunchKernelGGL(pm_ml_kernel, dim3(wgs), dim3(256), 0, stream, b, T, E, g, G2, gen_abs, gt, logits, sigma, scale,
+                     loss_rows, dlogits, probs, partial, ticket, out, probs_out, probs_scale);
+  MG_LAUNCH_CHECK("pm_ml_loss_mean");
   return MGGAN_OK;
 }
 

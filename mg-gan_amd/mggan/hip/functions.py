@@ -1322,11 +1322,14 @@ class PmMlFn(Function):
         dl = _empty(b, g, like=logits)
         probs = _empty(b, g, like=logits)
         n = float(norm or b)
-        lib.mggan_pm_ml_loss(b, T, E, g, _p(gen_abs), _p(gt), _p(logits), float(sigma), 1.0 / n, _p(loss_rows), _p(dl),
-                             _p(probs), _s())
-        lib.mggan_sum(_p(loss_rows), b, 1.0, _p(out), 0, _s())
-        if probs_out is not None:
-            lib.mggan_colmean(_p(probs), b, g, float(b) / n, _p(probs_out), _s())
+        key = ("pm", _s())
+        scratch = _LOSS_SCRATCH.get(key)
+        if scratch is None:
+            scratch = _LOSS_SCRATCH[key] = (torch.zeros(17 * 64, dtype=torch.float64, device=logits.device),
+                                            torch.zeros(1, dtype=torch.int32, device=logits.device))
+        lib.mggan_pm_ml_loss_mean(b, T, E, g, _p(gen_abs), _p(gt), _p(logits), float(sigma), 1.0 / n, _p(loss_rows),
+                                  _p(dl), _p(probs), _p(scratch[0]), _p(scratch[1]), _p(out), _p(probs_out),
+                                  float(b) / n, _s())
         ctx.dl = dl
         return out.view(())
 

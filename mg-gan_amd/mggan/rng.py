@@ -43,6 +43,7 @@ class DeviceRNG:
     def begin_iteration(self):
         """One launch draws the label uniforms of a whole iteration (three labels() calls)."""
         self._pool, self._used = torch.rand(8, device="cuda"), 0
+        self._npool = None  # the noise pool is drawn by the first noise() call of the iteration
 
     _pool, _used = None, 0
 
@@ -65,8 +66,21 @@ class DeviceRNG:
             if len(self._lens) > 64:
                 self._lens.clear()
             self._lens[key] = lens
-        per_scene = torch.randn(num_samples, len(sub_batches), dim, device=device)
+        per_scene = self._normals(num_samples, len(sub_batches), dim, device)
         return per_scene[:, lens[1]]  # one draw per scene, repeated for its pedestrians (utils.py:160-165)
+
+    _npool, _nused = None, 0
+
+    def _normals(self, k, s, dim, device):
+        """(k, s, dim) standard normals out of a per-iteration pool: the three generator calls of an iteration (1,
+        num_samples and 1 sample sets) are served by ONE randn launch instead of three."""
+        pool = self._npool
+        if pool is None or pool.shape[1:] != (s, dim) or pool.device != torch.device(device) or self._nused + k > pool.shape[0]:
+            pool = self._npool = torch.randn(max(2 * k + 8, 32), s, dim, device=device)
+            self._nused = 0
+        out = pool[self._nused:self._nused + k]
+        self._nused += k
+        return out
 
     def randn(self, *shape):
         return torch.randn(*shape, device="cuda")
