@@ -90,3 +90,47 @@ def test_variant_state_dict_surface(tag):
         assert list(sd.keys()) == list(ref.keys())
         for k, shp in ref.items():
             assert tuple(sd[k].shape) == tuple(shp), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--pool_type", "sgan"], ["--experiment", "discrete"],
+                                   ["--experiment", "discrete", "--pool_type", "sgan"]])
+def test_variants_graph_replay_and_prediction_strategies(extra):
+    """The variants run through the device-RNG path too: eager iterations, HIP-graph replay, every prediction strategy."""
+    import contextlib
+    import io
+
+    from mggan.data_utils import synthetic
+    from mggan.logging import Experiment
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.model.train import PiNetMultiGeneratorGAN
+
+    cfg = get_parser().parse_args(["--num_gens", "3", "--rng", "device"] + extra)
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        G, D = construct_model(cfg)
+    tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+    tr.G.train()
+    tr.D.train()
+    batch = tr.to_device(synthetic.make_batch(synthetic.scene_sizes(12, None, seed=3), seed=5))
+    batch["loss_mask"] = None
+    tr.defer_metrics = True
+    m = defaultdict(list)
+    tr.train_iteration(batch, m)
+    replay = tr.capture_iteration(batch, warmup=1)
+    for _ in range(3):
+        replay(m, True)
+    torch.cuda.synchronize()
+    for k, v in m.items():
+        assert np.isfinite(v).all(), k
+    assert 0.2 < m["train/discr_loss"][-1] < 3.0
+    tr.G.eval()
+    tr.D.eval()
+    b = batch["in_xy"].shape[1]
+    for strat in ("sampling", "expected", "uniform_expected", "smart_expected"):
+        with torch.no_grad():
+            p = tr.get_predict_func(strat)(batch["in_dxdy"], batch["in_xy"], batch["seq_start_end"], img=batch["features"],
+                                           num=6)
+        p = p[0] if isinstance(p, tuple) else p
+        assert tuple(p.shape) == (12, 6, b, 2) and bool(torch.isfinite(p).all()), strat
