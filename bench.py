@@ -115,7 +115,10 @@ def build_trainer(num_gens, rng, device, seed=0):
     from mggan.model.model_factory import construct_model
     from mggan.model.train import PiNetMultiGeneratorGAN
 
-    cfg = get_parser().parse_args(["--num_gens", str(num_gens), "--rng", rng, "--epochs", "500"])
+    # (MGGAN_BENCH_BN_SYNC=local: per-rank BatchNorm statistics in sharded runs -- an exploration knob; the default
+    #  keeps the global-batch statistics, i.e. the single-process results)
+    cfg = get_parser().parse_args(["--num_gens", str(num_gens), "--rng", rng, "--epochs", "500", "--bn_sync",
+                                   os.environ.get("MGGAN_BENCH_BN_SYNC", "global")])
     torch.manual_seed(145325)
     np.random.seed(435346)
     import io
@@ -352,6 +355,7 @@ def main():
                            {(64, 20, 4): "BASELINE configs[1]", (256, 32, 8): "BASELINE configs[2]"}.get(
                                (args.scenes, args.peds, args.num_gens), "custom shape")),
                        "b_per_gpu": b, "parallelism": "dp{}".format(world), "rng": args.rng,
+                       "bn_sync": tr.config.bn_sync,
                        "launch": ("eager" if not use_graph else "hipGraph replay of the whole iteration" if not sharded
                                   else "hipGraph replay of the whole iteration, RCCL collectives captured inside it"
                                   if getattr(tr, "graph_collectives", False)

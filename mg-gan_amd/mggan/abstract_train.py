@@ -54,7 +54,7 @@ class MultiGeneratorGAN(abc.ABC):
         self.rng = DeviceRNG() if getattr(config, "rng", "host") == "device" else HostRNG()
         self.G.rng = self.rng
         self.dist = DistContext()
-        self.dist.attach(self.G, self.D)
+        self.dist.attach(self.G, self.D, bn_sync=getattr(config, "bn_sync", "global"))
         if self.dist.enabled and os.environ.get("MGGAN_BRANCH_SHARDED", "0") != "1":
             # sharded runs are replayed as ~19 short graph segments (one per collective); forks that have to be
             # joined at every cut measured slower than one stream (3.49 vs 3.24 ms per iteration with dummy

@@ -65,6 +65,9 @@ def get_parser():
     # ---- additions of the MI355X build (not in the reference CLI) ----
     parser.add_argument("--rng", type=str, choices=["host", "device"], default="host",
                         help="host: reference draw order on the CPU generators; device: no host sync")
+    parser.add_argument("--bn_sync", type=str, choices=["global", "local"], default="global",
+                        help="sharded runs: BatchNorm statistics over the global batch (all-reduced: same results as one "
+                             "process) or per rank (what DistributedDataParallel does without SyncBatchNorm)")
     parser.add_argument("--synthetic_scenes", type=int, default=64, help="scenes per synthetic epoch")
     parser.add_argument("--synthetic_peds", type=int, default=0, help="pedestrians per scene (0 = ragged 1..6)")
     return parser
