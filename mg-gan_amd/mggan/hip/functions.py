@@ -27,7 +27,19 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+# Debugging aid (MGGAN_POISON=1 or poison_scratch(True)): scratch buffers start as NaN instead of whatever the allocator
+# hands back, so a kernel that reads what no kernel wrote shows up as NaN instead of as a box-dependent flake.
+_DEBUG = {"poison": os.environ.get("MGGAN_POISON", "0") == "1"}
+
+
+def poison_scratch(on=True):
+    _DEBUG["poison"] = bool(on)
+
+
 def _empty(*shape, like=None, dtype=F32):
+    if _DEBUG["poison"] and dtype == F32:
+        return torch.full(shape if not (len(shape) == 1 and isinstance(shape[0], (tuple, list))) else shape[0],
+                          float("nan"), dtype=dtype, device=like.device)
     return torch.empty(*shape, dtype=dtype, device=like.device)
 
 
@@ -260,7 +272,7 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
     if rows == 0:
         return
     nbytes = lib.mggan_wgrad_workspace_bytes(rows, K, N, n_groups)
-    ws = torch.empty(nbytes // 4, dtype=F32, device=dz.device if torch.is_tensor(dz) else x.device)
+    ws = _empty(nbytes // 4, like=dz if torch.is_tensor(dz) else x)
     if _SIDE["dirty"]:
         _SIDE["keep"].append(ws)
     defer = _DEFER["on"] and not _SIDE["dirty"] and not now  # now=True: the result is consumed right away
@@ -599,6 +611,9 @@ class SceneTables:
         import numpy as np
 
         sse = [(int(s), int(e)) for s, e in seq_start_end]
+        # a list repeated K times (the discriminator's masked path, discriminators.py:183) makes the reference write
+        # the same rows K times with identical values: one copy of every scene carries the whole result (A.1)
+        sse = list(dict.fromkeys(sse))
         ped_s0 = np.zeros(b, np.int32)
         ped_n = np.ones(b, np.int32)
         ped_prow = np.zeros(b, np.int32)
@@ -942,7 +957,7 @@ class SceneAttentionFn(Function):
         code1 = torch.empty(B, C, 16, 16, dtype=torch.uint8, device=img.device)
         grid = lib.mggan_cnn_bwd_grid(B)
         nb = grid * (256 // (C * C)) * (C * C * 9 + C) * 4
-        ws = torch.empty(nb // 4, dtype=F32, device=img.device)
+        ws = _empty(nb // 4, like=img)
         defer = _DEFER["on"]
         pw, pb = root.grad_ptr(c2w), root.grad_ptr(c2b)
         lib.mggan_conv2_bwd(_p(y1), B, C, _p(sc1), _p(sh1), _p(stat1), _p(y2), _p(G2), _p(stat2), _p(coef2), _p(c2w),
@@ -953,7 +968,7 @@ class SceneAttentionFn(Function):
             _queue_reduce(ws.data_ptr() + 4 * C * C * 9, pb, 0, 1, C, 0, C, grid, 1, wl)
         coef1 = bn_bwd(g1, be1, stat1, cnt1)
         nb = grid * 8 * (4 * C * 9 + C) * 4
-        ws = torch.empty(nb // 4, dtype=F32, device=img.device)
+        ws = _empty(nb // 4, like=img)
         pw, pb = root.grad_ptr(c1w), root.grad_ptr(c1b)
         lib.mggan_conv1_bwd(_p(img), B, C, _p(y1), _p(stat1), _p(coef1), _p(G1c), _p(code1), 0 if defer else pw,
                             0 if defer else pb, _p(ws), nb, st)
@@ -1061,7 +1076,7 @@ class DecoderRolloutFn(Function):
         dev = prep.device
         gabs = None if gabs is None else gabs.contiguous()
         grel = None if grel is None else grel.contiguous()
-        mk = lambda *s: torch.empty(*s, dtype=F32, device=dev)
+        mk = lambda *s: _empty(*s, like=prep)
         dH0, dQ, dEnc, dSocR = mk(R, H), mk(R, Hh), mk(R, EIN), mk(R, S)
         # persistent workgroups per generator; each leaves one partial block of weight gradients
         # (16-row tiles; about two resident workgroups per CU, each looping over its generator's tiles)
@@ -1139,7 +1154,7 @@ class DAssembleFn(Function):
         b, K, ws, wi, wp, wc, soc_all = ctx.dims
         dX = dX.contiguous()
         need = ctx.needs_input_grad
-        mk = lambda n, r, c: torch.empty(r, c, dtype=F32, device=dX.device) if n else None
+        mk = lambda n, r, c: _empty(r, c, like=dX) if n else None
         dsoc, din = mk(need[0], K * b if soc_all == 1 else b, ws), mk(need[1], b, wi)
         dpred, dsc = mk(need[2], K * b, wp), mk(need[3], b, wc)
         lib.mggan_d_assemble_bwd(b, K, ws, wi, wp, wc, soc_all, _p(dX), _p(dsoc), _p(din), _p(dpred), _p(dsc),

@@ -143,6 +143,10 @@ def test_selection_indices_and_row_tables():
     assert tb.P == 4 + 16 and tb.ped_n.tolist() == [1, 2, 2, 4, 4, 4, 4]
     assert tb.ped_prow.tolist() == [0, 0, 2, 4, 8, 12, 16]
     assert tb.pair_i[:4].tolist() == [1, 1, 2, 2] and tb.pair_j[:4].tolist() == [1, 2, 1, 2]
+    # the discriminator's masked path passes the scene list repeated K times: one copy of every scene is kept, and the
+    # tiles of the fused kernels address the same pair ranges as the per-pedestrian tables
+    rep = SceneTables([[0, 2], [2, 5]] * 3, 5, "cpu")
+    assert rep.P == 4 + 9 and rep.ped_prow.tolist() == [0, 2, 4, 7, 10] and rep.tiles_host.tolist() == [[0, 5, 0, 13]]
 
 
 def test_host_rng_follows_reference_draw_order(golden):

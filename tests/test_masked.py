@@ -75,7 +75,11 @@ def test_oracle_masked_iteration(masked, mode):
 
 
 @pytest.mark.gpu
-def test_hip_masked_iteration(masked):
+@pytest.mark.parametrize("poison", [False, True])
+def test_hip_masked_iteration(masked, poison):
+    """poison=True: every scratch buffer starts as NaN, so reading something no kernel wrote fails the comparison
+    (the discriminator's K-times repeated scene list once left the last repetition's pair range unwritten)."""
+    from mggan.hip import functions as HF
     from mggan.logging import Experiment
     from mggan.model.config import get_parser
     from mggan.model.model_factory import construct_model
@@ -95,5 +99,10 @@ def test_hip_masked_iteration(masked):
     tr.rng = tr.G.rng = ReplayRNG(labels=labels, noise=[torch.from_numpy(g["s_{}/noise".format(s)].copy()) for s, _ in STEPS],
                                   gen_idxs=[torch.from_numpy(g["s_{}/gen_idxs".format(s)].copy()) for s, _ in STEPS])
     m = defaultdict(list)
-    tr.train_iteration(bt, m)  # computes the loss mask from the NaNs like abstract_train.py:127-132
+    HF.poison_scratch(poison)
+    try:
+        tr.train_iteration(bt, m)  # computes the loss mask from the NaNs like abstract_train.py:127-132
+        torch.cuda.synchronize()
+    finally:
+        HF.poison_scratch(False)
     _check(g, m, tr.G, tr.D)
