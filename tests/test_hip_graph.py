@@ -62,3 +62,41 @@ def test_device_categorical_sampler_statistics():
     freq = torch.bincount(idx.flatten(), minlength=4).float() / idx.numel()
     ref = torch.softmax(logits[0], 0)
     assert float((freq.cpu() - ref.cpu()).abs().max()) < 0.01
+
+
+def test_branch_streams_and_graph_replay_are_bit_identical():
+    """No races, no order-dependent arithmetic: after several iterations the weights are bit-identical whether the
+    step graph runs on one stream, on the branch streams, or as a replayed HIP graph (same seeds)."""
+    import bench
+    from mggan.data_utils import synthetic
+    from mggan.hip import functions as HF
+
+    dev = torch.device("cuda", 0)
+
+    def run(branches, graph, iters=4):
+        HF.enable_branches(branches)
+        try:
+            tr = bench.build_trainer(3, "device", dev)
+            torch.cuda.manual_seed(777)
+            batch = tr.to_device(synthetic.make_batch(synthetic.scene_sizes(24, 6), seed=0))
+            batch["loss_mask"] = None
+            tr.defer_metrics = True
+            tr.zero_grads_in_step = True
+            m = defaultdict(list)
+            if graph:
+                replay = tr.capture_iteration(batch, warmup=1)
+                for _ in range(iters - 1):
+                    replay(m, False)
+            else:
+                for _ in range(iters):
+                    tr.train_iteration(batch, m)
+            tr.flush_metrics()
+            torch.cuda.synchronize()
+            return torch.cat([tr.G._flat.clone(), tr.D._flat.clone()]).cpu()
+        finally:
+            HF.enable_branches(True)
+
+    ref = run(False, False)
+    assert bool(torch.isfinite(ref).all())
+    for branches, graph in ((True, False), (True, True)):
+        assert torch.equal(run(branches, graph), ref), (branches, graph)
