@@ -97,7 +97,9 @@ class MultiGeneratorGAN(abc.ABC):
     def capture_iteration(self, batch, warmup=3):
         """Capture one full D+G+PM iteration on `batch` into a HIP graph (needs --rng device: no host
         sync anywhere in the iteration).  Returns replay(metrics) which re-runs the iteration on the
-        same static batch tensors (copy new data into them to change the input)."""
+        same static batch tensors (copy new data into them to change the input).  `warmup` eager iterations run
+        first: per-batch tables, streams and scratch are created lazily (with host copies), which a capture cannot
+        contain -- pass warmup=0 only when this trainer has already run an iteration on this batch."""
         if not getattr(self.rng, "on_device", False):
             raise RuntimeError("graph capture needs the device RNG (--rng device): the host RNG path reads the "
                                "PM-network logits back to the CPU")
