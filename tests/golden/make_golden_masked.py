@@ -128,5 +128,7 @@ if __name__ == "__main__":
             main(tag, extra, nan=False, keep_init=False)
     if "discrete" in which:  # one decoder conditioned on an embedded generator id (standard_discrete.py)
         main("discrete_g2", ["--experiment", "discrete"], nan=False, keep_init=False)
+    if "masked_sgan" in which:  # masked batch through the Social-GAN pooling (the K-times repeated scene list)
+        main("masked_sgan_g2", ["--pool_type", "sgan"], nan=True, keep_init=False)
     if "sgan" in which:  # Social-GAN pooling in G and D (social_gan.py:157-229) instead of the attention
         main("pool_sgan_g2", ["--pool_type", "sgan"], nan=False, keep_init=False)

@@ -11,7 +11,8 @@ import torch
 from conftest import GOLDEN
 from test_masked import STEPS, _batch, _check
 
-VARIANTS = ["obj_ls_g2", "obj_mm_g2", "wt_l2_g2", "wt_endpoint_g2", "wt_mgan_g2", "pool_sgan_g2", "discrete_g2"]
+VARIANTS = ["obj_ls_g2", "obj_mm_g2", "wt_l2_g2", "wt_endpoint_g2", "wt_mgan_g2", "pool_sgan_g2", "discrete_g2",
+            "masked_sgan_g2"]
 
 
 def _load(tag):
@@ -37,7 +38,7 @@ def test_oracle_variant_iteration(tag):
     D.train()
     tr = O.OracleTrainer(G, D, mode="block", gan_obj=o.get("gan_obj", "NS"), weighting_target=o.get("weighting_target", "ml"))
     bt, mask = _batch(g)
-    a = (bt["in_xy"], bt["in_dxdy"], bt["gt_xy"], bt["gt_dxdy"], bt["seq_start_end"])
+    a = (bt["in_xy"], bt["in_dxdy"], bt["gt_xy"][:, mask], bt["gt_dxdy"][:, mask], bt["seq_start_end"])
     m = defaultdict(list)
     for s, fn in STEPS:
         lab = g.get("s_{}/labels".format(s))
