@@ -207,7 +207,7 @@ class _WgradDesc(ctypes.Structure):
                 ("feature_major", ctypes.c_int)]
 
 
-_DEFER = {"on": False, "descs": [], "keep": [], "gemms": [], "events": {}}
+_DEFER = {"on": False, "descs": [], "keep": [], "gemms": [], "events": {}, "after": []}
 TRACE_NOTES = {"wgrad_multi_flops": [], "mlp_chain_flops": []}
 
 
@@ -262,6 +262,9 @@ def flush_grad_reduces():
         batch.append(desc)
         seen |= keys
     launch()
+    after, _DEFER["after"] = _DEFER["after"], []
+    for fn in after:  # consumers of reduced scratch (the LSTM gradient un-folding): behind the batched reductions
+        fn()
     _DEFER["descs"], _DEFER["keep"] = [], []
 
 
@@ -277,6 +280,19 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
         _SIDE["keep"].append(ws)
     defer = _DEFER["on"] and not _SIDE["dirty"] and not now  # now=True: the result is consumed right away
     pz, px = (_p(dz) if torch.is_tensor(dz) else dz), (_p(x) if torch.is_tensor(x) else x)
+    if defer and yact is None and overwrite:
+        # queued like the rest, but its reduction STORES into dW/db (scratch that a queued consumer reads afterwards)
+        _DEFER["gemms"].append(_WgradDesc(pz, px, ws.data_ptr(), _p(seg) or None, rows, K, N, lddz, ldx, seg_scale, n_groups,
+                                          fm))
+        cur = torch.cuda.current_stream()
+        if any(cur == st for st in _BR["streams"].values()):
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            _DEFER["events"][cur.cuda_stream] = ev
+        _DEFER["descs"].append(_ReduceDesc(ws.data_ptr(), dW_ptr, db_ptr or None, w_stride, b_stride, N, K + 1, 3, lddw,
+                                           lib.mggan_wgrad_splits(rows, K, N, n_groups), max(n_groups, 1), N * (K + 1), 0))
+        _DEFER["keep"].extend((ws, dz, x, seg))
+        return
     if defer and yact is None:
         # neither the GEMM nor its reduction runs now: both are queued (operands kept alive) and go out in the
         # batched launches of flush_grad_reduces() at the end of the backward pass
@@ -596,10 +612,16 @@ class LstmEncoderFn(Function):
         dprep = _empty(12 * H, like=dh)  # [dA (4H,2) | dbias (4H)], written (not accumulated) by the reduction
         with side_stream(dPre, Hp, Din, dprep):
             wgrad(dPre, 4 * H, Hp, H, gp[0], H, 0, rows, H, 4 * H)
-            wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, rows, 2, 4 * H, now=True,
+            later = _DEFER["on"] and not _SIDE["dirty"]  # inside the trainer's backward: GEMM and un-folding are queued
+            wgrad(dPre, 4 * H, Din, 2, dprep.data_ptr(), 2, dprep.data_ptr() + 4 * 8 * H, rows, 2, 4 * H, now=not later,
                   overwrite=True)
-            lib.mggan_lstm_unfold_grads(_p(emb_w), _p(emb_b), _p(w_ih), gp[1], gp[2], gp[3], gp[4], gp[5], 0, 1, H, E,
-                                        _p(dprep), 12 * H, _s())
+            unfold = lambda: lib.mggan_lstm_unfold_grads(_p(emb_w), _p(emb_b), _p(w_ih), gp[1], gp[2], gp[3], gp[4], gp[5],
+                                                         0, 1, H, E, _p(dprep), 12 * H, _s())
+            if later:
+                _DEFER["after"].append(unfold)
+                _DEFER["keep"].append(dprep)
+            else:
+                unfold()
         return (None,) * 9
 
 
@@ -1102,9 +1124,16 @@ class DecoderRolloutFn(Function):
                 _ReduceDesc(P + 4 * lay["A"], dprep.data_ptr(), None, 12 * H, 0, 4 * H, 2, 2, 2, NW, ng, wl, 0),
                 _ReduceDesc(P + 4 * lay["bias"], dprep.data_ptr() + 4 * 8 * H, None, 12 * H, 0, 1, 4 * H, 2, 4 * H, NW, ng,
                             wl, 0))
-            lib.mggan_grad_reduce_multi(ctypes.addressof(now), 2, st)
-            lib.mggan_lstm_unfold_grads(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), ptr["emb_w"], ptr["emb_b"],
-                                        ptr["w_ih"], ptr["b_ih"], ptr["b_hh"], stride, ng, H, E, _p(dprep), 12 * H, st)
+            unfold = lambda: lib.mggan_lstm_unfold_grads(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), ptr["emb_w"],
+                                                         ptr["emb_b"], ptr["w_ih"], ptr["b_ih"], ptr["b_hh"], stride, ng,
+                                                         H, E, _p(dprep), 12 * H, _s())
+            if _DEFER["on"]:  # off the critical chain: with the batched reductions at the end of the backward pass
+                _DEFER["descs"].extend(now)
+                _DEFER["after"].append(unfold)
+                _DEFER["keep"].extend((dprep, wpart, now))
+            else:
+                lib.mggan_grad_reduce_multi(ctypes.addressof(now), 2, st)
+                unfold()
             parts = [(0, ptr["w_hh"], 4 * H, H, H), (lay["W1"], ptr["w1"], Hh, H, H + S), (lay["b1"], ptr["b1"], 1, Hh, Hh),
                      (lay["W2"], ptr["w2"], 2, Hh, Hh), (lay["b2"], ptr["b2"], 1, 2, 2)]
             if _DEFER["on"]:
