@@ -237,7 +237,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 // ---- deferred, batched reduction of many weight-gradient partial buffers in ONE launch ----------
 // (a backward pass produces ~20 independent partial buffers; reducing each with its own launch costs
 // more in launch latency than in work)
-#define MG_MAX_REDUCE 24
+#define MG_MAX_REDUCE 48  // 48 x 72-byte descriptors: under the 4 KB kernel-argument limit
 struct ReduceDesc {
   const float* P;   // partials: [groups*splits][p_stride]
   float* dW;

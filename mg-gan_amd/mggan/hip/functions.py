@@ -256,7 +256,7 @@ def flush_grad_reduces():
 
     for desc in d:
         keys = {desc.dW} | ({desc.db} if desc.db else set())
-        if (keys & seen) or len(batch) == 24:
+        if (keys & seen) or len(batch) == 48:
             launch()
             batch, seen = [], set()
         batch.append(desc)
