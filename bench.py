@@ -372,11 +372,21 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sizes, args.num_gens, args.cpu_iters)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out))
+    else:
+        out = None
     if world > 1 or sharded:
         import torch.distributed as dist
 
+        dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # the JSON line is the LAST thing on stdout: librccl prints a version banner through C stdio, which sits in
+        # the C buffer until it is flushed (at exit, i.e. after anything Python printed earlier)
+        import ctypes
+
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
