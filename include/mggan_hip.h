@@ -186,6 +186,7 @@ int mggan_cnn_bwd_grid(int B);
 int mggan_conv1_fwd(const float* img, int B, int C, const float* W, const float* bias, float* y1, float* part,
                     mggan_stream_t stream);
 int mggan_bn_reduce(const float* part, int B, int W, double* sums, mggan_stream_t stream);
+/* training: 0 = eval (running statistics), n >= 1 = batch statistics and n momentum updates of the running ones */
 int mggan_bn_finalize(const double* sums, double count, int C, int training, const float* gamma, const float* beta,
                       float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps,
                       float* scale, float* shift, float* stat, mggan_stream_t stream);

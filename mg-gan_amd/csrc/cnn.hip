@@ -242,9 +242,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
     mean = (float)m;
     var = (float)v;
     const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
-    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
-    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
-    if (c == 0) *nbt += 1;
+    float rm = run_mean[c], rv = run_var[c];
+    for (int u = 0; u < training; ++u) {  // `training` = how many identical reference forwards this call stands for
+      rm = (1.f - momentum) * rm + momentum * mean;
+      rv = (1.f - momentum) * rv + momentum * (float)unb;
+    }
+    run_mean[c] = rm;
+    run_var[c] = rv;
+    if (c == 0) *nbt += training;
   } else {
     mean = run_mean[c];
     var = run_var[c];

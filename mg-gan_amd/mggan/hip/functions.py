@@ -916,10 +916,9 @@ class SceneAttentionFn(Function):
             scale, shift, stat = _empty(C, like=img), _empty(C, like=img), _empty(2 * C, like=img)
             # stat_updates > 1: this one forward stands for several identical reference forwards (shared
             # history context) -> the running statistics take the momentum update that many times (A.8)
-            for _ in range(stat_updates if training else 1):
-                lib.mggan_bn_finalize(_p(sums), n * hw, C, 1 if training else 0, _p(gamma), _p(beta),
-                                      _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked),
-                                      float(bn.momentum), float(bn.eps), _p(scale), _p(shift), _p(stat), st)
+            lib.mggan_bn_finalize(_p(sums), n * hw, C, stat_updates if training else 0, _p(gamma), _p(beta),
+                                  _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked),
+                                  float(bn.momentum), float(bn.eps), _p(scale), _p(shift), _p(stat), st)
             return scale, shift, stat, n * hw
 
         sc1, sh1, stat1, cnt1 = finalize(bn1, g1, be1, 33 * 33)
