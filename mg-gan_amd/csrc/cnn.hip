@@ -966,9 +966,11 @@ __global__ __launch_bounds__(1024) void partial_sum_kernel(const float* __restri
 
 // two workgroups per CU resident, every workgroup gets the same number of images (+-1)
 static int persistent_grid(int B) {
-  if (B <= 512) return B;
-  const int per = (B + 511) / 512;
-  return (B + per - 1) / per;
+  // 512 workgroups (two per CU) whenever there are more images than that: workgroup i takes images i, i + 512, ...,
+  // so with 1,280 images the first 256 workgroups get three and the other 256 two -- five per CU if the dispatcher
+  // deals workgroups round-robin -- where ceil(B / 3) = 427 equal workgroups left a third of the CUs with one
+  // workgroup and the rest with two (six images)
+  return B <= 512 ? B : 512;
 }
 
 extern "C" {
