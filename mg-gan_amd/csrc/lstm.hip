@@ -227,18 +227,28 @@ struct SeqBwdArgs {
   float* dPre;       // (R,T,4H) gate pre-activation gradients (weight gradients follow as GEMMs)
 };
 
-template <int H>
+// LW = number of W_hh rows (m) kept in LDS instead of registers.  H = 64 with everything in registers needs 288 VGPRs:
+// one wave per SIMD, one workgroup per CU, and the 320 workgroups of 1,280 rows take two rounds on 256 CUs; with a
+// quarter of the column in LDS (16 KB, shared by the workgroup's rows: 236 VGPRs) two workgroups fit a CU and one
+// round does it: 2.241 vs 2.267 ms/iter (128 rows in LDS: 2.262).  The forward kernel (416 VGPRs) was given the
+// same treatment and showed no difference: it is not on the critical chain.
+template <int H, int LW>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
-  constexpr int RT = 256 / H, G4 = 4 * H;
+  constexpr int RT = 256 / H, G4 = 4 * H, RW = G4 - LW;
   __shared__ __attribute__((aligned(16))) float dpbuf[RT][G4];
+  __shared__ float wl[LW > 0 ? LW : 1][H];
   const int rr = threadIdx.x / H, j = threadIdx.x % H;
   const int r = blockIdx.x * RT + rr;
   const bool valid = r < p.R;
   const int rc = valid ? r : p.R - 1;
 
-  v2f whc[G4 / 2];  // column j of W_hh in packed pairs: dh_prev[j] = sum_m W_hh[m][j] dpre[m]
+  v2f whc[RW / 2];  // column j of W_hh in packed pairs: dh_prev[j] = sum_m W_hh[m][j] dpre[m]
 #pragma unroll
-  for (int m = 0; m < G4; m += 2) whc[m / 2] = v2f{p.W_hh[(size_t)m * H + j], p.W_hh[(size_t)(m + 1) * H + j]};
+  for (int m = 0; m < RW; m += 2) whc[m / 2] = v2f{p.W_hh[(size_t)m * H + j], p.W_hh[(size_t)(m + 1) * H + j]};
+  if (LW > 0) {
+    for (int i = threadIdx.x; i < LW * H; i += 256) wl[i / H][i % H] = p.W_hh[(size_t)(RW + i / H) * H + (i % H)];
+    __syncthreads();
+  }
   float dh = p.dhT[(size_t)rc * p.ld_dhT + j], dc = 0.f;
 
   // software pipeline over time: the saved activations of step t-1 are fetched while step t is computed
@@ -276,10 +286,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
     lds_barrier();
     v2f nh0 = v2f{0.f, 0.f}, nh1 = v2f{0.f, 0.f};  // packed FMAs: two MACs per instruction
 #pragma unroll
-    for (int m = 0; m < G4; m += 4) {
+    for (int m = 0; m < RW; m += 4) {
       const float4 v = *reinterpret_cast<const float4*>(&dpbuf[rr][m]);
       nh0 = pk_fma(whc[m / 2], v2f{v.x, v.y}, nh0);
       nh1 = pk_fma(whc[m / 2 + 1], v2f{v.z, v.w}, nh1);
+    }
+#pragma unroll
+    for (int m = 0; m < LW; m += 4) {  // the rows of the column that live in LDS (conflict-free: consecutive j)
+      const float4 v = *reinterpret_cast<const float4*>(&dpbuf[rr][RW + m]);
+      nh0 = pk_fma(v2f{wl[m][j], wl[m + 1][j]}, v2f{v.x, v.y}, nh0);
+      nh1 = pk_fma(v2f{wl[m + 2][j], wl[m + 3][j]}, v2f{v.z, v.w}, nh1);
     }
     dh = (nh0.x + nh0.y) + (nh1.x + nh1.y);
     lds_barrier();
@@ -850,8 +866,8 @@ int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, co
   if (b == 0) return MGGAN_OK;
   SeqBwdArgs p = {};
   p.R = b; p.T = T; p.W_hh = W_hh; p.Gt = Gt; p.Cs = Cs; p.dhT = dhT; p.ld_dhT = ld_dhT; p.dPre = dPre;
-  if (H == 32) hipLaunchKernelGGL((lstm_bwd_kernel<32>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((lstm_bwd_kernel<64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
+  if (H == 32) hipLaunchKernelGGL((lstm_bwd_kernel<32, 0>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((lstm_bwd_kernel<64, 64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
   MG_LAUNCH_CHECK("lstm_encoder_bwd");
   return MGGAN_OK;
 }
