@@ -4,10 +4,12 @@
 One "step" = one full iteration of the reference loop body (abstract_train.py:114-168):
 discriminator step + generator step + PM-network step, each with forward, backward, gradient
 clipping and an AdamW update, on a synthetic batch already resident in HBM.
-Workload at N=1: BASELINE.json configs[1] -- 64 scenes x 20 pedestrians, num_gens=4, K=20 samples.
-N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns 64 scenes of a
-N*64-scene global batch (weak scaling); gradients / BatchNorm statistics / generator counts are
-all-reduced over RCCL.  value = N * b_local * steps / max-over-ranks(time).
+Headline workload: BASELINE.json configs[1] -- 64 scenes x 20 pedestrians, num_gens=4, K=20 samples; the same
+run also measures configs[2] (256 scenes x 32 pedestrians, num_gens=8) with the same protocol into `configs`.
+N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns that many scenes of an N-times larger
+global batch (weak scaling: the 64x20 shard is configs[4]'s, the 256x32 g=8 shard configs[3]'s); gradients /
+BatchNorm statistics / generator counts are exchanged between the ranks.
+value = N * b_local * steps / max-over-ranks(time).
 
 Prints ONE JSON line (rank 0) with `roofline` for the dominant C-ABI entry (timed live with HIP
 events on the launch stream) and `cpu_baseline` (the CPU oracle, block-diagonal mode, timed on
@@ -134,7 +136,8 @@ def build_trainer(num_gens, rng, device, seed=0):
     return tr
 
 
-def cpu_baseline(sizes, num_gens, iters):
+def cpu_baseline(sizes, num_gens, iters, mode="block", tag="same workload"):
+    """The CPU oracle timed on this box's host cores (test infrastructure used as the reported CPU baseline only)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mggan_oracle as O
     from mggan.data_utils import synthetic
@@ -144,7 +147,7 @@ def cpu_baseline(sizes, num_gens, iters):
     torch.manual_seed(145325)
     np.random.seed(435346)
     G, D = O.construct_oracle(num_gens)
-    tr = O.OracleTrainer(G, D, mode="block")
+    tr = O.OracleTrainer(G, D, mode=mode)
     batch = synthetic.make_batch(sizes, seed=0)
     m = defaultdict(list)
     tr.iteration(batch, m)  # warm-up
@@ -153,10 +156,153 @@ def cpu_baseline(sizes, num_gens, iters):
         tr.iteration(batch, m)
     dt = (time.perf_counter() - t0) / iters
     b = batch["in_xy"].shape[1]
-    return {"value": b / dt, "unit": "trajectories/s", "cores": threads, "kind": "port",
-            "sample": "{} full iterations (D+G+PM steps) of the same {}-scene x {}-ped, num_gens={} workload on the CPU "
-                      "oracle (oracle/mggan_oracle.py, block-diagonal mode, torch CPU {} threads, nproc={}); "
-                      "{:.2f} s/iteration".format(iters, len(sizes), sizes[0], num_gens, threads, os.cpu_count(), dt)}
+    return {"value": b / dt, "unit": "trajectories/s", "cores": threads, "kind": "port", "mode": mode,
+            "sample": "{} full iterations (D+G+PM steps) of {}: {} scenes, {} pedestrians, num_gens={} on the CPU "
+                      "oracle (oracle/mggan_oracle.py, {} mode, torch CPU {} threads, nproc={}); "
+                      "{:.2f} s/iteration".format(iters, tag, len(sizes), b, num_gens,
+                                                  "block-diagonal" if mode == "block" else
+                                                  "faithful (the reference's dense all-pairs operator sequence)",
+                                                  threads, os.cpu_count(), dt)}
+
+
+CONFIGS = {  # BASELINE.json configs
+    "c1": dict(scenes=32, peds=None, num_gens=1, name="BASELINE configs[0] shape: 32 ragged scenes (1-6 peds), num_gens=1"),
+    "c2": dict(scenes=64, peds=20, num_gens=4, name="BASELINE configs[1] / per-GPU shard of configs[4]"),
+    "c3": dict(scenes=256, peds=32, num_gens=8, name="BASELINE configs[2] / per-GPU shard of configs[3]"),
+}
+
+
+def _load_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        with open(path) as fh:
+            return json.load(fh)
+    return {}
+
+
+def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, graph=True, rng=None):
+    """Build a trainer for one workload, time exactly args.steps iterations between barriers, then (profile) time
+    every C-ABI entry with HIP events over three eager iterations.  -> dict (rank 0 keeps it)."""
+    import torch.distributed as dist
+    from mggan.data_utils import synthetic
+    from mggan.hip.lib import start_trace, stop_trace
+
+    rng = rng or args.rng
+    tr = build_trainer(num_gens, rng, dev, seed=rank)
+    tr.dist.equal_shards = True  # every rank holds the same number of scenes/pedestrians
+    sizes = synthetic.scene_sizes(scenes, peds)
+    batch = tr.to_device(synthetic.make_batch(sizes, seed=rank))
+    b = batch["in_xy"].shape[1]
+    batch["loss_mask"] = None  # synthetic data has no NaN ground truth: every pedestrian is valid
+    tr.defer_metrics = True
+    tr.zero_grads_in_step = True  # AdamW zeroes what it consumed: no separate memset per step
+    metrics = defaultdict(list)
+    use_graph = graph and rng == "device" and not args.no_graph
+    sharded = tr.dist.enabled
+    replay = None
+    if use_graph:
+        try:
+            replay = tr.capture_iteration(batch)
+        except Exception as exc:  # noqa: BLE001
+            if not sharded:
+                raise
+            # every rank runs the same program on the same shapes, so they all end up here together
+            print("[bench] rank {}: graph capture of the sharded iteration failed ({}: {}); launching eagerly".format(
+                rank, type(exc).__name__, exc), file=sys.stderr)
+            tr.dist.recorder = None
+            use_graph = False
+    if use_graph:
+        def run_step(fetch):
+            replay(metrics, fetch)
+    else:
+        def run_step(fetch):
+            tr.train_iteration(batch, metrics)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        run_step(i == args.warmup - 1)
+    tr.flush_metrics()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run_step(i == args.steps - 1)  # logged losses are fetched once (one D2H) inside the timed region
+    tr.flush_metrics()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    launch = ("eager launches" if not use_graph else "hipGraph replay of the whole iteration" if not sharded
+              else getattr(tr, "launch_mode", "hipGraph replay"))
+    res = {"config": tag, "workload": "{} scenes x {} peds per GPU, num_gens={}, num_samples=20, D+G+PM steps ({})".format(
+               scenes, peds if peds else "1-6 (ragged)", num_gens, CONFIGS.get(tag, {}).get("name", "custom shape")),
+           "b_per_gpu": b, "ms_per_step": round(dt / args.steps * 1e3, 4),
+           "value": round(world * b * args.steps / dt, 2), "unit": "trajectories/s", "rng": rng, "launch": launch,
+           "bn_sync": tr.config.bn_sync,
+           "last_losses": {k: round(v[-1], 6) for k, v in sorted(metrics.items()) if "probs" not in k}}
+    if not profile:
+        del tr, replay
+        torch.cuda.empty_cache()
+        return res
+
+    # ---- live per-entry timing (HIP events on the launch stream) for the roofline block ----
+    start_trace()
+    n_prof = 3
+    for _ in range(n_prof):
+        tr.train_iteration(batch, metrics)
+    tr.flush_metrics()
+    trace = stop_trace()
+    rows = []
+    for name, (calls, ms_list, arglist) in trace.items():
+        # one row per HIP kernel: an entry such as mggan_conv1_bwd launches a different template per channel count
+        by_kernel = {}
+        for a, ms in zip(arglist, ms_list):
+            r = by_kernel.setdefault(kernel_of(name, a), [0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += ms
+            r[2] += flops_of(name, a)
+        for sym, (c, ms, fl) in by_kernel.items():
+            rows.append((ms / n_prof, name, c / n_prof, fl / n_prof, sym))
+    rows.sort(reverse=True)
+    gpu_ms = sum(r[0] for r in rows)
+    total_flops = sum(r[3] for r in rows)
+    # HBM bytes per launch and MFMA-pipe utilisation from the committed rocprofv3 --pmc passes (DESIGN.md section 7)
+    traffic_tab = _load_json("hbm_traffic_{}.json".format(tag)) or (_load_json("hbm_traffic.json") if tag == "c2" else {})
+    mfma_tab = _load_json("mfma_util_{}.json".format(tag))
+
+    def roof(row):
+        ms, name, calls, fl, symbol = row
+        per_launch_s = ms / max(calls, 1) * 1e-3
+        achieved = fl / max(calls, 1) / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
+        return {"bound": "mfma", "kernel": symbol, "entry": name, "achieved": round(achieved, 3),
+                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_PEAK_TFLOPS, 5),
+                "traffic": traffic_tab.get(symbol, {}).get("bytes_per_launch"),
+                "mfma_util": mfma_tab.get(symbol, {}).get("mfma_util"),
+                "launches_per_step": round(calls, 2), "avg_launch_ms": round(per_launch_s * 1e3, 4)}
+
+    # the dominant kernel = the one with the largest share of the step's GPU time (summed over its launches)
+    roofline = roof(rows[0])
+    roofline["note"] = ("f32 (exact) -- peak is the dense f32 vector/MFMA rate; achieved = algorithmic FLOPs per launch "
+                        "(SURVEY App. D shapes) / average HIP-event duration of a launch of this kernel; traffic = HBM "
+                        "bytes per launch, mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE), both "
+                        "from the rocprofv3 --pmc passes committed under profiles/")
+    res.update({
+        "roofline": roofline, "roofline_top_kernels": [roof(r) for r in rows[:8]],
+        "iteration_flops_algorithmic_g": round(total_flops / 1e9, 2),
+        "iteration_tflops": round(total_flops / (dt / args.steps) / 1e12, 3),
+        "iteration_frac_of_f32_peak": round(total_flops / (dt / args.steps) / 1e12 / F32_PEAK_TFLOPS, 4),
+        "gpu_ms_per_step_sum_of_entries": round(gpu_ms, 3),
+        "launches_per_step": round(sum(r[2] for r in rows), 1),
+        "breakdown": [{"entry": n, "kernel": sym, "ms_per_step": round(ms, 4), "calls": round(c, 2), "gflop": round(fl / 1e9, 3)}
+                      for ms, n, c, fl, sym in rows[:14]]})
+    del tr, replay
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -164,14 +310,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scenes", type=int, default=64)
-    ap.add_argument("--peds", type=int, default=20)
-    ap.add_argument("--num_gens", type=int, default=4)
+    ap.add_argument("--config", default="c2", help="headline workload: c1 | c2 | c3 (= the per-GPU shard of configs[3]; "
+                    "alias c4) | custom (uses --scenes/--peds/--num_gens)")
+    ap.add_argument("--also", default="c3", help="comma list of further configs measured into the `configs` list ('' = none)")
+    ap.add_argument("--scenes", type=int, default=None)
+    ap.add_argument("--peds", type=int, default=None)
+    ap.add_argument("--num_gens", type=int, default=None)
     ap.add_argument("--rng", choices=["host", "device"], default="device")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--no-floor", action="store_true", help="skip the C1-shaped eager / host-RNG / graph floor timings")
+    ap.add_argument("--cpu-iters", type=int, default=5)
     args = ap.parse_args()
+    if args.config == "c4":
+        args.config = "c3"
+    if args.scenes is not None:  # explicit shape (round-1 command lines keep working)
+        CONFIGS["custom"] = dict(scenes=args.scenes, peds=args.peds, num_gens=args.num_gens or 4, name="custom shape")
+        for k, v in CONFIGS.items():
+            if k != "custom" and (v["scenes"], v["peds"], v["num_gens"]) == (args.scenes, args.peds, args.num_gens or 4):
+                args.config = k
+                break
+        else:
+            args.config = "custom"
+        args.also = ""
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -201,180 +362,66 @@ def main():
 
     from mggan.data_utils import synthetic
     from mggan.hip import lib as hiplib_mod  # noqa: F401
-    from mggan.hip.lib import start_trace, stop_trace
 
-    tr = build_trainer(args.num_gens, args.rng, dev, seed=rank)
-    tr.dist.equal_shards = True  # every rank holds the same number of scenes/pedestrians
-    sizes = synthetic.scene_sizes(args.scenes, args.peds)
-    batch = tr.to_device(synthetic.make_batch(sizes, seed=rank))
-    b = batch["in_xy"].shape[1]
-    batch["loss_mask"] = None  # synthetic data has no NaN ground truth: every pedestrian is valid
-    tr.defer_metrics = True
-    tr.zero_grads_in_step = True  # AdamW zeroes what it consumed: no separate memset per step
-    metrics = defaultdict(list)
-    use_graph = args.rng == "device" and not args.no_graph
-    replay = None
-    sharded = tr.dist.enabled
-    if use_graph and sharded and os.environ.get("MGGAN_GRAPH_COLLECTIVES", "0") != "0":
-        # opt-in (MGGAN_GRAPH_COLLECTIVES=1|auto, experimental): the RCCL collectives captured INSIDE one graph.  The
-        # attempt is checked (two replays must leave every rank with identical weights) and bounded in time; if it fails,
-        # a fresh trainer is built and the capture is cut into segments around eager collectives instead.
-        import threading
+    head_cfg = CONFIGS[args.config]
+    head = measure(args.config, head_cfg["scenes"], head_cfg["peds"], head_cfg["num_gens"], args, world, rank, dev)
+    others = []
+    for tag in [t for t in args.also.split(",") if t and t != args.config]:
+        c = CONFIGS[tag]
+        others.append(measure(tag, c["scenes"], c["peds"], c["num_gens"], args, world, rank, dev))
 
-        from mggan.parallel import replicas_in_sync
-
-        import torch.distributed as dist
-
-        warm = torch.zeros(1, device=dev)
-        dist.all_reduce(warm)  # first collective of the process: RCCL loads its kernels here, however long that takes
-        torch.cuda.synchronize()
-        done = threading.Event()
-
-        def watchdog():
-            if not done.wait(float(os.environ.get("MGGAN_GRAPH_TRIAL_TIMEOUT", "300"))):
-                print("[bench] rank {}: graph with captured collectives did not finish in time; rerun with "
-                      "MGGAN_GRAPH_COLLECTIVES=0".format(rank), file=sys.stderr, flush=True)
-                os._exit(17)
-
-        threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            replay = tr.capture_iteration(batch)
-            if tr.graph_collectives:
-                for _ in range(2):
-                    replay(metrics, False)
-                torch.cuda.synchronize()
-                if not replicas_in_sync(tr.G, tr.D):
-                    raise RuntimeError("ranks diverged after replaying the captured collectives")
-        except Exception as exc:  # noqa: BLE001
-            print("[bench] rank {}: one-graph capture with RCCL inside failed ({}: {}); cutting the capture into "
-                  "segments".format(rank, type(exc).__name__, exc), file=sys.stderr)
-            replay = None
-            os.environ["MGGAN_GRAPH_COLLECTIVES"] = "0"
-            torch.cuda.synchronize()
-            tr = build_trainer(args.num_gens, args.rng, dev, seed=rank)
-            tr.dist.equal_shards = True
-            tr.defer_metrics = True
-            tr.zero_grads_in_step = True
-        finally:
-            done.set()
-    if use_graph and replay is None:
-        try:
-            replay = tr.capture_iteration(batch)
-        except Exception as exc:  # noqa: BLE001
-            if not sharded:
-                raise
-            # every rank runs the same program on the same shapes, so they all end up here together
-            print("[bench] rank {}: graph-segment capture failed ({}: {}); launching eagerly".format(
-                rank, type(exc).__name__, exc), file=sys.stderr)
-            tr.dist.recorder = None
-            use_graph = False
-    if use_graph:
-        def run_step(fetch):
-            replay(metrics, fetch)
-    else:
-        def run_step(fetch):
-            tr.train_iteration(batch, metrics)
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        run_step(i == args.warmup - 1)
-    tr.flush_metrics()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_step(i == args.steps - 1)  # logged losses are fetched once (one D2H) inside the timed region
-    tr.flush_metrics()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # ---- live per-entry timing (HIP events on the launch stream) for the roofline block ----
-    start_trace()
-    n_prof = 3
-    for _ in range(n_prof):
-        tr.train_iteration(batch, metrics)
-    tr.flush_metrics()
-    trace = stop_trace()
-    rows = []
-    for name, (calls, ms_list, arglist) in trace.items():
-        # one row per HIP kernel: an entry such as mggan_conv1_bwd launches a different template per channel count
-        by_kernel = {}
-        for a, ms in zip(arglist, ms_list):
-            r = by_kernel.setdefault(kernel_of(name, a), [0, 0.0, 0.0])
-            r[0] += 1
-            r[1] += ms
-            r[2] += flops_of(name, a)
-        for sym, (c, ms, fl) in by_kernel.items():
-            rows.append((ms / n_prof, name, c // n_prof, fl / n_prof, sym))
-    rows.sort(reverse=True)
-    gpu_ms = sum(r[0] for r in rows)
-    total_flops = sum(r[3] for r in rows)
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
-    traffic_tab = {}
-    if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
-        with open(tpath) as fh:
-            traffic_tab = json.load(fh)
-
-    def roof(row):
-        ms, name, calls, fl, symbol = row
-        per_launch_s = ms / max(calls, 1) * 1e-3
-        achieved = fl / max(calls, 1) / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
-        return {"bound": "mfma", "kernel": symbol, "entry": name, "achieved": round(achieved, 3),
-                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_PEAK_TFLOPS, 5),
-                "traffic": traffic_tab.get(symbol, {}).get("bytes_per_launch"), "launches_per_step": calls,
-                "avg_launch_ms": round(per_launch_s * 1e3, 4)}
-
-    # the dominant kernel = the one with the largest share of the step's GPU time (summed over its launches)
-    roofline = roof(rows[0])
-    roofline["note"] = ("f32 (exact) -- peak is the dense f32 vector/MFMA rate; achieved = algorithmic FLOPs per launch "
-                        "(SURVEY App. D shapes) / average HIP-event duration of a launch of this kernel; traffic = HBM "
-                        "bytes per launch from the rocprofv3 --pmc passes committed under profiles/")
-    roofline_top = [roof(r) for r in rows[:6]]
-    breakdown = [{"entry": n, "ms_per_step": round(ms, 4), "calls": c, "gflop": round(fl / 1e9, 3)}
-                 for ms, n, c, fl, _ in rows[:12]]
-
+    out = None
     if rank == 0:
+        keep = ("config", "workload", "b_per_gpu", "ms_per_step", "value", "unit", "launch", "roofline",
+                "roofline_top_kernels", "iteration_flops_algorithmic_g", "iteration_tflops", "iteration_frac_of_f32_peak",
+                "launches_per_step", "breakdown")
         out = {
-            "metric": "train-step trajectories/sec", "value": round(world * b * args.steps / dt, 2),
-            "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "{} scenes x {} peds per GPU, num_gens={}, num_samples=20, D+G+PM steps ({})".format(
-                           args.scenes, args.peds, args.num_gens,
-                           {(64, 20, 4): "BASELINE configs[1]", (256, 32, 8): "BASELINE configs[2]"}.get(
-                               (args.scenes, args.peds, args.num_gens), "custom shape")),
-                       "b_per_gpu": b, "parallelism": "dp{}".format(world), "rng": args.rng,
-                       "bn_sync": tr.config.bn_sync,
-                       "launch": ("eager" if not use_graph else "hipGraph replay of the whole iteration" if not sharded
-                                  else "hipGraph replay of the whole iteration, RCCL collectives captured inside it"
-                                  if getattr(tr, "graph_collectives", False)
-                                  else "{} hipGraph segments per iteration, RCCL collectives between them".format(
-                                      replay.graph.n_graphs)),
-                       "last_losses": {k: round(v[-1], 6) for k, v in sorted(metrics.items()) if "probs" not in k}},
-            "roofline": roofline,
-            "roofline_top_kernels": roofline_top,
-            "iteration_flops_algorithmic_g": round(total_flops / 1e9, 2),
-            "iteration_tflops": round(total_flops / (dt / args.steps) / 1e12, 3),
-            "gpu_ms_per_step_sum_of_entries": round(gpu_ms, 3),
-            "breakdown": breakdown,
+            "metric": "train-step trajectories/sec", "value": head["value"], "unit": "trajectories/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": head["workload"], "b_per_gpu": head["b_per_gpu"], "parallelism": "dp{}".format(world),
+                       "rng": head["rng"], "bn_sync": head["bn_sync"], "launch": head["launch"],
+                       "last_losses": head["last_losses"]},
+            "roofline": head["roofline"], "roofline_top_kernels": head["roofline_top_kernels"],
+            "iteration_flops_algorithmic_g": head["iteration_flops_algorithmic_g"],
+            "iteration_tflops": head["iteration_tflops"],
+            "iteration_frac_of_f32_peak": head["iteration_frac_of_f32_peak"],
+            "gpu_ms_per_step_sum_of_entries": head["gpu_ms_per_step_sum_of_entries"],
+            "launches_per_step": head["launches_per_step"], "breakdown": head["breakdown"],
+            # every measured workload, the headline first (same timing protocol: warmup, barrier, K steps, barrier)
+            "configs": [{k: r[k] for k in keep if k in r} for r in [head] + others],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sizes, args.num_gens, args.cpu_iters)
-            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-    else:
-        out = None
-    if world > 1 or sharded:
+    if world == 1 and os.environ.get("MGGAN_FORCE_DIST", "0") != "1" and not args.no_floor:
+        # what a user of train() gets on ragged ETH-shaped batches (configs[0] shape): the graph floor, eager launches
+        # with the device RNG, and eager launches with the seed-comparable host RNG (one D2H + host multinomial per G call)
+        c1 = CONFIGS["c1"]
+        floor_args = argparse.Namespace(**vars(args))
+        floor_args.steps, floor_args.warmup = max(args.steps, 20), max(args.warmup, 5)
+        g1 = measure("c1", c1["scenes"], c1["peds"], c1["num_gens"], floor_args, world, rank, dev, profile=False)
+        e1 = measure("c1", c1["scenes"], c1["peds"], c1["num_gens"], floor_args, world, rank, dev, profile=False, graph=False)
+        h1 = measure("c1", c1["scenes"], c1["peds"], c1["num_gens"], floor_args, world, rank, dev, profile=False, graph=False,
+                     rng="host")
+        out["c1_shaped"] = {"workload": g1["workload"], "b": g1["b_per_gpu"], "graph_ms_per_step": g1["ms_per_step"],
+                            "graph_value": g1["value"], "eager_ms_per_step": e1["ms_per_step"], "eager_value": e1["value"],
+                            "host_rng_ms_per_step": h1["ms_per_step"], "host_rng_value": h1["value"],
+                            "note": "train() launches eagerly per loader batch with --rng host by default; the headline "
+                                    "needs capture_iteration on one static batch shape with --rng device"}
+        e2 = measure(args.config, head_cfg["scenes"], head_cfg["peds"], head_cfg["num_gens"], floor_args, world, rank, dev,
+                     profile=False, graph=False)
+        out["eager_ms_per_step"] = e2["ms_per_step"]
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sizes = synthetic.scene_sizes(head_cfg["scenes"], head_cfg["peds"])
+        out["cpu_baseline"] = cpu_baseline(sizes, head_cfg["num_gens"], args.cpu_iters, "block", "the headline workload")
+        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        # the reference's own operator sequence (dense all-pairs social features, per-pedestrian select loop) is cubic in
+        # the batch: at the full configs[0] shape (b~100) one iteration takes minutes, so the bounded sample is its first
+        # 8 scenes; the rate at the full shape is lower still (0.30 trajectories/s at b=96)
+        c1s = synthetic.scene_sizes(CONFIGS["c1"]["scenes"], None)[:8]
+        fb = cpu_baseline(c1s, 1, max(3, args.cpu_iters), "faithful", "the first 8 scenes of the configs[0] shape")
+        out["cpu_baseline_faithful_c1"] = fb
+        if "c1_shaped" in out:
+            out["gpu_c1_over_cpu_faithful"] = round(out["c1_shaped"]["graph_value"] / fb["value"], 1)
+    if world > 1 or os.environ.get("MGGAN_FORCE_DIST", "0") == "1":
         import torch.distributed as dist
 
         dist.barrier()

@@ -150,6 +150,7 @@ class MultiGeneratorGAN(abc.ABC):
                     self.dist.recorder = None
             torch.cuda.current_stream().wait_stream(side)
             run, graph = rec.replay, rec
+            self.launch_mode = "{} hipGraph segments per iteration, collectives between them".format(rec.n_graphs)
         else:
             graph = torch.cuda.CUDAGraph()
             dot = os.environ.get("MGGAN_GRAPH_DOT")  # debugging aid: dump the captured graph's nodes and edges
@@ -161,6 +162,8 @@ class MultiGeneratorGAN(abc.ABC):
             if dot:
                 graph.debug_dump(dot)
             run = graph.replay
+            self.launch_mode = "hipGraph replay of the whole iteration" + (
+                ", RCCL collectives captured inside it" if in_graph else "")
         pending, self._pending = self._pending, []
         self.defer_metrics = keep
 

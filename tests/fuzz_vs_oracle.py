@@ -16,6 +16,9 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [R, os.path.join(R, "mg-gan_amd"), os.path.join(R, "oracle")]
 
 
+TOL = 1e-3  # losses rtol 1e-3, post-step parameters relL2 1e-3
+
+
 def run_cases(seed=0, cases=12, verbose=True):
     import mggan_oracle as O
     from mggan.data_utils import synthetic
@@ -39,8 +42,10 @@ def _run(seed, cases, verbose, O, synthetic, Experiment, get_parser, construct_m
     rnd = random.Random(seed)
     failed = []
     for case in range(cases):
-        g = rnd.choice([1, 2, 3, 5]); K = rnd.choice([1, 4, 20])
+        g = rnd.choice([1, 2, 3, 5, 8]); K = rnd.choice([1, 4, 20])
         sizes = [rnd.randint(1, 9) for _ in range(rnd.randint(1, 9))]
+        if rnd.random() < 0.25:  # a wide batch: 32 or 64 scenes, up to 32 pedestrians each
+            sizes = [rnd.randint(1, 32) for _ in range(rnd.choice([32, 64]))]
         extra = rnd.choice([[], [], ["--pool_type", "sgan"], ["--gan_obj", "LS"], ["--gan_obj", "MM"], ["--weighting_target", "l2"], ["--experiment", "discrete"]])
         nanmask = rnd.random() < 0.4
         cfg = get_parser().parse_args(["--num_gens", str(g), "--num_samples", str(K)] + extra)
@@ -78,13 +83,13 @@ def _run(seed, cases, verbose, O, synthetic, Experiment, get_parser, construct_m
                 getattr(tro, step)(*cpu_args, m_cpu, mask, batch["features"], draws=draws)
                 for key, v in m_cpu.items():
                     if "probs" in key: continue
-                    if not abs(m_gpu[key][0] - v[0]) <= 2e-3 * abs(v[0]) + 1e-5:
+                    if not abs(m_gpu[key][0] - v[0]) <= TOL * abs(v[0]) + 1e-5:
                         ok = False; msg += " %s:%s gpu=%.6g cpu=%.6g" % (step[:3], key.split("/")[-1], m_gpu[key][0], v[0])
             for name, mod, ref in (("G", tr.G, Go), ("D", tr.D, Do)):
                 a = torch.cat([p.detach().cpu().flatten() for p in mod.parameters()]).double()
                 r = torch.cat([p.detach().flatten() for p in ref.parameters()]).double()
                 rel = float((a - r).norm() / r.norm())
-                if not rel <= 2e-3: ok = False; msg += " %s rel=%.2e" % (name, rel)
+                if not rel <= TOL: ok = False; msg += " %s rel=%.2e" % (name, rel)
         except Exception as e:
             ok = False; msg = " EXC %s: %s" % (type(e).__name__, str(e)[:150])
         if not ok:
