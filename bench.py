@@ -289,7 +289,7 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
     roofline = roof(rows[0])
     roofline["note"] = ("f32 (exact) -- peak is the dense f32 vector/MFMA rate; achieved = algorithmic FLOPs per launch "
                         "(SURVEY App. D shapes) / average HIP-event duration of a launch of this kernel; traffic = HBM "
-                        "bytes per launch, mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE), both "
+                        "bytes per launch, mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8 XCDs), both "
                         "from the rocprofv3 --pmc passes committed under profiles/")
     res.update({
         "roofline": roofline, "roofline_top_kernels": [roof(r) for r in rows[:8]],

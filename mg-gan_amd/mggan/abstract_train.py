@@ -28,7 +28,9 @@ class MultiGeneratorGAN(abc.ABC):
     def __init__(self, generator, discriminator, config, writer):
         self.writer = writer
         self.config = config
-        if not config.gpus:
+        # `--gpus` is a device-id string ("0" by default); meta_tags.csv read-back may hand it over as int 0 -- only an
+        # explicitly empty / None / False value asks for the CPU path, which this build does not have
+        if config.gpus is None or config.gpus is False or (isinstance(config.gpus, str) and config.gpus.strip() == ""):
             raise RuntimeError("the MI355X build has no CPU compute path: pass --gpus 0 (use the oracle for CPU runs)")
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible; the hot path runs only on the GPU (no CPU fallback)")
@@ -50,6 +52,7 @@ class MultiGeneratorGAN(abc.ABC):
         self.lr_schedulerD = CosineAnnealingLR(self.optimizerD, config.epochs, eta_min=0)
         self.lr_schedulerG = CosineAnnealingLR(self.optimizerG, config.epochs, eta_min=0)
         self.epoch = 0
+        self.total_iterations = 0  # abstract_train.py:104 (gates the discriminator step with --num_gen_steps)
 
         self.rng = DeviceRNG() if getattr(config, "rng", "host") == "device" else HostRNG()
         self.G.rng = self.rng
@@ -84,15 +87,24 @@ class MultiGeneratorGAN(abc.ABC):
         args = (in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, metrics, loss_mask, img)
         if hasattr(self.rng, "begin_iteration"):
             self.rng.begin_iteration()
+        cfg = self.config
+        run_d = self.total_iterations % max(int(cfg.num_gen_steps), 1) == 0 or self.epoch >= cfg.keep_gen_steps
         shared = None
-        if getattr(self, "share_trunk", False) and loss_mask is None and self.config.num_unrolling_steps == 0:
+        if getattr(self, "share_trunk", False) and loss_mask is None and cfg.num_unrolling_steps == 0 and run_d:
             # G is not updated between the no-grad generator call of the D step and the G step: one trunk
             # forward (with its backward graph) serves both; BatchNorm running stats still move twice (A.8)
             shared = {"g_trunk": self.G.trunk(in_xy, in_dxdy, sub_batches, img, passes=2)}
-        for _ in range(self.config.num_unrolling_steps + 1):
-            self.discriminator_step(*args, shared=shared)
+        # abstract_train.py:136-150: the discriminator step runs when total_iterations % num_gen_steps == 0 or
+        # epoch >= keep_gen_steps, and num_unrolling_steps + 1 times.  The reference's unrolling "backup" is
+        # `self.D.state_dict()` -- references to the live parameters, not copies -- so its load_state_dict(backup)
+        # after the generator / PM steps (:163-164) copies every tensor onto itself: the discriminator KEEPS all
+        # unrolled updates.  That literal behaviour is what runs here (nothing to restore).
+        if run_d:
+            for _ in range(cfg.num_unrolling_steps + 1):
+                self.discriminator_step(*args, shared=shared)
         self.generator_step(*args, shared=shared)
         self.net_chooser_step(*args)
+        self.total_iterations += 1
 
     def capture_iteration(self, batch, warmup=3):
         """Capture one full D+G+PM iteration on `batch` into a HIP graph (needs --rng device: no host
@@ -103,6 +115,9 @@ class MultiGeneratorGAN(abc.ABC):
         if not getattr(self.rng, "on_device", False):
             raise RuntimeError("graph capture needs the device RNG (--rng device): the host RNG path reads the "
                                "PM-network logits back to the CPU")
+        if int(self.config.num_gen_steps) != 1:
+            raise RuntimeError("graph capture replays ONE fixed iteration: --num_gen_steps must be 1 (the discriminator "
+                               "step would otherwise run in some iterations only)")
         batch = dict(batch)
         batch["loss_mask"] = None
         in_graph = False
@@ -225,19 +240,13 @@ class MultiGeneratorGAN(abc.ABC):
 
     @classmethod
     def load(cls, log_path, exp_name, version, checkpoint):
-        import csv
-
         version_dir = Path(log_path) / exp_name / "version_{}".format(version)
         checkpoint_dir = version_dir / "checkpoints"
         if checkpoint == "latest":
             epochs = [int(p.stem.split("_")[1]) for p in checkpoint_dir.iterdir() if p.stem.split("_")[1] != "best"]
             checkpoint = max(epochs)
         state_dicts = torch.load(checkpoint_dir / "checkpoint_{}.pth".format(checkpoint), map_location="cpu")
-        defaults = {a.dest: a.default for a in get_parser()._actions if not a.required and a.dest != "help"}
-        with open(version_dir / "meta_tags.csv") as f:
-            for row in csv.DictReader(f):
-                defaults[row["key"]] = _convert(row["value"])
-        config = Namespace(**defaults)
+        config = read_meta_tags(version_dir / "meta_tags.csv")
         g, d = cls.construct_model(config)
         m = cls(g, d, config, Experiment(log_path, name=exp_name, version=version))
         m.G.load_state_dict(state_dicts["generator"], strict=False)
@@ -273,6 +282,18 @@ class MultiGeneratorGAN(abc.ABC):
     @abc.abstractmethod
     def check_accuracy(self, loader, vis=False, prefix="", num_k=20):
         pass
+
+
+def read_meta_tags(path):
+    """meta_tags.csv (test_tube's `key,value` rows, utils.py:97-131 of the reference) over the parser defaults ->
+    Namespace.  `gpus` stays the device-id string it is on the command line ("0" must not turn into a falsy 0)."""
+    import csv
+
+    defaults = {a.dest: a.default for a in get_parser()._actions if not a.required and a.dest != "help"}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            defaults[row["key"]] = row["value"] if row["key"] == "gpus" else _convert(row["value"])
+    return Namespace(**defaults)
 
 
 def _convert(val):

@@ -81,6 +81,26 @@ class FlatModule(nn.Module):
             p.grad = view
         return self._flat_grad.data_ptr() + 4 * o
 
+    def adopt_foreign_grads(self):
+        """A gradient that reached a parameter through plain torch autograd (an index / cat path of the masked
+        discriminator forward, or any future torch operator) lives outside the flat buffer.  It is added into the
+        parameter's slot and the parameter counts as touched, so that clip + AdamW see exactly the reference's
+        `p.grad is not None` set.  (The HIP backward kernels never take this path: host-side pointer compares only.)"""
+        base = self._flat_grad.data_ptr()
+        for p, o in self._flat_items:
+            g = p.grad
+            if g is None or g.data_ptr() == base + 4 * o:
+                continue
+            n = p.numel()
+            slot = self._flat_grad[o:o + n]
+            if id(p) in self._touched:
+                slot.add_(g.reshape(-1))
+            else:
+                slot.copy_(g.reshape(-1))
+                self._touched.add(id(p))
+            self._grad_clean = False
+            p.grad = slot.view(p.shape)
+
     def zero_grad_flat(self):
         """Trainer fast path: one memset, every p.grad stays attached.  The memset is skipped when the last
         optimizer step already left the buffer zeroed (FlatAdamW.step(zero_grad=True)) and nothing wrote since."""

@@ -680,15 +680,25 @@ class SceneTables:
 _TABLE_CACHE = {}
 
 
+def scene_fingerprint(seq_start_end):
+    """Cheap content check for caches keyed by id(list): a caller that mutates its scene list in place (same id,
+    other bounds) must not get the tables of the old contents back."""
+    n = len(seq_start_end)
+    if n == 0:
+        return (0,)
+    return (n, int(seq_start_end[0][0]), int(seq_start_end[-1][1]), sum(int(e) * (i + 1) for i, (_, e) in enumerate(seq_start_end)))
+
+
 def scene_tables(seq_start_end, b, device):
     key = (id(seq_start_end), b, str(device))
     hit = _TABLE_CACHE.get(key)
-    if hit is not None and hit[0] is seq_start_end:
+    fp = scene_fingerprint(seq_start_end)
+    if hit is not None and hit[0] is seq_start_end and hit[2] == fp:
         return hit[1]
     t = SceneTables(seq_start_end, b, device)
     if len(_TABLE_CACHE) > 64:
         _TABLE_CACHE.clear()
-    _TABLE_CACHE[key] = (seq_start_end, t)
+    _TABLE_CACHE[key] = (seq_start_end, t, fp)
     return t
 
 
@@ -830,9 +840,11 @@ _POOL_CACHE = {}
 def pool_tables(seq_start_end, device):
     key = (id(seq_start_end), len(seq_start_end), str(device))
     hit = _POOL_CACHE.get(key)
-    if hit is not None and hit.key is seq_start_end:
+    fp = scene_fingerprint(seq_start_end)
+    if hit is not None and hit.key is seq_start_end and hit.fp == fp:
         return hit
     t = PoolTables(seq_start_end, device)
+    t.fp = fp
     if len(_POOL_CACHE) > 64:
         _POOL_CACHE.clear()
     _POOL_CACHE[key] = t

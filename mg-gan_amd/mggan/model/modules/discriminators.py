@@ -116,11 +116,12 @@ class MultiDiscriminatorTrajectory(FlatModule):
         enc0 = torch.cat([in_enc.repeat(2, 1), pred_enc], dim=1)
         cache = self.__dict__.setdefault("_pair_scenes", {})
         hit = cache.get(id(seq_start_end))
-        if hit is None or hit[0] is not seq_start_end:
+        fp = HF.scene_fingerprint(seq_start_end)
+        if hit is None or hit[0] is not seq_start_end or hit[2] != fp:
             if len(cache) > 16:
                 cache.clear()
             hit = (seq_start_end, [[int(s), int(e)] for s, e in seq_start_end] +
-                   [[int(s) + b, int(e) + b] for s, e in seq_start_end])
+                   [[int(s) + b, int(e) + b] for s, e in seq_start_end], fp)
             cache[id(seq_start_end)] = hit
         soc = self.social(in_xy[-1:], in_dxdy[-1:], enc0, hit[1], xy_mod=b)
         HF.join_branch(scene)

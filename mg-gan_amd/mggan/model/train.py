@@ -455,7 +455,12 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
 
     def check_accuracy(self, loader, vis=False, prefix="", num_k=20, predict_strategy="sampling", debug=False, **kw):
         preds = self.get_predictions(loader, num_preds=num_k, strategy=predict_strategy)
-        gts, sse, off = [], [], 0
+        ds = getattr(loader, "dataset", None)
+        ds = getattr(ds, "ds", ds)  # DeviceCropDataset wraps the on-disk dataset
+        if ds is not None and hasattr(ds, "pred_traj") and hasattr(ds, "seq_start_end"):
+            # the reference's path (train.py:255-257): ground truth, scene bounds and pixel ratios from the dataset
+            return evaluate_ade_fde(ds, preds, [num_k])
+        gts, sse, off = [], [], 0  # datasets that yield ready-made batches (the built-in synthetic one)
         for batch in loader:
             gts.append(batch["gt_xy"].permute(1, 0, 2))
             sse += [(s + off, e + off) for s, e in batch["seq_start_end"]]
@@ -464,6 +469,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         class _DS:
             pred_traj = torch.cat(gts, 0)
             seq_start_end = sse
+            dataset_name = getattr(loader.dataset, "dataset_name", None)
 
         return evaluate_ade_fde(_DS, preds, [num_k])
 

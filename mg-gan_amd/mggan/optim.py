@@ -37,6 +37,7 @@ class FlatAdamW:
         from mggan.hip.functions import join_side_stream
 
         join_side_stream()  # weight-gradient GEMMs issued on the side stream must have landed
+        r.adopt_foreign_grads()  # gradients that arrived through plain torch autograd count as touched too
         mask = r.touched_mask()
         st = torch.cuda.current_stream().cuda_stream
         lib.mggan_clip_adamw(r._flat.data_ptr(), r._flat_grad.data_ptr(), self.exp_avg.data_ptr(),

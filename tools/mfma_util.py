@@ -4,9 +4,12 @@ GRBM_GUI_ACTIVE (tools/profile_round.sh):
 
     python tools/mfma_util.py <results.db> > profiles/mfma_util_<cfg>.json
 
-mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE)  -- the gfx94x `MfmaUtil` formula
-(ROCm 7.2 ships no gfx950 derived-counter section, MI355X_MICROARCH.md "rocprofv3 PMC slots"); busy cycles are
-summed over every SIMD of the chip, GRBM_GUI_ACTIVE is the chip-active cycle count of the (serialised) dispatch.
+mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 32 CUs x GRBM_GUI_ACTIVE)  -- the gfx94x `MfmaUtil` formula
+(ROCm 7.2 ships no gfx950 derived-counter section, MI355X_MICROARCH.md "rocprofv3 PMC slots") with the XCD
+aggregation made explicit: busy cycles are summed over every SIMD of the chip, and rocprofv3 reports GRBM_GUI_ACTIVE
+summed over the 8 XCDs (calibration: decoder_bwd_mfma_kernel at 256x32, g=8: 23.7e6 "active cycles" for a 1.20 ms
+dispatch = 8 x 2.47 GHz x 1.20 ms), so the per-SIMD time base is GRBM_GUI_ACTIVE / 8 and the chip has
+4 x 256 SIMDs: busy / (4 * 256 * GUI / 8).  SQ_VALU_MFMA_BUSY_CYCLES = 32 x SQ_INSTS_MFMA holds for every kernel here.
 One `v_mfma_f32_16x16x4_f32` keeps its SIMD's matrix pipe busy for 32 cycles = 2048 FLOP, i.e. 64 FLOP/clk/SIMD:
 mfma_util x 157.3 TFLOP/s is the f32 rate the MFMA pipe actually delivered."""
 import json
@@ -33,7 +36,7 @@ def main(db):
         if not busy or not act:
             continue
         out[k] = {"mfma_busy_cycles_per_launch": busy, "gui_active_cycles_per_launch": act,
-                  "mfma_util": round(busy / (4 * 256 * act), 5), "launches": e["launches"]}
+                  "mfma_util": round(busy / (4 * 32 * act), 5), "launches": e["launches"]}
         for extra in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"):
             if extra in e:
                 out[k][extra.lower() + "_per_launch"] = e[extra]
