@@ -248,6 +248,14 @@ int mggan_pm_target(int b, int T, int E, int g, int mode, const float* gen_abs, 
 int mggan_pm_mgan_loss(int b, int g, const float* logits, float target_weight, float reg, float scale, float* loss_rows,
                        float* dlogits, float* probs, mggan_stream_t stream);
 /* Categorical(logits=...).sample((K,)).T on the device (standard.py:217-225): inverse CDF from uniforms u (b,K) */
+/* ---- device RNG: every draw of one training iteration in ONE launch (csrc/rng.hip, Philox4x32-10) ---------
+ * reference draws being replaced on the `--rng device` path: utils.py:18-25 (label uniforms),
+ * utils.py:152-165 (one N(0,1)^Z vector per scene, repeated for its pedestrians), standard.py:217-225 (Categorical
+ * sampling, here: the uniforms of the inverse-CDF sampler).  state[0] = seed, state[1] = iteration counter (advanced
+ * by the kernel itself: a captured graph draws fresh numbers at every replay); ticket = one zeroed word.
+ * noise[set][ped][z], set < n_sets, is identical for the pedestrians of a scene (ped_scene[ped]). */
+int mggan_draw_iteration(long long* state, unsigned int* ticket, int n_labels, float* labels, int n_sets, int b, int Z,
+                         const int* ped_scene, float* noise, long n_unif, float* unif, mggan_stream_t stream);
 int mggan_sample_categorical(int b, int K, int g, const float* logits, const float* u, long long* idx,
                              mggan_stream_t stream);
 /* device-side replacement of get_selection_indices + gather bookkeeping (utils.py:234-248,
@@ -269,6 +277,18 @@ int mggan_d_assemble_fwd(int b, int K, int w_soc, int w_in, int w_pred, int w_sc
                          mggan_stream_t stream);
 int mggan_d_assemble_bwd(int b, int K, int w_soc, int w_in, int w_pred, int w_scene, int soc_all, const float* dX,
                          float* dsoc0, float* din_enc, float* dpred_enc, float* dscene, mggan_stream_t stream);
+/* The same classifier input without intermediate copies (csrc/drows.hip): X (K*b, ldx) is written in place by its
+ * producers (pred_encoder chain -> columns of pred_enc, social attention -> columns of soc); d_rows_fill broadcasts
+ * in_enc / scene of pedestrian `ped` into rows k*b+ped and clears the soc columns [0, w_soc) of sample blocks
+ * k >= soc_blocks (blocks without social features); d_rows_reduce is the adjoint of the broadcast
+ * (sum over k, fixed order; a NULL destination is skipped).  Widths / offsets / strides: multiples of 4 floats. */
+int mggan_d_rows_fill(int b, int K, int soc_blocks, int w_soc, int c_in, int w_in, int c_scene, int w_scene,
+                      const float* in_enc, int ld_in, const float* scene, int ld_scene, float* X, int ldx,
+                      mggan_stream_t stream);
+int mggan_d_rows_reduce(int b, int K, int c_in, int w_in, int c_scene, int w_scene, const float* dX, int ldx, float* din,
+                        int ld_in, float* dscene, int ld_scene, mggan_stream_t stream);
+/* adjoint of mggan_steps_to_rows: rows (n, 2T) with row stride ld -> time-major (T, n, 2) */
+int mggan_rows_to_steps(const float* rows, int ld, int T, int n, float* out, mggan_stream_t stream);
 /* Time-major steps -> one row per trajectory: out[r][2t+c] = a[t][r][c] for r < n, and (b != NULL) out[n+r][2t+c] =
  * b[t][r][c] -- the input of the discriminator's pred_encoder (discriminators.py:129-131 permute + reshape; the real and
  * the fake trajectories of a pair pass in one launch) */

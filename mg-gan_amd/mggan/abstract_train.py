@@ -85,8 +85,10 @@ class MultiGeneratorGAN(abc.ABC):
             gt_dxdy, gt_xy = gt_dxdy[:, loss_mask], gt_xy[:, loss_mask]
         img = batch["features"] if "features" in batch else None
         args = (in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, metrics, loss_mask, img)
-        if hasattr(self.rng, "begin_iteration"):
-            self.rng.begin_iteration()
+        if hasattr(self.rng, "begin_iteration"):  # device RNG: ONE launch draws every random number of the iteration
+            self.rng.plan = (1, self.config.num_samples, self.config.num_expectation_samples)
+            self.rng.d_steps = self.config.num_unrolling_steps + 1
+            self.rng.begin_iteration(sub_batches, b, self.config.noise_dim, self.device)
         cfg = self.config
         run_d = self.total_iterations % max(int(cfg.num_gen_steps), 1) == 0 or self.epoch >= cfg.keep_gen_steps
         shared = None
@@ -99,11 +101,17 @@ class MultiGeneratorGAN(abc.ABC):
         # `self.D.state_dict()` -- references to the live parameters, not copies -- so its load_state_dict(backup)
         # after the generator / PM steps (:163-164) copies every tensor onto itself: the discriminator KEEPS all
         # unrolled updates.  That literal behaviour is what runs here (nothing to restore).
-        if run_d:
-            for _ in range(cfg.num_unrolling_steps + 1):
-                self.discriminator_step(*args, shared=shared)
-        self.generator_step(*args, shared=shared)
-        self.net_chooser_step(*args)
+        if hasattr(self, "_open_iteration"):
+            self._open_iteration()
+        try:
+            if run_d:
+                for _ in range(cfg.num_unrolling_steps + 1):
+                    self.discriminator_step(*args, shared=shared)
+            self.generator_step(*args, shared=shared)
+            self.net_chooser_step(*args)
+        finally:
+            if hasattr(self, "_close_iteration"):
+                self._close_iteration()
         self.total_iterations += 1
 
     def capture_iteration(self, batch, warmup=3):
@@ -172,8 +180,12 @@ class MultiGeneratorGAN(abc.ABC):
             if dot:
                 graph.enable_debug_mode()
             # (thread_local: RCCL's watchdog thread may query events while this thread captures)
-            with torch.cuda.graph(graph, capture_error_mode="thread_local" if in_graph else "global"):
-                self.train_iteration(batch, captured)
+            self._static_metrics = True
+            try:
+                with torch.cuda.graph(graph, capture_error_mode="thread_local" if in_graph else "global"):
+                    self.train_iteration(batch, captured)
+            finally:
+                self._static_metrics = False
             if dot:
                 graph.debug_dump(dot)
             run = graph.replay

@@ -387,30 +387,37 @@ class _McArgs(ctypes.Structure):
 MLP_MAX_WIDTH = 192
 
 
-def _chain_fwd(x, ldx, rows, spec, Ws, bs, save):
-    """One launch: act_n(... act_1(x W_1^T + b_1) ...) -> per-layer outputs (hidden ones only when `save`)."""
+def _chain_fwd(x, ldx, rows, spec, Ws, bs, save, out_into=None):
+    """One launch: act_n(... act_1(x W_1^T + b_1) ...) -> per-layer outputs (hidden ones only when `save`).
+    x: tensor or raw device pointer.  out_into = (tensor view, row stride): where the LAST layer's output goes
+    (a column block of a wider buffer) instead of a fresh tensor."""
     n = len(spec)
     K0 = Ws[0].shape[1]
     a = _McArgs()
-    a.X, a.ldx, a.rows, a.K0, a.n = _p(x), ldx, rows, K0, n
+    a.X, a.ldx, a.rows, a.K0, a.n = (_p(x) if torch.is_tensor(x) else x), ldx, rows, K0, n
     outs = []
     for i, ((act, slope), W, b) in enumerate(zip(spec, Ws, bs)):
         N, K = W.shape
         keep = i == n - 1 or save  # hidden activations only leave the chip when a backward pass needs them
-        y = _empty(rows, N, like=x) if keep else None
+        ld_y = N
+        if i == n - 1 and out_into is not None:
+            y, ld_y = out_into
+        else:
+            y = _empty(rows, N, like=W) if keep else None
         outs.append(y)
         st = a.s[i]
         st.W, st.bias, st.out = _p(W), _p(b), _p(y)
-        st.K, st.N, st.ldw, st.trans, st.act, st.slope, st.ld_out = K, N, K, 0, act, float(slope), N
+        st.K, st.N, st.ldw, st.trans, st.act, st.slope, st.ld_out = K, N, K, 0, act, float(slope), ld_y
     if _load_lib().trace is not None:
         TRACE_NOTES["mlp_chain_flops"].append(2.0 * rows * sum(W.shape[0] * W.shape[1] for W in Ws))
     lib.mggan_mlp_chain(ctypes.addressof(a), _s())
     return outs
 
 
-def _chain_bwd(dy, lddy, x, ldx, rows, outs, spec, Ws, bs, need_dx, train_w, owner, dx_into=None):
+def _chain_bwd(dy, lddy, x, ldx, rows, outs, spec, Ws, bs, need_dx, train_w, owner, dx_into=None, ld_last=None):
     """Adjoint of _chain_fwd in one launch (+ the weight-gradient GEMMs, queued or on the side stream).
-    dx_into = (pointer, row stride, accumulate): where the input gradient goes (default: a fresh tensor)."""
+    dx_into = (pointer, row stride, accumulate): where the input gradient goes (default: a fresh tensor);
+    ld_last: row stride of outs[-1] when it is a column block of a wider buffer."""
     n = len(spec)
     # gate gradients dz_l (l = n-1 .. 0): dz_{n-1} = dy * act'(y); dz_{l-1} = (dz_l W_l) * act'(h_{l-1})
     a = _McArgs()
@@ -418,9 +425,10 @@ def _chain_bwd(dy, lddy, x, ldx, rows, outs, spec, Ws, bs, need_dx, train_w, own
     dz = [None] * n
     act_last = spec[-1][0]
     if act_last != ACT_NONE:
-        a.in_mul, a.ld_in_mul, a.in_mul_act, a.in_mul_slope = _p(outs[-1]), outs[-1].shape[1], act_last, float(spec[-1][1])
+        a.in_mul, a.ld_in_mul, a.in_mul_act, a.in_mul_slope = (_p(outs[-1]), ld_last or outs[-1].shape[1], act_last,
+                                                               float(spec[-1][1]))
         if train_w:
-            dz[-1] = _empty(rows, Ws[-1].shape[0], like=x)
+            dz[-1] = _empty(rows, Ws[-1].shape[0], like=Ws[-1])
             a.in_store, a.ld_in_store = _p(dz[-1]), Ws[-1].shape[0]
     elif train_w:
         dz[-1] = dy
@@ -435,12 +443,12 @@ def _chain_bwd(dy, lddy, x, ldx, rows, outs, spec, Ws, bs, need_dx, train_w, own
         if l > 0:
             st.mul_src, st.ld_mul, st.mul_act, st.mul_slope = _p(outs[l - 1]), K, spec[l - 1][0], float(spec[l - 1][1])
             if train_w:
-                dz[l - 1] = _empty(rows, K, like=x)
+                dz[l - 1] = _empty(rows, K, like=Ws[l])
                 st.out, st.ld_out = _p(dz[l - 1]), K
         elif dx_into is not None:
             st.out, st.ld_out, st.accumulate = dx_into[0], dx_into[1], int(dx_into[2])
         else:
-            dx = _empty(rows, K, like=x)
+            dx = _empty(rows, K, like=Ws[l])
             st.out, st.ld_out = _p(dx), K
         k += 1
     a.n = k
@@ -556,8 +564,9 @@ def mlp(x, layers, owner=None):
 
 def steps_to_rows(a, b=None):
     """(T, n, 2) time-major steps [and a second set] -> (n [+ n], 2T) rows, one launch; inputs carry no gradient."""
-    T, n = a.shape[0], a.shape[-2]
-    a = a.reshape(T, n, 2).contiguous()
+    T = a.shape[0]
+    a = a.reshape(T, -1, 2).contiguous()
+    n = a.shape[1]
     out = _empty(2 * n if b is not None else n, 2 * T, like=a)
     lib.mggan_steps_to_rows(_p(a), _p(b.reshape(T, n, 2).contiguous()) if b is not None else 0, T, n, _p(out), _s())
     return out
@@ -580,7 +589,7 @@ class LstmEncoderFn(Function):
     """Linear(2,E) + nn.LSTM over T steps -> h_T   (common_modules.py:48-66)."""
 
     @staticmethod
-    def forward(ctx, x, emb_w, emb_b, w_ih, w_hh, b_ih, b_hh, owner, save):
+    def forward(ctx, x, emb_w, emb_b, w_ih, w_hh, b_ih, b_hh, owner, save, out=None):
         T, b, _ = x.shape
         H, E = w_hh.shape[1], emb_w.shape[0]
         x = x.contiguous()
@@ -592,8 +601,8 @@ class LstmEncoderFn(Function):
         Cs = _empty(b, T, H, like=x) if save else None
         Hp = _empty(b, T, H, like=x) if save else None
         Din = _empty(b, T, 2, like=x) if save else None
-        hout = _empty(b, H, like=x)
-        lib.mggan_lstm_encoder_fwd(_p(x), T, b, H, _p(prep), _p(hout), H, _p(Gt), _p(Cs), _p(Hp), _p(Din), _s())
+        hout, ld_out = _out(out, b, H, x)
+        lib.mggan_lstm_encoder_fwd(_p(x), T, b, H, _p(prep), _p(hout), ld_out, _p(Gt), _p(Cs), _p(Hp), _p(Din), _s())
         if save:
             ctx.dims, ctx.owner = (T, b, H, E), owner
             ctx.save_for_backward(emb_w, emb_b, w_ih, w_hh, b_ih, b_hh, prep, Gt, Cs, Hp, Din)
@@ -622,7 +631,7 @@ class LstmEncoderFn(Function):
                 _DEFER["keep"].append(dprep)
             else:
                 unfold()
-        return (None,) * 9
+        return (None,) * 10
 
 
 # ------------------------------------------------------------------------------------------
@@ -702,6 +711,126 @@ def scene_tables(seq_start_end, b, device):
     return t
 
 
+def alias_cols(buf, c0, c1):
+    """Columns [c0, c1) of a 2-d buffer as a tensor that SHARES the storage without being an autograd view of it
+    (Tensor.set_ on the storage: metadata only, no kernel).  A real view would tie the version counters together and
+    autograd refuses custom-Function outputs whose base is written again -- here several stages fill disjoint
+    column blocks of one buffer."""
+    return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(buf.untyped_storage(), buf.storage_offset() + c0 * buf.stride(1),
+                                                                   (buf.shape[0], c1 - c0), (buf.stride(0), buf.stride(1)))
+
+
+class OutSlot:
+    """Where a stage should leave its (rows, c1-c0) result: a column block of a wider preallocated buffer.  It is
+    handed to the autograd Functions as a plain Python object (not a tensor input): the Function creates the view inside
+    its forward and returns it as its output, so no torch.cat is needed to assemble [lstm | scene | social] and friends."""
+
+    def __init__(self, buf, c0, c1):
+        assert buf.dim() == 2 and buf.stride(1) == 1 and 0 <= c0 < c1 <= buf.shape[1]
+        self.buf, self.c0, self.c1 = buf, c0, c1
+
+    def view(self):
+        return alias_cols(self.buf, self.c0, self.c1)
+
+    @property
+    def ld(self):
+        return self.buf.stride(0)
+
+
+def _out(slot, rows, cols, like):
+    """-> (tensor to return, row stride) for a stage output: the slot's view or a fresh tensor."""
+    if slot is None:
+        return _empty(rows, cols, like=like), cols
+    v = slot.view()
+    assert tuple(v.shape) == (rows, cols), (tuple(v.shape), rows, cols)
+    return v, slot.ld
+
+
+def _social_fwd(xy_last, dxdy_last, h_ptr, ld_h, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat, S_ptr, ld_s, save, xy_mod,
+                like):
+    """SocialFeatures -> EmbedSocialFeatures -> AttentionPooling for rows [0,b) of a hidden-state matrix given by pointer
+    + row stride; S (b,Hh) is written through S_ptr / ld_s.  -> tuple of saved tensors for _social_bwd."""
+    Fd = wat.shape[0]
+    st = _s()
+    W3b = _empty(Fd, 65, like=like)
+    lib.mggan_social_w3b(_p(w3), _p(b3), _p(W3b), Fd, st)
+    # Wh = h W_at^T + b_at and vc = Wh [W3 | b3] as one two-stage chain launch
+    Wh, vc = _empty(b, Fd, like=like), _empty(b, 65, like=like)
+    a = _McArgs()
+    a.X, a.ldx, a.rows, a.K0, a.n = h_ptr, ld_h, b, Hh, 2
+    s0, s1 = a.s[0], a.s[1]
+    s0.W, s0.bias, s0.out, s0.K, s0.N, s0.ldw, s0.trans, s0.act, s0.ld_out = _p(wat), _p(bat), _p(Wh), Hh, Fd, Hh, 0, ACT_NONE, Fd
+    s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out = _p(W3b), _p(vc), Fd, 65, 65, 1, ACT_NONE, 65
+    if _load_lib().trace is not None:
+        TRACE_NOTES["mlp_chain_flops"].append(2.0 * b * (Hh * Fd + Fd * 65))
+    lib.mggan_mlp_chain(ctypes.addressof(a), st)
+    P = tb.P
+    feat = _empty(3, max(P, 1), like=like) if save else None      # feature-major [feature][pair]
+    l1 = _empty(32, max(P, 1), like=like) if save else None
+    l2 = _empty(64, max(P, 1), like=like) if save else None
+    att = _empty(max(P, 1), like=like)
+    if tb.tiles is not None:  # pair MLP, scores, softmax and pooling in one launch
+        lib.mggan_social_attention_fwd(tb.n_tiles, _p(tb.tiles), P, Hh, _p(tb.pair_i), _p(tb.pair_j),
+                                       _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(xy_last), _p(dxdy_last),
+                                       _p(w1), _p(b1), _p(w2), _p(b2), _p(vc), h_ptr, ld_h, _p(feat), _p(l1), _p(l2),
+                                       _p(att), S_ptr, ld_s, int(xy_mod), st)
+    else:  # a scene of more than 64 pedestrians does not fit a tile
+        if xy_mod:
+            rep_n = b // xy_mod
+            xy_last, dxdy_last = xy_last.repeat(rep_n, 1), dxdy_last.repeat(rep_n, 1)
+        sigma = _empty(max(P, 1), like=like)
+        lib.mggan_social_pairs_fwd(P, _p(tb.pair_i), _p(tb.pair_j), _p(xy_last), _p(dxdy_last), _p(w1), _p(b1),
+                                   _p(w2), _p(b2), _p(vc), _p(feat), _p(l1), _p(l2), _p(sigma), st)
+        lib.mggan_social_softmax_fwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(sigma), h_ptr, ld_h,
+                                     _p(att), S_ptr, ld_s, st)
+    return (W3b, Wh, vc, feat, l1, l2, att)
+
+
+def _social_bwd(saved, h_ptr, ld_h, h_keep, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat, dS_ptr, ld_ds, dh_ptr, ld_dh,
+                accumulate_dh, train_w1, train_w3, owner, like):
+    """Adjoint of _social_fwd.  dh (b,Hh) goes to dh_ptr / ld_dh (accumulate_dh: added to what is there); the weight
+    gradients are queued / launched like everywhere else.  h_keep: the tensor that owns h (kept alive)."""
+    W3b, Wh, vc, feat, l1, l2, att = saved
+    root = root_of(owner)
+    Fd, P = wat.shape[0], tb.P
+    st = _s()
+    dsigma = _empty(max(P, 1), like=like)
+    dz2 = _empty(64, max(P, 1), like=like)
+    dz1 = _empty(32, max(P, 1), like=like)
+    dvc = _empty(b, 65, like=like)
+    if tb.tiles is not None:
+        lib.mggan_social_attention_bwd(tb.n_tiles, _p(tb.tiles), P, b, Hh, _p(tb.pair_i), _p(tb.pair_j),
+                                       _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(att), h_ptr, ld_h, dS_ptr,
+                                       ld_ds, _p(vc), _p(l1), _p(l2), _p(w2), _p(dsigma), _p(dz2), _p(dz1), _p(dvc),
+                                       dh_ptr, ld_dh, int(accumulate_dh), st)
+    else:
+        lib.mggan_social_softmax_bwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(att), h_ptr, ld_h,
+                                     dS_ptr, ld_ds, _p(dsigma), dh_ptr, ld_dh, int(accumulate_dh), st)
+        lib.mggan_social_pairs_bwd(P, b, _p(tb.pair_j), _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(dsigma),
+                                   _p(vc), _p(l1), _p(l2), _p(w2), _p(dz2), _p(dz1), _p(dvc), st)
+    if train_w1:
+        with side_stream(dz2, dz1, l1, feat):
+            wgrad(dz2, P, l1, P, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64, fm=1)
+            wgrad(dz1, P, feat, P, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32, fm=1)
+    # dWh = dvc [W3|b3]^T and dh += dWh W_at as one two-stage chain launch; d[W3|b3] = Wh^T dvc
+    dWh = _empty(b, Fd, like=like)
+    a = _McArgs()
+    a.X, a.ldx, a.rows, a.K0, a.n = _p(dvc), 65, b, 65, 2
+    s0, s1 = a.s[0], a.s[1]
+    s0.W, s0.out, s0.K, s0.N, s0.ldw, s0.trans, s0.act, s0.ld_out = _p(W3b), _p(dWh), 65, Fd, 65, 0, ACT_NONE, Fd
+    s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out, s1.accumulate = _p(wat), dh_ptr, Fd, Hh, Hh, 1, ACT_NONE, ld_dh, 1
+    if _load_lib().trace is not None:
+        TRACE_NOTES["mlp_chain_flops"].append(2.0 * b * (65 * Fd + Fd * Hh))
+    lib.mggan_mlp_chain(ctypes.addressof(a), st)
+    if train_w3:
+        with side_stream(Wh, dvc, dWh, h_keep):
+            wgrad(Wh, Fd, dvc, 65, root.grad_ptr(w3), 64, 0, b, 64, Fd)
+            wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, 65, root.grad_ptr(b3), 1, 0, b, 1, Fd)
+            wgrad(dWh, Fd, h_ptr, ld_h, root.grad_ptr(wat), Hh, root.grad_ptr(bat), b, Hh, Fd)
+        if _DEFER["on"]:
+            _DEFER["keep"].append(h_keep)
+
+
 class SocialAttentionFn(Function):
     """SocialFeatures -> EmbedSocialFeatures -> AttentionPooling over in-scene pairs (social.py:7-123)."""
 
@@ -709,91 +838,97 @@ class SocialAttentionFn(Function):
     def forward(ctx, xy_last, dxdy_last, h, tb, w1, b1, w2, b2, w3, b3, wat, bat, owner, save, xy_mod=0):
         h, ld_h = _rows2d(h)
         b, Hh = h.shape
-        Fd = wat.shape[0]
         xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
-        st = _s()
-        W3b = _empty(Fd, 65, like=h)
-        lib.mggan_social_w3b(_p(w3), _p(b3), _p(W3b), Fd, st)
-        # Wh = h W_at^T + b_at and vc = Wh [W3 | b3] as one two-stage chain launch
-        Wh, vc = _empty(b, Fd, like=h), _empty(b, 65, like=h)
-        a = _McArgs()
-        a.X, a.ldx, a.rows, a.K0, a.n = _p(h), ld_h, b, Hh, 2
-        s0, s1 = a.s[0], a.s[1]
-        s0.W, s0.bias, s0.out, s0.K, s0.N, s0.ldw, s0.trans, s0.act, s0.ld_out = _p(wat), _p(bat), _p(Wh), Hh, Fd, Hh, 0, ACT_NONE, Fd
-        s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out = _p(W3b), _p(vc), Fd, 65, 65, 1, ACT_NONE, 65
-        if _load_lib().trace is not None:
-            TRACE_NOTES["mlp_chain_flops"].append(2.0 * b * (Hh * Fd + Fd * 65))
-        lib.mggan_mlp_chain(ctypes.addressof(a), st)
-        P = tb.P
-        feat = _empty(3, max(P, 1), like=h) if save else None      # feature-major [feature][pair]
-        l1 = _empty(32, max(P, 1), like=h) if save else None
-        l2 = _empty(64, max(P, 1), like=h) if save else None
-        att = _empty(max(P, 1), like=h)
         S = _empty(b, Hh, like=h)
-        if tb.tiles is not None:  # pair MLP, scores, softmax and pooling in one launch
-            lib.mggan_social_attention_fwd(tb.n_tiles, _p(tb.tiles), P, Hh, _p(tb.pair_i), _p(tb.pair_j),
-                                           _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(xy_last), _p(dxdy_last),
-                                           _p(w1), _p(b1), _p(w2), _p(b2), _p(vc), _p(h), ld_h, _p(feat), _p(l1), _p(l2),
-                                           _p(att), _p(S), Hh, int(xy_mod), st)
-        else:  # a scene of more than 64 pedestrians does not fit a tile
-            if xy_mod:
-                rep_n = b // xy_mod
-                xy_last, dxdy_last = xy_last.repeat(rep_n, 1), dxdy_last.repeat(rep_n, 1)
-            sigma = _empty(max(P, 1), like=h)
-            lib.mggan_social_pairs_fwd(P, _p(tb.pair_i), _p(tb.pair_j), _p(xy_last), _p(dxdy_last), _p(w1), _p(b1),
-                                       _p(w2), _p(b2), _p(vc), _p(feat), _p(l1), _p(l2), _p(sigma), st)
-            lib.mggan_social_softmax_fwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(sigma), _p(h), ld_h,
-                                         _p(att), _p(S), Hh, st)
+        saved = _social_fwd(xy_last, dxdy_last, _p(h), ld_h, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat, _p(S), Hh, save,
+                            xy_mod, h)
         if save:
             ctx.tb, ctx.owner, ctx.ld_h = tb, owner, ld_h
             ctx.train_w1, ctx.train_w3 = w1.requires_grad, w3.requires_grad
-            ctx.save_for_backward(h, w2, wat, W3b, Wh, vc, feat, l1, l2, att, w1, b1, b2, w3, b3, bat)
+            ctx.save_for_backward(h, w1, b1, w2, b2, w3, b3, wat, bat, *saved)
         return S
 
     @staticmethod
     def backward(ctx, dS):
-        h, w2, wat, W3b, Wh, vc, feat, l1, l2, att, w1, b1, b2, w3, b3, bat = ctx.saved_tensors
+        h, w1, b1, w2, b2, w3, b3, wat, bat = ctx.saved_tensors[:9]
+        saved = ctx.saved_tensors[9:]
         tb, ld_h = ctx.tb, ctx.ld_h
-        root = root_of(ctx.owner)
         b, Hh = h.shape
-        Fd, P = wat.shape[0], tb.P
-        st = _s()
         dS, ld_ds = _rows2d(dS)
-        dsigma = _empty(max(P, 1), like=h)
         dh = _empty(b, Hh, like=h)
-        dz2 = _empty(64, max(P, 1), like=h)
-        dz1 = _empty(32, max(P, 1), like=h)
-        dvc = _empty(b, 65, like=h)
-        if tb.tiles is not None:
-            lib.mggan_social_attention_bwd(tb.n_tiles, _p(tb.tiles), P, b, Hh, _p(tb.pair_i), _p(tb.pair_j),
-                                           _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(att), _p(h), ld_h, _p(dS),
-                                           ld_ds, _p(vc), _p(l1), _p(l2), _p(w2), _p(dsigma), _p(dz2), _p(dz1), _p(dvc),
-                                           _p(dh), Hh, 0, st)
-        else:
-            lib.mggan_social_softmax_bwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(att), _p(h), ld_h,
-                                         _p(dS), ld_ds, _p(dsigma), _p(dh), Hh, 0, st)
-            lib.mggan_social_pairs_bwd(P, b, _p(tb.pair_j), _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(dsigma),
-                                       _p(vc), _p(l1), _p(l2), _p(w2), _p(dz2), _p(dz1), _p(dvc), st)
-        if ctx.train_w1:
-            with side_stream(dz2, dz1, l1, feat):
-                wgrad(dz2, P, l1, P, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64, fm=1)
-                wgrad(dz1, P, feat, P, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32, fm=1)
-        # dWh = dvc [W3|b3]^T and dh += dWh W_at as one two-stage chain launch; d[W3|b3] = Wh^T dvc
-        dWh = _empty(b, Fd, like=h)
-        a = _McArgs()
-        a.X, a.ldx, a.rows, a.K0, a.n = _p(dvc), 65, b, 65, 2
-        s0, s1 = a.s[0], a.s[1]
-        s0.W, s0.out, s0.K, s0.N, s0.ldw, s0.trans, s0.act, s0.ld_out = _p(W3b), _p(dWh), 65, Fd, 65, 0, ACT_NONE, Fd
-        s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out, s1.accumulate = _p(wat), _p(dh), Fd, Hh, Hh, 1, ACT_NONE, Hh, 1
-        if _load_lib().trace is not None:
-            TRACE_NOTES["mlp_chain_flops"].append(2.0 * b * (65 * Fd + Fd * Hh))
-        lib.mggan_mlp_chain(ctypes.addressof(a), st)
-        if ctx.train_w3:
-            with side_stream(Wh, dvc, dWh, h):
-                wgrad(Wh, Fd, dvc, 65, root.grad_ptr(w3), 64, 0, b, 64, Fd)
-                wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, 65, root.grad_ptr(b3), 1, 0, b, 1, Fd)
-                wgrad(dWh, Fd, h, ld_h, root.grad_ptr(wat), Hh, root.grad_ptr(bat), b, Hh, Fd)
+        _social_bwd(saved, _p(h), ld_h, h, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat, _p(dS), ld_ds, _p(dh), Hh, 0,
+                    ctx.train_w1, ctx.train_w3, ctx.owner, h)
         return (None, None, dh if ctx.needs_input_grad[2] else None) + (None,) * 12
+
+
+class TrunkJoinFn(Function):
+    """The generator trunk's last stage (standard.py:144-155): social attention over the encoder state, and
+    enc_h = [lstm | scene | social] WITHOUT a concatenation: `enc` (and, through SceneTapFn below, `scene`) already sit
+    in their column blocks of the (b, 128) buffer (their producers were handed OutSlots), the social features are
+    written into the third block.  The gradient w.r.t. the encoder state (its column block of d enc_h plus the
+    attention's dh) is formed in place: no gradient add, no slice copies.
+    -> (enc_h (b,128), social (b,32) = its last column block)."""
+
+    @staticmethod
+    def forward(ctx, enc, xy_last, dxdy_last, tb, buf, w1, b1, w2, b2, w3, b3, wat, bat, owner, save, Sc):
+        b, W = buf.shape
+        Hh = enc.shape[1]
+        Fd = wat.shape[0]
+        assert W == Hh + Sc + Fd and buf.stride(1) == 1
+        base = buf.data_ptr()
+        if enc.data_ptr() != base or (b > 1 and enc.stride(0) != W):   # producer did not use its slot: copy in
+            alias_cols(buf, 0, Hh).copy_(enc)
+        xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
+        saved = _social_fwd(xy_last, dxdy_last, base, W, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat,
+                            base + 4 * (Hh + Sc), W, save, 0, buf)
+        if save:
+            ctx.tb, ctx.owner, ctx.dims = tb, owner, (b, W, Hh, Sc, Fd)
+            ctx.train_w1, ctx.train_w3 = w1.requires_grad, w3.requires_grad
+            ctx.save_for_backward(buf, w1, b1, w2, b2, w3, b3, wat, bat, *saved)
+        ctx.set_materialize_grads(False)
+        return alias_cols(buf, 0, W), alias_cols(buf, Hh + Sc, W)
+
+    @staticmethod
+    def backward(ctx, d_enc_h, d_soc):
+        buf, w1, b1, w2, b2, w3, b3, wat, bat = ctx.saved_tensors[:9]
+        saved = ctx.saved_tensors[9:]
+        b, W, Hh, Sc, Fd = ctx.dims
+        if d_enc_h is None:
+            d_enc_h = torch.zeros(b, W, dtype=F32, device=buf.device)
+        elif d_enc_h.stride(1) != 1 or (b > 1 and d_enc_h.stride(0) != W) or d_enc_h.data_ptr() % 16:
+            d_enc_h = d_enc_h.contiguous()
+        if d_soc is not None:  # a consumer of the separate `social` output that did not fold its gradient into d enc_h
+            d_enc_h = d_enc_h.clone()
+            d_enc_h[:, Hh + Sc:] += d_soc
+        g = d_enc_h.data_ptr()
+        # dS = d_enc_h[:, social block]; dh is ADDED to d_enc_h[:, lstm block] in place (this node is the only reader)
+        _social_bwd(saved, buf.data_ptr(), W, buf, b, Hh, ctx.tb, w1, b1, w2, b2, w3, b3, wat, bat, g + 4 * (Hh + Sc), W,
+                    g, W, 1, ctx.train_w1, ctx.train_w3, ctx.owner, buf)
+        return (d_enc_h[:, :Hh],) + (None,) * 15
+
+
+class ColsTapFn(Function):
+    """`part` already sits in columns [c0, c1) of `whole` (its producer wrote there through an OutSlot): declare that
+    to autograd.  Forward: nothing to compute (copies `part` in only if the producer did not use the slot).  Backward:
+    the gradient of `part` is that column block of d whole -- available at once, BEFORE the adjoint of whatever
+    produced the rest of `whole` runs, so that a long branch (the scene CNN's adjoint) starts as early as with
+    torch.cat's slice backward, without its copies."""
+
+    @staticmethod
+    def forward(ctx, whole, part, c0, c1):
+        base = whole.data_ptr() + 4 * c0 * whole.stride(1)
+        if part.data_ptr() != base or (whole.shape[0] > 1 and part.stride(0) != whole.stride(0)):
+            alias_cols(whole, c0, c1).copy_(part)
+        ctx.cols = (c0, c1)
+        ctx.set_materialize_grads(False)
+        return alias_cols(whole, 0, whole.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
+        c0, c1 = ctx.cols
+        return g, g[:, c0:c1], None, None
 
 
 # ------------------------------------------------------------------------------------------
@@ -902,7 +1037,7 @@ class SceneAttentionFn(Function):
 
     @staticmethod
     def forward(ctx, img, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb, bb, bn1, bn2, training, owner, sync, save,
-                stat_updates=1):
+                stat_updates=1, out_slot=None):
         img = img.contiguous()
         B, C = img.shape[0], c1w.shape[0]
         st = _s()
@@ -937,8 +1072,8 @@ class SceneAttentionFn(Function):
         y2 = _empty(B, C, 16, 16, like=img)
         lib.mggan_conv2_fwd(_p(y1), B, C, _p(sc1), _p(sh1), _p(c2w), _p(c2b), _p(y2), _p(part), st)
         sc2, sh2, stat2, cnt2 = finalize(bn2, g2, be2, 16 * 16)
-        out = _empty(B, 64, like=img)
-        lib.mggan_scene_attention_fwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(wa), _p(ba), _p(wb), _p(bb), _p(out), 64, st)
+        out, ld_o = _out(out_slot, B, 64, img)
+        lib.mggan_scene_attention_fwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(wa), _p(ba), _p(wb), _p(bb), _p(out), ld_o, st)
         if save:
             if not training:
                 raise RuntimeError("scene attention backward is only implemented for train-mode BatchNorm "
@@ -1009,7 +1144,7 @@ class SceneAttentionFn(Function):
             wl = 4 * C * 9 + C
             _queue_reduce(ws.data_ptr(), pw, 0, 1, 4 * C * 9, 0, 4 * C * 9, grid, 1, wl, keep=(ws,))
             _queue_reduce(ws.data_ptr() + 4 * 4 * C * 9, pb, 0, 1, C, 0, C, grid, 1, wl)
-        return (None,) * 20
+        return (None,) * 21
 
 
 # ------------------------------------------------------------------------------------------
@@ -1096,6 +1231,9 @@ class DecoderRolloutFn(Function):
                                       _p(Cs), _p(Hp), _p(Din), _p(Aact), _p(E2Din), _p(SocR), st)
         if save:
             ctx.meta = (rows, g0, n_gens, stride, T, owner, (b, EIN, Z, H, E, S, psz))
+            # `soc` is the last column block of `enc_h` itself (TrunkJoinFn hands out both): its gradient is folded into
+            # d enc_h by the gather below instead of travelling as a second tensor that autograd would have to add
+            ctx.soc_in_enc = (b > 0 and soc.data_ptr() == enc_h.data_ptr() + 4 * (EIN - S) and ld_soc == ld_enc)
             ctx.save_for_backward(e2d_w, e2d_b, prep, Gt, Cs, Hp, Din, Aact, E2Din, SocR)
         return out_abs, out_rel
 
@@ -1164,8 +1302,11 @@ class DecoderRolloutFn(Function):
             d_enc = mk(b, EIN)
             lib.mggan_gather_sum(_p(dEnc), EIN, _p(rows.inv), _p(d_enc), EIN, b, rows.K, EIN, 0, st)
         if ctx.needs_input_grad[1]:
-            d_soc = mk(b, S)
-            lib.mggan_gather_sum(_p(dSocR), S, _p(rows.inv), _p(d_soc), S, b, rows.K, S, 0, st)
+            if ctx.soc_in_enc and d_enc is not None:
+                lib.mggan_gather_sum(_p(dSocR), S, _p(rows.inv), d_enc.data_ptr() + 4 * (EIN - S), EIN, b, rows.K, S, 1, st)
+            else:
+                d_soc = mk(b, S)
+                lib.mggan_gather_sum(_p(dSocR), S, _p(rows.inv), _p(d_soc), S, b, rows.K, S, 0, st)
         return (d_enc, d_soc) + (None,) * 13
 
 
@@ -1200,6 +1341,180 @@ class DAssembleFn(Function):
         lib.mggan_d_assemble_bwd(b, K, ws, wi, wp, wc, soc_all, _p(dX), _p(dsoc), _p(din), _p(dpred), _p(dsc),
                                  _s())
         return dsoc, din, dpred, dsc, None, None
+
+
+class StepsToRowsFn(Function):
+    """(T, n, 2) time-major steps -> (n, 2T) rows and back (discriminators.py:129-131 permute + reshape), one launch
+    per direction."""
+
+    @staticmethod
+    def forward(ctx, a):
+        T, n = a.shape[0], a.shape[-2] * (a.shape[1] if a.dim() == 4 else 1)
+        ctx.shape = a.shape
+        return steps_to_rows(a.reshape(T, n, 2))
+
+    @staticmethod
+    def backward(ctx, g):
+        g, ld = _rows2d(g)
+        n, T = g.shape[0], g.shape[1] // 2
+        out = _empty(T, n, 2, like=g)
+        lib.mggan_rows_to_steps(_p(g), ld, T, n, _p(out), _s())
+        return out.view(ctx.shape)
+
+
+def _d_dims(D, in_w, scene_w):
+    pe, Wat = D.pred_encoder, D.social.attention.W
+    Hs, w_pe = Wat.weight.shape[0], pe[2].weight.shape[0]
+    assert Hs == in_w + w_pe == Wat.weight.shape[1], "social width must equal h_dim (discriminators.py:58-60)"
+    return Hs, in_w, w_pe, scene_w
+
+
+class DRowsBodyFn(Function):
+    """First node of the discriminator's pass over K*b (pedestrian, sample) rows (discriminators.py:113-196, pool_type
+    'sways', unmasked): pred_encoder -> X = [soc | in_enc | pred_enc | (scene)] -> social attention over the sample
+    blocks that have social features.  X is a single (K*b, 192) buffer every producer writes into in place (column
+    offset + row stride): no torch.cat / .repeat / slice copies, no gradient adds between autograd nodes.  The scene
+    block is filled by the second node (DRowsHeadsFn), so that the scene gradient leaves the backward pass before this
+    node's adjoint (social attention, pred_encoder) runs.
+      soc_blocks: number of leading sample blocks with social features (1: the list-repeat quirk of one K-sample call,
+                  SURVEY A.1; K: K independent single-sample calls batched -- the real/fake pair pass of a D step)"""
+
+    @staticmethod
+    def forward(ctx, in_enc, pred, pred2, anchor, D, tb, K, soc_blocks, xy_last, dxdy_last, xy_mod, w_sc, save):
+        in_enc, ld_in = _rows2d(in_enc)
+        b = in_enc.shape[0]
+        R = K * b
+        pe = D.pred_encoder
+        fc, Wat = D.social.feature_embedder.fc, D.social.attention.W
+        Hs, w_in, w_pe, w_sc = _d_dims(D, in_enc.shape[1], w_sc)
+        W = Hs + w_in + w_pe + w_sc
+        c_in, c_pe, c_sc = Hs, Hs + w_in, Hs + w_in + w_pe
+        st = _s()
+        T = pred.shape[0]
+        x = steps_to_rows(pred, pred2)  # predictions as rows (K*b, 2T)
+        assert x.shape[0] == R, (x.shape, K, b)
+        X = _empty(R, W, like=in_enc)
+        # pred_encoder, last layer straight into its column block of X
+        spec_pe = ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0))
+        Wpe, bpe = (pe[0].weight, pe[2].weight), (pe[0].bias, pe[2].bias)
+        outs_pe = _chain_fwd(x, 2 * T, R, spec_pe, Wpe, bpe, save, out_into=(alias_cols(X, c_pe, c_sc), W))
+        # broadcast in_enc into the sample blocks, clear the social block of the blocks without social features
+        lib.mggan_d_rows_fill(b, K, soc_blocks, Hs, c_in, w_in, c_sc, 0, _p(in_enc), ld_in, 0, 0, _p(X), W, st)
+        # social attention: h = X[:, in_enc | pred_enc] of the first soc_blocks*b rows, S -> X[:, soc block]
+        nsoc = soc_blocks * b
+        xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
+        sw = (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, Wat.weight, Wat.bias)
+        soc_saved = _social_fwd(xy_last, dxdy_last, _p(X) + 4 * c_in, W, nsoc, w_in + w_pe, tb, *sw, _p(X), W, save, xy_mod,
+                                X)
+        if save:
+            ctx.cfg = (D, tb, K, soc_blocks, b, T, W, (Hs, w_in, w_pe, w_sc),
+                       (Wpe[0].requires_grad, fc[0].weight.requires_grad, fc[4].weight.requires_grad), pred.shape,
+                       None if pred2 is None else pred2.shape)
+            ctx.save_for_backward(X, x, outs_pe[0], *soc_saved)
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        (D, tb, K, soc_blocks, b, T, W, (Hs, w_in, w_pe, w_sc), train, pshape, p2shape) = ctx.cfg
+        sv = ctx.saved_tensors
+        X, x, h_pe = sv[:3]
+        soc_saved = sv[3:]
+        R = K * b
+        c_in, c_pe, c_sc = Hs, Hs + w_in, Hs + w_in + w_pe
+        pe = D.pred_encoder
+        fc, Wat = D.social.feature_embedder.fc, D.social.attention.W
+        train_pe, train_s1, train_s3 = train
+        st = _s()
+        need_in, need_pred, need_pred2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if dX.stride(1) != 1 or (R > 1 and dX.stride(0) != W) or dX.data_ptr() % 16:
+            dX = dX.contiguous()
+        # social attention: dS = dX[:, soc block], dh ADDED into dX[:, in_enc | pred_enc] in place (dX comes from
+        # DRowsHeadsFn.backward and has no other reader)
+        nsoc = soc_blocks * b
+        sw = (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, Wat.weight, Wat.bias)
+        _social_bwd(soc_saved, _p(X) + 4 * c_in, W, X, nsoc, w_in + w_pe, tb, *sw, _p(dX), W, _p(dX) + 4 * c_in, W, 1,
+                    train_s1, train_s3, D.social, X)
+        din = None
+        if need_in:  # adjoint of the broadcast
+            din = _empty(b, w_in, like=X)
+            lib.mggan_d_rows_reduce(b, K, c_in, w_in, c_sc, 0, _p(dX), W, _p(din), w_in, 0, 0, st)
+        dpred = dpred2 = None
+        if need_pred or need_pred2 or train_pe:  # pred_encoder adjoint: dy = dX[:, pred_enc block]
+            spec_pe = ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0))
+            dx = _chain_bwd(alias_cols(dX, c_pe, c_sc), W, x, 2 * T, R, (h_pe, alias_cols(X, c_pe, c_sc)), spec_pe,
+                            (pe[0].weight, pe[2].weight), (pe[0].bias, pe[2].bias), need_pred or need_pred2, train_pe,
+                            pe[0], ld_last=W)
+            if need_pred or need_pred2:
+                n1 = R if p2shape is None else R // 2
+                if need_pred:
+                    dpred = _empty(T, n1, 2, like=X)
+                    lib.mggan_rows_to_steps(_p(dx), 2 * T, T, n1, _p(dpred), st)
+                    dpred = dpred.view(pshape)
+                if need_pred2:
+                    dpred2 = _empty(T, R - n1, 2, like=X)
+                    lib.mggan_rows_to_steps(_p(dx) + 4 * n1 * 2 * T, 2 * T, T, R - n1, _p(dpred2), st)
+                    dpred2 = dpred2.view(p2shape)
+        return (din, dpred, dpred2) + (None,) * 10
+
+
+class DRowsHeadsFn(Function):
+    """Second node of the row pass (discriminators.py:186-219): broadcasts the scene features into their column block
+    of X (in place) and runs the score head over all rows and the generator-id head over rows [row0, K*b).
+    Backward: both heads' input gradients land in ONE dX buffer (the second head accumulates inside its launch), the
+    scene gradient is the K-sum of its block.  -> (score (K*b, 1), id logits (K*b - row0, g) | None)"""
+
+    @staticmethod
+    def forward(ctx, X, scene, anchor, D, K, row0, save):
+        scene, ld_sc = _rows2d(scene)
+        b, w_sc = scene.shape
+        R, W = X.shape
+        assert R == K * b
+        c_sc = W - w_sc
+        st = _s()
+        ctx.set_materialize_grads(False)
+        lib.mggan_d_rows_fill(b, K, K, 0, 0, 0, c_sc, w_sc, 0, 0, _p(scene), ld_sc, _p(X), W, st)
+        d0 = D.discs[0]
+        spec_a = ((ACT_LEAKY, 0.2), (D._out_act(), 0.0))
+        Wa, ba = (d0[0].weight, d0[2].weight), (d0[0].bias, d0[2].bias)
+        outs_a = _chain_fwd(X, W, R, spec_a, Wa, ba, save)
+        outs_b, Wb = [None, None], None
+        mgan = D.gan_type == "mgan"
+        if mgan:
+            r = D.gen_id_reconstructor
+            Wb, bb = (r[0].weight, r[2].weight), (r[0].bias, r[2].bias)
+            outs_b = _chain_fwd(_p(X) + 4 * row0 * W, W, R - row0, ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0)), Wb, bb, save)
+        if save:
+            ctx.cfg = (D, K, row0, b, W, w_sc, mgan, Wa[0].requires_grad, bool(mgan and Wb[0].requires_grad))
+            ctx.save_for_backward(X, outs_a[0], outs_a[1], outs_b[0], outs_b[1])
+        return outs_a[-1], outs_b[-1]
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        D, K, row0, b, W, w_sc, mgan, train_a, train_b = ctx.cfg
+        X, ha, ya, hb, yb = ctx.saved_tensors
+        R = K * b
+        d0 = D.discs[0]
+        st = _s()
+        dX = _empty(R, W, like=X)
+        if dya is None:
+            dX.zero_()
+        else:
+            dya, ld = _rows2d(dya.reshape(R, -1))
+            _chain_bwd(dya, ld, X, W, R, (ha, ya), ((ACT_LEAKY, 0.2), (D._out_act(), 0.0)), (d0[0].weight, d0[2].weight),
+                       (d0[0].bias, d0[2].bias), True, train_a, d0[0], dx_into=(_p(dX), W, 0))
+        if mgan and dyb is not None:
+            r = D.gen_id_reconstructor
+            dyb, ld = _rows2d(dyb.reshape(R - row0, -1))
+            _chain_bwd(dyb, ld, _p(X) + 4 * row0 * W, W, R - row0, (hb, yb), ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0)),
+                       (r[0].weight, r[2].weight), (r[0].bias, r[2].bias), True, train_b, r[0],
+                       dx_into=(_p(dX) + 4 * row0 * W, W, 1))
+            if _DEFER["on"]:
+                _DEFER["keep"].append(X)
+        dsc = None
+        if ctx.needs_input_grad[1]:
+            dsc = _empty(b, w_sc, like=X)
+            lib.mggan_d_rows_reduce(b, K, 0, 0, W - w_sc, w_sc, _p(dX), W, 0, 0, _p(dsc), w_sc, st)
+        return (dX if ctx.needs_input_grad[0] else None, dsc) + (None,) * 5
 
 
 # ---------------------------------------- losses -------------------------------------------

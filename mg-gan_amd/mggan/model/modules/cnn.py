@@ -109,13 +109,13 @@ class AttentionGlobal(FlatModule):
                        margin_in=self.margin_in, batch_norm=True, non_lin_cnn="relu", num_layers=self.num_layers,
                        in_channels=4)
 
-    def forward(self, features, stat_updates=1):
+    def forward(self, features, stat_updates=1, out=None):
         """features (B,4,33,33) -> (B,64).  stat_updates: how many reference forwards this call stands for
-        (BatchNorm running statistics are updated that many times)."""
+        (BatchNorm running statistics are updated that many times).  out: an HF.OutSlot to write the result into."""
         HF.root_of(self)
         b1, b2 = self.CNN.encoder.ConvBlock_1.Block, self.CNN.encoder.ConvBlock_2.Block
         a = self.cnn_attention
         return HF.SceneAttentionFn.apply(features, b1.Conv_1.weight, b1.Conv_1.bias, b1.BN_1.weight, b1.BN_1.bias,
                                          b2.Conv_1.weight, b2.Conv_1.bias, b2.BN_1.weight, b2.BN_1.bias, a[0].weight,
                                          a[0].bias, a[2].weight, a[2].bias, b1.BN_1, b2.BN_1, self.training, self,
-                                         self.sync, HF.want_grad(a[0].weight), stat_updates)
+                                         self.sync, HF.want_grad(a[0].weight), stat_updates, out)

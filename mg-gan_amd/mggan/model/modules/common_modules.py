@@ -37,14 +37,15 @@ class TrajectoryEncoder(FlatModule):
         self.embedding = nn.Linear(inp_size, embedding_dim)
         self.encoder = nn.LSTM(input_size=embedding_dim, hidden_size=hidden_size, num_layers=num_layers)
 
-    def forward(self, inp, hc=None):
-        """inp (T, b, 2) -> h_T (b, hidden)."""
+    def forward(self, inp, hc=None, out=None):
+        """inp (T, b, 2) -> h_T (b, hidden).  out: an HF.OutSlot -- the result is written into (and returned as) that
+        column block of a wider buffer instead of a fresh tensor."""
         if hc is not None:
             raise ValueError("initial state is always zero on the reference hot path")
         L = self.encoder
         HF.root_of(self)
         return HF.LstmEncoderFn.apply(inp, self.embedding.weight, self.embedding.bias, L.weight_ih_l0, L.weight_hh_l0,
-                                      L.bias_ih_l0, L.bias_hh_l0, self, HF.want_grad(L.weight_hh_l0))
+                                      L.bias_ih_l0, L.bias_hh_l0, self, HF.want_grad(L.weight_hh_l0), out)
 
 
 class RelativeDecoder(FlatModule):

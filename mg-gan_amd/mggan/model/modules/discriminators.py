@@ -106,14 +106,6 @@ class MultiDiscriminatorTrajectory(FlatModule):
         self.ensure_flat()
         in_enc, scene = context
         b = in_xy.size(1)
-        pe = self.pred_encoder
-        if real_dxdy.requires_grad or fake_dxdy.requires_grad:
-            x = torch.cat([real_dxdy.reshape(real_dxdy.shape[0], b, 2).permute(1, 0, 2).reshape(b, -1),
-                           fake_dxdy.reshape(fake_dxdy.shape[0], b, 2).permute(1, 0, 2).reshape(b, -1)], 0)
-        else:  # (the discriminator step: both sets are constants) one launch instead of two permutes + cat
-            x = HF.steps_to_rows(real_dxdy, fake_dxdy)
-        pred_enc = HF.mlp(x, [(pe[0], HF.ACT_LEAKY, 0.2), (pe[2], HF.ACT_NONE, 0.0)])
-        enc0 = torch.cat([in_enc.repeat(2, 1), pred_enc], dim=1)
         cache = self.__dict__.setdefault("_pair_scenes", {})
         hit = cache.get(id(seq_start_end))
         fp = HF.scene_fingerprint(seq_start_end)
@@ -123,6 +115,21 @@ class MultiDiscriminatorTrajectory(FlatModule):
             hit = (seq_start_end, [[int(s), int(e)] for s, e in seq_start_end] +
                    [[int(s) + b, int(e) + b] for s, e in seq_start_end], fp)
             cache[id(seq_start_end)] = hit
+        if self.pool_type == "sways":
+            # one autograd node for the whole row pass (the row-pass nodes): rows [0,b) real, [b,2b) fake, both blocks with
+            # social features (two independent single-sample passes), generator-id head on the fake half
+            tb = HF.scene_tables(hit[1], 2 * b, in_enc.device)
+            y, branch = self._row_pass(in_enc, scene, real_dxdy.reshape(real_dxdy.shape[0], b, 2),
+                                       fake_dxdy.reshape(fake_dxdy.shape[0], b, 2), tb, 2, 2, b, in_xy[-1], in_dxdy[-1], b)
+            return y, (branch.reshape(b, 1, -1) if branch is not None else None)
+        pe = self.pred_encoder
+        if real_dxdy.requires_grad or fake_dxdy.requires_grad:
+            x = torch.cat([real_dxdy.reshape(real_dxdy.shape[0], b, 2).permute(1, 0, 2).reshape(b, -1),
+                           fake_dxdy.reshape(fake_dxdy.shape[0], b, 2).permute(1, 0, 2).reshape(b, -1)], 0)
+        else:  # (the discriminator step: both sets are constants) one launch instead of two permutes + cat
+            x = HF.steps_to_rows(real_dxdy, fake_dxdy)
+        pred_enc = HF.mlp(x, [(pe[0], HF.ACT_LEAKY, 0.2), (pe[2], HF.ACT_NONE, 0.0)])
+        enc0 = torch.cat([in_enc.repeat(2, 1), pred_enc], dim=1)
         soc = self.social(in_xy[-1:], in_dxdy[-1:], enc0, hit[1], xy_mod=b)
         HF.join_branch(scene)
         classifier_inp = HF.DAssembleFn.apply(soc, in_enc, pred_enc, scene, 2, True)
@@ -133,6 +140,16 @@ class MultiDiscriminatorTrajectory(FlatModule):
         r = self.gen_id_reconstructor
         y, branch = HF.two_heads(classifier_inp, head, [(r[0], HF.ACT_LEAKY, 0.2), (r[2], HF.ACT_NONE, 0.0)], b)
         return y, branch.reshape(b, 1, -1)
+
+    def _row_pass(self, in_enc, scene, pred, pred2, tb, K, soc_blocks, row0, xy_last, dxdy_last, xy_mod):
+        """-> (score (K*b,1), id logits (K*b-row0, g) | None) through the two row-pass nodes (HF.DRowsBodyFn builds
+        the classifier input in place, HF.DRowsHeadsFn adds the scene block and runs the heads)."""
+        anchor = self.discs[0][0].weight
+        save = HF.want_grad(in_enc, scene, pred, pred2, anchor)
+        X = HF.DRowsBodyFn.apply(in_enc, pred, pred2, anchor, self, tb, K, soc_blocks, xy_last, dxdy_last, xy_mod,
+                                 scene.shape[1], save)
+        HF.join_branch(scene)  # the scene CNN's branch only has to be there now
+        return HF.DRowsHeadsFn.apply(X, scene, anchor, self, K, row0, save)
 
     def forward(self, in_xy, in_dxdy, pred_xy, pred_dxdy, seq_start_end, return_all=False, img=None, mask=None,
                 context=None):
@@ -148,6 +165,21 @@ class MultiDiscriminatorTrajectory(FlatModule):
 
         if context is not None and masked:
             raise ValueError("a shared history context needs mask=None (all pedestrians valid)")
+        if not masked and self.pool_type == "sways" and n_samples * b > 0:
+            # the fused row pass: social features for sample block 0 only -- `seq_start_end * n_samples` is LIST
+            # repetition in the reference
+            if context is not None:
+                in_enc, scene = context
+            else:
+                fc = self.in_encoder_fc
+                in_enc = HF.mlp(self.in_encoder(in_dxdy), [(fc[0], HF.ACT_LEAKY, 0.2), (fc[2], HF.ACT_NONE, 0.0)])
+                scene = self.scene_encoder(img)
+            tb = HF.scene_tables(seq_start_end, full_b, in_enc.device)
+            y, branch_out = self._row_pass(in_enc, scene, pred_dxdy, None, tb, n_samples, 1, 0, in_xy[-1], in_dxdy[-1], 0)
+            output = y.reshape(n_samples, b).t()  # mean over the single discriminator is the identity
+            if self.gan_type == "gan":
+                return output
+            return output, branch_out.reshape(n_samples, b, -1).transpose(0, 1)
         in_enc, pred_enc = self._encode_parts(in_dxdy, pred_dxdy, context)
         if not masked:
             # social features only for sample block 0: `seq_start_end * n_samples` is LIST repetition (A.1)

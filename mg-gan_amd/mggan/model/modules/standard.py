@@ -102,15 +102,32 @@ class MultiGenerator(FlatModule):
         for that many identical reference forwards (the no-grad generator call of the discriminator step and
         the generator step see the same weights) -> BatchNorm running stats are updated that many times."""
         self.ensure_flat()
+        b = in_xy.size(1)
+        if self.pool_type != "sways" or b == 0:
+            with HF.branch():  # scene CNN || trajectory LSTM + social pooling
+                scene = self.scene_encoder(img, stat_updates=passes)
+            enc = self.encoder(get_input(in_xy, in_dxdy, self.inp_format))
+            soc = self.social(in_xy, in_dxdy, enc, sub_batches)
+            HF.join_branch(scene)
+            return torch.cat([enc, scene, soc], -1), soc
+        # enc_h = [lstm | scene | social] is ONE (b, 128) buffer: the three producers write their column blocks in
+        # place (HF.OutSlot), HF.TrunkJoinFn runs the social attention and hands out enc_h -- no torch.cat
+        He, Sc, Fs = self.encoder_h_dim, self.scene_dim, self.social_feat_size
+        buf = torch.empty(b, He + Sc + Fs, dtype=torch.float32, device=in_xy.device)
         with HF.branch():  # scene CNN || trajectory LSTM + social attention
             HF.mark("trunk.cnn.begin")
-            scene = self.scene_encoder(img, stat_updates=passes)
+            scene = self.scene_encoder(img, stat_updates=passes, out=HF.OutSlot(buf, He, He + Sc))
             HF.mark("trunk.cnn.end")
-        enc = self.encoder(get_input(in_xy, in_dxdy, self.inp_format))
-        soc = self.social(in_xy, in_dxdy, enc, sub_batches)
+        enc = self.encoder(get_input(in_xy, in_dxdy, self.inp_format), out=HF.OutSlot(buf, 0, He))
+        tb = HF.scene_tables(sub_batches, b, in_xy.device)
+        fc, W = self.social.feature_embedder.fc, self.social.attention.W
+        enc_h, soc = HF.TrunkJoinFn.apply(enc, in_xy[-1], in_dxdy[-1], tb, buf, fc[0].weight, fc[0].bias, fc[2].weight,
+                                          fc[2].bias, fc[4].weight, fc[4].bias, W.weight, W.bias, self.social,
+                                          HF.want_grad(enc, W.weight), Sc)
         HF.mark("trunk.soc.end")
-        HF.join_branch(scene)
-        return torch.cat([enc, scene, soc], -1), soc
+        HF.join_branch(scene)  # the scene block of enc_h is complete from here on
+        enc_h = HF.ColsTapFn.apply(enc_h, scene, He, He + Sc)
+        return enc_h, soc
 
     def _chooser(self, enc_h):
         nc = self.net_chooser

@@ -64,18 +64,41 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
 
     # ---- metric plumbing ---------------------------------------------------------------
     def _emit(self, train_metrics, items):
-        """items: list of (key, slot | (slot_a, slot_b) summed)."""
+        """items: list of (key, slot | (slot_a, slot_b) summed).  Every step owns its slots of the metric buffer, so one
+        snapshot per ITERATION serves all three steps (train_iteration -> _close_iteration); a step called on its own
+        is snapshotted right away."""
+        if getattr(self, "_iter_open", False):
+            self._iter_items.append((train_metrics, items))
+            return
         self._pending.append((train_metrics, items, self._m.clone()))
+        if not self.defer_metrics:
+            self.flush_metrics()
+
+    def _open_iteration(self):
+        self._iter_open, self._iter_items = True, []
+
+    def _close_iteration(self):
+        self._iter_open = False
+        items, self._iter_items = self._iter_items, []
+        if not items:
+            return
+        # inside a graph capture the buffer itself is registered: a replay refreshes it and replay(fetch=True) reads it
+        # before the next replay -- no copy kernel in the graph; eager deferred iterations need their own snapshot
+        snap = self._m if getattr(self, "_static_metrics", False) else self._m.clone()
+        for train_metrics, it in items:
+            self._pending.append((train_metrics, it, snap))
         if not self.defer_metrics:
             self.flush_metrics()
 
     def _fetch(self, pending):
         """One D2H copy per pending snapshot; sharded runs sum the per-rank partial means first (the loss
         kernels already divide by the GLOBAL row count)."""
+        cache = {}
         for train_metrics, items, snap in pending:
-            if self.dist.enabled:
-                snap = self.dist.all_reduce_(snap.clone())
-            v = snap.cpu().numpy()
+            v = cache.get(id(snap))
+            if v is None:
+                red = self.dist.all_reduce_(snap.clone()) if self.dist.enabled else snap
+                v = cache[id(snap)] = red.cpu().numpy()
             for key, slot in items:
                 train_metrics[key].append(float(v[slot] if isinstance(slot, int) else v[slot[0]] + v[slot[1]]))
 

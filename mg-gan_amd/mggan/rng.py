@@ -3,7 +3,7 @@
 HostRNG   -- the reference's draw order on the HOST generators (torch CPU global generator +
              numpy global), SURVEY App. B.  Seed-comparable with the reference; needs the
              PM-network logits on the host for Categorical sampling (one small D2H per G call).
-DeviceRNG -- same distributions drawn on the GPU (torch.cuda generator) with no host sync;
+DeviceRNG -- same distributions drawn on the GPU by one Philox launch per iteration (csrc/rng.hip), no host sync;
              statistically equivalent, not seed-identical.  Used by bench.py (`--rng device`).
 ReplayRNG -- replays recorded draws (golden fixtures / parity tests).
 """
@@ -33,53 +33,85 @@ class HostRNG:
 
 
 class DeviceRNG:
-    """Everything is drawn by the default CUDA generator (capturable in a HIP graph, no host sync)."""
+    """Every draw of an iteration comes from ONE Philox launch (csrc/rng.hip: mggan_draw_iteration) at the start of
+    the iteration: the label uniforms, the per-scene noise vectors of the three generator calls (already repeated for
+    the pedestrians of each scene) and the uniforms of the categorical sampler.  No host sync, no ATen kernel;
+    the iteration counter lives on the device and is advanced by the kernel, so a captured HIP graph draws fresh
+    numbers at every replay.  Seeded from torch's CUDA seed (torch.cuda.manual_seed) at the first draw."""
     on_device = True
 
-    def __init__(self, seed=0):
-        torch.cuda.manual_seed(seed)
-        self._lens = {}
+    def __init__(self, seed=None):
+        if seed is not None:
+            torch.cuda.manual_seed(seed)
+        self.plan = (1, 20, 1)  # noise sample sets of the D / G / PM generator calls (the trainer sets it from its config)
+        self.d_steps = 1        # discriminator steps per iteration (1 + num_unrolling_steps)
+        self._state = None
+        self._labels = self._noise = self._unif = None
+        self._lab_used = self._noise_used = self._unif_used = 0
+        self._shape = None
 
-    def begin_iteration(self):
-        """One launch draws the label uniforms of a whole iteration (three labels() calls)."""
-        self._pool, self._used = torch.rand(8, device="cuda"), 0
-        self._npool = None  # the noise pool is drawn by the first noise() call of the iteration
+    def _ensure_state(self, device):
+        if self._state is None or self._state.device != torch.device(device):
+            seed = int(torch.cuda.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+            self._state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+            self._ticket = torch.zeros(1, dtype=torch.int32, device=device)
 
-    _pool, _used = None, 0
+    def _draw(self, sub_batches, b, Z, device, sets=None, n_unif=None, n_labels=None):
+        from mggan.hip import functions as HF
+        from mggan.hip.lib import lib
+
+        self._ensure_state(device)
+        nd, K, E = self.plan
+        sets = nd * self.d_steps + K + E if sets is None else sets
+        n_unif = b * (nd * self.d_steps + K) if n_unif is None else n_unif
+        n_labels = 4 * self.d_steps + 4 if n_labels is None else n_labels
+        shape = (sets, b, Z, n_unif, n_labels, str(device))
+        if self._shape != shape:  # (re)allocate only when the batch shape changes: static addresses for graph replay
+            self._labels = torch.empty(max(n_labels, 1), dtype=torch.float32, device=device)
+            self._noise = torch.empty(max(sets, 1), b, Z, dtype=torch.float32, device=device)
+            self._unif = torch.empty(max(n_unif, 1), dtype=torch.float32, device=device)
+            self._shape = shape
+        tb = HF.scene_tables(sub_batches, b, device)
+        lib.mggan_draw_iteration(self._state.data_ptr(), self._ticket.data_ptr(), n_labels, self._labels.data_ptr(), sets,
+                                 b, Z, tb.ped_scene.data_ptr(), self._noise.data_ptr(), n_unif, self._unif.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+        self._lab_used = self._noise_used = self._unif_used = 0
+        self._sets, self._nu, self._nl = sets, n_unif, n_labels
+
+    def begin_iteration(self, sub_batches=None, b=None, noise_dim=8, device=None):
+        """One launch draws everything the iteration will ask for (on the caller's stream, before any fork)."""
+        if sub_batches is None:
+            self._shape_stale = True
+            return
+        self._draw(sub_batches, b, noise_dim, device)
 
     def labels(self):
         """-> ((u, 0.9, 1.0), (u', 0.0, 0.1)): smoothed labels real ~ U(.9,1), fake ~ U(0,.1) as device draws."""
-        if self._pool is None or self._used + 2 > self._pool.numel():
-            self.begin_iteration()
-        u = self._pool[self._used:self._used + 2]
-        self._used += 2
+        if self._labels is None or self._lab_used + 2 > self._nl:
+            dev = self._state.device if self._state is not None else torch.device("cuda", torch.cuda.current_device())
+            self._ensure_state(dev)
+            self._extra_labels = torch.empty(8, dtype=torch.float32, device=dev)
+            from mggan.hip.lib import lib
+
+            lib.mggan_draw_iteration(self._state.data_ptr(), self._ticket.data_ptr(), 8, self._extra_labels.data_ptr(), 0, 0,
+                                     0, 0, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+            self._labels, self._lab_used, self._nl = self._extra_labels, 0, 8
+            self._shape = None
+        u = self._labels[self._lab_used:self._lab_used + 2]
+        self._lab_used += 2
         return (u[0:1], 0.9, 1.0), (u[1:2], 0.0, 0.1)
 
     def noise(self, num_samples, dim, sub_batches, device):
-        key = (id(sub_batches), len(sub_batches))
-        lens = self._lens.get(key)
-        if lens is None or lens[0] is not sub_batches:
-            t = torch.tensor([int(e) - int(s) for s, e in sub_batches], device=device)
-            total = int(t.sum())
-            scene_of = torch.repeat_interleave(torch.arange(len(sub_batches), device=device), t, output_size=total)
-            lens = (sub_batches, scene_of)
-            if len(self._lens) > 64:
-                self._lens.clear()
-            self._lens[key] = lens
-        per_scene = self._normals(num_samples, len(sub_batches), dim, device)
-        return per_scene[:, lens[1]]  # one draw per scene, repeated for its pedestrians (utils.py:160-165)
-
-    _npool, _nused = None, 0
-
-    def _normals(self, k, s, dim, device):
-        """(k, s, dim) standard normals out of a per-iteration pool: the three generator calls of an iteration (1,
-        num_samples and 1 sample sets) are served by ONE randn launch instead of three."""
-        pool = self._npool
-        if pool is None or pool.shape[1:] != (s, dim) or pool.device != torch.device(device) or self._nused + k > pool.shape[0]:
-            pool = self._npool = torch.randn(max(2 * k + 8, 32), s, dim, device=device)
-            self._nused = 0
-        out = pool[self._nused:self._nused + k]
-        self._nused += k
+        """(num_samples, b, dim): one N(0,1)^dim draw per (sample, scene), repeated for its pedestrians (utils.py:160-165)."""
+        b = max((int(e) for _, e in sub_batches), default=0)
+        pool = self._noise
+        if (pool is None or pool.shape[1:] != (b, dim) or pool.device != torch.device(device)
+                or self._noise_used + num_samples > self._sets):
+            # outside a planned iteration (a stand-alone step or prediction call): draw exactly this request
+            self._draw(sub_batches, b, dim, device, sets=num_samples, n_unif=b * num_samples, n_labels=8)
+            pool = self._noise
+        out = pool[self._noise_used:self._noise_used + num_samples]
+        self._noise_used += num_samples
         return out
 
     def randn(self, *shape):
@@ -91,7 +123,15 @@ class DeviceRNG:
 
         lg = logits.detach().float().contiguous()
         b, g = lg.shape
-        u = torch.rand(b, num_samples, device=lg.device)
+        n = b * num_samples
+        if self._unif is not None and self._unif.device == lg.device and self._unif_used + n <= self._nu:
+            u = self._unif[self._unif_used:self._unif_used + n]
+            self._unif_used += n
+        else:
+            self._ensure_state(lg.device)
+            u = torch.empty(n, dtype=torch.float32, device=lg.device)
+            lib.mggan_draw_iteration(self._state.data_ptr(), self._ticket.data_ptr(), 0, 0, 0, 0, 0, 0, 0, n, u.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
         idx = torch.empty(b, num_samples, dtype=torch.int64, device=lg.device)
         lib.mggan_sample_categorical(b, num_samples, g, lg.data_ptr(), u.data_ptr(), idx.data_ptr(),
                                      torch.cuda.current_stream().cuda_stream)

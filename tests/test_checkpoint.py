@@ -121,8 +121,9 @@ def test_save_load_from_path_resume_is_bit_identical(tmp_path):
     state = gen.get_state()
     _run(tr, batch, sizes, g, gen, 2)
     want = torch.cat([tr.G._flat, tr.D._flat]).cpu()
-    want_buf = {k: v.cpu().clone() for k, v in list(tr.G.state_dict().items()) + list(tr.D.state_dict().items())
-                if "running" in k or "tracked" in k}
+    bufs = lambda t: {m + "." + k: v.cpu().clone() for m, mod in (("G", t.G), ("D", t.D)) for k, v in mod.state_dict().items()
+                      if "running" in k or "tracked" in k}
+    want_buf = bufs(tr)
 
     version_dir = tmp_path / "ck" / "version_3"
     assert (version_dir / "meta_tags.csv").exists() and (version_dir / "checkpoints" / "checkpoint_5.pth").exists()
@@ -136,9 +137,8 @@ def test_save_load_from_path_resume_is_bit_identical(tmp_path):
     _run(tr2, batch, sizes, g, gen2, 2)
     got = torch.cat([tr2.G._flat, tr2.D._flat]).cpu()
     assert torch.equal(got, want)
-    for k, v in list(tr2.G.state_dict().items()) + list(tr2.D.state_dict().items()):
-        if "running" in k or "tracked" in k:
-            assert torch.equal(v.cpu(), want_buf[k]), k
+    for k, v in bufs(tr2).items():
+        assert torch.equal(v, want_buf[k]), k
 
 
 @pytest.mark.gpu
