@@ -46,12 +46,16 @@ def kernel_of(name, a):
     }
     if name in fixed:
         return fixed[name]
-    if name == "mggan_conv1_fwd":
-        return "conv1_fwd_mfma_kernel<{}>".format(a[2])
+    if name == "mggan_conv1_pool":
+        return "conv1_pool_kernel<{}>".format(a[2])
+    if name == "mggan_conv2_fwd2":
+        return "conv2_fwd2_kernel<{}>".format(a[3])
     if name == "mggan_conv2_bwd":
-        return "conv2_bwd_mfma_kernel" if a[2] == 16 else "conv2_bwd_kernel<8>"
-    if name in ("mggan_conv1_bwd", "mggan_conv2_fwd"):
-        return "{}_kernel<{}>".format(name[len("mggan_"):], a[2])
+        return "conv2_bwd_mfma_kernel" if a[4] == 16 else "conv2_bwd_kernel<8>"
+    if name == "mggan_conv1_wgrad":
+        return "conv1_wgrad_kernel<{}>".format(a[2])
+    if name == "mggan_image_gram":
+        return "image_gram_kernel"
     return name
 
 
@@ -88,14 +92,16 @@ def flops_of(name, a):
         data = T * 2 * (4 * H * H + 2 * 4 * H + H * (H // 2) + (H // 2) * 2) + 2 * (EIN * H + H * (H // 2))
         wgrads = T * 2 * (4 * H * (H + 3) + (H // 2) * H + 2 * (H // 2))
         return float(R) * (data + wgrads)
-    if name == "mggan_conv1_fwd":
+    if name == "mggan_conv1_pool":
         return float(a[1]) * 2 * 33 * 33 * a[2] * 36
-    if name == "mggan_conv2_fwd":
-        return float(a[1]) * 2 * 256 * a[2] * a[2] * 9
+    if name == "mggan_conv2_fwd2":
+        return float(a[2]) * 2 * 256 * a[3] * a[3] * 9
     if name == "mggan_conv2_bwd":
-        return float(a[1]) * 2 * 2 * 256 * a[2] * a[2] * 9
-    if name == "mggan_conv1_bwd":
+        return float(a[3]) * 2 * 2 * 256 * a[4] * a[4] * 9
+    if name == "mggan_conv1_wgrad":  # the reference operator: a dense (C x 36) x (33*33 positions) weight gradient
         return float(a[1]) * 2 * 33 * 33 * a[2] * 36
+    if name == "mggan_image_gram":  # not in the reference's operator list (bookkeeping of the factorised conv1 gradient)
+        return 0.0
     if name == "mggan_scene_attention_fwd":
         return float(a[1]) * 64 * 2 * (a[2] * 32 * 2)
     if name == "mggan_scene_attention_bwd":

@@ -178,44 +178,68 @@ int mggan_segment_max_bwd(int P, int B, const int* pair_o, const int* ped_prow, 
 
 /* ---- scene CNN + physical attention -----------------------------------------------------
  * reference: cnn.py:119-160 (Conv_Blocks), :275-282 (CNN.forward), :109-116 (AttentionGlobal.forward)
- * img (B,4,33,33) -> y1 raw (B,C,33,36: rows padded to 36 floats) -> [BN+ReLU+pool] -> y2 raw (B,C,16,16) -> [BN+ReLU+pool]
- * -> attention over channels -> out (B,64).  part = per-image (sum, sumsq) per channel (B,2C);
- * mggan_bn_reduce folds them to f64 sums (all-reduce point for multi-GPU), mggan_bn_finalize
- * turns sums into scale/shift (+ running-stat update, stat = mean | invstd). */
-int mggan_cnn_bwd_grid(int B);
-int mggan_conv1_fwd(const float* img, int B, int C, const float* W, const float* bias, float* y1, float* part,
-                    mggan_stream_t stream);
-int mggan_bn_reduce(const float* part, int B, int W, double* sums, mggan_stream_t stream);
+ * img (B,4,33,33) -> conv1 (never stored at full resolution: the raw window maximum / minimum (B,C,16,16) x2 and the
+ * 2-bit window positions are kept -- ReLU(BN(.)) is monotone, so the pooled activation is ReLU(BN(x_max)) for a
+ * positive BatchNorm scale and ReLU(BN(x_min)) for a negative one) -> conv2 raw y2 (B,C,16,16) -> [BN+ReLU+pool] ->
+ * attention over channels -> out (B,64).
+ * Statistics: every kernel leaves ONE row of 2C doubles per workgroup in `part` ((sum, sumsq) forward, (sum g,
+ * sum g*xhat) backward).  With a `ticket` (one zeroed word, left at zero) the last workgroup of the launch folds the rows
+ * in index order and finalizes BatchNorm itself (scale / shift / stat = mean | invstd / `updates` momentum updates of
+ * the running statistics; backward: coef = [gamma*invstd | mean g | mean g*xhat], dgamma / dbeta accumulated).  With
+ * ticket == NULL the caller does it: mggan_bn_reduce_rows -> (all-reduce over ranks) -> mggan_bn_finalize /
+ * mggan_bn_bwd_coef. */
+int mggan_cnn_grid(int B);      /* workgroups (= partial rows) of conv1_pool / conv2_fwd2 / image_gram / conv1_wgrad */
+int mggan_cnn_bwd_grid(int B);  /* workgroups (= partial rows) of conv2_bwd */
+int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float* bias, float* xmax, float* xmin,
+                     unsigned char* code, double* part, unsigned int* ticket, double count, const float* gamma,
+                     const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
+                     float eps, int updates, float* scale, float* shift, float* stat, mggan_stream_t stream);
+int mggan_conv2_fwd2(const float* xmax, const float* xmin, int B, int C, const float* scale1, const float* shift1,
+                     const float* W, const float* bias, float* y2, double* part, unsigned int* ticket, double count,
+                     const float* gamma, const float* beta, float* run_mean, float* run_var,
+                     long long* num_batches_tracked, float momentum, float eps, int updates, float* scale, float* shift,
+                     float* stat, mggan_stream_t stream);
+int mggan_bn_reduce_rows(const double* part, int rows, int W, double* sums, mggan_stream_t stream);
 /* training: 0 = eval (running statistics), n >= 1 = batch statistics and n momentum updates of the running ones */
 int mggan_bn_finalize(const double* sums, double count, int C, int training, const float* gamma, const float* beta,
                       float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps,
                       float* scale, float* shift, float* stat, mggan_stream_t stream);
-/* single-GPU fast path: mggan_bn_reduce + mggan_bn_finalize (x `updates` running-stat updates) in ONE launch,
- * and the same for the backward statistics */
-int mggan_bn_stats_finalize(const float* part, int B, double count, int C, const float* gamma, const float* beta,
-                            float* run_mean, float* run_var, long long* num_batches_tracked, float momentum, float eps,
-                            int updates, float* scale, float* shift, float* stat, mggan_stream_t stream);
-int mggan_bn_bwd_stats_finalize(const float* part, int B, double count, int C, const float* gamma, const float* stat,
-                                float* coef, float* dgamma, float* dbeta, mggan_stream_t stream);
-/* sums: (sum g, sum g*xhat) over the GLOBAL batch (after the all-reduce); local_sums: this rank's share */
-int mggan_bn_bwd_finalize(const double* sums, const double* local_sums, double count, int C, const float* gamma,
-                          const float* stat, float* coef, float* dgamma, float* dbeta, mggan_stream_t stream);
-int mggan_conv2_fwd(const float* y1, int B, int C, const float* scale1, const float* shift1, const float* W,
-                    const float* bias, float* y2, float* part, mggan_stream_t stream);
+/* backward coefficients from partial rows (one rank) ... */
+int mggan_bn_bwd_rows_finalize(const double* part, int rows, double count, int C, const float* gamma, const float* stat,
+                               float* coef, double* coefd, float* dgamma, float* dbeta, mggan_stream_t stream);
+/* ... or from sums over the GLOBAL batch (after the all-reduce); local_sums: this rank's share (dgamma / dbeta) */
+int mggan_bn_bwd_coef(const double* sums, const double* local_sums, double count, int C, const float* gamma,
+                      const float* stat, float* coef, double* coefd, float* dgamma, float* dbeta, mggan_stream_t stream);
 int mggan_scene_attention_fwd(const float* y2, int B, int C, const float* scale2, const float* shift2, const float* Wa,
                               const float* ba, const float* Wb, const float* bb, float* out, int ld_out,
                               mggan_stream_t stream);
+/* part: ceil(B/4) rows */
 int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2, const float* shift2,
                               const float* stat2, const float* Wa, const float* ba, const float* Wb, const float* bb,
                               const float* dout, int ld_dout, float* ds, float* hact, float* dz, float* vsave,
-                              float* G2, float* part, mggan_stream_t stream);
-int mggan_conv2_bwd(const float* y1, int B, int C, const float* scale1, const float* shift1, const float* stat1,
-                    const float* y2, const float* G2, const float* stat2, const float* coef2, const float* W,
-                    float* G1c, unsigned char* code1, float* part1, float* dW, float* db, float* workspace,
-                    size_t workspace_bytes, mggan_stream_t stream);
-int mggan_conv1_bwd(const float* img, int B, int C, const float* y1, const float* stat1, const float* coef1,
-                    const float* G1c, const unsigned char* code1, float* dW, float* db, float* workspace,
-                    size_t workspace_bytes, mggan_stream_t stream);
+                              float* G2, double* part, unsigned int* ticket, double count, const float* gamma2,
+                              float* coef2, float* dgamma2, float* dbeta2, mggan_stream_t stream);
+/* conv2 adjoint (BatchNorm-2 backward on the fly, dW2 / db2 as per-workgroup partial rows in `workspace`, input
+ * gradient routed through ReLU / max-pool of block 1 -> G1c (B,C,16,16) + window position code1); part1:
+ * mggan_cnn_bwd_grid(B) rows; coefd1 = [gamma*invstd | S1 | S2 | mean | invstd] (C each) + count, f64, for
+ * mggan_conv1_wgrad.  workspace: mggan_cnn_bwd_grid(B) * (256/(C*C)) * (C*C*9 + C) floats. */
+int mggan_conv2_bwd(const float* xmax, const float* xmin, const unsigned char* codes, int B, int C, const float* scale1,
+                    const float* shift1, const float* stat1, const float* y2, const float* G2, const float* stat2,
+                    const float* coef2, const float* W, float* G1c, unsigned char* code1, double* part1, float* dW,
+                    float* db, float* workspace, size_t workspace_bytes, unsigned int* ticket, double count1,
+                    const float* gamma1, float* coef1, double* coefd1, float* dgamma1, float* dbeta1,
+                    mggan_stream_t stream);
+/* Gram matrix of the 3x3 patches of a batch of images, gram[s][t] (37 x 37 doubles; tap t = 9*ci + 3*ky + kx,
+ * tap 36 = the constant 1): the image-only part of every conv1 weight gradient of the batch (both CNNs, every
+ * backward pass).  workspace: mggan_cnn_grid(B) * 1536 doubles. */
+int mggan_image_gram(const float* img, int B, double* gram, double* workspace, size_t workspace_bytes,
+                     mggan_stream_t stream);
+/* conv1 weight gradient (the images need no input gradient): dW (C,4,3,3) += (gamma/sigma) * (A - mean(g) * B -
+ * mean(g*xhat) * Chat) with A from G1c / code1 (matrix cores) and B, Chat from the Gram matrix, in f64; the conv1 bias
+ * gradient is identically zero in front of a train-mode BatchNorm.  workspace: mggan_cnn_grid(B) * C * 36 doubles. */
+int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const unsigned char* code1, const double* gram,
+                      const float* W, const float* bias, const double* coefd, float* dW, double* workspace,
+                      size_t workspace_bytes, mggan_stream_t stream);
 
 /* ---- losses (+ gradients), clipping, AdamW ----------------------------------------------
  * reference: abstract_train.py:62-67, utils.py:18-25, train.py:58-75,92-113,181-200,626-639,

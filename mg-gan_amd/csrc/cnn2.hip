@@ -1,0 +1,654 @@
+// Scene CNN, second generation: no full-resolution activation ever touches HBM.
+//
+// Replaces (file:line under /root/reference/mggan/model/modules/cnn.py) Conv_Blocks :119-160 / CNN.forward :275-282 for
+// the first block and the weight gradient of its convolution:
+//
+//   conv1_pool_kernel   img (B,4,33,33) -> conv1 on the matrix cores, BatchNorm statistics, and the 2x2 pooling
+//                       decision on the RAW output: ReLU(scale*x+shift) is monotone in x, so maxpool(ReLU(BN(x))) is
+//                       ReLU(BN(x_max)) for scale >= 0 and ReLU(BN(x_min)) for scale < 0 -- the kernel keeps the raw
+//                       maximum AND minimum of every window (+ 2-bit positions), which needs no statistics.  What the
+//                       first-generation kernels wrote and re-read three times per pass, the raw (B,C,33,36) output
+//                       (76 KB per image), never exists; 36 KB per image are kept instead.
+//   conv2_fwd2_kernel   a1 = ReLU(scale1*x_sel+shift1) -> conv2 -> raw (B,C,16,16) + statistics.
+//   image_gram_kernel   P[s][t] = sum over images and positions of patch[s]*patch[t] (37x37, tap 36 = the constant 1):
+//                       the only DENSE quantity the conv1 weight gradient needs -- and it depends on the images alone,
+//                       so ONE launch per batch serves every backward pass of both CNNs (three per iteration).
+//   conv1_wgrad_kernel  A[c][t] = sum_pos dy_sparse[c][pos]*patch[pos][t] on the matrix cores (the gradient that
+//                       reaches a pooled cell sits on one of the four window positions).
+//   conv1_wgrad_finalize  dW = (gamma/sigma) * (A - m1*B - m2*Chat), Chat[c][t] = (sum_s W[c][s] P[s][t] + (bias-mean) B[t]) / sigma
+//                       -- the BatchNorm adjoint dx = (gamma/sigma)(dy - mean(dy) - xhat*mean(dy*xhat)) pushed through
+//                       the (linear) convolution, in f64: the two coherent sums that cancel in dW (dW is orthogonal
+//                       to W) never meet in f32.
+// Every kernel is persistent (<= 1024 workgroups walk the images), leaves ONE partial row per workgroup, and -- when
+// given a ticket word -- lets the last workgroup to finish fold the rows in index order (f64) and do the BatchNorm
+// bookkeeping itself: no separate reduce / finalize launches on the single-GPU path.
+#include "common.h"
+#include "../../include/mggan_hip.h"
+
+#define IH 33
+#define IPIX (IH * IH)
+#define ILD 40               // row stride of the zero-haloed 35x35 image in LDS
+#define IPLANE 1424          // plane stride, == 16 (mod 32): the two input channels a half-wave reads hit disjoint banks
+#define IZERO (4 * IPLANE)   // 64 zero floats behind the planes (operand of masked lanes)
+#define ILDS (4 * IPLANE + 64)
+#define A1_LD 20
+#define A1_PLANE (18 * A1_LD)
+#define NTAP 37              // 36 taps (ci,ky,kx) + the constant 1
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct BnFin {  // fused BatchNorm finalize (ticket == NULL: the caller reduces / finalizes itself, e.g. across ranks)
+  unsigned* ticket;
+  double count;
+  const float* gamma;
+  const float* beta;
+  float* run_mean;
+  float* run_var;
+  long long* nbt;
+  float momentum, eps;
+  int updates;
+  float* scale;
+  float* shift;
+  float* stat;
+};
+
+struct BnBwdFin {  // fused BatchNorm-backward finalize
+  unsigned* ticket;
+  double count;
+  const float* gamma;
+  const float* stat;   // [mean | invstd] of the forward pass
+  float* coef;         // [gamma*invstd | mean(g) | mean(g*xhat)]  (f32, per-element use)
+  double* coefd;       // [gamma*invstd | S1 | S2 | mean | invstd] + count  (f64, for conv1_wgrad_finalize); may be NULL
+  float* dgamma;
+  float* dbeta;
+};
+
+// (4,33,33) image -> interior of the zero-haloed planes (the halo is cleared once per workgroup)
+__device__ __forceinline__ void stage_image(const float* __restrict__ src, float* imgp) {
+  constexpr int NPIX = 4 * IPIX, PER = (NPIX + 255) / 256;
+  float v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    v[u] = src[e < NPIX ? e : 0];
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    if (e < NPIX) {
+      const int ci = e / IPIX, rem = e - ci * IPIX, y = rem / IH, x = rem - y * IH;
+      imgp[ci * IPLANE + (y + 1) * ILD + x + 1] = v[u];
+    }
+  }
+}
+
+// fixed-order f64 column sums of `rows` partial rows of width W (<= 32) by one 256-thread workgroup -> colsum[W] (LDS)
+__device__ __forceinline__ void colsum_rows(const double* part, int rows, int W, double* colsum, double* red /*[8][32]*/) {
+  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  double acc = 0.0;
+  if (col < W)
+    for (int r = rg; r < rows; r += 8) acc += __builtin_nontemporal_load(part + (size_t)r * W + col);
+  red[rg * 32 + col] = acc;
+  __syncthreads();
+  if (threadIdx.x < W) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i * 32 + threadIdx.x];
+    colsum[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// this workgroup's row is in memory; -> true for the workgroup that arrives last (its lanes may then read every row)
+__device__ __forceinline__ bool last_block(unsigned* ticket, int* flag_lds) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = atomicAdd(ticket, 1u);
+    *flag_lds = (t == gridDim.x - 1);
+    if (t == gridDim.x - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      *ticket = 0u;  // re-armed for the next launch / graph replay
+    }
+  }
+  __syncthreads();
+  return *flag_lds != 0;
+}
+
+__device__ __forceinline__ void bn_finalize_lane(const BnFin& f, int C, const double* sums) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const double m = sums[c] / f.count;
+  double v = sums[C + c] / f.count - m * m;
+  if (v < 0.0) v = 0.0;
+  const float mean = (float)m, var = (float)v;
+  const float unb = (float)(f.count > 1.0 ? v * f.count / (f.count - 1.0) : v);
+  float rm = f.run_mean[c], rv = f.run_var[c];
+  for (int u = 0; u < f.updates; ++u) {  // this forward may stand for several identical reference forwards (A.8)
+    rm = (1.f - f.momentum) * rm + f.momentum * mean;
+    rv = (1.f - f.momentum) * rv + f.momentum * unb;
+  }
+  f.run_mean[c] = rm;
+  f.run_var[c] = rv;
+  if (c == 0) *f.nbt += f.updates;
+  const float invstd = 1.0f / sqrtf(var + f.eps);
+  const float sc = f.gamma[c] * invstd;
+  f.scale[c] = sc;
+  f.shift[c] = f.beta[c] - mean * sc;
+  f.stat[c] = mean;
+  f.stat[C + c] = invstd;
+}
+
+__device__ __forceinline__ void bn_bwd_finalize_lane(const BnBwdFin& f, int C, const double* sums) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const float cs = f.gamma[c] * f.stat[C + c];
+  f.coef[c] = cs;
+  f.coef[C + c] = (float)(sums[c] / f.count);
+  f.coef[2 * C + c] = (float)(sums[C + c] / f.count);
+  if (f.coefd) {
+    f.coefd[c] = (double)f.gamma[c] * (double)f.stat[C + c];
+    f.coefd[C + c] = sums[c];
+    f.coefd[2 * C + c] = sums[C + c];
+    f.coefd[3 * C + c] = (double)f.stat[c];
+    f.coefd[4 * C + c] = (double)f.stat[C + c];
+    if (c == 0) f.coefd[5 * C] = f.count;
+  }
+  f.dbeta[c] += (float)sums[c];
+  f.dgamma[c] += (float)sums[C + c];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv1 + statistics + pooling decision.  Implicit GEMM on v_mfma_f32_16x16x4_f32: a tile is FOUR pooling windows,
+// row i = 4*window + element of the A operand, so that the D fragment of a lane (4 rows of one output channel) is
+// exactly one 2x2 window: max / min / argmax are lane-local.  K = 36 is ordered k = 4*tap + ci: the four lane groups
+// of a k-step read four different input-channel planes.
+template <int C>
+__global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __restrict__ img, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ xmax,
+                                                         float* __restrict__ xmin, unsigned char* __restrict__ code,
+                                                         double* part, BnFin fin) {
+  __shared__ __attribute__((aligned(16))) float imgp[ILDS];
+  __shared__ double redd[4][2][16];
+  __shared__ double colsum[32], cred[8 * 32];
+  __shared__ int flag;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fi = lane & 15, fk = lane >> 4;
+  for (int i = tid; i < ILDS; i += 256) imgp[i] = 0.f;
+  float bw[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s) bw[s] = fi < C ? W[fi * 36 + fk * 9 + s] : 0.f;
+  const float bv = fi < C ? bias[fi] : 0.f;
+  // A operand: lane (fi, fk) supplies row i = fi (window fi>>2, element fi&3) of input channel fk
+  const int aoff = fk * IPLANE + ((fi & 3) >> 1) * ILD + 2 * (fi >> 2) + (fi & 1);
+  double dsum = 0.0, dsq = 0.0;
+  __syncthreads();
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();  // the previous image's reads are done
+    stage_image(img + (size_t)b * 4 * IPIX, imgp);
+    __syncthreads();
+    float sum = 0.f, sq = 0.f;
+#pragma unroll 1
+    for (int t = w; t < 64; t += 8) {  // two independent tiles per pass keep the matrix pipe fed
+      const int t1 = t + 4;
+      const int py0 = t >> 2, px0 = (t & 3) * 4, py1 = t1 >> 2, px1 = (t1 & 3) * 4;
+      const float* p0 = imgp + 2 * py0 * ILD + 2 * px0 + aoff;
+      const float* p1 = imgp + 2 * py1 * ILD + 2 * px1 + aoff;
+      f32x4 a0 = {bv, bv, bv, bv}, a1 = {bv, bv, bv, bv};
+      float x0[9], x1[9];
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+        x0[s] = p0[(s / 3) * ILD + s % 3];
+        x1[s] = p1[(s / 3) * ILD + s % 3];
+      }
+#pragma unroll
+      for (int s = 0; s < 9; ++s) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[s], bw[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[s], bw[s], a1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 acc = h ? a1 : a0;
+        const int py = h ? py1 : py0, px = (h ? px1 : px0) + fk;
+        float mx = acc[0], mn = acc[0];
+        int cx = 0, cn = 0;
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+          if (acc[r] > mx) { mx = acc[r]; cx = r; }
+          if (acc[r] < mn) { mn = acc[r]; cn = r; }
+        }
+        sum += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        sq = fmaf(acc[0], acc[0], fmaf(acc[1], acc[1], fmaf(acc[2], acc[2], fmaf(acc[3], acc[3], sq))));
+        if (fi < C) {
+          const size_t o = (((size_t)b * C + fi) * 16 + py) * 16 + px;
+          xmax[o] = mx;
+          xmin[o] = mn;
+          code[o] = (unsigned char)(cx | (cn << 2));
+        }
+      }
+    }
+    // border row 32 / column 32 (never pooled): 65 positions, statistics only
+    for (int bt = w; bt < 5; bt += 4) {
+      const int i = 16 * bt + fi;
+      const int y = i < 33 ? 32 : (i < 65 ? i - 33 : 0), x = i < 33 ? i : (i < 65 ? 32 : 0);
+      const float* p = imgp + fk * IPLANE + y * ILD + x;
+      f32x4 a = {bv, bv, bv, bv};
+#pragma unroll
+      for (int s = 0; s < 9; ++s) a = __builtin_amdgcn_mfma_f32_16x16x4f32(p[(s / 3) * ILD + s % 3], bw[s], a, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * bt + 4 * fk + r < 65) {
+          sum += a[r];
+          sq = fmaf(a[r], a[r], sq);
+        }
+    }
+    dsum += (double)sum;  // f32 within an image, f64 across the images of this workgroup
+    dsq += (double)sq;
+  }
+  // lanes with the same fi (4 lane groups), then the 4 waves
+  dsum += __shfl_xor(dsum, 16, 64); dsq += __shfl_xor(dsq, 16, 64);
+  dsum += __shfl_xor(dsum, 32, 64); dsq += __shfl_xor(dsq, 32, 64);
+  if (fk == 0) { redd[w][0][fi] = dsum; redd[w][1][fi] = dsq; }
+  __syncthreads();
+  if (tid < 2 * C) {
+    const int which = tid / C, c = tid - which * C;
+    part[(size_t)blockIdx.x * 2 * C + tid] = (redd[0][which][c] + redd[1][which][c]) + (redd[2][which][c] + redd[3][which][c]);
+  }
+  if (!fin.ticket) return;
+  if (!last_block(fin.ticket, &flag)) return;
+  colsum_rows(part, gridDim.x, 2 * C, colsum, cred);
+  bn_finalize_lane(fin, C, colsum);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv2 forward: a1 = ReLU(BN1(x_sel)) with x_sel the window maximum (scale >= 0) or minimum (scale < 0)
+template <int C>
+__global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __restrict__ xmax, const float* __restrict__ xmin,
+                                                         const float* __restrict__ scale1, const float* __restrict__ shift1,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         float* __restrict__ y2, double* part, BnFin fin) {
+  constexpr int COT = C / 4;
+  __shared__ __attribute__((aligned(16))) float a1p[C * A1_PLANE];
+  __shared__ double colsum[32], cred[8 * 32];
+  __shared__ int flag;
+  for (int i = threadIdx.x; i < C * A1_PLANE; i += 256) a1p[i] = 0.f;
+  const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pg = threadIdx.x & 63;
+  const int py = pg >> 2, x0 = (pg & 3) * 4;
+  double dsum[COT], dsq[COT];
+#pragma unroll
+  for (int co = 0; co < COT; ++co) dsum[co] = dsq[co] = 0.0;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    {
+      const int ppy = threadIdx.x >> 4, ppx = threadIdx.x & 15;
+      float v[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const size_t gi = ((size_t)b * C + c) * 256 + threadIdx.x;
+        v[c] = (scale1[c] >= 0.f ? xmax : xmin)[gi];
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        a1p[c * A1_PLANE + (ppy + 1) * A1_LD + ppx + 1] = fmaxf(fmaf(v[c], scale1[c], shift1[c]), 0.f);
+    }
+    __syncthreads();
+    float acc[COT][4];
+#pragma unroll
+    for (int co = 0; co < COT; ++co) {
+      const float bv = bias[cg * COT + co];
+#pragma unroll
+      for (int px = 0; px < 4; ++px) acc[co][px] = bv;
+    }
+#pragma unroll 2
+    for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const float* rp = &a1p[ci * A1_PLANE + (py + ky) * A1_LD + x0];
+        const float4 ra = *reinterpret_cast<const float4*>(rp);
+        const float2 rb = *reinterpret_cast<const float2*>(rp + 4);
+        const float r[6] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int co = 0; co < COT; ++co) {
+            const float wv = W[((cg * COT + co) * C + ci) * 9 + ky * 3 + kx];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) acc[co][px] = fmaf(wv, r[px + kx], acc[co][px]);
+          }
+      }
+#pragma unroll
+    for (int co = 0; co < COT; ++co) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) { s += acc[co][px]; q = fmaf(acc[co][px], acc[co][px], q); }
+      *reinterpret_cast<float4*>(y2 + (((size_t)b * C + cg * COT + co) * 16 + py) * 16 + x0) =
+          make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+      dsum[co] += (double)wave_sum(s);
+      dsq[co] += (double)wave_sum(q);
+    }
+  }
+  if (pg == 0) {
+#pragma unroll
+    for (int co = 0; co < COT; ++co) {
+      part[(size_t)blockIdx.x * 2 * C + cg * COT + co] = dsum[co];
+      part[(size_t)blockIdx.x * 2 * C + C + cg * COT + co] = dsq[co];
+    }
+  }
+  if (!fin.ticket) return;
+  if (!last_block(fin.ticket, &flag)) return;
+  colsum_rows(part, gridDim.x, 2 * C, colsum, cred);
+  bn_finalize_lane(fin, C, colsum);
+}
+
+// sums[col] = sum over rows of part[row][col]  (f64; the sharded path all-reduces `sums` before finalizing)
+__global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const double* part, int rows, int W, double* sums) {
+  __shared__ double colsum[32], cred[8 * 32];
+  colsum_rows(part, rows, W, colsum, cred);
+  if ((int)threadIdx.x < W) sums[threadIdx.x] = colsum[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_rows_finalize_kernel(const double* part, int rows, int C, BnBwdFin fin) {
+  __shared__ double colsum[32], cred[8 * 32];
+  colsum_rows(part, rows, 2 * C, colsum, cred);
+  bn_bwd_finalize_lane(fin, C, colsum);
+}
+
+// coefficient block from already reduced (and, sharded, all-reduced) sums; dgamma / dbeta take the LOCAL sums
+__global__ void bn_bwd_coef_kernel(const double* sums, const double* local, int C, BnBwdFin fin) {
+  __shared__ double s[32];
+  if ((int)threadIdx.x < 2 * C) s[threadIdx.x] = sums[threadIdx.x];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const float keep_b = fin.dbeta[c], keep_g = fin.dgamma[c];
+  bn_bwd_finalize_lane(fin, C, s);
+  fin.dbeta[c] = keep_b + (float)local[c];
+  fin.dgamma[c] = keep_g + (float)local[C + c];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Gram matrix of the image patches: P[s][t] = sum_{img,pos} patch[pos][s] patch[pos][t], taps ordered t = 9*ci + 3*ky + kx,
+// tap 36 = 1.  A and B operand of a 16x16x4 MFMA are the SAME register when both index (tap, position): three LDS
+// reads (tap blocks 0-15, 16-31, 32-47) feed the six upper-triangle tile products of a k-step (4 positions of a row).
+__global__ __launch_bounds__(256) void image_gram_kernel(int B, const float* __restrict__ img, double* part /*[grid][6*256]*/) {
+  __shared__ __attribute__((aligned(16))) float imgp[ILDS + 64];
+  __shared__ double fold[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fi = lane & 15, fk = lane >> 4;
+  for (int i = tid; i < ILDS + 64; i += 256) imgp[i] = 0.f;
+  __syncthreads();
+  if (tid < 64) imgp[ILDS + tid] = 1.f;  // the constant tap
+  // per-lane operand offset of tap blocks 0..2 (tap = 16*blk + fi) relative to the k-step base (y*ILD + x0 + fk)
+  int toff[3];
+#pragma unroll
+  for (int blk = 0; blk < 3; ++blk) {
+    const int t = 16 * blk + fi;
+    toff[blk] = t < 36 ? (t / 9) * IPLANE + ((t % 9) / 3) * ILD + (t % 3) : (t == 36 ? ILDS : IZERO);
+  }
+  double acc[6][4];
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    stage_image(img + (size_t)b * 4 * IPIX, imgp);
+    __syncthreads();
+    f32x4 a[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks = w; ks < 33 * 9; ks += 4) {
+      const int y = ks / 9, x0 = (ks - y * 9) * 4;
+      const bool valid = x0 + fk < IH;  // only the last k-step of a row has masked positions (x = 33..35)
+      const int base = y * ILD + x0 + fk;
+      float v[3];
+#pragma unroll
+      for (int blk = 0; blk < 3; ++blk) {
+        const int o = toff[blk];
+        // masked lanes read zeros; the constant / zero pseudo-taps do not move with the position
+        v[blk] = imgp[valid ? (o >= IZERO ? o : base + o) : IZERO];
+      }
+      a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[0], v[0], a[0], 0, 0, 0);
+      a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[0], v[1], a[1], 0, 0, 0);
+      a[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[0], v[2], a[2], 0, 0, 0);
+      a[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[1], v[1], a[3], 0, 0, 0);
+      a[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[1], v[2], a[4], 0, 0, 0);
+      a[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2], v[2], a[5], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] += (double)a[q][r];  // f32 within an image, f64 across images
+  }
+  // fold the four waves (fixed order) tile by tile; D fragment: lane holds rows 4*fk + r, column fi
+  double* out = part + (size_t)blockIdx.x * 6 * 256;
+  for (int q = 0; q < 6; ++q)
+    for (int r = 0; r < 4; ++r) {
+      __syncthreads();
+      fold[w][lane] = acc[q][r];
+      __syncthreads();
+      if (w == 0) out[q * 256 + (4 * fk + r) * 16 + fi] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
+    }
+}
+
+// gram[s][t] (37 x 37, symmetric, f64) from the per-workgroup tile partials
+__global__ __launch_bounds__(256) void image_gram_finalize_kernel(const double* part, int rows, double* gram) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 6 * 256) return;
+  double t = 0.0;
+  for (int r = 0; r < rows; ++r) t += part[(size_t)r * 6 * 256 + e];
+  const int q = e >> 8, i = (e >> 4) & 15, j = e & 15;
+  const int bi = q < 3 ? 0 : (q < 5 ? 1 : 2), bj = q < 3 ? q : (q < 5 ? q - 2 : 2);
+  const int s = 16 * bi + i, u = 16 * bj + j;
+  if (s < NTAP && u < NTAP) {
+    gram[s * NTAP + u] = t;
+    if (bi != bj) gram[u * NTAP + s] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv1 weight gradient, sparse part: A[c][t] = sum over images and pooled cells of G1c[c][cell] * patch[pos(code)][t].
+// MFMA with K = the four positions of one pooling window: the A operand of lane (c = fi, k = fk) is the cell's gradient
+// if the saved argmax code equals fk, else 0 (lane-local); B = patch values from the LDS image.  Three N tiles
+// (taps 0-15, 16-31, 32-35 + pad).  Wave w takes cells w, w+4, ...
+template <int C>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(int B, const float* __restrict__ img, const float* __restrict__ G1c,
+                                                          const unsigned char* __restrict__ code1, double* part /*[grid][C*36]*/) {
+  __shared__ __attribute__((aligned(16))) float imgp[ILDS];
+  __shared__ float gs[16 * 256];
+  __shared__ unsigned char cs[16 * 256];
+  __shared__ double fold[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fi = lane & 15, fk = lane >> 4;
+  for (int i = tid; i < ILDS; i += 256) imgp[i] = 0.f;
+  for (int i = tid; i < 16 * 256; i += 256) { gs[i] = 0.f; cs[i] = 0; }
+  // B operand: lane (k = fk = window element, j = fi = tap 16*blk + fi): image offset of that tap at that element
+  int boff[3];
+#pragma unroll
+  for (int blk = 0; blk < 3; ++blk) {
+    const int t = 16 * blk + fi;
+    boff[blk] = t < 36 ? (t / 9) * IPLANE + ((t % 9) / 3 + (fk >> 1)) * ILD + (t % 3) + (fk & 1) : -1;
+  }
+  double acc[3][4];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
+  __syncthreads();
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    stage_image(img + (size_t)b * 4 * IPIX, imgp);
+    for (int i = tid; i < C * 256; i += 256) {
+      gs[i] = G1c[(size_t)b * C * 256 + i];
+      cs[i] = code1[(size_t)b * C * 256 + i];
+    }
+    __syncthreads();
+    f32x4 a[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int cell = w; cell < 256; cell += 4) {
+      const int py = cell >> 4, px = cell & 15;
+      const float g = (int)cs[fi * 256 + cell] == fk ? gs[fi * 256 + cell] : 0.f;  // rows fi >= C hold zeros
+      const int base = 2 * py * ILD + 2 * px;
+#pragma unroll
+      for (int blk = 0; blk < 3; ++blk) {
+        const float bv = boff[blk] >= 0 ? imgp[base + boff[blk]] : 0.f;
+        a[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(g, bv, a[blk], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] += (double)a[q][r];
+  }
+  // D fragment: lane holds rows c = 4*fk + r, column tap = 16*blk + fi
+  double* out = part + (size_t)blockIdx.x * C * 36;
+  for (int q = 0; q < 3; ++q)
+    for (int r = 0; r < 4; ++r) {
+      __syncthreads();
+      fold[w][lane] = acc[q][r];
+      __syncthreads();
+      const int c = 4 * fk + r, t = 16 * q + fi;
+      if (w == 0 && c < C && t < 36) out[c * 36 + t] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
+    }
+}
+
+// dW[c][t] += cs_c * (A[c][t] - m1_c * Bt[t] - m2_c * Chat[c][t])   (one workgroup per output channel, f64)
+// coefd = [cs | S1 | S2 | mean | invstd] (C each) + count, written by the BatchNorm-1 backward finalize
+__global__ __launch_bounds__(256) void conv1_wgrad_finalize_kernel(const double* part, int rows, int C,
+                                                                   const double* __restrict__ gram,
+                                                                   const float* __restrict__ W, const float* __restrict__ bias,
+                                                                   const double* __restrict__ coefd, float* dW) {
+  __shared__ double red[7][36];
+  const int c = blockIdx.x, t = threadIdx.x % 36, rg = threadIdx.x / 36;
+  if (rg < 7) {
+    double s = 0.0;
+    for (int r = rg; r < rows; r += 7) s += part[(size_t)r * C * 36 + c * 36 + t];
+    red[rg][t] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 36) return;
+  double A = 0.0;
+  for (int i = 0; i < 7; ++i) A += red[i][t];
+  const double cs = coefd[c], S1 = coefd[C + c], S2 = coefd[2 * C + c], mean = coefd[3 * C + c], inv = coefd[4 * C + c];
+  const double n = coefd[5 * C];
+  const double Bt = gram[36 * NTAP + t];
+  double wp = 0.0;
+  for (int s = 0; s < 36; ++s) wp += (double)W[c * 36 + s] * gram[s * NTAP + t];
+  const double chat = (wp + ((double)bias[c] - mean) * Bt) * inv;
+  dW[c * 36 + t] += (float)(cs * (A - (S1 / n) * Bt - (S2 / n) * chat));
+}
+
+static int grid_for(int B, int cap) { return B < cap ? B : cap; }
+
+extern "C" {
+
+int mggan_cnn_grid(int B) { return grid_for(B, 1024); }
+
+static BnFin make_fin(unsigned* ticket, double count, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                      long long* nbt, float momentum, float eps, int updates, float* scale, float* shift, float* stat) {
+  BnFin f;
+  f.ticket = ticket; f.count = count; f.gamma = gamma; f.beta = beta; f.run_mean = run_mean; f.run_var = run_var;
+  f.nbt = nbt; f.momentum = momentum; f.eps = eps; f.updates = updates; f.scale = scale; f.shift = shift; f.stat = stat;
+  return f;
+}
+
+int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float* bias, float* xmax, float* xmin,
+                     unsigned char* code, double* part, unsigned* ticket, double count, const float* gamma,
+                     const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
+                     float eps, int updates, float* scale, float* shift, float* stat, hipStream_t stream) {
+  MG_CHECK_ARG(C == 8 || C == 16, "conv1_pool: channels %d not built (8 or 16)", C);
+  if (B == 0) return MGGAN_OK;
+  MG_CHECK_ARG(img && W && bias && xmax && xmin && code && part, "conv1_pool: null pointer");
+  MG_CHECK_ARG(!ticket || (gamma && beta && run_mean && run_var && num_batches_tracked && scale && shift && stat),
+               "conv1_pool: the fused finalize needs the BatchNorm tensors");
+  const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
+                             scale, shift, stat);
+  const int grid = grid_for(B, 1024);
+  if (C == 16) hipLaunchKernelGGL((conv1_pool_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, xmax, xmin, code, part, fin);
+  else hipLaunchKernelGGL((conv1_pool_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, xmax, xmin, code, part, fin);
+  MG_LAUNCH_CHECK("conv1_pool");
+  return MGGAN_OK;
+}
+
+int mggan_conv2_fwd2(const float* xmax, const float* xmin, int B, int C, const float* scale1, const float* shift1,
+                     const float* W, const float* bias, float* y2, double* part, unsigned* ticket, double count,
+                     const float* gamma, const float* beta, float* run_mean, float* run_var,
+                     long long* num_batches_tracked, float momentum, float eps, int updates, float* scale, float* shift,
+                     float* stat, hipStream_t stream) {
+  MG_CHECK_ARG(C == 8 || C == 16, "conv2_fwd2: channels %d not built (8 or 16)", C);
+  if (B == 0) return MGGAN_OK;
+  MG_CHECK_ARG(xmax && xmin && scale1 && shift1 && W && bias && y2 && part, "conv2_fwd2: null pointer");
+  MG_CHECK_ARG(!ticket || (gamma && beta && run_mean && run_var && num_batches_tracked && scale && shift && stat),
+               "conv2_fwd2: the fused finalize needs the BatchNorm tensors");
+  const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
+                             scale, shift, stat);
+  const int grid = grid_for(B, 1024);
+  if (C == 16) hipLaunchKernelGGL((conv2_fwd2_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xmax, xmin, scale1, shift1, W, bias, y2, part, fin);
+  else hipLaunchKernelGGL((conv2_fwd2_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xmax, xmin, scale1, shift1, W, bias, y2, part, fin);
+  MG_LAUNCH_CHECK("conv2_fwd2");
+  return MGGAN_OK;
+}
+
+int mggan_bn_reduce_rows(const double* part, int rows, int W, double* sums, hipStream_t stream) {
+  MG_CHECK_ARG(part && sums && W > 0 && W <= 32, "bn_reduce_rows: bad arguments");
+  hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(1), dim3(256), 0, stream, part, rows, W, sums);
+  MG_LAUNCH_CHECK("bn_reduce_rows");
+  return MGGAN_OK;
+}
+
+static BnBwdFin make_bfin(unsigned* ticket, double count, const float* gamma, const float* stat, float* coef, double* coefd,
+                          float* dgamma, float* dbeta) {
+  BnBwdFin f;
+  f.ticket = ticket; f.count = count; f.gamma = gamma; f.stat = stat; f.coef = coef; f.coefd = coefd; f.dgamma = dgamma;
+  f.dbeta = dbeta;
+  return f;
+}
+
+int mggan_bn_bwd_rows_finalize(const double* part, int rows, double count, int C, const float* gamma, const float* stat,
+                               float* coef, double* coefd, float* dgamma, float* dbeta, hipStream_t stream) {
+  MG_CHECK_ARG(part && gamma && stat && coef && dgamma && dbeta && C <= 16, "bn_bwd_rows_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_rows_finalize_kernel, dim3(1), dim3(256), 0, stream, part, rows, C,
+                     make_bfin(nullptr, count, gamma, stat, coef, coefd, dgamma, dbeta));
+  MG_LAUNCH_CHECK("bn_bwd_rows_finalize");
+  return MGGAN_OK;
+}
+
+int mggan_bn_bwd_coef(const double* sums, const double* local_sums, double count, int C, const float* gamma,
+                      const float* stat, float* coef, double* coefd, float* dgamma, float* dbeta, hipStream_t stream) {
+  MG_CHECK_ARG(sums && local_sums && gamma && stat && coef && dgamma && dbeta && C <= 16, "bn_bwd_coef: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(1), dim3(64), 0, stream, sums, local_sums, C,
+                     make_bfin(nullptr, count, gamma, stat, coef, coefd, dgamma, dbeta));
+  MG_LAUNCH_CHECK("bn_bwd_coef");
+  return MGGAN_OK;
+}
+
+/* workspace: mggan_cnn_grid(B) * 1536 doubles */
+int mggan_image_gram(const float* img, int B, double* gram, double* workspace, size_t workspace_bytes,
+                     hipStream_t stream) {
+  MG_CHECK_ARG(gram && workspace && (img || B == 0), "image_gram: null pointer");
+  const int grid = grid_for(B, 1024);
+  MG_CHECK_ARG(workspace_bytes >= (size_t)(grid > 0 ? grid : 1) * 6 * 256 * sizeof(double), "image_gram: workspace too small");
+  if (grid > 0) hipLaunchKernelGGL(image_gram_kernel, dim3(grid), dim3(256), 0, stream, B, img, workspace);
+  hipLaunchKernelGGL(image_gram_finalize_kernel, dim3(6), dim3(256), 0, stream, workspace, grid, gram);
+  MG_LAUNCH_CHECK("image_gram");
+  return MGGAN_OK;
+}
+
+/* workspace: mggan_cnn_grid(B) * C * 36 doubles; dW (C,4,3,3) is ACCUMULATED into */
+int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const unsigned char* code1, const double* gram,
+                      const float* W, const float* bias, const double* coefd, float* dW, double* workspace,
+                      size_t workspace_bytes, hipStream_t stream) {
+  MG_CHECK_ARG(C == 8 || C == 16, "conv1_wgrad: channels %d not built (8 or 16)", C);
+  if (B == 0) return MGGAN_OK;
+  MG_CHECK_ARG(img && G1c && code1 && gram && W && bias && coefd && dW && workspace, "conv1_wgrad: null pointer");
+  const int grid = grid_for(B, 1024);
+  MG_CHECK_ARG(workspace_bytes >= (size_t)grid * C * 36 * sizeof(double), "conv1_wgrad: workspace too small");
+  if (C == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace);
+  else hipLaunchKernelGGL((conv1_wgrad_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace);
+  hipLaunchKernelGGL(conv1_wgrad_finalize_kernel, dim3(C), dim3(256), 0, stream, workspace, grid, C, gram, W, bias, coefd, dW);
+  MG_LAUNCH_CHECK("conv1_wgrad");
+  return MGGAN_OK;
+}
+
+}  // extern "C"

@@ -89,6 +89,9 @@ class MultiGeneratorGAN(abc.ABC):
             self.rng.plan = (1, self.config.num_samples, self.config.num_expectation_samples)
             self.rng.d_steps = self.config.num_unrolling_steps + 1
             self.rng.begin_iteration(sub_batches, b, self.config.noise_dim, self.device)
+        from mggan.hip import functions as HF
+
+        HF.begin_images(img)  # the Gram matrix of the image patches (conv1 weight gradients) starts beside the forward pass
         cfg = self.config
         run_d = self.total_iterations % max(int(cfg.num_gen_steps), 1) == 0 or self.epoch >= cfg.keep_gen_steps
         shared = None
@@ -110,6 +113,7 @@ class MultiGeneratorGAN(abc.ABC):
             self.generator_step(*args, shared=shared)
             self.net_chooser_step(*args)
         finally:
+            HF.end_images()
             if hasattr(self, "_close_iteration"):
                 self._close_iteration()
         self.total_iterations += 1

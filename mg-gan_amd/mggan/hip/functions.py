@@ -1032,8 +1032,73 @@ class PoolHiddenFn(Function):
         return (None, dh) + (None,) * 10
 
 
+# Gram matrices of the image patches (csrc/cnn2.hip: image_gram_kernel): the image-only part of every conv1 weight
+# gradient of a batch.  The trainer announces the batch's images at the start of an iteration (begin_images): ONE launch
+# on a side stream serves the backward passes of both scene CNNs; a backward pass that finds no announced Gram matrix
+# (a stand-alone call) computes it on the spot.
+_GRAM = {"reg": {}, "stream": None}
+
+
+def _gram_launch(img):
+    B = img.shape[0]
+    gram = torch.empty(37 * 37, dtype=torch.float64, device=img.device)
+    nb = max(lib.mggan_cnn_grid(B), 1) * 1536 * 8
+    ws = torch.empty(nb // 8, dtype=torch.float64, device=img.device)
+    lib.mggan_image_gram(_p(img), B, _p(gram), _p(ws), nb, _s())
+    return gram, ws
+
+
+def begin_images(img, side=True):
+    """Start the Gram matrix of this batch's image crops (B,4,33,33) beside the forward pass."""
+    _GRAM["reg"].clear()
+    if img is None or not img.is_cuda or img.shape[0] == 0:
+        return
+    img = img.contiguous()
+    if side and _BR["on"]:
+        if _GRAM["stream"] is None:
+            _GRAM["stream"] = torch.cuda.Stream()
+        st = _GRAM["stream"]
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            gram, ws = _gram_launch(img)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        _GRAM["reg"][img.data_ptr()] = (gram, ws, ev, img)
+    else:
+        gram, ws = _gram_launch(img)
+        _GRAM["reg"][img.data_ptr()] = (gram, ws, None, img)
+
+
+def end_images():
+    """The side stream of the Gram launch joins the current stream (every fork has to be joined before a capture ends)."""
+    st = _GRAM["stream"]
+    if st is not None and any(e[2] is not None for e in _GRAM["reg"].values()):
+        torch.cuda.current_stream().wait_stream(st)
+    _GRAM["reg"].clear()
+
+
+def _image_gram(img):
+    hit = _GRAM["reg"].get(img.data_ptr())
+    if hit is not None and hit[3].shape == img.shape:
+        if hit[2] is not None:
+            torch.cuda.current_stream().wait_event(hit[2])
+            hit[0].record_stream(torch.cuda.current_stream())
+        return hit[0]
+    return _gram_launch(img)[0]
+
+
+def _cnn_tickets(owner, dev):
+    t = owner.__dict__.get("_cnn_tickets")
+    if t is None or t.device != dev:
+        t = owner.__dict__["_cnn_tickets"] = torch.zeros(8, dtype=torch.int32, device=dev)
+    return t
+
+
 class SceneAttentionFn(Function):
-    """CNN (2 x Conv-BN-ReLU-MaxPool) + channel-softmax attention -> (B,64)  (cnn.py:109-282)."""
+    """CNN (2 x Conv-BN-ReLU-MaxPool) + channel-softmax attention -> (B,64)  (cnn.py:109-282).
+    Forward: conv1 + pooling decision -> conv2 -> attention (three launches, BatchNorm finalized by the producing
+    kernel's last workgroup).  Backward: attention adjoint -> conv2 adjoint -> conv1 weight gradient + its f64 finalize.
+    Saved for backward per image: raw window maximum / minimum and positions (36 KB), raw conv2 output (C KB)."""
 
     @staticmethod
     def forward(ctx, img, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb, bb, bn1, bn2, training, owner, sync, save,
@@ -1041,37 +1106,43 @@ class SceneAttentionFn(Function):
         img = img.contiguous()
         B, C = img.shape[0], c1w.shape[0]
         st = _s()
-        y1 = _empty(B, C, 33, 36, like=img)  # raw conv1 output, rows padded to 36 floats (csrc/cnn.hip:Y1_LD)
-        part = _empty(max(B, 1), 2 * C, like=img)
-        lib.mggan_conv1_fwd(_p(img), B, C, _p(c1w), _p(c1b), _p(y1), _p(part), st)
-        n_img = float(B)
+        dev = img.device
+        tk = _cnn_tickets(owner, dev)
+        grid = max(lib.mggan_cnn_grid(B), 1)
+        xmax, xmin = _empty(B, C, 16, 16, like=img), _empty(B, C, 16, 16, like=img)
+        code = torch.empty(B, C, 16, 16, dtype=torch.uint8, device=dev)
+        part = torch.empty(grid, 2 * C, dtype=torch.float64, device=dev)
+        fused = training and sync is None  # single GPU: the kernel's last workgroup finalizes BatchNorm itself
+        mk = lambda: (_empty(C, like=img), _empty(C, like=img), _empty(2 * C, like=img))
 
-        def finalize(bn, gamma, beta, hw):
-            sums = None
-            n = n_img
-            if training and sync is None:  # single GPU: column sums + finalize (+ repeated stat updates) in one launch
-                scale, shift, stat = _empty(C, like=img), _empty(C, like=img), _empty(2 * C, like=img)
-                lib.mggan_bn_stats_finalize(_p(part), B, n * hw, C, _p(gamma), _p(beta), _p(bn.running_mean),
-                                            _p(bn.running_var), _p(bn.num_batches_tracked), float(bn.momentum),
-                                            float(bn.eps), stat_updates, _p(scale), _p(shift), _p(stat), st)
-                return scale, shift, stat, n * hw
+        def bn_args(bn, gamma, beta, hw, k, out3):
+            return (tk.data_ptr() + 4 * k if fused else 0, float(B) * hw, _p(gamma), _p(beta), _p(bn.running_mean),
+                    _p(bn.running_var), _p(bn.num_batches_tracked), float(bn.momentum), float(bn.eps), stat_updates,
+                    _p(out3[0]), _p(out3[1]), _p(out3[2]))
+
+        def finalize_unfused(bn, gamma, beta, hw, out3):
+            """eval mode (running statistics) or sharded training (sums all-reduced over the ranks first)"""
+            sums, n = None, float(B)
             if training:
-                sums = torch.empty(2 * C, dtype=torch.float64, device=img.device)
-                lib.mggan_bn_reduce(_p(part), B, 2 * C, _p(sums), st)
-                if sync is not None:
-                    n = sync.all_reduce_stats(sums, n_img)
-            scale, shift, stat = _empty(C, like=img), _empty(C, like=img), _empty(2 * C, like=img)
-            # stat_updates > 1: this one forward stands for several identical reference forwards (shared
-            # history context) -> the running statistics take the momentum update that many times (A.8)
+                sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+                lib.mggan_bn_reduce_rows(_p(part), grid if B else 0, 2 * C, _p(sums), st)
+                n = sync.all_reduce_stats(sums, float(B))
             lib.mggan_bn_finalize(_p(sums), n * hw, C, stat_updates if training else 0, _p(gamma), _p(beta),
-                                  _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked),
-                                  float(bn.momentum), float(bn.eps), _p(scale), _p(shift), _p(stat), st)
-            return scale, shift, stat, n * hw
+                                  _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), float(bn.momentum),
+                                  float(bn.eps), _p(out3[0]), _p(out3[1]), _p(out3[2]), st)
+            return n * hw
 
-        sc1, sh1, stat1, cnt1 = finalize(bn1, g1, be1, 33 * 33)
+        b1 = mk()
+        lib.mggan_conv1_pool(_p(img), B, C, _p(c1w), _p(c1b), _p(xmax), _p(xmin), _p(code), _p(part),
+                             *bn_args(bn1, g1, be1, 33 * 33, 0, b1), st)
+        cnt1 = float(B) * 33 * 33 if fused else finalize_unfused(bn1, g1, be1, 33 * 33, b1)
+        sc1, sh1, stat1 = b1
         y2 = _empty(B, C, 16, 16, like=img)
-        lib.mggan_conv2_fwd(_p(y1), B, C, _p(sc1), _p(sh1), _p(c2w), _p(c2b), _p(y2), _p(part), st)
-        sc2, sh2, stat2, cnt2 = finalize(bn2, g2, be2, 16 * 16)
+        b2 = mk()
+        lib.mggan_conv2_fwd2(_p(xmax), _p(xmin), B, C, _p(sc1), _p(sh1), _p(c2w), _p(c2b), _p(y2), _p(part),
+                             *bn_args(bn2, g2, be2, 16 * 16, 1, b2), st)
+        cnt2 = float(B) * 16 * 16 if fused else finalize_unfused(bn2, g2, be2, 16 * 16, b2)
+        sc2, sh2, stat2 = b2
         out, ld_o = _out(out_slot, B, 64, img)
         lib.mggan_scene_attention_fwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(wa), _p(ba), _p(wb), _p(bb), _p(out), ld_o, st)
         if save:
@@ -1079,71 +1150,76 @@ class SceneAttentionFn(Function):
                 raise RuntimeError("scene attention backward is only implemented for train-mode BatchNorm "
                                    "(the reference never differentiates in eval mode)")
             ctx.owner, ctx.sync, ctx.counts = owner, sync, (cnt1, cnt2)
-            ctx.save_for_backward(img, y1, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa,
-                                  ba, wb, bb)
+            ctx.save_for_backward(img, xmax, xmin, code, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b,
+                                  g2, be2, wa, ba, wb, bb)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (img, y1, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb,
+        (img, xmax, xmin, code, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb,
          bb) = ctx.saved_tensors
         root, sync = root_of(ctx.owner), ctx.sync
         cnt1, cnt2 = ctx.counts
         B, C = img.shape[0], c1w.shape[0]
         st = _s()
+        dev = img.device
+        tk = _cnn_tickets(ctx.owner, dev)
+        fused = sync is None
         dout, ld = _rows2d(dout)
         rows = B * 64
         ds, vs = _empty(C, rows, like=img), _empty(C, rows, like=img)        # feature-major [feature][row]
         hact, dz = _empty(32, rows, like=img), _empty(32, rows, like=img)
         G2 = _empty(B, C, 16, 16, like=img)
-        part = _empty(B, 2 * C, like=img)
+        rows2 = max((B + 3) // 4, 1)
+        part2 = torch.empty(rows2, 2 * C, dtype=torch.float64, device=dev)
+        coef2 = _empty(3 * C, like=img)
         lib.mggan_scene_attention_bwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(stat2), _p(wa), _p(ba), _p(wb), _p(bb), _p(dout),
-                                      ld, _p(ds), _p(hact), _p(dz), _p(vs), _p(G2), _p(part), st)
+                                      ld, _p(ds), _p(hact), _p(dz), _p(vs), _p(G2), _p(part2),
+                                      tk.data_ptr() + 8 if fused else 0, cnt2, _p(g2), _p(coef2), root.grad_ptr(g2),
+                                      root.grad_ptr(be2), st)
         with side_stream(ds, hact, dz, vs):
             wgrad(ds, rows, hact, rows, root.grad_ptr(wb), 32, root.grad_ptr(bb), rows, 32, C, fm=1)
             wgrad(dz, rows, vs, rows, root.grad_ptr(wa), C, root.grad_ptr(ba), rows, C, 32, fm=1)
 
-        def bn_bwd(gamma, beta, stat, cnt):
-            if sync is None:
-                coef = _empty(3 * C, like=img)
-                lib.mggan_bn_bwd_stats_finalize(_p(part), B, cnt, C, _p(gamma), _p(stat), _p(coef), root.grad_ptr(gamma),
-                                                root.grad_ptr(beta), st)
-                return coef
-            sums = torch.empty(2 * C, dtype=torch.float64, device=img.device)
-            lib.mggan_bn_reduce(_p(part), B, 2 * C, _p(sums), st)
-            local = sums
-            if sync is not None:
-                local = sums.clone()
-                sync.all_reduce_(sums)
-            coef = _empty(3 * C, like=img)
-            lib.mggan_bn_bwd_finalize(_p(sums), _p(local), cnt, C, _p(gamma), _p(stat), _p(coef), root.grad_ptr(gamma),
-                                      root.grad_ptr(beta), st)
-            return coef
+        def bn_bwd_sharded(part, nrows, gamma, beta, stat, cnt, coef, coefd):
+            sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+            lib.mggan_bn_reduce_rows(_p(part), nrows if B else 0, 2 * C, _p(sums), st)
+            local = sums.clone()
+            sync.all_reduce_(sums)
+            lib.mggan_bn_bwd_coef(_p(sums), _p(local), cnt, C, _p(gamma), _p(stat), _p(coef), _p(coefd),
+                                  root.grad_ptr(gamma), root.grad_ptr(beta), st)
 
-        coef2 = bn_bwd(g2, be2, stat2, cnt2)
+        if not fused:
+            bn_bwd_sharded(part2, rows2, g2, be2, stat2, cnt2, coef2, None)
         G1c = _empty(B, C, 16, 16, like=img)
-        code1 = torch.empty(B, C, 16, 16, dtype=torch.uint8, device=img.device)
+        code1 = torch.empty(B, C, 16, 16, dtype=torch.uint8, device=dev)
         grid = lib.mggan_cnn_bwd_grid(B)
         nb = grid * (256 // (C * C)) * (C * C * 9 + C) * 4
         ws = _empty(nb // 4, like=img)
+        part1 = torch.empty(max(grid, 1), 2 * C, dtype=torch.float64, device=dev)
+        coef1 = _empty(3 * C, like=img)
+        coefd1 = torch.empty(5 * C + 1, dtype=torch.float64, device=dev)
         defer = _DEFER["on"]
         pw, pb = root.grad_ptr(c2w), root.grad_ptr(c2b)
-        lib.mggan_conv2_bwd(_p(y1), B, C, _p(sc1), _p(sh1), _p(stat1), _p(y2), _p(G2), _p(stat2), _p(coef2), _p(c2w),
-                            _p(G1c), _p(code1), _p(part), 0 if defer else pw, 0 if defer else pb, _p(ws), nb, st)
+        lib.mggan_conv2_bwd(_p(xmax), _p(xmin), _p(code), B, C, _p(sc1), _p(sh1), _p(stat1), _p(y2), _p(G2), _p(stat2),
+                            _p(coef2), _p(c2w), _p(G1c), _p(code1), _p(part1), 0 if defer else pw, 0 if defer else pb,
+                            _p(ws), nb, tk.data_ptr() + 12 if fused else 0, cnt1, _p(g1), _p(coef1), _p(coefd1),
+                            root.grad_ptr(g1), root.grad_ptr(be1), st)
         if defer:
             wl = C * C * 9 + C
             _queue_reduce(ws.data_ptr(), pw, 0, 1, C * C * 9, 0, C * C * 9, grid, 1, wl, keep=(ws,))
             _queue_reduce(ws.data_ptr() + 4 * C * C * 9, pb, 0, 1, C, 0, C, grid, 1, wl)
-        coef1 = bn_bwd(g1, be1, stat1, cnt1)
-        nb = grid * 8 * (4 * C * 9 + C) * 4
-        ws = _empty(nb // 4, like=img)
-        pw, pb = root.grad_ptr(c1w), root.grad_ptr(c1b)
-        lib.mggan_conv1_bwd(_p(img), B, C, _p(y1), _p(stat1), _p(coef1), _p(G1c), _p(code1), 0 if defer else pw,
-                            0 if defer else pb, _p(ws), nb, st)
-        if defer:
-            wl = 4 * C * 9 + C
-            _queue_reduce(ws.data_ptr(), pw, 0, 1, 4 * C * 9, 0, 4 * C * 9, grid, 1, wl, keep=(ws,))
-            _queue_reduce(ws.data_ptr() + 4 * 4 * C * 9, pb, 0, 1, C, 0, C, grid, 1, wl)
+        if not fused:
+            bn_bwd_sharded(part1, grid, g1, be1, stat1, cnt1, coef1, coefd1)
+        # conv1: the image needs no gradient; dW1 from the sparse routed gradients and the batch's Gram matrix (f64);
+        # db1 is identically zero in front of a train-mode BatchNorm (the slot is attached: the reference's set of
+        # touched parameters includes it)
+        root.grad_ptr(c1b)
+        gram = _image_gram(img)
+        nbw = max(lib.mggan_cnn_grid(B), 1) * C * 36 * 8
+        wsw = torch.empty(nbw // 8, dtype=torch.float64, device=dev)
+        lib.mggan_conv1_wgrad(_p(img), B, C, _p(G1c), _p(code1), _p(gram), _p(c1w), _p(c1b), _p(coefd1), root.grad_ptr(c1w),
+                              _p(wsw), nbw, st)
         return (None,) * 21
 
 

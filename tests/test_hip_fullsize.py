@@ -75,12 +75,36 @@ def _snapshot_steps(tr):
 FULL_SIZES = [pytest.param(64, 20, 4, id="configs1-64x20-g4"), pytest.param(256, 32, 8, id="configs2-256x32-g8")]
 
 
+def _oracle_iteration(tro, batch, steps, labels, dtype):
+    """D, G, PM step of the oracle with the recorded draws -> (metrics, {step: {param: clipped gradient}})."""
+    m_cpu, grads = defaultdict(list), {}
+    b = batch["in_xy"].shape[1]
+    mask = torch.ones(b, dtype=torch.bool)
+    cpu_args = tuple(batch[k].to(dtype) for k in ("in_xy", "in_dxdy", "gt_xy", "gt_dxdy")) + (batch["seq_start_end"],)
+    for (step, (noise, idx)), lab in zip(zip(("discriminator_step", "generator_step", "net_chooser_step"), steps),
+                                         ((labels[0], labels[1]), (labels[2], labels[2]), (labels[2], labels[2]))):
+        draws = {"noise": noise.to(dtype), "gen_idxs": idx, "labels": lab[0], "labels1": lab[0], "labels2": lab[1]}
+        getattr(tro, step)(*cpu_args, m_cpu, mask, batch["features"].to(dtype), draws=draws)
+        ref_mod = tro.D if step == "discriminator_step" else tro.G
+        grads[step] = {n: q.grad.detach().clone() for n, q in ref_mod.named_parameters() if q.grad is not None}
+    return m_cpu, grads
+
+
 @pytest.mark.parametrize("scenes,peds,g", FULL_SIZES)
 def test_full_size_iteration_matches_oracle(scenes, peds, g):
     """One D+G+PM iteration (the de-duplicated train_iteration path bench.py measures) against the oracle in
-    block-diagonal mode: every logged loss rtol 1e-3, every parameter gradient of every step per tensor
-    (relL2 1e-3 + element-wise 1e-3 of the tensor's largest entry, SURVEY A.12 iii), post-step parameters relL2 1e-3."""
-    from helpers import assert_grad_close
+    block-diagonal mode: every logged loss rtol 1e-3 and the post-step parameters relL2 1e-3 against the f32 oracle (the
+    reference's arithmetic); every parameter gradient of every step per tensor (relL2 1e-3 + element-wise 1e-3 of the
+    tensor's largest entry, SURVEY A.12 iii) against the SAME oracle evaluated in f64.  Why f64 for the gradients: at
+    these batch sizes the f32 CPU path is itself up to 1.2e-3 away from the exact value of the gradients that pass
+    through the train-mode BatchNorm of the scene CNN (measured: conv1 weight, PM step, 8,192 pedestrians: f32 oracle
+    vs f64 1.19e-3, HIP vs f64 7.7e-4) -- a comparison of two f32 evaluations at 1e-3 would test the oracle's noise.
+    The f32 oracle's own distance to f64 is checked alongside: the HIP path must not be the less accurate of the two
+    by more than the tolerance."""
+    import copy
+
+    import mggan_oracle as O
+    from helpers import assert_grad_close, rel_l2
     from mggan.data_utils import synthetic
 
     K = 20
@@ -89,28 +113,23 @@ def test_full_size_iteration_matches_oracle(scenes, peds, g):
     steps = _draws(sizes, g, K, torch.Generator().manual_seed(5))
     labels = [(0.95, 0.05), (0.93, 0.07), (0.97, 0.02)]
     tr, tro = _trainers(g)
+    tro64 = O.OracleTrainer(copy.deepcopy(tro.G).double(), copy.deepcopy(tro.D).double(), mode="block")
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     gpu_grads = _snapshot_steps(tr)
     m_gpu = _iteration(tr, batch, steps, labels)
-    # the oracle takes its draws per step
-    m_cpu = defaultdict(list)
-    b = sum(sizes)
-    mask = torch.ones(b, dtype=torch.bool)
-    cpu_args = (batch["in_xy"], batch["in_dxdy"], batch["gt_xy"], batch["gt_dxdy"], batch["seq_start_end"])
-    for (step, (noise, idx)), lab in zip(zip(("discriminator_step", "generator_step", "net_chooser_step"), steps),
-                                         ((labels[0], labels[1]), (labels[2], labels[2]), (labels[2], labels[2]))):
-        draws = {"noise": noise, "gen_idxs": idx, "labels": lab[0], "labels1": lab[0], "labels2": lab[1]}
-        getattr(tro, step)(*cpu_args, m_cpu, mask, batch["features"], draws=draws)
-        ref_mod = tro.D if step == "discriminator_step" else tro.G
-        ref = {n: q.grad for n, q in ref_mod.named_parameters() if q.grad is not None}
+    m_cpu, g32 = _oracle_iteration(tro, batch, steps, labels, torch.float32)
+    _, g64 = _oracle_iteration(tro64, batch, steps, labels, torch.float64)
+    for step, ref in g64.items():
         got = gpu_grads[step]
         assert set(got) == set(ref), (step, sorted(set(got) ^ set(ref)))
         group = max(float(v.abs().max()) for v in ref.values())
         for n, r in ref.items():
             if float(r.abs().max()) < 1e-4 * group:  # structurally zero up to round-off (conv bias before BatchNorm)
                 assert float(got[n].abs().max()) <= 1e-3 * group, (step, n)
-            else:
-                assert_grad_close(got[n], r, "{}:{}".format(step, n))
+                continue
+            assert_grad_close(got[n], r, "{}:{}".format(step, n))
+            ours, theirs = rel_l2(got[n], r), rel_l2(g32[step][n], r)
+            assert ours <= theirs + 1e-3, (step, n, ours, theirs)
     for key, v in m_cpu.items():  # losses: rtol 1e-3 (SURVEY A.12 ii)
         assert abs(m_gpu[key][0] - v[0]) <= 1e-3 * abs(v[0]) + 1e-6, (key, m_gpu[key][0], v[0])
     for mod, ref in ((tr.G, tro.G), (tr.D, tro.D)):  # post-step parameters: relL2 1e-3 (A.12 iv)
