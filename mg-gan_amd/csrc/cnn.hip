@@ -33,35 +33,50 @@ __device__ __forceinline__ void load6(const float* p, float r[6]) {
   r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y;
 }
 
-// fixed-order f64 column sums of `rows` partial rows of width W (<= 32) by one 256-thread workgroup
-__device__ __forceinline__ void colsum_rows(const double* part, int rows, int W, double* colsum, double* red /*[8][32]*/) {
-  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+// Partial rows travel between workgroups as agent-scope 8-byte atomics (write-through to the coherence point on the
+// producer side, L1-bypassing loads on the consumer side): no release fence, i.e. no write-back of the whole XCD L2
+// per workgroup.  -> true for the workgroup that arrives last (every row is then readable through load_part).
+__device__ __forceinline__ void store_part(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ double load_part(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// fixed-order f64 column sums of `rows` partial rows of width W (<= 32) by one 256-thread workgroup -> colsum[W] (LDS).
+// 8 (W > 16) or 16 row groups; every lane keeps 8 independent loads in flight (a lone workgroup has to hide the
+// memory latency by itself) and adds them in a fixed order.
+__device__ __forceinline__ void colsum_rows(const double* part, int rows, int W, double* colsum, double* red /*[8*32]*/) {
+  const int wp = W > 16 ? 32 : 16, ng = 256 / wp;
+  const int col = threadIdx.x % wp, rg = threadIdx.x / wp;
   double acc = 0.0;
-  if (col < W)
-    for (int r = rg; r < rows; r += 8) acc += __builtin_nontemporal_load(part + (size_t)r * W + col);
-  red[rg * 32 + col] = acc;
+  if (col < W) {
+    int r = rg;
+    for (; r + 7 * ng < rows; r += 8 * ng) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = load_part(part + (size_t)(r + u * ng) * W + col);
+      acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < rows; r += ng) acc += load_part(part + (size_t)r * W + col);
+  }
+  red[rg * wp + col] = acc;
   __syncthreads();
   if ((int)threadIdx.x < W) {
     double t = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t += red[i * 32 + threadIdx.x];
+    for (int i = 0; i < ng; ++i) t += red[i * wp + threadIdx.x];
     colsum[threadIdx.x] = t;
   }
   __syncthreads();
 }
 
-// -> true for the workgroup that arrives last (every other workgroup's partial row is then visible to it)
 __device__ __forceinline__ bool last_block(unsigned* ticket, int* flag_lds) {
-  __syncthreads();
+  __syncthreads();  // every lane's store_part has completed (each waited for its own)
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = atomicAdd(ticket, 1u);
     *flag_lds = (t == gridDim.x - 1);
-    if (t == gridDim.x - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      *ticket = 0u;
-    }
+    if (t == gridDim.x - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
   }
   __syncthreads();
   return *flag_lds != 0;
@@ -250,8 +265,9 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
   // one partial row per workgroup (f32 within an image, f64 across); the last workgroup folds the rows
   __syncthreads();
   if ((int)threadIdx.x < 2 * C)
-    part[(size_t)blockIdx.x * 2 * C + threadIdx.x] = ((double)sred[0][threadIdx.x] + (double)sred[1][threadIdx.x]) +
-                                                      ((double)sred[2][threadIdx.x] + (double)sred[3][threadIdx.x]);
+    store_part(part + (size_t)blockIdx.x * 2 * C + threadIdx.x,
+               ((double)sred[0][threadIdx.x] + (double)sred[1][threadIdx.x]) +
+                   ((double)sred[2][threadIdx.x] + (double)sred[3][threadIdx.x]));
   if (!fin.ticket) return;
   if (!last_block(fin.ticket, &flag)) return;
   colsum_rows(part, gridDim.x, 2 * C, colsum, cred);
@@ -377,8 +393,8 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
   if (pg == 0) {
 #pragma unroll
     for (int ci = 0; ci < COT; ++ci) {
-      part1[(size_t)blockIdx.x * 2 * C + cg * COT + ci] = ds1[ci];
-      part1[(size_t)blockIdx.x * 2 * C + C + cg * COT + ci] = ds2[ci];
+      store_part(part1 + (size_t)blockIdx.x * 2 * C + cg * COT + ci, ds1[ci]);
+      store_part(part1 + (size_t)blockIdx.x * 2 * C + C + cg * COT + ci, ds2[ci]);
     }
   }
   // fold the NQ row-group partials in LDS (fixed order) -> one partial row per workgroup
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
     if (threadIdx.x < 32)  // [0,16) = sum g, [16,32) = sum g*xhat: f32 within an image, f64 across images
       dstat += (double)((red[threadIdx.x] + red[32 + threadIdx.x]) + (red[64 + threadIdx.x] + red[96 + threadIdx.x]));
   }
-  if (threadIdx.x < 32) part1[(size_t)blockIdx.x * 2 * C + threadIdx.x] = dstat;
+  if (threadIdx.x < 32) store_part(part1 + (size_t)blockIdx.x * 2 * C + threadIdx.x, dstat);
   // ---- fold the four waves' weight-gradient fragments; wacc[t][r] of lane l is dW[co = 4*fk + r][ci = fi][tap t]
   lds_barrier();
   float* fold = dyp;  // reuse: [4][WLEN]

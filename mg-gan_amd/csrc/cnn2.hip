@@ -19,7 +19,7 @@
 //                       -- the BatchNorm adjoint dx = (gamma/sigma)(dy - mean(dy) - xhat*mean(dy*xhat)) pushed through
 //                       the (linear) convolution, in f64: the two coherent sums that cancel in dW (dW is orthogonal
 //                       to W) never meet in f32.
-// Every kernel is persistent (<= 1024 workgroups walk the images), leaves ONE partial row per workgroup, and -- when
+// Every kernel is persistent (<= 768 workgroups walk the images), leaves ONE partial row per workgroup, and -- when
 // given a ticket word -- lets the last workgroup to finish fold the rows in index order (f64) and do the BatchNorm
 // bookkeeping itself: no separate reduce / finalize launches on the single-GPU path.
 #include "common.h"
@@ -63,54 +63,71 @@ struct BnBwdFin {  // fused BatchNorm-backward finalize
   float* dbeta;
 };
 
-// (4,33,33) image -> interior of the zero-haloed planes (the halo is cleared once per workgroup)
-__device__ __forceinline__ void stage_image(const float* __restrict__ src, float* imgp) {
-  constexpr int NPIX = 4 * IPIX, PER = (NPIX + 255) / 256;
-  float v[PER];
+// (4,33,33) image -> interior of the zero-haloed planes (the halo is cleared once per workgroup), in two halves: the
+// global loads of the NEXT image are issued before the products of the current one and land in LDS after them
+#define IMG_PER ((4 * IPIX + 255) / 256)
+__device__ __forceinline__ void fetch_image(const float* __restrict__ src, float v[IMG_PER]) {
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
+  for (int u = 0; u < IMG_PER; ++u) {
     const int e = threadIdx.x + 256 * u;
-    v[u] = src[e < NPIX ? e : 0];
+    v[u] = src[e < 4 * IPIX ? e : 0];
   }
+}
+__device__ __forceinline__ void commit_image(const float v[IMG_PER], float* imgp) {
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
+  for (int u = 0; u < IMG_PER; ++u) {
     const int e = threadIdx.x + 256 * u;
-    if (e < NPIX) {
+    if (e < 4 * IPIX) {
       const int ci = e / IPIX, rem = e - ci * IPIX, y = rem / IH, x = rem - y * IH;
       imgp[ci * IPLANE + (y + 1) * ILD + x + 1] = v[u];
     }
   }
 }
 
-// fixed-order f64 column sums of `rows` partial rows of width W (<= 32) by one 256-thread workgroup -> colsum[W] (LDS)
-__device__ __forceinline__ void colsum_rows(const double* part, int rows, int W, double* colsum, double* red /*[8][32]*/) {
-  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+// Partial rows travel between workgroups as agent-scope 8-byte atomics (write-through to the coherence point on the
+// producer side, L1-bypassing loads on the consumer side): no release fence, i.e. no write-back of the whole XCD L2
+// per workgroup.  -> true for the workgroup that arrives last (every row is then readable through load_part).
+__device__ __forceinline__ void store_part(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ double load_part(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// fixed-order f64 column sums of `rows` partial rows of width W (<= 32) by one 256-thread workgroup -> colsum[W] (LDS).
+// 8 (W > 16) or 16 row groups; every lane keeps 8 independent loads in flight (a lone workgroup has to hide the
+// memory latency by itself) and adds them in a fixed order.
+__device__ __forceinline__ void colsum_rows(const double* part, int rows, int W, double* colsum, double* red /*[8*32]*/) {
+  const int wp = W > 16 ? 32 : 16, ng = 256 / wp;
+  const int col = threadIdx.x % wp, rg = threadIdx.x / wp;
   double acc = 0.0;
-  if (col < W)
-    for (int r = rg; r < rows; r += 8) acc += __builtin_nontemporal_load(part + (size_t)r * W + col);
-  red[rg * 32 + col] = acc;
-  __syncthreads();
-  if (threadIdx.x < W) {
-    double t = 0.0;
+  if (col < W) {
+    int r = rg;
+    for (; r + 7 * ng < rows; r += 8 * ng) {
+      double v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += red[i * 32 + threadIdx.x];
+      for (int u = 0; u < 8; ++u) v[u] = load_part(part + (size_t)(r + u * ng) * W + col);
+      acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < rows; r += ng) acc += load_part(part + (size_t)r * W + col);
+  }
+  red[rg * wp + col] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < W) {
+    double t = 0.0;
+    for (int i = 0; i < ng; ++i) t += red[i * wp + threadIdx.x];
     colsum[threadIdx.x] = t;
   }
   __syncthreads();
 }
 
-// this workgroup's row is in memory; -> true for the workgroup that arrives last (its lanes may then read every row)
 __device__ __forceinline__ bool last_block(unsigned* ticket, int* flag_lds) {
-  __syncthreads();
+  __syncthreads();  // every lane's store_part has completed (each waited for its own)
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = atomicAdd(ticket, 1u);
     *flag_lds = (t == gridDim.x - 1);
-    if (t == gridDim.x - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      *ticket = 0u;  // re-armed for the next launch / graph replay
-    }
+    if (t == gridDim.x - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
   }
   __syncthreads();
   return *flag_lds != 0;
@@ -182,11 +199,14 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __r
   // A operand: lane (fi, fk) supplies row i = fi (window fi>>2, element fi&3) of input channel fk
   const int aoff = fk * IPLANE + ((fi & 3) >> 1) * ILD + 2 * (fi >> 2) + (fi & 1);
   double dsum = 0.0, dsq = 0.0;
+  float pre[IMG_PER];
+  if ((int)blockIdx.x < B) fetch_image(img + (size_t)blockIdx.x * 4 * IPIX, pre);
   __syncthreads();
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();  // the previous image's reads are done
-    stage_image(img + (size_t)b * 4 * IPIX, imgp);
+    commit_image(pre, imgp);
     __syncthreads();
+    if (b + (int)gridDim.x < B) fetch_image(img + (size_t)(b + gridDim.x) * 4 * IPIX, pre);  // in flight under the products
     float sum = 0.f, sq = 0.f;
 #pragma unroll 1
     for (int t = w; t < 64; t += 8) {  // two independent tiles per pass keep the matrix pipe fed
@@ -252,7 +272,8 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __r
   __syncthreads();
   if (tid < 2 * C) {
     const int which = tid / C, c = tid - which * C;
-    part[(size_t)blockIdx.x * 2 * C + tid] = (redd[0][which][c] + redd[1][which][c]) + (redd[2][which][c] + redd[3][which][c]);
+    store_part(part + (size_t)blockIdx.x * 2 * C + tid,
+               (redd[0][which][c] + redd[1][which][c]) + (redd[2][which][c] + redd[3][which][c]));
   }
   if (!fin.ticket) return;
   if (!last_block(fin.ticket, &flag)) return;
@@ -277,21 +298,22 @@ __global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __r
   double dsum[COT], dsq[COT];
 #pragma unroll
   for (int co = 0; co < COT; ++co) dsum[co] = dsq[co] = 0.0;
+  float v[C];
+  auto fetch = [&](int b) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = (scale1[c] >= 0.f ? xmax : xmin)[((size_t)b * C + c) * 256 + threadIdx.x];
+  };
+  if ((int)blockIdx.x < B) fetch(blockIdx.x);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
     {
       const int ppy = threadIdx.x >> 4, ppx = threadIdx.x & 15;
-      float v[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const size_t gi = ((size_t)b * C + c) * 256 + threadIdx.x;
-        v[c] = (scale1[c] >= 0.f ? xmax : xmin)[gi];
-      }
 #pragma unroll
       for (int c = 0; c < C; ++c)
         a1p[c * A1_PLANE + (ppy + 1) * A1_LD + ppx + 1] = fmaxf(fmaf(v[c], scale1[c], shift1[c]), 0.f);
     }
     __syncthreads();
+    if (b + (int)gridDim.x < B) fetch(b + gridDim.x);  // the next image's inputs fly under this image's products
     float acc[COT][4];
 #pragma unroll
     for (int co = 0; co < COT; ++co) {
@@ -330,8 +352,8 @@ __global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __r
   if (pg == 0) {
 #pragma unroll
     for (int co = 0; co < COT; ++co) {
-      part[(size_t)blockIdx.x * 2 * C + cg * COT + co] = dsum[co];
-      part[(size_t)blockIdx.x * 2 * C + C + cg * COT + co] = dsq[co];
+      store_part(part + (size_t)blockIdx.x * 2 * C + cg * COT + co, dsum[co]);
+      store_part(part + (size_t)blockIdx.x * 2 * C + C + cg * COT + co, dsq[co]);
     }
   }
   if (!fin.ticket) return;
@@ -389,10 +411,13 @@ __global__ __launch_bounds__(256) void image_gram_kernel(int B, const float* __r
   for (int q = 0; q < 6; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
+  float pre[IMG_PER];
+  if ((int)blockIdx.x < B) fetch_image(img + (size_t)blockIdx.x * 4 * IPIX, pre);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
-    stage_image(img + (size_t)b * 4 * IPIX, imgp);
+    commit_image(pre, imgp);
     __syncthreads();
+    if (b + (int)gridDim.x < B) fetch_image(img + (size_t)(b + gridDim.x) * 4 * IPIX, pre);
     f32x4 a[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -431,12 +456,25 @@ __global__ __launch_bounds__(256) void image_gram_kernel(int B, const float* __r
     }
 }
 
-// gram[s][t] (37 x 37, symmetric, f64) from the per-workgroup tile partials
+// gram[s][t] (37 x 37, symmetric, f64) from the per-workgroup tile partials: 16 outputs x 16 row groups per workgroup,
+// 8 loads in flight per lane, fixed order
 __global__ __launch_bounds__(256) void image_gram_finalize_kernel(const double* part, int rows, double* gram) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= 6 * 256) return;
+  __shared__ double red[16][16];
+  const int e = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
   double t = 0.0;
-  for (int r = 0; r < rows; ++r) t += part[(size_t)r * 6 * 256 + e];
+  int r = rg;
+  for (; r + 7 * 16 < rows; r += 8 * 16) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(r + u * 16) * 6 * 256 + e];
+    t += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  for (; r < rows; r += 16) t += part[(size_t)r * 6 * 256 + e];
+  red[rg][threadIdx.x & 15] = t;
+  __syncthreads();
+  if (threadIdx.x >= 16) return;
+  t = 0.0;
+  for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
   const int q = e >> 8, i = (e >> 4) & 15, j = e & 15;
   const int bi = q < 3 ? 0 : (q < 5 ? 1 : 2), bj = q < 3 ? q : (q < 5 ? q - 2 : 2);
   const int s = 16 * bi + i, u = 16 * bj + j;
@@ -456,7 +494,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int B, const float* __
                                                           const unsigned char* __restrict__ code1, double* part /*[grid][C*36]*/) {
   __shared__ __attribute__((aligned(16))) float imgp[ILDS];
   __shared__ float gs[16 * 256];
-  __shared__ unsigned char cs[16 * 256];
+  __shared__ __attribute__((aligned(16))) unsigned char cs[16 * 256];
   __shared__ double fold[4][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fi = lane & 15, fk = lane >> 4;
   for (int i = tid; i < ILDS; i += 256) imgp[i] = 0.f;
@@ -473,15 +511,26 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int B, const float* __
   for (int q = 0; q < 3; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
+  float pre[IMG_PER], pg_[C];
+  unsigned pc_[C / 4];
+  auto fetch = [&](int b) {
+    fetch_image(img + (size_t)b * 4 * IPIX, pre);
+#pragma unroll
+    for (int u = 0; u < C; ++u) pg_[u] = G1c[(size_t)b * C * 256 + u * 256 + tid];
+#pragma unroll
+    for (int u = 0; u < C / 4; ++u) pc_[u] = reinterpret_cast<const unsigned*>(code1 + (size_t)b * C * 256)[u * 256 + tid];
+  };
+  if ((int)blockIdx.x < B) fetch(blockIdx.x);
   __syncthreads();
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
-    stage_image(img + (size_t)b * 4 * IPIX, imgp);
-    for (int i = tid; i < C * 256; i += 256) {
-      gs[i] = G1c[(size_t)b * C * 256 + i];
-      cs[i] = code1[(size_t)b * C * 256 + i];
-    }
+    commit_image(pre, imgp);
+#pragma unroll
+    for (int u = 0; u < C; ++u) gs[u * 256 + tid] = pg_[u];
+#pragma unroll
+    for (int u = 0; u < C / 4; ++u) reinterpret_cast<unsigned*>(cs)[u * 256 + tid] = pc_[u];
     __syncthreads();
+    if (b + (int)gridDim.x < B) fetch(b + gridDim.x);
     f32x4 a[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -523,7 +572,16 @@ __global__ __launch_bounds__(256) void conv1_wgrad_finalize_kernel(const double*
   const int c = blockIdx.x, t = threadIdx.x % 36, rg = threadIdx.x / 36;
   if (rg < 7) {
     double s = 0.0;
-    for (int r = rg; r < rows; r += 7) s += part[(size_t)r * C * 36 + c * 36 + t];
+    const double* p = part + c * 36 + t;
+    const size_t ld = (size_t)C * 36;
+    int r = rg;
+    for (; r + 7 * 7 < rows; r += 8 * 7) {  // 8 loads in flight per lane, fixed order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + u * 7) * ld];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < rows; r += 7) s += p[(size_t)r * ld];
     red[rg][t] = s;
   }
   __syncthreads();
@@ -539,11 +597,17 @@ __global__ __launch_bounds__(256) void conv1_wgrad_finalize_kernel(const double*
   dW[c * 36 + t] += (float)(cs * (A - (S1 / n) * Bt - (S2 / n) * chat));
 }
 
-static int grid_for(int B, int cap) { return B < cap ? B : cap; }
+// persistent grid: at most `cap` workgroups (three per CU), and every workgroup walks the same number of images
+// (the last one may fall short): 1,280 images -> 640 workgroups x 2, 8,192 -> 745 x 11
+static int grid_for(int B, int cap) {
+  if (B <= cap) return B;
+  const int per = (B + cap - 1) / cap;
+  return (B + per - 1) / per;
+}
 
 extern "C" {
 
-int mggan_cnn_grid(int B) { return grid_for(B, 1024); }
+int mggan_cnn_grid(int B) { return grid_for(B, 768); }
 
 static BnFin make_fin(unsigned* ticket, double count, const float* gamma, const float* beta, float* run_mean, float* run_var,
                       long long* nbt, float momentum, float eps, int updates, float* scale, float* shift, float* stat) {
@@ -564,7 +628,7 @@ int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float
                "conv1_pool: the fused finalize needs the BatchNorm tensors");
   const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
                              scale, shift, stat);
-  const int grid = grid_for(B, 1024);
+  const int grid = grid_for(B, 768);
   if (C == 16) hipLaunchKernelGGL((conv1_pool_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, xmax, xmin, code, part, fin);
   else hipLaunchKernelGGL((conv1_pool_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, xmax, xmin, code, part, fin);
   MG_LAUNCH_CHECK("conv1_pool");
@@ -583,7 +647,7 @@ int mggan_conv2_fwd2(const float* xmax, const float* xmin, int B, int C, const f
                "conv2_fwd2: the fused finalize needs the BatchNorm tensors");
   const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
                              scale, shift, stat);
-  const int grid = grid_for(B, 1024);
+  const int grid = grid_for(B, 768);
   if (C == 16) hipLaunchKernelGGL((conv2_fwd2_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xmax, xmin, scale1, shift1, W, bias, y2, part, fin);
   else hipLaunchKernelGGL((conv2_fwd2_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xmax, xmin, scale1, shift1, W, bias, y2, part, fin);
   MG_LAUNCH_CHECK("conv2_fwd2");
@@ -627,10 +691,10 @@ int mggan_bn_bwd_coef(const double* sums, const double* local_sums, double count
 int mggan_image_gram(const float* img, int B, double* gram, double* workspace, size_t workspace_bytes,
                      hipStream_t stream) {
   MG_CHECK_ARG(gram && workspace && (img || B == 0), "image_gram: null pointer");
-  const int grid = grid_for(B, 1024);
+  const int grid = grid_for(B, 768);
   MG_CHECK_ARG(workspace_bytes >= (size_t)(grid > 0 ? grid : 1) * 6 * 256 * sizeof(double), "image_gram: workspace too small");
   if (grid > 0) hipLaunchKernelGGL(image_gram_kernel, dim3(grid), dim3(256), 0, stream, B, img, workspace);
-  hipLaunchKernelGGL(image_gram_finalize_kernel, dim3(6), dim3(256), 0, stream, workspace, grid, gram);
+  hipLaunchKernelGGL(image_gram_finalize_kernel, dim3(96), dim3(256), 0, stream, workspace, grid, gram);
   MG_LAUNCH_CHECK("image_gram");
   return MGGAN_OK;
 }
@@ -642,7 +706,7 @@ int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const un
   MG_CHECK_ARG(C == 8 || C == 16, "conv1_wgrad: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(img && G1c && code1 && gram && W && bias && coefd && dW && workspace, "conv1_wgrad: null pointer");
-  const int grid = grid_for(B, 1024);
+  const int grid = grid_for(B, 768);
   MG_CHECK_ARG(workspace_bytes >= (size_t)grid * C * 36 * sizeof(double), "conv1_wgrad: workspace too small");
   if (C == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace);
   else hipLaunchKernelGGL((conv1_wgrad_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace);
