@@ -73,16 +73,25 @@ __device__ __forceinline__ void fetch_image(const float* __restrict__ src, float
     v[u] = src[e < 4 * IPIX ? e : 0];
   }
 }
+template <int LD, int PLANE>
 __device__ __forceinline__ void commit_image(const float v[IMG_PER], float* imgp) {
 #pragma unroll
   for (int u = 0; u < IMG_PER; ++u) {
     const int e = threadIdx.x + 256 * u;
     if (e < 4 * IPIX) {
       const int ci = e / IPIX, rem = e - ci * IPIX, y = rem / IH, x = rem - y * IH;
-      imgp[ci * IPLANE + (y + 1) * ILD + x + 1] = v[u];
+      imgp[ci * PLANE + (y + 1) * LD + x + 1] = v[u];
     }
   }
 }
+// Second LDS layout, for the kernels whose 16 lanes of an operand walk the 36 TAPS (Gram matrix, conv1 weight
+// gradient): row stride 35 (== 3 mod 32) and plane stride 35*35 = 1225 (== 9 mod 32) put tap t = 9*ci + 3*ky + kx
+// on bank t (mod 32): 16 consecutive taps -> 16 distinct banks, and a second lane group 16 columns to the right
+// takes the other 16 banks.
+#define GLD 35
+#define GPLANE 1225
+#define GZERO (4 * GPLANE)
+#define GLDS (4 * GPLANE + 64)
 
 // Partial rows travel between workgroups as agent-scope 8-byte atomics (write-through to the coherence point on the
 // producer side, L1-bypassing loads on the consumer side): no release fence, i.e. no write-back of the whole XCD L2
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __r
   __syncthreads();
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();  // the previous image's reads are done
-    commit_image(pre, imgp);
+    commit_image<ILD, IPLANE>(pre, imgp);
     __syncthreads();
     if (b + (int)gridDim.x < B) fetch_image(img + (size_t)(b + gridDim.x) * 4 * IPIX, pre);  // in flight under the products
     float sum = 0.f, sq = 0.f;
@@ -391,21 +400,25 @@ __global__ void bn_bwd_coef_kernel(const double* sums, const double* local, int 
 // ------------------------------------------------------------------------------------------------------------------
 // Gram matrix of the image patches: P[s][t] = sum_{img,pos} patch[pos][s] patch[pos][t], taps ordered t = 9*ci + 3*ky + kx,
 // tap 36 = 1.  A and B operand of a 16x16x4 MFMA are the SAME register when both index (tap, position): three LDS
-// reads (tap blocks 0-15, 16-31, 32-47) feed the six upper-triangle tile products of a k-step (4 positions of a row).
+// reads (tap blocks 0-15, 16-31, 32-47) feed the six upper-triangle tile products of a k-step.  The four positions of
+// a k-step are (y, x), (y, x+16), (y+1, x), (y+1, x+16): with the tap-per-bank layout the two lane groups of a
+// half-wave read disjoint banks (conflict-free ds_read_b32); column 32 is swept by nine extra k-steps per image.
 __global__ __launch_bounds__(256) void image_gram_kernel(int B, const float* __restrict__ img, double* part /*[grid][6*256]*/) {
-  __shared__ __attribute__((aligned(16))) float imgp[ILDS + 64];
+  __shared__ __attribute__((aligned(16))) float imgp[GLDS];
   __shared__ double fold[4][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fi = lane & 15, fk = lane >> 4;
-  for (int i = tid; i < ILDS + 64; i += 256) imgp[i] = 0.f;
-  __syncthreads();
-  if (tid < 64) imgp[ILDS + tid] = 1.f;  // the constant tap
-  // per-lane operand offset of tap blocks 0..2 (tap = 16*blk + fi) relative to the k-step base (y*ILD + x0 + fk)
+  for (int i = tid; i < GLDS; i += 256) imgp[i] = 0.f;
+  // lane (fi, fk): tap 16*blk + fi at position slot fk
   int toff[3];
+  bool real[3], one[3];
 #pragma unroll
   for (int blk = 0; blk < 3; ++blk) {
     const int t = 16 * blk + fi;
-    toff[blk] = t < 36 ? (t / 9) * IPLANE + ((t % 9) / 3) * ILD + (t % 3) : (t == 36 ? ILDS : IZERO);
+    real[blk] = t < 36;
+    one[blk] = t == 36;
+    toff[blk] = t < 36 ? (t / 9) * GPLANE + ((t % 9) / 3) * GLD + (t % 3) : 0;
   }
+  const int slot_main = (fk >> 1) * GLD + 16 * (fk & 1);
   double acc[6][4];
 #pragma unroll
   for (int q = 0; q < 6; ++q)
@@ -415,23 +428,30 @@ __global__ __launch_bounds__(256) void image_gram_kernel(int B, const float* __r
   if ((int)blockIdx.x < B) fetch_image(img + (size_t)blockIdx.x * 4 * IPIX, pre);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
-    commit_image(pre, imgp);
+    commit_image<GLD, GPLANE>(pre, imgp);
     __syncthreads();
     if (b + (int)gridDim.x < B) fetch_image(img + (size_t)(b + gridDim.x) * 4 * IPIX, pre);
     f32x4 a[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int ks = w; ks < 33 * 9; ks += 4) {
-      const int y = ks / 9, x0 = (ks - y * 9) * 4;
-      const bool valid = x0 + fk < IH;  // only the last k-step of a row has masked positions (x = 33..35)
-      const int base = y * ILD + x0 + fk;
+    for (int ks = w; ks < 17 * 16 + 9; ks += 4) {
+      int pos;
+      bool valid;
+      if (ks < 17 * 16) {  // rows (y0, y0+1), columns (x, x+16)
+        const int y0 = 2 * (ks >> 4), x = ks & 15;
+        pos = y0 * GLD + x + slot_main;
+        valid = y0 + (fk >> 1) < IH;
+      } else {  // column 32, rows 4*s + fk
+        const int y = 4 * (ks - 17 * 16) + fk;
+        pos = y * GLD + 32;
+        valid = y < IH;
+      }
       float v[3];
 #pragma unroll
       for (int blk = 0; blk < 3; ++blk) {
-        const int o = toff[blk];
-        // masked lanes read zeros; the constant / zero pseudo-taps do not move with the position
-        v[blk] = imgp[valid ? (o >= IZERO ? o : base + o) : IZERO];
+        v[blk] = imgp[(valid && real[blk]) ? pos + toff[blk] : GZERO];
+        if (valid && one[blk]) v[blk] = 1.f;
       }
       a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[0], v[0], a[0], 0, 0, 0);
       a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[0], v[1], a[1], 0, 0, 0);
@@ -486,26 +506,33 @@ __global__ __launch_bounds__(256) void image_gram_finalize_kernel(const double* 
 
 // ------------------------------------------------------------------------------------------------------------------
 // conv1 weight gradient, sparse part: A[c][t] = sum over images and pooled cells of G1c[c][cell] * patch[pos(code)][t].
-// MFMA with K = the four positions of one pooling window: the A operand of lane (c = fi, k = fk) is the cell's gradient
-// if the saved argmax code equals fk, else 0 (lane-local); B = patch values from the LDS image.  Three N tiles
-// (taps 0-15, 16-31, 32-35 + pad).  Wave w takes cells w, w+4, ...
+// MFMA with M = channel, N = tap (three tiles), K = four pooled cells that share ONE window element e: the A operand of
+// lane (c = fi, k = fk) is the gradient of cell k if the saved argmax position of (c, cell) equals e, else 0
+// (lane-local); B = the patch value of tap j at element e of cell k, from the tap-per-bank LDS image.  Wave w owns
+// window element e = w; the cells of a k-step are (py, px), (py, px+8), (py+1, px), (py+1, px+8): the two lane groups
+// of a half-wave sit 16 image columns apart, i.e. on disjoint banks.
+#define GS_LD 257   // row stride of the staged gradients (floats): channel c on bank c + cell
+#define CS_LD 260   // row stride of the staged codes (bytes)
 template <int C>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int B, const float* __restrict__ img, const float* __restrict__ G1c,
                                                           const unsigned char* __restrict__ code1, double* part /*[grid][C*36]*/) {
-  __shared__ __attribute__((aligned(16))) float imgp[ILDS];
-  __shared__ float gs[16 * 256];
-  __shared__ __attribute__((aligned(16))) unsigned char cs[16 * 256];
+  __shared__ __attribute__((aligned(16))) float imgp[GLDS];
+  __shared__ float gs[16 * GS_LD];
+  __shared__ __attribute__((aligned(16))) unsigned char cs[16 * CS_LD];
   __shared__ double fold[4][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fi = lane & 15, fk = lane >> 4;
-  for (int i = tid; i < ILDS; i += 256) imgp[i] = 0.f;
-  for (int i = tid; i < 16 * 256; i += 256) { gs[i] = 0.f; cs[i] = 0; }
-  // B operand: lane (k = fk = window element, j = fi = tap 16*blk + fi): image offset of that tap at that element
+  for (int i = tid; i < GLDS; i += 256) imgp[i] = 0.f;
+  for (int i = tid; i < 16 * GS_LD; i += 256) gs[i] = 0.f;
+  for (int i = tid; i < 16 * CS_LD; i += 256) cs[i] = 255;  // rows c >= C never match an element
+  const int e = w;
+  // B operand: lane (k = fk, j = fi): tap 16*blk + fi at element e of cell (py0 + (fk>>1), p + 8*(fk&1))
   int boff[3];
 #pragma unroll
   for (int blk = 0; blk < 3; ++blk) {
     const int t = 16 * blk + fi;
-    boff[blk] = t < 36 ? (t / 9) * IPLANE + ((t % 9) / 3 + (fk >> 1)) * ILD + (t % 3) + (fk & 1) : -1;
+    boff[blk] = t < 36 ? (t / 9) * GPLANE + ((t % 9) / 3 + 2 * (fk >> 1) + (e >> 1)) * GLD + (t % 3) + 16 * (fk & 1) + (e & 1) : -1;
   }
+  const int cell_lane = (fk >> 1) * 16 + 8 * (fk & 1);
   double acc[3][4];
 #pragma unroll
   for (int q = 0; q < 3; ++q)
@@ -524,24 +551,28 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int B, const float* __
   __syncthreads();
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
-    commit_image(pre, imgp);
+    commit_image<GLD, GPLANE>(pre, imgp);
 #pragma unroll
-    for (int u = 0; u < C; ++u) gs[u * 256 + tid] = pg_[u];
+    for (int u = 0; u < C; ++u) gs[u * GS_LD + tid] = pg_[u];
 #pragma unroll
-    for (int u = 0; u < C / 4; ++u) reinterpret_cast<unsigned*>(cs)[u * 256 + tid] = pc_[u];
+    for (int u = 0; u < C / 4; ++u) {  // word u*256 + tid of the (C,256) code bytes: channel = word / 64
+      const int word = u * 256 + tid;
+      reinterpret_cast<unsigned*>(cs)[(word >> 6) * (CS_LD / 4) + (word & 63)] = pc_[u];
+    }
     __syncthreads();
     if (b + (int)gridDim.x < B) fetch(b + gridDim.x);
     f32x4 a[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
-    for (int cell = w; cell < 256; cell += 4) {
-      const int py = cell >> 4, px = cell & 15;
-      const float g = (int)cs[fi * 256 + cell] == fk ? gs[fi * 256 + cell] : 0.f;  // rows fi >= C hold zeros
-      const int base = 2 * py * ILD + 2 * px;
+    for (int ks = 0; ks < 64; ++ks) {
+      const int py0 = 2 * (ks >> 3), p = ks & 7;
+      const int cell = py0 * 16 + p + cell_lane;
+      const float g = (int)cs[fi * CS_LD + cell] == e ? gs[fi * GS_LD + cell] : 0.f;
+      const int base = 2 * py0 * GLD + 2 * p;
 #pragma unroll
       for (int blk = 0; blk < 3; ++blk) {
-        const float bv = boff[blk] >= 0 ? imgp[base + boff[blk]] : 0.f;
+        const float bv = imgp[boff[blk] >= 0 ? base + boff[blk] : GZERO];
         a[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(g, bv, a[blk], 0, 0, 0);
       }
     }
@@ -550,7 +581,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int B, const float* __
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[q][r] += (double)a[q][r];
   }
-  // D fragment: lane holds rows c = 4*fk + r, column tap = 16*blk + fi
+  // D fragment: lane holds rows c = 4*fk + r, column tap = 16*blk + fi; the four waves (window elements) add up
   double* out = part + (size_t)blockIdx.x * C * 36;
   for (int q = 0; q < 3; ++q)
     for (int r = 0; r < 4; ++r) {
