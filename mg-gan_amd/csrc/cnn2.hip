@@ -434,19 +434,7 @@ __global__ __launch_bounds__(256) void image_gram_kernel(int B, const float* __r
     f32x4 a[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int ks = w; ks < 17 * 16 + 9; ks += 4) {
-      int pos;
-      bool valid;
-      if (ks < 17 * 16) {  // rows (y0, y0+1), columns (x, x+16)
-        const int y0 = 2 * (ks >> 4), x = ks & 15;
-        pos = y0 * GLD + x + slot_main;
-        valid = y0 + (fk >> 1) < IH;
-      } else {  // column 32, rows 4*s + fk
-        const int y = 4 * (ks - 17 * 16) + fk;
-        pos = y * GLD + 32;
-        valid = y < IH;
-      }
+    auto kstep = [&](int pos, bool valid) {
       float v[3];
 #pragma unroll
       for (int blk = 0; blk < 3; ++blk) {
@@ -459,6 +447,19 @@ __global__ __launch_bounds__(256) void image_gram_kernel(int B, const float* __r
       a[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[1], v[1], a[3], 0, 0, 0);
       a[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[1], v[2], a[4], 0, 0, 0);
       a[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2], v[2], a[5], 0, 0, 0);
+    };
+    // rows (y0, y0+1) x columns (x, x+16): wave w takes x = 4*j + w of every row pair
+#pragma unroll 1
+    for (int yp = 0; yp < 17; ++yp) {
+      const bool valid = 2 * yp + (fk >> 1) < IH;
+      const int rowpos = 2 * yp * GLD + slot_main + w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kstep(rowpos + 4 * j, valid);
+    }
+    // column 32, rows 4*s + fk
+    for (int s9 = w; s9 < 9; s9 += 4) {
+      const int y = 4 * s9 + fk;
+      kstep(y * GLD + 32, y < IH);
     }
 #pragma unroll
     for (int q = 0; q < 6; ++q)

@@ -91,7 +91,6 @@ class MultiGeneratorGAN(abc.ABC):
             self.rng.begin_iteration(sub_batches, b, self.config.noise_dim, self.device)
         from mggan.hip import functions as HF
 
-        HF.begin_images(img)  # the Gram matrix of the image patches (conv1 weight gradients) starts beside the forward pass
         cfg = self.config
         run_d = self.total_iterations % max(int(cfg.num_gen_steps), 1) == 0 or self.epoch >= cfg.keep_gen_steps
         shared = None
@@ -99,6 +98,10 @@ class MultiGeneratorGAN(abc.ABC):
             # G is not updated between the no-grad generator call of the D step and the G step: one trunk
             # forward (with its backward graph) serves both; BatchNorm running stats still move twice (A.8)
             shared = {"g_trunk": self.G.trunk(in_xy, in_dxdy, sub_batches, img, passes=2)}
+        # the Gram matrix of the image patches (image-only part of every conv1 weight gradient of the iteration) goes to
+        # a side stream AFTER the shared trunk: beside the latency-bound forward chain of the discriminator step instead
+        # of beside the trunk's own convolutions; its first reader is the scene CNN's adjoint of that step
+        HF.begin_images(img)
         # abstract_train.py:136-150: the discriminator step runs when total_iterations % num_gen_steps == 0 or
         # epoch >= keep_gen_steps, and num_unrolling_steps + 1 times.  The reference's unrolling "backup" is
         # `self.D.state_dict()` -- references to the live parameters, not copies -- so its load_state_dict(backup)
