@@ -241,6 +241,24 @@ int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const un
                       const float* W, const float* bias, const double* coefd, float* dW, double* workspace,
                       size_t workspace_bytes, mggan_stream_t stream);
 
+/* ---- in-graph all-reduce over peer-mapped memory (csrc/comm.hip; scene-sharded training) ------------
+ * No reference counterpart (the reference is single-process); replaces torch.distributed.all_reduce for the <= 360 KB
+ * messages of an iteration with a plain, HIP-graph-capturable kernel.  Every rank owns one uncached arena per channel
+ * (mggan_comm_arena_bytes(max_elems), max_elems counted in 8-byte elements), exports it with mggan_comm_ipc_handle
+ * (64-byte handle) and maps its peers' with mggan_comm_ipc_open.  mggan_comm_allreduce sums `n` elements of `data`
+ * (dtype 0 f32, 1 f64, 2 i32) over the ranks IN PLACE, adding the ranks' contributions in rank order (bit-identical on
+ * every rank).  All ranks must issue the same collectives in the same order on a channel.  A wait that exceeds 2 s sets
+ * the arena's error word (mggan_comm_error) instead of hanging. */
+size_t mggan_comm_arena_bytes(long max_elems);
+int mggan_comm_alloc(size_t bytes, void** out);
+int mggan_comm_free(void* p);
+int mggan_comm_ipc_handle(void* p, void* handle);
+int mggan_comm_ipc_open(const void* handle, void** out);
+int mggan_comm_ipc_close(void* p);
+int mggan_comm_allreduce(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
+                         mggan_stream_t stream);
+int mggan_comm_error(const void* arena, unsigned int* out);
+
 /* ---- losses (+ gradients), clipping, AdamW ----------------------------------------------
  * reference: abstract_train.py:62-67, utils.py:18-25, train.py:58-75,92-113,181-200,626-639,
  *            train.py:131-135,209-213,656-658, abstract_train.py:45-50 */

@@ -1,0 +1,182 @@
+// In-graph all-reduce between the GPUs of one node (scene-sharded training) -- a plain kernel, so the
+// sharded iteration stays ONE HIP graph with its branch streams; RCCL calls would cut the capture at every exchange
+// point (18 per iteration), and every message here is <= 360 KB, i.e. latency bound.
+//
+// One-shot exchange over peer-mapped memory (xGMI is point to point: every rank has a direct link to every other):
+// each rank owns an UNCACHED arena that its peers map through hipIpc*.  For a vector of n elements, workgroup k of
+// rank r (a) stores its chunk k into slot r of EVERY rank's arena, (b) system-scope fence, then stamps flag[r][k] of
+// every arena with the collective's sequence number, (c) waits until all W flags of chunk k in its OWN arena carry that
+// number, (d) adds the W slots in rank order -- every rank computes bit-identical sums, replicas cannot drift.
+// Two buffers alternate by sequence parity: a rank can only start collective s+2 after it finished s+1, which needed
+// every peer's flag of s+1, which a peer stamps only after it finished reading s.  Waits are bounded (wall clock):
+// a lost peer sets the arena's error word instead of hanging the GPU.
+// No reference counterpart (the reference is single-process); replaces torch.distributed.all_reduce on this path.
+#include <string.h>
+#include "common.h"
+#include "../../include/mggan_hip.h"
+
+#define COMM_MAX_RANKS 8
+#define COMM_CHUNK 2048                 // elements per workgroup (8 per lane)
+#define COMM_TIMEOUT_TICKS 200000000ll  // wall_clock64 ticks (100 MHz): 2 s
+
+struct CommHeader {        // at the start of every arena (local use only)
+  unsigned seq;            // collectives completed on this channel
+  unsigned done;           // workgroups of the running collective that have finished
+  unsigned error;          // set when a wait timed out
+  unsigned pad;
+};
+
+struct CommArgs {
+  void* arena[COMM_MAX_RANKS];  // arena of rank j for this channel, mapped into this process (arena[rank] = own)
+  void* data;                   // vector to reduce in place
+  long n;
+  long max_elems;               // capacity of one slot in elements of the widest type (8 bytes)
+  int rank, world, max_blocks, dtype;  // dtype 0: f32, 1: f64, 2: i32
+};
+
+__host__ __device__ inline size_t comm_flags_off() { return 64; }
+__host__ __device__ inline size_t comm_data_off(int max_blocks) {
+  const size_t f = 64 + (size_t)2 * COMM_MAX_RANKS * max_blocks * sizeof(unsigned);
+  return (f + 255) / 256 * 256;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void comm_allreduce_kernel(CommArgs a) {
+  char* mine = (char*)a.arena[a.rank];
+  CommHeader* hdr = (CommHeader*)mine;
+  const unsigned seq = __hip_atomic_load(&hdr->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const int buf = seq & 1, k = blockIdx.x, W = a.world, r = a.rank;
+  const long e0 = (long)k * COMM_CHUNK, cnt = min((long)COMM_CHUNK, a.n - e0);
+  const size_t slot_bytes = (size_t)a.max_elems * 8, doff = comm_data_off(a.max_blocks);
+  T* src = (T*)a.data + e0;
+  // (a) my chunk into slot r of every rank
+  for (int j = 0; j < W; ++j) {
+    T* dst = (T*)((char*)a.arena[j] + doff + ((size_t)buf * COMM_MAX_RANKS + r) * slot_bytes) + e0;
+    for (long i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  // (b) stamp, (c) wait
+  if ((int)threadIdx.x < W) {
+    unsigned* pf = (unsigned*)((char*)a.arena[threadIdx.x] + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + r) * a.max_blocks + k;
+    __hip_atomic_store(pf, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned* wf = (unsigned*)(mine + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + threadIdx.x) * a.max_blocks + k;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(wf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > COMM_TIMEOUT_TICKS) {
+        __hip_atomic_store(&hdr->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  // (d) fixed-order sum of the W slots of my own arena
+  const T* base = (const T*)(mine + doff + (size_t)buf * COMM_MAX_RANKS * slot_bytes) + e0;
+  const size_t stride = slot_bytes / sizeof(T);
+  for (long i = threadIdx.x; i < cnt; i += 256) {
+    T s = __builtin_nontemporal_load(base + i);
+    for (int j = 1; j < W; ++j) s += __builtin_nontemporal_load(base + (size_t)j * stride + i);
+    src[i] = s;
+  }
+  // the last workgroup closes the collective
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(&hdr->done, 1u);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(&hdr->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+extern "C" {
+
+size_t mggan_comm_arena_bytes(long max_elems) {
+  const int max_blocks = cdiv(max_elems * 2, COMM_CHUNK);  // 4-byte elements fill a slot with twice as many
+  return comm_data_off(max_blocks) + (size_t)2 * COMM_MAX_RANKS * max_elems * 8;
+}
+
+int mggan_comm_alloc(size_t bytes, void** out) {
+  MG_CHECK_ARG(out && bytes > 0, "comm_alloc: bad arguments");
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    mggan_set_error("comm_alloc: hipExtMallocWithFlags(%zu, uncached) failed: %s", bytes, hipGetErrorString(e));
+    return MGGAN_ERR_LAUNCH;
+  }
+  e = hipMemset(p, 0, bytes);
+  if (e != hipSuccess) {
+    mggan_set_error("comm_alloc: hipMemset failed: %s", hipGetErrorString(e));
+    return MGGAN_ERR_LAUNCH;
+  }
+  *out = p;
+  return MGGAN_OK;
+}
+
+int mggan_comm_free(void* p) {
+  if (p && hipFree(p) != hipSuccess) return MGGAN_ERR_LAUNCH;
+  return MGGAN_OK;
+}
+
+/* handle: 64 bytes (hipIpcMemHandle_t) */
+int mggan_comm_ipc_handle(void* p, void* handle) {
+  MG_CHECK_ARG(p && handle, "comm_ipc_handle: null pointer");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  hipError_t e = hipIpcGetMemHandle((hipIpcMemHandle_t*)handle, p);
+  if (e != hipSuccess) {
+    mggan_set_error("comm_ipc_handle: hipIpcGetMemHandle failed: %s", hipGetErrorString(e));
+    return MGGAN_ERR_LAUNCH;
+  }
+  return MGGAN_OK;
+}
+
+int mggan_comm_ipc_open(const void* handle, void** out) {
+  MG_CHECK_ARG(handle && out, "comm_ipc_open: null pointer");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  void* p = nullptr;
+  hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) {
+    mggan_set_error("comm_ipc_open: hipIpcOpenMemHandle failed: %s", hipGetErrorString(e));
+    return MGGAN_ERR_LAUNCH;
+  }
+  *out = p;
+  return MGGAN_OK;
+}
+
+int mggan_comm_ipc_close(void* p) {
+  if (p && hipIpcCloseMemHandle(p) != hipSuccess) return MGGAN_ERR_LAUNCH;
+  return MGGAN_OK;
+}
+
+/* arenas: `world` pointers (arena of rank j mapped into this process); data: n elements reduced in place */
+int mggan_comm_allreduce(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
+                         hipStream_t stream) {
+  MG_CHECK_ARG(arenas && data && world >= 1 && world <= COMM_MAX_RANKS && rank >= 0 && rank < world, "comm_allreduce: bad ranks");
+  MG_CHECK_ARG(dtype >= 0 && dtype <= 2, "comm_allreduce: dtype %d (0 f32, 1 f64, 2 i32)", dtype);
+  const long cap = dtype == 1 ? max_elems : 2 * max_elems;
+  MG_CHECK_ARG(n >= 0 && n <= cap, "comm_allreduce: %ld elements exceed the arena slot (%ld)", n, cap);
+  if (n == 0) return MGGAN_OK;
+  CommArgs a;
+  for (int j = 0; j < COMM_MAX_RANKS; ++j) a.arena[j] = j < world ? arenas[j] : nullptr;
+  a.data = data; a.n = n; a.max_elems = max_elems; a.rank = rank; a.world = world;
+  a.max_blocks = cdiv(max_elems * 2, COMM_CHUNK); a.dtype = dtype;
+  const int grid = cdiv(n, COMM_CHUNK);
+  if (dtype == 0) hipLaunchKernelGGL(comm_allreduce_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
+  else if (dtype == 1) hipLaunchKernelGGL(comm_allreduce_kernel<double>, dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(comm_allreduce_kernel<int>, dim3(grid), dim3(256), 0, stream, a);
+  MG_LAUNCH_CHECK("comm_allreduce");
+  return MGGAN_OK;
+}
+
+/* error word of an arena (host read; synchronises the device) */
+int mggan_comm_error(const void* arena, unsigned int* out) {
+  MG_CHECK_ARG(arena && out, "comm_error: null pointer");
+  CommHeader h;
+  if (hipMemcpy(&h, arena, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return MGGAN_ERR_LAUNCH;
+  *out = h.error;
+  return MGGAN_OK;
+}
+
+}  // extern "C"

@@ -58,7 +58,7 @@ class MultiGeneratorGAN(abc.ABC):
         self.G.rng = self.rng
         self.dist = DistContext()
         self.dist.attach(self.G, self.D, bn_sync=getattr(config, "bn_sync", "global"))
-        if self.dist.enabled and os.environ.get("MGGAN_BRANCH_SHARDED", "0") != "1":
+        if self.dist.enabled and self.dist.devcomm is None and os.environ.get("MGGAN_BRANCH_SHARDED", "0") != "1":
             # sharded runs are replayed as ~19 short graph segments (one per collective); forks that have to be
             # joined at every cut measured slower than one stream (3.49 vs 3.24 ms per iteration with dummy
             # collectives on one MI355X), so the branch streams stay off unless asked for
@@ -137,17 +137,12 @@ class MultiGeneratorGAN(abc.ABC):
         batch["loss_mask"] = None
         in_graph = False
         if self.dist.enabled:
-            # RCCL collectives can be captured: the sharded iteration is then ONE graph like the single-GPU one
-            # (branch streams on, no cut per collective).  EXPERIMENTAL, opt-in with MGGAN_GRAPH_COLLECTIVES=1
-            # ("auto": probe the backend first): with torch 2.10 / RCCL 2.26 the process group's watchdog thread
-            # intermittently queries an event that was recorded inside the capture and aborts the process
-            # (hipErrorCapturedEvent, about one run in three on one MI355X), so the default stays the segmented
-            # capture around eager collectives.
             from mggan.hip import functions as HF
-            from mggan.parallel import graph_collectives_ok
 
-            want = os.environ.get("MGGAN_GRAPH_COLLECTIVES", "0")
-            in_graph = want == "1" or (want == "auto" and graph_collectives_ok(self.device, self.dist.group))
+            # peer-mapped all-reduce kernels (mggan/devcomm.py): the collectives are ordinary launches, the sharded
+            # iteration is ONE graph like the single-GPU one, branch streams on.  Without them (ranks on several nodes,
+            # IPC mapping refused) every torch.distributed collective cuts the capture into graph segments.
+            in_graph = self.dist.devcomm is not None
             HF.enable_branches(in_graph or os.environ.get("MGGAN_BRANCH_SHARDED", "0") == "1")
         self.graph_collectives = in_graph
         keep, self.defer_metrics = self.defer_metrics, True
@@ -186,10 +181,9 @@ class MultiGeneratorGAN(abc.ABC):
             dot = os.environ.get("MGGAN_GRAPH_DOT")  # debugging aid: dump the captured graph's nodes and edges
             if dot:
                 graph.enable_debug_mode()
-            # (thread_local: RCCL's watchdog thread may query events while this thread captures)
             self._static_metrics = True
             try:
-                with torch.cuda.graph(graph, capture_error_mode="thread_local" if in_graph else "global"):
+                with torch.cuda.graph(graph):
                     self.train_iteration(batch, captured)
             finally:
                 self._static_metrics = False
@@ -197,7 +191,7 @@ class MultiGeneratorGAN(abc.ABC):
                 graph.debug_dump(dot)
             run = graph.replay
             self.launch_mode = "hipGraph replay of the whole iteration" + (
-                ", RCCL collectives captured inside it" if in_graph else "")
+                ", peer-mapped all-reduce kernels inside it" if in_graph else "")
         pending, self._pending = self._pending, []
         self.defer_metrics = keep
 

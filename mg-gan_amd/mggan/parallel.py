@@ -7,7 +7,8 @@ What couples the ranks:
   C1  parameter gradients    -> ONE all-reduce(sum) of the flat gradient buffer per optimizer step
   C2  BatchNorm statistics   -> all-reduce of the f64 per-channel sums (forward and backward)
   C3  batch-global counters  -> generator-id counts and loss normalisers
-All messages are <= 360 KB: latency-bound, so they are kept to one collective each.
+All messages are <= 360 KB: latency-bound, so they are kept to one collective each -- and, on one node, they are
+plain kernels over peer-mapped memory (mggan/devcomm.py, csrc/comm.hip) so that the iteration stays one HIP graph.
 """
 import os
 
@@ -59,11 +60,16 @@ class DistContext:
         self.rank = dist.get_rank(group) if self.enabled else 0
 
     recorder = None  # a SegmentRecorder while an iteration is being captured into HIP graphs
+    devcomm = None   # mggan.devcomm.DeviceComm: the collectives as plain kernels over peer-mapped memory
 
     def _collective(self, t):
-        """Sum `t` over the ranks in place.  While an iteration is being captured the collective CUTS the graph:
-        the kernels queued so far become one graph segment, the collective itself stays an eager call that is
-        replayed between the segments (so the capture does not depend on the backend being capturable)."""
+        """Sum `t` over the ranks in place.  Preferred: the peer-mapped kernel (mggan/devcomm.py) -- an ordinary
+        launch on the current stream, capturable, so the sharded iteration stays ONE graph.  Otherwise
+        torch.distributed: while an iteration is being captured that collective CUTS the graph (the kernels queued so
+        far become one graph segment, the collective stays an eager call replayed between the segments)."""
+        if self.devcomm is not None and self.devcomm.supports(t):
+            self.devcomm.all_reduce_(t)
+            return
         group = self.group
 
         def run():
@@ -86,7 +92,7 @@ class DistContext:
         if self.equal_shards:  # every rank holds n_local images: no count exchange, no host read-back
             self._collective(sums)
             return float(n_local) * self.world_size
-        if self.recorder is not None:
+        if self.recorder is not None or (sums.is_cuda and torch.cuda.is_current_stream_capturing()):
             raise RuntimeError("graph capture of a sharded iteration needs equal shards (the global image count of "
                                "unequal shards is read back to the host)")
         buf = torch.cat([sums, sums.new_tensor([float(n_local)])])
@@ -126,47 +132,10 @@ class DistContext:
                     m.sync = self if (self.enabled and bn_sync == "global") else None
             if r._flat is not None:
                 self._dev = r._flat.device
+        if self.enabled and self.devcomm is None and torch.device(self._dev).type == "cuda":
+            from mggan import devcomm
 
-
-def graph_collectives_ok(device, group=None):
-    """Can this backend's all-reduce be captured into a HIP graph and replayed?  RCCL can (the collective becomes
-    graph nodes on its internal stream); gloo cannot.  Checked by doing it: one small all-reduce captured, replayed
-    three times, results compared with the expected sums.  Every rank takes the same decision (the verdict itself
-    is all-reduced eagerly)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
-        return False
-    ok = 1.0
-    try:
-        world = dist.get_world_size(group)
-        x = torch.zeros(256, dtype=torch.float32, device=device)
-        y = torch.zeros(256, dtype=torch.float32, device=device)
-        dist.all_reduce(y, group=group)  # communicator set up outside the capture
-        torch.cuda.synchronize(device)
-        side = torch.cuda.Stream(device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            g.capture_begin(capture_error_mode="thread_local")
-            y.copy_(x)
-            dist.all_reduce(y, group=group)
-            y.mul_(2.0)
-            g.capture_end()
-        torch.cuda.current_stream(device).wait_stream(side)
-        for i in range(3):
-            x.fill_(float(i + 1))
-            g.replay()
-            torch.cuda.synchronize(device)
-            if not torch.allclose(y, torch.full_like(y, 2.0 * world * (i + 1))):
-                ok = 0.0
-    except Exception:  # noqa: BLE001 -- any failure means "use the segmented path"
-        ok = 0.0
-    try:
-        torch.cuda.synchronize(device)
-    except Exception:  # noqa: BLE001
-        ok = 0.0
-    v = torch.tensor([ok], dtype=torch.float32, device=device)
-    dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
-    return bool(v.item() > 0.5)
+            self.devcomm = devcomm.create(self.group, self._dev)
 
 
 def replicas_in_sync(*roots, group=None):

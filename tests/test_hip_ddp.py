@@ -1,7 +1,8 @@
 """GPU: the data-parallel HIP trainer (scene sharding + flat-gradient all-reduce + BatchNorm-statistics
 all-reduce + global generator counts) equals the single-process trainer.  Two ranks share the one GPU of
-the test box, so the process group uses gloo (RCCL refuses two ranks on one device); the code path through
-mggan.parallel.DistContext is the one bench.py --gpus N runs over RCCL."""
+the test box, so the process group uses gloo (RCCL refuses two ranks on one device) -- it only carries the start-up
+handshake: the collectives of the iteration are the peer-mapped all-reduce kernels of csrc/comm.hip (the two processes
+map each other's arenas through hipIpc), the code path bench.py --gpus N runs on a multi-GPU node."""
 import os
 import socket
 from collections import defaultdict
@@ -97,23 +98,29 @@ def test_two_ranks_match_single_process():
     assert np.array_equal(two[0][1], two[1][1])    # bit-identical replicas
 
 
-def _run_graph(rank, world, port, sizes, q):
-    """Sharded iteration captured as HIP-graph segments with the collectives replayed eagerly between them."""
+def _run_graph(rank, world, port, sizes, q, device_comm):
+    """Sharded iteration captured on `world` ranks (sharing the box's one GPU, handles exchanged over gloo):
+    device_comm=True: peer-mapped all-reduce kernels inside ONE graph; False: graph segments around eager collectives."""
     import sys
 
     for p in (os.path.join(ROOT, "mg-gan_amd"), ROOT):
         sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      MGGAN_DEVICE_COMM="1" if device_comm else "0")
+    if world == 1:
+        os.environ["MGGAN_FORCE_DIST"] = "1"
     import torch.distributed as dist
 
     import bench
     from mggan.data_utils import synthetic
-    from mggan.parallel import shard_batch
+    from mggan.parallel import replicas_in_sync, shard_batch
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
     tr = bench.build_trainer(2, "device", dev, seed=rank)
+    assert tr.dist.enabled
     tr.dist.equal_shards = True
     full = synthetic.make_batch(sizes, seed=9)
     batch = tr.to_device(shard_batch(full, rank, world))
@@ -124,85 +131,134 @@ def _run_graph(rank, world, port, sizes, q):
     for i in range(3):
         replay(m, True)
     torch.cuda.synchronize()
+    if tr.dist.devcomm is not None:
+        tr.dist.devcomm.check()
+    sync = replicas_in_sync(tr.G, tr.D)
     flat = torch.cat([tr.G._flat.cpu(), tr.D._flat.cpu()])
     steps = int(tr.optimizerD.seg_step.max().cpu())
+    one_graph = isinstance(replay.graph, torch.cuda.CUDAGraph)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, flat.numpy(), replay.graph.n_graphs, steps, {k: v for k, v in m.items() if "probs" not in k}))
+    q.put((rank, flat.numpy(), 1 if one_graph else replay.graph.n_graphs, steps,
+           {k: v for k, v in m.items() if "probs" not in k}, tr.dist.devcomm is not None, sync, tr.launch_mode))
 
 
-def test_two_ranks_graph_segments():
-    sizes = [3, 3, 3, 3]  # equal shards: 6 pedestrians per rank
+def _launch_graph(world, sizes, device_comm):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_graph, args=(r, 2, port, sizes, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run_graph, args=(r, world, port, sizes, q, device_comm)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=150) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=200) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, f0, n0, s0, m0), (_, f1, n1, s1, m1) = res
-    assert n0 == n1 and n0 > 10            # the collectives cut the iteration into graph segments
-    assert s0 == s1 == 2 + 3               # 2 eager warm-up iterations + 3 replays (capturing executes nothing)
+    return res
+
+
+def _check_replicas(res, replays=3):
+    (_, f0, n0, s0, m0, _, sync0, _), (_, f1, n1, s1, m1, _, sync1, _) = res
+    assert n0 == n1 and sync0 and sync1
+    assert s0 == s1 == 2 + replays         # 2 eager warm-up iterations + the replays (capturing executes nothing)
     assert np.isfinite(f0).all() and np.array_equal(f0, f1)  # replicas stay bit-identical through the replays
     for k, v in m0.items():
-        assert len(v) == 3 and np.isfinite(v).all(), k
+        assert len(v) == replays and np.isfinite(v).all(), k
         np.testing.assert_allclose(v, m1[k], rtol=1e-6)      # logged losses are global means on every rank
     assert 0.2 < m0["train/discr_loss"][-1] < 3.0
 
 
-def _run_one_graph(port, sizes, q):
-    """One rank, RCCL backend, collective hooks forced on: the all-reduces are captured inside the iteration graph."""
+def test_two_ranks_graph_segments():
+    """Fallback without peer-mapped memory: every torch.distributed collective cuts the capture."""
+    res = _launch_graph(2, [3, 3, 3, 3], device_comm=False)  # equal shards: 6 pedestrians per rank
+    _check_replicas(res)
+    assert res[0][2] > 10 and not res[0][5]  # the collectives cut the iteration into graph segments
+
+
+def test_two_ranks_one_graph_with_device_allreduce():
+    """Default on one node: the collectives are peer-mapped all-reduce kernels INSIDE the iteration graph (two
+    processes map each other's arenas through hipIpc; both replay ONE graph with the branch streams on)."""
+    res = _launch_graph(2, [3, 3, 3, 3], device_comm=True)
+    _check_replicas(res)
+    assert res[0][5] and res[0][2] == 1 and "peer-mapped" in res[0][7]
+    seg = _launch_graph(2, [3, 3, 3, 3], device_comm=False)
+    # same arithmetic as the segmented replay with eager gloo collectives (other reduction order across ranks: 1e-5)
+    rel = np.linalg.norm(res[0][1] - seg[0][1]) / np.linalg.norm(seg[0][1])
+    assert rel <= 1e-4, rel
+
+
+def test_one_rank_forced_collectives_stay_in_one_graph():
+    """MGGAN_FORCE_DIST=1: the collective hooks run with one rank -- what the sharded launch mode costs can be measured
+    on a one-GPU box (bench.py); here: it is one graph and trains."""
+    (r,) = _launch_graph(1, [3, 3, 3, 3], device_comm=True)
+    assert r[5] and r[2] == 1 and r[6] and np.isfinite(r[1]).all()
+
+
+def _run_allreduce(rank, world, port, q):
     import sys
 
     for p in (os.path.join(ROOT, "mg-gan_amd"), ROOT):
         sys.path.insert(0, p)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MGGAN_FORCE_DIST="1",
-                      MGGAN_GRAPH_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
-    import bench
-    from mggan.data_utils import synthetic
-    from mggan.parallel import graph_collectives_ok, replicas_in_sync
+    from mggan import devcomm
 
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    ok = graph_collectives_ok(dev)
-    tr = bench.build_trainer(2, "device", dev, seed=0)
-    assert tr.dist.enabled
-    tr.dist.equal_shards = True
-    batch = tr.to_device(synthetic.make_batch(sizes, seed=9))
-    batch["loss_mask"] = None
-    tr.defer_metrics = True
-    m = defaultdict(list)
-    replay = tr.capture_iteration(batch, warmup=2)
+    comm = devcomm.create(None, dev)
+    assert comm is not None, "peer mapping failed"
+    ok = True
+    gen = torch.Generator().manual_seed(3)  # every rank draws the same table and takes its row
+    side = torch.cuda.Stream()
+    for rnd, (n, dt) in enumerate([(5, torch.float64), (90000, torch.float32), (32, torch.float64), (8, torch.int32),
+                                   (2049, torch.float32), (131072, torch.float32), (1, torch.float32)] * 3):
+        if dt == torch.int32:
+            table = torch.randint(-50, 50, (world, n), generator=gen, dtype=torch.int32)
+        else:
+            table = torch.randn(world, n, generator=gen, dtype=dt)
+        want = table[0].clone()
+        for j in range(1, world):  # rank order, like the kernel
+            want += table[j]
+        x = table[rank].to(dev)
+        with torch.cuda.stream(side if rnd % 2 else torch.cuda.current_stream()):  # two channels
+            comm.all_reduce_(x)
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(x.cpu(), want)
+    # captured: the sequence counter lives on the device, a replay is a fresh collective
+    x = torch.full((1000,), float(rank + 1), device=dev)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        comm.all_reduce_(x)  # warm the channel of this stream outside the capture
+        x.fill_(float(rank + 1))
+        with torch.cuda.graph(g, stream=s):
+            comm.all_reduce_(x)
     for _ in range(3):
-        replay(m, True)
-    torch.cuda.synchronize()
-    sync = replicas_in_sync(tr.G, tr.D)
-    flat = torch.cat([tr.G._flat.cpu(), tr.D._flat.cpu()])
-    one_graph = isinstance(replay.graph, torch.cuda.CUDAGraph)
+        x.fill_(float(rank + 1))
+        g.replay()
+        torch.cuda.synchronize()
+        ok = ok and bool((x == sum(range(1, world + 1))).all())
+    comm.check()
+    dist.barrier()
+    comm.close()
     dist.destroy_process_group()
-    q.put((ok, tr.graph_collectives, one_graph, sync, flat.numpy(), {k: v for k, v in m.items() if "probs" not in k}))
+    q.put((rank, ok))
 
 
-@pytest.mark.skipif(os.environ.get("MGGAN_TEST_RCCL_GRAPH", "0") != "1",
-                    reason="experimental path (opt-in: MGGAN_TEST_RCCL_GRAPH=1); the RCCL watchdog intermittently aborts "
-                           "the process when collectives are captured (hipErrorCapturedEvent)")
-def test_rccl_collectives_inside_one_graph():
-    """RCCL all-reduces are capturable: the sharded iteration is then ONE HIP graph (no segment per collective)."""
+def test_device_allreduce_is_exact_and_capturable():
+    """csrc/comm.hip on its own: f32 / f64 / i32 vectors from 1 element to a full slot, on two channels, eager and
+    replayed from a graph, equal the rank-ordered sum to the bit."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_run_one_graph, args=(_free_port(), [3, 3, 3, 3], q))
-    p.start()
-    ok, in_graph, one_graph, sync, flat, m = q.get(timeout=300)
-    p.join(60)
-    assert p.exitcode == 0
-    assert ok and in_graph and one_graph and sync
-    assert np.isfinite(flat).all()
-    for k, v in m.items():
-        assert len(v) == 3 and np.isfinite(v).all(), k
-    assert 0.2 < m["train/discr_loss"][-1] < 3.0
+    port = _free_port()
+    procs = [ctx.Process(target=_run_allreduce, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
