@@ -251,7 +251,10 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
            "value": round(world * b * args.steps / dt, 2), "unit": "trajectories/s", "rng": rng, "launch": launch,
            "bn_sync": tr.config.bn_sync,
            "last_losses": {k: round(v[-1], 6) for k, v in sorted(metrics.items()) if "probs" not in k}}
+    if sharded and tr.dist.devcomm is not None:
+        tr.dist.devcomm.check()  # a timed-out wait inside a peer-mapped all-reduce would have flagged the arena
     if not profile:
+        tr.dist.close()
         del tr, replay
         torch.cuda.empty_cache()
         return res
@@ -306,6 +309,7 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
         "launches_per_step": round(sum(r[2] for r in rows), 1),
         "breakdown": [{"entry": n, "kernel": sym, "ms_per_step": round(ms, 4), "calls": round(c, 2), "gflop": round(fl / 1e9, 3)}
                       for ms, n, c, fl, sym in rows[:14]]})
+    tr.dist.close()
     del tr, replay
     torch.cuda.empty_cache()
     return res

@@ -258,6 +258,17 @@ int mggan_comm_ipc_close(void* p);
 int mggan_comm_allreduce(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
                          mggan_stream_t stream);
 int mggan_comm_error(const void* arena, unsigned int* out);
+/* Sharded scene CNN: one launch per BatchNorm exchange point -- fold this rank's partial rows, all-reduce the 2C sums
+ * and the element count over the ranks (peer-mapped arenas of the calling stream's channel), finalize with the global
+ * statistics (forward: scale / shift / stat / running statistics; backward: coef / coefd, dgamma / dbeta += this rank's
+ * share).  Same results on every rank. */
+int mggan_bn_sync_finalize(void* const* arenas, int rank, int world, long max_elems, const double* part, int rows,
+                           double local_count, int C, const float* gamma, const float* beta, float* run_mean,
+                           float* run_var, long long* num_batches_tracked, float momentum, float eps, int updates,
+                           float* scale, float* shift, float* stat, mggan_stream_t stream);
+int mggan_bn_bwd_sync_finalize(void* const* arenas, int rank, int world, long max_elems, const double* part, int rows,
+                               double local_count, int C, const float* gamma, const float* stat, float* coef,
+                               double* coefd, float* dgamma, float* dbeta, mggan_stream_t stream);
 
 /* ---- losses (+ gradients), clipping, AdamW ----------------------------------------------
  * reference: abstract_train.py:62-67, utils.py:18-25, train.py:58-75,92-113,181-200,626-639,

@@ -23,6 +23,7 @@
 // given a ticket word -- lets the last workgroup to finish fold the rows in index order (f64) and do the BatchNorm
 // bookkeeping itself: no separate reduce / finalize launches on the single-GPU path.
 #include "common.h"
+#include "comm_dev.h"
 #include "../../include/mggan_hip.h"
 
 #define IH 33
@@ -397,6 +398,35 @@ __global__ void bn_bwd_coef_kernel(const double* sums, const double* local, int 
   fin.dgamma[c] = keep_g + (float)local[C + c];
 }
 
+// Sharded training: fold this rank's partial rows, exchange the 2C sums (+ the rank's element count) with the other ranks
+// through the peer-mapped arenas, finalize with the GLOBAL statistics -- one launch per BatchNorm exchange point.
+__global__ __launch_bounds__(256) void bn_sync_finalize_kernel(CommArgs ca, const double* part, int rows, int C,
+                                                               double local_count, BnFin fin) {
+  __shared__ double colsum[64], cred[8 * 32];
+  colsum_rows(part, rows, 2 * C, colsum, cred);
+  if (threadIdx.x == 0) colsum[2 * C] = local_count;
+  comm_allreduce_small(ca, colsum, 2 * C + 1);
+  fin.count = colsum[2 * C];
+  bn_finalize_lane(fin, C, colsum);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_sync_finalize_kernel(CommArgs ca, const double* part, int rows, int C,
+                                                                   double local_count, BnBwdFin fin) {
+  __shared__ double colsum[64], local[64], cred[8 * 32];
+  colsum_rows(part, rows, 2 * C, colsum, cred);
+  if ((int)threadIdx.x < 2 * C) local[threadIdx.x] = colsum[threadIdx.x];
+  if (threadIdx.x == 0) colsum[2 * C] = local_count;
+  comm_allreduce_small(ca, colsum, 2 * C + 1);
+  fin.count = colsum[2 * C];
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  // coefficients from the global sums; the parameter gradients take this rank's share (the gradient all-reduce adds)
+  const float keep_b = fin.dbeta[c], keep_g = fin.dgamma[c];
+  bn_bwd_finalize_lane(fin, C, colsum);
+  fin.dbeta[c] = keep_b + (float)local[c];
+  fin.dgamma[c] = keep_g + (float)local[C + c];
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Gram matrix of the image patches: P[s][t] = sum_{img,pos} patch[pos][s] patch[pos][t], taps ordered t = 9*ci + 3*ky + kx,
 // tap 36 = 1.  A and B operand of a 16x16x4 MFMA are the SAME register when both index (tap, position): three LDS
@@ -716,6 +746,34 @@ int mggan_bn_bwd_coef(const double* sums, const double* local_sums, double count
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(1), dim3(64), 0, stream, sums, local_sums, C,
                      make_bfin(nullptr, count, gamma, stat, coef, coefd, dgamma, dbeta));
   MG_LAUNCH_CHECK("bn_bwd_coef");
+  return MGGAN_OK;
+}
+
+int mggan_bn_sync_finalize(void* const* arenas, int rank, int world, long max_elems, const double* part, int rows,
+                           double local_count, int C, const float* gamma, const float* beta, float* run_mean,
+                           float* run_var, long long* num_batches_tracked, float momentum, float eps, int updates,
+                           float* scale, float* shift, float* stat, hipStream_t stream) {
+  MG_CHECK_ARG(arenas && part && gamma && beta && run_mean && run_var && num_batches_tracked && scale && shift && stat &&
+                   C <= 16 && world >= 1 && world <= COMM_MAX_RANKS,
+               "bn_sync_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_sync_finalize_kernel, dim3(1), dim3(256), 0, stream, comm_make_args(arenas, rank, world, max_elems),
+                     part, rows, C, local_count,
+                     make_fin(nullptr, 0.0, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
+                              scale, shift, stat));
+  MG_LAUNCH_CHECK("bn_sync_finalize");
+  return MGGAN_OK;
+}
+
+int mggan_bn_bwd_sync_finalize(void* const* arenas, int rank, int world, long max_elems, const double* part, int rows,
+                               double local_count, int C, const float* gamma, const float* stat, float* coef,
+                               double* coefd, float* dgamma, float* dbeta, hipStream_t stream) {
+  MG_CHECK_ARG(arenas && part && gamma && stat && coef && dgamma && dbeta && C <= 16 && world >= 1 &&
+                   world <= COMM_MAX_RANKS,
+               "bn_bwd_sync_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_sync_finalize_kernel, dim3(1), dim3(256), 0, stream,
+                     comm_make_args(arenas, rank, world, max_elems), part, rows, C, local_count,
+                     make_bfin(nullptr, 0.0, gamma, stat, coef, coefd, dgamma, dbeta));
+  MG_LAUNCH_CHECK("bn_bwd_sync_finalize");
   return MGGAN_OK;
 }
 

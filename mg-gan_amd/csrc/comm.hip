@@ -15,30 +15,7 @@
 #include "common.h"
 #include "../../include/mggan_hip.h"
 
-#define COMM_MAX_RANKS 8
-#define COMM_CHUNK 2048                 // elements per workgroup (8 per lane)
-#define COMM_TIMEOUT_TICKS 200000000ll  // wall_clock64 ticks (100 MHz): 2 s
-
-struct CommHeader {        // at the start of every arena (local use only)
-  unsigned seq;            // collectives completed on this channel
-  unsigned done;           // workgroups of the running collective that have finished
-  unsigned error;          // set when a wait timed out
-  unsigned pad;
-};
-
-struct CommArgs {
-  void* arena[COMM_MAX_RANKS];  // arena of rank j for this channel, mapped into this process (arena[rank] = own)
-  void* data;                   // vector to reduce in place
-  long n;
-  long max_elems;               // capacity of one slot in elements of the widest type (8 bytes)
-  int rank, world, max_blocks, dtype;  // dtype 0: f32, 1: f64, 2: i32
-};
-
-__host__ __device__ inline size_t comm_flags_off() { return 64; }
-__host__ __device__ inline size_t comm_data_off(int max_blocks) {
-  const size_t f = 64 + (size_t)2 * COMM_MAX_RANKS * max_blocks * sizeof(unsigned);
-  return (f + 255) / 256 * 256;
-}
+#include "comm_dev.h"
 
 template <typename T>
 __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommArgs a) {

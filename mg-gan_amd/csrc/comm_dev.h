@@ -1,0 +1,79 @@
+// Device-side pieces of the peer-mapped all-reduce (csrc/comm.hip) that other kernels embed: the arena layout and a
+// small-vector exchange done by ONE workgroup (the BatchNorm statistics of the sharded scene CNN are 33 doubles: the
+// kernel that folds the partial rows also exchanges them and finalizes, csrc/cnn2.hip).
+#pragma once
+#include "common.h"
+
+#define COMM_MAX_RANKS 8
+#define COMM_CHUNK 2048                 // elements per workgroup (8 per lane)
+#define COMM_TIMEOUT_TICKS 200000000ll  // wall_clock64 ticks (100 MHz): 2 s
+
+struct CommHeader {        // at the start of every arena (local use only)
+  unsigned seq;            // collectives completed on this channel
+  unsigned done;           // workgroups of the running collective that have finished
+  unsigned error;          // set when a wait timed out
+  unsigned pad;
+};
+
+struct CommArgs {
+  void* arena[COMM_MAX_RANKS];  // arena of rank j for this channel, mapped into this process (arena[rank] = own)
+  void* data;                   // vector to reduce in place
+  long n;
+  long max_elems;               // capacity of one slot in elements of the widest type (8 bytes)
+  int rank, world, max_blocks, dtype;  // dtype 0: f32, 1: f64, 2: i32
+};
+
+__host__ __device__ inline size_t comm_flags_off() { return 64; }
+__host__ __device__ inline size_t comm_data_off(int max_blocks) {
+  const size_t f = 64 + (size_t)2 * COMM_MAX_RANKS * max_blocks * sizeof(unsigned);
+  return (f + 255) / 256 * 256;
+}
+
+
+// All-reduce (sum, rank order) of n <= 64 doubles held in LDS by one workgroup, as chunk 0 of a collective of its own
+// on the channel of `a` (same sequence / buffer protocol as comm_allreduce_kernel).  Every thread must call it.
+__device__ __forceinline__ void comm_allreduce_small(const CommArgs& a, double* vals, int n) {
+  char* mine = (char*)a.arena[a.rank];
+  CommHeader* hdr = (CommHeader*)mine;
+  const unsigned seq = __hip_atomic_load(&hdr->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const int buf = seq & 1, W = a.world, r = a.rank;
+  const size_t slot_bytes = (size_t)a.max_elems * 8, doff = comm_data_off(a.max_blocks);
+  __syncthreads();
+  for (int j = 0; j < W; ++j) {
+    double* dst = (double*)((char*)a.arena[j] + doff + ((size_t)buf * COMM_MAX_RANKS + r) * slot_bytes);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = vals[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if ((int)threadIdx.x < W) {
+    unsigned* pf = (unsigned*)((char*)a.arena[threadIdx.x] + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + r) * a.max_blocks;
+    __hip_atomic_store(pf, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned* wf = (unsigned*)(mine + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + threadIdx.x) * a.max_blocks;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(wf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > COMM_TIMEOUT_TICKS) {
+        __hip_atomic_store(&hdr->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  const double* base = (const double*)(mine + doff + (size_t)buf * COMM_MAX_RANKS * slot_bytes);
+  const size_t stride = slot_bytes / sizeof(double);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    double s = __builtin_nontemporal_load(base + i);
+    for (int j = 1; j < W; ++j) s += __builtin_nontemporal_load(base + (size_t)j * stride + i);
+    vals[i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static inline CommArgs comm_make_args(void* const* arenas, int rank, int world, long max_elems) {
+  CommArgs a;
+  for (int j = 0; j < COMM_MAX_RANKS; ++j) a.arena[j] = j < world ? arenas[j] : nullptr;
+  a.data = nullptr; a.n = 0; a.max_elems = max_elems; a.rank = rank; a.world = world;
+  a.max_blocks = cdiv(max_elems * 2, COMM_CHUNK); a.dtype = 1;
+  return a;
+}

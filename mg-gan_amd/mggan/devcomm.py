@@ -67,6 +67,11 @@ class DeviceComm:
             self._channel_of[sid] = ch
         return ch
 
+    def channel_args(self):
+        """(arenas, rank, world, max_elems) of the current stream's channel, for kernels that embed the small exchange
+        (mggan_bn_sync_finalize)."""
+        return self._arenas[self._channel()], self.rank, self.world, self.MAX_ELEMS
+
     def supports(self, t):
         cap = self.MAX_ELEMS * (1 if t.dtype == torch.float64 else 2)
         return t.is_cuda and t.is_contiguous() and t.dtype in _DTYPES and t.numel() <= cap

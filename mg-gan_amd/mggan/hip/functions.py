@@ -1121,7 +1121,14 @@ class SceneAttentionFn(Function):
                     _p(out3[0]), _p(out3[1]), _p(out3[2]))
 
         def finalize_unfused(bn, gamma, beta, hw, out3):
-            """eval mode (running statistics) or sharded training (sums all-reduced over the ranks first)"""
+            """eval mode (running statistics) or sharded training (sums exchanged between the ranks first)"""
+            dc = getattr(sync, "devcomm", None) if training else None
+            if dc is not None:  # fold + peer-mapped exchange + finalize: ONE launch per exchange point
+                lib.mggan_bn_sync_finalize(*dc.channel_args(), _p(part), grid if B else 0, float(B) * hw, C, _p(gamma),
+                                           _p(beta), _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked),
+                                           float(bn.momentum), float(bn.eps), stat_updates, _p(out3[0]), _p(out3[1]),
+                                           _p(out3[2]), st)
+                return float("nan")  # the global count travels with the sums; the backward pass re-exchanges its own
             sums, n = None, float(B)
             if training:
                 sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
@@ -1181,7 +1188,12 @@ class SceneAttentionFn(Function):
             wgrad(ds, rows, hact, rows, root.grad_ptr(wb), 32, root.grad_ptr(bb), rows, 32, C, fm=1)
             wgrad(dz, rows, vs, rows, root.grad_ptr(wa), C, root.grad_ptr(ba), rows, C, 32, fm=1)
 
-        def bn_bwd_sharded(part, nrows, gamma, beta, stat, cnt, coef, coefd):
+        def bn_bwd_sharded(part, nrows, gamma, beta, stat, cnt, coef, coefd, hw):
+            dc = getattr(sync, "devcomm", None)
+            if dc is not None:
+                lib.mggan_bn_bwd_sync_finalize(*dc.channel_args(), _p(part), nrows if B else 0, float(B) * hw, C, _p(gamma),
+                                               _p(stat), _p(coef), _p(coefd), root.grad_ptr(gamma), root.grad_ptr(beta), st)
+                return
             sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
             lib.mggan_bn_reduce_rows(_p(part), nrows if B else 0, 2 * C, _p(sums), st)
             local = sums.clone()
@@ -1190,7 +1202,7 @@ class SceneAttentionFn(Function):
                                   root.grad_ptr(gamma), root.grad_ptr(beta), st)
 
         if not fused:
-            bn_bwd_sharded(part2, rows2, g2, be2, stat2, cnt2, coef2, None)
+            bn_bwd_sharded(part2, rows2, g2, be2, stat2, cnt2, coef2, None, 16 * 16)
         G1c = _empty(B, C, 16, 16, like=img)
         code1 = torch.empty(B, C, 16, 16, dtype=torch.uint8, device=dev)
         grid = lib.mggan_cnn_bwd_grid(B)
@@ -1210,7 +1222,7 @@ class SceneAttentionFn(Function):
             _queue_reduce(ws.data_ptr(), pw, 0, 1, C * C * 9, 0, C * C * 9, grid, 1, wl, keep=(ws,))
             _queue_reduce(ws.data_ptr() + 4 * C * C * 9, pb, 0, 1, C, 0, C, grid, 1, wl)
         if not fused:
-            bn_bwd_sharded(part1, grid, g1, be1, stat1, cnt1, coef1, coefd1)
+            bn_bwd_sharded(part1, grid, g1, be1, stat1, cnt1, coef1, coefd1, 33 * 33)
         # conv1: the image needs no gradient; dW1 from the sparse routed gradients and the batch's Gram matrix (f64);
         # db1 is identically zero in front of a train-mode BatchNorm (the slot is attached: the reference's set of
         # touched parameters includes it)

@@ -123,6 +123,12 @@ class DistContext:
             join_side_stream()
             self._collective(root._flat_grad)
 
+    def close(self):
+        """Unmap / free the peer-mapped arenas (a process that builds several trainers in a row)."""
+        if self.devcomm is not None:
+            self.devcomm.close()
+            self.devcomm = None
+
     def attach(self, *roots, bn_sync="global"):
         """bn_sync 'global': the scene CNNs' BatchNorm statistics are all-reduced (14 of the ~18 collectives of an
         iteration; results equal a single process on the whole batch); 'local': per-rank statistics, no exchange."""
