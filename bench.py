@@ -233,6 +233,28 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
         run_step(i == args.warmup - 1)
     tr.flush_metrics()
     barrier()
+    if sharded and tr.dist.devcomm is not None:
+        # the peer-mapped all-reduce has never met this node before: the replicas must still hold identical weights
+        # and no wait may have timed out; otherwise every rank falls back to torch.distributed collectives together
+        from mggan.parallel import replicas_in_sync
+
+        ok = 1.0
+        try:
+            tr.dist.devcomm.check()
+            ok = 1.0 if replicas_in_sync(tr.G, tr.D) else 0.0
+        except Exception as exc:  # noqa: BLE001
+            print("[bench] rank {}: {}".format(rank, exc), file=sys.stderr)
+            ok = 0.0
+        v = torch.tensor([ok], device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        if float(v.item()) < 0.5:
+            print("[bench] rank {}: peer-mapped all-reduce rejected; re-measuring with torch.distributed collectives".format(
+                rank), file=sys.stderr)
+            os.environ["MGGAN_DEVICE_COMM"] = "0"
+            tr.dist.close()
+            del tr, replay
+            torch.cuda.empty_cache()
+            return measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile, graph, rng)
     t0 = time.perf_counter()
     for i in range(args.steps):
         run_step(i == args.steps - 1)  # logged losses are fetched once (one D2H) inside the timed region

@@ -50,9 +50,10 @@ __device__ __forceinline__ void comm_allreduce_small(const CommArgs& a, double* 
     __hip_atomic_store(pf, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     unsigned* wf = (unsigned*)(mine + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + threadIdx.x) * a.max_blocks;
     const long long t0 = wall_clock64();
+    const bool dead = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     while (__hip_atomic_load(wf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
       __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > COMM_TIMEOUT_TICKS) {
+      if (dead || wall_clock64() - t0 > COMM_TIMEOUT_TICKS) {
         __hip_atomic_store(&hdr->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }

@@ -23,39 +23,82 @@ class DeviceComm:
     CHANNELS = 6
 
     def __init__(self, group, device):
+        """Collective: every rank of `group` calls it.  Raises on EVERY rank if any rank fails (the phases end with an
+        exchange of verdicts, so the ranks never wait for a peer that has given up)."""
         self.group, self.device = group, torch.device(device)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        if self.world > 8:
-            raise RuntimeError("device all-reduce: at most 8 ranks (one node)")
-        nbytes = lib.mggan_comm_arena_bytes(self.MAX_ELEMS)
-        self._local, handles = [], []
-        with torch.cuda.device(self.device):
-            for _ in range(self.CHANNELS):
-                p = ctypes.c_void_p()
-                lib.mggan_comm_alloc(nbytes, ctypes.byref(p))
-                h = ctypes.create_string_buffer(64)
-                lib.mggan_comm_ipc_handle(p, h)
-                self._local.append(p)
-                handles.append(h.raw)
-            torch.cuda.synchronize(self.device)
+        self._local, self._opened, self._arenas, self._channel_of = [], [], [], {}
+
+        def agree(payload, what):
             everyone = [None] * self.world
-            dist.all_gather_object(everyone, (socket.gethostname(), os.getpid(), handles), group=group)
-            if len({h for h, _, _ in everyone}) != 1:
-                raise RuntimeError("device all-reduce: the ranks are not on one node")
-            self._arenas, self._opened = [], []
-            for ch in range(self.CHANNELS):
-                arr = (ctypes.c_void_p * self.world)()
-                for j, (_, pid, hs) in enumerate(everyone):
-                    if j == self.rank:
-                        arr[j] = self._local[ch]
-                    else:
-                        q = ctypes.c_void_p()
-                        lib.mggan_comm_ipc_open(hs[ch], ctypes.byref(q))
-                        self._opened.append(q)
-                        arr[j] = q
-                self._arenas.append(arr)
-        dist.barrier(group=group)  # every arena is mapped everywhere before the first collective
-        self._channel_of = {}
+            dist.all_gather_object(everyone, payload, group=group)
+            bad = [j for j, p in enumerate(everyone) if p is None]
+            if bad:
+                self.close()
+                raise RuntimeError("{} failed on rank(s) {}".format(what, bad))
+            return everyone
+
+        # phase 1: allocate and export this rank's arenas
+        mine = None
+        try:
+            if self.world > 8:
+                raise RuntimeError("at most 8 ranks (one node)")
+            nbytes = lib.mggan_comm_arena_bytes(self.MAX_ELEMS)
+            handles = []
+            with torch.cuda.device(self.device):
+                for _ in range(self.CHANNELS):
+                    p = ctypes.c_void_p()
+                    lib.mggan_comm_alloc(nbytes, ctypes.byref(p))
+                    self._local.append(p)
+                    h = ctypes.create_string_buffer(64)
+                    lib.mggan_comm_ipc_handle(p, h)
+                    handles.append(h.raw)
+                torch.cuda.synchronize(self.device)
+            mine = (socket.gethostname(), handles)
+        except Exception as exc:  # noqa: BLE001
+            print("[mggan] device all-reduce, rank {}: {}: {}".format(self.rank, type(exc).__name__, exc))
+        everyone = agree(mine, "arena allocation / export")
+        if len({h for h, _ in everyone}) != 1:
+            self.close()
+            raise RuntimeError("the ranks are not on one node")
+        # phase 2: map the peers' arenas
+        ok = None
+        try:
+            with torch.cuda.device(self.device):
+                for ch in range(self.CHANNELS):
+                    arr = (ctypes.c_void_p * self.world)()
+                    for j, (_, hs) in enumerate(everyone):
+                        if j == self.rank:
+                            arr[j] = self._local[ch]
+                        else:
+                            q = ctypes.c_void_p()
+                            lib.mggan_comm_ipc_open(hs[ch], ctypes.byref(q))
+                            self._opened.append(q)
+                            arr[j] = q
+                    self._arenas.append(arr)
+            ok = True
+        except Exception as exc:  # noqa: BLE001
+            print("[mggan] device all-reduce, rank {}: {}: {}".format(self.rank, type(exc).__name__, exc))
+        agree(ok, "peer mapping")  # also the barrier: every arena is mapped everywhere before the first collective
+        # phase 3: known-answer exchanges
+        agree(True if self.self_test() else None, "self test (wrong sums or a timed-out wait)")
+
+    def self_test(self):
+        """One f32, one f64 and one i32 exchange on the first channel with known answers, and no timed-out wait."""
+        w = self.world
+        want = float(w * (w + 1) // 2)
+        ok = True
+        with torch.cuda.device(self.device):
+            for dt, n in ((torch.float32, 3000), (torch.float64, 33), (torch.int32, 9)):
+                x = torch.full((n,), self.rank + 1, dtype=dt, device=self.device)
+                self.all_reduce_(x)
+                torch.cuda.synchronize(self.device)
+                ok = ok and bool((x == want).all())
+        try:
+            self.check()
+        except RuntimeError:
+            ok = False
+        return ok
 
     def _channel(self):
         sid = torch.cuda.current_stream(self.device).cuda_stream
@@ -106,16 +149,9 @@ def create(group, device):
     falls back to torch.distributed together)."""
     if os.environ.get("MGGAN_DEVICE_COMM", "1") == "0":
         return None
-    comm, ok = None, 1
     try:
-        comm = DeviceComm(group, device)
-    except Exception as exc:  # noqa: BLE001 -- the verdict is agreed on below
-        print("[mggan] device all-reduce unavailable on rank {}: {}: {}".format(dist.get_rank(group), type(exc).__name__, exc))
-        ok = 0
-    verdict = [None] * dist.get_world_size(group)
-    dist.all_gather_object(verdict, ok, group=group)
-    if not all(verdict):
-        if comm is not None:
-            comm.close()
+        return DeviceComm(group, device)  # raises on every rank together
+    except Exception as exc:  # noqa: BLE001
+        print("[mggan] device all-reduce unavailable ({}: {}); torch.distributed collectives between graph segments "
+              "instead".format(type(exc).__name__, exc))
         return None
-    return comm
