@@ -49,9 +49,9 @@ def kernel_of(name, a):
     if name == "mggan_conv1_pool":
         return "conv1_pool_kernel<{}>".format(a[2])
     if name == "mggan_conv2_fwd2":
-        return "conv2_fwd2_kernel<{}>".format(a[3])
+        return "conv2_fwd2_kernel<{}>".format(a[2])
     if name == "mggan_conv2_bwd":
-        return "conv2_bwd_mfma_kernel" if a[4] == 16 else "conv2_bwd_kernel<8>"
+        return "conv2_bwd_mfma_kernel" if a[2] == 16 else "conv2_bwd_kernel<8>"
     if name == "mggan_conv1_wgrad":
         return "conv1_wgrad_kernel<{}>".format(a[2])
     if name == "mggan_image_gram":
@@ -95,9 +95,9 @@ def flops_of(name, a):
     if name == "mggan_conv1_pool":
         return float(a[1]) * 2 * 33 * 33 * a[2] * 36
     if name == "mggan_conv2_fwd2":
-        return float(a[2]) * 2 * 256 * a[3] * a[3] * 9
+        return float(a[1]) * 2 * 256 * a[2] * a[2] * 9
     if name == "mggan_conv2_bwd":
-        return float(a[3]) * 2 * 2 * 256 * a[4] * a[4] * 9
+        return float(a[1]) * 2 * 2 * 256 * a[2] * a[2] * 9
     if name == "mggan_conv1_wgrad":  # the reference operator: a dense (C x 36) x (33*33 positions) weight gradient
         return float(a[1]) * 2 * 33 * 33 * a[2] * 36
     if name == "mggan_image_gram":  # not in the reference's operator list (bookkeeping of the factorised conv1 gradient)

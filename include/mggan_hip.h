@@ -178,9 +178,10 @@ int mggan_segment_max_bwd(int P, int B, const int* pair_o, const int* ped_prow, 
 
 /* ---- scene CNN + physical attention -----------------------------------------------------
  * reference: cnn.py:119-160 (Conv_Blocks), :275-282 (CNN.forward), :109-116 (AttentionGlobal.forward)
- * img (B,4,33,33) -> conv1 (never stored at full resolution: the raw window maximum / minimum (B,C,16,16) x2 and the
- * 2-bit window positions are kept -- ReLU(BN(.)) is monotone, so the pooled activation is ReLU(BN(x_max)) for a
- * positive BatchNorm scale and ReLU(BN(x_min)) for a negative one) -> conv2 raw y2 (B,C,16,16) -> [BN+ReLU+pool] ->
+ * img (B,4,33,33) -> conv1 (never stored at full resolution: ReLU(BN(.)) is monotone, so the pooled activation is
+ * ReLU(BN(x_max)) for a positive BatchNorm scale and ReLU(BN(x_min)) for a negative one, and the scale has the sign of
+ * the parameter gamma: the raw window extreme xsel (B,C,16,16) and its 2-bit position are kept) -> conv2 raw y2
+ * (B,C,16,16) -> [BN+ReLU+pool] ->
  * attention over channels -> out (B,64).
  * Statistics: every kernel leaves ONE row of 2C doubles per workgroup in `part` ((sum, sumsq) forward, (sum g,
  * sum g*xhat) backward).  With a `ticket` (one zeroed word, left at zero) the last workgroup of the launch folds the rows
@@ -190,11 +191,11 @@ int mggan_segment_max_bwd(int P, int B, const int* pair_o, const int* ped_prow, 
  * mggan_bn_bwd_coef. */
 int mggan_cnn_grid(int B);      /* workgroups (= partial rows) of conv1_pool / conv2_fwd2 / image_gram / conv1_wgrad */
 int mggan_cnn_bwd_grid(int B);  /* workgroups (= partial rows) of conv2_bwd */
-int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float* bias, float* xmax, float* xmin,
+int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float* bias, float* xsel,
                      unsigned char* code, double* part, unsigned int* ticket, double count, const float* gamma,
                      const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
                      float eps, int updates, float* scale, float* shift, float* stat, mggan_stream_t stream);
-int mggan_conv2_fwd2(const float* xmax, const float* xmin, int B, int C, const float* scale1, const float* shift1,
+int mggan_conv2_fwd2(const float* xsel, int B, int C, const float* scale1, const float* shift1,
                      const float* W, const float* bias, float* y2, double* part, unsigned int* ticket, double count,
                      const float* gamma, const float* beta, float* run_mean, float* run_var,
                      long long* num_batches_tracked, float momentum, float eps, int updates, float* scale, float* shift,
@@ -220,12 +221,12 @@ int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2
                               float* G2, double* part, unsigned int* ticket, double count, const float* gamma2,
                               float* coef2, float* dgamma2, float* dbeta2, mggan_stream_t stream);
 /* conv2 adjoint (BatchNorm-2 backward on the fly, dW2 / db2 as per-workgroup partial rows in `workspace`, input
- * gradient routed through ReLU / max-pool of block 1 -> G1c (B,C,16,16) + window position code1); part1:
+ * gradient routed through ReLU / max-pool of block 1 -> G1c (B,C,16,16)); part1:
  * mggan_cnn_bwd_grid(B) rows; coefd1 = [gamma*invstd | S1 | S2 | mean | invstd] (C each) + count, f64, for
  * mggan_conv1_wgrad.  workspace: mggan_cnn_bwd_grid(B) * (256/(C*C)) * (C*C*9 + C) floats. */
-int mggan_conv2_bwd(const float* xmax, const float* xmin, const unsigned char* codes, int B, int C, const float* scale1,
+int mggan_conv2_bwd(const float* xsel, int B, int C, const float* scale1,
                     const float* shift1, const float* stat1, const float* y2, const float* G2, const float* stat2,
-                    const float* coef2, const float* W, float* G1c, unsigned char* code1, double* part1, float* dW,
+                    const float* coef2, const float* W, float* G1c, double* part1, float* dW,
                     float* db, float* workspace, size_t workspace_bytes, unsigned int* ticket, double count1,
                     const float* gamma1, float* coef1, double* coefd1, float* dgamma1, float* dbeta1,
                     mggan_stream_t stream);

@@ -276,16 +276,13 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
 
 // ---------------- conv2 backward: BN2 bwd + weight grad + input grad routed through pool1/ReLU ----------------
 template <int C>
-__global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __restrict__ xmax,
-                                                        const float* __restrict__ xmin,
-                                                        const unsigned char* __restrict__ codes,
+__global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __restrict__ xsel,
                                                         const float* __restrict__ scale1,
                                                         const float* __restrict__ shift1,
                                                         const float* __restrict__ stat1, const float* __restrict__ y2,
                                                         const float* __restrict__ G2, const float* __restrict__ stat2,
                                                         const float* __restrict__ coef2, const float* __restrict__ W,
-                                                        float* G1c, unsigned char* code1, double* part1, float* wpart,
-                                                        BnBwdFin fin) {
+                                                        float* G1c, double* part1, float* wpart, BnBwdFin fin) {
   constexpr int COT = C / 4, PAIRS = C * C, NQ = 256 / PAIRS, ROWS = 16 / NQ, WLEN = PAIRS * 9 + C;
   __shared__ __attribute__((aligned(16))) float dyp[C * A1_PLANE];
   __shared__ __attribute__((aligned(16))) float a1p[C * A1_PLANE];
@@ -310,14 +307,11 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
       const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
 #pragma unroll 8
       for (int c = 0; c < C; ++c) {
-        // the pooled cell's raw conv1 value and position: window maximum for scale >= 0, minimum otherwise
+        // the pooled cell's raw conv1 value (the window extreme conv1_pool kept)
         const size_t gi = ((size_t)b * C + c) * 256 + threadIdx.x;
-        const bool up = scale1[c] >= 0.f;
-        const float raw = (up ? xmax : xmin)[gi];
-        const int code = up ? (codes[gi] & 3) : (codes[gi] >> 2);
+        const float raw = xsel[gi];
         a1p[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = fmaxf(fmaf(raw, scale1[c], shift1[c]), 0.f);
         y1r[c * 256 + threadIdx.x] = raw;
-        code1[gi] = (unsigned char)code;
         const float xh = (y2[gi] - stat2[c]) * stat2[C + c];
         dyp[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (G2[gi] - coef2[C + c] - xh * coef2[2 * C + c]);
       }
@@ -430,17 +424,14 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
 #define C2_PLANE 361
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float* __restrict__ xmax,
-                                                            const float* __restrict__ xmin,
-                                                            const unsigned char* __restrict__ codes,
+__global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float* __restrict__ xsel,
                                                             const float* __restrict__ scale1,
                                                             const float* __restrict__ shift1,
                                                             const float* __restrict__ stat1,
                                                             const float* __restrict__ y2, const float* __restrict__ G2,
                                                             const float* __restrict__ stat2,
                                                             const float* __restrict__ coef2, const float* __restrict__ W,
-                                                            float* G1c, unsigned char* code1, double* part1,
-                                                            float* wpart, BnBwdFin fin) {
+                                                            float* G1c, double* part1, float* wpart, BnBwdFin fin) {
   constexpr int C = 16, WLEN = C * C * 9 + C;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dyp = smem;                       // [C][18][20] padded planes, stride C2_PLANE
@@ -469,12 +460,9 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
 #pragma unroll 8
       for (int c = 0; c < C; ++c) {
         const size_t gi = ((size_t)b * C + c) * 256 + threadIdx.x;
-        const bool up = scale1[c] >= 0.f;
-        const float raw = (up ? xmax : xmin)[gi];
-        const int code = up ? (codes[gi] & 3) : (codes[gi] >> 2);
+        const float raw = xsel[gi];
         a1p[c * C2_PLANE + (py + 1) * A1_LD + px + 1] = fmaxf(fmaf(raw, scale1[c], shift1[c]), 0.f);
         y1r[c * 256 + threadIdx.x] = raw;
-        code1[gi] = (unsigned char)code;
         const float xh = (y2[gi] - stat2[c]) * stat2[C + c];
         dyp[c * C2_PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (G2[gi] - coef2[C + c] - xh * coef2[2 * C + c]);
       }
@@ -652,17 +640,16 @@ int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2
 /* conv2 adjoint: BatchNorm-2 backward on the fly, weight gradient (per-workgroup partial rows in `workspace`:
  * mggan_cnn_bwd_grid(B) * (256/(C*C)) * (C*C*9 + C) floats, reduced into dW / db here or by the caller's batched
  * reduction when dW == NULL), input gradient routed through ReLU / max-pool of block 1 -> G1c (B,C,16,16) at pooled
- * resolution + the window position it belongs to (code1).  part1: mggan_cnn_bwd_grid(B) rows of 2C doubles; with a
+ * resolution (it belongs to the window position conv1_pool recorded).  part1: mggan_cnn_bwd_grid(B) rows of 2C doubles; with a
  * ticket the launch also finishes the BatchNorm-1 adjoint (coef1, coefd1 for mggan_conv1_wgrad, dgamma1 / dbeta1). */
-int mggan_conv2_bwd(const float* xmax, const float* xmin, const unsigned char* codes, int B, int C, const float* scale1,
+int mggan_conv2_bwd(const float* xsel, int B, int C, const float* scale1,
                     const float* shift1, const float* stat1, const float* y2, const float* G2, const float* stat2,
-                    const float* coef2, const float* W, float* G1c, unsigned char* code1, double* part1, float* dW,
+                    const float* coef2, const float* W, float* G1c, double* part1, float* dW,
                     float* db, float* workspace, size_t workspace_bytes, unsigned* ticket, double count1,
                     const float* gamma1, float* coef1, double* coefd1, float* dgamma1, float* dbeta1, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv2_bwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
-  MG_CHECK_ARG(xmax && xmin && codes && scale1 && shift1 && stat1 && y2 && G2 && stat2 && coef2 && W && G1c && code1 &&
-                   part1 && workspace,
+  MG_CHECK_ARG(xsel && scale1 && shift1 && stat1 && y2 && G2 && stat2 && coef2 && W && G1c && part1 && workspace,
                "conv2_bwd: null pointer");
   MG_CHECK_ARG(!ticket || (gamma1 && coef1 && dgamma1 && dbeta1), "conv2_bwd: the fused finalize needs gamma / coef / grads");
   const int grid = persistent_grid(B), NQ = 256 / (C * C), wlen = C * C * 9 + C;
@@ -683,11 +670,11 @@ int mggan_conv2_bwd(const float* xmax, const float* xmin, const unsigned char* c
       }
       attr = true;
     }
-    hipLaunchKernelGGL(conv2_bwd_mfma_kernel, dim3(grid), dim3(256), lds, stream, B, xmax, xmin, codes, scale1, shift1,
-                       stat1, y2, G2, stat2, coef2, W, G1c, code1, part1, workspace, fin);
+    hipLaunchKernelGGL(conv2_bwd_mfma_kernel, dim3(grid), dim3(256), lds, stream, B, xsel, scale1, shift1,
+                       stat1, y2, G2, stat2, coef2, W, G1c, part1, workspace, fin);
   } else
-    hipLaunchKernelGGL((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xmax, xmin, codes, scale1, shift1,
-                       stat1, y2, G2, stat2, coef2, W, G1c, code1, part1, workspace, fin);
+    hipLaunchKernelGGL((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1,
+                       stat1, y2, G2, stat2, coef2, W, G1c, part1, workspace, fin);
   MG_LAUNCH_CHECK("conv2_bwd");
   if (!dW) return MGGAN_OK;  // deferred reduce of the [grid][C*C*9 + C] partial rows
   hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(1024), 0, stream, workspace, grid, wlen,

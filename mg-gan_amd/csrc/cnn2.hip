@@ -5,10 +5,11 @@
 //
 //   conv1_pool_kernel   img (B,4,33,33) -> conv1 on the matrix cores, BatchNorm statistics, and the 2x2 pooling
 //                       decision on the RAW output: ReLU(scale*x+shift) is monotone in x, so maxpool(ReLU(BN(x))) is
-//                       ReLU(BN(x_max)) for scale >= 0 and ReLU(BN(x_min)) for scale < 0 -- the kernel keeps the raw
-//                       maximum AND minimum of every window (+ 2-bit positions), which needs no statistics.  What the
-//                       first-generation kernels wrote and re-read three times per pass, the raw (B,C,33,36) output
-//                       (76 KB per image), never exists; 36 KB per image are kept instead.
+//                       ReLU(BN(x_max)) for scale >= 0 and ReLU(BN(x_min)) for scale < 0, and scale = gamma/sigma has the
+//                       sign of the PARAMETER gamma -- known before any statistics exist.  The kernel keeps that raw
+//                       extreme of every window (+ its 2-bit position).  What the first-generation kernels wrote and
+//                       re-read three times per pass, the raw (B,C,33,36) output (76 KB per image), never exists;
+//                       20 KB per image are kept instead.
 //   conv2_fwd2_kernel   a1 = ReLU(scale1*x_sel+shift1) -> conv2 -> raw (B,C,16,16) + statistics.
 //   image_gram_kernel   P[s][t] = sum over images and positions of patch[s]*patch[t] (37x37, tap 36 = the constant 1):
 //                       the only DENSE quantity the conv1 weight gradient needs -- and it depends on the images alone,
@@ -22,6 +23,7 @@
 // Every kernel is persistent (<= 768 workgroups walk the images), leaves ONE partial row per workgroup, and -- when
 // given a ticket word -- lets the last workgroup to finish fold the rows in index order (f64) and do the BatchNorm
 // bookkeeping itself: no separate reduce / finalize launches on the single-GPU path.
+#include <stdlib.h>
 #include "common.h"
 #include "comm_dev.h"
 #include "../../include/mggan_hip.h"
@@ -193,8 +195,8 @@ __device__ __forceinline__ void bn_bwd_finalize_lane(const BnBwdFin& f, int C, c
 // of a k-step read four different input-channel planes.
 template <int C>
 __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __restrict__ img, const float* __restrict__ W,
-                                                         const float* __restrict__ bias, float* __restrict__ xmax,
-                                                         float* __restrict__ xmin, unsigned char* __restrict__ code,
+                                                         const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                         float* __restrict__ xsel, unsigned char* __restrict__ code,
                                                          double* part, BnFin fin) {
   __shared__ __attribute__((aligned(16))) float imgp[ILDS];
   __shared__ double redd[4][2][16];
@@ -206,6 +208,9 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __r
 #pragma unroll
   for (int s = 0; s < 9; ++s) bw[s] = fi < C ? W[fi * 36 + fk * 9 + s] : 0.f;
   const float bv = fi < C ? bias[fi] : 0.f;
+  // the BatchNorm scale gamma/sigma has the sign of gamma: this lane's channel keeps the window MAXIMUM (gamma >= 0)
+  // or MINIMUM (gamma < 0) of the raw output -- sgn * max(sgn * x)
+  const float sgn = (fi < C && gamma[fi] < 0.f) ? -1.f : 1.f;
   // A operand: lane (fi, fk) supplies row i = fi (window fi>>2, element fi&3) of input channel fk
   const int aoff = fk * IPLANE + ((fi & 3) >> 1) * ILD + 2 * (fi >> 2) + (fi & 1);
   double dsum = 0.0, dsq = 0.0;
@@ -240,20 +245,15 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __r
       for (int h = 0; h < 2; ++h) {
         const f32x4 acc = h ? a1 : a0;
         const int py = h ? py1 : py0, px = (h ? px1 : px0) + fk;
-        float mx = acc[0], mn = acc[0];
-        int cx = 0, cn = 0;
-#pragma unroll
-        for (int r = 1; r < 4; ++r) {
-          if (acc[r] > mx) { mx = acc[r]; cx = r; }
-          if (acc[r] < mn) { mn = acc[r]; cn = r; }
-        }
+        const float s0 = sgn * acc[0], s1 = sgn * acc[1], s2 = sgn * acc[2], s3 = sgn * acc[3];
+        const float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+        const int cx = s0 == mx ? 0 : (s1 == mx ? 1 : (s2 == mx ? 2 : 3));  // the first position that attains it
         sum += (acc[0] + acc[1]) + (acc[2] + acc[3]);
         sq = fmaf(acc[0], acc[0], fmaf(acc[1], acc[1], fmaf(acc[2], acc[2], fmaf(acc[3], acc[3], sq))));
         if (fi < C) {
           const size_t o = (((size_t)b * C + fi) * 16 + py) * 16 + px;
-          xmax[o] = mx;
-          xmin[o] = mn;
-          code[o] = (unsigned char)(cx | (cn << 2));
+          xsel[o] = sgn * mx;
+          code[o] = (unsigned char)cx;
         }
       }
     }
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __r
 // ------------------------------------------------------------------------------------------------------------------
 // conv2 forward: a1 = ReLU(BN1(x_sel)) with x_sel the window maximum (scale >= 0) or minimum (scale < 0)
 template <int C>
-__global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __restrict__ xmax, const float* __restrict__ xmin,
+__global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __restrict__ xsel,
                                                          const float* __restrict__ scale1, const float* __restrict__ shift1,
                                                          const float* __restrict__ W, const float* __restrict__ bias,
                                                          float* __restrict__ y2, double* part, BnFin fin) {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __r
   float v[C];
   auto fetch = [&](int b) {
 #pragma unroll
-    for (int c = 0; c < C; ++c) v[c] = (scale1[c] >= 0.f ? xmax : xmin)[((size_t)b * C + c) * 256 + threadIdx.x];
+    for (int c = 0; c < C; ++c) v[c] = xsel[((size_t)b * C + c) * 256 + threadIdx.x];
   };
   if ((int)blockIdx.x < B) fetch(blockIdx.x);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -662,6 +662,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_finalize_kernel(const double*
 // persistent grid: at most `cap` workgroups (three per CU), and every workgroup walks the same number of images
 // (the last one may fall short): 1,280 images -> 640 workgroups x 2, 8,192 -> 745 x 11
 static int grid_for(int B, int cap) {
+  static int env_cap = -1;
+  if (env_cap < 0) { const char* e = getenv("MGGAN_CNN_CAP"); env_cap = e ? atoi(e) : 0; }
+  if (env_cap > 0) cap = env_cap;
   if (B <= cap) return B;
   const int per = (B + cap - 1) / cap;
   return (B + per - 1) / per;
@@ -679,39 +682,39 @@ static BnFin make_fin(unsigned* ticket, double count, const float* gamma, const 
   return f;
 }
 
-int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float* bias, float* xmax, float* xmin,
+int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float* bias, float* xsel,
                      unsigned char* code, double* part, unsigned* ticket, double count, const float* gamma,
                      const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
                      float eps, int updates, float* scale, float* shift, float* stat, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv1_pool: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
-  MG_CHECK_ARG(img && W && bias && xmax && xmin && code && part, "conv1_pool: null pointer");
-  MG_CHECK_ARG(!ticket || (gamma && beta && run_mean && run_var && num_batches_tracked && scale && shift && stat),
+  MG_CHECK_ARG(img && W && bias && gamma && xsel && code && part, "conv1_pool: null pointer");
+  MG_CHECK_ARG(!ticket || (beta && run_mean && run_var && num_batches_tracked && scale && shift && stat),
                "conv1_pool: the fused finalize needs the BatchNorm tensors");
   const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
                              scale, shift, stat);
   const int grid = grid_for(B, 768);
-  if (C == 16) hipLaunchKernelGGL((conv1_pool_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, xmax, xmin, code, part, fin);
-  else hipLaunchKernelGGL((conv1_pool_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, xmax, xmin, code, part, fin);
+  if (C == 16) hipLaunchKernelGGL((conv1_pool_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin);
+  else hipLaunchKernelGGL((conv1_pool_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin);
   MG_LAUNCH_CHECK("conv1_pool");
   return MGGAN_OK;
 }
 
-int mggan_conv2_fwd2(const float* xmax, const float* xmin, int B, int C, const float* scale1, const float* shift1,
+int mggan_conv2_fwd2(const float* xsel, int B, int C, const float* scale1, const float* shift1,
                      const float* W, const float* bias, float* y2, double* part, unsigned* ticket, double count,
                      const float* gamma, const float* beta, float* run_mean, float* run_var,
                      long long* num_batches_tracked, float momentum, float eps, int updates, float* scale, float* shift,
                      float* stat, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv2_fwd2: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
-  MG_CHECK_ARG(xmax && xmin && scale1 && shift1 && W && bias && y2 && part, "conv2_fwd2: null pointer");
+  MG_CHECK_ARG(xsel && scale1 && shift1 && W && bias && y2 && part, "conv2_fwd2: null pointer");
   MG_CHECK_ARG(!ticket || (gamma && beta && run_mean && run_var && num_batches_tracked && scale && shift && stat),
                "conv2_fwd2: the fused finalize needs the BatchNorm tensors");
   const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
                              scale, shift, stat);
   const int grid = grid_for(B, 768);
-  if (C == 16) hipLaunchKernelGGL((conv2_fwd2_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xmax, xmin, scale1, shift1, W, bias, y2, part, fin);
-  else hipLaunchKernelGGL((conv2_fwd2_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xmax, xmin, scale1, shift1, W, bias, y2, part, fin);
+  if (C == 16) hipLaunchKernelGGL((conv2_fwd2_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
+  else hipLaunchKernelGGL((conv2_fwd2_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
   MG_LAUNCH_CHECK("conv2_fwd2");
   return MGGAN_OK;
 }

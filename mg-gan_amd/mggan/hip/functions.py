@@ -1098,7 +1098,7 @@ class SceneAttentionFn(Function):
     """CNN (2 x Conv-BN-ReLU-MaxPool) + channel-softmax attention -> (B,64)  (cnn.py:109-282).
     Forward: conv1 + pooling decision -> conv2 -> attention (three launches, BatchNorm finalized by the producing
     kernel's last workgroup).  Backward: attention adjoint -> conv2 adjoint -> conv1 weight gradient + its f64 finalize.
-    Saved for backward per image: raw window maximum / minimum and positions (36 KB), raw conv2 output (C KB)."""
+    Saved for backward per image: the raw window extreme and its position (C x 1.25 KB), raw conv2 output (C KB)."""
 
     @staticmethod
     def forward(ctx, img, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb, bb, bn1, bn2, training, owner, sync, save,
@@ -1109,7 +1109,7 @@ class SceneAttentionFn(Function):
         dev = img.device
         tk = _cnn_tickets(owner, dev)
         grid = max(lib.mggan_cnn_grid(B), 1)
-        xmax, xmin = _empty(B, C, 16, 16, like=img), _empty(B, C, 16, 16, like=img)
+        xsel = _empty(B, C, 16, 16, like=img)  # raw conv1 output at the pooling position of every window
         code = torch.empty(B, C, 16, 16, dtype=torch.uint8, device=dev)
         part = torch.empty(grid, 2 * C, dtype=torch.float64, device=dev)
         fused = training and sync is None  # single GPU: the kernel's last workgroup finalizes BatchNorm itself
@@ -1140,13 +1140,13 @@ class SceneAttentionFn(Function):
             return n * hw
 
         b1 = mk()
-        lib.mggan_conv1_pool(_p(img), B, C, _p(c1w), _p(c1b), _p(xmax), _p(xmin), _p(code), _p(part),
+        lib.mggan_conv1_pool(_p(img), B, C, _p(c1w), _p(c1b), _p(xsel), _p(code), _p(part),
                              *bn_args(bn1, g1, be1, 33 * 33, 0, b1), st)
         cnt1 = float(B) * 33 * 33 if fused else finalize_unfused(bn1, g1, be1, 33 * 33, b1)
         sc1, sh1, stat1 = b1
         y2 = _empty(B, C, 16, 16, like=img)
         b2 = mk()
-        lib.mggan_conv2_fwd2(_p(xmax), _p(xmin), B, C, _p(sc1), _p(sh1), _p(c2w), _p(c2b), _p(y2), _p(part),
+        lib.mggan_conv2_fwd2(_p(xsel), B, C, _p(sc1), _p(sh1), _p(c2w), _p(c2b), _p(y2), _p(part),
                              *bn_args(bn2, g2, be2, 16 * 16, 1, b2), st)
         cnt2 = float(B) * 16 * 16 if fused else finalize_unfused(bn2, g2, be2, 16 * 16, b2)
         sc2, sh2, stat2 = b2
@@ -1157,13 +1157,13 @@ class SceneAttentionFn(Function):
                 raise RuntimeError("scene attention backward is only implemented for train-mode BatchNorm "
                                    "(the reference never differentiates in eval mode)")
             ctx.owner, ctx.sync, ctx.counts = owner, sync, (cnt1, cnt2)
-            ctx.save_for_backward(img, xmax, xmin, code, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b,
+            ctx.save_for_backward(img, xsel, code, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b,
                                   g2, be2, wa, ba, wb, bb)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (img, xmax, xmin, code, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb,
+        (img, xsel, code, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb,
          bb) = ctx.saved_tensors
         root, sync = root_of(ctx.owner), ctx.sync
         cnt1, cnt2 = ctx.counts
@@ -1204,7 +1204,6 @@ class SceneAttentionFn(Function):
         if not fused:
             bn_bwd_sharded(part2, rows2, g2, be2, stat2, cnt2, coef2, None, 16 * 16)
         G1c = _empty(B, C, 16, 16, like=img)
-        code1 = torch.empty(B, C, 16, 16, dtype=torch.uint8, device=dev)
         grid = lib.mggan_cnn_bwd_grid(B)
         nb = grid * (256 // (C * C)) * (C * C * 9 + C) * 4
         ws = _empty(nb // 4, like=img)
@@ -1213,8 +1212,8 @@ class SceneAttentionFn(Function):
         coefd1 = torch.empty(5 * C + 1, dtype=torch.float64, device=dev)
         defer = _DEFER["on"]
         pw, pb = root.grad_ptr(c2w), root.grad_ptr(c2b)
-        lib.mggan_conv2_bwd(_p(xmax), _p(xmin), _p(code), B, C, _p(sc1), _p(sh1), _p(stat1), _p(y2), _p(G2), _p(stat2),
-                            _p(coef2), _p(c2w), _p(G1c), _p(code1), _p(part1), 0 if defer else pw, 0 if defer else pb,
+        lib.mggan_conv2_bwd(_p(xsel), B, C, _p(sc1), _p(sh1), _p(stat1), _p(y2), _p(G2), _p(stat2),
+                            _p(coef2), _p(c2w), _p(G1c), _p(part1), 0 if defer else pw, 0 if defer else pb,
                             _p(ws), nb, tk.data_ptr() + 12 if fused else 0, cnt1, _p(g1), _p(coef1), _p(coefd1),
                             root.grad_ptr(g1), root.grad_ptr(be1), st)
         if defer:
@@ -1230,7 +1229,7 @@ class SceneAttentionFn(Function):
         gram = _image_gram(img)
         nbw = max(lib.mggan_cnn_grid(B), 1) * C * 36 * 8
         wsw = torch.empty(nbw // 8, dtype=torch.float64, device=dev)
-        lib.mggan_conv1_wgrad(_p(img), B, C, _p(G1c), _p(code1), _p(gram), _p(c1w), _p(c1b), _p(coefd1), root.grad_ptr(c1w),
+        lib.mggan_conv1_wgrad(_p(img), B, C, _p(G1c), _p(code), _p(gram), _p(c1w), _p(c1b), _p(coefd1), root.grad_ptr(c1w),
                               _p(wsw), nbw, st)
         return (None,) * 21
 
