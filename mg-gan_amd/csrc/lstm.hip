@@ -16,6 +16,7 @@
 // un-folded by the chain rule in mggan_lstm_unfold_grads.
 // Rows are pre-bucketed by generator so that a workgroup's lanes load one
 // generator's weights (L1-resident) and weight-gradient GEMMs see contiguous segments.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/mggan_hip.h"
 
@@ -143,6 +144,8 @@ struct SeqArgs {
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 // Instruction-issue bound, so the step loop is written for few instructions and <= 256 registers (two waves
@@ -216,6 +219,92 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(SeqArgs p) {
     }
   }
   if (valid) p.hout[(size_t)r * p.ld_hout + j] = hj;
+}
+
+// Matrix-core form of the trajectory encoder (same saved-tensor layout as lstm_fwd_kernel, which it replaces on
+// the hot path).  A workgroup of four waves owns a tile of 16 trajectories for all T steps; per step ONE matrix phase
+//     G = W_hh . h_{t-1}^T     (A = gate rows of W_hh held in registers for the whole sequence, B = the 16 x H tile of
+//                               h_{t-1} read from LDS, v_mfma_f32_16x16x4_f32: exact f32)
+// Wave w owns hidden units w*H/4 .. (w+1)*H/4 - 1; the rows of its M-tiles are permuted so that D register r of lane
+// (fi = lane & 15, fk = lane >> 4) of tile mt is gate r (i, f, g, o) of unit w*H/4 + 4*mt + fk for trajectory fi: the
+// cell update is lane-local, the input (dx, dy) enters as two FMAs per gate through the folded A = W_ih W_emb.
+// The lane-per-(row, unit) kernel above needs 416 VGPRs at H = 64 (one wave per SIMD, every lane walks all of W_hh's
+// column on the VALU: 7 % of the f32 peak); here the 64 x 64 recurrent product of a step is 64 MFMAs per wave.
+template <int H>
+__global__ __launch_bounds__(256) void lstm_fwd_mfma_kernel(SeqArgs p) {
+  constexpr int G4 = 4 * H, U = H / 4, MT = U / 4, KS = H / 4, HLDS = H + 4;
+  __shared__ __attribute__((aligned(16))) float hs[2][16 * HLDS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  const int r = blockIdx.x * 16 + fi;
+  const bool valid = r < p.R;
+  const int rc = valid ? r : p.R - 1;
+  const float* P = p.prep;
+  const float* WT = P + prep_off_whhT(H);
+  const bool sv = p.Gt != nullptr && valid;
+  // A operand of k-step ks: lane (fi, fk) supplies M row fi (unit w*U + 4*mt + (fi >> 2), gate fi & 3), K index KS*fk + ks
+  float Wg[MT][KS];
+  int uj[MT];
+  float ca0[MT][4], ca1[MT][4], cb[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) Wg[mt][ks] = WT[(KS * fk + ks) * G4 + (fi & 3) * H + w * U + 4 * mt + (fi >> 2)];
+    uj[mt] = w * U + 4 * mt + fk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = q * H + uj[mt];
+      ca0[mt][q] = P[prep_off_A(H) + m * 2];
+      ca1[mt][q] = P[prep_off_A(H) + m * 2 + 1];
+      cb[mt][q] = P[prep_off_bias(H) + m];
+    }
+  }
+  float c[MT], hprev[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) c[mt] = hprev[mt] = 0.f;
+  for (int t = 0; t < p.T; ++t) {
+    const size_t rt = (size_t)r * p.T + t;
+    const float2 d = *reinterpret_cast<const float2*>(p.x + ((size_t)t * p.b + rc) * 2);
+    f32x4 G[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) G[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t > 0) {  // h_0 = 0: nothing to multiply at the first step
+      const float* hb = &hs[t & 1][fi * HLDS + KS * fk];
+      float hB[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ks += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(hb + ks);
+        hB[ks] = v[0]; hB[ks + 1] = v[1]; hB[ks + 2] = v[2]; hB[ks + 3] = v[3];
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) G[mt] = MFMA16(Wg[mt][ks], hB[ks], G[mt]);
+    }
+    float* hw = hs[(t + 1) & 1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[q] = fmaf(ca1[mt][q], d.y, fmaf(ca0[mt][q], d.x, G[mt][q] + cb[mt][q]));
+      g[0] = mg_sigmoid(g[0]); g[1] = mg_sigmoid(g[1]); g[2] = mg_tanh(g[2]); g[3] = mg_sigmoid(g[3]);
+      c[mt] = fmaf(g[1], c[mt], g[0] * g[2]);
+      const float hn = g[3] * mg_tanh(c[mt]);
+      hw[fi * HLDS + uj[mt]] = hn;
+      if (sv) {
+        p.Hp[rt * H + uj[mt]] = hprev[mt];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p.Gt[rt * G4 + q * H + uj[mt]] = g[q];
+        p.Cs[rt * H + uj[mt]] = c[mt];
+      }
+      hprev[mt] = hn;
+    }
+    if (sv && w == 0 && fk == 0) *reinterpret_cast<float2*>(p.Din + rt * 2) = d;
+    lds_barrier();
+  }
+  if (valid) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) p.hout[(size_t)r * p.ld_hout + uj[mt]] = hprev[mt];
+  }
 }
 
 struct SeqBwdArgs {
@@ -314,8 +403,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
 // plus two cross-lane adds.  The u tile is computed by every wave (8 MFMAs) instead of a second exchange.
 // Saved for backward, in the lane layout the backward kernel reads back with one 16-byte load per unit:
 //     Gt (R,T,H,4) = gates (i,f,g,o) after activation;  Cs (R,T,H,2) = (c_t, h_t);  Hp (R,H) = h_0.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define DEC_HLD 36  // LDS h tile row stride in floats (16-byte aligned rows, conflict-light)
 
 struct DecFwdArgs {
@@ -853,8 +940,15 @@ int mggan_lstm_encoder_fwd(const float* x, int T, int b, int H, const float* pre
   SeqArgs p = {};
   p.R = b; p.T = T; p.b = b; p.prep = prep; p.x = x; p.hout = hout; p.ld_hout = ld_hout;
   p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Din = Din;
-  if (H == 32) hipLaunchKernelGGL((lstm_fwd_kernel<32>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((lstm_fwd_kernel<64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
+  static int valu = -1;  // MGGAN_LSTM_VALU=1: the lane-per-(row, unit) VALU kernel (A/B measurements)
+  if (valu < 0) { const char* e = getenv("MGGAN_LSTM_VALU"); valu = e && e[0] == '1'; }
+  if (valu) {
+    if (H == 32) hipLaunchKernelGGL((lstm_fwd_kernel<32>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((lstm_fwd_kernel<64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
+  } else {
+    if (H == 32) hipLaunchKernelGGL((lstm_fwd_mfma_kernel<32>), dim3(cdiv(b, 16)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((lstm_fwd_mfma_kernel<64>), dim3(cdiv(b, 16)), dim3(256), 0, stream, p);
+  }
   MG_LAUNCH_CHECK("lstm_encoder_fwd");
   return MGGAN_OK;
 }
