@@ -6,16 +6,18 @@
 //   enc_h_to_dec_h                model/modules/standard.py:91-94,244-252 (h0 = Linear(136,32)([enc_h|noise]), c0 = 0)
 //   selected-rollout gather       model/modules/standard.py:190-214 (folded: one row per selected (ped, sample))
 //
-// Design (CDNA4): one lane per (row, hidden unit); the four gate rows of W_hh for
-// that unit live in VGPRs for the whole sequence (weights are read from HBM/L2 once
-// per workgroup, never per step), h_t is exchanged through LDS (one 128-byte row per
-// trajectory, broadcast ds_read_b128), c_t stays in a register, all T steps and
-// (decoder) the hidden2pos head + autoregressive feedback run inside ONE launch.
-// The input embedding Linear(2,E) is folded algebraically into the gate weights
-// (A = W_ih W_emb, 4H x 2) by a tiny prep kernel each step; its gradient is
-// un-folded by the chain rule in mggan_lstm_unfold_grads.
-// Rows are pre-bucketed by generator so that a workgroup's lanes load one
-// generator's weights (L1-resident) and weight-gradient GEMMs see contiguous segments.
+// Design (CDNA4): both rollouts are matrix-core kernels (lstm_fwd_mfma_kernel, decoder_fwd/bwd_mfma_kernel): a
+// workgroup of four waves owns a tile of 16 rows for all T steps; the gate rows of W_hh are MFMA A-fragments held in
+// VGPRs for the whole sequence (read from L2 once per workgroup, never per step -- at these sizes registers beat an
+// LDS copy: 64 KB of W_hh at H = 64 is exactly 64 fragment registers per lane), h_t is exchanged through a 2-4 KB LDS
+// tile with ONE LDS-only barrier per step, c_t stays in registers, gate rows are permuted so that the cell update is
+// lane-local, and (decoder) the hidden2pos head + autoregressive feedback run inside the same launch.
+// The input embedding Linear(2,E) is folded algebraically into the gate weights (A = W_ih W_emb, 4H x 2) by a tiny
+// prep kernel; its gradient is un-folded by the chain rule in mggan_lstm_unfold_grads.  The encoder's adjoint
+// (lstm_bwd_kernel) is a VALU kernel, one lane per (row, unit); the lane-per-unit VALU forward is kept for A/B
+// measurements (MGGAN_LSTM_VALU=1).
+// Rows are pre-bucketed by generator so that a workgroup's lanes load one generator's weights (L1-resident) and the
+// per-generator weight gradients see contiguous segments.
 #include <stdlib.h>
 #include "common.h"
 #include "../../include/mggan_hip.h"
