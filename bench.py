@@ -56,6 +56,10 @@ def kernel_of(name, a):
         return "conv1_wgrad_kernel<{}>".format(a[2])
     if name == "mggan_image_gram":
         return "image_gram_kernel"
+    if name == "mggan_dheads_fwd":
+        return "dheads_fwd_kernel"
+    if name == "mggan_dheads_bwd_data":
+        return "dheads_bwd_kernel"
     return name
 
 
@@ -100,6 +104,10 @@ def flops_of(name, a):
         return float(a[1]) * 2 * 2 * 256 * a[2] * a[2] * 9
     if name == "mggan_conv1_wgrad":  # the reference operator: a dense (C x 36) x (33*33 positions) weight gradient
         return float(a[1]) * 2 * 33 * 33 * a[2] * 36
+    if name == "mggan_dheads_fwd":  # both heads: 2 x Linear(192,96) + Linear(96,1) + Linear(96,g)
+        return 2.0 * a[2] * (2 * 192 * 96 + 96 * (1 + a[3]))
+    if name == "mggan_dheads_bwd_data":  # their input gradient
+        return 2.0 * a[5] * (2 * 192 * 96 + 96 * (1 + a[6]))
     if name == "mggan_image_gram":  # not in the reference's operator list (bookkeeping of the factorised conv1 gradient)
         return 0.0
     if name == "mggan_scene_attention_fwd":

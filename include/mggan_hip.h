@@ -242,6 +242,18 @@ int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const un
                       const float* W, const float* bias, const double* coefd, float* dW, double* workspace,
                       size_t workspace_bytes, mggan_stream_t stream);
 
+/* ---- both discriminator heads over many rows, weight-stationary (csrc/dheads.hip) -------------------------------
+ * reference: discriminators.py:76-85,197-204 (discs[0]) and :97-108,211-219 (gen_id_reconstructor) on the K*b rows of
+ * the generator step.  X (rows, ldx >= 192) -> Ya (rows,1) = act_a(Linear(96,1)(LeakyReLU(Linear(192,96)(X)))),
+ * Yb (rows,g) = Linear(96,g)(LeakyReLU(Linear(192,96)(X))); Ha / Hb (rows,96) keep the hidden activations when not NULL.
+ * mggan_dheads_bwd_data: dX (rows, ld_dx) from dYa, dYb -- the input gradient only (frozen discriminator). */
+int mggan_dheads_fwd(const float* X, int ldx, int rows, int g, int act_a, const float* W1a, const float* b1a,
+                     const float* W2a, const float* b2a, const float* W1b, const float* b1b, const float* W2b,
+                     const float* b2b, float* Ha, float* Hb, float* Ya, float* Yb, mggan_stream_t stream);
+int mggan_dheads_bwd_data(const float* dYa, const float* dYb, const float* Ya, const float* Ha, const float* Hb, int rows,
+                          int g, int act_a, const float* W1a, const float* W2a, const float* W1b, const float* W2b,
+                          float* dX, int ld_dx, mggan_stream_t stream);
+
 /* ---- in-graph all-reduce over peer-mapped memory (csrc/comm.hip; scene-sharded training) ------------
  * No reference counterpart (the reference is single-process); replaces torch.distributed.all_reduce for the <= 360 KB
  * messages of an iteration with a plain, HIP-graph-capturable kernel.  Every rank owns one uncached arena per channel

@@ -1544,6 +1544,10 @@ class DRowsBodyFn(Function):
         return (din, dpred, dpred2) + (None,) * 10
 
 
+# from this many rows on, both discriminator heads run as one weight-stationary launch (csrc/dheads.hip)
+DHEADS_MIN_ROWS = int(os.environ.get("MGGAN_DHEADS_MIN_ROWS", "8192"))
+
+
 class DRowsHeadsFn(Function):
     """Second node of the row pass (discriminators.py:186-219): broadcasts the scene features into their column block
     of X (in place) and runs the score head over all rows and the generator-id head over rows [row0, K*b).
@@ -1563,40 +1567,62 @@ class DRowsHeadsFn(Function):
         d0 = D.discs[0]
         spec_a = ((ACT_LEAKY, 0.2), (D._out_act(), 0.0))
         Wa, ba = (d0[0].weight, d0[2].weight), (d0[0].bias, d0[2].bias)
-        outs_a = _chain_fwd(X, W, R, spec_a, Wa, ba, save)
-        outs_b, Wb = [None, None], None
         mgan = D.gan_type == "mgan"
-        if mgan:
-            r = D.gen_id_reconstructor
+        outs_b, Wb = [None, None], None
+        r = D.gen_id_reconstructor if mgan else None
+        # many rows, both heads over all of them (the generator step's K*b rows): ONE weight-stationary launch
+        big = (mgan and row0 == 0 and R >= DHEADS_MIN_ROWS and W == 192 and tuple(Wa[0].shape) == (96, 192)
+               and tuple(r[0].weight.shape) == (96, 192) and r[2].weight.shape[0] <= 15)
+        if big:
+            g = r[2].weight.shape[0]
             Wb, bb = (r[0].weight, r[2].weight), (r[0].bias, r[2].bias)
-            outs_b = _chain_fwd(_p(X) + 4 * row0 * W, W, R - row0, ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0)), Wb, bb, save)
+            ha = _empty(R, 96, like=X) if save else None
+            hb = _empty(R, 96, like=X) if save else None
+            ya, yb = _empty(R, 1, like=X), _empty(R, g, like=X)
+            lib.mggan_dheads_fwd(_p(X), W, R, g, D._out_act(), _p(Wa[0]), _p(ba[0]), _p(Wa[1]), _p(ba[1]), _p(Wb[0]),
+                                 _p(bb[0]), _p(Wb[1]), _p(bb[1]), _p(ha), _p(hb), _p(ya), _p(yb), st)
+            outs_a, outs_b = [ha, ya], [hb, yb]
+        else:
+            outs_a = _chain_fwd(X, W, R, spec_a, Wa, ba, save)
+            if mgan:
+                Wb, bb = (r[0].weight, r[2].weight), (r[0].bias, r[2].bias)
+                outs_b = _chain_fwd(_p(X) + 4 * row0 * W, W, R - row0, ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0)), Wb, bb, save)
         if save:
-            ctx.cfg = (D, K, row0, b, W, w_sc, mgan, Wa[0].requires_grad, bool(mgan and Wb[0].requires_grad))
+            ctx.cfg = (D, K, row0, b, W, w_sc, mgan, Wa[0].requires_grad, bool(mgan and Wb[0].requires_grad), big)
             ctx.save_for_backward(X, outs_a[0], outs_a[1], outs_b[0], outs_b[1])
         return outs_a[-1], outs_b[-1]
 
     @staticmethod
     def backward(ctx, dya, dyb):
-        D, K, row0, b, W, w_sc, mgan, train_a, train_b = ctx.cfg
+        D, K, row0, b, W, w_sc, mgan, train_a, train_b, big = ctx.cfg
         X, ha, ya, hb, yb = ctx.saved_tensors
         R = K * b
         d0 = D.discs[0]
         st = _s()
         dX = _empty(R, W, like=X)
-        if dya is None:
-            dX.zero_()
-        else:
-            dya, ld = _rows2d(dya.reshape(R, -1))
-            _chain_bwd(dya, ld, X, W, R, (ha, ya), ((ACT_LEAKY, 0.2), (D._out_act(), 0.0)), (d0[0].weight, d0[2].weight),
-                       (d0[0].bias, d0[2].bias), True, train_a, d0[0], dx_into=(_p(dX), W, 0))
-        if mgan and dyb is not None:
+        if big and not train_a and not train_b:  # frozen discriminator (generator step): input gradient only, one launch
             r = D.gen_id_reconstructor
-            dyb, ld = _rows2d(dyb.reshape(R - row0, -1))
-            _chain_bwd(dyb, ld, _p(X) + 4 * row0 * W, W, R - row0, (hb, yb), ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0)),
-                       (r[0].weight, r[2].weight), (r[0].bias, r[2].bias), True, train_b, r[0],
-                       dx_into=(_p(dX) + 4 * row0 * W, W, 1))
-            if _DEFER["on"]:
-                _DEFER["keep"].append(X)
+            g = r[2].weight.shape[0]
+            dya = torch.zeros(R, 1, dtype=F32, device=X.device) if dya is None else dya.reshape(R, 1).contiguous()
+            dyb = torch.zeros(R, g, dtype=F32, device=X.device) if dyb is None else dyb.reshape(R, g).contiguous()
+            lib.mggan_dheads_bwd_data(_p(dya), _p(dyb), _p(ya), _p(ha), _p(hb), R, g, D._out_act(), _p(d0[0].weight),
+                                      _p(d0[2].weight), _p(r[0].weight), _p(r[2].weight), _p(dX), W, st)
+        else:
+            if dya is None:
+                dX.zero_()
+            else:
+                dya, ld = _rows2d(dya.reshape(R, -1))
+                _chain_bwd(dya, ld, X, W, R, (ha, ya), ((ACT_LEAKY, 0.2), (D._out_act(), 0.0)),
+                           (d0[0].weight, d0[2].weight), (d0[0].bias, d0[2].bias), True, train_a, d0[0],
+                           dx_into=(_p(dX), W, 0))
+            if mgan and dyb is not None:
+                r = D.gen_id_reconstructor
+                dyb, ld = _rows2d(dyb.reshape(R - row0, -1))
+                _chain_bwd(dyb, ld, _p(X) + 4 * row0 * W, W, R - row0, (hb, yb), ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0)),
+                           (r[0].weight, r[2].weight), (r[0].bias, r[2].bias), True, train_b, r[0],
+                           dx_into=(_p(dX) + 4 * row0 * W, W, 1))
+                if _DEFER["on"]:
+                    _DEFER["keep"].append(X)
         dsc = None
         if ctx.needs_input_grad[1]:
             dsc = _empty(b, w_sc, like=X)
