@@ -92,7 +92,7 @@ def flops_of(name, a):
         R, T, H, EIN, Z = a[0], a[1], a[3], a[4], a[5]
         return float(R) * (2 * (EIN + Z) * H + T * (2 * 2 * 16 + 2 * (16 + H) * 4 * H + 2 * (2 * H * (H // 2) + (H // 2) * 2)))
     if name == "mggan_decoder_rollout_bwd_fused":  # BPTT data path + the fused per-generator weight gradients
-        T, H, EIN, R = a[2], a[3], a[4], a[22]
+        T, H, EIN, R = a[2], a[3], a[4], a[21]
         data = T * 2 * (4 * H * H + 2 * 4 * H + H * (H // 2) + (H // 2) * 2) + 2 * (EIN * H + H * (H // 2))
         wgrads = T * 2 * (4 * H * (H + 3) + (H // 2) * H + 2 * (H // 2))
         return float(R) * (data + wgrads)

@@ -114,13 +114,16 @@ int mggan_lstm_encoder_fwd(const float* x, int T, int b, int H, const float* pre
 int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, const float* W_hh, const float* prep,
                            const float* Gt, const float* Cs, float* dPre, mggan_stream_t stream);
 /* R rollout rows sorted by generator (generator g owns rows seg[g] .. seg[g+1]-1); row r: pedestrian
- * row_ped[r], noise slot row_slot[r], output position row_pos[r] in (T, Rout, 2).  One wave rolls out a
- * 16-row tile on the matrix cores (common_modules.py:97-131, standard.py:227-265). */
+ * row_ped[r], noise slot row_slot[r], output position row_pos[r] in (T, Rout, 2).  One workgroup rolls out a
+ * 16-row tile on the matrix cores (common_modules.py:97-131, standard.py:227-265).  Save buffers (all or none; private
+ * to this pair of entries, tile-blocked with tiles = ceil(R/16) + n_gens slots of 16 rows):
+ * Gt (tiles,T,H,16,4), Cs (tiles,T+1,H,16,2), Din (tiles,T,16,2), Aact (tiles,T,4,16,4); row-major E2Din (R,EIN+Z),
+ * SocR (R,S) feed the weight-gradient GEMMs. */
 int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const float* prep, int prep_stride,
                               const int* seg, int n_gens, const int* row_ped, const int* row_slot, const int* row_pos,
                               const float* enc_h, int ld_enc, const float* noise, const float* soc, int ld_soc,
                               const float* xy0, const float* dxdy0, const float* We2d, const float* be2d,
-                              float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Hp, float* Din,
+                              float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Din,
                               float* Aact, float* E2Din, float* SocR, mggan_stream_t stream);
 /* ---- social attention over in-scene ordered pairs ---------------------------------------
  * reference: social.py:67-104 (features), :33-48 (embedding MLP), :14-30 (attention pooling),
@@ -394,7 +397,7 @@ int mggan_decoder_bwd_fused_layout(int* wlen, int* off_A, int* off_bias, int* of
 int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, int Z, const int* seg, const int* row_pos,
                                     const float* W_hh, const float* W1, const float* W2, long param_stride,
                                     const float* We2d, const float* prep, int prep_stride, const float* Gt,
-                                    const float* Cs, const float* Hp, const float* Din,
+                                    const float* Cs, const float* Din,
                                     const float* Aact, const float* gabs, const float* grel, int Rout, float* dH0,
                                     float* dQ, float* dEnc, float* dSocR, float* wpart, mggan_stream_t stream);
 

@@ -28,6 +28,15 @@ void mggan_set_error(const char* fmt, ...);
     }                                                                      \
   } while (0)
 
+#define MG_CHECK_HIP(call, name)                                           \
+  do {                                                                     \
+    hipError_t e_ = (call);                                                \
+    if (e_ != hipSuccess) {                                                \
+      mggan_set_error("%s: %s", name, hipGetErrorString(e_));              \
+      return MGGAN_ERR_LAUNCH;                                             \
+    }                                                                      \
+  } while (0)
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // activation codes shared with the Python side

@@ -865,7 +865,7 @@ int mggan_pm_ml_loss_mean(int b, int T, int E, int g, const float* gen_abs, cons
                           unsigned* ticket, float* out, float* probs_out, float probs_scale, hipStream_t stream) {
   MG_CHECK_ARG(out, "pm_ml_loss_mean: null pointer");
   if (b == 0) {
-    hipMemsetAsync(out, 0, sizeof(float), stream);
+    MG_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), stream), "pm_ml_loss_mean: memset");
     return MGGAN_OK;
   }
   MG_CHECK_ARG(gen_abs && gt && logits && loss_rows && dlogits && partial && ticket && g <= 16,
@@ -916,7 +916,7 @@ int mggan_colmean(const float* x, int rows, int g, float scale, float* out, hipS
 
 int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count, hipStream_t stream) {
   MG_CHECK_ARG(idx && counts && inv_count && g <= 256, "gen_counts: bad arguments");
-  hipMemsetAsync(counts, 0, sizeof(int) * g, stream);
+  MG_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int) * g, stream), "gen_counts: memset");
   if (n > 0) {
     int blocks = cdiv(n, 2048);
     hipLaunchKernelGGL(count_kernel, dim3(blocks > 64 ? 64 : blocks), dim3(256), 0, stream, idx, n, g, counts);

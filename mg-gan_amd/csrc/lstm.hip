@@ -20,6 +20,7 @@
 // per-generator weight gradients see contiguous segments.
 #include <stdlib.h>
 #include "common.h"
+#include <type_traits>
 #include "../../include/mggan_hip.h"
 
 // ---- layout of one prepared (folded/transposed) weight block, in floats -----------
@@ -403,8 +404,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
 // (i, f, g, o) of unit 8w + 4mt + fk for tile row fi: the cell update is lane-local (two units per lane), the
 // autoregressive input enters as two FMAs per gate (A = W_ih W_emb folded), and dxdy = W2 u + b2 is four FMAs
 // plus two cross-lane adds.  The u tile is computed by every wave (8 MFMAs) instead of a second exchange.
-// Saved for backward, in the lane layout the backward kernel reads back with one 16-byte load per unit:
-//     Gt (R,T,H,4) = gates (i,f,g,o) after activation;  Cs (R,T,H,2) = (c_t, h_t);  Hp (R,H) = h_0.
+// Saved for backward in TILE-BLOCKED form: tile tg (= tiles of the generators before it + its index in its own
+// generator, see dec_tile_base) owns one contiguous record per step, rows innermost, so that every wave-wide store
+// here and load in the backward kernel is one contiguous 0.5-1 KB run (row-major (R,T,H,4) made each of them 16
+// separate 64-byte pieces 6 KB apart: 25 % slower backward):
+//     Gt (tiles,T,H,16,4)   = gates (i,f,g,o) after activation        Aact (tiles,T,4,16,4) = hidden2pos activations
+//     Cs (tiles,T+1,H,16,2) = (c_{t-1}, h_{t-1}) at step index t, i.e. slot 0 = (0, h_0)     Din (tiles,T,16,2)
+// with tiles = sum_g ceil(rows_g / 16) <= ceil(R/16) + n_gens.  Rows past a generator's end compute on a clamped
+// duplicate and ARE saved (finite values the backward kernel multiplies by zero).
 #define DEC_HLD 36  // LDS h tile row stride in floats (16-byte aligned rows, conflict-light)
 
 struct DecFwdArgs {
@@ -415,8 +422,15 @@ struct DecFwdArgs {
   const int *row_ped, *row_slot, *row_pos;
   const float *enc_h, *noise, *soc, *xy0, *dxdy0, *We2d, *be2d;
   float *out_abs, *out_rel;
-  float *Gt, *Cs, *Hp, *Din, *Aact, *E2Din, *SocR;
+  float *Gt, *Cs, *Din, *Aact, *E2Din, *SocR;
 };
+
+// first tile slot of generator gi in the tile-blocked save buffers
+__device__ __forceinline__ int dec_tile_base(const int* seg, int gi) {
+  int tb = 0;
+  for (int g = 0; g < gi; ++g) tb += (seg[g + 1] - seg[g] + 15) / 16;
+  return tb;
+}
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void decoder_fwd_mfma_kernel(DecFwdArgs p) {
   constexpr int H = 32, G4 = 128, Hh = 16;
@@ -433,13 +447,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int ntiles = (seg1 - seg0 + 15) / 16;
   const bool save = p.Gt != nullptr;
   const int IN = p.EIN + p.Z;
+  const int tbase = save ? dec_tile_base(p.seg, gi) : 0;
 
   for (int tile = wi; tile < ntiles; tile += p.NW) {
     const int r = seg0 + tile * 16 + fi;
     const bool valid = r < seg1;
     const int rc = valid ? r : seg1 - 1;
     const int ped = p.row_ped[rc], slot = p.row_slot[rc], pos = p.row_pos[rc];
-    const bool sv = save && valid, sv0 = sv && w == 0;
+    const bool sv = save && valid, sv0 = sv && w == 0;  // row-major saves (E2Din, SocR)
+    const size_t tg = (size_t)(tbase + tile);
     // ---- h0 = W_e2d [enc_h | noise] + b_e2d (standard.py:247-252): wave w -> units 8w .. 8w+7 (M rows 0..7) ----
     f32x4 hacc = f32x4{0.f, 0.f, 0.f, 0.f}, hacc2 = f32x4{0.f, 0.f, 0.f, 0.f};
     auto e2d_block = [&](int kb, f32x4& x4, f32x4& a4) {  // loads of one 16-wide K block (this lane's quad)
@@ -502,7 +518,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int q = 0; q < 4; ++q) hacc[q] += p.be2d[8 * w + 4 * fk + q];
       *reinterpret_cast<f32x4*>(&hs[0][fi * DEC_HLD + 8 * w + 4 * fk]) = hacc;
-      if (sv) *reinterpret_cast<f32x4*>(p.Hp + (size_t)r * H + 8 * w + 4 * fk) = hacc;
+      if (save) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float2*>(p.Cs + ((tg * (p.T + 1) * H + 8 * w + 4 * fk + q) * 16 + fi) * 2) = float2{0.f, hacc[q]};
+      }
     }
     // ---- time-invariant social half of hidden2pos: q = W1[:, H:] soc + b1 (every wave) ----
     f32x4 qv = f32x4{b1r[0], b1r[1], b1r[2], b1r[3]};
@@ -532,7 +552,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 
     for (int t = 0; t < p.T; ++t) {
-      const size_t rt = (size_t)r * p.T + t;
+      const size_t tt = tg * p.T + t, tc = tg * (p.T + 1) + t + 1;
       float* hw = hs[(t + 1) & 1];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -543,12 +563,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         c[mt] = fmaf(g[1], c[mt], g[0] * g[2]);
         const float hn = g[3] * mg_tanh(c[mt]);
         hw[fi * DEC_HLD + uj[mt]] = hn;
-        if (sv) {
-          *reinterpret_cast<f32x4*>(p.Gt + (rt * H + uj[mt]) * 4) = g;
-          *reinterpret_cast<float2*>(p.Cs + (rt * H + uj[mt]) * 2) = float2{c[mt], hn};
+        if (save) {
+          *reinterpret_cast<f32x4*>(p.Gt + ((tt * H + uj[mt]) * 16 + fi) * 4) = g;
+          *reinterpret_cast<float2*>(p.Cs + ((tc * H + uj[mt]) * 16 + fi) * 2) = float2{c[mt], hn};
         }
       }
-      if (sv0 && fk == 0) *reinterpret_cast<float2*>(p.Din + rt * 2) = float2{d0, d1};
+      if (save && w == 0 && fk == 0) *reinterpret_cast<float2*>(p.Din + (tt * 16 + fi) * 2) = float2{d0, d1};
       lds_barrier();
       const f32x4 ha = *reinterpret_cast<const f32x4*>(&hw[fi * DEC_HLD + 8 * fk]);
       const f32x4 hb = *reinterpret_cast<const f32x4*>(&hw[fi * DEC_HLD + 8 * fk + 4]);
@@ -580,7 +600,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         n0 = fmaf(w2r[0][q], av[q], n0);
         n1 = fmaf(w2r[1][q], av[q], n1);
       }
-      if (sv0) *reinterpret_cast<f32x4*>(p.Aact + rt * Hh + 4 * fk) = av;
+      if (save && w == 0) *reinterpret_cast<f32x4*>(p.Aact + ((tt * 4 + fk) * 16 + fi) * 4) = av;
       n0 += __shfl_xor(n0, 16, 64); n1 += __shfl_xor(n1, 16, 64);
       n0 += __shfl_xor(n0, 32, 64); n1 += __shfl_xor(n1, 32, 64);
       n0 += b20; n1 += b21;
@@ -615,14 +635,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #define DPLD 144  // dpbuf row stride (== 16 mod 32: conflict-free MFMA fragment reads, 16-B aligned rows)
 #define HLD 48    // h tile row stride (== 16 mod 32)
 struct DecFusedArgs {
-  int T, NW, Rout, EIN, Z;
+  int T, NW, Rout, EIN, Z, e2ld;
   const int* seg;        // generator segment offsets into the sorted rows (g+1)
   const int* row_pos;
   const float *W_hh, *W1, *W2, *We2d;
   long param_stride;
   const float* prep;
   int prep_stride;
-  const float *Gt, *Cs, *Hp, *Din, *Aact, *gabs, *grel;
+  const float *Gt, *Cs, *Din, *Aact, *gabs, *grel;
   float *dH0, *dQ, *dEnc, *dSocR, *wpart;
 };
 
@@ -638,15 +658,20 @@ struct DecFusedArgs {
 //   4. weight gradients with K = the 16 tile rows: [dW_hh | dA | dbias] += dPre^T [h_{t-1} | dxdy | 1]
 //      (wave w: position tiles 2w, 2w+1 x three column tiles, 24 MFMAs), dW1[:, :H] += du^T h_t (2 MFMAs)
 // The LDS tiles are multi-buffered over t so that the single barrier per step is enough.
-#define DB_RS 132  // dPre tile row stride (== 4 mod 32: conflict-free 16-byte row reads)
+#define DB_RS 196  // dPre tile row stride (== 4 mod 64: conflict-free 16-byte row reads).  Row r starts 16 (r & 3) floats in
+                   // (hence 176 used + pad): the transposed 4-byte reads of the weight-gradient phase (lane = (position
+                   // fi, row 4 ks + fk)) then start 20 banks apart per fk instead of 4 - 2-way on 12 banks, not 4-way -
+                   // and the row accesses keep compile-time offsets (an XOR swizzle cost more VALU than it saved)
 #define DB_HS 48   // h tile row stride (== 16 mod 32: conflict-free transposed reads); cols 32,33 = dxdy, 34 = 1
 
+template <int DIAG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void decoder_bwd_mfma_kernel(DecFusedArgs p) {
   constexpr int H = 32, Hh = 16, S = 32;
   __shared__ __attribute__((aligned(16))) float dps[2][16 * DB_RS];
   __shared__ __attribute__((aligned(16))) float hts[3][16 * DB_HS];
   __shared__ __attribute__((aligned(16))) float dus[2][16 * Hh];
   __shared__ float red[16 * 52];
+  extern __shared__ __attribute__((aligned(16))) float tailw[];  // W_e2d[:, :EIN] (H x e2ld) | W1[:, H:] (Hh x 36)
   const int gi = blockIdx.x / p.NW, wi = blockIdx.x % p.NW;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
   const long po = (long)gi * p.param_stride;
@@ -656,7 +681,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int seg0 = p.seg[gi], seg1 = p.seg[gi + 1];
   const int ntiles = (seg1 - seg0 + 15) / 16;
   const int IN = p.EIN + p.Z;
+  const int tbase = dec_tile_base(p.seg, gi);
   const int uj[2] = {8 * w + fk, 8 * w + 4 + fk};
+  const int sw = (fi & 3) << 4;
   const int sel = fi & 3, us = 8 * w + 4 * (sel & 1) + (fi >> 2);  // A-operand row role of this lane
 
   // A operands.  Position p = unit*4 + gate in the dPre tile <-> original gate row (p & 3)*H + (p >> 2).
@@ -673,6 +700,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     w2c[0][q] = p.W2[po + 4 * fk + q];
     w2c[1][q] = p.W2[po + Hh + 4 * fk + q];
   }
+  // The per-tile epilogue (dEnc, dSocR) multiplies by W_e2d[:, :EIN] and W1[:, H:]: from global memory that was three
+  // exposed load round trips per tile (10k of a tile's 75k cycles); they are staged once per workgroup instead.
+  float* e2s = tailw;
+  float* w1s = tailw + H * p.e2ld;
+  for (int i = threadIdx.x; i < H * p.EIN; i += 256) e2s[(i / p.EIN) * p.e2ld + i % p.EIN] = p.We2d[(size_t)(i / p.EIN) * IN + i % p.EIN];
+  for (int i = threadIdx.x; i < Hh * S; i += 256) w1s[(i / S) * 36 + i % S] = W1[(size_t)(i / S) * (H + S) + H + i % S];
   // constant part of the h tiles: column 34 = 1 (bias), 35..47 = 0
   for (int i = threadIdx.x; i < 3 * 16 * 16; i += 256) {
     const int bsel = i / 256, row = (i / 16) % 16, col = i % 16;
@@ -688,108 +721,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int q = 0; q < 4; ++q) accW2[0][q] = accW2[1][q] = accb1[q] = 0.f;
 
+  const long long K0 = (DIAG & 16) ? clock64() : 0;
+  long long acc_pre = 0, acc_loop = 0, acc_tail = 0, acc_n = 0, KP = 0;
+  long long sk[6] = {0, 0, 0, 0, 0, 0};
   for (int tile = wi; tile < ntiles; tile += p.NW) {
+    const long long Q0 = (DIAG & 16) ? clock64() : 0;
     const int r = seg0 + tile * 16 + fi;
     const bool valid = r < seg1;
     const int rc = valid ? r : seg1 - 1;
     const float vm = valid ? 1.f : 0.f;  // rows past the segment end contribute nothing
     const int pos = p.row_pos[rc];
-    const size_t r0 = (size_t)rc * p.T;
+    const size_t tg = (size_t)(tbase + tile);
     float dh[2] = {0.f, 0.f}, dc[2] = {0.f, 0.f}, dd0 = 0.f, dd1 = 0.f, s0 = 0.f, s1 = 0.f;
     f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
-    // prefetch registers of the next step
+    // Saved activations of the next step, fetched one whole step ahead (HBM latency under this kernel's own traffic is
+    // longer than the matrix phase: fetching after the barrier instead, without the second register set, cost 15 %).
     f32x4 n_g[2], n_av;
-    float2 n_ch[2], n_din, n_ga = float2{0.f, 0.f}, n_gr = float2{0.f, 0.f};
+    float2 n_ch[2], n_din, n_ga, n_gr;
     float cc[2];
+    const float gam = p.gabs ? 1.f : 0.f, grm = p.grel ? 1.f : 0.f;
+    // A missing output gradient is zero: its ADDRESS is redirected and the value masked where it is consumed - a
+    // select on a value just loaded makes the compiler wait for the whole batch of loads on the spot (that is how
+    // this loop lost its prefetch once).  Every load below is one contiguous run per wave (tile-blocked saves).
     auto fetch = [&](int t) {
-      const size_t rt = r0 + t;
+      const size_t tt = tg * p.T + t, tc = tg * (p.T + 1) + t;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        n_g[mt] = *reinterpret_cast<const f32x4*>(p.Gt + (rt * H + uj[mt]) * 4);
-        n_ch[mt] = t > 0 ? *reinterpret_cast<const float2*>(p.Cs + ((rt - 1) * H + uj[mt]) * 2)
-                         : float2{0.f, p.Hp[(size_t)rc * H + uj[mt]]};  // (c_{t-1}, h_{t-1})
+        n_g[mt] = *reinterpret_cast<const f32x4*>(p.Gt + ((tt * H + uj[mt]) * 16 + fi) * 4);
+        n_ch[mt] = *reinterpret_cast<const float2*>(p.Cs + ((tc * H + uj[mt]) * 16 + fi) * 2);  // (c_{t-1}, h_{t-1})
       }
-      n_av = *reinterpret_cast<const f32x4*>(p.Aact + rt * Hh + 4 * fk);
-      n_din = *reinterpret_cast<const float2*>(p.Din + rt * 2);
+      n_av = *reinterpret_cast<const f32x4*>(p.Aact + ((tt * 4 + fk) * 16 + fi) * 4);
+      const float* din = p.Din + (tt * 16 + fi) * 2;
+      n_din = *reinterpret_cast<const float2*>(din);
       const size_t o = ((size_t)t * p.Rout + pos) * 2;
-      if (p.gabs) n_ga = *reinterpret_cast<const float2*>(p.gabs + o);
-      if (p.grel) n_gr = *reinterpret_cast<const float2*>(p.grel + o);
+      n_ga = *reinterpret_cast<const float2*>(p.gabs ? p.gabs + o : din);
+      n_gr = *reinterpret_cast<const float2*>(p.grel ? p.grel + o : din);
     };
-    lds_barrier();  // the previous tile's last LDS reads are done
+    // Weight gradients of step tt, K = the 16 tile rows.  They hang off nothing in the recurrence, so they run one step
+    // late, at the head of step tt - 1, where their 26 MFMAs cover that step's gate arithmetic (VALU) instead of
+    // queueing behind the 32 MFMAs of the recurrence; the LDS tiles of step tt are not rewritten before step tt - 2.
+    auto wgrad = [&](int tt) {
+      const float* dpr = dps[tt & 1];
+      const float* dur = dus[tt & 1];
+      const float* htp = hts[tt % 3];        // h_{tt-1} | dxdy_tt | 1
+      const float* htq = hts[(tt + 1) % 3];  // h_tt
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const float2 ch = *reinterpret_cast<const float2*>(p.Cs + ((r0 + p.T - 1) * H + uj[mt]) * 2);
-      cc[mt] = ch.x;
-      hts[p.T % 3][fi * DB_HS + uj[mt]] = ch.y;  // h_{T-1}
-    }
-    fetch(p.T - 1);
-
-    for (int t = p.T - 1; t >= 0; --t) {
-      float* dpw = dps[t & 1];
-      float* duw = dus[t & 1];
-      float* htw = hts[t % 3];              // receives h_{t-1}
-      const float* htc = hts[(t + 1) % 3];  // holds h_t
-      const f32x4 g4[2] = {n_g[0], n_g[1]}, av = n_av;
-      const float2 ch[2] = {n_ch[0], n_ch[1]}, din = n_din, ga = n_ga, gr = n_gr;
-      if (t > 0) fetch(t - 1);
-      s0 += ga.x; s1 += ga.y;
-      const float g0 = (s0 + dd0 + gr.x) * vm, g1 = (s1 + dd1 + gr.y) * vm;
-      f32x4 du;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        du[q] = fmaf(w2c[0][q], g0, w2c[1][q] * g1) * (av[q] > 0.f ? 1.f : 0.01f);
-        accW2[0][q] = fmaf(g0, av[q], accW2[0][q]);
-        accW2[1][q] = fmaf(g1, av[q], accW2[1][q]);
-      }
-      dq += du;
-      accb2[0] += g0; accb2[1] += g1;
-      if (w == 0) {
-        *reinterpret_cast<f32x4*>(&duw[fi * Hh + 4 * fk]) = du;
-        if (fk == 0) *reinterpret_cast<float2*>(&htw[fi * DB_HS + H]) = din;
-      }
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) htw[fi * DB_HS + uj[mt]] = ch[mt].y;
-      // dh += W1[:, :H]^T du  (rows 4 fk + {0,1} of the M tile are this lane's units)
-      f32x4 a1 = f32x4{dh[0], dh[1], 0.f, 0.f}, a2 = f32x4{0.f, 0.f, 0.f, 0.f};
-      a1 = MFMA16(Aw1[0], du[0], a1);
-      a2 = MFMA16(Aw1[1], du[1], a2);
-      a1 = MFMA16(Aw1[2], du[2], a1);
-      a2 = MFMA16(Aw1[3], du[3], a2);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const float dhv = a1[mt] + a2[mt];
-        const float gi_ = g4[mt][0], gf = g4[mt][1], gg = g4[mt][2], go = g4[mt][3];
-        const float tc = mg_tanh(cc[mt]);
-        const float dO = dhv * tc;
-        const float dcv = fmaf(dhv * go, 1.f - tc * tc, dc[mt]);
-        f32x4 dp;
-        dp[0] = dcv * gg * gi_ * (1.f - gi_) * vm;
-        dp[1] = dcv * ch[mt].x * gf * (1.f - gf) * vm;
-        dp[2] = dcv * gi_ * (1.f - gg * gg) * vm;
-        dp[3] = dO * go * (1.f - go) * vm;
-        dc[mt] = dcv * gf;
-        cc[mt] = ch[mt].x;
-        *reinterpret_cast<f32x4*>(&dpw[fi * DB_RS + uj[mt] * 4]) = dp;
-      }
-      lds_barrier();
-      // [dh_{t-1} (own units) ; d dxdy_t] = [W_hh^T ; A^T] dPre^T, K = 128 gate rows in tile-position order
-      f32x4 acc[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&dpw[fi * DB_RS + 16 * j + 4 * fk]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = MFMA16(Ah[4 * j + q], b4[q], acc[q]);
-      }
-      // weight gradients, K = the 16 tile rows
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < ((DIAG & 1) ? 0 : 4); ++ks) {
         float a[2], bv[3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = dpw[(4 * ks + fk) * DB_RS + 16 * (2 * w + i) + fi];
+        for (int i = 0; i < 2; ++i) a[i] = dpr[(4 * ks + fk) * DB_RS + 16 * fk + 16 * (2 * w + i) + fi];
 #pragma unroll
-        for (int n = 0; n < 3; ++n) bv[n] = htw[(4 * ks + fk) * DB_HS + 16 * n + fi];
+        for (int n = 0; n < 3; ++n) bv[n] = htp[(4 * ks + fk) * DB_HS + 16 * n + fi];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -800,11 +782,107 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const int ks = 2 * kh + kk;
-          accU = MFMA16(duw[(4 * ks + fk) * Hh + fi], htc[(4 * ks + fk) * DB_HS + 16 * nt + fi], accU);
+          accU = MFMA16(dur[(4 * ks + fk) * Hh + fi], htq[(4 * ks + fk) * DB_HS + 16 * nt + fi], accU);
         }
+      }
+    };
+    lds_barrier();  // the previous tile's last LDS reads are done
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float2 ch = *reinterpret_cast<const float2*>(p.Cs + (((tg * (p.T + 1) + p.T) * H + uj[mt]) * 16 + fi) * 2);
+      cc[mt] = ch.x;
+      hts[p.T % 3][fi * DB_HS + uj[mt]] = ch.y;  // h_{T-1}
+    }
+    fetch(p.T - 1);
+
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    auto tick = [&]() -> long long {
+      if (!(DIAG & 16)) return 0;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      long long v = clock64();
+      asm volatile("" ::: "memory");
+      return v;
+    };
+    auto step = [&](int t, auto first) {
+      const long long T0 = tick();
+      float* dpw = dps[t & 1];
+      float* duw = dus[t & 1];
+      float* htw = hts[t % 3];  // receives h_{t-1}
+      const f32x4 c_g[2] = {n_g[0], n_g[1]}, c_av = n_av;
+      const float2 c_ch[2] = {n_ch[0], n_ch[1]}, c_din = n_din, c_ga = n_ga, c_gr = n_gr;
+      if (DIAG & 8) fetch(p.T - 1); else
+      if (!(DIAG & 2)) fetch(t > 0 ? t - 1 : 0);  // a whole step ahead (step 0 re-reads its own slots: no branch)
+      s0 = fmaf(c_ga.x, gam, s0); s1 = fmaf(c_ga.y, gam, s1);
+      const float g0 = (s0 + dd0 + c_gr.x * grm) * vm, g1 = (s1 + dd1 + c_gr.y * grm) * vm;
+      f32x4 du;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        du[q] = fmaf(w2c[0][q], g0, w2c[1][q] * g1) * (c_av[q] > 0.f ? 1.f : 0.01f);
+        accW2[0][q] = fmaf(g0, c_av[q], accW2[0][q]);
+        accW2[1][q] = fmaf(g1, c_av[q], accW2[1][q]);
+      }
+      dq += du;
+      accb2[0] += g0; accb2[1] += g1;
+      if (w == 0) {
+        *reinterpret_cast<f32x4*>(&duw[fi * Hh + 4 * fk]) = du;
+        if (fk == 0) *reinterpret_cast<float2*>(&htw[fi * DB_HS + H]) = c_din;
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) htw[fi * DB_HS + uj[mt]] = c_ch[mt].y;
+      // dh += W1[:, :H]^T du  (rows 4 fk + {0,1} of the M tile are this lane's units)
+      f32x4 a1 = f32x4{dh[0], dh[1], 0.f, 0.f}, a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+      a1 = MFMA16(Aw1[0], du[0], a1);
+      a2 = MFMA16(Aw1[1], du[1], a2);
+      a1 = MFMA16(Aw1[2], du[2], a1);
+      a2 = MFMA16(Aw1[3], du[3], a2);
+      const long long T1 = tick();
+      if constexpr (!decltype(first)::value) wgrad(t + 1);
+      const long long T2 = tick();
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const float dhv = a1[mt] + a2[mt];
+        const float gi_ = c_g[mt][0], gf = c_g[mt][1], gg = c_g[mt][2], go = c_g[mt][3];
+        const float cprev = c_ch[mt].x;
+        const float tc = mg_tanh(cc[mt]);
+        const float dO = dhv * tc;
+        const float dcv = fmaf(dhv * go, 1.f - tc * tc, dc[mt]);
+        f32x4 dp;
+        dp[0] = dcv * gg * gi_ * (1.f - gi_) * vm;
+        dp[1] = dcv * cprev * gf * (1.f - gf) * vm;
+        dp[2] = dcv * gi_ * (1.f - gg * gg) * vm;
+        dp[3] = dO * go * (1.f - go) * vm;
+        dc[mt] = dcv * gf;
+        cc[mt] = cprev;
+        *reinterpret_cast<f32x4*>(&dpw[fi * DB_RS + sw + uj[mt] * 4]) = dp;
+      }
+      const long long T3 = tick();
+      lds_barrier();
+      const long long T4 = tick();
+      // [dh_{t-1} (own units) ; d dxdy_t] = [W_hh^T ; A^T] dPre^T, K = 128 gate rows in tile-position order
+      f32x4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < ((DIAG & 4) ? 1 : 8); ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&dpw[fi * DB_RS + sw + 16 * j + 4 * fk]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = MFMA16(Ah[4 * j + q], b4[q], acc[q]);
       }
       const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
       dh[0] = sum[0]; dh[1] = sum[1]; dd0 = sum[2]; dd1 = sum[3];
+      if (DIAG & 16) {
+        const long long T5 = tick() + (long long)(dh[0] * 1e-30f);
+        tk[0] += T1 - T0; tk[1] += T2 - T1; tk[2] += T3 - T2; tk[3] += T4 - T3; tk[4] += T5 - T4; tk[5] += 1;
+      }
+    };
+    const long long Q1 = tick();
+    step(p.T - 1, std::true_type{});
+    for (int t = p.T - 2; t >= 0; --t) step(t, std::false_type{});
+    wgrad(0);
+    const long long Q2 = tick();
+    if (DIAG & 16) {
+      acc_pre += Q1 - Q0; acc_loop += Q2 - Q1; acc_n += 1; KP = Q2;
+      for (int i = 0; i < 6; ++i) sk[i] += tk[i];
     }
     // ---- per-row outputs of this tile: dH0, dQ, d(enc_h row), d(social row) ----
     float* h0t = hts[2];  // h_{-1} slot of the t = 0 step is hts[0]; hts[2] held h_1 (last read at t = 1)
@@ -819,7 +897,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (w < 2) {  // dSocR^T [S x rows] = W1[:, H:]^T dQ^T : wave w -> social columns 16 w .. 16 w + 15
       f32x4 ds = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) ds = MFMA16(W1[(size_t)(4 * fk + ks) * (H + S) + H + 16 * w + fi], dq[ks], ds);
+      for (int ks = 0; ks < 4; ++ks) ds = MFMA16(w1s[(4 * fk + ks) * 36 + 16 * w + fi], dq[ks], ds);
       if (valid) *reinterpret_cast<f32x4*>(p.dSocR + (size_t)r * S + 16 * w + 4 * fk) = ds;
     }
     lds_barrier();
@@ -832,8 +910,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         f32x4 de = f32x4{0.f, 0.f, 0.f, 0.f}, de2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          de = MFMA16(cin ? p.We2d[(size_t)(8 * fk + ks) * IN + col] : 0.f, ha[ks], de);
-          de2 = MFMA16(cin ? p.We2d[(size_t)(8 * fk + 4 + ks) * IN + col] : 0.f, hb[ks], de2);
+          de = MFMA16(cin ? e2s[(8 * fk + ks) * p.e2ld + col] : 0.f, ha[ks], de);
+          de2 = MFMA16(cin ? e2s[(8 * fk + 4 + ks) * p.e2ld + col] : 0.f, hb[ks], de2);
         }
         de += de2;
         if (valid && 16 * ct + 4 * fk + 3 < p.EIN) *reinterpret_cast<f32x4*>(p.dEnc + (size_t)r * p.EIN + 16 * ct + 4 * fk) = de;
@@ -841,6 +919,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
 
+  if ((DIAG & 16) && (blockIdx.x == 37 || blockIdx.x == 300) && threadIdx.x == 64) {
+    const long long K1 = clock64();
+    printf("wg %d: %lld tiles, total %lld cycles: per tile pre-loop %lld loop %lld tail %lld | per step: head+du %lld wgrad %lld gates %lld barrier %lld recurrence %lld\n",
+           (int)blockIdx.x, acc_n, K1 - K0, acc_pre / acc_n, acc_loop / acc_n, (K1 - K0 - acc_pre - acc_loop) / acc_n,
+           sk[0] / sk[5], sk[1] / sk[5], sk[2] / sk[5], sk[3] / sk[5], sk[4] / sk[5]);
+  }
   // ---- this workgroup's partial block ----
   float* wp = p.wpart + (size_t)blockIdx.x * DF_WLEN;
   // accW[i][n][q] of lane (fi, fk): tile position pp = 16 (2w + i) + 4 fk + q, column 16 n + fi
@@ -972,7 +1056,7 @@ int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const 
                               const int* seg, int n_gens, const int* row_ped, const int* row_slot, const int* row_pos,
                               const float* enc_h, int ld_enc, const float* noise, const float* soc, int ld_soc,
                               const float* xy0, const float* dxdy0, const float* We2d, const float* be2d,
-                              float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Hp, float* Din,
+                              float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Din,
                               float* Aact, float* E2Din, float* SocR, hipStream_t stream) {
   MG_CHECK_ARG(prep && seg && row_ped && row_slot && row_pos && enc_h && noise && soc && xy0 && dxdy0 && We2d && be2d &&
                    out_abs && out_rel,
@@ -981,7 +1065,7 @@ int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const 
   MG_CHECK_ARG(EIN % 4 == 0 && Z % 4 == 0 && ld_enc % 4 == 0 && ld_soc % 4 == 0 && n_gens > 0,
                "decoder_rollout_fwd: widths must be multiples of 4 (enc %d, noise %d)", EIN, Z);
   const bool s = Gt != nullptr;
-  MG_CHECK_ARG(s == (Cs != nullptr) && s == (Hp != nullptr) && s == (Din != nullptr) && s == (Aact != nullptr) &&
+  MG_CHECK_ARG(s == (Cs != nullptr) && s == (Din != nullptr) && s == (Aact != nullptr) &&
                    s == (E2Din != nullptr) && s == (SocR != nullptr),
                "decoder_rollout_fwd: save buffers must be all set or all NULL");
   if (R == 0) return MGGAN_OK;
@@ -990,7 +1074,7 @@ int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const 
   p.prep = prep; p.prep_stride = prep_stride; p.row_ped = row_ped; p.row_slot = row_slot; p.row_pos = row_pos;
   p.enc_h = enc_h; p.noise = noise; p.soc = soc; p.xy0 = xy0; p.dxdy0 = dxdy0; p.We2d = We2d; p.be2d = be2d;
   p.out_abs = out_abs; p.out_rel = out_rel;
-  p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Din = Din; p.Aact = Aact; p.E2Din = E2Din; p.SocR = SocR;
+  p.Gt = Gt; p.Cs = Cs; p.Din = Din; p.Aact = Aact; p.E2Din = E2Din; p.SocR = SocR;
   // one workgroup per 16-row tile, NW workgroups per generator (sized for an even split of R)
   const int per_gen = cdiv(cdiv(R, n_gens), 16);
   p.NW = per_gen < 1 ? 1 : (per_gen > 2048 / n_gens ? (2048 / n_gens > 0 ? 2048 / n_gens : 1) : per_gen);
@@ -1009,19 +1093,30 @@ int mggan_decoder_bwd_fused_layout(int* wlen, int* off_A, int* off_bias, int* of
 int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, int Z, const int* seg, const int* row_pos,
                                     const float* W_hh, const float* W1, const float* W2, long param_stride,
                                     const float* We2d, const float* prep, int prep_stride, const float* Gt,
-                                    const float* Cs, const float* Hp, const float* Din,
+                                    const float* Cs, const float* Din,
                                     const float* Aact, const float* gabs, const float* grel, int Rout, float* dH0,
                                     float* dQ, float* dEnc, float* dSocR, float* wpart, hipStream_t stream) {
-  MG_CHECK_ARG(seg && row_pos && W_hh && W1 && W2 && We2d && prep && Gt && Cs && Hp && Din && Aact && dH0 && dQ &&
+  MG_CHECK_ARG(seg && row_pos && W_hh && W1 && W2 && We2d && prep && Gt && Cs && Din && Aact && dH0 && dQ &&
                    dEnc && dSocR && wpart,
                "decoder_rollout_bwd_fused: null pointer");
   MG_CHECK_ARG(H == 32 && NW > 0 && n_gens > 0, "decoder_rollout_bwd_fused: decoder_h_dim %d not built (32)", H);
   DecFusedArgs p = {};
   p.T = T; p.NW = NW; p.Rout = Rout; p.EIN = EIN; p.Z = Z; p.seg = seg; p.row_pos = row_pos;
   p.W_hh = W_hh; p.W1 = W1; p.W2 = W2; p.We2d = We2d; p.param_stride = param_stride; p.prep = prep;
-  p.prep_stride = prep_stride; p.Gt = Gt; p.Cs = Cs; p.Hp = Hp; p.Din = Din; p.Aact = Aact;
+  p.prep_stride = prep_stride; p.Gt = Gt; p.Cs = Cs; p.Din = Din; p.Aact = Aact;
   p.gabs = gabs; p.grel = grel; p.dH0 = dH0; p.dQ = dQ; p.dEnc = dEnc; p.dSocR = dSocR; p.wpart = wpart;
-  hipLaunchKernelGGL(decoder_bwd_mfma_kernel, dim3(n_gens * NW), dim3(256), 0, stream, p);
+  p.e2ld = EIN + ((10 - EIN % 8) % 8);  // == 2 mod 8: the A-fragment reads (row 8 fk + ks) hit four 16-bank groups
+  const size_t dyn = sizeof(float) * ((size_t)H * p.e2ld + (H / 2) * 36);
+  MG_CHECK_ARG(dyn <= 64 * 1024, "decoder_rollout_bwd_fused: encoder width %d too large for the staged epilogue", EIN);
+  static int diag = -1;
+  if (diag < 0) { const char* e = getenv("MGGAN_DEC_DIAG"); diag = e ? atoi(e) : 0; }
+  if (diag == 1) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<1>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
+  else if (diag == 2) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<2>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
+  else if (diag == 4) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<4>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
+  else if (diag == 16) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<16>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
+  else if (diag == 8) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<8>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
+  else if (diag == 7) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<7>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
+  else hipLaunchKernelGGL(decoder_bwd_mfma_kernel<0>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
   MG_LAUNCH_CHECK("decoder_rollout_bwd_fused");
   return MGGAN_OK;
 }

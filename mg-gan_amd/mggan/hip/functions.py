@@ -1308,25 +1308,26 @@ class DecoderRolloutFn(Function):
                             _p(g0["w_hh"]), _p(g0["w1"]), _p(g0["b1"]), _p(g0["w2"]), _p(g0["b2"]), stride, n_gens, H, E,
                             S, 1, _p(prep), psz, st)
         mk = (lambda *s: _empty(*s, like=enc_h)) if save else (lambda *s: None)
-        # Gt (R,T,H,4) gates i,f,g,o; Cs (R,T,H,2) = (c_t, h_t); Hp (R,H) = h_0
-        Gt, Cs, Hp = mk(R, T, H, 4), mk(R, T, H, 2), mk(R, H)
-        Din, Aact, E2Din, SocR = mk(R, T, 2), mk(R, T, H // 2), mk(R, EIN + Z), mk(R, S)
+        # tile-blocked saves (16-row tiles, every generator's last tile padded): gates, (c, h) with slot 0 = (0, h_0), ...
+        tiles = -(-R // 16) + n_gens
+        Gt, Cs = mk(tiles, T, H, 16, 4), mk(tiles, T + 1, H, 16, 2)
+        Din, Aact, E2Din, SocR = mk(tiles, T, 16, 2), mk(tiles, T, 4, 16, 4), mk(R, EIN + Z), mk(R, S)
         out_abs, out_rel = _empty(T, R, 2, like=enc_h), _empty(T, R, 2, like=enc_h)
         lib.mggan_decoder_rollout_fwd(R, T, b, H, EIN, Z, _p(prep), psz, _p(rows.seg), n_gens, _p(rows.row_ped),
                                       _p(rows.row_slot), _p(rows.row_pos), _p(enc_h), ld_enc, _p(noise) or _p(enc_h), _p(soc), ld_soc,
                                       _p(xy0), _p(dxdy0), _p(e2d_w), _p(e2d_b), _p(out_abs), _p(out_rel), R, _p(Gt),
-                                      _p(Cs), _p(Hp), _p(Din), _p(Aact), _p(E2Din), _p(SocR), st)
+                                      _p(Cs), _p(Din), _p(Aact), _p(E2Din), _p(SocR), st)
         if save:
             ctx.meta = (rows, g0, n_gens, stride, T, owner, (b, EIN, Z, H, E, S, psz))
             # `soc` is the last column block of `enc_h` itself (TrunkJoinFn hands out both): its gradient is folded into
             # d enc_h by the gather below instead of travelling as a second tensor that autograd would have to add
             ctx.soc_in_enc = (b > 0 and soc.data_ptr() == enc_h.data_ptr() + 4 * (EIN - S) and ld_soc == ld_enc)
-            ctx.save_for_backward(e2d_w, e2d_b, prep, Gt, Cs, Hp, Din, Aact, E2Din, SocR)
+            ctx.save_for_backward(e2d_w, e2d_b, prep, Gt, Cs, Din, Aact, E2Din, SocR)
         return out_abs, out_rel
 
     @staticmethod
     def backward(ctx, gabs, grel):
-        e2d_w, e2d_b, prep, Gt, Cs, Hp, Din, Aact, E2Din, SocR = ctx.saved_tensors
+        e2d_w, e2d_b, prep, Gt, Cs, Din, Aact, E2Din, SocR = ctx.saved_tensors
         rows, g0, n_gens, stride, T, owner, (b, EIN, Z, H, E, S, psz) = ctx.meta
         root = root_of(owner)
         R, Hh = rows.R, H // 2
@@ -1338,7 +1339,7 @@ class DecoderRolloutFn(Function):
         dH0, dQ, dEnc, dSocR = mk(R, H), mk(R, Hh), mk(R, EIN), mk(R, S)
         # persistent workgroups per generator; each leaves one partial block of weight gradients
         # (16-row tiles; about two resident workgroups per CU, each looping over its generator's tiles)
-        NW = max(1, min(-(-R // (16 * n_gens)), 512 // n_gens))
+        NW = max(1, min(-(-R // (16 * n_gens)), int(os.environ.get('MGGAN_DEC_NW', 512)) // n_gens))
         lay = _fused_layout()
         wpart = mk(n_gens * NW, lay["wlen"])
         train_w = g0["w_hh"].requires_grad
@@ -1351,7 +1352,7 @@ class DecoderRolloutFn(Function):
             ptr = {k: gp(v) for k, v in g0.items()}
         lib.mggan_decoder_rollout_bwd_fused(n_gens, NW, T, H, EIN, Z, _p(rows.seg), _p(rows.row_pos), _p(g0["w_hh"]),
                                             _p(g0["w1"]), _p(g0["w2"]), stride, _p(e2d_w), _p(prep), psz, _p(Gt), _p(Cs),
-                                            _p(Hp), _p(Din), _p(Aact), _p(gabs), _p(grel), R, _p(dH0), _p(dQ),
+                                            _p(Din), _p(Aact), _p(gabs), _p(grel), R, _p(dH0), _p(dQ),
                                             _p(dEnc), _p(dSocR), _p(wpart), st)
         if train_w:
             ng, wl, P = n_gens, lay["wlen"], wpart.data_ptr()
@@ -1691,12 +1692,14 @@ class _GanLossArgs(ctypes.Structure):  # mirrors csrc/loss_opt.hip:GanLossArgs
 _LOSS_SCRATCH = {}
 
 
-def _loss_scratch():
-    """Per-stream scratch of mggan_gan_losses: (96 doubles, one ticket word the kernel always leaves at zero)."""
-    key = _s()
+def _loss_scratch(kind="gan", doubles=96):
+    """Per-device scratch of a loss kernel: (partial sums, one ticket word the kernel always leaves at zero).
+    The loss launches of an iteration are ordered on the main stream, so one scratch per kind is enough - and keying it
+    by stream would allocate (and zero-fill, two ATen launches) again inside a graph capture, whose stream is new."""
+    key = (kind, torch.cuda.current_device())
     hit = _LOSS_SCRATCH.get(key)
     if hit is None:
-        hit = _LOSS_SCRATCH[key] = (torch.zeros(96, dtype=torch.float64, device="cuda"),
+        hit = _LOSS_SCRATCH[key] = (torch.zeros(doubles, dtype=torch.float64, device="cuda"),
                                     torch.zeros(1, dtype=torch.int32, device="cuda"))
     return hit
 
@@ -1805,11 +1808,7 @@ class PmMlFn(Function):
         dl = _empty(b, g, like=logits)
         probs = _empty(b, g, like=logits)
         n = float(norm or b)
-        key = ("pm", _s())
-        scratch = _LOSS_SCRATCH.get(key)
-        if scratch is None:
-            scratch = _LOSS_SCRATCH[key] = (torch.zeros(17 * 64, dtype=torch.float64, device=logits.device),
-                                            torch.zeros(1, dtype=torch.int32, device=logits.device))
+        scratch = _loss_scratch("pm", 17 * 64)
         lib.mggan_pm_ml_loss_mean(b, T, E, g, _p(gen_abs), _p(gt), _p(logits), float(sigma), 1.0 / n, _p(loss_rows),
                                   _p(dl), _p(probs), _p(scratch[0]), _p(scratch[1]), _p(out), _p(probs_out),
                                   float(b) / n, _s())
