@@ -20,7 +20,6 @@
 // per-generator weight gradients see contiguous segments.
 #include <stdlib.h>
 #include "common.h"
-#include <type_traits>
 #include "../../include/mggan_hip.h"
 
 // ---- layout of one prepared (folded/transposed) weight block, in floats -----------
@@ -658,13 +657,11 @@ struct DecFusedArgs {
 //   4. weight gradients with K = the 16 tile rows: [dW_hh | dA | dbias] += dPre^T [h_{t-1} | dxdy | 1]
 //      (wave w: position tiles 2w, 2w+1 x three column tiles, 24 MFMAs), dW1[:, :H] += du^T h_t (2 MFMAs)
 // The LDS tiles are multi-buffered over t so that the single barrier per step is enough.
-#define DB_RS 196  // dPre tile row stride (== 4 mod 64: conflict-free 16-byte row reads).  Row r starts 16 (r & 3) floats in
-                   // (hence 176 used + pad): the transposed 4-byte reads of the weight-gradient phase (lane = (position
-                   // fi, row 4 ks + fk)) then start 20 banks apart per fk instead of 4 - 2-way on 12 banks, not 4-way -
-                   // and the row accesses keep compile-time offsets (an XOR swizzle cost more VALU than it saved)
+#define DB_RS 148  // dPre tile row stride == 20 mod 64: the 16-byte row accesses of a 16-lane group land on banks 20 fi (+0..3),
+                   // sixteen distinct 4-bank groups, and the transposed 4-byte reads of the weight-gradient phase (lane =
+                   // (position fi, row 4 ks + fk)) start 20 banks apart per fk - 2-way on 12 banks (stride 132: 4-way)
 #define DB_HS 48   // h tile row stride (== 16 mod 32: conflict-free transposed reads); cols 32,33 = dxdy, 34 = 1
 
-template <int DIAG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void decoder_bwd_mfma_kernel(DecFusedArgs p) {
   constexpr int H = 32, Hh = 16, S = 32;
   __shared__ __attribute__((aligned(16))) float dps[2][16 * DB_RS];
@@ -683,7 +680,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int IN = p.EIN + p.Z;
   const int tbase = dec_tile_base(p.seg, gi);
   const int uj[2] = {8 * w + fk, 8 * w + 4 + fk};
-  const int sw = (fi & 3) << 4;
   const int sel = fi & 3, us = 8 * w + 4 * (sel & 1) + (fi >> 2);  // A-operand row role of this lane
 
   // A operands.  Position p = unit*4 + gate in the dPre tile <-> original gate row (p & 3)*H + (p >> 2).
@@ -721,11 +717,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int q = 0; q < 4; ++q) accW2[0][q] = accW2[1][q] = accb1[q] = 0.f;
 
-  const long long K0 = (DIAG & 16) ? clock64() : 0;
-  long long acc_pre = 0, acc_loop = 0, acc_tail = 0, acc_n = 0, KP = 0;
-  long long sk[6] = {0, 0, 0, 0, 0, 0};
   for (int tile = wi; tile < ntiles; tile += p.NW) {
-    const long long Q0 = (DIAG & 16) ? clock64() : 0;
     const int r = seg0 + tile * 16 + fi;
     const bool valid = r < seg1;
     const int rc = valid ? r : seg1 - 1;
@@ -734,8 +726,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t tg = (size_t)(tbase + tile);
     float dh[2] = {0.f, 0.f}, dc[2] = {0.f, 0.f}, dd0 = 0.f, dd1 = 0.f, s0 = 0.f, s1 = 0.f;
     f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
-    // Saved activations of the next step, fetched one whole step ahead (HBM latency under this kernel's own traffic is
-    // longer than the matrix phase: fetching after the barrier instead, without the second register set, cost 15 %).
+    // Saved activations of the next step, fetched one whole step ahead into a second register set.  (The 512
+    // workgroups run in step and ask for their 13 KB records at the same moment: served as a burst, the last of them
+    // waits for most of a step.  Fetching after the step's barrier without the second set cost 15 %; moving the
+    // records global -> LDS by DMA, asm-issued so that the compiler does not drain vmcnt early, freed the registers
+    // but exposed the same wait in front of the barrier: no gain, not kept.)
     f32x4 n_g[2], n_av;
     float2 n_ch[2], n_din, n_ga, n_gr;
     float cc[2];
@@ -757,35 +752,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       n_ga = *reinterpret_cast<const float2*>(p.gabs ? p.gabs + o : din);
       n_gr = *reinterpret_cast<const float2*>(p.grel ? p.grel + o : din);
     };
-    // Weight gradients of step tt, K = the 16 tile rows.  They hang off nothing in the recurrence, so they run one step
-    // late, at the head of step tt - 1, where their 26 MFMAs cover that step's gate arithmetic (VALU) instead of
-    // queueing behind the 32 MFMAs of the recurrence; the LDS tiles of step tt are not rewritten before step tt - 2.
-    auto wgrad = [&](int tt) {
-      const float* dpr = dps[tt & 1];
-      const float* dur = dus[tt & 1];
-      const float* htp = hts[tt % 3];        // h_{tt-1} | dxdy_tt | 1
-      const float* htq = hts[(tt + 1) % 3];  // h_tt
-#pragma unroll
-      for (int ks = 0; ks < ((DIAG & 1) ? 0 : 4); ++ks) {
-        float a[2], bv[3];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = dpr[(4 * ks + fk) * DB_RS + 16 * fk + 16 * (2 * w + i) + fi];
-#pragma unroll
-        for (int n = 0; n < 3; ++n) bv[n] = htp[(4 * ks + fk) * DB_HS + 16 * n + fi];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int n = 0; n < 3; ++n) accW[i][n] = MFMA16(a[i], bv[n], accW[i][n]);
-      }
-      {  // dW1[:, :H] += du^T h_t : wave w -> column tile (w & 1), K half (w >> 1)
-        const int nt = w & 1, kh = w >> 1;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int ks = 2 * kh + kk;
-          accU = MFMA16(dur[(4 * ks + fk) * Hh + fi], htq[(4 * ks + fk) * DB_HS + 16 * nt + fi], accU);
-        }
-      }
-    };
     lds_barrier();  // the previous tile's last LDS reads are done
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -795,23 +761,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     fetch(p.T - 1);
 
-    long long tk[6] = {0, 0, 0, 0, 0, 0};
-    auto tick = [&]() -> long long {
-      if (!(DIAG & 16)) return 0;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      long long v = clock64();
-      asm volatile("" ::: "memory");
-      return v;
-    };
-    auto step = [&](int t, auto first) {
-      const long long T0 = tick();
+    for (int t = p.T - 1; t >= 0; --t) {
       float* dpw = dps[t & 1];
       float* duw = dus[t & 1];
-      float* htw = hts[t % 3];  // receives h_{t-1}
+      float* htw = hts[t % 3];              // receives h_{t-1}
+      const float* htc = hts[(t + 1) % 3];  // holds h_t
       const f32x4 c_g[2] = {n_g[0], n_g[1]}, c_av = n_av;
       const float2 c_ch[2] = {n_ch[0], n_ch[1]}, c_din = n_din, c_ga = n_ga, c_gr = n_gr;
-      if (DIAG & 8) fetch(p.T - 1); else
-      if (!(DIAG & 2)) fetch(t > 0 ? t - 1 : 0);  // a whole step ahead (step 0 re-reads its own slots: no branch)
+      fetch(t > 0 ? t - 1 : 0);  // (step 0 re-reads its own slots: no branch between the loads)
       s0 = fmaf(c_ga.x, gam, s0); s1 = fmaf(c_ga.y, gam, s1);
       const float g0 = (s0 + dd0 + c_gr.x * grm) * vm, g1 = (s1 + dd1 + c_gr.y * grm) * vm;
       f32x4 du;
@@ -835,14 +792,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       a2 = MFMA16(Aw1[1], du[1], a2);
       a1 = MFMA16(Aw1[2], du[2], a1);
       a2 = MFMA16(Aw1[3], du[3], a2);
-      const long long T1 = tick();
-      if constexpr (!decltype(first)::value) wgrad(t + 1);
-      const long long T2 = tick();
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const float dhv = a1[mt] + a2[mt];
         const float gi_ = c_g[mt][0], gf = c_g[mt][1], gg = c_g[mt][2], go = c_g[mt][3];
-        const float cprev = c_ch[mt].x;
+        const float cprev = c_ch[mt].x;  // slot 0 of Cs holds c_{-1} = 0
         const float tc = mg_tanh(cc[mt]);
         const float dO = dhv * tc;
         const float dcv = fmaf(dhv * go, 1.f - tc * tc, dc[mt]);
@@ -853,36 +807,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         dp[3] = dO * go * (1.f - go) * vm;
         dc[mt] = dcv * gf;
         cc[mt] = cprev;
-        *reinterpret_cast<f32x4*>(&dpw[fi * DB_RS + sw + uj[mt] * 4]) = dp;
+        *reinterpret_cast<f32x4*>(&dpw[fi * DB_RS + uj[mt] * 4]) = dp;
       }
-      const long long T3 = tick();
       lds_barrier();
-      const long long T4 = tick();
       // [dh_{t-1} (own units) ; d dxdy_t] = [W_hh^T ; A^T] dPre^T, K = 128 gate rows in tile-position order
       f32x4 acc[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < ((DIAG & 4) ? 1 : 8); ++j) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&dpw[fi * DB_RS + sw + 16 * j + 4 * fk]);
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&dpw[fi * DB_RS + 16 * j + 4 * fk]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = MFMA16(Ah[4 * j + q], b4[q], acc[q]);
       }
+      // weight gradients, K = the 16 tile rows.  (Run one step late, beside the next step's gate arithmetic, they
+      // took exactly as long: the two workgroups of a CU already fill each other's gaps.)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        float a[2], bv[3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = dpw[(4 * ks + fk) * DB_RS + 16 * (2 * w + i) + fi];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bv[n] = htw[(4 * ks + fk) * DB_HS + 16 * n + fi];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) accW[i][n] = MFMA16(a[i], bv[n], accW[i][n]);
+      }
+      {  // dW1[:, :H] += du^T h_t : wave w -> column tile (w & 1), K half (w >> 1)
+        const int nt = w & 1, kh = w >> 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int ks = 2 * kh + kk;
+          accU = MFMA16(duw[(4 * ks + fk) * Hh + fi], htc[(4 * ks + fk) * DB_HS + 16 * nt + fi], accU);
+        }
+      }
       const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
       dh[0] = sum[0]; dh[1] = sum[1]; dd0 = sum[2]; dd1 = sum[3];
-      if (DIAG & 16) {
-        const long long T5 = tick() + (long long)(dh[0] * 1e-30f);
-        tk[0] += T1 - T0; tk[1] += T2 - T1; tk[2] += T3 - T2; tk[3] += T4 - T3; tk[4] += T5 - T4; tk[5] += 1;
-      }
-    };
-    const long long Q1 = tick();
-    step(p.T - 1, std::true_type{});
-    for (int t = p.T - 2; t >= 0; --t) step(t, std::false_type{});
-    wgrad(0);
-    const long long Q2 = tick();
-    if (DIAG & 16) {
-      acc_pre += Q1 - Q0; acc_loop += Q2 - Q1; acc_n += 1; KP = Q2;
-      for (int i = 0; i < 6; ++i) sk[i] += tk[i];
     }
     // ---- per-row outputs of this tile: dH0, dQ, d(enc_h row), d(social row) ----
     float* h0t = hts[2];  // h_{-1} slot of the t = 0 step is hts[0]; hts[2] held h_1 (last read at t = 1)
@@ -919,12 +880,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
 
-  if ((DIAG & 16) && (blockIdx.x == 37 || blockIdx.x == 300) && threadIdx.x == 64) {
-    const long long K1 = clock64();
-    printf("wg %d: %lld tiles, total %lld cycles: per tile pre-loop %lld loop %lld tail %lld | per step: head+du %lld wgrad %lld gates %lld barrier %lld recurrence %lld\n",
-           (int)blockIdx.x, acc_n, K1 - K0, acc_pre / acc_n, acc_loop / acc_n, (K1 - K0 - acc_pre - acc_loop) / acc_n,
-           sk[0] / sk[5], sk[1] / sk[5], sk[2] / sk[5], sk[3] / sk[5], sk[4] / sk[5]);
-  }
   // ---- this workgroup's partial block ----
   float* wp = p.wpart + (size_t)blockIdx.x * DF_WLEN;
   // accW[i][n][q] of lane (fi, fk): tile position pp = 16 (2w + i) + 4 fk + q, column 16 n + fi
@@ -1108,15 +1063,7 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
   p.e2ld = EIN + ((10 - EIN % 8) % 8);  // == 2 mod 8: the A-fragment reads (row 8 fk + ks) hit four 16-bank groups
   const size_t dyn = sizeof(float) * ((size_t)H * p.e2ld + (H / 2) * 36);
   MG_CHECK_ARG(dyn <= 64 * 1024, "decoder_rollout_bwd_fused: encoder width %d too large for the staged epilogue", EIN);
-  static int diag = -1;
-  if (diag < 0) { const char* e = getenv("MGGAN_DEC_DIAG"); diag = e ? atoi(e) : 0; }
-  if (diag == 1) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<1>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
-  else if (diag == 2) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<2>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
-  else if (diag == 4) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<4>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
-  else if (diag == 16) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<16>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
-  else if (diag == 8) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<8>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
-  else if (diag == 7) hipLaunchKernelGGL(decoder_bwd_mfma_kernel<7>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
-  else hipLaunchKernelGGL(decoder_bwd_mfma_kernel<0>, dim3(n_gens * NW), dim3(256), dyn, stream, p);
+  hipLaunchKernelGGL(decoder_bwd_mfma_kernel, dim3(n_gens * NW), dim3(256), dyn, stream, p);
   MG_LAUNCH_CHECK("decoder_rollout_bwd_fused");
   return MGGAN_OK;
 }

@@ -207,7 +207,7 @@ class _WgradDesc(ctypes.Structure):
                 ("feature_major", ctypes.c_int)]
 
 
-_DEFER = {"on": False, "descs": [], "keep": [], "gemms": [], "events": {}, "after": []}
+_DEFER = {"on": False, "descs": [], "keep": [], "gemms": [], "events": {}, "revents": {}, "after": []}
 TRACE_NOTES = {"wgrad_multi_flops": [], "mlp_chain_flops": []}
 
 
@@ -215,7 +215,19 @@ def defer_grad_reduce(on=True):
     _DEFER["on"] = bool(on)
 
 
+def _note_branch_partials():
+    """Partial sums queued for the batched reduction were (or are about to be) written by a kernel on the CURRENT stream.
+    On a branch stream that point is remembered as an event, so that the reduction can go out as soon as every producer
+    is done - beside what the branch still has to do (the scene CNN's conv1 adjoint) - instead of behind a full join."""
+    cur = torch.cuda.current_stream()
+    if any(cur == st for st in _BR["streams"].values()):
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        _DEFER["revents"][cur.cuda_stream] = ev
+
+
 def _queue_reduce(P, dW, db, M, Naug, has_bias, lddw, splits, groups, p_stride, w_stride=0, b_stride=0, keep=()):
+    _note_branch_partials()
     _DEFER["descs"].append(_ReduceDesc(P, dW, db or None, w_stride, b_stride, M, Naug, has_bias, lddw, splits, groups,
                                        p_stride, 0))
     _DEFER["keep"].extend(keep)
@@ -225,7 +237,9 @@ def flush_wgrad_gemms():
     """Launch the queued weight-gradient GEMMs (partial sums; one launch per operand layout and 16 problems) on
     the current stream.  Called BEFORE the branch streams are joined: the GEMMs need the branch streams only up to
     the points where those queued their operands (events recorded then), so they run beside the rest of a branch's
-    backward (the scene CNN's convolution adjoints) instead of after it."""
+    backward (the scene CNN's convolution adjoints) instead of after it.  (Launching them in earlier batches on a stream
+    of their own, beside the backward pass that is still queueing operands, was measured and is worse: the GEMM grids
+    take the CUs the latency-bound main chain needs - 2.17-2.34 ms per configs[1] iteration against 2.08.)"""
     gm = _DEFER["gemms"]
     if not gm:
         return
@@ -240,6 +254,15 @@ def flush_wgrad_gemms():
     _DEFER["gemms"] = []
 
 
+def _note_gemm_operands():
+    """The operands of a GEMM queued from a branch stream are complete on that stream from here on."""
+    cur = torch.cuda.current_stream()
+    if any(cur == st for st in _BR["streams"].values()):
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        _DEFER["events"][cur.cuda_stream] = ev
+
+
 def flush_grad_reduces():
     """Batched reduce.  Two partial buffers that accumulate into the SAME gradient tensor (e.g. the real and
     the fake pass of a discriminator step) must not share a launch: batches are cut at such conflicts."""
@@ -247,6 +270,10 @@ def flush_grad_reduces():
     if not d:
         return
     flush_wgrad_gemms()
+    cur = torch.cuda.current_stream()
+    for ev in _DEFER["revents"].values():
+        cur.wait_event(ev)
+    _DEFER["revents"] = {}
     batch, seen = [], set()
 
     def launch():
@@ -284,11 +311,7 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
         # queued like the rest, but its reduction STORES into dW/db (scratch that a queued consumer reads afterwards)
         _DEFER["gemms"].append(_WgradDesc(pz, px, ws.data_ptr(), _p(seg) or None, rows, K, N, lddz, ldx, seg_scale, n_groups,
                                           fm))
-        cur = torch.cuda.current_stream()
-        if any(cur == st for st in _BR["streams"].values()):
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            _DEFER["events"][cur.cuda_stream] = ev
+        _note_gemm_operands()
         _DEFER["descs"].append(_ReduceDesc(ws.data_ptr(), dW_ptr, db_ptr or None, w_stride, b_stride, N, K + 1, 3, lddw,
                                            lib.mggan_wgrad_splits(rows, K, N, n_groups), max(n_groups, 1), N * (K + 1), 0))
         _DEFER["keep"].extend((ws, dz, x, seg))
@@ -299,11 +322,7 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
         _DEFER["gemms"].append(_WgradDesc(pz, px, ws.data_ptr(), _p(seg) or None, rows, K, N, lddz, ldx, seg_scale, n_groups,
                                           fm))
         keep = (ws, dz, x, seg)
-        cur = torch.cuda.current_stream()
-        if any(cur == st for st in _BR["streams"].values()):  # queued from a branch stream: operands ready from here on
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            _DEFER["events"][cur.cuda_stream] = ev
+        _note_gemm_operands()
     elif overwrite:  # partial sums now, then a storing (not accumulating) reduction: the destination is scratch
         lib.mggan_wgrad(pz, lddz, px, ldx, 0, lddw, db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, fm,
                         _p(yact), ld_yact, act, float(slope), ws.data_ptr(), nbytes, _s())
@@ -1339,7 +1358,7 @@ class DecoderRolloutFn(Function):
         dH0, dQ, dEnc, dSocR = mk(R, H), mk(R, Hh), mk(R, EIN), mk(R, S)
         # persistent workgroups per generator; each leaves one partial block of weight gradients
         # (16-row tiles; about two resident workgroups per CU, each looping over its generator's tiles)
-        NW = max(1, min(-(-R // (16 * n_gens)), int(os.environ.get('MGGAN_DEC_NW', 512)) // n_gens))
+        NW = max(1, min(-(-R // (16 * n_gens)), 512 // n_gens))
         lay = _fused_layout()
         wpart = mk(n_gens * NW, lay["wlen"])
         train_w = g0["w_hh"].requires_grad
@@ -1365,6 +1384,7 @@ class DecoderRolloutFn(Function):
                                                          ptr["emb_b"], ptr["w_ih"], ptr["b_ih"], ptr["b_hh"], stride, ng,
                                                          H, E, _p(dprep), 12 * H, _s())
             if _DEFER["on"]:  # off the critical chain: with the batched reductions at the end of the backward pass
+                _note_branch_partials()
                 _DEFER["descs"].extend(now)
                 _DEFER["after"].append(unfold)
                 _DEFER["keep"].extend((dprep, wpart, now))

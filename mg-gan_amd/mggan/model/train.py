@@ -154,10 +154,13 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         if HF._MARKS["on"] and 0 in HF._BR["streams"]:
             with torch.cuda.stream(HF._BR["streams"][0]):
                 HF.mark("bwd.branch0.end")
+        # the batched reduction of the partial sums (and the LSTM un-folding behind it) waits for its producers only -
+        # events recorded where branch streams queued partials - not for the branches' last kernels
+        HF.flush_grad_reduces()
+        HF.mark("bwd.reduce.end")
         if HF._BR["on"]:
             torch.cuda.current_stream().wait_stream(self._bwd_stream)
         HF.join_branch(force=True)  # backward nodes ran on the streams of their forwards
-        HF.flush_grad_reduces()
 
     # ---- the three steps -----------------------------------------------------------------
     def discriminator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None,
