@@ -301,7 +301,10 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
     to take it off the critical path."""
     if rows == 0:
         return
-    nbytes = lib.mggan_wgrad_workspace_bytes(rows, K, N, n_groups)
+    if fm:  # feature-major operands: the streaming kernel's slabs
+        nbytes, splits = lib.mggan_wgrad_workspace_bytes_fm(rows, K, N), lib.mggan_wgrad_splits_fm(rows, K, N)
+    else:
+        nbytes, splits = lib.mggan_wgrad_workspace_bytes(rows, K, N, n_groups), lib.mggan_wgrad_splits(rows, K, N, n_groups)
     ws = _empty(nbytes // 4, like=dz if torch.is_tensor(dz) else x)
     if _SIDE["dirty"]:
         _SIDE["keep"].append(ws)
@@ -313,7 +316,7 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
                                           fm))
         _note_gemm_operands()
         _DEFER["descs"].append(_ReduceDesc(ws.data_ptr(), dW_ptr, db_ptr or None, w_stride, b_stride, N, K + 1, 3, lddw,
-                                           lib.mggan_wgrad_splits(rows, K, N, n_groups), max(n_groups, 1), N * (K + 1), 0))
+                                           splits, max(n_groups, 1), N * (K + 1), 0))
         _DEFER["keep"].extend((ws, dz, x, seg))
         return
     if defer and yact is None:
@@ -327,7 +330,7 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
         lib.mggan_wgrad(pz, lddz, px, ldx, 0, lddw, db_ptr, rows, K, N, _p(seg), seg_scale, n_groups, w_stride, b_stride, fm,
                         _p(yact), ld_yact, act, float(slope), ws.data_ptr(), nbytes, _s())
         one = (_ReduceDesc * 1)(_ReduceDesc(ws.data_ptr(), dW_ptr, db_ptr or None, w_stride, b_stride, N, K + 1, 3, lddw,
-                                            lib.mggan_wgrad_splits(rows, K, N, n_groups), max(n_groups, 1), N * (K + 1), 0))
+                                            splits, max(n_groups, 1), N * (K + 1), 0))
         lib.mggan_grad_reduce_multi(ctypes.addressof(one), 1, _s())
         return
     else:
@@ -336,7 +339,7 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
         keep = (ws,)
     if defer:
         ng = max(n_groups, 1)
-        _queue_reduce(ws.data_ptr(), dW_ptr, db_ptr, N, K + 1, 1, lddw, lib.mggan_wgrad_splits(rows, K, N, n_groups), ng,
+        _queue_reduce(ws.data_ptr(), dW_ptr, db_ptr, N, K + 1, 1, lddw, splits, ng,
                       N * (K + 1), w_stride, b_stride, keep=keep)
 
 

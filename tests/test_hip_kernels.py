@@ -72,10 +72,41 @@ def test_linear_fwd_bwd_wgrad(rows, K, N, act):
     # feature-major operands ([feature][row]) give the same result
     dZt, Xt = dZ.t().contiguous(), Xd[:, :K].t().contiguous()
     dW2, db2 = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    nb2 = lib.mggan_wgrad_workspace_bytes_fm(rows, K, N)
+    ws2 = torch.empty(nb2 // 4, device=dev)
     lib.mggan_wgrad(dZt.data_ptr(), rows, Xt.data_ptr(), rows, dW2.data_ptr(), K, db2.data_ptr(), rows, K, N, 0, 1, 0, 0,
-                    0, 1, 0, 0, 0, 0.0, ws.data_ptr(), nb, st())
+                    0, 1, 0, 0, 0, 0.0, ws2.data_ptr(), nb2, st())
     np.testing.assert_allclose(dW2.cpu().numpy(), dW_ref.float().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(db2.cpu().numpy(), dZ_ref.double().sum(0).float().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("rows,ld,K,N", [(25600, 25600, 32, 64), (1003, 1003, 3, 32), (4099, 4100, 8, 32),
+                                         (100003, 100004, 32, 16), (70000, 70000, 64, 64), (15, 16, 16, 32),
+                                         (5000, 5000, 33, 17)])
+def test_wgrad_streaming_feature_major(rows, ld, K, N):
+    """The streaming kernel behind feature-major weight gradients (<= 64 x 64 outputs): aligned and unaligned row
+    strides, slabs with partial super-steps, every tile-count variant; against f64."""
+    lib, dev = _lib(), _dev()
+    g = torch.Generator().manual_seed(rows + K + N)
+    dZ = torch.randn(N, ld, generator=g)
+    X = torch.randn(K, ld, generator=g)
+    dZd, Xd = dZ.to(dev), X.to(dev)
+    dW, db = torch.full((N, K), 0.25, device=dev), torch.full((N,), -1.0, device=dev)
+    nb = lib.mggan_wgrad_workspace_bytes_fm(rows, K, N)
+    assert nb == lib.mggan_wgrad_splits_fm(rows, K, N) * N * (K + 1) * 4
+    ws = torch.full((nb // 4,), float("nan"), device=dev)
+    lib.mggan_wgrad(dZd.data_ptr(), ld, Xd.data_ptr(), ld, dW.data_ptr(), K, db.data_ptr(), rows, K, N, 0, 1, 0, 0, 0, 1,
+                    0, 0, 0, 0.0, ws.data_ptr(), nb, st())
+    ref = dZ[:, :rows].double() @ X[:, :rows].double().t()
+    scale = float(rows) ** 0.5
+    np.testing.assert_allclose(dW.cpu().numpy(), ref.float().numpy() + 0.25, rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(db.cpu().numpy(), dZ[:, :rows].double().sum(1).float().numpy() - 1.0, rtol=1e-4,
+                               atol=2e-5 * scale)
+    # bit-reproducible (fixed summation order)
+    dW2, db2 = torch.full((N, K), 0.25, device=dev), torch.full((N,), -1.0, device=dev)
+    lib.mggan_wgrad(dZd.data_ptr(), ld, Xd.data_ptr(), ld, dW2.data_ptr(), K, db2.data_ptr(), rows, K, N, 0, 1, 0, 0, 0, 1,
+                    0, 0, 0, 0.0, ws.data_ptr(), nb, st())
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
 
 
 def test_wgrad_grouped_segments():
