@@ -66,11 +66,6 @@ int mggan_linear_bwd_data(const float* dZ, int lddz, const float* W, int ldw, fl
  * decoder weights).  seg == NULL, n_groups <= 1: one group over all rows. */
 int mggan_wgrad_splits(int rows, int K, int N, int n_groups);
 size_t mggan_wgrad_workspace_bytes(int rows, int K, int N, int n_groups);
-/* the same for feature-major operands ([feature][row], feature_major = 1 below): products of at most 64 x 64 outputs are
- * streamed (one contiguous slab of rows per workgroup, fragments loaded straight from memory) and leave one partial
- * block per slab */
-int mggan_wgrad_splits_fm(int rows, int K, int N);
-size_t mggan_wgrad_workspace_bytes_fm(int rows, int K, int N);
 /* feature_major != 0: dZ is stored [N][lddz] and X [K][ldx] (element (row, f) at p[f*ld + row]) */
 int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, int lddw, float* db, int rows, int K,
                 int N, const int* seg, int seg_scale, int n_groups, long w_stride, long b_stride, int feature_major,

@@ -302,40 +302,49 @@ __global__ void act_bwd_kernel(const float* __restrict__ dY, int lddy, const flo
   dZ[(size_t)r * lddz + n] = dY[(size_t)r * lddy + n] * mg_act_grad_from_out(Y[(size_t)r * ldy + n], act, slope);
 }
 
-// ---- streaming weight gradients of feature-major operands --------------------------------------------------
-// dW[n][k] = sum_r dZ[n][r] X[k][r], db[n] = sum_r dZ[n][r] with both operands stored [feature][row] (the pair /
-// position kernels of the social and scene attention write them that way, one lane per row).  These are the
-// skinny products of the step: 25,600 - 524,288 rows against <= 64 x 64 outputs, i.e. pure operand streaming
-// (442 MB per discriminator step at 256 x 32 pedestrians).  The tiled kernel above stages 64 x 64 x 32 blocks through
-// LDS with 4-byte loads and two barriers per 32 rows and reached a third of the HBM rate on them.  Here a wave reads
-// its MFMA fragments straight from memory: with the reduction index of a 16-row super-step permuted as
-// k = 4 fk + i (the same permutation on both operands: the sum is over the same set), lane (fi, fk) needs rows
-// r + 4 fk .. r + 4 fk + 3 of feature fi - one 16-byte load per operand tile, no LDS, no barrier, every element
-// read exactly once.  The four waves of a workgroup interleave the super-steps of one contiguous slab of rows and
-// fold their accumulators through LDS at the end: ONE partial block [N][K+1] per workgroup (column K = db, summed on
-// the VALU from the fragments already loaded), in the layout grad_reduce_multi_kernel folds.
+// ---- streaming weight gradients --------------------------------------------------------------------------------
+// dW[n][k] = sum_r dZ[r][n] X[r][k], db[n] = sum_r dZ[r][n]: 1,280 - 524,288 rows against outputs of a few dozen
+// features, i.e. operand streaming (442 MB of pair activations per discriminator step at 256 x 32 pedestrians).  The
+// tiled kernel above stages 64 x 64 x 32 blocks through LDS with 4-byte loads and two barriers per 32 rows and reached a
+// third of the HBM rate on them.  Here a wave reads its MFMA fragments straight from memory, no LDS, no barrier:
+//  * feature-major operands ([feature][row]: the pair / position kernels of the social and scene attention write them
+//    that way, one lane per row): with the reduction index of a 16-row super-step permuted as k = 4 fk + i (the same
+//    permutation on both operands: the sum is over the same set), lane (fi, fk) needs rows r + 4 fk .. r + 4 fk + 3 of
+//    feature fi - one 16-byte load per operand tile;
+//  * row-major operands ([row][feature], everything else): the same rows as four 4-byte loads, 16 lanes side by side.
+// A workgroup owns one contiguous slab of rows and one panel of at most 64 x 64 outputs (wider products are cut into
+// panels: an operand is then read once per panel of the OTHER operand); its four waves interleave the slab's
+// super-steps and fold their accumulators through LDS at the end: ONE partial block per slab, [N][K+1] with column
+// K = db (summed on the VALU from the fragments already loaded), in the layout grad_reduce_multi_kernel folds.
 struct StreamProb {
-  const float *A, *B;  // dZ (N features x rows), X (K features x rows)
+  const float *A, *B;  // dZ, X
   float* P;            // partial blocks [slab][M][Kf + 1]
-  int rows, M, Kf, lda, ldb, slab, blk0, vec;
-};
+  int rows, M, Kf, lda, ldb, slab, blk0, mode, pm, pk;  // mode 0: feature-major, 16-byte loads; 1: feature-major,
+};                                                      // unaligned; 2: row-major
 #define MG_MAX_STREAM_BATCH 16
 struct StreamBatch {
   StreamProb p[MG_MAX_STREAM_BATCH];
   int n;
 };
 
-template <int MT, int NT, bool VEC>
-__device__ __forceinline__ void wgrad_stream_slab(const StreamProb& q, const int slab, float* red) {
+template <int MT, int NT, int MODE>
+__device__ __forceinline__ void wgrad_stream_slab(const StreamProb& q, const int slab, const int m0, const int k0,
+                                                  float* red) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
   const int r0 = slab * q.slab, r1 = min(q.rows, r0 + q.slab);
   // features past the matrix read feature 0: their products only reach output rows / columns that are never stored
   const float* ap[MT];
   const float* bp[NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) ap[i] = q.A + (size_t)(16 * i + fi < q.M ? 16 * i + fi : 0) * q.lda + 4 * fk;
+  for (int i = 0; i < MT; ++i) {
+    const int f = m0 + 16 * i + fi < q.M ? m0 + 16 * i + fi : 0;
+    ap[i] = MODE == 2 ? q.A + (size_t)(4 * fk) * q.lda + f : q.A + (size_t)f * q.lda + 4 * fk;
+  }
 #pragma unroll
-  for (int j = 0; j < NT; ++j) bp[j] = q.B + (size_t)(16 * j + fi < q.Kf ? 16 * j + fi : 0) * q.ldb + 4 * fk;
+  for (int j = 0; j < NT; ++j) {
+    const int f = k0 + 16 * j + fi < q.Kf ? k0 + 16 * j + fi : 0;
+    bp[j] = MODE == 2 ? q.B + (size_t)(4 * fk) * q.ldb + f : q.B + (size_t)f * q.ldb + 4 * fk;
+  }
   f32x4 acc[MT][NT];
   float bsum[MT];
 #pragma unroll
@@ -344,9 +353,11 @@ __device__ __forceinline__ void wgrad_stream_slab(const StreamProb& q, const int
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  auto load = [&](const float* p, int r) -> f32x4 {
-    if (VEC) return *reinterpret_cast<const f32x4*>(p + r);
-    return f32x4{p[r], p[r + 1], p[r + 2], p[r + 3]};
+  auto load = [&](const float* p, int r, int ld) -> f32x4 {  // rows r + 4 fk + (0..3) of this lane's feature
+    if (MODE == 0) return *reinterpret_cast<const f32x4*>(p + r);
+    if (MODE == 1) return f32x4{p[r], p[r + 1], p[r + 2], p[r + 3]};
+    const float* pr = p + (size_t)r * ld;
+    return f32x4{pr[0], pr[ld], pr[2 * ld], pr[3 * ld]};
   };
   auto mac = [&](const f32x4* a, const f32x4* b) {
 #pragma unroll
@@ -359,29 +370,29 @@ __device__ __forceinline__ void wgrad_stream_slab(const StreamProb& q, const int
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
   };
   // full super-steps, two in flight per wave (wave w takes super-steps w, w + 4, ...: the workgroup walks its slab
-  // 256 bytes per feature at a time)
+  // 64 rows at a time)
   const int nfull = (r1 - r0) / 16;
   f32x4 a0[MT], b0[NT], a1[MT], b1[NT];
   int s = w;
   if (s < nfull) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a0[i] = load(ap[i], r0 + 16 * s);
+    for (int i = 0; i < MT; ++i) a0[i] = load(ap[i], r0 + 16 * s, q.lda);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) b0[j] = load(bp[j], r0 + 16 * s);
+    for (int j = 0; j < NT; ++j) b0[j] = load(bp[j], r0 + 16 * s, q.ldb);
   }
   for (; s < nfull; s += 8) {
     const bool more = s + 4 < nfull;
     const int rn = r0 + 16 * (more ? s + 4 : s);  // (the last odd step re-reads itself: no branch between the loads)
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a1[i] = load(ap[i], rn);
+    for (int i = 0; i < MT; ++i) a1[i] = load(ap[i], rn, q.lda);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) b1[j] = load(bp[j], rn);
+    for (int j = 0; j < NT; ++j) b1[j] = load(bp[j], rn, q.ldb);
     mac(a0, b0);
     const int rm = r0 + 16 * (s + 8 < nfull ? s + 8 : s);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a0[i] = load(ap[i], rm);
+    for (int i = 0; i < MT; ++i) a0[i] = load(ap[i], rm, q.lda);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) b0[j] = load(bp[j], rm);
+    for (int j = 0; j < NT; ++j) b0[j] = load(bp[j], rm, q.ldb);
     if (more) mac(a1, b1);
   }
   // the slab's last (partial) super-step: wave 0, element by element
@@ -389,16 +400,16 @@ __device__ __forceinline__ void wgrad_stream_slab(const StreamProb& q, const int
     const int r = r0 + 16 * nfull;
     f32x4 a[MT], b[NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int e = 0; e < 4; ++e) {
+      const bool in = r + 4 * fk + e < r1;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[i][e] = r + 4 * fk + e < r1 ? ap[i][r + e] : 0.f;
+      for (int i = 0; i < MT; ++i) a[i][e] = in ? (MODE == 2 ? ap[i][(size_t)(r + e) * q.lda] : ap[i][r + e]) : 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) b[j][e] = r + 4 * fk + e < r1 ? bp[j][r + e] : 0.f;
+      for (int j = 0; j < NT; ++j) b[j][e] = in ? (MODE == 2 ? bp[j][(size_t)(r + e) * q.ldb] : bp[j][r + e]) : 0.f;
+    }
     mac(a, b);
   }
-  // fold the four waves (fixed order) and store this workgroup's partial block
+  // fold the four waves (fixed order) and store this workgroup's part of the slab's partial block
   const int Naug = q.Kf + 1;
   float* P = q.P + (size_t)slab * q.M * Naug;
   f32x4* red4 = reinterpret_cast<f32x4*>(red);
@@ -414,14 +425,15 @@ __device__ __forceinline__ void wgrad_stream_slab(const StreamProb& q, const int
         const f32x4 v = (src[0] + src[64]) + (src[128] + src[192]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int gm = 16 * i + 4 * fk + r, gn = 16 * j + fi;
+          const int gm = m0 + 16 * i + 4 * fk + r, gn = k0 + 16 * j + fi;
           if (gm < q.M && gn < q.Kf) P[(size_t)gm * Naug + gn] = v[r];
         }
       }
     }
   }
+  if (k0 != 0) return;  // db comes from the first panel of a row of panels
   __syncthreads();
-  // db: lane (fi, fk) holds the sum over its rows of feature 16 i + fi
+  // lane (fi, fk) holds the sum over its rows of feature m0 + 16 i + fi
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     float v = bsum[i];
@@ -431,18 +443,14 @@ __device__ __forceinline__ void wgrad_stream_slab(const StreamProb& q, const int
   }
   __syncthreads();
   if (threadIdx.x < 16 * MT) {
-    const int i = threadIdx.x >> 4, f = threadIdx.x & 15, gm = 16 * i + f;
+    const int i = threadIdx.x >> 4, f = threadIdx.x & 15, gm = m0 + 16 * i + f;
     const float* src = red + i * 64 + f;
     if (gm < q.M) P[(size_t)gm * Naug + q.Kf] = (src[0] + src[16]) + (src[32] + src[48]);
   }
 }
 
-template <int MT, int NT>
-__device__ __forceinline__ void wgrad_stream_dispatch(const StreamProb& q, int slab, float* red) {
-  if (q.vec) wgrad_stream_slab<MT, NT, true>(q, slab, red);
-  else wgrad_stream_slab<MT, NT, false>(q, slab, red);
-}
-
+// one kernel per operand layout: each keeps its own register budget (the row-major form needs more address registers)
+template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_stream_kernel(StreamBatch bt) {
   __shared__ __attribute__((aligned(16))) float red[2 * 4 * 64 * 4];
   int di = 0;
@@ -450,20 +458,28 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(StreamBatch bt) {
   for (int i = 1; i < bt.n; ++i)
     if ((int)blockIdx.x >= bt.p[i].blk0) di = i;
   const StreamProb& q = bt.p[di];
-  const int slab = blockIdx.x - q.blk0;
-  const int mt = (q.M + 15) >> 4, nt = (q.Kf + 15) >> 4;  // 1..4 each
+  const int rel = blockIdx.x - q.blk0, np = q.pm * q.pk;
+  const int slab = rel / np, panel = rel - slab * np;
+  const int m0 = 64 * (panel / q.pk), k0 = 64 * (panel % q.pk);
+  const int mt = (min(64, q.M - m0) + 15) >> 4, nt = (min(64, q.Kf - k0) + 15) >> 4;  // 1..4 each
   const int MTc = mt > 2 ? 4 : mt, NTc = nt > 2 ? 4 : nt;
   switch (MTc * 8 + NTc) {
-    case 1 * 8 + 1: wgrad_stream_dispatch<1, 1>(q, slab, red); break;
-    case 1 * 8 + 2: wgrad_stream_dispatch<1, 2>(q, slab, red); break;
-    case 1 * 8 + 4: wgrad_stream_dispatch<1, 4>(q, slab, red); break;
-    case 2 * 8 + 1: wgrad_stream_dispatch<2, 1>(q, slab, red); break;
-    case 2 * 8 + 2: wgrad_stream_dispatch<2, 2>(q, slab, red); break;
-    case 2 * 8 + 4: wgrad_stream_dispatch<2, 4>(q, slab, red); break;
-    case 4 * 8 + 1: wgrad_stream_dispatch<4, 1>(q, slab, red); break;
-    case 4 * 8 + 2: wgrad_stream_dispatch<4, 2>(q, slab, red); break;
-    default: wgrad_stream_dispatch<4, 4>(q, slab, red); break;
+    case 1 * 8 + 1: wgrad_stream_slab<1, 1, MODE>(q, slab, m0, k0, red); break;
+    case 1 * 8 + 2: wgrad_stream_slab<1, 2, MODE>(q, slab, m0, k0, red); break;
+    case 1 * 8 + 4: wgrad_stream_slab<1, 4, MODE>(q, slab, m0, k0, red); break;
+    case 2 * 8 + 1: wgrad_stream_slab<2, 1, MODE>(q, slab, m0, k0, red); break;
+    case 2 * 8 + 2: wgrad_stream_slab<2, 2, MODE>(q, slab, m0, k0, red); break;
+    case 2 * 8 + 4: wgrad_stream_slab<2, 4, MODE>(q, slab, m0, k0, red); break;
+    case 4 * 8 + 1: wgrad_stream_slab<4, 1, MODE>(q, slab, m0, k0, red); break;
+    case 4 * 8 + 2: wgrad_stream_slab<4, 2, MODE>(q, slab, m0, k0, red); break;
+    default: wgrad_stream_slab<4, 4, MODE>(q, slab, m0, k0, red); break;
   }
+}
+
+static void launch_stream(const StreamBatch& sb, int blocks, int mode, hipStream_t stream) {
+  if (mode == 0) hipLaunchKernelGGL(wgrad_stream_kernel<0>, dim3(blocks), dim3(256), 0, stream, sb);
+  else if (mode == 1) hipLaunchKernelGGL(wgrad_stream_kernel<1>, dim3(blocks), dim3(256), 0, stream, sb);
+  else hipLaunchKernelGGL(wgrad_stream_kernel<2>, dim3(blocks), dim3(256), 0, stream, sb);
 }
 
 extern "C" {
@@ -518,32 +534,25 @@ size_t mggan_wgrad_workspace_bytes(int rows, int K, int N, int n_groups) {
   return (size_t)splits * (n_groups > 0 ? n_groups : 1) * N * (K + 1) * sizeof(float);
 }
 
-// rows per workgroup of the streaming kernel: ~768 workgroups for the largest problems, never less than 256 rows
+// rows per workgroup of the streaming kernel: ~768 slabs for the largest problems, never less than 128 rows
 static int stream_slab_rows(int rows) {
   int s = cdiv(cdiv(rows, 768), 64) * 64;
-  return s < 256 ? 256 : s;
-}
-static bool stream_ok(int K, int N, int n_groups) { return K >= 1 && N >= 1 && K <= 64 && N <= 64 && n_groups <= 1; }
-
-int mggan_wgrad_splits_fm(int rows, int K, int N) {
-  if (!stream_ok(K, N, 0)) return mggan_wgrad_splits(rows, K, N, 0);
-  return rows > 0 ? cdiv(rows, stream_slab_rows(rows)) : 1;
-}
-
-size_t mggan_wgrad_workspace_bytes_fm(int rows, int K, int N) {
-  return (size_t)mggan_wgrad_splits_fm(rows, K, N) * N * (K + 1) * sizeof(float);
+  return s < 128 ? 128 : s;
 }
 
 static StreamProb stream_problem(const float* dZ, const float* X, float* workspace, int rows, int K, int N, int lddz,
-                                 int ldx) {
+                                 int ldx, int feature_major) {
   StreamProb q = {};
   q.A = dZ; q.B = X; q.P = workspace; q.rows = rows; q.M = N; q.Kf = K; q.lda = lddz; q.ldb = ldx;
   q.slab = stream_slab_rows(rows);
-  q.vec = (lddz % 4 == 0) && (ldx % 4 == 0) && ((size_t)dZ % 16 == 0) && ((size_t)X % 16 == 0);
+  q.pm = cdiv(N, 64); q.pk = cdiv(K, 64);
+  const bool vec = (lddz % 4 == 0) && (ldx % 4 == 0) && ((size_t)dZ % 16 == 0) && ((size_t)X % 16 == 0);
+  q.mode = feature_major ? (vec ? 0 : 1) : 2;
   return q;
 }
 
 int mggan_wgrad_splits(int rows, int K, int N, int n_groups) {
+  if (n_groups <= 1) return rows > 0 ? cdiv(rows, stream_slab_rows(rows)) : 1;  // slabs of the streaming kernel
   // short dependent chains: 128-256 rows (4-8 pipelined k-steps) per workgroup, up to ~4 workgroups per CU
   int ng = n_groups > 0 ? n_groups : 1;
   int tiles = cdiv(N, BM) * cdiv(K + 1, BN) * ng;
@@ -583,8 +592,8 @@ int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, i
   if (rows == 0) return MGGAN_OK;
   const int ng = n_groups > 0 ? n_groups : 1;
   MG_CHECK_ARG(ng == 1 || seg, "wgrad: grouped mode needs segment offsets");
-  const bool streaming = feature_major && stream_ok(K, N, n_groups) && !(Yact && act != ACT_NONE);
-  const int splits = streaming ? mggan_wgrad_splits_fm(rows, K, N) : mggan_wgrad_splits(rows, K, N, n_groups);
+  const bool streaming = n_groups <= 1 && !(Yact && act != ACT_NONE);  // (grouped / fused-derivative forms: tiled kernel)
+  const int splits = mggan_wgrad_splits(rows, K, N, n_groups);
   const int Naug = K + 1;
   size_t need = (size_t)splits * ng * N * Naug * sizeof(float);
   if (workspace_bytes < need || !workspace) {
@@ -604,9 +613,9 @@ int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, i
   if (streaming) {
     StreamBatch sb;
     sb.n = 1;
-    sb.p[0] = stream_problem(dZ, X, (float*)workspace, rows, K, N, lddz, ldx);
+    sb.p[0] = stream_problem(dZ, X, (float*)workspace, rows, K, N, lddz, ldx, feature_major);
     sb.p[0].blk0 = 0;
-    hipLaunchKernelGGL(wgrad_stream_kernel, dim3(splits), dim3(256), 0, stream, sb);
+    launch_stream(sb, splits * sb.p[0].pm * sb.p[0].pk, sb.p[0].mode, stream);
   } else if (feature_major) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
   else if (g.Yact) hipLaunchKernelGGL((gemm_kernel<true, true, true>), grid, dim3(256), 0, stream, g);
   else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
@@ -630,22 +639,24 @@ struct WgradDesc {  // mirrors the ctypes structure in mggan/hip/functions.py
 int mggan_wgrad_multi(const void* descs, int n, hipStream_t stream) {
   MG_CHECK_ARG(descs || n == 0, "wgrad_multi: null descriptor array");
   const WgradDesc* d = (const WgradDesc*)descs;
-  {  // feature-major problems that fit the streaming kernel: one launch per 16 of them
+  for (int mode = 0; mode < 3; ++mode) {  // ungrouped problems: the streaming kernel, one launch per layout and 16 problems
     StreamBatch sb;
     sb.n = 0;
     int blocks = 0;
     auto launch = [&]() {
       if (sb.n == 0) return;
-      hipLaunchKernelGGL(wgrad_stream_kernel, dim3(blocks), dim3(256), 0, stream, sb);
+      launch_stream(sb, blocks, mode, stream);
       sb.n = 0;
       blocks = 0;
     };
     for (int i = 0; i < n; ++i) {
-      if (!d[i].feature_major || d[i].rows == 0 || !stream_ok(d[i].K, d[i].N, d[i].n_groups)) continue;
-      MG_CHECK_ARG(d[i].dZ && d[i].X && d[i].workspace, "wgrad_multi: bad descriptor %d", i);
-      StreamProb q = stream_problem(d[i].dZ, d[i].X, d[i].workspace, d[i].rows, d[i].K, d[i].N, d[i].lddz, d[i].ldx);
+      if (d[i].rows == 0 || d[i].n_groups > 1) continue;
+      MG_CHECK_ARG(d[i].dZ && d[i].X && d[i].workspace && d[i].K > 0 && d[i].N > 0, "wgrad_multi: bad descriptor %d", i);
+      StreamProb q = stream_problem(d[i].dZ, d[i].X, d[i].workspace, d[i].rows, d[i].K, d[i].N, d[i].lddz, d[i].ldx,
+                                    d[i].feature_major);
+      if (q.mode != mode) continue;
       q.blk0 = blocks;
-      blocks += mggan_wgrad_splits_fm(d[i].rows, d[i].K, d[i].N);
+      blocks += mggan_wgrad_splits(d[i].rows, d[i].K, d[i].N, 0) * q.pm * q.pk;
       sb.p[sb.n] = q;
       if (++sb.n == MG_MAX_STREAM_BATCH) launch();
     }
@@ -665,7 +676,7 @@ int mggan_wgrad_multi(const void* descs, int n, hipStream_t stream) {
     };
     for (int i = 0; i < n; ++i) {
       if ((d[i].feature_major != 0) != (fm != 0) || d[i].rows == 0) continue;
-      if (fm && stream_ok(d[i].K, d[i].N, d[i].n_groups)) continue;  // went out with the streaming batch
+      if (d[i].n_groups <= 1) continue;  // went out with the streaming batch
       MG_CHECK_ARG(d[i].dZ && d[i].X && d[i].workspace && d[i].K > 0 && d[i].N > 0, "wgrad_multi: bad descriptor %d", i);
       const int ng = d[i].n_groups > 0 ? d[i].n_groups : 1;
       MG_CHECK_ARG(ng == 1 || d[i].seg, "wgrad_multi: grouped mode needs segment offsets");

@@ -301,10 +301,7 @@ def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scal
     to take it off the critical path."""
     if rows == 0:
         return
-    if fm:  # feature-major operands: the streaming kernel's slabs
-        nbytes, splits = lib.mggan_wgrad_workspace_bytes_fm(rows, K, N), lib.mggan_wgrad_splits_fm(rows, K, N)
-    else:
-        nbytes, splits = lib.mggan_wgrad_workspace_bytes(rows, K, N, n_groups), lib.mggan_wgrad_splits(rows, K, N, n_groups)
+    nbytes, splits = lib.mggan_wgrad_workspace_bytes(rows, K, N, n_groups), lib.mggan_wgrad_splits(rows, K, N, n_groups)
     ws = _empty(nbytes // 4, like=dz if torch.is_tensor(dz) else x)
     if _SIDE["dirty"]:
         _SIDE["keep"].append(ws)

@@ -72,10 +72,8 @@ def test_linear_fwd_bwd_wgrad(rows, K, N, act):
     # feature-major operands ([feature][row]) give the same result
     dZt, Xt = dZ.t().contiguous(), Xd[:, :K].t().contiguous()
     dW2, db2 = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
-    nb2 = lib.mggan_wgrad_workspace_bytes_fm(rows, K, N)
-    ws2 = torch.empty(nb2 // 4, device=dev)
     lib.mggan_wgrad(dZt.data_ptr(), rows, Xt.data_ptr(), rows, dW2.data_ptr(), K, db2.data_ptr(), rows, K, N, 0, 1, 0, 0,
-                    0, 1, 0, 0, 0, 0.0, ws2.data_ptr(), nb2, st())
+                    0, 1, 0, 0, 0, 0.0, ws.data_ptr(), nb, st())
     np.testing.assert_allclose(dW2.cpu().numpy(), dW_ref.float().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(db2.cpu().numpy(), dZ_ref.double().sum(0).float().numpy(), rtol=1e-4, atol=1e-4)
 
@@ -92,8 +90,8 @@ def test_wgrad_streaming_feature_major(rows, ld, K, N):
     X = torch.randn(K, ld, generator=g)
     dZd, Xd = dZ.to(dev), X.to(dev)
     dW, db = torch.full((N, K), 0.25, device=dev), torch.full((N,), -1.0, device=dev)
-    nb = lib.mggan_wgrad_workspace_bytes_fm(rows, K, N)
-    assert nb == lib.mggan_wgrad_splits_fm(rows, K, N) * N * (K + 1) * 4
+    nb = lib.mggan_wgrad_workspace_bytes(rows, K, N, 0)
+    assert nb == lib.mggan_wgrad_splits(rows, K, N, 0) * N * (K + 1) * 4
     ws = torch.full((nb // 4,), float("nan"), device=dev)
     lib.mggan_wgrad(dZd.data_ptr(), ld, Xd.data_ptr(), ld, dW.data_ptr(), K, db.data_ptr(), rows, K, N, 0, 1, 0, 0, 0, 1,
                     0, 0, 0, 0.0, ws.data_ptr(), nb, st())
@@ -107,6 +105,27 @@ def test_wgrad_streaming_feature_major(rows, ld, K, N):
     lib.mggan_wgrad(dZd.data_ptr(), ld, Xd.data_ptr(), ld, dW2.data_ptr(), K, db2.data_ptr(), rows, K, N, 0, 1, 0, 0, 0, 1,
                     0, 0, 0, 0.0, ws.data_ptr(), nb, st())
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("rows,K,N", [(5003, 64, 256), (20000, 136, 32), (16384, 192, 96), (333, 1, 64), (4096, 65, 65),
+                                      (131, 24, 64)])
+def test_wgrad_streaming_row_major(rows, K, N):
+    """Row-major operands through the streaming kernel: outputs wider than one 64 x 64 panel, padded row strides."""
+    lib, dev = _lib(), _dev()
+    g = torch.Generator().manual_seed(rows + K + N)
+    ldz, ldx = N + 3, K + 1
+    dZ, X = torch.randn(rows, ldz, generator=g), torch.randn(rows, ldx, generator=g)
+    dZd, Xd = dZ.to(dev), X.to(dev)
+    dW, db = torch.full((N, K), 0.25, device=dev), torch.full((N,), -1.0, device=dev)
+    nb = lib.mggan_wgrad_workspace_bytes(rows, K, N, 0)
+    ws = torch.full((nb // 4,), float("nan"), device=dev)
+    lib.mggan_wgrad(dZd.data_ptr(), ldz, Xd.data_ptr(), ldx, dW.data_ptr(), K, db.data_ptr(), rows, K, N, 0, 1, 0, 0, 0, 0,
+                    0, 0, 0, 0.0, ws.data_ptr(), nb, st())
+    ref = dZ[:, :N].double().t() @ X[:, :K].double()
+    scale = float(rows) ** 0.5
+    np.testing.assert_allclose(dW.cpu().numpy(), ref.float().numpy() + 0.25, rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(db.cpu().numpy(), dZ[:, :N].double().sum(0).float().numpy() - 1.0, rtol=1e-4,
+                               atol=2e-5 * scale)
 
 
 def test_wgrad_grouped_segments():
