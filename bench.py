@@ -38,7 +38,7 @@ def kernel_of(name, a):
     fixed = {
         "mggan_decoder_rollout_bwd_fused": "decoder_bwd_mfma_kernel",
         "mggan_decoder_rollout_fwd": "decoder_fwd_mfma_kernel",
-        "mggan_wgrad_multi": "gemm_multi_kernel<true,true>",
+        "mggan_wgrad_multi": "wgrad_stream_kernel",  # <0> feature-major + <2> row-major launches of one batch
         "mggan_wgrad": "gemm_kernel<true,true,false>",
         "mggan_linear_fwd": "gemm_kernel<false,false,false>",
         "mggan_linear_bwd_data": "gemm_kernel<false,true,false>",
@@ -122,6 +122,30 @@ def flops_of(name, a):
         return float(a[2]) * 2 * (96 + 2048 + 64 + a[3])
     if name == "mggan_social_attention_bwd":
         return float(a[2]) * 2 * (64 + 2048 + 3 * a[4] + 65)
+    return 0.0
+
+
+def bytes_of(name, a):
+    """Algorithmic HBM bytes of one C-ABI call for the entries that stream large operands once (DESIGN.md section 7
+    states the per-unit figures): every saved activation / operand read or written exactly once, weights ignored."""
+    if name == "mggan_wgrad_multi":  # both operands of every product of the batch, once
+        from mggan.hip import functions as HF
+
+        notes = HF.TRACE_NOTES["wgrad_multi_bytes"]
+        return notes.pop(0) if notes else 0.0
+    if name == "mggan_decoder_rollout_fwd":  # saves per (row, step): gates 4H, (c,h) 2H, activations H/2, input 2 (+ outputs)
+        R, T, H = a[0], a[1], a[3]
+        save = 0.0 if not a[25] else 4.0 * (4 * H + 2 * H + H // 2 + 2)
+        return float(R) * T * (save + 4.0 * 4)
+    if name == "mggan_decoder_rollout_bwd_fused":  # reads the same record back, plus the two output gradients
+        T, H, R = a[2], a[3], a[21]
+        return float(R) * T * 4.0 * (4 * H + 2 * H + H // 2 + 2 + 4)
+    if name == "mggan_social_attention_bwd":  # per pair: reads l1 (32), l2 (64), att; writes dz1 (32), dz2 (64), dsigma
+        return float(a[2]) * 4.0 * (32 + 64 + 1 + 32 + 64 + 1)
+    if name == "mggan_social_attention_fwd":  # per pair (training): writes feat (3), l1 (32), l2 (64), att
+        return float(a[2]) * 4.0 * ((3 + 32 + 64 if a[18] else 0) + 1)
+    if name == "mggan_image_gram":  # the batch's images, once
+        return float(a[1]) * 4 * 33 * 33 * 4.0
     return 0.0
 
 
@@ -301,12 +325,13 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
         # one row per HIP kernel: an entry such as mggan_conv1_bwd launches a different template per channel count
         by_kernel = {}
         for a, ms in zip(arglist, ms_list):
-            r = by_kernel.setdefault(kernel_of(name, a), [0, 0.0, 0.0])
+            r = by_kernel.setdefault(kernel_of(name, a), [0, 0.0, 0.0, 0.0])
             r[0] += 1
             r[1] += ms
             r[2] += flops_of(name, a)
-        for sym, (c, ms, fl) in by_kernel.items():
-            rows.append((ms / n_prof, name, c / n_prof, fl / n_prof, sym))
+            r[3] += bytes_of(name, a)
+        for sym, (c, ms, fl, by) in by_kernel.items():
+            rows.append((ms / n_prof, name, c / n_prof, fl / n_prof, sym, by / n_prof))
     rows.sort(reverse=True)
     gpu_ms = sum(r[0] for r in rows)
     total_flops = sum(r[3] for r in rows)
@@ -314,20 +339,35 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
     traffic_tab = _load_json("hbm_traffic_{}.json".format(tag)) or (_load_json("hbm_traffic.json") if tag == "c2" else {})
     mfma_tab = _load_json("mfma_util_{}.json".format(tag))
 
+    def family(tab, symbol, key, how):
+        """Counter value of a kernel, or of the launches of a family (wgrad_stream_kernel -> <0>, <2>) taken together."""
+        if symbol in tab:
+            return tab[symbol].get(key)
+        vals = [e.get(key) for k, e in tab.items() if k.startswith(symbol + "<") and e.get(key) is not None]
+        return how(vals) if vals else None
+
     def roof(row):
-        ms, name, calls, fl, symbol = row
+        ms, name, calls, fl, symbol, by = row
         per_launch_s = ms / max(calls, 1) * 1e-3
-        achieved = fl / max(calls, 1) / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
-        return {"bound": "mfma", "kernel": symbol, "entry": name, "achieved": round(achieved, 3),
-                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_PEAK_TFLOPS, 5),
-                "traffic": traffic_tab.get(symbol, {}).get("bytes_per_launch"),
-                "mfma_util": mfma_tab.get(symbol, {}).get("mfma_util"),
-                "launches_per_step": round(calls, 2), "avg_launch_ms": round(per_launch_s * 1e3, 4)}
+        tf = fl / max(calls, 1) / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
+        gbs = by / max(calls, 1) / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        common = {"kernel": symbol, "entry": name, "traffic": family(traffic_tab, symbol, "bytes_per_launch", sum),
+                  "mfma_util": family(mfma_tab, symbol, "mfma_util", max),
+                  "launches_per_step": round(calls, 2), "avg_launch_ms": round(per_launch_s * 1e3, 4),
+                  "tflops": round(tf, 3), "algorithmic_gbs": round(gbs, 1)}
+        # the binding roof is the one the kernel sits closer to
+        if gbs / HBM_PEAK_GBS > tf / F32_PEAK_TFLOPS:
+            return dict(common, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(gbs / HBM_PEAK_GBS, 5))
+        return dict(common, bound="mfma", achieved=round(tf, 3), peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(tf / F32_PEAK_TFLOPS, 5))
 
     # the dominant kernel = the one with the largest share of the step's GPU time (summed over its launches)
     roofline = roof(rows[0])
-    roofline["note"] = ("f32 (exact) -- peak is the dense f32 vector/MFMA rate; achieved = algorithmic FLOPs per launch "
-                        "(SURVEY App. D shapes) / average HIP-event duration of a launch of this kernel; traffic = HBM "
+    roofline["note"] = ("f32 (exact) -- mfma: peak is the dense f32 vector/MFMA rate, achieved = algorithmic FLOPs per launch "
+                        "(SURVEY App. D shapes) / average HIP-event duration of a launch of this kernel; hbm: achieved = "
+                        "algorithmic bytes per launch (every operand once, DESIGN.md section 7) / the same duration, peak 8 TB/s; "
+                        "the bound reported is the roof the kernel sits closer to; traffic = HBM "
                         "bytes per launch, mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8 XCDs), both "
                         "from the rocprofv3 --pmc passes committed under profiles/")
     res.update({
@@ -337,8 +377,8 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
         "iteration_frac_of_f32_peak": round(total_flops / (dt / args.steps) / 1e12 / F32_PEAK_TFLOPS, 4),
         "gpu_ms_per_step_sum_of_entries": round(gpu_ms, 3),
         "launches_per_step": round(sum(r[2] for r in rows), 1),
-        "breakdown": [{"entry": n, "kernel": sym, "ms_per_step": round(ms, 4), "calls": round(c, 2), "gflop": round(fl / 1e9, 3)}
-                      for ms, n, c, fl, sym in rows[:14]]})
+        "breakdown": [{"entry": n, "kernel": sym, "ms_per_step": round(ms, 4), "calls": round(c, 2), "gflop": round(fl / 1e9, 3),
+                       "algorithmic_mb": round(by / 1e6, 1)} for ms, n, c, fl, sym, by in rows[:14]]})
     tr.dist.close()
     del tr, replay
     torch.cuda.empty_cache()

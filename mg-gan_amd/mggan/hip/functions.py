@@ -208,7 +208,7 @@ class _WgradDesc(ctypes.Structure):
 
 
 _DEFER = {"on": False, "descs": [], "keep": [], "gemms": [], "events": {}, "revents": {}, "after": []}
-TRACE_NOTES = {"wgrad_multi_flops": [], "mlp_chain_flops": []}
+TRACE_NOTES = {"wgrad_multi_flops": [], "wgrad_multi_bytes": [], "mlp_chain_flops": []}
 
 
 def defer_grad_reduce(on=True):
@@ -250,6 +250,7 @@ def flush_wgrad_gemms():
     arr = (_WgradDesc * len(gm))(*gm)
     if _load_lib().trace is not None:  # bench.py's per-entry trace: algorithmic FLOPs of this batch
         TRACE_NOTES["wgrad_multi_flops"].append(sum(2.0 * g.rows * g.K * g.N for g in gm))
+        TRACE_NOTES["wgrad_multi_bytes"].append(sum(4.0 * g.rows * (g.K + g.N) for g in gm))  # each operand once
     lib.mggan_wgrad_multi(ctypes.addressof(arr), len(gm), _s())
     _DEFER["gemms"] = []
 
