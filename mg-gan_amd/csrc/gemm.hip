@@ -267,11 +267,18 @@ __global__ __launch_bounds__(1024) void grad_reduce_multi_kernel(ReduceBatch bt)
   float s = 0.f;
   if (o < total) {
     const float* p = D.P + ((size_t)grp * D.splits) * D.p_stride + o;
-    float s0 = 0.f, s1 = 0.f;
+    // eight partial sums per thread = eight loads in flight: the streaming weight-gradient kernel leaves up to 768
+    // partial blocks per problem and a thread's 48 of them, fetched two at a time, were 24 dependent round trips
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int z = zl;
-    for (; z + 16 < D.splits; z += 32) { s0 += p[(size_t)z * D.p_stride]; s1 += p[(size_t)(z + 16) * D.p_stride]; }
-    if (z < D.splits) s0 += p[(size_t)z * D.p_stride];
-    s = s0 + s1;
+    for (; z + 16 * 7 < D.splits; z += 16 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += p[(size_t)(z + 16 * u) * D.p_stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (z + 16 * u < D.splits) a[u] += p[(size_t)(z + 16 * u) * D.p_stride];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   red[zl][lane] = s;
   __syncthreads();
