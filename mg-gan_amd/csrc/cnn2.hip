@@ -662,9 +662,6 @@ __global__ __launch_bounds__(256) void conv1_wgrad_finalize_kernel(const double*
 // persistent grid: at most `cap` workgroups (three per CU), and every workgroup walks the same number of images
 // (the last one may fall short): 1,280 images -> 640 workgroups x 2, 8,192 -> 745 x 11
 static int grid_for(int B, int cap) {
-  static int env_cap = -1;
-  if (env_cap < 0) { const char* e = getenv("MGGAN_CNN_CAP"); env_cap = e ? atoi(e) : 0; }
-  if (env_cap > 0) cap = env_cap;
   if (B <= cap) return B;
   const int per = (B + cap - 1) / cap;
   return (B + per - 1) / per;

@@ -211,11 +211,23 @@ __global__ __launch_bounds__(256) void social_dvc_kernel(int b, int P, const int
   const int n = na[j];
   float acc = 0.f;
   if (n > 1) {
-    const int s0 = s0a[j], lj = j - s0;
-    for (int i = 0; i < n; ++i) {
-      const int p = prow[s0 + i] + lj;
-      acc = fmaf(dsigma[p], m < L2 ? l2s[(size_t)m * P + p] : 1.0f, acc);
+    const int s0 = s0a[j], pb = prow[s0] + (j - s0);
+    const float* dsg = dsigma + pb;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    if (m < L2) {
+      const float* l2 = l2s + (size_t)m * P + pb;
+      for (; i + 3 < n; i += 4) {
+        a0 = fmaf(dsg[i * n], l2[i * n], a0);
+        a1 = fmaf(dsg[(i + 1) * n], l2[(i + 1) * n], a1);
+        a2 = fmaf(dsg[(i + 2) * n], l2[(i + 2) * n], a2);
+        a3 = fmaf(dsg[(i + 3) * n], l2[(i + 3) * n], a3);
+      }
+      for (; i < n; ++i) a0 = fmaf(dsg[i * n], l2[i * n], a0);
+    } else {
+      for (; i < n; ++i) a0 += dsg[i * n];
     }
+    acc = (a0 + a1) + (a2 + a3);
   }
   dvc[(size_t)j * (L2 + 1) + m] = acc;
 }
@@ -287,11 +299,23 @@ __global__ __launch_bounds__(256) void social_fwd_fused_kernel(
     if (w == 0) sg_s[lane] = sc;
     __syncthreads();
     // every wave walks its lanes' softmax rows (same values in all four; wave 0 publishes)
+    // (loops over a run-time n are walked four entries at a time with independent partial results: one LDS or memory
+    //  round trip per group of four instead of per entry - these walks were most of a workgroup's critical path)
     const int seg0 = prow[i] - p0, n = na[i];
-    float mx = -INFINITY;
-    for (int jj = 0; jj < n; ++jj) mx = fmaxf(mx, sg_s[seg0 + jj]);
-    float den = 0.f;
-    for (int jj = 0; jj < n; ++jj) den += __expf(sg_s[seg0 + jj] - mx);
+    const float* row = sg_s + seg0;
+    float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+    int jj = 0;
+    for (; jj + 3 < n; jj += 4) {
+      m0 = fmaxf(m0, row[jj]); m1 = fmaxf(m1, row[jj + 1]); m2 = fmaxf(m2, row[jj + 2]); m3 = fmaxf(m3, row[jj + 3]);
+    }
+    for (; jj < n; ++jj) m0 = fmaxf(m0, row[jj]);
+    const float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    for (jj = 0; jj + 3 < n; jj += 4) {
+      d0 += __expf(row[jj] - mx); d1 += __expf(row[jj + 1] - mx); d2 += __expf(row[jj + 2] - mx); d3 += __expf(row[jj + 3] - mx);
+    }
+    for (; jj < n; ++jj) d0 += __expf(row[jj] - mx);
+    const float den = (d0 + d1) + (d2 + d3);
     const float a = __expf(sc - mx) * (1.0f / den);
     if (w == 0) {
       a_s[lane] = a;
@@ -304,8 +328,18 @@ __global__ __launch_bounds__(256) void social_fwd_fused_kernel(
     const int n = na[q];
     float acc = 0.f;
     if (n > 1) {  // social.py:19-20: a lone pedestrian pools nothing
-      const int seg0 = prow[q] - p0, s0 = s0a[q];
-      for (int jj = 0; jj < n; ++jj) acc = fmaf(a_s[seg0 + jj], h[(size_t)(s0 + jj) * ld_h + k], acc);
+      const float* ar = a_s + (prow[q] - p0);
+      const float* hr = h + (size_t)s0a[q] * ld_h + k;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int jj = 0;
+      for (; jj + 3 < n; jj += 4) {
+        a0 = fmaf(ar[jj], hr[(size_t)jj * ld_h], a0);
+        a1 = fmaf(ar[jj + 1], hr[(size_t)(jj + 1) * ld_h], a1);
+        a2 = fmaf(ar[jj + 2], hr[(size_t)(jj + 2) * ld_h], a2);
+        a3 = fmaf(ar[jj + 3], hr[(size_t)(jj + 3) * ld_h], a3);
+      }
+      for (; jj < n; ++jj) a0 = fmaf(ar[jj], hr[(size_t)jj * ld_h], a0);
+      acc = (a0 + a1) + (a2 + a3);
     }
     S[(size_t)q * ld_s + k] = acc;
   }
@@ -343,8 +377,12 @@ __global__ __launch_bounds__(256) void social_bwd_fused_kernel(
   if (w == 0) ad_s[lane] = a_ij * da;
   __syncthreads();
   const int seg0 = prow[i] - p0, n = na[i];
-  float dot = 0.f;
-  for (int jj = 0; jj < n; ++jj) dot += ad_s[seg0 + jj];
+  const float* adr = ad_s + seg0;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  int jj = 0;
+  for (; jj + 3 < n; jj += 4) { t0 += adr[jj]; t1 += adr[jj + 1]; t2 += adr[jj + 2]; t3 += adr[jj + 3]; }
+  for (; jj < n; ++jj) t0 += adr[jj];
+  const float dot = (t0 + t1) + (t2 + t3);
   const float dsg = a_ij * (da - dot);
   if (w == 0 && ok) dsigma[p] = dsg;
   const float* v = vc + (size_t)j * (L2 + 1);
@@ -386,8 +424,20 @@ __global__ __launch_bounds__(256) void social_dh_dvc_kernel(int b, int P, int nb
     const int n = na[j];
     float acc = 0.f;
     if (n > 1) {
-      const int s0 = s0a[j], lj = j - s0;
-      for (int i = 0; i < n; ++i) acc = fmaf(att[prow[s0 + i] + lj], dS[(size_t)(s0 + i) * ld_ds + k], acc);
+      // the pairs of a scene are an n x n block in pedestrian order: pair (s0 + i, j) sits at prow[s0] + i n + (j - s0)
+      // (no table lookup per term, and four independent partial sums keep the loads of a column in flight)
+      const int s0 = s0a[j], pb = prow[s0] + (j - s0);
+      const float* ds = dS + (size_t)s0 * ld_ds + k;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int i = 0;
+      for (; i + 3 < n; i += 4) {
+        a0 = fmaf(att[pb + i * n], ds[(size_t)i * ld_ds], a0);
+        a1 = fmaf(att[pb + (i + 1) * n], ds[(size_t)(i + 1) * ld_ds], a1);
+        a2 = fmaf(att[pb + (i + 2) * n], ds[(size_t)(i + 2) * ld_ds], a2);
+        a3 = fmaf(att[pb + (i + 3) * n], ds[(size_t)(i + 3) * ld_ds], a3);
+      }
+      for (; i < n; ++i) a0 = fmaf(att[pb + i * n], ds[(size_t)i * ld_ds], a0);
+      acc = (a0 + a1) + (a2 + a3);
     }
     float* d = dh + (size_t)j * ld_dh + k;
     *d = accumulate ? (*d + acc) : acc;
@@ -399,11 +449,23 @@ __global__ __launch_bounds__(256) void social_dh_dvc_kernel(int b, int P, int nb
   const int n = na[j];
   float acc = 0.f;
   if (n > 1) {
-    const int s0 = s0a[j], lj = j - s0;
-    for (int i = 0; i < n; ++i) {
-      const int p = prow[s0 + i] + lj;
-      acc = fmaf(dsigma[p], m < L2 ? l2s[(size_t)m * P + p] : 1.0f, acc);
+    const int s0 = s0a[j], pb = prow[s0] + (j - s0);
+    const float* dsg = dsigma + pb;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    if (m < L2) {
+      const float* l2 = l2s + (size_t)m * P + pb;
+      for (; i + 3 < n; i += 4) {
+        a0 = fmaf(dsg[i * n], l2[i * n], a0);
+        a1 = fmaf(dsg[(i + 1) * n], l2[(i + 1) * n], a1);
+        a2 = fmaf(dsg[(i + 2) * n], l2[(i + 2) * n], a2);
+        a3 = fmaf(dsg[(i + 3) * n], l2[(i + 3) * n], a3);
+      }
+      for (; i < n; ++i) a0 = fmaf(dsg[i * n], l2[i * n], a0);
+    } else {
+      for (; i < n; ++i) a0 += dsg[i * n];
     }
+    acc = (a0 + a1) + (a2 + a3);
   }
   dvc[(size_t)j * (L2 + 1) + m] = acc;
 }
