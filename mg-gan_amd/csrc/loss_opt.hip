@@ -240,13 +240,20 @@ __global__ __launch_bounds__(256) void l2_scene_kernel(int S, int T, int K, int 
   const int p0 = scenes[2 * s], p1 = scenes[2 * s + 1];
   for (int k = grp; k < K; k += 8) {
     float acc = 0.f;
-    for (int ped = p0 + l; ped < p1; ped += 32)
-      for (int t = 0; t < T; ++t) {
-        const float2 a = *reinterpret_cast<const float2*>(gen_abs + (((size_t)t * K + k) * b + ped) * 2);
-        const float2 g = *reinterpret_cast<const float2*>(gt + ((size_t)t * b + ped) * 2);
-        const float dx = a.x - g.x, dy = a.y - g.y;
-        acc += sqrtf(dx * dx + dy * dy);
+    auto dist = [&](int t, int ped) {
+      const float2 a = *reinterpret_cast<const float2*>(gen_abs + (((size_t)t * K + k) * b + ped) * 2);
+      const float2 g = *reinterpret_cast<const float2*>(gt + ((size_t)t * b + ped) * 2);
+      const float dx = a.x - g.x, dy = a.y - g.y;
+      return sqrtf(dx * dx + dy * dy);
+    };
+    for (int ped = p0 + l; ped < p1; ped += 32) {  // four steps at a time: eight loads in flight, same summation order
+      int t = 0;
+      for (; t + 3 < T; t += 4) {
+        const float d0 = dist(t, ped), d1 = dist(t + 1, ped), d2 = dist(t + 2, ped), d3 = dist(t + 3, ped);
+        acc += d0; acc += d1; acc += d2; acc += d3;
       }
+      for (; t < T; ++t) acc += dist(t, ped);
+    }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if (l == 0) ksum[k] = acc;
@@ -371,13 +378,20 @@ __global__ __launch_bounds__(256) void pm_ml_kernel(int b, int T, int E, int g, 
     float lp = 0.f;
     if (ok) {
       float acc = 0.f;
-      for (int e = 0; e < E; ++e)
-        for (int t = 0; t < T; ++t) {
-          const float2 a = *reinterpret_cast<const float2*>(gen_abs + ((((size_t)t * E + e) * g + gi) * b + ped) * 2);
-          const float2 y = *reinterpret_cast<const float2*>(gt + ((size_t)t * b + ped) * 2);
-          const float dx = a.x - y.x, dy = a.y - y.y;
-          acc += (-dx * dx * inv2s + cst) + (-dy * dy * inv2s + cst);
+      auto term = [&](int e, int t) {
+        const float2 a = *reinterpret_cast<const float2*>(gen_abs + ((((size_t)t * E + e) * g + gi) * b + ped) * 2);
+        const float2 y = *reinterpret_cast<const float2*>(gt + ((size_t)t * b + ped) * 2);
+        const float dx = a.x - y.x, dy = a.y - y.y;
+        return (-dx * dx * inv2s + cst) + (-dy * dy * inv2s + cst);
+      };
+      for (int e = 0; e < E; ++e) {  // four steps at a time (eight loads in flight), summed in the same order
+        int t = 0;
+        for (; t + 3 < T; t += 4) {
+          const float v0 = term(e, t), v1 = term(e, t + 1), v2 = term(e, t + 2), v3 = term(e, t + 3);
+          acc += v0; acc += v1; acc += v2; acc += v3;
         }
+        for (; t < T; ++t) acc += term(e, t);
+      }
       lp = acc / (float)E;
     }
     __syncthreads();

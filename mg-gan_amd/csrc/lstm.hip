@@ -928,8 +928,20 @@ __global__ void gather_sum_kernel(const float* __restrict__ src, int lds_, const
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)b * ncols) return;
   int ped = (int)(i / ncols), c = (int)(i % ncols);
-  float s = 0.f;
-  for (int k = 0; k < K; ++k) s += src[(size_t)inv[(size_t)k * b + ped] * lds_ + c];
+  // four rows at a time: their indices first, then the four gathers - a one-by-one walk was K times two dependent
+  // round trips (index, then row)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < K; k += 4) {
+    const int i0 = inv[(size_t)k * b + ped], i1 = inv[(size_t)(k + 1) * b + ped], i2 = inv[(size_t)(k + 2) * b + ped],
+              i3 = inv[(size_t)(k + 3) * b + ped];
+    s0 += src[(size_t)i0 * lds_ + c];
+    s1 += src[(size_t)i1 * lds_ + c];
+    s2 += src[(size_t)i2 * lds_ + c];
+    s3 += src[(size_t)i3 * lds_ + c];
+  }
+  for (; k < K; ++k) s0 += src[(size_t)inv[(size_t)k * b + ped] * lds_ + c];
+  const float s = (s0 + s1) + (s2 + s3);
   float* d = dst + (size_t)ped * ldd + c;
   *d = accumulate ? (*d + s) : s;
 }
