@@ -393,6 +393,88 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(SeqBwdArgs p) {
   }
 }
 
+// Matrix-core form of the encoder's BPTT (same arguments and the same dPre layout as lstm_bwd_kernel, which it replaces
+// on the hot path).  A wave owns 16 trajectories x 16 hidden units for all T steps: H = 64 -> four unit blocks of one
+// 16-row tile per workgroup, H = 32 -> two unit blocks of two tiles.  Per step
+//   1. gate gradients dPre of the lane's own four units (VALU; lane (fi, fk) owns units 16 ub + 4 fk + r of row fi,
+//      which is exactly where the D registers of step 2 put dh_{t-1}: the state never leaves the lane)
+//      -> global (R,T,4H) for the weight-gradient GEMM and an LDS tile [row][unit*4 + gate], one 16-byte store per unit
+//   2. barrier; dh_{t-1}^T [units x rows] = W_hh^T [units x 4H] . dPre^T [4H x rows]: A = this wave's 16 columns of W_hh
+//      held in registers for the whole sequence (K index in tile-position order), B = the dPre tile read back as
+//      16-byte rows: 4H / 4 MFMAs per wave and step (exact f32).
+// The lane-per-(row, unit) kernel walked its W_hh column on the VALU (2.4 % of the f32 peak; 209 us for the
+// discriminator's 8,192 x 64 encoder at configs[2], on the discriminator step's critical chain).
+template <int H>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_bwd_mfma_kernel(SeqBwdArgs p) {
+  constexpr int G4 = 4 * H, UB = H / 16, RTILES = 4 / UB, KS = H;  // KS = 4H / 4 MFMA k-steps
+  constexpr int LD = G4 + 20;  // dPre tile row stride: == 20 mod 64 (H = 64: 276, H = 32: 148)
+  __shared__ __attribute__((aligned(16))) float dps[2][RTILES][16 * LD];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  const int ub = w % UB, rtile = w / UB;
+  const int r = (blockIdx.x * RTILES + rtile) * 16 + fi;
+  const bool valid = r < p.R;
+  const int rc = valid ? r : p.R - 1;
+  const int u0 = 16 * ub + 4 * fk;  // this lane's four units u0 .. u0 + 3 (as outputs of the matrix phase and in the gates)
+  // A operand: M row fi = unit 16 ub + fi; k-step ks = 4 S + i covers tile position pp = 16 S + 4 fk + i
+  // (position = unit*4 + gate <-> gate row (pp & 3) * H + (pp >> 2) of W_hh)
+  float Ah[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int pp = 16 * (ks >> 2) + 4 * fk + (ks & 3), m = (pp & 3) * H + (pp >> 2);
+    Ah[ks] = p.W_hh[(size_t)m * H + 16 * ub + fi];
+  }
+  f32x4 dh = *reinterpret_cast<const f32x4*>(p.dhT + (size_t)rc * p.ld_dhT + u0);
+  f32x4 dc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float vm = valid ? 1.f : 0.f;
+  // saved activations of the next step to process, one step ahead (address selected, value masked at use: a select on a
+  // loaded value would make the compiler wait for the loads on the spot)
+  f32x4 n_g[4], n_c, n_cp;
+  auto fetch = [&](int t) {
+    const size_t rt = (size_t)rc * p.T + t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) n_g[q] = *reinterpret_cast<const f32x4*>(p.Gt + rt * G4 + q * H + u0);
+    n_c = *reinterpret_cast<const f32x4*>(p.Cs + rt * H + u0);
+    n_cp = *reinterpret_cast<const f32x4*>(p.Cs + (t > 0 ? rt - 1 : rt) * H + u0);
+  };
+  fetch(p.T - 1);
+  for (int t = p.T - 1; t >= 0; --t) {
+    const size_t rt = (size_t)rc * p.T + t;
+    const f32x4 gi = n_g[0], gf = n_g[1], gg = n_g[2], go = n_g[3], cc = n_c;
+    const float cm = t > 0 ? 1.f : 0.f;
+    const f32x4 cp = n_cp * cm;
+    fetch(t > 0 ? t - 1 : 0);
+    float* tile = dps[t & 1][rtile];
+    f32x4 dq[4];  // [gate][unit]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float tc = mg_tanh(cc[e]);
+      const float dO = dh[e] * tc;
+      const float dcv = fmaf(dh[e] * go[e], 1.f - tc * tc, dc[e]);
+      dq[0][e] = dcv * gg[e] * gi[e] * (1.f - gi[e]) * vm;
+      dq[1][e] = dcv * cp[e] * gf[e] * (1.f - gf[e]) * vm;
+      dq[2][e] = dcv * gi[e] * (1.f - gg[e] * gg[e]) * vm;
+      dq[3][e] = dO * go[e] * (1.f - go[e]) * vm;
+      dc[e] = dcv * gf[e];
+      *reinterpret_cast<f32x4*>(&tile[fi * LD + (u0 + e) * 4]) = f32x4{dq[0][e], dq[1][e], dq[2][e], dq[3][e]};
+    }
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p.dPre + rt * G4 + q * H + u0) = dq[q];
+    }
+    lds_barrier();
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int S = 0; S < KS / 4; ++S) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(&tile[fi * LD + 16 * S + 4 * fk]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = MFMA16(Ah[4 * S + i], b4[i], acc[i]);
+    }
+    dh = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // Decoder rollout, matrix-core form.  A workgroup of four waves owns a tile of 16 rollout rows of one
 // generator for all T steps.  Per step ONE matrix phase with B = h_t (read from a 2 KB LDS tile):
@@ -1013,8 +1095,18 @@ int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, co
   if (b == 0) return MGGAN_OK;
   SeqBwdArgs p = {};
   p.R = b; p.T = T; p.W_hh = W_hh; p.Gt = Gt; p.Cs = Cs; p.dhT = dhT; p.ld_dhT = ld_dhT; p.dPre = dPre;
-  if (H == 32) hipLaunchKernelGGL((lstm_bwd_kernel<32, 0>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((lstm_bwd_kernel<64, 64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
+  static int valu = -1;  // MGGAN_LSTM_VALU=1: the lane-per-(row, unit) VALU kernels (A/B measurements)
+  if (valu < 0) { const char* e = getenv("MGGAN_LSTM_VALU"); valu = e && e[0] == '1'; }
+  const bool vec = (ld_dhT % 4 == 0) && ((size_t)dhT % 16 == 0);  // the matrix-core kernel reads dh_T as 16-byte quads
+  // below ~4k trajectories the 16/32-row tiles leave most CUs without a workgroup (1,280 rows: 40-80 workgroups) and
+  // the lane-per-(row, unit) kernel with its 4/8-row workgroups is as fast or faster (measured at 1,280: 17-23 us either way)
+  if (valu || !vec || b < 4096) {
+    if (H == 32) hipLaunchKernelGGL((lstm_bwd_kernel<32, 0>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((lstm_bwd_kernel<64, 64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
+  } else {
+    if (H == 32) hipLaunchKernelGGL((lstm_bwd_mfma_kernel<32>), dim3(cdiv(b, 32)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((lstm_bwd_mfma_kernel<64>), dim3(cdiv(b, 16)), dim3(256), 0, stream, p);
+  }
   MG_LAUNCH_CHECK("lstm_encoder_bwd");
   return MGGAN_OK;
 }
