@@ -315,3 +315,28 @@ def test_social_attention_tiles_match_the_unfused_launches(H, sizes):
     torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5)
     for a, c in zip(p1, p0):
         torch.testing.assert_close(a, c, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("H,E,b", [(64, 64, 4100), (32, 16, 4133)])
+def test_lstm_encoder_large_batch_matches_torch_f64(H, E, b):
+    """The matrix-core encoder kernels (forward, and BPTT from 4,096 trajectories up) on a ragged row count: output and
+    every parameter gradient against nn.Linear + nn.LSTM evaluated in float64 (common_modules.py:48-66)."""
+    from mggan.model.modules.common_modules import TrajectoryEncoder
+
+    torch.manual_seed(H + b)
+    enc = TrajectoryEncoder(hidden_size=H, embedding_dim=E)
+    ref_emb, ref_lstm = torch.nn.Linear(2, E).double(), torch.nn.LSTM(E, H).double()
+    ref_emb.load_state_dict({k: v.double() for k, v in enc.embedding.state_dict().items()})
+    ref_lstm.load_state_dict({k: v.double() for k, v in enc.encoder.state_dict().items()})
+    enc = enc.to(_dev()).flatten_parameters_()
+    x = torch.randn(7, b, 2) * 0.5
+    cot = torch.randn(b, H)
+    y = enc(x.to(_dev()))
+    (y * cot.to(_dev())).sum().backward()
+    _, (h, _) = ref_lstm(ref_emb(x.double()))
+    (h[0] * cot.double()).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), h[0].detach().float().numpy(), rtol=1e-4, atol=2e-6)
+    got = dict(enc.named_parameters())
+    for name, p in list(ref_emb.named_parameters(prefix="embedding")) + list(ref_lstm.named_parameters(prefix="encoder")):
+        g, r = got[name].grad.detach().cpu().double(), p.grad
+        assert float((g - r).norm() / r.norm()) < 1e-4, name
