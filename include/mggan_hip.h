@@ -303,7 +303,7 @@ int mggan_bce_rows(int rows, int kind, const float* p, float label, const float*
  * A + B + grad_c*C, and the gradients of `total` wrt p and the logits are left in dp / dlogits.  `args` points to
  *   { const float* p; const float* label_u[2]; const int* row_gen; const int* seg; const float* inv_count;
  *     const float* logits; const int* target; float* dp; float* dlogits; float* out[3]; float* total;
- *     double* partial; unsigned* ticket;   (96 doubles of scratch; one word that is zero before the first call)
+ *     double* partial; unsigned* ticket;   (768 doubles of scratch; one word that is zero before the first call)
  *     float label[2], lo[2], hi[2], scale[3], sign_a, grad_c; int nA, nB, nC, g, ld, kind, weighted_c; }
  * label_u[q] != NULL: the smoothed label of term q is lo + (hi-lo)*u drawn on the device; counts per generator come
  * from seg (g+1 offsets of the generator-sorted rows) or from inv_count. */

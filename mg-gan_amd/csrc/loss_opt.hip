@@ -121,7 +121,7 @@ __global__ void ce_rows_kernel(int rows, int g, const float* __restrict__ logits
 // 6-8 dependent few-microsecond kernels on the critical chain.  Up to GAN_LOSS_MAX_WG 1024-thread workgroups take
 // the rows grid-strided and accumulate the per-term sums in double; the last workgroup to finish adds the
 // per-workgroup sums in index order, so the result is deterministic.
-#define GAN_LOSS_MAX_WG 32
+#define GAN_LOSS_MAX_WG 256
 struct GanLossArgs {
   const float* p;         // (nA + nB) discriminator outputs: rows [0,nA) term A, [nA,nA+nB) term B
   const float* label_u[2];  // device uniform draw per term (label = lo + (hi-lo)*u) or NULL -> label[]
@@ -213,12 +213,19 @@ __global__ __launch_bounds__(1024) void gan_losses_kernel(GanLossArgs a) {
     last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
   }
   __syncthreads();
-  if (!last || t != 0) return;
+  if (!last || t >= 64) return;
   __threadfence();
+  // the first wave of the last workgroup: lane l takes the workgroups l, l + 64, ... in index order, then a fixed
+  // shuffle tree (a lone lane walking 3 x gridDim dependent loads was most of this launch at 160k rows)
   double tot[3] = {0.0, 0.0, 0.0};
-  for (unsigned b = 0; b < gridDim.x; ++b)
+  for (unsigned b = t; b < gridDim.x; b += 64)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) tot[q] += ((volatile double*)a.partial)[b * 3 + q];
+    for (int q = 0; q < 3; ++q) tot[q] += __hip_atomic_load(a.partial + b * 3 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) tot[q] += __shfl_xor(tot[q], o, 64);
+  if (t != 0) return;
   const float A = (float)tot[0], B = (float)tot[1], C = (float)tot[2];
   if (a.out[0]) *a.out[0] = A;
   if (a.out[1]) *a.out[1] = B;
@@ -785,7 +792,7 @@ int mggan_gan_losses(const void* args, hipStream_t stream) {
   MG_CHECK_ARG(!a.weighted_c || a.row_gen, "gan_losses: weighted classifier term needs counts");
   int rows = a.nA > a.nB ? a.nA : a.nB;
   if (a.nC > rows) rows = a.nC;
-  int wgs = cdiv(rows, 2048);  // two rows of every term per thread
+  int wgs = cdiv(rows, 1024);  // one row of every term per thread up to 262,144 rows
   wgs = wgs < 1 ? 1 : (wgs > GAN_LOSS_MAX_WG ? GAN_LOSS_MAX_WG : wgs);
   hipLaunchKernelGGL(gan_losses_kernel, dim3(wgs), dim3(1024), 0, stream, a);
   MG_LAUNCH_CHECK("gan_losses");

@@ -1713,7 +1713,7 @@ class _GanLossArgs(ctypes.Structure):  # mirrors csrc/loss_opt.hip:GanLossArgs
 _LOSS_SCRATCH = {}
 
 
-def _loss_scratch(kind="gan", doubles=96):
+def _loss_scratch(kind="gan", doubles=768):
     """Per-device scratch of a loss kernel: (partial sums, one ticket word the kernel always leaves at zero).
     The loss launches of an iteration are ordered on the main stream, so one scratch per kind is enough - and keying it
     by stream would allocate (and zero-fill, two ATen launches) again inside a graph capture, whose stream is new."""
