@@ -617,8 +617,15 @@ __global__ __launch_bounds__(64) void bucket_scan_kernel(int nblk, int g, int* b
   __shared__ int tot[BR_MAXG];
   const int q = threadIdx.x;
   if (q < g) {
-    int run = 0;
-    for (int i = 0; i < nblk; ++i) { const int c = blk_cnt[i * BR_MAXG + q]; blk_cnt[i * BR_MAXG + q] = run; run += c; }
+    int run = 0, i = 0;
+    for (; i + 7 < nblk; i += 8) {  // eight counts in flight, then their running offsets (160 blocks at 163,840 rows)
+      int c[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) c[e] = blk_cnt[(i + e) * BR_MAXG + q];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { blk_cnt[(i + e) * BR_MAXG + q] = run; run += c[e]; }
+    }
+    for (; i < nblk; ++i) { const int c = blk_cnt[i * BR_MAXG + q]; blk_cnt[i * BR_MAXG + q] = run; run += c; }
     tot[q] = run;
   }
   __syncthreads();
@@ -717,23 +724,25 @@ __global__ __launch_bounds__(BR_BLOCK) void bucket_small_kernel(const long long*
 }
 
 // Categorical(logits).sample((K,)).T by inverse CDF from caller-provided uniforms u (b,K) in [0,1):
-// one lane per pedestrian (standard.py:217-225 on the device, no host round trip)
+// one lane per (pedestrian, sample) (standard.py:217-225 on the device, no host round trip).  Every lane rebuilds its
+// pedestrian's g-entry CDF (the row is an L1 hit) - a lane per pedestrian walking its K samples was K dependent
+// strided round trips (61 us at 8,192 x 20).  Same arithmetic per sample, same picks.
 __global__ void sample_categorical_kernel(int b, int K, int g, const float* __restrict__ logits,
                                           const float* __restrict__ u, long long* idx) {
-  const int ped = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ped >= b) return;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)b * K) return;
+  const int ped = (int)(i / K);
+  const float* l = logits + (size_t)ped * g;
   float cdf[BR_MAXG];
   float mx = -INFINITY;
-  for (int i = 0; i < g; ++i) mx = fmaxf(mx, logits[(size_t)ped * g + i]);
+  for (int c = 0; c < g; ++c) mx = fmaxf(mx, l[c]);
   float run = 0.f;
-  for (int i = 0; i < g; ++i) { run += __expf(logits[(size_t)ped * g + i] - mx); cdf[i] = run; }
-  for (int k = 0; k < K; ++k) {
-    const float x = u[(size_t)ped * K + k] * run;
-    int pick = g - 1;
-    for (int i = g - 2; i >= 0; --i)
-      if (x < cdf[i]) pick = i;
-    idx[(size_t)ped * K + k] = pick;
-  }
+  for (int c = 0; c < g; ++c) { run += __expf(l[c] - mx); cdf[c] = run; }
+  const float x = u[i] * run;
+  int pick = g - 1;
+  for (int c = g - 2; c >= 0; --c)
+    if (x < cdf[c]) pick = c;
+  idx[i] = pick;
 }
 
 extern "C" {
@@ -742,7 +751,7 @@ int mggan_sample_categorical(int b, int K, int g, const float* logits, const flo
                              hipStream_t stream) {
   if (b == 0) return MGGAN_OK;
   MG_CHECK_ARG(logits && u && idx && g >= 1 && g <= BR_MAXG, "sample_categorical: bad arguments (num_gens <= 16)");
-  hipLaunchKernelGGL(sample_categorical_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, K, g, logits, u, idx);
+  hipLaunchKernelGGL(sample_categorical_kernel, dim3(cdiv((long)b * K, 256)), dim3(256), 0, stream, b, K, g, logits, u, idx);
   MG_LAUNCH_CHECK("sample_categorical");
   return MGGAN_OK;
 }
