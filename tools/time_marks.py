@@ -19,7 +19,25 @@ from mggan.data_utils import synthetic  # noqa: E402
 from mggan.hip import functions as HF  # noqa: E402
 
 
+def mark_every_backward_node():
+    """MGGAN_MARKS_NODES=1: one more mark behind every autograd node's backward (on the stream it ran on)."""
+    import inspect
+
+    for name, cls in list(vars(HF).items()):
+        if inspect.isclass(cls) and issubclass(cls, torch.autograd.Function) and cls is not torch.autograd.Function:
+            inner = cls.backward
+
+            def wrapped(ctx, *g, _inner=inner, _name=name):
+                out = _inner(ctx, *g)
+                HF.mark("node." + _name)
+                return out
+
+            cls.backward = staticmethod(wrapped)
+
+
 def main(scenes=64, peds=20, num_gens=4):
+    if os.environ.get("MGGAN_MARKS_NODES") == "1":
+        mark_every_backward_node()
     dev = torch.device("cuda", 0)
     tr = bench.build_trainer(num_gens, "device", dev)
     batch = tr.to_device(synthetic.make_batch(synthetic.scene_sizes(scenes, peds), seed=0))
