@@ -418,10 +418,15 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
 // Same staging as conv2_bwd_kernel; both GEMM-shaped parts run on exact-f32 MFMA (16x16x4):
 //   weight grad  dW[co][(tap,ci)] += sum_pos dy[co][pos] * a1[ci][pos+tap]   M=co(16), N=(tap,ci)(9 tiles), K=pos
 //   input grad   da1[pos][ci]      = sum_{tap,co} dy[co][pos+tap'] * Wflip   M=pos (16 rows of 16), N=ci, K=(tap,co)
-// LDS planes are 361 floats apart (== 9 mod 32): a 16-lane fragment read that walks channels hits 16
-// distinct banks.  Wave w owns image rows 4w..4w+3 in both products; the wave-private weight-grad
+// LDS: ds_read_b32 serves 32 lanes per pass over 32 banks, i.e. two values of fk at a time.  Planes are 386 floats
+// apart (== 2 mod 32): a fragment read that walks the 16 channels (fi) at two adjacent positions (fk) hits banks
+// 2 fi + fk, all 32 distinct; the reads that walk 16 adjacent positions (fi) of two planes take planes EIGHT apart
+// (8 * 386 == 16 mod 32) - the reduction index of the input-gradient product is ordered co = c + 8 (fk & 1) +
+// 4 (fk >> 1) for that, on both operands - and the flipped weights have row stride 18 (8 * 18 == 16 mod 32).  With
+// 361 (== 9 mod 32, chosen for 16-lane passes) half of this kernel's LDS cycles were bank conflicts.  Wave w owns image rows 4w..4w+3 in both products; the wave-private weight-grad
 // accumulators persist over the workgroup's images and meet in LDS once at the end.
-#define C2_PLANE 361
+#define C2_PLANE 386
+#define C2_WLD 18  // row stride of the flipped weights [tap'][co][ci]
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float* __restrict__ xsel,
@@ -438,14 +443,14 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
   float* a1p = dyp + C * C2_PLANE;         // same layout
   float* y1r = a1p + C * C2_PLANE;         // [C][256] raw conv1 value at the pooling argmax
   float* wf = y1r + C * 256;               // [tap'][co][ci] = W[co][ci][8 - tap'] (flipped kernel), 2304
-  float* red = wf + 9 * C * C;             // [4][32] cross-wave statistics
+  float* red = wf + 9 * C * C2_WLD;        // [4][32] cross-wave statistics
   __shared__ double colsum[32], cred[8 * 32];
   __shared__ int flag;
   double dstat = 0.0;                      // threads 0..31: this workgroup's sum g (0..15) / sum g*xhat (16..31)
   for (int i = threadIdx.x; i < 2 * C * C2_PLANE; i += 256) dyp[i] = 0.f;  // dyp and a1p (halos stay zero)
   for (int i = threadIdx.x; i < 9 * C * C; i += 256) {
     const int tp = i / (C * C), co = (i / C) % C, ci = i % C;
-    wf[i] = W[(co * C + ci) * 9 + (8 - tp)];
+    wf[(tp * C + co) * C2_WLD + ci] = W[(co * C + ci) * 9 + (8 - tp)];
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
   f32x4_t wacc[9];
@@ -492,10 +497,10 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
       for (int tp = 0; tp < 9; ++tp) {
 #pragma unroll
         for (int c4 = 0; c4 < C; c4 += 4) {
-          const int co = c4 + fk;
+          const int co = (c4 >> 2) + 8 * (fk & 1) + 4 * (fk >> 1);
           // A[i = x][k = (tp, co)] = dy[co] at padded (y + tp/3, x + tp%3);  B[k][j = ci] = wf[tp][co][ci]
           const float a = dyp[co * C2_PLANE + (y + tp / 3) * A1_LD + fi + tp % 3];
-          const float bv = wf[(tp * C + co) * C + fi];
+          const float bv = wf[(tp * C + co) * C2_WLD + fi];
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
         }
       }
@@ -660,7 +665,7 @@ int mggan_conv2_bwd(const float* xsel, int B, int C, const float* scale1,
   }
   const BnBwdFin fin = make_bfin(ticket, count1, gamma1, stat1, coef1, coefd1, dgamma1, dbeta1);
   if (C == 16) {
-    const size_t lds = (size_t)(2 * 16 * C2_PLANE + 16 * 256 + 9 * 256 + 128) * sizeof(float);
+    const size_t lds = (size_t)(2 * 16 * C2_PLANE + 16 * 256 + 9 * 16 * C2_WLD + 128) * sizeof(float);
     static bool attr = false;
     if (!attr) {
       if (hipFuncSetAttribute((const void*)conv2_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=

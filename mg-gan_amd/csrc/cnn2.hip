@@ -304,7 +304,10 @@ __global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __r
   __shared__ int flag;
   for (int i = threadIdx.x; i < C * A1_PLANE; i += 256) a1p[i] = 0.f;
   const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pg = threadIdx.x & 63;
-  const int py = pg >> 2, x0 = (pg & 3) * 4;
+  // lane -> (row py, column quad x0): the 16 lanes of a ds_read_b128 phase are 16 ROWS of one quad - row stride 20 puts
+  // them on sixteen distinct 4-bank groups (20 py mod 64); four rows x four quads per phase (the first version) wrapped the
+  // fourth row onto the first: 2-way conflicts on every read, 64 % of the LDS cycles of this kernel at 8,192 images
+  const int py = pg & 15, x0 = (pg >> 4) * 4;
   double dsum[COT], dsq[COT];
 #pragma unroll
   for (int co = 0; co < COT; ++co) dsum[co] = dsq[co] = 0.0;
