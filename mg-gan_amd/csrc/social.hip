@@ -352,7 +352,11 @@ __global__ __launch_bounds__(256) void social_bwd_fused_kernel(
     const float* __restrict__ h, int ld_h, const float* __restrict__ dS, int ld_ds, const float* __restrict__ vc,
     const float* __restrict__ l1s, const float* __restrict__ l2s, const float* __restrict__ W2, float* dsigma,
     float* dz2, float* dz1) {
-  __shared__ float part[4][L1][64];
+  // 84 % of this kernel's wave time is spent parked on memory: its duration is (workgroups / resident workgroups) x
+  // one workgroup's chain of dependent round trips.  The four partial W2^T dz2 vectors are therefore folded in two halves
+  // of 16 layer-1 units through a 16 KB buffer (one more barrier) instead of all 32 through 32 KB: eight resident
+  // workgroups per CU instead of four.
+  __shared__ float part[4][L1 / 2][64];
   __shared__ float dpart[4][64];
   __shared__ float ad_s[64];
   const int4 tl = tiles[blockIdx.x];
@@ -398,13 +402,17 @@ __global__ __launch_bounds__(256) void social_bwd_fused_kernel(
     for (int k = 0; k < L1; ++k) d1[k] = fmaf(W2[m * L1 + k], z, d1[k]);
   }
 #pragma unroll
-  for (int k = 0; k < L1; ++k) part[w][k][lane] = d1[k];
-  __syncthreads();
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();  // every wave has read the first half
 #pragma unroll
-  for (int kk = 0; kk < L1 / 4; ++kk) {
-    const int k = w * (L1 / 4) + kk;
-    const float t = (part[0][k][lane] + part[1][k][lane]) + (part[2][k][lane] + part[3][k][lane]);
-    if (ok) dz1[(size_t)k * P + p] = l1s[(size_t)k * P + p] > 0.f ? t : 0.f;
+    for (int k = 0; k < L1 / 2; ++k) part[w][k][lane] = d1[half * (L1 / 2) + k];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < L1 / 8; ++kk) {
+      const int kl = w * (L1 / 8) + kk, k = half * (L1 / 2) + kl;
+      const float t = (part[0][kl][lane] + part[1][kl][lane]) + (part[2][kl][lane] + part[3][kl][lane]);
+      if (ok) dz1[(size_t)k * P + p] = l1s[(size_t)k * P + p] > 0.f ? t : 0.f;
+    }
   }
 }
 
