@@ -64,6 +64,35 @@ def test_device_categorical_sampler_statistics():
     assert float((freq.cpu() - ref.cpu()).abs().max()) < 0.01
 
 
+@pytest.mark.parametrize("b,K,g", [(1280, 20, 4), (8192, 20, 8), (37, 1, 16), (5, 3, 1)])
+def test_device_categorical_sampler_is_the_inverse_cdf(b, K, g):
+    """mggan_sample_categorical (one lane per (pedestrian, sample)) against the inverse CDF evaluated in float64 on the
+    host: the same pick for every uniform that is not within rounding distance of a CDF step."""
+    import ctypes
+
+    import numpy as np
+
+    from mggan.hip import lib
+
+    gen = torch.Generator().manual_seed(b + K + g)
+    logits = torch.randn(b, g, generator=gen) * 2
+    u = torch.rand(b, K, generator=gen)
+    idx = torch.empty(b, K, dtype=torch.int64, device="cuda")
+    ld, ud = logits.cuda(), u.cuda()
+    lib.mggan_sample_categorical(b, K, g, ld.data_ptr(), ud.data_ptr(), idx.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+    e = np.exp(logits.double().numpy() - logits.double().numpy().max(1, keepdims=True))
+    cdf = np.cumsum(e, 1)
+    x = u.double().numpy() * cdf[:, -1:]
+    ref = np.minimum((x[:, :, None] >= cdf[:, None, :]).sum(2), g - 1)
+    margin = np.abs(x[:, :, None] - cdf[:, None, :]).min(2) / cdf[:, -1:]
+    got = idx.cpu().numpy()
+    clear = margin > 1e-5
+    assert clear.mean() > 0.99
+    np.testing.assert_array_equal(got[clear], ref[clear])
+    assert got.min() >= 0 and got.max() <= g - 1
+
+
 def test_branch_streams_and_graph_replay_are_bit_identical():
     """No races, no order-dependent arithmetic: after several iterations the weights are bit-identical whether the
     step graph runs on one stream, on the branch streams, or as a replayed HIP graph (same seeds)."""
