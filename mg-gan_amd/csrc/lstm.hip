@@ -736,13 +736,13 @@ struct DecFusedArgs {
 //        [ W_hh^T (own 8 units) ; A^T ] . dPre^T  ->  dh_{t-1} of the own units and d(dxdy_t)       (32 MFMAs)
 //      (M rows 4 fk + {0,1} = the lane's two units, rows 4 fk + {2,3} = the two input components: every lane
 //      gets the complete sums in its D registers, no partial exchange)
-//   4. weight gradients with K = the 16 tile rows: [dW_hh | dA | dbias] += dPre^T [h_{t-1} | dxdy | 1]
-//      (wave w: position tiles 2w, 2w+1 x three column tiles, 24 MFMAs), dW1[:, :H] += du^T h_t (2 MFMAs)
+//   4. weight gradients with K = the 16 tile rows: dW_hh += dPre^T h_{t-1} (wave w: position tiles 2w, 2w+1 x two
+//      column tiles, 16 MFMAs), dW1[:, :H] += du^T h_t (2 MFMAs); dA / dbias = dPre^T [dxdy | 1] are lane-local sums
 // The LDS tiles are multi-buffered over t so that the single barrier per step is enough.
 #define DB_RS 148  // dPre tile row stride == 20 mod 64: the 16-byte row accesses of a 16-lane group land on banks 20 fi (+0..3),
                    // sixteen distinct 4-bank groups, and the transposed 4-byte reads of the weight-gradient phase (lane =
                    // (position fi, row 4 ks + fk)) start 20 banks apart per fk - 2-way on 12 banks (stride 132: 4-way)
-#define DB_HS 48   // h tile row stride (== 16 mod 32: conflict-free transposed reads); cols 32,33 = dxdy, 34 = 1
+#define DB_HS 48   // h tile row stride (== 16 mod 32: conflict-free transposed reads)
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void decoder_bwd_mfma_kernel(DecFusedArgs p) {
   constexpr int H = 32, Hh = 16, S = 32;
@@ -784,17 +784,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float* w1s = tailw + H * p.e2ld;
   for (int i = threadIdx.x; i < H * p.EIN; i += 256) e2s[(i / p.EIN) * p.e2ld + i % p.EIN] = p.We2d[(size_t)(i / p.EIN) * IN + i % p.EIN];
   for (int i = threadIdx.x; i < Hh * S; i += 256) w1s[(i / S) * 36 + i % S] = W1[(size_t)(i / S) * (H + S) + H + i % S];
-  // constant part of the h tiles: column 34 = 1 (bias), 35..47 = 0
-  for (int i = threadIdx.x; i < 3 * 16 * 16; i += 256) {
-    const int bsel = i / 256, row = (i / 16) % 16, col = i % 16;
-    hts[bsel][row * DB_HS + H + col] = col == 2 ? 1.f : 0.f;
-  }
-
-  f32x4 accW[2][3], accU = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accW[2][2], accU = f32x4{0.f, 0.f, 0.f, 0.f};
+  // dA (4H x 2) and dbias (4H) = dPre^T [dxdy | 1]: lane-local sums over the lane's own (unit, gate) entries and its tile
+  // row, folded over the 16 rows once at the end.  As a third 16-column tile of the matrix product (13 of its 16 columns
+  // padding) they cost 8 of the 62 MFMAs of a step.
+  float accA0[2][4], accA1[2][4], accBs[2][4];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) accW[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q) accA0[a][q] = accA1[a][q] = accBs[a][q] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) accW[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   float accW2[2][4], accb1[4], accb2[2] = {0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < 4; ++q) accW2[0][q] = accW2[1][q] = accb1[q] = 0.f;
@@ -864,7 +866,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       accb2[0] += g0; accb2[1] += g1;
       if (w == 0) {
         *reinterpret_cast<f32x4*>(&duw[fi * Hh + 4 * fk]) = du;
-        if (fk == 0) *reinterpret_cast<float2*>(&htw[fi * DB_HS + H]) = c_din;
       }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) htw[fi * DB_HS + uj[mt]] = c_ch[mt].y;
@@ -890,6 +891,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         dc[mt] = dcv * gf;
         cc[mt] = cprev;
         *reinterpret_cast<f32x4*>(&dpw[fi * DB_RS + uj[mt] * 4]) = dp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          accA0[mt][q] = fmaf(dp[q], c_din.x, accA0[mt][q]);
+          accA1[mt][q] = fmaf(dp[q], c_din.y, accA1[mt][q]);
+          accBs[mt][q] += dp[q];
+        }
       }
       lds_barrier();
       // [dh_{t-1} (own units) ; d dxdy_t] = [W_hh^T ; A^T] dPre^T, K = 128 gate rows in tile-position order
@@ -906,15 +913,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // took exactly as long: the two workgroups of a CU already fill each other's gaps.)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        float a[2], bv[3];
+        float a[2], bv[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i] = dpw[(4 * ks + fk) * DB_RS + 16 * (2 * w + i) + fi];
 #pragma unroll
-        for (int n = 0; n < 3; ++n) bv[n] = htw[(4 * ks + fk) * DB_HS + 16 * n + fi];
+        for (int n = 0; n < 2; ++n) bv[n] = htw[(4 * ks + fk) * DB_HS + 16 * n + fi];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int n = 0; n < 3; ++n) accW[i][n] = MFMA16(a[i], bv[n], accW[i][n]);
+          for (int n = 0; n < 2; ++n) accW[i][n] = MFMA16(a[i], bv[n], accW[i][n]);
       }
       {  // dW1[:, :H] += du^T h_t : wave w -> column tile (w & 1), K half (w >> 1)
         const int nt = w & 1, kh = w >> 1;
@@ -972,8 +979,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int pp = 16 * (2 * w + i) + 4 * fk + q, m = (pp & 3) * H + (pp >> 2);
       wp[m * H + fi] = accW[i][0][q];
       wp[m * H + 16 + fi] = accW[i][1][q];
-      if (fi < 2) wp[DF_OFF_A + m * 2 + fi] = accW[i][2][q];
-      else if (fi == 2) wp[DF_OFF_B + m] = accW[i][2][q];
+    }
+  // dA / dbias: fold the 16 tile rows (lanes fi of a fixed fk) in a fixed tree; lane fi == 0 stores
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v0 = accA0[mt][q], v1 = accA1[mt][q], v2 = accBs[mt][q];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        v0 += __shfl_xor(v0, o, 64);
+        v1 += __shfl_xor(v1, o, 64);
+        v2 += __shfl_xor(v2, o, 64);
+      }
+      if (fi == 0) {
+        const int m = q * H + uj[mt];
+        wp[DF_OFF_A + m * 2] = v0;
+        wp[DF_OFF_A + m * 2 + 1] = v1;
+        wp[DF_OFF_B + m] = v2;
+      }
     }
   lds_barrier();
   // W1h: column tile (w & 1) is shared by waves w and w ^ 2 (K halves): sum them through LDS
