@@ -218,14 +218,19 @@ def _load_json(name):
     return {}
 
 
-def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, graph=True, rng=None):
+def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, graph=True, rng=None, transport=None):
     """Build a trainer for one workload, time exactly args.steps iterations between barriers, then (profile) time
-    every C-ABI entry with HIP events over three eager iterations.  -> dict (rank 0 keeps it)."""
+    every C-ABI entry with HIP events over three eager iterations.  -> dict (rank 0 keeps it).
+    transport (sharded runs): None = the default (peer-mapped all-reduce kernels inside the one graph when every rank
+    could map its peers, else RCCL between graph segments), "rccl" = torch.distributed (backend nccl == RCCL) collectives
+    between graph segments, "peer-mapped" = the kernels of csrc/comm.hip."""
     import torch.distributed as dist
     from mggan.data_utils import synthetic
     from mggan.hip.lib import start_trace, stop_trace
 
     rng = rng or args.rng
+    if transport is not None:  # read by mggan.devcomm.create when the trainer attaches its DistContext
+        os.environ["MGGAN_DEVICE_COMM"] = "0" if transport == "rccl" else "1"
     tr = build_trainer(num_gens, rng, dev, seed=rank)
     tr.dist.equal_shards = True  # every rank holds the same number of scenes/pedestrians
     sizes = synthetic.scene_sizes(scenes, peds)
@@ -282,11 +287,12 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
         if float(v.item()) < 0.5:
             print("[bench] rank {}: peer-mapped all-reduce rejected; re-measuring with torch.distributed collectives".format(
                 rank), file=sys.stderr)
-            os.environ["MGGAN_DEVICE_COMM"] = "0"
             tr.dist.close()
             del tr, replay
             torch.cuda.empty_cache()
-            return measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile, graph, rng)
+            res = measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile, graph, rng, transport="rccl")
+            res["collective_note"] = "peer-mapped all-reduce rejected by the post-warm-up check; fell back to RCCL"
+            return res
     t0 = time.perf_counter()
     for i in range(args.steps):
         run_step(i == args.steps - 1)  # logged losses are fetched once (one D2H) inside the timed region
@@ -304,6 +310,8 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
            "b_per_gpu": b, "ms_per_step": round(dt / args.steps * 1e3, 4),
            "value": round(world * b * args.steps / dt, 2), "unit": "trajectories/s", "rng": rng, "launch": launch,
            "bn_sync": tr.config.bn_sync,
+           "collective": (None if not sharded else "peer-mapped" if tr.dist.devcomm is not None else
+                          "rccl-segments" if use_graph else "rccl-eager"),
            "last_losses": {k: round(v[-1], 6) for k, v in sorted(metrics.items()) if "probs" not in k}}
     if sharded and tr.dist.devcomm is not None:
         tr.dist.devcomm.check()  # a timed-out wait inside a peer-mapped all-reduce would have flagged the arena
@@ -385,6 +393,28 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
     return res
 
 
+def self_launch(n):
+    """Re-exec this command line as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py ...`
+    (rendezvous on 127.0.0.1, a free port).  -> exit code of the job."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    # (MGGAN_DIST_BACKEND=gloo: ranks may share a GPU -- the functional check of this path on a one-GPU box)
+    if have < n and not (have >= 1 and os.environ.get("MGGAN_DIST_BACKEND") == "gloo"):
+        print("[bench] --gpus {} asked for, {} HIP device(s) visible".format(n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -401,6 +431,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-floor", action="store_true", help="skip the C1-shaped eager / host-RNG / graph floor timings")
     ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--no-transport-ab", action="store_true", help="N>1: skip the second pass on the other collective transport")
     args = ap.parse_args()
     if args.config == "c4":
         args.config = "c3"
@@ -414,6 +445,10 @@ def main():
             args.config = "custom"
         args.also = ""
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("MGGAN_FORCE_DIST", "0") != "1":
+        # `python bench.py --gpus N` on its own: start N ranks (one per GPU) of this very command under
+        # torch.distributed.run and hand its output (the one JSON line of rank 0) through
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -449,10 +484,25 @@ def main():
     for tag in [t for t in args.also.split(",") if t and t != args.config]:
         c = CONFIGS[tag]
         others.append(measure(tag, c["scenes"], c["peds"], c["num_gens"], args, world, rank, dev))
+    transports = None
+    if world > 1 and not args.no_transport_ab:
+        # the same workloads on the other transport (north_star names RCCL; the default keeps the iteration ONE graph
+        # with the exchange points as peer-mapped kernels): both numbers in the line, same timing protocol
+        other = "rccl" if head.get("collective") == "peer-mapped" else "peer-mapped"
+        transports = []
+        for tag in [args.config] + [t for t in args.also.split(",") if t and t != args.config]:
+            c = CONFIGS[tag]
+            alt = measure(tag, c["scenes"], c["peds"], c["num_gens"], args, world, rank, dev, profile=False, transport=other)
+            base = head if tag == args.config else [o for o in others if o["config"] == tag][0]
+            transports.append({"config": tag, base["collective"]: {"ms_per_step": base["ms_per_step"], "value": base["value"],
+                                                                    "launch": base["launch"]},
+                               alt["collective"]: {"ms_per_step": alt["ms_per_step"], "value": alt["value"],
+                                                   "launch": alt["launch"]}})
+        os.environ.pop("MGGAN_DEVICE_COMM", None)
 
     out = None
     if rank == 0:
-        keep = ("config", "workload", "b_per_gpu", "ms_per_step", "value", "unit", "launch", "roofline",
+        keep = ("config", "workload", "b_per_gpu", "ms_per_step", "value", "unit", "launch", "collective", "roofline",
                 "roofline_top_kernels", "iteration_flops_algorithmic_g", "iteration_tflops", "iteration_frac_of_f32_peak",
                 "launches_per_step", "breakdown")
         out = {
@@ -461,7 +511,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": head["workload"], "b_per_gpu": head["b_per_gpu"], "parallelism": "dp{}".format(world),
                        "rng": head["rng"], "bn_sync": head["bn_sync"], "launch": head["launch"],
-                       "last_losses": head["last_losses"]},
+                       "collective": head.get("collective"), "last_losses": head["last_losses"]},
             "roofline": head["roofline"], "roofline_top_kernels": head["roofline_top_kernels"],
             "iteration_flops_algorithmic_g": head["iteration_flops_algorithmic_g"],
             "iteration_tflops": head["iteration_tflops"],
@@ -471,6 +521,8 @@ def main():
             # every measured workload, the headline first (same timing protocol: warmup, barrier, K steps, barrier)
             "configs": [{k: r[k] for k in keep if k in r} for r in [head] + others],
         }
+        if transports is not None:
+            out["collective_transports"] = transports
     if world == 1 and os.environ.get("MGGAN_FORCE_DIST", "0") != "1" and not args.no_floor:
         # what a user of train() gets on ragged ETH-shaped batches (configs[0] shape): the graph floor, eager launches
         # with the device RNG, and eager launches with the seed-comparable host RNG (one D2H + host multinomial per G call)

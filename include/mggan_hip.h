@@ -263,8 +263,10 @@ int mggan_dheads_bwd_data(const float* dYa, const float* dYb, const float* Ya, c
  * (mggan_comm_arena_bytes(max_elems), max_elems counted in 8-byte elements), exports it with mggan_comm_ipc_handle
  * (64-byte handle) and maps its peers' with mggan_comm_ipc_open.  mggan_comm_allreduce sums `n` elements of `data`
  * (dtype 0 f32, 1 f64, 2 i32) over the ranks IN PLACE, adding the ranks' contributions in rank order (bit-identical on
- * every rank).  All ranks must issue the same collectives in the same order on a channel.  A wait that exceeds 2 s sets
- * the arena's error word (mggan_comm_error) instead of hanging. */
+ * every rank).  All ranks must issue the same collectives in the same order on a channel.  A wait that exceeds the bound
+ * (mggan_comm_set_timeout, 30 s by default) sets the arena's error word (mggan_comm_error) and the process's host-mapped
+ * error word (mggan_comm_host_error: a host pointer, readable without a device sync) instead of hanging, and the
+ * collective leaves NaN (INT_MIN for i32) in `data` -- never a sum over stale slots. */
 size_t mggan_comm_arena_bytes(long max_elems);
 int mggan_comm_alloc(size_t bytes, void** out);
 int mggan_comm_free(void* p);
@@ -274,6 +276,8 @@ int mggan_comm_ipc_close(void* p);
 int mggan_comm_allreduce(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
                          mggan_stream_t stream);
 int mggan_comm_error(const void* arena, unsigned int* out);
+int mggan_comm_set_timeout(double seconds);
+int mggan_comm_host_error(unsigned int** out);
 /* Sharded scene CNN: one launch per BatchNorm exchange point -- fold this rank's partial rows, all-reduce the 2C sums
  * and the element count over the ranks (peer-mapped arenas of the calling stream's channel), finalize with the global
  * statistics (forward: scale / shift / stat / running statistics; backward: coef / coefd, dgamma / dbeta += this rank's

@@ -8,8 +8,10 @@
 // every arena with the collective's sequence number, (c) waits until all W flags of chunk k in its OWN arena carry that
 // number, (d) adds the W slots in rank order -- every rank computes bit-identical sums, replicas cannot drift.
 // Two buffers alternate by sequence parity: a rank can only start collective s+2 after it finished s+1, which needed
-// every peer's flag of s+1, which a peer stamps only after it finished reading s.  Waits are bounded (wall clock):
-// a lost peer sets the arena's error word instead of hanging the GPU.
+// every peer's flag of s+1, which a peer stamps only after it finished reading s.  Waits are bounded (wall clock,
+// mggan_comm_set_timeout, 30 s by default): a lost peer sets the arena's error word and a host-mapped word
+// (mggan_comm_host_error: readable without a device sync) instead of hanging the GPU, and the collective then leaves NaN
+// (INT_MIN) behind -- never a sum over stale slots.
 // No reference counterpart (the reference is single-process); replaces torch.distributed.all_reduce on this path.
 #include <string.h>
 #include "common.h"
@@ -17,8 +19,14 @@
 
 #include "comm_dev.h"
 
+static long long g_timeout_ticks = (long long)(COMM_TIMEOUT_DEFAULT_S * COMM_TICKS_PER_S);
+static unsigned* g_host_error = nullptr;
+long long comm_timeout_ticks() { return g_timeout_ticks; }
+unsigned* comm_host_error() { return g_host_error; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommArgs a) {
+  __shared__ int lost_s;
   char* mine = (char*)a.arena[a.rank];
   CommHeader* hdr = (CommHeader*)mine;
   const unsigned seq = __hip_atomic_load(&hdr->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -31,6 +39,7 @@ __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommArgs a) {
     T* dst = (T*)((char*)a.arena[j] + doff + ((size_t)buf * COMM_MAX_RANKS + r) * slot_bytes) + e0;
     for (long i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
   }
+  if (threadIdx.x == 0) lost_s = 0;
   __threadfence_system();
   __syncthreads();
   // (b) stamp, (c) wait
@@ -38,25 +47,18 @@ __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommArgs a) {
     unsigned* pf = (unsigned*)((char*)a.arena[threadIdx.x] + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + r) * a.max_blocks + k;
     __hip_atomic_store(pf, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     unsigned* wf = (unsigned*)(mine + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + threadIdx.x) * a.max_blocks + k;
-    const long long t0 = wall_clock64();
-    // (an arena that has timed out once gives up at once from then on: a broken link costs 2 s, not 2 s per collective)
-    const bool dead = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-    while (__hip_atomic_load(wf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      __builtin_amdgcn_s_sleep(2);
-      if (dead || wall_clock64() - t0 > COMM_TIMEOUT_TICKS) {
-        __hip_atomic_store(&hdr->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
+    if (!comm_wait_flag(wf, seq, hdr, a)) lost_s = 1;
   }
   __syncthreads();
-  // (d) fixed-order sum of the W slots of my own arena
+  // (d) fixed-order sum of the W slots of my own arena -- or, when a peer never arrived, poison: a failed exchange must
+  // be visible in the weights (NaN), not look like a gradient
+  const bool lost = lost_s != 0;
   const T* base = (const T*)(mine + doff + (size_t)buf * COMM_MAX_RANKS * slot_bytes) + e0;
   const size_t stride = slot_bytes / sizeof(T);
   for (long i = threadIdx.x; i < cnt; i += 256) {
     T s = __builtin_nontemporal_load(base + i);
     for (int j = 1; j < W; ++j) s += __builtin_nontemporal_load(base + (size_t)j * stride + i);
-    src[i] = s;
+    src[i] = lost ? comm_poison<T>() : s;
   }
   // the last workgroup closes the collective
   __syncthreads();
@@ -141,11 +143,37 @@ int mggan_comm_allreduce(void* const* arenas, int rank, int world, long max_elem
   for (int j = 0; j < COMM_MAX_RANKS; ++j) a.arena[j] = j < world ? arenas[j] : nullptr;
   a.data = data; a.n = n; a.max_elems = max_elems; a.rank = rank; a.world = world;
   a.max_blocks = cdiv(max_elems * 2, COMM_CHUNK); a.dtype = dtype;
+  a.timeout_ticks = g_timeout_ticks; a.host_error = g_host_error;
   const int grid = cdiv(n, COMM_CHUNK);
   if (dtype == 0) hipLaunchKernelGGL(comm_allreduce_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
   else if (dtype == 1) hipLaunchKernelGGL(comm_allreduce_kernel<double>, dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(comm_allreduce_kernel<int>, dim3(grid), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("comm_allreduce");
+  return MGGAN_OK;
+}
+
+/* bound of every wait inside a collective, in seconds (> 0); applies to launches and captures made afterwards */
+int mggan_comm_set_timeout(double seconds) {
+  MG_CHECK_ARG(seconds > 0.0 && seconds < 1e6, "comm_set_timeout: %g s", seconds);
+  g_timeout_ticks = (long long)(seconds * COMM_TICKS_PER_S);
+  return MGGAN_OK;
+}
+
+/* One host-mapped error word per process, set by any collective whose wait timed out: *out is a HOST pointer the
+   caller may read at any time without synchronising the device (allocated on first use; reset = store 0). */
+int mggan_comm_host_error(unsigned int** out) {
+  MG_CHECK_ARG(out, "comm_host_error: null pointer");
+  if (!g_host_error) {
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) {
+      mggan_set_error("comm_host_error: hipHostMalloc failed: %s", hipGetErrorString(e));
+      return MGGAN_ERR_LAUNCH;
+    }
+    memset(p, 0, 64);
+    g_host_error = (unsigned*)p;
+  }
+  *out = g_host_error;
   return MGGAN_OK;
 }
 

@@ -6,7 +6,9 @@
 
 #define COMM_MAX_RANKS 8
 #define COMM_CHUNK 2048                 // elements per workgroup (8 per lane)
-#define COMM_TIMEOUT_TICKS 200000000ll  // wall_clock64 ticks (100 MHz): 2 s
+#define COMM_TICKS_PER_S 100000000ll     // wall_clock64 ticks (100 MHz)
+#define COMM_TIMEOUT_DEFAULT_S 30.0      // ranks drift apart for seconds in ordinary runs (per-rank data loading, validation,
+                                         // checkpoints): the bound is for a LOST peer, not a late one (mggan_comm_set_timeout)
 
 struct CommHeader {        // at the start of every arena (local use only)
   unsigned seq;            // collectives completed on this channel
@@ -21,7 +23,34 @@ struct CommArgs {
   long n;
   long max_elems;               // capacity of one slot in elements of the widest type (8 bytes)
   int rank, world, max_blocks, dtype;  // dtype 0: f32, 1: f64, 2: i32
+  long long timeout_ticks;             // bound of every wait
+  unsigned* host_error;                // host-mapped word, set (with the arena's) when a wait timed out; may be null
 };
+
+long long comm_timeout_ticks();  // csrc/comm.hip
+unsigned* comm_host_error();
+
+// What a timed-out collective leaves behind: never a sum over stale slots.
+template <typename T> __device__ __forceinline__ T comm_poison();
+template <> __device__ __forceinline__ float comm_poison<float>() { return __builtin_nanf(""); }
+template <> __device__ __forceinline__ double comm_poison<double>() { return __builtin_nan(""); }
+template <> __device__ __forceinline__ int comm_poison<int>() { return (int)0x80000000; }
+
+// Waits until *wf == seq or the bound passes; an arena that has timed out once gives up at once from then on (a broken
+// link costs one bound, not one per collective).  -> true when the flag arrived.
+__device__ __forceinline__ bool comm_wait_flag(unsigned* wf, unsigned seq, CommHeader* hdr, const CommArgs& a) {
+  const long long t0 = wall_clock64();
+  const bool dead = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  while (__hip_atomic_load(wf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+    __builtin_amdgcn_s_sleep(2);
+    if (dead || wall_clock64() - t0 > a.timeout_ticks) {
+      __hip_atomic_store(&hdr->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.host_error) __hip_atomic_store(a.host_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+  }
+  return true;
+}
 
 __host__ __device__ inline size_t comm_flags_off() { return 64; }
 __host__ __device__ inline size_t comm_data_off(int max_blocks) {
@@ -43,29 +72,24 @@ __device__ __forceinline__ void comm_allreduce_small(const CommArgs& a, double* 
     double* dst = (double*)((char*)a.arena[j] + doff + ((size_t)buf * COMM_MAX_RANKS + r) * slot_bytes);
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = vals[i];
   }
+  __shared__ int comm_lost;
+  if (threadIdx.x == 0) comm_lost = 0;
   __threadfence_system();
   __syncthreads();
   if ((int)threadIdx.x < W) {
     unsigned* pf = (unsigned*)((char*)a.arena[threadIdx.x] + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + r) * a.max_blocks;
     __hip_atomic_store(pf, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     unsigned* wf = (unsigned*)(mine + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + threadIdx.x) * a.max_blocks;
-    const long long t0 = wall_clock64();
-    const bool dead = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-    while (__hip_atomic_load(wf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      __builtin_amdgcn_s_sleep(2);
-      if (dead || wall_clock64() - t0 > COMM_TIMEOUT_TICKS) {
-        __hip_atomic_store(&hdr->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
+    if (!comm_wait_flag(wf, seq, hdr, a)) comm_lost = 1;
   }
   __syncthreads();
+  const bool lost = comm_lost != 0;
   const double* base = (const double*)(mine + doff + (size_t)buf * COMM_MAX_RANKS * slot_bytes);
   const size_t stride = slot_bytes / sizeof(double);
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     double s = __builtin_nontemporal_load(base + i);
     for (int j = 1; j < W; ++j) s += __builtin_nontemporal_load(base + (size_t)j * stride + i);
-    vals[i] = s;
+    vals[i] = lost ? comm_poison<double>() : s;  // a lost peer shows up as NaN statistics, never as a partial sum
   }
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -76,5 +100,6 @@ static inline CommArgs comm_make_args(void* const* arenas, int rank, int world, 
   for (int j = 0; j < COMM_MAX_RANKS; ++j) a.arena[j] = j < world ? arenas[j] : nullptr;
   a.data = nullptr; a.n = 0; a.max_elems = max_elems; a.rank = rank; a.world = world;
   a.max_blocks = cdiv(max_elems * 2, COMM_CHUNK); a.dtype = 1;
+  a.timeout_ticks = comm_timeout_ticks(); a.host_error = comm_host_error();
   return a;
 }

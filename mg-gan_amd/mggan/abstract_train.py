@@ -120,6 +120,7 @@ class MultiGeneratorGAN(abc.ABC):
             if hasattr(self, "_close_iteration"):
                 self._close_iteration()
         self.total_iterations += 1
+        self.dist.check()
 
     def capture_iteration(self, batch, warmup=3):
         """Capture one full D+G+PM iteration on `batch` into a HIP graph (needs --rng device: no host
@@ -141,8 +142,13 @@ class MultiGeneratorGAN(abc.ABC):
 
             # peer-mapped all-reduce kernels (mggan/devcomm.py): the collectives are ordinary launches, the sharded
             # iteration is ONE graph like the single-GPU one, branch streams on.  Without them (ranks on several nodes,
-            # IPC mapping refused) every torch.distributed collective cuts the capture into graph segments.
-            in_graph = self.dist.devcomm is not None
+            # IPC mapping refused, a gradient buffer larger than an arena slot, unequal shards) every torch.distributed
+            # collective cuts the capture into graph segments.
+            in_graph = self.dist.graph_safe(self.G, self.D)
+            if not in_graph and self.dist.devcomm is not None:
+                # the decision is per trainer, not per collective: a torch.distributed call inside the single-graph
+                # capture would fail, so the peer-mapped kernels are set aside for this trainer's captures
+                self.dist.close()
             HF.enable_branches(in_graph or os.environ.get("MGGAN_BRANCH_SHARDED", "0") == "1")
         self.graph_collectives = in_graph
         keep, self.defer_metrics = self.defer_metrics, True
@@ -197,6 +203,7 @@ class MultiGeneratorGAN(abc.ABC):
 
         def replay(metrics=None, fetch=True):
             run()
+            self.dist.check()  # host read: a peer-mapped collective of an earlier replay has timed out -> stop here
             if metrics is not None and fetch:
                 self._fetch([(metrics, items, snap) for _, items, snap in pending])
 
@@ -212,14 +219,17 @@ class MultiGeneratorGAN(abc.ABC):
                                     workers=cfg.workers, shuffle=False, **kw)
         track_metric = "val/ADE k=20"
         min_track_metric = math.inf
+        self.total_iterations = 0  # a local of train() in the reference (abstract_train.py:104): every call starts at 0
         for epoch in range(cfg.epochs):
             self.epoch += 1
             self.D.train()
             self.G.train()
             metrics = defaultdict(list)
+            self.dist.host_barrier()  # loaders, validation and checkpoints are per-rank host phases
             for batch in train_loader:
                 batch = self.to_device(batch)
                 self.train_iteration(batch, metrics)
+            self.dist.check(sync=True)
 
             if self.epoch % cfg.val_every == 0:
                 self.D.eval()

@@ -19,15 +19,26 @@ _DTYPES = {torch.float32: 0, torch.float64: 1, torch.int32: 2}
 
 
 class DeviceComm:
-    MAX_ELEMS = 1 << 16  # 8-byte elements per slot: 512 KB (the flat gradient buffers are 211-360 KB)
-    CHANNELS = 6
+    MAX_ELEMS = 1 << 16  # 8-byte elements per slot: 512 KB (the flat gradient buffers are 211-360 KB at the default widths)
+    # A channel is a logical ROLE, not a raw stream: 0 = the main chain (the caller's stream and every stream that is
+    # ordered with it by fork/join -- the capture stream, the autograd-backward stream), 1 + i = branch stream i of
+    # mggan.hip.functions.  A process that trains eagerly and then captures, or captures several times, keeps using the
+    # same arenas; all ranks run the same program, so they agree on the roles.
+    CHANNELS = 1 + 4
 
-    def __init__(self, group, device):
+    def __init__(self, group, device, max_elems=None):
         """Collective: every rank of `group` calls it.  Raises on EVERY rank if any rank fails (the phases end with an
-        exchange of verdicts, so the ranks never wait for a peer that has given up)."""
+        exchange of verdicts, so the ranks never wait for a peer that has given up).  max_elems: slot capacity in 8-byte
+        elements (sized by the caller from the largest vector it will reduce; the same on every rank)."""
         self.group, self.device = group, torch.device(device)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self._local, self._opened, self._arenas, self._channel_of = [], [], [], {}
+        self._local, self._opened, self._arenas = [], [], []
+        if max_elems is not None:
+            self.MAX_ELEMS = max(int(max_elems), 1 << 10)
+        lib.mggan_comm_set_timeout(float(os.environ.get("MGGAN_COMM_TIMEOUT_S", "30")))
+        hp = ctypes.POINTER(ctypes.c_uint)()
+        lib.mggan_comm_host_error(ctypes.byref(hp))
+        self._host_error = hp  # host-mapped word: set by any collective of this process whose wait timed out
 
         def agree(payload, what):
             everyone = [None] * self.world
@@ -101,14 +112,15 @@ class DeviceComm:
         return ok
 
     def _channel(self):
-        sid = torch.cuda.current_stream(self.device).cuda_stream
-        ch = self._channel_of.get(sid)
-        if ch is None:
-            ch = len(self._channel_of)
-            if ch >= self.CHANNELS:
-                raise RuntimeError("device all-reduce: more than {} streams issue collectives".format(self.CHANNELS))
-            self._channel_of[sid] = ch
-        return ch
+        from mggan.hip import functions as HF
+
+        cur = torch.cuda.current_stream(self.device)
+        for which, st in HF._BR["streams"].items():
+            if cur == st:
+                if not 0 <= int(which) < self.CHANNELS - 1:
+                    raise RuntimeError("device all-reduce: branch stream {} has no channel".format(which))
+                return 1 + int(which)
+        return 0
 
     def channel_args(self):
         """(arenas, rank, world, max_elems) of the current stream's channel, for kernels that embed the small exchange
@@ -125,8 +137,20 @@ class DeviceComm:
                                  t.numel(), _DTYPES[t.dtype], torch.cuda.current_stream(self.device).cuda_stream)
         return t
 
-    def check(self):
-        """Raise if a wait timed out on any channel (a peer was lost or the ranks issued different collectives)."""
+    def failed(self):
+        """True once any collective of this process has timed out.  A plain host read (no device sync, no HIP call): cheap
+        enough for every iteration of the training loop; the device may still be running, so a False is final only after
+        a synchronisation."""
+        return bool(self._host_error[0])
+
+    def check(self, sync=True):
+        """Raise if a wait timed out on any channel (a peer was lost or the ranks issued different collectives).
+        sync=False: only look at the host-mapped word (what has been reported so far)."""
+        if not sync:
+            if self.failed():
+                raise RuntimeError("device all-reduce: a wait timed out on rank {} (a peer was lost or the ranks issued "
+                                   "different collectives); the reduced buffers hold NaN".format(self.rank))
+            return
         bad = []
         for ch, p in enumerate(self._local):
             e = ctypes.c_uint()
@@ -144,13 +168,13 @@ class DeviceComm:
         self._opened, self._local = [], []
 
 
-def create(group, device):
+def create(group, device, max_elems=None):
     """-> DeviceComm or None (disabled by MGGAN_DEVICE_COMM=0, or the mapping failed on some rank: every rank then
     falls back to torch.distributed together)."""
     if os.environ.get("MGGAN_DEVICE_COMM", "1") == "0":
         return None
     try:
-        return DeviceComm(group, device)  # raises on every rank together
+        return DeviceComm(group, device, max_elems)  # raises on every rank together
     except Exception as exc:  # noqa: BLE001
         print("[mggan] device all-reduce unavailable ({}: {}); torch.distributed collectives between graph segments "
               "instead".format(type(exc).__name__, exc))

@@ -915,8 +915,10 @@ class TrunkJoinFn(Function):
         b, W, Hh, Sc, Fd = ctx.dims
         if d_enc_h is None:
             d_enc_h = torch.zeros(b, W, dtype=F32, device=buf.device)
-        elif d_enc_h.stride(1) != 1 or (b > 1 and d_enc_h.stride(0) != W) or d_enc_h.data_ptr() % 16:
+        elif d_enc_h.stride(1) != 1 or (b > 1 and d_enc_h.stride(0) != W):
             d_enc_h = d_enc_h.contiguous()
+        elif d_enc_h.data_ptr() % 16:  # contiguous() is a no-op on a contiguous view at an odd storage offset
+            d_enc_h = d_enc_h.clone()
         if d_soc is not None:  # a consumer of the separate `social` output that did not fold its gradient into d enc_h
             d_enc_h = d_enc_h.clone()
             d_enc_h[:, Hh + Sc:] += d_soc
@@ -1535,8 +1537,10 @@ class DRowsBodyFn(Function):
         train_pe, train_s1, train_s3 = train
         st = _s()
         need_in, need_pred, need_pred2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        if dX.stride(1) != 1 or (R > 1 and dX.stride(0) != W) or dX.data_ptr() % 16:
+        if dX.stride(1) != 1 or (R > 1 and dX.stride(0) != W):
             dX = dX.contiguous()
+        elif dX.data_ptr() % 16:  # contiguous() is a no-op on a contiguous view at an odd storage offset
+            dX = dX.clone()
         # social attention: dS = dX[:, soc block], dh ADDED into dX[:, in_enc | pred_enc] in place (dX comes from
         # DRowsHeadsFn.backward and has no other reader)
         nsoc = soc_blocks * b

@@ -141,7 +141,33 @@ class DistContext:
         if self.enabled and self.devcomm is None and torch.device(self._dev).type == "cuda":
             from mggan import devcomm
 
-            self.devcomm = devcomm.create(self.group, self._dev)
+            # slot capacity from the largest vector this trainer reduces (the flat gradient buffers; f32 = half an
+            # 8-byte element each), rounded up to a power of two; every rank builds the same models
+            need = max([(r._flat_grad.numel() + 1) // 2 for r in roots if getattr(r, "_flat_grad", None) is not None] + [1])
+            cap = 1 << 16
+            while cap < need:
+                cap <<= 1
+            self.devcomm = devcomm.create(self.group, self._dev, cap)
+
+    def graph_safe(self, *roots):
+        """Can every collective of an iteration run INSIDE one captured graph?  Needs the peer-mapped kernels, equal
+        shards (unequal ones read the global row count back to the host) and slots that hold the flat gradient buffers;
+        otherwise capture_iteration uses graph segments with the collectives between them."""
+        if self.devcomm is None or not self.equal_shards:
+            return False
+        return all(r._flat_grad is None or self.devcomm.supports(r._flat_grad) for r in roots)
+
+    def check(self, sync=False):
+        """Raise if a peer-mapped collective has timed out (sync=False: a host read, free; the training loop calls it every
+        iteration -- a lost peer leaves NaN in the reduced buffers and must stop the run, not train on)."""
+        if self.devcomm is not None:
+            self.devcomm.check(sync=sync)
+
+    def host_barrier(self):
+        """Line the ranks up on the host (after per-rank host phases -- data-loader construction, validation, checkpoint
+        writes -- the ranks can be seconds apart; the in-kernel waits of the first collective afterwards are bounded)."""
+        if self.enabled and self.world_size > 1:
+            dist.barrier(group=self.group)
 
 
 def replicas_in_sync(*roots, group=None):

@@ -52,7 +52,14 @@ class DeviceRNG:
 
     def _ensure_state(self, device):
         if self._state is None or self._state.device != torch.device(device):
-            seed = int(torch.cuda.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+            seed = int(torch.cuda.initial_seed())
+            # every process of a sharded run is seeded alike (abstract_train.py seeds at import) and numbers its scenes
+            # from 0: without the rank in the key all ranks would draw the same noise vectors and label uniforms
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_rank() > 0:
+                seed ^= dist.get_rank() * 0x9E3779B97F4A7C15
+            seed &= 0x7FFFFFFFFFFFFFFF
             self._state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
             self._ticket = torch.zeros(1, dtype=torch.int32, device=device)
 

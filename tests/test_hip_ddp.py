@@ -98,8 +98,9 @@ def test_two_ranks_match_single_process():
     assert np.array_equal(two[0][1], two[1][1])    # bit-identical replicas
 
 
-def _run_graph(rank, world, port, sizes, q, device_comm):
-    """Sharded iteration captured on `world` ranks (sharing the box's one GPU, handles exchanged over gloo):
+def _run_graph(rank, world, port, sizes, q, device_comm, backend="gloo", own_device=False):
+    """Sharded iteration captured on `world` ranks (sharing the box's one GPU, handles exchanged over gloo -- or, with
+    own_device, one GPU per rank and any backend: tests/test_hip_multigpu.py):
     device_comm=True: peer-mapped all-reduce kernels inside ONE graph; False: graph segments around eager collectives."""
     import sys
 
@@ -115,10 +116,13 @@ def _run_graph(rank, world, port, sizes, q, device_comm):
     from mggan.data_utils import synthetic
     from mggan.parallel import replicas_in_sync, shard_batch
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(2)
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", rank if own_device else 0)
     torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    torch.set_num_threads(2)
     tr = bench.build_trainer(2, "device", dev, seed=rank)
     assert tr.dist.enabled
     tr.dist.equal_shards = True
@@ -143,11 +147,12 @@ def _run_graph(rank, world, port, sizes, q, device_comm):
            {k: v for k, v in m.items() if "probs" not in k}, tr.dist.devcomm is not None, sync, tr.launch_mode))
 
 
-def _launch_graph(world, sizes, device_comm):
+def _launch_graph(world, sizes, device_comm, backend="gloo", own_device=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_graph, args=(r, world, port, sizes, q, device_comm)) for r in range(world)]
+    procs = [ctx.Process(target=_run_graph, args=(r, world, port, sizes, q, device_comm, backend, own_device))
+             for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=200) for _ in range(world)], key=lambda t: t[0])
@@ -158,14 +163,15 @@ def _launch_graph(world, sizes, device_comm):
 
 
 def _check_replicas(res, replays=3):
-    (_, f0, n0, s0, m0, _, sync0, _), (_, f1, n1, s1, m1, _, sync1, _) = res
-    assert n0 == n1 and sync0 and sync1
-    assert s0 == s1 == 2 + replays         # 2 eager warm-up iterations + the replays (capturing executes nothing)
-    assert np.isfinite(f0).all() and np.array_equal(f0, f1)  # replicas stay bit-identical through the replays
-    for k, v in m0.items():
-        assert len(v) == replays and np.isfinite(v).all(), k
-        np.testing.assert_allclose(v, m1[k], rtol=1e-6)      # logged losses are global means on every rank
-    assert 0.2 < m0["train/discr_loss"][-1] < 3.0
+    (_, f0, n0, s0, m0, _, sync0, _) = res[0]
+    assert np.isfinite(f0).all() and 0.2 < m0["train/discr_loss"][-1] < 3.0
+    for (_, f1, n1, s1, m1, _, sync1, _) in res[1:]:
+        assert n0 == n1 and sync0 and sync1
+        assert s0 == s1 == 2 + replays         # 2 eager warm-up iterations + the replays (capturing executes nothing)
+        assert np.array_equal(f0, f1)          # replicas stay bit-identical through the replays
+        for k, v in m0.items():
+            assert len(v) == replays and np.isfinite(v).all(), k
+            np.testing.assert_allclose(v, m1[k], rtol=1e-6)      # logged losses are global means on every rank
 
 
 def test_two_ranks_graph_segments():
@@ -194,7 +200,7 @@ def test_one_rank_forced_collectives_stay_in_one_graph():
     assert r[5] and r[2] == 1 and r[6] and np.isfinite(r[1]).all()
 
 
-def _run_allreduce(rank, world, port, q):
+def _run_allreduce(rank, world, port, q, backend="gloo", own_device=False):
     import sys
 
     for p in (os.path.join(ROOT, "mg-gan_amd"), ROOT):
@@ -204,14 +210,19 @@ def _run_allreduce(rank, world, port, q):
 
     from mggan import devcomm
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", rank if own_device else 0)
     torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     comm = devcomm.create(None, dev)
     assert comm is not None, "peer mapping failed"
     ok = True
     gen = torch.Generator().manual_seed(3)  # every rank draws the same table and takes its row
-    side = torch.cuda.Stream()
+    from mggan.hip import functions as HF
+
+    side = HF._BR["streams"][0] = torch.cuda.Stream()  # a branch stream has a channel (arena) of its own
     for rnd, (n, dt) in enumerate([(5, torch.float64), (90000, torch.float32), (32, torch.float64), (8, torch.int32),
                                    (2049, torch.float32), (131072, torch.float32), (1, torch.float32)] * 3):
         if dt == torch.int32:
@@ -242,23 +253,97 @@ def _run_allreduce(rank, world, port, q):
         torch.cuda.synchronize()
         ok = ok and bool((x == sum(range(1, world + 1))).all())
     comm.check()
+    ok = ok and not comm.failed()
     dist.barrier()
     comm.close()
     dist.destroy_process_group()
     q.put((rank, ok))
 
 
-def test_device_allreduce_is_exact_and_capturable():
-    """csrc/comm.hip on its own: f32 / f64 / i32 vectors from 1 element to a full slot, on two channels, eager and
-    replayed from a graph, equal the rank-ordered sum to the bit."""
+def _launch_allreduce(world, backend="gloo", own_device=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_allreduce, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run_allreduce, args=(r, world, port, q, backend, own_device)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=200) for _ in range(2)]
+    res = [q.get(timeout=200) for _ in range(world)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert all(ok for _, ok in res)
+    return res
+
+
+def test_device_allreduce_is_exact_and_capturable():
+    """csrc/comm.hip on its own: f32 / f64 / i32 vectors from 1 element to a full slot, on two channels, eager and
+    replayed from a graph, equal the rank-ordered sum to the bit."""
+    assert all(ok for _, ok in _launch_allreduce(2))
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts two ranks itself and prints n_gpus: 2 (here
+    the ranks share the box's one GPU over gloo -- a functional check of the launcher and of the line's transport A/B)."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MGGAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                          "--config", "c1", "--also", "", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
+    kinds = set().union(*[set(t) - {"config"} for t in line["collective_transports"]])
+    assert kinds == {"peer-mapped", "rccl-segments"}, kinds
+
+
+def _run_lost_peer(rank, world, port, q):
+    import sys
+
+    for p in (os.path.join(ROOT, "mg-gan_amd"), ROOT):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      MGGAN_COMM_TIMEOUT_S="2")
+    import torch.distributed as dist
+
+    from mggan import devcomm
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    comm = devcomm.create(None, dev)
+    assert comm is not None and not comm.failed()
+    x = torch.ones(5000, device=dev)
+    if rank == 0:  # rank 1 never issues this collective: a lost peer
+        comm.all_reduce_(x)
+        torch.cuda.synchronize()
+    dist.barrier()
+    raised = False
+    try:
+        comm.check(sync=False)
+    except RuntimeError:
+        raised = True
+    q.put((rank, bool(torch.isnan(x).all().cpu()), comm.failed(), raised))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+def test_lost_peer_poisons_the_result_and_is_reported_without_a_sync():
+    """A wait that exceeds the bound must not hand back a sum over stale slots: the vector comes back NaN and the
+    host-mapped error word (read every iteration by the training loop) is set."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_lost_peer, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r, rest) for r, *rest in [q.get(timeout=200) for _ in range(2)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == [True, True, True]      # rank 0 waited 2 s for a peer that never came
+    assert res[1] == [False, False, False]   # rank 1 did nothing and saw nothing
