@@ -118,10 +118,16 @@ def flops_of(name, a):
         return float(a[0]) * 2 * (96 + 2048 + 64)
     if name == "mggan_social_pairs_bwd":
         return float(a[0]) * 2 * (64 + 2048)
-    if name == "mggan_social_attention_fwd":
-        return float(a[2]) * 2 * (96 + 2048 + 64 + a[3])
-    if name == "mggan_social_attention_bwd":
-        return float(a[2]) * 2 * (64 + 2048 + 3 * a[4] + 65)
+    if name in ("mggan_social_rows_fwd", "mggan_social_rows_bwd"):
+        # per in-scene ordered pair (the launcher notes the pair count): forward 3->32->64 pair MLP + score + pooling;
+        # backward softmax / score / layer-2 adjoints and, when the pair MLP trains (partials given), its weight gradients
+        from mggan.hip import functions as HF
+
+        notes = HF.TRACE_NOTES[name[6:] + "_pairs"]
+        P, H = (notes.pop(0) if notes else 0), a[2]
+        if name.endswith("fwd"):
+            return float(P) * 2 * (96 + 2048 + 64 + H)
+        return float(P) * 2 * (64 + 3 * H + 65 + (2048 + 2048 + 96 if a[21] else 0))
     return 0.0
 
 
@@ -140,10 +146,6 @@ def bytes_of(name, a):
     if name == "mggan_decoder_rollout_bwd_fused":  # reads the same record back, plus the two output gradients
         T, H, R = a[2], a[3], a[21]
         return float(R) * T * 4.0 * (4 * H + 2 * H + H // 2 + 2 + 4)
-    if name == "mggan_social_attention_bwd":  # per pair: reads l1 (32), l2 (64), att; writes dz1 (32), dz2 (64), dsigma
-        return float(a[2]) * 4.0 * (32 + 64 + 1 + 32 + 64 + 1)
-    if name == "mggan_social_attention_fwd":  # per pair (training): writes feat (3), l1 (32), l2 (64), att
-        return float(a[2]) * 4.0 * ((3 + 32 + 64 if a[18] else 0) + 1)
     if name == "mggan_image_gram":  # the batch's images, once
         return float(a[1]) * 4 * 33 * 33 * 4.0
     return 0.0

@@ -145,23 +145,26 @@ int mggan_social_pairs_bwd(int P, int b, const int* pair_j, const int* ped_prow,
                            const float* dsigma, const float* vc, const float* l1, const float* l2, const float* W2,
                            float* dz2, float* dz1, float* dvc, mggan_stream_t stream);
 
-/* Fused launches of the same math over pedestrian-aligned tiles: tiles[t] = {ped0, ped1, first pair, pair count},
- * consecutive pedestrians whose pairs are contiguous and number <= 64 (host-built once per batch; a scene of more
- * than 64 pedestrians needs the unfused entry points above).  _fwd = pairs_fwd + softmax_fwd in one launch (sigma
- * never reaches HBM), _bwd = softmax_bwd + pairs_bwd in one launch plus one launch for both column reductions.
+/* The same math as ONE launch per direction for scenes of up to 64 pedestrians (csrc/social_rows.hip): a workgroup
+ * owns whole scenes (scenes[s] = {first row, past-last row}), a wave owns attention rows, the 32->64 pair layer and its
+ * adjoint run on MFMA, the softmax over a scene is wave-level shuffle reductions, and NOTHING per pair is stored:
+ * _bwd recomputes the pair MLP from the positions.  vc: [rows][ldv] with v_j in columns 0..63 and c_j in column 64
+ * (ldv a multiple of 4, >= 68, rows 16-byte aligned); dvc has the same layout.  max_n = largest scene (<= 64).
  * xy_mod > 0: the pedestrian rows repeat with that period (xy_last / dxdy_last hold one period: the real and the fake
- * half of a discriminator pair pass share the observed positions). */
-int mggan_social_attention_fwd(int n_tiles, const int* tiles, int P, int H, const int* pair_i, const int* pair_j,
-                               const int* ped_prow, const int* ped_s0, const int* ped_n, const float* xy_last,
-                               const float* dxdy_last, const float* W1, const float* b1, const float* W2,
-                               const float* b2, const float* vc, const float* h, int ld_h, float* feat, float* l1,
-                               float* l2, float* att, float* S, int ld_s, int xy_mod, mggan_stream_t stream);
-int mggan_social_attention_bwd(int n_tiles, const int* tiles, int P, int b, int H, const int* pair_i,
-                               const int* pair_j, const int* ped_prow, const int* ped_s0, const int* ped_n,
-                               const float* att, const float* h, int ld_h, const float* dS, int ld_ds,
-                               const float* vc, const float* l1, const float* l2, const float* W2, float* dsigma,
-                               float* dz2, float* dz1, float* dvc, float* dh, int ld_dh, int accumulate_dh,
-                               mggan_stream_t stream);
+ * half of a discriminator pair pass share the observed positions).
+ * _bwd: dvc[j] = sum_i dsigma_ij [l2_ij | 1], dh[j] (+)= sum_i a_ij dS_i; partials != NULL: also the weight gradients of
+ * the 3->32 and 32->64 layers, as mggan_social_rows_grid(S) partial blocks of mggan_social_rows_partial_floats() floats
+ * ([64][33] = dW2 | db2, then [32][4] = dW1 | db1) for mggan_grad_reduce_multi.  Rows that belong to no scene are not
+ * written. */
+int mggan_social_rows_grid(int S);
+int mggan_social_rows_partial_floats(void);
+int mggan_social_rows_fwd(int S, const int* scenes, int H, int max_n, const float* xy_last, const float* dxdy_last,
+                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* vc,
+                          int ldv, const float* h, int ld_h, float* S_out, int ld_s, mggan_stream_t stream);
+int mggan_social_rows_bwd(int S, const int* scenes, int H, int max_n, const float* xy_last, const float* dxdy_last,
+                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* vc,
+                          int ldv, const float* h, int ld_h, const float* dS, int ld_ds, float* dvc, float* dh, int ld_dh,
+                          int accumulate_dh, float* partials, mggan_stream_t stream);
 
 /* ---- Social-GAN pooling (--pool_type sgan) ------------------------------------------------
  * reference: social_gan.py:199-229 (PoolHiddenNet.forward): per scene, every pedestrian i and every j of its scene

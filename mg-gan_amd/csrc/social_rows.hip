@@ -1,0 +1,586 @@
+// Social attention of MG-GAN as ROW-structured, recomputing MFMA kernels for gfx950.
+//
+// Replaces (file:line under /root/reference/mggan/model/modules/social.py):
+//   SocialFeatures / BearingMTX / DCA_MTX   :67-104  (distance, cos-bearing, DCA of ordered pairs)
+//   EmbedSocialFeatures.fc                  :33-48   (MLP 3 -> 32 -> 64 -> F, ReLU)
+//   AttentionPooling.forward                :14-30   (sigma_ij = f_ij . (W h_j + b); sigma_ii = -1000;
+//                                                     softmax over the scene; S_i = sum_j a_ij h_j; n==1 -> 0)
+// and their adjoints INCLUDING the weight gradients of the 3->32 and 32->64 layers.  Algebra as in social.hip: the last
+// embedding layer is linear, sigma_ij = l2_ij . v_j + c_j with [v_j | c_j] = (W_at h_j + b_at) [W3 | b3] (65 values per
+// pedestrian, computed by the chain kernel before this one).
+//
+// Work decomposition.  A workgroup (4 waves) owns whole scenes; wave w owns the attention rows i = w, w+4, ... of the
+// scene and walks each row in blocks of 16 neighbours j.  Inside a block lane (pp, kq) = (lane & 15, lane >> 4) stands
+// for neighbour j = 16 jb + pp and for the kq-th quarter of every feature axis:
+//   * both layers of the pair MLP TRANSPOSED on v_mfma_f32_16x16x4_f32: l1^T (32 x 16 pairs) = [W1 | b1] (32 x 4)
+//     [f ; 1] (4 x 16 pairs) is two MFMAs whose D fragment IS the B operand of the next product -- lane (pp, kq) gets
+//     units u(s) = 16 (s>>2) + 4 kq + (s&3), s = 0..7, of its pair, and the reduction index of z2^T (64 x 16 pairs) =
+//     W2 (64 x 32) l1^T is walked in exactly that order (an MFMA's k index may be permuted freely as long as A agrees);
+//     b2 enters as one more k step against a row of ones; the D fragment of lane (pp, kq) is z2[pair pp][m = 16 t + 4 kq
+//     + r].  The weights are MFMA operands only (accumulator-file registers), never VALU operands;
+//   * the score is a 16-term dot product per lane with the lane's slice of v_j (row-invariant registers) + two
+//     cross-row adds; the softmax over the scene is DPP row reductions + a loop over the <= 4 blocks: no LDS, no barrier
+//     ("wavefront shuffle reductions for the attention softmax");
+//   * backward: the adjoint dz1^T = W2^T dz2^T takes the D registers of the forward product AS ITS B OPERAND (the
+//     reduction index of an MFMA may be permuted freely as long as A agrees: k-step (t, r) <-> m = 16 t + 4 kq + r), and
+//     its D fragment lands on the units u(s) the lane already holds l1 for;
+//   * sums over i for a fixed neighbour (dvc_j = sum_i dsigma_ij [l2_ij | 1], dh_j = sum_i a_ij dS_i) stay in the
+//     registers of the lane that stands for j while the wave walks its rows; the four waves' partial sums meet in LDS
+//     once per scene (fixed order);
+//   * the weight gradient dW2 = sum_pairs dz2 l1^T contracts over PAIRS, the one index that sits on the N axis of the
+//     products above: dz2 and l1 of a block are transposed through 6.5 KB of wave-private LDS (conflict-free both ways:
+//     row strides 68 / 36 floats, pair = step + 4 k) into A / B fragments; dW2, dW1, db1, db2 accumulate in registers over
+//     every scene of the workgroup and leave ONE partial block per workgroup for the batched fixed-order reduction
+//     (grad_reduce_multi_kernel) -- nothing per pair is ever written to HBM (the fused tile kernels this file replaces
+//     stored 100 floats per pair in the forward pass and 97 more in the backward pass for the weight-gradient GEMMs).
+// Scenes of more than 64 pedestrians take the unfused kernels of social.hip.
+#include "common.h"
+#include "../../include/mggan_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define SR_LDV 68    // staged row of a scene: v_j (64) | c_j | pad
+#define SR_LDZ 68    // dz2 transposition tile [16 pairs][64 + 4]
+#define SR_LD1 36    // l1 / dz1 transposition tiles [16 pairs][32 + 4]; the dz1 tile's pad columns hold (f0, f1, f2, 1)
+#define SR_TILE_FLOATS (16 * SR_LDZ + 2 * 16 * SR_LD1)  // wave-private transposition tiles
+#define SR_WG_FLOATS (64 * 33 + 32 * 4)                 // partial block of a workgroup: dW2|db2 [64][33], dW1|db1 [32][4]
+
+struct SocRowsArgs {
+  const int* scenes;  // [S][2] = first / past-last pedestrian row
+  const float *xy, *dxy;
+  const float *W1, *b1, *W2, *b2;
+  const float* vc;    // [b][ldv]: v_j (64) | c_j at column 64
+  const float* h;
+  const float* dS;
+  float *Sout, *dvc, *dh, *partials;
+  int S, xy_mod, ldv, ld_h, ld_s, ld_ds, ld_dh, accumulate_dh;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float sr_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// all-lanes sum / max over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1)
+__device__ __forceinline__ float row_sum16(float v) {
+  v += sr_dpp<0x128>(v);
+  v += sr_dpp<0x124>(v);
+  v += sr_dpp<0x122>(v);
+  v += sr_dpp<0x121>(v);
+  return v;
+}
+__device__ __forceinline__ float row_max16(float v) {
+  v = fmaxf(v, sr_dpp<0x128>(v));
+  v = fmaxf(v, sr_dpp<0x124>(v));
+  v = fmaxf(v, sr_dpp<0x122>(v));
+  v = fmaxf(v, sr_dpp<0x121>(v));
+  return v;
+}
+// sum over the four DPP rows of a wave (the four kq quarters), result in every lane
+__device__ __forceinline__ float quarters_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+// LDS traffic between the lanes of ONE wave (the transposition tiles): program order is execution order, the compiler
+// only has to keep it
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// SocialFeatures of the ordered pair (i, j): social.py:67-104 (same operation order as social.hip:pair_features)
+__device__ __forceinline__ void sr_features(float pix, float piy, float vix, float viy, float pjx, float pjy, float vjx,
+                                            float vjy, float f[3]) {
+  const float dpx = pix - pjx, dpy = piy - pjy;
+  const float dvx = vix - vjx, dvy = viy - vjy;
+  const float dist = sqrtf(dpx * dpx + dpy * dpy);
+  const float bearing = (dpx * vix + dpy * viy) / (dist * sqrtf(vix * vix + viy * viy) + 1e-6f);
+  const float ttca = -(dpx * dvx + dpy * dvy) / (dvx * dvx + dvy * dvy + 1e-6f);
+  const float cx = dpx + ttca * dvx, cy = dpy + ttca * dvy;
+  f[0] = dist;
+  f[1] = bearing;
+  f[2] = sqrtf(cx * cx + cy * cy);
+}
+
+__device__ __forceinline__ int sr_unit(int s, int kq) { return 16 * (s >> 2) + 4 * kq + (s & 3); }
+
+// loop-invariant weight fragments of a lane: MFMA A operands only
+struct SrWeights {
+  float w1a[2];     // [W1 | b1][16 tp + pp][kq]
+  float w2a[4][8];  // W2[16 t + pp][u(s)]
+  float b2a[4];     // b2[16 t + pp] on the kq == 0 lanes, 0 elsewhere (one k step against a row of ones)
+};
+
+__device__ __forceinline__ void sr_load_weights(const SocRowsArgs& a, int pp, int kq, SrWeights& W) {
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp) W.w1a[tp] = kq < 3 ? a.W1[(16 * tp + pp) * 3 + kq] : a.b1[16 * tp + pp];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) W.w2a[t][s] = a.W2[(16 * t + pp) * 32 + sr_unit(s, kq)];
+    W.b2a[t] = kq == 0 ? a.b2[16 * t + pp] : 0.f;
+  }
+}
+
+// what a lane keeps in registers about "its" neighbour j of a j-block (v_j and h_j are read from the staged scene)
+struct SrNeighbour {
+  float c, px, py, vx, vy;
+  int j;
+  bool ok;  // j < n
+};
+
+__device__ __forceinline__ void sr_load_neighbour(const SocRowsArgs& a, int s0, int n, int j, SrNeighbour& N) {
+  N.ok = j < n;
+  N.j = N.ok ? j : 0;
+  const int jc = s0 + N.j;
+  N.c = a.vc[(size_t)jc * a.ldv + 64];
+  const int jx = a.xy_mod > 0 ? jc % a.xy_mod : jc;
+  N.px = a.xy[2 * jx]; N.py = a.xy[2 * jx + 1];
+  N.vx = a.dxy[2 * jx]; N.vy = a.dxy[2 * jx + 1];
+}
+
+// [v_j | c_j] and h_j of the scene's pedestrians into LDS (every wave reads every neighbour)
+template <int H>
+__device__ __forceinline__ void sr_stage_scene(const SocRowsArgs& a, int s0, int n, float* vs, float* hs) {
+  for (int e = threadIdx.x; e < n * (SR_LDV / 4); e += 256) {
+    const int row = e / (SR_LDV / 4), c = e - row * (SR_LDV / 4);
+    *reinterpret_cast<f32x4*>(vs + row * SR_LDV + 4 * c) =
+        *reinterpret_cast<const f32x4*>(a.vc + (size_t)(s0 + row) * a.ldv + 4 * c);
+  }
+  for (int e = threadIdx.x; e < n * (H / 4); e += 256) {
+    const int row = e / (H / 4), c = e - row * (H / 4);
+    *reinterpret_cast<f32x4*>(hs + row * (H + 4) + 4 * c) =
+        *reinterpret_cast<const f32x4*>(a.h + (size_t)(s0 + row) * a.ld_h + 4 * c);
+  }
+}
+
+// the pair MLP for the 16 pairs (row i, neighbours of one block): l1[s] = unit u(s) of the lane's pair,
+// z[t][r] = PRE-activation of layer-2 unit 16 t + 4 kq + r
+__device__ __forceinline__ void sr_pair_mlp(const SrWeights& W, int kq, const float f[3], float l1[8], f32x4 z[4]) {
+  const float fb = kq == 0 ? f[0] : kq == 1 ? f[1] : kq == 2 ? f[2] : 1.0f;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 p0 = MFMA16(W.w1a[0], fb, zero), p1 = MFMA16(W.w1a[1], fb, zero);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    l1[r] = fmaxf(p0[r], 0.f);
+    l1[4 + r] = fmaxf(p1[r], 0.f);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) z[t] = MFMA16(W.b2a[t], 1.0f, zero);
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) z[t] = MFMA16(W.w2a[t][s], l1[s], z[t]);
+}
+
+// sigma_ij = l2_ij . v_j + c_j  (social.py:25: sigma_ii = -1000; padding lanes: -inf)
+__device__ __forceinline__ float sr_score(const f32x4 z[4], const float* vrow, const SrNeighbour& N, bool self) {
+  float sp0 = 0.f, sp1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; t += 2) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(vrow + 16 * t), v1 = *reinterpret_cast<const f32x4*>(vrow + 16 * t + 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sp0 = fmaf(fmaxf(z[t][r], 0.f), v0[r], sp0);
+      sp1 = fmaf(fmaxf(z[t + 1][r], 0.f), v1[r], sp1);
+    }
+  }
+  const float sg = quarters_sum(sp0 + sp1) + N.c;
+  return !N.ok ? -INFINITY : (self ? -1000.0f : sg);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int H, int NJB>
+__global__ __launch_bounds__(256) void social_rows_fwd_kernel(const SocRowsArgs a) {
+  constexpr int HQ = H / 4, LDH = H + 4;
+  __shared__ __attribute__((aligned(16))) float vs[16 * NJB * SR_LDV];
+  __shared__ __attribute__((aligned(16))) float hs[16 * NJB * LDH];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pp = lane & 15, kq = lane >> 4;
+  SrWeights W;
+  sr_load_weights(a, pp, kq, W);
+  for (int sc = blockIdx.x; sc < a.S; sc += gridDim.x) {
+    const int s0 = a.scenes[2 * sc], n = a.scenes[2 * sc + 1] - s0;
+    if (n <= 1) {  // social.py:19-20: a lone pedestrian pools nothing
+      if (n == 1 && (int)threadIdx.x < H) a.Sout[(size_t)s0 * a.ld_s + threadIdx.x] = 0.f;
+      continue;
+    }
+    __syncthreads();  // every wave is done with the previous scene's rows
+    sr_stage_scene<H>(a, s0, n, vs, hs);
+    SrNeighbour N[NJB];
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) sr_load_neighbour(a, s0, n, 16 * jb + pp, N[jb]);
+    __syncthreads();
+    for (int i = w; i < n; i += 4) {
+      const int gi = s0 + i, ix = a.xy_mod > 0 ? gi % a.xy_mod : gi;
+      const float pix = a.xy[2 * ix], piy = a.xy[2 * ix + 1], vix = a.dxy[2 * ix], viy = a.dxy[2 * ix + 1];
+      float sg[NJB];
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        if (16 * jb >= n) {  // wave-uniform: the scene has no neighbour in this block
+          sg[jb] = -INFINITY;
+          continue;
+        }
+        float f[3], l1[8];
+        f32x4 z[4];
+        sr_features(pix, piy, vix, viy, N[jb].px, N[jb].py, N[jb].vx, N[jb].vy, f);
+        sr_pair_mlp(W, kq, f, l1, z);
+        sg[jb] = sr_score(z, vs + N[jb].j * SR_LDV + 4 * kq, N[jb], 16 * jb + pp == i);
+      }
+      float mx = sg[0];
+#pragma unroll
+      for (int jb = 1; jb < NJB; ++jb) mx = fmaxf(mx, sg[jb]);
+      mx = row_max16(mx);
+      float e[NJB], den = 0.f;
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        e[jb] = N[jb].ok ? __expf(sg[jb] - mx) : 0.f;
+        den += e[jb];
+      }
+      const float inv = 1.0f / row_sum16(den);
+      float out[HQ];
+#pragma unroll
+      for (int k = 0; k < HQ; ++k) out[k] = 0.f;
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        if (16 * jb >= n) continue;
+        const float at = e[jb] * inv;
+        const float* hrow = hs + N[jb].j * LDH + kq * HQ;
+#pragma unroll
+        for (int k = 0; k < HQ; k += 4) {
+          const f32x4 h4 = *reinterpret_cast<const f32x4*>(hrow + k);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) out[k + q] = fmaf(at, h4[q], out[k + q]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < HQ; ++k) out[k] = row_sum16(out[k]);
+      if (pp == 0) {
+        float* dst = a.Sout + (size_t)gi * a.ld_s + kq * HQ;
+#pragma unroll
+        for (int k = 0; k < HQ; k += 4) *reinterpret_cast<f32x4*>(dst + k) = f32x4{out[k], out[k + 1], out[k + 2], out[k + 3]};
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward.  TRAIN: also the weight gradients of the pair MLP (one partial block per workgroup).  KEEP: the forward
+// values of a row's blocks stay in registers between the score pass and the adjoint pass (else: recomputed).
+template <int H, int NJB, bool TRAIN, bool KEEP>
+__global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs a) {
+  constexpr int HQ = H / 4, LDH = H + 4;
+  constexpr int LDC = 68 + H;  // reduction row: dv (64) | dc | pad (3) | dh (H); 4 mod 32
+  constexpr int RED_FLOATS = 4 * 16 * LDC;
+  constexpr int A_FLOATS = (4 * SR_TILE_FLOATS > RED_FLOATS ? 4 * SR_TILE_FLOATS : RED_FLOATS) > 4 * SR_WG_FLOATS
+                               ? (4 * SR_TILE_FLOATS > RED_FLOATS ? 4 * SR_TILE_FLOATS : RED_FLOATS)
+                               : 4 * SR_WG_FLOATS;
+  // region A: the waves' transposition tiles while rows are walked; the neighbour-sum exchange at the end of a scene;
+  // the weight-gradient exchange at the end of the workgroup (separated by barriers)
+  __shared__ __attribute__((aligned(16))) float smem[A_FLOATS];
+  __shared__ __attribute__((aligned(16))) float vs[16 * NJB * SR_LDV];
+  __shared__ __attribute__((aligned(16))) float hs[16 * NJB * LDH];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pp = lane & 15, kq = lane >> 4;
+  float* Zs = smem + w * SR_TILE_FLOATS;  // [16][SR_LDZ]
+  float* L1s = Zs + 16 * SR_LDZ;          // [16][SR_LD1]
+  float* Gs = L1s + 16 * SR_LD1;          // [16][SR_LD1]: dz1 | (f0, f1, f2, 1)
+  float* red = smem;                      // [4][16][LDC]
+  SrWeights W;
+  sr_load_weights(a, pp, kq, W);
+  float w2t[2][4][4];  // A operand of dz1^T = W2^T dz2^T: W2[m = 16 t + 4 kq + r][u = 16 tp + pp]
+  f32x4 dW2[4][2];     // dW2[m = 16 tm + 4 kq + r][u = 16 tu + pp], over every scene of this workgroup
+  f32x4 dW1[2];        // [dW1 | db1][u = 16 tp + 4 kq + r][c = pp] (lanes pp < 4)
+  float db2[4];        // db2[16 tm + pp], partial over the lane's pairs (folded over kq at the end)
+  if (TRAIN) {
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w2t[tp][t][r] = a.W2[(16 * t + 4 * kq + r) * 32 + 16 * tp + pp];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      dW2[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dW2[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      db2[t] = 0.f;
+    }
+    dW1[0] = dW1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int sc = blockIdx.x; sc < a.S; sc += gridDim.x) {
+    const int s0 = a.scenes[2 * sc], n = a.scenes[2 * sc + 1] - s0;
+    if (n <= 1) {  // no attention, no gradient: dvc = 0, dh untouched (or 0)
+      if (n == 1) {
+        if ((int)threadIdx.x < 65) a.dvc[(size_t)s0 * a.ldv + threadIdx.x] = 0.f;
+        if (!a.accumulate_dh && (int)threadIdx.x < H) a.dh[(size_t)s0 * a.ld_dh + threadIdx.x] = 0.f;
+      }
+      continue;
+    }
+    sr_stage_scene<H>(a, s0, n, vs, hs);  // (the previous scene ended with a barrier)
+    SrNeighbour N[NJB];
+    f32x4 dv[NJB][4];
+    float dc[NJB], dhq[NJB][HQ];
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) {
+      sr_load_neighbour(a, s0, n, 16 * jb + pp, N[jb]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dv[jb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dc[jb] = 0.f;
+#pragma unroll
+      for (int k = 0; k < HQ; ++k) dhq[jb][k] = 0.f;
+    }
+    __syncthreads();
+    for (int i = w; i < n; i += 4) {
+      const int gi = s0 + i, ix = a.xy_mod > 0 ? gi % a.xy_mod : gi;
+      const float pix = a.xy[2 * ix], piy = a.xy[2 * ix + 1], vix = a.dxy[2 * ix], viy = a.dxy[2 * ix + 1];
+      float dsq[HQ];  // dS_i[kq HQ + k]
+      {
+        const float* src = a.dS + (size_t)gi * a.ld_ds + kq * HQ;
+#pragma unroll
+        for (int k = 0; k < HQ; k += 4) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(src + k);
+          dsq[k] = t4[0]; dsq[k + 1] = t4[1]; dsq[k + 2] = t4[2]; dsq[k + 3] = t4[3];
+        }
+      }
+      // pass 1 over the row's blocks: the forward values (kept or thrown away), the score, and da_ij = dS_i . h_j
+      constexpr int NK = KEEP ? NJB : 1;
+      float f[NK][3], l1[NK][8], sg[NJB], da[NJB];
+      f32x4 z[NK][4];
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        if (16 * jb >= n) {
+          sg[jb] = -INFINITY;
+          da[jb] = 0.f;
+          continue;
+        }
+        const int q = KEEP ? jb : 0;
+        sr_features(pix, piy, vix, viy, N[jb].px, N[jb].py, N[jb].vx, N[jb].vy, f[q]);
+        sr_pair_mlp(W, kq, f[q], l1[q], z[q]);
+        sg[jb] = sr_score(z[q], vs + N[jb].j * SR_LDV + 4 * kq, N[jb], 16 * jb + pp == i);
+        const float* hrow = hs + N[jb].j * LDH + kq * HQ;
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < HQ; k += 4) {
+          const f32x4 h4 = *reinterpret_cast<const f32x4*>(hrow + k);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) d = fmaf(dsq[k + c], h4[c], d);
+        }
+        da[jb] = quarters_sum(d);
+      }
+      float mx = sg[0];
+#pragma unroll
+      for (int jb = 1; jb < NJB; ++jb) mx = fmaxf(mx, sg[jb]);
+      mx = row_max16(mx);
+      float at[NJB], den = 0.f;
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        at[jb] = N[jb].ok ? __expf(sg[jb] - mx) : 0.f;
+        den += at[jb];
+      }
+      const float inv = 1.0f / row_sum16(den);
+      float dot = 0.f;
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        at[jb] *= inv;
+        dot = fmaf(at[jb], da[jb], dot);
+      }
+      dot = row_sum16(dot);
+      // pass 2: the adjoints
+#pragma unroll
+      for (int jb = 0; jb < NJB; ++jb) {
+        if (16 * jb >= n) continue;
+        const int q = KEEP ? jb : 0;
+        if (!KEEP) {
+          sr_features(pix, piy, vix, viy, N[jb].px, N[jb].py, N[jb].vx, N[jb].vy, f[q]);
+          sr_pair_mlp(W, kq, f[q], l1[q], z[q]);
+        }
+        // neighbour sums: dh_j += a_ij dS_i ; d[v_j | c_j] += dsigma_ij [l2_ij | 1]
+#pragma unroll
+        for (int k = 0; k < HQ; ++k) dhq[jb][k] = fmaf(at[jb], dsq[k], dhq[jb][k]);
+        // softmax adjoint (0 on padding lanes; sigma_ii is the constant -1000: nothing flows through it)
+        const float dsg = (16 * jb + pp == i) ? 0.f : at[jb] * (da[jb] - dot);
+        dc[jb] += dsg;
+        const float* vrow = vs + N[jb].j * SR_LDV + 4 * kq;
+        f32x4 dz2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(vrow + 16 * t);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dv[jb][t][r] = fmaf(dsg, fmaxf(z[q][t][r], 0.f), dv[jb][t][r]);
+            dz2[t][r] = z[q][t][r] > 0.f ? dsg * v4[r] : 0.f;
+          }
+        }
+        if (TRAIN) {
+          // dz1^T (32 units x 16 pairs) = W2^T dz2^T: B operand = registers in the D layout of the forward product
+          f32x4 d1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              d1[0] = MFMA16(w2t[0][t][r], dz2[t][r], d1[0]);
+              d1[1] = MFMA16(w2t[1][t][r], dz2[t][r], d1[1]);
+            }
+          // d1[tp][r] = unit 16 tp + 4 kq + r = u(s = 4 tp + r): the units this lane holds l1 for.
+          // All three weight gradients contract over the 16 PAIRS: dz2, l1, dz1 and the features go through the wave's
+          // LDS tiles into A / B fragments (pair = step + 4 k)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(Zs + pp * SR_LDZ + 16 * t + 4 * kq) = dz2[t];
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp) {
+            *reinterpret_cast<f32x4*>(L1s + pp * SR_LD1 + 16 * tp + 4 * kq) =
+                f32x4{l1[q][4 * tp], l1[q][4 * tp + 1], l1[q][4 * tp + 2], l1[q][4 * tp + 3]};
+            f32x4 g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r] = l1[q][4 * tp + r] > 0.f ? d1[tp][r] : 0.f;
+            *reinterpret_cast<f32x4*>(Gs + pp * SR_LD1 + 16 * tp + 4 * kq) = g;
+          }
+          if (kq == 0) *reinterpret_cast<f32x4*>(Gs + pp * SR_LD1 + 32) = f32x4{f[q][0], f[q][1], f[q][2], 1.0f};
+          wave_lds_sync();
+#pragma unroll
+          for (int sp = 0; sp < 4; ++sp) {  // k step sp: MFMA k index kq <-> pair sp + 4 kq
+            const int pr = sp + 4 * kq;
+            const float* zr = Zs + pr * SR_LDZ + pp;
+            const float* lr = L1s + pr * SR_LD1 + pp;
+            const float* gr = Gs + pr * SR_LD1 + pp;
+            const float b0 = lr[0], b1v = lr[16];
+            const float fc = pp < 4 ? gr[32] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+              const float av = zr[16 * tm];
+              db2[tm] += av;
+              dW2[tm][0] = MFMA16(av, b0, dW2[tm][0]);
+              dW2[tm][1] = MFMA16(av, b1v, dW2[tm][1]);
+            }
+            dW1[0] = MFMA16(gr[0], fc, dW1[0]);
+            dW1[1] = MFMA16(gr[16], fc, dW1[1]);
+          }
+          wave_lds_sync();  // the tiles are rewritten by the next block
+        }
+      }
+    }
+    // the four waves' neighbour sums meet in LDS (region A: every wave must be done with its tiles), one j-block per
+    // round, fixed order
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) {
+      if (16 * jb >= n) break;
+      __syncthreads();
+      float* mine = red + (w * 16 + pp) * LDC;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(mine + 16 * t + 4 * kq) = dv[jb][t];
+      if (kq == 0) mine[64] = dc[jb];
+#pragma unroll
+      for (int k = 0; k < HQ; k += 4)
+        *reinterpret_cast<f32x4*>(mine + 68 + kq * HQ + k) = f32x4{dhq[jb][k], dhq[jb][k + 1], dhq[jb][k + 2], dhq[jb][k + 3]};
+      __syncthreads();
+      for (int e = threadIdx.x; e < 16 * (65 + H); e += 256) {
+        const int jl = e / (65 + H), c = e - jl * (65 + H), j = 16 * jb + jl;
+        if (j >= n) break;
+        const float* r0 = red + jl * LDC + (c < 65 ? c : c + 3);
+        const float v = (r0[0] + r0[16 * LDC]) + (r0[32 * LDC] + r0[48 * LDC]);
+        if (c < 65) {
+          a.dvc[(size_t)(s0 + j) * a.ldv + c] = v;
+        } else {
+          float* d = a.dh + (size_t)(s0 + j) * a.ld_dh + (c - 65);
+          *d = a.accumulate_dh ? *d + v : v;
+        }
+      }
+    }
+    __syncthreads();  // region A and the staged scene are free again
+  }
+
+  if (TRAIN) {
+    // one partial block per workgroup: [64][33] = dW2 | db2, then [32][4] = dW1 | db1
+    float* mine = smem + w * SR_WG_FLOATS;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * tm + 4 * kq + r;
+        mine[m * 33 + pp] = dW2[tm][0][r];
+        mine[m * 33 + 16 + pp] = dW2[tm][1][r];
+      }
+      const float sb = quarters_sum(db2[tm]);
+      if (kq == 0) mine[(16 * tm + pp) * 33 + 32] = sb;
+    }
+    if (pp < 4) {
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[64 * 33 + (16 * tp + 4 * kq + r) * 4 + pp] = dW1[tp][r];
+    }
+    __syncthreads();
+    float* out = a.partials + (size_t)blockIdx.x * SR_WG_FLOATS;
+    for (int e = threadIdx.x; e < SR_WG_FLOATS; e += 256)
+      out[e] = (smem[e] + smem[SR_WG_FLOATS + e]) + (smem[2 * SR_WG_FLOATS + e] + smem[3 * SR_WG_FLOATS + e]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int sr_grid(int S) { return S < 256 ? S : 256; }  // persistent: one workgroup per CU walks scenes sc, sc + grid, ...
+static int sr_njb(int max_n) { return max_n <= 16 ? 1 : max_n <= 32 ? 2 : 4; }
+
+extern "C" {
+
+int mggan_social_rows_grid(int S) { return sr_grid(S); }
+int mggan_social_rows_partial_floats(void) { return SR_WG_FLOATS; }
+
+#define SR_FWD(HH, NN) hipLaunchKernelGGL((social_rows_fwd_kernel<HH, NN>), dim3(sr_grid(S)), dim3(256), 0, stream, a)
+#define SR_BWD(HH, NN, TT, KK) \
+  hipLaunchKernelGGL((social_rows_bwd_kernel<HH, NN, TT, KK>), dim3(sr_grid(S)), dim3(256), 0, stream, a)
+
+int mggan_social_rows_fwd(int S, const int* scenes, int H, int max_n, const float* xy_last, const float* dxdy_last,
+                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* vc,
+                          int ldv, const float* h, int ld_h, float* Sout, int ld_s, hipStream_t stream) {
+  MG_CHECK_ARG(H == 32 || H == 64, "social_rows_fwd: hidden size %d not built (32 or 64)", H);
+  MG_CHECK_ARG(S >= 0 && max_n >= 0 && max_n <= 64 && xy_mod >= 0, "social_rows_fwd: bad sizes (S %d, max_n %d)", S, max_n);
+  if (S == 0) return MGGAN_OK;
+  MG_CHECK_ARG(scenes && xy_last && dxdy_last && W1 && b1 && W2 && b2 && vc && h && Sout, "social_rows_fwd: null pointer");
+  MG_CHECK_ARG(ldv >= SR_LDV && ldv % 4 == 0 && ld_h % 4 == 0 && ld_s % 4 == 0 && ((size_t)vc % 16) == 0 &&
+                   ((size_t)h % 16) == 0 && ((size_t)Sout % 16) == 0,
+               "social_rows_fwd: vc / h / S rows must be 16-byte aligned (ldv %d, ld_h %d, ld_s %d)", ldv, ld_h, ld_s);
+  SocRowsArgs a = {};
+  a.scenes = scenes; a.xy = xy_last; a.dxy = dxdy_last; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.vc = vc; a.h = h;
+  a.Sout = Sout; a.S = S; a.xy_mod = xy_mod; a.ldv = ldv; a.ld_h = ld_h; a.ld_s = ld_s;
+  const int njb = sr_njb(max_n);
+  if (H == 32) {
+    if (njb == 1) SR_FWD(32, 1); else if (njb == 2) SR_FWD(32, 2); else SR_FWD(32, 4);
+  } else {
+    if (njb == 1) SR_FWD(64, 1); else if (njb == 2) SR_FWD(64, 2); else SR_FWD(64, 4);
+  }
+  MG_LAUNCH_CHECK("social_rows_fwd");
+  return MGGAN_OK;
+}
+
+int mggan_social_rows_bwd(int S, const int* scenes, int H, int max_n, const float* xy_last, const float* dxdy_last,
+                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* vc,
+                          int ldv, const float* h, int ld_h, const float* dS, int ld_ds, float* dvc, float* dh, int ld_dh,
+                          int accumulate_dh, float* partials, hipStream_t stream) {
+  MG_CHECK_ARG(H == 32 || H == 64, "social_rows_bwd: hidden size %d not built (32 or 64)", H);
+  MG_CHECK_ARG(S >= 0 && max_n >= 0 && max_n <= 64 && xy_mod >= 0, "social_rows_bwd: bad sizes (S %d, max_n %d)", S, max_n);
+  if (S == 0) return MGGAN_OK;
+  MG_CHECK_ARG(scenes && xy_last && dxdy_last && W1 && b1 && W2 && b2 && vc && h && dS && dvc && dh,
+               "social_rows_bwd: null pointer");
+  MG_CHECK_ARG(ldv >= SR_LDV && ldv % 4 == 0 && ld_h % 4 == 0 && ld_ds % 4 == 0 && ((size_t)vc % 16) == 0 &&
+                   ((size_t)h % 16) == 0 && ((size_t)dS % 16) == 0,
+               "social_rows_bwd: vc / h / dS rows must be 16-byte aligned (ldv %d, ld_h %d, ld_ds %d)", ldv, ld_h, ld_ds);
+  SocRowsArgs a = {};
+  a.scenes = scenes; a.xy = xy_last; a.dxy = dxdy_last; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.vc = vc; a.h = h;
+  a.dS = dS; a.dvc = dvc; a.dh = dh; a.partials = partials; a.S = S; a.xy_mod = xy_mod; a.ldv = ldv; a.ld_h = ld_h;
+  a.ld_ds = ld_ds; a.ld_dh = ld_dh; a.accumulate_dh = accumulate_dh;
+  const int njb = sr_njb(max_n);
+  const bool train = partials != nullptr;
+  // (four blocks per row: the forward values of a row are recomputed in the adjoint pass instead of kept)
+#define SR_BWD_N(HH, TT) \
+  do { if (njb == 1) SR_BWD(HH, 1, TT, true); else if (njb == 2) SR_BWD(HH, 2, TT, true); else SR_BWD(HH, 4, TT, false); } while (0)
+  if (H == 32) {
+    if (train) SR_BWD_N(32, true); else SR_BWD_N(32, false);
+  } else {
+    if (train) SR_BWD_N(64, true); else SR_BWD_N(64, false);
+  }
+  MG_LAUNCH_CHECK("social_rows_bwd");
+  return MGGAN_OK;
+}
+
+}  // extern "C"

@@ -208,7 +208,8 @@ class _WgradDesc(ctypes.Structure):
 
 
 _DEFER = {"on": False, "descs": [], "keep": [], "gemms": [], "events": {}, "revents": {}, "after": []}
-TRACE_NOTES = {"wgrad_multi_flops": [], "wgrad_multi_bytes": [], "mlp_chain_flops": []}
+TRACE_NOTES = {"wgrad_multi_flops": [], "wgrad_multi_bytes": [], "mlp_chain_flops": [], "social_rows_fwd_pairs": [],
+               "social_rows_bwd_pairs": []}
 
 
 def defer_grad_reduce(on=True):
@@ -682,28 +683,17 @@ class SceneTables:
                 ped_prow[s:e] = P + np.arange(n) * n
                 P += n * n
         self.P, self.b, self.S = P, b, len(sse)
-        # tiles of the fused social kernels: runs of consecutive pedestrians with <= 64 pairs between them
-        # ({ped0, ped1, first pair, pair count}); None when a scene is too large for one tile
-        self.tiles, self.n_tiles = None, 0
-        if b and int(ped_n.max()) <= 64:
-            tl, q0, p0, cnt = [], 0, 0, 0
-            for q in range(b):
-                nq = int(ped_n[q]) if ped_n[q] > 1 else 0
-                if cnt + nq > 64 or q - q0 >= 64:
-                    tl.append((q0, q, p0, cnt))
-                    q0, p0, cnt = q, p0 + cnt, 0
-                cnt += nq
-            tl.append((q0, b, p0, cnt))
-            self.tiles_host = np.asarray(tl, np.int32)
-            self.n_tiles = len(tl)
+        # the row-structured social kernels walk whole scenes of up to 64 pedestrians and write only rows that belong
+        # to a scene: they need the scenes to tile [0, b) (every collated batch does)
+        self.max_n = int(ped_n.max()) if b else 0
+        self.cover = sum(e - s for s, e in sse) == b and all(e > s for s, e in sse)
+        self.rows_ok = self.cover and self.max_n <= 64
         cat = (lambda l: np.concatenate(l).astype(np.int32)) if pi else (lambda l: np.zeros(0, np.int32))
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.pair_i, self.pair_j = to(cat(pi)), to(cat(pj))
         self.ped_s0, self.ped_n, self.ped_prow, self.ped_scene = to(ped_s0), to(ped_n), to(ped_prow), to(ped_scene)
         self.scenes = to(np.asarray(sse, np.int32).reshape(-1, 2))
         self.seq_start_end = sse
-        if self.n_tiles:
-            self.tiles = to(self.tiles_host)
 
 
 _TABLE_CACHE = {}
@@ -766,76 +756,105 @@ def _out(slot, rows, cols, like):
     return v, slot.ld
 
 
+SOC_LDV = 68  # row stride of [v_j | c_j] for the row-structured kernels (16-byte aligned rows)
+
+
 def _social_fwd(xy_last, dxdy_last, h_ptr, ld_h, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat, S_ptr, ld_s, save, xy_mod,
                 like):
     """SocialFeatures -> EmbedSocialFeatures -> AttentionPooling for rows [0,b) of a hidden-state matrix given by pointer
     + row stride; S (b,Hh) is written through S_ptr / ld_s.  -> tuple of saved tensors for _social_bwd."""
     Fd = wat.shape[0]
     st = _s()
+    rows = tb.rows_ok
+    ldv = SOC_LDV if rows else 65
     W3b = _empty(Fd, 65, like=like)
     lib.mggan_social_w3b(_p(w3), _p(b3), _p(W3b), Fd, st)
     # Wh = h W_at^T + b_at and vc = Wh [W3 | b3] as one two-stage chain launch
-    Wh, vc = _empty(b, Fd, like=like), _empty(b, 65, like=like)
+    Wh, vc = _empty(b, Fd, like=like), _empty(b, ldv, like=like)
     a = _McArgs()
     a.X, a.ldx, a.rows, a.K0, a.n = h_ptr, ld_h, b, Hh, 2
     s0, s1 = a.s[0], a.s[1]
     s0.W, s0.bias, s0.out, s0.K, s0.N, s0.ldw, s0.trans, s0.act, s0.ld_out = _p(wat), _p(bat), _p(Wh), Hh, Fd, Hh, 0, ACT_NONE, Fd
-    s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out = _p(W3b), _p(vc), Fd, 65, 65, 1, ACT_NONE, 65
+    s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out = _p(W3b), _p(vc), Fd, 65, 65, 1, ACT_NONE, ldv
     if _load_lib().trace is not None:
         TRACE_NOTES["mlp_chain_flops"].append(2.0 * b * (Hh * Fd + Fd * 65))
     lib.mggan_mlp_chain(ctypes.addressof(a), st)
+    if rows:
+        # pair MLP (MFMA), scores, softmax and pooling in one launch; nothing per pair is stored: the backward pass
+        # recomputes the pair MLP from the positions
+        if _load_lib().trace is not None:
+            TRACE_NOTES["social_rows_fwd_pairs"].append(tb.P)
+        lib.mggan_social_rows_fwd(tb.S, _p(tb.scenes), Hh, tb.max_n, _p(xy_last), _p(dxdy_last), int(xy_mod), _p(w1),
+                                  _p(b1), _p(w2), _p(b2), _p(vc), ldv, h_ptr, ld_h, S_ptr, ld_s, st)
+        return (W3b, Wh, vc, None, None, None, None)
+    # a scene of more than 64 pedestrians (or scenes that do not tile the batch): per-stage kernels over the pair list
     P = tb.P
     feat = _empty(3, max(P, 1), like=like) if save else None      # feature-major [feature][pair]
     l1 = _empty(32, max(P, 1), like=like) if save else None
     l2 = _empty(64, max(P, 1), like=like) if save else None
     att = _empty(max(P, 1), like=like)
-    if tb.tiles is not None:  # pair MLP, scores, softmax and pooling in one launch
-        lib.mggan_social_attention_fwd(tb.n_tiles, _p(tb.tiles), P, Hh, _p(tb.pair_i), _p(tb.pair_j),
-                                       _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(xy_last), _p(dxdy_last),
-                                       _p(w1), _p(b1), _p(w2), _p(b2), _p(vc), h_ptr, ld_h, _p(feat), _p(l1), _p(l2),
-                                       _p(att), S_ptr, ld_s, int(xy_mod), st)
-    else:  # a scene of more than 64 pedestrians does not fit a tile
-        if xy_mod:
-            rep_n = b // xy_mod
-            xy_last, dxdy_last = xy_last.repeat(rep_n, 1), dxdy_last.repeat(rep_n, 1)
-        sigma = _empty(max(P, 1), like=like)
-        lib.mggan_social_pairs_fwd(P, _p(tb.pair_i), _p(tb.pair_j), _p(xy_last), _p(dxdy_last), _p(w1), _p(b1),
-                                   _p(w2), _p(b2), _p(vc), _p(feat), _p(l1), _p(l2), _p(sigma), st)
-        lib.mggan_social_softmax_fwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(sigma), h_ptr, ld_h,
-                                     _p(att), S_ptr, ld_s, st)
+    if xy_mod:
+        rep_n = b // xy_mod
+        xy_last, dxdy_last = xy_last.repeat(rep_n, 1), dxdy_last.repeat(rep_n, 1)
+    sigma = _empty(max(P, 1), like=like)
+    lib.mggan_social_pairs_fwd(P, _p(tb.pair_i), _p(tb.pair_j), _p(xy_last), _p(dxdy_last), _p(w1), _p(b1),
+                               _p(w2), _p(b2), _p(vc), _p(feat), _p(l1), _p(l2), _p(sigma), st)
+    lib.mggan_social_softmax_fwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(sigma), h_ptr, ld_h,
+                                 _p(att), S_ptr, ld_s, st)
     return (W3b, Wh, vc, feat, l1, l2, att)
 
 
-def _social_bwd(saved, h_ptr, ld_h, h_keep, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat, dS_ptr, ld_ds, dh_ptr, ld_dh,
-                accumulate_dh, train_w1, train_w3, owner, like):
+def _social_bwd(saved, xy_last, dxdy_last, xy_mod, h_ptr, ld_h, h_keep, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat, dS_ptr,
+                ld_ds, dh_ptr, ld_dh, accumulate_dh, train_w1, train_w3, owner, like):
     """Adjoint of _social_fwd.  dh (b,Hh) goes to dh_ptr / ld_dh (accumulate_dh: added to what is there); the weight
     gradients are queued / launched like everywhere else.  h_keep: the tensor that owns h (kept alive)."""
     W3b, Wh, vc, feat, l1, l2, att = saved
     root = root_of(owner)
     Fd, P = wat.shape[0], tb.P
     st = _s()
-    dsigma = _empty(max(P, 1), like=like)
-    dz2 = _empty(64, max(P, 1), like=like)
-    dz1 = _empty(32, max(P, 1), like=like)
-    dvc = _empty(b, 65, like=like)
-    if tb.tiles is not None:
-        lib.mggan_social_attention_bwd(tb.n_tiles, _p(tb.tiles), P, b, Hh, _p(tb.pair_i), _p(tb.pair_j),
-                                       _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(att), h_ptr, ld_h, dS_ptr,
-                                       ld_ds, _p(vc), _p(l1), _p(l2), _p(w2), _p(dsigma), _p(dz2), _p(dz1), _p(dvc),
-                                       dh_ptr, ld_dh, int(accumulate_dh), st)
+    rows = tb.rows_ok
+    ldv = SOC_LDV if rows else 65
+    dvc = _empty(b, ldv, like=like)
+    if rows:
+        part, grid, pf = None, 0, 0
+        if train_w1:  # one partial block [dW2 | db2 ; dW1 | db1] per workgroup, folded by the batched reduction
+            grid, pf = lib.mggan_social_rows_grid(tb.S), lib.mggan_social_rows_partial_floats()
+            part = _empty(grid * pf, like=like)
+        if _load_lib().trace is not None:
+            TRACE_NOTES["social_rows_bwd_pairs"].append(tb.P)
+        lib.mggan_social_rows_bwd(tb.S, _p(tb.scenes), Hh, tb.max_n, _p(xy_last), _p(dxdy_last), int(xy_mod), _p(w1),
+                                  _p(b1), _p(w2), _p(b2), _p(vc), ldv, h_ptr, ld_h, dS_ptr, ld_ds, _p(dvc), dh_ptr, ld_dh,
+                                  int(accumulate_dh), _p(part), st)
+        if train_w1:
+            p0 = part.data_ptr()
+            descs = ((p0, root.grad_ptr(w2), root.grad_ptr(b2), 64, 33, 32), (p0 + 4 * 64 * 33, root.grad_ptr(w1), root.grad_ptr(b1), 32, 4, 3))
+            if _DEFER["on"] and not _SIDE["dirty"]:
+                for k, (pp_, dw, db, M, Naug, lddw) in enumerate(descs):
+                    _queue_reduce(pp_, dw, db, M, Naug, 1, lddw, grid, 1, pf, keep=(part,) if k == 0 else ())
+            else:
+                arr = (_ReduceDesc * 2)(*[_ReduceDesc(pp_, dw, db or None, 0, 0, M, Naug, 1, lddw, grid, 1, pf, 0)
+                                          for pp_, dw, db, M, Naug, lddw in descs])
+                lib.mggan_grad_reduce_multi(ctypes.addressof(arr), 2, st)
+                if _SIDE["dirty"]:
+                    _SIDE["keep"].append(part)
     else:
+        if xy_mod:
+            pass  # (the per-stage kernels saved their features in the forward pass)
+        dsigma = _empty(max(P, 1), like=like)
+        dz2 = _empty(64, max(P, 1), like=like)
+        dz1 = _empty(32, max(P, 1), like=like)
         lib.mggan_social_softmax_bwd(b, Hh, _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(att), h_ptr, ld_h,
                                      dS_ptr, ld_ds, _p(dsigma), dh_ptr, ld_dh, int(accumulate_dh), st)
         lib.mggan_social_pairs_bwd(P, b, _p(tb.pair_j), _p(tb.ped_prow), _p(tb.ped_s0), _p(tb.ped_n), _p(dsigma),
                                    _p(vc), _p(l1), _p(l2), _p(w2), _p(dz2), _p(dz1), _p(dvc), st)
-    if train_w1:
-        with side_stream(dz2, dz1, l1, feat):
-            wgrad(dz2, P, l1, P, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64, fm=1)
-            wgrad(dz1, P, feat, P, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32, fm=1)
+        if train_w1:
+            with side_stream(dz2, dz1, l1, feat):
+                wgrad(dz2, P, l1, P, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64, fm=1)
+                wgrad(dz1, P, feat, P, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32, fm=1)
     # dWh = dvc [W3|b3]^T and dh += dWh W_at as one two-stage chain launch; d[W3|b3] = Wh^T dvc
     dWh = _empty(b, Fd, like=like)
     a = _McArgs()
-    a.X, a.ldx, a.rows, a.K0, a.n = _p(dvc), 65, b, 65, 2
+    a.X, a.ldx, a.rows, a.K0, a.n = _p(dvc), ldv, b, 65, 2
     s0, s1 = a.s[0], a.s[1]
     s0.W, s0.out, s0.K, s0.N, s0.ldw, s0.trans, s0.act, s0.ld_out = _p(W3b), _p(dWh), 65, Fd, 65, 0, ACT_NONE, Fd
     s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out, s1.accumulate = _p(wat), dh_ptr, Fd, Hh, Hh, 1, ACT_NONE, ld_dh, 1
@@ -844,8 +863,8 @@ def _social_bwd(saved, h_ptr, ld_h, h_keep, b, Hh, tb, w1, b1, w2, b2, w3, b3, w
     lib.mggan_mlp_chain(ctypes.addressof(a), st)
     if train_w3:
         with side_stream(Wh, dvc, dWh, h_keep):
-            wgrad(Wh, Fd, dvc, 65, root.grad_ptr(w3), 64, 0, b, 64, Fd)
-            wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, 65, root.grad_ptr(b3), 1, 0, b, 1, Fd)
+            wgrad(Wh, Fd, dvc, ldv, root.grad_ptr(w3), 64, 0, b, 64, Fd)
+            wgrad(Wh, Fd, dvc.data_ptr() + 4 * 64, ldv, root.grad_ptr(b3), 1, 0, b, 1, Fd)
             wgrad(dWh, Fd, h_ptr, ld_h, root.grad_ptr(wat), Hh, root.grad_ptr(bat), b, Hh, Fd)
         if _DEFER["on"]:
             _DEFER["keep"].append(h_keep)
@@ -863,21 +882,23 @@ class SocialAttentionFn(Function):
         saved = _social_fwd(xy_last, dxdy_last, _p(h), ld_h, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat, _p(S), Hh, save,
                             xy_mod, h)
         if save:
-            ctx.tb, ctx.owner, ctx.ld_h = tb, owner, ld_h
+            ctx.tb, ctx.owner, ctx.ld_h, ctx.xy_mod = tb, owner, ld_h, xy_mod
             ctx.train_w1, ctx.train_w3 = w1.requires_grad, w3.requires_grad
-            ctx.save_for_backward(h, w1, b1, w2, b2, w3, b3, wat, bat, *saved)
+            ctx.save_for_backward(h, w1, b1, w2, b2, w3, b3, wat, bat, xy_last, dxdy_last, *saved)
         return S
 
     @staticmethod
     def backward(ctx, dS):
-        h, w1, b1, w2, b2, w3, b3, wat, bat = ctx.saved_tensors[:9]
-        saved = ctx.saved_tensors[9:]
+        h, w1, b1, w2, b2, w3, b3, wat, bat, xy_last, dxdy_last = ctx.saved_tensors[:11]
+        saved = ctx.saved_tensors[11:]
         tb, ld_h = ctx.tb, ctx.ld_h
         b, Hh = h.shape
         dS, ld_ds = _rows2d(dS)
+        if dS.data_ptr() % 16:
+            dS = dS.clone()
         dh = _empty(b, Hh, like=h)
-        _social_bwd(saved, _p(h), ld_h, h, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat, _p(dS), ld_ds, _p(dh), Hh, 0,
-                    ctx.train_w1, ctx.train_w3, ctx.owner, h)
+        _social_bwd(saved, xy_last, dxdy_last, ctx.xy_mod, _p(h), ld_h, h, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat,
+                    _p(dS), ld_ds, _p(dh), Hh, 0, ctx.train_w1, ctx.train_w3, ctx.owner, h)
         return (None, None, dh if ctx.needs_input_grad[2] else None) + (None,) * 12
 
 
@@ -904,14 +925,14 @@ class TrunkJoinFn(Function):
         if save:
             ctx.tb, ctx.owner, ctx.dims = tb, owner, (b, W, Hh, Sc, Fd)
             ctx.train_w1, ctx.train_w3 = w1.requires_grad, w3.requires_grad
-            ctx.save_for_backward(buf, w1, b1, w2, b2, w3, b3, wat, bat, *saved)
+            ctx.save_for_backward(buf, w1, b1, w2, b2, w3, b3, wat, bat, xy_last, dxdy_last, *saved)
         ctx.set_materialize_grads(False)
         return alias_cols(buf, 0, W), alias_cols(buf, Hh + Sc, W)
 
     @staticmethod
     def backward(ctx, d_enc_h, d_soc):
-        buf, w1, b1, w2, b2, w3, b3, wat, bat = ctx.saved_tensors[:9]
-        saved = ctx.saved_tensors[9:]
+        buf, w1, b1, w2, b2, w3, b3, wat, bat, xy_last, dxdy_last = ctx.saved_tensors[:11]
+        saved = ctx.saved_tensors[11:]
         b, W, Hh, Sc, Fd = ctx.dims
         if d_enc_h is None:
             d_enc_h = torch.zeros(b, W, dtype=F32, device=buf.device)
@@ -924,8 +945,8 @@ class TrunkJoinFn(Function):
             d_enc_h[:, Hh + Sc:] += d_soc
         g = d_enc_h.data_ptr()
         # dS = d_enc_h[:, social block]; dh is ADDED to d_enc_h[:, lstm block] in place (this node is the only reader)
-        _social_bwd(saved, buf.data_ptr(), W, buf, b, Hh, ctx.tb, w1, b1, w2, b2, w3, b3, wat, bat, g + 4 * (Hh + Sc), W,
-                    g, W, 1, ctx.train_w1, ctx.train_w3, ctx.owner, buf)
+        _social_bwd(saved, xy_last, dxdy_last, 0, buf.data_ptr(), W, buf, b, Hh, ctx.tb, w1, b1, w2, b2, w3, b3, wat, bat,
+                    g + 4 * (Hh + Sc), W, g, W, 1, ctx.train_w1, ctx.train_w3, ctx.owner, buf)
         return (d_enc_h[:, :Hh],) + (None,) * 15
 
 
@@ -1520,16 +1541,16 @@ class DRowsBodyFn(Function):
         if save:
             ctx.cfg = (D, tb, K, soc_blocks, b, T, W, (Hs, w_in, w_pe, w_sc),
                        (Wpe[0].requires_grad, fc[0].weight.requires_grad, fc[4].weight.requires_grad), pred.shape,
-                       None if pred2 is None else pred2.shape)
-            ctx.save_for_backward(X, x, outs_pe[0], *soc_saved)
+                       None if pred2 is None else pred2.shape, xy_mod)
+            ctx.save_for_backward(X, x, outs_pe[0], xy_last, dxdy_last, *soc_saved)
         return X
 
     @staticmethod
     def backward(ctx, dX):
-        (D, tb, K, soc_blocks, b, T, W, (Hs, w_in, w_pe, w_sc), train, pshape, p2shape) = ctx.cfg
+        (D, tb, K, soc_blocks, b, T, W, (Hs, w_in, w_pe, w_sc), train, pshape, p2shape, xy_mod) = ctx.cfg
         sv = ctx.saved_tensors
-        X, x, h_pe = sv[:3]
-        soc_saved = sv[3:]
+        X, x, h_pe, xy_last, dxdy_last = sv[:5]
+        soc_saved = sv[5:]
         R = K * b
         c_in, c_pe, c_sc = Hs, Hs + w_in, Hs + w_in + w_pe
         pe = D.pred_encoder
@@ -1545,8 +1566,8 @@ class DRowsBodyFn(Function):
         # DRowsHeadsFn.backward and has no other reader)
         nsoc = soc_blocks * b
         sw = (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, Wat.weight, Wat.bias)
-        _social_bwd(soc_saved, _p(X) + 4 * c_in, W, X, nsoc, w_in + w_pe, tb, *sw, _p(dX), W, _p(dX) + 4 * c_in, W, 1,
-                    train_s1, train_s3, D.social, X)
+        _social_bwd(soc_saved, xy_last, dxdy_last, xy_mod, _p(X) + 4 * c_in, W, X, nsoc, w_in + w_pe, tb, *sw, _p(dX), W,
+                    _p(dX) + 4 * c_in, W, 1, train_s1, train_s3, D.social, X)
         din = None
         if need_in:  # adjoint of the broadcast
             din = _empty(b, w_in, like=X)

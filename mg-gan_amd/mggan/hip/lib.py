@@ -39,7 +39,8 @@ def parse_header(path=HEADER_PATH):
 
 
 # functions whose int return value is data, not a status code
-_VALUE_RETURNING = {"mggan_version", "mggan_wgrad_splits", "mggan_lstm_prep_size", "mggan_cnn_bwd_grid", "mggan_cnn_grid", "mggan_comm_arena_bytes"}
+_VALUE_RETURNING = {"mggan_version", "mggan_wgrad_splits", "mggan_lstm_prep_size", "mggan_cnn_bwd_grid", "mggan_cnn_grid", "mggan_comm_arena_bytes", "mggan_social_rows_grid",
+                    "mggan_social_rows_partial_floats"}
 
 _lib = None
 

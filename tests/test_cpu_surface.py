@@ -143,10 +143,12 @@ def test_selection_indices_and_row_tables():
     assert tb.P == 4 + 16 and tb.ped_n.tolist() == [1, 2, 2, 4, 4, 4, 4]
     assert tb.ped_prow.tolist() == [0, 0, 2, 4, 8, 12, 16]
     assert tb.pair_i[:4].tolist() == [1, 1, 2, 2] and tb.pair_j[:4].tolist() == [1, 2, 1, 2]
-    # the discriminator's masked path passes the scene list repeated K times: one copy of every scene is kept, and the
-    # tiles of the fused kernels address the same pair ranges as the per-pedestrian tables
+    assert tb.rows_ok and tb.max_n == 4 and tb.scenes.tolist() == [[0, 1], [1, 3], [3, 7]]
+    # the discriminator's masked path passes the scene list repeated K times: one copy of every scene is kept
     rep = SceneTables([[0, 2], [2, 5]] * 3, 5, "cpu")
-    assert rep.P == 4 + 9 and rep.ped_prow.tolist() == [0, 2, 4, 7, 10] and rep.tiles_host.tolist() == [[0, 5, 0, 13]]
+    assert rep.P == 4 + 9 and rep.ped_prow.tolist() == [0, 2, 4, 7, 10] and rep.S == 2 and rep.rows_ok
+    # scenes that do not tile the batch, or a scene of more than 64 pedestrians: the per-stage kernels
+    assert not SceneTables([[0, 2], [3, 5]], 5, "cpu").rows_ok and not SceneTables([[0, 65]], 65, "cpu").rows_ok
 
 
 def test_host_rng_follows_reference_draw_order(golden):
