@@ -389,11 +389,12 @@ int mggan_inv_counts(const int* counts, int g, float* inv_count, mggan_stream_t 
 /* flat parameter buffer + segment table: elem_seg[i] = segment of element i (-1 = padding),
  * active[s] = segment takes part in this step (grad not None), seg_step[s] = Adam step count.
  * zero_grad != 0: the consumed gradients are left at 0 instead of their clipped values (saves the caller's
- * memset before the next backward pass). */
+ * memset before the next backward pass).  lr_dev != NULL: the learning rate is read from that device word instead of
+ * `lr` (a captured HIP graph then follows the per-epoch schedule without being captured again). */
 int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, const int* elem_seg, int nseg,
-                     const unsigned char* active, int* seg_step, float max_norm, double lr, double beta1, double beta2,
-                     double eps, double weight_decay, int zero_grad, double* workspace, float* norm_out,
-                     mggan_stream_t stream);
+                     const unsigned char* active, int* seg_step, float max_norm, double lr, const double* lr_dev,
+                     double beta1, double beta2, double eps, double weight_decay, int zero_grad, double* workspace,
+                     float* norm_out, mggan_stream_t stream);
 
 /* Fused decoder backward: BPTT + in-kernel per-generator weight gradients (dW_hh and dW1[:, :H] on MFMA).
  * n_gens*NW persistent workgroups; workgroup (g, w) leaves one partial block of `wlen` floats at

@@ -520,9 +520,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, float* grad, f
                                                     const int* __restrict__ elem_seg,
                                                     const unsigned char* __restrict__ active,
                                                     const int* __restrict__ seg_step, const double* __restrict__ partial,
-                                                    float max_norm, double lr, double beta1, double beta2,
-                                                    double eps_d, double wd, int zero_grad, float* norm_out) {
+                                                    float max_norm, double lr_arg, const double* __restrict__ lr_dev,
+                                                    double beta1, double beta2, double eps_d, double wd, int zero_grad,
+                                                    float* norm_out) {
   __shared__ double red[256];
+  const double lr = lr_dev ? *lr_dev : lr_arg;  // device-resident: a captured graph follows the schedule
   red[threadIdx.x] = threadIdx.x < NORM_BLOCKS ? partial[threadIdx.x] : 0.0;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -965,9 +967,9 @@ int mggan_inv_counts(const int* counts, int g, float* inv_count, hipStream_t str
 
 /* workspace: 256 doubles */
 int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, const int* elem_seg, int nseg,
-                     const unsigned char* active, int* seg_step, float max_norm, double lr, double beta1, double beta2,
-                     double eps, double weight_decay, int zero_grad, double* workspace, float* norm_out,
-                     hipStream_t stream) {
+                     const unsigned char* active, int* seg_step, float max_norm, double lr, const double* lr_dev,
+                     double beta1, double beta2, double eps, double weight_decay, int zero_grad, double* workspace,
+                     float* norm_out, hipStream_t stream) {
   MG_CHECK_ARG(param && grad && m && v && elem_seg && active && seg_step && workspace, "clip_adamw: null pointer");
   if (n == 0) return MGGAN_OK;
   hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, grad, n, elem_seg, active,
@@ -975,7 +977,7 @@ int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, cons
   int blocks = cdiv(n, 256 * 4);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, m, v, n, elem_seg, active, seg_step,
-                     workspace, max_norm, lr, beta1, beta2, eps, weight_decay, zero_grad, norm_out);
+                     workspace, max_norm, lr, lr_dev, beta1, beta2, eps, weight_decay, zero_grad, norm_out);
   MG_LAUNCH_CHECK("clip_adamw");
   return MGGAN_OK;
 }

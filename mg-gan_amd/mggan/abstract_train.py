@@ -4,6 +4,7 @@ One iteration = discriminator step -> generator step -> PM-network step (:136-15
 import abc
 import math
 import os
+import time
 from argparse import Namespace
 from collections import defaultdict
 from pathlib import Path
@@ -122,7 +123,7 @@ class MultiGeneratorGAN(abc.ABC):
         self.total_iterations += 1
         self.dist.check()
 
-    def capture_iteration(self, batch, warmup=3):
+    def capture_iteration(self, batch, warmup=3, pool=None):
         """Capture one full D+G+PM iteration on `batch` into a HIP graph (needs --rng device: no host
         sync anywhere in the iteration).  Returns replay(metrics) which re-runs the iteration on the
         same static batch tensors (copy new data into them to change the input).  `warmup` eager iterations run
@@ -189,7 +190,9 @@ class MultiGeneratorGAN(abc.ABC):
                 graph.enable_debug_mode()
             self._static_metrics = True
             try:
-                with torch.cuda.graph(graph):
+                # pool: graphs that are only ever replayed one after the other (train()'s graph cache) share their
+                # scratch memory -- nothing but the metric buffer is read after a replay
+                with torch.cuda.graph(graph, pool=pool):
                     self.train_iteration(batch, captured)
             finally:
                 self._static_metrics = False
@@ -208,11 +211,28 @@ class MultiGeneratorGAN(abc.ABC):
                 self._fetch([(metrics, items, snap) for _, items, snap in pending])
 
         replay.graph = graph
+        replay.pending = pending  # [(metrics dict at capture, [(key, slot | (slot, slot))], snapshot buffer)]
         return replay
+
+    def graph_mode(self):
+        """Does train() replay captured iterations?  --graph on | off | auto (auto: whenever the configuration allows it).
+        A captured iteration cannot contain a host synchronisation (so: the device RNG) nor host decisions that change
+        from one iteration to the next (--num_gen_steps gating, the epoch-dependent target of --weighting_target mgan);
+        the learning rate is read from device memory, so the cosine schedule needs no re-capture."""
+        cfg = self.config
+        mode = getattr(cfg, "graph", "auto")
+        ok = (getattr(self.rng, "on_device", False) and int(cfg.num_gen_steps) == 1 and cfg.weighting_target != "mgan")
+        if mode == "on" and not ok:
+            raise ValueError("--graph on needs --rng device, --num_gen_steps 1 and a --weighting_target other than 'mgan'")
+        return ok and mode != "off"
 
     def train(self):
         cfg = self.config
         kw = dict(synthetic_scenes=getattr(cfg, "synthetic_scenes", 64), synthetic_peds=getattr(cfg, "synthetic_peds", 0))
+        if getattr(cfg, "cache_device", 0):
+            kw["cache_device"] = self.device
+        graphs = self.iteration_graphs = IterationGraphs(self, getattr(cfg, "graph_shapes", 8)) if self.graph_mode() else None
+        self.epoch_seconds, self.epoch_iterations = [], []  # wall time of the training loop of every epoch (bench.py)
         train_loader = get_dataloader(dataset=cfg.dataset, phase="train", augment=cfg.augment,
                                       batch_size=cfg.batch_size, workers=cfg.workers, shuffle=True, **kw)
         val_loader = get_dataloader(dataset=cfg.dataset, phase="val", augment=False, batch_size=cfg.batch_size,
@@ -226,9 +246,27 @@ class MultiGeneratorGAN(abc.ABC):
             self.G.train()
             metrics = defaultdict(list)
             self.dist.host_barrier()  # loaders, validation and checkpoints are per-rank host phases
+            torch.cuda.synchronize()
+            t_epoch, n_it = time.perf_counter(), 0
+            # the logged losses stay on the device until the end of the epoch (one read-back every 64 iterations at most):
+            # an eager iteration is host-bound, and a read-back per step drains the launch queue three times per iteration
+            keep_defer, self.defer_metrics = getattr(self, "defer_metrics", False), True
             for batch in train_loader:
+                n_it += 1
+                if graphs is not None and graphs.step(batch, metrics):
+                    continue
                 batch = self.to_device(batch)
                 self.train_iteration(batch, metrics)
+                if n_it % 64 == 0 and hasattr(self, "flush_metrics"):
+                    self.flush_metrics()
+            self.defer_metrics = keep_defer
+            if hasattr(self, "flush_metrics"):
+                self.flush_metrics()
+            if graphs is not None:
+                graphs.flush(metrics)  # the epoch's replayed iterations: one D2H of their summed metric snapshots
+            torch.cuda.synchronize()
+            self.epoch_seconds.append(time.perf_counter() - t_epoch)
+            self.epoch_iterations.append(n_it)
             self.dist.check(sync=True)
 
             if self.epoch % cfg.val_every == 0:
@@ -249,6 +287,8 @@ class MultiGeneratorGAN(abc.ABC):
             if self.epoch % cfg.save_every == 0:
                 self.save()
             self.l2_weight *= cfg.l2_decay_rate
+            if hasattr(self, "_set_l2_weight"):
+                self._set_l2_weight(self.l2_weight)
             self.lr_schedulerD.step()
             self.lr_schedulerG.step()
             self.writer.save()
@@ -305,6 +345,102 @@ class MultiGeneratorGAN(abc.ABC):
     @abc.abstractmethod
     def check_accuracy(self, loader, vis=False, prefix="", num_k=20):
         pass
+
+
+class IterationGraphs:
+    """train()'s graph cache (reference loop: abstract_train.py:114-168).  Key = the batch's shape: its scene sizes and
+    tensor shapes.  A shape seen for the first time gets static input buffers and runs ONE eager iteration on them (which
+    also builds, and pins, every per-shape table); at its second appearance the iteration is captured (nothing executes
+    during a capture) and replayed; from then on a batch of that shape costs one copy into the static buffers and one
+    graph launch.  Batches with NaN ground truth (masked pedestrians), shapes beyond `limit` and a failed capture take
+    the eager path.  The logged losses of replayed iterations are summed on the device and read back once per epoch."""
+
+    class Entry:
+        def __init__(self, static):
+            self.static, self.replay, self.failed = static, None, False
+
+    def __init__(self, trainer, limit=8):
+        self.tr, self.limit, self.entries = trainer, int(limit), {}
+        self.pool = torch.cuda.graph_pool_handle()
+        self._acc = {}  # id(snapshot buffer) -> [buffer, running sum, count, items]
+        self.replays = self.eager = 0
+
+    @staticmethod
+    def key_of(batch):
+        sse = batch["seq_start_end"]
+        return (tuple(int(e) - int(s) for s, e in sse),) + tuple(
+            (k, tuple(v.shape)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+
+    def step(self, batch, metrics):
+        """-> True when the batch was consumed here (eagerly on its static buffers, or as a replay)."""
+        from mggan.hip import functions as HF
+
+        tr = self.tr
+        if "loss_mask" in batch:
+            valid = batch["loss_mask"] is None
+        else:
+            gt = batch["gt_xy"]
+            valid = (not gt.is_cuda) and not bool(torch.isnan(gt).any())  # (a device batch would need a sync to tell)
+        if not valid:
+            return False
+        key = self.key_of(batch)
+        ent = self.entries.get(key)
+        if ent is None:
+            if len(self.entries) >= self.limit:
+                return False
+            static = {k: (v.to(tr.device).clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+            static["seq_start_end"] = [[int(s), int(e)] for s, e in batch["seq_start_end"]]  # the tables are keyed by it
+            static["loss_mask"] = None
+            ent = self.entries[key] = self.Entry(static)
+            with HF.pin_tables():
+                tr.train_iteration(static, metrics)
+            self.eager += 1
+            return True
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                ent.static[k].copy_(v, non_blocking=True)
+        if ent.replay is None and not ent.failed:
+            try:
+                with HF.pin_tables():
+                    ent.replay = tr.capture_iteration(ent.static, warmup=0, pool=self.pool)
+            except Exception as exc:  # noqa: BLE001
+                ent.failed = True
+                print("[mggan] graph capture failed for batch shape {} ({}: {}); eager launches for this shape".format(
+                    key[0][:8], type(exc).__name__, exc))
+                torch.cuda.synchronize()
+        if ent.replay is None:
+            tr.train_iteration(ent.static, metrics)
+            self.eager += 1
+            return True
+        ent.replay(None, False)
+        tr.total_iterations += 1
+        self.replays += 1
+        seen = set()
+        for _, items, snap in ent.replay.pending:  # the replay refreshed its snapshot buffers: add them up on the device
+            acc = self._acc.setdefault(id(snap), [snap, torch.zeros_like(snap), 0, set()])
+            acc[3].add(tuple(items))
+            if id(snap) not in seen:
+                seen.add(id(snap))
+                acc[1] += snap
+                acc[2] += 1
+        return True
+
+    def flush(self, metrics):
+        """The replayed iterations of the epoch enter `metrics` as their mean, once per iteration (the epoch's logged
+        value is the mean over its iterations, abstract_train.py:194)."""
+        tr = self.tr
+        for acc in self._acc.values():
+            snap, total, count, item_lists = acc
+            if count == 0:
+                continue
+            red = tr.dist.all_reduce_(total.clone()) if tr.dist.enabled else total
+            v = (red / count).cpu().numpy()
+            for items in sorted(item_lists):
+                for key, slot in items:
+                    val = float(v[slot] if isinstance(slot, int) else v[slot[0]] + v[slot[1]])
+                    metrics[key].extend([val] * count)
+            total.zero_()
+            acc[2] = 0
 
 
 def read_meta_tags(path):

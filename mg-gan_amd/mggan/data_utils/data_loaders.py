@@ -9,20 +9,32 @@ from mggan.data_utils import synthetic
 class SyntheticScenes(torch.utils.data.Dataset):
     """Each item is one batch of `scenes_per_batch` scenes (already collated)."""
 
-    def __init__(self, num_batches, scenes_per_batch, peds_per_scene=None, seed=0):
+    def __init__(self, num_batches, scenes_per_batch, peds_per_scene=None, seed=0, cache_device=None):
         self.num_batches, self.spb, self.pps, self.seed = num_batches, scenes_per_batch, peds_per_scene, seed
         self.dataset_name = "synthetic"
+        # cache_device: a produced batch stays resident in HBM (288 GB: an epoch of 64x20-pedestrian batches is 22 MB
+        # each); later epochs hand over device tensors, with the all-valid verdict of the NaN scan taken once on the host
+        self.cache_device, self._cache = cache_device, {}
 
     def __len__(self):
         return self.num_batches
 
     def __getitem__(self, i):
+        hit = self._cache.get(i)
+        if hit is not None:
+            return hit
         sizes = synthetic.scene_sizes(self.spb, self.pps, seed=self.seed + i)
-        return synthetic.make_batch(sizes, seed=self.seed + 1000 + i)
+        batch = synthetic.make_batch(sizes, seed=self.seed + 1000 + i)
+        if self.cache_device is not None:
+            mask = ~batch["gt_xy"].isnan().any(2).any(0)
+            batch = {k: (v.to(self.cache_device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            batch["loss_mask"] = None if bool(mask.all()) else mask.to(self.cache_device)
+            self._cache[i] = batch
+        return batch
 
 
 def get_dataloader(dataset, phase, augment=False, batch_size=8, workers=0, shuffle=False, synthetic_scenes=64,
-                   synthetic_peds=0, crop_device=None):
+                   synthetic_peds=0, crop_device=None, cache_device=None):
     """crop_device: a HIP device -> the image crops of un-augmented on-disk datasets are cut on the GPU from scene
     images resident in HBM (mggan/data_utils/device_crops.py); `features` then arrives on that device."""
     assert phase in ("train", "val", "test")
@@ -52,5 +64,7 @@ def get_dataloader(dataset, phase, augment=False, batch_size=8, workers=0, shuff
                                            collate_fn=seq_collate_scene, drop_last=False)
     n_batches = max(1, synthetic_scenes // max(batch_size, 1))
     ds = SyntheticScenes(n_batches if phase == "train" else max(1, n_batches // 4), batch_size,
-                         synthetic_peds if synthetic_peds > 0 else None, seed={"train": 0, "val": 7, "test": 13}[phase])
-    return torch.utils.data.DataLoader(ds, batch_size=None, shuffle=shuffle, num_workers=workers)
+                         synthetic_peds if synthetic_peds > 0 else None, seed={"train": 0, "val": 7, "test": 13}[phase],
+                         cache_device=cache_device)
+    return torch.utils.data.DataLoader(ds, batch_size=None, shuffle=shuffle,
+                                       num_workers=0 if cache_device is not None else workers)

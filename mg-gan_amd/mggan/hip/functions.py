@@ -696,7 +696,45 @@ class SceneTables:
         self.seq_start_end = sse
 
 
-_TABLE_CACHE = {}
+# Per-batch index tables, row tables and random-number pools are built lazily (with host copies) and cached by shape or
+# by the identity of the caller's scene list.  A captured HIP graph holds raw pointers into them, so whatever an iteration
+# touched while `pin_tables()` was active (the trainer's graph cache: the first eager iteration on a static batch and
+# its capture) is never evicted; everything else is bounded.
+_PIN = {"on": 0}
+
+
+class pin_tables:
+    def __enter__(self):
+        _PIN["on"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _PIN["on"] -= 1
+        return False
+
+
+class BoundedCache(dict):
+    def __init__(self, limit):
+        super().__init__()
+        self.limit, self.pinned = limit, set()
+
+    def get(self, key, default=None):
+        hit = super().get(key, default)
+        if hit is not default and _PIN["on"]:
+            self.pinned.add(key)
+        return hit
+
+    def put(self, key, value):
+        if len(self) - len(self.pinned) > self.limit:
+            for k in [k for k in self if k not in self.pinned]:
+                del self[k]
+        self[key] = value
+        if _PIN["on"]:
+            self.pinned.add(key)
+        return value
+
+
+_TABLE_CACHE = BoundedCache(64)
 
 
 def scene_fingerprint(seq_start_end):
@@ -715,9 +753,7 @@ def scene_tables(seq_start_end, b, device):
     if hit is not None and hit[0] is seq_start_end and hit[2] == fp:
         return hit[1]
     t = SceneTables(seq_start_end, b, device)
-    if len(_TABLE_CACHE) > 64:
-        _TABLE_CACHE.clear()
-    _TABLE_CACHE[key] = (seq_start_end, t, fp)
+    _TABLE_CACHE.put(key, (seq_start_end, t, fp))
     return t
 
 
@@ -1012,7 +1048,7 @@ class PoolTables:
         self.key = seq_start_end
 
 
-_POOL_CACHE = {}
+_POOL_CACHE = BoundedCache(64)
 
 
 def pool_tables(seq_start_end, device):
@@ -1023,10 +1059,7 @@ def pool_tables(seq_start_end, device):
         return hit
     t = PoolTables(seq_start_end, device)
     t.fp = fp
-    if len(_POOL_CACHE) > 64:
-        _POOL_CACHE.clear()
-    _POOL_CACHE[key] = t
-    return t
+    return _POOL_CACHE.put(key, t)
 
 
 class PoolHiddenFn(Function):

@@ -70,6 +70,12 @@ def get_parser():
     parser.add_argument("--bn_sync", type=str, choices=["global", "local"], default="global",
                         help="sharded runs: BatchNorm statistics over the global batch (all-reduced: same results as one "
                              "process) or per rank (what DistributedDataParallel does without SyncBatchNorm)")
+    parser.add_argument("--graph", type=str, choices=["auto", "on", "off"], default="auto",
+                        help="train(): replay the iteration as a captured HIP graph per batch shape (needs --rng device; "
+                             "auto = on whenever the configuration allows it), eager launches otherwise")
+    parser.add_argument("--graph_shapes", type=int, default=8, help="batch shapes the graph cache of train() keeps")
+    parser.add_argument("--cache_device", type=int, default=0,
+                        help="synthetic dataset: keep the produced batches resident in HBM after their first use")
     parser.add_argument("--synthetic_scenes", type=int, default=64, help="scenes per synthetic epoch")
     parser.add_argument("--synthetic_peds", type=int, default=0, help="pedestrians per scene (0 = ragged 1..6)")
     return parser

@@ -106,15 +106,12 @@ class MultiDiscriminatorTrajectory(FlatModule):
         self.ensure_flat()
         in_enc, scene = context
         b = in_xy.size(1)
-        cache = self.__dict__.setdefault("_pair_scenes", {})
+        cache = self.__dict__.setdefault("_pair_scenes", HF.BoundedCache(16))
         hit = cache.get(id(seq_start_end))
         fp = HF.scene_fingerprint(seq_start_end)
         if hit is None or hit[0] is not seq_start_end or hit[2] != fp:
-            if len(cache) > 16:
-                cache.clear()
-            hit = (seq_start_end, [[int(s), int(e)] for s, e in seq_start_end] +
-                   [[int(s) + b, int(e) + b] for s, e in seq_start_end], fp)
-            cache[id(seq_start_end)] = hit
+            hit = cache.put(id(seq_start_end), (seq_start_end, [[int(s), int(e)] for s, e in seq_start_end] +
+                                                [[int(s) + b, int(e) + b] for s, e in seq_start_end], fp))
         if self.pool_type == "sways":
             # one autograd node for the whole row pass (the row-pass nodes): rows [0,b) real, [b,2b) fake, both blocks with
             # social features (two independent single-sample passes), generator-id head on the fake half

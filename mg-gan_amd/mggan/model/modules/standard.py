@@ -86,15 +86,12 @@ class MultiGenerator(FlatModule):
     def _all_rows(self, n, b, dev):
         """Row table of "every generator on every (sample, pedestrian)": static per shape, cached."""
         key = (n, b, str(dev))
-        cache = self.__dict__.setdefault("_all_rows_cache", {})
+        cache = self.__dict__.setdefault("_all_rows_cache", HF.BoundedCache(16))
         rows = cache.get(key)
         if rows is None:
             g = self.n_gs
-            rows = HF.RolloutRows(np.tile(np.repeat(np.arange(g), b), n), np.tile(np.arange(b), n * g),
-                                  np.repeat(np.arange(n), g * b), g, b, dev)
-            if len(cache) > 16:
-                cache.clear()
-            cache[key] = rows
+            rows = cache.put(key, HF.RolloutRows(np.tile(np.repeat(np.arange(g), b), n), np.tile(np.arange(b), n * g),
+                                                 np.repeat(np.arange(n), g * b), g, b, dev))
         return rows
 
     def trunk(self, in_xy, in_dxdy, sub_batches, img, passes=1):

@@ -58,13 +58,11 @@ class DiscreteLatentGenerator(MultiGenerator):
 
     def _rows(self, R, dev):
         """Every row its own 'pedestrian', one generator, noise slot 0."""
-        cache = self.__dict__.setdefault("_rows_cache", {})
+        cache = self.__dict__.setdefault("_rows_cache", HF.BoundedCache(16))
         key = (R, str(dev))
         rows = cache.get(key)
         if rows is None:
-            if len(cache) > 16:
-                cache.clear()
-            rows = cache[key] = HF.RolloutRows(np.zeros(R, np.int64), np.arange(R), np.zeros(R, np.int64), 1, R, dev)
+            rows = cache.put(key, HF.RolloutRows(np.zeros(R, np.int64), np.arange(R), np.zeros(R, np.int64), 1, R, dev))
         return rows
 
     def _code(self, one_hot_rows):

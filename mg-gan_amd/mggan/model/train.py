@@ -46,6 +46,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         HF.register_unit_grad(self._one)
         self._w = {k: (self._one if float(v) == 1.0 else torch.full((), float(v), device=dev)) for k, v in
                    (("l2", config.l2_loss_weight), ("clf", config.clf_loss_weight), ("pi", config.pi_net_loss_weight))}
+        if float(getattr(config, "l2_decay_rate", 1)) != 1.0:  # decays per epoch (abstract_train.py:197): its own device word
+            self._w["l2"] = torch.full((), float(config.l2_loss_weight), device=dev)
         self.defer_metrics = False  # True: steps only enqueue work; fetch with flush_metrics()
         # legitimate de-duplications (same results): D's history context once per D step, and the
         # generator trunk once for {no-grad G call of the D step, G step} (G's weights do not change in between)
@@ -61,6 +63,11 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self.zero_grads_in_step = False
         self._pending = []
         self._bwd_stream = None
+
+    def _set_l2_weight(self, value):
+        """self.l2_weight decays per epoch (abstract_train.py:197); the backward pass reads it from device memory."""
+        if self._w["l2"] is not self._one:
+            self._w["l2"].fill_(float(value))
 
     # ---- metric plumbing ---------------------------------------------------------------
     def _emit(self, train_metrics, items):

@@ -12,7 +12,7 @@ from mggan.hip.lib import lib
 class FlatAdamW:
     def __init__(self, root, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         self.root = root.ensure_flat()
-        self.base_lr = self.lr = lr
+        self.base_lr = self._lr = lr
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         f = root._flat
         self.exp_avg = torch.zeros_like(f)
@@ -22,6 +22,17 @@ class FlatAdamW:
         self._ws = torch.zeros(256, dtype=torch.float64, device=f.device)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=f.device)
         self._flat_id = f.data_ptr()
+        # the learning rate the kernel reads lives on the device: a captured iteration follows the schedule
+        self._lr_dev = torch.full((1,), float(lr), dtype=torch.float64, device=f.device)
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        self._lr_dev.fill_(self._lr)
 
     def zero_grad(self):
         self.root.zero_grad_flat()
@@ -43,7 +54,7 @@ class FlatAdamW:
         lib.mggan_clip_adamw(r._flat.data_ptr(), r._flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                              self.exp_avg_sq.data_ptr(), r._flat.numel(), r._elem_seg.data_ptr(), self.nseg,
                              mask.data_ptr(), self.seg_step.data_ptr(), float(max_norm), float(self.lr),
-                             float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                             self._lr_dev.data_ptr(), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                              1 if zero_grad else 0, self._ws.data_ptr(), self.grad_norm.data_ptr(), st)
         if zero_grad:
             r._grad_clean = True  # every gradient written since the last memset has been consumed and zeroed

@@ -46,6 +46,7 @@ class DeviceRNG:
         self.plan = (1, 20, 1)  # noise sample sets of the D / G / PM generator calls (the trainer sets it from its config)
         self.d_steps = 1        # discriminator steps per iteration (1 + num_unrolling_steps)
         self._state = None
+        self._pools = None
         self._labels = self._noise = self._unif = None
         self._lab_used = self._noise_used = self._unif_used = 0
         self._shape = None
@@ -73,10 +74,17 @@ class DeviceRNG:
         n_unif = b * (nd * self.d_steps + K) if n_unif is None else n_unif
         n_labels = 4 * self.d_steps + 4 if n_labels is None else n_labels
         shape = (sets, b, Z, n_unif, n_labels, str(device))
-        if self._shape != shape:  # (re)allocate only when the batch shape changes: static addresses for graph replay
-            self._labels = torch.empty(max(n_labels, 1), dtype=torch.float32, device=device)
-            self._noise = torch.empty(max(sets, 1), b, Z, dtype=torch.float32, device=device)
-            self._unif = torch.empty(max(n_unif, 1), dtype=torch.float32, device=device)
+        if self._shape != shape:
+            # one pool per batch shape, kept: static addresses for graph replay (a trainer that alternates between batch
+            # shapes -- its graph cache -- must find the pool a captured iteration was recorded with untouched)
+            if self._pools is None:
+                self._pools = HF.BoundedCache(8)
+            pool = self._pools.get(shape)
+            if pool is None:
+                pool = self._pools.put(shape, (torch.empty(max(n_labels, 1), dtype=torch.float32, device=device),
+                                               torch.empty(max(sets, 1), b, Z, dtype=torch.float32, device=device),
+                                               torch.empty(max(n_unif, 1), dtype=torch.float32, device=device)))
+            self._labels, self._noise, self._unif = pool
             self._shape = shape
         tb = HF.scene_tables(sub_batches, b, device)
         lib.mggan_draw_iteration(self._state.data_ptr(), self._ticket.data_ptr(), n_labels, self._labels.data_ptr(), sets,

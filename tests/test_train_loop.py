@@ -1,0 +1,75 @@
+"""GPU: MultiGeneratorGAN.train() (reference loop /root/reference/mggan/abstract_train.py:114-168) on the launch mode the
+benchmark measures: with --rng device the loop replays one captured HIP graph per batch shape (first appearance of a
+shape: eager on static buffers; second: capture; then replays) and must train exactly like eager launches."""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _train(graph, peds, shapes=8, epochs=3, scenes=16, bs=4):
+    from mggan.logging import Experiment
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.model.train import PiNetMultiGeneratorGAN
+
+    cfg = get_parser().parse_args(["--num_gens", "2", "--rng", "device", "--graph", graph, "--graph_shapes", str(shapes),
+                                   "--epochs", str(epochs), "--batch_size", str(bs), "--synthetic_scenes", str(scenes),
+                                   "--synthetic_peds", str(peds), "--cache_device", "1", "--val_every", "1000",
+                                   "--save_every", "1000"])
+    torch.manual_seed(145325)
+    np.random.seed(435346)
+    with contextlib.redirect_stdout(io.StringIO()):
+        G, D = construct_model(cfg)
+    tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+    torch.cuda.manual_seed(77)
+    g = torch.Generator().manual_seed(3)  # the loader shuffles with torch's global CPU generator
+    torch.manual_seed(int(torch.randint(0, 2 ** 31, (1,), generator=g)))
+    metrics = tr.train()
+    torch.cuda.synchronize()
+    return tr, metrics
+
+
+@pytest.mark.parametrize("peds,shapes", [(3, 8), (0, 8), (0, 2)])
+def test_train_replays_graphs_and_matches_eager(peds, shapes):
+    """peds=3: one batch shape (one graph); peds=0: ragged scenes, a shape per batch of the epoch -- with a cache of two
+    shapes most batches stay eager, and eager iterations run between replays of pinned graphs."""
+    tr_g, m_g = _train("auto", peds, shapes)
+    tr_e, m_e = _train("off", peds)
+    ig = tr_g.iteration_graphs
+    assert ig is not None and tr_e.iteration_graphs is None
+    n_shapes = 1 if peds else 4
+    assert len(ig.entries) == min(n_shapes, shapes)
+    # a shape's first batch runs eagerly on the static buffers, every later one is a replay
+    assert ig.replays == (3 * 4 - 1 if peds else (3 - 1) * min(4, shapes)), (ig.replays, ig.eager)
+    assert sum(tr_g.epoch_iterations) == 12
+    for k, v in m_e.items():
+        assert np.isfinite(v) and np.isfinite(m_g[k]), k
+        np.testing.assert_allclose(m_g[k], v, rtol=1e-5, atol=1e-7, err_msg=k)  # epoch mean of the logged losses
+    for a, b in ((tr_g.G, tr_e.G), (tr_g.D, tr_e.D)):
+        assert torch.equal(a._flat, b._flat)  # replays are bit-identical to eager launches
+
+
+def test_graph_follows_the_learning_rate_schedule():
+    """The cosine schedule changes the learning rate every epoch; a captured iteration reads it from device memory."""
+    tr, _ = _train("auto", 3, epochs=4)
+    assert tr.iteration_graphs.replays == 4 * 4 - 1
+    assert tr.optimizerG.lr < tr.optimizerG.base_lr and float(tr.optimizerG._lr_dev.cpu()) == tr.optimizerG.lr
+
+
+def test_graph_on_needs_the_device_rng():
+    from mggan.logging import Experiment
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.model.train import PiNetMultiGeneratorGAN
+
+    cfg = get_parser().parse_args(["--graph", "on", "--epochs", "1"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        G, D = construct_model(cfg)
+    tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+    with pytest.raises(ValueError):
+        tr.train()
