@@ -205,6 +205,46 @@ def cpu_baseline(sizes, num_gens, iters, mode="block", tag="same workload"):
                                                   threads, os.cpu_count(), dt)}
 
 
+def train_loop_leg(tag, args, dev, batches=25, epochs=6):
+    """MultiGeneratorGAN.train() itself (the reference's loop, abstract_train.py:114-168) on the synthetic loader at the
+    headline shape: device-resident batches, --rng device, the loop's own graph cache.  Epoch 1 produces the data and runs
+    the shape's first iteration eagerly, its second iteration captures; the figure is the median over the later epochs of
+    (wall time of the epoch's training loop, device-synchronised) / iterations."""
+    import contextlib
+    import io
+
+    from mggan.logging import Experiment
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.model.train import PiNetMultiGeneratorGAN
+
+    c = CONFIGS[tag]
+    cfg = get_parser().parse_args([
+        "--num_gens", str(c["num_gens"]), "--rng", "device", "--graph", "auto", "--cache_device", "1", "--epochs", str(epochs),
+        "--batch_size", str(c["scenes"]), "--synthetic_scenes", str(c["scenes"] * batches), "--synthetic_peds",
+        str(c["peds"] or 0), "--val_every", "1000000", "--save_every", "1000000"])
+    torch.manual_seed(145325)
+    np.random.seed(435346)
+    with contextlib.redirect_stdout(io.StringIO()):
+        G, D = construct_model(cfg)
+    tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+    torch.cuda.manual_seed(1234)
+    tr.zero_grads_in_step = True
+    last = tr.train()
+    ig = tr.iteration_graphs
+    per_it = sorted(s / n for s, n in list(zip(tr.epoch_seconds, tr.epoch_iterations))[2:])
+    ms = per_it[len(per_it) // 2] * 1e3
+    b = c["scenes"] * (c["peds"] or 3)
+    tr.dist.close()
+    return {"workload": "train() on the synthetic loader: {} batches of {} scenes x {} peds per epoch, num_gens={}, {} epochs "
+                        "(batches resident in HBM, --rng device, graph cache)".format(batches, c["scenes"], c["peds"],
+                                                                                      c["num_gens"], epochs),
+            "ms_per_step": round(ms, 4), "value": round(b / ms * 1e3, 2), "unit": "trajectories/s",
+            "replayed_iterations": ig.replays if ig else 0, "eager_iterations": (ig.eager if ig else sum(tr.epoch_iterations)),
+            "ms_per_step_by_epoch": [round(s / n * 1e3, 4) for s, n in zip(tr.epoch_seconds, tr.epoch_iterations)],
+            "last_losses": {k: round(v, 6) for k, v in sorted(last.items()) if "probs" not in k}}
+
+
 CONFIGS = {  # BASELINE.json configs (SURVEY 8d)
     "c1": dict(scenes=32, peds=None, num_gens=1, name="BASELINE configs[0] shape: 32 ragged scenes (1-6 peds), num_gens=1"),
     "c2": dict(scenes=64, peds=20, num_gens=4, name="BASELINE configs[1] / per-GPU shard of configs[4]"),
@@ -538,11 +578,16 @@ def main():
         out["c1_shaped"] = {"workload": g1["workload"], "b": g1["b_per_gpu"], "graph_ms_per_step": g1["ms_per_step"],
                             "graph_value": g1["value"], "eager_ms_per_step": e1["ms_per_step"], "eager_value": e1["value"],
                             "host_rng_ms_per_step": h1["ms_per_step"], "host_rng_value": h1["value"],
-                            "note": "train() launches eagerly per loader batch with --rng host by default; the headline "
-                                    "needs capture_iteration on one static batch shape with --rng device"}
+                            "note": "train() replays a captured graph per batch shape with --rng device (`train_loop` below); "
+                                    "a shape's first batch, shapes beyond its cache and --rng host (the seed-comparable "
+                                    "mode) launch eagerly"}
         e2 = measure(args.config, head_cfg["scenes"], head_cfg["peds"], head_cfg["num_gens"], floor_args, world, rank, dev,
                      profile=False, graph=False)
         out["eager_ms_per_step"] = e2["ms_per_step"]
+        if head_cfg["peds"]:
+            tl = train_loop_leg(args.config, args, dev)
+            tl["vs_graph_headline"] = round(tl["value"] / out["value"], 3)
+            out["train_loop"] = tl
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sizes = synthetic.scene_sizes(head_cfg["scenes"], head_cfg["peds"])
         out["cpu_baseline"] = cpu_baseline(sizes, head_cfg["num_gens"], args.cpu_iters, "block", "the headline workload")
@@ -553,8 +598,6 @@ def main():
         c1s = synthetic.scene_sizes(CONFIGS["c1"]["scenes"], None)[:8]
         fb = cpu_baseline(c1s, 1, max(3, args.cpu_iters), "faithful", "the first 8 scenes of the configs[0] shape")
         out["cpu_baseline_faithful_c1"] = fb
-        if "c1_shaped" in out:
-            out["gpu_c1_over_cpu_faithful"] = round(out["c1_shaped"]["graph_value"] / fb["value"], 1)
     if world > 1 or os.environ.get("MGGAN_FORCE_DIST", "0") == "1":
         import torch.distributed as dist
 

@@ -19,7 +19,14 @@ ACT_NONE, ACT_LEAKY, ACT_SIGMOID, ACT_SIGMOID_EPS = 0, 1, 2, 3
 F32 = torch.float32
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _s():
+    """Raw handle of torch's current stream (torch.cuda.current_stream() builds a Stream object per call: 10 us of host
+    time, a hundred times per eager iteration)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -135,7 +142,12 @@ def join_side_stream():
 # the stream of its forward, so the backward pass inherits the same two-branch shape; inside a HIP-graph
 # capture the fork/join events become graph edges.  A branch ALWAYS starts by waiting for the main stream, and
 # every step ends joined, so memory freed by one stream is never re-used by the other before it is ordered.
-_BR = {"on": os.environ.get("MGGAN_BRANCH", "1") == "1", "streams": {}, "dirty": set()}
+_BR = {"on": os.environ.get("MGGAN_BRANCH", "1") == "1", "streams": {}, "dirty": set(), "raw": {}}
+
+
+def _on_branch():
+    """Is torch's current stream one of the branch streams?  (raw-handle lookup: no Stream object per call)"""
+    return bool(_BR["raw"]) and _s() in _BR["raw"]
 
 
 def enable_branches(on=True):
@@ -160,9 +172,10 @@ class branch:
         side = _BR["streams"].get(self.which)
         if side is None:
             side = _BR["streams"][self.which] = torch.cuda.Stream()
-        cur = torch.cuda.current_stream()
-        if any(cur == s for s in _BR["streams"].values()):
+            _BR["raw"][side.cuda_stream] = self.which
+        if _on_branch():
             return self
+        cur = torch.cuda.current_stream()
         side.wait_stream(cur)
         _BR["dirty"].add(self.which)
         self.ctx = torch.cuda.stream(side)
@@ -178,17 +191,24 @@ class branch:
 def join_branch(*tensors, which=None, force=False):
     """The current stream waits for branch stream `which` (None: all of them); `tensors` (branch results consumed
     from here on) are registered with the consuming stream so the allocator keeps them until it is done."""
-    cur = torch.cuda.current_stream()
+    cur = None
     for w, side in list(_BR["streams"].items()):
         if which is not None and w != which:
             continue
-        if not (w in _BR["dirty"] or force) or cur == side:
+        if not (w in _BR["dirty"] or force):
+            continue
+        if cur is None:
+            cur = torch.cuda.current_stream()
+        if cur == side:
             continue
         cur.wait_stream(side)
         _BR["dirty"].discard(w)
-    for t in tensors:
-        if t is not None and torch.is_tensor(t):
-            t.record_stream(cur)
+    if tensors:
+        if cur is None:
+            cur = torch.cuda.current_stream()
+        for t in tensors:
+            if t is not None and torch.is_tensor(t):
+                t.record_stream(cur)
 
 
 class _ReduceDesc(ctypes.Structure):
@@ -220,8 +240,8 @@ def _note_branch_partials():
     """Partial sums queued for the batched reduction were (or are about to be) written by a kernel on the CURRENT stream.
     On a branch stream that point is remembered as an event, so that the reduction can go out as soon as every producer
     is done - beside what the branch still has to do (the scene CNN's conv1 adjoint) - instead of behind a full join."""
-    cur = torch.cuda.current_stream()
-    if any(cur == st for st in _BR["streams"].values()):
+    if _on_branch():
+        cur = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(cur)
         _DEFER["revents"][cur.cuda_stream] = ev
@@ -258,8 +278,8 @@ def flush_wgrad_gemms():
 
 def _note_gemm_operands():
     """The operands of a GEMM queued from a branch stream are complete on that stream from here on."""
-    cur = torch.cuda.current_stream()
-    if any(cur == st for st in _BR["streams"].values()):
+    if _on_branch():
+        cur = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(cur)
         _DEFER["events"][cur.cuda_stream] = ev
@@ -297,13 +317,20 @@ def flush_grad_reduces():
     _DEFER["descs"], _DEFER["keep"] = [], []
 
 
+_WGRAD_GEO = {}  # (rows, K, N, groups) -> (workspace bytes, splits): two C calls per weight gradient otherwise
+
+
 def wgrad(dz, lddz, x, ldx, dW_ptr, lddw, db_ptr, rows, K, N, seg=None, seg_scale=1, n_groups=0, w_stride=0,
           b_stride=0, fm=0, now=False, yact=None, ld_yact=0, act=0, slope=0.0, overwrite=False):
     """dW += dz^T x, db += colsum(dz)  (deterministic split reduction).  Call inside `with side_stream(...)`
     to take it off the critical path."""
     if rows == 0:
         return
-    nbytes, splits = lib.mggan_wgrad_workspace_bytes(rows, K, N, n_groups), lib.mggan_wgrad_splits(rows, K, N, n_groups)
+    geo = _WGRAD_GEO.get((rows, K, N, n_groups))
+    if geo is None:
+        geo = _WGRAD_GEO[(rows, K, N, n_groups)] = (lib.mggan_wgrad_workspace_bytes(rows, K, N, n_groups),
+                                                    lib.mggan_wgrad_splits(rows, K, N, n_groups))
+    nbytes, splits = geo
     ws = _empty(nbytes // 4, like=dz if torch.is_tensor(dz) else x)
     if _SIDE["dirty"]:
         _SIDE["keep"].append(ws)

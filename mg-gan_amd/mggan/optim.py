@@ -50,7 +50,9 @@ class FlatAdamW:
         join_side_stream()  # weight-gradient GEMMs issued on the side stream must have landed
         r.adopt_foreign_grads()  # gradients that arrived through plain torch autograd count as touched too
         mask = r.touched_mask()
-        st = torch.cuda.current_stream().cuda_stream
+        from mggan.hip.functions import _s
+
+        st = _s()
         lib.mggan_clip_adamw(r._flat.data_ptr(), r._flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                              self.exp_avg_sq.data_ptr(), r._flat.numel(), r._elem_seg.data_ptr(), self.nseg,
                              mask.data_ptr(), self.seg_step.data_ptr(), float(max_norm), float(self.lr),

@@ -89,7 +89,7 @@ class DeviceRNG:
         tb = HF.scene_tables(sub_batches, b, device)
         lib.mggan_draw_iteration(self._state.data_ptr(), self._ticket.data_ptr(), n_labels, self._labels.data_ptr(), sets,
                                  b, Z, tb.ped_scene.data_ptr(), self._noise.data_ptr(), n_unif, self._unif.data_ptr(),
-                                 torch.cuda.current_stream().cuda_stream)
+                                 HF._s())
         self._lab_used = self._noise_used = self._unif_used = 0
         self._sets, self._nu, self._nl = sets, n_unif, n_labels
 
@@ -106,10 +106,11 @@ class DeviceRNG:
             dev = self._state.device if self._state is not None else torch.device("cuda", torch.cuda.current_device())
             self._ensure_state(dev)
             self._extra_labels = torch.empty(8, dtype=torch.float32, device=dev)
+            from mggan.hip import functions as HF
             from mggan.hip.lib import lib
 
             lib.mggan_draw_iteration(self._state.data_ptr(), self._ticket.data_ptr(), 8, self._extra_labels.data_ptr(), 0, 0,
-                                     0, 0, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+                                     0, 0, 0, 0, 0, HF._s())
             self._labels, self._lab_used, self._nl = self._extra_labels, 0, 8
             self._shape = None
         u = self._labels[self._lab_used:self._lab_used + 2]
@@ -134,6 +135,7 @@ class DeviceRNG:
 
     def sample_generators(self, logits, num_samples):
         """Inverse-CDF categorical sampling in one HIP launch (torch.multinomial costs ~12 tiny kernels)."""
+        from mggan.hip import functions as HF
         from mggan.hip.lib import lib
 
         lg = logits.detach().float().contiguous()
@@ -146,10 +148,10 @@ class DeviceRNG:
             self._ensure_state(lg.device)
             u = torch.empty(n, dtype=torch.float32, device=lg.device)
             lib.mggan_draw_iteration(self._state.data_ptr(), self._ticket.data_ptr(), 0, 0, 0, 0, 0, 0, 0, n, u.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream)
+                                     HF._s())
         idx = torch.empty(b, num_samples, dtype=torch.int64, device=lg.device)
         lib.mggan_sample_categorical(b, num_samples, g, lg.data_ptr(), u.data_ptr(), idx.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream)
+                                     HF._s())
         return idx
 
 

@@ -42,10 +42,17 @@ def test_train_replays_graphs_and_matches_eager(peds, shapes):
     tr_e, m_e = _train("off", peds)
     ig = tr_g.iteration_graphs
     assert ig is not None and tr_e.iteration_graphs is None
-    n_shapes = 1 if peds else 4
-    assert len(ig.entries) == min(n_shapes, shapes)
+    from mggan.data_utils import synthetic
+
+    per_shape = {}  # batches of an epoch per distinct shape (ragged: the sizes of batch i are drawn with seed i)
+    for i in range(4):
+        k = tuple(synthetic.scene_sizes(4, peds or None, seed=i))
+        per_shape[k] = per_shape.get(k, 0) + 1
+    assert len(ig.entries) == min(len(per_shape), shapes)
     # a shape's first batch runs eagerly on the static buffers, every later one is a replay
-    assert ig.replays == (3 * 4 - 1 if peds else (3 - 1) * min(4, shapes)), (ig.replays, ig.eager)
+    cached = {k for k, _ in [(e[0], 0) for e in ig.entries]}
+    assert ig.replays == sum(3 * per_shape[k] - 1 for k in cached), (ig.replays, ig.eager)
+    assert ig.replays + ig.eager + (12 - sum(3 * per_shape[k] for k in cached)) == 12
     assert sum(tr_g.epoch_iterations) == 12
     for k, v in m_e.items():
         assert np.isfinite(v) and np.isfinite(m_g[k]), k

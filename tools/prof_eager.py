@@ -16,6 +16,8 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from mggan.data_utils import synthetic  # noqa: E402
 
+if os.environ.get("MGGAN_AUTOGRAD_ONE_THREAD") == "1":  # backward nodes on the calling thread: visible to cProfile
+    torch.autograd.set_multithreading_enabled(False)
 tag = sys.argv[1] if len(sys.argv) > 1 else "c1"
 rng = sys.argv[2] if len(sys.argv) > 2 else "device"
 c = bench.CONFIGS[tag]
