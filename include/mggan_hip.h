@@ -155,16 +155,21 @@ int mggan_social_pairs_bwd(int P, int b, const int* pair_j, const int* ped_prow,
  * _bwd: dvc[j] = sum_i dsigma_ij [l2_ij | 1], dh[j] (+)= sum_i a_ij dS_i; partials != NULL: also the weight gradients of
  * the 3->32 and 32->64 layers, as mggan_social_rows_grid(S) partial blocks of mggan_social_rows_partial_floats() floats
  * ([64][33] = dW2 | db2, then [32][4] = dW1 | db1) for mggan_grad_reduce_multi.  Rows that belong to no scene are not
- * written. */
-int mggan_social_rows_grid(int S);
+ * written.  With few scenes the rows of a scene are dealt to mggan_social_rows_splits(S, max_n) workgroups; _bwd then needs
+ * `scratch` (splits x dvc_rows x (65 + H) floats) and `tickets` (S words, zero before the first launch; the kernel leaves
+ * them at zero): the last workgroup of a scene to arrive folds the shares in split order (results do not depend on the
+ * arrival order). */
+int mggan_social_rows_splits(int S, int max_n);
+int mggan_social_rows_grid(int S, int max_n);
 int mggan_social_rows_partial_floats(void);
 int mggan_social_rows_fwd(int S, const int* scenes, int H, int max_n, const float* xy_last, const float* dxdy_last,
                           int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* vc,
                           int ldv, const float* h, int ld_h, float* S_out, int ld_s, mggan_stream_t stream);
 int mggan_social_rows_bwd(int S, const int* scenes, int H, int max_n, const float* xy_last, const float* dxdy_last,
                           int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* vc,
-                          int ldv, const float* h, int ld_h, const float* dS, int ld_ds, float* dvc, float* dh, int ld_dh,
-                          int accumulate_dh, float* partials, mggan_stream_t stream);
+                          int ldv, const float* h, int ld_h, const float* dS, int ld_ds, float* dvc, int dvc_rows, float* dh,
+                          int ld_dh, int accumulate_dh, float* partials, float* scratch, unsigned* tickets,
+                          mggan_stream_t stream);
 
 /* ---- Social-GAN pooling (--pool_type sgan) ------------------------------------------------
  * reference: social_gan.py:199-229 (PoolHiddenNet.forward): per scene, every pedestrian i and every j of its scene

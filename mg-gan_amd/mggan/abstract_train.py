@@ -100,9 +100,11 @@ class MultiGeneratorGAN(abc.ABC):
             # forward (with its backward graph) serves both; BatchNorm running stats still move twice (A.8)
             shared = {"g_trunk": self.G.trunk(in_xy, in_dxdy, sub_batches, img, passes=2)}
         # the Gram matrix of the image patches (image-only part of every conv1 weight gradient of the iteration) goes to
-        # a side stream AFTER the shared trunk: beside the latency-bound forward chain of the discriminator step instead
-        # of beside the trunk's own convolutions; its first reader is the scene CNN's adjoint of that step
-        HF.begin_images(img)
+        # a side stream beside the latency-bound ROW PASS of the discriminator step (discriminator_step starts it once
+        # its history context -- scene CNN and LSTM -- and the fake trajectories are queued; beside those it stretched all
+        # of them: conv1_pool<8> 100 us instead of 30 at configs[1], the PM-network's 8 us chain 343 us at configs[2]);
+        # its first reader is the scene CNN's adjoint of that step
+        HF.begin_images(img, defer=os.environ.get("MGGAN_GRAM_EARLY", "0") != "1")
         # abstract_train.py:136-150: the discriminator step runs when total_iterations % num_gen_steps == 0 or
         # epoch >= keep_gen_steps, and num_unrolling_steps + 1 times.  The reference's unrolling "backup" is
         # `self.D.state_dict()` -- references to the live parameters, not copies -- so its load_state_dict(backup)
@@ -114,6 +116,7 @@ class MultiGeneratorGAN(abc.ABC):
             if run_d:
                 for _ in range(cfg.num_unrolling_steps + 1):
                     self.discriminator_step(*args, shared=shared)
+            HF.launch_images()  # (no discriminator step in this iteration, or one that did not start it)
             self.generator_step(*args, shared=shared)
             self.net_chooser_step(*args)
         finally:

@@ -36,7 +36,7 @@ def _p(t):
 
 # Debugging aid (MGGAN_POISON=1 or poison_scratch(True)): scratch buffers start as NaN instead of whatever the allocator
 # hands back, so a kernel that reads what no kernel wrote shows up as NaN instead of as a box-dependent flake.
-_DEBUG = {"poison": os.environ.get("MGGAN_POISON", "0") == "1"}
+_DEBUG = {"poison": os.environ.get("MGGAN_POISON", "0") == "1", "wgrad_dump": os.environ.get("MGGAN_WGRAD_DUMP", "0") == "1"}
 
 
 def poison_scratch(on=True):
@@ -269,6 +269,9 @@ def flush_wgrad_gemms():
         cur.wait_event(ev)
     _DEFER["events"] = {}
     arr = (_WgradDesc * len(gm))(*gm)
+    if _DEBUG.get("wgrad_dump"):  # MGGAN_WGRAD_DUMP=1: what a step's weight-gradient batch is made of
+        print("[wgrad batch] " + "; ".join("{}x({}x{}){}".format(g.rows, g.N, g.K, " fm" if g.feature_major else "")
+                                           for g in gm) + " | MB {:.1f}".format(sum(4e-6 * g.rows * (g.K + g.N) for g in gm)))
     if _load_lib().trace is not None:  # bench.py's per-entry trace: algorithmic FLOPs of this batch
         TRACE_NOTES["wgrad_multi_flops"].append(sum(2.0 * g.rows * g.K * g.N for g in gm))
         TRACE_NOTES["wgrad_multi_bytes"].append(sum(4.0 * g.rows * (g.K + g.N) for g in gm))  # each operand once
@@ -881,13 +884,21 @@ def _social_bwd(saved, xy_last, dxdy_last, xy_mod, h_ptr, ld_h, h_keep, b, Hh, t
     if rows:
         part, grid, pf = None, 0, 0
         if train_w1:  # one partial block [dW2 | db2 ; dW1 | db1] per workgroup, folded by the batched reduction
-            grid, pf = lib.mggan_social_rows_grid(tb.S), lib.mggan_social_rows_partial_floats()
+            grid, pf = lib.mggan_social_rows_grid(tb.S, tb.max_n), lib.mggan_social_rows_partial_floats()
             part = _empty(grid * pf, like=like)
+        rs, scr, tick = lib.mggan_social_rows_splits(tb.S, tb.max_n), None, None
+        if rs > 1:  # few scenes: a scene's rows are dealt to `rs` workgroups whose neighbour sums meet in scratch
+            scr = _empty(rs * b * (65 + Hh), like=like)
+            tick = tb.__dict__.setdefault("soc_tickets", {}).get(Hh)
+            if tick is None:  # zero once; the kernel leaves the words at zero (one launch per (tables, width) at a time)
+                tick = tb.soc_tickets[Hh] = torch.zeros(tb.S, dtype=torch.int32, device=like.device)
         if _load_lib().trace is not None:
             TRACE_NOTES["social_rows_bwd_pairs"].append(tb.P)
         lib.mggan_social_rows_bwd(tb.S, _p(tb.scenes), Hh, tb.max_n, _p(xy_last), _p(dxdy_last), int(xy_mod), _p(w1),
-                                  _p(b1), _p(w2), _p(b2), _p(vc), ldv, h_ptr, ld_h, dS_ptr, ld_ds, _p(dvc), dh_ptr, ld_dh,
-                                  int(accumulate_dh), _p(part), st)
+                                  _p(b1), _p(w2), _p(b2), _p(vc), ldv, h_ptr, ld_h, dS_ptr, ld_ds, _p(dvc), b, dh_ptr, ld_dh,
+                                  int(accumulate_dh), _p(part), _p(scr), _p(tick), st)
+        if scr is not None and (_DEFER["on"] or _SIDE["dirty"]):
+            _DEFER["keep"].append(scr)
         if train_w1:
             p0 = part.data_ptr()
             descs = ((p0, root.grad_ptr(w2), root.grad_ptr(b2), 64, 33, 32), (p0 + 4 * 64 * 33, root.grad_ptr(w1), root.grad_ptr(b1), 32, 4, 3))
@@ -1139,7 +1150,7 @@ class PoolHiddenFn(Function):
 # gradient of a batch.  The trainer announces the batch's images at the start of an iteration (begin_images): ONE launch
 # on a side stream serves the backward passes of both scene CNNs; a backward pass that finds no announced Gram matrix
 # (a stand-alone call) computes it on the spot.
-_GRAM = {"reg": {}, "stream": None}
+_GRAM = {"reg": {}, "stream": None, "pending": None}
 
 
 def _gram_launch(img):
@@ -1151,17 +1162,30 @@ def _gram_launch(img):
     return gram, ws
 
 
-def begin_images(img, side=True):
-    """Start the Gram matrix of this batch's image crops (B,4,33,33) beside the forward pass."""
+def begin_images(img, side=True, defer=False):
+    """Announce this batch's image crops (B,4,33,33); their Gram matrix is started on a side stream now, or -- defer=True
+    -- at the point of the iteration where launch_images() is called (the trainer picks a latency-bound stretch: next to
+    the discriminator's convolutions and LSTM it only stretches all three)."""
     _GRAM["reg"].clear()
+    _GRAM["pending"] = None
     if img is None or not img.is_cuda or img.shape[0] == 0:
         return
     img = img.contiguous()
+    if defer and side and _BR["on"]:
+        _GRAM["pending"] = img
+        return
+    _start_gram(img, side)
+
+
+def _start_gram(img, side=True, after_branches=()):
     if side and _BR["on"]:
         if _GRAM["stream"] is None:
             _GRAM["stream"] = torch.cuda.Stream()
         st = _GRAM["stream"]
         st.wait_stream(torch.cuda.current_stream())
+        for w in after_branches:  # ... and behind what those branch streams have queued (without joining them)
+            if w in _BR["streams"]:
+                st.wait_stream(_BR["streams"][w])
         with torch.cuda.stream(st):
             gram, ws = _gram_launch(img)
             ev = torch.cuda.Event()
@@ -1172,15 +1196,25 @@ def begin_images(img, side=True):
         _GRAM["reg"][img.data_ptr()] = (gram, ws, None, img)
 
 
+def launch_images(after_branches=()):
+    """Start the announced Gram matrix behind what the current stream (and the named branch streams) have queued so far
+    (no-op when it is running)."""
+    img, _GRAM["pending"] = _GRAM.get("pending"), None
+    if img is not None:
+        _start_gram(img, True, after_branches)
+
+
 def end_images():
     """The side stream of the Gram launch joins the current stream (every fork has to be joined before a capture ends)."""
     st = _GRAM["stream"]
     if st is not None and any(e[2] is not None for e in _GRAM["reg"].values()):
         torch.cuda.current_stream().wait_stream(st)
     _GRAM["reg"].clear()
+    _GRAM["pending"] = None
 
 
 def _image_gram(img):
+    launch_images()  # (announced but never started: a step order the trainer did not foresee)
     hit = _GRAM["reg"].get(img.data_ptr())
     if hit is not None and hit[3].shape == img.shape:
         if hit[2] is not None:

@@ -21,7 +21,7 @@ def _ctype(decl):
         return ctypes.c_void_p
     base = d.rsplit(" ", 1)[0] if " " in d else d
     base = base.replace("const", "").strip()
-    return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+    return {"int": ctypes.c_int, "unsigned": ctypes.c_uint, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
             "size_t": ctypes.c_size_t, "long long": ctypes.c_longlong}[base]
 
 
@@ -39,7 +39,7 @@ def parse_header(path=HEADER_PATH):
 
 
 # functions whose int return value is data, not a status code
-_VALUE_RETURNING = {"mggan_version", "mggan_wgrad_splits", "mggan_lstm_prep_size", "mggan_cnn_bwd_grid", "mggan_cnn_grid", "mggan_comm_arena_bytes", "mggan_social_rows_grid",
+_VALUE_RETURNING = {"mggan_version", "mggan_wgrad_splits", "mggan_lstm_prep_size", "mggan_cnn_bwd_grid", "mggan_cnn_grid", "mggan_comm_arena_bytes", "mggan_social_rows_grid", "mggan_social_rows_splits",
                     "mggan_social_rows_partial_floats"}
 
 _lib = None

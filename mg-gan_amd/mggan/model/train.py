@@ -206,6 +206,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             # and the two or three loss terms as one launch / one autograd node
             HF.mark("D.ctx.end")
             join_fake()
+            HF.launch_images(after_branches=(0,))  # behind the history LSTM (this stream) and D's scene CNN (branch 0)
             HF.mark("D.pair.begin")
             y, branch_out = self.D.forward_pair(in_xy, in_dxdy, gt_dxdy, gen_out.rel, sub_batches, ctx)
             HF.mark("D.pair.end")
