@@ -34,6 +34,7 @@
 //     (grad_reduce_multi_kernel) -- nothing per pair is ever written to HBM (the fused tile kernels this file replaces
 //     stored 100 floats per pair in the forward pass and 97 more in the backward pass for the weight-gradient GEMMs).
 // Scenes of more than 64 pedestrians take the unfused kernels of social.hip.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/mggan_hip.h"
 
@@ -559,10 +560,14 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
 // ---------------------------------------------------------------------------------------------------------------
 // persistent: one workgroup per CU walks units (scene, row split) un, un + grid, ...
 static int sr_grid(int S, int RS) { return S * RS < 256 ? S * RS : 256; }
-// few scenes: the rows of a scene are dealt to up to four workgroups (a wave still needs rows to amortise its set-up)
+// few scenes: the rows of a scene are dealt to two workgroups.  (Measured at 64 scenes x 20 pedestrians: the backward launch
+// 41 / 35 / 42 us with 1 / 2 / 4 splits -- a workgroup's fixed costs (weight fragments, staging the scene, the exchanges at
+// its end) outweigh the rows from four on; the knob MGGAN_SOC_SPLITS forces a value.)
 static int sr_splits(int S, int max_n) {
+  static const char* force = getenv("MGGAN_SOC_SPLITS");  // measurement knob: 1, 2 or 4
+  if (force && atoi(force) >= 1 && atoi(force) <= 4 && 4 * atoi(force) <= (max_n > 4 ? max_n : 4)) return atoi(force);
   int rs = 1;
-  while (rs < 4 && S * rs * 2 <= 256 && 4 * rs * 2 <= max_n) rs *= 2;
+  while (rs < 2 && S * rs * 2 <= 256 && 4 * rs * 2 <= max_n) rs *= 2;
   return rs;
 }
 static int sr_njb(int max_n) { return max_n <= 16 ? 1 : max_n <= 32 ? 2 : 4; }

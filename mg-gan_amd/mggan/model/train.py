@@ -194,6 +194,10 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             HF.mark("D.fake.end")
         # history LSTM + scene CNN of D are identical in the real and the fake pass: run them once
         ctx = self.D.history_context(in_dxdy, img, passes=2) if (loss_mask is None and self.share_context) else None
+        # the Gram matrix of the image crops starts behind the history LSTM on this stream (by then D's scene CNN on its
+        # branch stream is nearly through as well): beside the latency-bound row pass.  (Forked from this stream only: a
+        # side stream with two parents inside a capture makes hipStreamEndCapture crash.)
+        HF.launch_images()
         pair = ctx is not None and getattr(self, "pair_passes", True)
         kind = 1 if self.config.gan_obj == "LS" else 0  # phi_1 / phi_2: squared error for 'LS', BCE for 'NS' and 'MM'
         join_fake = lambda: HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, g_logits,
@@ -206,7 +210,6 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             # and the two or three loss terms as one launch / one autograd node
             HF.mark("D.ctx.end")
             join_fake()
-            HF.launch_images(after_branches=(0,))  # behind the history LSTM (this stream) and D's scene CNN (branch 0)
             HF.mark("D.pair.begin")
             y, branch_out = self.D.forward_pair(in_xy, in_dxdy, gt_dxdy, gen_out.rel, sub_batches, ctx)
             HF.mark("D.pair.end")
