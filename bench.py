@@ -127,7 +127,7 @@ def flops_of(name, a):
         P, H = (notes.pop(0) if notes else 0), a[2]
         if name.endswith("fwd"):
             return float(P) * 2 * (96 + 2048 + 64 + H)
-        return float(P) * 2 * (64 + 3 * H + 65 + (2048 + 2048 + 96 if a[22] else 0))
+        return float(P) * 2 * (64 + 3 * H + 65 + (2048 + 2048 + 96 if a[28] else 0))
     return 0.0
 
 

@@ -145,31 +145,33 @@ int mggan_social_pairs_bwd(int P, int b, const int* pair_j, const int* ped_prow,
                            const float* dsigma, const float* vc, const float* l1, const float* l2, const float* W2,
                            float* dz2, float* dz1, float* dvc, mggan_stream_t stream);
 
-/* The same math as ONE launch per direction for scenes of up to 64 pedestrians (csrc/social_rows.hip): a workgroup
- * owns whole scenes (scenes[s] = {first row, past-last row}), a wave owns attention rows, the 32->64 pair layer and its
- * adjoint run on MFMA, the softmax over a scene is wave-level shuffle reductions, and NOTHING per pair is stored:
- * _bwd recomputes the pair MLP from the positions.  vc: [rows][ldv] with v_j in columns 0..63 and c_j in column 64
- * (ldv a multiple of 4, >= 68, rows 16-byte aligned); dvc has the same layout.  max_n = largest scene (<= 64).
- * xy_mod > 0: the pedestrian rows repeat with that period (xy_last / dxdy_last hold one period: the real and the fake
- * half of a discriminator pair pass share the observed positions).
- * _bwd: dvc[j] = sum_i dsigma_ij [l2_ij | 1], dh[j] (+)= sum_i a_ij dS_i; partials != NULL: also the weight gradients of
- * the 3->32 and 32->64 layers, as mggan_social_rows_grid(S) partial blocks of mggan_social_rows_partial_floats() floats
- * ([64][33] = dW2 | db2, then [32][4] = dW1 | db1) for mggan_grad_reduce_multi.  Rows that belong to no scene are not
- * written.  With few scenes the rows of a scene are dealt to mggan_social_rows_splits(S, max_n) workgroups; _bwd then needs
- * `scratch` (splits x dvc_rows x (65 + H) floats) and `tickets` (S words, zero before the first launch; the kernel leaves
- * them at zero): the last workgroup of a scene to arrive folds the shares in split order (results do not depend on the
- * arrival order). */
+/* The same math -- INCLUDING the per-pedestrian dense stages Wh_j = W_at h_j + b_at, [v_j | c_j] = Wh_j [W3 | b3] and
+ * their adjoints -- as ONE launch per direction for scenes of up to 64 pedestrians (csrc/social_rows.hip): a workgroup
+ * owns whole scenes (scenes[s] = {first row, past-last row}), a wave owns attention rows, the pair MLP and its adjoint run
+ * on MFMA, the softmax over a scene is wave-level shuffle reductions, and NOTHING per pair is stored: _bwd recomputes the
+ * pair MLP from the positions.  H = width of h (32 | 64), F = social feature width (rows of W3 / W_at, <= 64), max_n =
+ * largest scene (<= 64).  xy_mod > 0: the pedestrian rows repeat with that period (xy_last / dxdy_last hold one period:
+ * the real and the fake half of a discriminator pair pass share the observed positions).
+ * _bwd: dh[j] (+)= sum_i a_ij dS_i + dWh_j W_at; side outputs for the weight-gradient GEMMs of W3 | b3 | W_at | b_at:
+ * Wh (rows, F), dWh (rows, F), dvc (rows, ldv) = d[v_j | c_j] (65 columns used); partials != NULL: also the weight
+ * gradients of the 3->32 and 32->64 layers, as mggan_social_rows_grid(S, max_n) partial blocks of
+ * mggan_social_rows_partial_floats() floats ([64][33] = dW2 | db2, then [32][4] = dW1 | db1) for mggan_grad_reduce_multi.
+ * Rows that belong to no scene are not written.  With few scenes the rows of a scene are dealt to
+ * mggan_social_rows_splits(S, max_n) workgroups; _bwd then needs `scratch` (splits x dvc_rows x (65 + H) floats) and
+ * `tickets` (S words, zero before the first launch; the kernel leaves them at zero): the last workgroup of a scene to
+ * arrive folds the shares in split order (results do not depend on the arrival order). */
 int mggan_social_rows_splits(int S, int max_n);
 int mggan_social_rows_grid(int S, int max_n);
 int mggan_social_rows_partial_floats(void);
-int mggan_social_rows_fwd(int S, const int* scenes, int H, int max_n, const float* xy_last, const float* dxdy_last,
-                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* vc,
-                          int ldv, const float* h, int ld_h, float* S_out, int ld_s, mggan_stream_t stream);
-int mggan_social_rows_bwd(int S, const int* scenes, int H, int max_n, const float* xy_last, const float* dxdy_last,
-                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* vc,
-                          int ldv, const float* h, int ld_h, const float* dS, int ld_ds, float* dvc, int dvc_rows, float* dh,
-                          int ld_dh, int accumulate_dh, float* partials, float* scratch, unsigned* tickets,
-                          mggan_stream_t stream);
+int mggan_social_rows_fwd(int S, const int* scenes, int H, int F, int max_n, const float* xy_last, const float* dxdy_last,
+                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                          const float* b3, const float* Wat, const float* bat, const float* h, int ld_h, float* S_out,
+                          int ld_s, mggan_stream_t stream);
+int mggan_social_rows_bwd(int S, const int* scenes, int H, int F, int max_n, const float* xy_last, const float* dxdy_last,
+                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                          const float* b3, const float* Wat, const float* bat, const float* h, int ld_h, const float* dS,
+                          int ld_ds, float* dvc, int ldv, int dvc_rows, float* Wh, float* dWh, float* dh, int ld_dh,
+                          int accumulate_dh, float* partials, float* scratch, unsigned* tickets, mggan_stream_t stream);
 
 /* ---- Social-GAN pooling (--pool_type sgan) ------------------------------------------------
  * reference: social_gan.py:199-229 (PoolHiddenNet.forward): per scene, every pedestrian i and every j of its scene

@@ -51,10 +51,12 @@ struct SocRowsArgs {
   const int* scenes;  // [S][2] = first / past-last pedestrian row
   const float *xy, *dxy;
   const float *W1, *b1, *W2, *b2;
-  const float* vc;    // [b][ldv]: v_j (64) | c_j at column 64
+  const float *Wat, *bat, *W3, *b3;  // attention map W_at (F x H) | b_at (F), last embedding layer W3 (F x 64) | b3 (F)
   const float* h;
   const float* dS;
   float *Sout, *dvc, *dh, *partials;
+  float *Wh_out, *dWh_out;  // backward: Wh = h W_at^T + b_at and its gradient, (rows, F), for the weight-gradient GEMMs
+  int F;                    // social feature width (<= 64)
   float* scratch;     // row_splits > 1: neighbour sums of every (scene, split), [unit][first row of the scene ...][65 + H]
   unsigned* tickets;  // row_splits > 1: one word per scene, zero between launches
   int S, xy_mod, ldv, ld_h, ld_s, ld_ds, ld_dh, accumulate_dh;
@@ -136,29 +138,104 @@ struct SrNeighbour {
   bool ok;  // j < n
 };
 
-__device__ __forceinline__ void sr_load_neighbour(const SocRowsArgs& a, int s0, int n, int j, SrNeighbour& N) {
+__device__ __forceinline__ void sr_load_neighbour(const SocRowsArgs& a, int s0, int n, int j, const float* vs, SrNeighbour& N) {
   N.ok = j < n;
   N.j = N.ok ? j : 0;
   const int jc = s0 + N.j;
-  N.c = a.vc[(size_t)jc * a.ldv + 64];
+  N.c = vs[N.j * SR_LDV + 64];
   const int jx = a.xy_mod > 0 ? jc % a.xy_mod : jc;
   N.px = a.xy[2 * jx]; N.py = a.xy[2 * jx + 1];
   N.vx = a.dxy[2 * jx]; N.vy = a.dxy[2 * jx + 1];
 }
 
-// [v_j | c_j] and h_j of the scene's pedestrians into LDS (every wave reads every neighbour)
-template <int H>
-__device__ __forceinline__ void sr_stage_scene(const SocRowsArgs& a, int s0, int n, float* vs, float* hs) {
-  for (int e = threadIdx.x; e < n * (SR_LDV / 4); e += 256) {
-    const int row = e / (SR_LDV / 4), c = e - row * (SR_LDV / 4);
-    *reinterpret_cast<f32x4*>(vs + row * SR_LDV + 4 * c) =
-        *reinterpret_cast<const f32x4*>(a.vc + (size_t)(s0 + row) * a.ldv + 4 * c);
+// The per-pedestrian dense stages run inside the same launch, per scene, on the staged rows: Wh_j = W_at h_j + b_at,
+// [v_j | c_j] = Wh_j [W3 | b3] -- and their adjoints in the backward kernel -- as 16 x 16 MFMA tiles whose operands are
+// read from LDS (the weights sit there for the life of the workgroup).  (A first version walked them on the VALU, two
+// LDS reads per FMA: 14 us per 32-pedestrian scene of the discriminator, more than the launches it replaced.)
+#define SR_LDW 68  // row stride of the staged [W3 | .] rows and of Wh / dWh in LDS (4 mod 32: see sr_tile)
+
+// acc (+)= A[j0 .. j0+15][0 .. K) x B, one 16 x 16 tile per wave: acc[r] <-> row 4 kq + r, column pp.
+// A row-major in LDS (K contiguous, lda % 4 == 0); NT: B given as Bt[col][k] (K contiguous); else B[k][col].
+// The reduction index is walked as k = 16 S + 4 kq + r: one 16-byte read per operand and S (NT); strides that are
+// 4 mod 32 keep both forms free of bank conflicts.
+template <bool NT>
+__device__ __forceinline__ f32x4 sr_tile(const float* A, int lda, int j0, const float* B, int ldb, int c0, int K, f32x4 acc,
+                                         int pp, int kq) {
+  const float* ar = A + (j0 + pp) * lda + 4 * kq;
+  for (int S = 0; S < K; S += 16) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ar + S);
+    f32x4 b4;
+    if (NT) {
+      b4 = *reinterpret_cast<const f32x4*>(B + (c0 + pp) * ldb + S + 4 * kq);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b4[r] = B[(S + 4 * kq + r) * ldb + c0 + pp];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = MFMA16(a4[r], b4[r], acc);
   }
+  return acc;
+}
+
+struct SrDense {  // LDS of the dense stages
+  float* wat;     // W_at [F][H + 4]
+  float* w3;      // W3   [F][SR_LDW]
+  float* bat;     // [64]
+  float* b3;      // [64]
+  float* wh;      // Wh / dWh of the scene [rows][SR_LDW]
+};
+
+template <int H>
+__device__ __forceinline__ void sr_stage_dense_weights(const SocRowsArgs& a, const SrDense& D) {
+  const int F = a.F;
+  for (int e = threadIdx.x; e < F * H; e += 256) D.wat[(e / H) * (H + 4) + (e % H)] = a.Wat[e];
+  for (int e = threadIdx.x; e < F * 64; e += 256) D.w3[(e >> 6) * SR_LDW + (e & 63)] = a.W3[e];
+  for (int f = threadIdx.x; f < F; f += 256) {
+    D.bat[f] = a.bat[f];
+    D.b3[f] = a.b3[f];
+  }
+}
+
+// h rows of the scene -> hs; Wh -> D.wh (and wh_out); [v | c] -> vs.  Every thread of the workgroup calls it.
+template <int H>
+__device__ __forceinline__ void sr_stage_scene(const SocRowsArgs& a, int s0, int n, const SrDense& D, float* vs, float* hs,
+                                               float* wh_out) {
+  constexpr int LDH = H + 4;
+  const int F = a.F, lane = threadIdx.x & 63, w = threadIdx.x >> 6, pp = lane & 15, kq = lane >> 4;
+  const int jt = (n + 15) >> 4;
   for (int e = threadIdx.x; e < n * (H / 4); e += 256) {
     const int row = e / (H / 4), c = e - row * (H / 4);
-    *reinterpret_cast<f32x4*>(hs + row * (H + 4) + 4 * c) =
+    *reinterpret_cast<f32x4*>(hs + row * LDH + 4 * c) =
         *reinterpret_cast<const f32x4*>(a.h + (size_t)(s0 + row) * a.ld_h + 4 * c);
   }
+  __syncthreads();
+  for (int t = w; t < jt * (F >> 4); t += 4) {  // Wh = h W_at^T + b_at
+    const int j0 = 16 * (t / (F >> 4)), f0 = 16 * (t % (F >> 4));
+    const float bias = D.bat[f0 + pp];
+    const f32x4 acc = sr_tile<true>(hs, LDH, j0, D.wat, H + 4, f0, H, f32x4{bias, bias, bias, bias}, pp, kq);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = j0 + 4 * kq + r;
+      D.wh[j * SR_LDW + f0 + pp] = acc[r];
+      if (wh_out && j < n) wh_out[(size_t)(s0 + j) * F + f0 + pp] = acc[r];
+    }
+  }
+  __syncthreads();
+  for (int t = w; t < jt * 4; t += 4) {  // v = Wh W3
+    const int j0 = 16 * (t >> 2), m0 = 16 * (t & 3);
+    const f32x4 acc = sr_tile<false>(D.wh, SR_LDW, j0, D.w3, SR_LDW, m0, F, f32x4{0.f, 0.f, 0.f, 0.f}, pp, kq);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vs[(j0 + 4 * kq + r) * SR_LDV + m0 + pp] = acc[r];
+  }
+  for (int j = threadIdx.x; j < n; j += 256) {  // c = Wh . b3
+    float c0 = 0.f, c1 = 0.f;
+    for (int f = 0; f < F; f += 2) {
+      c0 = fmaf(D.wh[j * SR_LDW + f], D.b3[f], c0);
+      c1 = fmaf(D.wh[j * SR_LDW + f + 1], D.b3[f + 1], c1);
+    }
+    vs[j * SR_LDV + 64] = c0 + c1;
+  }
+  __syncthreads();
 }
 
 // the pair MLP for the 16 pairs (row i, neighbours of one block): l1[s] = unit u(s) of the lane's pair,
@@ -202,9 +279,13 @@ __global__ __launch_bounds__(256) void social_rows_fwd_kernel(const SocRowsArgs 
   constexpr int HQ = H / 4, LDH = H + 4;
   __shared__ __attribute__((aligned(16))) float vs[16 * NJB * SR_LDV];
   __shared__ __attribute__((aligned(16))) float hs[16 * NJB * LDH];
+  __shared__ __attribute__((aligned(16))) float wat_s[64 * (H + 4)], w3_s[64 * SR_LDW], whs[16 * NJB * SR_LDW];
+  __shared__ float bat_s[64], b3_s[64];
+  const SrDense DN = {wat_s, w3_s, bat_s, b3_s, whs};
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pp = lane & 15, kq = lane >> 4;
   SrWeights W;
   sr_load_weights(a, pp, kq, W);
+  sr_stage_dense_weights<H>(a, DN);
   const int RS = a.row_splits;
   for (int un = blockIdx.x; un < a.S * RS; un += gridDim.x) {
     const int sc = un / RS, rs = un - sc * RS;
@@ -213,12 +294,11 @@ __global__ __launch_bounds__(256) void social_rows_fwd_kernel(const SocRowsArgs 
       if (n == 1 && rs == 0 && (int)threadIdx.x < H) a.Sout[(size_t)s0 * a.ld_s + threadIdx.x] = 0.f;
       continue;
     }
-    __syncthreads();  // every wave is done with the previous scene's rows
-    sr_stage_scene<H>(a, s0, n, vs, hs);
+    __syncthreads();  // every wave is done with the previous scene's rows (and the dense weights are staged)
+    sr_stage_scene<H>(a, s0, n, DN, vs, hs, nullptr);
     SrNeighbour N[NJB];
 #pragma unroll
-    for (int jb = 0; jb < NJB; ++jb) sr_load_neighbour(a, s0, n, 16 * jb + pp, N[jb]);
-    __syncthreads();
+    for (int jb = 0; jb < NJB; ++jb) sr_load_neighbour(a, s0, n, 16 * jb + pp, vs, N[jb]);
     for (int i = 4 * rs + w; i < n; i += 4 * RS) {
       const int gi = s0 + i, ix = a.xy_mod > 0 ? gi % a.xy_mod : gi;
       const float pix = a.xy[2 * ix], piy = a.xy[2 * ix + 1], vix = a.dxy[2 * ix], viy = a.dxy[2 * ix + 1];
@@ -286,8 +366,11 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
   // region A: the waves' transposition tiles while rows are walked; the neighbour-sum exchange at the end of a scene;
   // the weight-gradient exchange at the end of the workgroup (separated by barriers)
   __shared__ __attribute__((aligned(16))) float smem[A_FLOATS];
-  __shared__ __attribute__((aligned(16))) float vs[16 * NJB * SR_LDV];
-  __shared__ __attribute__((aligned(16))) float hs[16 * NJB * LDH];
+  __shared__ __attribute__((aligned(16))) float vs[16 * NJB * SR_LDV];  // [v | c] of the scene; its gradient at the end
+  __shared__ __attribute__((aligned(16))) float hs[16 * NJB * LDH];     // h of the scene; the neighbour part of dh at the end
+  __shared__ __attribute__((aligned(16))) float wat_s[64 * (H + 4)], w3_s[64 * SR_LDW], whs[16 * NJB * SR_LDW];
+  __shared__ float bat_s[64], b3_s[64];
+  const SrDense DN = {wat_s, w3_s, bat_s, b3_s, whs};
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pp = lane & 15, kq = lane >> 4;
   float* Zs = smem + w * SR_TILE_FLOATS;  // [16][SR_LDZ]
   float* L1s = Zs + 16 * SR_LDZ;          // [16][SR_LD1]
@@ -295,6 +378,7 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
   float* red = smem;                      // [4][16][LDC]
   SrWeights W;
   sr_load_weights(a, pp, kq, W);
+  sr_stage_dense_weights<H>(a, DN);
   float w2t[2][4][4];  // A operand of dz1^T = W2^T dz2^T: W2[m = 16 t + 4 kq + r][u = 16 tp + pp]
   f32x4 dW2[4][2];     // dW2[m = 16 tm + 4 kq + r][u = 16 tu + pp], over every scene of this workgroup
   f32x4 dW1[2];        // [dW1 | db1][u = 16 tp + 4 kq + r][c = pp] (lanes pp < 4)
@@ -320,27 +404,31 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
   for (int un = blockIdx.x; un < a.S * RS; un += gridDim.x) {
     const int sc = un / RS, rs = un - sc * RS;
     const int s0 = a.scenes[2 * sc], n = a.scenes[2 * sc + 1] - s0;
-    if (n <= 1) {  // no attention, no gradient: dvc = 0, dh untouched (or 0)
+    if (n <= 1) {  // no attention, no gradient: dvc = dWh = 0 (Wh: any finite value), dh untouched (or 0)
       if (n == 1 && rs == 0) {
         if ((int)threadIdx.x < 65) a.dvc[(size_t)s0 * a.ldv + threadIdx.x] = 0.f;
+        if ((int)threadIdx.x < a.F) {
+          a.Wh_out[(size_t)s0 * a.F + threadIdx.x] = 0.f;
+          a.dWh_out[(size_t)s0 * a.F + threadIdx.x] = 0.f;
+        }
         if (!a.accumulate_dh && (int)threadIdx.x < H) a.dh[(size_t)s0 * a.ld_dh + threadIdx.x] = 0.f;
       }
       continue;
     }
-    sr_stage_scene<H>(a, s0, n, vs, hs);  // (the previous scene ended with a barrier)
+    __syncthreads();  // (the dense weights are staged; the previous scene's epilogue is through with vs / hs / whs)
+    sr_stage_scene<H>(a, s0, n, DN, vs, hs, rs == 0 ? a.Wh_out : nullptr);
     SrNeighbour N[NJB];
     f32x4 dv[NJB][4];
     float dc[NJB], dhq[NJB][HQ];
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb) {
-      sr_load_neighbour(a, s0, n, 16 * jb + pp, N[jb]);
+      sr_load_neighbour(a, s0, n, 16 * jb + pp, vs, N[jb]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) dv[jb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       dc[jb] = 0.f;
 #pragma unroll
       for (int k = 0; k < HQ; ++k) dhq[jb][k] = 0.f;
     }
-    __syncthreads();
     for (int i = 4 * rs + w; i < n; i += 4 * RS) {
       const int gi = s0 + i, ix = a.xy_mod > 0 ? gi % a.xy_mod : gi;
       const float pix = a.xy[2 * ix], piy = a.xy[2 * ix + 1], vix = a.dxy[2 * ix], viy = a.dxy[2 * ix + 1];
@@ -470,8 +558,9 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
         }
       }
     }
-    // the four waves' neighbour sums meet in LDS (region A: every wave must be done with its tiles), one j-block per
-    // round, fixed order
+    // the four waves' neighbour sums meet in LDS (region A: every wave must be done with its tiles -- and, below, with the
+    // staged scene), one j-block per round, fixed order.  The folded sums stay on chip: d[v | c] -> vs, the neighbour part
+    // of dh -> hs (one workgroup per scene), or this workgroup's share -> scratch (row splits)
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb) {
       if (16 * jb >= n) break;
@@ -490,18 +579,18 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
         const float* r0 = red + jl * LDC + (c < 65 ? c : c + 3);
         const float v = (r0[0] + r0[16 * LDC]) + (r0[32 * LDC] + r0[48 * LDC]);
         if (RS > 1) {
-          // this workgroup's share of the scene's neighbour sums: agent-scope atomic stores (write-through: visible to
-          // the workgroup that folds the shares without a release fence -- MI355X_MICROARCH "valid forms")
+          // agent-scope atomic stores (write-through: visible to the workgroup that folds the shares without a release
+          // fence -- MI355X_MICROARCH "valid forms")
           __hip_atomic_store(a.scratch + ((size_t)rs * a.dvc_rows + s0 + j) * (65 + H) + c, v, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
         } else if (c < 65) {
-          a.dvc[(size_t)(s0 + j) * a.ldv + c] = v;
+          vs[j * SR_LDV + c] = v;
         } else {
-          float* d = a.dh + (size_t)(s0 + j) * a.ld_dh + (c - 65);
-          *d = a.accumulate_dh ? *d + v : v;
+          hs[j * LDH + (c - 65)] = v;
         }
       }
     }
+    bool finish = true;
     if (RS > 1) {
       // the last workgroup of the scene to arrive folds the RS shares in split order
       __syncthreads();  // (drains this workgroup's stores)
@@ -511,17 +600,50 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
         if (last_s) __hip_atomic_store(a.tickets + sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
-      if (last_s) {
+      finish = last_s != 0;
+      if (finish) {
         for (int e = threadIdx.x; e < n * (65 + H); e += 256) {
           const int j = e / (65 + H), c = e - j * (65 + H);
           const float* src = a.scratch + (size_t)(s0 + j) * (65 + H) + c;
           float v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           for (int q = 1; q < RS; ++q)
             v += __hip_atomic_load(src + (size_t)q * a.dvc_rows * (65 + H), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (c < 65) {
-            a.dvc[(size_t)(s0 + j) * a.ldv + c] = v;
-          } else {
-            float* d = a.dh + (size_t)(s0 + j) * a.ld_dh + (c - 65);
+          if (c < 65) vs[j * SR_LDV + c] = v;
+          else hs[j * LDH + (c - 65)] = v;
+        }
+      }
+    }
+    if (finish) {
+      // adjoints of the dense stages, on chip (MFMA tiles): dWh_j = d[v_j | c_j] [W3 | b3]^T, dh_j = (neighbour part)
+      // + dWh_j W_at
+      const int F = a.F, jt = (n + 15) >> 4;
+      __syncthreads();
+      for (int e = threadIdx.x; e < n * 65; e += 256) {
+        const int j = e / 65, m = e - j * 65;
+        a.dvc[(size_t)(s0 + j) * a.ldv + m] = vs[j * SR_LDV + m];  // operand of dW3 = Wh^T dv, db3 = Wh^T dc
+      }
+      for (int t = w; t < jt * (F >> 4); t += 4) {
+        const int j0 = 16 * (t / (F >> 4)), f0 = 16 * (t % (F >> 4));
+        f32x4 acc = sr_tile<true>(vs, SR_LDV, j0, w3_s, SR_LDW, f0, 64, f32x4{0.f, 0.f, 0.f, 0.f}, pp, kq);
+        const float b3f = b3_s[f0 + pp];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = j0 + 4 * kq + r;
+          acc[r] = fmaf(vs[j * SR_LDV + 64], b3f, acc[r]);
+          whs[j * SR_LDW + f0 + pp] = acc[r];
+          if (j < n) a.dWh_out[(size_t)(s0 + j) * F + f0 + pp] = acc[r];
+        }
+      }
+      __syncthreads();
+      for (int t = w; t < jt * (H >> 4); t += 4) {
+        const int j0 = 16 * (t / (H >> 4)), k0 = 16 * (t % (H >> 4));
+        const f32x4 acc = sr_tile<false>(whs, SR_LDW, j0, wat_s, H + 4, k0, F, f32x4{0.f, 0.f, 0.f, 0.f}, pp, kq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = j0 + 4 * kq + r;
+          if (j < n) {
+            const float v = acc[r] + hs[j * LDH + k0 + pp];
+            float* d = a.dh + (size_t)(s0 + j) * a.ld_dh + k0 + pp;
             *d = a.accumulate_dh ? *d + v : v;
           }
         }
@@ -583,19 +705,21 @@ int mggan_social_rows_partial_floats(void) { return SR_WG_FLOATS; }
 #define SR_BWD(HH, NN, TT, KK) \
   hipLaunchKernelGGL((social_rows_bwd_kernel<HH, NN, TT, KK>), dim3(sr_grid(S, a.row_splits)), dim3(256), 0, stream, a)
 
-int mggan_social_rows_fwd(int S, const int* scenes, int H, int max_n, const float* xy_last, const float* dxdy_last,
-                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* vc,
-                          int ldv, const float* h, int ld_h, float* Sout, int ld_s, hipStream_t stream) {
+int mggan_social_rows_fwd(int S, const int* scenes, int H, int F, int max_n, const float* xy_last, const float* dxdy_last,
+                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                          const float* b3, const float* Wat, const float* bat, const float* h, int ld_h, float* Sout,
+                          int ld_s, hipStream_t stream) {
   MG_CHECK_ARG(H == 32 || H == 64, "social_rows_fwd: hidden size %d not built (32 or 64)", H);
-  MG_CHECK_ARG(S >= 0 && max_n >= 0 && max_n <= 64 && xy_mod >= 0, "social_rows_fwd: bad sizes (S %d, max_n %d)", S, max_n);
+  MG_CHECK_ARG(S >= 0 && max_n >= 0 && max_n <= 64 && xy_mod >= 0 && F >= 16 && F <= 64 && F % 16 == 0,
+               "social_rows_fwd: bad sizes (S %d, max_n %d, F %d: 16, 32, 48 or 64)", S, max_n, F);
   if (S == 0) return MGGAN_OK;
-  MG_CHECK_ARG(scenes && xy_last && dxdy_last && W1 && b1 && W2 && b2 && vc && h && Sout, "social_rows_fwd: null pointer");
-  MG_CHECK_ARG(ldv >= SR_LDV && ldv % 4 == 0 && ld_h % 4 == 0 && ld_s % 4 == 0 && ((size_t)vc % 16) == 0 &&
-                   ((size_t)h % 16) == 0 && ((size_t)Sout % 16) == 0,
-               "social_rows_fwd: vc / h / S rows must be 16-byte aligned (ldv %d, ld_h %d, ld_s %d)", ldv, ld_h, ld_s);
+  MG_CHECK_ARG(scenes && xy_last && dxdy_last && W1 && b1 && W2 && b2 && W3 && b3 && Wat && bat && h && Sout,
+               "social_rows_fwd: null pointer");
+  MG_CHECK_ARG(ld_h % 4 == 0 && ld_s % 4 == 0 && ((size_t)h % 16) == 0 && ((size_t)Sout % 16) == 0,
+               "social_rows_fwd: h / S rows must be 16-byte aligned (ld_h %d, ld_s %d)", ld_h, ld_s);
   SocRowsArgs a = {};
-  a.scenes = scenes; a.xy = xy_last; a.dxy = dxdy_last; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.vc = vc; a.h = h;
-  a.Sout = Sout; a.S = S; a.xy_mod = xy_mod; a.ldv = ldv; a.ld_h = ld_h; a.ld_s = ld_s;
+  a.scenes = scenes; a.xy = xy_last; a.dxy = dxdy_last; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
+  a.Wat = Wat; a.bat = bat; a.F = F; a.h = h; a.Sout = Sout; a.S = S; a.xy_mod = xy_mod; a.ld_h = ld_h; a.ld_s = ld_s;
   a.row_splits = sr_splits(S, max_n);
   const int njb = sr_njb(max_n);
   if (H == 32) {
@@ -607,21 +731,22 @@ int mggan_social_rows_fwd(int S, const int* scenes, int H, int max_n, const floa
   return MGGAN_OK;
 }
 
-int mggan_social_rows_bwd(int S, const int* scenes, int H, int max_n, const float* xy_last, const float* dxdy_last,
-                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* vc,
-                          int ldv, const float* h, int ld_h, const float* dS, int ld_ds, float* dvc, int dvc_rows, float* dh,
-                          int ld_dh, int accumulate_dh, float* partials, float* scratch, unsigned* tickets,
-                          hipStream_t stream) {
+int mggan_social_rows_bwd(int S, const int* scenes, int H, int F, int max_n, const float* xy_last, const float* dxdy_last,
+                          int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                          const float* b3, const float* Wat, const float* bat, const float* h, int ld_h, const float* dS,
+                          int ld_ds, float* dvc, int ldv, int dvc_rows, float* Wh, float* dWh, float* dh, int ld_dh,
+                          int accumulate_dh, float* partials, float* scratch, unsigned* tickets, hipStream_t stream) {
   MG_CHECK_ARG(H == 32 || H == 64, "social_rows_bwd: hidden size %d not built (32 or 64)", H);
-  MG_CHECK_ARG(S >= 0 && max_n >= 0 && max_n <= 64 && xy_mod >= 0, "social_rows_bwd: bad sizes (S %d, max_n %d)", S, max_n);
+  MG_CHECK_ARG(S >= 0 && max_n >= 0 && max_n <= 64 && xy_mod >= 0 && F >= 16 && F <= 64 && F % 16 == 0,
+               "social_rows_bwd: bad sizes (S %d, max_n %d, F %d: 16, 32, 48 or 64)", S, max_n, F);
   if (S == 0) return MGGAN_OK;
-  MG_CHECK_ARG(scenes && xy_last && dxdy_last && W1 && b1 && W2 && b2 && vc && h && dS && dvc && dh,
-               "social_rows_bwd: null pointer");
-  MG_CHECK_ARG(ldv >= SR_LDV && ldv % 4 == 0 && ld_h % 4 == 0 && ld_ds % 4 == 0 && ((size_t)vc % 16) == 0 &&
-                   ((size_t)h % 16) == 0 && ((size_t)dS % 16) == 0,
-               "social_rows_bwd: vc / h / dS rows must be 16-byte aligned (ldv %d, ld_h %d, ld_ds %d)", ldv, ld_h, ld_ds);
+  MG_CHECK_ARG(scenes && xy_last && dxdy_last && W1 && b1 && W2 && b2 && W3 && b3 && Wat && bat && h && dS && dvc && Wh &&
+                   dWh && dh, "social_rows_bwd: null pointer");
+  MG_CHECK_ARG(ldv >= 65 && ld_h % 4 == 0 && ld_ds % 4 == 0 && ((size_t)h % 16) == 0 && ((size_t)dS % 16) == 0,
+               "social_rows_bwd: h / dS rows must be 16-byte aligned (ld_h %d, ld_ds %d); ldv %d >= 65", ld_h, ld_ds, ldv);
   SocRowsArgs a = {};
-  a.scenes = scenes; a.xy = xy_last; a.dxy = dxdy_last; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.vc = vc; a.h = h;
+  a.scenes = scenes; a.xy = xy_last; a.dxy = dxdy_last; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
+  a.Wat = Wat; a.bat = bat; a.F = F; a.h = h; a.Wh_out = Wh; a.dWh_out = dWh;
   a.dS = dS; a.dvc = dvc; a.dh = dh; a.partials = partials; a.S = S; a.xy_mod = xy_mod; a.ldv = ldv; a.ld_h = ld_h;
   a.ld_ds = ld_ds; a.ld_dh = ld_dh; a.accumulate_dh = accumulate_dh;
   a.row_splits = sr_splits(S, max_n); a.dvc_rows = dvc_rows; a.scratch = scratch; a.tickets = tickets;

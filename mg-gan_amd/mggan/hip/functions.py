@@ -822,38 +822,33 @@ def _out(slot, rows, cols, like):
     return v, slot.ld
 
 
-SOC_LDV = 68  # row stride of [v_j | c_j] for the row-structured kernels (16-byte aligned rows)
-
-
 def _social_fwd(xy_last, dxdy_last, h_ptr, ld_h, b, Hh, tb, w1, b1, w2, b2, w3, b3, wat, bat, S_ptr, ld_s, save, xy_mod,
                 like):
     """SocialFeatures -> EmbedSocialFeatures -> AttentionPooling for rows [0,b) of a hidden-state matrix given by pointer
     + row stride; S (b,Hh) is written through S_ptr / ld_s.  -> tuple of saved tensors for _social_bwd."""
     Fd = wat.shape[0]
     st = _s()
-    rows = tb.rows_ok
-    ldv = SOC_LDV if rows else 65
+    if tb.rows_ok and Fd <= 64 and Fd % 16 == 0:
+        # ONE launch: Wh = h W_at^T + b_at, [v | c] = Wh [W3 | b3], pair MLP (MFMA), scores, softmax, pooling; nothing is
+        # stored for the backward pass, which recomputes all of it from h and the positions
+        if _load_lib().trace is not None:
+            TRACE_NOTES["social_rows_fwd_pairs"].append(tb.P)
+        lib.mggan_social_rows_fwd(tb.S, _p(tb.scenes), Hh, Fd, tb.max_n, _p(xy_last), _p(dxdy_last), int(xy_mod), _p(w1),
+                                  _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(wat), _p(bat), h_ptr, ld_h, S_ptr, ld_s, st)
+        return (None,) * 7
+    # a scene of more than 64 pedestrians (or scenes that do not tile the batch): per-stage kernels over the pair list
     W3b = _empty(Fd, 65, like=like)
     lib.mggan_social_w3b(_p(w3), _p(b3), _p(W3b), Fd, st)
     # Wh = h W_at^T + b_at and vc = Wh [W3 | b3] as one two-stage chain launch
-    Wh, vc = _empty(b, Fd, like=like), _empty(b, ldv, like=like)
+    Wh, vc = _empty(b, Fd, like=like), _empty(b, 65, like=like)
     a = _McArgs()
     a.X, a.ldx, a.rows, a.K0, a.n = h_ptr, ld_h, b, Hh, 2
     s0, s1 = a.s[0], a.s[1]
     s0.W, s0.bias, s0.out, s0.K, s0.N, s0.ldw, s0.trans, s0.act, s0.ld_out = _p(wat), _p(bat), _p(Wh), Hh, Fd, Hh, 0, ACT_NONE, Fd
-    s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out = _p(W3b), _p(vc), Fd, 65, 65, 1, ACT_NONE, ldv
+    s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out = _p(W3b), _p(vc), Fd, 65, 65, 1, ACT_NONE, 65
     if _load_lib().trace is not None:
         TRACE_NOTES["mlp_chain_flops"].append(2.0 * b * (Hh * Fd + Fd * 65))
     lib.mggan_mlp_chain(ctypes.addressof(a), st)
-    if rows:
-        # pair MLP (MFMA), scores, softmax and pooling in one launch; nothing per pair is stored: the backward pass
-        # recomputes the pair MLP from the positions
-        if _load_lib().trace is not None:
-            TRACE_NOTES["social_rows_fwd_pairs"].append(tb.P)
-        lib.mggan_social_rows_fwd(tb.S, _p(tb.scenes), Hh, tb.max_n, _p(xy_last), _p(dxdy_last), int(xy_mod), _p(w1),
-                                  _p(b1), _p(w2), _p(b2), _p(vc), ldv, h_ptr, ld_h, S_ptr, ld_s, st)
-        return (W3b, Wh, vc, None, None, None, None)
-    # a scene of more than 64 pedestrians (or scenes that do not tile the batch): per-stage kernels over the pair list
     P = tb.P
     feat = _empty(3, max(P, 1), like=like) if save else None      # feature-major [feature][pair]
     l1 = _empty(32, max(P, 1), like=like) if save else None
@@ -878,10 +873,9 @@ def _social_bwd(saved, xy_last, dxdy_last, xy_mod, h_ptr, ld_h, h_keep, b, Hh, t
     root = root_of(owner)
     Fd, P = wat.shape[0], tb.P
     st = _s()
-    rows = tb.rows_ok
-    ldv = SOC_LDV if rows else 65
-    dvc = _empty(b, ldv, like=like)
-    if rows:
+    if tb.rows_ok and Fd <= 64 and Fd % 16 == 0:
+        ldv = 68
+        dvc, Wh, dWh = _empty(b, ldv, like=like), _empty(b, Fd, like=like), _empty(b, Fd, like=like)
         part, grid, pf = None, 0, 0
         if train_w1:  # one partial block [dW2 | db2 ; dW1 | db1] per workgroup, folded by the batched reduction
             grid, pf = lib.mggan_social_rows_grid(tb.S, tb.max_n), lib.mggan_social_rows_partial_floats()
@@ -894,9 +888,10 @@ def _social_bwd(saved, xy_last, dxdy_last, xy_mod, h_ptr, ld_h, h_keep, b, Hh, t
                 tick = tb.soc_tickets[Hh] = torch.zeros(tb.S, dtype=torch.int32, device=like.device)
         if _load_lib().trace is not None:
             TRACE_NOTES["social_rows_bwd_pairs"].append(tb.P)
-        lib.mggan_social_rows_bwd(tb.S, _p(tb.scenes), Hh, tb.max_n, _p(xy_last), _p(dxdy_last), int(xy_mod), _p(w1),
-                                  _p(b1), _p(w2), _p(b2), _p(vc), ldv, h_ptr, ld_h, dS_ptr, ld_ds, _p(dvc), b, dh_ptr, ld_dh,
-                                  int(accumulate_dh), _p(part), _p(scr), _p(tick), st)
+        lib.mggan_social_rows_bwd(tb.S, _p(tb.scenes), Hh, Fd, tb.max_n, _p(xy_last), _p(dxdy_last), int(xy_mod), _p(w1),
+                                  _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(wat), _p(bat), h_ptr, ld_h, dS_ptr, ld_ds,
+                                  _p(dvc), ldv, b, _p(Wh), _p(dWh), dh_ptr, ld_dh, int(accumulate_dh), _p(part), _p(scr),
+                                  _p(tick), st)
         if scr is not None and (_DEFER["on"] or _SIDE["dirty"]):
             _DEFER["keep"].append(scr)
         if train_w1:
@@ -912,8 +907,8 @@ def _social_bwd(saved, xy_last, dxdy_last, xy_mod, h_ptr, ld_h, h_keep, b, Hh, t
                 if _SIDE["dirty"]:
                     _SIDE["keep"].append(part)
     else:
-        if xy_mod:
-            pass  # (the per-stage kernels saved their features in the forward pass)
+        ldv = 65
+        dvc = _empty(b, ldv, like=like)
         dsigma = _empty(max(P, 1), like=like)
         dz2 = _empty(64, max(P, 1), like=like)
         dz1 = _empty(32, max(P, 1), like=like)
@@ -925,16 +920,16 @@ def _social_bwd(saved, xy_last, dxdy_last, xy_mod, h_ptr, ld_h, h_keep, b, Hh, t
             with side_stream(dz2, dz1, l1, feat):
                 wgrad(dz2, P, l1, P, root.grad_ptr(w2), 32, root.grad_ptr(b2), P, 32, 64, fm=1)
                 wgrad(dz1, P, feat, P, root.grad_ptr(w1), 3, root.grad_ptr(b1), P, 3, 32, fm=1)
-    # dWh = dvc [W3|b3]^T and dh += dWh W_at as one two-stage chain launch; d[W3|b3] = Wh^T dvc
-    dWh = _empty(b, Fd, like=like)
-    a = _McArgs()
-    a.X, a.ldx, a.rows, a.K0, a.n = _p(dvc), ldv, b, 65, 2
-    s0, s1 = a.s[0], a.s[1]
-    s0.W, s0.out, s0.K, s0.N, s0.ldw, s0.trans, s0.act, s0.ld_out = _p(W3b), _p(dWh), 65, Fd, 65, 0, ACT_NONE, Fd
-    s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out, s1.accumulate = _p(wat), dh_ptr, Fd, Hh, Hh, 1, ACT_NONE, ld_dh, 1
-    if _load_lib().trace is not None:
-        TRACE_NOTES["mlp_chain_flops"].append(2.0 * b * (65 * Fd + Fd * Hh))
-    lib.mggan_mlp_chain(ctypes.addressof(a), st)
+        # dWh = dvc [W3|b3]^T and dh += dWh W_at as one two-stage chain launch; d[W3|b3] = Wh^T dvc
+        dWh = _empty(b, Fd, like=like)
+        a = _McArgs()
+        a.X, a.ldx, a.rows, a.K0, a.n = _p(dvc), ldv, b, 65, 2
+        s0, s1 = a.s[0], a.s[1]
+        s0.W, s0.out, s0.K, s0.N, s0.ldw, s0.trans, s0.act, s0.ld_out = _p(W3b), _p(dWh), 65, Fd, 65, 0, ACT_NONE, Fd
+        s1.W, s1.out, s1.K, s1.N, s1.ldw, s1.trans, s1.act, s1.ld_out, s1.accumulate = _p(wat), dh_ptr, Fd, Hh, Hh, 1, ACT_NONE, ld_dh, 1
+        if _load_lib().trace is not None:
+            TRACE_NOTES["mlp_chain_flops"].append(2.0 * b * (65 * Fd + Fd * Hh))
+        lib.mggan_mlp_chain(ctypes.addressof(a), st)
     if train_w3:
         with side_stream(Wh, dvc, dWh, h_keep):
             wgrad(Wh, Fd, dvc, ldv, root.grad_ptr(w3), 64, 0, b, 64, Fd)
