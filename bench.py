@@ -112,8 +112,8 @@ def flops_of(name, a):
         return 0.0
     if name == "mggan_scene_attention_fwd":
         return float(a[1]) * 64 * 2 * (a[2] * 32 * 2)
-    if name == "mggan_scene_attention_bwd":
-        return float(a[1]) * 64 * 2 * (a[2] * 32 * 2) * 3
+    if name == "mggan_scene_attention_bwd":  # two data adjoints + the two weight gradients (the forward recomputation is not counted)
+        return float(a[1]) * 64 * 2 * (a[2] * 32 * 2) * 2
     if name == "mggan_social_pairs_fwd":
         return float(a[0]) * 2 * (96 + 2048 + 64)
     if name == "mggan_social_pairs_bwd":

@@ -227,12 +227,18 @@ int mggan_bn_bwd_coef(const double* sums, const double* local_sums, double count
 int mggan_scene_attention_fwd(const float* y2, int B, int C, const float* scale2, const float* shift2, const float* Wa,
                               const float* ba, const float* Wb, const float* bb, float* out, int ld_out,
                               mggan_stream_t stream);
-/* part: ceil(B/4) rows */
+/* Adjoint of the attention head INCLUDING the weight gradients of both layers (MFMA; nothing per position is stored):
+ * G2 = gradient on the raw conv2 output grid (B,C,16,16); wpart: mggan_scene_attention_grid(B) partial blocks of
+ * mggan_scene_attention_partial_floats(C) floats ([32][C+1] = dWa | dba, then [C][33] = dWb | dbb) for
+ * mggan_grad_reduce_multi; part: the same number of rows of 2C doubles (BatchNorm-2 adjoint sums per workgroup);
+ * ticket != NULL: the launch also finishes the BatchNorm-2 adjoint (coef2, dgamma2 / dbeta2 accumulated). */
+int mggan_scene_attention_grid(int B);
+int mggan_scene_attention_partial_floats(int C);
 int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2, const float* shift2,
                               const float* stat2, const float* Wa, const float* ba, const float* Wb, const float* bb,
-                              const float* dout, int ld_dout, float* ds, float* hact, float* dz, float* vsave,
-                              float* G2, double* part, unsigned int* ticket, double count, const float* gamma2,
-                              float* coef2, float* dgamma2, float* dbeta2, mggan_stream_t stream);
+                              const float* dout, int ld_dout, float* G2, float* wpart, double* part,
+                              unsigned int* ticket, double count, const float* gamma2, float* coef2, float* dgamma2,
+                              float* dbeta2, mggan_stream_t stream);
 /* conv2 adjoint (BatchNorm-2 backward on the fly, dW2 / db2 as per-workgroup partial rows in `workspace`, input
  * gradient routed through ReLU / max-pool of block 1 -> G1c (B,C,16,16)); part1:
  * mggan_cnn_bwd_grid(B) rows; coefd1 = [gamma*invstd | S1 | S2 | mean | invstd] (C each) + count, f64, for

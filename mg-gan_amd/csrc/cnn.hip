@@ -153,9 +153,52 @@ __device__ __forceinline__ float pool_bn_relu(const float* __restrict__ base, in
 }
 
 // ---------------- attention head: BN2+ReLU+pool prologue, 64 positions per image ----------------
-// One lane per position (wave = image).  The 2*32*C MLP weights are staged in LDS and the hidden layer is
-// walked with a rolled loop (hidden unit k: recompute h_k, use it, forget it): keeping all of it in
-// registers / scalar registers made the compiler spill ~1k SGPRs through v_writelane (12.6k instructions).
+// AttentionGlobal (cnn.py:109-116) per pooled position: MLP C -> 32 -> C (LeakyReLU .01), softmax over CHANNELS,
+// out = sum_c a_c v_c -- forward and adjoint, INCLUDING the weight gradients of both layers, on v_mfma_f32_16x16x4_f32.
+// A wave owns whole images and walks an image in four groups of 16 positions.  Inside a group lane (pp, kq) =
+// (lane & 15, lane >> 4) stands for position 16 g + pp and for channels 4 kq + r, r = 0..3 (C = 8: the upper two quarters
+// are padding -- zero weights, zero activations, score -inf):
+//   * the prologue (BatchNorm 2 scale/shift, ReLU, 2x2 max-pool with the reference's first-maximum rule) leaves v[r] of
+//     the lane's four channels in registers: exactly the B operand of h^T (32 x 16 pos) = [Wa | ba] [v ; 1] when the
+//     reduction index is walked as c = 4 k + step (an MFMA's k index may be permuted as long as A agrees);
+//   * its D fragment (unit 16 t + 4 kq + r of the lane's position) is the B operand of s^T (C x 16 pos) = [Wb | bb] [h ; 1],
+//     whose D fragment is the score of channel 4 kq + r -- the lane's own channels again: softmax = four registers + two
+//     cross-row shuffles, out = a . v likewise;
+//   * backward: ds -> dh^T = Wb^T ds^T -> dz = dh * leaky'(h) -> dv^T += Wa^T dz^T, every product taking the previous D
+//     registers as its B operand; nothing is transposed;
+//   * the weight gradients contract over POSITIONS (the N axis of all of the above): dz, h, v, ds of a group go through
+//     7 KB of wave-private LDS tiles (row strides 36 / 20 floats: conflict-free both ways) into A / B fragments, dWa / dWb
+//     accumulate in registers over every image of the wave, biases as lane-local sums; one partial block per workgroup
+//     for the batched fixed-order reduction.
+// The fused-tile kernel this replaces wrote ds / v / dz / h (2C + 64 floats per position, 201 MB per launch at 8,192
+// images) for a weight-gradient GEMM to read back -- the largest item of that GEMM's batch -- and ran the MLP on the
+// VALU with LDS-resident weights.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define AT_LDU 36  // dz / h tiles [16 pos][32 + 4]
+#define AT_LDC 20  // v / ds tiles [16 pos][16 + 4]
+#define AT_TILE_FLOATS (2 * 16 * AT_LDU + 2 * 16 * AT_LDC)
+
+template <int CTRL>
+__device__ __forceinline__ float at_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float at_row_sum16(float v) {  // all-lanes sum over a DPP row (row_ror 8, 4, 2, 1)
+  v += at_dpp<0x128>(v);
+  v += at_dpp<0x124>(v);
+  v += at_dpp<0x122>(v);
+  v += at_dpp<0x121>(v);
+  return v;
+}
+__device__ __forceinline__ void at_wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// partial block of a workgroup: [32][C + 1] = dWa | dba, then [C][33] = dWb | dbb
+#define AT_WG_FLOATS(C) (32 * ((C) + 1) + (C) * 33)
+
 template <int C, bool BWD>
 __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restrict__ y2, const float* __restrict__ scale2,
                                                    const float* __restrict__ shift2, const float* __restrict__ Wa,
@@ -163,111 +206,246 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
                                                    const float* __restrict__ bb, float* out, int ld_out,
                                                    // backward only
                                                    const float* __restrict__ dout, int ld_dout,
-                                                   const float* __restrict__ stat2, float* ds_s, float* hact,
-                                                   float* dz_s, float* vsave, float* G2, double* part, BnBwdFin fin) {
-  __shared__ __attribute__((aligned(16))) float wa[HID][C];   // Wa[k][c]
-  __shared__ __attribute__((aligned(16))) float wbT[HID][C];  // Wb[c][k] transposed
-  __shared__ float bas[HID];
-  __shared__ float sred[4][2 * C];
+                                                   const float* __restrict__ stat2, float* G2, float* wpart, double* part,
+                                                   BnBwdFin fin) {
+  constexpr int WGF = AT_WG_FLOATS(C);
+  constexpr int SMF = BWD ? (4 * AT_TILE_FLOATS > 4 * WGF ? 4 * AT_TILE_FLOATS : 4 * WGF) : 1;
+  __shared__ __attribute__((aligned(16))) float smem[SMF];
+  __shared__ double sred[BWD ? 4 * 2 * C : 1];
   __shared__ double colsum[32], cred[BWD ? 8 * 32 : 1];
   __shared__ int flag;
-  for (int i = threadIdx.x; i < HID * C; i += 256) {
-    wa[i / C][i % C] = Wa[i];
-    wbT[i % HID][i / HID] = Wb[i];
-  }
-  if (threadIdx.x < HID) bas[threadIdx.x] = ba[threadIdx.x];
-  __syncthreads();
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), pos = threadIdx.x & 63;
-  if (b >= B) {  // whole waves leave together (the backward pass still meets the others at the barriers below)
-    if (!BWD) return;
-    if (pos < 2 * C) sred[threadIdx.x >> 6][pos] = 0.f;
-  }
-  if (b < B) {
-  const int py = pos >> 3, px = pos & 7;
-  float v[C], raw[C];
-  int code[C];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pp = lane & 15, kq = lane >> 4;
+  const bool chq = 4 * kq < C;  // this lane's channel quarter exists
+  // ---- loop-invariant MFMA A operands ----
+  // h^T = Wa v^T: step r <-> channel 4 k + r;  s^T = Wb h^T: step (t, r) <-> unit 16 t + 4 k + r
+  float wa_a[2][4], wb_a[2][4];
+  // dh^T = Wb^T ds^T (step r <-> channel 4 k + r), dv^T = Wa^T dz^T (step (t, r) <-> unit 16 t + 4 k + r)
+  float wbt_a[2][4], wat_a[2][4];
+  f32x4 ba_c[2], bb_c;  // the biases in the D layout of their product: accumulator init
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float* base = y2 + (((size_t)b * C + c) * 16 + 2 * py) * 16 + 2 * px;
-    v[c] = pool_bn_relu(base, 16, scale2[c], shift2[c], code[c], raw[c]);
-  }
-  float sc[C];
+  for (int t = 0; t < 2; ++t) {
+    const int u = 16 * t + pp;
 #pragma unroll
-  for (int c = 0; c < C; ++c) sc[c] = bb[c];
-#pragma unroll 2
-  for (int k = 0; k < HID; ++k) {
-    float h0 = bas[k], h1 = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; c += 2) { h0 = fmaf(wa[k][c], v[c], h0); h1 = fmaf(wa[k][c + 1], v[c + 1], h1); }
-    float h = h0 + h1;
-    h = h > 0.f ? h : 0.01f * h;  // nn.LeakyReLU() default slope, cnn.py:19-20
-#pragma unroll
-    for (int c = 0; c < C; ++c) sc[c] = fmaf(wbT[k][c], h, sc[c]);
-  }
-  float mx = -INFINITY;
-#pragma unroll
-  for (int c = 0; c < C; ++c) mx = fmaxf(mx, sc[c]);
-  float den = 0.f;
-#pragma unroll
-  for (int c = 0; c < C; ++c) { sc[c] = __expf(sc[c] - mx); den += sc[c]; }
-  const float inv = 1.f / den;
-  float o = 0.f;
-#pragma unroll
-  for (int c = 0; c < C; ++c) { sc[c] *= inv; o = fmaf(sc[c], v[c], o); }
-  if (!BWD) {
-    out[(size_t)b * ld_out + pos] = o;
-    return;
-  }
-  // ---- backward: out = sum_c a_c v_c, a = softmax(s) ----
-  const float go = dout[(size_t)b * ld_dout + pos];
-  const size_t row = (size_t)b * 64 + pos, NR = (size_t)B * 64;  // saved arrays are [feature][NR]
-  float dv[C], dsv[C], dot = 0.f;
-#pragma unroll
-  for (int c = 0; c < C; ++c) { dv[c] = go * sc[c]; dot = fmaf(sc[c], go * v[c], dot); }
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    dsv[c] = sc[c] * (go * v[c] - dot);
-    ds_s[c * NR + row] = dsv[c];
-    vsave[c * NR + row] = v[c];
-  }
-#pragma unroll 2
-  for (int k = 0; k < HID; ++k) {
-    float h0 = bas[k], h1 = 0.f, d0 = 0.f, d1 = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; c += 2) {
-      h0 = fmaf(wa[k][c], v[c], h0);
-      h1 = fmaf(wa[k][c + 1], v[c + 1], h1);
-      d0 = fmaf(wbT[k][c], dsv[c], d0);
-      d1 = fmaf(wbT[k][c + 1], dsv[c + 1], d1);
-    }
-    const float hp = h0 + h1;
-    const float d = (d0 + d1) * (hp > 0.f ? 1.f : 0.01f);
-    dz_s[k * NR + row] = d;
-    hact[k * NR + row] = hp > 0.f ? hp : 0.01f * hp;
-#pragma unroll
-    for (int c = 0; c < C; ++c) dv[c] = fmaf(wa[k][c], d, dv[c]);
-  }
-  // route through max-pool + ReLU to the raw conv2 output grid; partial sums for the BN backward
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float g = v[c] > 0.f ? dv[c] : 0.f;
-    float* gb = G2 + (((size_t)b * C + c) * 16 + 2 * py) * 16 + 2 * px;
-    *reinterpret_cast<float2*>(gb) = make_float2(code[c] == 0 ? g : 0.f, code[c] == 1 ? g : 0.f);
-    *reinterpret_cast<float2*>(gb + 16) = make_float2(code[c] == 2 ? g : 0.f, code[c] == 3 ? g : 0.f);
-    const float xh = (raw[c] - stat2[c]) * stat2[C + c];
-    const float s1 = wave_sum(g), s2 = wave_sum(g * xh);
-    if (pos == 0) {
-      sred[threadIdx.x >> 6][c] = s1;
-      sred[threadIdx.x >> 6][C + c] = s2;
+    for (int r = 0; r < 4; ++r) {
+      const int c = 4 * kq + r, um = 16 * t + 4 * kq + r;
+      wa_a[t][r] = c < C ? Wa[u * C + c] : 0.f;
+      wb_a[t][r] = pp < C ? Wb[pp * HID + um] : 0.f;
+      if (BWD) {
+        wbt_a[t][r] = c < C ? Wb[c * HID + u] : 0.f;
+        wat_a[t][r] = pp < C ? Wa[um * C + pp] : 0.f;
+      }
+      ba_c[t][r] = ba[um];
     }
   }
-  }  // b < B
-  // one partial row per workgroup (f32 within an image, f64 across); the last workgroup folds the rows
+  float sc2[4], sh2[4], mean2[4], istd2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = chq ? 4 * kq + r : 0;
+    bb_c[r] = chq ? bb[c] : 0.f;
+    sc2[r] = scale2[c];
+    sh2[r] = shift2[c];
+    if (BWD) {
+      mean2[r] = stat2[c];
+      istd2[r] = stat2[C + c];
+    }
+  }
+  // ---- accumulators over every image of this wave (backward) ----
+  f32x4 dWa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // dWa[u = 16 t + 4 kq + r][c = pp]
+  f32x4 dWb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // dWb[c = 4 kq + r][u = 16 t + pp]
+  float dba[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dbb[4] = {0.f, 0.f, 0.f, 0.f};  // lane-local (over positions)
+  double s1d[4] = {0.0, 0.0, 0.0, 0.0}, s2d[4] = {0.0, 0.0, 0.0, 0.0};  // BatchNorm-2 adjoint sums of channel 4 kq + r
+  float s1i[4] = {0.f, 0.f, 0.f, 0.f}, s2i[4] = {0.f, 0.f, 0.f, 0.f};  // ... of the image at hand (f32 within, f64 across)
+  float* DZs = smem + (BWD ? w * AT_TILE_FLOATS : 0);
+  float* Hs = DZs + 16 * AT_LDU;
+  float* Vs = Hs + 16 * AT_LDU;
+  float* DSs = Vs + 16 * AT_LDC;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  // the 2x2 windows of the lane's four channels at position 16 g + pp of image b (raw conv2 output)
+  auto load_windows = [&](int b, int g, f32x4 win[4]) {
+    const int pos = 16 * g + pp, py = pos >> 3, px = pos & 7;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (chq) {
+        const float* base = y2 + (((size_t)b * C + 4 * kq + r) * 16 + 2 * py) * 16 + 2 * px;
+        const float2 lo = *reinterpret_cast<const float2*>(base), hi = *reinterpret_cast<const float2*>(base + 16);
+        win[r] = f32x4{lo.x, lo.y, hi.x, hi.y};
+      } else {
+        win[r] = zero;
+      }
+    }
+  };
+  // a wave walks (image, group) pairs; the windows of the NEXT pair are in flight while this one is computed (a wave
+  // that loads, waits, computes, loads again spends four memory latencies per image)
+  const int b0 = blockIdx.x * 4 + w, bstep = gridDim.x * 4;
+  const int n_it = b0 < B ? 4 * ((B - 1 - b0) / bstep + 1) : 0;
+  f32x4 cur[4], nxt[4];
+  if (n_it > 0) load_windows(b0, 0, cur);
+#pragma unroll 1
+  for (int it = 0; it < n_it; ++it) {
+    const int b = b0 + (it >> 2) * bstep, g = it & 3;
+    if (it + 1 < n_it) load_windows(b0 + ((it + 1) >> 2) * bstep, (it + 1) & 3, nxt);
+    const int pos = 16 * g + pp, py = pos >> 3, px = pos & 7;
+    // prologue: v = maxpool2(relu(bn2(y2))), first maximum wins (pool_bn_relu)
+    float v[4], raw[4];
+    int code[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float best = fmaxf(fmaf(cur[r][0], sc2[r], sh2[r]), 0.f);
+      code[r] = 0;
+      raw[r] = cur[r][0];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const float z = fmaxf(fmaf(cur[r][k], sc2[r], sh2[r]), 0.f);
+        if (z > best) { best = z; code[r] = k; raw[r] = cur[r][k]; }
+      }
+      v[r] = chq ? best : 0.f;
+    }
+    // h = leaky(Wa v + ba): D fragment = unit 16 t + 4 kq + r of position pp
+    f32x4 hp[2] = {ba_c[0], ba_c[1]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      hp[0] = MFMA16(wa_a[0][r], v[r], hp[0]);
+      hp[1] = MFMA16(wa_a[1][r], v[r], hp[1]);
+    }
+    f32x4 h[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[t][r] = hp[t][r] > 0.f ? hp[t][r] : 0.01f * hp[t][r];  // nn.LeakyReLU(), cnn.py:19-20
+    // s = Wb h + bb: D fragment = channel 4 kq + r (two accumulator chains)
+    f32x4 sa = bb_c, sb = zero;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sa = MFMA16(wb_a[0][r], h[0][r], sa);
+      sb = MFMA16(wb_a[1][r], h[1][r], sb);
+    }
+    const f32x4 sc = sa + sb;
+    float mx = chq ? fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])) : -INFINITY;
+    mx = quarters_max(mx);
+    float a[4], den = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a[r] = chq ? __expf(sc[r] - mx) : 0.f;
+      den += a[r];
+    }
+    const float inv = 1.f / quarters_sum(den);
+    float o = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a[r] *= inv;
+      o = fmaf(a[r], v[r], o);
+    }
+    o = quarters_sum(o);
+    if (!BWD) {
+      if (kq == 0) out[(size_t)b * ld_out + pos] = o;
+    } else {
+      // ---- backward: out = sum_c a_c v_c, a = softmax(s) ----
+      const float go = dout[(size_t)b * ld_dout + pos];
+      const float dot = go * o;  // sum_c a_c (go v_c)
+      f32x4 dv, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dv[r] = go * a[r];
+        ds[r] = a[r] * (go * v[r] - dot);
+        dbb[r] += ds[r];
+      }
+      // dh^T = Wb^T ds^T; dz = dh * leaky'(h)
+      f32x4 dz[2] = {zero, zero};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dz[0] = MFMA16(wbt_a[0][r], ds[r], dz[0]);
+        dz[1] = MFMA16(wbt_a[1][r], ds[r], dz[1]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dz[t][r] *= hp[t][r] > 0.f ? 1.f : 0.01f;
+          dba[t][r] += dz[t][r];
+        }
+      // dv^T += Wa^T dz^T (two accumulator chains)
+      f32x4 dv2 = zero;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dv = MFMA16(wat_a[0][r], dz[0][r], dv);
+        dv2 = MFMA16(wat_a[1][r], dz[1][r], dv2);
+      }
+      dv += dv2;
+      // route through max-pool + ReLU to the raw conv2 output grid; partial sums of the BatchNorm-2 adjoint
+      if (chq) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gg = v[r] > 0.f ? dv[r] : 0.f;
+          float* gb = G2 + (((size_t)b * C + 4 * kq + r) * 16 + 2 * py) * 16 + 2 * px;
+          *reinterpret_cast<float2*>(gb) = make_float2(code[r] == 0 ? gg : 0.f, code[r] == 1 ? gg : 0.f);
+          *reinterpret_cast<float2*>(gb + 16) = make_float2(code[r] == 2 ? gg : 0.f, code[r] == 3 ? gg : 0.f);
+          s1i[r] += gg;
+          s2i[r] = fmaf(gg, (raw[r] - mean2[r]) * istd2[r], s2i[r]);
+        }
+      }
+      // weight gradients: contraction over the 16 positions through the wave's LDS tiles (pos = step + 4 k)
+      *reinterpret_cast<f32x4*>(DZs + pp * AT_LDU + 4 * kq) = dz[0];
+      *reinterpret_cast<f32x4*>(DZs + pp * AT_LDU + 16 + 4 * kq) = dz[1];
+      *reinterpret_cast<f32x4*>(Hs + pp * AT_LDU + 4 * kq) = h[0];
+      *reinterpret_cast<f32x4*>(Hs + pp * AT_LDU + 16 + 4 * kq) = h[1];
+      *reinterpret_cast<f32x4*>(Vs + pp * AT_LDC + 4 * kq) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(DSs + pp * AT_LDC + 4 * kq) = ds;
+      at_wave_lds_sync();
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const int pr = sp + 4 * kq;
+        const float vb = Vs[pr * AT_LDC + pp], da = DSs[pr * AT_LDC + pp];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          dWa[t] = MFMA16(DZs[pr * AT_LDU + 16 * t + pp], vb, dWa[t]);
+          dWb[t] = MFMA16(da, Hs[pr * AT_LDU + 16 * t + pp], dWb[t]);
+        }
+      }
+      at_wave_lds_sync();  // the tiles are rewritten by the next group
+      if (g == 3) {  // the image is through: f32 sums within it, f64 across images
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s1d[r] += (double)at_row_sum16(s1i[r]);
+          s2d[r] += (double)at_row_sum16(s2i[r]);
+          s1i[r] = s2i[r] = 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cur[r] = nxt[r];
+  }
+  if (!BWD) return;
+  // ---- one partial block per workgroup: the four waves meet in LDS (fixed order) ----
   __syncthreads();
+  {
+    float* mine = smem + w * WGF;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = 16 * t + 4 * kq + r;
+        if (pp < C) mine[u * (C + 1) + pp] = dWa[t][r];
+        const float sb = at_row_sum16(dba[t][r]);
+        if (pp == 0) mine[u * (C + 1) + C] = sb;
+        if (chq) mine[32 * (C + 1) + (4 * kq + r) * 33 + 16 * t + pp] = dWb[t][r];
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sb = at_row_sum16(dbb[r]);
+      if (pp == 0 && chq) mine[32 * (C + 1) + (4 * kq + r) * 33 + 32] = sb;
+      if (pp == 0 && chq) {
+        sred[w * 2 * C + 4 * kq + r] = s1d[r];
+        sred[w * 2 * C + C + 4 * kq + r] = s2d[r];
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < WGF; e += 256)
+    wpart[(size_t)blockIdx.x * WGF + e] = (smem[e] + smem[WGF + e]) + (smem[2 * WGF + e] + smem[3 * WGF + e]);
   if ((int)threadIdx.x < 2 * C)
     store_part(part + (size_t)blockIdx.x * 2 * C + threadIdx.x,
-               ((double)sred[0][threadIdx.x] + (double)sred[1][threadIdx.x]) +
-                   ((double)sred[2][threadIdx.x] + (double)sred[3][threadIdx.x]));
+               (sred[threadIdx.x] + sred[2 * C + threadIdx.x]) + (sred[4 * C + threadIdx.x] + sred[6 * C + threadIdx.x]));
   if (!fin.ticket) return;
   if (!last_block(fin.ticket, &flag)) return;
   colsum_rows(part, gridDim.x, 2 * C, colsum, cred);
@@ -602,6 +780,12 @@ int mggan_bn_finalize(const double* sums, double count, int C, int training, con
   return MGGAN_OK;
 }
 
+// persistent: a wave walks images b, b + 4 grid, ... (its weight fragments are loaded once)
+static int attn_grid(int B) { return cdiv(B, 4) < 1024 ? cdiv(B, 4) : 1024; }
+
+int mggan_scene_attention_grid(int B) { return B > 0 ? attn_grid(B) : 0; }
+int mggan_scene_attention_partial_floats(int C) { return AT_WG_FLOATS(C); }
+
 int mggan_scene_attention_fwd(const float* y2, int B, int C, const float* scale2, const float* shift2, const float* Wa,
                               const float* ba, const float* Wb, const float* bb, float* out, int ld_out,
                               hipStream_t stream) {
@@ -610,34 +794,36 @@ int mggan_scene_attention_fwd(const float* y2, int B, int C, const float* scale2
   MG_CHECK_ARG(y2 && scale2 && shift2 && Wa && ba && Wb && bb && out, "scene_attention_fwd: null pointer");
   const BnBwdFin none = make_bfin(nullptr, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   if (C == 16)
-    hipLaunchKernelGGL((attn_kernel<16, false>), dim3(cdiv(B, 4)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, none);
+    hipLaunchKernelGGL((attn_kernel<16, false>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
+                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, none);
   else
-    hipLaunchKernelGGL((attn_kernel<8, false>), dim3(cdiv(B, 4)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, none);
+    hipLaunchKernelGGL((attn_kernel<8, false>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
+                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, none);
   MG_LAUNCH_CHECK("scene_attention_fwd");
   return MGGAN_OK;
 }
 
-/* part: ceil(B/4) rows of 2C doubles (sum g | sum g*xhat per workgroup).  ticket != NULL: the launch also finishes
- * the BatchNorm-2 adjoint (coef2 = [gamma*invstd | mean g | mean g*xhat], dgamma2 / dbeta2 accumulated) */
+/* wpart: mggan_scene_attention_grid(B) partial blocks of mggan_scene_attention_partial_floats(C) floats ([32][C+1] = dWa |
+ * dba, then [C][33] = dWb | dbb) for mggan_grad_reduce_multi; part: the same number of rows of 2C doubles (sum g | sum
+ * g*xhat per workgroup).  ticket != NULL: the launch also finishes the BatchNorm-2 adjoint (coef2 = [gamma*invstd | mean
+ * g | mean g*xhat], dgamma2 / dbeta2 accumulated) */
 int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2, const float* shift2,
                               const float* stat2, const float* Wa, const float* ba, const float* Wb, const float* bb,
-                              const float* dout, int ld_dout, float* ds, float* hact, float* dz, float* vsave,
-                              float* G2, double* part, unsigned* ticket, double count, const float* gamma2, float* coef2,
-                              float* dgamma2, float* dbeta2, hipStream_t stream) {
+                              const float* dout, int ld_dout, float* G2, float* wpart, double* part, unsigned* ticket,
+                              double count, const float* gamma2, float* coef2, float* dgamma2, float* dbeta2,
+                              hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "scene_attention_bwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
-  MG_CHECK_ARG(y2 && scale2 && shift2 && stat2 && Wa && ba && Wb && bb && dout && ds && hact && dz && vsave && G2 && part,
+  MG_CHECK_ARG(y2 && scale2 && shift2 && stat2 && Wa && ba && Wb && bb && dout && G2 && wpart && part,
                "scene_attention_bwd: null pointer");
   MG_CHECK_ARG(!ticket || (gamma2 && coef2 && dgamma2 && dbeta2), "scene_attention_bwd: the fused finalize needs gamma / coef / grads");
   const BnBwdFin fin = make_bfin(ticket, count, gamma2, stat2, coef2, nullptr, dgamma2, dbeta2);
   if (C == 16)
-    hipLaunchKernelGGL((attn_kernel<16, true>), dim3(cdiv(B, 4)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, ds, hact, dz, vsave, G2, part, fin);
+    hipLaunchKernelGGL((attn_kernel<16, true>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
+                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, G2, wpart, part, fin);
   else
-    hipLaunchKernelGGL((attn_kernel<8, true>), dim3(cdiv(B, 4)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, ds, hact, dz, vsave, G2, part, fin);
+    hipLaunchKernelGGL((attn_kernel<8, true>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
+                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, G2, wpart, part, fin);
   MG_LAUNCH_CHECK("scene_attention_bwd");
   return MGGAN_OK;
 }

@@ -78,6 +78,24 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Sum / max over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: two
+// v_permlane{16,32}_swap + two VALU ops (gfx950) instead of two ds_bpermute round trips through the LDS crossbar.
+// swap16(x, x) -> {[r0, r0, r2, r2], [r1, r1, r3, r3]}, swap32(y, y) -> {[lo, lo], [hi, hi]} (checked on hardware
+// against __shfl_xor: bit-identical).
+typedef unsigned mg_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float quarters_sum(float v) {
+  const mg_u2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float a = __uint_as_float(s[0]) + __uint_as_float(s[1]);
+  const mg_u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+__device__ __forceinline__ float quarters_max(float v) {
+  const mg_u2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float a = fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+  const mg_u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+  return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

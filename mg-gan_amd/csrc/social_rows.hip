@@ -83,12 +83,7 @@ __device__ __forceinline__ float row_max16(float v) {
   v = fmaxf(v, sr_dpp<0x121>(v));
   return v;
 }
-// sum over the four DPP rows of a wave (the four kq quarters), result in every lane
-__device__ __forceinline__ float quarters_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
-}
+// (sum over the four DPP rows of a wave -- the four kq quarters: quarters_sum, common.h)
 // LDS traffic between the lanes of ONE wave (the transposition tiles): program order is execution order, the compiler
 // only has to keep it
 __device__ __forceinline__ void wave_lds_sync() {

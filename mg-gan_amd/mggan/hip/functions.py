@@ -1305,20 +1305,29 @@ class SceneAttentionFn(Function):
         tk = _cnn_tickets(ctx.owner, dev)
         fused = sync is None
         dout, ld = _rows2d(dout)
-        rows = B * 64
-        ds, vs = _empty(C, rows, like=img), _empty(C, rows, like=img)        # feature-major [feature][row]
-        hact, dz = _empty(32, rows, like=img), _empty(32, rows, like=img)
         G2 = _empty(B, C, 16, 16, like=img)
-        rows2 = max((B + 3) // 4, 1)
+        rows2 = max(lib.mggan_scene_attention_grid(B), 1)
         part2 = torch.empty(rows2, 2 * C, dtype=torch.float64, device=dev)
         coef2 = _empty(3 * C, like=img)
+        # the attention head's weight gradients come out of the same launch: one partial block per workgroup
+        pf = lib.mggan_scene_attention_partial_floats(C)
+        wpart = _empty(rows2 * pf, like=img)
         lib.mggan_scene_attention_bwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(stat2), _p(wa), _p(ba), _p(wb), _p(bb), _p(dout),
-                                      ld, _p(ds), _p(hact), _p(dz), _p(vs), _p(G2), _p(part2),
-                                      tk.data_ptr() + 8 if fused else 0, cnt2, _p(g2), _p(coef2), root.grad_ptr(g2),
-                                      root.grad_ptr(be2), st)
-        with side_stream(ds, hact, dz, vs):
-            wgrad(ds, rows, hact, rows, root.grad_ptr(wb), 32, root.grad_ptr(bb), rows, 32, C, fm=1)
-            wgrad(dz, rows, vs, rows, root.grad_ptr(wa), C, root.grad_ptr(ba), rows, C, 32, fm=1)
+                                      ld, _p(G2), _p(wpart), _p(part2), tk.data_ptr() + 8 if fused else 0, cnt2, _p(g2),
+                                      _p(coef2), root.grad_ptr(g2), root.grad_ptr(be2), st)
+        if B:
+            p0 = wpart.data_ptr()
+            adescs = ((p0, root.grad_ptr(wa), root.grad_ptr(ba), 32, C + 1, C),
+                      (p0 + 4 * 32 * (C + 1), root.grad_ptr(wb), root.grad_ptr(bb), C, 33, 32))
+            if _DEFER["on"] and not _SIDE["dirty"]:
+                for k, (pp_, dw, db, M, Naug, lddw) in enumerate(adescs):
+                    _queue_reduce(pp_, dw, db, M, Naug, 1, lddw, rows2, 1, pf, keep=(wpart,) if k == 0 else ())
+            else:
+                arr = (_ReduceDesc * 2)(*[_ReduceDesc(pp_, dw, db or None, 0, 0, M, Naug, 1, lddw, rows2, 1, pf, 0)
+                                          for pp_, dw, db, M, Naug, lddw in adescs])
+                lib.mggan_grad_reduce_multi(ctypes.addressof(arr), 2, st)
+                if _SIDE["dirty"]:
+                    _SIDE["keep"].append(wpart)
 
         def bn_bwd_sharded(part, nrows, gamma, beta, stat, cnt, coef, coefd, hw):
             dc = getattr(sync, "devcomm", None)
