@@ -10,26 +10,11 @@ from mggan.hip.flat import FlatModule
 from mggan.hip import functions as HF
 
 
-def make_mlp(dim_list, activation_list, batch_norm=False, dropout=0):
-    layers = []
-    index = 0
-    for dim_in, dim_out in zip(dim_list[:-1], dim_list[1:]):
-        activation = activation_list[index]
-        layers.append(nn.Linear(dim_in, dim_out))
-        if batch_norm:
-            layers.append(nn.BatchNorm1d(dim_out))
-        if activation == "relu":
-            layers.append(nn.ReLU())
-        elif activation == "tanh":
-            layers.append(nn.Tanh())
-        elif activation == "leakyrelu":
-            layers.append(nn.LeakyReLU())
-        elif activation == "sigmoid":
-            layers.append(nn.Sigmoid())
-        if dropout > 0 and index < len(dim_list) - 2:
-            layers.append(nn.Dropout(p=dropout))
-        index += 1
-    return nn.Sequential(*layers)
+def attention_head(channels, hidden):
+    """The channel-attention MLP of AttentionGlobal (reference: make_mlp([C, mlp_dim, C], ["leakyrelu", None]),
+    cnn.py:102-107): Linear(C, hidden) -> LeakyReLU(0.01) -> Linear(hidden, C) as an nn.Sequential, so that the
+    state_dict keys ("0.weight", "2.weight", ...) and the order of the seeded initialisation are the reference's."""
+    return nn.Sequential(nn.Linear(channels, hidden), nn.LeakyReLU(), nn.Linear(hidden, channels))
 
 
 class Conv_Blocks(nn.Module):
@@ -100,8 +85,7 @@ class AttentionGlobal(FlatModule):
         self.sync = None  # set by mggan.parallel for multi-GPU batch statistics
         self.init_cnn()
         self.final_embedding = self.CNN.bottleneck_dim + self.noise_attention_dim
-        self.cnn_attention = make_mlp([self.CNN.bootleneck_channel, self.mlp_dim, self.CNN.bootleneck_channel],
-                                      activation_list=["leakyrelu", None])
+        self.cnn_attention = attention_head(self.CNN.bootleneck_channel, self.mlp_dim)
         self.init_cnn()
 
     def init_cnn(self):
