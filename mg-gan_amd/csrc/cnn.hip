@@ -636,23 +636,37 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
   for (int t = 0; t < 9; ++t) wacc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float bacc = 0.f;
 
+  // the three planes of the NEXT image (raw conv1 value, raw conv2 output, its gradient: 48 values per thread) are in
+  // flight while this one is computed: a workgroup that loads, waits, stages, computes spends a memory latency per image
+  // with its matrix pipes idle (MFMA busy 0.47 with two workgroups per CU covering for each other)
+  float rx[C], ry[C], rg[C];
+  auto fetch = [&](int b) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const size_t gi = ((size_t)b * C + c) * 256 + threadIdx.x;
+      rx[c] = xsel[gi];
+      ry[c] = y2[gi];
+      rg[c] = G2[gi];
+    }
+  };
+  if ((int)blockIdx.x < B) fetch(blockIdx.x);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     lds_barrier();
     {
       const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
-#pragma unroll 8
+#pragma unroll
       for (int c = 0; c < C; ++c) {
-        const size_t gi = ((size_t)b * C + c) * 256 + threadIdx.x;
-        const float raw = xsel[gi];
+        const float raw = rx[c];
         a1p[c * C2_PLANE + (py + 1) * A1_LD + px + 1] = fmaxf(fmaf(raw, scale1[c], shift1[c]), 0.f);
         y1r[c * 256 + threadIdx.x] = raw;
-        const float xh = (y2[gi] - stat2[c]) * stat2[C + c];
-        dyp[c * C2_PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (G2[gi] - coef2[C + c] - xh * coef2[2 * C + c]);
+        const float xh = (ry[c] - stat2[c]) * stat2[C + c];
+        dyp[c * C2_PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (rg[c] - coef2[C + c] - xh * coef2[2 * C + c]);
       }
     }
+    if (b + (int)gridDim.x < B) fetch(b + gridDim.x);
     lds_barrier();
     // ---- (1) weight gradient: K runs over this wave's 64 positions (rows 4w..4w+3), 4 positions per MFMA
-#pragma unroll 1
+#pragma unroll 2
     for (int ks = 0; ks < 16; ++ks) {
       const int y = 4 * w + (ks >> 2), x0 = (ks & 3) * 4;
       // A[i = co][k = position x0+fk]
@@ -667,28 +681,35 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
     }
     // ---- (2) input gradient for rows 4w..4w+3: M = 16 x-positions of one row, N = ci, K = (tap', co)
     float s1 = 0.f, s2 = 0.f;  // BN1-backward partial sums for channel ci = fi
-#pragma unroll 1
-    for (int ry = 0; ry < 4; ++ry) {
-      const int y = 4 * w + ry;
-      f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // (the wave's four rows together: four independent accumulator chains -- one chain of 36 dependent MFMAs per row
+    //  paid the 40-cycle dependent latency on every one of them -- and one read of the weight fragment serves four rows)
+    f32x4_t acc4[4];
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
+    for (int ry = 0; ry < 4; ++ry) acc4[ry] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c4 = 0; c4 < C; c4 += 4) {
-          const int co = (c4 >> 2) + 8 * (fk & 1) + 4 * (fk >> 1);
-          // A[i = x][k = (tp, co)] = dy[co] at padded (y + tp/3, x + tp%3);  B[k][j = ci] = wf[tp][co][ci]
-          const float a = dyp[co * C2_PLANE + (y + tp / 3) * A1_LD + fi + tp % 3];
-          const float bv = wf[(tp * C + co) * C2_WLD + fi];
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+    for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+      for (int c4 = 0; c4 < C; c4 += 4) {
+        const int co = (c4 >> 2) + 8 * (fk & 1) + 4 * (fk >> 1);
+        // A[i = x][k = (tp, co)] = dy[co] at padded (y + tp/3, x + tp%3);  B[k][j = ci] = wf[tp][co][ci]
+        const float bv = wf[(tp * C + co) * C2_WLD + fi];
+#pragma unroll
+        for (int ry = 0; ry < 4; ++ry) {
+          const float a = dyp[co * C2_PLANE + (4 * w + ry + tp / 3) * A1_LD + fi + tp % 3];
+          acc4[ry] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc4[ry], 0, 0, 0);
         }
       }
+    }
+#pragma unroll
+    for (int ry = 0; ry < 4; ++ry) {
+      const int y = 4 * w + ry;
       // D fragment: register r <-> x = 4*fk + r, column = ci = fi
       float g[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int x = 4 * fk + r;
         const bool on = a1p[fi * C2_PLANE + (y + 1) * A1_LD + x + 1] > 0.f;
-        g[r] = on ? acc[r] : 0.f;
+        g[r] = on ? acc4[ry][r] : 0.f;
         const float xh = (y1r[fi * 256 + y * 16 + x] - stat1[fi]) * stat1[C + fi];
         s1 += g[r];
         s2 = fmaf(g[r], xh, s2);
