@@ -92,6 +92,8 @@ class MultiGeneratorGAN(abc.ABC):
             self.rng.begin_iteration(sub_batches, b, self.config.noise_dim, self.device)
         from mggan.hip import functions as HF
 
+        if not (self.dist.enabled and self.dist.devcomm is None):  # (segmented sharded replay: the trainer set them off)
+            HF.auto_branches(b)
         cfg = self.config
         run_d = self.total_iterations % max(int(cfg.num_gen_steps), 1) == 0 or self.epoch >= cfg.keep_gen_steps
         shared = None
