@@ -179,17 +179,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AT_LDC 20  // v / ds tiles [16 pos][16 + 4]
 #define AT_TILE_FLOATS (2 * 16 * AT_LDU + 2 * 16 * AT_LDC)
 
-template <int CTRL>
-__device__ __forceinline__ float at_dpp(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float at_row_sum16(float v) {  // all-lanes sum over a DPP row (row_ror 8, 4, 2, 1)
-  v += at_dpp<0x128>(v);
-  v += at_dpp<0x124>(v);
-  v += at_dpp<0x122>(v);
-  v += at_dpp<0x121>(v);
-  return v;
-}
 __device__ __forceinline__ void at_wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -406,8 +395,8 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
       if (g == 3) {  // the image is through: f32 sums within it, f64 across images
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s1d[r] += (double)at_row_sum16(s1i[r]);
-          s2d[r] += (double)at_row_sum16(s2i[r]);
+          s1d[r] += (double)row_sum16(s1i[r]);
+          s2d[r] += (double)row_sum16(s2i[r]);
           s1i[r] = s2i[r] = 0.f;
         }
       }
@@ -426,13 +415,13 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
       for (int r = 0; r < 4; ++r) {
         const int u = 16 * t + 4 * kq + r;
         if (pp < C) mine[u * (C + 1) + pp] = dWa[t][r];
-        const float sb = at_row_sum16(dba[t][r]);
+        const float sb = row_sum16(dba[t][r]);
         if (pp == 0) mine[u * (C + 1) + C] = sb;
         if (chq) mine[32 * (C + 1) + (4 * kq + r) * 33 + 16 * t + pp] = dWb[t][r];
       }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float sb = at_row_sum16(dbb[r]);
+      const float sb = row_sum16(dbb[r]);
       if (pp == 0 && chq) mine[32 * (C + 1) + (4 * kq + r) * 33 + 32] = sb;
       if (pp == 0 && chq) {
         sred[w * 2 * C + 4 * kq + r] = s1d[r];

@@ -96,6 +96,27 @@ __device__ __forceinline__ float quarters_max(float v) {
   return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
 }
 
+// All-lanes sum / max over the 16 lanes of a DPP row (lanes l ^ 1, 2, 4, 8 ...): four row_ror DPP operations on the
+// VALU instead of four ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ float mg_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+  v += mg_dpp<0x128>(v);  // row_ror:8
+  v += mg_dpp<0x124>(v);  // row_ror:4
+  v += mg_dpp<0x122>(v);
+  v += mg_dpp<0x121>(v);
+  return v;
+}
+__device__ __forceinline__ float row_max16(float v) {
+  v = fmaxf(v, mg_dpp<0x128>(v));
+  v = fmaxf(v, mg_dpp<0x124>(v));
+  v = fmaxf(v, mg_dpp<0x122>(v));
+  v = fmaxf(v, mg_dpp<0x121>(v));
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

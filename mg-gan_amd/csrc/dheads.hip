@@ -127,8 +127,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int o = 0; o < GM; ++o)
         if (o < n2) {
-          float v = p2[r][o];
-          v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+          const float v = row_sum16(p2[r][o]);  // DPP row reduction (was four ds_bpermute per value: 128 per wave and tile)
           if (fi == 0) part[w][4 * fk + r][o] = v;
         }
     __syncthreads();

@@ -682,8 +682,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         n1 = fmaf(w2r[1][q], av[q], n1);
       }
       if (save && w == 0) *reinterpret_cast<f32x4*>(p.Aact + ((tt * 4 + fk) * 16 + fi) * 4) = av;
-      n0 += __shfl_xor(n0, 16, 64); n1 += __shfl_xor(n1, 16, 64);
-      n0 += __shfl_xor(n0, 32, 64); n1 += __shfl_xor(n1, 32, 64);
+      n0 = quarters_sum(n0);  // v_permlane{16,32}_swap: the four lane groups hold the four unit quarters
+      n1 = quarters_sum(n1);
       n0 += b20; n1 += b21;
       d0 = n0; d1 = n1;
       x0 += n0; x1 += n1;
@@ -742,13 +742,18 @@ struct DecFusedArgs {
 #define DB_RS 148  // dPre tile row stride == 20 mod 64: the 16-byte row accesses of a 16-lane group land on banks 20 fi (+0..3),
                    // sixteen distinct 4-bank groups, and the transposed 4-byte reads of the weight-gradient phase (lane =
                    // (position fi, row 4 ks + fk)) start 20 banks apart per fk - 2-way on 12 banks (stride 132: 4-way)
-#define DB_HS 48   // h tile row stride (== 16 mod 32: conflict-free transposed reads)
+#define DB_HS 36   // h tile row stride, and
+#define DB_US 20   // du tile row stride: 4 x stride == 16 mod 32.  The weight-gradient products walk the 16 tile rows as
+                   // row = step + 4 k (k = the MFMA's reduction lane group): the two lane groups of a 32-lane LDS pass then
+                   // start 4 x stride = 16 banks apart on all three tiles (4 x 148 == 16 mod 32 too).  With row = 4 step + k
+                   // the dPre reads of the two groups sat 20 banks apart, 2-way on 12 banks: 45 % of this kernel's LDS
+                   // cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void decoder_bwd_mfma_kernel(DecFusedArgs p) {
   constexpr int H = 32, Hh = 16, S = 32;
   __shared__ __attribute__((aligned(16))) float dps[2][16 * DB_RS];
   __shared__ __attribute__((aligned(16))) float hts[3][16 * DB_HS];
-  __shared__ __attribute__((aligned(16))) float dus[2][16 * Hh];
+  __shared__ __attribute__((aligned(16))) float dus[2][16 * DB_US];
   __shared__ float red[16 * 52];
   extern __shared__ __attribute__((aligned(16))) float tailw[];  // W_e2d[:, :EIN] (H x e2ld) | W1[:, H:] (Hh x 36)
   const int gi = blockIdx.x / p.NW, wi = blockIdx.x % p.NW;
@@ -865,7 +870,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       dq += du;
       accb2[0] += g0; accb2[1] += g1;
       if (w == 0) {
-        *reinterpret_cast<f32x4*>(&duw[fi * Hh + 4 * fk]) = du;
+        *reinterpret_cast<f32x4*>(&duw[fi * DB_US + 4 * fk]) = du;
       }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) htw[fi * DB_HS + uj[mt]] = c_ch[mt].y;
@@ -915,9 +920,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int ks = 0; ks < 4; ++ks) {
         float a[2], bv[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = dpw[(4 * ks + fk) * DB_RS + 16 * (2 * w + i) + fi];
+        for (int i = 0; i < 2; ++i) a[i] = dpw[(ks + 4 * fk) * DB_RS + 16 * (2 * w + i) + fi];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) bv[n] = htw[(4 * ks + fk) * DB_HS + 16 * n + fi];
+        for (int n = 0; n < 2; ++n) bv[n] = htw[(ks + 4 * fk) * DB_HS + 16 * n + fi];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const int ks = 2 * kh + kk;
-          accU = MFMA16(duw[(4 * ks + fk) * Hh + fi], htc[(4 * ks + fk) * DB_HS + 16 * nt + fi], accU);
+          accU = MFMA16(duw[(ks + 4 * fk) * DB_US + fi], htc[(ks + 4 * fk) * DB_HS + 16 * nt + fi], accU);
         }
       }
       const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);

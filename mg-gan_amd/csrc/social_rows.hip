@@ -64,25 +64,7 @@ struct SocRowsArgs {
   int row_splits;     // the rows of a scene are dealt to this many workgroups (few scenes: more of the chip at work)
 };
 
-template <int CTRL>
-__device__ __forceinline__ float sr_dpp(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-// all-lanes sum / max over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1)
-__device__ __forceinline__ float row_sum16(float v) {
-  v += sr_dpp<0x128>(v);
-  v += sr_dpp<0x124>(v);
-  v += sr_dpp<0x122>(v);
-  v += sr_dpp<0x121>(v);
-  return v;
-}
-__device__ __forceinline__ float row_max16(float v) {
-  v = fmaxf(v, sr_dpp<0x128>(v));
-  v = fmaxf(v, sr_dpp<0x124>(v));
-  v = fmaxf(v, sr_dpp<0x122>(v));
-  v = fmaxf(v, sr_dpp<0x121>(v));
-  return v;
-}
+// (row_sum16 / row_max16: all-lanes reductions over a DPP row, common.h)
 // (sum over the four DPP rows of a wave -- the four kq quarters: quarters_sum, common.h)
 // LDS traffic between the lanes of ONE wave (the transposition tiles): program order is execution order, the compiler
 // only has to keep it
