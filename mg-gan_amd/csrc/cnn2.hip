@@ -375,6 +375,98 @@ __global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __r
   bn_finalize_lane(fin, C, colsum);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv2 forward on the matrix cores (implicit GEMM, exact-f32 16x16x4 MFMA): per image row y,
+//     y2[co][y][x] = b[co] + sum_{tap, ci} a1[ci][y + ky][x + kx] W[co][ci][tap]        M = 16 x, N = co, K = (tap, ci)
+// The A operand walks the zero-haloed a1 planes in LDS; its reduction index is ordered so that the two lane groups of a
+// 32-lane LDS pass take planes whose distance is 16 banks (C = 16: planes 386 apart, ci = c + 8 (k & 1) + 4 (k >> 1);
+// C = 8: planes 388 apart, ci = c + 4 (k & 1) + 2 (k >> 1)) -- the layout rule of conv2_bwd_mfma_kernel (cnn.hip) --; the
+// B operand (the weights of a k step) is loop-invariant: 9 C / 4 registers per lane, loaded once per workgroup.  Wave w
+// owns image rows 4 w .. 4 w + 3 as four independent accumulator chains; the D fragment (x = 4 k + r, co) goes out as
+// one 16-byte store per row.  C = 8 fills half of the N tile.  (The register-tiled VALU kernel above needs one scalar
+// weight load per four FMAs and ran at 0.38 of the f32 rate at 8,192 images; it stays selectable: MGGAN_CONV2_VALU=1.)
+template <int C>
+__global__ __launch_bounds__(256) void conv2_fwd_mfma_kernel(int B, const float* __restrict__ xsel,
+                                                             const float* __restrict__ scale1,
+                                                             const float* __restrict__ shift1, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, float* __restrict__ y2,
+                                                             double* part, BnFin fin) {
+  constexpr int PLANE = C == 16 ? 386 : 388, KS = C / 4;
+  __shared__ __attribute__((aligned(16))) float a1p[C * PLANE];
+  __shared__ double redd[4][2][16];
+  __shared__ double colsum[32], cred[8 * 32];
+  __shared__ int flag;
+  for (int i = threadIdx.x; i < C * PLANE; i += 256) a1p[i] = 0.f;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  // reduction index of k step (tap, c): input channel of this lane's k group
+  int cik[KS];
+#pragma unroll
+  for (int c = 0; c < KS; ++c) cik[c] = C == 16 ? c + 8 * (fk & 1) + 4 * (fk >> 1) : c + 4 * (fk & 1) + 2 * (fk >> 1);
+  float wb[9][KS];  // B[k = (tap, ci)][j = co = fi]
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int c = 0; c < KS; ++c) wb[tp][c] = fi < C ? W[(fi * C + cik[c]) * 9 + tp] : 0.f;
+  const float bv = fi < C ? bias[fi] : 0.f;
+  double dsum = 0.0, dsq = 0.0;  // channel fi, this wave's rows, every image of the workgroup
+  float v[C];
+  auto fetch = [&](int b) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = xsel[((size_t)b * C + c) * 256 + threadIdx.x];
+  };
+  if ((int)blockIdx.x < B) fetch(blockIdx.x);
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    {
+      const int ppy = threadIdx.x >> 4, ppx = threadIdx.x & 15;
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        a1p[c * PLANE + (ppy + 1) * A1_LD + ppx + 1] = fmaxf(fmaf(v[c], scale1[c], shift1[c]), 0.f);
+    }
+    __syncthreads();
+    if (b + (int)gridDim.x < B) fetch(b + gridDim.x);  // the next image's inputs fly under this image's products
+    f32x4 acc[4];
+#pragma unroll
+    for (int ry = 0; ry < 4; ++ry) acc[ry] = f32x4{bv, bv, bv, bv};
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        const float* ap = &a1p[cik[c] * PLANE + (4 * w + tp / 3) * A1_LD + fi + tp % 3];
+#pragma unroll
+        for (int ry = 0; ry < 4; ++ry)
+          acc[ry] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ry * A1_LD], wb[tp][c], acc[ry], 0, 0, 0);
+      }
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int ry = 0; ry < 4; ++ry) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sm += acc[ry][r];
+        sq = fmaf(acc[ry][r], acc[ry][r], sq);
+      }
+      if (fi < C)
+        *reinterpret_cast<f32x4*>(y2 + (((size_t)b * C + fi) * 16 + 4 * w + ry) * 16 + 4 * fk) = acc[ry];
+    }
+    dsum += (double)quarters_sum(sm);  // f32 within an image, f64 across images
+    dsq += (double)quarters_sum(sq);
+  }
+  if (lane < 16) {
+    redd[w][0][lane] = dsum;
+    redd[w][1][lane] = dsq;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * C) {
+    const int which = threadIdx.x / C, c = threadIdx.x % C;
+    store_part(part + (size_t)blockIdx.x * 2 * C + threadIdx.x,
+               (redd[0][which][c] + redd[1][which][c]) + (redd[2][which][c] + redd[3][which][c]));
+  }
+  if (!fin.ticket) return;
+  if (!last_block(fin.ticket, &flag)) return;
+  colsum_rows(part, gridDim.x, 2 * C, colsum, cred);
+  bn_finalize_lane(fin, C, colsum);
+}
+
 // sums[col] = sum over rows of part[row][col]  (f64; the sharded path all-reduces `sums` before finalizing)
 __global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const double* part, int rows, int W, double* sums) {
   __shared__ double colsum[32], cred[8 * 32];
@@ -713,8 +805,15 @@ int mggan_conv2_fwd2(const float* xsel, int B, int C, const float* scale1, const
   const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
                              scale, shift, stat);
   const int grid = grid_for(B, 768);
-  if (C == 16) hipLaunchKernelGGL((conv2_fwd2_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
-  else hipLaunchKernelGGL((conv2_fwd2_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
+  static int valu = -1;  // MGGAN_CONV2_VALU=1: the register-tiled VALU kernel (A/B measurements)
+  if (valu < 0) { const char* e = getenv("MGGAN_CONV2_VALU"); valu = e && e[0] == '1'; }
+  if (valu) {
+    if (C == 16) hipLaunchKernelGGL((conv2_fwd2_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
+    else hipLaunchKernelGGL((conv2_fwd2_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
+  } else {
+    if (C == 16) hipLaunchKernelGGL((conv2_fwd_mfma_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
+    else hipLaunchKernelGGL((conv2_fwd_mfma_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
+  }
   MG_LAUNCH_CHECK("conv2_fwd2");
   return MGGAN_OK;
 }
