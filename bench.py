@@ -49,9 +49,9 @@ def kernel_of(name, a):
     if name == "mggan_conv1_pool":
         return "conv1_pool_kernel<{}>".format(a[2])
     if name == "mggan_conv2_fwd2":
-        return "conv2_fwd2_kernel<{}>".format(a[2])
+        return "conv2_fwd_mfma_kernel<{}>".format(a[2])
     if name == "mggan_conv2_bwd":
-        return "conv2_bwd_mfma_kernel" if a[2] == 16 else "conv2_bwd_kernel<8>"
+        return "conv2_bwd_mfma_kernel<{}>".format(a[2])
     if name == "mggan_conv1_wgrad":
         return "conv1_wgrad_kernel<{}>".format(a[2])
     if name == "mggan_image_gram":

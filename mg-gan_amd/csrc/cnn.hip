@@ -8,6 +8,7 @@
 // BatchNorm runs in train mode on the hot path (abstract_train.py:111-112): batch statistics sit between conv and
 // ReLU, so each block is "conv + partial sums" -> finalize (fused into the producing kernel's last workgroup) -> the
 // NEXT kernel applies scale/shift + ReLU (+ 2x2 max-pool) in its prologue while staging its input tile into LDS.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/mggan_hip.h"
 
@@ -596,6 +597,20 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
 #define C2_WLD 18  // row stride of the flipped weights [tap'][co][ci]
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// C = 8 (the discriminator's CNN) on the same code: planes 388 apart (4 * 388 == 16 mod 32: the input-gradient product
+// orders its reduction index co = c + 4 (fk & 1) + 2 (fk >> 1)); the weight-gradient product packs TWO taps into one N
+// tile (columns 0..7: tap t0, columns 8..15: tap t1 -- pairs (0,2) (3,5) (6,8) (1,4) (7,-): the first three sit two
+// columns apart, i.e. on disjoint banks), 5 MFMAs per k step instead of 9; the M tile (co) and the N tile of the input
+// gradient (ci) are half empty.  152 MFMAs per wave and image against 288 at C = 16.
+template <int C>
+struct C2Geo {
+  static constexpr int PLANE = C == 16 ? 386 : 388;
+  static constexpr int NT = C == 16 ? 9 : 5;  // N tiles of the weight-gradient product
+  static constexpr int KS = C / 4;            // k steps per tap of the input-gradient product
+  static constexpr int LDS_FLOATS = 2 * C * PLANE + C * 256 + 9 * C * C2_WLD + 128;
+};
+
+template <int C>
 __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float* __restrict__ xsel,
                                                             const float* __restrict__ scale1,
                                                             const float* __restrict__ shift1,
@@ -604,30 +619,49 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
                                                             const float* __restrict__ stat2,
                                                             const float* __restrict__ coef2, const float* __restrict__ W,
                                                             float* G1c, double* part1, float* wpart, BnBwdFin fin) {
-  constexpr int C = 16, WLEN = C * C * 9 + C;
+  constexpr int WLEN = C * C * 9 + C, PLANE = C2Geo<C>::PLANE, NT = C2Geo<C>::NT, KS = C2Geo<C>::KS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* dyp = smem;                       // [C][18][20] padded planes, stride C2_PLANE
-  float* a1p = dyp + C * C2_PLANE;         // same layout
-  float* y1r = a1p + C * C2_PLANE;         // [C][256] raw conv1 value at the pooling argmax
-  float* wf = y1r + C * 256;               // [tap'][co][ci] = W[co][ci][8 - tap'] (flipped kernel), 2304
+  float* dyp = smem;                       // [C][18][20] padded planes, stride PLANE
+  float* a1p = dyp + C * PLANE;            // same layout
+  float* y1r = a1p + C * PLANE;            // [C][256] raw conv1 value at the pooling argmax
+  float* wf = y1r + C * 256;               // [tap'][co][ci] = W[co][ci][8 - tap'] (flipped kernel)
   float* red = wf + 9 * C * C2_WLD;        // [4][32] cross-wave statistics
   __shared__ double colsum[32], cred[8 * 32];
   __shared__ int flag;
-  double dstat = 0.0;                      // threads 0..31: this workgroup's sum g (0..15) / sum g*xhat (16..31)
-  for (int i = threadIdx.x; i < 2 * C * C2_PLANE; i += 256) dyp[i] = 0.f;  // dyp and a1p (halos stay zero)
+  double dstat = 0.0;                      // threads 0..2C-1: this workgroup's sum g (0..C-1) / sum g*xhat (C..2C-1)
+  for (int i = threadIdx.x; i < 2 * C * PLANE; i += 256) dyp[i] = 0.f;  // dyp and a1p (halos stay zero)
   for (int i = threadIdx.x; i < 9 * C * C; i += 256) {
     const int tp = i / (C * C), co = (i / C) % C, ci = i % C;
     wf[(tp * C + co) * C2_WLD + ci] = W[(co * C + ci) * 9 + (8 - tp)];
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
-  f32x4_t wacc[9];
+  // weight-gradient product: A[i = co = fi][k = position], B[k = position][j]: C = 16: j = ci, one tap per tile;
+  // C = 8: j = ci + 8 * which tap of the tile's pair.  boff: the lane's a1 plane and tap offset per tile (-1: no tap)
+  const int cfi = fi & (C - 1);
+  const bool arow = fi < C;
+  int boff[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) wacc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) {
+    int tap;
+    if (C == 16) {
+      tap = t;
+    } else {
+      const int t0 = t < 3 ? 3 * t : (t == 3 ? 1 : 7), t1 = t < 3 ? 3 * t + 2 : (t == 3 ? 4 : -1);
+      tap = fi < 8 ? t0 : t1;
+    }
+    boff[t] = tap < 0 ? -1 : cfi * PLANE + (tap / 3) * A1_LD + tap % 3;
+  }
+  // input-gradient product: reduction index of k step (tap', c): output channel of this lane's k group
+  int cok[KS];
+#pragma unroll
+  for (int c = 0; c < KS; ++c) cok[c] = C == 16 ? c + 8 * (fk & 1) + 4 * (fk >> 1) : c + 4 * (fk & 1) + 2 * (fk >> 1);
+  f32x4_t wacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wacc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float bacc = 0.f;
 
-  // the three planes of the NEXT image (raw conv1 value, raw conv2 output, its gradient: 48 values per thread) are in
-  // flight while this one is computed: a workgroup that loads, waits, stages, computes spends a memory latency per image
-  // with its matrix pipes idle (MFMA busy 0.47 with two workgroups per CU covering for each other)
+  // the three planes of the NEXT image (raw conv1 value, raw conv2 output, its gradient) are in flight while this one is
+  // computed
   float rx[C], ry[C], rg[C];
   auto fetch = [&](int b) {
 #pragma unroll
@@ -646,10 +680,10 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const float raw = rx[c];
-        a1p[c * C2_PLANE + (py + 1) * A1_LD + px + 1] = fmaxf(fmaf(raw, scale1[c], shift1[c]), 0.f);
+        a1p[c * PLANE + (py + 1) * A1_LD + px + 1] = fmaxf(fmaf(raw, scale1[c], shift1[c]), 0.f);
         y1r[c * 256 + threadIdx.x] = raw;
         const float xh = (ry[c] - stat2[c]) * stat2[C + c];
-        dyp[c * C2_PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (rg[c] - coef2[C + c] - xh * coef2[2 * C + c]);
+        dyp[c * PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (rg[c] - coef2[C + c] - xh * coef2[2 * C + c]);
       }
     }
     if (b + (int)gridDim.x < B) fetch(b + gridDim.x);
@@ -659,12 +693,14 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
     for (int ks = 0; ks < 16; ++ks) {
       const int y = 4 * w + (ks >> 2), x0 = (ks & 3) * 4;
       // A[i = co][k = position x0+fk]
-      const float a = dyp[fi * C2_PLANE + (y + 1) * A1_LD + x0 + 1 + fk];
+      const float av = dyp[cfi * PLANE + (y + 1) * A1_LD + x0 + 1 + fk];
+      const float a = arow ? av : 0.f;
       bacc += a;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        // B[k = position][j = ci] for tap t = (ky,kx): a1 value at (y+ky, x+kx) in padded coordinates
-        const float bv = a1p[fi * C2_PLANE + (y + t / 3) * A1_LD + x0 + fk + t % 3];
+      for (int t = 0; t < NT; ++t) {
+        // B[k = position][j]: a1 value at (y + ky, x + kx) in padded coordinates of the lane's (channel, tap)
+        const float bq = a1p[(boff[t] < 0 ? 0 : boff[t]) + y * A1_LD + x0 + fk];
+        const float bv = boff[t] < 0 ? 0.f : bq;
         wacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, wacc[t], 0, 0, 0);
       }
     }
@@ -674,56 +710,69 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
     //  paid the 40-cycle dependent latency on every one of them -- and one read of the weight fragment serves four rows)
     f32x4_t acc4[4];
 #pragma unroll
-    for (int ry = 0; ry < 4; ++ry) acc4[ry] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int ry_ = 0; ry_ < 4; ++ry_) acc4[ry_] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
 #pragma unroll
-      for (int c4 = 0; c4 < C; c4 += 4) {
-        const int co = (c4 >> 2) + 8 * (fk & 1) + 4 * (fk >> 1);
+      for (int c = 0; c < KS; ++c) {
+        const int co = cok[c];
         // A[i = x][k = (tp, co)] = dy[co] at padded (y + tp/3, x + tp%3);  B[k][j = ci] = wf[tp][co][ci]
-        const float bv = wf[(tp * C + co) * C2_WLD + fi];
+        const float bq = wf[(tp * C + co) * C2_WLD + cfi];
+        const float bv = arow ? bq : 0.f;
 #pragma unroll
-        for (int ry = 0; ry < 4; ++ry) {
-          const float a = dyp[co * C2_PLANE + (4 * w + ry + tp / 3) * A1_LD + fi + tp % 3];
-          acc4[ry] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc4[ry], 0, 0, 0);
+        for (int ry_ = 0; ry_ < 4; ++ry_) {
+          const float a = dyp[co * PLANE + (4 * w + ry_ + tp / 3) * A1_LD + fi + tp % 3];
+          acc4[ry_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc4[ry_], 0, 0, 0);
         }
       }
     }
+    if (arow) {
 #pragma unroll
-    for (int ry = 0; ry < 4; ++ry) {
-      const int y = 4 * w + ry;
-      // D fragment: register r <-> x = 4*fk + r, column = ci = fi
-      float g[4];
+      for (int ry_ = 0; ry_ < 4; ++ry_) {
+        const int y = 4 * w + ry_;
+        // D fragment: register r <-> x = 4*fk + r, column = ci = fi
+        float g[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int x = 4 * fk + r;
-        const bool on = a1p[fi * C2_PLANE + (y + 1) * A1_LD + x + 1] > 0.f;
-        g[r] = on ? acc4[ry][r] : 0.f;
-        const float xh = (y1r[fi * 256 + y * 16 + x] - stat1[fi]) * stat1[C + fi];
-        s1 += g[r];
-        s2 = fmaf(g[r], xh, s2);
+        for (int r = 0; r < 4; ++r) {
+          const int x = 4 * fk + r;
+          const bool on = a1p[fi * PLANE + (y + 1) * A1_LD + x + 1] > 0.f;
+          g[r] = on ? acc4[ry_][r] : 0.f;
+          const float xh = (y1r[fi * 256 + y * 16 + x] - stat1[fi]) * stat1[C + fi];
+          s1 += g[r];
+          s2 = fmaf(g[r], xh, s2);
+        }
+        *reinterpret_cast<float4*>(G1c + (((size_t)b * C + fi) * 16 + y) * 16 + 4 * fk) = make_float4(g[0], g[1], g[2], g[3]);
       }
-      *reinterpret_cast<float4*>(G1c + (((size_t)b * C + fi) * 16 + y) * 16 + 4 * fk) = make_float4(g[0], g[1], g[2], g[3]);
     }
     // per-channel statistics: fold the 4 lane groups, then the 4 waves
-    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    s1 = quarters_sum(s1);
+    s2 = quarters_sum(s2);
     if (lane < 16) { red[w * 32 + lane] = s1; red[w * 32 + 16 + lane] = s2; }
     lds_barrier();
-    if (threadIdx.x < 32)  // [0,16) = sum g, [16,32) = sum g*xhat: f32 within an image, f64 across images
-      dstat += (double)((red[threadIdx.x] + red[32 + threadIdx.x]) + (red[64 + threadIdx.x] + red[96 + threadIdx.x]));
+    if (threadIdx.x < 2 * C) {  // [0,C) = sum g, [C,2C) = sum g*xhat: f32 within an image, f64 across images
+      const int q = threadIdx.x < C ? threadIdx.x : 16 + threadIdx.x - C;
+      dstat += (double)((red[q] + red[32 + q]) + (red[64 + q] + red[96 + q]));
+    }
   }
-  if (threadIdx.x < 32) store_part(part1 + (size_t)blockIdx.x * 2 * C + threadIdx.x, dstat);
-  // ---- fold the four waves' weight-gradient fragments; wacc[t][r] of lane l is dW[co = 4*fk + r][ci = fi][tap t]
+  if (threadIdx.x < 2 * C) store_part(part1 + (size_t)blockIdx.x * 2 * C + threadIdx.x, dstat);
+  // ---- fold the four waves' weight-gradient fragments; wacc[t][r] of lane l is dW[co = 4*fk + r][ci][tap]
   lds_barrier();
   float* fold = dyp;  // reuse: [4][WLEN]
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t) {
+    int tap;
+    if (C == 16) {
+      tap = t;
+    } else {
+      const int t0 = t < 3 ? 3 * t : (t == 3 ? 1 : 7), t1 = t < 3 ? 3 * t + 2 : (t == 3 ? 4 : -1);
+      tap = fi < 8 ? t0 : t1;
+    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) fold[w * WLEN + ((4 * fk + r) * C + fi) * 9 + t] = wacc[t][r];
-  bacc += __shfl_xor(bacc, 16, 64);
-  bacc += __shfl_xor(bacc, 32, 64);  // lanes 0..15: sum over this wave's positions of dy[co = lane]
-  if (lane < 16) fold[w * WLEN + C * C * 9 + lane] = bacc;
+    for (int r = 0; r < 4; ++r)
+      if (4 * fk + r < C && tap >= 0) fold[w * WLEN + ((4 * fk + r) * C + cfi) * 9 + tap] = wacc[t][r];
+  }
+  bacc = quarters_sum(bacc);  // lanes 0..C-1: sum over this wave's positions of dy[co = lane]
+  if (lane < C) fold[w * WLEN + C * C * 9 + lane] = bacc;
   lds_barrier();
   float* wp = wpart + (size_t)blockIdx.x * WLEN;
   for (int i = threadIdx.x; i < WLEN; i += 256)
@@ -860,19 +909,25 @@ int mggan_conv2_bwd(const float* xsel, int B, int C, const float* scale1,
     return MGGAN_ERR_WORKSPACE;
   }
   const BnBwdFin fin = make_bfin(ticket, count1, gamma1, stat1, coef1, coefd1, dgamma1, dbeta1);
-  if (C == 16) {
-    const size_t lds = (size_t)(2 * 16 * C2_PLANE + 16 * 256 + 9 * 16 * C2_WLD + 128) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute((const void*)conv2_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-          hipSuccess) {
+  static int valu = -1;  // MGGAN_CONV2_VALU=1: the VALU kernel for C = 8 (A/B measurements)
+  if (valu < 0) { const char* e = getenv("MGGAN_CONV2_VALU"); valu = e && e[0] == '1'; }
+  if (C == 16 || !valu) {
+    const size_t lds = (size_t)(C == 16 ? C2Geo<16>::LDS_FLOATS : C2Geo<8>::LDS_FLOATS) * sizeof(float);
+    static bool attr[2] = {false, false};
+    const void* fn = C == 16 ? (const void*)conv2_bwd_mfma_kernel<16> : (const void*)conv2_bwd_mfma_kernel<8>;
+    if (!attr[C == 16]) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         mggan_set_error("conv2_bwd: cannot raise the dynamic LDS limit to %zu bytes", lds);
         return MGGAN_ERR_LAUNCH;
       }
-      attr = true;
+      attr[C == 16] = true;
     }
-    hipLaunchKernelGGL(conv2_bwd_mfma_kernel, dim3(grid), dim3(256), lds, stream, B, xsel, scale1, shift1,
-                       stat1, y2, G2, stat2, coef2, W, G1c, part1, workspace, fin);
+    if (C == 16)
+      hipLaunchKernelGGL(conv2_bwd_mfma_kernel<16>, dim3(grid), dim3(256), lds, stream, B, xsel, scale1, shift1, stat1, y2, G2,
+                         stat2, coef2, W, G1c, part1, workspace, fin);
+    else
+      hipLaunchKernelGGL(conv2_bwd_mfma_kernel<8>, dim3(grid), dim3(256), lds, stream, B, xsel, scale1, shift1, stat1, y2, G2,
+                         stat2, coef2, W, G1c, part1, workspace, fin);
   } else
     hipLaunchKernelGGL((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1,
                        stat1, y2, G2, stat2, coef2, W, G1c, part1, workspace, fin);
