@@ -55,7 +55,7 @@ class MultiGeneratorGAN(abc.ABC):
         self.epoch = 0
         self.total_iterations = 0  # abstract_train.py:104 (gates the discriminator step with --num_gen_steps)
 
-        self.rng = DeviceRNG() if getattr(config, "rng", "host") == "device" else HostRNG()
+        self.rng = DeviceRNG() if getattr(config, "rng", "device") == "device" else HostRNG()
         self.G.rng = self.rng
         self.dist = DistContext()
         self.dist.attach(self.G, self.D, bn_sync=getattr(config, "bn_sync", "global"))

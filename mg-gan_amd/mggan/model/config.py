@@ -65,8 +65,10 @@ def get_parser():
     parser.add_argument("--d_hist_loss_lambda", default=1.0, type=float, dest="d_hist_loss_lambda")
     parser.opt_list("--gan_obj", default="NS", type=str, dest="gan_obj", options=["NS", "MM", "LS", "W"], tunable=False)
     # ---- additions of the MI355X build (not in the reference CLI) ----
-    parser.add_argument("--rng", type=str, choices=["host", "device"], default="host",
-                        help="host: reference draw order on the CPU generators; device: no host sync")
+    parser.add_argument("--rng", type=str, choices=["host", "device"], default="device",
+                        help="device (default): every random number of an iteration from one Philox launch, no host sync "
+                             "-- train() replays captured iterations; host: the reference's draw order on the CPU "
+                             "generators (seed-comparable with the reference; eager launches, one read-back per generator call)")
     parser.add_argument("--bn_sync", type=str, choices=["global", "local"], default="global",
                         help="sharded runs: BatchNorm statistics over the global batch (all-reduced: same results as one "
                              "process) or per rank (what DistributedDataParallel does without SyncBatchNorm)")

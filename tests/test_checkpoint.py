@@ -35,7 +35,7 @@ def test_meta_tags_round_trip_keeps_gpu_string_and_types(tmp_path):
         for k, v in (("num_gens", 2), ("gpus", 0), ("dataset", "eth")):
             w.writerow([k, v])
     old = read_meta_tags(tmp_path / "old.csv")
-    assert old.num_gens == 2 and old.gpus == "0" and old.rng == "host" and old.dataset == "eth"
+    assert old.num_gens == 2 and old.gpus == "0" and old.rng == "device" and old.dataset == "eth"
 
 
 def test_evaluate_ade_fde_masks_nan_ground_truth_and_scales_pixels():

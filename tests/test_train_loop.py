@@ -74,7 +74,7 @@ def test_graph_on_needs_the_device_rng():
     from mggan.model.model_factory import construct_model
     from mggan.model.train import PiNetMultiGeneratorGAN
 
-    cfg = get_parser().parse_args(["--graph", "on", "--epochs", "1"])
+    cfg = get_parser().parse_args(["--graph", "on", "--rng", "host", "--epochs", "1"])
     with contextlib.redirect_stdout(io.StringIO()):
         G, D = construct_model(cfg)
     tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
