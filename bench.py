@@ -60,6 +60,8 @@ def kernel_of(name, a):
         return "dheads_fwd_kernel"
     if name == "mggan_dheads_bwd_data":
         return "dheads_bwd_kernel"
+    if name in ("mggan_dheads_lean_fwd", "mggan_dheads_lean_bwd", "mggan_dheads_shared"):
+        return name[len("mggan_"):] + "_kernel"
     return name
 
 
@@ -108,6 +110,14 @@ def flops_of(name, a):
         return 2.0 * a[2] * (2 * 192 * 96 + 96 * (1 + a[3]))
     if name == "mggan_dheads_bwd_data":  # their input gradient
         return 2.0 * a[5] * (2 * 192 * 96 + 96 * (1 + a[6]))
+    # the lean heads (sample blocks >= 1 of the generator step's pass): the products they EXECUTE -- the per-pedestrian
+    # part is shared by the K rows of a pedestrian, so this is less than the reference operator's 192-wide row product
+    if name == "mggan_dheads_lean_fwd":
+        return 2.0 * (a[4] - a[3]) * (32 * 192 + 96 * (1 + a[6]))
+    if name == "mggan_dheads_lean_bwd":
+        return 2.0 * (a[5] - a[4]) * (32 * 192 + 96 * (1 + a[6]))
+    if name == "mggan_dheads_shared":
+        return 2.0 * a[2] * 96 * 192
     if name == "mggan_image_gram":  # not in the reference's operator list (bookkeeping of the factorised conv1 gradient)
         return 0.0
     if name == "mggan_scene_attention_fwd":

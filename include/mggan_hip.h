@@ -273,6 +273,21 @@ int mggan_dheads_bwd_data(const float* dYa, const float* dYb, const float* Ya, c
                           int g, int act_a, const float* W1a, const float* W2a, const float* W1b, const float* W2b,
                           float* dX, int ld_dx, mggan_stream_t stream);
 
+/* Lean form of the same heads for the sample blocks k >= 1 of a K-sample pass with a frozen discriminator (the generator
+ * step; discriminators.py:179-219): in_enc and scene are shared by a pedestrian's K rows and the social block is zero
+ * from block 1 on, so P[ped] = b1 + W1[:, in_enc | scene] [in_enc | scene](ped) is computed once per pedestrian
+ * (mggan_dheads_shared, from the block-0 rows of X) and the row product keeps K = 32 (the pred_enc block at c_pe).
+ * mask: ceil((rows-row0)/16)*64 64-bit words of LeakyReLU sign bits, written by _fwd (NULL: not kept), read by _bwd,
+ * which writes dX[row][c_pe .. c_pe+31] only. */
+int mggan_dheads_shared(const float* X, int ldx, int b, int c_in, int c_sc, const float* W1a, const float* b1a,
+                        const float* W1b, const float* b1b, float* P, mggan_stream_t stream);
+int mggan_dheads_lean_fwd(const float* X, int ldx, int c_pe, int row0, int rows, int b, int g, int act_a, const float* P,
+                          const float* W1a, const float* W2a, const float* b2a, const float* W1b, const float* W2b,
+                          const float* b2b, unsigned long long* mask, float* Ya, float* Yb, mggan_stream_t stream);
+int mggan_dheads_lean_bwd(const float* dYa, const float* dYb, const float* Ya, const unsigned long long* mask, int row0,
+                          int rows, int g, int act_a, const float* W1a, const float* W2a, const float* W1b, const float* W2b,
+                          int c_pe, float* dX, int ld_dx, mggan_stream_t stream);
+
 /* ---- in-graph all-reduce over peer-mapped memory (csrc/comm.hip; scene-sharded training) ------------
  * No reference counterpart (the reference is single-process); replaces torch.distributed.all_reduce for the <= 360 KB
  * messages of an iteration with a plain, HIP-graph-capturable kernel.  Every rank owns one uncached arena per channel

@@ -238,6 +238,226 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lean form for the sample blocks k >= 1 of a K-sample pass with a frozen discriminator (the generator step).
+// A classifier row (k, ped) is [soc | in_enc | pred_enc | scene] (discriminators.py:179-196): in_enc and scene are
+// the pedestrian's, the same in all K blocks; the social block is zero from block 1 on (the list-repeat of
+// seq_start_end); only the 32 pred_enc columns differ from row to row.  With
+//     P[ped] = b1 + W1[:, in_enc] in_enc(ped) + W1[:, scene] scene(ped)            (once per pedestrian, 96 -> 192)
+// the first layers of both heads are   hidden(k, ped) = P[ped] + W1[:, pred_enc] pred_enc(k, ped)   for k >= 1:
+// K = 32 instead of 192 in the row product (96 MFMAs per 16-row tile instead of 576), and the rows never have to be
+// assembled: X is read in its pred_enc block only.  The backward pass wants d pred_enc alone (in_enc and scene carry no
+// gradient when the discriminator is frozen): 192 -> 32, again 96 MFMAs.  LeakyReLU's derivative travels as one bit
+// per hidden unit (a 64-bit word per lane and tile) instead of the 768 B per row of saved activations.
+// Every wave owns whole tiles (no workgroup-level exchange): products in the transposed orientation
+// D[hidden][row] so that the P tile, the input gradient and the stationary weights are all 16-byte accesses.
+// Block 0 (rows [0, b), the rows with social features) goes through the full-width kernels above.
+struct DLeanArgs {
+  const float* X;       // (rows, ldx): only columns c_pe .. c_pe+31 of rows >= row0 are read
+  int ldx, c_pe, row0, rows, b, g, act_a;
+  const float* P;       // (b, 192)
+  const float *W1a, *W1b, *W2a, *b2a, *W2b, *b2b;
+  unsigned long long* mask;  // [(tile * 64 + lane)]: bit 4 j + r of lane (fi, fk) <-> hidden unit 16 j + 4 fk + r of row fi
+  float *Ya, *Yb;
+  const float *dYa, *dYb;
+  float* dX;
+  int ld_dx;
+};
+struct DSharedArgs {
+  const float* X;       // block-0 rows (b, ldx) with the in_enc (32 wide at c_in) and scene (64 wide at c_sc) blocks filled
+  int ldx, b, c_in, c_sc;
+  const float *W1a, *b1a, *W1b, *b1b;
+  float* P;
+};
+
+// P tile of 16 pedestrians: wave w -> hidden units 48 w .. 48 w + 47
+__global__ __launch_bounds__(256) void dheads_shared_kernel(DSharedArgs a) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  const int ped = blockIdx.x * 16 + fi;
+  const bool valid = ped < a.b;
+  f32x4 xv[6];
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const int col = (s < 2 ? a.c_in + 16 * s : a.c_sc + 16 * (s - 2)) + 4 * fk;
+    xv[s] = valid ? *reinterpret_cast<const f32x4*>(a.X + (size_t)ped * a.ldx + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int n = 48 * w + 16 * j + fi;
+    const float* Wrow = n < DH_HID ? a.W1a + (size_t)n * DH_IN : a.W1b + (size_t)(n - DH_HID) * DH_IN;
+    f32x4 wv[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+      wv[s] = *reinterpret_cast<const f32x4*>(Wrow + (s < 2 ? a.c_in + 16 * s : a.c_sc + 16 * (s - 2)) + 4 * fk);
+    const int h0 = 48 * w + 16 * j + 4 * fk;  // this lane's four hidden units (D rows 4 fk + r)
+    f32x4 acc0 = *reinterpret_cast<const f32x4*>((h0 < DH_HID ? a.b1a + h0 : a.b1b + (h0 - DH_HID)));
+    f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      acc0 = MFMA16(wv[s][0], xv[s][0], acc0);
+      acc1 = MFMA16(wv[s][1], xv[s][1], acc1);
+      acc0 = MFMA16(wv[s][2], xv[s][2], acc0);
+      acc1 = MFMA16(wv[s][3], xv[s][3], acc1);
+    }
+    if (valid) *reinterpret_cast<f32x4*>(a.P + (size_t)ped * DH_IN + h0) = acc0 + acc1;
+  }
+}
+
+__device__ __forceinline__ void dl_stage_w2(const DLeanArgs& a, float* w2l) {
+  for (int i = threadIdx.x; i < (1 + a.g) * DH_HID; i += 256) w2l[i] = i < DH_HID ? a.W2a[i] : a.W2b[i - DH_HID];
+  __syncthreads();
+}
+
+template <int GM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dheads_lean_fwd_kernel(DLeanArgs a) {
+  __shared__ __attribute__((aligned(16))) float w2l[(1 + DH_MAXG) * DH_HID];  // w2a (96) then W2b (g x 96)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  // A operands: W1cat[:, pred_enc] (192 x 32) from LDS (row stride 36: the 16-byte reads of a 16-lane group start 4 banks
+  // apart) -- as 96 stationary registers next to the 48 accumulators and the prefetched P tile they spilled
+  __shared__ __attribute__((aligned(16))) float w1s[2 * DH_HID * 36];
+  for (int i = threadIdx.x; i < 2 * DH_HID * 8; i += 256) {
+    const int n = i >> 3, q = (i & 7) * 4;
+    const float* Wrow = (n < DH_HID ? a.W1a + (size_t)n * DH_IN : a.W1b + (size_t)(n - DH_HID) * DH_IN) + a.c_pe + q;
+    *reinterpret_cast<f32x4*>(&w1s[n * 36 + q]) = *reinterpret_cast<const f32x4*>(Wrow);
+  }
+  dl_stage_w2(a, w2l);
+  const float* awl = &w1s[fi * 36 + 4 * fk];  // hidden tile j, k block ss: awl[16 j * 36 + 16 ss]
+  const float b2a = a.b2a[0];
+  const int nt = (a.rows - a.row0 + 15) / 16;
+  const int nwv = gridDim.x * 4;
+  f32x4 nx[2], nP[12];
+  auto fetch = [&](int t) {
+    const int gr = a.row0 + 16 * t + fi;
+    const bool valid = gr < a.rows;
+    const int grc = valid ? gr : a.rows - 1;  // (clamped address, masked where it is consumed)
+    const float* xr = a.X + (size_t)grc * a.ldx + a.c_pe + 4 * fk;
+    nx[0] = *reinterpret_cast<const f32x4*>(xr);
+    nx[1] = *reinterpret_cast<const f32x4*>(xr + 16);
+    const float* pr = a.P + (size_t)(grc % a.b) * DH_IN + 4 * fk;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) nP[j] = *reinterpret_cast<const f32x4*>(pr + 16 * j);
+  };
+  int t = blockIdx.x * 4 + w;
+  if (t < nt) fetch(t);
+  for (; t < nt; t += nwv) {
+    const int gr = a.row0 + 16 * t + fi;
+    const bool valid = gr < a.rows;
+    f32x4 acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = nP[j];
+    const f32x4 x0 = nx[0], x1 = nx[1];
+    if (t + nwv < nt) fetch(t + nwv);
+    const float* awt = awl;
+    asm volatile("" : "+v"(awt));  // (the reads are loop invariant: hoisted, they are the 96 registers again)
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(awt + 16 * j * 36), a1 = *reinterpret_cast<const f32x4*>(awt + 16 * j * 36 + 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j] = MFMA16(a0[i], x0[i], acc[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j] = MFMA16(a1[i], x1[i], acc[j]);
+    }
+    // lane (fi, fk): hidden units 16 j + 4 fk + r of row fi
+    unsigned long long m = 0ull;
+    float ya = 0.f, yb[GM];
+#pragma unroll
+    for (int o = 0; o < GM; ++o) yb[o] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      f32x4 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[j][r];
+        const bool pos = v > 0.f;
+        h[r] = pos ? v : 0.2f * v;  // LeakyReLU(0.2), discriminators.py:80,101
+        m |= (unsigned long long)pos << (4 * j + r);
+      }
+      if (j < 6) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(&w2l[16 * j + 4 * fk]);
+        ya = fmaf(h[0], wv[0], fmaf(h[1], wv[1], fmaf(h[2], wv[2], fmaf(h[3], wv[3], ya))));
+      } else {
+#pragma unroll
+        for (int o = 0; o < GM; ++o)
+          if (o < a.g) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(&w2l[DH_HID + o * DH_HID + 16 * (j - 6) + 4 * fk]);
+            yb[o] = fmaf(h[0], wv[0], fmaf(h[1], wv[1], fmaf(h[2], wv[2], fmaf(h[3], wv[3], yb[o]))));
+          }
+      }
+    }
+    ya = quarters_sum(ya);
+#pragma unroll
+    for (int o = 0; o < GM; ++o)
+      if (o < a.g) yb[o] = quarters_sum(yb[o]);
+    if (valid && fk == 0) {
+      a.Ya[gr] = mg_act(ya + b2a, a.act_a, 0.f);
+#pragma unroll
+      for (int o = 0; o < GM; ++o)
+        if (o < a.g) a.Yb[(size_t)gr * a.g + o] = yb[o] + a.b2b[o];
+    }
+    if (a.mask) a.mask[(size_t)t * 64 + lane] = m;
+  }
+}
+
+// d pred_enc^T [32 x rows] = W1cat[:, pred_enc]^T dH^T, dH = [dza w2a^T | dYb W2b] .* LeakyReLU'(hidden) built per lane
+template <int GM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dheads_lean_bwd_kernel(DLeanArgs a) {
+  __shared__ __attribute__((aligned(16))) float w2l[(1 + DH_MAXG) * DH_HID];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  dl_stage_w2(a, w2l);
+  // stationary A operands: row = pred_enc column 16 ct + fi, k = hidden unit 16 ss + 4 fk + i
+  float aw[2][48];
+#pragma unroll
+  for (int ss = 0; ss < 12; ++ss)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hid = 16 * ss + 4 * fk + i;
+      const float* Wrow = (hid < DH_HID ? a.W1a + (size_t)hid * DH_IN : a.W1b + (size_t)(hid - DH_HID) * DH_IN) + a.c_pe + fi;
+      aw[0][4 * ss + i] = Wrow[0];
+      aw[1][4 * ss + i] = Wrow[16];
+    }
+  const int nt = (a.rows - a.row0 + 15) / 16;
+  const int nwv = gridDim.x * 4;
+  for (int t = blockIdx.x * 4 + w; t < nt; t += nwv) {
+    const int gr = a.row0 + 16 * t + fi;
+    const bool valid = gr < a.rows;
+    const int grc = valid ? gr : a.rows - 1;
+    const unsigned long long m = a.mask[(size_t)t * 64 + lane];
+    const float vm = valid ? 1.f : 0.f;
+    const float dza = a.dYa[grc] * mg_act_grad_from_out(a.Ya[grc], a.act_a, 0.f) * vm;
+    float dyb[GM];
+#pragma unroll
+    for (int o = 0; o < GM; ++o) dyb[o] = o < a.g ? a.dYb[(size_t)grc * a.g + o] * vm : 0.f;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[ct][0] = acc[ct][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ss = 0; ss < 12; ++ss) {
+      f32x4 d;
+      if (ss < 6) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(&w2l[16 * ss + 4 * fk]);
+        d = wv * dza;
+      } else {
+        d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < GM; ++o)
+          if (o < a.g) d += *reinterpret_cast<const f32x4*>(&w2l[DH_HID + o * DH_HID + 16 * (ss - 6) + 4 * fk]) * dyb[o];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dv = d[i] * (((m >> (4 * ss + i)) & 1ull) ? 1.f : 0.2f);
+        acc[0][i & 1] = MFMA16(aw[0][4 * ss + i], dv, acc[0][i & 1]);
+        acc[1][i & 1] = MFMA16(aw[1][4 * ss + i], dv, acc[1][i & 1]);
+      }
+    }
+    if (valid) {
+      float* o = a.dX + (size_t)gr * a.ld_dx + a.c_pe + 4 * fk;
+      *reinterpret_cast<f32x4*>(o) = acc[0][0] + acc[0][1];
+      *reinterpret_cast<f32x4*>(o + 16) = acc[1][0] + acc[1][1];
+    }
+  }
+}
+
 extern "C" {
 
 static int dheads_check(const DHeadsArgs& a, const char* what) {
@@ -287,6 +507,72 @@ int mggan_dheads_bwd_data(const float* dYa, const float* dYb, const float* Ya, c
   MG_CHECK_ARG(dYa && dYb && Ya && Ha && Hb && dX && ld_dx >= DH_IN, "dheads_bwd_data: null pointer");
   hipLaunchKernelGGL(dheads_bwd_kernel, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("dheads_bwd_data");
+  return MGGAN_OK;
+}
+
+
+static int dlean_grid(int rows) {
+  const int nw = (rows + 15) / 16;     // one wave per 16-row tile
+  const int wg = (nw + 3) / 4;
+  return wg < 512 ? wg : 512;
+}
+
+/* P (b,192) = [b1a ; b1b] + W1cat[:, c_in .. c_in+31] X[:, c_in ..] + W1cat[:, c_sc .. c_sc+63] X[:, c_sc ..] over the block-0
+ * rows of X: the part of both heads' first layers that the K sample blocks of a pedestrian share */
+int mggan_dheads_shared(const float* X, int ldx, int b, int c_in, int c_sc, const float* W1a, const float* b1a,
+                        const float* W1b, const float* b1b, float* P, hipStream_t stream) {
+  if (b == 0) return MGGAN_OK;
+  MG_CHECK_ARG(X && W1a && b1a && W1b && b1b && P, "dheads_shared: null pointer");
+  MG_CHECK_ARG(ldx >= DH_IN && (ldx & 3) == 0 && (((size_t)X) & 15) == 0 && (((size_t)P) & 15) == 0 && c_in % 4 == 0 &&
+                   c_sc % 4 == 0 && c_in >= 0 && c_in + 32 <= DH_IN && c_sc >= 0 && c_sc + 64 <= DH_IN,
+               "dheads_shared: bad layout (ldx %d, c_in %d, c_sc %d)", ldx, c_in, c_sc);
+  DSharedArgs a = {X, ldx, b, c_in, c_sc, W1a, b1a, W1b, b1b, P};
+  hipLaunchKernelGGL(dheads_shared_kernel, dim3((b + 15) / 16), dim3(256), 0, stream, a);
+  MG_LAUNCH_CHECK("dheads_shared");
+  return MGGAN_OK;
+}
+
+/* rows [row0, rows) of a K-sample pass (row = k*b + ped): Ya / Yb of both heads from P[row % b] and the pred_enc block
+ * (32 columns at c_pe) of X; mask (ceil((rows-row0)/16) * 64 words, or NULL): LeakyReLU sign bits for the backward pass */
+int mggan_dheads_lean_fwd(const float* X, int ldx, int c_pe, int row0, int rows, int b, int g, int act_a, const float* P,
+                          const float* W1a, const float* W2a, const float* b2a, const float* W1b, const float* W2b,
+                          const float* b2b, unsigned long long* mask, float* Ya, float* Yb, hipStream_t stream) {
+  MG_CHECK_ARG(g >= 1 && g <= DH_MAXG - 1 && row0 >= 0 && b > 0, "dheads_lean_fwd: g = %d not in 1..%d", g, DH_MAXG - 1);
+  if (rows <= row0) return MGGAN_OK;
+  MG_CHECK_ARG(X && P && W1a && W2a && b2a && W1b && W2b && b2b && Ya && Yb, "dheads_lean_fwd: null pointer");
+  MG_CHECK_ARG(ldx >= DH_IN && (ldx & 3) == 0 && (((size_t)X) & 15) == 0 && (((size_t)P) & 15) == 0 && c_pe % 4 == 0 &&
+                   c_pe >= 0 && c_pe + 32 <= DH_IN,
+               "dheads_lean_fwd: bad layout (ldx %d, c_pe %d)", ldx, c_pe);
+  MG_CHECK_ARG(act_a == ACT_NONE || act_a == ACT_SIGMOID_EPS || act_a == ACT_SIGMOID, "dheads_lean_fwd: output activation %d", act_a);
+  DLeanArgs a = {};
+  a.X = X; a.ldx = ldx; a.c_pe = c_pe; a.row0 = row0; a.rows = rows; a.b = b; a.g = g; a.act_a = act_a; a.P = P;
+  a.W1a = W1a; a.W1b = W1b; a.W2a = W2a; a.b2a = b2a; a.W2b = W2b; a.b2b = b2b; a.mask = mask; a.Ya = Ya; a.Yb = Yb;
+  const dim3 grid(dlean_grid(rows - row0));
+  if (g <= 4) hipLaunchKernelGGL(dheads_lean_fwd_kernel<4>, grid, dim3(256), 0, stream, a);
+  else if (g <= 8) hipLaunchKernelGGL(dheads_lean_fwd_kernel<8>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(dheads_lean_fwd_kernel<16>, grid, dim3(256), 0, stream, a);
+  MG_LAUNCH_CHECK("dheads_lean_fwd");
+  return MGGAN_OK;
+}
+
+/* dX[row][c_pe .. c_pe+31] for rows [row0, rows): the pred_enc gradient of both heads (frozen discriminator) */
+int mggan_dheads_lean_bwd(const float* dYa, const float* dYb, const float* Ya, const unsigned long long* mask, int row0,
+                          int rows, int g, int act_a, const float* W1a, const float* W2a, const float* W1b, const float* W2b,
+                          int c_pe, float* dX, int ld_dx, hipStream_t stream) {
+  MG_CHECK_ARG(g >= 1 && g <= DH_MAXG - 1 && row0 >= 0, "dheads_lean_bwd: g = %d not in 1..%d", g, DH_MAXG - 1);
+  if (rows <= row0) return MGGAN_OK;
+  MG_CHECK_ARG(dYa && dYb && Ya && mask && W1a && W2a && W1b && W2b && dX, "dheads_lean_bwd: null pointer");
+  MG_CHECK_ARG(ld_dx >= DH_IN && (ld_dx & 3) == 0 && (((size_t)dX) & 15) == 0 && c_pe % 4 == 0 && c_pe >= 0 && c_pe + 32 <= DH_IN,
+               "dheads_lean_bwd: bad layout (ld_dx %d, c_pe %d)", ld_dx, c_pe);
+  DLeanArgs a = {};
+  a.c_pe = c_pe; a.row0 = row0; a.rows = rows; a.g = g; a.act_a = act_a; a.b = 1;
+  a.W1a = W1a; a.W1b = W1b; a.W2a = W2a; a.W2b = W2b; a.mask = const_cast<unsigned long long*>(mask);
+  a.Ya = const_cast<float*>(Ya); a.dYa = dYa; a.dYb = dYb; a.dX = dX; a.ld_dx = ld_dx;
+  const dim3 grid(dlean_grid(rows - row0));
+  if (g <= 4) hipLaunchKernelGGL(dheads_lean_bwd_kernel<4>, grid, dim3(256), 0, stream, a);
+  else if (g <= 8) hipLaunchKernelGGL(dheads_lean_bwd_kernel<8>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(dheads_lean_bwd_kernel<16>, grid, dim3(256), 0, stream, a);
+  MG_LAUNCH_CHECK("dheads_lean_bwd");
   return MGGAN_OK;
 }
 

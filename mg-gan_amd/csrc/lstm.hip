@@ -765,6 +765,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int seg0 = p.seg[gi], seg1 = p.seg[gi + 1];
   const int ntiles = (seg1 - seg0 + 15) / 16;
   const int IN = p.EIN + p.Z;
+  float* wp = p.wpart + (size_t)blockIdx.x * DF_WLEN;
+  if (wi >= ntiles) {  // NW leaves room for an uneven split between the generators: no tile, an all-zero partial block
+    for (int i = threadIdx.x; i < DF_WLEN; i += 256) wp[i] = 0.f;
+    return;
+  }
   const int tbase = dec_tile_base(p.seg, gi);
   const int uj[2] = {8 * w + fk, 8 * w + 4 + fk};
   const int sel = fi & 3, us = 8 * w + 4 * (sel & 1) + (fi >> 2);  // A-operand row role of this lane
@@ -975,7 +980,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 
   // ---- this workgroup's partial block ----
-  float* wp = p.wpart + (size_t)blockIdx.x * DF_WLEN;
   // accW[i][n][q] of lane (fi, fk): tile position pp = 16 (2w + i) + 4 fk + q, column 16 n + fi
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1163,8 +1167,11 @@ int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const 
   p.enc_h = enc_h; p.noise = noise; p.soc = soc; p.xy0 = xy0; p.dxdy0 = dxdy0; p.We2d = We2d; p.be2d = be2d;
   p.out_abs = out_abs; p.out_rel = out_rel;
   p.Gt = Gt; p.Cs = Cs; p.Din = Din; p.Aact = Aact; p.E2Din = E2Din; p.SocR = SocR;
-  // one workgroup per 16-row tile, NW workgroups per generator (sized for an even split of R)
-  const int per_gen = cdiv(cdiv(R, n_gens), 16);
+  // one workgroup per 16-row tile, NW workgroups per generator.  The split of R between the generators is drawn on
+  // the device (the PM network's categorical samples): sized for an even split, the generator that drew a few rows more
+  // than R / g sent some workgroups through a SECOND tile and doubled the launch (93 us instead of ~50 at 5,120 rows).
+  // Every generator gets room for all tiles; a workgroup without a tile leaves at once.
+  const int per_gen = cdiv(R, 16) + 1;
   p.NW = per_gen < 1 ? 1 : (per_gen > 2048 / n_gens ? (2048 / n_gens > 0 ? 2048 / n_gens : 1) : per_gen);
   hipLaunchKernelGGL(decoder_fwd_mfma_kernel, dim3(n_gens * p.NW), dim3(256), 0, stream, p);
   MG_LAUNCH_CHECK("decoder_rollout_fwd");

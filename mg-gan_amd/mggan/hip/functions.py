@@ -1493,8 +1493,11 @@ class DecoderRolloutFn(Function):
         mk = lambda *s: _empty(*s, like=prep)
         dH0, dQ, dEnc, dSocR = mk(R, H), mk(R, Hh), mk(R, EIN), mk(R, S)
         # persistent workgroups per generator; each leaves one partial block of weight gradients
-        # (16-row tiles; about two resident workgroups per CU, each looping over its generator's tiles)
-        NW = max(1, min(-(-R // (16 * n_gens)), 512 // n_gens))
+        # (16-row tiles; about two resident workgroups per CU, each looping over its generator's tiles).  The split of
+        # the rows between the generators is a device-side draw: below the cap every generator gets room for ALL tiles
+        # (sized for an even split, the generator with a few rows more sent workgroups through a second tile:
+        # 140 us instead of ~75 at 5,120 rows); a workgroup without a tile writes a zero block and leaves
+        NW = max(1, min(-(-R // 16) + 1, 512 // n_gens))
         lay = _fused_layout()
         wpart = mk(n_gens * NW, lay["wlen"])
         train_w = g0["w_hh"].requires_grad
@@ -1624,7 +1627,7 @@ class DRowsBodyFn(Function):
                   SURVEY A.1; K: K independent single-sample calls batched -- the real/fake pair pass of a D step)"""
 
     @staticmethod
-    def forward(ctx, in_enc, pred, pred2, anchor, D, tb, K, soc_blocks, xy_last, dxdy_last, xy_mod, w_sc, save):
+    def forward(ctx, in_enc, pred, pred2, anchor, D, tb, K, soc_blocks, xy_last, dxdy_last, xy_mod, w_sc, save, lean=False):
         in_enc, ld_in = _rows2d(in_enc)
         b = in_enc.shape[0]
         R = K * b
@@ -1643,7 +1646,8 @@ class DRowsBodyFn(Function):
         Wpe, bpe = (pe[0].weight, pe[2].weight), (pe[0].bias, pe[2].bias)
         outs_pe = _chain_fwd(x, 2 * T, R, spec_pe, Wpe, bpe, save, out_into=(alias_cols(X, c_pe, c_sc), W))
         # broadcast in_enc into the sample blocks, clear the social block of the blocks without social features
-        lib.mggan_d_rows_fill(b, K, soc_blocks, Hs, c_in, w_in, c_sc, 0, _p(in_enc), ld_in, 0, 0, _p(X), W, st)
+        # (lean heads, dheads_lean_ok: only block 0 is ever read outside its pred_enc columns)
+        lib.mggan_d_rows_fill(b, 1 if lean else K, soc_blocks, Hs, c_in, w_in, c_sc, 0, _p(in_enc), ld_in, 0, 0, _p(X), W, st)
         # social attention: h = X[:, in_enc | pred_enc] of the first soc_blocks*b rows, S -> X[:, soc block]
         nsoc = soc_blocks * b
         xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
@@ -1700,11 +1704,29 @@ class DRowsBodyFn(Function):
                     dpred2 = _empty(T, R - n1, 2, like=X)
                     lib.mggan_rows_to_steps(_p(dx) + 4 * n1 * 2 * T, 2 * T, T, R - n1, _p(dpred2), st)
                     dpred2 = dpred2.view(p2shape)
-        return (din, dpred, dpred2) + (None,) * 10
+        return (din, dpred, dpred2) + (None,) * 11
 
 
 # from this many rows on, both discriminator heads run as one weight-stationary launch (csrc/dheads.hip)
 DHEADS_MIN_ROWS = int(os.environ.get("MGGAN_DHEADS_MIN_ROWS", "8192"))
+
+
+def dheads_lean_ok(D, in_enc, scene, K, soc_blocks, row0):
+    """True when the K-sample row pass can take the lean heads (csrc/dheads.hip: P per pedestrian + the pred_enc
+    product per row): a frozen discriminator whose history / scene features carry no gradient (the generator step, the
+    evaluation passes), social features on sample block 0 only, the default widths."""
+    if os.environ.get("MGGAN_DHEADS_LEAN", "1") == "0":
+        return False
+    b = in_enc.shape[0]
+    if not (D.gan_type == "mgan" and row0 == 0 and soc_blocks == 1 and K >= 2 and K * b >= DHEADS_MIN_ROWS):
+        return False
+    d0, r, pe = D.discs[0], D.gen_id_reconstructor, D.pred_encoder
+    if torch.is_grad_enabled() and (in_enc.requires_grad or scene.requires_grad or d0[0].weight.requires_grad
+                                    or d0[2].weight.requires_grad or r[0].weight.requires_grad or r[2].weight.requires_grad):
+        return False
+    Hs = D.social.attention.W.weight.shape[0]
+    return (tuple(d0[0].weight.shape) == (96, 192) and tuple(r[0].weight.shape) == (96, 192) and r[2].weight.shape[0] <= 15
+            and Hs == 64 and in_enc.shape[1] == 32 and pe[2].weight.shape[0] == 32 and scene.shape[1] == 64)
 
 
 class DRowsHeadsFn(Function):
@@ -1714,7 +1736,7 @@ class DRowsHeadsFn(Function):
     scene gradient is the K-sum of its block.  -> (score (K*b, 1), id logits (K*b - row0, g) | None)"""
 
     @staticmethod
-    def forward(ctx, X, scene, anchor, D, K, row0, save):
+    def forward(ctx, X, scene, anchor, D, K, row0, save, lean=False):
         scene, ld_sc = _rows2d(scene)
         b, w_sc = scene.shape
         R, W = X.shape
@@ -1722,8 +1744,30 @@ class DRowsHeadsFn(Function):
         c_sc = W - w_sc
         st = _s()
         ctx.set_materialize_grads(False)
-        lib.mggan_d_rows_fill(b, K, K, 0, 0, 0, c_sc, w_sc, 0, 0, _p(scene), ld_sc, _p(X), W, st)
+        lib.mggan_d_rows_fill(b, 1 if lean else K, K, 0, 0, 0, c_sc, w_sc, 0, 0, _p(scene), ld_sc, _p(X), W, st)
         d0 = D.discs[0]
+        if lean:
+            # block 0 (the rows with social features) through the full-width kernels, the other K-1 blocks from the
+            # per-pedestrian part P and their pred_enc columns
+            r = D.gen_id_reconstructor
+            g, act = r[2].weight.shape[0], D._out_act()
+            c_in, c_pe = 64, 96
+            wa = (d0[0].weight, d0[0].bias, d0[2].weight, d0[2].bias)
+            wb = (r[0].weight, r[0].bias, r[2].weight, r[2].bias)
+            P = _empty(b, 192, like=X)
+            lib.mggan_dheads_shared(_p(X), W, b, c_in, c_sc, _p(wa[0]), _p(wa[1]), _p(wb[0]), _p(wb[1]), _p(P), st)
+            ha = _empty(b, 96, like=X) if save else None
+            hb = _empty(b, 96, like=X) if save else None
+            ya, yb = _empty(R, 1, like=X), _empty(R, g, like=X)
+            lib.mggan_dheads_fwd(_p(X), W, b, g, act, _p(wa[0]), _p(wa[1]), _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[1]),
+                                 _p(wb[2]), _p(wb[3]), _p(ha), _p(hb), _p(ya), _p(yb), st)
+            mask = torch.empty(-(-(R - b) // 16) * 64, dtype=torch.int64, device=X.device) if save else None
+            lib.mggan_dheads_lean_fwd(_p(X), W, c_pe, b, R, b, g, act, _p(P), _p(wa[0]), _p(wa[2]), _p(wa[3]), _p(wb[0]),
+                                      _p(wb[2]), _p(wb[3]), _p(mask), _p(ya), _p(yb), st)
+            if save:
+                ctx.cfg = (D, K, row0, b, W, w_sc, True, False, False, "lean")
+                ctx.save_for_backward(ha, ya, hb, mask)
+            return ya, yb
         spec_a = ((ACT_LEAKY, 0.2), (D._out_act(), 0.0))
         Wa, ba = (d0[0].weight, d0[2].weight), (d0[0].bias, d0[2].bias)
         mgan = D.gan_type == "mgan"
@@ -1754,10 +1798,24 @@ class DRowsHeadsFn(Function):
     @staticmethod
     def backward(ctx, dya, dyb):
         D, K, row0, b, W, w_sc, mgan, train_a, train_b, big = ctx.cfg
-        X, ha, ya, hb, yb = ctx.saved_tensors
         R = K * b
         d0 = D.discs[0]
         st = _s()
+        if big == "lean":
+            # rows [0, b): all 192 columns (the social block and its h columns feed DRowsBodyFn.backward); the other
+            # blocks: the pred_enc columns only -- nothing else of dX is read (no gradient for in_enc / scene here)
+            ha, ya, hb, mask = ctx.saved_tensors
+            r = D.gen_id_reconstructor
+            g, act = r[2].weight.shape[0], D._out_act()
+            dX = _empty(R, W, like=ya)
+            dya = torch.zeros(R, 1, dtype=F32, device=ya.device) if dya is None else dya.reshape(R, 1).contiguous()
+            dyb = torch.zeros(R, g, dtype=F32, device=ya.device) if dyb is None else dyb.reshape(R, g).contiguous()
+            lib.mggan_dheads_bwd_data(_p(dya), _p(dyb), _p(ya), _p(ha), _p(hb), b, g, act, _p(d0[0].weight),
+                                      _p(d0[2].weight), _p(r[0].weight), _p(r[2].weight), _p(dX), W, st)
+            lib.mggan_dheads_lean_bwd(_p(dya), _p(dyb), _p(ya), _p(mask), b, R, g, act, _p(d0[0].weight), _p(d0[2].weight),
+                                      _p(r[0].weight), _p(r[2].weight), 96, _p(dX), W, st)
+            return (dX if ctx.needs_input_grad[0] else None,) + (None,) * 7
+        X, ha, ya, hb, yb = ctx.saved_tensors
         dX = _empty(R, W, like=X)
         if big and not train_a and not train_b:  # frozen discriminator (generator step): input gradient only, one launch
             r = D.gen_id_reconstructor
@@ -1786,7 +1844,7 @@ class DRowsHeadsFn(Function):
         if ctx.needs_input_grad[1]:
             dsc = _empty(b, w_sc, like=X)
             lib.mggan_d_rows_reduce(b, K, 0, 0, W - w_sc, w_sc, _p(dX), W, 0, 0, _p(dsc), w_sc, st)
-        return (dX if ctx.needs_input_grad[0] else None, dsc) + (None,) * 5
+        return (dX if ctx.needs_input_grad[0] else None, dsc) + (None,) * 6
 
 
 # ---------------------------------------- losses -------------------------------------------

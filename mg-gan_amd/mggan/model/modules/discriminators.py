@@ -143,10 +143,11 @@ class MultiDiscriminatorTrajectory(FlatModule):
         the classifier input in place, HF.DRowsHeadsFn adds the scene block and runs the heads)."""
         anchor = self.discs[0][0].weight
         save = HF.want_grad(in_enc, scene, pred, pred2, anchor)
+        lean = HF.dheads_lean_ok(self, in_enc, scene, K, soc_blocks, row0)
         X = HF.DRowsBodyFn.apply(in_enc, pred, pred2, anchor, self, tb, K, soc_blocks, xy_last, dxdy_last, xy_mod,
-                                 scene.shape[1], save)
+                                 scene.shape[1], save, lean)
         HF.join_branch(scene)  # the scene CNN's branch only has to be there now
-        return HF.DRowsHeadsFn.apply(X, scene, anchor, self, K, row0, save)
+        return HF.DRowsHeadsFn.apply(X, scene, anchor, self, K, row0, save, lean)
 
     def forward(self, in_xy, in_dxdy, pred_xy, pred_dxdy, seq_start_end, return_all=False, img=None, mask=None,
                 context=None):

@@ -381,3 +381,49 @@ def test_lstm_encoder_large_batch_matches_torch_f64(H, E, b):
     for name, p in list(ref_emb.named_parameters(prefix="embedding")) + list(ref_lstm.named_parameters(prefix="encoder")):
         g, r = got[name].grad.detach().cpu().double(), p.grad
         assert float((g - r).norm() / r.norm()) < 1e-4, name
+
+
+@pytest.mark.parametrize("g,sizes,K", [(4, [20] * 103 + [7, 1, 13], 4), (8, [32] * 40, 20)])
+def test_discriminator_lean_heads_match_the_full_width_pass(monkeypatch, g, sizes, K):
+    """K-sample pass of a frozen discriminator (the generator step): the lean heads (per-pedestrian part P + the pred_enc
+    product per row, csrc/dheads.hip) against the full-width kernels over the assembled rows -- scores, generator-id
+    logits and the gradient that flows back into the predictions.  b is not a multiple of 16 in the first case (the
+    16-row tiles wrap around the pedestrians of a block)."""
+    from mggan.data_utils.synthetic import make_batch
+    from mggan.hip import functions as HF
+    from mggan.hip.lib import load
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+
+    dev = _dev()
+    torch.manual_seed(21)
+    _, D = construct_model(get_parser().parse_args(["--num_gens", str(g)]))
+    D = D.to(dev).flatten_parameters_()
+    D.train()
+    for p in D.parameters():
+        p.requires_grad_(False)
+    bt = make_batch(sizes, seed=4, device=dev)
+    b = bt["in_xy"].shape[1]
+    monkeypatch.setattr(HF, "DHEADS_MIN_ROWS", 1024)
+    pred_d0 = (bt["gt_dxdy"][:, None] + 0.3 * torch.randn(12, K, b, 2, device=dev)).contiguous()
+    cot_o, cot_b = torch.randn(b, K, device=dev), torch.randn(b, K, g, device=dev)
+    res = []
+    for lean in ("1", "0"):
+        monkeypatch.setenv("MGGAN_DHEADS_LEAN", lean)
+        pd = pred_d0.clone().requires_grad_()
+        px = bt["in_xy"][-1][None, None] + torch.cumsum(pd, 0)
+        calls = []
+        L = load()
+        L.trace = calls
+        try:
+            o, br = D(bt["in_xy"], bt["in_dxdy"], px, pd, bt["seq_start_end"], img=bt["features"])
+            ((o * cot_o).sum() + (br * cot_b).sum()).backward()
+        finally:
+            L.trace = None
+        names = {c[0] for c in calls}
+        assert ("mggan_dheads_lean_fwd" in names) == (lean == "1") and ("mggan_dheads_lean_bwd" in names) == (lean == "1")
+        res.append((o.detach().clone(), br.detach().clone(), pd.grad.clone()))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-5, atol=2e-6)
+    scale = float(res[1][2].abs().max())
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-4, atol=1e-5 * scale)
