@@ -60,7 +60,8 @@ def kernel_of(name, a):
         return "dheads_fwd_kernel"
     if name == "mggan_dheads_bwd_data":
         return "dheads_bwd_kernel"
-    if name in ("mggan_dheads_lean_fwd", "mggan_dheads_lean_bwd", "mggan_dheads_shared"):
+    if name in ("mggan_dheads_lean_fwd", "mggan_dheads_lean_bwd", "mggan_dheads_shared", "mggan_d_rows_lean_fwd",
+                "mggan_d_rows_lean_bwd"):
         return name[len("mggan_"):] + "_kernel"
     return name
 
@@ -118,6 +119,10 @@ def flops_of(name, a):
         return 2.0 * (a[5] - a[4]) * (32 * 192 + 96 * (1 + a[6]))
     if name == "mggan_dheads_shared":
         return 2.0 * a[2] * 96 * 192
+    if name == "mggan_d_rows_lean_fwd":  # + the pred_encoder (24 -> 64 -> 32) in front
+        return 2.0 * (a[3] - a[2]) * (24 * 64 + 64 * 32 + 32 * 192 + 96 * (1 + a[5]))
+    if name == "mggan_d_rows_lean_bwd":
+        return 2.0 * (a[6] - a[5]) * (24 * 64 + 64 * 32 + 32 * 192 + 96 * (1 + a[7]))
     if name == "mggan_image_gram":  # not in the reference's operator list (bookkeeping of the factorised conv1 gradient)
         return 0.0
     if name == "mggan_scene_attention_fwd":

@@ -288,6 +288,22 @@ int mggan_dheads_lean_bwd(const float* dYa, const float* dYb, const float* Ya, c
                           int rows, int g, int act_a, const float* W1a, const float* W2a, const float* W1b, const float* W2b,
                           int c_pe, float* dX, int ld_dx, mggan_stream_t stream);
 
+/* The lean pass one stage further back (csrc/dheads.hip): rows [row0, rows) from the predicted steps pred (T = 12, rows, 2;
+ * row = k*b + ped) through the frozen pred_encoder (discriminators.py:42-43,129-131: Wp1 (64,24), bp1, Wp2 (32,64), bp2)
+ * and both heads in ONE launch, and from dYa / dYb to dpred (12, rows, 2) in one: the chain of transposed products keeps
+ * the activations in registers (no row copy of the steps, no pred_enc block, no hidden activations in memory). */
+int mggan_d_rows_lean_fwd(const float* pred, int T, int row0, int rows, int b, int g, int act_a, const float* Wp1,
+                          const float* bp1, const float* Wp2, const float* bp2, const float* P, int c_pe, const float* W1a,
+                          const float* W2a, const float* b2a, const float* W1b, const float* W2b, const float* b2b,
+                          unsigned long long* mask, float* Ya, float* Yb, mggan_stream_t stream);
+int mggan_d_rows_lean_bwd(const float* dYa, const float* dYb, const float* Ya, const unsigned long long* mask, int T,
+                          int row0, int rows, int g, int act_a, const float* Wp1, const float* Wp2, int c_pe,
+                          const float* W1a, const float* W2a, const float* W1b, const float* W2b, float* dpred,
+                          mggan_stream_t stream);
+/* the first `rows` rows of steps (T, n, 2) as rows (rows, 2T); rows (n, ld) into the first n rows of steps (T, n_out, 2) */
+int mggan_steps_to_rows_n(const float* a, int T, int n, int rows, float* out, mggan_stream_t stream);
+int mggan_rows_to_steps_n(const float* rows, int ld, int T, int n, int n_out, float* out, mggan_stream_t stream);
+
 /* ---- in-graph all-reduce over peer-mapped memory (csrc/comm.hip; scene-sharded training) ------------
  * No reference counterpart (the reference is single-process); replaces torch.distributed.all_reduce for the <= 360 KB
  * messages of an iteration with a plain, HIP-graph-capturable kernel.  Every rank owns one uncached arena per channel
@@ -369,6 +385,12 @@ int mggan_sample_categorical(int b, int K, int g, const float* logits, const flo
  * row_gen_pos = generator id per output position; blk_cnt = scratch, 16 * ceil(b*K/1024) ints. */
 int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, int* row_ped, int* row_slot,
                       int* row_pos, int* inv, int* seg, int* row_gen_pos, int* blk_cnt, mggan_stream_t stream);
+/* both of the above behind one entry -- ONE launch up to 2,048 rows (the single-sample rollouts of the discriminator
+ * step), the separate launches beyond: idx receives the picks, the row tables are those of mggan_bucket_rows;
+ * ticket: reserved (one word, untouched) */
+int mggan_sample_bucket_rows(int b, int K, int g, const float* logits, const float* u, long long* idx, int* row_gen,
+                             int* row_ped, int* row_slot, int* row_pos, int* inv, int* seg, int* row_gen_pos, int* blk_cnt,
+                             unsigned int* ticket, mggan_stream_t stream);
 int mggan_scale(float* x, long n, const float* scalar, mggan_stream_t stream);
 /* classifier input of the discriminator (discriminators.py:141,185,196): rows k*b+ped =
  * [soc | in_enc | pred_enc | scene], and its adjoint.  soc_all = 0: social features exist for sample block 0 only

@@ -458,6 +458,261 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same lean pass taken one stage further back: the rows of the blocks k >= 1 go from the predicted steps straight
+// to the two head outputs in ONE launch, and from the output gradients straight to the gradient of the steps in one.
+//   x (24 = 2 T) -> pred_encoder: Linear(24,64) - LeakyReLU(0.2) - Linear(64,32)  (discriminators.py:42-43,129-131)
+//                -> hidden = P[ped] + W1cat[:, pred_enc] pred_enc -> LeakyReLU(0.2) -> second layers
+// as a chain of transposed products  Y^T = W X^T : the D fragment of one product (lane (fi, fk): units 16 j + 4 fk + r of
+// row fi) IS the B operand of the next one when its k-step (j, r) is read as unit 16 j + 4 fk + r, so the activations
+// never leave the registers - no (K b, 24) row copy of the steps, no (K b, 32) pred_enc block, no (K b, 64) hidden
+// activations, and their three launches (steps_to_rows, the pred_encoder chain, rows_to_steps on the way back) are
+// gone.  The frozen pred_encoder keeps nothing but 16 more sign bits in the mask word (bits 48 + 4 j + r).
+struct DRowsLeanArgs {
+  DLeanArgs h;            // heads part: P, W1*, W2*, mask, Ya / Yb, dYa / dYb, row0, rows, b, g, act_a, c_pe (X / dX unused)
+  const float* pred;      // (T = 12, rows, 2) steps, row = k*b + ped
+  const float *Wp1, *bp1, *Wp2, *bp2;  // (64,24), (64), (32,64), (32)
+  float* dpred;           // (12, rows, 2)
+};
+#define DR_T 12
+#define DR_HP 64
+#define DR_LD1 28   // wp1 rows: 24 coefficients in lane order, 8-byte aligned
+#define DR_LD2 68
+
+template <int GM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void d_rows_lean_fwd_kernel(DRowsLeanArgs q) {
+  const DLeanArgs& a = q.h;
+  __shared__ __attribute__((aligned(16))) float w2l[(1 + DH_MAXG) * DH_HID];
+  __shared__ __attribute__((aligned(16))) float w1s[2 * DH_HID * 36];
+  __shared__ __attribute__((aligned(16))) float wp1[DR_HP * DR_LD1];   // [unit][6 fk + s]: coefficient of step t = fk + 4 (s >> 1), component s & 1
+  __shared__ __attribute__((aligned(16))) float wp2[32 * DR_LD2];      // [pred_enc column][unit]
+  __shared__ __attribute__((aligned(16))) float bp[DR_HP + 32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  for (int i = threadIdx.x; i < 2 * DH_HID * 8; i += 256) {
+    const int n = i >> 3, c = (i & 7) * 4;
+    const float* Wrow = (n < DH_HID ? a.W1a + (size_t)n * DH_IN : a.W1b + (size_t)(n - DH_HID) * DH_IN) + a.c_pe + c;
+    *reinterpret_cast<f32x4*>(&w1s[n * 36 + c]) = *reinterpret_cast<const f32x4*>(Wrow);
+  }
+  for (int i = threadIdx.x; i < DR_HP * 24; i += 256) {
+    const int n = i / 24, p = i % 24, k4 = p / 6, s = p % 6;
+    wp1[n * DR_LD1 + p] = q.Wp1[n * 24 + 2 * (k4 + 4 * (s >> 1)) + (s & 1)];
+  }
+  for (int i = threadIdx.x; i < 32 * DR_HP; i += 256) wp2[(i / DR_HP) * DR_LD2 + i % DR_HP] = q.Wp2[i];
+  for (int i = threadIdx.x; i < DR_HP + 32; i += 256) bp[i] = i < DR_HP ? q.bp1[i] : q.bp2[i - DR_HP];
+  dl_stage_w2(a, w2l);
+  const float* awl = &w1s[fi * 36 + 4 * fk];
+  const float b2a = a.b2a[0];
+  const int nt = (a.rows - a.row0 + 15) / 16;
+  const int nwv = gridDim.x * 4;
+  float2 nx[3];
+  f32x4 nP[12];
+  auto fetch = [&](int t) {
+    const int gr = a.row0 + 16 * t + fi;
+    const int grc = gr < a.rows ? gr : a.rows - 1;  // (clamped address, masked where it is consumed)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) nx[u] = *reinterpret_cast<const float2*>(q.pred + ((size_t)(fk + 4 * u) * a.rows + grc) * 2);
+    const float* pr = a.P + (size_t)(grc % a.b) * DH_IN + 4 * fk;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) nP[j] = *reinterpret_cast<const f32x4*>(pr + 16 * j);
+  };
+  int t = blockIdx.x * 4 + w;
+  if (t < nt) fetch(t);
+  for (; t < nt; t += nwv) {
+    const int gr = a.row0 + 16 * t + fi;
+    const bool valid = gr < a.rows;
+    f32x4 acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = nP[j];
+    const float xs[6] = {nx[0].x, nx[0].y, nx[1].x, nx[1].y, nx[2].x, nx[2].y};
+    if (t + nwv < nt) fetch(t + nwv);
+    const float* lw = &w1s[0];
+    asm volatile("" : "+v"(lw));  // (every LDS operand below is loop invariant: hoisted, they are 200 registers)
+    const long sh = lw - &w1s[0];
+    unsigned long long m = 0ull;
+    // pred_encoder, first layer: units 16 j + 4 fk + r of row fi
+    f32x4 h1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* wr = &wp1[(16 * j + fi) * DR_LD1 + 6 * fk] + sh;
+      const float2 c0 = *reinterpret_cast<const float2*>(wr), c1 = *reinterpret_cast<const float2*>(wr + 2),
+                   c2 = *reinterpret_cast<const float2*>(wr + 4);
+      f32x4 z = *reinterpret_cast<const f32x4*>(&bp[16 * j + 4 * fk] + sh);
+      z = MFMA16(c0.x, xs[0], z); z = MFMA16(c0.y, xs[1], z);
+      z = MFMA16(c1.x, xs[2], z); z = MFMA16(c1.y, xs[3], z);
+      z = MFMA16(c2.x, xs[4], z); z = MFMA16(c2.y, xs[5], z);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool pos = z[r] > 0.f;
+        h1[j][r] = pos ? z[r] : 0.2f * z[r];
+        m |= (unsigned long long)pos << (48 + 4 * j + r);
+      }
+    }
+    // second layer: pred_enc columns 16 ct + 4 fk + r (two accumulator chains per column tile)
+    f32x4 pe[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      f32x4 za = *reinterpret_cast<const f32x4*>(&bp[DR_HP + 16 * ct + 4 * fk] + sh), zb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(&wp2[(16 * ct + fi) * DR_LD2 + 16 * j + 4 * fk] + sh);
+        const f32x4 wb = *reinterpret_cast<const f32x4*>(&wp2[(16 * ct + fi) * DR_LD2 + 16 * (j + 1) + 4 * fk] + sh);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          za = MFMA16(wa[r], h1[j][r], za);
+          zb = MFMA16(wb[r], h1[j + 1][r], zb);
+        }
+      }
+      pe[ct] = za + zb;
+    }
+    // first layers of both heads on top of the pedestrian's shared part
+    const float* awt = awl + sh;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(awt + 16 * j * 36), a1 = *reinterpret_cast<const f32x4*>(awt + 16 * j * 36 + 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j] = MFMA16(a0[i], pe[0][i], acc[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j] = MFMA16(a1[i], pe[1][i], acc[j]);
+    }
+    float ya = 0.f, yb[GM];
+#pragma unroll
+    for (int o = 0; o < GM; ++o) yb[o] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      f32x4 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[j][r];
+        const bool pos = v > 0.f;
+        h[r] = pos ? v : 0.2f * v;
+        m |= (unsigned long long)pos << (4 * j + r);
+      }
+      if (j < 6) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(&w2l[16 * j + 4 * fk]);
+        ya = fmaf(h[0], wv[0], fmaf(h[1], wv[1], fmaf(h[2], wv[2], fmaf(h[3], wv[3], ya))));
+      } else {
+#pragma unroll
+        for (int o = 0; o < GM; ++o)
+          if (o < a.g) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(&w2l[DH_HID + o * DH_HID + 16 * (j - 6) + 4 * fk]);
+            yb[o] = fmaf(h[0], wv[0], fmaf(h[1], wv[1], fmaf(h[2], wv[2], fmaf(h[3], wv[3], yb[o]))));
+          }
+      }
+    }
+    ya = quarters_sum(ya);
+#pragma unroll
+    for (int o = 0; o < GM; ++o)
+      if (o < a.g) yb[o] = quarters_sum(yb[o]);
+    if (valid && fk == 0) {
+      a.Ya[gr] = mg_act(ya + b2a, a.act_a, 0.f);
+#pragma unroll
+      for (int o = 0; o < GM; ++o)
+        if (o < a.g) a.Yb[(size_t)gr * a.g + o] = yb[o] + a.b2b[o];
+    }
+    if (a.mask) a.mask[(size_t)t * 64 + lane] = m;
+  }
+}
+
+template <int GM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void d_rows_lean_bwd_kernel(DRowsLeanArgs q) {
+  const DLeanArgs& a = q.h;
+  __shared__ __attribute__((aligned(16))) float w2l[(1 + DH_MAXG) * DH_HID];
+  __shared__ __attribute__((aligned(16))) float wp2t[DR_HP * 36];      // [unit][pred_enc column]
+  __shared__ __attribute__((aligned(16))) float wp1t[32 * DR_LD2];     // [step coefficient 2 t + c (rows 24 .. 31 zero)][unit]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  for (int i = threadIdx.x; i < 32 * DR_HP; i += 256) wp2t[(i % DR_HP) * 36 + i / DR_HP] = q.Wp2[i];
+  for (int i = threadIdx.x; i < 32 * DR_HP; i += 256) {
+    const int f = i / DR_HP, n = i % DR_HP;
+    wp1t[f * DR_LD2 + n] = f < 24 ? q.Wp1[n * 24 + f] : 0.f;
+  }
+  dl_stage_w2(a, w2l);
+  float aw[2][48];
+#pragma unroll
+  for (int ss = 0; ss < 12; ++ss)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hid = 16 * ss + 4 * fk + i;
+      const float* Wrow = (hid < DH_HID ? a.W1a + (size_t)hid * DH_IN : a.W1b + (size_t)(hid - DH_HID) * DH_IN) + a.c_pe + fi;
+      aw[0][4 * ss + i] = Wrow[0];
+      aw[1][4 * ss + i] = Wrow[16];
+    }
+  const int nt = (a.rows - a.row0 + 15) / 16;
+  const int nwv = gridDim.x * 4;
+  for (int t = blockIdx.x * 4 + w; t < nt; t += nwv) {
+    const int gr = a.row0 + 16 * t + fi;
+    const bool valid = gr < a.rows;
+    const int grc = valid ? gr : a.rows - 1;
+    const unsigned long long m = a.mask[(size_t)t * 64 + lane];
+    const float vm = valid ? 1.f : 0.f;
+    const float dza = a.dYa[grc] * mg_act_grad_from_out(a.Ya[grc], a.act_a, 0.f) * vm;
+    float dyb[GM];
+#pragma unroll
+    for (int o = 0; o < GM; ++o) dyb[o] = o < a.g ? a.dYb[(size_t)grc * a.g + o] * vm : 0.f;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[ct][0] = acc[ct][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ss = 0; ss < 12; ++ss) {
+      f32x4 d;
+      if (ss < 6) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(&w2l[16 * ss + 4 * fk]);
+        d = wv * dza;
+      } else {
+        d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < GM; ++o)
+          if (o < a.g) d += *reinterpret_cast<const f32x4*>(&w2l[DH_HID + o * DH_HID + 16 * (ss - 6) + 4 * fk]) * dyb[o];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dv = d[i] * (((m >> (4 * ss + i)) & 1ull) ? 1.f : 0.2f);
+        acc[0][i & 1] = MFMA16(aw[0][4 * ss + i], dv, acc[0][i & 1]);
+        acc[1][i & 1] = MFMA16(aw[1][4 * ss + i], dv, acc[1][i & 1]);
+      }
+    }
+    const f32x4 dpe[2] = {acc[0][0] + acc[0][1], acc[1][0] + acc[1][1]};  // pred_enc columns 16 ct + 4 fk + r of row fi
+    const float* lw = &wp2t[0];
+    asm volatile("" : "+v"(lw));
+    const long sh = lw - &wp2t[0];
+    // pred_encoder adjoint: d h1 = W_p2^T d pred_enc, through LeakyReLU', d x = W_p1^T d h1
+    f32x4 dh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wp2t[(16 * j + fi) * 36 + 4 * fk] + sh);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wp2t[(16 * j + fi) * 36 + 16 + 4 * fk] + sh);
+      f32x4 za = f32x4{0.f, 0.f, 0.f, 0.f}, zb = za;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        za = MFMA16(w0[r], dpe[0][r], za);
+        zb = MFMA16(w1[r], dpe[1][r], zb);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh[j][r] = (za[r] + zb[r]) * (((m >> (48 + 4 * j + r)) & 1ull) ? 1.f : 0.2f);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 za = f32x4{0.f, 0.f, 0.f, 0.f}, zb = za;
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(&wp1t[(16 * mt + fi) * DR_LD2 + 16 * j + 4 * fk] + sh);
+        const f32x4 wb = *reinterpret_cast<const f32x4*>(&wp1t[(16 * mt + fi) * DR_LD2 + 16 * (j + 1) + 4 * fk] + sh);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          za = MFMA16(wa[r], dh[j][r], za);
+          zb = MFMA16(wb[r], dh[j + 1][r], zb);
+        }
+      }
+      const f32x4 dx = za + zb;  // coefficients 16 mt + 4 fk + r = steps 8 mt + 2 fk (+1), both components
+      const int t0 = 8 * mt + 2 * fk;
+      if (valid && t0 < DR_T) {
+        *reinterpret_cast<float2*>(q.dpred + ((size_t)t0 * a.rows + gr) * 2) = float2{dx[0], dx[1]};
+        *reinterpret_cast<float2*>(q.dpred + ((size_t)(t0 + 1) * a.rows + gr) * 2) = float2{dx[2], dx[3]};
+      }
+    }
+  }
+}
+
 extern "C" {
 
 static int dheads_check(const DHeadsArgs& a, const char* what) {
@@ -573,6 +828,64 @@ int mggan_dheads_lean_bwd(const float* dYa, const float* dYb, const float* Ya, c
   else if (g <= 8) hipLaunchKernelGGL(dheads_lean_bwd_kernel<8>, grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(dheads_lean_bwd_kernel<16>, grid, dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("dheads_lean_bwd");
+  return MGGAN_OK;
+}
+
+
+static int d_rows_lean_check(const char* what, int T, int row0, int rows, int b, int g, int act_a) {
+  MG_CHECK_ARG(T == DR_T, "%s: pred_len %d not built (12)", what, T);
+  MG_CHECK_ARG(g >= 1 && g <= DH_MAXG - 1 && row0 >= 0 && b > 0, "%s: g = %d not in 1..%d", what, g, DH_MAXG - 1);
+  MG_CHECK_ARG(act_a == ACT_NONE || act_a == ACT_SIGMOID_EPS || act_a == ACT_SIGMOID, "%s: output activation %d", what, act_a);
+  (void)rows;
+  return MGGAN_OK;
+}
+
+/* rows [row0, rows) of a K-sample pass, from the predicted steps pred (T=12, rows, 2) to the outputs of both heads in one
+ * launch: pred_encoder (Wp1 (64,24), bp1, Wp2 (32,64), bp2) -> P[row % b] + W1cat[:, c_pe .. c_pe+31] pred_enc -> heads.
+ * mask as mggan_dheads_lean_fwd (bits 48..63: the pred_encoder's hidden units) */
+int mggan_d_rows_lean_fwd(const float* pred, int T, int row0, int rows, int b, int g, int act_a, const float* Wp1,
+                          const float* bp1, const float* Wp2, const float* bp2, const float* P, int c_pe, const float* W1a,
+                          const float* W2a, const float* b2a, const float* W1b, const float* W2b, const float* b2b,
+                          unsigned long long* mask, float* Ya, float* Yb, hipStream_t stream) {
+  if (int rc = d_rows_lean_check("d_rows_lean_fwd", T, row0, rows, b, g, act_a)) return rc;
+  if (rows <= row0) return MGGAN_OK;
+  MG_CHECK_ARG(pred && Wp1 && bp1 && Wp2 && bp2 && P && W1a && W2a && b2a && W1b && W2b && b2b && Ya && Yb,
+               "d_rows_lean_fwd: null pointer");
+  MG_CHECK_ARG((((size_t)P) & 15) == 0 && (((size_t)pred) & 7) == 0 && c_pe % 4 == 0 && c_pe >= 0 && c_pe + 32 <= DH_IN,
+               "d_rows_lean_fwd: bad layout (c_pe %d)", c_pe);
+  DRowsLeanArgs q = {};
+  DLeanArgs& a = q.h;
+  a.c_pe = c_pe; a.row0 = row0; a.rows = rows; a.b = b; a.g = g; a.act_a = act_a; a.P = P;
+  a.W1a = W1a; a.W1b = W1b; a.W2a = W2a; a.b2a = b2a; a.W2b = W2b; a.b2b = b2b; a.mask = mask; a.Ya = Ya; a.Yb = Yb;
+  q.pred = pred; q.Wp1 = Wp1; q.bp1 = bp1; q.Wp2 = Wp2; q.bp2 = bp2;
+  const dim3 grid(dlean_grid(rows - row0));
+  if (g <= 4) hipLaunchKernelGGL(d_rows_lean_fwd_kernel<4>, grid, dim3(256), 0, stream, q);
+  else if (g <= 8) hipLaunchKernelGGL(d_rows_lean_fwd_kernel<8>, grid, dim3(256), 0, stream, q);
+  else hipLaunchKernelGGL(d_rows_lean_fwd_kernel<16>, grid, dim3(256), 0, stream, q);
+  MG_LAUNCH_CHECK("d_rows_lean_fwd");
+  return MGGAN_OK;
+}
+
+/* dpred (12, rows, 2), rows [row0, rows): the gradient of the predicted steps from dYa / dYb (frozen discriminator) */
+int mggan_d_rows_lean_bwd(const float* dYa, const float* dYb, const float* Ya, const unsigned long long* mask, int T,
+                          int row0, int rows, int g, int act_a, const float* Wp1, const float* Wp2, int c_pe,
+                          const float* W1a, const float* W2a, const float* W1b, const float* W2b, float* dpred,
+                          hipStream_t stream) {
+  if (int rc = d_rows_lean_check("d_rows_lean_bwd", T, row0, rows, 1, g, act_a)) return rc;
+  if (rows <= row0) return MGGAN_OK;
+  MG_CHECK_ARG(dYa && dYb && Ya && mask && Wp1 && Wp2 && W1a && W2a && W1b && W2b && dpred, "d_rows_lean_bwd: null pointer");
+  MG_CHECK_ARG((((size_t)dpred) & 7) == 0 && c_pe % 4 == 0 && c_pe >= 0 && c_pe + 32 <= DH_IN, "d_rows_lean_bwd: bad layout (c_pe %d)", c_pe);
+  DRowsLeanArgs q = {};
+  DLeanArgs& a = q.h;
+  a.c_pe = c_pe; a.row0 = row0; a.rows = rows; a.g = g; a.act_a = act_a; a.b = 1;
+  a.W1a = W1a; a.W1b = W1b; a.W2a = W2a; a.W2b = W2b; a.mask = const_cast<unsigned long long*>(mask);
+  a.Ya = const_cast<float*>(Ya); a.dYa = dYa; a.dYb = dYb;
+  q.Wp1 = Wp1; q.Wp2 = Wp2; q.dpred = dpred;
+  const dim3 grid(dlean_grid(rows - row0));
+  if (g <= 4) hipLaunchKernelGGL(d_rows_lean_bwd_kernel<4>, grid, dim3(256), 0, stream, q);
+  else if (g <= 8) hipLaunchKernelGGL(d_rows_lean_bwd_kernel<8>, grid, dim3(256), 0, stream, q);
+  else hipLaunchKernelGGL(d_rows_lean_bwd_kernel<16>, grid, dim3(256), 0, stream, q);
+  MG_LAUNCH_CHECK("d_rows_lean_bwd");
   return MGGAN_OK;
 }
 

@@ -50,12 +50,13 @@ __global__ __launch_bounds__(256) void d_rows_reduce_kernel(int b, int K, int c_
 }
 
 // rows (n, 2T) with row stride ld -> time-major steps (T, n, 2): the adjoint of steps_to_rows
-__global__ __launch_bounds__(256) void rows_to_steps_kernel(const float* __restrict__ rows, int ld, int T, int n,
+// (n rows into a step tensor of n_out >= n rows per step: the first n rows of every step are written)
+__global__ __launch_bounds__(256) void rows_to_steps_kernel(const float* __restrict__ rows, int ld, int T, int n, int n_out,
                                                             float* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)n * T) return;
   const int r = (int)(i / T), t = (int)(i % T);
-  *reinterpret_cast<float2*>(out + ((size_t)t * n + r) * 2) = *reinterpret_cast<const float2*>(rows + (size_t)r * ld + 2 * t);
+  *reinterpret_cast<float2*>(out + ((size_t)t * n_out + r) * 2) = *reinterpret_cast<const float2*>(rows + (size_t)r * ld + 2 * t);
 }
 
 extern "C" {
@@ -91,8 +92,17 @@ int mggan_d_rows_reduce(int b, int K, int c_in, int w_in, int c_scene, int w_sce
 int mggan_rows_to_steps(const float* rows, int ld, int T, int n, float* out, hipStream_t stream) {
   if ((long)n * T == 0) return MGGAN_OK;
   MG_CHECK_ARG(rows && out && ld >= 2 * T && ld % 2 == 0, "rows_to_steps: bad arguments");
-  hipLaunchKernelGGL(rows_to_steps_kernel, dim3(cdiv((long)n * T, 256)), dim3(256), 0, stream, rows, ld, T, n, out);
+  hipLaunchKernelGGL(rows_to_steps_kernel, dim3(cdiv((long)n * T, 256)), dim3(256), 0, stream, rows, ld, T, n, n, out);
   MG_LAUNCH_CHECK("rows_to_steps");
+  return MGGAN_OK;
+}
+
+/* rows (n, ld >= 2T) -> the first n rows of every step of out (T, n_out, 2) */
+int mggan_rows_to_steps_n(const float* rows, int ld, int T, int n, int n_out, float* out, hipStream_t stream) {
+  if ((long)n * T == 0) return MGGAN_OK;
+  MG_CHECK_ARG(rows && out && ld >= 2 * T && ld % 2 == 0 && n <= n_out, "rows_to_steps_n: bad arguments");
+  hipLaunchKernelGGL(rows_to_steps_kernel, dim3(cdiv((long)n * T, 256)), dim3(256), 0, stream, rows, ld, T, n, n_out, out);
+  MG_LAUNCH_CHECK("rows_to_steps_n");
   return MGGAN_OK;
 }
 

@@ -725,26 +725,115 @@ __global__ __launch_bounds__(BR_BLOCK) void bucket_small_kernel(const long long*
   }
 }
 
-// Categorical(logits).sample((K,)).T by inverse CDF from caller-provided uniforms u (b,K) in [0,1):
-// one lane per (pedestrian, sample) (standard.py:217-225 on the device, no host round trip).  Every lane rebuilds its
-// pedestrian's g-entry CDF (the row is an L1 hit) - a lane per pedestrian walking its K samples was K dependent
-// strided round trips (61 us at 8,192 x 20).  Same arithmetic per sample, same picks.
+// Categorical(logits).sample((K,)).T by inverse CDF from caller-provided uniforms u (b,K) in [0,1)
+// (standard.py:217-225 on the device, no host round trip).  sb_build / sb_pick are THE arithmetic of a pick: every
+// kernel below that samples goes through them, so that the fused and the stand-alone launches choose alike.
+__device__ __forceinline__ void sb_build(const float* __restrict__ l, int g, float (&cdf)[BR_MAXG], float& run) {
+  float v[BR_MAXG], mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < BR_MAXG; ++c) {
+    v[c] = c < g ? l[c] : -INFINITY;
+    mx = fmaxf(mx, v[c]);
+  }
+  run = 0.f;
+#pragma unroll
+  for (int c = 0; c < BR_MAXG; ++c) {
+    if (c < g) run += __expf(v[c] - mx);
+    cdf[c] = run;
+  }
+}
+__device__ __forceinline__ int sb_pick(const float (&cdf)[BR_MAXG], int g, float x) {
+  int pick = g - 1;
+#pragma unroll
+  for (int c = BR_MAXG - 2; c >= 0; --c)
+    if (c < g - 1 && x < cdf[c]) pick = c;
+  return pick;
+}
+
+// One lane per (pedestrian, sample).  Every lane rebuilds its pedestrian's g-entry CDF (the row is an L1 hit) - a lane
+// per pedestrian walking its K samples was K dependent strided round trips (61 us at 8,192 x 20).
 __global__ void sample_categorical_kernel(int b, int K, int g, const float* __restrict__ logits,
                                           const float* __restrict__ u, long long* idx) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)b * K) return;
   const int ped = (int)(i / K);
-  const float* l = logits + (size_t)ped * g;
-  float cdf[BR_MAXG];
-  float mx = -INFINITY;
-  for (int c = 0; c < g; ++c) mx = fmaxf(mx, l[c]);
-  float run = 0.f;
-  for (int c = 0; c < g; ++c) { run += __expf(l[c] - mx); cdf[c] = run; }
-  const float x = u[i] * run;
-  int pick = g - 1;
-  for (int c = g - 2; c >= 0; --c)
-    if (x < cdf[c]) pick = c;
-  idx[i] = pick;
+  float cdf[BR_MAXG], run;
+  sb_build(logits + (size_t)ped * g, g, cdf, run);
+  idx[i] = sb_pick(cdf, g, u[i] * run);
+}
+
+// ---- sampling + bucketing in one launch for small row counts ------------------------------------------------------
+// (Beyond a few thousand rows the fusion does not pay: a two-launch form - one workgroup per (sample, 1024-pedestrian
+// chunk) re-drawing the earlier samples of its lanes for the occurrence offsets, block counts scanned by the last
+// workgroup to finish - took 76 us at 8,192 x 20 against 25 us for the five separate launches: the re-draws and the
+// serial, L2-latency-bound scan behind a ticket cost more than the launches they replace.)
+// Small row counts (the single-sample rollouts of the discriminator step, small batches): everything in ONE workgroup,
+// generator ids and occurrence offsets staged in LDS between the passes.  Same stable order as the multi-pass version.
+#define SB_SMALL 2048
+__global__ __launch_bounds__(BR_BLOCK) void sample_bucket_small_kernel(int b, int K, int g, const float* __restrict__ logits,
+                                                                       const float* __restrict__ u, long long* idx,
+                                                                       int* row_gen_pos, int* inv, int* seg, int* row_gen,
+                                                                       int* row_ped, int* row_slot, int* row_pos) {
+  __shared__ unsigned char s_gen[SB_SMALL];
+  __shared__ unsigned short s_slot[SB_SMALL];
+  __shared__ int hist[BR_MAXG], base[BR_MAXG], wcnt[BR_BLOCK / 64][BR_MAXG];
+  const int R = b * K, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t < BR_MAXG) hist[t] = 0;
+  __syncthreads();
+  for (int ped = t; ped < b; ped += BR_BLOCK) {
+    float cdf[BR_MAXG], run;
+    sb_build(logits + (size_t)ped * g, g, cdf, run);
+    int seen[BR_MAXG];
+#pragma unroll
+    for (int q = 0; q < BR_MAXG; ++q) seen[q] = 0;
+    for (int k = 0; k < K; ++k) {
+      const int gi = sb_pick(cdf, g, u[(size_t)ped * K + k] * run);
+      int slot = 0;
+#pragma unroll
+      for (int q = 0; q < BR_MAXG; ++q) {
+        if (q == gi) { slot = seen[q]; seen[q] += 1; }
+      }
+      idx[(size_t)ped * K + k] = gi;
+      row_gen_pos[k * b + ped] = gi;
+      s_gen[k * b + ped] = (unsigned char)gi;
+      s_slot[k * b + ped] = (unsigned short)slot;
+    }
+#pragma unroll
+    for (int q = 0; q < BR_MAXG; ++q)
+      if (seen[q]) atomicAdd(&hist[q], seen[q]);
+  }
+  __syncthreads();
+  if (t == 0) {
+    int runc = 0;
+    for (int i = 0; i < g; ++i) { seg[i] = runc; base[i] = runc; runc += hist[i]; }
+    seg[g] = runc;
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < R; c0 += BR_BLOCK) {
+    const int pos = c0 + t;
+    const bool ok = pos < R;
+    const int gi = ok ? (int)s_gen[pos] : -1;
+    int rank = 0;
+    for (int q = 0; q < g; ++q) {
+      const unsigned long long m = __ballot(gi == q);
+      if (gi == q) rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wcnt[wv][q] = __popcll(m);
+    }
+    __syncthreads();
+    if (ok) {
+      int before = 0;
+      for (int i = 0; i < wv; ++i) before += wcnt[i][gi];
+      const int r = base[gi] + before + rank;
+      row_gen[r] = gi; row_ped[r] = pos % b; row_slot[r] = (int)s_slot[pos]; row_pos[r] = pos; inv[pos] = r;
+    }
+    __syncthreads();
+    if (t < g) {
+      int tot = 0;
+      for (int i = 0; i < BR_BLOCK / 64; ++i) tot += wcnt[i][t];
+      base[t] += tot;
+    }
+    __syncthreads();
+  }
 }
 
 extern "C" {
@@ -756,6 +845,29 @@ int mggan_sample_categorical(int b, int K, int g, const float* logits, const flo
   hipLaunchKernelGGL(sample_categorical_kernel, dim3(cdiv((long)b * K, 256)), dim3(256), 0, stream, b, K, g, logits, u, idx);
   MG_LAUNCH_CHECK("sample_categorical");
   return MGGAN_OK;
+}
+
+int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, int* row_ped, int* row_slot, int* row_pos,
+                      int* inv, int* seg, int* row_gen_pos, int* blk_cnt, hipStream_t stream);
+
+/* mggan_sample_categorical + mggan_bucket_rows; ONE launch up to 2,048 rows: the same picks, the same tables */
+int mggan_sample_bucket_rows(int b, int K, int g, const float* logits, const float* u, long long* idx, int* row_gen,
+                             int* row_ped, int* row_slot, int* row_pos, int* inv, int* seg, int* row_gen_pos, int* blk_cnt,
+                             unsigned int* ticket, hipStream_t stream) {
+  MG_CHECK_ARG(g >= 1 && g <= BR_MAXG && K >= 0 && K < 65536, "sample_bucket_rows: num_gens %d not in 1..%d (samples %d)", g, BR_MAXG, K);
+  const long Rl = (long)b * K;
+  if (Rl == 0) return MGGAN_OK;
+  MG_CHECK_ARG(logits && u && idx && row_gen && row_ped && row_slot && row_pos && inv && seg && row_gen_pos && blk_cnt && ticket,
+               "sample_bucket_rows: null pointer");
+  const int R = (int)Rl;
+  if (R <= SB_SMALL) {
+    hipLaunchKernelGGL(sample_bucket_small_kernel, dim3(1), dim3(BR_BLOCK), 0, stream, b, K, g, logits, u, idx, row_gen_pos,
+                       inv, seg, row_gen, row_ped, row_slot, row_pos);
+    MG_LAUNCH_CHECK("sample_bucket_rows");
+    return MGGAN_OK;
+  }
+  if (int rc = mggan_sample_categorical(b, K, g, logits, u, idx, stream)) return rc;
+  return mggan_bucket_rows(idx, b, K, g, row_gen, row_ped, row_slot, row_pos, inv, seg, row_gen_pos, blk_cnt, stream);
 }
 
 int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, int* row_ped, int* row_slot,
@@ -817,6 +929,16 @@ int mggan_steps_to_rows(const float* a, const float* b, int T, int n, float* out
   MG_CHECK_ARG(a && out, "steps_to_rows: null pointer");
   hipLaunchKernelGGL(steps_to_rows_kernel, dim3(cdiv((long)rows * T, 256)), dim3(256), 0, stream, a, b, T, n, rows, out);
   MG_LAUNCH_CHECK("steps_to_rows");
+  return MGGAN_OK;
+}
+
+/* the first `rows` rows only of steps laid out (T, n, 2): out (rows, 2T) */
+int mggan_steps_to_rows_n(const float* a, int T, int n, int rows, float* out, hipStream_t stream) {
+  MG_CHECK_ARG(T >= 0 && n >= 0 && rows >= 0 && rows <= n, "steps_to_rows_n: bad sizes (%d of %d rows)", rows, n);
+  if ((long)rows * T == 0) return MGGAN_OK;
+  MG_CHECK_ARG(a && out, "steps_to_rows_n: null pointer");
+  hipLaunchKernelGGL(steps_to_rows_kernel, dim3(cdiv((long)rows * T, 256)), dim3(256), 0, stream, a, (const float*)nullptr, T, n, rows, out);
+  MG_LAUNCH_CHECK("steps_to_rows_n");
   return MGGAN_OK;
 }
 

@@ -1411,18 +1411,22 @@ class RolloutRows:
         self.row_gen_pos = to(gen)
 
 
-def device_rollout_rows(idx, n_gens):
-    """RolloutRows built on the GPU from sampled generator ids (b, K) int64 -- no host round trip."""
-    b, K = idx.shape
+def empty_rollout_rows(b, K, n_gens, dev):
+    """-> (RolloutRows with unfilled device tables, the block-count scratch of the bucketing launches)."""
     R = b * K
-    dev = idx.device
     rows = RolloutRows.__new__(RolloutRows)
     mk = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
     rows.R, rows.b, rows.K = R, b, K
     rows.row_gen, rows.row_ped, rows.row_slot, rows.row_pos, rows.inv = mk(R), mk(R), mk(R), mk(R), mk(R)
     rows.seg, rows.row_gen_pos = mk(n_gens + 1), mk(R)
+    return rows, mk(16 * ((R + 1023) // 1024))
+
+
+def device_rollout_rows(idx, n_gens):
+    """RolloutRows built on the GPU from sampled generator ids (b, K) int64 -- no host round trip."""
+    b, K = idx.shape
+    rows, blk = empty_rollout_rows(b, K, n_gens, idx.device)
     idx = idx.contiguous()
-    blk = mk(16 * ((R + 1023) // 1024))
     lib.mggan_bucket_rows(_p(idx), b, K, n_gens, _p(rows.row_gen), _p(rows.row_ped), _p(rows.row_slot),
                           _p(rows.row_pos), _p(rows.inv), _p(rows.seg), _p(rows.row_gen_pos), _p(blk), _s())
     return rows
@@ -1727,6 +1731,103 @@ def dheads_lean_ok(D, in_enc, scene, K, soc_blocks, row0):
     Hs = D.social.attention.W.weight.shape[0]
     return (tuple(d0[0].weight.shape) == (96, 192) and tuple(r[0].weight.shape) == (96, 192) and r[2].weight.shape[0] <= 15
             and Hs == 64 and in_enc.shape[1] == 32 and pe[2].weight.shape[0] == 32 and scene.shape[1] == 64)
+
+
+def d_rows_lean_ok(D, in_enc, scene, pred, K, soc_blocks, row0):
+    """dheads_lean_ok and, on top, everything DRowsLeanFn assumes: the whole discriminator frozen (pred_encoder and social
+    attention included), the default prediction length."""
+    if os.environ.get("MGGAN_DROWS_LEAN", "1") == "0" or not dheads_lean_ok(D, in_enc, scene, K, soc_blocks, row0):
+        return False
+    pe, soc = D.pred_encoder, D.social
+    if torch.is_grad_enabled() and (pe[0].weight.requires_grad or pe[2].weight.requires_grad
+                                    or any(q.requires_grad for q in soc.parameters())):
+        return False
+    return pred.shape[0] == 12 and tuple(pe[0].weight.shape) == (64, 24) and tuple(pe[2].weight.shape) == (32, 64)
+
+
+class DRowsLeanFn(Function):
+    """The K-sample row pass of a FROZEN discriminator (the generator step, the evaluation passes) in its lean form
+    (discriminators.py:113-219, pool_type 'sways', unmasked):
+      sample block 0 (the only rows with social features): pred_encoder -> X0 = [soc | in_enc | pred_enc |
+        scene] (b, 192) -> social attention -> both heads, through the kernels of the generic path;
+      blocks 1 .. K-1: ONE launch from the predicted steps to both head outputs (csrc/dheads.hip: pred_encoder ->
+        P[ped] + W1[:, pred_enc] pred_enc -> heads), one launch back to the gradient of the steps.
+    -> (score (K*b, 1), id logits (K*b, g)); the only gradient: d pred."""
+
+    @staticmethod
+    def forward(ctx, in_enc, scene, pred, D, tb, K, xy_last, dxdy_last, save):
+        in_enc, ld_in = _rows2d(in_enc)
+        scene, ld_sc = _rows2d(scene)
+        b = in_enc.shape[0]
+        R, T = K * b, pred.shape[0]
+        pshape = pred.shape
+        pred = pred.reshape(T, R, 2).contiguous()
+        st = _s()
+        ctx.set_materialize_grads(False)
+        pe, d0, r = D.pred_encoder, D.discs[0], D.gen_id_reconstructor
+        fc, Wat = D.social.feature_embedder.fc, D.social.attention.W
+        W, c_in, c_pe, c_sc = 192, 64, 96, 128
+        g, act = r[2].weight.shape[0], D._out_act()
+        # ---- block 0 ----
+        x0 = _empty(b, 2 * T, like=in_enc)
+        lib.mggan_steps_to_rows_n(_p(pred), T, R, b, _p(x0), st)
+        X = _empty(b, W, like=in_enc)
+        spec_pe = ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0))
+        Wpe, bpe = (pe[0].weight, pe[2].weight), (pe[0].bias, pe[2].bias)
+        outs_pe = _chain_fwd(x0, 2 * T, b, spec_pe, Wpe, bpe, save, out_into=(alias_cols(X, c_pe, c_sc), W))
+        lib.mggan_d_rows_fill(b, 1, 1, c_in, c_in, c_pe - c_in, c_sc, 0, _p(in_enc), ld_in, 0, 0, _p(X), W, st)
+        xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
+        sw = (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, Wat.weight, Wat.bias)
+        soc_saved = _social_fwd(xy_last, dxdy_last, _p(X) + 4 * c_in, W, b, c_sc - c_in, tb, *sw, _p(X), W, save, 0, X)
+        join_branch(scene)  # the scene CNN's branch only has to be there now
+        lib.mggan_d_rows_fill(b, 1, 1, 0, 0, 0, c_sc, W - c_sc, 0, 0, _p(scene), ld_sc, _p(X), W, st)
+        wa = (d0[0].weight, d0[0].bias, d0[2].weight, d0[2].bias)
+        wb = (r[0].weight, r[0].bias, r[2].weight, r[2].bias)
+        P = _empty(b, W, like=X)
+        lib.mggan_dheads_shared(_p(X), W, b, c_in, c_sc, _p(wa[0]), _p(wa[1]), _p(wb[0]), _p(wb[1]), _p(P), st)
+        ha = _empty(b, 96, like=X) if save else None
+        hb = _empty(b, 96, like=X) if save else None
+        ya, yb = _empty(R, 1, like=X), _empty(R, g, like=X)
+        lib.mggan_dheads_fwd(_p(X), W, b, g, act, _p(wa[0]), _p(wa[1]), _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[1]),
+                             _p(wb[2]), _p(wb[3]), _p(ha), _p(hb), _p(ya), _p(yb), st)
+        # ---- blocks 1 .. K-1 ----
+        mask = torch.empty(-(-(R - b) // 16) * 64, dtype=torch.int64, device=X.device) if save else None
+        lib.mggan_d_rows_lean_fwd(_p(pred), T, b, R, b, g, act, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(P), c_pe,
+                                  _p(wa[0]), _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[2]), _p(wb[3]), _p(mask), _p(ya), _p(yb),
+                                  st)
+        if save:
+            ctx.cfg = (D, tb, K, b, T, pshape, g, act)
+            ctx.save_for_backward(X, x0, outs_pe[0], xy_last, dxdy_last, ha, ya, hb, mask, *soc_saved)
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        D, tb, K, b, T, pshape, g, act = ctx.cfg
+        sv = ctx.saved_tensors
+        X, x0, h_pe, xy_last, dxdy_last, ha, ya, hb, mask = sv[:9]
+        soc_saved = sv[9:]
+        R = K * b
+        st = _s()
+        pe, d0, r = D.pred_encoder, D.discs[0], D.gen_id_reconstructor
+        fc, Wat = D.social.feature_embedder.fc, D.social.attention.W
+        W, c_in, c_pe, c_sc = 192, 64, 96, 128
+        dya = torch.zeros(R, 1, dtype=F32, device=ya.device) if dya is None else dya.reshape(R, 1).contiguous()
+        dyb = torch.zeros(R, g, dtype=F32, device=ya.device) if dyb is None else dyb.reshape(R, g).contiguous()
+        dpred = _empty(T, R, 2, like=ya)
+        lib.mggan_d_rows_lean_bwd(_p(dya), _p(dyb), _p(ya), _p(mask), T, b, R, g, act, _p(pe[0].weight), _p(pe[2].weight),
+                                  c_pe, _p(d0[0].weight), _p(d0[2].weight), _p(r[0].weight), _p(r[2].weight), _p(dpred), st)
+        # block 0: heads -> social attention (dh added into the in_enc | pred_enc columns) -> pred_encoder
+        dX = _empty(b, W, like=ya)
+        lib.mggan_dheads_bwd_data(_p(dya), _p(dyb), _p(ya), _p(ha), _p(hb), b, g, act, _p(d0[0].weight), _p(d0[2].weight),
+                                  _p(r[0].weight), _p(r[2].weight), _p(dX), W, st)
+        sw = (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, Wat.weight, Wat.bias)
+        _social_bwd(soc_saved, xy_last, dxdy_last, 0, _p(X) + 4 * c_in, W, X, b, c_sc - c_in, tb, *sw, _p(dX), W,
+                    _p(dX) + 4 * c_in, W, 1, False, False, D.social, X)
+        spec_pe = ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0))
+        dx0 = _chain_bwd(alias_cols(dX, c_pe, c_sc), W, x0, 2 * T, b, (h_pe, alias_cols(X, c_pe, c_sc)), spec_pe,
+                         (pe[0].weight, pe[2].weight), (pe[0].bias, pe[2].bias), True, False, pe[0], ld_last=W)
+        lib.mggan_rows_to_steps_n(_p(dx0), 2 * T, T, b, R, _p(dpred), st)
+        return (None, None, dpred.view(pshape)) + (None,) * 6
 
 
 class DRowsHeadsFn(Function):

@@ -143,6 +143,9 @@ class MultiDiscriminatorTrajectory(FlatModule):
         the classifier input in place, HF.DRowsHeadsFn adds the scene block and runs the heads)."""
         anchor = self.discs[0][0].weight
         save = HF.want_grad(in_enc, scene, pred, pred2, anchor)
+        if pred2 is None and HF.d_rows_lean_ok(self, in_enc, scene, pred, K, soc_blocks, row0):
+            # frozen discriminator, K >= 2 sample blocks: block 0 through the generic kernels, the others in one launch
+            return HF.DRowsLeanFn.apply(in_enc, scene, pred, self, tb, K, xy_last, dxdy_last, save)
         lean = HF.dheads_lean_ok(self, in_enc, scene, K, soc_blocks, row0)
         X = HF.DRowsBodyFn.apply(in_enc, pred, pred2, anchor, self, tb, K, soc_blocks, xy_last, dxdy_last, xy_mod,
                                  scene.shape[1], save, lean)

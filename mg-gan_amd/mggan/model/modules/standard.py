@@ -174,9 +174,17 @@ class MultiGenerator(FlatModule):
             shape = (self.pred_len, K, g, b, 2)
             return GeneratorOutput(pr.view(shape), pa.view(shape)), net_chooser_out, sampled_gen_idxs
 
+        rows = None
         with torch.no_grad():  # `logits`: the PM-network output of the same trunk and weights, computed by an earlier call
-            net_chooser_out, sampled_gen_idxs = self.get_samples(enc_h, num_samples, logits=logits)
-        if sampled_gen_idxs.is_cuda and getattr(self.rng, "on_device", False):
+            if getattr(self.rng, "on_device", False) and hasattr(self.rng, "sample_rows") and enc_h.is_cuda:
+                net_chooser_out = logits if logits is not None else self._chooser(enc_h) if self.use_pinet else \
+                    self.net_prior.expand(enc_h.size(0), -1)
+                sampled_gen_idxs, rows = self.rng.sample_rows(net_chooser_out, num_samples)  # picks + row tables, one launch
+            else:
+                net_chooser_out, sampled_gen_idxs = self.get_samples(enc_h, num_samples, logits=logits)
+        if rows is not None:
+            pass
+        elif sampled_gen_idxs.is_cuda and getattr(self.rng, "on_device", False):
             rows = HF.device_rollout_rows(sampled_gen_idxs, g)  # no host round trip
         else:
             idx_host = sampled_gen_idxs.cpu()

@@ -63,6 +63,7 @@ class DeviceRNG:
             seed &= 0x7FFFFFFFFFFFFFFF
             self._state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
             self._ticket = torch.zeros(1, dtype=torch.int32, device=device)
+            self._bticket = torch.zeros(1, dtype=torch.int32, device=device)  # mggan_sample_bucket_rows (self-resetting)
 
     def _draw(self, sub_batches, b, Z, device, sets=None, n_unif=None, n_labels=None):
         from mggan.hip import functions as HF
@@ -153,6 +154,32 @@ class DeviceRNG:
         lib.mggan_sample_categorical(b, num_samples, g, lg.data_ptr(), u.data_ptr(), idx.data_ptr(),
                                      HF._s())
         return idx
+
+    def sample_rows(self, logits, num_samples):
+        """sample_generators + the rollout-row tables of the picks (HF.device_rollout_rows) behind one entry: one launch
+        instead of two up to 2,048 rows (the single-sample rollouts of the discriminator step).
+        -> (generator indexes (b, num_samples) int64, HF.RolloutRows)."""
+        from mggan.hip import functions as HF
+        from mggan.hip.lib import lib
+
+        lg = logits.detach().float().contiguous()
+        b, g = lg.shape
+        n = b * num_samples
+        self._ensure_state(lg.device)
+        if self._unif is not None and self._unif.device == lg.device and self._unif_used + n <= self._nu:
+            u = self._unif[self._unif_used:self._unif_used + n]
+            self._unif_used += n
+        else:
+            u = torch.empty(n, dtype=torch.float32, device=lg.device)
+            lib.mggan_draw_iteration(self._state.data_ptr(), self._ticket.data_ptr(), 0, 0, 0, 0, 0, 0, 0, n, u.data_ptr(),
+                                     HF._s())
+        idx = torch.empty(b, num_samples, dtype=torch.int64, device=lg.device)
+        rows, blk = HF.empty_rollout_rows(b, num_samples, g, lg.device)
+        lib.mggan_sample_bucket_rows(b, num_samples, g, lg.data_ptr(), u.data_ptr(), idx.data_ptr(), rows.row_gen.data_ptr(),
+                                     rows.row_ped.data_ptr(), rows.row_slot.data_ptr(), rows.row_pos.data_ptr(),
+                                     rows.inv.data_ptr(), rows.seg.data_ptr(), rows.row_gen_pos.data_ptr(), blk.data_ptr(),
+                                     self._bticket.data_ptr(), HF._s())
+        return idx, rows
 
 
 class ReplayRNG:

@@ -93,6 +93,35 @@ def test_device_categorical_sampler_is_the_inverse_cdf(b, K, g):
     assert got.min() >= 0 and got.max() <= g - 1
 
 
+@pytest.mark.parametrize("b,K,g", [(1280, 1, 4), (256, 20, 4), (1280, 20, 4), (8192, 20, 8), (37, 3, 16), (409, 20, 5),
+                                   (8192, 1, 8), (5, 3, 1)])
+def test_fused_sampling_and_bucketing_match_the_separate_launches(b, K, g):
+    """mggan_sample_bucket_rows (one launch up to 2,048 rows) against mggan_sample_categorical followed by
+    mggan_bucket_rows on the same logits and uniforms: identical picks and identical row tables."""
+    from mggan.hip import lib
+    from mggan.hip.functions import device_rollout_rows, empty_rollout_rows
+
+    gen = torch.Generator().manual_seed(3 * b + K + g)
+    ld = (torch.randn(b, g, generator=gen) * 2).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for rep in range(2):
+        ud = torch.rand(b, K, generator=gen).cuda()
+        idx = torch.empty(b, K, dtype=torch.int64, device="cuda")
+        lib.mggan_sample_categorical(b, K, g, ld.data_ptr(), ud.data_ptr(), idx.data_ptr(), st)
+        ref = device_rollout_rows(idx, g)
+        idx2 = torch.full((b, K), -1, dtype=torch.int64, device="cuda")
+        rows, blk = empty_rollout_rows(b, K, g, ld.device)
+        lib.mggan_sample_bucket_rows(b, K, g, ld.data_ptr(), ud.data_ptr(), idx2.data_ptr(), rows.row_gen.data_ptr(),
+                                     rows.row_ped.data_ptr(), rows.row_slot.data_ptr(), rows.row_pos.data_ptr(),
+                                     rows.inv.data_ptr(), rows.seg.data_ptr(), rows.row_gen_pos.data_ptr(), blk.data_ptr(),
+                                     ticket.data_ptr(), st)
+        assert torch.equal(idx, idx2), (b, K, g, rep)
+        for name in ("row_gen", "row_ped", "row_slot", "row_pos", "inv", "seg", "row_gen_pos"):
+            assert torch.equal(getattr(rows, name), getattr(ref, name)), (name, b, K, g, rep)
+        assert int(ticket) == 0
+
+
 def test_branch_streams_and_graph_replay_are_bit_identical():
     """No races, no order-dependent arithmetic: after several iterations the weights are bit-identical whether the
     step graph runs on one stream, on the branch streams, or as a replayed HIP graph (same seeds)."""

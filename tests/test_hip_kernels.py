@@ -408,8 +408,10 @@ def test_discriminator_lean_heads_match_the_full_width_pass(monkeypatch, g, size
     pred_d0 = (bt["gt_dxdy"][:, None] + 0.3 * torch.randn(12, K, b, 2, device=dev)).contiguous()
     cot_o, cot_b = torch.randn(b, K, device=dev), torch.randn(b, K, g, device=dev)
     res = []
-    for lean in ("1", "0"):
-        monkeypatch.setenv("MGGAN_DHEADS_LEAN", lean)
+    # the one-launch row pass (steps -> heads), the lean heads over the assembled pred_enc block, the full-width pass
+    for mode, (rows_lean, heads_lean) in enumerate((("1", "1"), ("0", "1"), ("0", "0"))):
+        monkeypatch.setenv("MGGAN_DROWS_LEAN", rows_lean)
+        monkeypatch.setenv("MGGAN_DHEADS_LEAN", heads_lean)
         pd = pred_d0.clone().requires_grad_()
         px = bt["in_xy"][-1][None, None] + torch.cumsum(pd, 0)
         calls = []
@@ -421,9 +423,12 @@ def test_discriminator_lean_heads_match_the_full_width_pass(monkeypatch, g, size
         finally:
             L.trace = None
         names = {c[0] for c in calls}
-        assert ("mggan_dheads_lean_fwd" in names) == (lean == "1") and ("mggan_dheads_lean_bwd" in names) == (lean == "1")
+        for entry, want in (("mggan_d_rows_lean_fwd", mode == 0), ("mggan_d_rows_lean_bwd", mode == 0),
+                            ("mggan_dheads_lean_fwd", mode == 1), ("mggan_dheads_lean_bwd", mode == 1)):
+            assert (entry in names) == want, (mode, entry)
         res.append((o.detach().clone(), br.detach().clone(), pd.grad.clone()))
-    torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-6)
-    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-5, atol=2e-6)
-    scale = float(res[1][2].abs().max())
-    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-4, atol=1e-5 * scale)
+    scale = float(res[2][2].abs().max())
+    for k in (0, 1):
+        torch.testing.assert_close(res[k][0], res[2][0], rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close(res[k][1], res[2][1], rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close(res[k][2], res[2][2], rtol=1e-4, atol=1e-5 * scale)
