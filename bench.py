@@ -93,10 +93,13 @@ def flops_of(name, a):
         return float(T) * b * 2 * (4 * H * H)
     if name == "mggan_decoder_rollout_fwd":
         R, T, H, EIN, Z = a[0], a[1], a[3], a[4], a[5]
-        return float(R) * (2 * (EIN + Z) * H + T * (2 * 2 * 16 + 2 * (16 + H) * 4 * H + 2 * (2 * H * (H // 2) + (H // 2) * 2)))
+        e2d = Z if a[31] else EIN + Z  # (Qe given: the enc_h part of h0 came once per pedestrian, mggan_decoder_e2d_shared)
+        return float(R) * (2 * e2d * H + T * (2 * 2 * 16 + 2 * (16 + H) * 4 * H + 2 * (2 * H * (H // 2) + (H // 2) * 2)))
+    if name == "mggan_decoder_e2d_shared":
+        return 2.0 * a[2] * a[3] * 32
     if name == "mggan_decoder_rollout_bwd_fused":  # BPTT data path + the fused per-generator weight gradients
         T, H, EIN, R = a[2], a[3], a[4], a[21]
-        data = T * 2 * (4 * H * H + 2 * 4 * H + H * (H // 2) + (H // 2) * 2) + 2 * (EIN * H + H * (H // 2))
+        data = T * 2 * (4 * H * H + 2 * 4 * H + H * (H // 2) + (H // 2) * 2) + 2 * ((EIN if a[24] else 0) * H + H * (H // 2))
         wgrads = T * 2 * (4 * H * (H + 3) + (H // 2) * H + 2 * (H // 2))
         return float(R) * (data + wgrads)
     if name == "mggan_conv1_pool":

@@ -124,7 +124,12 @@ int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const 
                               const float* enc_h, int ld_enc, const float* noise, const float* soc, int ld_soc,
                               const float* xy0, const float* dxdy0, const float* We2d, const float* be2d,
                               float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Din,
-                              float* Aact, float* E2Din, float* SocR, mggan_stream_t stream);
+                              float* Aact, float* E2Din, float* SocR, const float* Qe, float* Nz, mggan_stream_t stream);
+/* Qe (b, 32) = be2d + We2d[:, :EIN] enc_h (standard.py:247-252), the part of h0 the K rollout rows of a pedestrian share
+ * (W_e2d is one module for all generators): mggan_decoder_rollout_fwd then multiplies the noise columns only and keeps
+ * Nz (R, Z), the rows' noise vectors, instead of E2Din (R, EIN+Z).  We2d: (32, ldw) row-major, EIN a multiple of 16. */
+int mggan_decoder_e2d_shared(const float* enc_h, int ld_enc, int b, int EIN, const float* We2d, int ldw, const float* be2d,
+                             float* Q, mggan_stream_t stream);
 /* ---- social attention over in-scene ordered pairs ---------------------------------------
  * reference: social.py:67-104 (features), :33-48 (embedding MLP), :14-30 (attention pooling),
  *            discriminators.py:179-184 (D-side call; only sample block 0 carries features)
@@ -449,7 +454,9 @@ int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, cons
 /* Fused decoder backward: BPTT + in-kernel per-generator weight gradients (dW_hh and dW1[:, :H] on MFMA).
  * n_gens*NW persistent workgroups; workgroup (g, w) leaves one partial block of `wlen` floats at
  * wpart[(g*NW + w) * wlen] laid out as [W_hh | A | bias | W1h | b1 | W2 | b2] (offsets from
- * mggan_decoder_bwd_fused_layout); reduce them with mggan_grad_reduce_multi (groups = n_gens, splits = NW). */
+ * mggan_decoder_bwd_fused_layout); reduce them with mggan_grad_reduce_multi (groups = n_gens, splits = NW).
+ * dEnc (R, EIN) = dH0 We2d[:, :EIN], or NULL: the caller folds dH0 over the rows of a pedestrian and multiplies once
+ * per pedestrian (the adjoint of the Qe form of mggan_decoder_rollout_fwd). */
 int mggan_decoder_bwd_fused_layout(int* wlen, int* off_A, int* off_bias, int* off_W1, int* off_b1, int* off_W2,
                                    int* off_b2);
 int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, int Z, const int* seg, const int* row_pos,

@@ -495,6 +495,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // duplicate and ARE saved (finite values the backward kernel multiplies by zero).
 #define DEC_HLD 36  // LDS h tile row stride in floats (16-byte aligned rows, conflict-light)
 
+// Q^T [32 x 16 pedestrians] = W_e2d[:, :EIN] enc_h^T + b: one wave per 16-pedestrian tile, both unit tiles
+__global__ __launch_bounds__(256) void e2d_shared_kernel(const float* __restrict__ enc_h, int ld_enc, int b, int EIN,
+                                                         const float* __restrict__ We2d, int ldw,
+                                                         const float* __restrict__ be2d, float* __restrict__ Q) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  const int ped = (blockIdx.x * 4 + w) * 16 + fi;
+  if ((blockIdx.x * 4 + w) * 16 >= b) return;
+  const bool valid = ped < b;
+  const float* xr = enc_h + (size_t)(valid ? ped : b - 1) * ld_enc + 4 * fk;
+  const float* w0 = We2d + (size_t)fi * ldw + 4 * fk;
+  const float* w1 = We2d + (size_t)(16 + fi) * ldw + 4 * fk;
+  f32x4 a0 = *reinterpret_cast<const f32x4*>(be2d + 4 * fk), a1 = *reinterpret_cast<const f32x4*>(be2d + 16 + 4 * fk);
+  f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
+  for (int k = 0; k < EIN; k += 16) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(xr + k);
+    const f32x4 u = *reinterpret_cast<const f32x4*>(w0 + k), v = *reinterpret_cast<const f32x4*>(w1 + k);
+    a0 = MFMA16(u[0], x[0], a0); a1 = MFMA16(v[0], x[0], a1);
+    c0 = MFMA16(u[1], x[1], c0); c1 = MFMA16(v[1], x[1], c1);
+    a0 = MFMA16(u[2], x[2], a0); a1 = MFMA16(v[2], x[2], a1);
+    c0 = MFMA16(u[3], x[3], c0); c1 = MFMA16(v[3], x[3], c1);
+  }
+  if (valid) {  // D rows 4 fk + r = units, column fi = pedestrian
+    *reinterpret_cast<f32x4*>(Q + (size_t)ped * 32 + 4 * fk) = a0 + c0;
+    *reinterpret_cast<f32x4*>(Q + (size_t)ped * 32 + 16 + 4 * fk) = a1 + c1;
+  }
+}
+
 struct DecFwdArgs {
   int T, b, NW, Rout, EIN, Z, ld_enc, ld_soc;
   const int* seg;
@@ -504,6 +531,8 @@ struct DecFwdArgs {
   const float *enc_h, *noise, *soc, *xy0, *dxdy0, *We2d, *be2d;
   float *out_abs, *out_rel;
   float *Gt, *Cs, *Din, *Aact, *E2Din, *SocR;
+  const float* Qe;  // (b, H) = b_e2d + W_e2d[:, :EIN] enc_h per pedestrian, or NULL (then the kernel does that product per row)
+  float* Nz;        // with Qe: (R, Z) the rows' noise vectors, kept for the weight gradient instead of E2Din
 };
 
 // first tile slot of generator gi in the tile-blocked save buffers
@@ -546,12 +575,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       if (kq + 3 < p.EIN) x4 = *reinterpret_cast<const f32x4*>(p.enc_h + (size_t)ped * p.ld_enc + kq);
       else if (kq >= p.EIN && kin)
         x4 = *reinterpret_cast<const f32x4*>(p.noise + ((size_t)slot * p.b + ped) * p.Z + (kq - p.EIN));
-      if (sv0 && kin) *reinterpret_cast<f32x4*>(p.E2Din + (size_t)r * IN + kq) = x4;
+      if (sv0 && kin) {
+        if (p.Qe) *reinterpret_cast<f32x4*>(p.Nz + (size_t)r * p.Z + (kq - p.EIN)) = x4;
+        else *reinterpret_cast<f32x4*>(p.E2Din + (size_t)r * IN + kq) = x4;
+      }
       // A rows = this wave's units: W_e2d[8w + fi][kq .. kq+3] (row-major parameter, one 16-byte load)
       a4 = (kin && fi < 8) ? *reinterpret_cast<const f32x4*>(p.We2d + (size_t)(8 * w + fi) * IN + kq)
                            : f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    for (int kb0 = 0; kb0 * 16 < IN; kb0 += 3) {  // three blocks of loads in flight, then their 12 MFMAs
+    // The enc_h part of the product is the same for the K rows of a pedestrian (and for every generator: W_e2d is
+    // shared): with Qe it arrives as 32 floats per row and only the noise columns are multiplied here - 4 MFMAs per
+    // wave and tile instead of 36, no 512-byte enc_h gather per row, no (R, EIN) copy kept for the weight gradient.
+    if (p.Qe && fk < 2) hacc = *reinterpret_cast<const f32x4*>(p.Qe + (size_t)ped * H + 8 * w + 4 * fk);
+    for (int kb0 = p.Qe ? p.EIN / 16 : 0; kb0 * 16 < IN; kb0 += 3) {  // three blocks of loads in flight, then their 12 MFMAs
       f32x4 xs[3], as[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) e2d_block(kb0 + i, xs[i], as[i]);
@@ -597,7 +633,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     lds_barrier();  // the previous tile's last reads of hs[0] are done
     if (fk < 2) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hacc[q] += p.be2d[8 * w + 4 * fk + q];
+      for (int q = 0; q < 4; ++q) hacc[q] += p.Qe ? 0.f : p.be2d[8 * w + 4 * fk + q];  // (Qe carries the bias)
       *reinterpret_cast<f32x4*>(&hs[0][fi * DEC_HLD + 8 * w + 4 * fk]) = hacc;
       if (save) {
 #pragma unroll
@@ -792,7 +828,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // exposed load round trips per tile (10k of a tile's 75k cycles); they are staged once per workgroup instead.
   float* e2s = tailw;
   float* w1s = tailw + H * p.e2ld;
-  for (int i = threadIdx.x; i < H * p.EIN; i += 256) e2s[(i / p.EIN) * p.e2ld + i % p.EIN] = p.We2d[(size_t)(i / p.EIN) * IN + i % p.EIN];
+  // (dEnc == NULL: the caller sums dH0 over the rows of a pedestrian first and multiplies once per pedestrian)
+  if (p.dEnc)
+    for (int i = threadIdx.x; i < H * p.EIN; i += 256) e2s[(i / p.EIN) * p.e2ld + i % p.EIN] = p.We2d[(size_t)(i / p.EIN) * IN + i % p.EIN];
   for (int i = threadIdx.x; i < Hh * S; i += 256) w1s[(i / S) * 36 + i % S] = W1[(size_t)(i / S) * (H + S) + H + i % S];
   f32x4 accW[2][2], accU = f32x4{0.f, 0.f, 0.f, 0.f};
   // dA (4H x 2) and dbias (4H) = dPre^T [dxdy | 1]: lane-local sums over the lane's own (unit, gate) entries and its tile
@@ -960,8 +998,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int ks = 0; ks < 4; ++ks) ds = MFMA16(w1s[(4 * fk + ks) * 36 + 16 * w + fi], dq[ks], ds);
       if (valid) *reinterpret_cast<f32x4*>(p.dSocR + (size_t)r * S + 16 * w + 4 * fk) = ds;
     }
-    lds_barrier();
-    {  // dEnc^T [EIN x rows] = W_e2d[:, :EIN]^T dH0^T : wave w -> 16-column tiles w, w + 4, ...
+    if (p.dEnc) lds_barrier();
+    if (p.dEnc) {  // dEnc^T [EIN x rows] = W_e2d[:, :EIN]^T dH0^T : wave w -> 16-column tiles w, w + 4, ...
       const f32x4 ha = *reinterpret_cast<const f32x4*>(&h0t[fi * DB_HS + 8 * fk]);
       const f32x4 hb = *reinterpret_cast<const f32x4*>(&h0t[fi * DB_HS + 8 * fk + 4]);
       for (int ct = w; ct * 16 < p.EIN; ct += 4) {
@@ -1144,12 +1182,26 @@ int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, co
   return MGGAN_OK;
 }
 
+/* Q (b, 32) = be2d + We2d[:, :EIN] enc_h: the part of h0 = enc_h_to_dec_h([enc_h | noise]) (standard.py:247-252) that
+ * the K rollout rows of a pedestrian share (W_e2d is one module for all generators).  We2d: (32, ldw) row-major. */
+int mggan_decoder_e2d_shared(const float* enc_h, int ld_enc, int b, int EIN, const float* We2d, int ldw, const float* be2d,
+                             float* Q, hipStream_t stream) {
+  if (b == 0) return MGGAN_OK;
+  MG_CHECK_ARG(enc_h && We2d && be2d && Q, "decoder_e2d_shared: null pointer");
+  MG_CHECK_ARG(EIN > 0 && EIN % 16 == 0 && ld_enc % 4 == 0 && ldw % 4 == 0 && ldw >= EIN && (((size_t)enc_h) & 15) == 0 &&
+                   (((size_t)We2d) & 15) == 0 && (((size_t)Q) & 15) == 0,
+               "decoder_e2d_shared: bad layout (EIN %d, ld_enc %d, ldw %d)", EIN, ld_enc, ldw);
+  hipLaunchKernelGGL(e2d_shared_kernel, dim3(cdiv(cdiv(b, 16), 4)), dim3(256), 0, stream, enc_h, ld_enc, b, EIN, We2d, ldw, be2d, Q);
+  MG_LAUNCH_CHECK("decoder_e2d_shared");
+  return MGGAN_OK;
+}
+
 int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const float* prep, int prep_stride,
                               const int* seg, int n_gens, const int* row_ped, const int* row_slot, const int* row_pos,
                               const float* enc_h, int ld_enc, const float* noise, const float* soc, int ld_soc,
                               const float* xy0, const float* dxdy0, const float* We2d, const float* be2d,
                               float* out_abs, float* out_rel, int Rout, float* Gt, float* Cs, float* Din,
-                              float* Aact, float* E2Din, float* SocR, hipStream_t stream) {
+                              float* Aact, float* E2Din, float* SocR, const float* Qe, float* Nz, hipStream_t stream) {
   MG_CHECK_ARG(prep && seg && row_ped && row_slot && row_pos && enc_h && noise && soc && xy0 && dxdy0 && We2d && be2d &&
                    out_abs && out_rel,
                "decoder_rollout_fwd: null pointer");
@@ -1158,19 +1210,19 @@ int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const 
                "decoder_rollout_fwd: widths must be multiples of 4 (enc %d, noise %d)", EIN, Z);
   const bool s = Gt != nullptr;
   MG_CHECK_ARG(s == (Cs != nullptr) && s == (Din != nullptr) && s == (Aact != nullptr) &&
-                   s == (E2Din != nullptr) && s == (SocR != nullptr),
+                   s == ((Qe ? Nz : E2Din) != nullptr) && s == (SocR != nullptr),
                "decoder_rollout_fwd: save buffers must be all set or all NULL");
+  MG_CHECK_ARG(!Qe || EIN % 16 == 0, "decoder_rollout_fwd: the per-pedestrian part needs an encoder width that is a multiple of 16 (%d)", EIN);
   if (R == 0) return MGGAN_OK;
   DecFwdArgs p = {};
   p.T = T; p.b = b; p.Rout = Rout; p.EIN = EIN; p.Z = Z; p.ld_enc = ld_enc; p.ld_soc = ld_soc; p.seg = seg;
   p.prep = prep; p.prep_stride = prep_stride; p.row_ped = row_ped; p.row_slot = row_slot; p.row_pos = row_pos;
   p.enc_h = enc_h; p.noise = noise; p.soc = soc; p.xy0 = xy0; p.dxdy0 = dxdy0; p.We2d = We2d; p.be2d = be2d;
   p.out_abs = out_abs; p.out_rel = out_rel;
-  p.Gt = Gt; p.Cs = Cs; p.Din = Din; p.Aact = Aact; p.E2Din = E2Din; p.SocR = SocR;
+  p.Gt = Gt; p.Cs = Cs; p.Din = Din; p.Aact = Aact; p.E2Din = E2Din; p.SocR = SocR; p.Qe = Qe; p.Nz = Nz;
   // one workgroup per 16-row tile, NW workgroups per generator.  The split of R between the generators is drawn on
-  // the device (the PM network's categorical samples): sized for an even split, the generator that drew a few rows more
-  // than R / g sent some workgroups through a SECOND tile and doubled the launch (93 us instead of ~50 at 5,120 rows).
-  // Every generator gets room for all tiles; a workgroup without a tile leaves at once.
+  // the device (the PM network's categorical samples): below the cap every generator gets room for ALL tiles, so that
+  // an uneven draw does not send some workgroups through a second tile; a workgroup without a tile leaves at once.
   const int per_gen = cdiv(R, 16) + 1;
   p.NW = per_gen < 1 ? 1 : (per_gen > 2048 / n_gens ? (2048 / n_gens > 0 ? 2048 / n_gens : 1) : per_gen);
   hipLaunchKernelGGL(decoder_fwd_mfma_kernel, dim3(n_gens * p.NW), dim3(256), 0, stream, p);
@@ -1192,7 +1244,7 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
                                     const float* Aact, const float* gabs, const float* grel, int Rout, float* dH0,
                                     float* dQ, float* dEnc, float* dSocR, float* wpart, hipStream_t stream) {
   MG_CHECK_ARG(seg && row_pos && W_hh && W1 && W2 && We2d && prep && Gt && Cs && Din && Aact && dH0 && dQ &&
-                   dEnc && dSocR && wpart,
+                   dSocR && wpart,
                "decoder_rollout_bwd_fused: null pointer");
   MG_CHECK_ARG(H == 32 && NW > 0 && n_gens > 0, "decoder_rollout_bwd_fused: decoder_h_dim %d not built (32)", H);
   DecFusedArgs p = {};

@@ -1444,6 +1444,9 @@ def _fused_layout():
     return _FUSED_LAYOUT
 
 
+E2D_SHARED_MIN_ROWS = int(os.environ.get("MGGAN_E2D_SHARED_MIN_ROWS", "4096"))
+
+
 class DecoderRolloutFn(Function):
     """enc_h_to_dec_h + per-generator RelativeDecoder rollouts for the selected rows
     (standard.py:227-265, common_modules.py:97-131)."""
@@ -1470,23 +1473,42 @@ class DecoderRolloutFn(Function):
         # tile-blocked saves (16-row tiles, every generator's last tile padded): gates, (c, h) with slot 0 = (0, h_0), ...
         tiles = -(-R // 16) + n_gens
         Gt, Cs = mk(tiles, T, H, 16, 4), mk(tiles, T + 1, H, 16, 2)
-        Din, Aact, E2Din, SocR = mk(tiles, T, 16, 2), mk(tiles, T, 4, 16, 4), mk(R, EIN + Z), mk(R, S)
+        # h0 = W_e2d [enc_h | noise] + b: the enc_h part is the pedestrian's, the same for its K rows and for every
+        # generator -> once per pedestrian (Qe), the rows multiply their noise columns only and keep those (Nz)
+        # (worth its extra launch from a few rows per pedestrian and a few thousand rows on)
+        shared = (R >= 4 * b and R >= E2D_SHARED_MIN_ROWS and EIN % 16 == 0 and Z > 0 and e2d_w.shape[0] == 32
+                  and enc_h.data_ptr() % 16 == 0 and ld_enc % 4 == 0)
+        Qe = Nz = E2Din = None
+        if shared:
+            Qe = _empty(b, H, like=enc_h)
+            lib.mggan_decoder_e2d_shared(_p(enc_h), ld_enc, b, EIN, _p(e2d_w), EIN + Z, _p(e2d_b), _p(Qe), st)
+            Nz = mk(R, Z)
+        else:
+            E2Din = mk(R, EIN + Z)
+        Din, Aact, SocR = mk(tiles, T, 16, 2), mk(tiles, T, 4, 16, 4), mk(R, S)
         out_abs, out_rel = _empty(T, R, 2, like=enc_h), _empty(T, R, 2, like=enc_h)
         lib.mggan_decoder_rollout_fwd(R, T, b, H, EIN, Z, _p(prep), psz, _p(rows.seg), n_gens, _p(rows.row_ped),
                                       _p(rows.row_slot), _p(rows.row_pos), _p(enc_h), ld_enc, _p(noise) or _p(enc_h), _p(soc), ld_soc,
                                       _p(xy0), _p(dxdy0), _p(e2d_w), _p(e2d_b), _p(out_abs), _p(out_rel), R, _p(Gt),
-                                      _p(Cs), _p(Din), _p(Aact), _p(E2Din), _p(SocR), st)
+                                      _p(Cs), _p(Din), _p(Aact), _p(E2Din), _p(SocR), _p(Qe), _p(Nz), st)
         if save:
+            ctx.shared, ctx.ld_enc = shared, ld_enc
             ctx.meta = (rows, g0, n_gens, stride, T, owner, (b, EIN, Z, H, E, S, psz))
             # `soc` is the last column block of `enc_h` itself (TrunkJoinFn hands out both): its gradient is folded into
             # d enc_h by the gather below instead of travelling as a second tensor that autograd would have to add
             ctx.soc_in_enc = (b > 0 and soc.data_ptr() == enc_h.data_ptr() + 4 * (EIN - S) and ld_soc == ld_enc)
-            ctx.save_for_backward(e2d_w, e2d_b, prep, Gt, Cs, Din, Aact, E2Din, SocR)
+            if shared:
+                ctx.save_for_backward(e2d_w, e2d_b, prep, Gt, Cs, Din, Aact, Nz, SocR, enc_h)
+            else:
+                ctx.save_for_backward(e2d_w, e2d_b, prep, Gt, Cs, Din, Aact, E2Din, SocR)
         return out_abs, out_rel
 
     @staticmethod
     def backward(ctx, gabs, grel):
-        e2d_w, e2d_b, prep, Gt, Cs, Din, Aact, E2Din, SocR = ctx.saved_tensors
+        if ctx.shared:
+            e2d_w, e2d_b, prep, Gt, Cs, Din, Aact, Nz, SocR, enc_h = ctx.saved_tensors
+        else:
+            e2d_w, e2d_b, prep, Gt, Cs, Din, Aact, E2Din, SocR = ctx.saved_tensors
         rows, g0, n_gens, stride, T, owner, (b, EIN, Z, H, E, S, psz) = ctx.meta
         root = root_of(owner)
         R, Hh = rows.R, H // 2
@@ -1495,12 +1517,12 @@ class DecoderRolloutFn(Function):
         gabs = None if gabs is None else gabs.contiguous()
         grel = None if grel is None else grel.contiguous()
         mk = lambda *s: _empty(*s, like=prep)
-        dH0, dQ, dEnc, dSocR = mk(R, H), mk(R, Hh), mk(R, EIN), mk(R, S)
+        dH0, dQ, dEnc, dSocR = mk(R, H), mk(R, Hh), None if ctx.shared else mk(R, EIN), mk(R, S)
         # persistent workgroups per generator; each leaves one partial block of weight gradients
         # (16-row tiles; about two resident workgroups per CU, each looping over its generator's tiles).  The split of
         # the rows between the generators is a device-side draw: below the cap every generator gets room for ALL tiles
-        # (sized for an even split, the generator with a few rows more sent workgroups through a second tile:
-        # 140 us instead of ~75 at 5,120 rows); a workgroup without a tile writes a zero block and leaves
+        # (an uneven draw then does not send workgroups through a second tile); a workgroup without a tile writes a
+        # zero block and leaves
         NW = max(1, min(-(-R // 16) + 1, 512 // n_gens))
         lay = _fused_layout()
         wpart = mk(n_gens * NW, lay["wlen"])
@@ -1544,14 +1566,29 @@ class DecoderRolloutFn(Function):
                                                   for off, dst, M, N, ld in parts])
                 lib.mggan_grad_reduce_multi(ctypes.addressof(arr), len(parts), st)
             wgrad(dQ, Hh, SocR, S, ptr["w1"] + 4 * H, H + S, 0, R, S, Hh, rows.seg, 1, ng, stride, stride)
+        dQe = None
+        if ctx.shared and (e2d_w.requires_grad or ctx.needs_input_grad[0]):
+            # adjoint of the per-pedestrian part of h0: dH0 folded over the K rows of a pedestrian, then ONE product
+            # (weight gradient over b rows instead of R, d enc_h over b rows instead of R)
+            dQe = mk(b, H)
+            lib.mggan_gather_sum(_p(dH0), H, _p(rows.inv), _p(dQe), H, b, rows.K, H, 0, st)
         if e2d_w.requires_grad:
             pw, pb = root.grad_ptr(e2d_w), root.grad_ptr(e2d_b)
-            with side_stream(dH0, E2Din):
-                wgrad(dH0, H, E2Din, EIN + Z, pw, EIN + Z, pb, R, EIN + Z, H)
+            if ctx.shared:
+                with side_stream(dQe, enc_h, dH0, Nz):
+                    wgrad(dQe, H, enc_h, ctx.ld_enc, pw, EIN + Z, pb, b, EIN, H)
+                    wgrad(dH0, H, Nz, Z, pw + 4 * EIN, EIN + Z, 0, R, Z, H)
+            else:
+                with side_stream(dH0, E2Din):
+                    wgrad(dH0, H, E2Din, EIN + Z, pw, EIN + Z, pb, R, EIN + Z, H)
         d_enc = d_soc = None
         if ctx.needs_input_grad[0]:
             d_enc = mk(b, EIN)
-            lib.mggan_gather_sum(_p(dEnc), EIN, _p(rows.inv), _p(d_enc), EIN, b, rows.K, EIN, 0, st)
+            if ctx.shared:
+                lib.mggan_linear_bwd_data(_p(dQe), H, _p(e2d_w), EIN + Z, _p(d_enc), EIN, b, EIN, H, 0, 0, 0, ACT_NONE, 0.0,
+                                          st)
+            else:
+                lib.mggan_gather_sum(_p(dEnc), EIN, _p(rows.inv), _p(d_enc), EIN, b, rows.K, EIN, 0, st)
         if ctx.needs_input_grad[1]:
             if ctx.soc_in_enc and d_enc is not None:
                 lib.mggan_gather_sum(_p(dSocR), S, _p(rows.inv), d_enc.data_ptr() + 4 * (EIN - S), EIN, b, rows.K, S, 1, st)

@@ -432,3 +432,54 @@ def test_discriminator_lean_heads_match_the_full_width_pass(monkeypatch, g, size
         torch.testing.assert_close(res[k][0], res[2][0], rtol=2e-5, atol=2e-6)
         torch.testing.assert_close(res[k][1], res[2][1], rtol=2e-5, atol=2e-6)
         torch.testing.assert_close(res[k][2], res[2][2], rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_decoder_h0_shared_part_matches_the_per_row_product(monkeypatch):
+    """h0 = W_e2d [enc_h | noise] + b with the enc_h part computed once per pedestrian (mggan_decoder_e2d_shared + the
+    noise columns per row; backward: dH0 folded over a pedestrian's rows, one product per pedestrian) against the
+    per-row product: rollouts and every generator gradient (W_e2d / b_e2d included)."""
+    from mggan.data_utils.synthetic import make_batch
+    from mggan.hip import functions as HF
+    from mggan.hip.lib import load
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.rng import ReplayRNG
+
+    dev = _dev()
+    g, K, sizes = 3, 6, [5, 1, 9, 17, 3, 32, 2]
+    bt = make_batch(sizes, seed=9, device=dev)
+    b = bt["in_xy"].shape[1]
+    gen = torch.Generator().manual_seed(77)
+    idx = torch.randint(0, g, (b, K), generator=gen)
+    noise = torch.randn(K, len(sizes), 8, generator=gen).repeat_interleave(torch.tensor(sizes), dim=1).to(dev)
+    cot = torch.randn(12, K, b, 2, generator=gen).to(dev)
+    res = []
+    for min_rows in (0, 1 << 30):
+        monkeypatch.setattr(HF, "E2D_SHARED_MIN_ROWS", min_rows)
+        torch.manual_seed(5)
+        G, _ = construct_model(get_parser().parse_args(["--num_gens", str(g)]))
+        G = G.to(dev).flatten_parameters_()
+        G.train()
+        G.rng = ReplayRNG(gen_idxs=[idx])
+        calls = []
+        L = load()
+        L.trace = calls
+        try:
+            go, _, _ = G(bt["in_xy"], bt["in_dxdy"], bt["seq_start_end"], noise=noise, all_gen_out=False, img=bt["features"],
+                         num_samples=K)
+            ((go.abs * cot).sum() + (go.rel * cot.flip(0)).sum()).backward()
+            HF.join_side_stream()
+            torch.cuda.synchronize()
+        finally:
+            L.trace = None
+        assert ("mggan_decoder_e2d_shared" in {c[0] for c in calls}) == (min_rows == 0)
+        res.append((go.abs.detach().clone(), go.rel.detach().clone(),
+                    {n: q.grad.detach().clone() for n, q in G.named_parameters() if q.grad is not None}))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-5, atol=2e-6)
+    assert res[0][2].keys() == res[1][2].keys() and any("enc_h_to_dec_h" in n for n in res[0][2])
+    gmax = max(float(v.abs().max()) for v in res[1][2].values())
+    for n, ref in res[1][2].items():
+        # (the bias of a convolution in front of a BatchNorm has a zero gradient: rounding noise of ~1e-8 on both sides)
+        scale = max(float(ref.abs().max()), 1e-3 * gmax)
+        torch.testing.assert_close(res[0][2][n], ref, rtol=2e-4, atol=2e-5 * scale, msg=lambda m, n=n: n + ": " + m)
