@@ -223,38 +223,58 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __r
     __syncthreads();
     if (b + (int)gridDim.x < B) fetch_image(img + (size_t)(b + gridDim.x) * 4 * IPIX, pre);  // in flight under the products
     float sum = 0.f, sq = 0.f;
+    // Wave w owns the pooled rows py = w, w + 4, w + 8, w + 12; a row is four tiles (px0 = 0, 4, 8, 12), two at a time
+    // through the matrix pipe.  A lane then holds window px0 + fk of each tile: a 4 x 4 transposition between the tile
+    // index and the lane group (four permlane swaps per value) turns that into px = 4 fk .. 4 fk + 3, i.e. ONE 16-byte
+    // store of the selected values and one 4-byte store of the four position codes per lane and row, instead of four
+    // 4-byte and four 1-byte stores scattered over 16 channel planes (the stores were 35 of 159 us at 8,192 images).
 #pragma unroll 1
-    for (int t = w; t < 64; t += 8) {  // two independent tiles per pass keep the matrix pipe fed
-      const int t1 = t + 4;
-      const int py0 = t >> 2, px0 = (t & 3) * 4, py1 = t1 >> 2, px1 = (t1 & 3) * 4;
-      const float* p0 = imgp + 2 * py0 * ILD + 2 * px0 + aoff;
-      const float* p1 = imgp + 2 * py1 * ILD + 2 * px1 + aoff;
-      f32x4 a0 = {bv, bv, bv, bv}, a1 = {bv, bv, bv, bv};
-      float x0[9], x1[9];
+    for (int py = w; py < 16; py += 4) {
+      float sel[4];
+      unsigned cod[4];
 #pragma unroll
-      for (int s = 0; s < 9; ++s) {
-        x0[s] = p0[(s / 3) * ILD + s % 3];
-        x1[s] = p1[(s / 3) * ILD + s % 3];
-      }
+      for (int half = 0; half < 2; ++half) {
+        const int px0 = 8 * half, px1 = 8 * half + 4;
+        const float* p0 = imgp + 2 * py * ILD + 2 * px0 + aoff;
+        const float* p1 = imgp + 2 * py * ILD + 2 * px1 + aoff;
+        f32x4 a0 = {bv, bv, bv, bv}, a1 = {bv, bv, bv, bv};
+        float x0[9], x1[9];
 #pragma unroll
-      for (int s = 0; s < 9; ++s) {
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[s], bw[s], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[s], bw[s], a1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const f32x4 acc = h ? a1 : a0;
-        const int py = h ? py1 : py0, px = (h ? px1 : px0) + fk;
-        const float s0 = sgn * acc[0], s1 = sgn * acc[1], s2 = sgn * acc[2], s3 = sgn * acc[3];
-        const float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
-        const int cx = s0 == mx ? 0 : (s1 == mx ? 1 : (s2 == mx ? 2 : 3));  // the first position that attains it
-        sum += (acc[0] + acc[1]) + (acc[2] + acc[3]);
-        sq = fmaf(acc[0], acc[0], fmaf(acc[1], acc[1], fmaf(acc[2], acc[2], fmaf(acc[3], acc[3], sq))));
-        if (fi < C) {
-          const size_t o = (((size_t)b * C + fi) * 16 + py) * 16 + px;
-          xsel[o] = sgn * mx;
-          code[o] = (unsigned char)cx;
+        for (int s = 0; s < 9; ++s) {
+          x0[s] = p0[(s / 3) * ILD + s % 3];
+          x1[s] = p1[(s / 3) * ILD + s % 3];
         }
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[s], bw[s], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[s], bw[s], a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 acc = h ? a1 : a0;
+          const float s0 = sgn * acc[0], s1 = sgn * acc[1], s2 = sgn * acc[2], s3 = sgn * acc[3];
+          const float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+          const int cx = s0 == mx ? 0 : (s1 == mx ? 1 : (s2 == mx ? 2 : 3));  // the first position that attains it
+          sum += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+          sq = fmaf(acc[0], acc[0], fmaf(acc[1], acc[1], fmaf(acc[2], acc[2], fmaf(acc[3], acc[3], sq))));
+          sel[2 * half + h] = sgn * mx;
+          cod[2 * half + h] = (unsigned)cx;
+        }
+      }
+      // tile j, lane group fk  ->  lane group j, element fk
+      const mg_u2 sa = __builtin_amdgcn_permlane16_swap(__float_as_uint(sel[0]), __float_as_uint(sel[1]), false, false);
+      const mg_u2 sb = __builtin_amdgcn_permlane16_swap(__float_as_uint(sel[2]), __float_as_uint(sel[3]), false, false);
+      const mg_u2 s02 = __builtin_amdgcn_permlane32_swap(sa[0], sb[0], false, false);
+      const mg_u2 s13 = __builtin_amdgcn_permlane32_swap(sa[1], sb[1], false, false);
+      const mg_u2 ca = __builtin_amdgcn_permlane16_swap(cod[0], cod[1], false, false);
+      const mg_u2 cb = __builtin_amdgcn_permlane16_swap(cod[2], cod[3], false, false);
+      const mg_u2 c02 = __builtin_amdgcn_permlane32_swap(ca[0], cb[0], false, false);
+      const mg_u2 c13 = __builtin_amdgcn_permlane32_swap(ca[1], cb[1], false, false);
+      if (fi < C) {
+        const size_t o = (((size_t)b * C + fi) * 16 + py) * 16 + 4 * fk;
+        *reinterpret_cast<f32x4*>(xsel + o) = f32x4{__uint_as_float(s02[0]), __uint_as_float(s13[0]), __uint_as_float(s02[1]),
+                                                    __uint_as_float(s13[1])};
+        *reinterpret_cast<unsigned*>(code + o) = c02[0] | (c13[0] << 8) | (c02[1] << 16) | (c13[1] << 24);
       }
     }
     // border row 32 / column 32 (never pooled): 65 positions, statistics only
@@ -574,7 +594,7 @@ __global__ __launch_bounds__(256) void image_gram_kernel(int B, const float* __r
       a[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2], v[2], a[5], 0, 0, 0);
     };
     // rows (y0, y0+1) x columns (x, x+16): wave w takes x = 4*j + w of every row pair
-#pragma unroll 1
+#pragma unroll 4  // (one row pair per trip left the matrix pipe waiting for its LDS reads: 271 -> 227 us at 8,192 images)
     for (int yp = 0; yp < 17; ++yp) {
       const bool valid = 2 * yp + (fk >> 1) < IH;
       const int rowpos = 2 * yp * GLD + slot_main + w;
@@ -690,7 +710,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int B, const float* __
     f32x4 a[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+    // (unrolled deep: the operands of a k step are three LDS reads behind a byte compare; with two steps per trip the
+    // matrix pipe waited for them -- 181 -> 149 us at 8,192 images with C = 16, 172 -> 140 with C = 8)
+#pragma unroll 16
     for (int ks = 0; ks < 64; ++ks) {
       const int py0 = 2 * (ks >> 3), p = ks & 7;
       const int cell = py0 * 16 + p + cell_lane;

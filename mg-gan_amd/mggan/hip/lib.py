@@ -5,7 +5,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmggan_hip.so")
+# (MGGAN_HIP_LIB: another build of the same library, for A/B measurements of a kernel variant on one box)
+LIB_PATH = os.environ.get("MGGAN_HIP_LIB") or os.path.join(_HERE, "libmggan_hip.so")
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "..", "include", "mggan_hip.h"))
 
 
