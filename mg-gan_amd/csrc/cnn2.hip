@@ -405,8 +405,10 @@ __global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __r
 // owns image rows 4 w .. 4 w + 3 as four independent accumulator chains; the D fragment (x = 4 k + r, co) goes out as
 // one 16-byte store per row.  C = 8 fills half of the N tile.  (The register-tiled VALU kernel above needs one scalar
 // weight load per four FMAs and ran at 0.38 of the f32 rate at 8,192 images; it stays selectable: MGGAN_CONV2_VALU=1.)
+// (three waves per SIMD: at 172 registers two of the three workgroups a CU is dealt were resident -- 133 -> 102 us at
+// 8,192 images with C = 16, six spilled registers included)
 template <int C>
-__global__ __launch_bounds__(256) void conv2_fwd_mfma_kernel(int B, const float* __restrict__ xsel,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv2_fwd_mfma_kernel(int B, const float* __restrict__ xsel,
                                                              const float* __restrict__ scale1,
                                                              const float* __restrict__ shift1, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ y2,
