@@ -457,8 +457,9 @@ __device__ __forceinline__ void wgrad_stream_slab(const StreamProb& q, const int
 }
 
 // one kernel per operand layout: each keeps its own register budget (the row-major form needs more address registers)
+// (three waves per SIMD: the row-major form compiled to 176 registers, two waves -- 59 -> 50 us per launch at 256 x 32)
 template <int MODE>
-__global__ __launch_bounds__(256) void wgrad_stream_kernel(StreamBatch bt) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_stream_kernel(StreamBatch bt) {
   __shared__ __attribute__((aligned(16))) float red[2 * 4 * 64 * 4];
   int di = 0;
 #pragma unroll 1
