@@ -1750,6 +1750,7 @@ class DRowsBodyFn(Function):
 
 # from this many rows on, both discriminator heads run as one weight-stationary launch (csrc/dheads.hip)
 DHEADS_MIN_ROWS = int(os.environ.get("MGGAN_DHEADS_MIN_ROWS", "8192"))
+DHEADS_PAIR_MIN_ROWS = int(os.environ.get("MGGAN_DHEADS_PAIR_MIN_ROWS", "2048"))
 
 
 def dheads_lean_ok(D, in_enc, scene, K, soc_blocks, row0):
@@ -1912,8 +1913,10 @@ class DRowsHeadsFn(Function):
         outs_b, Wb = [None, None], None
         r = D.gen_id_reconstructor if mgan else None
         # many rows, both heads over all of them (the generator step's K*b rows): ONE weight-stationary launch
-        big = (mgan and row0 == 0 and R >= DHEADS_MIN_ROWS and W == 192 and tuple(Wa[0].shape) == (96, 192)
-               and tuple(r[0].weight.shape) == (96, 192) and r[2].weight.shape[0] <= 15)
+        # (row0 > 0 -- the real / fake pair pass of the discriminator step: the id head's rows [0, row0) are computed and
+        #  dropped; one launch instead of two chain launches from a couple of thousand rows on)
+        big = (mgan and R >= (DHEADS_MIN_ROWS if row0 == 0 else DHEADS_PAIR_MIN_ROWS) and W == 192
+               and tuple(Wa[0].shape) == (96, 192) and tuple(r[0].weight.shape) == (96, 192) and r[2].weight.shape[0] <= 15)
         if big:
             g = r[2].weight.shape[0]
             Wb, bb = (r[0].weight, r[2].weight), (r[0].bias, r[2].bias)
@@ -1922,7 +1925,8 @@ class DRowsHeadsFn(Function):
             ya, yb = _empty(R, 1, like=X), _empty(R, g, like=X)
             lib.mggan_dheads_fwd(_p(X), W, R, g, D._out_act(), _p(Wa[0]), _p(ba[0]), _p(Wa[1]), _p(ba[1]), _p(Wb[0]),
                                  _p(bb[0]), _p(Wb[1]), _p(bb[1]), _p(ha), _p(hb), _p(ya), _p(yb), st)
-            outs_a, outs_b = [ha, ya], [hb, yb]
+            outs_a, outs_b = [ha, ya], [hb if hb is None or not row0 else hb[row0:], yb if not row0 else yb[row0:]]
+            big = row0 == 0  # (the frozen-heads adjoint below is written for both heads over all rows)
         else:
             outs_a = _chain_fwd(X, W, R, spec_a, Wa, ba, save)
             if mgan:
