@@ -277,6 +277,12 @@ int mggan_dheads_fwd(const float* X, int ldx, int rows, int g, int act_a, const 
 int mggan_dheads_bwd_data(const float* dYa, const float* dYb, const float* Ya, const float* Ha, const float* Hb, int rows,
                           int g, int act_a, const float* W1a, const float* W2a, const float* W1b, const float* W2b,
                           float* dX, int ld_dx, mggan_stream_t stream);
+/* the same adjoint for TRAINABLE heads over a real/fake pair pass (discriminator step): head B covers rows
+ * [row0_b, rows) only (Hb and dYb start at that row); besides dX it leaves dH (rows,192) = the first layers' gate
+ * gradients [head A | head B] and dza (rows) = dYa * act'(Ya): the operands of the four weight-gradient products */
+int mggan_dheads_bwd_train(const float* dYa, const float* dYb, const float* Ya, const float* Ha, const float* Hb, int rows,
+                           int row0_b, int g, int act_a, const float* W1a, const float* W2a, const float* W1b,
+                           const float* W2b, float* dX, int ld_dx, float* dH, float* dza, mggan_stream_t stream);
 
 /* Lean form of the same heads for the sample blocks k >= 1 of a K-sample pass with a frozen discriminator (the generator
  * step; discriminators.py:179-219): in_enc and scene are shared by a pedestrian's K rows and the social block is zero

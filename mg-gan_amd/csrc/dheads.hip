@@ -35,6 +35,11 @@ struct DHeadsArgs {
   const float *dYa, *dYb;  // backward: gradients of the outputs
   float* dX;           // backward: (rows, ld_dx)
   int ld_dx;
+  // backward with trainable heads (the discriminator step's pair pass): head B exists for rows >= row0_b only (Hb / dYb
+  // are indexed from there), and the gate gradients the weight-gradient GEMMs need are written out
+  int row0_b;
+  float* dH_out;       // (rows, 192) = [dZ1 of head A | dZ1 of head B], or NULL
+  float* dza_out;      // (rows) = dYa * act'(Ya), or NULL
 };
 
 // 16 x 192 tile: global rows [r0, r0+16) -> 12 registers per thread -> LDS
@@ -179,8 +184,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int q = threadIdx.x + 256 * u, r = q / 48, k = (q - r * 48) * 4;
-      const float* H = k < DH_HID ? a.Ha + k : a.Hb + (k - DH_HID);
-      hpre[u] = r0 + r < a.rows ? *reinterpret_cast<const f32x4*>(H + (size_t)(r0 + r) * DH_HID) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool isb = k >= DH_HID;
+      const float* H = isb ? a.Hb + (k - DH_HID) : a.Ha + k;
+      const int hr = r0 + r - (isb ? a.row0_b : 0);
+      hpre[u] = (r0 + r < a.rows && hr >= 0) ? *reinterpret_cast<const f32x4*>(H + (size_t)hr * DH_HID) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   if ((int)blockIdx.x < ntiles) fetch_h(blockIdx.x * 16);
@@ -197,17 +204,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (gr < a.rows) {
         if (k < DH_HID) {
           const float dza = a.dYa[gr] * mg_act_grad_from_out(a.Ya[gr], a.act_a, 0.f);
+          if (a.dza_out && k == 0) a.dza_out[gr] = dza;
 #pragma unroll
           for (int i = 0; i < 4; ++i) d[i] = dza * w2s[k + i];
-        } else {
+        } else if (gr >= a.row0_b) {
           for (int o = 0; o < g; ++o) {
-            const float dy = a.dYb[(size_t)gr * g + o];
+            const float dy = a.dYb[(size_t)(gr - a.row0_b) * g + o];
 #pragma unroll
             for (int i = 0; i < 4; ++i) d[i] = fmaf(dy, w2s[DH_HID + o * DH_HID + (k - DH_HID) + i], d[i]);
           }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) d[i] *= hpre[u][i] > 0.f ? 1.f : 0.2f;
+        if (a.dH_out) *reinterpret_cast<f32x4*>(a.dH_out + (size_t)gr * DH_IN + k) = d;
       }
       *reinterpret_cast<f32x4*>(&tl[r * DH_LDX + k]) = d;
     }
@@ -770,6 +779,28 @@ static int dlean_grid(int rows) {
   const int nw = (rows + 15) / 16;     // one wave per 16-row tile
   const int wg = (nw + 3) / 4;
   return wg < 512 ? wg : 512;
+}
+
+/* mggan_dheads_bwd_data for TRAINABLE heads over a pair pass: head B covers rows [row0_b, rows) only (Hb, dYb start
+ * there); besides dX the launch leaves dH (rows,192) = the first layers' gate gradients [head A | head B] and dza (rows) =
+ * dYa * act'(Ya), the operands of the four weight-gradient products (mggan_wgrad*) */
+int mggan_dheads_bwd_train(const float* dYa, const float* dYb, const float* Ya, const float* Ha, const float* Hb, int rows,
+                           int row0_b, int g, int act_a, const float* W1a, const float* W2a, const float* W1b,
+                           const float* W2b, float* dX, int ld_dx, float* dH, float* dza, hipStream_t stream) {
+  DHeadsArgs a = {};
+  a.rows = rows; a.g = g; a.act_a = act_a; a.row0_b = row0_b;
+  a.W1a = W1a; a.W2a = W2a; a.W1b = W1b; a.W2b = W2b;
+  a.b1a = a.b2a = a.b1b = a.b2b = W1a;  // unused by the backward kernel
+  a.Ha = const_cast<float*>(Ha); a.Hb = const_cast<float*>(Hb); a.Ya = const_cast<float*>(Ya);
+  a.dYa = dYa; a.dYb = dYb; a.dX = dX; a.ld_dx = ld_dx; a.dH_out = dH; a.dza_out = dza;
+  if (int rc = dheads_check(a, "dheads_bwd_train")) return rc;
+  if (rows == 0) return MGGAN_OK;
+  MG_CHECK_ARG(dYa && dYb && Ya && Ha && Hb && dX && dH && dza && ld_dx >= DH_IN && row0_b >= 0 && row0_b <= rows &&
+                   (((size_t)dH) & 15) == 0,
+               "dheads_bwd_train: bad arguments");
+  hipLaunchKernelGGL(dheads_bwd_kernel, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
+  MG_LAUNCH_CHECK("dheads_bwd_train");
+  return MGGAN_OK;
 }
 
 /* P (b,192) = [b1a ; b1b] + W1cat[:, c_in .. c_in+31] X[:, c_in ..] + W1cat[:, c_sc .. c_sc+63] X[:, c_sc ..] over the block-0

@@ -1926,7 +1926,7 @@ class DRowsHeadsFn(Function):
             lib.mggan_dheads_fwd(_p(X), W, R, g, D._out_act(), _p(Wa[0]), _p(ba[0]), _p(Wa[1]), _p(ba[1]), _p(Wb[0]),
                                  _p(bb[0]), _p(Wb[1]), _p(bb[1]), _p(ha), _p(hb), _p(ya), _p(yb), st)
             outs_a, outs_b = [ha, ya], [hb if hb is None or not row0 else hb[row0:], yb if not row0 else yb[row0:]]
-            big = row0 == 0  # (the frozen-heads adjoint below is written for both heads over all rows)
+            big = True if row0 == 0 else "pair"
         else:
             outs_a = _chain_fwd(X, W, R, spec_a, Wa, ba, save)
             if mgan:
@@ -1959,7 +1959,27 @@ class DRowsHeadsFn(Function):
             return (dX if ctx.needs_input_grad[0] else None,) + (None,) * 7
         X, ha, ya, hb, yb = ctx.saved_tensors
         dX = _empty(R, W, like=X)
-        if big and not train_a and not train_b:  # frozen discriminator (generator step): input gradient only, one launch
+        if big and train_a and train_b and dya is not None and dyb is not None:
+            # trainable heads (the discriminator step's pair pass): one launch for the input gradient of both heads; it
+            # leaves the gate gradients of the first layers and of head A's output, the operands of the four
+            # weight-gradient products (two chain launches otherwise)
+            r = D.gen_id_reconstructor
+            g = r[2].weight.shape[0]
+            dya = dya.reshape(R, 1).contiguous()
+            dyb = dyb.reshape(R - row0, g).contiguous()
+            dH, dza = _empty(R, 192, like=X), _empty(R, 1, like=X)
+            lib.mggan_dheads_bwd_train(_p(dya), _p(dyb), _p(ya), _p(ha), _p(hb), R, row0, g, D._out_act(), _p(d0[0].weight),
+                                       _p(d0[2].weight), _p(r[0].weight), _p(r[2].weight), _p(dX), W, _p(dH), _p(dza), st)
+            root = root_of(d0[0])
+            gp = root.grad_ptr
+            with side_stream(dH, dza, dyb, X, ha, hb):
+                wgrad(dH, 192, X, W, gp(d0[0].weight), 192, gp(d0[0].bias), R, 192, 96)
+                wgrad(dza, 1, ha, 96, gp(d0[2].weight), 96, gp(d0[2].bias), R, 96, 1)
+                wgrad(dH[row0:, 96:], 192, X[row0:], W, gp(r[0].weight), 192, gp(r[0].bias), R - row0, 192, 96)
+                wgrad(dyb, g, hb, 96, gp(r[2].weight), 96, gp(r[2].bias), R - row0, 96, g)
+            if _DEFER["on"]:
+                _DEFER["keep"].append(X)
+        elif big is True and not train_a and not train_b:  # frozen discriminator (generator step): input gradient only, one launch
             r = D.gen_id_reconstructor
             g = r[2].weight.shape[0]
             dya = torch.zeros(R, 1, dtype=F32, device=X.device) if dya is None else dya.reshape(R, 1).contiguous()
