@@ -311,6 +311,13 @@ int mggan_d_rows_lean_bwd(const float* dYa, const float* dYb, const float* Ya, c
                           int row0, int rows, int g, int act_a, const float* Wp1, const float* Wp2, int c_pe,
                           const float* W1a, const float* W2a, const float* W1b, const float* W2b, float* dpred,
                           mggan_stream_t stream);
+/* pred_encoder (discriminators.py:42-43,129-131: Linear(24,64) - LeakyReLU(0.2) - Linear(64,32)) from time-major steps
+ * (T = 12, n_stride, 2) straight into its column block of the classifier input: rows [0, rows_a) from a, the rest from b2
+ * (the real and the fake half of a pair pass); h1 (rows,64) / xrows (rows,24): hidden layer and row copy of the steps for
+ * the weight gradients, when not NULL.  One launch instead of steps_to_rows + a chain launch. */
+int mggan_pred_encoder_fwd(const float* a, const float* b2, int T, int n_stride, int rows_a, int rows, const float* Wp1,
+                           const float* bp1, const float* Wp2, const float* bp2, float* X, int ldx, int c_pe, float* h1,
+                           float* xrows, mggan_stream_t stream);
 /* the first `rows` rows of steps (T, n, 2) as rows (rows, 2T); rows (n, ld) into the first n rows of steps (T, n_out, 2) */
 int mggan_steps_to_rows_n(const float* a, int T, int n, int rows, float* out, mggan_stream_t stream);
 int mggan_rows_to_steps_n(const float* rows, int ld, int T, int n, int n_out, float* out, mggan_stream_t stream);

@@ -722,6 +722,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pred_encoder alone (discriminators.py:42-43,129-131), from the time-major steps straight into its column block of the
+// classifier input: the first two products of the chain above as their own launch, for the passes that go on through the
+// generic kernels (the discriminator step's real/fake pair pass, sample block 0 of the generator step).  Replaces
+// steps_to_rows + a 3-stage mlp_chain launch (11 + 15 us in the configs[1] graph); keeps the row copy of the steps and the
+// hidden layer when a backward pass follows (operands of the weight gradients).
+struct PredEncArgs {
+  const float *a, *b2;   // steps (T = 12, n_stride, 2): rows [0, rows_a) from a, rows [rows_a, rows) from b2
+  int n_stride, rows_a, rows;
+  const float *Wp1, *bp1, *Wp2, *bp2;
+  float* X;              // (rows, ldx): columns c_pe .. c_pe+31 receive pred_enc
+  int ldx, c_pe;
+  float *h1, *xrows;     // (rows, 64), (rows, 24) or NULL
+};
+__global__ __launch_bounds__(256) void pred_encoder_fwd_kernel(PredEncArgs q) {
+  __shared__ __attribute__((aligned(16))) float wp1[DR_HP * DR_LD1];
+  __shared__ __attribute__((aligned(16))) float wp2[32 * DR_LD2];
+  __shared__ __attribute__((aligned(16))) float bp[DR_HP + 32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  for (int i = threadIdx.x; i < DR_HP * 24; i += 256) {
+    const int n = i / 24, p = i % 24, k4 = p / 6, s = p % 6;
+    wp1[n * DR_LD1 + p] = q.Wp1[n * 24 + 2 * (k4 + 4 * (s >> 1)) + (s & 1)];
+  }
+  for (int i = threadIdx.x; i < 32 * DR_HP; i += 256) wp2[(i / DR_HP) * DR_LD2 + i % DR_HP] = q.Wp2[i];
+  for (int i = threadIdx.x; i < DR_HP + 32; i += 256) bp[i] = i < DR_HP ? q.bp1[i] : q.bp2[i - DR_HP];
+  __syncthreads();
+  const int nt = (q.rows + 15) / 16;
+  for (int t = blockIdx.x * 4 + w; t < nt; t += gridDim.x * 4) {
+    const int gr = 16 * t + fi;
+    const bool valid = gr < q.rows;
+    const int grc = valid ? gr : q.rows - 1;
+    const float* src = grc < q.rows_a ? q.a + (size_t)grc * 2 : q.b2 + (size_t)(grc - q.rows_a) * 2;
+    float2 x[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) x[u] = *reinterpret_cast<const float2*>(src + (size_t)(fk + 4 * u) * q.n_stride * 2);
+    if (q.xrows && valid) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) *reinterpret_cast<float2*>(q.xrows + (size_t)gr * 24 + 2 * (fk + 4 * u)) = x[u];
+    }
+    const float xs[6] = {x[0].x, x[0].y, x[1].x, x[1].y, x[2].x, x[2].y};
+    f32x4 h1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* wr = &wp1[(16 * j + fi) * DR_LD1 + 6 * fk];
+      const float2 c0 = *reinterpret_cast<const float2*>(wr), c1 = *reinterpret_cast<const float2*>(wr + 2),
+                   c2 = *reinterpret_cast<const float2*>(wr + 4);
+      f32x4 z = *reinterpret_cast<const f32x4*>(&bp[16 * j + 4 * fk]);
+      z = MFMA16(c0.x, xs[0], z); z = MFMA16(c0.y, xs[1], z);
+      z = MFMA16(c1.x, xs[2], z); z = MFMA16(c1.y, xs[3], z);
+      z = MFMA16(c2.x, xs[4], z); z = MFMA16(c2.y, xs[5], z);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h1[j][r] = z[r] > 0.f ? z[r] : 0.2f * z[r];
+      if (q.h1 && valid) *reinterpret_cast<f32x4*>(q.h1 + (size_t)gr * DR_HP + 16 * j + 4 * fk) = h1[j];
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      f32x4 za = *reinterpret_cast<const f32x4*>(&bp[DR_HP + 16 * ct + 4 * fk]), zb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(&wp2[(16 * ct + fi) * DR_LD2 + 16 * j + 4 * fk]);
+        const f32x4 wb = *reinterpret_cast<const f32x4*>(&wp2[(16 * ct + fi) * DR_LD2 + 16 * (j + 1) + 4 * fk]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          za = MFMA16(wa[r], h1[j][r], za);
+          zb = MFMA16(wb[r], h1[j + 1][r], zb);
+        }
+      }
+      if (valid) *reinterpret_cast<f32x4*>(q.X + (size_t)gr * q.ldx + q.c_pe + 16 * ct + 4 * fk) = za + zb;
+    }
+  }
+}
+
 extern "C" {
 
 static int dheads_check(const DHeadsArgs& a, const char* what) {
@@ -917,6 +990,28 @@ int mggan_d_rows_lean_bwd(const float* dYa, const float* dYb, const float* Ya, c
   else if (g <= 8) hipLaunchKernelGGL(d_rows_lean_bwd_kernel<8>, grid, dim3(256), 0, stream, q);
   else hipLaunchKernelGGL(d_rows_lean_bwd_kernel<16>, grid, dim3(256), 0, stream, q);
   MG_LAUNCH_CHECK("d_rows_lean_bwd");
+  return MGGAN_OK;
+}
+
+
+/* pred_encoder (Linear(24,64) - LeakyReLU(0.2) - Linear(64,32)) over `rows` rows taken from time-major steps (T = 12,
+ * n_stride, 2): rows [0, rows_a) from a, the rest from b2 (NULL when rows_a == rows); pred_enc -> X[:, c_pe .. c_pe+31]
+ * (row stride ldx); h1 (rows,64) and xrows (rows,24): the hidden layer and the row copy of the steps, when not NULL */
+int mggan_pred_encoder_fwd(const float* a, const float* b2, int T, int n_stride, int rows_a, int rows, const float* Wp1,
+                           const float* bp1, const float* Wp2, const float* bp2, float* X, int ldx, int c_pe, float* h1,
+                           float* xrows, hipStream_t stream) {
+  MG_CHECK_ARG(T == DR_T, "pred_encoder_fwd: pred_len %d not built (12)", T);
+  if (rows <= 0) return MGGAN_OK;
+  MG_CHECK_ARG(a && (b2 || rows_a == rows) && Wp1 && bp1 && Wp2 && bp2 && X, "pred_encoder_fwd: null pointer");
+  MG_CHECK_ARG(rows_a >= 0 && rows_a <= rows && rows_a <= n_stride && rows - rows_a <= n_stride && (ldx & 3) == 0 &&
+                   (c_pe & 3) == 0 && (((size_t)X) & 15) == 0 && (((size_t)a) & 7) == 0 && (!b2 || (((size_t)b2) & 7) == 0) &&
+                   (!h1 || (((size_t)h1) & 15) == 0) && (!xrows || (((size_t)xrows) & 7) == 0),
+               "pred_encoder_fwd: bad layout (rows %d of which %d from a, stride %d, ldx %d, c_pe %d)", rows, rows_a, n_stride,
+               ldx, c_pe);
+  PredEncArgs q = {a, b2, n_stride, rows_a, rows, Wp1, bp1, Wp2, bp2, X, ldx, c_pe, h1, xrows};
+  const int nt = (rows + 15) / 16, wg = (nt + 3) / 4;
+  hipLaunchKernelGGL(pred_encoder_fwd_kernel, dim3(wg < 1024 ? wg : 1024), dim3(256), 0, stream, q);
+  MG_LAUNCH_CHECK("pred_encoder_fwd");
   return MGGAN_OK;
 }
 

@@ -1679,13 +1679,25 @@ class DRowsBodyFn(Function):
         c_in, c_pe, c_sc = Hs, Hs + w_in, Hs + w_in + w_pe
         st = _s()
         T = pred.shape[0]
-        x = steps_to_rows(pred, pred2)  # predictions as rows (K*b, 2T)
-        assert x.shape[0] == R, (x.shape, K, b)
         X = _empty(R, W, like=in_enc)
         # pred_encoder, last layer straight into its column block of X
         spec_pe = ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0))
         Wpe, bpe = (pe[0].weight, pe[2].weight), (pe[0].bias, pe[2].bias)
-        outs_pe = _chain_fwd(x, 2 * T, R, spec_pe, Wpe, bpe, save, out_into=(alias_cols(X, c_pe, c_sc), W))
+        if pred_encoder_kernel_ok(pe, T, w_pe):
+            # from the time-major steps in one launch (csrc/dheads.hip) instead of steps_to_rows + a chain launch
+            a = pred.reshape(T, -1, 2).contiguous()
+            n = a.shape[1]
+            a2 = None if pred2 is None else pred2.reshape(T, n, 2).contiguous()
+            assert n * (1 if pred2 is None else 2) == R, (a.shape, K, b)
+            x = _empty(R, 2 * T, like=in_enc) if save else None
+            h_pe = _empty(R, 64, like=in_enc) if save else None
+            lib.mggan_pred_encoder_fwd(_p(a), _p(a2), T, n, n, R, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(X), W, c_pe,
+                                       _p(h_pe), _p(x), st)
+            outs_pe = [h_pe, None]
+        else:
+            x = steps_to_rows(pred, pred2)  # predictions as rows (K*b, 2T)
+            assert x.shape[0] == R, (x.shape, K, b)
+            outs_pe = _chain_fwd(x, 2 * T, R, spec_pe, Wpe, bpe, save, out_into=(alias_cols(X, c_pe, c_sc), W))
         # broadcast in_enc into the sample blocks, clear the social block of the blocks without social features
         # (lean heads, dheads_lean_ok: only block 0 is ever read outside its pred_enc columns)
         lib.mggan_d_rows_fill(b, 1 if lean else K, soc_blocks, Hs, c_in, w_in, c_sc, 0, _p(in_enc), ld_in, 0, 0, _p(X), W, st)
@@ -1771,6 +1783,12 @@ def dheads_lean_ok(D, in_enc, scene, K, soc_blocks, row0):
             and Hs == 64 and in_enc.shape[1] == 32 and pe[2].weight.shape[0] == 32 and scene.shape[1] == 64)
 
 
+def pred_encoder_kernel_ok(pe, T, w_pe):
+    """The discriminator's pred_encoder in its default shape (2*12 -> 64 -> 32): mggan_pred_encoder_fwd applies."""
+    return (os.environ.get("MGGAN_PRED_ENC_KERNEL", "1") != "0" and T == 12 and w_pe == 32
+            and tuple(pe[0].weight.shape) == (64, 24) and tuple(pe[2].weight.shape) == (32, 64))
+
+
 def d_rows_lean_ok(D, in_enc, scene, pred, K, soc_blocks, row0):
     """dheads_lean_ok and, on top, everything DRowsLeanFn assumes: the whole discriminator frozen (pred_encoder and social
     attention included), the default prediction length."""
@@ -1807,12 +1825,13 @@ class DRowsLeanFn(Function):
         W, c_in, c_pe, c_sc = 192, 64, 96, 128
         g, act = r[2].weight.shape[0], D._out_act()
         # ---- block 0 ----
-        x0 = _empty(b, 2 * T, like=in_enc)
-        lib.mggan_steps_to_rows_n(_p(pred), T, R, b, _p(x0), st)
         X = _empty(b, W, like=in_enc)
-        spec_pe = ((ACT_LEAKY, 0.2), (ACT_NONE, 0.0))
         Wpe, bpe = (pe[0].weight, pe[2].weight), (pe[0].bias, pe[2].bias)
-        outs_pe = _chain_fwd(x0, 2 * T, b, spec_pe, Wpe, bpe, save, out_into=(alias_cols(X, c_pe, c_sc), W))
+        x0 = _empty(b, 2 * T, like=in_enc) if save else None
+        h_pe0 = _empty(b, 64, like=in_enc) if save else None
+        lib.mggan_pred_encoder_fwd(_p(pred), 0, T, R, b, b, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(X), W, c_pe,
+                                   _p(h_pe0), _p(x0), st)
+        outs_pe = [h_pe0, None]
         lib.mggan_d_rows_fill(b, 1, 1, c_in, c_in, c_pe - c_in, c_sc, 0, _p(in_enc), ld_in, 0, 0, _p(X), W, st)
         xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
         sw = (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, Wat.weight, Wat.bias)
