@@ -140,11 +140,12 @@ class MultiGeneratorGAN(abc.ABC):
         if int(self.config.num_gen_steps) != 1:
             raise RuntimeError("graph capture replays ONE fixed iteration: --num_gen_steps must be 1 (the discriminator "
                                "step would otherwise run in some iterations only)")
+        from mggan.hip import functions as HF
+
         batch = dict(batch)
         batch["loss_mask"] = None
         in_graph = False
         if self.dist.enabled:
-            from mggan.hip import functions as HF
 
             # peer-mapped all-reduce kernels (mggan/devcomm.py): the collectives are ordinary launches, the sharded
             # iteration is ONE graph like the single-GPU one, branch streams on.  Without them (ranks on several nodes,
@@ -160,11 +161,11 @@ class MultiGeneratorGAN(abc.ABC):
         keep, self.defer_metrics = self.defer_metrics, True
         scratch = defaultdict(list)
         side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
+        side.wait_stream(HF._cur())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.train_iteration(batch, scratch)
-        torch.cuda.current_stream().wait_stream(side)
+        HF._cur().wait_stream(side)
         self.flush_metrics()
         captured = defaultdict(list)
         if self.dist.enabled and not in_graph:
@@ -176,7 +177,7 @@ class MultiGeneratorGAN(abc.ABC):
                 raise RuntimeError("graph capture of a sharded iteration needs equal shards (dist.equal_shards)")
             rec = SegmentRecorder()
             torch.cuda.synchronize()
-            side.wait_stream(torch.cuda.current_stream())
+            side.wait_stream(HF._cur())
             with torch.cuda.stream(side):
                 self.dist.recorder = rec
                 rec.begin()
@@ -185,7 +186,7 @@ class MultiGeneratorGAN(abc.ABC):
                 finally:
                     rec.end()
                     self.dist.recorder = None
-            torch.cuda.current_stream().wait_stream(side)
+            HF._cur().wait_stream(side)
             run, graph = rec.replay, rec
             self.launch_mode = "{} hipGraph segments per iteration, collectives between them".format(rec.n_graphs)
         else:

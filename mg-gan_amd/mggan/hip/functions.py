@@ -22,12 +22,29 @@ F32 = torch.float32
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+_STREAM_OBJS = {}
+
+
 def _s():
     """Raw handle of torch's current stream (torch.cuda.current_stream() builds a Stream object per call: 10 us of host
     time, a hundred times per eager iteration)."""
     if _RAW_STREAM is not None:
-        return _RAW_STREAM(torch.cuda.current_device())
+        return _RAW_STREAM(_GET_DEVICE() if _GET_DEVICE is not None else torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+def _cur():
+    """torch.cuda.current_stream() without a new Stream object per call: the objects are kept by (device, raw handle)
+    (torch's streams live in a static pool: a handle never changes its meaning).  60 calls per eager iteration."""
+    if _RAW_STREAM is None or _GET_DEVICE is None:
+        return torch.cuda.current_stream()
+    dev = _GET_DEVICE()
+    key = (dev, _RAW_STREAM(dev))
+    obj = _STREAM_OBJS.get(key)
+    if obj is None:
+        obj = _STREAM_OBJS[key] = torch.cuda.current_stream()
+    return obj
 
 
 def _p(t):
@@ -116,7 +133,7 @@ class side_stream:
             self.ctx = None
             return self
         side = _side_stream()
-        side.wait_stream(torch.cuda.current_stream())
+        side.wait_stream(_cur())
         _SIDE["keep"].extend(self.keep)
         _SIDE["dirty"] = True
         self.ctx = torch.cuda.stream(side)
@@ -131,7 +148,7 @@ class side_stream:
 
 def join_side_stream():
     if _SIDE["dirty"]:
-        torch.cuda.current_stream().wait_stream(_side_stream())
+        _cur().wait_stream(_side_stream())
         _SIDE["keep"].clear()
         _SIDE["dirty"] = False
 
@@ -189,7 +206,7 @@ class branch:
             _BR["raw"][side.cuda_stream] = self.which
         if _on_branch():
             return self
-        cur = torch.cuda.current_stream()
+        cur = _cur()
         side.wait_stream(cur)
         _BR["dirty"].add(self.which)
         self.ctx = torch.cuda.stream(side)
@@ -212,14 +229,14 @@ def join_branch(*tensors, which=None, force=False):
         if not (w in _BR["dirty"] or force):
             continue
         if cur is None:
-            cur = torch.cuda.current_stream()
+            cur = _cur()
         if cur == side:
             continue
         cur.wait_stream(side)
         _BR["dirty"].discard(w)
     if tensors:
         if cur is None:
-            cur = torch.cuda.current_stream()
+            cur = _cur()
         for t in tensors:
             if t is not None and torch.is_tensor(t):
                 t.record_stream(cur)
@@ -255,7 +272,7 @@ def _note_branch_partials():
     On a branch stream that point is remembered as an event, so that the reduction can go out as soon as every producer
     is done - beside what the branch still has to do (the scene CNN's conv1 adjoint) - instead of behind a full join."""
     if _on_branch():
-        cur = torch.cuda.current_stream()
+        cur = _cur()
         ev = torch.cuda.Event()
         ev.record(cur)
         _DEFER["revents"][cur.cuda_stream] = ev
@@ -278,7 +295,7 @@ def flush_wgrad_gemms():
     gm = _DEFER["gemms"]
     if not gm:
         return
-    cur = torch.cuda.current_stream()
+    cur = _cur()
     for ev in _DEFER["events"].values():
         cur.wait_event(ev)
     _DEFER["events"] = {}
@@ -296,7 +313,7 @@ def flush_wgrad_gemms():
 def _note_gemm_operands():
     """The operands of a GEMM queued from a branch stream are complete on that stream from here on."""
     if _on_branch():
-        cur = torch.cuda.current_stream()
+        cur = _cur()
         ev = torch.cuda.Event()
         ev.record(cur)
         _DEFER["events"][cur.cuda_stream] = ev
@@ -309,7 +326,7 @@ def flush_grad_reduces():
     if not d:
         return
     flush_wgrad_gemms()
-    cur = torch.cuda.current_stream()
+    cur = _cur()
     for ev in _DEFER["revents"].values():
         cur.wait_event(ev)
     _DEFER["revents"] = {}
@@ -1191,7 +1208,7 @@ def _start_gram(img, side=True, after_branches=()):
         if _GRAM["stream"] is None:
             _GRAM["stream"] = torch.cuda.Stream()
         st = _GRAM["stream"]
-        st.wait_stream(torch.cuda.current_stream())
+        st.wait_stream(_cur())
         for w in after_branches:  # ... and behind what those branch streams have queued (without joining them)
             if w in _BR["streams"]:
                 st.wait_stream(_BR["streams"][w])
@@ -1217,7 +1234,7 @@ def end_images():
     """The side stream of the Gram launch joins the current stream (every fork has to be joined before a capture ends)."""
     st = _GRAM["stream"]
     if st is not None and any(e[2] is not None for e in _GRAM["reg"].values()):
-        torch.cuda.current_stream().wait_stream(st)
+        _cur().wait_stream(st)
     _GRAM["reg"].clear()
     _GRAM["pending"] = None
 
@@ -1227,8 +1244,8 @@ def _image_gram(img):
     hit = _GRAM["reg"].get(img.data_ptr())
     if hit is not None and hit[3].shape == img.shape:
         if hit[2] is not None:
-            torch.cuda.current_stream().wait_event(hit[2])
-            hit[0].record_stream(torch.cuda.current_stream())
+            _cur().wait_event(hit[2])
+            hit[0].record_stream(_cur())
         return hit[0]
     return _gram_launch(img)[0]
 

@@ -146,7 +146,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                 # on.  Called from a throw-away stream, that wait lands there and the main stream stays where its
                 # own last backward node left it: the weight-gradient GEMMs below then run beside the tail of the
                 # branch streams (the scene CNN's convolution adjoints) instead of behind it.
-                main = torch.cuda.current_stream()
+                main = HF._cur()
                 if self._bwd_stream is None:
                     self._bwd_stream = torch.cuda.Stream()
                 self._bwd_stream.wait_stream(main)
@@ -170,7 +170,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         HF.flush_grad_reduces()
         HF.mark("bwd.reduce.end")
         if HF._BR["on"]:
-            torch.cuda.current_stream().wait_stream(self._bwd_stream)
+            HF._cur().wait_stream(self._bwd_stream)
         HF.join_branch(force=True)  # backward nodes ran on the streams of their forwards
 
     # ---- the three steps -----------------------------------------------------------------
