@@ -1,3 +1,7 @@
+#!/bin/bash
+# Kernel trace only (the first step of tools/profile_round.sh): per-kernel statistics and one iteration's timeline of a
+# configuration under rocprofv3 --kernel-trace.   gpurun -- 'bash tools/kernel_trace.sh r03x c2'
+#   -> gpurun_out/<tag>_<cfg>_{kernel_stats,iteration_timeline}.txt
 TAG=$1; CFG=$2
 R=$(pwd); OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
