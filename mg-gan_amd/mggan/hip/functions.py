@@ -164,8 +164,10 @@ def join_side_stream():
 # 1.67 ms with branches, 1.94 ms without); at 256 x 32 every kernel fills the chip by itself and concurrent kernels only
 # take each other's CUs and cache (6.66 ms with branches, 6.45 ms without; eight hardware queues instead of four: 7.76 ms).
 # Measured in between (branches on / off): 2,560 pedestrians 2.59 / 2.74 ms, 4,096: 3.73 / 3.81, 6,144: 5.07 / 5.18.
+# Re-measured after the round-3 kernels (each of which leaves more of the chip free): 8,192 pedestrians 5.29 / 5.37 ms,
+# 12,288: 7.70 / 7.59, 16,384: 9.92 / 9.64 -- the crossover moved up, the default threshold with it (6,144 -> 8,192).
 _BR = {"on": os.environ.get("MGGAN_BRANCH", "auto") != "0", "streams": {}, "dirty": set(), "raw": {},
-       "auto": os.environ.get("MGGAN_BRANCH", "auto") == "auto", "max_b": int(os.environ.get("MGGAN_BRANCH_MAX_B", "6144"))}
+       "auto": os.environ.get("MGGAN_BRANCH", "auto") == "auto", "max_b": int(os.environ.get("MGGAN_BRANCH_MAX_B", "8192"))}
 
 
 def auto_branches(b):
