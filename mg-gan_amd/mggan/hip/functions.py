@@ -1780,8 +1780,10 @@ class DRowsBodyFn(Function):
 
 
 # from this many rows on, both discriminator heads run as one weight-stationary launch (csrc/dheads.hip)
-DHEADS_MIN_ROWS = int(os.environ.get("MGGAN_DHEADS_MIN_ROWS", "8192"))
-DHEADS_PAIR_MIN_ROWS = int(os.environ.get("MGGAN_DHEADS_PAIR_MIN_ROWS", "2048"))
+# (re-measured at the configs[0] shape -- 204 pair-pass rows, 2,040 rows in the generator step: 0.91 ms per iteration
+#  with the round's first thresholds 8,192 / 2,048, 0.85 ms with these; no difference at configs[1])
+DHEADS_MIN_ROWS = int(os.environ.get("MGGAN_DHEADS_MIN_ROWS", "1024"))
+DHEADS_PAIR_MIN_ROWS = int(os.environ.get("MGGAN_DHEADS_PAIR_MIN_ROWS", "64"))
 
 
 def dheads_lean_ok(D, in_enc, scene, K, soc_blocks, row0):
