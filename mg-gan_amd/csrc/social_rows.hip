@@ -665,8 +665,11 @@ static int sr_grid(int S, int RS) { return S * RS < 256 ? S * RS : 256; }
 static int sr_splits(int S, int max_n) {
   static const char* force = getenv("MGGAN_SOC_SPLITS");  // measurement knob: 1, 2 or 4
   if (force && atoi(force) >= 1 && atoi(force) <= 4 && 4 * atoi(force) <= (max_n > 4 ? max_n : 4)) return atoi(force);
+  // (inside the iteration graph, beside the branch streams' kernels, the unsplit launch wins at 64 scenes: 1.478 vs
+  //  1.489 ms per iteration over three alternating pairs -- no ticket fold, half the workgroups competing for CUs; the split
+  //  is kept for really few scenes)
   int rs = 1;
-  while (rs < 2 && S * rs * 2 <= 256 && 4 * rs * 2 <= max_n) rs *= 2;
+  while (rs < 2 && S * rs * 2 <= 64 && 4 * rs * 2 <= max_n) rs *= 2;
   return rs;
 }
 static int sr_njb(int max_n) { return max_n <= 16 ? 1 : max_n <= 32 ? 2 : 4; }
