@@ -254,33 +254,60 @@ def marked_replay(tr, batch, entries, replays=8):
     return {k: v / replays for k, v in acc.items()}
 
 
-def cpu_baseline(sizes, num_gens, iters, mode="block", tag="same workload"):
-    """The CPU oracle timed on this box's host cores (test infrastructure used as the reported CPU baseline only)."""
+def cpu_baseline_worker(spec):
+    """Child process of cpu_baseline(): pins itself to `threads` cores BEFORE torch spawns its OpenMP team, times every
+    iteration on its own and prints one JSON line."""
+    spec = json.loads(spec)
+    threads = spec["threads"]
+    try:
+        cores = sorted(os.sched_getaffinity(0))[:threads]
+        os.sched_setaffinity(0, cores)
+    except (AttributeError, OSError):
+        cores = []
+    torch.set_num_threads(threads)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mggan_oracle as O
     from mggan.data_utils import synthetic
 
-    threads = min(16, os.cpu_count() or 1)  # more threads are slower for these small operators
-    torch.set_num_threads(threads)
     torch.manual_seed(145325)
     np.random.seed(435346)
-    G, D = O.construct_oracle(num_gens)
-    tr = O.OracleTrainer(G, D, mode=mode)
-    batch = synthetic.make_batch(sizes, seed=0)
+    G, D = O.construct_oracle(spec["num_gens"])
+    tr = O.OracleTrainer(G, D, mode=spec["mode"])
+    batch = synthetic.make_batch(spec["sizes"], seed=0)
     m = defaultdict(list)
-    tr.iteration(batch, m)  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(iters):
+    for _ in range(spec.get("warmup", 1)):
         tr.iteration(batch, m)
-    dt = (time.perf_counter() - t0) / iters
-    b = batch["in_xy"].shape[1]
-    return {"value": b / dt, "unit": "trajectories/s", "cores": threads, "kind": "port", "mode": mode,
-            "sample": "{} full iterations (D+G+PM steps) of {}: {} scenes, {} pedestrians, num_gens={} on the CPU "
-                      "oracle (oracle/mggan_oracle.py, {} mode, torch CPU {} threads, nproc={}); "
-                      "{:.2f} s/iteration".format(iters, tag, len(sizes), b, num_gens,
-                                                  "block-diagonal" if mode == "block" else
-                                                  "faithful (the reference's dense all-pairs operator sequence)",
-                                                  threads, os.cpu_count(), dt)}
+    secs = []
+    for _ in range(spec["iters"]):
+        t0 = time.perf_counter()
+        tr.iteration(batch, m)
+        secs.append(time.perf_counter() - t0)
+    print(json.dumps({"seconds": secs, "b": int(batch["in_xy"].shape[1]), "pinned_cores": len(cores),
+                      "threads": torch.get_num_threads()}), flush=True)
+
+
+def cpu_baseline(sizes, num_gens, iters, mode="block", tag="same workload"):
+    """The CPU oracle timed on this box's host cores (test infrastructure used as the reported CPU baseline only):
+    a child process pinned to `threads` cores, one warm-up, then `iters` (>= 5) iterations timed one by one;
+    value = b / median, `spread` = (min, max) of the per-iteration rates."""
+    import subprocess
+
+    threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    iters = max(5, iters)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    spec = json.dumps({"sizes": [int(x) for x in sizes], "num_gens": num_gens, "iters": iters, "mode": mode,
+                       "threads": threads})
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", spec], env=env, check=True,
+                       capture_output=True, text=True)
+    w = json.loads(r.stdout.strip().splitlines()[-1])
+    secs = sorted(w["seconds"])
+    med = secs[len(secs) // 2]
+    b = w["b"]
+    return {"value": b / med, "unit": "trajectories/s", "cores": w["threads"], "kind": "port", "mode": mode,
+            "spread": [round(b / secs[-1], 2), round(b / secs[0], 2)], "s_per_iteration": round(med, 4),
+            "iterations": iters, "pinned_cores": w["pinned_cores"], "nproc": os.cpu_count(),
+            "sample": "median of {} full D+G+PM iterations of {} ({} scenes, {} peds, num_gens={}) on oracle/mggan_oracle.py, "
+                      "{} mode, {} pinned threads".format(iters, tag, len(sizes), b, num_gens, mode, w["threads"])}
 
 
 def train_loop_leg(tag, args, dev, batches=25, epochs=6):
@@ -531,6 +558,86 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
     return res
 
 
+LINE_LIMIT = 4096  # the driver keeps the last 8 KB of stdout: the one JSON line must fit with room to spare
+
+ROOFLINE_KEYS = ("kernel", "entry", "bound", "achieved", "peak", "unit", "frac", "traffic", "mfma_util", "avg_launch_ms")
+
+
+def _clean(x):
+    """NaN / inf -> None (the line is strict JSON), numpy scalars -> Python numbers."""
+    if isinstance(x, dict):
+        return {str(k): _clean(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_clean(v) for v in x]
+    if isinstance(x, (np.floating, np.integer)):
+        x = x.item()
+    if isinstance(x, float) and not np.isfinite(x):
+        return None
+    return x
+
+
+def compact_line(full):
+    """The ONE line the driver parses: the contract's keys, the roofline block of the dominant kernel, the CPU baseline and
+    one short entry per measured workload.  Everything else (per-kernel tables, breakdowns, floors, train() leg, notes)
+    goes to bench_detail.json."""
+    full = _clean(full)
+    cfg = full.get("config", {})
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "b_per_gpu", "parallelism", "launch", "collective") if k in cfg}
+    if full.get("roofline"):
+        line["roofline"] = {k: full["roofline"].get(k) for k in ROOFLINE_KEYS}
+    if full.get("cpu_baseline"):
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "mode", "sample", "spread") if k in cb}
+        line["cpu_baseline"]["value"] = round(cb["value"], 2)
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:200]
+    confs = []
+    for r in full.get("configs", []):
+        e = {"workload": r.get("config"), "b_per_gpu": r.get("b_per_gpu"), "ms_per_step": r.get("ms_per_step"),
+             "value": r.get("value")}
+        if r.get("roofline"):
+            e.update(kernel=r["roofline"].get("kernel"), frac=r["roofline"].get("frac"), bound=r["roofline"].get("bound"))
+        if r.get("iteration_frac_of_f32_peak") is not None:
+            e["iteration_frac_of_f32_peak"] = r["iteration_frac_of_f32_peak"]
+        confs.append(e)
+    if confs:
+        line["configs"] = confs
+    for k in ("iteration_frac_of_f32_peak", "launches_per_step", "gpu_over_cpu"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+    if full.get("collective_transports"):
+        line["collective_transports"] = [
+            {"workload": t.get("config"), **{k: {"ms_per_step": v.get("ms_per_step"), "value": v.get("value")}
+                                             for k, v in t.items() if isinstance(v, dict)}}
+            for t in full["collective_transports"]]
+    line["detail"] = "bench_detail.json"
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:  # never expected: drop the optional blocks rather than print an unparseable line
+        for k in ("collective_transports", "configs"):
+            line.pop(k, None)
+            text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def emit(full):
+    """Write the full record to bench_detail.json (repo root, and gpurun_out/ so that it travels back from a GPU box) and
+    return the compact line."""
+    text = compact_line(full)
+    blob = json.dumps(_clean(full), allow_nan=False, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "bench_detail.json"), "w") as fh:
+                fh.write(blob)
+        except OSError:
+            pass
+    return text
+
+
 def self_launch(n):
     """Re-exec this command line as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py ...`
     (rendezvous on 127.0.0.1, a free port).  -> exit code of the job."""
@@ -570,7 +677,10 @@ def main():
     ap.add_argument("--no-floor", action="store_true", help="skip the C1-shaped eager / host-RNG / graph floor timings")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--no-transport-ab", action="store_true", help="N>1: skip the second pass on the other collective transport")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_baseline_worker(args.cpu_worker)
     if args.config == "c4":
         args.config = "c3"
     if args.scenes is not None:  # explicit shape (round-1 command lines keep working)
@@ -707,7 +817,7 @@ def main():
 
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        print(emit(out), flush=True)
 
 
 if __name__ == "__main__":

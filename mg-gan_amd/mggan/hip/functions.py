@@ -7,6 +7,7 @@ into the root module's flat gradient buffer (hip/flat.py), so backward returns
 None for parameter inputs.
 """
 import ctypes
+import json
 import os
 
 import torch
@@ -53,7 +54,8 @@ def _p(t):
 
 # Debugging aid (MGGAN_POISON=1 or poison_scratch(True)): scratch buffers start as NaN instead of whatever the allocator
 # hands back, so a kernel that reads what no kernel wrote shows up as NaN instead of as a box-dependent flake.
-_DEBUG = {"poison": os.environ.get("MGGAN_POISON", "0") == "1", "wgrad_dump": os.environ.get("MGGAN_WGRAD_DUMP", "0") == "1"}
+_DEBUG = {"poison": os.environ.get("MGGAN_POISON", "0") == "1", "wgrad_dump": os.environ.get("MGGAN_WGRAD_DUMP", "0") == "1",
+          "reduce_dump": os.environ.get("MGGAN_REDUCE_DUMP", "0") == "1"}
 
 
 def poison_scratch(on=True):
@@ -337,6 +339,9 @@ def flush_grad_reduces():
     def launch():
         if batch:
             arr = (_ReduceDesc * len(batch))(*batch)
+            if _DEBUG.get("reduce_dump"):  # MGGAN_REDUCE_DUMP=1: (M, Naug, splits, groups, p_stride) of every partial buffer
+                print("[reduce batch] " + json.dumps([[q.M, q.Naug, q.splits, q.groups, q.p_stride] for q in batch])
+                      + " | MB {:.1f}".format(sum(4e-6 * q.M * q.Naug * q.splits * q.groups for q in batch)))
             lib.mggan_grad_reduce_multi(ctypes.addressof(arr), len(batch), _s())
 
     for desc in d:
