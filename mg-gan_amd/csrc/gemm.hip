@@ -251,53 +251,106 @@ struct ReduceBatch {
   int n;
 };
 
-__global__ __launch_bounds__(1024) void grad_reduce_multi_kernel(ReduceBatch bt) {
-  __shared__ float red[16][64];
+// A bandwidth kernel: a workgroup of 8 waves owns a chunk of 256 consecutive outputs of one (buffer, group) and walks
+// the buffer's partial blocks (rows of p_stride floats) with wave w on rows w, w + 8, ...; a lane takes four outputs as
+// ONE 16-byte load per row when the buffer allows it (base and row pitch 16-byte aligned: a wave then reads 1 KB per row)
+// and as four coalesced 4-byte loads otherwise, eight rows in flight per lane.  The eight waves meet in 8 KB of LDS and
+// are added in wave order: the sum is a fixed function of (splits, layout), not of timing.  The producers keep `splits`
+// at a few hundred at most (stream_slab_rows), so a wave's walk is at most four or five rounds of eight loads.
+// (Round 3's form -- 64 outputs per 1,024-thread workgroup, 256-byte wave reads 4 bytes per lane -- took 121 us for the
+// 42-58 MB a backward pass of 8,192 pedestrians left behind: 0.35-0.5 TB/s.)
+#define MG_RED_WAVES 8
+template <bool VEC>
+__device__ __forceinline__ void grad_reduce_chunk(const ReduceDesc& D, const int grp, const int c0, const int total,
+                                                  float (*red)[256]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // the four outputs of this lane: VEC: c0 + 4 lane + e (one 16-byte load); else c0 + 64 e + lane (four 4-byte loads)
+  f32x4 a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* base = D.P + ((size_t)grp * D.splits) * D.p_stride + c0;
+  const size_t ps = (size_t)D.p_stride;
+  if (VEC) {
+    const int c = 4 * lane;
+    if (c0 + c < total) {  // (total % 4 == 0 on this path: a lane's four outputs are all inside or all outside)
+      const float* p = base + c;
+      int z = w;
+      for (; z + MG_RED_WAVES * 7 < D.splits; z += MG_RED_WAVES * 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += *reinterpret_cast<const f32x4*>(p + (size_t)(z + MG_RED_WAVES * u) * ps);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (z + MG_RED_WAVES * u < D.splits) a[u] += *reinterpret_cast<const f32x4*>(p + (size_t)(z + MG_RED_WAVES * u) * ps);
+    }
+  } else {
+    bool in[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) in[e] = c0 + 64 * e + lane < total;
+    const float* p = base + lane;
+    int z = w;
+    for (; z + MG_RED_WAVES * 7 < D.splits; z += MG_RED_WAVES * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* q = p + (size_t)(z + MG_RED_WAVES * u) * ps;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (in[e]) a[u][e] += q[64 * e];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (z + MG_RED_WAVES * u < D.splits) {
+        const float* q = p + (size_t)(z + MG_RED_WAVES * u) * ps;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (in[e]) a[u][e] += q[64 * e];
+      }
+  }
+  const f32x4 s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  // LDS column = offset of the output inside the chunk
+  if (VEC) {
+    *reinterpret_cast<f32x4*>(&red[w][4 * lane]) = s;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[w][64 * e + lane] = s[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int o = c0 + threadIdx.x;
+    if (o < total) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < MG_RED_WAVES; ++i) t += red[i][threadIdx.x];
+      const int m = o / D.Naug, n = o - m * D.Naug;
+      const bool overwrite = (D.has_bias & 2) != 0;  // bit 1: '=' instead of '+=' (scratch destinations)
+      if ((D.has_bias & 1) && n == D.Naug - 1) {
+        if (D.db) {
+          float* q = D.db + grp * D.b_stride + m;
+          *q = overwrite ? t : *q + t;
+        }
+      } else {
+        float* q = D.dW + grp * D.w_stride + (size_t)m * D.lddw + n;
+        *q = overwrite ? t : *q + t;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * MG_RED_WAVES) void grad_reduce_multi_kernel(ReduceBatch bt) {
+  __shared__ __attribute__((aligned(16))) float red[MG_RED_WAVES][256];
   int di = 0;
 #pragma unroll 1
   for (int i = 1; i < bt.n; ++i)
     if ((int)blockIdx.x >= bt.d[i].block0) di = i;
   const ReduceDesc& D = bt.d[di];
   const int total = D.M * D.Naug;
-  const int bpg = (total + 63) / 64;  // blocks per group
+  const int cpg = (total + 255) / 256;  // chunks per group
   const int rel = blockIdx.x - D.block0;
-  const int grp = rel / bpg;
-  const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
-  const int o = (rel % bpg) * 64 + lane;
-  float s = 0.f;
-  if (o < total) {
-    const float* p = D.P + ((size_t)grp * D.splits) * D.p_stride + o;
-    // eight partial sums per thread = eight loads in flight: the streaming weight-gradient kernel leaves up to 768
-    // partial blocks per problem and a thread's 48 of them, fetched two at a time, were 24 dependent round trips
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int z = zl;
-    for (; z + 16 * 7 < D.splits; z += 16 * 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += p[(size_t)(z + 16 * u) * D.p_stride];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (z + 16 * u < D.splits) a[u] += p[(size_t)(z + 16 * u) * D.p_stride];
-    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-  }
-  red[zl][lane] = s;
-  __syncthreads();
-  if (zl == 0 && o < total) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i][lane];
-    const int m = o / D.Naug, n = o % D.Naug;
-    const bool overwrite = (D.has_bias & 2) != 0;  // bit 1: '=' instead of '+=' (scratch destinations)
-    if ((D.has_bias & 1) && n == D.Naug - 1) {
-      if (D.db) {
-        float* q = D.db + grp * D.b_stride + m;
-        *q = overwrite ? t : *q + t;
-      }
-    } else {
-      float* q = D.dW + grp * D.w_stride + (size_t)m * D.lddw + n;
-      *q = overwrite ? t : *q + t;
-    }
-  }
+  const int grp = rel / cpg, c0 = (rel - grp * cpg) * 256;
+  const bool vec = (((size_t)D.P & 15) == 0) && (D.p_stride & 3) == 0 && (total & 3) == 0;
+  if (vec) grad_reduce_chunk<true>(D, grp, c0, total, red);
+  else grad_reduce_chunk<false>(D, grp, c0, total, red);
 }
 
 // dZ = dY * act'(Y)
@@ -542,9 +595,15 @@ size_t mggan_wgrad_workspace_bytes(int rows, int K, int N, int n_groups) {
   return (size_t)splits * (n_groups > 0 ? n_groups : 1) * N * (K + 1) * sizeof(float);
 }
 
-// rows per workgroup of the streaming kernel: ~768 slabs for the largest problems, never less than 128 rows
-static int stream_slab_rows(int rows) {
-  int s = cdiv(cdiv(rows, 768), 64) * 64;
+// rows per workgroup (slab) of the streaming kernel.  Every slab leaves a partial block of N (K + 1) floats that the
+// batched reduction reads back, so a slab must be long enough for that block to be small beside the operands it was
+// summed from (<= 1/8: with round 3's fixed 768 slabs the 57,344 x (256 x 64) gate-gradient product wrote 30 MB of
+// partials for 73 MB of operands), and there are at most 256 slabs per problem (a wave of the reduction then walks at most
+// 32 rows; the problems of a batch fill the chip together, not each on its own); never less than 128 rows.
+static int stream_slab_rows(int rows, int K, int N) {
+  int s = cdiv(cdiv(rows, 256), 64) * 64;
+  const int by_output = cdiv(cdiv(8L * N * (K + 1), K + N), 64) * 64;
+  if (by_output > s) s = by_output;
   return s < 128 ? 128 : s;
 }
 
@@ -552,7 +611,7 @@ static StreamProb stream_problem(const float* dZ, const float* X, float* workspa
                                  int ldx, int feature_major) {
   StreamProb q = {};
   q.A = dZ; q.B = X; q.P = workspace; q.rows = rows; q.M = N; q.Kf = K; q.lda = lddz; q.ldb = ldx;
-  q.slab = stream_slab_rows(rows);
+  q.slab = stream_slab_rows(rows, K, N);
   q.pm = cdiv(N, 64); q.pk = cdiv(K, 64);
   const bool vec = (lddz % 4 == 0) && (ldx % 4 == 0) && ((size_t)dZ % 16 == 0) && ((size_t)X % 16 == 0);
   q.mode = feature_major ? (vec ? 0 : 1) : 2;
@@ -560,7 +619,7 @@ static StreamProb stream_problem(const float* dZ, const float* X, float* workspa
 }
 
 int mggan_wgrad_splits(int rows, int K, int N, int n_groups) {
-  if (n_groups <= 1) return rows > 0 ? cdiv(rows, stream_slab_rows(rows)) : 1;  // slabs of the streaming kernel
+  if (n_groups <= 1) return rows > 0 ? cdiv(rows, stream_slab_rows(rows, K, N)) : 1;  // slabs of the streaming kernel
   // short dependent chains: 128-256 rows (4-8 pipelined k-steps) per workgroup, up to ~4 workgroups per CU
   int ng = n_groups > 0 ? n_groups : 1;
   int tiles = cdiv(N, BM) * cdiv(K + 1, BN) * ng;
@@ -584,9 +643,9 @@ int mggan_grad_reduce_multi(const void* descs, int n, hipStream_t stream) {
       bt.d[i] = in[i0 + i];
       MG_CHECK_ARG(bt.d[i].P && bt.d[i].dW && bt.d[i].splits > 0 && bt.d[i].groups > 0, "grad_reduce_multi: bad descriptor");
       bt.d[i].block0 = blocks;
-      blocks += cdiv((long)bt.d[i].M * bt.d[i].Naug, 64) * bt.d[i].groups;
+      blocks += cdiv((long)bt.d[i].M * bt.d[i].Naug, 256) * bt.d[i].groups;
     }
-    hipLaunchKernelGGL(grad_reduce_multi_kernel, dim3(blocks), dim3(1024), 0, stream, bt);
+    hipLaunchKernelGGL(grad_reduce_multi_kernel, dim3(blocks), dim3(64 * MG_RED_WAVES), 0, stream, bt);
     MG_LAUNCH_CHECK("grad_reduce_multi");
   }
   return MGGAN_OK;

@@ -114,6 +114,7 @@ class MultiGeneratorGAN(abc.ABC):
         # unrolled updates.  That literal behaviour is what runs here (nothing to restore).
         if hasattr(self, "_open_iteration"):
             self._open_iteration()
+        prep_was = HF.prep_cache(True)  # folded LSTM weights are kept per weight version inside the iteration
         try:
             if run_d:
                 for _ in range(cfg.num_unrolling_steps + 1):
@@ -122,6 +123,7 @@ class MultiGeneratorGAN(abc.ABC):
             self.generator_step(*args, shared=shared)
             self.net_chooser_step(*args)
         finally:
+            HF.prep_cache(prep_was)
             HF.end_images()
             if hasattr(self, "_close_iteration"):
                 self._close_iteration()
@@ -152,6 +154,8 @@ class MultiGeneratorGAN(abc.ABC):
             # IPC mapping refused, a gradient buffer larger than an arena slot, unequal shards) every torch.distributed
             # collective cuts the capture into graph segments.
             in_graph = self.dist.graph_safe(self.G, self.D)
+            if not in_graph and not self.dist.equal_shards:
+                raise RuntimeError("graph capture of a sharded iteration needs equal shards (dist.equal_shards)")
             if not in_graph and self.dist.devcomm is not None:
                 # the decision is per trainer, not per collective: a torch.distributed call inside the single-graph
                 # capture would fail, so the peer-mapped kernels are set aside for this trainer's captures
@@ -159,6 +163,36 @@ class MultiGeneratorGAN(abc.ABC):
             HF.enable_branches(in_graph or os.environ.get("MGGAN_BRANCH_SHARDED", "0") == "1")
         self.graph_collectives = in_graph
         keep, self.defer_metrics = self.defer_metrics, True
+        n_pending = len(self._pending)
+        try:
+            run, graph, captured = self._capture(batch, warmup, pool, in_graph, HF)
+        except BaseException:
+            # a failed capture must not leak into the eager iterations that follow: metric items recorded during the aborted
+            # capture, queued reductions / weight-gradient GEMMs whose operands are gone, side-stream bookkeeping
+            self.defer_metrics = keep
+            del self._pending[n_pending:]
+            HF.reset_deferred()
+            raise
+        pending, self._pending = self._pending, []
+        self.defer_metrics = keep
+        # nothing executed during the capture: the folded-weight buffers it allocated are empty until the first replay
+        HF.bump_weight_version(self.G)
+        HF.bump_weight_version(self.D)
+
+        def replay(metrics=None, fetch=True):
+            run()
+            HF.bump_weight_version(self.G)  # the optimizer steps inside the graph are invisible to the host
+            HF.bump_weight_version(self.D)
+            self.dist.check()  # host read: a peer-mapped collective of an earlier replay has timed out -> stop here
+            if metrics is not None and fetch:
+                self._fetch([(metrics, items, snap) for _, items, snap in pending])
+
+        replay.graph = graph
+        replay.pending = pending  # [(metrics dict at capture, [(key, slot | (slot, slot))], snapshot buffer)]
+        return replay
+
+    def _capture(self, batch, warmup, pool, in_graph, HF):
+        """The warm-up iterations and the capture itself.  -> (run, graph object, metrics dict of the captured iteration)"""
         scratch = defaultdict(list)
         side = torch.cuda.Stream()
         side.wait_stream(HF._cur())
@@ -168,13 +202,18 @@ class MultiGeneratorGAN(abc.ABC):
         HF._cur().wait_stream(side)
         self.flush_metrics()
         captured = defaultdict(list)
+        it0 = self.total_iterations  # the captured iteration executes nothing: it does not count (the replays do)
+        try:
+            return self._capture_graph(batch, pool, in_graph, HF, side, captured)
+        finally:
+            self.total_iterations = it0
+
+    def _capture_graph(self, batch, pool, in_graph, HF, side, captured):
         if self.dist.enabled and not in_graph:
             # sharded iteration: the collectives cut the capture into graph segments and stay eager calls
             # between them (parallel.SegmentRecorder)
             from mggan.parallel import SegmentRecorder
 
-            if not self.dist.equal_shards:
-                raise RuntimeError("graph capture of a sharded iteration needs equal shards (dist.equal_shards)")
             rec = SegmentRecorder()
             torch.cuda.synchronize()
             side.wait_stream(HF._cur())
@@ -207,18 +246,7 @@ class MultiGeneratorGAN(abc.ABC):
             run = graph.replay
             self.launch_mode = "hipGraph replay of the whole iteration" + (
                 ", peer-mapped all-reduce kernels inside it" if in_graph else "")
-        pending, self._pending = self._pending, []
-        self.defer_metrics = keep
-
-        def replay(metrics=None, fetch=True):
-            run()
-            self.dist.check()  # host read: a peer-mapped collective of an earlier replay has timed out -> stop here
-            if metrics is not None and fetch:
-                self._fetch([(metrics, items, snap) for _, items, snap in pending])
-
-        replay.graph = graph
-        replay.pending = pending  # [(metrics dict at capture, [(key, slot | (slot, slot))], snapshot buffer)]
-        return replay
+        return run, graph, captured
 
     def graph_mode(self):
         """Does train() replay captured iterations?  --graph on | off | auto (auto: whenever the configuration allows it).
@@ -230,6 +258,10 @@ class MultiGeneratorGAN(abc.ABC):
         ok = (getattr(self.rng, "on_device", False) and int(cfg.num_gen_steps) == 1 and cfg.weighting_target != "mgan")
         if mode == "on" and not ok:
             raise ValueError("--graph on needs --rng device, --num_gen_steps 1 and a --weighting_target other than 'mgan'")
+        if self.dist.enabled and not self.dist.equal_shards:
+            # a sharded iteration is only capturable with equal shards (unequal ones read the global row count back to
+            # the host): without them train() launches eagerly instead of trying -- and failing -- a capture per shape
+            return False
         return ok and mode != "off"
 
     def train(self):
@@ -439,8 +471,11 @@ class IterationGraphs:
             snap, total, count, item_lists = acc
             if count == 0:
                 continue
-            red = tr.dist.all_reduce_(total.clone()) if tr.dist.enabled else total
-            v = (red / count).cpu().numpy()
+            if tr.dist.enabled:  # the count travels with the sums: ranks may have replayed different numbers of iterations
+                red = tr.dist.all_reduce_(torch.cat([total.double(), total.new_tensor([count]).double()]))
+                v = (red[:-1] / red[-1].clamp(min=1) * tr.dist.world_size).cpu().numpy()
+            else:
+                v = (total / count).cpu().numpy()
             for items in sorted(item_lists):
                 for key, slot in items:
                     val = float(v[slot] if isinstance(slot, int) else v[slot[0]] + v[slot[1]])

@@ -91,6 +91,10 @@ class DeviceComm:
         except Exception as exc:  # noqa: BLE001
             print("[mggan] device all-reduce, rank {}: {}: {}".format(self.rank, type(exc).__name__, exc))
         agree(ok, "peer mapping")  # also the barrier: every arena is mapped everywhere before the first collective
+        # the host-mapped error word is one per process: a timed-out collective of an EARLIER communicator (closed since)
+        # must not fail this one's first check -- its own arenas are fresh.  Cleared here, where every rank has agreed that
+        # the new arenas are mapped and no collective of this communicator has run yet.
+        self._host_error[0] = 0
         # phase 3: known-answer exchanges
         agree(True if self.self_test() else None, "self test (wrong sums or a timed-out wait)")
 

@@ -27,10 +27,25 @@ class FlatModule(nn.Module):
         # Module._apply (.to / .cuda / .double) and load_state_dict(assign=True) re-seat EVERY parameter: three probes
         # (first, middle, last) see that; walking all ~150 parameters cost 10 us, thirty times per eager iteration
         base, items = f.data_ptr(), self._flat_items
+        if not items:
+            return True
         for p, off in (items[0], items[len(items) // 2], items[-1]):
             if p.data_ptr() != base + 4 * off:
                 return False
         return True
+
+    def flat_is_current_full(self):
+        """Every parameter checked (the optimizer step does this once per step: a SINGLE re-seated parameter --
+        `p.data = ...`, `module.weight = nn.Parameter(...)`, a partial load_state_dict(assign=True) -- escapes the three
+        probes of the hot path, and the kernels would keep reading and writing its stale slot)."""
+        f = self._flat
+        if f is None:
+            return False
+        base = f.data_ptr()
+        named = list(self.parameters())
+        if len(named) != len(self._flat_items):
+            return False
+        return all(p is q and q.data_ptr() == base + 4 * off for p, (q, off) in zip(named, self._flat_items))
 
     def ensure_flat(self):
         if not self.flat_is_current():

@@ -271,6 +271,15 @@ def defer_grad_reduce(on=True):
     _DEFER["on"] = bool(on)
 
 
+def reset_deferred():
+    """Forget everything queued for later launches (a capture failed half-way through a backward pass: the queued
+    reductions / weight-gradient products point at operands of the aborted iteration and must never be folded into the
+    gradients of a later one)."""
+    _DEFER.update(descs=[], keep=[], gemms=[], events={}, revents={}, after=[])
+    _SIDE["keep"].clear()
+    _SIDE["dirty"] = False
+
+
 def _note_branch_partials():
     """Partial sums queued for the batched reduction were (or are about to be) written by a kernel on the CURRENT stream.
     On a branch stream that point is remembered as an event, so that the reduction can go out as soon as every producer
@@ -674,6 +683,54 @@ def two_heads(x, layers_a, layers_b, row0=0):
 
 
 # ------------------------------------------------------------------------------------------
+# Folded LSTM weights (`prep`: W_ih.emb folded into two input coefficients per gate row, transposed W_hh, ...) only change
+# when the weights do.  Inside the trainer's iteration (`prep_cache(True)`) a fold is launched once per weight VERSION and
+# kept: per iteration the generator's encoder is folded twice (after the generator's and after the PM network's AdamW
+# step), its decoders once, the discriminator's encoder once -- four launches instead of seven, none of them in front of
+# the discriminator step's rollouts.  A version = the data pointers and torch version counters of the folded tensors
+# (load_state_dict, in-place torch ops) + a counter the kernels that write weights through raw pointers bump
+# (FlatAdamW.step; a graph replay bumps it for both models: the launches inside a graph are invisible to the host).
+# A capture needs no special case: the folds it records are those of an iteration that follows a complete iteration, and
+# a replay is only ever preceded by a complete iteration (the warm-up iteration of capture_iteration, or another replay);
+# a capture that follows a replay finds every entry stale and records more folds than needed, never fewer.
+# Outside the trainer (module calls in tests, predict) every forward folds, as before.
+_PREP = {"on": False, "entries": {}, "enabled": os.environ.get("MGGAN_PREP_CACHE", "1") != "0"}
+
+
+def prep_cache(on):
+    """-> the previous setting.  The entries survive switching it off (the trainer switches it on per iteration)."""
+    was, _PREP["on"] = _PREP["on"], bool(on)
+    return was
+
+
+def clear_prep_cache():
+    _PREP["entries"].clear()
+
+
+def bump_weight_version(root):
+    """The weights of `root` (a FlatModule) were written by a kernel (optimizer step, graph replay)."""
+    object.__setattr__(root, "_kernel_version", getattr(root, "_kernel_version", 0) + 1)
+
+
+def _prep_for(owner, tensors, psz_total, like, fold):
+    """-> the folded-weight buffer for `tensors` (the module's raw weights); `fold(prep)` launches the fold."""
+    if not (_PREP["on"] and _PREP["enabled"]) or owner is None:
+        prep = _empty(psz_total, like=like)
+        fold(prep)
+        return prep
+    root = getattr(owner, "_flat_root", owner)
+    key = (getattr(root, "_kernel_version", 0),) + tuple((t.data_ptr(), t._version) for t in tensors)
+    ent = _PREP["entries"].get(id(owner))
+    if ent is not None and ent[0] == key and ent[1].numel() == psz_total:
+        return ent[1]
+    # a NEW buffer per version: graphs captured earlier re-fold into the buffer they recorded, and a backward pass that has
+    # not run yet keeps the version it saved
+    prep = torch.empty(psz_total, dtype=F32, device=like.device)
+    fold(prep)
+    _PREP["entries"][id(owner)] = (key, prep, owner)
+    return prep
+
+
 class LstmEncoderFn(Function):
     """Linear(2,E) + nn.LSTM over T steps -> h_T   (common_modules.py:48-66)."""
 
@@ -683,9 +740,9 @@ class LstmEncoderFn(Function):
         H, E = w_hh.shape[1], emb_w.shape[0]
         x = x.contiguous()
         psz = lib.mggan_lstm_prep_size(H, 0, 0)
-        prep = _empty(psz, like=x)
-        lib.mggan_lstm_fold(_p(emb_w), _p(emb_b), _p(w_ih), _p(b_ih), _p(b_hh), _p(w_hh), 0, 0, 0, 0, 0, 1, H, E, 0, 0,
-                            _p(prep), psz, _s())
+        prep = _prep_for(owner, (emb_w, emb_b, w_ih, b_ih, b_hh, w_hh), psz, x,
+                         lambda prep: lib.mggan_lstm_fold(_p(emb_w), _p(emb_b), _p(w_ih), _p(b_ih), _p(b_hh), _p(w_hh), 0, 0, 0,
+                                                          0, 0, 1, H, E, 0, 0, _p(prep), psz, _s()))
         Gt = _empty(b, T, 4 * H, like=x) if save else None
         Cs = _empty(b, T, H, like=x) if save else None
         Hp = _empty(b, T, H, like=x) if save else None
@@ -1489,10 +1546,12 @@ class DecoderRolloutFn(Function):
         st = _s()
         ctx.set_materialize_grads(False)
         psz = lib.mggan_lstm_prep_size(H, S, 1)
-        prep = _empty(n_gens, psz, like=enc_h)
-        lib.mggan_lstm_fold(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), _p(g0["b_ih"]), _p(g0["b_hh"]),
-                            _p(g0["w_hh"]), _p(g0["w1"]), _p(g0["b1"]), _p(g0["w2"]), _p(g0["b2"]), stride, n_gens, H, E,
-                            S, 1, _p(prep), psz, st)
+        # (every generator's tensors: `g0` names the first generator's, the others sit `stride` floats apart)
+        prep = _prep_for(owner, tuple(owner.generator_parameters()), n_gens * psz, enc_h,
+                         lambda prep: lib.mggan_lstm_fold(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), _p(g0["b_ih"]),
+                                                          _p(g0["b_hh"]), _p(g0["w_hh"]), _p(g0["w1"]), _p(g0["b1"]),
+                                                          _p(g0["w2"]), _p(g0["b2"]), stride, n_gens, H, E, S, 1, _p(prep),
+                                                          psz, st)).view(n_gens, psz)
         mk = (lambda *s: _empty(*s, like=enc_h)) if save else (lambda *s: None)
         # tile-blocked saves (16-row tiles, every generator's last tile padded): gates, (c, h) with slot 0 = (0, h_0), ...
         tiles = -(-R // 16) + n_gens

@@ -45,6 +45,10 @@ class FlatAdamW:
         r = self.root
         if r._flat.data_ptr() != self._flat_id:
             raise RuntimeError("the module's flat parameter buffer was rebuilt after the optimizer was created")
+        if not r.flat_is_current_full():
+            raise RuntimeError("a parameter of the module was re-seated outside its flat buffer (p.data = ..., a replaced "
+                               "nn.Parameter, load_state_dict(assign=True)): call flatten_parameters_() and rebuild the "
+                               "optimizer")
         from mggan.hip.functions import join_side_stream
 
         join_side_stream()  # weight-gradient GEMMs issued on the side stream must have landed
@@ -58,6 +62,9 @@ class FlatAdamW:
                              mask.data_ptr(), self.seg_step.data_ptr(), float(max_norm), float(self.lr),
                              self._lr_dev.data_ptr(), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                              1 if zero_grad else 0, self._ws.data_ptr(), self.grad_norm.data_ptr(), st)
+        from mggan.hip.functions import bump_weight_version
+
+        bump_weight_version(r)  # folded LSTM weights cached by the trainer's iteration are stale from here on
         if zero_grad:
             r._grad_clean = True  # every gradient written since the last memset has been consumed and zeroed
 

@@ -87,6 +87,11 @@ class DeviceRNG:
                                                torch.empty(max(n_unif, 1), dtype=torch.float32, device=device)))
             self._labels, self._noise, self._unif = pool
             self._shape = shape
+        elif HF._PIN["on"] and self._pools is not None:
+            # same shape as the previous draw, which may have run unpinned (an eager batch beyond the graph cache, a
+            # masked batch, validation): a capture about to record pointers into this pool must find it pinned, or the
+            # bounded cache may evict -- and free -- it under the graph
+            self._pools.get(shape)
         tb = HF.scene_tables(sub_batches, b, device)
         lib.mggan_draw_iteration(self._state.data_ptr(), self._ticket.data_ptr(), n_labels, self._labels.data_ptr(), sets,
                                  b, Z, tb.ped_scene.data_ptr(), self._noise.data_ptr(), n_unif, self._unif.data_ptr(),

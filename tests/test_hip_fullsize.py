@@ -73,6 +73,11 @@ def _snapshot_steps(tr):
 
 # BASELINE.json configs[1] and configs[2] (C2 = 64 x 20, g=4; C3 = 256 x 32, g=8)
 FULL_SIZES = [pytest.param(64, 20, 4, id="configs1-64x20-g4"), pytest.param(256, 32, 8, id="configs2-256x32-g8")]
+# + BASELINE.json configs[0]'s shape (32 ragged scenes of 1-6 pedestrians incl. n = 1, one generator)
+ALL_SIZES = [pytest.param(32, None, 1, id="configs0-32xragged-g1")] + FULL_SIZES
+# The ELEMENT-WISE bound of one tensor is stated on top of the f32 oracle's own error: the conv1 weight of the two scene
+# CNNs (two coherent sums that cancel behind the train-mode BatchNorm) -- found by shape in the test.
+# Every other tensor is held to 1e-3 of its largest entry against f64, as SURVEY A.12 iii says.
 
 
 def _oracle_iteration(tro, batch, steps, labels, dtype):
@@ -90,7 +95,7 @@ def _oracle_iteration(tro, batch, steps, labels, dtype):
     return m_cpu, grads
 
 
-@pytest.mark.parametrize("scenes,peds,g", FULL_SIZES)
+@pytest.mark.parametrize("scenes,peds,g", ALL_SIZES)
 def test_full_size_iteration_matches_oracle(scenes, peds, g):
     """One D+G+PM iteration (the de-duplicated train_iteration path bench.py measures) against the oracle in
     block-diagonal mode: every logged loss rtol 1e-3 and the post-step parameters relL2 1e-3 against the f32 oracle (the
@@ -119,6 +124,10 @@ def test_full_size_iteration_matches_oracle(scenes, peds, g):
     m_gpu = _iteration(tr, batch, steps, labels)
     m_cpu, g32 = _oracle_iteration(tro, batch, steps, labels, torch.float32)
     _, g64 = _oracle_iteration(tro64, batch, steps, labels, torch.float64)
+    conv1 = [n for n, q in list(tr.G.named_parameters()) + list(tr.D.named_parameters())
+             if n.startswith("scene_encoder") and q.dim() == 4 and q.shape[1] == 4]
+    assert len(set(conv1)) == 1, conv1  # (the same name in both models: the first convolution of the scene CNN)
+    relaxed = set(conv1)
     for step, ref in g64.items():
         got = gpu_grads[step]
         assert set(got) == set(ref), (step, sorted(set(got) ^ set(ref)))
@@ -136,7 +145,7 @@ def test_full_size_iteration_matches_oracle(scenes, peds, g):
             assert ours <= theirs + 1e-3, (step, n, ours, theirs)
             scale = float(r.abs().max())
             el_ours = float((got[n].detach().cpu().double() - r.double()).abs().max())
-            el_theirs = float((g32[step][n].double() - r.double()).abs().max())
+            el_theirs = float((g32[step][n].double() - r.double()).abs().max()) if n in relaxed else 0.0
             assert el_ours <= el_theirs + 1e-3 * scale, (step, n, el_ours / scale, el_theirs / scale)
     for key, v in m_cpu.items():  # losses: rtol 1e-3 (SURVEY A.12 ii)
         assert abs(m_gpu[key][0] - v[0]) <= 1e-3 * abs(v[0]) + 1e-6, (key, m_gpu[key][0], v[0])
@@ -146,7 +155,7 @@ def test_full_size_iteration_matches_oracle(scenes, peds, g):
         assert float((a - r).norm() / r.norm()) <= 1e-3
 
 
-@pytest.mark.parametrize("scenes,peds,g", FULL_SIZES)
+@pytest.mark.parametrize("scenes,peds,g", ALL_SIZES)
 def test_full_size_iteration_is_bit_reproducible(scenes, peds, g):
     from mggan.data_utils import synthetic
 
@@ -198,3 +207,47 @@ def test_generator_is_equivariant_to_scene_order(scenes, peds, g):
         outs.append((out.abs.cpu(), logits.cpu()))
     np.testing.assert_allclose(outs[1][0].numpy(), outs[0][0][:, :, perm].numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(outs[1][1].numpy(), outs[0][1][perm].numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("sizes,g", [pytest.param([70, 3, 100, 1, 65], 2, id="scenes-of-65-to-100-peds-g2")])
+def test_scenes_larger_than_64_pedestrians_match_oracle(sizes, g):
+    """Scenes of more than 64 pedestrians leave the row-structured social kernels (csrc/social_rows.hip walks scenes of up
+    to 64) for the per-stage kernels of csrc/social.hip, in the generator's attention AND in the discriminator's
+    (/root/reference/mggan/model/modules/social.py:7-123): one full D+G+PM iteration against the oracle -- losses 1e-3,
+    every parameter gradient of every step (relL2 and element-wise 1e-3 against the oracle in f64), post-step parameters."""
+    import copy
+
+    import mggan_oracle as O
+    from helpers import rel_l2
+    from mggan.data_utils import synthetic
+    from mggan.hip import functions as HF
+
+    K = 20
+    assert not HF.SceneTables([[0, 70]], 70, "cpu").rows_ok  # (the premise: such a scene is not a "rows" scene)
+    batch = synthetic.make_batch(sizes, seed=6)
+    steps = _draws(sizes, g, K, torch.Generator().manual_seed(15))
+    labels = [(0.95, 0.05), (0.93, 0.07), (0.97, 0.02)]
+    tr, tro = _trainers(g, seed=21)
+    tro64 = O.OracleTrainer(copy.deepcopy(tro.G).double(), copy.deepcopy(tro.D).double(), mode="block")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    gpu_grads = _snapshot_steps(tr)
+    m_gpu = _iteration(tr, batch, steps, labels)
+    m_cpu, _ = _oracle_iteration(tro, batch, steps, labels, torch.float32)
+    _, g64 = _oracle_iteration(tro64, batch, steps, labels, torch.float64)
+    for step, ref in g64.items():
+        got = gpu_grads[step]
+        assert set(got) == set(ref), (step, sorted(set(got) ^ set(ref)))
+        group = max(float(v.abs().max()) for v in ref.values())
+        for n, r in ref.items():
+            if float(r.abs().max()) < 1e-4 * group:
+                assert float(got[n].abs().max()) <= 1e-3 * group, (step, n)
+                continue
+            assert rel_l2(got[n], r) <= 1e-3, (step, n, rel_l2(got[n], r))
+            scale = float(r.abs().max())
+            assert float((got[n].detach().cpu().double() - r.double()).abs().max()) <= 1e-3 * scale, (step, n)
+    for key, v in m_cpu.items():
+        assert abs(m_gpu[key][0] - v[0]) <= 1e-3 * abs(v[0]) + 1e-6, (key, m_gpu[key][0], v[0])
+    for mod, ref in ((tr.G, tro.G), (tr.D, tro.D)):
+        a = torch.cat([p.detach().cpu().flatten() for p in mod.parameters()]).double()
+        r = torch.cat([p.detach().flatten() for p in ref.parameters()]).double()
+        assert float((a - r).norm() / r.norm()) <= 1e-3

@@ -158,3 +158,49 @@ def test_branch_streams_and_graph_replay_are_bit_identical():
     assert bool(torch.isfinite(ref).all())
     for branches, graph in ((True, False), (True, True)):
         assert torch.equal(run(branches, graph), ref), (branches, graph)
+
+
+def test_folded_weights_are_cached_per_weight_version():
+    """Inside the trainer's iteration the folded LSTM weights are launched once per weight version: four mggan_lstm_fold
+    calls per steady-state iteration instead of seven, and the weights after eager iterations, a capture, replays and
+    more eager iterations are bit-identical to a run that folds in every forward (MGGAN_PREP_CACHE=0 semantics)."""
+    import bench
+    from mggan.data_utils import synthetic
+    from mggan.hip import functions as HF
+    from mggan.hip.lib import start_trace, stop_trace
+
+    dev = torch.device("cuda", 0)
+
+    def run(cache):
+        keep = HF._PREP["enabled"]
+        HF._PREP["enabled"] = cache
+        HF.clear_prep_cache()
+        try:
+            tr = bench.build_trainer(3, "device", dev)
+            torch.cuda.manual_seed(99)
+            batch = tr.to_device(synthetic.make_batch(synthetic.scene_sizes(8, 5), seed=1))
+            batch["loss_mask"] = None
+            tr.defer_metrics = True
+            m = defaultdict(list)
+            tr.train_iteration(batch, m)  # (the first iteration folds everything once more: nothing is cached yet)
+            start_trace()
+            tr.train_iteration(batch, m)
+            folds = stop_trace().get("mggan_lstm_fold", (0, [], []))[0]
+            replay = tr.capture_iteration(batch, warmup=0)
+            for _ in range(2):
+                replay(m, False)
+            tr.train_iteration(batch, m)  # eager again, right after a replay: every cached fold is stale
+            with torch.no_grad():  # a weight written behind the optimizer's back, through torch
+                tr.G.encoder.embedding.weight.mul_(1.5)
+            tr.train_iteration(batch, m)
+            tr.flush_metrics()
+            torch.cuda.synchronize()
+            return folds, torch.cat([tr.G._flat.clone(), tr.D._flat.clone()]).cpu()
+        finally:
+            HF._PREP["enabled"] = keep
+            HF.clear_prep_cache()
+
+    f_on, w_on = run(True)
+    f_off, w_off = run(False)
+    assert (f_on, f_off) == (4, 7), (f_on, f_off)
+    assert bool(torch.isfinite(w_on).all()) and torch.equal(w_on, w_off)

@@ -152,6 +152,61 @@ def test_wgrad_grouped_segments():
                                    rtol=1e-4, atol=2e-4)
 
 
+def test_grad_reduce_multi_layouts():
+    """The batched fixed-order reduction on every layout its producers leave behind: 16-byte aligned partial blocks (one
+    vector load per lane), unaligned bases / odd pitches / odd totals (scalar loads), groups, the bias column, storing
+    and accumulating destinations, 1 ... 1,030 partial blocks, outputs narrower and wider than a 256-float chunk; a second
+    launch on the same inputs gives the same bits."""
+    import ctypes
+    from mggan.hip import functions as HF
+
+    lib, dev = _lib(), _dev()
+    g = torch.Generator().manual_seed(11)
+    cases = [  # (M, Naug, has_bias, splits, groups, pitch slack, base offset in floats, overwrite)
+        (128, 32, 0, 64, 8, 948, 0, False), (128, 2, 0, 64, 8, 4788, 1, True), (16, 33, 1, 81, 8, 0, 0, False),
+        (96, 193, 1, 29, 1, 0, 0, False), (1, 97, 1, 128, 1, 0, 0, False), (256, 65, 1, 128, 1, 0, 0, True),
+        (1, 2304, 0, 512, 1, 16, 0, False), (32, 17, 1, 1030, 1, 528, 0, False), (3, 5, 1, 1, 2, 1, 3, False),
+        (64, 4, 0, 7, 3, 0, 2, False)]
+    descs, checks, keep = [], [], []
+    for M, Naug, hb, splits, groups, slack, off, ow in cases:
+        total = M * Naug
+        pitch = total + slack
+        P = torch.randn(off + groups * splits * pitch, generator=g).to(dev)
+        N = Naug - 1 if hb else Naug
+        lddw = N + 2
+        w_stride, b_stride = M * lddw + 5, M + 3
+        dW = torch.full((groups * w_stride,), 0.5, device=dev)
+        db = torch.full((groups * b_stride,), -0.25, device=dev)
+        descs.append(HF._ReduceDesc(P.data_ptr() + 4 * off, dW.data_ptr(), db.data_ptr() if hb else None, w_stride, b_stride, M,
+                                    Naug, hb | (2 if ow else 0), lddw, splits, groups, pitch, 0))
+        ref = P[off:].view(groups, splits, pitch)[:, :, :total].double().sum(1).view(groups, M, Naug).cpu()
+        checks.append((dW, db, ref, M, N, hb, lddw, w_stride, b_stride, groups, ow, splits))
+        keep.append(P)
+    arr = (HF._ReduceDesc * len(descs))(*descs)
+
+    def run():
+        for dW, db, *_ in checks:
+            dW.fill_(0.5)
+            db.fill_(-0.25)
+        lib.mggan_grad_reduce_multi(ctypes.addressof(arr), len(descs), st())
+        torch.cuda.synchronize()
+        return [(c[0].clone(), c[1].clone()) for c in checks]
+
+    first = run()
+    for (dW, db, ref, M, N, hb, lddw, w_stride, b_stride, groups, ow, splits), (w1, b1) in zip(checks, first):
+        base = 0.0 if ow else 0.5
+        tol = 3e-6 * splits ** 0.5 + 1e-6
+        for gi in range(groups):
+            got = dW[gi * w_stride:gi * w_stride + M * lddw].view(M, lddw).cpu().double()
+            np.testing.assert_allclose(got[:, :N].numpy(), ref[gi, :, :N].numpy() + base, rtol=1e-5, atol=tol)
+            assert torch.all(got[:, N:] == 0.5)  # the padding columns of the destination are not touched
+            if hb:
+                gb = db[gi * b_stride:gi * b_stride + M].cpu().double()
+                np.testing.assert_allclose(gb.numpy(), ref[gi, :, N].numpy() + (0.0 if ow else -0.25), rtol=1e-5, atol=tol)
+    for (w1, b1), (w2, b2) in zip(first, run()):
+        assert torch.equal(w1, w2) and torch.equal(b1, b2)
+
+
 def test_gather_sum_and_transpose():
     lib, dev = _lib(), _dev()
     g = torch.Generator().manual_seed(5)

@@ -189,6 +189,65 @@ def test_three_training_iterations(golden):
                         assert int(sd[k]) == int(ref[k]), k
 
 
+def test_seeded_host_rng_iterations_match_reference(golden):
+    """north_star: "on identical seeds".  No recorded draw is injected here: every step is seeded exactly as the golden
+    run seeded the reference (torch.manual_seed / np.random.seed, /root/reference/mggan/abstract_train.py:14-15 style)
+    and runs with the seed-comparable host RNG (--rng host).  The generator ids the PM network's categorical sampler
+    picked (`sampled_gen_idxs`, /root/reference/mggan/model/modules/standard.py:217-225) must be BIT-EXACT -- they are
+    integers drawn from GPU-computed logits by the host generator -- the noise identical, the smoothed labels equal, and
+    every logged loss of three iterations within 1e-3."""
+    from mggan.rng import HostRNG
+
+    tr = make_trainer(golden)
+    bt = batch_from(golden, DEV)
+    mask = torch.ones(bt["in_xy"].shape[1], dtype=torch.bool, device=DEV)
+    args = (bt["in_xy"], bt["in_dxdy"], bt["gt_xy"], bt["gt_dxdy"], bt["seq_start_end"])
+    seen = {}
+
+    class Recording(HostRNG):
+        def labels(self):
+            out = super().labels()
+            seen.setdefault("labels", []).append(out)
+            return out
+
+        def noise(self, *a):
+            out = super().noise(*a)
+            seen.setdefault("noise", []).append(out.cpu())
+            return out
+
+        def sample_generators(self, logits, num_samples):
+            out = super().sample_generators(logits, num_samples)
+            seen["gen_idxs"] = out.clone()
+            return out
+
+    tr.rng = tr.G.rng = Recording()
+    for it in range(1, 4):
+        for step, fn in (("d", tr.discriminator_step), ("g", tr.generator_step), ("pm", tr.net_chooser_step)):
+            p = "s{}_{}".format(it, step)
+            seen.clear()
+            torch.manual_seed(int(golden[p + "/seed_torch"]))
+            np.random.seed(int(golden[p + "/seed_numpy"]))
+            m = defaultdict(list)
+            fn(*args, m, mask, bt["features"])
+            if step != "pm":  # (the PM step evaluates every generator: nothing is sampled)
+                got = seen["gen_idxs"].cpu().numpy()
+                assert got.dtype == np.int64 and np.array_equal(got, golden[p + "/gen_idxs"]), (p, "sampled_gen_idxs")
+            np.testing.assert_array_equal(torch.cat(seen["noise"]).numpy().reshape(golden[p + "/noise"].shape),
+                                          golden[p + "/noise"])
+            if p + "/labels" in golden:
+                np.testing.assert_allclose(np.array(seen["labels"], dtype=np.float64), golden[p + "/labels"], rtol=1e-6)
+            for k, v in m.items():
+                ref = float(golden[p + "/metric/" + k])
+                assert abs(v[0] - ref) <= 1e-3 * abs(ref) + 1e-6, (p, k, v[0], ref)
+    for mod, pre in ((tr.G, "G"), (tr.D, "D")):
+        ref = sd_from(golden, pre + "3")
+        sd = {k: v.cpu() for k, v in mod.state_dict().items()}
+        fl = [k for k in ref if ref[k].is_floating_point()]
+        a = torch.cat([sd[k].flatten().double() for k in fl]).numpy()
+        r = torch.cat([ref[k].flatten().double() for k in fl]).numpy()
+        assert rel_l2(a, r) <= 1e-3, (pre, rel_l2(a, r))
+
+
 def test_predict_and_ade_fde(golden):
     from mggan.metrics import compute_metrics_from_batch
     from mggan.rng import ReplayRNG
