@@ -608,7 +608,7 @@ def compact_line(full):
             line[k] = full[k]
     if full.get("collective_transports"):
         line["collective_transports"] = [
-            {"workload": t.get("config"), **{k: {"ms_per_step": v.get("ms_per_step"), "value": v.get("value")}
+            {"config": t.get("config"), **{k: {"ms_per_step": v.get("ms_per_step"), "value": v.get("value")}
                                              for k, v in t.items() if isinstance(v, dict)}}
             for t in full["collective_transports"]]
     line["detail"] = "bench_detail.json"

@@ -707,24 +707,43 @@ def clear_prep_cache():
     _PREP["entries"].clear()
 
 
-def bump_weight_version(root):
-    """The weights of `root` (a FlatModule) were written by a kernel (optimizer step, graph replay)."""
-    object.__setattr__(root, "_kernel_version", getattr(root, "_kernel_version", 0) + 1)
+def bump_weight_version(root, touched=None):
+    """The weights of `root` (a FlatModule) were written by a kernel: an optimizer step (`touched` = ids of the parameters
+    it updated -- AdamW skips parameters without a gradient, so the PM network's step leaves the decoders alone) or a graph
+    replay (touched=None: everything)."""
+    v = getattr(root, "_kernel_version", 0) + 1
+    object.__setattr__(root, "_kernel_version", v)
+    if touched is None:
+        object.__setattr__(root, "_all_written_at", v)
+    else:
+        at = getattr(root, "_written_at", None)
+        if at is None:
+            at = {}
+            object.__setattr__(root, "_written_at", at)
+        for i in touched:
+            at[i] = v
 
 
 def _prep_for(owner, tensors, psz_total, like, fold):
-    """-> the folded-weight buffer for `tensors` (the module's raw weights); `fold(prep)` launches the fold."""
+    """-> the folded-weight buffer for `tensors` (the module's raw weights); `fold(prep)` launches the fold.
+    Inside the trainer's iteration ONE buffer per module, re-folded in place when its weights have a new version: every
+    captured graph and every eager iteration reads and writes the same buffer (a graph's discriminator step reads what
+    the previous iteration's generator step folded).  In place is safe: a fold only follows an optimizer step, which is
+    ordered behind every reader of the old contents (the backward pass of its own step)."""
     if not (_PREP["on"] and _PREP["enabled"]) or owner is None:
         prep = _empty(psz_total, like=like)
         fold(prep)
         return prep
     root = getattr(owner, "_flat_root", owner)
-    key = (getattr(root, "_kernel_version", 0),) + tuple((t.data_ptr(), t._version) for t in tensors)
+    at = getattr(root, "_written_at", None) or {}
+    written = max([getattr(root, "_all_written_at", 0)] + [at.get(id(t), 0) for t in tensors])
+    key = (written,) + tuple((t.data_ptr(), t._version) for t in tensors)
     ent = _PREP["entries"].get(id(owner))
-    if ent is not None and ent[0] == key and ent[1].numel() == psz_total:
+    if ent is not None and ent[1].numel() == psz_total and ent[1].device == like.device:
+        if ent[0] != key:
+            fold(ent[1])
+            _PREP["entries"][id(owner)] = (key, ent[1], owner)
         return ent[1]
-    # a NEW buffer per version: graphs captured earlier re-fold into the buffer they recorded, and a backward pass that has
-    # not run yet keeps the version it saved
     prep = torch.empty(psz_total, dtype=F32, device=like.device)
     fold(prep)
     _PREP["entries"][id(owner)] = (key, prep, owner)

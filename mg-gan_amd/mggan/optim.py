@@ -64,7 +64,7 @@ class FlatAdamW:
                              1 if zero_grad else 0, self._ws.data_ptr(), self.grad_norm.data_ptr(), st)
         from mggan.hip.functions import bump_weight_version
 
-        bump_weight_version(r)  # folded LSTM weights cached by the trainer's iteration are stale from here on
+        bump_weight_version(r, tuple(r._touched))  # folded LSTM weights of the updated parameters are stale from here on
         if zero_grad:
             r._grad_clean = True  # every gradient written since the last memset has been consumed and zeroed
 

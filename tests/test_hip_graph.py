@@ -195,10 +195,15 @@ def test_folded_weights_are_cached_per_weight_version():
             tr.train_iteration(batch, m)
             tr.flush_metrics()
             torch.cuda.synchronize()
-            return folds, torch.cat([tr.G._flat.clone(), tr.D._flat.clone()]).cpu()
+            out = folds, torch.cat([tr.G._flat.clone(), tr.D._flat.clone()]).cpu()
+            del replay
+            return out
         finally:
             HF._PREP["enabled"] = keep
             HF.clear_prep_cache()
+            import gc
+
+            gc.collect()
 
     f_on, w_on = run(True)
     f_off, w_off = run(False)
