@@ -340,12 +340,18 @@ def train_loop_leg(tag, args, dev, batches=25, epochs=6):
     per_it = sorted(s / n for s, n in list(zip(tr.epoch_seconds, tr.epoch_iterations))[2:])
     ms = per_it[len(per_it) // 2] * 1e3
     b = c["scenes"] * (c["peds"] or 3)
+    if not c["peds"]:  # ragged batches: the mean pedestrian count of the loader's batches
+        from mggan.data_utils import synthetic
+
+        b = float(np.mean([sum(synthetic.scene_sizes(c["scenes"], None, seed=i)) for i in range(batches)]))
     tr.dist.close()
     return {"workload": "train() on the synthetic loader: {} batches of {} scenes x {} peds per epoch, num_gens={}, {} epochs "
                         "(batches resident in HBM, --rng device, graph cache)".format(batches, c["scenes"], c["peds"],
                                                                                       c["num_gens"], epochs),
             "ms_per_step": round(ms, 4), "value": round(b / ms * 1e3, 2), "unit": "trajectories/s",
             "replayed_iterations": ig.replays if ig else 0, "eager_iterations": (ig.eager if ig else sum(tr.epoch_iterations)),
+            "graphs": len(ig.entries) if ig else 0, "padded_iterations": ig.padded if ig else 0,
+            "mean_b": round(float(b), 1),
             "ms_per_step_by_epoch": [round(s / n * 1e3, 4) for s, n in zip(tr.epoch_seconds, tr.epoch_iterations)],
             "last_losses": {k: round(v, 6) for k, v in sorted(last.items()) if "probs" not in k}}
 
@@ -795,6 +801,12 @@ def main():
             tl = train_loop_leg(args.config, args, dev)
             tl["vs_graph_headline"] = round(tl["value"] / out["value"], 3)
             out["train_loop"] = tl
+        # train() on RAGGED batches of the configs[0] shape (32 scenes of 1-6 pedestrians, a new tuple of sizes every batch,
+        # like the reference loader's): padded to shape buckets, one captured graph per bucket replays them all
+        tr_ = train_loop_leg("c1", args, dev)
+        tr_["vs_c1_graph_floor"] = round(tr_["ms_per_step"] / g1["ms_per_step"], 3)
+        tr_["vs_c1_eager"] = round(tr_["ms_per_step"] / e1["ms_per_step"], 3)
+        out["train_loop_ragged"] = tr_
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sizes = synthetic.scene_sizes(head_cfg["scenes"], head_cfg["peds"])
         out["cpu_baseline"] = cpu_baseline(sizes, head_cfg["num_gens"], args.cpu_iters, "block", "the headline workload")

@@ -206,18 +206,24 @@ int mggan_segment_max_bwd(int P, int B, const int* pair_o, const int* ped_prow, 
  * in index order and finalizes BatchNorm itself (scale / shift / stat = mean | invstd / `updates` momentum updates of
  * the running statistics; backward: coef = [gamma*invstd | mean g | mean g*xhat], dgamma / dbeta accumulated).  With
  * ticket == NULL the caller does it: mggan_bn_reduce_rows -> (all-reduce over ranks) -> mggan_bn_finalize /
- * mggan_bn_bwd_coef. */
+ * mggan_bn_bwd_coef.
+ * `dims` (may be NULL = every image is real): a 16-byte record in DEVICE memory {int n_real; int s_real; float
+ * b_padded / n_real; pad} of a batch that the trainer padded to its shape bucket with inert "phantom" pedestrians at the
+ * end (the reference loader's ragged batches, /root/reference/mggan/data_utils/trajectories_scene.py:40-78, replayed as one
+ * captured graph per bucket): the image loops stop at n_real, the element counts of the statistics shrink with it, and
+ * the attention head writes zero features for the phantom rows.  The launch geometry stays that of B. */
 int mggan_cnn_grid(int B);      /* workgroups (= partial rows) of conv1_pool / conv2_fwd2 / image_gram / conv1_wgrad */
 int mggan_cnn_bwd_grid(int B);  /* workgroups (= partial rows) of conv2_bwd */
 int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float* bias, float* xsel,
                      unsigned char* code, double* part, unsigned int* ticket, double count, const float* gamma,
                      const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
-                     float eps, int updates, float* scale, float* shift, float* stat, mggan_stream_t stream);
+                     float eps, int updates, float* scale, float* shift, float* stat, const int* dims,
+                     mggan_stream_t stream);
 int mggan_conv2_fwd2(const float* xsel, int B, int C, const float* scale1, const float* shift1,
                      const float* W, const float* bias, float* y2, double* part, unsigned int* ticket, double count,
                      const float* gamma, const float* beta, float* run_mean, float* run_var,
                      long long* num_batches_tracked, float momentum, float eps, int updates, float* scale, float* shift,
-                     float* stat, mggan_stream_t stream);
+                     float* stat, const int* dims, mggan_stream_t stream);
 int mggan_bn_reduce_rows(const double* part, int rows, int W, double* sums, mggan_stream_t stream);
 /* training: 0 = eval (running statistics), n >= 1 = batch statistics and n momentum updates of the running ones */
 int mggan_bn_finalize(const double* sums, double count, int C, int training, const float* gamma, const float* beta,
@@ -231,7 +237,7 @@ int mggan_bn_bwd_coef(const double* sums, const double* local_sums, double count
                       const float* stat, float* coef, double* coefd, float* dgamma, float* dbeta, mggan_stream_t stream);
 int mggan_scene_attention_fwd(const float* y2, int B, int C, const float* scale2, const float* shift2, const float* Wa,
                               const float* ba, const float* Wb, const float* bb, float* out, int ld_out,
-                              mggan_stream_t stream);
+                              const int* dims, mggan_stream_t stream);
 /* Adjoint of the attention head INCLUDING the weight gradients of both layers (MFMA; nothing per position is stored):
  * G2 = gradient on the raw conv2 output grid (B,C,16,16); wpart: mggan_scene_attention_grid(B) partial blocks of
  * mggan_scene_attention_partial_floats(C) floats ([32][C+1] = dWa | dba, then [C][33] = dWb | dbb) for
@@ -243,7 +249,7 @@ int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2
                               const float* stat2, const float* Wa, const float* ba, const float* Wb, const float* bb,
                               const float* dout, int ld_dout, float* G2, float* wpart, double* part,
                               unsigned int* ticket, double count, const float* gamma2, float* coef2, float* dgamma2,
-                              float* dbeta2, mggan_stream_t stream);
+                              float* dbeta2, const int* dims, mggan_stream_t stream);
 /* conv2 adjoint (BatchNorm-2 backward on the fly, dW2 / db2 as per-workgroup partial rows in `workspace`, input
  * gradient routed through ReLU / max-pool of block 1 -> G1c (B,C,16,16)); part1:
  * mggan_cnn_bwd_grid(B) rows; coefd1 = [gamma*invstd | S1 | S2 | mean | invstd] (C each) + count, f64, for
@@ -253,18 +259,18 @@ int mggan_conv2_bwd(const float* xsel, int B, int C, const float* scale1,
                     const float* coef2, const float* W, float* G1c, double* part1, float* dW,
                     float* db, float* workspace, size_t workspace_bytes, unsigned int* ticket, double count1,
                     const float* gamma1, float* coef1, double* coefd1, float* dgamma1, float* dbeta1,
-                    mggan_stream_t stream);
+                    const int* dims, mggan_stream_t stream);
 /* Gram matrix of the 3x3 patches of a batch of images, gram[s][t] (37 x 37 doubles; tap t = 9*ci + 3*ky + kx,
  * tap 36 = the constant 1): the image-only part of every conv1 weight gradient of the batch (both CNNs, every
  * backward pass).  workspace: mggan_cnn_grid(B) * 1536 doubles. */
 int mggan_image_gram(const float* img, int B, double* gram, double* workspace, size_t workspace_bytes,
-                     mggan_stream_t stream);
+                     const int* dims, mggan_stream_t stream);
 /* conv1 weight gradient (the images need no input gradient): dW (C,4,3,3) += (gamma/sigma) * (A - mean(g) * B -
  * mean(g*xhat) * Chat) with A from G1c / code1 (matrix cores) and B, Chat from the Gram matrix, in f64; the conv1 bias
  * gradient is identically zero in front of a train-mode BatchNorm.  workspace: mggan_cnn_grid(B) * C * 36 doubles. */
 int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const unsigned char* code1, const double* gram,
                       const float* W, const float* bias, const double* coefd, float* dW, double* workspace,
-                      size_t workspace_bytes, mggan_stream_t stream);
+                      size_t workspace_bytes, const int* dims, mggan_stream_t stream);
 
 /* ---- both discriminator heads over many rows, weight-stationary (csrc/dheads.hip) -------------------------------
  * reference: discriminators.py:76-85,197-204 (discs[0]) and :97-108,211-219 (gen_id_reconstructor) on the K*b rows of
@@ -373,7 +379,10 @@ int mggan_bce_rows(int rows, int kind, const float* p, float label, const float*
  *   { const float* p; const float* label_u[2]; const int* row_gen; const int* seg; const float* inv_count;
  *     const float* logits; const int* target; float* dp; float* dlogits; float* out[3]; float* total;
  *     double* partial; unsigned* ticket;   (768 doubles of scratch; one word that is zero before the first call)
- *     float label[2], lo[2], hi[2], scale[3], sign_a, grad_c; int nA, nB, nC, g, ld, kind, weighted_c; }
+ *     const int* dims;                     (padded batch, see the scene-CNN section; NULL: every row is real)
+ *     float label[2], lo[2], hi[2], scale[3], sign_a, grad_c; int nA, nB, nC, g, ld, kind, weighted_c, bmod; }
+ * With dims, row r of every term belongs to pedestrian r % bmod: phantom rows get zero gradients and take no part in the
+ * sums, and the scales (reciprocals of the PADDED row counts) are corrected by dims' factor.
  * label_u[q] != NULL: the smoothed label of term q is lo + (hi-lo)*u drawn on the device; counts per generator come
  * from seg (g+1 offsets of the generator-sorted rows) or from inv_count. */
 int mggan_gan_losses(const void* args, mggan_stream_t stream);
@@ -441,7 +450,7 @@ int mggan_ce_rows(int rows, int g, const float* logits, int ld, const int* targe
                   float* loss_rows, float* dlogits, int ldd, mggan_stream_t stream);
 int mggan_l2_min_scene(int S, int T, int K, int b, const int* scenes, const int* ped_scene, const float* gen_abs,
                        const float* gt, float grad_scale, float* scene_loss, int* scene_arg, float* gabs,
-                       mggan_stream_t stream);
+                       const int* dims, mggan_stream_t stream);
 int mggan_pm_ml_loss(int b, int T, int E, int g, const float* gen_abs, const float* gt, const float* logits, float sigma,
                      float scale, float* loss_rows, float* dlogits, float* probs, mggan_stream_t stream);
 /* the same plus the reductions the trainer needs, in ONE launch: *out = sum of the loss rows, probs_out[g] =
@@ -449,10 +458,13 @@ int mggan_pm_ml_loss(int b, int T, int E, int g, const float* gen_abs, const flo
  * that is zero before the first call (the kernel leaves it at zero) */
 int mggan_pm_ml_loss_mean(int b, int T, int E, int g, const float* gen_abs, const float* gt, const float* logits,
                           float sigma, float scale, float* loss_rows, float* dlogits, float* probs, double* partial,
-                          unsigned* ticket, float* out, float* probs_out, float probs_scale, mggan_stream_t stream);
+                          unsigned* ticket, float* out, float* probs_out, float probs_scale, const int* dims,
+                          mggan_stream_t stream);
 int mggan_sum(const float* x, long n, float alpha, float* out, int accumulate, mggan_stream_t stream);
 int mggan_colmean(const float* x, int rows, int g, float scale, float* out, mggan_stream_t stream);
-int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count, mggan_stream_t stream);
+/* dims / bmod as in mggan_gan_losses: rows of phantom pedestrians (row % bmod >= n_real) are not counted */
+int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count, const int* dims, int bmod,
+                     mggan_stream_t stream);
 int mggan_inv_counts(const int* counts, int g, float* inv_count, mggan_stream_t stream);
 /* flat parameter buffer + segment table: elem_seg[i] = segment of element i (-1 = padding),
  * active[s] = segment takes part in this step (grad not None), seg_step[s] = Adam step count.

@@ -197,7 +197,14 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
                                                    // backward only
                                                    const float* __restrict__ dout, int ld_dout,
                                                    const float* __restrict__ stat2, float* G2, float* wpart, double* part,
-                                                   BnBwdFin fin) {
+                                                   BnBwdFin fin, const int* dims) {
+  MG_REAL_IMAGES_COUNT(B, dims, fin)
+  if (!BWD && B < B_padded_) {
+    // phantom pedestrians of a padded batch get a zero scene feature (finite: their rows travel through every row-wise
+    // kernel downstream and meet zero gradients in the weight-gradient products)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < (B_padded_ - B) * 64; i += gridDim.x * 256)
+      out[(size_t)(B + i / 64) * ld_out + (i & 63)] = 0.f;
+  }
   constexpr int WGF = AT_WG_FLOATS(C);
   constexpr int SMF = BWD ? (4 * AT_TILE_FLOATS > 4 * WGF ? 4 * AT_TILE_FLOATS : 4 * WGF) : 1;
   __shared__ __attribute__((aligned(16))) float smem[SMF];
@@ -450,7 +457,9 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
                                                         const float* __restrict__ stat1, const float* __restrict__ y2,
                                                         const float* __restrict__ G2, const float* __restrict__ stat2,
                                                         const float* __restrict__ coef2, const float* __restrict__ W,
-                                                        float* G1c, double* part1, float* wpart, BnBwdFin fin) {
+                                                        float* G1c, double* part1, float* wpart, BnBwdFin fin,
+                                                        const int* dims) {
+  MG_REAL_IMAGES_COUNT(B, dims, fin)
   constexpr int COT = C / 4, PAIRS = C * C, NQ = 256 / PAIRS, ROWS = 16 / NQ, WLEN = PAIRS * 9 + C;
   __shared__ __attribute__((aligned(16))) float dyp[C * A1_PLANE];
   __shared__ __attribute__((aligned(16))) float a1p[C * A1_PLANE];
@@ -618,7 +627,9 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
                                                             const float* __restrict__ y2, const float* __restrict__ G2,
                                                             const float* __restrict__ stat2,
                                                             const float* __restrict__ coef2, const float* __restrict__ W,
-                                                            float* G1c, double* part1, float* wpart, BnBwdFin fin) {
+                                                            float* G1c, double* part1, float* wpart, BnBwdFin fin,
+                                                            const int* dims) {
+  MG_REAL_IMAGES_COUNT(B, dims, fin)
   constexpr int WLEN = C * C * 9 + C, PLANE = C2Geo<C>::PLANE, NT = C2Geo<C>::NT, KS = C2Geo<C>::KS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dyp = smem;                       // [C][18][20] padded planes, stride PLANE
@@ -847,17 +858,17 @@ int mggan_scene_attention_partial_floats(int C) { return AT_WG_FLOATS(C); }
 
 int mggan_scene_attention_fwd(const float* y2, int B, int C, const float* scale2, const float* shift2, const float* Wa,
                               const float* ba, const float* Wb, const float* bb, float* out, int ld_out,
-                              hipStream_t stream) {
+                              const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "scene_attention_fwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(y2 && scale2 && shift2 && Wa && ba && Wb && bb && out, "scene_attention_fwd: null pointer");
   const BnBwdFin none = make_bfin(nullptr, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   if (C == 16)
     hipLaunchKernelGGL((attn_kernel<16, false>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, none);
+                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, none, dims);
   else
     hipLaunchKernelGGL((attn_kernel<8, false>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, none);
+                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, none, dims);
   MG_LAUNCH_CHECK("scene_attention_fwd");
   return MGGAN_OK;
 }
@@ -870,7 +881,7 @@ int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2
                               const float* stat2, const float* Wa, const float* ba, const float* Wb, const float* bb,
                               const float* dout, int ld_dout, float* G2, float* wpart, double* part, unsigned* ticket,
                               double count, const float* gamma2, float* coef2, float* dgamma2, float* dbeta2,
-                              hipStream_t stream) {
+                              const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "scene_attention_bwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(y2 && scale2 && shift2 && stat2 && Wa && ba && Wb && bb && dout && G2 && wpart && part,
@@ -879,10 +890,10 @@ int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2
   const BnBwdFin fin = make_bfin(ticket, count, gamma2, stat2, coef2, nullptr, dgamma2, dbeta2);
   if (C == 16)
     hipLaunchKernelGGL((attn_kernel<16, true>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, G2, wpart, part, fin);
+                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, G2, wpart, part, fin, dims);
   else
     hipLaunchKernelGGL((attn_kernel<8, true>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, G2, wpart, part, fin);
+                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, G2, wpart, part, fin, dims);
   MG_LAUNCH_CHECK("scene_attention_bwd");
   return MGGAN_OK;
 }
@@ -896,7 +907,8 @@ int mggan_conv2_bwd(const float* xsel, int B, int C, const float* scale1,
                     const float* shift1, const float* stat1, const float* y2, const float* G2, const float* stat2,
                     const float* coef2, const float* W, float* G1c, double* part1, float* dW,
                     float* db, float* workspace, size_t workspace_bytes, unsigned* ticket, double count1,
-                    const float* gamma1, float* coef1, double* coefd1, float* dgamma1, float* dbeta1, hipStream_t stream) {
+                    const float* gamma1, float* coef1, double* coefd1, float* dgamma1, float* dbeta1, const int* dims,
+                    hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv2_bwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(xsel && scale1 && shift1 && stat1 && y2 && G2 && stat2 && coef2 && W && G1c && part1 && workspace,
@@ -924,13 +936,13 @@ int mggan_conv2_bwd(const float* xsel, int B, int C, const float* scale1,
     }
     if (C == 16)
       hipLaunchKernelGGL(conv2_bwd_mfma_kernel<16>, dim3(grid), dim3(256), lds, stream, B, xsel, scale1, shift1, stat1, y2, G2,
-                         stat2, coef2, W, G1c, part1, workspace, fin);
+                         stat2, coef2, W, G1c, part1, workspace, fin, dims);
     else
       hipLaunchKernelGGL(conv2_bwd_mfma_kernel<8>, dim3(grid), dim3(256), lds, stream, B, xsel, scale1, shift1, stat1, y2, G2,
-                         stat2, coef2, W, G1c, part1, workspace, fin);
+                         stat2, coef2, W, G1c, part1, workspace, fin, dims);
   } else
     hipLaunchKernelGGL((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1,
-                       stat1, y2, G2, stat2, coef2, W, G1c, part1, workspace, fin);
+                       stat1, y2, G2, stat2, coef2, W, G1c, part1, workspace, fin, dims);
   MG_LAUNCH_CHECK("conv2_bwd");
   if (!dW) return MGGAN_OK;  // deferred reduce of the [grid][C*C*9 + C] partial rows
   hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(1024), 0, stream, workspace, grid, wlen,

@@ -197,7 +197,8 @@ template <int C>
 __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __restrict__ img, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const float* __restrict__ gamma,
                                                          float* __restrict__ xsel, unsigned char* __restrict__ code,
-                                                         double* part, BnFin fin) {
+                                                         double* part, BnFin fin, const int* dims) {
+  MG_REAL_IMAGES_COUNT(B, dims, fin)
   __shared__ __attribute__((aligned(16))) float imgp[ILDS];
   __shared__ double redd[4][2][16];
   __shared__ double colsum[32], cred[8 * 32];
@@ -317,7 +318,9 @@ template <int C>
 __global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __restrict__ xsel,
                                                          const float* __restrict__ scale1, const float* __restrict__ shift1,
                                                          const float* __restrict__ W, const float* __restrict__ bias,
-                                                         float* __restrict__ y2, double* part, BnFin fin) {
+                                                         float* __restrict__ y2, double* part, BnFin fin,
+                                                         const int* dims) {
+  MG_REAL_IMAGES_COUNT(B, dims, fin)
   constexpr int COT = C / 4;
   __shared__ __attribute__((aligned(16))) float a1p[C * A1_PLANE];
   __shared__ double colsum[32], cred[8 * 32];
@@ -412,7 +415,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                              const float* __restrict__ scale1,
                                                              const float* __restrict__ shift1, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ y2,
-                                                             double* part, BnFin fin) {
+                                                             double* part, BnFin fin, const int* dims) {
+  MG_REAL_IMAGES_COUNT(B, dims, fin)
   constexpr int PLANE = C == 16 ? 386 : 388, KS = C / 4;
   __shared__ __attribute__((aligned(16))) float a1p[C * PLANE];
   __shared__ double redd[4][2][16];
@@ -550,7 +554,9 @@ __global__ __launch_bounds__(256) void bn_bwd_sync_finalize_kernel(CommArgs ca, 
 // reads (tap blocks 0-15, 16-31, 32-47) feed the six upper-triangle tile products of a k-step.  The four positions of
 // a k-step are (y, x), (y, x+16), (y+1, x), (y+1, x+16): with the tap-per-bank layout the two lane groups of a
 // half-wave read disjoint banks (conflict-free ds_read_b32); column 32 is swept by nine extra k-steps per image.
-__global__ __launch_bounds__(256) void image_gram_kernel(int B, const float* __restrict__ img, double* part /*[grid][6*256]*/) {
+__global__ __launch_bounds__(256) void image_gram_kernel(int B, const float* __restrict__ img, double* part /*[grid][6*256]*/,
+                                                         const int* dims) {
+  MG_REAL_IMAGES(B, dims)
   __shared__ __attribute__((aligned(16))) float imgp[GLDS];
   __shared__ double fold[4][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fi = lane & 15, fk = lane >> 4;
@@ -663,7 +669,9 @@ __global__ __launch_bounds__(256) void image_gram_finalize_kernel(const double* 
 #define CS_LD 260   // row stride of the staged codes (bytes)
 template <int C>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int B, const float* __restrict__ img, const float* __restrict__ G1c,
-                                                          const unsigned char* __restrict__ code1, double* part /*[grid][C*36]*/) {
+                                                          const unsigned char* __restrict__ code1, double* part /*[grid][C*36]*/,
+                                                          const int* dims) {
+  MG_REAL_IMAGES(B, dims)
   __shared__ __attribute__((aligned(16))) float imgp[GLDS];
   __shared__ float gs[16 * GS_LD];
   __shared__ __attribute__((aligned(16))) unsigned char cs[16 * CS_LD];
@@ -801,7 +809,7 @@ static BnFin make_fin(unsigned* ticket, double count, const float* gamma, const 
 int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float* bias, float* xsel,
                      unsigned char* code, double* part, unsigned* ticket, double count, const float* gamma,
                      const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
-                     float eps, int updates, float* scale, float* shift, float* stat, hipStream_t stream) {
+                     float eps, int updates, float* scale, float* shift, float* stat, const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv1_pool: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(img && W && bias && gamma && xsel && code && part, "conv1_pool: null pointer");
@@ -810,8 +818,8 @@ int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float
   const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
                              scale, shift, stat);
   const int grid = grid_for(B, 768);
-  if (C == 16) hipLaunchKernelGGL((conv1_pool_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin);
-  else hipLaunchKernelGGL((conv1_pool_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin);
+  if (C == 16) hipLaunchKernelGGL((conv1_pool_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, dims);
+  else hipLaunchKernelGGL((conv1_pool_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, dims);
   MG_LAUNCH_CHECK("conv1_pool");
   return MGGAN_OK;
 }
@@ -820,7 +828,7 @@ int mggan_conv2_fwd2(const float* xsel, int B, int C, const float* scale1, const
                      const float* W, const float* bias, float* y2, double* part, unsigned* ticket, double count,
                      const float* gamma, const float* beta, float* run_mean, float* run_var,
                      long long* num_batches_tracked, float momentum, float eps, int updates, float* scale, float* shift,
-                     float* stat, hipStream_t stream) {
+                     float* stat, const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv2_fwd2: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(xsel && scale1 && shift1 && W && bias && y2 && part, "conv2_fwd2: null pointer");
@@ -832,11 +840,11 @@ int mggan_conv2_fwd2(const float* xsel, int B, int C, const float* scale1, const
   static int valu = -1;  // MGGAN_CONV2_VALU=1: the register-tiled VALU kernel (A/B measurements)
   if (valu < 0) { const char* e = getenv("MGGAN_CONV2_VALU"); valu = e && e[0] == '1'; }
   if (valu) {
-    if (C == 16) hipLaunchKernelGGL((conv2_fwd2_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
-    else hipLaunchKernelGGL((conv2_fwd2_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
+    if (C == 16) hipLaunchKernelGGL((conv2_fwd2_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
+    else hipLaunchKernelGGL((conv2_fwd2_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
   } else {
-    if (C == 16) hipLaunchKernelGGL((conv2_fwd_mfma_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
-    else hipLaunchKernelGGL((conv2_fwd_mfma_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin);
+    if (C == 16) hipLaunchKernelGGL((conv2_fwd_mfma_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
+    else hipLaunchKernelGGL((conv2_fwd_mfma_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
   }
   MG_LAUNCH_CHECK("conv2_fwd2");
   return MGGAN_OK;
@@ -905,11 +913,11 @@ int mggan_bn_bwd_sync_finalize(void* const* arenas, int rank, int world, long ma
 
 /* workspace: mggan_cnn_grid(B) * 1536 doubles */
 int mggan_image_gram(const float* img, int B, double* gram, double* workspace, size_t workspace_bytes,
-                     hipStream_t stream) {
+                     const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(gram && workspace && (img || B == 0), "image_gram: null pointer");
   const int grid = grid_for(B, 768);
   MG_CHECK_ARG(workspace_bytes >= (size_t)(grid > 0 ? grid : 1) * 6 * 256 * sizeof(double), "image_gram: workspace too small");
-  if (grid > 0) hipLaunchKernelGGL(image_gram_kernel, dim3(grid), dim3(256), 0, stream, B, img, workspace);
+  if (grid > 0) hipLaunchKernelGGL(image_gram_kernel, dim3(grid), dim3(256), 0, stream, B, img, workspace, dims);
   hipLaunchKernelGGL(image_gram_finalize_kernel, dim3(96), dim3(256), 0, stream, workspace, grid, gram);
   MG_LAUNCH_CHECK("image_gram");
   return MGGAN_OK;
@@ -918,14 +926,14 @@ int mggan_image_gram(const float* img, int B, double* gram, double* workspace, s
 /* workspace: mggan_cnn_grid(B) * C * 36 doubles; dW (C,4,3,3) is ACCUMULATED into */
 int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const unsigned char* code1, const double* gram,
                       const float* W, const float* bias, const double* coefd, float* dW, double* workspace,
-                      size_t workspace_bytes, hipStream_t stream) {
+                      size_t workspace_bytes, const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv1_wgrad: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(img && G1c && code1 && gram && W && bias && coefd && dW && workspace, "conv1_wgrad: null pointer");
   const int grid = grid_for(B, 768);
   MG_CHECK_ARG(workspace_bytes >= (size_t)grid * C * 36 * sizeof(double), "conv1_wgrad: workspace too small");
-  if (C == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace);
-  else hipLaunchKernelGGL((conv1_wgrad_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace);
+  if (C == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
+  else hipLaunchKernelGGL((conv1_wgrad_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
   hipLaunchKernelGGL(conv1_wgrad_finalize_kernel, dim3(C), dim3(256), 0, stream, workspace, grid, C, gram, W, bias, coefd, dW);
   MG_LAUNCH_CHECK("conv1_wgrad");
   return MGGAN_OK;

@@ -71,6 +71,31 @@ __device__ __forceinline__ float mg_act_grad_from_out(float y, int act, float sl
   return 1.f;
 }
 
+// Padded batches (the trainer's shape buckets, mggan/abstract_train.py): a batch is padded to its bucket's pedestrian
+// count with inert "phantom" pedestrians at the end, and the kernels that mix rows (BatchNorm statistics, loss means,
+// generator counts) are told how many leading rows are real through a 16-byte record in DEVICE memory -- a replayed graph
+// reads it afresh, the launch geometry stays that of the bucket:  {int n_real; int s_real; float b_pad / n_real; pad}.
+// A null pointer means "every row is real".
+__device__ __forceinline__ int mg_real_rows(const int* dims, int n) {
+  if (!dims) return n;
+  const int r = dims[0];
+  return r < n ? (r < 0 ? 0 : r) : n;
+}
+__device__ __forceinline__ int mg_real_scenes(const int* dims, int n) {
+  if (!dims) return n;
+  const int r = dims[1];
+  return r < n ? (r < 0 ? 0 : r) : n;
+}
+// normalisers computed on the host from the padded count (1 / (c b_pad)) times this = 1 / (c n_real)
+__device__ __forceinline__ float mg_pad_corr(const int* dims) { return dims ? __int_as_float(dims[2]) : 1.f; }
+// image loops of the scene CNN kernels: only the real images, and the element count of the statistics shrinks with them
+#define MG_REAL_IMAGES(B, dims)                       \
+  const int B_padded_ = (B);                          \
+  (B) = mg_real_rows((dims), (B));
+#define MG_REAL_IMAGES_COUNT(B, dims, fin)            \
+  MG_REAL_IMAGES(B, dims)                             \
+  if ((B) != B_padded_ && B_padded_ > 0) (fin).count = (fin).count * (double)(B) / (double)B_padded_;
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
 // store (s_waitcnt vmcnt(0)), which costs a full HBM write round trip per barrier in kernels that stream
 // their saved activations out inside a time loop.

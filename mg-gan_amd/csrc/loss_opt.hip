@@ -136,8 +136,10 @@ struct GanLossArgs {
   float* total;           // A + B + grad_c * C
   double* partial;        // 3 * GAN_LOSS_MAX_WG doubles of scratch
   unsigned* ticket;       // one zero-initialised word; the kernel leaves it at zero again
+  const int* dims;        // padded batch (common.h): rows whose pedestrian (row % bmod) is a phantom take no part, the
+                          // host-side normalisers (of the padded counts) are corrected; NULL: every row is real
   float label[2], lo[2], hi[2], scale[3], sign_a, grad_c;
-  int nA, nB, nC, g, ld, kind, weighted_c;
+  int nA, nB, nC, g, ld, kind, weighted_c, bmod;
 };
 
 __device__ __forceinline__ float bce_term(int kind, float p, float y, float w, float* dp) {
@@ -170,18 +172,26 @@ __global__ __launch_bounds__(1024) void gan_losses_kernel(GanLossArgs a) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) y[q] = a.label_u[q] ? a.lo[q] + (a.hi[q] - a.lo[q]) * (*a.label_u[q]) : a.label[q];
   const int first = blockIdx.x * 1024 + t, step = gridDim.x * 1024;
+  const int bm = a.bmod > 0 ? a.bmod : 1, nr = a.dims ? mg_real_rows(a.dims, bm) : bm;  // row r <-> pedestrian r % bm
+  const float corr = mg_pad_corr(a.dims);
   for (int r = first; r < a.nA; r += step) {
-    const float w = (weighted ? invc[a.row_gen[r]] : 1.f) * a.scale[0] * a.sign_a;
+    if (a.dims && r % bm >= nr) { a.dp[r] = 0.f; continue; }
+    const float w = (weighted ? invc[a.row_gen[r]] : 1.f) * (a.scale[0] * corr) * a.sign_a;
     float d;
     acc[0] += (double)bce_term(a.kind, a.p[r], y[0], w, &d);
     a.dp[r] = d;
   }
   for (int r = first; r < a.nB; r += step) {
+    if (a.dims && r % bm >= nr) { a.dp[a.nA + r] = 0.f; continue; }
     float d;
-    acc[1] += (double)bce_term(a.kind, a.p[a.nA + r], y[1], a.scale[1], &d);
+    acc[1] += (double)bce_term(a.kind, a.p[a.nA + r], y[1], a.scale[1] * corr, &d);
     a.dp[a.nA + r] = d;
   }
   for (int r = first; r < a.nC; r += step) {
+    if (a.dims && r % bm >= nr) {
+      for (int c = 0; c < a.g; ++c) a.dlogits[(size_t)r * a.g + c] = 0.f;
+      continue;
+    }
     const float* l = a.logits + (size_t)r * a.ld;
     const int tg = a.target[r];
     float mx = -INFINITY;
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(1024) void gan_losses_kernel(GanLossArgs a) {
     float den = 0.f;
     for (int c = 0; c < a.g; ++c) den += __expf(l[c] - mx);
     const float lse = mx + __logf(den);
-    const float w = (a.weighted_c ? invc[tg] : 1.f) * a.scale[2];
+    const float w = (a.weighted_c ? invc[tg] : 1.f) * (a.scale[2] * corr);
     acc[2] += (double)(w * (lse - l[tg]));
     for (int c = 0; c < a.g; ++c)
       a.dlogits[(size_t)r * a.g + c] = a.grad_c * (w * (__expf(l[c] - lse) - (c == tg ? 1.f : 0.f)));
@@ -241,9 +251,13 @@ __global__ __launch_bounds__(1024) void gan_losses_kernel(GanLossArgs a) {
 #define L2_MAXK 256
 __global__ __launch_bounds__(256) void l2_scene_kernel(int S, int T, int K, int b, const int* __restrict__ scenes,
                                                        const float* __restrict__ gen_abs, const float* __restrict__ gt,
-                                                       float* scene_loss, int* scene_arg) {
+                                                       float* scene_loss, int* scene_arg, const int* dims) {
   __shared__ float ksum[L2_MAXK];
   const int s = blockIdx.x, grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+  if (s >= mg_real_scenes(dims, S)) {  // a phantom scene of a padded batch: no loss, no sample carries a gradient
+    if (threadIdx.x == 0) { scene_loss[s] = 0.f; scene_arg[s] = -1; }
+    return;
+  }
   const int p0 = scenes[2 * s], p1 = scenes[2 * s + 1];
   for (int k = grp; k < K; k += 8) {
     float acc = 0.f;
@@ -281,16 +295,17 @@ __global__ __launch_bounds__(256) void l2_scene_kernel(int S, int T, int K, int 
       }
       if (v < best) { best = v; bestk = vi; }
     }
-    if (lane == 0) { scene_loss[s] = best; scene_arg[s] = bestk; }
+    if (lane == 0) { scene_loss[s] = best * mg_pad_corr(dims); scene_arg[s] = bestk; }  // (the sum is divided by b_pad)
   }
 }
 
 // gabs[t][k][ped] = scale * (abs-gt)/|abs-gt| if k == argmin(scene(ped)) else 0
 __global__ void l2_grad_kernel(int T, int K, int b, const int* __restrict__ ped_scene, const int* __restrict__ scene_arg,
                                const float* __restrict__ gen_abs, const float* __restrict__ gt, float scale,
-                               float* gabs) {
+                               float* gabs, const int* dims) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)T * K * b) return;
+  scale *= mg_pad_corr(dims);
   const int ped = (int)(i % b), k = (int)((i / b) % K), t = (int)(i / ((long)b * K));
   float gx = 0.f, gy = 0.f;
   if (scene_arg[ped_scene[ped]] == k) {
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(256) void pm_ml_kernel(int b, int T, int E, int g, 
                                                     const float* __restrict__ gt, const float* __restrict__ logits,
                                                     float sigma, float scale, float* loss_rows, float* dlogits,
                                                     float* probs, double* partial, unsigned* ticket, float* out,
-                                                    float* probs_out, float probs_scale) {
+                                                    float* probs_out, float probs_scale, const int* dims) {
   __shared__ float s_lp[256];
   __shared__ double red[17][256];  // [value][pedestrian slot of this workgroup]
   __shared__ int last;
@@ -376,12 +391,19 @@ __global__ __launch_bounds__(256) void pm_ml_kernel(int b, int T, int E, int g, 
   const float cst = -__logf(sigma) - 0.91893853320467274178f;  // -log(sigma) - 0.5 log(2 pi)
   const int per = 256 / G2;  // pedestrians per workgroup pass
   const int slot = threadIdx.x / G2, gi = threadIdx.x % G2;
+  const int nr = mg_real_rows(dims, b);  // padded batch: the phantom pedestrians [nr, b) get zero rows, the means are over nr
+  scale *= mg_pad_corr(dims);
   double wsum[17];
 #pragma unroll
   for (int q = 0; q < 17; ++q) wsum[q] = 0.0;
   for (int p0 = blockIdx.x * per; p0 < b; p0 += gridDim.x * per) {
     const int ped = p0 + slot;
-    const bool ok = slot < per && ped < b && gi < g;
+    const bool ok = slot < per && ped < nr && gi < g;
+    if (slot < per && ped >= nr && ped < b && gi < g) {
+      dlogits[(size_t)ped * g + gi] = 0.f;
+      if (probs) probs[(size_t)ped * g + gi] = 0.f;
+      if (gi == 0) loss_rows[ped] = 0.f;
+    }
     float lp = 0.f;
     if (ok) {
       float acc = 0.f;
@@ -452,7 +474,7 @@ __global__ __launch_bounds__(256) void pm_ml_kernel(int b, int T, int E, int g, 
     double t = 0.0;
     for (unsigned w = 0; w < gridDim.x; ++w) t += ((volatile double*)partial)[(size_t)w * 17 + q];
     if (q == 0) *out = (float)t;
-    else if (probs_out) probs_out[q - 1] = probs_scale * (float)(t / (double)b);
+    else if (probs_out) probs_out[q - 1] = probs_scale * (float)(t / (double)(nr > 0 ? nr : 1));
   }
   if (threadIdx.x == 0) *ticket = 0u;
 }
@@ -560,11 +582,14 @@ __global__ void adam_inc_kernel(int nseg, const unsigned char* __restrict__ acti
 }
 
 // counts of generator ids (int32 atomics: exact, order independent) and their reciprocals
-__global__ __launch_bounds__(256) void count_kernel(const int* __restrict__ idx, int n, int g, int* counts) {
+__global__ __launch_bounds__(256) void count_kernel(const int* __restrict__ idx, int n, int g, int* counts,
+                                                    const int* dims, int bmod) {
   __shared__ int hist[256];
   hist[threadIdx.x] = 0;
   __syncthreads();
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) atomicAdd(&hist[idx[i]], 1);
+  const int bm = bmod > 0 ? bmod : 1, nr = dims ? mg_real_rows(dims, bm) : bm;  // row i <-> pedestrian i % bm
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    if (!dims || i % bm < nr) atomicAdd(&hist[idx[i]], 1);
   __syncthreads();
   if (threadIdx.x < g && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], hist[threadIdx.x]);
 }
@@ -984,17 +1009,17 @@ int mggan_ce_rows(int rows, int g, const float* logits, int ld, const int* targe
 }
 
 int mggan_l2_min_scene(int S, int T, int K, int b, const int* scenes, const int* ped_scene, const float* gen_abs,
-                       const float* gt, float grad_scale, float* scene_loss, int* scene_arg, float* gabs,
+                       const float* gt, float grad_scale, float* scene_loss, int* scene_arg, float* gabs, const int* dims,
                        hipStream_t stream) {
   if (S == 0) return MGGAN_OK;
   MG_CHECK_ARG(scenes && ped_scene && gen_abs && gt && scene_loss && scene_arg, "l2_min_scene: null pointer");
   MG_CHECK_ARG(K <= L2_MAXK, "l2_min_scene: %d samples per pedestrian not built (<= %d)", K, L2_MAXK);
   hipLaunchKernelGGL(l2_scene_kernel, dim3(S), dim3(256), 0, stream, S, T, K, b, scenes, gen_abs, gt, scene_loss,
-                     scene_arg);
+                     scene_arg, dims);
   MG_LAUNCH_CHECK("l2_scene");
   if (gabs) {
     hipLaunchKernelGGL(l2_grad_kernel, dim3(cdiv((long)T * K * b, 256)), dim3(256), 0, stream, T, K, b, ped_scene,
-                       scene_arg, gen_abs, gt, grad_scale, gabs);
+                       scene_arg, gen_abs, gt, grad_scale, gabs, dims);
     MG_LAUNCH_CHECK("l2_grad");
   }
   return MGGAN_OK;
@@ -1009,14 +1034,15 @@ int mggan_pm_ml_loss(int b, int T, int E, int g, const float* gen_abs, const flo
   const int per = 256 / G2;
   hipLaunchKernelGGL(pm_ml_kernel, dim3(cdiv(b, per)), dim3(256), 0, stream, b, T, E, g, G2, gen_abs, gt, logits, sigma,
                      scale, loss_rows, dlogits, probs, (double*)nullptr, (unsigned*)nullptr, (float*)nullptr,
-                     (float*)nullptr, 0.f);
+                     (float*)nullptr, 0.f, (const int*)nullptr);
   MG_LAUNCH_CHECK("pm_ml_loss");
   return MGGAN_OK;
 }
 
 int mggan_pm_ml_loss_mean(int b, int T, int E, int g, const float* gen_abs, const float* gt, const float* logits,
                           float sigma, float scale, float* loss_rows, float* dlogits, float* probs, double* partial,
-                          unsigned* ticket, float* out, float* probs_out, float probs_scale, hipStream_t stream) {
+                          unsigned* ticket, float* out, float* probs_out, float probs_scale, const int* dims,
+                          hipStream_t stream) {
   MG_CHECK_ARG(out, "pm_ml_loss_mean: null pointer");
   if (b == 0) {
     MG_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), stream), "pm_ml_loss_mean: memset");
@@ -1030,7 +1056,7 @@ int mggan_pm_ml_loss_mean(int b, int T, int E, int g, const float* gen_abs, cons
   int wgs = cdiv(b, per);
   if (wgs > PM_MAX_WG) wgs = PM_MAX_WG;
   hipLaunchKernelGGL(pm_ml_kernel, dim3(wgs), dim3(256), 0, stream, b, T, E, g, G2, gen_abs, gt, logits, sigma, scale,
-                     loss_rows, dlogits, probs, partial, ticket, out, probs_out, probs_scale);
+                     loss_rows, dlogits, probs, partial, ticket, out, probs_out, probs_scale, dims);
   MG_LAUNCH_CHECK("pm_ml_loss_mean");
   return MGGAN_OK;
 }
@@ -1068,12 +1094,13 @@ int mggan_colmean(const float* x, int rows, int g, float scale, float* out, hipS
   return MGGAN_OK;
 }
 
-int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count, hipStream_t stream) {
+int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count, const int* dims, int bmod,
+                     hipStream_t stream) {
   MG_CHECK_ARG(idx && counts && inv_count && g <= 256, "gen_counts: bad arguments");
   MG_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int) * g, stream), "gen_counts: memset");
   if (n > 0) {
     int blocks = cdiv(n, 2048);
-    hipLaunchKernelGGL(count_kernel, dim3(blocks > 64 ? 64 : blocks), dim3(256), 0, stream, idx, n, g, counts);
+    hipLaunchKernelGGL(count_kernel, dim3(blocks > 64 ? 64 : blocks), dim3(256), 0, stream, idx, n, g, counts, dims, bmod);
   }
   hipLaunchKernelGGL(inv_count_kernel, dim3(1), dim3(256), 0, stream, counts, g, inv_count);
   MG_LAUNCH_CHECK("gen_counts");

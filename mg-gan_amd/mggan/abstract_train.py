@@ -75,6 +75,16 @@ class MultiGeneratorGAN(abc.ABC):
 
     def train_iteration(self, batch, metrics):
         """Loop body of abstract_train.py:114-168 for one collated batch (already on the device)."""
+        from mggan.hip import functions as HF
+
+        pad = batch.get("pad")  # a bucket's static scene tables (IterationGraphs): the batch ends in phantom pedestrians
+        pad_was = HF.set_pad_dims(pad.dims, pad.b) if pad is not None else HF.set_pad_dims(None)
+        try:
+            self._train_iteration(batch, metrics)
+        finally:
+            HF.set_pad_dims(*pad_was)
+
+    def _train_iteration(self, batch, metrics):
         in_xy, in_dxdy = batch["in_xy"], batch["in_dxdy"]
         b = in_xy.size(1)
         sub_batches = batch["seq_start_end"] if "seq_start_end" in batch else list(zip(range(b), range(1, b + 1)))
@@ -288,7 +298,10 @@ class MultiGeneratorGAN(abc.ABC):
         kw = dict(synthetic_scenes=getattr(cfg, "synthetic_scenes", 64), synthetic_peds=getattr(cfg, "synthetic_peds", 0))
         if getattr(cfg, "cache_device", 0):
             kw["cache_device"] = self.device
-        graphs = self.iteration_graphs = IterationGraphs(self, getattr(cfg, "graph_shapes", 8)) if self.graph_mode() else None
+        pad = getattr(cfg, "graph_pad", "auto")
+        graphs = self.iteration_graphs = IterationGraphs(
+            self, getattr(cfg, "graph_shapes", 8), pad=pad, bucket=getattr(cfg, "graph_bucket", "quarter"),
+            capture=self.graph_mode()) if (self.graph_mode() or pad == "on") else None
         self.epoch_seconds, self.epoch_iterations = [], []  # wall time of the training loop of every epoch (bench.py)
         train_loader = get_dataloader(dataset=cfg.dataset, phase="train", augment=cfg.augment,
                                       batch_size=cfg.batch_size, workers=cfg.workers, shuffle=True, **kw)
@@ -404,29 +417,134 @@ class MultiGeneratorGAN(abc.ABC):
         pass
 
 
+def bucket_size(n, mode="quarter"):
+    """Smallest bucket >= n.  quarter: multiples of 8 up to 64, then four buckets per octave (64, 80, 96, 112, 128, 160,
+    ...: at most a fifth of a bucket is padding); pow2: powers of two from 8 on.  -> (bucket, the bucket below it)"""
+    n = max(int(n), 1)
+    if mode == "pow2":
+        p = 8
+        while p < n:
+            p *= 2
+        return p, (p // 2 if p > 8 else 0)
+    if n <= 64:
+        p = -(-n // 8) * 8
+        return p, p - 8
+    step = 16
+    while 8 * step < n:  # buckets (4 step, 8 step] in steps of `step`
+        step *= 2
+    p = -(-n // step) * step
+    return p, p - step
+
+
 class IterationGraphs:
-    """train()'s graph cache (reference loop: abstract_train.py:114-168).  Key = the batch's shape: its scene sizes and
-    tensor shapes.  A shape seen for the first time gets static input buffers and runs ONE eager iteration on them (which
-    also builds, and pins, every per-shape table); at its second appearance the iteration is captured (nothing executes
-    during a capture) and replayed; from then on a batch of that shape costs one copy into the static buffers and one
-    graph launch.  Batches with NaN ground truth (masked pedestrians), shapes beyond `limit` and a failed capture take
-    the eager path.  The logged losses of replayed iterations are summed on the device and read back once per epoch."""
+    """train()'s graph cache (reference loop: abstract_train.py:114-168).
+
+    Uniform batches (every scene the same size -- the synthetic benchmark shapes): key = the batch's exact shape.  A shape
+    seen for the first time gets static input buffers and runs ONE eager iteration on them (which also builds, and pins,
+    every per-shape table); at its second appearance the iteration is captured (nothing executes during a capture) and
+    replayed; from then on a batch of that shape costs one copy into the static buffers and one graph launch.
+
+    Ragged batches (the reference loader, /root/reference/mggan/data_utils/trajectories_scene.py:40-78: a new tuple of
+    scene sizes almost every batch) are padded to a SHAPE BUCKET: (pedestrians rounded up to bucket_size, scene slots,
+    largest scene rounded up to 16).  The padding consists of inert phantom pedestrians behind the real ones (constant
+    trajectories, black crops, scenes of their own): every row-wise kernel computes them like any other row, the kernels
+    that mix rows -- BatchNorm statistics of the scene CNNs, loss means, generator counts, per-scene L2 -- read the number of
+    real pedestrians / scenes from device memory (HF.StaticSceneTables.dims), and the scene tables live at fixed device
+    addresses that are re-filled for every batch (one host-to-device copy).  One captured graph per bucket then replays
+    every batch that falls into it; the results equal the unpadded iteration up to the order of the floating-point sums
+    (tests/test_train_loop.py) and are bit-identical to eager launches on the same padded batch.
+
+    Batches with NaN ground truth (masked pedestrians), shapes / buckets beyond `limit` and a failed capture take the
+    eager path.  The logged losses of replayed iterations are summed on the device and read back once per epoch."""
 
     class Entry:
         def __init__(self, static):
-            self.static, self.replay, self.failed = static, None, False
+            self.static, self.replay, self.failed, self.tables = static, None, False, None
 
-    def __init__(self, trainer, limit=8):
+    def __init__(self, trainer, limit=8, pad="auto", bucket="quarter", capture=True):
         self.tr, self.limit, self.entries = trainer, int(limit), {}
+        self.pad, self.bucket, self.capture = pad, bucket, bool(capture)
         self.pool = torch.cuda.graph_pool_handle()
         self._acc = {}  # id(snapshot buffer) -> [buffer, running sum, count, items]
-        self.replays = self.eager = 0
+        self.replays = self.eager = self.padded = 0
 
     @staticmethod
     def key_of(batch):
         sse = batch["seq_start_end"]
         return (tuple(int(e) - int(s) for s, e in sse),) + tuple(
             (k, tuple(v.shape)) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+
+    PED_AXIS = {"in_xy": 1, "in_dxdy": 1, "gt_xy": 1, "gt_dxdy": 1, "features": 0}
+
+    def bucket_of(self, batch):
+        """-> (key, b_pad, S_pad, max_n_pad) of the shape bucket a ragged batch is padded to, or None (uniform batch,
+        padding switched off or not supported by this configuration, a scene of more than 64 pedestrians, tensors the
+        padder does not know)."""
+        tr = self.tr
+        if self.pad == "off" or not (self.capture or self.pad == "on") or not tr.padding_ok():
+            return None
+        sse = [(int(s), int(e)) for s, e in batch["seq_start_end"]]
+        sizes = [e - s for s, e in sse]
+        if not sizes or len(set(sizes)) == 1 or max(sizes) > 64 or min(sizes) < 1:
+            return None
+        b = batch["in_xy"].shape[1]
+        if sse[0][0] != 0 or sse[-1][1] != b or any(sse[i][1] != sse[i + 1][0] for i in range(len(sse) - 1)):
+            return None
+        if any(torch.is_tensor(v) and k not in self.PED_AXIS for k, v in batch.items()):
+            return None
+        b_pad, below = bucket_size(b, self.bucket)
+        S_b = bucket_size(len(sse), "quarter")[0]
+        from mggan.hip.functions import StaticSceneTables
+
+        S_pad = StaticSceneTables.slots_for(S_b, b_pad, below + 1)
+        max_n = -(-max(max(sizes), StaticSceneTables.PHANTOM_SCENE) // 16) * 16
+        other = tuple((k, tuple(d for i, d in enumerate(v.shape) if i != self.PED_AXIS[k]))
+                      for k, v in sorted(batch.items()) if torch.is_tensor(v))
+        return ("pad", b_pad, S_pad, max_n) + other, b_pad, S_pad, max_n
+
+    def _padded_entry(self, key, b_pad, S_pad, max_n, batch):
+        """Static buffers of a bucket: the batch tensors at the padded size, pre-filled with the phantom pedestrians
+        (constant positions x = slot within a phantom scene, zero steps, black crops), and the static scene tables."""
+        from mggan.hip import functions as HF
+
+        tr = self.tr
+        tables = HF.StaticSceneTables(b_pad, S_pad, max_n, tr.device)
+        tables.register(tr.D.__dict__.setdefault("_pair_scenes", HF.BoundedCache(16)))
+        static = {}
+        for k, v in batch.items():
+            if not torch.is_tensor(v):
+                continue
+            ax = self.PED_AXIS[k]
+            shape = list(v.shape)
+            shape[ax] = b_pad
+            t = torch.zeros(shape, dtype=v.dtype, device=tr.device)
+            if k in ("in_xy", "gt_xy"):
+                t[..., 0] = (torch.arange(b_pad, device=tr.device) % HF.StaticSceneTables.PHANTOM_SCENE).to(v.dtype)
+            static[k] = t
+        ent = self.Entry(static)
+        ent.template = {k: t.clone() for k, t in static.items()}
+        static["seq_start_end"], static["loss_mask"], static["pad"] = tables.seq_start_end, None, tables
+        ent.tables, ent.n_loaded = tables, b_pad
+        return ent
+
+    def _load(self, ent, batch):
+        """Copy a batch into an entry's static buffers (padded entries: the real pedestrians in front, the phantom
+        pedestrians restored behind them where the previous batch was longer, the scene tables re-filled)."""
+        if ent.tables is None:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    ent.static[k].copy_(v, non_blocking=True)
+            return
+        b = batch["in_xy"].shape[1]
+        for k, v in batch.items():
+            if not torch.is_tensor(v):
+                continue
+            dst, ax = ent.static[k], self.PED_AXIS[k]
+            dst.narrow(ax, 0, b).copy_(v, non_blocking=True)
+            if ent.n_loaded > b:
+                dst.narrow(ax, b, ent.n_loaded - b).copy_(ent.template[k].narrow(ax, b, ent.n_loaded - b))
+        ent.n_loaded = b
+        ent.tables.fill(batch["seq_start_end"])
 
     def step(self, batch, metrics):
         """-> True when the batch was consumed here (eagerly on its static buffers, or as a replay)."""
@@ -440,30 +558,37 @@ class IterationGraphs:
             valid = (not gt.is_cuda) and not bool(torch.isnan(gt).any())  # (a device batch would need a sync to tell)
         if not valid:
             return False
-        key = self.key_of(batch)
+        bucket = self.bucket_of(batch)
+        if bucket is None and not self.capture:
+            return False
+        key = bucket[0] if bucket is not None else self.key_of(batch)
         ent = self.entries.get(key)
         if ent is None:
             if len(self.entries) >= self.limit:
                 return False
-            static = {k: (v.to(tr.device).clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
-            static["seq_start_end"] = [[int(s), int(e)] for s, e in batch["seq_start_end"]]  # the tables are keyed by it
-            static["loss_mask"] = None
-            ent = self.entries[key] = self.Entry(static)
+            if bucket is not None:
+                ent = self.entries[key] = self._padded_entry(*bucket, batch)
+                self._load(ent, batch)
+            else:
+                static = {k: (v.to(tr.device).clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+                static["seq_start_end"] = [[int(s), int(e)] for s, e in batch["seq_start_end"]]  # the tables are keyed by it
+                static["loss_mask"] = None
+                ent = self.entries[key] = self.Entry(static)
             with HF.pin_tables():
-                tr.train_iteration(static, metrics)
+                tr.train_iteration(ent.static, metrics)
             self.eager += 1
+            self.padded += ent.tables is not None
             return True
-        for k, v in batch.items():
-            if torch.is_tensor(v):
-                ent.static[k].copy_(v, non_blocking=True)
-        if ent.replay is None and not ent.failed:
+        self._load(ent, batch)
+        self.padded += ent.tables is not None
+        if self.capture and ent.replay is None and not ent.failed:
             try:
                 with HF.pin_tables():
                     ent.replay = tr.capture_iteration(ent.static, warmup=0, pool=self.pool)
             except Exception as exc:  # noqa: BLE001
                 ent.failed = True
                 print("[mggan] graph capture failed for batch shape {} ({}: {}); eager launches for this shape".format(
-                    key[0][:8], type(exc).__name__, exc))
+                    key[0][:8] if bucket is None else key[:4], type(exc).__name__, exc))
                 torch.cuda.synchronize()
         if ent.replay is None:
             tr.train_iteration(ent.static, metrics)

@@ -58,6 +58,27 @@ _DEBUG = {"poison": os.environ.get("MGGAN_POISON", "0") == "1", "wgrad_dump": os
           "reduce_dump": os.environ.get("MGGAN_REDUCE_DUMP", "0") == "1"}
 
 
+# Padded batches (train()'s shape buckets, abstract_train.IterationGraphs): the record {n_real, s_real, b_pad / n_real}
+# in device memory that the row-mixing kernels read (csrc/common.h); None = the batch at hand is not padded.
+_PAD = {"dims": None, "b": 0}
+
+
+def set_pad_dims(dims, b_pad=0):
+    """dims: int32 device tensor of 4 words (or None).  The trainer sets it for the duration of an iteration."""
+    was = (_PAD["dims"], _PAD["b"])
+    _PAD["dims"], _PAD["b"] = dims, int(b_pad)
+    return was
+
+
+def pad_dims():
+    return _PAD["dims"]
+
+
+def _pad_ptr(t=None):
+    t = _PAD["dims"] if t is None else t
+    return t.data_ptr() if t is not None else 0
+
+
 def poison_scratch(on=True):
     _DEBUG["poison"] = bool(on)
 
@@ -840,6 +861,113 @@ class SceneTables:
         self.seq_start_end = sse
 
 
+class StaticSceneTables:
+    """The scene tables of a SHAPE BUCKET (train()'s padded batches): fixed capacity (b_pad pedestrians, S_pad scene slots),
+    fixed device addresses, contents re-filled in place for every batch -- a captured graph reads them afresh at every replay.
+    Slots [0, s_real) are the batch's scenes, the next ones hold the phantom pedestrians [n_real, b_pad) in scenes of at most
+    PHANTOM_SCENE of them, the rest are empty (start == end == b_pad).  Only the row-structured kernels are served (scenes of
+    at most 64 pedestrians): no pair tables.  `doubled`: also the tables of the discriminator's 2b-row pair pass (rows
+    [0, b_pad) real, [b_pad, 2 b_pad) fake: the same scenes twice, discriminators.py forward_pair).
+    One packed int32 buffer: [dims 4 | scenes 2S | ped_scene b | ped_s0 b | ped_n b | scenes2 4S | ped_scene2 2b | ped_s02 2b |
+    ped_n2 2b] -- ONE host-to-device copy per batch."""
+    PHANTOM_SCENE = 16
+    static = True
+
+    class View:
+        static = True
+
+    def __init__(self, b_pad, S_pad, max_n, device):
+        import numpy as np
+
+        self.b, self.S, self.max_n, self.device = int(b_pad), int(S_pad), int(max_n), torch.device(device)
+        b, S = self.b, self.S
+        sizes = [4, 2 * S, b, b, b, 4 * S, 2 * b, 2 * b, 2 * b]
+        offs = np.concatenate([[0], np.cumsum([-(-n // 4) * 4 for n in sizes])])  # 16-byte aligned fields
+        self._off = [int(o) for o in offs]
+        total = self._off[-1]
+        # host staging: a ring of pinned buffers, each guarded by the event of its last copy (the host runs several replays
+        # ahead of the GPU: the copy of batch i may not have happened yet when batch i + 1 is laid out)
+        self._ring = [[torch.zeros(total, dtype=torch.int32).pin_memory(), None] for _ in range(8)]
+        self._turn = 0
+        self.dev = torch.zeros(total, dtype=torch.int32, device=self.device)
+        f = lambda i, n: self.dev[self._off[i]:self._off[i] + n]
+        self.dims = f(0, 4)
+        self.seq_start_end = [[0, 0] for _ in range(S)]      # the list object the trainer passes around (mutated in place)
+        self.seq_start_end2 = [[0, 0] for _ in range(2 * S)]  # ... and the pair pass's
+        one, two = self, StaticSceneTables.View()
+        one.scenes, one.ped_scene, one.ped_s0, one.ped_n = f(1, 2 * S).view(S, 2), f(2, b), f(3, b), f(4, b)
+        two.scenes, two.ped_scene, two.ped_s0, two.ped_n = f(5, 4 * S).view(2 * S, 2), f(6, 2 * b), f(7, 2 * b), f(8, 2 * b)
+        empty = torch.zeros(0, dtype=torch.int32, device=self.device)
+        for t, bb, SS, lst in ((one, b, S, self.seq_start_end), (two, 2 * b, 2 * S, self.seq_start_end2)):
+            t.P, t.b, t.S, t.max_n, t.cover, t.rows_ok = 0, bb, SS, self.max_n, True, True
+            t.pair_i = t.pair_j = empty
+            t.ped_prow = torch.zeros(bb, dtype=torch.int32, device=self.device)
+            t.seq_start_end = lst
+        self.pair = two
+        self.n_real = self.s_real = 0
+
+    @staticmethod
+    def slots_for(S_real_max, b_pad, b_min):
+        """Scene slots a bucket needs: its real scenes + the phantom scenes of its emptiest batch."""
+        ph = max(b_pad - b_min, 0)
+        return int(S_real_max) + -(-ph // StaticSceneTables.PHANTOM_SCENE)
+
+    def fill(self, seq_start_end, stream=None):
+        """Write the tables of a batch with these (real) scenes; phantom pedestrians follow the last real one."""
+        import numpy as np
+
+        sse = [(int(s), int(e)) for s, e in seq_start_end]
+        b, S, PH = self.b, self.S, self.PHANTOM_SCENE
+        n_real = sse[-1][1] if sse else 0
+        scenes = list(sse)
+        p = n_real
+        while p < b:
+            scenes.append((p, min(p + PH, b)))
+            p += PH
+        if len(scenes) > S or n_real > b or max((e - s_ for s_, e in sse), default=0) > self.max_n:
+            raise ValueError("batch does not fit its bucket ({} scenes incl. phantoms > {}, or {} pedestrians > {})".format(
+                len(scenes), S, n_real, b))
+        s_real = len(sse)
+        scenes += [(b, b)] * (S - len(scenes))
+        sc = np.asarray(scenes, np.int32).reshape(S, 2)
+        n = sc[:, 1] - sc[:, 0]
+        ped_scene = np.repeat(np.arange(S, dtype=np.int32), n)
+        ped_s0 = np.repeat(sc[:, 0], n)
+        ped_n = np.repeat(n, n).astype(np.int32)
+        slot = self._ring[self._turn]
+        self._turn = (self._turn + 1) % len(self._ring)
+        if slot[1] is not None:
+            slot[1].synchronize()
+        h, o = slot[0].numpy(), self._off
+        h[0], h[1] = n_real, s_real
+        h[2:3].view(np.float32)[0] = np.float32(b) / np.float32(max(n_real, 1))
+        h[o[1]:o[1] + 2 * S] = sc.reshape(-1)
+        h[o[2]:o[2] + b], h[o[3]:o[3] + b], h[o[4]:o[4] + b] = ped_scene, ped_s0, ped_n
+        h[o[5]:o[5] + 4 * S] = np.concatenate([sc, sc + b]).reshape(-1)
+        h[o[6]:o[6] + 2 * b] = np.concatenate([ped_scene, ped_scene + S])
+        h[o[7]:o[7] + 2 * b] = np.concatenate([ped_s0, ped_s0 + b])
+        h[o[8]:o[8] + 2 * b] = np.concatenate([ped_n, ped_n])
+        self.dev.copy_(slot[0], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        for lst, arr in ((self.seq_start_end, sc), (self.seq_start_end2, np.concatenate([sc, sc + b]))):
+            for item, (s_, e) in zip(lst, arr.tolist()):
+                item[0], item[1] = s_, e
+        self.n_real, self.s_real = n_real, s_real
+
+    def register(self, pair_cache=None):
+        """Make scene_tables() (and the discriminator's pair-pass cache) hand these tables out for the static lists."""
+        key = (id(self.seq_start_end), self.b, str(self.device))
+        _TABLE_CACHE[key] = (self.seq_start_end, self, None)
+        _TABLE_CACHE.pinned.add(key)
+        key2 = (id(self.seq_start_end2), 2 * self.b, str(self.device))
+        _TABLE_CACHE[key2] = (self.seq_start_end2, self.pair, None)
+        _TABLE_CACHE.pinned.add(key2)
+        if pair_cache is not None:
+            pair_cache[id(self.seq_start_end)] = (self.seq_start_end, self.seq_start_end2, None, True)
+            pair_cache.pinned.add(id(self.seq_start_end))
+
+
 # Per-batch index tables, row tables and random-number pools are built lazily (with host copies) and cached by shape or
 # by the identity of the caller's scene list.  A captured HIP graph holds raw pointers into them, so whatever an iteration
 # touched while `pin_tables()` was active (the trainer's graph cache: the first eager iteration on a static batch and
@@ -894,8 +1022,8 @@ def scene_tables(seq_start_end, b, device):
     key = (id(seq_start_end), b, str(device))
     hit = _TABLE_CACHE.get(key)
     fp = scene_fingerprint(seq_start_end)
-    if hit is not None and hit[0] is seq_start_end and hit[2] == fp:
-        return hit[1]
+    if hit is not None and hit[0] is seq_start_end and (hit[2] == fp or getattr(hit[1], "static", False)):
+        return hit[1]  # (static: the tables of a shape bucket, re-filled in place for every batch)
     t = SceneTables(seq_start_end, b, device)
     _TABLE_CACHE.put(key, (seq_start_end, t, fp))
     return t
@@ -1262,12 +1390,13 @@ class PoolHiddenFn(Function):
 _GRAM = {"reg": {}, "stream": None, "pending": None}
 
 
-def _gram_launch(img):
+def _gram_launch(img, dims=None):
     B = img.shape[0]
+    dims = _PAD["dims"] if dims is None else dims
     gram = torch.empty(37 * 37, dtype=torch.float64, device=img.device)
     nb = max(lib.mggan_cnn_grid(B), 1) * 1536 * 8
     ws = torch.empty(nb // 8, dtype=torch.float64, device=img.device)
-    lib.mggan_image_gram(_p(img), B, _p(gram), _p(ws), nb, _s())
+    lib.mggan_image_gram(_p(img), B, _p(gram), _p(ws), nb, _pad_ptr(dims) if dims is not None else 0, _s())
     return gram, ws
 
 
@@ -1322,7 +1451,7 @@ def end_images():
     _GRAM["pending"] = None
 
 
-def _image_gram(img):
+def _image_gram(img, dims=None):
     launch_images()  # (announced but never started: a step order the trainer did not foresee)
     hit = _GRAM["reg"].get(img.data_ptr())
     if hit is not None and hit[3].shape == img.shape:
@@ -1330,7 +1459,7 @@ def _image_gram(img):
             _cur().wait_event(hit[2])
             hit[0].record_stream(_cur())
         return hit[0]
-    return _gram_launch(img)[0]
+    return _gram_launch(img, dims)[0]
 
 
 def _cnn_tickets(owner, dev):
@@ -1386,23 +1515,27 @@ class SceneAttentionFn(Function):
             return n * hw
 
         b1 = mk()
+        dims = _PAD["dims"]  # padded batch: only the real images enter the convolutions and the statistics
+        if dims is not None and not fused:
+            raise RuntimeError("padded batches need the fused BatchNorm finalize (train mode, one GPU)")
+        pd = _pad_ptr(dims)
         lib.mggan_conv1_pool(_p(img), B, C, _p(c1w), _p(c1b), _p(xsel), _p(code), _p(part),
-                             *bn_args(bn1, g1, be1, 33 * 33, 0, b1), st)
+                             *bn_args(bn1, g1, be1, 33 * 33, 0, b1), pd, st)
         cnt1 = float(B) * 33 * 33 if fused else finalize_unfused(bn1, g1, be1, 33 * 33, b1)
         sc1, sh1, stat1 = b1
         y2 = _empty(B, C, 16, 16, like=img)
         b2 = mk()
         lib.mggan_conv2_fwd2(_p(xsel), B, C, _p(sc1), _p(sh1), _p(c2w), _p(c2b), _p(y2), _p(part),
-                             *bn_args(bn2, g2, be2, 16 * 16, 1, b2), st)
+                             *bn_args(bn2, g2, be2, 16 * 16, 1, b2), pd, st)
         cnt2 = float(B) * 16 * 16 if fused else finalize_unfused(bn2, g2, be2, 16 * 16, b2)
         sc2, sh2, stat2 = b2
         out, ld_o = _out(out_slot, B, 64, img)
-        lib.mggan_scene_attention_fwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(wa), _p(ba), _p(wb), _p(bb), _p(out), ld_o, st)
+        lib.mggan_scene_attention_fwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(wa), _p(ba), _p(wb), _p(bb), _p(out), ld_o, pd, st)
         if save:
             if not training:
                 raise RuntimeError("scene attention backward is only implemented for train-mode BatchNorm "
                                    "(the reference never differentiates in eval mode)")
-            ctx.owner, ctx.sync, ctx.counts = owner, sync, (cnt1, cnt2)
+            ctx.owner, ctx.sync, ctx.counts, ctx.dims = owner, sync, (cnt1, cnt2), dims
             ctx.save_for_backward(img, xsel, code, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b,
                                   g2, be2, wa, ba, wb, bb)
         return out
@@ -1418,6 +1551,7 @@ class SceneAttentionFn(Function):
         dev = img.device
         tk = _cnn_tickets(ctx.owner, dev)
         fused = sync is None
+        pd = _pad_ptr(ctx.dims) if ctx.dims is not None else 0
         dout, ld = _rows2d(dout)
         G2 = _empty(B, C, 16, 16, like=img)
         rows2 = max(lib.mggan_scene_attention_grid(B), 1)
@@ -1428,7 +1562,7 @@ class SceneAttentionFn(Function):
         wpart = _empty(rows2 * pf, like=img)
         lib.mggan_scene_attention_bwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(stat2), _p(wa), _p(ba), _p(wb), _p(bb), _p(dout),
                                       ld, _p(G2), _p(wpart), _p(part2), tk.data_ptr() + 8 if fused else 0, cnt2, _p(g2),
-                                      _p(coef2), root.grad_ptr(g2), root.grad_ptr(be2), st)
+                                      _p(coef2), root.grad_ptr(g2), root.grad_ptr(be2), pd, st)
         if B:
             p0 = wpart.data_ptr()
             adescs = ((p0, root.grad_ptr(wa), root.grad_ptr(ba), 32, C + 1, C),
@@ -1470,7 +1604,7 @@ class SceneAttentionFn(Function):
         lib.mggan_conv2_bwd(_p(xsel), B, C, _p(sc1), _p(sh1), _p(stat1), _p(y2), _p(G2), _p(stat2),
                             _p(coef2), _p(c2w), _p(G1c), _p(part1), 0 if defer else pw, 0 if defer else pb,
                             _p(ws), nb, tk.data_ptr() + 12 if fused else 0, cnt1, _p(g1), _p(coef1), _p(coefd1),
-                            root.grad_ptr(g1), root.grad_ptr(be1), st)
+                            root.grad_ptr(g1), root.grad_ptr(be1), pd, st)
         if defer:
             wl = C * C * 9 + C
             _queue_reduce(ws.data_ptr(), pw, 0, 1, C * C * 9, 0, C * C * 9, grid, 1, wl, keep=(ws,))
@@ -1481,11 +1615,11 @@ class SceneAttentionFn(Function):
         # db1 is identically zero in front of a train-mode BatchNorm (the slot is attached: the reference's set of
         # touched parameters includes it)
         root.grad_ptr(c1b)
-        gram = _image_gram(img)
+        gram = _image_gram(img, ctx.dims)
         nbw = max(lib.mggan_cnn_grid(B), 1) * C * 36 * 8
         wsw = torch.empty(nbw // 8, dtype=torch.float64, device=dev)
         lib.mggan_conv1_wgrad(_p(img), B, C, _p(G1c), _p(code), _p(gram), _p(c1w), _p(c1b), _p(coefd1), root.grad_ptr(c1w),
-                              _p(wsw), nbw, st)
+                              _p(wsw), nbw, pd, st)
         return (None,) * 21
 
 
@@ -2183,11 +2317,11 @@ class _GanLossArgs(ctypes.Structure):  # mirrors csrc/loss_opt.hip:GanLossArgs
                 ("seg", ctypes.c_void_p), ("inv_count", ctypes.c_void_p), ("logits", ctypes.c_void_p),
                 ("target", ctypes.c_void_p), ("dp", ctypes.c_void_p), ("dlogits", ctypes.c_void_p),
                 ("out", ctypes.c_void_p * 3), ("total", ctypes.c_void_p), ("partial", ctypes.c_void_p),
-                ("ticket", ctypes.c_void_p),
+                ("ticket", ctypes.c_void_p), ("dims", ctypes.c_void_p),
                 ("label", ctypes.c_float * 2), ("lo", ctypes.c_float * 2), ("hi", ctypes.c_float * 2),
                 ("scale", ctypes.c_float * 3), ("sign_a", ctypes.c_float), ("grad_c", ctypes.c_float),
                 ("nA", ctypes.c_int), ("nB", ctypes.c_int), ("nC", ctypes.c_int), ("g", ctypes.c_int),
-                ("ld", ctypes.c_int), ("kind", ctypes.c_int), ("weighted_c", ctypes.c_int)]
+                ("ld", ctypes.c_int), ("kind", ctypes.c_int), ("weighted_c", ctypes.c_int), ("bmod", ctypes.c_int)]
 
 
 _LOSS_SCRATCH = {}
@@ -2248,6 +2382,10 @@ class GanLossesFn(Function):
         a.total = _p(total)
         partial, ticket = _loss_scratch()
         a.partial, a.ticket = _p(partial), _p(ticket)
+        if _PAD["dims"] is not None:  # padded batch: row r of every term belongs to pedestrian r % b_pad
+            assert a.seg is None or not a.seg, "padded batches count generators without the phantom rows (inv_count)"
+            a.dims, a.bmod = _pad_ptr(), _PAD["b"]
+            assert a.bmod > 0 and a.nA % a.bmod == 0 and a.nB % a.bmod == 0 and a.nC % a.bmod == 0
         lib.mggan_gan_losses(ctypes.addressof(a), _s())
         ctx.dp, ctx.dl, ctx.shape = dp, dl, p.shape
         return total.view(())
@@ -2288,7 +2426,7 @@ class L2MinSceneFn(Function):
         scene_arg = torch.empty(tb.S, dtype=torch.int32, device=gen_abs.device)
         gabs = _empty(T, K, b, 2, like=gen_abs)
         lib.mggan_l2_min_scene(tb.S, T, K, b, _p(tb.scenes), _p(tb.ped_scene), _p(gen_abs), _p(gt), 1.0 / b_norm,
-                               _p(scene_loss), _p(scene_arg), _p(gabs), _s())
+                               _p(scene_loss), _p(scene_arg), _p(gabs), _pad_ptr(), _s())
         lib.mggan_sum(_p(scene_loss), tb.S, 1.0 / b_norm, _p(out), 0, _s())
         ctx.gabs = gabs
         return out.view(())
@@ -2312,7 +2450,7 @@ class PmMlFn(Function):
         scratch = _loss_scratch("pm", 17 * 64)
         lib.mggan_pm_ml_loss_mean(b, T, E, g, _p(gen_abs), _p(gt), _p(logits), float(sigma), 1.0 / n, _p(loss_rows),
                                   _p(dl), _p(probs), _p(scratch[0]), _p(scratch[1]), _p(out), _p(probs_out),
-                                  float(b) / n, _s())
+                                  float(b) / n, _pad_ptr(), _s())
         ctx.dl = dl
         return out.view(())
 

@@ -76,6 +76,14 @@ def get_parser():
                         help="train(): replay the iteration as a captured HIP graph per batch shape (needs --rng device; "
                              "auto = on whenever the configuration allows it), eager launches otherwise")
     parser.add_argument("--graph_shapes", type=int, default=8, help="batch shapes the graph cache of train() keeps")
+    parser.add_argument("--graph_pad", type=str, choices=["auto", "on", "off"], default="auto",
+                        help="train(): pad RAGGED batches (the reference loader's: a new tuple of scene sizes almost every "
+                             "batch) to shape buckets with inert phantom pedestrians, so that one captured graph per bucket "
+                             "replays them all.  auto: whenever graphs are replayed; on: also with --graph off (eager "
+                             "launches on the padded batches: what a replay is bit-identical to); off: exact shapes only")
+    parser.add_argument("--graph_bucket", type=str, choices=["quarter", "pow2"], default="quarter",
+                        help="bucket sizes of --graph_pad: four per octave (at most a quarter of a bucket is padding) or "
+                             "powers of two (fewer graphs, up to half)")
     parser.add_argument("--cache_device", type=int, default=0,
                         help="synthetic dataset: keep the produced batches resident in HBM after their first use")
     parser.add_argument("--synthetic_scenes", type=int, default=64, help="scenes per synthetic epoch")

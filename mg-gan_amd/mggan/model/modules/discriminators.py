@@ -109,7 +109,7 @@ class MultiDiscriminatorTrajectory(FlatModule):
         cache = self.__dict__.setdefault("_pair_scenes", HF.BoundedCache(16))
         hit = cache.get(id(seq_start_end))
         fp = HF.scene_fingerprint(seq_start_end)
-        if hit is None or hit[0] is not seq_start_end or hit[2] != fp:
+        if hit is None or hit[0] is not seq_start_end or (hit[2] != fp and len(hit) < 4):  # (4th item: a bucket's static lists)
             hit = cache.put(id(seq_start_end), (seq_start_end, [[int(s), int(e)] for s, e in seq_start_end] +
                                                 [[int(s) + b, int(e) + b] for s, e in seq_start_end], fp))
         if self.pool_type == "sways":

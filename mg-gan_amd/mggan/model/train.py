@@ -64,6 +64,17 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self._pending = []
         self._bwd_stream = None
 
+    def padding_ok(self):
+        """Can train() pad ragged batches to shape buckets (abstract_train.IterationGraphs)?  The kernels that mix rows
+        know about phantom pedestrians on the default path only: sways pooling, the fused pair pass and shared contexts,
+        'ml' PM-network target, per-scene min-over-samples L2, one GPU."""
+        cfg = self.config
+        return (cfg.pool_type == "sways" and cfg.experiment == "multi_generator" and cfg.weighting_target == "ml"
+                and cfg.l2_loss_type in ("min_g_z", "min_z", "min_g_min_z", "none") and self.gan_type in ("mgan", "gan")
+                and self.share_context and self.share_trunk and getattr(self, "pair_passes", True)
+                and int(cfg.num_unrolling_steps) == 0 and not self.dist.enabled
+                and getattr(self.rng, "on_device", False))
+
     def _set_l2_weight(self, value):
         """self.l2_weight decays per epoch (abstract_train.py:197); the backward pass reads it from device memory."""
         if self._w["l2"] is not self._one:
@@ -128,7 +139,9 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         counts = torch.empty(g, dtype=torch.int32, device=self.device)
         inv = torch.empty(g, dtype=torch.float32, device=self.device)
         st = HF._s()
-        lib.mggan_gen_counts(row_gen.data_ptr(), row_gen.numel(), g, counts.data_ptr(), inv.data_ptr(), st)
+        # (padded batch: the rows of phantom pedestrians -- row % b_pad >= n_real -- are not counted)
+        lib.mggan_gen_counts(row_gen.data_ptr(), row_gen.numel(), g, counts.data_ptr(), inv.data_ptr(), HF._pad_ptr(),
+                             HF._PAD["b"], st)
         if self.dist.enabled:
             self.dist.all_reduce_(counts)
             lib.mggan_inv_counts(counts.data_ptr(), g, inv.data_ptr(), st)
@@ -321,7 +334,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         o = dict(nA=disc_out.numel(), labels=(label_fake if obj == "MM" else label_real, None), norms=(n_rows, 0, n_rows),
                  kind=1 if obj == "LS" else 0, sign_a=-1.0 if obj == "MM" else 1.0, grad_c=float(cfg.clf_loss_weight),
                  weighted_c=True, g=self.G.n_gs, outs=(m[M_ADV:M_ADV + 1], None, m[M_CLF:M_CLF + 1] if mgan else None))
-        if rows_g is not None and rows_g.R == gen_idxs.numel() and not self.dist.enabled:
+        if rows_g is not None and rows_g.R == gen_idxs.numel() and not self.dist.enabled and HF.pad_dims() is None:
             o["row_gen"], o["seg"] = rows_g.row_gen_pos, rows_g.seg  # counts = segment lengths of the bucketed rows
         else:
             o["row_gen"], o["inv_count"] = self._gen_weights(gen_idxs)

@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _train(graph, peds, shapes=8, epochs=3, scenes=16, bs=4):
+def _train(graph, peds, shapes=8, epochs=3, scenes=16, bs=4, extra=("--graph_pad", "off")):
     from mggan.logging import Experiment
     from mggan.model.config import get_parser
     from mggan.model.model_factory import construct_model
@@ -20,7 +20,7 @@ def _train(graph, peds, shapes=8, epochs=3, scenes=16, bs=4):
     cfg = get_parser().parse_args(["--num_gens", "2", "--rng", "device", "--graph", graph, "--graph_shapes", str(shapes),
                                    "--epochs", str(epochs), "--batch_size", str(bs), "--synthetic_scenes", str(scenes),
                                    "--synthetic_peds", str(peds), "--cache_device", "1", "--val_every", "1000",
-                                   "--save_every", "1000"])
+                                   "--save_every", "1000"] + list(extra))
     torch.manual_seed(145325)
     np.random.seed(435346)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -59,6 +59,27 @@ def test_train_replays_graphs_and_matches_eager(peds, shapes):
         np.testing.assert_allclose(m_g[k], v, rtol=1e-5, atol=1e-7, err_msg=k)  # epoch mean of the logged losses
     for a, b in ((tr_g.G, tr_e.G), (tr_g.D, tr_e.D)):
         assert torch.equal(a._flat, b._flat)  # replays are bit-identical to eager launches
+
+
+@pytest.mark.parametrize("bucket,shapes,graphs", [("quarter", 2, 2), ("pow2", 2, 1)])
+def test_ragged_batches_replay_one_graph_per_bucket(bucket, shapes, graphs):
+    """The reference loader's batches (trajectories_scene.py:40-78) carry a new tuple of scene sizes almost every time: 8
+    batches per epoch of 8 scenes with 1-6 pedestrians, 22-29 pedestrians per batch.  Padded to shape buckets, a graph cache
+    of TWO shapes replays more than 90 % of the iterations, and the run is bit-identical to eager launches on the same
+    padded batches (--graph off --graph_pad on)."""
+    extra = ["--graph_pad", "on", "--graph_bucket", bucket]
+    tr_g, m_g = _train("auto", 0, shapes, epochs=4, scenes=64, bs=8, extra=extra)
+    tr_e, m_e = _train("off", 0, shapes, epochs=4, scenes=64, bs=8, extra=extra)
+    ig, ie = tr_g.iteration_graphs, tr_e.iteration_graphs
+    total = sum(tr_g.epoch_iterations)
+    assert total == 32 and len(ig.entries) == graphs and ig.padded == total and ie.padded == total
+    assert ig.replays == total - graphs and ig.replays >= 0.9 * total and ig.eager == graphs
+    assert ie.replays == 0 and ie.eager == total
+    for k, v in m_e.items():
+        assert np.isfinite(v) and np.isfinite(m_g[k]), k
+        np.testing.assert_allclose(m_g[k], v, rtol=1e-5, atol=1e-7, err_msg=k)
+    for a, b in ((tr_g.G, tr_e.G), (tr_g.D, tr_e.D)):
+        assert torch.equal(a._flat, b._flat)  # replays of a bucket's graph == eager launches on the padded batches
 
 
 def test_graph_follows_the_learning_rate_schedule():
