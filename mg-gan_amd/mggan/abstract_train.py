@@ -25,9 +25,6 @@ torch.random.manual_seed(145325)
 np.random.seed(435346)
 
 
-_LIVE_GRAPHS = []  # see _capture_graph
-
-
 class MultiGeneratorGAN(abc.ABC):
     def __init__(self, generator, discriminator, config, writer):
         self.writer = writer
@@ -207,7 +204,7 @@ class MultiGeneratorGAN(abc.ABC):
     def _capture(self, batch, warmup, pool, in_graph, HF):
         """The warm-up iterations and the capture itself.  -> (run, graph object, metrics dict of the captured iteration)"""
         scratch = defaultdict(list)
-        side = torch.cuda.Stream()
+        side = HF.role_stream("capture")  # (one per process: torch's stream pool wraps around after 32 objects)
         side.wait_stream(HF._cur())
         with torch.cuda.stream(side):
             for _ in range(warmup):
@@ -216,9 +213,8 @@ class MultiGeneratorGAN(abc.ABC):
         self.flush_metrics()
         captured = defaultdict(list)
         it0 = self.total_iterations  # the captured iteration executes nothing: it does not count (the replays do)
-        # no cyclic garbage collection while a stream is capturing: a collection that finalises an older trainer's graphs,
-        # streams or events in the middle of a capture calls HIP entry points that are not allowed there (seen as an abort
-        # inside "Garbage-collecting" when a capture followed tests that left such cycles behind)
+        # no cyclic garbage collection while a stream is capturing: a collection that finalises an older trainer's graphs
+        # or events in the middle of a capture calls HIP entry points that are not allowed there
         import gc
 
         gc.collect()
@@ -250,7 +246,6 @@ class MultiGeneratorGAN(abc.ABC):
                     self.dist.recorder = None
             HF._cur().wait_stream(side)
             run, graph = rec.replay, rec
-            _LIVE_GRAPHS.append(rec)
             self.launch_mode = "{} hipGraph segments per iteration, collectives between them".format(rec.n_graphs)
         else:
             graph = torch.cuda.CUDAGraph()
@@ -268,11 +263,6 @@ class MultiGeneratorGAN(abc.ABC):
             if dot:
                 graph.debug_dump(dot)
             run = graph.replay
-            # Instantiated multi-stream graphs are never destroyed while the process lives.  hipGraphLaunch of a LATER graph
-            # segfaulted in hip::Graph::UpdateStreams (ROCm 7.0 runtime inside torch 2.10) after earlier graph execs with
-            # parallel branches had been destroyed (rocgdb backtrace, tests/test_hip_graph.py + tests/test_train_loop.py in
-            # one process); keeping the few graphs a process captures alive costs their (shared) scratch pools only.
-            _LIVE_GRAPHS.append(graph)
             self.launch_mode = "hipGraph replay of the whole iteration" + (
                 ", peer-mapped all-reduce kernels inside it" if in_graph else "")
         return run, graph, captured

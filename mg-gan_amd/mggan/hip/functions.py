@@ -79,6 +79,28 @@ def _pad_ptr(t=None):
     return t.data_ptr() if t is not None else 0
 
 
+# torch.cuda.Stream() hands out the streams of a pool of 32 per device round-robin: the 33rd object ALIASES the first.
+# A trainer that made two streams of its own per capture (the capture stream, the backward stream) reached that after 16
+# captures in one process, the capture stream then WAS one of the branch streams, and hipStreamEndCapture segfaulted
+# (a stream forked from itself).  Every stream role is therefore created once per process and device, here.
+_ROLE_STREAMS = {}
+
+
+def role_stream(role):
+    key = (role, torch.cuda.current_device())
+    st = _ROLE_STREAMS.get(key)
+    if st is None:
+        taken = {s.cuda_stream for s in _ROLE_STREAMS.values()}
+        for _ in range(64):  # (a pool slot another role already holds is skipped)
+            st = torch.cuda.Stream()
+            if st.cuda_stream not in taken:
+                break
+        else:
+            raise RuntimeError("no free HIP stream for role {!r}".format(role))
+        _ROLE_STREAMS[key] = st
+    return st
+
+
 def poison_scratch(on=True):
     _DEBUG["poison"] = bool(on)
 
@@ -140,7 +162,7 @@ def enable_side_stream(on=True):
 
 def _side_stream():
     if _SIDE["stream"] is None:
-        _SIDE["stream"] = torch.cuda.Stream()
+        _SIDE["stream"] = role_stream("wgrad-side")
     return _SIDE["stream"]
 
 
@@ -227,7 +249,7 @@ class branch:
             return self
         side = _BR["streams"].get(self.which)
         if side is None:
-            side = _BR["streams"][self.which] = torch.cuda.Stream()
+            side = _BR["streams"][self.which] = role_stream(("branch", self.which))
             _BR["raw"][side.cuda_stream] = self.which
         if _on_branch():
             return self
@@ -1418,7 +1440,7 @@ def begin_images(img, side=True, defer=False):
 def _start_gram(img, side=True, after_branches=()):
     if side and _BR["on"]:
         if _GRAM["stream"] is None:
-            _GRAM["stream"] = torch.cuda.Stream()
+            _GRAM["stream"] = role_stream("gram")
         st = _GRAM["stream"]
         st.wait_stream(_cur())
         for w in after_branches:  # ... and behind what those branch streams have queued (without joining them)

@@ -161,7 +161,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                 # branch streams (the scene CNN's convolution adjoints) instead of behind it.
                 main = HF._cur()
                 if self._bwd_stream is None:
-                    self._bwd_stream = torch.cuda.Stream()
+                    self._bwd_stream = HF.role_stream("backward")
                 self._bwd_stream.wait_stream(main)
                 with torch.cuda.stream(self._bwd_stream), torch.autograd.set_multithreading_enabled(False):
                     torch.autograd.backward(losses, grads)
