@@ -106,8 +106,10 @@ def _worker(rank, world, port, q):
     q.put((rank, "ok"))
 
 
-def test_two_rank_gloo_sharded_equals_single_process():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_sharded_equals_single_process(world):
+    """world 2 and world 4 (six scenes over four ranks: uneven shards, 1-2 scenes each)."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -117,4 +119,4 @@ def test_two_rank_gloo_sharded_equals_single_process():
         p.join(180)
         assert p.exitcode == 0, p.exitcode
     got = sorted(q.get(timeout=5) for _ in range(world))
-    assert got == [(0, "ok"), (1, "ok")]
+    assert got == [(r, "ok") for r in range(world)]
