@@ -37,7 +37,6 @@ def kernel_of(name, a):
     summaries under profiles/ name it."""
     fixed = {
         "mggan_decoder_rollout_bwd_fused": "decoder_bwd_mfma_kernel",
-        "mggan_decoder_rollout_fwd": "decoder_fwd_mfma_kernel",
         "mggan_wgrad_multi": "wgrad_stream_kernel",  # <0> feature-major + <2> row-major launches of one batch
         "mggan_wgrad": "gemm_kernel<true,true,false>",
         "mggan_linear_fwd": "gemm_kernel<false,false,false>",
@@ -46,6 +45,10 @@ def kernel_of(name, a):
     }
     if name in fixed:
         return fixed[name]
+    if name == "mggan_decoder_rollout_fwd":  # (one wave per tile from 65,536 rollout rows on, csrc/lstm.hip)
+        return "decoder_fwd_wave_kernel" if a[0] >= 65536 and os.environ.get("MGGAN_DEC_FWD") != "4" else "decoder_fwd_mfma_kernel"
+    if name in ("mggan_social_rows_fwd", "mggan_social_rows_bwd"):
+        return name[len("mggan_"):] + "_kernel"
     if name == "mggan_conv1_pool":
         return "conv1_pool_kernel<{}>".format(a[2])
     if name == "mggan_conv2_fwd2":

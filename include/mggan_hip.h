@@ -482,6 +482,9 @@ int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, cons
  * mggan_decoder_bwd_fused_layout); reduce them with mggan_grad_reduce_multi (groups = n_gens, splits = NW).
  * dEnc (R, EIN) = dH0 We2d[:, :EIN], or NULL: the caller folds dH0 over the rows of a pedestrian and multiplies once
  * per pedestrian (the adjoint of the Qe form of mggan_decoder_rollout_fwd). */
+/* floats of padding between the tile records of the rollout's saved state: Gt is tiles x (T*H*64 + gt_pad) floats, Cs
+ * tiles x ((T+1)*H*32 + cs_pad) (see mggan_decoder_rollout_fwd) */
+int mggan_decoder_save_pads(int* gt_pad, int* cs_pad);
 int mggan_decoder_bwd_fused_layout(int* wlen, int* off_A, int* off_bias, int* off_W1, int* off_b1, int* off_W2,
                                    int* off_b2);
 int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, int Z, const int* seg, const int* row_pos,

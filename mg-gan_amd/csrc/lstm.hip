@@ -494,6 +494,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // with tiles = sum_g ceil(rows_g / 16) <= ceil(R/16) + n_gens.  Rows past a generator's end compute on a clamped
 // duplicate and ARE saved (finite values the backward kernel multiplies by zero).
 #define DEC_HLD 36  // LDS h tile row stride in floats (16-byte aligned rows, conflict-light)
+// Optional padding between the tile records of the saved state (floats, multiples of 4).  A tile's record starts a multiple
+// of 96 KB (gates) / 52 KB (cell state) after the first; padding them apart (272 / 144 floats) to spread workgroups that
+// walk their tiles in step over the memory channels was measured and changes nothing (576 vs 571-591 us): 0 by default.
+#ifndef DEC_GT_PAD
+#define DEC_GT_PAD 0
+#endif
+#ifndef DEC_CS_PAD
+#define DEC_CS_PAD 0
+#endif
 
 // Q^T [32 x 16 pedestrians] = W_e2d[:, :EIN] enc_h^T + b: one wave per 16-pedestrian tile, both unit tiles
 __global__ __launch_bounds__(256) void e2d_shared_kernel(const float* __restrict__ enc_h, int ld_enc, int b, int EIN,
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       if (save) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float2*>(p.Cs + ((tg * (p.T + 1) * H + 8 * w + 4 * fk + q) * 16 + fi) * 2) = float2{0.f, hacc[q]};
+          *reinterpret_cast<float2*>(p.Cs + tg * DEC_CS_PAD + ((tg * (p.T + 1) * H + 8 * w + 4 * fk + q) * 16 + fi) * 2) = float2{0.f, hacc[q]};
       }
     }
     // ---- time-invariant social half of hidden2pos: q = W1[:, H:] soc + b1 (every wave) ----
@@ -681,8 +690,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float hn = g[3] * mg_tanh(c[mt]);
         hw[fi * DEC_HLD + uj[mt]] = hn;
         if (save) {
-          *reinterpret_cast<f32x4*>(p.Gt + ((tt * H + uj[mt]) * 16 + fi) * 4) = g;
-          *reinterpret_cast<float2*>(p.Cs + ((tc * H + uj[mt]) * 16 + fi) * 2) = float2{c[mt], hn};
+          *reinterpret_cast<f32x4*>(p.Gt + tg * DEC_GT_PAD + ((tt * H + uj[mt]) * 16 + fi) * 4) = g;
+          *reinterpret_cast<float2*>(p.Cs + tg * DEC_CS_PAD + ((tc * H + uj[mt]) * 16 + fi) * 2) = float2{c[mt], hn};
         }
       }
       if (save && w == 0 && fk == 0) *reinterpret_cast<float2*>(p.Din + (tt * 16 + fi) * 2) = float2{d0, d1};
@@ -724,6 +733,186 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       d0 = n0; d1 = n1;
       x0 += n0; x1 += n1;
       if (valid && w == 0 && fk == 0) {
+        const size_t o = ((size_t)t * p.Rout + pos) * 2;
+        *reinterpret_cast<float2*>(p.out_abs + o) = float2{x0, x1};
+        *reinterpret_cast<float2*>(p.out_rel + o) = float2{n0, n1};
+      }
+    }
+  }
+}
+
+// ---- the rollout forward, ONE WAVE per 16-row tile ------------------------------------------------------------
+// The four-wave kernel above splits the 32 hidden units of a tile over four waves: every step ends in an LDS exchange of
+// h and a barrier, every wave repeats the position head, and a workgroup's waves wait for each other's transcendentals.
+// Here a wave owns ALL 32 units of its 16 rows and nothing leaves its registers:
+//   * gates: G^T[128 x 16] = [W_hh | A | b] [h ; d ; 1] as 8 M tiles x 9 k steps of v_mfma_f32_16x16x4_f32.  A row of tile t
+//     is (gate fi & 3, unit 4 t + (fi >> 2)), so the D fragment of lane (row n, group fk) is the four gates of unit 4 t + fk:
+//     the cell update is lane-local, and the lane ends up with h of the units 4 t + fk, t = 0..7.
+//   * the reduction index of an MFMA may be permuted freely as long as both operands agree: k step ks, group fk <-> unit
+//     4 ks + fk.  The B operand of the NEXT step's products (h[unit 4 ks + fk][n]) is then exactly the value the lane just
+//     computed for tile ks -- the D fragment of one step is the B operand of the next, with no LDS, no barrier, no shuffle.
+//   * the folded input embedding (two coefficients per gate row) and the bias ride as a ninth k step against [d0, d1, 1, 0]
+//     instead of 96 coefficient registers and three FMAs per gate.
+//   * the position head's hidden layer u = W1[:, :H] h + q is one more M tile over the same B operands (8 MFMAs per wave
+//     and step instead of 8 per wave in each of four waves).
+// 80 MFMAs per wave and step for 16 rows (four-wave kernel: 4 x 24 = 96), eight independent accumulator chains, and the
+// waves of a SIMD belong to different tiles: one wave's MFMAs run under another's cell update.  The saved state has the
+// layout of the four-wave kernel (the adjoint below reads it unchanged).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void decoder_fwd_wave_kernel(DecFwdArgs p) {
+  constexpr int H = 32, G4 = 128, Hh = 16;
+  const int gi = blockIdx.x / p.NW, wi = blockIdx.x % p.NW;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
+  const float* P = p.prep + (size_t)gi * p.prep_stride;
+  const float* WT = P + prep_off_whhT(H);
+  const float* w1T = P + prep_off_w1T(H);
+  const float* b1 = w1T + 2 * H * Hh;
+  const float* w2 = b1 + Hh;
+  const float* b2 = w2 + 2 * Hh;
+  const int seg0 = p.seg[gi], seg1 = p.seg[gi + 1];
+  const int ntiles = (seg1 - seg0 + 15) / 16;
+  if (wi * 4 + w >= ntiles) return;  // (no barrier anywhere below: a wave may leave on its own)
+  const bool save = p.Gt != nullptr;
+  const int IN = p.EIN + p.Z;
+  const int tbase = save ? dec_tile_base(p.seg, gi) : 0;
+  // ---- loop-invariant A operands (this generator's weights; L2-resident) ----
+  float Ag[8][9], Au[8];
+  {
+    const int grow = (fi & 3) * H + (fi >> 2);  // + 4 t: gate row of W_hh / A / bias this lane supplies for tile t
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) Ag[t][ks] = WT[(4 * ks + fk) * G4 + grow + 4 * t];
+      const int m = grow + 4 * t;
+      Ag[t][8] = fk == 0 ? P[prep_off_A(H) + 2 * m] : fk == 1 ? P[prep_off_A(H) + 2 * m + 1]
+                 : fk == 2 ? P[prep_off_bias(H) + m] : 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) Au[ks] = w1T[(4 * ks + fk) * Hh + fi];
+  }
+  float w2r[2][4], b1r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    w2r[0][q] = w2[4 * fk + q];
+    w2r[1][q] = w2[Hh + 4 * fk + q];
+    b1r[q] = b1[4 * fk + q];
+  }
+  const float b20 = b2[0], b21 = b2[1];
+
+  for (int tile = wi * 4 + w; tile < ntiles; tile += p.NW * 4) {
+    const int r = seg0 + tile * 16 + fi;
+    const bool valid = r < seg1;
+    const int rc = valid ? r : seg1 - 1;
+    const int ped = p.row_ped[rc], slot = p.row_slot[rc], pos = p.row_pos[rc];
+    const bool sv = save && valid;
+    const size_t tg = (size_t)(tbase + tile);
+    // ---- h0 = W_e2d [enc_h | noise] + b_e2d (standard.py:247-252): two M tiles whose rows are permuted so that the D
+    //      fragment of lane (n, fk) holds the units 4 t + fk (row 4 fk' + r of tile j <-> unit 4 (r + 4 j) + fk') ----
+    f32x4 h0a[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int urow[2] = {4 * (fi & 3) + (fi >> 2), 4 * ((fi & 3) + 4) + (fi >> 2)};  // A row fi of tile j <-> this unit
+    if (p.Qe) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h0a[j][q] = p.Qe[(size_t)ped * H + 4 * (q + 4 * j) + fk];  // (carries the bias)
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h0a[j][q] = p.be2d[4 * (q + 4 * j) + fk];
+    }
+    for (int kb = p.Qe ? p.EIN / 4 : 0; 4 * kb < IN; ++kb) {  // k step kb: inputs 4 kb + fk
+      const int k = 4 * kb + fk;
+      float x = 0.f;
+      if (k < p.EIN) x = p.enc_h[(size_t)ped * p.ld_enc + k];
+      else if (k < IN) x = p.noise[((size_t)slot * p.b + ped) * p.Z + (k - p.EIN)];
+      if (sv && k < IN) {
+        if (p.Qe) p.Nz[(size_t)r * p.Z + (k - p.EIN)] = x;
+        else p.E2Din[(size_t)r * IN + k] = x;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) h0a[j] = MFMA16(k < IN ? p.We2d[(size_t)urow[j] * IN + k] : 0.f, x, h0a[j]);
+    }
+    float h[8], c[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      h[t] = h0a[t >> 2][t & 3];
+      c[t] = 0.f;
+    }
+    if (save) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        *reinterpret_cast<float2*>(p.Cs + tg * DEC_CS_PAD + ((tg * (p.T + 1) * H + 4 * t + fk) * 16 + fi) * 2) = float2{0.f, h[t]};
+    }
+    // ---- time-invariant social half of hidden2pos: q = W1[:, H:] soc + b1 ----
+    f32x4 qv = f32x4{b1r[0], b1r[1], b1r[2], b1r[3]};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float sx = p.soc[(size_t)ped * p.ld_soc + 4 * ks + fk];
+      if (sv) p.SocR[(size_t)r * H + 4 * ks + fk] = sx;
+      qv = MFMA16(w1T[(H + 4 * ks + fk) * Hh + fi], sx, qv);
+    }
+    float d0 = p.dxdy0[ped * 2], d1 = p.dxdy0[ped * 2 + 1];
+    float x0 = p.xy0[ped * 2], x1 = p.xy0[ped * 2 + 1];
+
+    f32x4 gS[8];  // the gates of the previous step, stored one step late (see below)
+    for (int t = 0; t < p.T; ++t) {
+      const size_t tt = tg * p.T + t, tc = tg * (p.T + 1) + t + 1;
+      // gates of this step from h_{t-1} (the lane's own values are the B operands) and the last displacement
+      const float din = fk == 0 ? d0 : fk == 1 ? d1 : fk == 2 ? 1.f : 0.f;
+      f32x4 G[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) G[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) G[u] = MFMA16(Ag[u][ks], h[ks], G[u]);
+        // the saved state of step t-1 leaves HERE, one unit per k step, between the matrix instructions of step t
+        // (instead of 16 stores in one burst behind the cell update)
+        if (save && t > 0) {
+          *reinterpret_cast<f32x4*>(p.Gt + tg * DEC_GT_PAD + (((tt - 1) * H + 4 * ks + fk) * 16 + fi) * 4) = gS[ks];
+          *reinterpret_cast<float2*>(p.Cs + tg * DEC_CS_PAD + (((tc - 1) * H + 4 * ks + fk) * 16 + fi) * 2) = float2{c[ks], h[ks]};
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) G[u] = MFMA16(Ag[u][8], din, G[u]);
+      if (save && fk == 0) *reinterpret_cast<float2*>(p.Din + (tt * 16 + fi) * 2) = float2{d0, d1};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        f32x4 g = G[u];
+        g[0] = mg_sigmoid(g[0]); g[1] = mg_sigmoid(g[1]); g[2] = mg_tanh(g[2]); g[3] = mg_sigmoid(g[3]);
+        c[u] = fmaf(g[1], c[u], g[0] * g[2]);
+        h[u] = g[3] * mg_tanh(c[u]);
+        gS[u] = g;
+      }
+      if (save && t == p.T - 1) {  // the last step's record has no next step to hide under
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          *reinterpret_cast<f32x4*>(p.Gt + tg * DEC_GT_PAD + ((tt * H + 4 * u + fk) * 16 + fi) * 4) = gS[u];
+          *reinterpret_cast<float2*>(p.Cs + tg * DEC_CS_PAD + ((tc * H + 4 * u + fk) * 16 + fi) * 2) = float2{c[u], h[u]};
+        }
+      }
+      // u = LeakyReLU(W1[:, :H] h_t + q): lane (n, fk) holds hidden units 4 fk + r of row n
+      f32x4 ua = qv, ub = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks += 2) {
+        ua = MFMA16(Au[ks], h[ks], ua);
+        ub = MFMA16(Au[ks + 1], h[ks + 1], ub);
+      }
+      f32x4 av;
+      float n0 = 0.f, n1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float uu = ua[q] + ub[q];
+        av[q] = uu > 0.f ? uu : 0.01f * uu;  // LeakyReLU(0.01), utils.py:143-144
+        n0 = fmaf(w2r[0][q], av[q], n0);
+        n1 = fmaf(w2r[1][q], av[q], n1);
+      }
+      if (save) *reinterpret_cast<f32x4*>(p.Aact + ((tt * 4 + fk) * 16 + fi) * 4) = av;
+      n0 = quarters_sum(n0) + b20;  // v_permlane{16,32}_swap: the four lane groups hold the four unit quarters
+      n1 = quarters_sum(n1) + b21;
+      d0 = n0; d1 = n1;
+      x0 += n0; x1 += n1;
+      if (valid && fk == 0) {
         const size_t o = ((size_t)t * p.Rout + pos) * 2;
         *reinterpret_cast<float2*>(p.out_abs + o) = float2{x0, x1};
         *reinterpret_cast<float2*>(p.out_rel + o) = float2{n0, n1};
@@ -874,8 +1063,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const size_t tt = tg * p.T + t, tc = tg * (p.T + 1) + t;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        n_g[mt] = *reinterpret_cast<const f32x4*>(p.Gt + ((tt * H + uj[mt]) * 16 + fi) * 4);
-        n_ch[mt] = *reinterpret_cast<const float2*>(p.Cs + ((tc * H + uj[mt]) * 16 + fi) * 2);  // (c_{t-1}, h_{t-1})
+        n_g[mt] = *reinterpret_cast<const f32x4*>(p.Gt + tg * DEC_GT_PAD + ((tt * H + uj[mt]) * 16 + fi) * 4);
+        n_ch[mt] = *reinterpret_cast<const float2*>(p.Cs + tg * DEC_CS_PAD + ((tc * H + uj[mt]) * 16 + fi) * 2);  // (c_{t-1}, h_{t-1})
       }
       n_av = *reinterpret_cast<const f32x4*>(p.Aact + ((tt * 4 + fk) * 16 + fi) * 4);
       const float* din = p.Din + (tt * 16 + fi) * 2;
@@ -887,7 +1076,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     lds_barrier();  // the previous tile's last LDS reads are done
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const float2 ch = *reinterpret_cast<const float2*>(p.Cs + (((tg * (p.T + 1) + p.T) * H + uj[mt]) * 16 + fi) * 2);
+      const float2 ch = *reinterpret_cast<const float2*>(p.Cs + tg * DEC_CS_PAD + (((tg * (p.T + 1) + p.T) * H + uj[mt]) * 16 + fi) * 2);
       cc[mt] = ch.x;
       hts[p.T % 3][fi * DB_HS + uj[mt]] = ch.y;  // h_{T-1}
     }
@@ -1225,8 +1414,29 @@ int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const 
   // an uneven draw does not send some workgroups through a second tile; a workgroup without a tile leaves at once.
   const int per_gen = cdiv(R, 16) + 1;
   p.NW = per_gen < 1 ? 1 : (per_gen > 2048 / n_gens ? (2048 / n_gens > 0 ? 2048 / n_gens : 1) : per_gen);
-  hipLaunchKernelGGL(decoder_fwd_mfma_kernel, dim3(n_gens * p.NW), dim3(256), 0, stream, p);
+  // Two kernels.  Four waves per tile (a tile's 32 units over four waves, LDS exchange + barrier per step): the shorter
+  // dependency chain per tile, best while the launch is a latency chain (8,192 rows: 34 us against 67).  One wave per tile
+  // (decoder_fwd_wave_kernel: nothing leaves the registers, 80 instead of 96 MFMAs per 16 rows and step): best once there
+  // are several tiles per SIMD -- alone on the GPU at 163,840 rows 0.31 ms against 0.41-0.54 without the saved state, 0.45
+  // against 0.51 with it.  MGGAN_DEC_FWD = 4 | 1 forces one of them (A/B measurements).
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("MGGAN_DEC_FWD"); force = e && (e[0] == '4' || e[0] == '1') ? e[0] - '0' : 0; }
+  const bool wave = force ? force == 1 : R >= 65536;
+  if (!wave) {
+    hipLaunchKernelGGL(decoder_fwd_mfma_kernel, dim3(n_gens * p.NW), dim3(256), 0, stream, p);
+  } else {
+    // a wave per tile: four tiles per workgroup, the same persistent-grid rule in workgroups of four tiles
+    const int per_gen4 = cdiv(cdiv(R, 16) + 1, 4);
+    const int cap = 1024 / n_gens > 0 ? 1024 / n_gens : 1;
+    p.NW = per_gen4 < 1 ? 1 : (per_gen4 > cap ? cap : per_gen4);
+    hipLaunchKernelGGL(decoder_fwd_wave_kernel, dim3(n_gens * p.NW), dim3(256), 0, stream, p);
+  }
   MG_LAUNCH_CHECK("decoder_rollout_fwd");
+  return MGGAN_OK;
+}
+
+int mggan_decoder_save_pads(int* gt_pad, int* cs_pad) {
+  *gt_pad = DEC_GT_PAD; *cs_pad = DEC_CS_PAD;
   return MGGAN_OK;
 }
 

@@ -1700,6 +1700,17 @@ def _fused_layout():
     return _FUSED_LAYOUT
 
 
+_SAVE_PADS = []
+
+
+def _save_pads():
+    if not _SAVE_PADS:
+        a, b = ctypes.c_int(), ctypes.c_int()
+        lib.mggan_decoder_save_pads(ctypes.byref(a), ctypes.byref(b))
+        _SAVE_PADS.extend((a.value, b.value))
+    return _SAVE_PADS
+
+
 E2D_SHARED_MIN_ROWS = int(os.environ.get("MGGAN_E2D_SHARED_MIN_ROWS", "4096"))
 
 
@@ -1730,7 +1741,8 @@ class DecoderRolloutFn(Function):
         mk = (lambda *s: _empty(*s, like=enc_h)) if save else (lambda *s: None)
         # tile-blocked saves (16-row tiles, every generator's last tile padded): gates, (c, h) with slot 0 = (0, h_0), ...
         tiles = -(-R // 16) + n_gens
-        Gt, Cs = mk(tiles, T, H, 16, 4), mk(tiles, T + 1, H, 16, 2)
+        gt_pad, cs_pad = _save_pads()  # (tile records padded apart: csrc/lstm.hip DEC_GT_PAD)
+        Gt, Cs = mk(tiles, T * H * 64 + gt_pad), mk(tiles, (T + 1) * H * 32 + cs_pad)
         # h0 = W_e2d [enc_h | noise] + b: the enc_h part is the pedestrian's, the same for its K rows and for every
         # generator -> once per pedestrian (Qe), the rows multiply their noise columns only and keep those (Nz)
         # (worth its extra launch from a few rows per pedestrian and a few thousand rows on)

@@ -120,7 +120,10 @@ def test_padded_steps_equal_the_unpadded_ones(sizes, g):
             assert abs(m_b[k] - v) <= 1e-5 * abs(v) + 1e-7, (step, k, m_b[k], v)
         top = max(float(v.abs().max()) for v in g_a.values())
         for n, r in g_a.items():
-            scale = max(float(r.abs().max()), 1e-4 * top)
+            if float(r.abs().max()) < 1e-4 * top:  # structurally zero up to round-off (a conv bias before BatchNorm)
+                assert float(g_b[n].abs().max()) <= 1e-3 * top, (step, n)
+                continue
+            scale = float(r.abs().max())
             assert float((g_b[n] - r).abs().max()) <= 1e-5 * scale + 1e-9, (step, n, float((g_b[n] - r).abs().max()), scale)
 
     tr_a, _ = _trainer(g)
