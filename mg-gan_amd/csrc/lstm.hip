@@ -1465,6 +1465,9 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
   p.e2ld = EIN + ((10 - EIN % 8) % 8);  // == 2 mod 8: the A-fragment reads (row 8 fk + ks) hit four 16-bank groups
   const size_t dyn = sizeof(float) * ((size_t)H * p.e2ld + (H / 2) * 36);
   MG_CHECK_ARG(dyn <= 64 * 1024, "decoder_rollout_bwd_fused: encoder width %d too large for the staged epilogue", EIN);
+  // (One wave per tile, as in decoder_fwd_wave_kernel, was written and measured for this kernel too -- correct, ~500 registers,
+  //  one wave per SIMD: 0.87 vs 0.79 ms at 163,840 rows and 180 vs 143 us at 25,600; with nothing else resident on its
+  //  SIMD a wave exposes every dependent latency of the gate arithmetic.  Not kept)
   hipLaunchKernelGGL(decoder_bwd_mfma_kernel, dim3(n_gens * NW), dim3(256), dyn, stream, p);
   MG_LAUNCH_CHECK("decoder_rollout_bwd_fused");
   return MGGAN_OK;
