@@ -337,6 +337,65 @@ __device__ __forceinline__ void grad_reduce_chunk(const ReduceDesc& D, const int
   }
 }
 
+// Tall and narrow buffers (hundreds of partial blocks of a few hundred outputs: the per-workgroup partials of the scene CNN
+// and the attention kernels, the slabs of the small products at 1,280 pedestrians): a chunk of 64 outputs, a lane = four
+// outputs (cg = lane & 15) of one of FOUR rows a wave reads at once (rg = lane >> 4): 32 rows in flight per workgroup
+// pass instead of 8, four times the workgroups.  (With 256-output chunks these buffers made the launch 25-29 us at
+// 1,280 pedestrians, where round 3's kernel took 15.)
+template <bool VEC>
+__device__ __forceinline__ void grad_reduce_chunk_tall(const ReduceDesc& D, const int grp, const int c0, const int total,
+                                                       float (*red)[256]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, cg = lane & 15, rg = lane >> 4;
+  constexpr int RG = 4 * MG_RED_WAVES;  // row groups per workgroup
+  f32x4 a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int c = c0 + 4 * cg;
+  const float* p = D.P + ((size_t)grp * D.splits) * D.p_stride + c;
+  const size_t ps = (size_t)D.p_stride;
+  bool in[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) in[e] = c + e < total;
+  auto ld = [&](int z) -> f32x4 {
+    const float* q = p + (size_t)z * ps;
+    if (VEC) return in[0] ? *reinterpret_cast<const f32x4*>(q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    return f32x4{in[0] ? q[0] : 0.f, in[1] ? q[1] : 0.f, in[2] ? q[2] : 0.f, in[3] ? q[3] : 0.f};
+  };
+  int z = 4 * w + rg;
+  for (; z + RG * 7 < D.splits; z += RG * 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += ld(z + RG * u);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (z + RG * u < D.splits) a[u] += ld(z + RG * u);
+  const f32x4 s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  // LDS: red[wave][rg * 64 + 4 cg + e]
+  *reinterpret_cast<f32x4*>(&red[w][64 * rg + 4 * cg]) = s;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int o = c0 + threadIdx.x;
+    if (o < total) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < MG_RED_WAVES; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t += red[i][64 * r + threadIdx.x];
+      const int m = o / D.Naug, n = o - m * D.Naug;
+      const bool overwrite = (D.has_bias & 2) != 0;
+      if ((D.has_bias & 1) && n == D.Naug - 1) {
+        if (D.db) {
+          float* q = D.db + grp * D.b_stride + m;
+          *q = overwrite ? t : *q + t;
+        }
+      } else {
+        float* q = D.dW + grp * D.w_stride + (size_t)m * D.lddw + n;
+        *q = overwrite ? t : *q + t;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(64 * MG_RED_WAVES) void grad_reduce_multi_kernel(ReduceBatch bt) {
   __shared__ __attribute__((aligned(16))) float red[MG_RED_WAVES][256];
   int di = 0;
@@ -345,11 +404,16 @@ __global__ __launch_bounds__(64 * MG_RED_WAVES) void grad_reduce_multi_kernel(Re
     if ((int)blockIdx.x >= bt.d[i].block0) di = i;
   const ReduceDesc& D = bt.d[di];
   const int total = D.M * D.Naug;
-  const int cpg = (total + 255) / 256;  // chunks per group
+  const bool tall = (D.has_bias & 4) != 0;  // (set by the launcher)
+  const int cw = tall ? 64 : 256;
+  const int cpg = (total + cw - 1) / cw;  // chunks per group
   const int rel = blockIdx.x - D.block0;
-  const int grp = rel / cpg, c0 = (rel - grp * cpg) * 256;
+  const int grp = rel / cpg, c0 = (rel - grp * cpg) * cw;
   const bool vec = (((size_t)D.P & 15) == 0) && (D.p_stride & 3) == 0 && (total & 3) == 0;
-  if (vec) grad_reduce_chunk<true>(D, grp, c0, total, red);
+  if (tall) {
+    if (vec) grad_reduce_chunk_tall<true>(D, grp, c0, total, red);
+    else grad_reduce_chunk_tall<false>(D, grp, c0, total, red);
+  } else if (vec) grad_reduce_chunk<true>(D, grp, c0, total, red);
   else grad_reduce_chunk<false>(D, grp, c0, total, red);
 }
 
@@ -643,7 +707,10 @@ int mggan_grad_reduce_multi(const void* descs, int n, hipStream_t stream) {
       bt.d[i] = in[i0 + i];
       MG_CHECK_ARG(bt.d[i].P && bt.d[i].dW && bt.d[i].splits > 0 && bt.d[i].groups > 0, "grad_reduce_multi: bad descriptor");
       bt.d[i].block0 = blocks;
-      blocks += cdiv((long)bt.d[i].M * bt.d[i].Naug, 256) * bt.d[i].groups;
+      const long total = (long)bt.d[i].M * bt.d[i].Naug;
+      const bool tall = bt.d[i].splits >= 128 && total <= 8192;  // many partial blocks of few outputs: 64-output chunks
+      bt.d[i].has_bias = (bt.d[i].has_bias & 3) | (tall ? 4 : 0);
+      blocks += cdiv(total, tall ? 64 : 256) * bt.d[i].groups;
     }
     hipLaunchKernelGGL(grad_reduce_multi_kernel, dim3(blocks), dim3(64 * MG_RED_WAVES), 0, stream, bt);
     MG_LAUNCH_CHECK("grad_reduce_multi");
