@@ -478,21 +478,24 @@ int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, cons
 
 /* Fused decoder backward: BPTT + in-kernel per-generator weight gradients (dW_hh and dW1[:, :H] on MFMA).
  * n_gens*NW persistent workgroups; workgroup (g, w) leaves one partial block of `wlen` floats at
- * wpart[(g*NW + w) * wlen] laid out as [W_hh | A | bias | W1h | b1 | W2 | b2] (offsets from
+ * wpart[(g*NW + w) * wlen] laid out as [W_hh | A | bias | W1h | b1 | W2 | b2 | W1s] (offsets from
  * mggan_decoder_bwd_fused_layout); reduce them with mggan_grad_reduce_multi (groups = n_gens, splits = NW).
+ * SocR (R, S): the rows' social features as the forward saved them -- with it the block also carries W1s = dW1[:, H:]
+ * (16 x 32, the social half of hidden2pos: dQ^T SocR); NULL: that part of the block is zero.
  * dEnc (R, EIN) = dH0 We2d[:, :EIN], or NULL: the caller folds dH0 over the rows of a pedestrian and multiplies once
  * per pedestrian (the adjoint of the Qe form of mggan_decoder_rollout_fwd). */
 /* floats of padding between the tile records of the rollout's saved state: Gt is tiles x (T*H*64 + gt_pad) floats, Cs
  * tiles x ((T+1)*H*32 + cs_pad) (see mggan_decoder_rollout_fwd) */
 int mggan_decoder_save_pads(int* gt_pad, int* cs_pad);
 int mggan_decoder_bwd_fused_layout(int* wlen, int* off_A, int* off_bias, int* off_W1, int* off_b1, int* off_W2,
-                                   int* off_b2);
+                                   int* off_b2, int* off_W1s);
 int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, int Z, const int* seg, const int* row_pos,
                                     const float* W_hh, const float* W1, const float* W2, long param_stride,
                                     const float* We2d, const float* prep, int prep_stride, const float* Gt,
                                     const float* Cs, const float* Din,
                                     const float* Aact, const float* gabs, const float* grel, int Rout, float* dH0,
-                                    float* dQ, float* dEnc, float* dSocR, float* wpart, mggan_stream_t stream);
+                                    float* dQ, float* dEnc, float* dSocR, float* wpart, const float* SocR,
+                                    mggan_stream_t stream);
 
 /* ---- input pipeline: per-pedestrian scene crops cut on the GPU -----------------------------
  * Replaces the per-pedestrian PIL crop loop of BaseTrajectories.py:254-288 / trajectories_scene.py:349-356.

@@ -931,7 +931,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 // needs; dA / dbias / dW2 / db1 / db2 are lane-local FMAs.  Each workgroup leaves ONE partial block
 //     [ W_hh 4096 | A 256 | bias 128 | W1h 512 | b1 16 | W2 32 | b2 2 (+2 pad) ]
 // which the batched gradient reduce folds per generator.
-#define DF_WLEN 5044
+#define DF_WLEN 5556
+#define DF_OFF_W1S 5044  // dW1[:, H:] (16 x 32): the social half of hidden2pos, K = the rows of the workgroup's tiles
 #define DF_OFF_A 4096
 #define DF_OFF_B 4352
 #define DF_OFF_W1 4480
@@ -950,6 +951,7 @@ struct DecFusedArgs {
   int prep_stride;
   const float *Gt, *Cs, *Din, *Aact, *gabs, *grel;
   float *dH0, *dQ, *dEnc, *dSocR, *wpart;
+  const float* SocR;  // (R, S) the rows' social features (saved by the forward), or NULL: no dW1[:, H:] in the block
 };
 
 // Matrix-core form of the fused backward, in the lane layout of decoder_fwd_mfma_kernel: four waves per
@@ -1021,7 +1023,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (p.dEnc)
     for (int i = threadIdx.x; i < H * p.EIN; i += 256) e2s[(i / p.EIN) * p.e2ld + i % p.EIN] = p.We2d[(size_t)(i / p.EIN) * IN + i % p.EIN];
   for (int i = threadIdx.x; i < Hh * S; i += 256) w1s[(i / S) * 36 + i % S] = W1[(size_t)(i / S) * (H + S) + H + i % S];
-  f32x4 accW[2][2], accU = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accW[2][2], accU = f32x4{0.f, 0.f, 0.f, 0.f}, accS = f32x4{0.f, 0.f, 0.f, 0.f};
   // dA (4H x 2) and dbias (4H) = dPre^T [dxdy | 1]: lane-local sums over the lane's own (unit, gate) entries and its tile
   // row, folded over the 16 rows once at the end.  As a third 16-column tile of the matrix product (13 of its 16 columns
   // padding) they cost 8 of the 62 MFMAs of a step.
@@ -1181,6 +1183,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (w == 0 && valid) *reinterpret_cast<f32x4*>(p.dQ + (size_t)r * Hh + 4 * fk) = dq;
 #pragma unroll
     for (int q = 0; q < 4; ++q) accb1[q] += dq[q];
+    if (p.SocR) {
+      // dW1[:, H:] += dQ^T SocR over the 16 rows of the tile (once per tile: dQ is the sum over the steps, the social
+      // features do not change with the step): dQ goes through the du tile that the last step left free and comes back
+      // transposed, wave w -> column tile (w & 1), K half (w >> 1) as for dW1[:, :H].  (As a grouped GEMM over all R rows
+      // behind the backward pass this product was a launch of its own: 166 us at 163,840 rows, 26 us at 25,600.)
+      float* dqs = dus[1];
+      if (w == 0) *reinterpret_cast<f32x4*>(&dqs[fi * DB_US + 4 * fk]) = dq;
+      lds_barrier();
+      const int nt = w & 1, kh = w >> 1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int row = 2 * kh + kk + 4 * fk;
+        const int rr = min(seg0 + tile * 16 + row, seg1 - 1);  // (rows past the segment end: dQ is zero there)
+        accS = MFMA16(dqs[row * DB_US + fi], p.SocR[(size_t)rr * S + 16 * nt + fi], accS);
+      }
+    }
     if (w < 2) {  // dSocR^T [S x rows] = W1[:, H:]^T dQ^T : wave w -> social columns 16 w .. 16 w + 15
       f32x4 ds = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1237,9 +1255,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   lds_barrier();
   // W1h: column tile (w & 1) is shared by waves w and w ^ 2 (K halves): sum them through LDS
-  float* u = dps[0];  // [4][256]
+  float* u = dps[0];  // [4][256], and the social half behind it
 #pragma unroll
-  for (int q = 0; q < 4; ++q) u[w * 256 + (4 * fk + q) * 16 + fi] = accU[q];
+  for (int q = 0; q < 4; ++q) {
+    u[w * 256 + (4 * fk + q) * 16 + fi] = accU[q];
+    u[1024 + w * 256 + (4 * fk + q) * 16 + fi] = accS[q];
+  }
   if (w == 0) {  // lane-local accumulators (W2, b1, b2) -> fold over the 16 tile rows
     float* f = red + fi * 52;
 #pragma unroll
@@ -1261,6 +1282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int i = threadIdx.x; i < 512; i += 256) {
     const int m = i / 32, k = i % 32, nt = k / 16;
     wp[DF_OFF_W1 + i] = u[nt * 256 + m * 16 + (k & 15)] + u[(nt + 2) * 256 + m * 16 + (k & 15)];
+    wp[DF_OFF_W1S + i] = u[1024 + nt * 256 + m * 16 + (k & 15)] + u[1024 + (nt + 2) * 256 + m * 16 + (k & 15)];
   }
 }
 
@@ -1441,9 +1463,9 @@ int mggan_decoder_save_pads(int* gt_pad, int* cs_pad) {
 }
 
 int mggan_decoder_bwd_fused_layout(int* wlen, int* off_A, int* off_bias, int* off_W1, int* off_b1, int* off_W2,
-                                   int* off_b2) {
+                                   int* off_b2, int* off_W1s) {
   *wlen = DF_WLEN; *off_A = DF_OFF_A; *off_bias = DF_OFF_B; *off_W1 = DF_OFF_W1; *off_b1 = DF_OFF_B1;
-  *off_W2 = DF_OFF_W2; *off_b2 = DF_OFF_B2;
+  *off_W2 = DF_OFF_W2; *off_b2 = DF_OFF_B2; *off_W1s = DF_OFF_W1S;
   return MGGAN_OK;
 }
 
@@ -1452,7 +1474,8 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
                                     const float* We2d, const float* prep, int prep_stride, const float* Gt,
                                     const float* Cs, const float* Din,
                                     const float* Aact, const float* gabs, const float* grel, int Rout, float* dH0,
-                                    float* dQ, float* dEnc, float* dSocR, float* wpart, hipStream_t stream) {
+                                    float* dQ, float* dEnc, float* dSocR, float* wpart, const float* SocR,
+                                    hipStream_t stream) {
   MG_CHECK_ARG(seg && row_pos && W_hh && W1 && W2 && We2d && prep && Gt && Cs && Din && Aact && dH0 && dQ &&
                    dSocR && wpart,
                "decoder_rollout_bwd_fused: null pointer");
@@ -1462,6 +1485,7 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
   p.W_hh = W_hh; p.W1 = W1; p.W2 = W2; p.We2d = We2d; p.param_stride = param_stride; p.prep = prep;
   p.prep_stride = prep_stride; p.Gt = Gt; p.Cs = Cs; p.Din = Din; p.Aact = Aact;
   p.gabs = gabs; p.grel = grel; p.dH0 = dH0; p.dQ = dQ; p.dEnc = dEnc; p.dSocR = dSocR; p.wpart = wpart;
+  p.SocR = SocR;
   p.e2ld = EIN + ((10 - EIN % 8) % 8);  // == 2 mod 8: the A-fragment reads (row 8 fk + ks) hit four 16-bank groups
   const size_t dyn = sizeof(float) * ((size_t)H * p.e2ld + (H / 2) * 36);
   MG_CHECK_ARG(dyn <= 64 * 1024, "decoder_rollout_bwd_fused: encoder width %d too large for the staged epilogue", EIN);

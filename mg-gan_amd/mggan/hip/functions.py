@@ -1694,9 +1694,9 @@ _FUSED_LAYOUT = {}
 def _fused_layout():
     """Offsets (in floats) inside one partial block of mggan_decoder_rollout_bwd_fused."""
     if not _FUSED_LAYOUT:
-        v = [ctypes.c_int() for _ in range(7)]
+        v = [ctypes.c_int() for _ in range(8)]
         lib.mggan_decoder_bwd_fused_layout(*[ctypes.byref(x) for x in v])
-        _FUSED_LAYOUT.update(zip(("wlen", "A", "bias", "W1", "b1", "W2", "b2"), (x.value for x in v)))
+        _FUSED_LAYOUT.update(zip(("wlen", "A", "bias", "W1", "b1", "W2", "b2", "W1s"), (x.value for x in v)))
     return _FUSED_LAYOUT
 
 
@@ -1807,7 +1807,7 @@ class DecoderRolloutFn(Function):
         lib.mggan_decoder_rollout_bwd_fused(n_gens, NW, T, H, EIN, Z, _p(rows.seg), _p(rows.row_pos), _p(g0["w_hh"]),
                                             _p(g0["w1"]), _p(g0["w2"]), stride, _p(e2d_w), _p(prep), psz, _p(Gt), _p(Cs),
                                             _p(Din), _p(Aact), _p(gabs), _p(grel), R, _p(dH0), _p(dQ),
-                                            _p(dEnc), _p(dSocR), _p(wpart), st)
+                                            _p(dEnc), _p(dSocR), _p(wpart), _p(SocR) if train_w else 0, st)
         if train_w:
             ng, wl, P = n_gens, lay["wlen"], wpart.data_ptr()
             dprep = mk(n_gens, 12 * H)  # scratch: the reduction stores into it (has_bias bit 1)
@@ -1826,8 +1826,11 @@ class DecoderRolloutFn(Function):
             else:
                 lib.mggan_grad_reduce_multi(ctypes.addressof(now), 2, st)
                 unfold()
+            # (W1s = dW1[:, H:], the social half of hidden2pos: summed inside the launch, tile by tile -- as a grouped GEMM
+            #  over all R rows behind the backward pass it was a launch of its own)
             parts = [(0, ptr["w_hh"], 4 * H, H, H), (lay["W1"], ptr["w1"], Hh, H, H + S), (lay["b1"], ptr["b1"], 1, Hh, Hh),
-                     (lay["W2"], ptr["w2"], 2, Hh, Hh), (lay["b2"], ptr["b2"], 1, 2, 2)]
+                     (lay["W2"], ptr["w2"], 2, Hh, Hh), (lay["b2"], ptr["b2"], 1, 2, 2),
+                     (lay["W1s"], ptr["w1"] + 4 * H, Hh, S, H + S)]
             if _DEFER["on"]:
                 for i, (off, dst, M, N, ld) in enumerate(parts):
                     _queue_reduce(P + 4 * off, dst, 0, M, N, 0, ld, NW, ng, wl, stride, 0, keep=(wpart,) if i == 0 else ())
@@ -1835,7 +1838,6 @@ class DecoderRolloutFn(Function):
                 arr = (_ReduceDesc * len(parts))(*[_ReduceDesc(P + 4 * off, dst, None, stride, 0, M, N, 0, ld, NW, ng, wl, 0)
                                                   for off, dst, M, N, ld in parts])
                 lib.mggan_grad_reduce_multi(ctypes.addressof(arr), len(parts), st)
-            wgrad(dQ, Hh, SocR, S, ptr["w1"] + 4 * H, H + S, 0, R, S, Hh, rows.seg, 1, ng, stride, stride)
         dQe = None
         if ctx.shared and (e2d_w.requires_grad or ctx.needs_input_grad[0]):
             # adjoint of the per-pedestrian part of h0: dH0 folded over the K rows of a pedestrian, then ONE product
