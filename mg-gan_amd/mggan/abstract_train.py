@@ -454,7 +454,7 @@ class IterationGraphs:
     def __init__(self, trainer, limit=8, pad="auto", bucket="quarter", capture=True):
         self.tr, self.limit, self.entries = trainer, int(limit), {}
         self.pad, self.bucket, self.capture = pad, bucket, bool(capture)
-        self.pool = torch.cuda.graph_pool_handle()
+        self.pool = None  # the graphs' shared memory pool (created with the first capture)
         self._acc = {}  # id(snapshot buffer) -> [buffer, running sum, count, items]
         self.replays = self.eager = self.padded = 0
 
@@ -573,6 +573,8 @@ class IterationGraphs:
         self.padded += ent.tables is not None
         if self.capture and ent.replay is None and not ent.failed:
             try:
+                if self.pool is None:
+                    self.pool = torch.cuda.graph_pool_handle()
                 with HF.pin_tables():
                     ent.replay = tr.capture_iteration(ent.static, warmup=0, pool=self.pool)
             except Exception as exc:  # noqa: BLE001

@@ -217,3 +217,49 @@ def test_cosine_schedule_matches_torch():
         ref_opt.step()
         ref.step()
         assert abs(o.lr - ref_opt.param_groups[0]["lr"]) < 1e-12
+
+
+def test_bucket_sizes():
+    """Shape buckets of train()'s padded ragged batches (abstract_train.bucket_size): monotone, at least the batch, bounded
+    padding."""
+    from mggan.abstract_train import bucket_size
+
+    for mode in ("quarter", "pow2"):
+        prev = 0
+        for n in range(1, 3000):
+            p, below = bucket_size(n, mode)
+            assert p >= n > below and p >= prev
+            assert (p - n) <= max(p // 2 if mode == "pow2" else p // 5, 7), (mode, n, p)
+            prev = p
+
+
+def test_ragged_batches_map_to_shape_buckets():
+    """IterationGraphs.bucket_of (host logic, no GPU): uniform batches keep exact-shape graphs, ragged batches of one bucket
+    share a key, the scene slots cover the phantom scenes of the bucket's emptiest batch, scenes of more than 64 pedestrians
+    and configurations without padding support are left alone."""
+    from mggan.abstract_train import IterationGraphs
+    from mggan.data_utils import synthetic
+
+    class Tr:
+        device = "cpu"
+
+        def padding_ok(self):
+            return True
+
+    ig = IterationGraphs(Tr(), pad="auto", capture=True)
+    assert ig.bucket_of(synthetic.make_batch([3, 3, 3, 3], seed=0)) is None  # uniform: exact shape
+    keys = set()
+    for i in range(8):  # the loader's 8-scene batches of 1-6 pedestrians: 22-29 pedestrians -> buckets 24 and 32
+        batch = synthetic.make_batch(synthetic.scene_sizes(8, None, seed=i), seed=i)
+        key, b_pad, S_pad, max_n = ig.bucket_of(batch)
+        b = batch["in_xy"].shape[1]
+        assert b_pad in (24, 32) and b_pad >= b > b_pad - 8 and max_n == 16
+        assert S_pad >= 8 + -(-(b_pad - b) // 16)  # its scenes + its phantom scenes fit
+        keys.add(key)
+    assert len(keys) == 2
+    assert ig.bucket_of(synthetic.make_batch([70, 3], seed=0)) is None  # a scene of more than 64 pedestrians
+    assert IterationGraphs(Tr(), pad="off").bucket_of(batch) is None
+    assert IterationGraphs(Tr(), pad="auto", capture=False).bucket_of(batch) is None  # (no graphs: padding only with 'on')
+    assert IterationGraphs(Tr(), pad="on", capture=False).bucket_of(batch) is not None
+    Tr.padding_ok = lambda self: False
+    assert ig.bucket_of(batch) is None

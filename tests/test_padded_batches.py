@@ -182,15 +182,3 @@ def test_padded_iteration_matches_the_oracle():
         a = torch.cat([p.detach().cpu().flatten() for p in mod.parameters()]).double()
         r = torch.cat([p.detach().flatten() for p in ref.parameters()]).double()
         assert float((a - r).norm() / r.norm()) <= 1e-3
-
-
-def test_bucket_sizes():
-    from mggan.abstract_train import bucket_size
-
-    for mode in ("quarter", "pow2"):
-        prev = 0
-        for n in range(1, 3000):
-            p, below = bucket_size(n, mode)
-            assert p >= n > below and p >= prev
-            assert (p - n) <= max(p // 2 if mode == "pow2" else p // 5, 7), (mode, n, p)
-            prev = p
