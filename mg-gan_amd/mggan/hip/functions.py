@@ -909,7 +909,9 @@ class StaticSceneTables:
         total = self._off[-1]
         # host staging: a ring of pinned buffers, each guarded by the event of its last copy (the host runs several replays
         # ahead of the GPU: the copy of batch i may not have happened yet when batch i + 1 is laid out)
-        self._ring = [[torch.zeros(total, dtype=torch.int32).pin_memory(), None] for _ in range(8)]
+        cuda = self.device.type == "cuda"  # (on the CPU -- the host-logic tests -- plain buffers, no events)
+        self._ring = [[torch.zeros(total, dtype=torch.int32).pin_memory() if cuda else torch.zeros(total, dtype=torch.int32),
+                       None] for _ in range(8)]
         self._turn = 0
         self.dev = torch.zeros(total, dtype=torch.int32, device=self.device)
         f = lambda i, n: self.dev[self._off[i]:self._off[i] + n]
@@ -970,8 +972,9 @@ class StaticSceneTables:
         h[o[7]:o[7] + 2 * b] = np.concatenate([ped_s0, ped_s0 + b])
         h[o[8]:o[8] + 2 * b] = np.concatenate([ped_n, ped_n])
         self.dev.copy_(slot[0], non_blocking=True)
-        slot[1] = torch.cuda.Event()
-        slot[1].record()
+        if self.device.type == "cuda":
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
         for lst, arr in ((self.seq_start_end, sc), (self.seq_start_end2, np.concatenate([sc, sc + b]))):
             for item, (s_, e) in zip(lst, arr.tolist()):
                 item[0], item[1] = s_, e

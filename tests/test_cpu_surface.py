@@ -263,3 +263,40 @@ def test_ragged_batches_map_to_shape_buckets():
     assert IterationGraphs(Tr(), pad="on", capture=False).bucket_of(batch) is not None
     Tr.padding_ok = lambda self: False
     assert ig.bucket_of(batch) is None
+
+
+def test_static_scene_tables_layout():
+    """HF.StaticSceneTables (host logic, CPU device): the real scenes first, the phantom pedestrians behind them in scenes of
+    at most 16, empty slots at the end; the pedestrian -> scene maps; the doubled tables of the discriminator's pair pass; the
+    record the kernels read (n_real, s_real, b_pad / n_real); the static lists the trainer passes around are updated in place."""
+    import numpy as np
+
+    from mggan.hip.functions import StaticSceneTables
+
+    tb = StaticSceneTables(48, 12, 16, "cpu")
+    lst, lst2 = tb.seq_start_end, tb.seq_start_end2
+    for sse in ([[0, 3], [3, 4], [4, 10], [10, 12]], [[0, 6], [6, 7], [7, 20]]):
+        tb.fill(sse)
+        n, S = sse[-1][1], len(sse)
+        d = tb.dims.numpy()
+        assert (int(d[0]), int(d[1])) == (n, S) and abs(float(d[2:3].view(np.float32)[0]) - 48.0 / n) < 1e-6
+        sc = tb.scenes.numpy()
+        assert sc[:S].tolist() == sse and tb.seq_start_end is lst and lst[:S] == sse
+        ph = sc[S:]
+        sizes = ph[:, 1] - ph[:, 0]
+        assert ph[0, 0] == n and (sizes <= 16).all() and sizes.sum() == 48 - n  # the phantoms tile [n, 48)
+        assert (ph[sizes == 0] == 48).all() and (np.diff(sc.reshape(-1)) >= 0).all()
+        ped_scene, ped_s0, ped_n = tb.ped_scene.numpy(), tb.ped_s0.numpy(), tb.ped_n.numpy()
+        for p in range(48):
+            s0, s1 = sc[ped_scene[p]]
+            assert s0 <= p < s1 and ped_s0[p] == s0 and ped_n[p] == s1 - s0
+        two = tb.pair
+        assert two.b == 96 and two.S == 24 and tb.seq_start_end2 is lst2
+        sc2 = two.scenes.numpy()
+        assert (sc2[:12] == sc).all() and (sc2[12:] == sc + 48).all() and lst2 == sc2.tolist()
+        assert (two.ped_scene.numpy()[48:] == ped_scene + 12).all() and (two.ped_s0.numpy()[48:] == ped_s0 + 48).all()
+        assert (two.ped_n.numpy()[:48] == ped_n).all() and (two.ped_n.numpy()[48:] == ped_n).all()
+    with pytest.raises(ValueError):
+        tb.fill([[0, 20], [20, 49]])  # more pedestrians than the bucket holds
+    with pytest.raises(ValueError):
+        tb.fill([[i, i + 1] for i in range(13)])  # more scenes than slots
