@@ -497,6 +497,13 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
                                     float* dQ, float* dEnc, float* dSocR, float* wpart, const float* SocR,
                                     mggan_stream_t stream);
 
+/* A ragged batch into the static buffers of its shape bucket (train()'s padded batches, mggan/abstract_train.py
+ * IterationGraphs; reference collate /root/reference/mggan/data_utils/trajectories_scene.py:40-78): `descs` = n (<= 8) records
+ * { const float* src; float* dst; long inner; int outer, position; }, every tensor (outer, pedestrians, inner) contiguous
+ * with b pedestrians in src and b_pad in dst.  The real pedestrians are copied in front, the phantom pedestrians [b, b_pad)
+ * get their constant content: 0, and -- position tensors -- element 0 of the inner axis = pedestrian % period (distinct
+ * positions inside a phantom scene).  One launch. */
+int mggan_pad_batch(const void* descs, int n, int b, int b_pad, int period, mggan_stream_t stream);
 /* ---- input pipeline: per-pedestrian scene crops cut on the GPU -----------------------------
  * Replaces the per-pedestrian PIL crop loop of BaseTrajectories.py:254-288 / trajectories_scene.py:349-356.
  * atlas = the u8 RGB "small" scene images (H,W,3) packed back to back in device memory; pedestrian p reads the

@@ -28,7 +28,61 @@ __global__ __launch_bounds__(256) void crop_patches_kernel(const unsigned char* 
   }
 }
 
+// ---- a ragged batch into the static buffers of its shape bucket (train()'s padded batches) -------------------------
+// Every batch tensor is (outer, pedestrians, inner) contiguous (in_xy (8, b, 2): outer = 8, inner = 2; the crops
+// (b, 4, 33, 33): outer = 1, inner = 4,356).  The real pedestrians are copied in front; the phantom pedestrians behind them
+// get their constant content (position tensors: x = slot within a phantom scene of `period` pedestrians, everything else 0).
+// ONE launch instead of a copy plus a restore per tensor.
+#define MG_PAD_MAX 8
+struct PadTensor {
+  const float* src;
+  float* dst;
+  long inner;
+  int outer, position;
+  long first;  // first work item of this tensor
+};
+struct PadBatch {
+  PadTensor t[MG_PAD_MAX];
+  int n, b, b_pad, period;
+  long total;
+};
+__global__ __launch_bounds__(256) void pad_batch_kernel(PadBatch a) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long)gridDim.x * 256) {
+    int k = 0;
+#pragma unroll 1
+    for (int q = 1; q < a.n; ++q)
+      if (i >= a.t[q].first) k = q;
+    const PadTensor& T = a.t[k];
+    const long e = i - T.first, in = e % T.inner, rest = e / T.inner;
+    const int ped = (int)(rest % a.b_pad), o = (int)(rest / a.b_pad);
+    float v;
+    if (ped < a.b) v = T.src[((long)o * a.b + ped) * T.inner + in];
+    else v = (T.position && in == 0) ? (float)(ped % a.period) : 0.f;
+    T.dst[e] = v;
+  }
+}
+
 extern "C" {
+
+int mggan_pad_batch(const void* descs, int n, int b, int b_pad, int period, hipStream_t stream) {
+  struct Desc { const float* src; float* dst; long inner; int outer, position; };
+  MG_CHECK_ARG(descs && n > 0 && n <= MG_PAD_MAX && b >= 0 && b <= b_pad && period > 0, "pad_batch: bad arguments");
+  const Desc* d = (const Desc*)descs;
+  PadBatch a;
+  a.n = n; a.b = b; a.b_pad = b_pad; a.period = period; a.total = 0;
+  for (int i = 0; i < n; ++i) {
+    MG_CHECK_ARG(d[i].dst && (d[i].src || b == 0) && d[i].inner > 0 && d[i].outer > 0, "pad_batch: bad tensor %d", i);
+    a.t[i].src = d[i].src; a.t[i].dst = d[i].dst; a.t[i].inner = d[i].inner; a.t[i].outer = d[i].outer;
+    a.t[i].position = d[i].position; a.t[i].first = a.total;
+    a.total += (long)d[i].outer * b_pad * d[i].inner;
+  }
+  if (a.total == 0) return MGGAN_OK;
+  int blocks = cdiv(a.total, 256 * 4);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pad_batch_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  MG_LAUNCH_CHECK("pad_batch");
+  return MGGAN_OK;
+}
 
 int mggan_crop_patches(const unsigned char* atlas, const long long* img_off, const int* img_hw, const int* centers, int n,
                        int margin, float* out, hipStream_t stream) {

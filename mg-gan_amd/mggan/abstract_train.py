@@ -2,6 +2,7 @@
 MultiGeneratorGAN.{train, save, load, load_from_path} and the optimizer / schedule setup.
 One iteration = discriminator step -> generator step -> PM-network step (:136-159)."""
 import abc
+import ctypes
 import math
 import os
 import time
@@ -407,6 +408,11 @@ class MultiGeneratorGAN(abc.ABC):
         pass
 
 
+class _PadDesc(ctypes.Structure):  # mirrors csrc/crop.hip: mggan_pad_batch
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("inner", ctypes.c_long), ("outer", ctypes.c_int),
+                ("position", ctypes.c_int)]
+
+
 def bucket_size(n, mode="quarter"):
     """Smallest bucket >= n.  quarter: multiples of 8 up to 64, then four buckets per octave (64, 80, 96, 112, 128, 160,
     ...: at most a fifth of a bucket is padding); pow2: powers of two from 8 on.  -> (bucket, the bucket below it)"""
@@ -504,17 +510,14 @@ class IterationGraphs:
         for k, v in batch.items():
             if not torch.is_tensor(v):
                 continue
-            ax = self.PED_AXIS[k]
+            if v.dtype != torch.float32:
+                raise TypeError("padded batches hold float32 tensors ({}: {})".format(k, v.dtype))
             shape = list(v.shape)
-            shape[ax] = b_pad
-            t = torch.zeros(shape, dtype=v.dtype, device=tr.device)
-            if k in ("in_xy", "gt_xy"):
-                t[..., 0] = (torch.arange(b_pad, device=tr.device) % HF.StaticSceneTables.PHANTOM_SCENE).to(v.dtype)
-            static[k] = t
+            shape[self.PED_AXIS[k]] = b_pad
+            static[k] = torch.zeros(shape, dtype=v.dtype, device=tr.device)  # (filled by mggan_pad_batch, every batch)
         ent = self.Entry(static)
-        ent.template = {k: t.clone() for k, t in static.items()}
         static["seq_start_end"], static["loss_mask"], static["pad"] = tables.seq_start_end, None, tables
-        ent.tables, ent.n_loaded = tables, b_pad
+        ent.tables = tables
         return ent
 
     def _load(self, ent, batch):
@@ -525,15 +528,25 @@ class IterationGraphs:
                 if torch.is_tensor(v):
                     ent.static[k].copy_(v, non_blocking=True)
             return
+        from mggan.hip import functions as HF
+        from mggan.hip.lib import lib
+
         b = batch["in_xy"].shape[1]
-        for k, v in batch.items():
-            if not torch.is_tensor(v):
-                continue
-            dst, ax = ent.static[k], self.PED_AXIS[k]
-            dst.narrow(ax, 0, b).copy_(v, non_blocking=True)
-            if ent.n_loaded > b:
-                dst.narrow(ax, b, ent.n_loaded - b).copy_(ent.template[k].narrow(ax, b, ent.n_loaded - b))
-        ent.n_loaded = b
+        keys = [k for k, v in batch.items() if torch.is_tensor(v)]
+        descs = (_PadDesc * len(keys))()
+        keep = []
+        for d, k in zip(descs, keys):
+            v = batch[k].to(self.tr.device, non_blocking=True).contiguous()  # (a no-op for device-resident batches)
+            keep.append(v)
+            ax, dst = self.PED_AXIS[k], ent.static[k]
+            outer = 1
+            for n in v.shape[:ax]:
+                outer *= int(n)
+            d.src, d.dst, d.inner, d.outer = v.data_ptr(), dst.data_ptr(), v.numel() // max(outer * b, 1), outer
+            d.position = 1 if k in ("in_xy", "gt_xy") else 0
+        # ONE launch: the real pedestrians in front, the phantom pedestrians (constant positions x = slot within a phantom
+        # scene, zero steps, black crops) behind them
+        lib.mggan_pad_batch(ctypes.addressof(descs), len(keys), b, ent.tables.b, HF.StaticSceneTables.PHANTOM_SCENE, HF._s())
         ent.tables.fill(batch["seq_start_end"])
 
     def step(self, batch, metrics):
