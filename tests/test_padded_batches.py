@@ -183,3 +183,65 @@ def test_padded_iteration_matches_the_oracle():
         a = torch.cat([p.detach().cpu().flatten() for p in mod.parameters()]).double()
         r = torch.cat([p.detach().flatten() for p in ref.parameters()]).double()
         assert float((a - r).norm() / r.norm()) <= 1e-3
+
+
+def test_padded_iterations_match_the_reference_golden(golden):
+    """The padded path against the REAL reference: the golden run's three D+G+PM iterations on its ragged scenes
+    (tests/golden/make_golden.py, recorded draws), executed on the batch padded to its shape bucket -- every logged loss
+    within 1e-3, the parameters after iterations 1 and 3 relL2 1e-3, BatchNorm counters exact.  (The phantom pedestrians
+    get arbitrary noise and generator ids.)"""
+    from helpers import batch_from, rel_l2, sd_from
+    from mggan.abstract_train import IterationGraphs
+    from mggan.logging import Experiment
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.model.train import PiNetMultiGeneratorGAN
+    from mggan.rng import ReplayRNG
+
+    g = int(golden["meta/num_gens"])
+    cfg = get_parser().parse_args(["--num_gens", str(g)])
+    G, D = construct_model(cfg)
+    G.load_state_dict(sd_from(golden, "G0"), strict=True)
+    D.load_state_dict(sd_from(golden, "D0"), strict=True)
+    tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+    tr.G.train()
+    tr.D.train()
+    assert tr.share_context and tr.share_trunk
+    bt = batch_from(golden, "cuda")
+    b = bt["in_xy"].shape[1]
+    ig = IterationGraphs(tr, pad="on", capture=False)
+    tr.padding_ok = lambda: True
+    key, b_pad, S_pad, max_n = ig.bucket_of(bt)
+    assert b_pad > b
+    ent = ig._padded_entry(key, b_pad, S_pad, max_n, bt)
+    ig._load(ent, bt)
+    gen = torch.Generator().manual_seed(4)
+    for it in range(1, 4):
+        labels, noise, idxs = [], [], []
+        for step in ("d", "g", "pm"):
+            p = "s{}_{}".format(it, step)
+            lab = golden.get(p + "/labels")
+            labels += [] if lab is None else [tuple(r) for r in lab]
+            n = torch.from_numpy(golden[p + "/noise"].copy())
+            i = torch.from_numpy(golden[p + "/gen_idxs"].copy())
+            noise.append(torch.cat([n, torch.randn(n.shape[0], b_pad - b, n.shape[2], generator=gen)], 1))
+            idxs.append(torch.cat([i, torch.randint(0, g, (b_pad - b, i.shape[1]), generator=gen)], 0))
+        tr.rng = tr.G.rng = ReplayRNG(labels=labels, noise=noise, gen_idxs=idxs)
+        m = defaultdict(list)
+        tr.train_iteration(ent.static, m)
+        for step in ("d", "g", "pm"):
+            p = "s{}_{}".format(it, step)
+            for k in [k for k in golden if k.startswith(p + "/metric/")]:
+                name, ref = k.split("/metric/")[1], float(golden[k])
+                assert abs(m[name][0] - ref) <= 1e-3 * abs(ref) + 1e-6, (p, name, m[name][0], ref)
+        if it in (1, 3):
+            for mod, pre in ((tr.G, "G"), (tr.D, "D")):
+                ref = sd_from(golden, pre + str(it))
+                sd = {k: v.cpu() for k, v in mod.state_dict().items()}
+                fl = [k for k in ref if ref[k].is_floating_point()]
+                a = torch.cat([sd[k].flatten().double() for k in fl]).numpy()
+                r = torch.cat([ref[k].flatten().double() for k in fl]).numpy()
+                assert rel_l2(a, r) <= 1e-3, (pre, it, rel_l2(a, r))
+                for k in ref:
+                    if not ref[k].is_floating_point():
+                        assert int(sd[k]) == int(ref[k]), k
