@@ -74,6 +74,13 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifdef SR_PROFILE  // measurement build (tools/bench_social.py): segment cycle counts of workgroup 0, wave 0 -> a.scratch
+#define SR_T(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); prof[k] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SR_T(k) do {} while (0)
+#endif
+
 // SocialFeatures of the ordered pair (i, j): social.py:67-104 (same operation order as social.hip:pair_features)
 __device__ __forceinline__ void sr_features(float pix, float piy, float vix, float viy, float pjx, float pjy, float vjx,
                                             float vjy, float f[3]) {
@@ -162,31 +169,37 @@ struct SrDense {  // LDS of the dense stages
   float* wh;      // Wh / dWh of the scene [rows][SR_LDW]
 };
 
-template <int H>
+template <int H, int NW>
 __device__ __forceinline__ void sr_stage_dense_weights(const SocRowsArgs& a, const SrDense& D) {
+  constexpr int NT = 64 * NW;
   const int F = a.F;
-  for (int e = threadIdx.x; e < F * H; e += 256) D.wat[(e / H) * (H + 4) + (e % H)] = a.Wat[e];
-  for (int e = threadIdx.x; e < F * 64; e += 256) D.w3[(e >> 6) * SR_LDW + (e & 63)] = a.W3[e];
-  for (int f = threadIdx.x; f < F; f += 256) {
+  // 16-byte loads (the weight matrices are contiguous and 16-byte aligned: checked by the launchers)
+  for (int e = threadIdx.x; e < F * (H / 4); e += NT)
+    *reinterpret_cast<f32x4*>(D.wat + (e / (H / 4)) * (H + 4) + 4 * (e % (H / 4))) = *reinterpret_cast<const f32x4*>(a.Wat + 4 * e);
+  for (int e = threadIdx.x; e < F * 16; e += NT)
+    *reinterpret_cast<f32x4*>(D.w3 + (e >> 4) * SR_LDW + 4 * (e & 15)) = *reinterpret_cast<const f32x4*>(a.W3 + 4 * e);
+  for (int f = threadIdx.x; f < F; f += NT) {
     D.bat[f] = a.bat[f];
+    // [W3 | b3]: c_j = Wh_j . b3 is column 64 of the product that gives v_j
+    *reinterpret_cast<f32x4*>(D.w3 + f * SR_LDW + 64) = f32x4{a.b3[f], 0.f, 0.f, 0.f};
     D.b3[f] = a.b3[f];
   }
 }
 
 // h rows of the scene -> hs; Wh -> D.wh (and wh_out); [v | c] -> vs.  Every thread of the workgroup calls it.
-template <int H>
+template <int H, int NW>
 __device__ __forceinline__ void sr_stage_scene(const SocRowsArgs& a, int s0, int n, const SrDense& D, float* vs, float* hs,
                                                float* wh_out) {
-  constexpr int LDH = H + 4;
+  constexpr int LDH = H + 4, NT = 64 * NW;
   const int F = a.F, lane = threadIdx.x & 63, w = threadIdx.x >> 6, pp = lane & 15, kq = lane >> 4;
   const int jt = (n + 15) >> 4;
-  for (int e = threadIdx.x; e < n * (H / 4); e += 256) {
+  for (int e = threadIdx.x; e < n * (H / 4); e += NT) {
     const int row = e / (H / 4), c = e - row * (H / 4);
     *reinterpret_cast<f32x4*>(hs + row * LDH + 4 * c) =
         *reinterpret_cast<const f32x4*>(a.h + (size_t)(s0 + row) * a.ld_h + 4 * c);
   }
   __syncthreads();
-  for (int t = w; t < jt * (F >> 4); t += 4) {  // Wh = h W_at^T + b_at
+  for (int t = w; t < jt * (F >> 4); t += NW) {  // Wh = h W_at^T + b_at
     const int j0 = 16 * (t / (F >> 4)), f0 = 16 * (t % (F >> 4));
     const float bias = D.bat[f0 + pp];
     const f32x4 acc = sr_tile<true>(hs, LDH, j0, D.wat, H + 4, f0, H, f32x4{bias, bias, bias, bias}, pp, kq);
@@ -198,19 +211,13 @@ __device__ __forceinline__ void sr_stage_scene(const SocRowsArgs& a, int s0, int
     }
   }
   __syncthreads();
-  for (int t = w; t < jt * 4; t += 4) {  // v = Wh W3
-    const int j0 = 16 * (t >> 2), m0 = 16 * (t & 3);
+  for (int t = w; t < jt * 5; t += NW) {  // [v | c] = Wh [W3 | b3]  (the fifth column tile: c in its first column)
+    const int j0 = 16 * (t / 5), m0 = 16 * (t % 5);
     const f32x4 acc = sr_tile<false>(D.wh, SR_LDW, j0, D.w3, SR_LDW, m0, F, f32x4{0.f, 0.f, 0.f, 0.f}, pp, kq);
+    if (m0 + pp <= 64) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) vs[(j0 + 4 * kq + r) * SR_LDV + m0 + pp] = acc[r];
-  }
-  for (int j = threadIdx.x; j < n; j += 256) {  // c = Wh . b3
-    float c0 = 0.f, c1 = 0.f;
-    for (int f = 0; f < F; f += 2) {
-      c0 = fmaf(D.wh[j * SR_LDW + f], D.b3[f], c0);
-      c1 = fmaf(D.wh[j * SR_LDW + f + 1], D.b3[f + 1], c1);
+      for (int r = 0; r < 4; ++r) vs[(j0 + 4 * kq + r) * SR_LDV + m0 + pp] = acc[r];
     }
-    vs[j * SR_LDV + 64] = c0 + c1;
   }
   __syncthreads();
 }
@@ -251,18 +258,21 @@ __device__ __forceinline__ float sr_score(const f32x4 z[4], const float* vrow, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int H, int NJB>
-__global__ __launch_bounds__(256) void social_rows_fwd_kernel(const SocRowsArgs a) {
+// NW waves per workgroup.  A lone wave issues one 16x16x4 product every ~50 cycles (measured with s_memtime around the
+// products of these kernels: 47 - 58 cycles each, chains of four accumulators or two alike), the pipe takes one every 32:
+// two waves per SIMD fill it.
+template <int H, int NJB, int NW>
+__global__ __launch_bounds__(64 * NW) void social_rows_fwd_kernel(const SocRowsArgs a) {
   constexpr int HQ = H / 4, LDH = H + 4;
   __shared__ __attribute__((aligned(16))) float vs[16 * NJB * SR_LDV];
   __shared__ __attribute__((aligned(16))) float hs[16 * NJB * LDH];
-  __shared__ __attribute__((aligned(16))) float wat_s[64 * (H + 4)], w3_s[64 * SR_LDW], whs[16 * NJB * SR_LDW];
+  __shared__ __attribute__((aligned(16))) float wat_s[64 * (H + 4)], w3_s[64 * SR_LDW + 16], whs[16 * NJB * SR_LDW];
   __shared__ float bat_s[64], b3_s[64];
   const SrDense DN = {wat_s, w3_s, bat_s, b3_s, whs};
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pp = lane & 15, kq = lane >> 4;
   SrWeights W;
   sr_load_weights(a, pp, kq, W);
-  sr_stage_dense_weights<H>(a, DN);
+  sr_stage_dense_weights<H, NW>(a, DN);
   const int RS = a.row_splits;
   for (int un = blockIdx.x; un < a.S * RS; un += gridDim.x) {
     const int sc = un / RS, rs = un - sc * RS;
@@ -272,11 +282,11 @@ __global__ __launch_bounds__(256) void social_rows_fwd_kernel(const SocRowsArgs 
       continue;
     }
     __syncthreads();  // every wave is done with the previous scene's rows (and the dense weights are staged)
-    sr_stage_scene<H>(a, s0, n, DN, vs, hs, nullptr);
+    sr_stage_scene<H, NW>(a, s0, n, DN, vs, hs, nullptr);
     SrNeighbour N[NJB];
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb) sr_load_neighbour(a, s0, n, 16 * jb + pp, vs, N[jb]);
-    for (int i = 4 * rs + w; i < n; i += 4 * RS) {
+    for (int i = NW * rs + w; i < n; i += NW * RS) {
       const int gi = s0 + i, ix = a.xy_mod > 0 ? gi % a.xy_mod : gi;
       const float pix = a.xy[2 * ix], piy = a.xy[2 * ix + 1], vix = a.dxy[2 * ix], viy = a.dxy[2 * ix + 1];
       float sg[NJB];
@@ -332,96 +342,231 @@ __global__ __launch_bounds__(256) void social_rows_fwd_kernel(const SocRowsArgs 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward.  TRAIN: also the weight gradients of the pair MLP (one partial block per workgroup).  KEEP: the forward
 // values of a row's blocks stay in registers between the score pass and the adjoint pass (else: recomputed).
-template <int H, int NJB, bool TRAIN, bool KEEP>
-__global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs a) {
-  constexpr int HQ = H / 4, LDH = H + 4;
-  constexpr int LDC = 68 + H;  // reduction row: dv (64) | dc | pad (3) | dh (H); 4 mod 32
-  constexpr int RED_FLOATS = 4 * 16 * LDC;
-  constexpr int A_FLOATS = (4 * SR_TILE_FLOATS > RED_FLOATS ? 4 * SR_TILE_FLOATS : RED_FLOATS) > 4 * SR_WG_FLOATS
-                               ? (4 * SR_TILE_FLOATS > RED_FLOATS ? 4 * SR_TILE_FLOATS : RED_FLOATS)
-                               : 4 * SR_WG_FLOATS;
-  // region A: the waves' transposition tiles while rows are walked; the neighbour-sum exchange at the end of a scene;
-  // the weight-gradient exchange at the end of the workgroup (separated by barriers)
+//
+// Registers decide how many waves a SIMD holds, and a lone wave leaves the matrix pipe a third idle (see the forward
+// kernel): the round-3 form of this kernel kept 500 values per lane (one wave per SIMD).  What left the registers:
+//   * the A-operand fragments of W2 (forward and transposed) sit in LDS, one row per LANE, shared by every wave (a
+//     16-byte read feeds four products);
+//   * da_ij = dS_i . h_j and the neighbour part of dh (dh_j = sum_i a_ij dS_i) are two small matrix products per scene
+//     on the staged rows (DA = dS h^T before the rows are walked, dh = A^T dS after), not HQ running sums per lane and
+//     block: the row walk reads da_ij from LDS and leaves a_ij in the same slot;
+//   * the positions of the scene's pedestrians are staged in LDS (the head of a row was a global round trip).
+#define SR_LDC 68  // fold row of a wave and neighbour: dv (64) | dc | pad
+
+// The pair MLP's second layer in LDS: W2 row-major, row stride 36 (== 4 mod 32).  Both A-operand fragments come straight
+// from it:  forward  W2[16 t + pp][16 sh + 4 kq + 0..3] = units u(4 sh + 0..3, kq): one 16-byte read feeds four products
+//           adjoint  W2[16 t + 4 kq + r][16 tp + pp]: 4-byte reads, the four kq groups 16 banks apart
+// and the bias the D fragment of the layer-2 product starts from, the same for the 16 lanes of a kq:
+//   bzs[16 kq + 4 t + r] = b2[16 t + 4 kq + r]
+#define SR_LD2 36
+// An LDS address the compiler cannot prove loop-invariant: the reads behind it stay where they are written.  (Left alone it
+// hoists the row-invariant fragments -- W2, v_j -- out of the row loop "into registers", finds none free, parks them in
+// scratch and reloads them at the head of every row: 52 registers' worth, a global round trip per row.)
+__device__ __forceinline__ const float* sr_here(const float* p) {
+  asm volatile("" : "+v"(p));
+  return p;
+}
+// W2T (TRAIN, scenes of up to 32): the transposed copy, row stride 68 -- the adjoint fragments W2[16 t + 4 kq + 0..3][16 tp + pp]
+// as ONE 16-byte read (32 four-byte reads per block kept the products waiting: 112 cycles apiece instead of 40)
+#define SR_LD2T 68
+template <int NW, bool W2T>
+__device__ __forceinline__ void sr_stage_w2(const SocRowsArgs& a, float* w2s, float* w2t, float* bzs) {
+  for (int e = threadIdx.x; e < 64 * 8; e += 64 * NW) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.W2 + 4 * e);
+    *reinterpret_cast<f32x4*>(w2s + (e >> 3) * SR_LD2 + 4 * (e & 7)) = v;
+    if (W2T) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w2t[(4 * (e & 7) + j) * SR_LD2T + (e >> 3)] = v[j];
+    }
+  }
+  if (threadIdx.x < 64) bzs[threadIdx.x] = a.b2[16 * ((threadIdx.x >> 2) & 3) + 4 * (threadIdx.x >> 4) + (threadIdx.x & 3)];
+}
+
+// sr_pair_mlp with the layer-2 fragments read from LDS (wf = w2s + pp * SR_LD2 + 4 kq, bz = bzs + 16 kq)
+__device__ __forceinline__ void sr_pair_mlp_lds(const float w1a[2], const float* wf, const float* bz, int kq, const float f[3],
+                                                float l1[8], f32x4 z[4]) {
+  const float fb = kq == 0 ? f[0] : kq == 1 ? f[1] : kq == 2 ? f[2] : 1.0f;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 p0 = MFMA16(w1a[0], fb, zero), p1 = MFMA16(w1a[1], fb, zero);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) z[t] = *reinterpret_cast<const f32x4*>(bz + 4 * t);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    l1[r] = fmaxf(p0[r], 0.f);
+    l1[4 + r] = fmaxf(p1[r], 0.f);
+  }
+#pragma unroll
+  for (int sh = 0; sh < 2; ++sh) {
+    f32x4 w4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w4[t] = *reinterpret_cast<const f32x4*>(wf + 16 * t * SR_LD2 + 16 * sh);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) z[t] = MFMA16(w4[t][j], l1[4 * sh + j], z[t]);
+  }
+}
+
+// KEEP: 1 = the forward values of every block of a row stay in registers between the score pass and the adjoint pass;
+// 2 = those of the row's LAST block only (the adjoint pass starts with it, the others are recomputed); 0 = none.
+template <int H, int NJB, int NW, bool TRAIN, int KEEP>
+__global__ __launch_bounds__(64 * NW) void social_rows_bwd_kernel(const SocRowsArgs a) {
+  constexpr int NT = 64 * NW, LDH = H + 4, NR = 16 * NJB;
+  constexpr int DAL = NR + 4;           // row stride of DA / A (4 mod 32 or 20 mod 32: see the reads below)
+  constexpr int JR = NJB <= 2 ? NJB : 1;  // neighbour blocks folded per exchange round
+  constexpr int RED_FLOATS = NW * 16 * JR * SR_LDC;
+  constexpr int TILES = TRAIN ? NW * SR_TILE_FLOATS : 0, EXCH = TRAIN ? NW * SR_WG_FLOATS : 0, WHS = NR * SR_LDW;
+  constexpr int A0 = RED_FLOATS > TILES ? RED_FLOATS : TILES, A1 = EXCH > WHS ? EXCH : WHS, A_FLOATS = A0 > A1 ? A0 : A1;
+  // region A, one use at a time (barriers between): Wh of the scene while it is staged; the waves' transposition tiles while
+  // rows are walked; the neighbour-sum exchange; dWh in the epilogue; the weight-gradient exchange at the end of the workgroup
   __shared__ __attribute__((aligned(16))) float smem[A_FLOATS];
-  __shared__ __attribute__((aligned(16))) float vs[16 * NJB * SR_LDV];  // [v | c] of the scene; its gradient at the end
-  __shared__ __attribute__((aligned(16))) float hs[16 * NJB * LDH];     // h of the scene; the neighbour part of dh at the end
-  __shared__ __attribute__((aligned(16))) float wat_s[64 * (H + 4)], w3_s[64 * SR_LDW], whs[16 * NJB * SR_LDW];
+  __shared__ __attribute__((aligned(16))) float vs[NR * SR_LDV];  // [v | c] of the scene; its gradient at the end
+  __shared__ __attribute__((aligned(16))) float hs[NR * LDH];     // h of the scene; the neighbour part of dh at the end
+  __shared__ __attribute__((aligned(16))) float dss[NR * LDH];    // dS of the scene (pad rows zero)
+  __shared__ __attribute__((aligned(16))) float das[NR * DAL];    // da_ij, replaced by a_ij as the rows are walked
+  __shared__ __attribute__((aligned(16))) float pvs[NR * 4];      // (x, y, dx, dy) of the scene's pedestrians
+  __shared__ __attribute__((aligned(16))) float wat_s[64 * (H + 4)], w3_s[64 * SR_LDW + 16];
+  constexpr bool W2T = TRAIN;
+  constexpr int NFS = KEEP == 0 ? 1 : NJB;  // feature slots of a wave (no KEEP: the adjoint pass computes them again, one block at a time)
+  __shared__ __attribute__((aligned(16))) float w2s[64 * SR_LD2], w2ts[W2T ? 32 * SR_LD2T : 4];
+  __shared__ __attribute__((aligned(16))) float bzs[64];
+  __shared__ __attribute__((aligned(16))) float fss[NW * NFS * 64];  // the pair features of a row's blocks, per wave
   __shared__ float bat_s[64], b3_s[64];
+  float* whs = smem;
   const SrDense DN = {wat_s, w3_s, bat_s, b3_s, whs};
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pp = lane & 15, kq = lane >> 4;
   float* Zs = smem + w * SR_TILE_FLOATS;  // [16][SR_LDZ]
   float* L1s = Zs + 16 * SR_LDZ;          // [16][SR_LD1]
   float* Gs = L1s + 16 * SR_LD1;          // [16][SR_LD1]: dz1 | (f0, f1, f2, 1)
-  float* red = smem;                      // [4][16][LDC]
-  SrWeights W;
-  sr_load_weights(a, pp, kq, W);
-  sr_stage_dense_weights<H>(a, DN);
-  float w2t[2][4][4];  // A operand of dz1^T = W2^T dz2^T: W2[m = 16 t + 4 kq + r][u = 16 tp + pp]
-  f32x4 dW2[4][2];     // dW2[m = 16 tm + 4 kq + r][u = 16 tu + pp], over every scene of this workgroup
-  f32x4 dW1[2];        // [dW1 | db1][u = 16 tp + 4 kq + r][c = pp] (lanes pp < 4)
-  float db2[4];        // db2[16 tm + pp], partial over the lane's pairs (folded over kq at the end)
-  if (TRAIN) {
+  float* red = smem;                      // [NW][16 JR][SR_LDC]
+  const float* wfl = w2s + pp * SR_LD2 + 4 * kq;   // forward fragments
+  const float* wtl = W2T ? w2ts + pp * SR_LD2T + 4 * kq : w2s + 4 * kq * SR_LD2 + pp;  // adjoint fragments
+  const float* bzl = bzs + 16 * kq;
+  float w1a[2];
 #pragma unroll
-    for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w2t[tp][t][r] = a.W2[(16 * t + 4 * kq + r) * 32 + 16 * tp + pp];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      dW2[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dW2[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      db2[t] = 0.f;
-    }
-    dW1[0] = dW1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  for (int tp = 0; tp < 2; ++tp) w1a[tp] = kq < 3 ? a.W1[(16 * tp + pp) * 3 + kq] : a.b1[16 * tp + pp];
+  sr_stage_w2<NW, W2T>(a, w2s, w2ts, bzs);
+  sr_stage_dense_weights<H, NW>(a, DN);
+  bool wrote = false;  // this workgroup's partial block has been started
 
   const int RS = a.row_splits;
   __shared__ int last_s;
+#ifdef SR_PROFILE
+  unsigned long long prof[16], tlast = __builtin_amdgcn_s_memtime();
+  for (int k = 0; k < 16; ++k) prof[k] = 0;
+#endif
+  SR_T(0);  // 0: fragments, dense weights issued
   for (int un = blockIdx.x; un < a.S * RS; un += gridDim.x) {
     const int sc = un / RS, rs = un - sc * RS;
     const int s0 = a.scenes[2 * sc], n = a.scenes[2 * sc + 1] - s0;
     if (n <= 1) {  // no attention, no gradient: dvc = dWh = 0 (Wh: any finite value), dh untouched (or 0)
+      int tid_n = threadIdx.x;  // (afresh: see below)
+      asm volatile("" : "+v"(tid_n));
       if (n == 1 && rs == 0) {
-        if ((int)threadIdx.x < 65) a.dvc[(size_t)s0 * a.ldv + threadIdx.x] = 0.f;
-        if ((int)threadIdx.x < a.F) {
-          a.Wh_out[(size_t)s0 * a.F + threadIdx.x] = 0.f;
-          a.dWh_out[(size_t)s0 * a.F + threadIdx.x] = 0.f;
+        if (tid_n < 65) a.dvc[(size_t)s0 * a.ldv + tid_n] = 0.f;
+        if (tid_n < a.F) {
+          a.Wh_out[(size_t)s0 * a.F + tid_n] = 0.f;
+          a.dWh_out[(size_t)s0 * a.F + tid_n] = 0.f;
         }
-        if (!a.accumulate_dh && (int)threadIdx.x < H) a.dh[(size_t)s0 * a.ld_dh + threadIdx.x] = 0.f;
+        if (!a.accumulate_dh && tid_n < H) a.dh[(size_t)s0 * a.ld_dh + tid_n] = 0.f;
       }
       continue;
     }
-    __syncthreads();  // (the dense weights are staged; the previous scene's epilogue is through with vs / hs / whs)
-    sr_stage_scene<H>(a, s0, n, DN, vs, hs, rs == 0 ? a.Wh_out : nullptr);
-    SrNeighbour N[NJB];
+    const int F = a.F, jt = (n + 15) >> 4;
+    __syncthreads();  // (the fragments and dense weights are staged; the previous scene's epilogue is through with everything)
+    SR_T(1);  // 1: weights staged (barrier)
+    // (thread indices afresh for the staging stage: what the prologue derived from them would otherwise be carried through the row
+    // loop, where no register is free -- in scratch)
+    int tid_s = threadIdx.x;
+    asm volatile("" : "+v"(tid_s));
+    const int w_s = tid_s >> 6, pp_s = tid_s & 15, kq_s = (tid_s >> 4) & 3;
+    // ---- stage the scene: h, dS (pad rows zero: they enter the two small products as operands), positions
+    for (int e = tid_s; e < 16 * jt * (H / 4); e += NT) {
+      const int row = e / (H / 4), c = e - row * (H / 4);
+      f32x4 h4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
+      if (row < n) {
+        h4 = *reinterpret_cast<const f32x4*>(a.h + (size_t)(s0 + row) * a.ld_h + 4 * c);
+        d4 = *reinterpret_cast<const f32x4*>(a.dS + (size_t)(s0 + row) * a.ld_ds + 4 * c);
+      }
+      *reinterpret_cast<f32x4*>(hs + row * LDH + 4 * c) = h4;
+      *reinterpret_cast<f32x4*>(dss + row * LDH + 4 * c) = d4;
+    }
+    for (int j = tid_s; j < 16 * jt; j += NT) {
+      const int jc = s0 + (j < n ? j : 0), jx = a.xy_mod > 0 ? jc % a.xy_mod : jc;
+      *reinterpret_cast<f32x4*>(pvs + 4 * j) = f32x4{a.xy[2 * jx], a.xy[2 * jx + 1], a.dxy[2 * jx], a.dxy[2 * jx + 1]};
+    }
+    __syncthreads();
+    SR_T(2);  // 2: h, dS, positions staged
+    for (int t = w_s; t < jt * (F >> 4); t += NW) {  // Wh = h W_at^T + b_at
+      const int j0 = 16 * (t / (F >> 4)), f0 = 16 * (t % (F >> 4));
+      const float bias = bat_s[f0 + pp_s];
+      const f32x4 acc = sr_tile<true>(hs, LDH, j0, wat_s, H + 4, f0, H, f32x4{bias, bias, bias, bias}, pp_s, kq_s);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + 4 * kq_s + r;
+        whs[j * SR_LDW + f0 + pp_s] = acc[r];
+        if (rs == 0 && j < n) a.Wh_out[(size_t)(s0 + j) * F + f0 + pp_s] = acc[r];
+      }
+    }
+    // DA = dS h^T (rows of another split: zero -- the slot ends as a_ij, and this workgroup's A^T dS takes its own rows only)
+    for (int t = w_s; t < jt * jt; t += NW) {
+      const int i0 = 16 * (t / jt), j0 = 16 * (t % jt);
+      const f32x4 acc = sr_tile<true>(dss, LDH, i0, hs, LDH, j0, H, f32x4{0.f, 0.f, 0.f, 0.f}, pp_s, kq_s);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * kq_s + r;
+        das[i * DAL + j0 + pp_s] = (RS == 1 || (i / NW) % RS == rs) ? acc[r] : 0.f;
+      }
+    }
+    __syncthreads();
+    SR_T(3);  // 3: Wh, DA
+    for (int t = w_s; t < jt * 5; t += NW) {  // [v | c] = Wh [W3 | b3]  (the fifth column tile: c in its first column)
+      const int j0 = 16 * (t / 5), m0 = 16 * (t % 5);
+      const f32x4 acc = sr_tile<false>(whs, SR_LDW, j0, w3_s, SR_LDW, m0, F, f32x4{0.f, 0.f, 0.f, 0.f}, pp_s, kq_s);
+      if (m0 + pp_s <= 64) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vs[(j0 + 4 * kq_s + r) * SR_LDV + m0 + pp_s] = acc[r];
+      }
+    }
+    __syncthreads();  // (Wh is dead: region A belongs to the waves' tiles now)
+    SR_T(4);  // 4: v, c
+
+    // ---- the rows
+    // The weight-gradient accumulators live for the rows of ONE scene and are folded into the workgroup's partial block
+    // right behind them: kept across scenes they sat in registers through the staging and epilogue tile products, which
+    // need the room -- the compiler parked 50 of them in scratch and fetched them back, twice per scene.
+    f32x4 dW2[4][2];     // dW2[m = 16 tm + 4 kq + r][u = 16 tu + pp]
+    f32x4 dW1[2];        // [dW1 | db1][u = 16 tp + 4 kq + r][c = pp] (lanes pp < 4)
+    float db2[4];        // db2[16 tm + pp], partial over the lane's pairs (folded over kq below)
+    if (TRAIN) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dW2[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dW2[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db2[t] = 0.f;
+      }
+      dW1[0] = dW1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // (What a lane knows about its neighbour j of a block -- position, c_j -- is read from the staged scene per block, and the
+    // pair features wait for the adjoint pass in a wave-private LDS slot: registers held across the row loop are what
+    // decides whether eight waves fit.)
     f32x4 dv[NJB][4];
-    float dc[NJB], dhq[NJB][HQ];
+    float dc[NJB];
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb) {
-      sr_load_neighbour(a, s0, n, 16 * jb + pp, vs, N[jb]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) dv[jb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       dc[jb] = 0.f;
-#pragma unroll
-      for (int k = 0; k < HQ; ++k) dhq[jb][k] = 0.f;
     }
-    for (int i = 4 * rs + w; i < n; i += 4 * RS) {
-      const int gi = s0 + i, ix = a.xy_mod > 0 ? gi % a.xy_mod : gi;
-      const float pix = a.xy[2 * ix], piy = a.xy[2 * ix + 1], vix = a.dxy[2 * ix], viy = a.dxy[2 * ix + 1];
-      float dsq[HQ];  // dS_i[kq HQ + k]
-      {
-        const float* src = a.dS + (size_t)gi * a.ld_ds + kq * HQ;
-#pragma unroll
-        for (int k = 0; k < HQ; k += 4) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4*>(src + k);
-          dsq[k] = t4[0]; dsq[k + 1] = t4[1]; dsq[k + 2] = t4[2]; dsq[k + 3] = t4[3];
-        }
-      }
-      // pass 1 over the row's blocks: the forward values (kept or thrown away), the score, and da_ij = dS_i . h_j
-      constexpr int NK = KEEP ? NJB : 1;
-      float f[NK][3], l1[NK][8], sg[NJB], da[NJB];
+    float* fsl = fss + w * (NFS * 64);  // [NFS][16 pairs][f0 f1 f2 1]
+    for (int i = NW * rs + w; i < n; i += NW * RS) {
+      // pass 1 over the row's blocks: the forward values (kept or thrown away) and the score
+      // (l1 is not kept across the passes: two products bring it back, 8 registers per block do not fit)
+      constexpr int NK = KEEP == 1 ? NJB : 1;
+      const int jbl = (n - 1) >> 4;  // the row's last block
+      float sg[NJB], da[NJB];
       f32x4 z[NK][4];
+      SR_T(5);  // 5: row head
 #pragma unroll
       for (int jb = 0; jb < NJB; ++jb) {
         if (16 * jb >= n) {
@@ -429,20 +574,33 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
           da[jb] = 0.f;
           continue;
         }
-        const int q = KEEP ? jb : 0;
-        sr_features(pix, piy, vix, viy, N[jb].px, N[jb].py, N[jb].vx, N[jb].vy, f[q]);
-        sr_pair_mlp(W, kq, f[q], l1[q], z[q]);
-        sg[jb] = sr_score(z[q], vs + N[jb].j * SR_LDV + 4 * kq, N[jb], 16 * jb + pp == i);
-        const float* hrow = hs + N[jb].j * LDH + kq * HQ;
-        float d = 0.f;
-#pragma unroll
-        for (int k = 0; k < HQ; k += 4) {
-          const f32x4 h4 = *reinterpret_cast<const f32x4*>(hrow + k);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) d = fmaf(dsq[k + c], h4[c], d);
+        const int q = KEEP == 1 ? jb : 0;
+        const bool ok = 16 * jb + pp < n;
+        const int j = ok ? 16 * jb + pp : 0;
+        da[jb] = das[i * DAL + 16 * jb + pp];
+        float f[3], l1[8];
+        {
+          const f32x4 qi = *reinterpret_cast<const f32x4*>(sr_here(pvs + 4 * i));
+          const f32x4 qj = *reinterpret_cast<const f32x4*>(sr_here(pvs + 4 * j));
+          sr_features(qi[0], qi[1], qi[2], qi[3], qj[0], qj[1], qj[2], qj[3], f);
         }
-        da[jb] = quarters_sum(d);
+        if (KEEP != 0 && kq == 0) *reinterpret_cast<f32x4*>(fsl + jb * 64 + 4 * pp) = f32x4{f[0], f[1], f[2], 1.0f};
+        sr_pair_mlp_lds(w1a, sr_here(wfl), sr_here(bzl), kq, f, l1, z[q]);
+        const float* vrow = sr_here(vs + j * SR_LDV + 4 * kq);
+        float sp0 = 0.f, sp1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(vrow + 16 * t), v1 = *reinterpret_cast<const f32x4*>(vrow + 16 * t + 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sp0 = fmaf(fmaxf(z[q][t][r], 0.f), v0[r], sp0);
+            sp1 = fmaf(fmaxf(z[q][t + 1][r], 0.f), v1[r], sp1);
+          }
+        }
+        const float sgv = quarters_sum(sp0 + sp1) + vrow[64 - 4 * kq];  // sigma_ij = l2_ij . v_j + c_j
+        sg[jb] = !ok ? -INFINITY : (16 * jb + pp == i ? -1000.0f : sgv);  // (social.py:25: sigma_ii = -1000)
       }
+      SR_T(6);  // 6: pass 1
       float mx = sg[0];
 #pragma unroll
       for (int jb = 1; jb < NJB; ++jb) mx = fmaxf(mx, sg[jb]);
@@ -450,7 +608,7 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
       float at[NJB], den = 0.f;
 #pragma unroll
       for (int jb = 0; jb < NJB; ++jb) {
-        at[jb] = N[jb].ok ? __expf(sg[jb] - mx) : 0.f;
+        at[jb] = 16 * jb + pp < n ? __expf(sg[jb] - mx) : 0.f;
         den += at[jb];
       }
       const float inv = 1.0f / row_sum16(den);
@@ -461,22 +619,45 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
         dot = fmaf(at[jb], da[jb], dot);
       }
       dot = row_sum16(dot);
+      SR_T(7);  // 7: softmax
       // pass 2: the adjoints
 #pragma unroll
-      for (int jb = 0; jb < NJB; ++jb) {
+      for (int jbr = 0; jbr < NJB; ++jbr) {
+        const int jb = KEEP == 2 ? NJB - 1 - jbr : jbr;  // (KEEP == 2: the block whose forward values are still there first)
         if (16 * jb >= n) continue;
-        const int q = KEEP ? jb : 0;
-        if (!KEEP) {
-          sr_features(pix, piy, vix, viy, N[jb].px, N[jb].py, N[jb].vx, N[jb].vy, f[q]);
-          sr_pair_mlp(W, kq, f[q], l1[q], z[q]);
-        }
-        // neighbour sums: dh_j += a_ij dS_i ; d[v_j | c_j] += dsigma_ij [l2_ij | 1]
+        const int q = KEEP == 1 ? jb : 0;
+        const int j = 16 * jb + pp < n ? 16 * jb + pp : 0;
+        if (KEEP == 0 || (KEEP == 2 && jb != jbl)) {
+          float f[3], l1[8];
+          const f32x4 qi = *reinterpret_cast<const f32x4*>(sr_here(pvs + 4 * i));
+          const f32x4 qj = *reinterpret_cast<const f32x4*>(sr_here(pvs + 4 * j));
+          sr_features(qi[0], qi[1], qi[2], qi[3], qj[0], qj[1], qj[2], qj[3], f);
+          sr_pair_mlp_lds(w1a, sr_here(wfl), sr_here(bzl), kq, f, l1, z[q]);
+          if (TRAIN) {
+            if (KEEP == 0 && kq == 0) *reinterpret_cast<f32x4*>(fsl + 4 * pp) = f32x4{f[0], f[1], f[2], 1.0f};
 #pragma unroll
-        for (int k = 0; k < HQ; ++k) dhq[jb][k] = fmaf(at[jb], dsq[k], dhq[jb][k]);
-        // softmax adjoint (0 on padding lanes; sigma_ii is the constant -1000: nothing flows through it)
-        const float dsg = (16 * jb + pp == i) ? 0.f : at[jb] * (da[jb] - dot);
+            for (int tp = 0; tp < 2; ++tp)
+              *reinterpret_cast<f32x4*>(L1s + pp * SR_LD1 + 16 * tp + 4 * kq) =
+                  f32x4{l1[4 * tp], l1[4 * tp + 1], l1[4 * tp + 2], l1[4 * tp + 3]};
+          }
+        } else if (TRAIN) {
+          // (l1 again: two products; it goes straight to its tile -- d1's mask reads it back)
+          const float fb = sr_here(fsl + (KEEP == 0 ? 0 : jb) * 64 + 4 * pp)[kq];
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 p0 = MFMA16(w1a[0], fb, zero), p1 = MFMA16(w1a[1], fb, zero);
+          *reinterpret_cast<f32x4*>(L1s + pp * SR_LD1 + 4 * kq) =
+              f32x4{fmaxf(p0[0], 0.f), fmaxf(p0[1], 0.f), fmaxf(p0[2], 0.f), fmaxf(p0[3], 0.f)};
+          *reinterpret_cast<f32x4*>(L1s + pp * SR_LD1 + 16 + 4 * kq) =
+              f32x4{fmaxf(p1[0], 0.f), fmaxf(p1[1], 0.f), fmaxf(p1[2], 0.f), fmaxf(p1[3], 0.f)};
+        }
+        const float daj = sr_here(das + i * DAL + 16 * jb)[pp];
+        wave_lds_sync();
+        if (kq == 0) das[i * DAL + 16 * jb + pp] = at[jb];  // a_ij for dh_j = sum_i a_ij dS_i (0 on padding lanes)
+        // softmax adjoint (0 on padding lanes; sigma_ii is the constant -1000: nothing flows through it);
+        // d[v_j | c_j] += dsigma_ij [l2_ij | 1]
+        const float dsg = (16 * jb + pp == i) ? 0.f : at[jb] * (daj - dot);
         dc[jb] += dsg;
-        const float* vrow = vs + N[jb].j * SR_LDV + 4 * kq;
+        const float* vrow = sr_here(vs + j * SR_LDV + 4 * kq);
         f32x4 dz2[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -486,32 +667,42 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
             dv[jb][t][r] = fmaf(dsg, fmaxf(z[q][t][r], 0.f), dv[jb][t][r]);
             dz2[t][r] = z[q][t][r] > 0.f ? dsg * v4[r] : 0.f;
           }
+          if (TRAIN) *reinterpret_cast<f32x4*>(Zs + pp * SR_LDZ + 16 * t + 4 * kq) = dz2[t];
         }
+        SR_T(8);  // 8: sums, dz2
         if (TRAIN) {
           // dz1^T (32 units x 16 pairs) = W2^T dz2^T: B operand = registers in the D layout of the forward product
           f32x4 d1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+          const float* wt = sr_here(wtl);
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+          for (int t = 0; t < 4; ++t) {
+            if (W2T) {
+              const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + 16 * t), w1 = *reinterpret_cast<const f32x4*>(wt + 16 * SR_LD2T + 16 * t);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              d1[0] = MFMA16(w2t[0][t][r], dz2[t][r], d1[0]);
-              d1[1] = MFMA16(w2t[1][t][r], dz2[t][r], d1[1]);
+              for (int r = 0; r < 4; ++r) {
+                d1[0] = MFMA16(w0[r], dz2[t][r], d1[0]);
+                d1[1] = MFMA16(w1[r], dz2[t][r], d1[1]);
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                d1[0] = MFMA16(wt[(16 * t + r) * SR_LD2], dz2[t][r], d1[0]);
+                d1[1] = MFMA16(wt[(16 * t + r) * SR_LD2 + 16], dz2[t][r], d1[1]);
+              }
             }
-          // d1[tp][r] = unit 16 tp + 4 kq + r = u(s = 4 tp + r): the units this lane holds l1 for.
+          }
+          SR_T(9);  // 9: dz1 products
+          // d1[tp][r] = unit 16 tp + 4 kq + r = u(s = 4 tp + r): the units this lane wrote l1 for.
           // All three weight gradients contract over the 16 PAIRS: dz2, l1, dz1 and the features go through the wave's
           // LDS tiles into A / B fragments (pair = step + 4 k)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(Zs + pp * SR_LDZ + 16 * t + 4 * kq) = dz2[t];
-#pragma unroll
           for (int tp = 0; tp < 2; ++tp) {
-            *reinterpret_cast<f32x4*>(L1s + pp * SR_LD1 + 16 * tp + 4 * kq) =
-                f32x4{l1[q][4 * tp], l1[q][4 * tp + 1], l1[q][4 * tp + 2], l1[q][4 * tp + 3]};
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(L1s + pp * SR_LD1 + 16 * tp + 4 * kq);
             f32x4 g;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) g[r] = l1[q][4 * tp + r] > 0.f ? d1[tp][r] : 0.f;
+            for (int r = 0; r < 4; ++r) g[r] = l4[r] > 0.f ? d1[tp][r] : 0.f;
             *reinterpret_cast<f32x4*>(Gs + pp * SR_LD1 + 16 * tp + 4 * kq) = g;
           }
-          if (kq == 0) *reinterpret_cast<f32x4*>(Gs + pp * SR_LD1 + 32) = f32x4{f[q][0], f[q][1], f[q][2], 1.0f};
           wave_lds_sync();
 #pragma unroll
           for (int sp = 0; sp < 4; ++sp) {  // k step sp: MFMA k index kq <-> pair sp + 4 kq
@@ -520,7 +711,7 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
             const float* lr = L1s + pr * SR_LD1 + pp;
             const float* gr = Gs + pr * SR_LD1 + pp;
             const float b0 = lr[0], b1v = lr[16];
-            const float fc = pp < 4 ? gr[32] : 0.f;
+            const float fc = pp < 4 ? fsl[(KEEP == 0 ? 0 : jb) * 64 + 4 * pr + pp] : 0.f;
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) {
               const float av = zr[16 * tm];
@@ -532,46 +723,102 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
             dW1[1] = MFMA16(gr[16], fc, dW1[1]);
           }
           wave_lds_sync();  // the tiles are rewritten by the next block
+          SR_T(10);  // 10: tiles + weight-gradient products
         }
       }
     }
-    // the four waves' neighbour sums meet in LDS (region A: every wave must be done with its tiles -- and, below, with the
-    // staged scene), one j-block per round, fixed order.  The folded sums stay on chip: d[v | c] -> vs, the neighbour part
-    // of dh -> hs (one workgroup per scene), or this workgroup's share -> scratch (row splits)
+    SR_T(11);  // 11: loop tail
+    // (thread indices afresh for the exchanges and the epilogue: what the prologue derived from them would otherwise be carried through the row
+    // loop, where no register is free -- in scratch)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int w_e = tid_e >> 6, pp_e = tid_e & 15, kq_e = (tid_e >> 4) & 3;
+    if (TRAIN) {
+      // this scene's share of the workgroup's partial block: [64][33] = dW2 | db2, then [32][4] = dW1 | db1
+      __syncthreads();  // every wave is done with its tiles (region A)
+      float* mine = smem + w_e * SR_WG_FLOATS;
 #pragma unroll
-    for (int jb = 0; jb < NJB; ++jb) {
-      if (16 * jb >= n) break;
+      for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * tm + 4 * kq_e + r;
+          mine[m * 33 + pp_e] = dW2[tm][0][r];
+          mine[m * 33 + 16 + pp_e] = dW2[tm][1][r];
+        }
+        const float sb = quarters_sum(db2[tm]);
+        if (kq_e == 0) mine[(16 * tm + pp_e) * 33 + 32] = sb;
+      }
+      if (pp_e < 4) {
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mine[64 * 33 + (16 * tp + 4 * kq_e + r) * 4 + pp_e] = dW1[tp][r];
+      }
       __syncthreads();
-      float* mine = red + (w * 16 + pp) * LDC;
+      float* out = a.partials + (size_t)blockIdx.x * SR_WG_FLOATS;
+      for (int e = tid_e; e < SR_WG_FLOATS; e += NT) {
+        float v = (smem[e] + smem[SR_WG_FLOATS + e]) + (smem[2 * SR_WG_FLOATS + e] + smem[3 * SR_WG_FLOATS + e]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(mine + 16 * t + 4 * kq) = dv[jb][t];
-      if (kq == 0) mine[64] = dc[jb];
+        for (int q = 4; q < NW; q += 4)
+          v += (smem[q * SR_WG_FLOATS + e] + smem[(q + 1) * SR_WG_FLOATS + e]) +
+               (smem[(q + 2) * SR_WG_FLOATS + e] + smem[(q + 3) * SR_WG_FLOATS + e]);
+        out[e] = wrote ? out[e] + v : v;
+      }
+      wrote = true;
+    }
+    SR_T(14);  // 14: partial block
+    // ---- the waves' neighbour sums meet in LDS (region A: every wave must be done with its tiles), fixed order, JR blocks per
+    // round; the folded d[v | c] replace [v | c] in vs.  Beside the first round: the neighbour part of dh = A^T dS -> hs
+    // (h is dead: DA was its last reader; every row's a_ij is in place after the barrier)
 #pragma unroll
-      for (int k = 0; k < HQ; k += 4)
-        *reinterpret_cast<f32x4*>(mine + 68 + kq * HQ + k) = f32x4{dhq[jb][k], dhq[jb][k + 1], dhq[jb][k + 2], dhq[jb][k + 3]};
+    for (int jb0 = 0; jb0 < NJB; jb0 += JR) {
+      if (16 * jb0 >= n) break;
       __syncthreads();
-      for (int e = threadIdx.x; e < 16 * (65 + H); e += 256) {
-        const int jl = e / (65 + H), c = e - jl * (65 + H), j = 16 * jb + jl;
+#pragma unroll
+      for (int q = 0; q < JR; ++q) {
+        float* mine = red + ((w_e * JR + q) * 16 + pp_e) * SR_LDC;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(mine + 16 * t + 4 * kq_e) = dv[jb0 + q][t];
+        if (kq_e == 0) mine[64] = dc[jb0 + q];
+      }
+      if (jb0 == 0)
+        for (int t = w_e; t < jt * (H >> 4); t += NW) {
+          const int j0 = 16 * (t / (H >> 4)), k0 = 16 * (t % (H >> 4));
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          for (int S = 0; S < 16 * jt; S += 16)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc = MFMA16(das[(S + 4 * kq_e + r) * DAL + j0 + pp_e], dss[(S + 4 * kq_e + r) * LDH + k0 + pp_e], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hs[(j0 + 4 * kq_e + r) * LDH + k0 + pp_e] = acc[r];
+        }
+      __syncthreads();
+      for (int e = tid_e; e < 16 * JR * 65; e += NT) {
+        const int jl = e / 65, c = e - jl * 65, j = 16 * jb0 + jl;
         if (j >= n) break;
-        const float* r0 = red + jl * LDC + (c < 65 ? c : c + 3);
-        const float v = (r0[0] + r0[16 * LDC]) + (r0[32 * LDC] + r0[48 * LDC]);
-        if (RS > 1) {
-          // agent-scope atomic stores (write-through: visible to the workgroup that folds the shares without a release
-          // fence -- MI355X_MICROARCH "valid forms")
-          __hip_atomic_store(a.scratch + ((size_t)rs * a.dvc_rows + s0 + j) * (65 + H) + c, v, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        } else if (c < 65) {
-          vs[j * SR_LDV + c] = v;
-        } else {
-          hs[j * LDH + (c - 65)] = v;
-        }
+        const float* r0 = red + jl * SR_LDC + c;
+        float v = (r0[0] + r0[16 * JR * SR_LDC]) + (r0[2 * 16 * JR * SR_LDC] + r0[3 * 16 * JR * SR_LDC]);
+#pragma unroll
+        for (int q = 4; q < NW; q += 4)
+          v += (r0[q * 16 * JR * SR_LDC] + r0[(q + 1) * 16 * JR * SR_LDC]) +
+               (r0[(q + 2) * 16 * JR * SR_LDC] + r0[(q + 3) * 16 * JR * SR_LDC]);
+        vs[j * SR_LDV + c] = v;
       }
     }
+    SR_T(12);  // 12: wave fold, A^T dS
     bool finish = true;
     if (RS > 1) {
-      // the last workgroup of the scene to arrive folds the RS shares in split order
+      // this workgroup's share -> scratch; the last workgroup of the scene to arrive folds the RS shares in split order.
+      // (agent-scope atomic stores: write-through, visible to the folding workgroup without a release fence --
+      // MI355X_MICROARCH "valid forms")
+      __syncthreads();
+      for (int e = tid_e; e < n * (65 + H); e += NT) {
+        const int j = e / (65 + H), c = e - j * (65 + H);
+        __hip_atomic_store(a.scratch + ((size_t)rs * a.dvc_rows + s0 + j) * (65 + H) + c,
+                           c < 65 ? vs[j * SR_LDV + c] : hs[j * LDH + (c - 65)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __syncthreads();  // (drains this workgroup's stores)
-      if (threadIdx.x == 0) {
+      if (tid_e == 0) {
         const unsigned t = __hip_atomic_fetch_add(a.tickets + sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_s = t == (unsigned)(RS - 1);
         if (last_s) __hip_atomic_store(a.tickets + sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -579,7 +826,7 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
       __syncthreads();
       finish = last_s != 0;
       if (finish) {
-        for (int e = threadIdx.x; e < n * (65 + H); e += 256) {
+        for (int e = tid_e; e < n * (65 + H); e += NT) {
           const int j = e / (65 + H), c = e - j * (65 + H);
           const float* src = a.scratch + (size_t)(s0 + j) * (65 + H) + c;
           float v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -593,67 +840,47 @@ __global__ __launch_bounds__(256) void social_rows_bwd_kernel(const SocRowsArgs 
     if (finish) {
       // adjoints of the dense stages, on chip (MFMA tiles): dWh_j = d[v_j | c_j] [W3 | b3]^T, dh_j = (neighbour part)
       // + dWh_j W_at
-      const int F = a.F, jt = (n + 15) >> 4;
       __syncthreads();
-      for (int e = threadIdx.x; e < n * 65; e += 256) {
+      for (int e = tid_e; e < n * 65; e += NT) {
         const int j = e / 65, m = e - j * 65;
         a.dvc[(size_t)(s0 + j) * a.ldv + m] = vs[j * SR_LDV + m];  // operand of dW3 = Wh^T dv, db3 = Wh^T dc
       }
-      for (int t = w; t < jt * (F >> 4); t += 4) {
+      for (int t = w_e; t < jt * (F >> 4); t += NW) {
         const int j0 = 16 * (t / (F >> 4)), f0 = 16 * (t % (F >> 4));
-        f32x4 acc = sr_tile<true>(vs, SR_LDV, j0, w3_s, SR_LDW, f0, 64, f32x4{0.f, 0.f, 0.f, 0.f}, pp, kq);
-        const float b3f = b3_s[f0 + pp];
+        f32x4 acc = sr_tile<true>(vs, SR_LDV, j0, w3_s, SR_LDW, f0, 64, f32x4{0.f, 0.f, 0.f, 0.f}, pp_e, kq_e);
+        const float b3f = b3_s[f0 + pp_e];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int j = j0 + 4 * kq + r;
+          const int j = j0 + 4 * kq_e + r;
           acc[r] = fmaf(vs[j * SR_LDV + 64], b3f, acc[r]);
-          whs[j * SR_LDW + f0 + pp] = acc[r];
-          if (j < n) a.dWh_out[(size_t)(s0 + j) * F + f0 + pp] = acc[r];
+          whs[j * SR_LDW + f0 + pp_e] = acc[r];
+          if (j < n) a.dWh_out[(size_t)(s0 + j) * F + f0 + pp_e] = acc[r];
         }
       }
       __syncthreads();
-      for (int t = w; t < jt * (H >> 4); t += 4) {
+      for (int t = w_e; t < jt * (H >> 4); t += NW) {
         const int j0 = 16 * (t / (H >> 4)), k0 = 16 * (t % (H >> 4));
-        const f32x4 acc = sr_tile<false>(whs, SR_LDW, j0, wat_s, H + 4, k0, F, f32x4{0.f, 0.f, 0.f, 0.f}, pp, kq);
+        const f32x4 acc = sr_tile<false>(whs, SR_LDW, j0, wat_s, H + 4, k0, F, f32x4{0.f, 0.f, 0.f, 0.f}, pp_e, kq_e);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int j = j0 + 4 * kq + r;
+          const int j = j0 + 4 * kq_e + r;
           if (j < n) {
-            const float v = acc[r] + hs[j * LDH + k0 + pp];
-            float* d = a.dh + (size_t)(s0 + j) * a.ld_dh + k0 + pp;
+            const float v = acc[r] + hs[j * LDH + k0 + pp_e];
+            float* d = a.dh + (size_t)(s0 + j) * a.ld_dh + k0 + pp_e;
             *d = a.accumulate_dh ? *d + v : v;
           }
         }
       }
     }
-    __syncthreads();  // region A and the staged scene are free again
   }
 
-  if (TRAIN) {
-    // one partial block per workgroup: [64][33] = dW2 | db2, then [32][4] = dW1 | db1
-    float* mine = smem + w * SR_WG_FLOATS;
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 16 * tm + 4 * kq + r;
-        mine[m * 33 + pp] = dW2[tm][0][r];
-        mine[m * 33 + 16 + pp] = dW2[tm][1][r];
-      }
-      const float sb = quarters_sum(db2[tm]);
-      if (kq == 0) mine[(16 * tm + pp) * 33 + 32] = sb;
-    }
-    if (pp < 4) {
-#pragma unroll
-      for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mine[64 * 33 + (16 * tp + 4 * kq + r) * 4 + pp] = dW1[tp][r];
-    }
-    __syncthreads();
-    float* out = a.partials + (size_t)blockIdx.x * SR_WG_FLOATS;
-    for (int e = threadIdx.x; e < SR_WG_FLOATS; e += 256)
-      out[e] = (smem[e] + smem[SR_WG_FLOATS + e]) + (smem[2 * SR_WG_FLOATS + e] + smem[3 * SR_WG_FLOATS + e]);
-  }
+  SR_T(13);  // 13: dense adjoints
+  if (TRAIN && !wrote)  // (a workgroup without a scene of two or more pedestrians)
+    for (int e = threadIdx.x; e < SR_WG_FLOATS; e += NT) a.partials[(size_t)blockIdx.x * SR_WG_FLOATS + e] = 0.f;
+#ifdef SR_PROFILE
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.scratch)
+    for (int k = 0; k < 16; ++k) a.scratch[k] = (float)prof[k];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -662,17 +889,20 @@ static int sr_grid(int S, int RS) { return S * RS < 256 ? S * RS : 256; }
 // few scenes: the rows of a scene are dealt to two workgroups.  (Measured at 64 scenes x 20 pedestrians: the backward launch
 // 41 / 35 / 42 us with 1 / 2 / 4 splits -- a workgroup's fixed costs (weight fragments, staging the scene, the exchanges at
 // its end) outweigh the rows from four on; the knob MGGAN_SOC_SPLITS forces a value.)
+// waves per workgroup: eight (two per SIMD); four where the scene's staged rows leave no room for eight waves' tiles
+#define SR_NW(NN) ((NN) == 4 ? 4 : 8)
+static int sr_njb(int max_n) { return max_n <= 16 ? 1 : max_n <= 32 ? 2 : 4; }
 static int sr_splits(int S, int max_n) {
+  const int nw = SR_NW(sr_njb(max_n));
   static const char* force = getenv("MGGAN_SOC_SPLITS");  // measurement knob: 1, 2 or 4
-  if (force && atoi(force) >= 1 && atoi(force) <= 4 && 4 * atoi(force) <= (max_n > 4 ? max_n : 4)) return atoi(force);
+  if (force && atoi(force) >= 1 && atoi(force) <= 4 && nw * atoi(force) <= (max_n > nw ? max_n : nw)) return atoi(force);
   // (inside the iteration graph, beside the branch streams' kernels, the unsplit launch wins at 64 scenes: 1.478 vs
   //  1.489 ms per iteration over three alternating pairs -- no ticket fold, half the workgroups competing for CUs; the split
   //  is kept for really few scenes)
   int rs = 1;
-  while (rs < 2 && S * rs * 2 <= 64 && 4 * rs * 2 <= max_n) rs *= 2;
+  while (rs < 2 && S * rs * 2 <= 64 && nw * rs * 2 <= max_n) rs *= 2;
   return rs;
 }
-static int sr_njb(int max_n) { return max_n <= 16 ? 1 : max_n <= 32 ? 2 : 4; }
 
 extern "C" {
 
@@ -681,9 +911,17 @@ int mggan_social_rows_grid(int S, int max_n) { return sr_grid(S, sr_splits(S, ma
 int mggan_social_rows_partial_floats(void) { return SR_WG_FLOATS; }
 
 #define SR_FWD(HH, NN) \
-  hipLaunchKernelGGL((social_rows_fwd_kernel<HH, NN>), dim3(sr_grid(S, a.row_splits)), dim3(256), 0, stream, a)
-#define SR_BWD(HH, NN, TT, KK) \
-  hipLaunchKernelGGL((social_rows_bwd_kernel<HH, NN, TT, KK>), dim3(sr_grid(S, a.row_splits)), dim3(256), 0, stream, a)
+  hipLaunchKernelGGL((social_rows_fwd_kernel<HH, NN, SR_NW(NN)>), dim3(sr_grid(S, a.row_splits)), dim3(64 * SR_NW(NN)), 0, stream, a)
+#ifndef SR_KEEP2
+#define SR_KEEP2 1
+#endif
+#ifndef SR_NW2
+#define SR_NW2 8
+#endif
+#define SR_NWB(NN, TT) ((TT) && (NN) == 2 ? SR_NW2 : SR_NW(NN))
+#define SR_BWD(HH, NN, TT, KK)                                                                                     \
+  hipLaunchKernelGGL((social_rows_bwd_kernel<HH, NN, SR_NWB(NN, TT), TT, KK>), dim3(sr_grid(S, a.row_splits)),     \
+                     dim3(64 * SR_NWB(NN, TT)), 0, stream, a)
 
 int mggan_social_rows_fwd(int S, const int* scenes, int H, int F, int max_n, const float* xy_last, const float* dxdy_last,
                           int xy_mod, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
@@ -697,6 +935,7 @@ int mggan_social_rows_fwd(int S, const int* scenes, int H, int F, int max_n, con
                "social_rows_fwd: null pointer");
   MG_CHECK_ARG(ld_h % 4 == 0 && ld_s % 4 == 0 && ((size_t)h % 16) == 0 && ((size_t)Sout % 16) == 0,
                "social_rows_fwd: h / S rows must be 16-byte aligned (ld_h %d, ld_s %d)", ld_h, ld_s);
+  MG_CHECK_ARG(((size_t)W3 % 16) == 0 && ((size_t)Wat % 16) == 0, "social_rows_fwd: W3 / W_at must be 16-byte aligned");
   SocRowsArgs a = {};
   a.scenes = scenes; a.xy = xy_last; a.dxy = dxdy_last; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
   a.Wat = Wat; a.bat = bat; a.F = F; a.h = h; a.Sout = Sout; a.S = S; a.xy_mod = xy_mod; a.ld_h = ld_h; a.ld_s = ld_s;
@@ -724,6 +963,8 @@ int mggan_social_rows_bwd(int S, const int* scenes, int H, int F, int max_n, con
                    dWh && dh, "social_rows_bwd: null pointer");
   MG_CHECK_ARG(ldv >= 65 && ld_h % 4 == 0 && ld_ds % 4 == 0 && ((size_t)h % 16) == 0 && ((size_t)dS % 16) == 0,
                "social_rows_bwd: h / dS rows must be 16-byte aligned (ld_h %d, ld_ds %d); ldv %d >= 65", ld_h, ld_ds, ldv);
+  MG_CHECK_ARG(((size_t)W2 % 16) == 0 && ((size_t)W3 % 16) == 0 && ((size_t)Wat % 16) == 0,
+               "social_rows_bwd: W2 / W3 / W_at must be 16-byte aligned");
   SocRowsArgs a = {};
   a.scenes = scenes; a.xy = xy_last; a.dxy = dxdy_last; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
   a.Wat = Wat; a.bat = bat; a.F = F; a.h = h; a.Wh_out = Wh; a.dWh_out = dWh;
@@ -737,7 +978,7 @@ int mggan_social_rows_bwd(int S, const int* scenes, int H, int F, int max_n, con
   const bool train = partials != nullptr;
   // (four blocks per row: the forward values of a row are recomputed in the adjoint pass instead of kept)
 #define SR_BWD_N(HH, TT) \
-  do { if (njb == 1) SR_BWD(HH, 1, TT, true); else if (njb == 2) SR_BWD(HH, 2, TT, true); else SR_BWD(HH, 4, TT, false); } while (0)
+  do { if (njb == 1) SR_BWD(HH, 1, TT, 1); else if (njb == 2) SR_BWD(HH, 2, TT, (TT ? SR_KEEP2 : 1)); else SR_BWD(HH, 4, TT, 0); } while (0)
   if (H == 32) {
     if (train) SR_BWD_N(32, true); else SR_BWD_N(32, false);
   } else {
