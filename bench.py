@@ -47,8 +47,8 @@ def kernel_of(name, a):
         return fixed[name]
     if name == "mggan_decoder_rollout_fwd":  # (one wave per tile from 65,536 rollout rows on, csrc/lstm.hip)
         return "decoder_fwd_wave_kernel" if a[0] >= 65536 and os.environ.get("MGGAN_DEC_FWD") != "4" else "decoder_fwd_mfma_kernel"
-    if name in ("mggan_social_rows_fwd", "mggan_social_rows_bwd"):
-        return name[len("mggan_"):] + "_kernel"
+    if name in ("mggan_social_rows_fwd", "mggan_social_rows_bwd"):  # (one kernel per hidden width, as the tables name them)
+        return "{}_kernel<{}>".format(name[len("mggan_"):], a[2])
     if name == "mggan_conv1_pool":
         return "conv1_pool_kernel<{}>".format(a[2])
     if name == "mggan_conv2_fwd2":

@@ -96,6 +96,12 @@ __device__ __forceinline__ float mg_pad_corr(const int* dims) { return dims ? __
   MG_REAL_IMAGES(B, dims)                             \
   if ((B) != B_padded_ && B_padded_ > 0) (fin).count = (fin).count * (double)(B) / (double)B_padded_;
 
+// The lane index from the execution-mask count (v_mbcnt) instead of the work-item id register: a value that can be had again
+// anywhere at two instructions need not be kept (or spilled) across a loop that leaves no register free.  With the wave
+// index in a scalar register (mg_wave) the pair replaces threadIdx.x in the tails of such kernels.
+__device__ __forceinline__ int mg_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ int mg_wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
 // store (s_waitcnt vmcnt(0)), which costs a full HBM write round trip per barrier in kernels that stream
 // their saved activations out inside a time loop.

@@ -153,11 +153,22 @@ __device__ __forceinline__ float bce_term(int kind, float p, float y, float w, f
 }
 
 __global__ __launch_bounds__(1024) void gan_losses_kernel(GanLossArgs a) {
-  __shared__ double red[3][1024];
+  __shared__ double red[3][16];
   __shared__ float invc[256];
   __shared__ int last;
   const int t = threadIdx.x;
   const bool weighted = a.row_gen != nullptr;
+  // Everything this thread reads from memory for its first rows is asked for before the barrier below: labels, the
+  // padded-batch record, p, the row's generator.  (Behind the barrier they were a second and a third round trip of a
+  // launch that is little else: 12 us for 2,560 rows.)
+  float y[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) y[q] = a.label_u[q] ? a.lo[q] + (a.hi[q] - a.lo[q]) * (*a.label_u[q]) : a.label[q];
+  const int first = blockIdx.x * 1024 + t, step = gridDim.x * 1024;
+  const int bm = a.bmod > 0 ? a.bmod : 1, nr = a.dims ? mg_real_rows(a.dims, bm) : bm;  // row r <-> pedestrian r % bm
+  const float corr = mg_pad_corr(a.dims);
+  const float pA0 = first < a.nA ? a.p[first] : 0.5f, pB0 = first < a.nB ? a.p[a.nA + first] : 0.5f;
+  const int gA0 = weighted && first < a.nA ? a.row_gen[first] : 0;
   if (weighted && t < a.g) {
     if (a.seg) {
       const int c = a.seg[t + 1] - a.seg[t];
@@ -168,23 +179,17 @@ __global__ __launch_bounds__(1024) void gan_losses_kernel(GanLossArgs a) {
   }
   __syncthreads();
   double acc[3] = {0.0, 0.0, 0.0};
-  float y[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) y[q] = a.label_u[q] ? a.lo[q] + (a.hi[q] - a.lo[q]) * (*a.label_u[q]) : a.label[q];
-  const int first = blockIdx.x * 1024 + t, step = gridDim.x * 1024;
-  const int bm = a.bmod > 0 ? a.bmod : 1, nr = a.dims ? mg_real_rows(a.dims, bm) : bm;  // row r <-> pedestrian r % bm
-  const float corr = mg_pad_corr(a.dims);
   for (int r = first; r < a.nA; r += step) {
     if (a.dims && r % bm >= nr) { a.dp[r] = 0.f; continue; }
-    const float w = (weighted ? invc[a.row_gen[r]] : 1.f) * (a.scale[0] * corr) * a.sign_a;
+    const float w = (weighted ? invc[r == first ? gA0 : a.row_gen[r]] : 1.f) * (a.scale[0] * corr) * a.sign_a;
     float d;
-    acc[0] += (double)bce_term(a.kind, a.p[r], y[0], w, &d);
+    acc[0] += (double)bce_term(a.kind, r == first ? pA0 : a.p[r], y[0], w, &d);
     a.dp[r] = d;
   }
   for (int r = first; r < a.nB; r += step) {
     if (a.dims && r % bm >= nr) { a.dp[a.nA + r] = 0.f; continue; }
     float d;
-    acc[1] += (double)bce_term(a.kind, a.p[a.nA + r], y[1], a.scale[1] * corr, &d);
+    acc[1] += (double)bce_term(a.kind, r == first ? pB0 : a.p[a.nA + r], y[1], a.scale[1] * corr, &d);
     a.dp[a.nA + r] = d;
   }
   for (int r = first; r < a.nC; r += step) {
@@ -204,21 +209,39 @@ __global__ __launch_bounds__(1024) void gan_losses_kernel(GanLossArgs a) {
     for (int c = 0; c < a.g; ++c)
       a.dlogits[(size_t)r * a.g + c] = a.grad_c * (w * (__expf(l[c] - lse) - (c == tg ? 1.f : 0.f)));
   }
+  // workgroup sums: a fixed shuffle tree per wave, the 16 wave sums through LDS, the same tree again (two barriers; the
+  // ten-round LDS tree of 1,024 doubles this replaces was a third of the launch)
 #pragma unroll
-  for (int q = 0; q < 3; ++q) red[q][t] = acc[q];
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] += __shfl_xor(acc[q], o, 64);
+  if ((t & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) red[q][t >> 6] = acc[q];
+  }
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if (t < o) {
+  if (t < 64) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) red[q][t] += red[q][t + o];
-    }
-    __syncthreads();
+    for (int q = 0; q < 3; ++q) acc[q] = t < 16 ? red[q][t] : 0.0;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] += __shfl_xor(acc[q], o, 64);
+  }
+  if (gridDim.x == 1) {  // one workgroup: nothing to meet
+    if (t != 0) return;
+    const float A = (float)acc[0], B = (float)acc[1], C = (float)acc[2];
+    if (a.out[0]) *a.out[0] = A;
+    if (a.out[1]) *a.out[1] = B;
+    if (a.out[2]) *a.out[2] = C;
+    *a.total = (a.nA ? A : 0.f) + (a.nB ? B : 0.f) + (a.nC ? a.grad_c * C : 0.f);
+    return;
   }
   // per-workgroup sums meet in `partial`; the workgroup that takes the last ticket adds them in index order
   // (a fixed order: the result does not depend on which workgroup finishes last) and re-arms the ticket
   if (t == 0) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) a.partial[blockIdx.x * 3 + q] = red[q][0];
+    for (int q = 0; q < 3; ++q) a.partial[blockIdx.x * 3 + q] = acc[q];
     __threadfence();
     last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
   }
@@ -940,7 +963,9 @@ int mggan_gan_losses(const void* args, hipStream_t stream) {
   MG_CHECK_ARG(!a.weighted_c || a.row_gen, "gan_losses: weighted classifier term needs counts");
   int rows = a.nA > a.nB ? a.nA : a.nB;
   if (a.nC > rows) rows = a.nC;
-  int wgs = cdiv(rows, 1024);  // one row of every term per thread up to 262,144 rows
+  // one row of every term per thread up to 262,144 rows; up to 4,096 rows ONE workgroup takes four rows per thread: the
+  // ticket round trip of a second workgroup (partial sums out, atomic, partial sums back) costs more than the rows
+  int wgs = rows <= 4096 ? 1 : cdiv(rows, 1024);
   wgs = wgs < 1 ? 1 : (wgs > GAN_LOSS_MAX_WG ? GAN_LOSS_MAX_WG : wgs);
   hipLaunchKernelGGL(gan_losses_kernel, dim3(wgs), dim3(1024), 0, stream, a);
   MG_LAUNCH_CHECK("gan_losses");

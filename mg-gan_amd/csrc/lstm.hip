@@ -645,9 +645,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       for (int q = 0; q < 4; ++q) hacc[q] += p.Qe ? 0.f : p.be2d[8 * w + 4 * fk + q];  // (Qe carries the bias)
       *reinterpret_cast<f32x4*>(&hs[0][fi * DEC_HLD + 8 * w + 4 * fk]) = hacc;
       if (save) {
+        // (the lane's offset afresh: computed once per workgroup its 64-bit form was the one value too many for three
+        // waves per SIMD -- it went to scratch and came back per tile)
+        int lo = ((8 * w + 4 * fk) * 16 + fi) * 2;
+        asm volatile("" : "+v"(lo));
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float2*>(p.Cs + tg * DEC_CS_PAD + ((tg * (p.T + 1) * H + 8 * w + 4 * fk + q) * 16 + fi) * 2) = float2{0.f, hacc[q]};
+          *reinterpret_cast<float2*>(p.Cs + tg * DEC_CS_PAD + (tg * (p.T + 1) * H + q) * 32 + lo) = float2{0.f, hacc[q]};
       }
     }
     // ---- time-invariant social half of hidden2pos: q = W1[:, H:] soc + b1 (every wave) ----

@@ -910,8 +910,12 @@ int mggan_social_rows_splits(int S, int max_n) { return sr_splits(S, max_n); }
 int mggan_social_rows_grid(int S, int max_n) { return sr_grid(S, sr_splits(S, max_n)); }
 int mggan_social_rows_partial_floats(void) { return SR_WG_FLOATS; }
 
+#ifndef SR_NWF
+#define SR_NWF 8
+#endif
+#define SR_NWFW(NN) ((NN) == 4 ? 4 : SR_NWF)
 #define SR_FWD(HH, NN) \
-  hipLaunchKernelGGL((social_rows_fwd_kernel<HH, NN, SR_NW(NN)>), dim3(sr_grid(S, a.row_splits)), dim3(64 * SR_NW(NN)), 0, stream, a)
+  hipLaunchKernelGGL((social_rows_fwd_kernel<HH, NN, SR_NWFW(NN)>), dim3(sr_grid(S, a.row_splits)), dim3(64 * SR_NWFW(NN)), 0, stream, a)
 #ifndef SR_KEEP2
 #define SR_KEEP2 1
 #endif
