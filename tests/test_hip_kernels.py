@@ -329,7 +329,8 @@ def test_mlp_chain_matches_torch(rows, dims, acts, train_w, need_dx):
 
 @pytest.mark.parametrize("H,sizes", [(32, [1, 2, 20, 1, 1, 7, 33, 64, 3, 5, 1]), (64, [20] * 7 + [1] * 70 + [13, 2]),
                                      (32, [1, 1, 1]), (64, [32] * 9 + [17, 16, 15]), (32, [16, 5, 4, 3, 2, 1] * 3),
-                                     (64, [48, 64, 33, 1, 50]), (32, [20] * 300)])
+                                     (64, [48, 64, 33, 1, 50]), (32, [20] * 300),
+                                     (64, [24, 31, 17, 2]), (32, [32] * 4 + [19])])  # (few scenes of two blocks: row splits)
 def test_social_attention_rows_match_the_unfused_launches(H, sizes):
     """The row-structured social attention (csrc/social_rows.hip: one launch per direction, MFMA pair MLP, nothing saved
     per pair, weight gradients inside the backward launch) against the per-stage entry points on ragged scenes: lone
