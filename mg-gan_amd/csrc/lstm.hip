@@ -1390,7 +1390,11 @@ int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, co
   const bool vec = (ld_dhT % 4 == 0) && ((size_t)dhT % 16 == 0);  // the matrix-core kernel reads dh_T as 16-byte quads
   // below ~4k trajectories the 16/32-row tiles leave most CUs without a workgroup (1,280 rows: 40-80 workgroups) and
   // the lane-per-(row, unit) kernel with its 4/8-row workgroups is as fast or faster (measured at 1,280: 17-23 us either way)
-  if (valu || !vec || b < 4096) {
+  // (MGGAN_LSTM_MFMA_MIN_B: measurement knob for the threshold.  Inside the configs[1] graph, three alternating pairs:
+  //  1.429-1.433 ms with the lane-per-unit kernel, 1.423-1.432 with the matrix-core one -- within the noise)
+  static int min_b = -1;
+  if (min_b < 0) { const char* e = getenv("MGGAN_LSTM_MFMA_MIN_B"); min_b = e ? atoi(e) : 4096; }
+  if (valu || !vec || b < min_b) {
     if (H == 32) hipLaunchKernelGGL((lstm_bwd_kernel<32, 0>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((lstm_bwd_kernel<64, 64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
   } else {
