@@ -36,7 +36,6 @@ def kernel_of(name, a):
     """C-ABI entry -> the HIP kernel that does its work, named as tools/hbm_traffic.py and the rocprofv3
     summaries under profiles/ name it."""
     fixed = {
-        "mggan_decoder_rollout_bwd_fused": "decoder_bwd_mfma_kernel",
         "mggan_wgrad_multi": "wgrad_stream_kernel",  # <0> feature-major + <2> row-major launches of one batch
         "mggan_wgrad": "gemm_kernel<true,true,false>",
         "mggan_linear_fwd": "gemm_kernel<false,false,false>",
@@ -45,6 +44,9 @@ def kernel_of(name, a):
     }
     if name in fixed:
         return fixed[name]
+    if name == "mggan_decoder_rollout_bwd_fused":  # (two waves per tile from 65,536 rollout rows on, csrc/lstm.hip; a[21] = rows)
+        force = os.environ.get("MGGAN_DEC_BWD", "")
+        return "decoder_bwd_pair_kernel" if force == "2" or (force != "4" and a[21] >= 65536) else "decoder_bwd_mfma_kernel"
     if name == "mggan_decoder_rollout_fwd":  # (one wave per tile from 65,536 rollout rows on, csrc/lstm.hip)
         return "decoder_fwd_wave_kernel" if a[0] >= 65536 and os.environ.get("MGGAN_DEC_FWD") != "4" else "decoder_fwd_mfma_kernel"
     if name in ("mggan_social_rows_fwd", "mggan_social_rows_bwd"):  # (one kernel per hidden width, as the tables name them)

@@ -1294,6 +1294,373 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+#ifdef DEC_PROFILE  // measurement build: segment cycle counts of workgroup 0, wave 0, printed at the end
+#define DP_T(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); prof[k] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DP_T(k) do {} while (0)
+#endif
+// ------------------------------------------------------------------------------------
+// The fused backward with TWO waves per 16-row tile (round 4).  In decoder_bwd_mfma_kernel every wave's recurrence
+// product has an M tile of 8 units + 8 copies of the two `d dxdy` rows: 128 products per tile and step where 64 carry
+// information, and two tiles in flight per CU.  Here wave u of a tile owns units 16 u .. 16 u + 15 (lane (fi, fk): units
+// 16 u + 4 fk + 0..3 of tile row fi -- the D rows of its recurrence product, so dh lands where the gate arithmetic wants
+// it), the M axis of [W_hh^T] . dPre^T is all units (32 products per wave), the weight gradient dW_hh += dPre^T h is split by
+// its M tiles (32 per wave), and d dxdy = A^T dPre (2 x 128 per row) is a lane-local dot product over the lane's own 16
+// gate gradients, folded over the four lane groups (v_permlane swaps) and the two waves (LDS, behind the step's one
+// barrier).  144 instead of 216 products per tile and step, the vector work per tile unchanged; a workgroup of four waves
+// carries two tiles (slots) of one generator side by side, two workgroups per CU: four tiles in flight per CU.
+// f32 products and vector instructions share the SIMD's pipe: what counts is their sum per tile.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void decoder_bwd_pair_kernel(DecFusedArgs p) {
+  constexpr int H = 32, Hh = 16, S = 32;
+  __shared__ __attribute__((aligned(16))) float dps[2][2][16 * DB_RS];   // [slot][t & 1]
+  __shared__ __attribute__((aligned(16))) float hts[2][3][16 * DB_HS + 16];  // [slot][t % 3]; columns 32..35 of a row: (dx, dy, 1, 0)
+  __shared__ __attribute__((aligned(16))) float dus[2][2][16 * DB_US];   // [slot][t & 1]
+  __shared__ __attribute__((aligned(16))) float dds[2][2][2][16 * 2];    // [slot][t & 1][wave of the pair][row][component]
+  __shared__ __attribute__((aligned(16))) float cAs[2][4][32];           // [u][fk][(r, gate) x (x, y)]: A of the lane's positions
+  // the A fragments of the recurrence product, one row per (u, lane): in registers they were 32 values too many for two
+  // waves per SIMD (the compiler parked them in scratch and fetched them back every step)
+  __shared__ __attribute__((aligned(16))) float ahs[2][64][36];
+  extern __shared__ __attribute__((aligned(16))) float tailw[];  // W_e2d[:, :EIN] (H x e2ld, dEnc only) | W1[:, H:] (Hh x 36)
+  const int gi = blockIdx.x / p.NW, wi = blockIdx.x % p.NW;
+  // (the wave index in a scalar register: slot, tile and the tile's record bases are then scalars and the per-lane part of
+  // every saved-state address is a 32-bit offset -- as 64-bit per-lane pointers they did not fit)
+  const int lane = threadIdx.x & 63, w = mg_wave(), fi = lane & 15, fk = lane >> 4;
+  const int slot = w >> 1, u = w & 1, ub = 16 * u + 4 * fk;
+  const long po = (long)gi * p.param_stride;
+  const float* P = p.prep + (size_t)gi * p.prep_stride;
+  const float* Whh = p.W_hh + po;
+  const float* W1 = p.W1 + po;
+  const int seg0 = p.seg[gi], seg1 = p.seg[gi + 1];
+  const int ntiles = (seg1 - seg0 + 15) / 16;
+  float* wp = p.wpart + (size_t)blockIdx.x * DF_WLEN;
+  if (2 * wi >= ntiles) {  // no tile for this workgroup: an all-zero partial block
+    for (int i = threadIdx.x; i < DF_WLEN; i += 256) wp[i] = 0.f;
+    return;
+  }
+  const int tbase = dec_tile_base(p.seg, gi);
+  // A operands.  Position pp = unit*4 + gate in the dPre tile <-> original gate row (pp & 3)*H + (pp >> 2).
+  float Aw1[4], w2c[2][4];
+  for (int e = threadIdx.x; e < 2 * 64 * 32; e += 256) {
+    const int uu = e >> 11, ll = (e >> 5) & 63, ks = e & 31;
+    const int pp = 16 * (ks >> 2) + 4 * (ll >> 4) + (ks & 3), m = (pp & 3) * H + (pp >> 2);
+    ahs[uu][ll][ks] = Whh[(size_t)m * H + 16 * uu + (ll & 15)];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) Aw1[ks] = W1[(size_t)(4 * fk + ks) * (H + S) + 16 * u + fi];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    w2c[0][q] = p.W2[po + 4 * fk + q];
+    w2c[1][q] = p.W2[po + Hh + 4 * fk + q];
+  }
+  if (threadIdx.x < 256) {  // cAs[u'][fk'][(4 r + q) * 2 + c] = A[gate row q*H + 16 u' + 4 fk' + r][c]
+    const int e = threadIdx.x, uu = e >> 7, ff = (e >> 5) & 3, k = e & 31, rr = k >> 3, qq = (k >> 1) & 3, c = k & 1;
+    cAs[uu][ff][k] = P[prep_off_A(H) + (qq * H + 16 * uu + 4 * ff + rr) * 2 + c];
+  }
+  float* e2s = tailw;
+  float* w1s = p.dEnc ? tailw + H * p.e2ld : tailw;
+  const int IN = p.EIN + p.Z;
+  if (p.dEnc)
+    for (int i = threadIdx.x; i < H * p.EIN; i += 256) e2s[(i / p.EIN) * p.e2ld + i % p.EIN] = p.We2d[(size_t)(i / p.EIN) * IN + i % p.EIN];
+  for (int i = threadIdx.x; i < Hh * S; i += 256) w1s[(i / S) * 36 + i % S] = W1[(size_t)(i / S) * (H + S) + H + i % S];
+  f32x4 accW[4][2], accU = f32x4{0.f, 0.f, 0.f, 0.f}, accS = f32x4{0.f, 0.f, 0.f, 0.f};
+  // dA (4H x 2) and dbias (4H) = dPre^T [dxdy | 1] ride as a third column tile of the dW_hh product: (dx, dy, 1, 0) sit in the
+  // four pad columns of the h tile's rows.  (As lane-local sums -- 48 accumulators per lane with four units per lane -- they
+  // pushed the step loop's operands into scratch, and a scratch reload waits for every load issued before it: the prefetch.)
+  f32x4 accX[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) accW[a][0] = accW[a][1] = accX[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float accW2[2][4], accb1[4], accb2[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) accW2[0][q] = accW2[1][q] = accb1[q] = 0.f;
+  const float* cAl = cAs[u][fk];
+#ifdef DEC_PROFILE
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+
+  for (int base = 2 * wi; base < ntiles; base += 2 * p.NW) {
+    const int tile = base + slot;
+    const bool tvalid = tile < ntiles;  // (the second slot of the last pair may be empty: it walks the last tile, masked)
+    const int tl = tvalid ? tile : ntiles - 1;
+    const int r = seg0 + tl * 16 + fi;
+    const bool valid = tvalid && r < seg1;
+    const int rc = r < seg1 ? r : seg1 - 1;
+    const float vm = valid ? 1.f : 0.f;
+    const int pos = p.row_pos[rc];
+    const size_t tg = (size_t)(tbase + tl);
+    f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f}, cc, dq = {0.f, 0.f, 0.f, 0.f};
+    float dd0 = 0.f, dd1 = 0.f, s0 = 0.f, s1 = 0.f;
+    f32x4 n_g[4], n_av;
+    float2 n_ch[4], n_din, n_ga, n_gr;
+    const float gam = p.gabs ? 1.f : 0.f, grm = p.grel ? 1.f : 0.f;
+    // the tile's records (scalar bases) and this lane's offsets inside a step's record
+    const float* gt_t = p.Gt + tg * DEC_GT_PAD + tg * p.T * (H * 64);
+    const float* cs_t = p.Cs + tg * DEC_CS_PAD + tg * (p.T + 1) * (H * 32);
+    const float* av_t = p.Aact + tg * p.T * 256;
+    const float* din_t = p.Din + tg * p.T * 32;
+    const int og = (ub * 16 + fi) * 4, oc = (ub * 16 + fi) * 2, oa = (fk * 16 + fi) * 4, od = fi * 2;
+    const int oga = p.gabs ? pos * 2 : od, ogr = p.grel ? pos * 2 : od;
+    auto fetch = [&](int t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        n_g[q] = *reinterpret_cast<const f32x4*>(gt_t + t * (H * 64) + og + q * 64);
+        n_ch[q] = *reinterpret_cast<const float2*>(cs_t + t * (H * 32) + oc + q * 32);  // (c_{t-1}, h_{t-1})
+      }
+      n_av = *reinterpret_cast<const f32x4*>(av_t + t * 256 + oa);
+      const float* din = din_t + t * 32;
+      n_din = *reinterpret_cast<const float2*>(din + od);
+      // (a missing output gradient: the ADDRESS is redirected to the step's input record -- scalar base, per-lane offset
+      // chosen once per tile -- and the value masked where it is consumed: no branch, no select on a loaded value)
+      n_ga = *reinterpret_cast<const float2*>((p.gabs ? p.gabs + (size_t)t * p.Rout * 2 : din) + oga);
+      n_gr = *reinterpret_cast<const float2*>((p.grel ? p.grel + (size_t)t * p.Rout * 2 : din) + ogr);
+    };
+    lds_barrier();  // the previous tiles' last LDS reads are done
+    {
+      f32x4 hT;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float2 ch = *reinterpret_cast<const float2*>(cs_t + p.T * (H * 32) + oc + q * 32);
+        cc[q] = ch.x;
+        hT[q] = ch.y;
+      }
+      *reinterpret_cast<f32x4*>(&hts[slot][p.T % 3][fi * DB_HS + ub]) = hT;  // h_{T-1}
+    }
+    fetch(p.T - 1);
+
+    for (int t = p.T - 1; t >= 0; --t) {
+      float* dpw = dps[slot][t & 1];
+      float* duw = dus[slot][t & 1];
+      float* htw = hts[slot][t % 3];              // receives h_{t-1}
+      const float* htc = hts[slot][(t + 1) % 3];  // holds h_t
+      float* ddw = dds[slot][t & 1][0];
+      // ONE register set for the saved activations: the next step's are asked for behind this step's gate arithmetic (their
+      // last reader) and arrive under its products -- a second set (fetched a whole step ahead, as the four-wave kernel does)
+      // is 34 registers this kernel does not have
+      f32x4(&c_g)[4] = n_g;
+      float2(&c_ch)[4] = n_ch;
+      const f32x4 c_av = n_av;
+      const float2 c_din = n_din, c_ga = n_ga, c_gr = n_gr;
+      DP_T(0);  // 0: between steps / tile prologue
+#ifdef DEC_PROBE_LOADS  // measurement build: the step's loads and nothing else
+      dh += (c_g[0] + c_g[1]) + (c_g[2] + c_g[3]) + c_av;
+      dd0 += c_ch[0].x + c_ch[1].y + c_ch[2].x + c_ch[3].y + c_din.x + c_ga.x + c_gr.y;
+      continue;
+#endif
+      s0 = fmaf(c_ga.x, gam, s0); s1 = fmaf(c_ga.y, gam, s1);
+      const float g0 = (s0 + dd0 + c_gr.x * grm) * vm, g1 = (s1 + dd1 + c_gr.y * grm) * vm;
+      f32x4 du;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        du[q] = fmaf(w2c[0][q], g0, w2c[1][q] * g1) * (c_av[q] > 0.f ? 1.f : 0.01f);
+        accW2[0][q] = fmaf(g0, c_av[q], accW2[0][q]);
+        accW2[1][q] = fmaf(g1, c_av[q], accW2[1][q]);
+      }
+      dq += du;
+      accb2[0] += g0; accb2[1] += g1;
+      if (u == 0) *reinterpret_cast<f32x4*>(&duw[fi * DB_US + 4 * fk]) = du;
+      *reinterpret_cast<f32x4*>(&htw[fi * DB_HS + ub]) = f32x4{c_ch[0].y, c_ch[1].y, c_ch[2].y, c_ch[3].y};
+      if (u == 0 && fk == 0) *reinterpret_cast<f32x4*>(&htw[fi * DB_HS + 32]) = f32x4{c_din.x, c_din.y, 1.f, 0.f};
+      // dh += W1[:, :H]^T du  (rows 4 fk + r of the M tile are this lane's units)
+      f32x4 a1 = dh, a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+      a1 = MFMA16(Aw1[0], du[0], a1);
+      a2 = MFMA16(Aw1[1], du[1], a2);
+      a1 = MFMA16(Aw1[2], du[2], a1);
+      a2 = MFMA16(Aw1[3], du[3], a2);
+      DP_T(1);  // 1: step head (loads issued, du, W1 products)
+      float dp0 = 0.f, dp1 = 0.f;  // this lane's share of d dxdy_t = A^T dPre
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float dhv = a1[q] + a2[q];
+        const float gi_ = c_g[q][0], gf = c_g[q][1], gg = c_g[q][2], go = c_g[q][3];
+        const float cprev = c_ch[q].x;  // slot 0 of Cs holds c_{-1} = 0
+        const float tc = mg_tanh(cc[q]);
+        const float dO = dhv * tc;
+        const float dcv = fmaf(dhv * go, 1.f - tc * tc, dc[q]);
+        f32x4 dp;
+        dp[0] = dcv * gg * gi_ * (1.f - gi_) * vm;
+        dp[1] = dcv * cprev * gf * (1.f - gf) * vm;
+        dp[2] = dcv * gi_ * (1.f - gg * gg) * vm;
+        dp[3] = dO * go * (1.f - go) * vm;
+        dc[q] = dcv * gf;
+        cc[q] = cprev;
+        *reinterpret_cast<f32x4*>(&dpw[fi * DB_RS + (ub + q) * 4]) = dp;
+        const f32x4 ca = *reinterpret_cast<const f32x4*>(cAl + 8 * q), cb = *reinterpret_cast<const f32x4*>(cAl + 8 * q + 4);
+        dp0 = fmaf(dp[0], ca[0], fmaf(dp[1], ca[2], fmaf(dp[2], cb[0], fmaf(dp[3], cb[2], dp0))));
+        dp1 = fmaf(dp[0], ca[1], fmaf(dp[1], ca[3], fmaf(dp[2], cb[1], fmaf(dp[3], cb[3], dp1))));
+      }
+      fetch(t > 0 ? t - 1 : 0);  // (step 0 re-reads its own slots: no branch between the loads)
+      dp0 = quarters_sum(dp0);
+      dp1 = quarters_sum(dp1);
+      if (fk == 0) *reinterpret_cast<float2*>(&ddw[u * 32 + fi * 2]) = float2{dp0, dp1};
+      DP_T(2);  // 2: gate arithmetic, tile writes
+      lds_barrier();
+      DP_T(3);  // 3: barrier
+      {
+        const float2 da = *reinterpret_cast<const float2*>(&ddw[fi * 2]), db = *reinterpret_cast<const float2*>(&ddw[32 + fi * 2]);
+        dd0 = da.x + db.x;
+        dd1 = da.y + db.y;
+      }
+      // dh_{t-1} (own 16 units) = W_hh^T dPre^T, K = 128 gate rows in tile-position order
+      f32x4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int aho = lane * 36;  // (read here, every step -- not hoisted into registers that are not there; the OFFSET is laundered:
+      asm volatile("" : "+v"(aho));  //  a laundered pointer would be read with FLAT loads, which count on vmcnt like the prefetch)
+      const float* ahl = &ahs[u][0][0] + aho;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&dpw[fi * DB_RS + 16 * j + 4 * fk]);
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ahl + 4 * j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = MFMA16(a4[q], b4[q], acc[q]);
+      }
+      DP_T(4);  // 4: recurrence products
+      // weight gradients, K = the 16 tile rows: dW_hh position tiles 4 u .. 4 u + 3 x two column tiles
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        float a[4], bv[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = dpw[(ks + 4 * fk) * DB_RS + 16 * (4 * u + i) + fi];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bv[n] = htw[(ks + 4 * fk) * DB_HS + 16 * n + fi];  // (n = 2: columns 32..35 count, the rest is ignored)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) accW[i][n] = MFMA16(a[i], bv[n], accW[i][n]);
+          accX[i] = MFMA16(a[i], bv[2], accX[i]);
+        }
+        // dW1[:, :H] += du^T h_t : wave u -> column tile u
+        accU = MFMA16(duw[(ks + 4 * fk) * DB_US + fi], htc[(ks + 4 * fk) * DB_HS + 16 * u + fi], accU);
+      }
+      dh = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      DP_T(5);  // 5: weight-gradient products
+    }
+    // ---- per-row outputs of this tile: dH0, dQ, d(enc_h row), d(social row) ----
+    const int lane_t = mg_lane(), fi_t = lane_t & 15, fk_t = lane_t >> 4, ub_t = 16 * u + 4 * fk_t;  // (afresh: see the tail)
+    const int r_t = seg0 + tl * 16 + fi_t;
+    const bool valid_t = tvalid && r_t < seg1;
+    float* h0t = hts[slot][2];  // h_{-1} slot of the t = 0 step is hts[0]; hts[2] held h_1 (last read at t = 1)
+    if (valid_t) *reinterpret_cast<f32x4*>(p.dH0 + (size_t)r_t * H + ub_t) = dh;
+    *reinterpret_cast<f32x4*>(&h0t[fi_t * DB_HS + ub_t]) = dh;
+    if (u == 0 && valid_t) *reinterpret_cast<f32x4*>(p.dQ + (size_t)r_t * Hh + 4 * fk_t) = dq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accb1[q] += dq[q];
+    if (p.SocR) {
+      // dW1[:, H:] += dQ^T SocR over the 16 rows of the tile: wave u -> column tile u
+      float* dqs = dus[slot][1];
+      if (u == 0) *reinterpret_cast<f32x4*>(&dqs[fi_t * DB_US + 4 * fk_t]) = dq;
+      lds_barrier();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int row = ks + 4 * fk_t;
+        const int rr = min(seg0 + tl * 16 + row, seg1 - 1);  // (rows past the segment end: dQ is zero there)
+        accS = MFMA16(dqs[row * DB_US + fi_t], p.SocR[(size_t)rr * S + 16 * u + fi_t], accS);
+      }
+    }
+    {  // dSocR^T [S x rows] = W1[:, H:]^T dQ^T : wave u -> social columns 16 u .. 16 u + 15
+      f32x4 ds = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ds = MFMA16(w1s[(4 * fk_t + ks) * 36 + 16 * u + fi_t], dq[ks], ds);
+      if (valid_t) *reinterpret_cast<f32x4*>(p.dSocR + (size_t)r_t * S + 16 * u + 4 * fk_t) = ds;
+    }
+    if (p.dEnc) {
+      lds_barrier();
+      // dEnc^T [EIN x rows] = W_e2d[:, :EIN]^T dH0^T : wave u -> 16-column tiles u, u + 2, ...
+      const f32x4 ha = *reinterpret_cast<const f32x4*>(&h0t[fi_t * DB_HS + 8 * fk_t]);
+      const f32x4 hb = *reinterpret_cast<const f32x4*>(&h0t[fi_t * DB_HS + 8 * fk_t + 4]);
+      for (int ct = u; ct * 16 < p.EIN; ct += 2) {
+        const int col = 16 * ct + fi_t;
+        const bool cin = col < p.EIN;
+        f32x4 de = f32x4{0.f, 0.f, 0.f, 0.f}, de2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          de = MFMA16(cin ? e2s[(8 * fk_t + ks) * p.e2ld + col] : 0.f, ha[ks], de);
+          de2 = MFMA16(cin ? e2s[(8 * fk_t + 4 + ks) * p.e2ld + col] : 0.f, hb[ks], de2);
+        }
+        de += de2;
+        if (valid_t && 16 * ct + 4 * fk_t + 3 < p.EIN) *reinterpret_cast<f32x4*>(p.dEnc + (size_t)r_t * p.EIN + 16 * ct + 4 * fk_t) = de;
+      }
+    }
+  }
+
+  // (lane indices afresh -- v_mbcnt -- for the tail: what the prologue derived from them is not carried through the step loop)
+  const int lane_e = mg_lane(), fi_e = lane_e & 15, fk_e = lane_e >> 4, ub_e = 16 * u + 4 * fk_e;
+  // ---- this workgroup's partial block: the two slots meet in an LDS image of it (slot 0 writes, slot 1 adds) ----
+  lds_barrier();
+  float* blk = &dps[0][0][0];  // DF_WLEN floats (the dPre tiles are done with)
+  static_assert(sizeof(dps) >= DF_WLEN * sizeof(float), "partial block image");
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    if (slot == round) {
+      // accW[i][n][q] of lane_e (fi_e, fk_e): tile position pp = 16 (4 u + i) + 4 fk_e + q, column 16 n + fi_e
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pp = 16 * (4 * u + i) + 4 * fk_e + q, m = (pp & 3) * H + (pp >> 2);
+          if (round == 0) {
+            blk[m * H + fi_e] = accW[i][0][q];
+            blk[m * H + 16 + fi_e] = accW[i][1][q];
+          } else {
+            blk[m * H + fi_e] += accW[i][0][q];
+            blk[m * H + 16 + fi_e] += accW[i][1][q];
+          }
+        }
+      // dA / dbias: columns 0, 1, 2 of the third column tile
+      if (fi_e < 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int pp = 16 * (4 * u + i) + 4 * fk_e + q, m = (pp & 3) * H + (pp >> 2);
+            float* d = fi_e < 2 ? &blk[DF_OFF_A + m * 2 + fi_e] : &blk[DF_OFF_B + m];
+            *d = round == 0 ? accX[i][q] : *d + accX[i][q];
+          }
+      }
+      // W1h / W1s: accU / accS [q] of lane_e (fi_e, fk_e): row 4 fk_e + q, column 16 u + fi_e
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int o = (4 * fk_e + q) * 32 + 16 * u + fi_e;
+        if (round == 0) { blk[DF_OFF_W1 + o] = accU[q]; blk[DF_OFF_W1S + o] = accS[q]; }
+        else { blk[DF_OFF_W1 + o] += accU[q]; blk[DF_OFF_W1S + o] += accS[q]; }
+      }
+      if (u == 0) {  // lane_e-local accumulators (W2, b1, b2): folded over the 16 tile rows in a fixed tree
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v0 = accW2[0][q], v1 = accW2[1][q], v2 = accb1[q];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            v0 += __shfl_xor(v0, o, 64);
+            v1 += __shfl_xor(v1, o, 64);
+            v2 += __shfl_xor(v2, o, 64);
+          }
+          if (fi_e == 0) {
+            if (round == 0) { blk[DF_OFF_W2 + 4 * fk_e + q] = v0; blk[DF_OFF_W2 + Hh + 4 * fk_e + q] = v1; blk[DF_OFF_B1 + 4 * fk_e + q] = v2; }
+            else { blk[DF_OFF_W2 + 4 * fk_e + q] += v0; blk[DF_OFF_W2 + Hh + 4 * fk_e + q] += v1; blk[DF_OFF_B1 + 4 * fk_e + q] += v2; }
+          }
+        }
+        float b0 = accb2[0], b1v = accb2[1];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          b0 += __shfl_xor(b0, o, 64);
+          b1v += __shfl_xor(b1v, o, 64);
+        }
+        if (lane_e == 0) {
+          if (round == 0) { blk[DF_OFF_B2] = b0; blk[DF_OFF_B2 + 1] = b1v; blk[DF_OFF_B2 + 2] = 0.f; blk[DF_OFF_B2 + 3] = 0.f; }
+          else { blk[DF_OFF_B2] += b0; blk[DF_OFF_B2 + 1] += b1v; }
+        }
+      }
+    }
+    lds_barrier();
+  }
+  for (int i = threadIdx.x; i < DF_WLEN; i += 256) wp[i] = blk[i];
+#ifdef DEC_PROFILE
+  DP_T(6);  // 6: tile epilogues and the partial block
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    printf("DECPROF between %llu head %llu gates %llu barrier %llu recurrence %llu wgrad %llu rest %llu\n", prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[6]);
+#endif
+}
+
 // dst[ped][c] (+)= sum_k src[inv[k*b + ped]][c]
 __global__ void gather_sum_kernel(const float* __restrict__ src, int lds_, const int* __restrict__ inv, float* dst,
                                   int ldd, int b, int K, int ncols, int accumulate) {
@@ -1504,7 +1871,17 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
   // (One wave per tile, as in decoder_fwd_wave_kernel, was written and measured for this kernel too -- correct, ~500 registers,
   //  one wave per SIMD: 0.87 vs 0.79 ms at 163,840 rows and 180 vs 143 us at 25,600; with nothing else resident on its
   //  SIMD a wave exposes every dependent latency of the gate arithmetic.  Not kept)
-  hipLaunchKernelGGL(decoder_bwd_mfma_kernel, dim3(n_gens * NW), dim3(256), dyn, stream, p);
+  // Two waves per tile (decoder_bwd_pair_kernel) from 65,536 rollout rows on: 0.675 vs 0.81 ms at 163,840 rows; at 25,600
+  // rows (1,600 tiles on 1,024 tile slots: two rounds either way) 156 vs 153 us.  MGGAN_DEC_BWD=2 / 4 forces one (A/B).
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("MGGAN_DEC_BWD"); force = e ? (e[0] == '4' ? 4 : e[0] == '2' ? 2 : 0) : 0; }
+  const bool pair = force == 2 || (force == 0 && Rout >= 65536);
+  if (pair) {
+    const size_t dyn2 = sizeof(float) * ((dEnc ? (size_t)H * p.e2ld : 0) + (H / 2) * 36);
+    hipLaunchKernelGGL(decoder_bwd_pair_kernel, dim3(n_gens * NW), dim3(256), dyn2, stream, p);
+  } else {
+    hipLaunchKernelGGL(decoder_bwd_mfma_kernel, dim3(n_gens * NW), dim3(256), dyn, stream, p);
+  }
   MG_LAUNCH_CHECK("decoder_rollout_bwd_fused");
   return MGGAN_OK;
 }

@@ -362,9 +362,9 @@ __global__ __launch_bounds__(64 * NW) void social_rows_fwd_kernel(const SocRowsA
 // An LDS address the compiler cannot prove loop-invariant: the reads behind it stay where they are written.  (Left alone it
 // hoists the row-invariant fragments -- W2, v_j -- out of the row loop "into registers", finds none free, parks them in
 // scratch and reloads them at the head of every row: 52 registers' worth, a global round trip per row.)
-__device__ __forceinline__ const float* sr_here(const float* p) {
-  asm volatile("" : "+v"(p));
-  return p;
+__device__ __forceinline__ int sr_here(int off) {  // (the OFFSET: a laundered pointer loses its address space and is read
+  asm volatile("" : "+v"(off));                     //  with FLAT loads, which also count on vmcnt)
+  return off;
 }
 // W2T (TRAIN, scenes of up to 32): the transposed copy, row stride 68 -- the adjoint fragments W2[16 t + 4 kq + 0..3][16 tp + pp]
 // as ONE 16-byte read (32 four-byte reads per block kept the products waiting: 112 cycles apiece instead of 40)
@@ -439,9 +439,8 @@ __global__ __launch_bounds__(64 * NW) void social_rows_bwd_kernel(const SocRowsA
   float* L1s = Zs + 16 * SR_LDZ;          // [16][SR_LD1]
   float* Gs = L1s + 16 * SR_LD1;          // [16][SR_LD1]: dz1 | (f0, f1, f2, 1)
   float* red = smem;                      // [NW][16 JR][SR_LDC]
-  const float* wfl = w2s + pp * SR_LD2 + 4 * kq;   // forward fragments
-  const float* wtl = W2T ? w2ts + pp * SR_LD2T + 4 * kq : w2s + 4 * kq * SR_LD2 + pp;  // adjoint fragments
-  const float* bzl = bzs + 16 * kq;
+  const int wfo = pp * SR_LD2 + 4 * kq;                                          // forward fragments (in w2s)
+  const int wto = W2T ? pp * SR_LD2T + 4 * kq : 4 * kq * SR_LD2 + pp;            // adjoint fragments (in w2ts / w2s)
   float w1a[2];
 #pragma unroll
   for (int tp = 0; tp < 2; ++tp) w1a[tp] = kq < 3 ? a.W1[(16 * tp + pp) * 3 + kq] : a.b1[16 * tp + pp];
@@ -580,13 +579,13 @@ __global__ __launch_bounds__(64 * NW) void social_rows_bwd_kernel(const SocRowsA
         da[jb] = das[i * DAL + 16 * jb + pp];
         float f[3], l1[8];
         {
-          const f32x4 qi = *reinterpret_cast<const f32x4*>(sr_here(pvs + 4 * i));
-          const f32x4 qj = *reinterpret_cast<const f32x4*>(sr_here(pvs + 4 * j));
+          const f32x4 qi = *reinterpret_cast<const f32x4*>((pvs + sr_here(4 * i)));
+          const f32x4 qj = *reinterpret_cast<const f32x4*>((pvs + sr_here(4 * j)));
           sr_features(qi[0], qi[1], qi[2], qi[3], qj[0], qj[1], qj[2], qj[3], f);
         }
         if (KEEP != 0 && kq == 0) *reinterpret_cast<f32x4*>(fsl + jb * 64 + 4 * pp) = f32x4{f[0], f[1], f[2], 1.0f};
-        sr_pair_mlp_lds(w1a, sr_here(wfl), sr_here(bzl), kq, f, l1, z[q]);
-        const float* vrow = sr_here(vs + j * SR_LDV + 4 * kq);
+        sr_pair_mlp_lds(w1a, w2s + sr_here(wfo), bzs + sr_here(16 * kq), kq, f, l1, z[q]);
+        const float* vrow = vs + sr_here(j * SR_LDV + 4 * kq);
         float sp0 = 0.f, sp1 = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; t += 2) {
@@ -629,10 +628,10 @@ __global__ __launch_bounds__(64 * NW) void social_rows_bwd_kernel(const SocRowsA
         const int j = 16 * jb + pp < n ? 16 * jb + pp : 0;
         if (KEEP == 0 || (KEEP == 2 && jb != jbl)) {
           float f[3], l1[8];
-          const f32x4 qi = *reinterpret_cast<const f32x4*>(sr_here(pvs + 4 * i));
-          const f32x4 qj = *reinterpret_cast<const f32x4*>(sr_here(pvs + 4 * j));
+          const f32x4 qi = *reinterpret_cast<const f32x4*>((pvs + sr_here(4 * i)));
+          const f32x4 qj = *reinterpret_cast<const f32x4*>((pvs + sr_here(4 * j)));
           sr_features(qi[0], qi[1], qi[2], qi[3], qj[0], qj[1], qj[2], qj[3], f);
-          sr_pair_mlp_lds(w1a, sr_here(wfl), sr_here(bzl), kq, f, l1, z[q]);
+          sr_pair_mlp_lds(w1a, w2s + sr_here(wfo), bzs + sr_here(16 * kq), kq, f, l1, z[q]);
           if (TRAIN) {
             if (KEEP == 0 && kq == 0) *reinterpret_cast<f32x4*>(fsl + 4 * pp) = f32x4{f[0], f[1], f[2], 1.0f};
 #pragma unroll
@@ -642,7 +641,7 @@ __global__ __launch_bounds__(64 * NW) void social_rows_bwd_kernel(const SocRowsA
           }
         } else if (TRAIN) {
           // (l1 again: two products; it goes straight to its tile -- d1's mask reads it back)
-          const float fb = sr_here(fsl + (KEEP == 0 ? 0 : jb) * 64 + 4 * pp)[kq];
+          const float fb = fss[sr_here(w * (NFS * 64) + (KEEP == 0 ? 0 : jb) * 64 + 4 * pp) + kq];
           const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
           const f32x4 p0 = MFMA16(w1a[0], fb, zero), p1 = MFMA16(w1a[1], fb, zero);
           *reinterpret_cast<f32x4*>(L1s + pp * SR_LD1 + 4 * kq) =
@@ -650,14 +649,14 @@ __global__ __launch_bounds__(64 * NW) void social_rows_bwd_kernel(const SocRowsA
           *reinterpret_cast<f32x4*>(L1s + pp * SR_LD1 + 16 + 4 * kq) =
               f32x4{fmaxf(p1[0], 0.f), fmaxf(p1[1], 0.f), fmaxf(p1[2], 0.f), fmaxf(p1[3], 0.f)};
         }
-        const float daj = sr_here(das + i * DAL + 16 * jb)[pp];
+        const float daj = das[sr_here(i * DAL + 16 * jb) + pp];
         wave_lds_sync();
         if (kq == 0) das[i * DAL + 16 * jb + pp] = at[jb];  // a_ij for dh_j = sum_i a_ij dS_i (0 on padding lanes)
         // softmax adjoint (0 on padding lanes; sigma_ii is the constant -1000: nothing flows through it);
         // d[v_j | c_j] += dsigma_ij [l2_ij | 1]
         const float dsg = (16 * jb + pp == i) ? 0.f : at[jb] * (daj - dot);
         dc[jb] += dsg;
-        const float* vrow = sr_here(vs + j * SR_LDV + 4 * kq);
+        const float* vrow = vs + sr_here(j * SR_LDV + 4 * kq);
         f32x4 dz2[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -673,7 +672,7 @@ __global__ __launch_bounds__(64 * NW) void social_rows_bwd_kernel(const SocRowsA
         if (TRAIN) {
           // dz1^T (32 units x 16 pairs) = W2^T dz2^T: B operand = registers in the D layout of the forward product
           f32x4 d1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-          const float* wt = sr_here(wtl);
+          const float* wt = W2T ? w2ts + sr_here(wto) : w2s + sr_here(wto);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             if (W2T) {

@@ -148,7 +148,8 @@ def test_padded_steps_equal_the_unpadded_ones(sizes, g):
         assert float((x - y).norm() / x.norm()) <= 1e-3, float((x - y).norm() / x.norm())
         for k in sa:
             if "running_" in k:
-                np.testing.assert_allclose(sp[k].cpu().numpy(), sa[k].cpu().numpy(), rtol=1e-3, atol=1e-6, err_msg=k)
+                ref = sa[k].cpu().numpy()  # (relative to the tensor: an element near zero has no relative error to speak of)
+                np.testing.assert_allclose(sp[k].cpu().numpy(), ref, rtol=1e-3, atol=1e-4 * float(np.abs(ref).max()), err_msg=k)
 
 
 def test_padded_iteration_matches_the_oracle():
