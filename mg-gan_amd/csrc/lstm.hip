@@ -1374,6 +1374,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int q = 0; q < 4; ++q) accW2[0][q] = accW2[1][q] = accb1[q] = 0.f;
   const float* cAl = cAs[u][fk];
+  // (explicitly GLOBAL pointers: behind a select of two pointers the compiler no longer knows the address space and issues
+  //  FLAT loads, which count on lgkmcnt as well -- the LDS wait in front of the step's barrier then waits for them)
+  typedef __attribute__((address_space(1))) float gfloat;
+  const gfloat* ga_base = (const gfloat*)(p.gabs ? p.gabs : p.Din);
+  const gfloat* gr_base = (const gfloat*)(p.grel ? p.grel : p.Din);
 #ifdef DEC_PROFILE
   unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
@@ -1409,10 +1414,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       n_av = *reinterpret_cast<const f32x4*>(av_t + t * 256 + oa);
       const float* din = din_t + t * 32;
       n_din = *reinterpret_cast<const float2*>(din + od);
-      // (a missing output gradient: the ADDRESS is redirected to the step's input record -- scalar base, per-lane offset
-      // chosen once per tile -- and the value masked where it is consumed: no branch, no select on a loaded value)
-      n_ga = *reinterpret_cast<const float2*>((p.gabs ? p.gabs + (size_t)t * p.Rout * 2 : din) + oga);
-      n_gr = *reinterpret_cast<const float2*>((p.grel ? p.grel + (size_t)t * p.Rout * 2 : din) + ogr);
+      // (a missing output gradient: the ADDRESS is redirected to the step's input record -- base chosen once per launch, per-lane
+      // offset once per tile -- and the value masked where it is consumed: no branch, no select on a loaded value)
+      const gfloat* pa = ga_base + (p.gabs ? (size_t)t * p.Rout * 2 : tg * p.T * 32 + t * 32) + oga;
+      const gfloat* pr = gr_base + (p.grel ? (size_t)t * p.Rout * 2 : tg * p.T * 32 + t * 32) + ogr;
+      n_ga = float2{pa[0], pa[1]};  // (one 8-byte load each)
+      n_gr = float2{pr[0], pr[1]};
     };
     lds_barrier();  // the previous tiles' last LDS reads are done
     {
