@@ -2,6 +2,7 @@
 against the golden vectors produced by the real reference and against the CPU oracle.
 Tolerances: SURVEY A.12 (outputs/losses rtol 1e-3; gradients and post-step weights relL2 1e-3)."""
 import copy
+import os
 from collections import defaultdict
 
 import numpy as np
@@ -300,3 +301,18 @@ def test_shared_context_iteration_matches_reference(golden):
                 for k in ref:
                     if not ref[k].is_floating_point():
                         assert int(sd[k]) == int(ref[k]), k
+
+
+def test_large_batch_rollout_kernels_on_the_golden_vectors():
+    """The rollout kernels picked from 65,536 rollout rows on (one wave per tile forward, two waves per tile adjoint:
+    csrc/lstm.hip) are forced onto the small golden cases -- ragged tiles, generators without rows, an empty second tile
+    slot -- in a child process (the choice is read once per process)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MGGAN_DEC_FWD="1", MGGAN_DEC_BWD="2")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                          "decoder_rollout or generator_forward_backward or three_training_iterations"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-500:]
