@@ -311,8 +311,10 @@ def test_large_batch_rollout_kernels_on_the_golden_vectors():
     import sys
 
     env = dict(os.environ, MGGAN_DEC_FWD="1", MGGAN_DEC_BWD="2")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                          "decoder_rollout or generator_forward_backward or three_training_iterations"],
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(here, "test_hip_kernels.py"),
+                          "-q", "-x", "-m", "gpu", "-k", "decoder_rollout or generator_forward_backward or "
+                          "three_training_iterations or decoder_h0_shared_part"],  # (the last one: the per-row h0 path, dEnc)
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
     assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-500:]
