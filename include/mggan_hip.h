@@ -88,6 +88,12 @@ int mggan_wgrad_multi(const void* descs, int n, mggan_stream_t stream);
 int mggan_grad_reduce_multi(const void* descs, int n, mggan_stream_t stream);
 int mggan_transpose(const float* W, float* WT, int N, int K, mggan_stream_t stream);
 /* dst[ped][c] (+)= sum_k src[inv[k*b+ped]][c] : adjoint of "repeat over samples" */
+/* The per-pedestrian tail of the rollout adjoint (shared h0, reference: the enc_h_to_dec_h adjoint of
+ * /root/reference/mggan/model/modules/standard.py:118-131 summed over a pedestrian's K rollout rows) in one launch:
+ * dQe (b,32) = sum over the K rows of a pedestrian of dH0; dEnc (b, ld_enc) = dQe . W_e2d[:, :EIN] (W_e2d row-major, row
+ * stride ldw); the last S columns of dEnc additionally receive the K-row sums of dSocR (R,S) (S = 0: none; S <= 32). */
+int mggan_rollout_ped_adjoint(const float* dH0, const float* dSocR, const int* inv, const float* W_e2d, int ldw, float* dQe,
+                              float* dEnc, int ld_enc, int b, int K, int EIN, int S, mggan_stream_t stream);
 int mggan_gather_sum(const float* src, int ld_src, const int* inv, float* dst, int ld_dst, int b, int K, int ncols,
                      int accumulate, mggan_stream_t stream);
 

@@ -1693,6 +1693,63 @@ __global__ void gather_sum_kernel(const float* __restrict__ src, int lds_, const
 }
 
 // WT[k][n] = W[n][k]
+// The per-pedestrian tail of the rollout adjoint in ONE launch (it was gather_sum -> linear_bwd_data -> gather_sum, three
+// dependent launches on the critical chain of the generator step):
+//   dQe[ped]  = sum_k dH0[inv[k b + ped]]                       (H = 32 columns; also the operand of the e2d weight gradient)
+//   dEnc[ped] = dQe[ped] . W_e2d[:, :EIN]                       (EIN columns)
+//   dEnc[ped][EIN - S ..] += sum_k dSocR[inv[k b + ped]]        (the social block is the last S columns of enc_h; S = 0: none)
+// A workgroup takes 8 pedestrians: thread (p, c) first folds column c of the K rows of pedestrian p (four gathers in flight),
+// the 8 x 32 block meets in LDS, then every thread owns columns c, c + 32, ... of its pedestrian's dEnc row.
+__global__ __launch_bounds__(256) void rollout_ped_adjoint_kernel(const float* __restrict__ dH0, const float* __restrict__ dSocR,
+                                                                  const int* __restrict__ inv, const float* __restrict__ W,
+                                                                  int ldw, float* __restrict__ dQe, float* __restrict__ dEnc,
+                                                                  int ld_enc, int b, int K, int EIN, int S) {
+  constexpr int H = 32;
+  __shared__ float q[8][H + 1];
+  const int p = threadIdx.x >> 5, c = threadIdx.x & 31, ped = blockIdx.x * 8 + p;
+  const bool ok = ped < b;
+  const int pc = ok ? ped : b - 1;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  const bool soc = c < S;  // (S <= 32)
+  int k = 0;
+  for (; k + 3 < K; k += 4) {
+    const int i0 = inv[(size_t)k * b + pc], i1 = inv[(size_t)(k + 1) * b + pc], i2 = inv[(size_t)(k + 2) * b + pc],
+              i3 = inv[(size_t)(k + 3) * b + pc];
+    s0 += dH0[(size_t)i0 * H + c];
+    s1 += dH0[(size_t)i1 * H + c];
+    s2 += dH0[(size_t)i2 * H + c];
+    s3 += dH0[(size_t)i3 * H + c];
+    if (soc) {
+      t0 += dSocR[(size_t)i0 * S + c];
+      t1 += dSocR[(size_t)i1 * S + c];
+      t2 += dSocR[(size_t)i2 * S + c];
+      t3 += dSocR[(size_t)i3 * S + c];
+    }
+  }
+  for (; k < K; ++k) {
+    const int i0 = inv[(size_t)k * b + pc];
+    s0 += dH0[(size_t)i0 * H + c];
+    if (soc) t0 += dSocR[(size_t)i0 * S + c];
+  }
+  const float s = (s0 + s1) + (s2 + s3), ts = (t0 + t1) + (t2 + t3);
+  q[p][c] = s;
+  if (ok) dQe[(size_t)ped * H + c] = s;
+  __syncthreads();
+  if (!ok) return;  // (a whole 32-lane group at a time: the groups of a wave do not shuffle across)
+  for (int c0 = 0; c0 < EIN; c0 += 32) {  // (uniform trip count: the shuffle below wants all 32 lanes of the pedestrian)
+    const int col = c0 + c, cc = col < EIN ? col : EIN - 1;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; h += 2) {
+      a0 = fmaf(q[p][h], W[(size_t)h * ldw + cc], a0);
+      a1 = fmaf(q[p][h + 1], W[(size_t)(h + 1) * ldw + cc], a1);
+    }
+    // the social block is the last S columns: social column j = col - (EIN - S) was summed by lane j of this pedestrian
+    const float tj = __shfl(ts, (col - (EIN - S)) & 31, 32);
+    if (col < EIN) dEnc[(size_t)ped * ld_enc + col] = (a0 + a1) + (S > 0 && col >= EIN - S ? tj : 0.f);
+  }
+}
+
 __global__ void transpose_kernel(const float* __restrict__ W, float* __restrict__ WT, int N, int K) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * K) return;
@@ -1901,6 +1958,18 @@ int mggan_gather_sum(const float* src, int ld_src, const int* inv, float* dst, i
   hipLaunchKernelGGL(gather_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, src, ld_src, inv, dst, ld_dst, b, K,
                      ncols, accumulate);
   MG_LAUNCH_CHECK("gather_sum");
+  return MGGAN_OK;
+}
+
+int mggan_rollout_ped_adjoint(const float* dH0, const float* dSocR, const int* inv, const float* W_e2d, int ldw, float* dQe,
+                              float* dEnc, int ld_enc, int b, int K, int EIN, int S, hipStream_t stream) {
+  MG_CHECK_ARG(dH0 && inv && W_e2d && dQe && dEnc && (S == 0 || dSocR), "rollout_ped_adjoint: null pointer");
+  MG_CHECK_ARG(b >= 0 && K >= 1 && EIN >= 1 && S >= 0 && S <= 32 && S <= EIN && ldw >= EIN && ld_enc >= EIN,
+               "rollout_ped_adjoint: bad sizes (b %d, K %d, EIN %d, S %d)", b, K, EIN, S);
+  if (b == 0) return MGGAN_OK;
+  hipLaunchKernelGGL(rollout_ped_adjoint_kernel, dim3(cdiv(b, 8)), dim3(256), 0, stream, dH0, dSocR, inv, W_e2d, ldw, dQe, dEnc,
+                     ld_enc, b, K, EIN, S);
+  MG_LAUNCH_CHECK("rollout_ped_adjoint");
   return MGGAN_OK;
 }
 

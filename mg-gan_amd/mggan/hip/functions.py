@@ -1842,7 +1842,17 @@ class DecoderRolloutFn(Function):
                                                   for off, dst, M, N, ld in parts])
                 lib.mggan_grad_reduce_multi(ctypes.addressof(arr), len(parts), st)
         dQe = None
-        if ctx.shared and (e2d_w.requires_grad or ctx.needs_input_grad[0]):
+        d_enc = d_soc = None
+        # shared h0, d enc_h wanted, the social block inside enc_h (the trainer's case): the whole per-pedestrian tail -- dH0 and
+        # dSocR folded over a pedestrian's K rows, d enc_h = dQe W_e2d[:, :EIN] -- is ONE launch (it was three in a row)
+        fused_tail = (ctx.shared and ctx.needs_input_grad[0] and H == 32 and S <= 32 and
+                      (not ctx.needs_input_grad[1] or ctx.soc_in_enc))
+        if fused_tail:
+            dQe, d_enc = mk(b, H), mk(b, EIN)
+            with_soc = ctx.needs_input_grad[1] and ctx.soc_in_enc
+            lib.mggan_rollout_ped_adjoint(_p(dH0), _p(dSocR) if with_soc else None, _p(rows.inv), _p(e2d_w), EIN + Z, _p(dQe),
+                                          _p(d_enc), EIN, b, rows.K, EIN, S if with_soc else 0, st)
+        elif ctx.shared and (e2d_w.requires_grad or ctx.needs_input_grad[0]):
             # adjoint of the per-pedestrian part of h0: dH0 folded over the K rows of a pedestrian, then ONE product
             # (weight gradient over b rows instead of R, d enc_h over b rows instead of R)
             dQe = mk(b, H)
@@ -1856,7 +1866,8 @@ class DecoderRolloutFn(Function):
             else:
                 with side_stream(dH0, E2Din):
                     wgrad(dH0, H, E2Din, EIN + Z, pw, EIN + Z, pb, R, EIN + Z, H)
-        d_enc = d_soc = None
+        if fused_tail:
+            return (d_enc, None) + (None,) * 13
         if ctx.needs_input_grad[0]:
             d_enc = mk(b, EIN)
             if ctx.shared:
