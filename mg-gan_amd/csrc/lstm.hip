@@ -1364,12 +1364,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = threadIdx.x; i < H * p.EIN; i += 256) e2s[(i / p.EIN) * p.e2ld + i % p.EIN] = p.We2d[(size_t)(i / p.EIN) * IN + i % p.EIN];
   for (int i = threadIdx.x; i < Hh * S; i += 256) w1s[(i / S) * 36 + i % S] = W1[(size_t)(i / S) * (H + S) + H + i % S];
   f32x4 accW[4][2], accU = f32x4{0.f, 0.f, 0.f, 0.f}, accS = f32x4{0.f, 0.f, 0.f, 0.f};
-  // dA (4H x 2) and dbias (4H) = dPre^T [dxdy | 1] ride as a third column tile of the dW_hh product: (dx, dy, 1, 0) sit in the
-  // four pad columns of the h tile's rows.  (As lane-local sums -- 48 accumulators per lane with four units per lane -- they
-  // pushed the step loop's operands into scratch, and a scratch reload waits for every load issued before it: the prefetch.)
-  f32x4 accX[4];
+  // dA (4H x 2) and dbias (4H) = dPre^T [dxdy | 1]: lane-local sums over the A fragments of the dW_hh product -- the lane
+  // that feeds position 16 (4 u + i) + fi of rows ks + 4 fk into those products multiplies them by (dx, dy, 1) of the same
+  // rows ((dx, dy) sit in the pad columns of the h tile's rows), 12 accumulators, folded over fk at the end.  (As sums over the
+  // lane's own gate gradients -- 48 accumulators with four units per lane -- they pushed the step loop's operands into
+  // scratch; as a third column tile of the product they cost 16 of 88 products per wave and step for 3 useful columns.)
+  float accX[4][3];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) accW[a][0] = accW[a][1] = accX[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < 4; ++a) {
+    accW[a][0] = accW[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accX[a][0] = accX[a][1] = accX[a][2] = 0.f;
+  }
   float accW2[2][4], accb1[4], accb2[2] = {0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < 4; ++q) accW2[0][q] = accW2[1][q] = accb1[q] = 0.f;
@@ -1525,16 +1530,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // weight gradients, K = the 16 tile rows: dW_hh position tiles 4 u .. 4 u + 3 x two column tiles
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        float a[4], bv[3];
+        float a[4], bv[2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = dpw[(ks + 4 * fk) * DB_RS + 16 * (4 * u + i) + fi];
 #pragma unroll
-        for (int n = 0; n < 3; ++n) bv[n] = htw[(ks + 4 * fk) * DB_HS + 16 * n + fi];  // (n = 2: columns 32..35 count, the rest is ignored)
+        for (int n = 0; n < 2; ++n) bv[n] = htw[(ks + 4 * fk) * DB_HS + 16 * n + fi];
+        const float2 dxy = *reinterpret_cast<const float2*>(&htw[(ks + 4 * fk) * DB_HS + 32]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
           for (int n = 0; n < 2; ++n) accW[i][n] = MFMA16(a[i], bv[n], accW[i][n]);
-          accX[i] = MFMA16(a[i], bv[2], accX[i]);
+          accX[i][0] = fmaf(a[i], dxy.x, accX[i][0]);
+          accX[i][1] = fmaf(a[i], dxy.y, accX[i][1]);
+          accX[i][2] += a[i];
         }
         // dW1[:, :H] += du^T h_t : wave u -> column tile u
         accU = MFMA16(duw[(ks + 4 * fk) * DB_US + fi], htc[(ks + 4 * fk) * DB_HS + 16 * u + fi], accU);
@@ -1613,16 +1621,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             blk[m * H + 16 + fi_e] += accW[i][1][q];
           }
         }
-      // dA / dbias: columns 0, 1, 2 of the third column tile
-      if (fi_e < 3) {
+      // dA / dbias: the lane's sums for position 16 (4 u + i) + fi, folded over the four row groups fk
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int pp = 16 * (4 * u + i) + 4 * fk_e + q, m = (pp & 3) * H + (pp >> 2);
-            float* d = fi_e < 2 ? &blk[DF_OFF_A + m * 2 + fi_e] : &blk[DF_OFF_B + m];
-            *d = round == 0 ? accX[i][q] : *d + accX[i][q];
-          }
+      for (int i = 0; i < 4; ++i) {
+        const float v0 = quarters_sum(accX[i][0]), v1 = quarters_sum(accX[i][1]), v2 = quarters_sum(accX[i][2]);
+        if (fk_e == 0) {
+          const int pp = 16 * (4 * u + i) + fi_e, m = (pp & 3) * H + (pp >> 2);
+          if (round == 0) { blk[DF_OFF_A + m * 2] = v0; blk[DF_OFF_A + m * 2 + 1] = v1; blk[DF_OFF_B + m] = v2; }
+          else { blk[DF_OFF_A + m * 2] += v0; blk[DF_OFF_A + m * 2 + 1] += v1; blk[DF_OFF_B + m] += v2; }
+        }
       }
       // W1h / W1s: accU / accS [q] of lane_e (fi_e, fk_e): row 4 fk_e + q, column 16 u + fi_e
 #pragma unroll
@@ -1935,11 +1942,12 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
   // (One wave per tile, as in decoder_fwd_wave_kernel, was written and measured for this kernel too -- correct, ~500 registers,
   //  one wave per SIMD: 0.87 vs 0.79 ms at 163,840 rows and 180 vs 143 us at 25,600; with nothing else resident on its
   //  SIMD a wave exposes every dependent latency of the gate arithmetic.  Not kept)
-  // Two waves per tile (decoder_bwd_pair_kernel) from 65,536 rollout rows on: 0.675 vs 0.81 ms at 163,840 rows; at 25,600
-  // rows (1,600 tiles on 1,024 tile slots: two rounds either way) 156 vs 153 us.  MGGAN_DEC_BWD=2 / 4 forces one (A/B).
+  // Two waves per tile (decoder_bwd_pair_kernel) from 4,096 rollout rows on: 0.64 vs 0.81 ms at 163,840 rows, 151 vs 155 us
+  // at 25,600 (1,600 tiles on 1,024 tile slots: two rounds); below that the four-wave kernel's one tile per workgroup
+  // spreads a few dozen tiles over more CUs.  MGGAN_DEC_BWD=2 / 4 forces one (A/B).
   static int force = -1;
   if (force < 0) { const char* e = getenv("MGGAN_DEC_BWD"); force = e ? (e[0] == '4' ? 4 : e[0] == '2' ? 2 : 0) : 0; }
-  const bool pair = force == 2 || (force == 0 && Rout >= 65536);
+  const bool pair = force == 2 || (force == 0 && Rout >= 4096);
   if (pair) {
     const size_t dyn2 = sizeof(float) * ((dEnc ? (size_t)H * p.e2ld : 0) + (H / 2) * 36);
     hipLaunchKernelGGL(decoder_bwd_pair_kernel, dim3(n_gens * NW), dim3(256), dyn2, stream, p);
