@@ -535,7 +535,8 @@ __global__ __launch_bounds__(64 * NW) void social_rows_bwd_kernel(const SocRowsA
     // right behind them: kept across scenes they sat in registers through the staging and epilogue tile products, which
     // need the room -- the compiler parked 50 of them in scratch and fetched them back, twice per scene.
     f32x4 dW2[4][2];     // dW2[m = 16 tm + 4 kq + r][u = 16 tu + pp]
-    f32x4 dW1[2];        // [dW1 | db1][u = 16 tp + 4 kq + r][c = pp] (lanes pp < 4)
+    f32x4 dW1[2];        // [dW1 | db1][u = 16 tp + pp][c = 0..3], partial over the lane's pairs (folded over kq below): vector
+                         // FMAs -- as products with a 4-column B tile they were 8 of 106 per block for 128 outputs
     float db2[4];        // db2[16 tm + pp], partial over the lane's pairs (folded over kq below)
     if (TRAIN) {
 #pragma unroll
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(64 * NW) void social_rows_bwd_kernel(const SocRowsA
             const float* lr = L1s + pr * SR_LD1 + pp;
             const float* gr = Gs + pr * SR_LD1 + pp;
             const float b0 = lr[0], b1v = lr[16];
-            const float fc = pp < 4 ? fsl[(KEEP == 0 ? 0 : jb) * 64 + 4 * pr + pp] : 0.f;
+            const f32x4 f4 = *reinterpret_cast<const f32x4*>(fsl + (KEEP == 0 ? 0 : jb) * 64 + 4 * pr);  // (f0, f1, f2, 1) of pair pr
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) {
               const float av = zr[16 * tm];
@@ -718,8 +719,12 @@ __global__ __launch_bounds__(64 * NW) void social_rows_bwd_kernel(const SocRowsA
               dW2[tm][0] = MFMA16(av, b0, dW2[tm][0]);
               dW2[tm][1] = MFMA16(av, b1v, dW2[tm][1]);
             }
-            dW1[0] = MFMA16(gr[0], fc, dW1[0]);
-            dW1[1] = MFMA16(gr[16], fc, dW1[1]);
+            const float g0 = gr[0], g1 = gr[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              dW1[0][c] = fmaf(g0, f4[c], dW1[0][c]);
+              dW1[1][c] = fmaf(g1, f4[c], dW1[1][c]);
+            }
           }
           wave_lds_sync();  // the tiles are rewritten by the next block
           SR_T(10);  // 10: tiles + weight-gradient products
@@ -747,12 +752,13 @@ __global__ __launch_bounds__(64 * NW) void social_rows_bwd_kernel(const SocRowsA
         const float sb = quarters_sum(db2[tm]);
         if (kq_e == 0) mine[(16 * tm + pp_e) * 33 + 32] = sb;
       }
-      if (pp_e < 4) {
 #pragma unroll
-        for (int tp = 0; tp < 2; ++tp)
+      for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mine[64 * 33 + (16 * tp + 4 * kq_e + r) * 4 + pp_e] = dW1[tp][r];
-      }
+        for (int c = 0; c < 4; ++c) {
+          const float sw = quarters_sum(dW1[tp][c]);
+          if (kq_e == 0) mine[64 * 33 + (16 * tp + pp_e) * 4 + c] = sw;
+        }
       __syncthreads();
       float* out = a.partials + (size_t)blockIdx.x * SR_WG_FLOATS;
       for (int e = tid_e; e < SR_WG_FLOATS; e += NT) {
