@@ -161,7 +161,7 @@ int mggan_social_pairs_bwd(int P, int b, const int* pair_j, const int* ped_prow,
  * owns whole scenes (scenes[s] = {first row, past-last row}), a wave owns attention rows, the pair MLP and its adjoint run
  * on MFMA, the softmax over a scene is wave-level shuffle reductions, and NOTHING per pair is stored: _bwd recomputes the
  * pair MLP from the positions.  H = width of h (32 | 64), F = social feature width (rows of W3 / W_at, <= 64), max_n =
- * largest scene (<= 64).  xy_mod > 0: the pedestrian rows repeat with that period (xy_last / dxdy_last hold one period:
+ * largest scene (<= 64); W2, W3 and W_at must be 16-byte aligned (they are staged with 16-byte loads).  xy_mod > 0: the pedestrian rows repeat with that period (xy_last / dxdy_last hold one period:
  * the real and the fake half of a discriminator pair pass share the observed positions).
  * _bwd: dh[j] (+)= sum_i a_ij dS_i + dWh_j W_at; side outputs for the weight-gradient GEMMs of W3 | b3 | W_at | b_at:
  * Wh (rows, F), dWh (rows, F), dvc (rows, ldv) = d[v_j | c_j] (65 columns used); partials != NULL: also the weight
