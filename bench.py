@@ -47,8 +47,8 @@ def kernel_of(name, a):
     if name == "mggan_decoder_rollout_bwd_fused":  # (two waves per tile from 4,096 rollout rows on, csrc/lstm.hip; a[21] = rows)
         force = os.environ.get("MGGAN_DEC_BWD", "")
         return "decoder_bwd_pair_kernel" if force == "2" or (force != "4" and a[21] >= 4096) else "decoder_bwd_mfma_kernel"
-    if name == "mggan_decoder_rollout_fwd":  # (one wave per tile from 65,536 rollout rows on, csrc/lstm.hip)
-        return "decoder_fwd_wave_kernel" if a[0] >= 65536 and os.environ.get("MGGAN_DEC_FWD") != "4" else "decoder_fwd_mfma_kernel"
+    if name == "mggan_decoder_rollout_fwd":  # (one wave per tile from 16,384 rollout rows on, csrc/lstm.hip)
+        return "decoder_fwd_wave_kernel" if a[0] >= 16384 and os.environ.get("MGGAN_DEC_FWD") != "4" else "decoder_fwd_mfma_kernel"
     if name in ("mggan_social_rows_fwd", "mggan_social_rows_bwd"):  # (one kernel per hidden width, as the tables name them)
         return "{}_kernel<{}>".format(name[len("mggan_"):], a[2])
     if name == "mggan_conv1_pool":

@@ -1893,7 +1893,11 @@ int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const 
   // against 0.51 with it.  MGGAN_DEC_FWD = 4 | 1 forces one of them (A/B measurements).
   static int force = -1;
   if (force < 0) { const char* e = getenv("MGGAN_DEC_FWD"); force = e && (e[0] == '4' || e[0] == '1') ? e[0] - '0' : 0; }
-  const bool wave = force ? force == 1 : R >= 65536;
+  // (threshold: 16,384 rows -- the 25,600-row launch of the generator step at configs[1] inside the graph, two alternating
+  //  pairs: 1.407-1.409 ms with the wave kernel, 1.413-1.416 with the four-wave one; MGGAN_DEC_FWD_MIN moves it)
+  static int wave_min = -1;
+  if (wave_min < 0) { const char* e = getenv("MGGAN_DEC_FWD_MIN"); wave_min = e ? atoi(e) : 16384; }
+  const bool wave = force ? force == 1 : R >= wave_min;
   if (!wave) {
     hipLaunchKernelGGL(decoder_fwd_mfma_kernel, dim3(n_gens * p.NW), dim3(256), 0, stream, p);
   } else {
