@@ -1954,6 +1954,7 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
   const bool pair = force == 2 || (force == 0 && Rout >= 4096);
   if (pair) {
     const size_t dyn2 = sizeof(float) * ((dEnc ? (size_t)H * p.e2ld : 0) + (H / 2) * 36);
+    MG_CHECK_ARG(dyn2 <= 64 * 1024, "decoder_rollout_bwd_fused: encoder width %d too large for the staged epilogue", EIN);
     hipLaunchKernelGGL(decoder_bwd_pair_kernel, dim3(n_gens * NW), dim3(256), dyn2, stream, p);
   } else {
     hipLaunchKernelGGL(decoder_bwd_mfma_kernel, dim3(n_gens * NW), dim3(256), dyn, stream, p);
