@@ -899,6 +899,80 @@ int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, i
                       int* inv, int* seg, int* row_gen_pos, int* blk_cnt, hipStream_t stream);
 
 /* mggan_sample_categorical + mggan_bucket_rows; ONE launch up to 2,048 rows: the same picks, the same tables */
+// Above SB_SMALL rows: picks, occurrence slots, per-block counts AND the scan in ONE launch (it was four: sample_categorical,
+// bucket_slots, bucket_count, bucket_scan -- 34 us in a row in front of the generator step's rollout at configs[1]).  A lane is
+// a pedestrian: its CDF once, its K picks and slots in sample order; the counts of the picks' position blocks are gathered in
+// an LDS image of blk_cnt (integer LDS atomics) and its non-zero cells added to the global table (zeroed by the launcher) at the
+// end -- exact and order independent.  (One global atomic per pick: 25,600 of them on a hundred addresses took 25 us.)  The workgroup that takes the last ticket
+// turns the counts into exclusive offsets per generator and the segment table (the same arithmetic as bucket_scan_kernel)
+// and re-arms the ticket.  bucket_scatter_kernel follows.
+__global__ __launch_bounds__(256) void sample_slots_scan_kernel(int b, int K, int g, const float* __restrict__ logits,
+                                                                const float* __restrict__ u, long long* idx, int* row_gen_pos,
+                                                                int* inv, int* blk_cnt, int nblk, int* seg, unsigned* ticket) {
+  __shared__ int last;
+  __shared__ int tot[BR_MAXG];
+  extern __shared__ int hist[];  // [nblk][BR_MAXG]
+  for (int i = threadIdx.x; i < nblk * BR_MAXG; i += 256) hist[i] = 0;
+  __syncthreads();
+  const int ped = blockIdx.x * 256 + threadIdx.x;
+  if (ped < b) {
+    float cdf[BR_MAXG], run;
+    sb_build(logits + (size_t)ped * g, g, cdf, run);
+    int seen[BR_MAXG];
+#pragma unroll
+    for (int q = 0; q < BR_MAXG; ++q) seen[q] = 0;
+    for (int k0 = 0; k0 < K; k0 += 4) {  // four draws in flight
+      float uu[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) uu[e] = k0 + e < K ? u[(size_t)ped * K + k0 + e] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = k0 + e;
+        if (k >= K) break;
+        const int gi = sb_pick(cdf, g, uu[e] * run);
+        int slot = 0;
+#pragma unroll
+        for (int q = 0; q < BR_MAXG; ++q)
+          if (q == gi) { slot = seen[q]; seen[q] += 1; }
+        idx[(size_t)ped * K + k] = gi;
+        const int pos = k * b + ped;
+        row_gen_pos[pos] = gi;
+        inv[pos] = slot;
+        atomicAdd(&hist[(pos / BR_BLOCK) * BR_MAXG + gi], 1);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nblk * BR_MAXG; i += 256)
+    if (hist[i]) atomicAdd(&blk_cnt[i], hist[i]);
+  __syncthreads();  // (this workgroup's atomics are through; the ticket below is taken behind them)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int q = threadIdx.x;
+  if (q < g) {
+    int runc = 0;
+    for (int i = 0; i < nblk; ++i) {
+      int* cell = &blk_cnt[i * BR_MAXG + q];
+      const int c = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cell, runc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      runc += c;
+    }
+    tot[q] = runc;
+  }
+  __syncthreads();
+  if (q == 0) {
+    int runc = 0;
+    for (int i = 0; i < g; ++i) { seg[i] = runc; runc += tot[i]; }
+    seg[g] = runc;
+    *ticket = 0u;
+  }
+}
+
 int mggan_sample_bucket_rows(int b, int K, int g, const float* logits, const float* u, long long* idx, int* row_gen,
                              int* row_ped, int* row_slot, int* row_pos, int* inv, int* seg, int* row_gen_pos, int* blk_cnt,
                              unsigned int* ticket, hipStream_t stream) {
@@ -914,8 +988,21 @@ int mggan_sample_bucket_rows(int b, int K, int g, const float* logits, const flo
     MG_LAUNCH_CHECK("sample_bucket_rows");
     return MGGAN_OK;
   }
-  if (int rc = mggan_sample_categorical(b, K, g, logits, u, idx, stream)) return rc;
-  return mggan_bucket_rows(idx, b, K, g, row_gen, row_ped, row_slot, row_pos, inv, seg, row_gen_pos, blk_cnt, stream);
+  static int merged = -1;  // MGGAN_SB_MERGED=0: the five-launch path (A/B measurements)
+  if (merged < 0) { const char* e = getenv("MGGAN_SB_MERGED"); merged = !(e && e[0] == '0'); }
+  if (!merged) {
+    if (int rc = mggan_sample_categorical(b, K, g, logits, u, idx, stream)) return rc;
+    return mggan_bucket_rows(idx, b, K, g, row_gen, row_ped, row_slot, row_pos, inv, seg, row_gen_pos, blk_cnt, stream);
+  }
+  const int nblk = cdiv(R, BR_BLOCK);
+  MG_CHECK_HIP(hipMemsetAsync(blk_cnt, 0, sizeof(int) * (size_t)nblk * BR_MAXG, stream), "sample_bucket_rows: memset");
+  MG_CHECK_ARG(nblk <= 1024, "sample_bucket_rows: %d rows exceed the count image (1,048,576)", R);
+  hipLaunchKernelGGL(sample_slots_scan_kernel, dim3(cdiv(b, 256)), dim3(256), sizeof(int) * (size_t)nblk * BR_MAXG, stream, b, K, g,
+                     logits, u, idx, row_gen_pos, inv, blk_cnt, nblk, seg, ticket);
+  hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, b, g, blk_cnt, seg, row_gen,
+                     row_ped, row_slot, row_pos, inv);
+  MG_LAUNCH_CHECK("sample_bucket_rows");
+  return MGGAN_OK;
 }
 
 int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, int* row_ped, int* row_slot,
