@@ -96,8 +96,9 @@ def test_device_categorical_sampler_is_the_inverse_cdf(b, K, g):
 @pytest.mark.parametrize("b,K,g", [(1280, 1, 4), (256, 20, 4), (1280, 20, 4), (8192, 20, 8), (37, 3, 16), (409, 20, 5),
                                    (8192, 1, 8), (5, 3, 1)])
 def test_fused_sampling_and_bucketing_match_the_separate_launches(b, K, g):
-    """mggan_sample_bucket_rows (one launch up to 2,048 rows) against mggan_sample_categorical followed by
-    mggan_bucket_rows on the same logits and uniforms: identical picks and identical row tables."""
+    """mggan_sample_bucket_rows (one launch up to 2,048 rows; above: picks, slots, counts and the scan in one launch with a
+    last-ticket scan, then the scatter) against mggan_sample_categorical followed by mggan_bucket_rows on the same logits and
+    uniforms: identical picks and identical row tables, twice in a row (the ticket re-arms itself)."""
     from mggan.hip import lib
     from mggan.hip.functions import device_rollout_rows, empty_rollout_rows
 

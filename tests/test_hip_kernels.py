@@ -539,3 +539,33 @@ def test_decoder_h0_shared_part_matches_the_per_row_product(monkeypatch):
         # (the bias of a convolution in front of a BatchNorm has a zero gradient: rounding noise of ~1e-8 on both sides)
         scale = max(float(ref.abs().max()), 1e-3 * gmax)
         torch.testing.assert_close(res[0][2][n], ref, rtol=2e-4, atol=2e-5 * scale, msg=lambda m, n=n: n + ": " + m)
+
+
+@pytest.mark.parametrize("b,K,EIN,S,Z", [(1280, 20, 128, 32, 8), (37, 3, 128, 32, 8), (409, 5, 96, 0, 8), (64, 1, 72, 32, 4),
+                                         (10, 20, 50, 18, 8)])
+def test_rollout_ped_adjoint_matches_the_three_launches(b, K, EIN, S, Z):
+    """mggan_rollout_ped_adjoint (the per-pedestrian tail of the rollout adjoint in one launch) against gather_sum ->
+    linear_bwd_data -> gather_sum(accumulate) on the same operands: widths that are not multiples of 32, a social block that
+    does not start on a 32-column boundary, no social block, pedestrian counts that do not fill a workgroup."""
+    from mggan.hip import functions as HF
+    from mggan.hip import lib
+
+    dev = _dev()
+    gen = torch.Generator().manual_seed(7 * b + K + EIN)
+    R, H = b * K, 32
+    dH0 = torch.randn(R, H, generator=gen).to(dev)
+    dSocR = torch.randn(R, max(S, 1), generator=gen).to(dev)
+    W = (torch.randn(H, EIN + Z, generator=gen) * 0.3).to(dev)
+    inv = torch.stack([torch.randperm(R, generator=gen)[:b] for _ in range(K)]).reshape(-1).to(torch.int32).to(dev)  # (K*b)
+    st = torch.cuda.current_stream().cuda_stream
+    p = HF._p
+    dQe0, dEnc0 = torch.empty(b, H, device=dev), torch.empty(b, EIN, device=dev)
+    lib.mggan_gather_sum(p(dH0), H, p(inv), p(dQe0), H, b, K, H, 0, st)
+    lib.mggan_linear_bwd_data(p(dQe0), H, p(W), EIN + Z, p(dEnc0), EIN, b, EIN, H, 0, 0, 0, HF.ACT_NONE, 0.0, st)
+    if S:
+        lib.mggan_gather_sum(p(dSocR), S, p(inv), dEnc0.data_ptr() + 4 * (EIN - S), EIN, b, K, S, 1, st)
+    dQe1, dEnc1 = torch.full((b, H), float("nan"), device=dev), torch.full((b, EIN), float("nan"), device=dev)
+    lib.mggan_rollout_ped_adjoint(p(dH0), p(dSocR) if S else None, p(inv), p(W), EIN + Z, p(dQe1), p(dEnc1), EIN, b, K, EIN, S, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dQe1, dQe0)  # the same four-way sums in the same order
+    torch.testing.assert_close(dEnc1, dEnc0, rtol=1e-5, atol=1e-5)
