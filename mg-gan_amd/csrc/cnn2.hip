@@ -789,6 +789,14 @@ __global__ __launch_bounds__(256) void conv1_wgrad_finalize_kernel(const double*
 // persistent grid: at most `cap` workgroups (three per CU), and every workgroup walks the same number of images
 // (the last one may fall short): 1,280 images -> 640 workgroups x 2, 8,192 -> 745 x 11
 static int grid_for(int B, int cap) {
+  static int knob = -1;  // MGGAN_CNN_GRID: measurement knob -- exactly this many workgroups (unequal image counts)
+  if (knob < 0) { const char* e = getenv("MGGAN_CNN_GRID"); knob = e ? atoi(e) : 0; }
+  if (knob > 0) return B < knob ? B : knob;
+  // a few images per workgroup: 512 workgroups (two per CU), workgroup i takes images i, i + 512, ... -- with 1,280 images
+  // three or two each, five per CU when the dispatcher deals workgroups round-robin; the equal split (640 x 2) leaves half
+  // of the CUs with three workgroups = six images (configs[1]: 1.394-1.400 vs 1.407-1.409 ms, two alternating pairs;
+  // from 8,192 images on the three-per-CU rule below wins: 4.74-4.77 vs 4.84-4.87 ms)
+  if (B > 512 && B <= 2048) return 512;
   if (B <= cap) return B;
   const int per = (B + cap - 1) / cap;
   return (B + per - 1) / per;
