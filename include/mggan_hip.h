@@ -32,6 +32,11 @@ const char* mggan_last_error(void);
 int mggan_version(void);
 /* Measurement aid: *slot = the device's 100 MHz wall clock when the stream (or the captured graph) gets here. */
 int mggan_timestamp(unsigned long long* slot, mggan_stream_t stream);
+/* Measurement aid: while on, every kernel launch of the library is noted; mggan_launch_log_read writes
+ * "symbol:threads;symbol:threads;..." (mangled device-function names, as rocprofv3 --kernel-trace reports them) of the
+ * launches since the last read into `out` and clears the log.  Process-wide; off by default (one flag load per launch). */
+int mggan_launch_log(int on);
+int mggan_launch_log_read(char* out, int cap);
 
 /* ---- dense layers: nn.Linear (+activation) forward / input grad / weight grad -------
  * reference: utils.py:134-149 (make_mlp), discriminators.py:46-56,76-108,
@@ -242,18 +247,22 @@ int mggan_bn_bwd_rows_finalize(const double* part, int rows, double count, int C
 int mggan_bn_bwd_coef(const double* sums, const double* local_sums, double count, int C, const float* gamma,
                       const float* stat, float* coef, double* coefd, float* dgamma, float* dbeta, mggan_stream_t stream);
 int mggan_scene_attention_fwd(const float* y2, int B, int C, const float* scale2, const float* shift2, const float* Wa,
-                              const float* ba, const float* Wb, const float* bb, float* out, int ld_out,
-                              const int* dims, mggan_stream_t stream);
-/* Adjoint of the attention head INCLUDING the weight gradients of both layers (MFMA; nothing per position is stored):
- * G2 = gradient on the raw conv2 output grid (B,C,16,16); wpart: mggan_scene_attention_grid(B) partial blocks of
+                              const float* ba, const float* Wb, const float* bb, float* out, int ld_out, float* ysel,
+                              unsigned char* ycode, const int* dims, mggan_stream_t stream);
+/* ysel / ycode above (both or neither; a forward pass that will be differentiated passes them): per image, channel and
+ * pooled cell -- laid out (B, 64 cells, C) -- the raw conv2 value that won its 2x2 window and which of the four it was -- all the adjoint needs
+ * of the conv2 output.
+ * Adjoint of the attention head INCLUDING the weight gradients of both layers (MFMA; nothing per position is stored):
+ * g2sel (B,64,C) = gradient that reaches the raw conv2 output grid, ONE value per pooled cell (it sits on window position
+ * ycode of the (B,C,16,16) grid, the other three are zero: mggan_conv2_bwd spreads it); wpart: mggan_scene_attention_grid(B) partial blocks of
  * mggan_scene_attention_partial_floats(C) floats ([32][C+1] = dWa | dba, then [C][33] = dWb | dbb) for
  * mggan_grad_reduce_multi; part: the same number of rows of 2C doubles (BatchNorm-2 adjoint sums per workgroup);
  * ticket != NULL: the launch also finishes the BatchNorm-2 adjoint (coef2, dgamma2 / dbeta2 accumulated). */
 int mggan_scene_attention_grid(int B);
 int mggan_scene_attention_partial_floats(int C);
-int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2, const float* shift2,
-                              const float* stat2, const float* Wa, const float* ba, const float* Wb, const float* bb,
-                              const float* dout, int ld_dout, float* G2, float* wpart, double* part,
+int mggan_scene_attention_bwd(const float* ysel, const unsigned char* ycode, int B, int C, const float* scale2,
+                              const float* shift2, const float* stat2, const float* Wa, const float* ba, const float* Wb,
+                              const float* bb, const float* dout, int ld_dout, float* g2sel, float* wpart, double* part,
                               unsigned int* ticket, double count, const float* gamma2, float* coef2, float* dgamma2,
                               float* dbeta2, const int* dims, mggan_stream_t stream);
 /* conv2 adjoint (BatchNorm-2 backward on the fly, dW2 / db2 as per-workgroup partial rows in `workspace`, input
@@ -261,7 +270,8 @@ int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2
  * mggan_cnn_bwd_grid(B) rows; coefd1 = [gamma*invstd | S1 | S2 | mean | invstd] (C each) + count, f64, for
  * mggan_conv1_wgrad.  workspace: mggan_cnn_bwd_grid(B) * (256/(C*C)) * (C*C*9 + C) floats. */
 int mggan_conv2_bwd(const float* xsel, int B, int C, const float* scale1,
-                    const float* shift1, const float* stat1, const float* y2, const float* G2, const float* stat2,
+                    const float* shift1, const float* stat1, const float* y2, const float* g2sel,
+                    const unsigned char* ycode, const float* stat2,
                     const float* coef2, const float* W, float* G1c, double* part1, float* dW,
                     float* db, float* workspace, size_t workspace_bytes, unsigned int* ticket, double count1,
                     const float* gamma1, float* coef1, double* coefd1, float* dgamma1, float* dbeta1,

@@ -156,7 +156,7 @@ __device__ __forceinline__ float pool_bn_relu(const float* __restrict__ base, in
 // ---------------- attention head: BN2+ReLU+pool prologue, 64 positions per image ----------------
 // AttentionGlobal (cnn.py:109-116) per pooled position: MLP C -> 32 -> C (LeakyReLU .01), softmax over CHANNELS,
 // out = sum_c a_c v_c -- forward and adjoint, INCLUDING the weight gradients of both layers, on v_mfma_f32_16x16x4_f32.
-// A wave owns whole images and walks an image in four groups of 16 positions.  Inside a group lane (pp, kq) =
+// A workgroup owns whole images, wave g of it the g-th group of 16 positions of each.  Inside a group lane (pp, kq) =
 // (lane & 15, lane >> 4) stands for position 16 g + pp and for channels 4 kq + r, r = 0..3 (C = 8: the upper two quarters
 // are padding -- zero weights, zero activations, score -inf):
 //   * the prologue (BatchNorm 2 scale/shift, ReLU, 2x2 max-pool with the reference's first-maximum rule) leaves v[r] of
@@ -189,14 +189,24 @@ __device__ __forceinline__ void at_wave_lds_sync() {
 // partial block of a workgroup: [32][C + 1] = dWa | dba, then [C][33] = dWb | dbb
 #define AT_WG_FLOATS(C) (32 * ((C) + 1) + (C) * 33)
 
+// Work split (round 5): a WORKGROUP owns whole images, wave g of it the g-th group of 16 positions of every one of them
+// (before: a wave walked the four groups of its images one after the other -- four dependent chains of matrix products per
+// image and wave; at 1,280 images that serial walk WAS the launch).  What the forward pass decides per pooled cell -- the
+// raw conv2 value that wins its 2x2 window and which of the four it is -- is kept (ysel: one float, ycode: one byte per
+// channel and cell, both (B, 64 cells, C): a lane's four channels are one 16-byte and one 4-byte access) and is all the
+// adjoint reads back: 5 bytes instead of the 16-byte window, and the gradient it routes
+// to the raw conv2 grid leaves as ONE float per cell (g2sel; the position is ycode) instead of a 2x2 block with three
+// zeros.  Per image and channel: 0.58 KB in + 0.25 KB out instead of 1 KB + 1 KB (268 MB per launch at 8,192 images, C = 16).
 template <int C, bool BWD>
 __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restrict__ y2, const float* __restrict__ scale2,
                                                    const float* __restrict__ shift2, const float* __restrict__ Wa,
                                                    const float* __restrict__ ba, const float* __restrict__ Wb,
                                                    const float* __restrict__ bb, float* out, int ld_out,
+                                                   float* ysel_out, unsigned char* ycode_out,  // forward: saved selection
                                                    // backward only
+                                                   const float* __restrict__ ysel, const unsigned char* __restrict__ ycode,
                                                    const float* __restrict__ dout, int ld_dout,
-                                                   const float* __restrict__ stat2, float* G2, float* wpart, double* part,
+                                                   const float* __restrict__ stat2, float* g2sel, float* wpart, double* part,
                                                    BnBwdFin fin, const int* dims) {
   MG_REAL_IMAGES_COUNT(B, dims, fin)
   if (!BWD && B < B_padded_) {
@@ -213,6 +223,7 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
   __shared__ int flag;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pp = lane & 15, kq = lane >> 4;
   const bool chq = 4 * kq < C;  // this lane's channel quarter exists
+  const int pos = 16 * w + pp, py = pos >> 3, px = pos & 7;  // wave w = group w of every image of the workgroup
   // ---- loop-invariant MFMA A operands ----
   // h^T = Wa v^T: step r <-> channel 4 k + r;  s^T = Wb h^T: step (t, r) <-> unit 16 t + 4 k + r
   float wa_a[2][4], wb_a[2][4];
@@ -250,53 +261,79 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
   f32x4 dWa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // dWa[u = 16 t + 4 kq + r][c = pp]
   f32x4 dWb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // dWb[c = 4 kq + r][u = 16 t + pp]
   float dba[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dbb[4] = {0.f, 0.f, 0.f, 0.f};  // lane-local (over positions)
-  double s1d[4] = {0.0, 0.0, 0.0, 0.0}, s2d[4] = {0.0, 0.0, 0.0, 0.0};  // BatchNorm-2 adjoint sums of channel 4 kq + r
-  float s1i[4] = {0.f, 0.f, 0.f, 0.f}, s2i[4] = {0.f, 0.f, 0.f, 0.f};  // ... of the image at hand (f32 within, f64 across)
+  // BatchNorm-2 adjoint sums of channel 4 kq + r: a lane adds ONE term per image (its position), in f64 from the start
+  double s1d[4] = {0.0, 0.0, 0.0, 0.0}, s2d[4] = {0.0, 0.0, 0.0, 0.0};
   float* DZs = smem + (BWD ? w * AT_TILE_FLOATS : 0);
   float* Hs = DZs + 16 * AT_LDU;
   float* Vs = Hs + 16 * AT_LDU;
   float* DSs = Vs + 16 * AT_LDC;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
-  // the 2x2 windows of the lane's four channels at position 16 g + pp of image b (raw conv2 output)
-  auto load_windows = [&](int b, int g, f32x4 win[4]) {
-    const int pos = 16 * g + pp, py = pos >> 3, px = pos & 7;
+  // what a lane needs of image b: forward -- the 2x2 windows of its four channels at its position (raw conv2 output);
+  // backward -- the saved winner of each window, its index, and the gradient of the attended feature at its position
+  struct In {
+    f32x4 win[4];
+    float sel[4];
+    int code[4];
+    float go;
+  };
+  auto load_in = [&](int b, In& in) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (chq) {
-        const float* base = y2 + (((size_t)b * C + 4 * kq + r) * 16 + 2 * py) * 16 + 2 * px;
-        const float2 lo = *reinterpret_cast<const float2*>(base), hi = *reinterpret_cast<const float2*>(base + 16);
-        win[r] = f32x4{lo.x, lo.y, hi.x, hi.y};
-      } else {
-        win[r] = zero;
+      if (!BWD) {
+        if (chq) {
+          const float* base = y2 + (((size_t)b * C + 4 * kq + r) * 16 + 2 * py) * 16 + 2 * px;
+          const float2 lo = *reinterpret_cast<const float2*>(base), hi = *reinterpret_cast<const float2*>(base + 16);
+          in.win[r] = f32x4{lo.x, lo.y, hi.x, hi.y};
+        } else {
+          in.win[r] = zero;
+        }
       }
     }
+    if (BWD) {  // (cell-major, channel innermost: the lane's four channels are 16 + 4 consecutive bytes)
+      const size_t ci = ((size_t)b * 64 + pos) * C + (chq ? 4 * kq : 0);
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(ysel + ci);
+      const unsigned cw = *reinterpret_cast<const unsigned*>(ycode + ci);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        in.sel[r] = sv[r];
+        in.code[r] = (int)((cw >> (8 * r)) & 0xffu);
+      }
+      in.go = dout[(size_t)b * ld_dout + pos];
+    }
   };
-  // a wave walks (image, group) pairs; the windows of the NEXT pair are in flight while this one is computed (a wave
-  // that loads, waits, computes, loads again spends four memory latencies per image)
-  const int b0 = blockIdx.x * 4 + w, bstep = gridDim.x * 4;
-  const int n_it = b0 < B ? 4 * ((B - 1 - b0) / bstep + 1) : 0;
-  f32x4 cur[4], nxt[4];
-  if (n_it > 0) load_windows(b0, 0, cur);
+  // the inputs of the NEXT image are in flight while this one is computed
+  In cur, nxt;
+  if ((int)blockIdx.x < B) load_in(blockIdx.x, cur);
 #pragma unroll 1
-  for (int it = 0; it < n_it; ++it) {
-    const int b = b0 + (it >> 2) * bstep, g = it & 3;
-    if (it + 1 < n_it) load_windows(b0 + ((it + 1) >> 2) * bstep, (it + 1) & 3, nxt);
-    const int pos = 16 * g + pp, py = pos >> 3, px = pos & 7;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    if (b + (int)gridDim.x < B) load_in(b + gridDim.x, nxt);
     // prologue: v = maxpool2(relu(bn2(y2))), first maximum wins (pool_bn_relu)
     float v[4], raw[4];
     int code[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float best = fmaxf(fmaf(cur[r][0], sc2[r], sh2[r]), 0.f);
-      code[r] = 0;
-      raw[r] = cur[r][0];
+      if (!BWD) {
+        float best = fmaxf(fmaf(cur.win[r][0], sc2[r], sh2[r]), 0.f);
+        code[r] = 0;
+        raw[r] = cur.win[r][0];
 #pragma unroll
-      for (int k = 1; k < 4; ++k) {
-        const float z = fmaxf(fmaf(cur[r][k], sc2[r], sh2[r]), 0.f);
-        if (z > best) { best = z; code[r] = k; raw[r] = cur[r][k]; }
+        for (int k = 1; k < 4; ++k) {
+          const float z = fmaxf(fmaf(cur.win[r][k], sc2[r], sh2[r]), 0.f);
+          if (z > best) { best = z; code[r] = k; raw[r] = cur.win[r][k]; }
+        }
+        v[r] = chq ? best : 0.f;
+      } else {  // the forward pass kept the winner: the same expression gives the same v
+        raw[r] = cur.sel[r];
+        code[r] = cur.code[r];
+        v[r] = chq ? fmaxf(fmaf(raw[r], sc2[r], sh2[r]), 0.f) : 0.f;
       }
-      v[r] = chq ? best : 0.f;
+    }
+    if (!BWD && ysel_out && chq) {
+      const size_t ci = ((size_t)b * 64 + pos) * C + 4 * kq;
+      *reinterpret_cast<f32x4*>(ysel_out + ci) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+      *reinterpret_cast<unsigned*>(ycode_out + ci) =
+          (unsigned)code[0] | ((unsigned)code[1] << 8) | ((unsigned)code[2] << 16) | ((unsigned)code[3] << 24);
     }
     // h = leaky(Wa v + ba): D fragment = unit 16 t + 4 kq + r of position pp
     f32x4 hp[2] = {ba_c[0], ba_c[1]};
@@ -338,7 +375,7 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
       if (kq == 0) out[(size_t)b * ld_out + pos] = o;
     } else {
       // ---- backward: out = sum_c a_c v_c, a = softmax(s) ----
-      const float go = dout[(size_t)b * ld_dout + pos];
+      const float go = cur.go;
       const float dot = go * o;  // sum_c a_c (go v_c)
       f32x4 dv, ds;
 #pragma unroll
@@ -369,17 +406,18 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
         dv2 = MFMA16(wat_a[1][r], dz[1][r], dv2);
       }
       dv += dv2;
-      // route through max-pool + ReLU to the raw conv2 output grid; partial sums of the BatchNorm-2 adjoint
+      // through max-pool + ReLU: ONE value per pooled cell (it sits on window position ycode of the raw conv2 grid);
+      // partial sums of the BatchNorm-2 adjoint
       if (chq) {
+        f32x4 gq;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float gg = v[r] > 0.f ? dv[r] : 0.f;
-          float* gb = G2 + (((size_t)b * C + 4 * kq + r) * 16 + 2 * py) * 16 + 2 * px;
-          *reinterpret_cast<float2*>(gb) = make_float2(code[r] == 0 ? gg : 0.f, code[r] == 1 ? gg : 0.f);
-          *reinterpret_cast<float2*>(gb + 16) = make_float2(code[r] == 2 ? gg : 0.f, code[r] == 3 ? gg : 0.f);
-          s1i[r] += gg;
-          s2i[r] = fmaf(gg, (raw[r] - mean2[r]) * istd2[r], s2i[r]);
+          gq[r] = gg;
+          s1d[r] += (double)gg;
+          s2d[r] += (double)(gg * ((raw[r] - mean2[r]) * istd2[r]));
         }
+        *reinterpret_cast<f32x4*>(g2sel + ((size_t)b * 64 + pos) * C + 4 * kq) = gq;
       }
       // weight gradients: contraction over the 16 positions through the wave's LDS tiles (pos = step + 4 k)
       *reinterpret_cast<f32x4*>(DZs + pp * AT_LDU + 4 * kq) = dz[0];
@@ -399,18 +437,9 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
           dWb[t] = MFMA16(da, Hs[pr * AT_LDU + 16 * t + pp], dWb[t]);
         }
       }
-      at_wave_lds_sync();  // the tiles are rewritten by the next group
-      if (g == 3) {  // the image is through: f32 sums within it, f64 across images
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s1d[r] += (double)row_sum16(s1i[r]);
-          s2d[r] += (double)row_sum16(s2i[r]);
-          s1i[r] = s2i[r] = 0.f;
-        }
-      }
+      at_wave_lds_sync();  // the tiles are rewritten by the next image
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) cur[r] = nxt[r];
+    cur = nxt;
   }
   if (!BWD) return;
   // ---- one partial block per workgroup: the four waves meet in LDS (fixed order) ----
@@ -431,9 +460,16 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
     for (int r = 0; r < 4; ++r) {
       const float sb = row_sum16(dbb[r]);
       if (pp == 0 && chq) mine[32 * (C + 1) + (4 * kq + r) * 33 + 32] = sb;
+      // the 16 positions of the wave's group, in lane order (f64 xor-fold over the DPP row)
+      double t1 = s1d[r], t2 = s2d[r];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        t1 += __shfl_xor(t1, o, 64);
+        t2 += __shfl_xor(t2, o, 64);
+      }
       if (pp == 0 && chq) {
-        sred[w * 2 * C + 4 * kq + r] = s1d[r];
-        sred[w * 2 * C + C + 4 * kq + r] = s2d[r];
+        sred[w * 2 * C + 4 * kq + r] = t1;
+        sred[w * 2 * C + C + 4 * kq + r] = t2;
       }
     }
   }
@@ -455,7 +491,9 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
                                                         const float* __restrict__ scale1,
                                                         const float* __restrict__ shift1,
                                                         const float* __restrict__ stat1, const float* __restrict__ y2,
-                                                        const float* __restrict__ G2, const float* __restrict__ stat2,
+                                                        const float* __restrict__ g2sel,
+                                                        const unsigned char* __restrict__ ycode,
+                                                        const float* __restrict__ stat2,
                                                         const float* __restrict__ coef2, const float* __restrict__ W,
                                                         float* G1c, double* part1, float* wpart, BnBwdFin fin,
                                                         const int* dims) {
@@ -490,7 +528,10 @@ __global__ __launch_bounds__(256) void conv2_bwd_kernel(int B, const float* __re
         a1p[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = fmaxf(fmaf(raw, scale1[c], shift1[c]), 0.f);
         y1r[c * 256 + threadIdx.x] = raw;
         const float xh = (y2[gi] - stat2[c]) * stat2[C + c];
-        dyp[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (G2[gi] - coef2[C + c] - xh * coef2[2 * C + c]);
+        // the gradient that reached the raw conv2 grid: one value per pooled cell, on window position ycode
+        const size_t ce = ((size_t)b * 64 + (py >> 1) * 8 + (px >> 1)) * C + c;
+        const float gr = (int)ycode[ce] == (py & 1) * 2 + (px & 1) ? g2sel[ce] : 0.f;
+        dyp[c * A1_PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (gr - coef2[C + c] - xh * coef2[2 * C + c]);
       }
     }
     lds_barrier();
@@ -624,7 +665,9 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
                                                             const float* __restrict__ scale1,
                                                             const float* __restrict__ shift1,
                                                             const float* __restrict__ stat1,
-                                                            const float* __restrict__ y2, const float* __restrict__ G2,
+                                                            const float* __restrict__ y2,
+                                                            const float* __restrict__ g2sel,
+                                                            const unsigned char* __restrict__ ycode,
                                                             const float* __restrict__ stat2,
                                                             const float* __restrict__ coef2, const float* __restrict__ W,
                                                             float* G1c, double* part1, float* wpart, BnBwdFin fin,
@@ -673,14 +716,27 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
 
   // the three planes of the NEXT image (raw conv1 value, raw conv2 output, its gradient) are in flight while this one is
   // computed
-  float rx[C], ry[C], rg[C];
+  // (the gradient on the raw conv2 grid arrives as ONE value per pooled cell + the window position that won the cell in the
+  //  forward pass -- attn_kernel: g2sel / ycode -- and is spread onto this thread's position here)
+  // Both are (B, 64 cells, C): the C values of this thread's cell are C/4 16-byte loads + one of C bytes, kept RAW until
+  // the staging pass (a select on a value just loaded would put the wait for it right behind the prefetch).
+  float rx[C], ry[C];
+  f32x4_t rg[C / 4];
+  unsigned rcode[C / 4];
+  const int my_cell = (threadIdx.x >> 5) * 8 + ((threadIdx.x & 15) >> 1);
+  const unsigned my_k = ((threadIdx.x >> 4) & 1) * 2 + (threadIdx.x & 1);
   auto fetch = [&](int b) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const size_t gi = ((size_t)b * C + c) * 256 + threadIdx.x;
       rx[c] = xsel[gi];
       ry[c] = y2[gi];
-      rg[c] = G2[gi];
+    }
+    const size_t ce = ((size_t)b * 64 + my_cell) * C;
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+      rg[q] = *reinterpret_cast<const f32x4_t*>(g2sel + ce + 4 * q);
+      rcode[q] = *reinterpret_cast<const unsigned*>(ycode + ce + 4 * q);
     }
   };
   if ((int)blockIdx.x < B) fetch(blockIdx.x);
@@ -694,7 +750,8 @@ __global__ __launch_bounds__(256) void conv2_bwd_mfma_kernel(int B, const float*
         a1p[c * PLANE + (py + 1) * A1_LD + px + 1] = fmaxf(fmaf(raw, scale1[c], shift1[c]), 0.f);
         y1r[c * 256 + threadIdx.x] = raw;
         const float xh = (ry[c] - stat2[c]) * stat2[C + c];
-        dyp[c * PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (rg[c] - coef2[C + c] - xh * coef2[2 * C + c]);
+        const float gr = ((rcode[c >> 2] >> (8 * (c & 3))) & 0xffu) == my_k ? rg[c >> 2][c & 3] : 0.f;
+        dyp[c * PLANE + (py + 1) * A1_LD + px + 1] = coef2[c] * (gr - coef2[C + c] - xh * coef2[2 * C + c]);
       }
     }
     if (b + (int)gridDim.x < B) fetch(b + gridDim.x);
@@ -844,31 +901,38 @@ int mggan_bn_finalize(const double* sums, double count, int C, int training, con
                       float* scale, float* shift, float* stat, hipStream_t stream) {
   MG_CHECK_ARG(gamma && beta && run_mean && run_var && scale && shift && stat && C <= 64, "bn_finalize: bad arguments");
   MG_CHECK_ARG(!training || (sums && num_batches_tracked), "bn_finalize: training needs sums and the batch counter");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, count, C, training, gamma, beta, run_mean,
+  MG_LAUNCH(bn_finalize_kernel, dim3(1), dim3(64), 0, stream, sums, count, C, training, gamma, beta, run_mean,
                      run_var, num_batches_tracked, momentum, eps, scale, shift, stat);
   MG_LAUNCH_CHECK("bn_finalize");
   return MGGAN_OK;
 }
 
-// persistent: a wave walks images b, b + 4 grid, ... (its weight fragments are loaded once)
-static int attn_grid(int B) { return cdiv(B, 4) < 1024 ? cdiv(B, 4) : 1024; }
+// persistent: a workgroup walks images b, b + grid, ... (its waves' weight fragments are loaded once); every workgroup
+// gets the same number of images (+-1), at most 1,024 workgroups (MGGAN_ATTN_GRID: exactly that many, A/B measurements)
+static int attn_grid(int B) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("MGGAN_ATTN_GRID"); forced = e ? atoi(e) : 0; }
+  if (forced > 0) return forced < B ? forced : B;
+  return cdiv(B, cdiv(B, 1024));
+}
 
 int mggan_scene_attention_grid(int B) { return B > 0 ? attn_grid(B) : 0; }
 int mggan_scene_attention_partial_floats(int C) { return AT_WG_FLOATS(C); }
 
 int mggan_scene_attention_fwd(const float* y2, int B, int C, const float* scale2, const float* shift2, const float* Wa,
-                              const float* ba, const float* Wb, const float* bb, float* out, int ld_out,
-                              const int* dims, hipStream_t stream) {
+                              const float* ba, const float* Wb, const float* bb, float* out, int ld_out, float* ysel,
+                              unsigned char* ycode, const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "scene_attention_fwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(y2 && scale2 && shift2 && Wa && ba && Wb && bb && out, "scene_attention_fwd: null pointer");
+  MG_CHECK_ARG((ysel == nullptr) == (ycode == nullptr), "scene_attention_fwd: ysel and ycode come together");
   const BnBwdFin none = make_bfin(nullptr, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   if (C == 16)
-    hipLaunchKernelGGL((attn_kernel<16, false>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, none, dims);
+    MG_LAUNCH((attn_kernel<16, false>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba, Wb, bb,
+              out, ld_out, ysel, ycode, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, none, dims);
   else
-    hipLaunchKernelGGL((attn_kernel<8, false>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, out, ld_out, nullptr, 0, nullptr, nullptr, nullptr, nullptr, none, dims);
+    MG_LAUNCH((attn_kernel<8, false>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba, Wb, bb,
+              out, ld_out, ysel, ycode, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, none, dims);
   MG_LAUNCH_CHECK("scene_attention_fwd");
   return MGGAN_OK;
 }
@@ -877,23 +941,23 @@ int mggan_scene_attention_fwd(const float* y2, int B, int C, const float* scale2
  * dba, then [C][33] = dWb | dbb) for mggan_grad_reduce_multi; part: the same number of rows of 2C doubles (sum g | sum
  * g*xhat per workgroup).  ticket != NULL: the launch also finishes the BatchNorm-2 adjoint (coef2 = [gamma*invstd | mean
  * g | mean g*xhat], dgamma2 / dbeta2 accumulated) */
-int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2, const float* shift2,
-                              const float* stat2, const float* Wa, const float* ba, const float* Wb, const float* bb,
-                              const float* dout, int ld_dout, float* G2, float* wpart, double* part, unsigned* ticket,
-                              double count, const float* gamma2, float* coef2, float* dgamma2, float* dbeta2,
-                              const int* dims, hipStream_t stream) {
+int mggan_scene_attention_bwd(const float* ysel, const unsigned char* ycode, int B, int C, const float* scale2,
+                              const float* shift2, const float* stat2, const float* Wa, const float* ba, const float* Wb,
+                              const float* bb, const float* dout, int ld_dout, float* g2sel, float* wpart, double* part,
+                              unsigned* ticket, double count, const float* gamma2, float* coef2, float* dgamma2,
+                              float* dbeta2, const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "scene_attention_bwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
-  MG_CHECK_ARG(y2 && scale2 && shift2 && stat2 && Wa && ba && Wb && bb && dout && G2 && wpart && part,
+  MG_CHECK_ARG(ysel && ycode && scale2 && shift2 && stat2 && Wa && ba && Wb && bb && dout && g2sel && wpart && part,
                "scene_attention_bwd: null pointer");
   MG_CHECK_ARG(!ticket || (gamma2 && coef2 && dgamma2 && dbeta2), "scene_attention_bwd: the fused finalize needs gamma / coef / grads");
   const BnBwdFin fin = make_bfin(ticket, count, gamma2, stat2, coef2, nullptr, dgamma2, dbeta2);
   if (C == 16)
-    hipLaunchKernelGGL((attn_kernel<16, true>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, G2, wpart, part, fin, dims);
+    MG_LAUNCH((attn_kernel<16, true>), dim3(attn_grid(B)), dim3(256), 0, stream, B, nullptr, scale2, shift2, Wa, ba, Wb,
+              bb, nullptr, 0, nullptr, nullptr, ysel, ycode, dout, ld_dout, stat2, g2sel, wpart, part, fin, dims);
   else
-    hipLaunchKernelGGL((attn_kernel<8, true>), dim3(attn_grid(B)), dim3(256), 0, stream, B, y2, scale2, shift2, Wa, ba,
-                       Wb, bb, nullptr, 0, dout, ld_dout, stat2, G2, wpart, part, fin, dims);
+    MG_LAUNCH((attn_kernel<8, true>), dim3(attn_grid(B)), dim3(256), 0, stream, B, nullptr, scale2, shift2, Wa, ba, Wb,
+              bb, nullptr, 0, nullptr, nullptr, ysel, ycode, dout, ld_dout, stat2, g2sel, wpart, part, fin, dims);
   MG_LAUNCH_CHECK("scene_attention_bwd");
   return MGGAN_OK;
 }
@@ -904,14 +968,15 @@ int mggan_scene_attention_bwd(const float* y2, int B, int C, const float* scale2
  * resolution (it belongs to the window position conv1_pool recorded).  part1: mggan_cnn_bwd_grid(B) rows of 2C doubles; with a
  * ticket the launch also finishes the BatchNorm-1 adjoint (coef1, coefd1 for mggan_conv1_wgrad, dgamma1 / dbeta1). */
 int mggan_conv2_bwd(const float* xsel, int B, int C, const float* scale1,
-                    const float* shift1, const float* stat1, const float* y2, const float* G2, const float* stat2,
+                    const float* shift1, const float* stat1, const float* y2, const float* g2sel,
+                    const unsigned char* ycode, const float* stat2,
                     const float* coef2, const float* W, float* G1c, double* part1, float* dW,
                     float* db, float* workspace, size_t workspace_bytes, unsigned* ticket, double count1,
                     const float* gamma1, float* coef1, double* coefd1, float* dgamma1, float* dbeta1, const int* dims,
                     hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv2_bwd: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
-  MG_CHECK_ARG(xsel && scale1 && shift1 && stat1 && y2 && G2 && stat2 && coef2 && W && G1c && part1 && workspace,
+  MG_CHECK_ARG(xsel && scale1 && shift1 && stat1 && y2 && g2sel && ycode && stat2 && coef2 && W && G1c && part1 && workspace,
                "conv2_bwd: null pointer");
   MG_CHECK_ARG(!ticket || (gamma1 && coef1 && dgamma1 && dbeta1), "conv2_bwd: the fused finalize needs gamma / coef / grads");
   const int grid = persistent_grid(B), NQ = 256 / (C * C), wlen = C * C * 9 + C;
@@ -935,19 +1000,19 @@ int mggan_conv2_bwd(const float* xsel, int B, int C, const float* scale1,
       attr[C == 16] = true;
     }
     if (C == 16)
-      hipLaunchKernelGGL(conv2_bwd_mfma_kernel<16>, dim3(grid), dim3(256), lds, stream, B, xsel, scale1, shift1, stat1, y2, G2,
-                         stat2, coef2, W, G1c, part1, workspace, fin, dims);
+      MG_LAUNCH(conv2_bwd_mfma_kernel<16>, dim3(grid), dim3(256), lds, stream, B, xsel, scale1, shift1, stat1, y2, g2sel,
+                ycode, stat2, coef2, W, G1c, part1, workspace, fin, dims);
     else
-      hipLaunchKernelGGL(conv2_bwd_mfma_kernel<8>, dim3(grid), dim3(256), lds, stream, B, xsel, scale1, shift1, stat1, y2, G2,
-                         stat2, coef2, W, G1c, part1, workspace, fin, dims);
+      MG_LAUNCH(conv2_bwd_mfma_kernel<8>, dim3(grid), dim3(256), lds, stream, B, xsel, scale1, shift1, stat1, y2, g2sel,
+                ycode, stat2, coef2, W, G1c, part1, workspace, fin, dims);
   } else
-    hipLaunchKernelGGL((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1,
-                       stat1, y2, G2, stat2, coef2, W, G1c, part1, workspace, fin, dims);
+    MG_LAUNCH((conv2_bwd_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, stat1, y2, g2sel, ycode,
+              stat2, coef2, W, G1c, part1, workspace, fin, dims);
   MG_LAUNCH_CHECK("conv2_bwd");
   if (!dW) return MGGAN_OK;  // deferred reduce of the [grid][C*C*9 + C] partial rows
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(1024), 0, stream, workspace, grid, wlen,
+  MG_LAUNCH(partial_sum_kernel, dim3(cdiv(C * C * 9, 64)), dim3(1024), 0, stream, workspace, grid, wlen,
                      C * C * 9, dW);
-  hipLaunchKernelGGL(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, workspace + C * C * 9, grid, wlen,
+  MG_LAUNCH(partial_sum_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, workspace + C * C * 9, grid, wlen,
                      C, db);
   MG_LAUNCH_CHECK("conv2_bwd reduce");
   return MGGAN_OK;

@@ -826,8 +826,8 @@ int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float
   const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
                              scale, shift, stat);
   const int grid = grid_for(B, 768);
-  if (C == 16) hipLaunchKernelGGL((conv1_pool_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, dims);
-  else hipLaunchKernelGGL((conv1_pool_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, dims);
+  if (C == 16) MG_LAUNCH((conv1_pool_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, dims);
+  else MG_LAUNCH((conv1_pool_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, dims);
   MG_LAUNCH_CHECK("conv1_pool");
   return MGGAN_OK;
 }
@@ -848,11 +848,11 @@ int mggan_conv2_fwd2(const float* xsel, int B, int C, const float* scale1, const
   static int valu = -1;  // MGGAN_CONV2_VALU=1: the register-tiled VALU kernel (A/B measurements)
   if (valu < 0) { const char* e = getenv("MGGAN_CONV2_VALU"); valu = e && e[0] == '1'; }
   if (valu) {
-    if (C == 16) hipLaunchKernelGGL((conv2_fwd2_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
-    else hipLaunchKernelGGL((conv2_fwd2_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
+    if (C == 16) MG_LAUNCH((conv2_fwd2_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
+    else MG_LAUNCH((conv2_fwd2_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
   } else {
-    if (C == 16) hipLaunchKernelGGL((conv2_fwd_mfma_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
-    else hipLaunchKernelGGL((conv2_fwd_mfma_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
+    if (C == 16) MG_LAUNCH((conv2_fwd_mfma_kernel<16>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
+    else MG_LAUNCH((conv2_fwd_mfma_kernel<8>), dim3(grid), dim3(256), 0, stream, B, xsel, scale1, shift1, W, bias, y2, part, fin, dims);
   }
   MG_LAUNCH_CHECK("conv2_fwd2");
   return MGGAN_OK;
@@ -860,7 +860,7 @@ int mggan_conv2_fwd2(const float* xsel, int B, int C, const float* scale1, const
 
 int mggan_bn_reduce_rows(const double* part, int rows, int W, double* sums, hipStream_t stream) {
   MG_CHECK_ARG(part && sums && W > 0 && W <= 32, "bn_reduce_rows: bad arguments");
-  hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(1), dim3(256), 0, stream, part, rows, W, sums);
+  MG_LAUNCH(bn_reduce_rows_kernel, dim3(1), dim3(256), 0, stream, part, rows, W, sums);
   MG_LAUNCH_CHECK("bn_reduce_rows");
   return MGGAN_OK;
 }
@@ -876,7 +876,7 @@ static BnBwdFin make_bfin(unsigned* ticket, double count, const float* gamma, co
 int mggan_bn_bwd_rows_finalize(const double* part, int rows, double count, int C, const float* gamma, const float* stat,
                                float* coef, double* coefd, float* dgamma, float* dbeta, hipStream_t stream) {
   MG_CHECK_ARG(part && gamma && stat && coef && dgamma && dbeta && C <= 16, "bn_bwd_rows_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_rows_finalize_kernel, dim3(1), dim3(256), 0, stream, part, rows, C,
+  MG_LAUNCH(bn_bwd_rows_finalize_kernel, dim3(1), dim3(256), 0, stream, part, rows, C,
                      make_bfin(nullptr, count, gamma, stat, coef, coefd, dgamma, dbeta));
   MG_LAUNCH_CHECK("bn_bwd_rows_finalize");
   return MGGAN_OK;
@@ -885,7 +885,7 @@ int mggan_bn_bwd_rows_finalize(const double* part, int rows, double count, int C
 int mggan_bn_bwd_coef(const double* sums, const double* local_sums, double count, int C, const float* gamma,
                       const float* stat, float* coef, double* coefd, float* dgamma, float* dbeta, hipStream_t stream) {
   MG_CHECK_ARG(sums && local_sums && gamma && stat && coef && dgamma && dbeta && C <= 16, "bn_bwd_coef: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(1), dim3(64), 0, stream, sums, local_sums, C,
+  MG_LAUNCH(bn_bwd_coef_kernel, dim3(1), dim3(64), 0, stream, sums, local_sums, C,
                      make_bfin(nullptr, count, gamma, stat, coef, coefd, dgamma, dbeta));
   MG_LAUNCH_CHECK("bn_bwd_coef");
   return MGGAN_OK;
@@ -898,7 +898,7 @@ int mggan_bn_sync_finalize(void* const* arenas, int rank, int world, long max_el
   MG_CHECK_ARG(arenas && part && gamma && beta && run_mean && run_var && num_batches_tracked && scale && shift && stat &&
                    C <= 16 && world >= 1 && world <= COMM_MAX_RANKS,
                "bn_sync_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_sync_finalize_kernel, dim3(1), dim3(256), 0, stream, comm_make_args(arenas, rank, world, max_elems),
+  MG_LAUNCH(bn_sync_finalize_kernel, dim3(1), dim3(256), 0, stream, comm_make_args(arenas, rank, world, max_elems),
                      part, rows, C, local_count,
                      make_fin(nullptr, 0.0, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
                               scale, shift, stat));
@@ -912,7 +912,7 @@ int mggan_bn_bwd_sync_finalize(void* const* arenas, int rank, int world, long ma
   MG_CHECK_ARG(arenas && part && gamma && stat && coef && dgamma && dbeta && C <= 16 && world >= 1 &&
                    world <= COMM_MAX_RANKS,
                "bn_bwd_sync_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_sync_finalize_kernel, dim3(1), dim3(256), 0, stream,
+  MG_LAUNCH(bn_bwd_sync_finalize_kernel, dim3(1), dim3(256), 0, stream,
                      comm_make_args(arenas, rank, world, max_elems), part, rows, C, local_count,
                      make_bfin(nullptr, 0.0, gamma, stat, coef, coefd, dgamma, dbeta));
   MG_LAUNCH_CHECK("bn_bwd_sync_finalize");
@@ -925,8 +925,8 @@ int mggan_image_gram(const float* img, int B, double* gram, double* workspace, s
   MG_CHECK_ARG(gram && workspace && (img || B == 0), "image_gram: null pointer");
   const int grid = grid_for(B, 768);
   MG_CHECK_ARG(workspace_bytes >= (size_t)(grid > 0 ? grid : 1) * 6 * 256 * sizeof(double), "image_gram: workspace too small");
-  if (grid > 0) hipLaunchKernelGGL(image_gram_kernel, dim3(grid), dim3(256), 0, stream, B, img, workspace, dims);
-  hipLaunchKernelGGL(image_gram_finalize_kernel, dim3(96), dim3(256), 0, stream, workspace, grid, gram);
+  if (grid > 0) MG_LAUNCH(image_gram_kernel, dim3(grid), dim3(256), 0, stream, B, img, workspace, dims);
+  MG_LAUNCH(image_gram_finalize_kernel, dim3(96), dim3(256), 0, stream, workspace, grid, gram);
   MG_LAUNCH_CHECK("image_gram");
   return MGGAN_OK;
 }
@@ -940,9 +940,9 @@ int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const un
   MG_CHECK_ARG(img && G1c && code1 && gram && W && bias && coefd && dW && workspace, "conv1_wgrad: null pointer");
   const int grid = grid_for(B, 768);
   MG_CHECK_ARG(workspace_bytes >= (size_t)grid * C * 36 * sizeof(double), "conv1_wgrad: workspace too small");
-  if (C == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
-  else hipLaunchKernelGGL((conv1_wgrad_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
-  hipLaunchKernelGGL(conv1_wgrad_finalize_kernel, dim3(C), dim3(256), 0, stream, workspace, grid, C, gram, W, bias, coefd, dW);
+  if (C == 16) MG_LAUNCH((conv1_wgrad_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
+  else MG_LAUNCH((conv1_wgrad_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
+  MG_LAUNCH(conv1_wgrad_finalize_kernel, dim3(C), dim3(256), 0, stream, workspace, grid, C, gram, W, bias, coefd, dW);
   MG_LAUNCH_CHECK("conv1_wgrad");
   return MGGAN_OK;
 }

@@ -145,9 +145,9 @@ int mggan_comm_allreduce(void* const* arenas, int rank, int world, long max_elem
   a.max_blocks = cdiv(max_elems * 2, COMM_CHUNK); a.dtype = dtype;
   a.timeout_ticks = g_timeout_ticks; a.host_error = g_host_error;
   const int grid = cdiv(n, COMM_CHUNK);
-  if (dtype == 0) hipLaunchKernelGGL(comm_allreduce_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
-  else if (dtype == 1) hipLaunchKernelGGL(comm_allreduce_kernel<double>, dim3(grid), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(comm_allreduce_kernel<int>, dim3(grid), dim3(256), 0, stream, a);
+  if (dtype == 0) MG_LAUNCH(comm_allreduce_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
+  else if (dtype == 1) MG_LAUNCH(comm_allreduce_kernel<double>, dim3(grid), dim3(256), 0, stream, a);
+  else MG_LAUNCH(comm_allreduce_kernel<int>, dim3(grid), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("comm_allreduce");
   return MGGAN_OK;
 }

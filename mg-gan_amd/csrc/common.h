@@ -37,6 +37,17 @@ void mggan_set_error(const char* fmt, ...);
     }                                                                      \
   } while (0)
 
+// Every kernel launch of the library goes through MG_LAUNCH: while the launch log is on (mggan_launch_log, a
+// measurement aid: bench.py / tools name the HIP kernel an entry ran by its SYMBOL, the name rocprofv3 reports) the host
+// function pointer and the launch size are noted; otherwise it is hipLaunchKernelGGL and one load of a flag.
+extern int g_mggan_launch_log;
+void mggan_note_launch(const void* host_fn, dim3 grid, dim3 block);
+#define MG_LAUNCH(kernel, grid, block, ...)                                                   \
+  do {                                                                                        \
+    if (g_mggan_launch_log) mggan_note_launch((const void*)(kernel), (grid), (block));        \
+    hipLaunchKernelGGL(kernel, (grid), (block), __VA_ARGS__);                                 \
+  } while (0)
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // activation codes shared with the Python side

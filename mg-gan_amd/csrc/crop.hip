@@ -79,7 +79,7 @@ int mggan_pad_batch(const void* descs, int n, int b, int b_pad, int period, hipS
   if (a.total == 0) return MGGAN_OK;
   int blocks = cdiv(a.total, 256 * 4);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pad_batch_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  MG_LAUNCH(pad_batch_kernel, dim3(blocks), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("pad_batch");
   return MGGAN_OK;
 }
@@ -92,7 +92,7 @@ int mggan_crop_patches(const unsigned char* atlas, const long long* img_off, con
   const long long total = (long long)n * 4 * (2 * margin + 1) * (2 * margin + 1);
   int blocks = cdiv(total, 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(crop_patches_kernel, dim3(blocks), dim3(256), 0, stream, atlas, img_off, img_hw, centers, n, margin, out);
+  MG_LAUNCH(crop_patches_kernel, dim3(blocks), dim3(256), 0, stream, atlas, img_off, img_hw, centers, n, margin, out);
   MG_LAUNCH_CHECK("crop_patches");
   return MGGAN_OK;
 }

@@ -821,9 +821,9 @@ int mggan_dheads_fwd(const float* X, int ldx, int rows, int g, int act_a, const 
   if (int rc = dheads_check(a, "dheads_fwd")) return rc;
   if (rows == 0) return MGGAN_OK;
   MG_CHECK_ARG(X && Ya && Yb && ldx >= DH_IN && (ldx & 3) == 0 && (((size_t)X) & 15) == 0, "dheads_fwd: bad input / outputs");
-  if (g <= 4) hipLaunchKernelGGL(dheads_fwd_kernel<4>, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
-  else if (g <= 8) hipLaunchKernelGGL(dheads_fwd_kernel<8>, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(dheads_fwd_kernel<16>, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
+  if (g <= 4) MG_LAUNCH(dheads_fwd_kernel<4>, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
+  else if (g <= 8) MG_LAUNCH(dheads_fwd_kernel<8>, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
+  else MG_LAUNCH(dheads_fwd_kernel<16>, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("dheads_fwd");
   return MGGAN_OK;
 }
@@ -842,7 +842,7 @@ int mggan_dheads_bwd_data(const float* dYa, const float* dYb, const float* Ya, c
   if (int rc = dheads_check(a, "dheads_bwd_data")) return rc;
   if (rows == 0) return MGGAN_OK;
   MG_CHECK_ARG(dYa && dYb && Ya && Ha && Hb && dX && ld_dx >= DH_IN, "dheads_bwd_data: null pointer");
-  hipLaunchKernelGGL(dheads_bwd_kernel, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
+  MG_LAUNCH(dheads_bwd_kernel, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("dheads_bwd_data");
   return MGGAN_OK;
 }
@@ -871,7 +871,7 @@ int mggan_dheads_bwd_train(const float* dYa, const float* dYb, const float* Ya, 
   MG_CHECK_ARG(dYa && dYb && Ya && Ha && Hb && dX && dH && dza && ld_dx >= DH_IN && row0_b >= 0 && row0_b <= rows &&
                    (((size_t)dH) & 15) == 0,
                "dheads_bwd_train: bad arguments");
-  hipLaunchKernelGGL(dheads_bwd_kernel, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
+  MG_LAUNCH(dheads_bwd_kernel, dim3(dheads_grid(rows)), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("dheads_bwd_train");
   return MGGAN_OK;
 }
@@ -886,7 +886,7 @@ int mggan_dheads_shared(const float* X, int ldx, int b, int c_in, int c_sc, cons
                    c_sc % 4 == 0 && c_in >= 0 && c_in + 32 <= DH_IN && c_sc >= 0 && c_sc + 64 <= DH_IN,
                "dheads_shared: bad layout (ldx %d, c_in %d, c_sc %d)", ldx, c_in, c_sc);
   DSharedArgs a = {X, ldx, b, c_in, c_sc, W1a, b1a, W1b, b1b, P};
-  hipLaunchKernelGGL(dheads_shared_kernel, dim3((b + 15) / 16), dim3(256), 0, stream, a);
+  MG_LAUNCH(dheads_shared_kernel, dim3((b + 15) / 16), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("dheads_shared");
   return MGGAN_OK;
 }
@@ -907,9 +907,9 @@ int mggan_dheads_lean_fwd(const float* X, int ldx, int c_pe, int row0, int rows,
   a.X = X; a.ldx = ldx; a.c_pe = c_pe; a.row0 = row0; a.rows = rows; a.b = b; a.g = g; a.act_a = act_a; a.P = P;
   a.W1a = W1a; a.W1b = W1b; a.W2a = W2a; a.b2a = b2a; a.W2b = W2b; a.b2b = b2b; a.mask = mask; a.Ya = Ya; a.Yb = Yb;
   const dim3 grid(dlean_grid(rows - row0));
-  if (g <= 4) hipLaunchKernelGGL(dheads_lean_fwd_kernel<4>, grid, dim3(256), 0, stream, a);
-  else if (g <= 8) hipLaunchKernelGGL(dheads_lean_fwd_kernel<8>, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(dheads_lean_fwd_kernel<16>, grid, dim3(256), 0, stream, a);
+  if (g <= 4) MG_LAUNCH(dheads_lean_fwd_kernel<4>, grid, dim3(256), 0, stream, a);
+  else if (g <= 8) MG_LAUNCH(dheads_lean_fwd_kernel<8>, grid, dim3(256), 0, stream, a);
+  else MG_LAUNCH(dheads_lean_fwd_kernel<16>, grid, dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("dheads_lean_fwd");
   return MGGAN_OK;
 }
@@ -928,9 +928,9 @@ int mggan_dheads_lean_bwd(const float* dYa, const float* dYb, const float* Ya, c
   a.W1a = W1a; a.W1b = W1b; a.W2a = W2a; a.W2b = W2b; a.mask = const_cast<unsigned long long*>(mask);
   a.Ya = const_cast<float*>(Ya); a.dYa = dYa; a.dYb = dYb; a.dX = dX; a.ld_dx = ld_dx;
   const dim3 grid(dlean_grid(rows - row0));
-  if (g <= 4) hipLaunchKernelGGL(dheads_lean_bwd_kernel<4>, grid, dim3(256), 0, stream, a);
-  else if (g <= 8) hipLaunchKernelGGL(dheads_lean_bwd_kernel<8>, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(dheads_lean_bwd_kernel<16>, grid, dim3(256), 0, stream, a);
+  if (g <= 4) MG_LAUNCH(dheads_lean_bwd_kernel<4>, grid, dim3(256), 0, stream, a);
+  else if (g <= 8) MG_LAUNCH(dheads_lean_bwd_kernel<8>, grid, dim3(256), 0, stream, a);
+  else MG_LAUNCH(dheads_lean_bwd_kernel<16>, grid, dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("dheads_lean_bwd");
   return MGGAN_OK;
 }
@@ -963,9 +963,9 @@ int mggan_d_rows_lean_fwd(const float* pred, int T, int row0, int rows, int b, i
   a.W1a = W1a; a.W1b = W1b; a.W2a = W2a; a.b2a = b2a; a.W2b = W2b; a.b2b = b2b; a.mask = mask; a.Ya = Ya; a.Yb = Yb;
   q.pred = pred; q.Wp1 = Wp1; q.bp1 = bp1; q.Wp2 = Wp2; q.bp2 = bp2;
   const dim3 grid(dlean_grid(rows - row0));
-  if (g <= 4) hipLaunchKernelGGL(d_rows_lean_fwd_kernel<4>, grid, dim3(256), 0, stream, q);
-  else if (g <= 8) hipLaunchKernelGGL(d_rows_lean_fwd_kernel<8>, grid, dim3(256), 0, stream, q);
-  else hipLaunchKernelGGL(d_rows_lean_fwd_kernel<16>, grid, dim3(256), 0, stream, q);
+  if (g <= 4) MG_LAUNCH(d_rows_lean_fwd_kernel<4>, grid, dim3(256), 0, stream, q);
+  else if (g <= 8) MG_LAUNCH(d_rows_lean_fwd_kernel<8>, grid, dim3(256), 0, stream, q);
+  else MG_LAUNCH(d_rows_lean_fwd_kernel<16>, grid, dim3(256), 0, stream, q);
   MG_LAUNCH_CHECK("d_rows_lean_fwd");
   return MGGAN_OK;
 }
@@ -986,9 +986,9 @@ int mggan_d_rows_lean_bwd(const float* dYa, const float* dYb, const float* Ya, c
   a.Ya = const_cast<float*>(Ya); a.dYa = dYa; a.dYb = dYb;
   q.Wp1 = Wp1; q.Wp2 = Wp2; q.dpred = dpred;
   const dim3 grid(dlean_grid(rows - row0));
-  if (g <= 4) hipLaunchKernelGGL(d_rows_lean_bwd_kernel<4>, grid, dim3(256), 0, stream, q);
-  else if (g <= 8) hipLaunchKernelGGL(d_rows_lean_bwd_kernel<8>, grid, dim3(256), 0, stream, q);
-  else hipLaunchKernelGGL(d_rows_lean_bwd_kernel<16>, grid, dim3(256), 0, stream, q);
+  if (g <= 4) MG_LAUNCH(d_rows_lean_bwd_kernel<4>, grid, dim3(256), 0, stream, q);
+  else if (g <= 8) MG_LAUNCH(d_rows_lean_bwd_kernel<8>, grid, dim3(256), 0, stream, q);
+  else MG_LAUNCH(d_rows_lean_bwd_kernel<16>, grid, dim3(256), 0, stream, q);
   MG_LAUNCH_CHECK("d_rows_lean_bwd");
   return MGGAN_OK;
 }
@@ -1010,7 +1010,7 @@ int mggan_pred_encoder_fwd(const float* a, const float* b2, int T, int n_stride,
                ldx, c_pe);
   PredEncArgs q = {a, b2, n_stride, rows_a, rows, Wp1, bp1, Wp2, bp2, X, ldx, c_pe, h1, xrows};
   const int nt = (rows + 15) / 16, wg = (nt + 3) / 4;
-  hipLaunchKernelGGL(pred_encoder_fwd_kernel, dim3(wg < 1024 ? wg : 1024), dim3(256), 0, stream, q);
+  MG_LAUNCH(pred_encoder_fwd_kernel, dim3(wg < 1024 ? wg : 1024), dim3(256), 0, stream, q);
   MG_LAUNCH_CHECK("pred_encoder_fwd");
   return MGGAN_OK;
 }

@@ -71,7 +71,7 @@ int mggan_d_rows_fill(int b, int K, int soc_blocks, int w_soc, int c_in, int w_i
                "d_rows_fill: widths, column offsets and row strides must be multiples of 4 floats");
   const long n = (long)K * b * ((w_soc + w_in + w_scene) / 4);
   if (n == 0) return MGGAN_OK;
-  hipLaunchKernelGGL(d_rows_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, soc_blocks, w_soc, c_in, w_in,
+  MG_LAUNCH(d_rows_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, soc_blocks, w_soc, c_in, w_in,
                      c_scene, w_scene, in_enc, ld_in, scene, ld_scene, X, ldx);
   MG_LAUNCH_CHECK("d_rows_fill");
   return MGGAN_OK;
@@ -83,7 +83,7 @@ int mggan_d_rows_reduce(int b, int K, int c_in, int w_in, int c_scene, int w_sce
   MG_CHECK_ARG(dX, "d_rows_reduce: null pointer");
   const long n = (long)b * (w_in + w_scene);
   if (n == 0) return MGGAN_OK;
-  hipLaunchKernelGGL(d_rows_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, c_in, w_in, c_scene, w_scene, dX,
+  MG_LAUNCH(d_rows_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, c_in, w_in, c_scene, w_scene, dX,
                      ldx, din, ld_in, dscene, ld_scene);
   MG_LAUNCH_CHECK("d_rows_reduce");
   return MGGAN_OK;
@@ -92,7 +92,7 @@ int mggan_d_rows_reduce(int b, int K, int c_in, int w_in, int c_scene, int w_sce
 int mggan_rows_to_steps(const float* rows, int ld, int T, int n, float* out, hipStream_t stream) {
   if ((long)n * T == 0) return MGGAN_OK;
   MG_CHECK_ARG(rows && out && ld >= 2 * T && ld % 2 == 0, "rows_to_steps: bad arguments");
-  hipLaunchKernelGGL(rows_to_steps_kernel, dim3(cdiv((long)n * T, 256)), dim3(256), 0, stream, rows, ld, T, n, n, out);
+  MG_LAUNCH(rows_to_steps_kernel, dim3(cdiv((long)n * T, 256)), dim3(256), 0, stream, rows, ld, T, n, n, out);
   MG_LAUNCH_CHECK("rows_to_steps");
   return MGGAN_OK;
 }
@@ -101,7 +101,7 @@ int mggan_rows_to_steps(const float* rows, int ld, int T, int n, float* out, hip
 int mggan_rows_to_steps_n(const float* rows, int ld, int T, int n, int n_out, float* out, hipStream_t stream) {
   if ((long)n * T == 0) return MGGAN_OK;
   MG_CHECK_ARG(rows && out && ld >= 2 * T && ld % 2 == 0 && n <= n_out, "rows_to_steps_n: bad arguments");
-  hipLaunchKernelGGL(rows_to_steps_kernel, dim3(cdiv((long)n * T, 256)), dim3(256), 0, stream, rows, ld, T, n, n_out, out);
+  MG_LAUNCH(rows_to_steps_kernel, dim3(cdiv((long)n * T, 256)), dim3(256), 0, stream, rows, ld, T, n, n_out, out);
   MG_LAUNCH_CHECK("rows_to_steps_n");
   return MGGAN_OK;
 }

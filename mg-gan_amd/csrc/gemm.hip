@@ -602,9 +602,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 static void launch_stream(const StreamBatch& sb, int blocks, int mode, hipStream_t stream) {
-  if (mode == 0) hipLaunchKernelGGL(wgrad_stream_kernel<0>, dim3(blocks), dim3(256), 0, stream, sb);
-  else if (mode == 1) hipLaunchKernelGGL(wgrad_stream_kernel<1>, dim3(blocks), dim3(256), 0, stream, sb);
-  else hipLaunchKernelGGL(wgrad_stream_kernel<2>, dim3(blocks), dim3(256), 0, stream, sb);
+  if (mode == 0) MG_LAUNCH(wgrad_stream_kernel<0>, dim3(blocks), dim3(256), 0, stream, sb);
+  else if (mode == 1) MG_LAUNCH(wgrad_stream_kernel<1>, dim3(blocks), dim3(256), 0, stream, sb);
+  else MG_LAUNCH(wgrad_stream_kernel<2>, dim3(blocks), dim3(256), 0, stream, sb);
 }
 
 extern "C" {
@@ -618,7 +618,7 @@ int mggan_linear_fwd(const float* X, int ldx, const float* W, const float* bias,
   g.M = rows; g.N = N; g.K = K; g.lda = ldx; g.ldb = K; g.ldc = ldy;
   g.act = act; g.slope = slope;
   dim3 grid(cdiv(N, BN), cdiv(rows, BM), 1);
-  hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  MG_LAUNCH((gemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
   MG_LAUNCH_CHECK("linear_fwd");
   return MGGAN_OK;
 }
@@ -628,7 +628,7 @@ int mggan_act_bwd(const float* dY, int lddy, const float* Y, int ldy, float* dZ,
   MG_CHECK_ARG(dY && Y && dZ, "act_bwd: null pointer");
   long n = (long)rows * N;
   if (n == 0) return MGGAN_OK;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, dY, lddy, Y, ldy, dZ, lddz, rows, N, act,
+  MG_LAUNCH(act_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, dY, lddy, Y, ldy, dZ, lddz, rows, N, act,
                      slope);
   MG_LAUNCH_CHECK("act_bwd");
   return MGGAN_OK;
@@ -646,9 +646,9 @@ int mggan_linear_bwd_data(const float* dZ, int lddz, const float* W, int ldw, fl
   dim3 grid(cdiv(K, BN), cdiv(rows, BM), 1);
   if (Yact && act != ACT_NONE) {
     g.Yact = Yact; g.ld_yact = ld_yact; g.act_a = act; g.slope_a = slope;
-    hipLaunchKernelGGL((gemm_kernel<false, true, true>), grid, dim3(256), 0, stream, g);
+    MG_LAUNCH((gemm_kernel<false, true, true>), grid, dim3(256), 0, stream, g);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, stream, g);
+    MG_LAUNCH((gemm_kernel<false, true>), grid, dim3(256), 0, stream, g);
   }
   MG_LAUNCH_CHECK("linear_bwd_data");
   return MGGAN_OK;
@@ -712,7 +712,7 @@ int mggan_grad_reduce_multi(const void* descs, int n, hipStream_t stream) {
       bt.d[i].has_bias = (bt.d[i].has_bias & 3) | (tall ? 4 : 0);
       blocks += cdiv(total, tall ? 64 : 256) * bt.d[i].groups;
     }
-    hipLaunchKernelGGL(grad_reduce_multi_kernel, dim3(blocks), dim3(64 * MG_RED_WAVES), 0, stream, bt);
+    MG_LAUNCH(grad_reduce_multi_kernel, dim3(blocks), dim3(64 * MG_RED_WAVES), 0, stream, bt);
     MG_LAUNCH_CHECK("grad_reduce_multi");
   }
   return MGGAN_OK;
@@ -750,13 +750,13 @@ int mggan_wgrad(const float* dZ, int lddz, const float* X, int ldx, float* dW, i
     sb.p[0] = stream_problem(dZ, X, (float*)workspace, rows, K, N, lddz, ldx, feature_major);
     sb.p[0].blk0 = 0;
     launch_stream(sb, splits * sb.p[0].pm * sb.p[0].pk, sb.p[0].mode, stream);
-  } else if (feature_major) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
-  else if (g.Yact) hipLaunchKernelGGL((gemm_kernel<true, true, true>), grid, dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
+  } else if (feature_major) MG_LAUNCH((gemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  else if (g.Yact) MG_LAUNCH((gemm_kernel<true, true, true>), grid, dim3(256), 0, stream, g);
+  else MG_LAUNCH((gemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
   MG_LAUNCH_CHECK("wgrad");
   if (!dW) return MGGAN_OK;  // deferred: the caller reduces the partials later (mggan_grad_reduce_multi)
   dim3 rgrid(cdiv((long)N * Naug, 64), ng, 1);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(1024), 0, stream, (const float*)workspace, dW, db, N, Naug, 1,
+  MG_LAUNCH(wgrad_reduce_kernel, rgrid, dim3(1024), 0, stream, (const float*)workspace, dW, db, N, Naug, 1,
                      lddw, splits, w_stride, b_stride);
   MG_LAUNCH_CHECK("wgrad_reduce");
   return MGGAN_OK;
@@ -803,8 +803,8 @@ int mggan_wgrad_multi(const void* descs, int n, hipStream_t stream) {
     int blocks = 0;
     auto launch = [&]() {
       if (bt.n == 0) return;
-      if (fm) hipLaunchKernelGGL((gemm_multi_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, bt);
-      else hipLaunchKernelGGL((gemm_multi_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, bt);
+      if (fm) MG_LAUNCH((gemm_multi_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, bt);
+      else MG_LAUNCH((gemm_multi_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, bt);
       bt.n = 0;
       blocks = 0;
     };

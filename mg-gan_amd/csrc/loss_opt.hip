@@ -890,7 +890,7 @@ int mggan_sample_categorical(int b, int K, int g, const float* logits, const flo
                              hipStream_t stream) {
   if (b == 0) return MGGAN_OK;
   MG_CHECK_ARG(logits && u && idx && g >= 1 && g <= BR_MAXG, "sample_categorical: bad arguments (num_gens <= 16)");
-  hipLaunchKernelGGL(sample_categorical_kernel, dim3(cdiv((long)b * K, 256)), dim3(256), 0, stream, b, K, g, logits, u, idx);
+  MG_LAUNCH(sample_categorical_kernel, dim3(cdiv((long)b * K, 256)), dim3(256), 0, stream, b, K, g, logits, u, idx);
   MG_LAUNCH_CHECK("sample_categorical");
   return MGGAN_OK;
 }
@@ -983,7 +983,7 @@ int mggan_sample_bucket_rows(int b, int K, int g, const float* logits, const flo
                "sample_bucket_rows: null pointer");
   const int R = (int)Rl;
   if (R <= SB_SMALL) {
-    hipLaunchKernelGGL(sample_bucket_small_kernel, dim3(1), dim3(BR_BLOCK), 0, stream, b, K, g, logits, u, idx, row_gen_pos,
+    MG_LAUNCH(sample_bucket_small_kernel, dim3(1), dim3(BR_BLOCK), 0, stream, b, K, g, logits, u, idx, row_gen_pos,
                        inv, seg, row_gen, row_ped, row_slot, row_pos);
     MG_LAUNCH_CHECK("sample_bucket_rows");
     return MGGAN_OK;
@@ -995,11 +995,16 @@ int mggan_sample_bucket_rows(int b, int K, int g, const float* logits, const flo
     return mggan_bucket_rows(idx, b, K, g, row_gen, row_ped, row_slot, row_pos, inv, seg, row_gen_pos, blk_cnt, stream);
   }
   const int nblk = cdiv(R, BR_BLOCK);
+  // the scan kernel keeps the block counts in dynamic LDS (nblk * BR_MAXG ints) beside a few static words: above what fits
+  // into 64 KB the five-launch path takes over (decided BEFORE anything is written)
+  if ((size_t)nblk * BR_MAXG * sizeof(int) > 64 * 1024 - 256) {
+    if (int rc = mggan_sample_categorical(b, K, g, logits, u, idx, stream)) return rc;
+    return mggan_bucket_rows(idx, b, K, g, row_gen, row_ped, row_slot, row_pos, inv, seg, row_gen_pos, blk_cnt, stream);
+  }
   MG_CHECK_HIP(hipMemsetAsync(blk_cnt, 0, sizeof(int) * (size_t)nblk * BR_MAXG, stream), "sample_bucket_rows: memset");
-  MG_CHECK_ARG(nblk <= 1024, "sample_bucket_rows: %d rows exceed the count image (1,048,576)", R);
-  hipLaunchKernelGGL(sample_slots_scan_kernel, dim3(cdiv(b, 256)), dim3(256), sizeof(int) * (size_t)nblk * BR_MAXG, stream, b, K, g,
+  MG_LAUNCH(sample_slots_scan_kernel, dim3(cdiv(b, 256)), dim3(256), sizeof(int) * (size_t)nblk * BR_MAXG, stream, b, K, g,
                      logits, u, idx, row_gen_pos, inv, blk_cnt, nblk, seg, ticket);
-  hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, b, g, blk_cnt, seg, row_gen,
+  MG_LAUNCH(bucket_scatter_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, b, g, blk_cnt, seg, row_gen,
                      row_ped, row_slot, row_pos, inv);
   MG_LAUNCH_CHECK("sample_bucket_rows");
   return MGGAN_OK;
@@ -1013,15 +1018,15 @@ int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, i
   const int R = b * K, nblk = cdiv(R, BR_BLOCK);
   if (R == 0) return MGGAN_OK;
   if (R <= 4 * BR_BLOCK) {
-    hipLaunchKernelGGL(bucket_small_kernel, dim3(1), dim3(BR_BLOCK), 0, stream, idx, b, K, g, row_gen_pos, inv, seg,
+    MG_LAUNCH(bucket_small_kernel, dim3(1), dim3(BR_BLOCK), 0, stream, idx, b, K, g, row_gen_pos, inv, seg,
                        row_gen, row_ped, row_slot, row_pos);
     MG_LAUNCH_CHECK("bucket_rows");
     return MGGAN_OK;
   }
-  hipLaunchKernelGGL(bucket_slots_kernel, dim3(cdiv(b, 256)), dim3(256), 0, stream, idx, b, K, row_gen_pos, inv);
-  hipLaunchKernelGGL(bucket_count_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, g, blk_cnt);
-  hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(64), 0, stream, nblk, g, blk_cnt, seg);
-  hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, b, g, blk_cnt, seg,
+  MG_LAUNCH(bucket_slots_kernel, dim3(cdiv(b, 256)), dim3(256), 0, stream, idx, b, K, row_gen_pos, inv);
+  MG_LAUNCH(bucket_count_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, g, blk_cnt);
+  MG_LAUNCH(bucket_scan_kernel, dim3(1), dim3(64), 0, stream, nblk, g, blk_cnt, seg);
+  MG_LAUNCH(bucket_scatter_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, b, g, blk_cnt, seg,
                      row_gen, row_ped, row_slot, row_pos, inv);
   MG_LAUNCH_CHECK("bucket_rows");
   return MGGAN_OK;
@@ -1033,7 +1038,7 @@ int mggan_bce_rows(int rows, int kind, const float* p, float label, const float*
   if (rows == 0) return MGGAN_OK;
   MG_CHECK_ARG(p && loss_rows && ((row_gen == nullptr) == (inv_count == nullptr)) && (kind == 0 || kind == 1),
                "bce_rows: bad arguments");
-  hipLaunchKernelGGL(bce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rows, kind, p, label, label_u, label_lo,
+  MG_LAUNCH(bce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rows, kind, p, label, label_u, label_lo,
                      label_hi, scale, row_gen, inv_count, loss_rows, dp);
   MG_LAUNCH_CHECK("bce_rows");
   return MGGAN_OK;
@@ -1054,7 +1059,7 @@ int mggan_gan_losses(const void* args, hipStream_t stream) {
   // ticket round trip of a second workgroup (partial sums out, atomic, partial sums back) costs more than the rows
   int wgs = rows <= 4096 ? 1 : cdiv(rows, 1024);
   wgs = wgs < 1 ? 1 : (wgs > GAN_LOSS_MAX_WG ? GAN_LOSS_MAX_WG : wgs);
-  hipLaunchKernelGGL(gan_losses_kernel, dim3(wgs), dim3(1024), 0, stream, a);
+  MG_LAUNCH(gan_losses_kernel, dim3(wgs), dim3(1024), 0, stream, a);
   MG_LAUNCH_CHECK("gan_losses");
   return MGGAN_OK;
 }
@@ -1064,7 +1069,7 @@ int mggan_steps_to_rows(const float* a, const float* b, int T, int n, float* out
   const int rows = b ? 2 * n : n;
   if ((long)rows * T == 0) return MGGAN_OK;
   MG_CHECK_ARG(a && out, "steps_to_rows: null pointer");
-  hipLaunchKernelGGL(steps_to_rows_kernel, dim3(cdiv((long)rows * T, 256)), dim3(256), 0, stream, a, b, T, n, rows, out);
+  MG_LAUNCH(steps_to_rows_kernel, dim3(cdiv((long)rows * T, 256)), dim3(256), 0, stream, a, b, T, n, rows, out);
   MG_LAUNCH_CHECK("steps_to_rows");
   return MGGAN_OK;
 }
@@ -1074,7 +1079,7 @@ int mggan_steps_to_rows_n(const float* a, int T, int n, int rows, float* out, hi
   MG_CHECK_ARG(T >= 0 && n >= 0 && rows >= 0 && rows <= n, "steps_to_rows_n: bad sizes (%d of %d rows)", rows, n);
   if ((long)rows * T == 0) return MGGAN_OK;
   MG_CHECK_ARG(a && out, "steps_to_rows_n: null pointer");
-  hipLaunchKernelGGL(steps_to_rows_kernel, dim3(cdiv((long)rows * T, 256)), dim3(256), 0, stream, a, (const float*)nullptr, T, n, rows, out);
+  MG_LAUNCH(steps_to_rows_kernel, dim3(cdiv((long)rows * T, 256)), dim3(256), 0, stream, a, (const float*)nullptr, T, n, rows, out);
   MG_LAUNCH_CHECK("steps_to_rows_n");
   return MGGAN_OK;
 }
@@ -1082,7 +1087,7 @@ int mggan_steps_to_rows_n(const float* a, int T, int n, int rows, float* out, hi
 int mggan_scale(float* x, long n, const float* scalar, hipStream_t stream) {
   if (n == 0) return MGGAN_OK;
   MG_CHECK_ARG(x && scalar, "scale: null pointer");
-  hipLaunchKernelGGL(scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, n, scalar);
+  MG_LAUNCH(scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, n, scalar);
   MG_LAUNCH_CHECK("scale");
   return MGGAN_OK;
 }
@@ -1093,7 +1098,7 @@ int mggan_d_assemble_fwd(int b, int K, int w_soc, int w_in, int w_pred, int w_sc
   MG_CHECK_ARG(soc0 && in_enc && pred_enc && scene && X, "d_assemble_fwd: null pointer");
   const long n = (long)K * b * (w_soc + w_in + w_pred + w_scene);
   if (n == 0) return MGGAN_OK;
-  hipLaunchKernelGGL(d_assemble_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, w_soc, w_in, w_pred, w_scene,
+  MG_LAUNCH(d_assemble_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, w_soc, w_in, w_pred, w_scene,
                      soc_all, soc0, in_enc, pred_enc, scene, X);
   MG_LAUNCH_CHECK("d_assemble_fwd");
   return MGGAN_OK;
@@ -1104,7 +1109,7 @@ int mggan_d_assemble_bwd(int b, int K, int w_soc, int w_in, int w_pred, int w_sc
   MG_CHECK_ARG(dX, "d_assemble_bwd: null pointer");
   const long n = (long)b * (w_soc + w_in + w_pred + w_scene);
   if (n == 0) return MGGAN_OK;
-  hipLaunchKernelGGL(d_assemble_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, w_soc, w_in, w_pred, w_scene,
+  MG_LAUNCH(d_assemble_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, b, K, w_soc, w_in, w_pred, w_scene,
                      soc_all, dX, dsoc0, din_enc, dpred_enc, dscene);
   MG_LAUNCH_CHECK("d_assemble_bwd");
   return MGGAN_OK;
@@ -1114,7 +1119,7 @@ int mggan_ce_rows(int rows, int g, const float* logits, int ld, const int* targe
                   float* loss_rows, float* dlogits, int ldd, hipStream_t stream) {
   if (rows == 0) return MGGAN_OK;
   MG_CHECK_ARG(logits && target && loss_rows && g > 0, "ce_rows: bad arguments");
-  hipLaunchKernelGGL(ce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rows, g, logits, ld, target,
+  MG_LAUNCH(ce_rows_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, rows, g, logits, ld, target,
                      inv_count, scale, loss_rows, dlogits, ldd);
   MG_LAUNCH_CHECK("ce_rows");
   return MGGAN_OK;
@@ -1126,11 +1131,11 @@ int mggan_l2_min_scene(int S, int T, int K, int b, const int* scenes, const int*
   if (S == 0) return MGGAN_OK;
   MG_CHECK_ARG(scenes && ped_scene && gen_abs && gt && scene_loss && scene_arg, "l2_min_scene: null pointer");
   MG_CHECK_ARG(K <= L2_MAXK, "l2_min_scene: %d samples per pedestrian not built (<= %d)", K, L2_MAXK);
-  hipLaunchKernelGGL(l2_scene_kernel, dim3(S), dim3(256), 0, stream, S, T, K, b, scenes, gen_abs, gt, scene_loss,
+  MG_LAUNCH(l2_scene_kernel, dim3(S), dim3(256), 0, stream, S, T, K, b, scenes, gen_abs, gt, scene_loss,
                      scene_arg, dims);
   MG_LAUNCH_CHECK("l2_scene");
   if (gabs) {
-    hipLaunchKernelGGL(l2_grad_kernel, dim3(cdiv((long)T * K * b, 256)), dim3(256), 0, stream, T, K, b, ped_scene,
+    MG_LAUNCH(l2_grad_kernel, dim3(cdiv((long)T * K * b, 256)), dim3(256), 0, stream, T, K, b, ped_scene,
                        scene_arg, gen_abs, gt, grad_scale, gabs, dims);
     MG_LAUNCH_CHECK("l2_grad");
   }
@@ -1144,7 +1149,7 @@ int mggan_pm_ml_loss(int b, int T, int E, int g, const float* gen_abs, const flo
   int G2 = 1;
   while (G2 < g) G2 *= 2;
   const int per = 256 / G2;
-  hipLaunchKernelGGL(pm_ml_kernel, dim3(cdiv(b, per)), dim3(256), 0, stream, b, T, E, g, G2, gen_abs, gt, logits, sigma,
+  MG_LAUNCH(pm_ml_kernel, dim3(cdiv(b, per)), dim3(256), 0, stream, b, T, E, g, G2, gen_abs, gt, logits, sigma,
                      scale, loss_rows, dlogits, probs, (double*)nullptr, (unsigned*)nullptr, (float*)nullptr,
                      (float*)nullptr, 0.f, (const int*)nullptr);
   MG_LAUNCH_CHECK("pm_ml_loss");
@@ -1167,7 +1172,7 @@ int mggan_pm_ml_loss_mean(int b, int T, int E, int g, const float* gen_abs, cons
   const int per = 256 / G2;
   int wgs = cdiv(b, per);
   if (wgs > PM_MAX_WG) wgs = PM_MAX_WG;
-  hipLaunchKernelGGL(pm_ml_kernel, dim3(wgs), dim3(256), 0, stream, b, T, E, g, G2, gen_abs, gt, logits, sigma, scale,
+  MG_LAUNCH(pm_ml_kernel, dim3(wgs), dim3(256), 0, stream, b, T, E, g, G2, gen_abs, gt, logits, sigma, scale,
                      loss_rows, dlogits, probs, partial, ticket, out, probs_out, probs_scale, dims);
   MG_LAUNCH_CHECK("pm_ml_loss_mean");
   return MGGAN_OK;
@@ -1177,7 +1182,7 @@ int mggan_pm_mgan_loss(int b, int g, const float* logits, float target_weight, f
                        float* dlogits, float* probs, hipStream_t stream) {
   if (b == 0) return MGGAN_OK;
   MG_CHECK_ARG(logits && loss_rows && dlogits && g > 0, "pm_mgan_loss: bad arguments");
-  hipLaunchKernelGGL(pm_mgan_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, g, logits, target_weight, reg, scale,
+  MG_LAUNCH(pm_mgan_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, g, logits, target_weight, reg, scale,
                      loss_rows, dlogits, probs);
   MG_LAUNCH_CHECK("pm_mgan_loss");
   return MGGAN_OK;
@@ -1187,21 +1192,21 @@ int mggan_pm_target(int b, int T, int E, int g, int mode, const float* gen_abs, 
                     hipStream_t stream) {
   if (b == 0) return MGGAN_OK;
   MG_CHECK_ARG(gen_abs && gt && target && (mode == 0 || mode == 1), "pm_target: bad arguments");
-  hipLaunchKernelGGL(pm_target_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, T, E, g, mode, gen_abs, gt, target);
+  MG_LAUNCH(pm_target_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, T, E, g, mode, gen_abs, gt, target);
   MG_LAUNCH_CHECK("pm_target");
   return MGGAN_OK;
 }
 
 int mggan_sum(const float* x, long n, float alpha, float* out, int accumulate, hipStream_t stream) {
   MG_CHECK_ARG(out && (x || n == 0), "sum: null pointer");
-  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, stream, x, n, alpha, out, accumulate);
+  MG_LAUNCH(sum_kernel, dim3(1), dim3(1024), 0, stream, x, n, alpha, out, accumulate);
   MG_LAUNCH_CHECK("sum");
   return MGGAN_OK;
 }
 
 int mggan_colmean(const float* x, int rows, int g, float scale, float* out, hipStream_t stream) {
   MG_CHECK_ARG(x && out && rows > 0 && g > 0, "colmean: bad arguments");
-  hipLaunchKernelGGL(colmean_kernel, dim3(g), dim3(256), 0, stream, x, rows, g, scale, out);
+  MG_LAUNCH(colmean_kernel, dim3(g), dim3(256), 0, stream, x, rows, g, scale, out);
   MG_LAUNCH_CHECK("colmean");
   return MGGAN_OK;
 }
@@ -1212,16 +1217,16 @@ int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count
   MG_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int) * g, stream), "gen_counts: memset");
   if (n > 0) {
     int blocks = cdiv(n, 2048);
-    hipLaunchKernelGGL(count_kernel, dim3(blocks > 64 ? 64 : blocks), dim3(256), 0, stream, idx, n, g, counts, dims, bmod);
+    MG_LAUNCH(count_kernel, dim3(blocks > 64 ? 64 : blocks), dim3(256), 0, stream, idx, n, g, counts, dims, bmod);
   }
-  hipLaunchKernelGGL(inv_count_kernel, dim3(1), dim3(256), 0, stream, counts, g, inv_count);
+  MG_LAUNCH(inv_count_kernel, dim3(1), dim3(256), 0, stream, counts, g, inv_count);
   MG_LAUNCH_CHECK("gen_counts");
   return MGGAN_OK;
 }
 
 int mggan_inv_counts(const int* counts, int g, float* inv_count, hipStream_t stream) {
   MG_CHECK_ARG(counts && inv_count && g <= 256, "inv_counts: bad arguments");
-  hipLaunchKernelGGL(inv_count_kernel, dim3(1), dim3(256), 0, stream, counts, g, inv_count);
+  MG_LAUNCH(inv_count_kernel, dim3(1), dim3(256), 0, stream, counts, g, inv_count);
   MG_LAUNCH_CHECK("inv_counts");
   return MGGAN_OK;
 }
@@ -1233,11 +1238,11 @@ int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, cons
                      float* norm_out, hipStream_t stream) {
   MG_CHECK_ARG(param && grad && m && v && elem_seg && active && seg_step && workspace, "clip_adamw: null pointer");
   if (n == 0) return MGGAN_OK;
-  hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, grad, n, elem_seg, active,
+  MG_LAUNCH(gradnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, grad, n, elem_seg, active,
                      workspace, nseg, seg_step);
   int blocks = cdiv(n, 256 * 4);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, m, v, n, elem_seg, active, seg_step,
+  MG_LAUNCH(adamw_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, m, v, n, elem_seg, active, seg_step,
                      workspace, max_norm, lr, lr_dev, beta1, beta2, eps, weight_decay, zero_grad, norm_out);
   MG_LAUNCH_CHECK("clip_adamw");
   return MGGAN_OK;

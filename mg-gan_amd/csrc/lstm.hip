@@ -1776,7 +1776,7 @@ int mggan_lstm_fold(const float* W_emb, const float* b_emb, const float* W_ih, c
   MG_CHECK_ARG(!dec || (W1 && b1 && W2 && b2), "lstm_fold: decoder head pointers missing");
   MG_CHECK_ARG(prep_stride >= prep_size(H, S, dec), "lstm_fold: prep stride too small");
   FoldArgs a = {W_emb, b_emb, W_ih, b_ih, b_hh, W_hh, W1, b1, W2, b2, param_stride, prep, prep_stride, H, E, S, dec};
-  hipLaunchKernelGGL(lstm_fold_kernel, dim3(n_groups, 8), dim3(256), 0, stream, a);
+  MG_LAUNCH(lstm_fold_kernel, dim3(n_groups, 8), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("lstm_fold");
   return MGGAN_OK;
 }
@@ -1787,7 +1787,7 @@ int mggan_lstm_unfold_grads(const float* W_emb, const float* b_emb, const float*
   MG_CHECK_ARG(W_emb && b_emb && W_ih && dW_emb && db_emb && dW_ih && db_ih && db_hh && dprep,
                "lstm_unfold_grads: null pointer");
   UnfoldArgs a = {W_emb, b_emb, W_ih, dW_emb, db_emb, dW_ih, db_ih, db_hh, param_stride, dprep, dprep_stride, H, E};
-  hipLaunchKernelGGL(lstm_unfold_kernel, dim3(n_groups, 12), dim3(256), 0, stream, a);
+  MG_LAUNCH(lstm_unfold_kernel, dim3(n_groups, 12), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("lstm_unfold_grads");
   return MGGAN_OK;
 }
@@ -1806,11 +1806,11 @@ int mggan_lstm_encoder_fwd(const float* x, int T, int b, int H, const float* pre
   static int valu = -1;  // MGGAN_LSTM_VALU=1: the lane-per-(row, unit) VALU kernel (A/B measurements)
   if (valu < 0) { const char* e = getenv("MGGAN_LSTM_VALU"); valu = e && e[0] == '1'; }
   if (valu) {
-    if (H == 32) hipLaunchKernelGGL((lstm_fwd_kernel<32>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((lstm_fwd_kernel<64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
+    if (H == 32) MG_LAUNCH((lstm_fwd_kernel<32>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
+    else MG_LAUNCH((lstm_fwd_kernel<64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
   } else {
-    if (H == 32) hipLaunchKernelGGL((lstm_fwd_mfma_kernel<32>), dim3(cdiv(b, 16)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((lstm_fwd_mfma_kernel<64>), dim3(cdiv(b, 16)), dim3(256), 0, stream, p);
+    if (H == 32) MG_LAUNCH((lstm_fwd_mfma_kernel<32>), dim3(cdiv(b, 16)), dim3(256), 0, stream, p);
+    else MG_LAUNCH((lstm_fwd_mfma_kernel<64>), dim3(cdiv(b, 16)), dim3(256), 0, stream, p);
   }
   MG_LAUNCH_CHECK("lstm_encoder_fwd");
   return MGGAN_OK;
@@ -1833,11 +1833,11 @@ int mggan_lstm_encoder_bwd(const float* dhT, int ld_dhT, int T, int b, int H, co
   static int min_b = -1;
   if (min_b < 0) { const char* e = getenv("MGGAN_LSTM_MFMA_MIN_B"); min_b = e ? atoi(e) : 4096; }
   if (valu || !vec || b < min_b) {
-    if (H == 32) hipLaunchKernelGGL((lstm_bwd_kernel<32, 0>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((lstm_bwd_kernel<64, 64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
+    if (H == 32) MG_LAUNCH((lstm_bwd_kernel<32, 0>), dim3(cdiv(b, 8)), dim3(256), 0, stream, p);
+    else MG_LAUNCH((lstm_bwd_kernel<64, 64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, p);
   } else {
-    if (H == 32) hipLaunchKernelGGL((lstm_bwd_mfma_kernel<32>), dim3(cdiv(b, 32)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((lstm_bwd_mfma_kernel<64>), dim3(cdiv(b, 16)), dim3(256), 0, stream, p);
+    if (H == 32) MG_LAUNCH((lstm_bwd_mfma_kernel<32>), dim3(cdiv(b, 32)), dim3(256), 0, stream, p);
+    else MG_LAUNCH((lstm_bwd_mfma_kernel<64>), dim3(cdiv(b, 16)), dim3(256), 0, stream, p);
   }
   MG_LAUNCH_CHECK("lstm_encoder_bwd");
   return MGGAN_OK;
@@ -1852,7 +1852,7 @@ int mggan_decoder_e2d_shared(const float* enc_h, int ld_enc, int b, int EIN, con
   MG_CHECK_ARG(EIN > 0 && EIN % 16 == 0 && ld_enc % 4 == 0 && ldw % 4 == 0 && ldw >= EIN && (((size_t)enc_h) & 15) == 0 &&
                    (((size_t)We2d) & 15) == 0 && (((size_t)Q) & 15) == 0,
                "decoder_e2d_shared: bad layout (EIN %d, ld_enc %d, ldw %d)", EIN, ld_enc, ldw);
-  hipLaunchKernelGGL(e2d_shared_kernel, dim3(cdiv(cdiv(b, 16), 4)), dim3(256), 0, stream, enc_h, ld_enc, b, EIN, We2d, ldw, be2d, Q);
+  MG_LAUNCH(e2d_shared_kernel, dim3(cdiv(cdiv(b, 16), 4)), dim3(256), 0, stream, enc_h, ld_enc, b, EIN, We2d, ldw, be2d, Q);
   MG_LAUNCH_CHECK("decoder_e2d_shared");
   return MGGAN_OK;
 }
@@ -1899,13 +1899,13 @@ int mggan_decoder_rollout_fwd(int R, int T, int b, int H, int EIN, int Z, const 
   if (wave_min < 0) { const char* e = getenv("MGGAN_DEC_FWD_MIN"); wave_min = e ? atoi(e) : 16384; }
   const bool wave = force ? force == 1 : R >= wave_min;
   if (!wave) {
-    hipLaunchKernelGGL(decoder_fwd_mfma_kernel, dim3(n_gens * p.NW), dim3(256), 0, stream, p);
+    MG_LAUNCH(decoder_fwd_mfma_kernel, dim3(n_gens * p.NW), dim3(256), 0, stream, p);
   } else {
     // a wave per tile: four tiles per workgroup, the same persistent-grid rule in workgroups of four tiles
     const int per_gen4 = cdiv(cdiv(R, 16) + 1, 4);
     const int cap = 1024 / n_gens > 0 ? 1024 / n_gens : 1;
     p.NW = per_gen4 < 1 ? 1 : (per_gen4 > cap ? cap : per_gen4);
-    hipLaunchKernelGGL(decoder_fwd_wave_kernel, dim3(n_gens * p.NW), dim3(256), 0, stream, p);
+    MG_LAUNCH(decoder_fwd_wave_kernel, dim3(n_gens * p.NW), dim3(256), 0, stream, p);
   }
   MG_LAUNCH_CHECK("decoder_rollout_fwd");
   return MGGAN_OK;
@@ -1955,9 +1955,9 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
   if (pair) {
     const size_t dyn2 = sizeof(float) * ((dEnc ? (size_t)H * p.e2ld : 0) + (H / 2) * 36);
     MG_CHECK_ARG(dyn2 <= 64 * 1024, "decoder_rollout_bwd_fused: encoder width %d too large for the staged epilogue", EIN);
-    hipLaunchKernelGGL(decoder_bwd_pair_kernel, dim3(n_gens * NW), dim3(256), dyn2, stream, p);
+    MG_LAUNCH(decoder_bwd_pair_kernel, dim3(n_gens * NW), dim3(256), dyn2, stream, p);
   } else {
-    hipLaunchKernelGGL(decoder_bwd_mfma_kernel, dim3(n_gens * NW), dim3(256), dyn, stream, p);
+    MG_LAUNCH(decoder_bwd_mfma_kernel, dim3(n_gens * NW), dim3(256), dyn, stream, p);
   }
   MG_LAUNCH_CHECK("decoder_rollout_bwd_fused");
   return MGGAN_OK;
@@ -1968,7 +1968,7 @@ int mggan_gather_sum(const float* src, int ld_src, const int* inv, float* dst, i
   MG_CHECK_ARG(src && inv && dst, "gather_sum: null pointer");
   long n = (long)b * ncols;
   if (n == 0) return MGGAN_OK;
-  hipLaunchKernelGGL(gather_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, src, ld_src, inv, dst, ld_dst, b, K,
+  MG_LAUNCH(gather_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, src, ld_src, inv, dst, ld_dst, b, K,
                      ncols, accumulate);
   MG_LAUNCH_CHECK("gather_sum");
   return MGGAN_OK;
@@ -1980,7 +1980,7 @@ int mggan_rollout_ped_adjoint(const float* dH0, const float* dSocR, const int* i
   MG_CHECK_ARG(b >= 0 && K >= 1 && EIN >= 1 && S >= 0 && S <= 32 && S <= EIN && ldw >= EIN && ld_enc >= EIN,
                "rollout_ped_adjoint: bad sizes (b %d, K %d, EIN %d, S %d)", b, K, EIN, S);
   if (b == 0) return MGGAN_OK;
-  hipLaunchKernelGGL(rollout_ped_adjoint_kernel, dim3(cdiv(b, 8)), dim3(256), 0, stream, dH0, dSocR, inv, W_e2d, ldw, dQe, dEnc,
+  MG_LAUNCH(rollout_ped_adjoint_kernel, dim3(cdiv(b, 8)), dim3(256), 0, stream, dH0, dSocR, inv, W_e2d, ldw, dQe, dEnc,
                      ld_enc, b, K, EIN, S);
   MG_LAUNCH_CHECK("rollout_ped_adjoint");
   return MGGAN_OK;
@@ -1988,7 +1988,7 @@ int mggan_rollout_ped_adjoint(const float* dH0, const float* dSocR, const int* i
 
 int mggan_transpose(const float* W, float* WT, int N, int K, hipStream_t stream) {
   MG_CHECK_ARG(W && WT, "transpose: null pointer");
-  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv((long)N * K, 256)), dim3(256), 0, stream, W, WT, N, K);
+  MG_LAUNCH(transpose_kernel, dim3(cdiv((long)N * K, 256)), dim3(256), 0, stream, W, WT, N, K);
   MG_LAUNCH_CHECK("transpose");
   return MGGAN_OK;
 }

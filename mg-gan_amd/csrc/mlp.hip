@@ -215,7 +215,7 @@ int mggan_mlp_chain(const void* args, hipStream_t stream) {
   }
   MG_CHECK_ARG(a.s[a.n - 1].out, "mlp_chain: the last stage needs an output pointer");
   if (a.rows == 0) return MGGAN_OK;
-  hipLaunchKernelGGL(mlp_chain_kernel, dim3(cdiv(a.rows, MC_ROWS)), dim3(256), 0, stream, a);
+  MG_LAUNCH(mlp_chain_kernel, dim3(cdiv(a.rows, MC_ROWS)), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("mlp_chain");
   return MGGAN_OK;
 }

@@ -79,7 +79,7 @@ int mggan_pool_pairs_fwd(int P, const int* pair_i, const int* pair_j, const floa
   MG_CHECK_ARG(P >= 0 && E > 0 && H > 0 && xy_mod >= 0, "pool_pairs_fwd: bad sizes");
   if (P == 0) return MGGAN_OK;
   MG_CHECK_ARG(pair_i && pair_j && xy_last && We && be && h && X && rel, "pool_pairs_fwd: null pointer");
-  hipLaunchKernelGGL(pool_pairs_fwd_kernel, dim3(cdiv((long)P * (E + H), 256)), dim3(256), 0, stream, P, pair_i, pair_j,
+  MG_LAUNCH(pool_pairs_fwd_kernel, dim3(cdiv((long)P * (E + H), 256)), dim3(256), 0, stream, P, pair_i, pair_j,
                      xy_last, xy_mod, We, be, E, h, ld_h, H, X, rel);
   MG_LAUNCH_CHECK("pool_pairs_fwd");
   return MGGAN_OK;
@@ -89,7 +89,7 @@ int mggan_pool_gather_bwd(int b, int H, int E, const int* hid_ptr, const int* hi
                           int ld_dh, hipStream_t stream) {
   if ((long)b * H == 0) return MGGAN_OK;
   MG_CHECK_ARG(hid_ptr && hid_pairs && dX && dh, "pool_gather_bwd: null pointer");
-  hipLaunchKernelGGL(pool_gather_bwd_kernel, dim3(cdiv((long)b * H, 256)), dim3(256), 0, stream, b, H, E, hid_ptr,
+  MG_LAUNCH(pool_gather_bwd_kernel, dim3(cdiv((long)b * H, 256)), dim3(256), 0, stream, b, H, E, hid_ptr,
                      hid_pairs, dX, dh, ld_dh);
   MG_LAUNCH_CHECK("pool_gather_bwd");
   return MGGAN_OK;
@@ -99,7 +99,7 @@ int mggan_segment_max_fwd(int rows, int B, const int* ped_prow, const int* ped_n
                           hipStream_t stream) {
   if ((long)rows * B == 0) return MGGAN_OK;
   MG_CHECK_ARG(ped_prow && ped_n && Y && out && arg, "segment_max_fwd: null pointer");
-  hipLaunchKernelGGL(segment_max_fwd_kernel, dim3(cdiv((long)rows * B, 256)), dim3(256), 0, stream, rows, B, ped_prow,
+  MG_LAUNCH(segment_max_fwd_kernel, dim3(cdiv((long)rows * B, 256)), dim3(256), 0, stream, rows, B, ped_prow,
                      ped_n, Y, out, arg);
   MG_LAUNCH_CHECK("segment_max_fwd");
   return MGGAN_OK;
@@ -109,7 +109,7 @@ int mggan_segment_max_bwd(int P, int B, const int* pair_o, const int* ped_prow, 
                           const int* arg, float* dY, hipStream_t stream) {
   if ((long)P * B == 0) return MGGAN_OK;
   MG_CHECK_ARG(pair_o && ped_prow && dOut && arg && dY, "segment_max_bwd: null pointer");
-  hipLaunchKernelGGL(segment_max_bwd_kernel, dim3(cdiv((long)P * B, 256)), dim3(256), 0, stream, P, B, pair_o, ped_prow,
+  MG_LAUNCH(segment_max_bwd_kernel, dim3(cdiv((long)P * B, 256)), dim3(256), 0, stream, P, B, pair_o, ped_prow,
                      dOut, ld_dout, arg, dY);
   MG_LAUNCH_CHECK("segment_max_bwd");
   return MGGAN_OK;

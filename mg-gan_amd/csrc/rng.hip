@@ -91,7 +91,7 @@ extern "C" int mggan_draw_iteration(long long* state, unsigned int* ticket, int 
   MG_CHECK_ARG((n_labels == 0 || labels) && (n_unif == 0 || unif), "draw_iteration: null output");
   MG_CHECK_ARG(n_sets == 0 || b == 0 || (noise && ped_scene && Z > 0), "draw_iteration: noise needs ped_scene and Z > 0");
   const long n = (n_labels + 3) / 4 + (long)n_sets * b * ((Z + 3) / 4) + (n_unif + 3) / 4;
-  hipLaunchKernelGGL(draw_iteration_kernel, dim3(n > 0 ? cdiv(n, 256) : 1), dim3(256), 0, stream, state, ticket, n_labels,
+  MG_LAUNCH(draw_iteration_kernel, dim3(n > 0 ? cdiv(n, 256) : 1), dim3(256), 0, stream, state, ticket, n_labels,
                      labels, n_sets, b, Z, ped_scene, noise, n_unif, unif);
   MG_LAUNCH_CHECK("draw_iteration");
   return MGGAN_OK;

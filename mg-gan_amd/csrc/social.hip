@@ -246,7 +246,7 @@ extern "C" {
 
 int mggan_social_w3b(const float* W3, const float* b3, float* W3b, int F, hipStream_t stream) {
   MG_CHECK_ARG(W3 && b3 && W3b && F > 0, "social_w3b: bad arguments");
-  hipLaunchKernelGGL(social_w3b_kernel, dim3(cdiv(F * (L2 + 1), 256)), dim3(256), 0, stream, W3, b3, W3b, F);
+  MG_LAUNCH(social_w3b_kernel, dim3(cdiv(F * (L2 + 1), 256)), dim3(256), 0, stream, W3, b3, W3b, F);
   MG_LAUNCH_CHECK("social_w3b");
   return MGGAN_OK;
 }
@@ -260,7 +260,7 @@ int mggan_social_pairs_fwd(int P, const int* pair_i, const int* pair_j, const fl
                "social_pairs_fwd: null pointer");
   MG_CHECK_ARG((feat == nullptr) == (l1 == nullptr) && (l1 == nullptr) == (l2 == nullptr),
                "social_pairs_fwd: save buffers must be all set or all NULL");
-  hipLaunchKernelGGL(social_pairs_fwd_kernel, dim3(cdiv(P, 64)), dim3(256), 0, stream, P, pair_i, pair_j, xy_last,
+  MG_LAUNCH(social_pairs_fwd_kernel, dim3(cdiv(P, 64)), dim3(256), 0, stream, P, pair_i, pair_j, xy_last,
                      dxdy_last, W1, b1, W2, b2, vc, feat, l1, l2, sigma);
   MG_LAUNCH_CHECK("social_pairs_fwd");
   return MGGAN_OK;
@@ -268,8 +268,8 @@ int mggan_social_pairs_fwd(int P, const int* pair_i, const int* pair_j, const fl
 
 #define SOC_DISPATCH(KERNEL, H, ...)                                                                         \
   do {                                                                                                       \
-    if ((H) == 32) hipLaunchKernelGGL((KERNEL<32>), dim3(cdiv(b, 8)), dim3(256), 0, stream, __VA_ARGS__);    \
-    else hipLaunchKernelGGL((KERNEL<64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, __VA_ARGS__);              \
+    if ((H) == 32) MG_LAUNCH((KERNEL<32>), dim3(cdiv(b, 8)), dim3(256), 0, stream, __VA_ARGS__);    \
+    else MG_LAUNCH((KERNEL<64>), dim3(cdiv(b, 4)), dim3(256), 0, stream, __VA_ARGS__);              \
   } while (0)
 
 int mggan_social_softmax_fwd(int b, int H, const int* ped_prow, const int* ped_s0, const int* ped_n,
@@ -302,12 +302,12 @@ int mggan_social_pairs_bwd(int P, int b, const int* pair_j, const int* ped_prow,
   MG_CHECK_ARG(ped_prow && ped_s0 && ped_n && dvc, "social_pairs_bwd: null pointer");
   if (P > 0) {
     MG_CHECK_ARG(pair_j && dsigma && vc && l1 && l2 && W2 && dz2 && dz1, "social_pairs_bwd: null pointer");
-    hipLaunchKernelGGL(social_pairs_bwd_kernel, dim3(cdiv(P, 64)), dim3(256), 0, stream, P, pair_j, dsigma, vc, l1, l2,
+    MG_LAUNCH(social_pairs_bwd_kernel, dim3(cdiv(P, 64)), dim3(256), 0, stream, P, pair_j, dsigma, vc, l1, l2,
                        W2, dz2, dz1);
     MG_LAUNCH_CHECK("social_pairs_bwd");
   }
   if (b > 0) {
-    hipLaunchKernelGGL(social_dvc_kernel, dim3(cdiv((long)b * (L2 + 1), 256)), dim3(256), 0, stream, b, P, ped_prow,
+    MG_LAUNCH(social_dvc_kernel, dim3(cdiv((long)b * (L2 + 1), 256)), dim3(256), 0, stream, b, P, ped_prow,
                        ped_s0, ped_n, dsigma, l2, dvc);
     MG_LAUNCH_CHECK("social_dvc");
   }

@@ -920,7 +920,7 @@ int mggan_social_rows_partial_floats(void) { return SR_WG_FLOATS; }
 #endif
 #define SR_NWFW(NN) ((NN) == 4 ? 4 : SR_NWF)
 #define SR_FWD(HH, NN) \
-  hipLaunchKernelGGL((social_rows_fwd_kernel<HH, NN, SR_NWFW(NN)>), dim3(sr_grid(S, a.row_splits)), dim3(64 * SR_NWFW(NN)), 0, stream, a)
+  MG_LAUNCH((social_rows_fwd_kernel<HH, NN, SR_NWFW(NN)>), dim3(sr_grid(S, a.row_splits)), dim3(64 * SR_NWFW(NN)), 0, stream, a)
 #ifndef SR_KEEP2
 #define SR_KEEP2 1
 #endif
@@ -929,7 +929,7 @@ int mggan_social_rows_partial_floats(void) { return SR_WG_FLOATS; }
 #endif
 #define SR_NWB(NN, TT) ((TT) && (NN) == 2 ? SR_NW2 : SR_NW(NN))
 #define SR_BWD(HH, NN, TT, KK)                                                                                     \
-  hipLaunchKernelGGL((social_rows_bwd_kernel<HH, NN, SR_NWB(NN, TT), TT, KK>), dim3(sr_grid(S, a.row_splits)),     \
+  MG_LAUNCH((social_rows_bwd_kernel<HH, NN, SR_NWB(NN, TT), TT, KK>), dim3(sr_grid(S, a.row_splits)),     \
                      dim3(64 * SR_NWB(NN, TT)), 0, stream, a)
 
 int mggan_social_rows_fwd(int S, const int* scenes, int H, int F, int max_n, const float* xy_last, const float* dxdy_last,

@@ -183,6 +183,10 @@ class MultiGeneratorGAN(abc.ABC):
             self.defer_metrics = keep
             del self._pending[n_pending:]
             HF.reset_deferred()
+            # during a capture nothing executes, but every fold it RECORDED was booked as done: the buffers still hold the
+            # previous weight version.  The eager iteration that follows a failed capture must fold again.
+            HF.bump_weight_version(self.G)
+            HF.bump_weight_version(self.D)
             raise
         pending, self._pending = self._pending, []
         self.defer_metrics = keep
@@ -190,10 +194,24 @@ class MultiGeneratorGAN(abc.ABC):
         HF.bump_weight_version(self.G)
         HF.bump_weight_version(self.D)
 
+        # A steady-state graph folds a module's LSTM weights only BEHIND the optimizer step that changed them and reads, at its
+        # start, what the previous iteration left in the folded buffers.  True after the capture (nothing executed, the
+        # eager iteration before it left every fold current) and after every replay; anything else that writes weights
+        # in between -- an eager iteration, load_state_dict, a parameter broadcast -- shows in the fingerprint, and the
+        # replay re-folds the module's buffers first.
+        # (one fingerprint per trainer: the graphs of train()'s cache replay one after the other and each leaves the buffers
+        #  as the next one expects them)
+        fp = self._fold_fp = {"G": HF.weights_fingerprint(self.G), "D": HF.weights_fingerprint(self.D)}
+
         def replay(metrics=None, fetch=True):
+            fp = self._fold_fp
+            for tag, root in (("G", self.G), ("D", self.D)):
+                if HF.weights_fingerprint(root) != fp[tag]:
+                    HF.refold_root(root)
             run()
             HF.bump_weight_version(self.G)  # the optimizer steps inside the graph are invisible to the host
             HF.bump_weight_version(self.D)
+            fp["G"], fp["D"] = HF.weights_fingerprint(self.G), HF.weights_fingerprint(self.D)
             self.dist.check()  # host read: a peer-mapped collective of an earlier replay has timed out -> stop here
             if metrics is not None and fetch:
                 self._fetch([(metrics, items, snap) for _, items, snap in pending])
@@ -292,7 +310,7 @@ class MultiGeneratorGAN(abc.ABC):
         pad = getattr(cfg, "graph_pad", "auto")
         graphs = self.iteration_graphs = IterationGraphs(
             self, getattr(cfg, "graph_shapes", 8), pad=pad, bucket=getattr(cfg, "graph_bucket", "quarter"),
-            capture=self.graph_mode()) if (self.graph_mode() or pad == "on") else None
+            capture=self.graph_mode(), bucket_limit=getattr(cfg, "graph_buckets", 64)) if (self.graph_mode() or pad == "on") else None
         self.epoch_seconds, self.epoch_iterations = [], []  # wall time of the training loop of every epoch (bench.py)
         train_loader = get_dataloader(dataset=cfg.dataset, phase="train", augment=cfg.augment,
                                       batch_size=cfg.batch_size, workers=cfg.workers, shuffle=True, **kw)
@@ -324,7 +342,12 @@ class MultiGeneratorGAN(abc.ABC):
             if hasattr(self, "flush_metrics"):
                 self.flush_metrics()
             if graphs is not None:
+                r0, e0 = (graphs.history[-1][:2] if graphs.history else (0, 0))
                 graphs.flush(metrics)  # the epoch's replayed iterations: one D2H of their summed metric snapshots
+                if graphs.history and self.dist.rank == 0:
+                    r1, e1, n_g = graphs.history[-1]
+                    print("[mggan] epoch {}: {} of {} iterations replayed from {} graph(s)".format(
+                        self.epoch, r1 - r0, (r1 - r0) + (e1 - e0), n_g))
             torch.cuda.synchronize()
             self.epoch_seconds.append(time.perf_counter() - t_epoch)
             self.epoch_iterations.append(n_it)
@@ -457,8 +480,13 @@ class IterationGraphs:
         def __init__(self, static):
             self.static, self.replay, self.failed, self.tables = static, None, False, None
 
-    def __init__(self, trainer, limit=8, pad="auto", bucket="quarter", capture=True):
+    def __init__(self, trainer, limit=8, pad="auto", bucket="quarter", capture=True, bucket_limit=64):
         self.tr, self.limit, self.entries = trainer, int(limit), {}
+        # padded buckets have their own, larger limit: the reference loader's batches fall into a few dozen of them
+        # (pedestrian count in quarter-octave steps x scene slots x largest-scene class), where a limit of 8 kept the first
+        # eight buckets of a run and sent every other batch down the eager path for good
+        self.bucket_limit = int(bucket_limit)
+        self.history = []  # (replays, eager iterations, graphs) at every flush, i.e. once per epoch: the replay rate
         self.pad, self.bucket, self.capture = pad, bucket, bool(capture)
         self.pool = None  # the graphs' shared memory pool (created with the first capture)
         self._acc = {}  # id(snapshot buffer) -> [buffer, running sum, count, items]
@@ -567,7 +595,8 @@ class IterationGraphs:
         key = bucket[0] if bucket is not None else self.key_of(batch)
         ent = self.entries.get(key)
         if ent is None:
-            if len(self.entries) >= self.limit:
+            n_pad = sum(1 for e in self.entries.values() if e.tables is not None)
+            if (n_pad >= self.bucket_limit) if bucket is not None else (len(self.entries) - n_pad >= self.limit):
                 return False
             if bucket is not None:
                 ent = self.entries[key] = self._padded_entry(*bucket, batch)
@@ -614,23 +643,43 @@ class IterationGraphs:
 
     def flush(self, metrics):
         """The replayed iterations of the epoch enter `metrics` as their mean, once per iteration (the epoch's logged
-        value is the mean over its iterations, abstract_train.py:194)."""
+        value is the mean over its iterations, abstract_train.py:194).  Sharded runs: ONE host-side exchange per flush,
+        issued by every rank whatever it replayed (a rank whose batches all ran eagerly, or whose buckets were captured in
+        another order, must not issue fewer or differently ordered collectives than its peers): the per-metric (sum, count)
+        pairs travel as one object and are merged by metric name."""
         tr = self.tr
+        local = {}  # metric key -> [sum over this rank's replayed iterations, their number]
         for acc in self._acc.values():
             snap, total, count, item_lists = acc
             if count == 0:
                 continue
-            if tr.dist.enabled:  # the count travels with the sums: ranks may have replayed different numbers of iterations
-                red = tr.dist.all_reduce_(torch.cat([total.double(), total.new_tensor([count]).double()]))
-                v = (red[:-1] / red[-1].clamp(min=1) * tr.dist.world_size).cpu().numpy()
-            else:
-                v = (total / count).cpu().numpy()
+            v = total.double().cpu().numpy()
             for items in sorted(item_lists):
                 for key, slot in items:
-                    val = float(v[slot] if isinstance(slot, int) else v[slot[0]] + v[slot[1]])
-                    metrics[key].extend([val] * count)
+                    e = local.setdefault(key, [0.0, 0])
+                    e[0] += float(v[slot] if isinstance(slot, int) else v[slot[0]] + v[slot[1]])
+                    e[1] += count
             total.zero_()
             acc[2] = 0
+        merged = local
+        if tr.dist.enabled:
+            import torch.distributed as dist
+
+            parts = [None] * tr.dist.world_size
+            dist.all_gather_object(parts, local, group=tr.dist.group)
+            merged = {}
+            for part in parts:
+                for key, (s_, c_) in part.items():
+                    e = merged.setdefault(key, [0.0, 0])
+                    e[0] += s_
+                    e[1] += c_
+        for key in sorted(local):
+            s_, c_ = merged[key]
+            # (a logged loss of a sharded iteration is this rank's share of the global-batch mean: the ranks' values add up)
+            val = s_ / max(c_, 1) * tr.dist.world_size if tr.dist.enabled else s_ / max(c_, 1)
+            metrics[key].extend([val] * local[key][1])
+        if self.replays + self.eager:
+            self.history.append((self.replays, self.eager, len(self.entries)))
 
 
 def read_meta_tags(path):

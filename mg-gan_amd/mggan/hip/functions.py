@@ -737,7 +737,11 @@ def two_heads(x, layers_a, layers_b, row0=0):
 # a replay is only ever preceded by a complete iteration (the warm-up iteration of capture_iteration, or another replay);
 # a capture that follows a replay finds every entry stale and records more folds than needed, never fewer.
 # Outside the trainer (module calls in tests, predict) every forward folds, as before.
-_PREP = {"on": False, "entries": {}, "enabled": os.environ.get("MGGAN_PREP_CACHE", "1") != "0"}
+# An entry lives ON its owner module (attribute `_mggan_prep` = [key, buffer, fold]); `owners` only remembers, weakly,
+# which modules carry one: a trainer that goes away takes its folded-weight buffers with it.
+import weakref  # noqa: E402
+
+_PREP = {"on": False, "owners": weakref.WeakSet(), "enabled": os.environ.get("MGGAN_PREP_CACHE", "1") != "0"}
 
 
 def prep_cache(on):
@@ -747,7 +751,33 @@ def prep_cache(on):
 
 
 def clear_prep_cache():
-    _PREP["entries"].clear()
+    for owner in list(_PREP["owners"]):
+        if hasattr(owner, "_mggan_prep"):
+            object.__delattr__(owner, "_mggan_prep")
+    _PREP["owners"].clear()
+
+
+def weights_fingerprint(root):
+    """What the host can see of writes to the weights of `root`: the kernel-side version counter (optimizer steps, graph
+    replays: bump_weight_version) and torch's own version counters (load_state_dict, a parameter broadcast, any in-place
+    torch op)."""
+    return (getattr(root, "_kernel_version", 0),) + tuple(p._version for p in root.parameters())
+
+
+def refold_root(root):
+    """Re-fold, in place and on the current stream, every cached folded-weight buffer of the modules under `root`.  A graph
+    replay reads those buffers as the PREVIOUS iteration left them (a steady-state graph folds a module's weights only behind
+    the optimizer step that changed them); anything else that wrote the weights since -- an eager iteration, a loaded
+    checkpoint, a broadcast -- is caught by the trainer (weights_fingerprint) and answered with this before the replay."""
+    n = 0
+    for owner in list(_PREP["owners"]):
+        ent = getattr(owner, "_mggan_prep", None)
+        if ent is None or getattr(owner, "_flat_root", owner) is not root:
+            continue
+        ent[2](ent[1])
+        ent[0] = None  # (the key no longer describes the contents for the host-side cache: the next eager use folds again)
+        n += 1
+    return n
 
 
 def bump_weight_version(root, touched=None):
@@ -781,15 +811,17 @@ def _prep_for(owner, tensors, psz_total, like, fold):
     at = getattr(root, "_written_at", None) or {}
     written = max([getattr(root, "_all_written_at", 0)] + [at.get(id(t), 0) for t in tensors])
     key = (written,) + tuple((t.data_ptr(), t._version) for t in tensors)
-    ent = _PREP["entries"].get(id(owner))
+    ent = getattr(owner, "_mggan_prep", None)
     if ent is not None and ent[1].numel() == psz_total and ent[1].device == like.device:
         if ent[0] != key:
             fold(ent[1])
-            _PREP["entries"][id(owner)] = (key, ent[1], owner)
+            ent[0] = key
+        ent[2] = fold  # (the closure of the latest use: same weights, same buffer, the current stream at call time)
         return ent[1]
     prep = torch.empty(psz_total, dtype=F32, device=like.device)
     fold(prep)
-    _PREP["entries"][id(owner)] = (key, prep, owner)
+    object.__setattr__(owner, "_mggan_prep", [key, prep, fold])
+    _PREP["owners"].add(owner)
     return prep
 
 
@@ -1555,20 +1587,25 @@ class SceneAttentionFn(Function):
         cnt2 = float(B) * 16 * 16 if fused else finalize_unfused(bn2, g2, be2, 16 * 16, b2)
         sc2, sh2, stat2 = b2
         out, ld_o = _out(out_slot, B, 64, img)
-        lib.mggan_scene_attention_fwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(wa), _p(ba), _p(wb), _p(bb), _p(out), ld_o, pd, st)
+        # what the adjoint needs of the conv2 output per pooled cell: the raw value that won the 2x2 window and its position
+        # (cell-major, channel innermost: (B, 64, C))
+        ysel = _empty(B, 64, C, like=img) if save else None
+        ycode = torch.empty(B, 64, C, dtype=torch.uint8, device=dev) if save else None
+        lib.mggan_scene_attention_fwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(wa), _p(ba), _p(wb), _p(bb), _p(out), ld_o,
+                                      _p(ysel), _p(ycode), pd, st)
         if save:
             if not training:
                 raise RuntimeError("scene attention backward is only implemented for train-mode BatchNorm "
                                    "(the reference never differentiates in eval mode)")
             ctx.owner, ctx.sync, ctx.counts, ctx.dims = owner, sync, (cnt1, cnt2), dims
             ctx.save_for_backward(img, xsel, code, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b,
-                                  g2, be2, wa, ba, wb, bb)
+                                  g2, be2, wa, ba, wb, bb, ysel, ycode)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (img, xsel, code, y2, sc1, sh1, stat1, sc2, sh2, stat2, c1w, c1b, g1, be1, c2w, c2b, g2, be2, wa, ba, wb,
-         bb) = ctx.saved_tensors
+         bb, ysel, ycode) = ctx.saved_tensors
         root, sync = root_of(ctx.owner), ctx.sync
         cnt1, cnt2 = ctx.counts
         B, C = img.shape[0], c1w.shape[0]
@@ -1578,14 +1615,14 @@ class SceneAttentionFn(Function):
         fused = sync is None
         pd = _pad_ptr(ctx.dims) if ctx.dims is not None else 0
         dout, ld = _rows2d(dout)
-        G2 = _empty(B, C, 16, 16, like=img)
+        G2 = _empty(B, 64, C, like=img)  # one value per pooled cell and channel (its window position: ycode)
         rows2 = max(lib.mggan_scene_attention_grid(B), 1)
         part2 = torch.empty(rows2, 2 * C, dtype=torch.float64, device=dev)
         coef2 = _empty(3 * C, like=img)
         # the attention head's weight gradients come out of the same launch: one partial block per workgroup
         pf = lib.mggan_scene_attention_partial_floats(C)
         wpart = _empty(rows2 * pf, like=img)
-        lib.mggan_scene_attention_bwd(_p(y2), B, C, _p(sc2), _p(sh2), _p(stat2), _p(wa), _p(ba), _p(wb), _p(bb), _p(dout),
+        lib.mggan_scene_attention_bwd(_p(ysel), _p(ycode), B, C, _p(sc2), _p(sh2), _p(stat2), _p(wa), _p(ba), _p(wb), _p(bb), _p(dout),
                                       ld, _p(G2), _p(wpart), _p(part2), tk.data_ptr() + 8 if fused else 0, cnt2, _p(g2),
                                       _p(coef2), root.grad_ptr(g2), root.grad_ptr(be2), pd, st)
         if B:
@@ -1626,7 +1663,7 @@ class SceneAttentionFn(Function):
         coefd1 = torch.empty(5 * C + 1, dtype=torch.float64, device=dev)
         defer = _DEFER["on"]
         pw, pb = root.grad_ptr(c2w), root.grad_ptr(c2b)
-        lib.mggan_conv2_bwd(_p(xsel), B, C, _p(sc1), _p(sh1), _p(stat1), _p(y2), _p(G2), _p(stat2),
+        lib.mggan_conv2_bwd(_p(xsel), B, C, _p(sc1), _p(sh1), _p(stat1), _p(y2), _p(G2), _p(ycode), _p(stat2),
                             _p(coef2), _p(c2w), _p(G1c), _p(part1), 0 if defer else pw, 0 if defer else pb,
                             _p(ws), nb, tk.data_ptr() + 12 if fused else 0, cnt1, _p(g1), _p(coef1), _p(coefd1),
                             root.grad_ptr(g1), root.grad_ptr(be1), pd, st)
@@ -1740,7 +1777,7 @@ class DecoderRolloutFn(Function):
                          lambda prep: lib.mggan_lstm_fold(_p(g0["emb_w"]), _p(g0["emb_b"]), _p(g0["w_ih"]), _p(g0["b_ih"]),
                                                           _p(g0["b_hh"]), _p(g0["w_hh"]), _p(g0["w1"]), _p(g0["b1"]),
                                                           _p(g0["w2"]), _p(g0["b2"]), stride, n_gens, H, E, S, 1, _p(prep),
-                                                          psz, st)).view(n_gens, psz)
+                                                          psz, _s())).view(n_gens, psz)
         mk = (lambda *s: _empty(*s, like=enc_h)) if save else (lambda *s: None)
         # tile-blocked saves (16-row tiles, every generator's last tile padded): gates, (c, h) with slot 0 = (0, h_0), ...
         tiles = -(-R // 16) + n_gens

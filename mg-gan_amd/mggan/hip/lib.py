@@ -40,7 +40,7 @@ def parse_header(path=HEADER_PATH):
 
 
 # functions whose int return value is data, not a status code
-_VALUE_RETURNING = {"mggan_version", "mggan_wgrad_splits", "mggan_lstm_prep_size", "mggan_cnn_bwd_grid", "mggan_cnn_grid", "mggan_comm_arena_bytes", "mggan_social_rows_grid", "mggan_social_rows_splits",
+_VALUE_RETURNING = {"mggan_version", "mggan_launch_log", "mggan_launch_log_read", "mggan_wgrad_splits", "mggan_lstm_prep_size", "mggan_cnn_bwd_grid", "mggan_cnn_grid", "mggan_comm_arena_bytes", "mggan_social_rows_grid", "mggan_social_rows_splits",
                     "mggan_scene_attention_grid", "mggan_scene_attention_partial_floats",
                     "mggan_social_rows_partial_floats"}
 
@@ -57,11 +57,25 @@ class _Lib:
         self.marks = None  # {"names": entries to bracket, "buf": int64 device buffer, "calls": [(name, args)]} -- device-clock
         #                    marks around chosen entries, ON THE ENTRY'S STREAM: they can be captured into a HIP graph, so a
         #                    replay times those kernels in the regime the replay runs in (bench.py: roofline block)
+        self.sink = None   # a list: every call appends (entry, [(kernel symbol, threads)]) while the launch log is on
+        self._logbuf = ctypes.create_string_buffer(8192)
         self.decls = parse_header()
         for name, (res, argtypes) in self.decls.items():
             fn = getattr(cdll, name)  # AttributeError here == header/library mismatch
             fn.argtypes = argtypes
             fn.restype = res
+
+    def launch_log(self, on):
+        """Switch the library's launch log (include/mggan_hip.h: mggan_launch_log) on / off; it starts empty."""
+        self._c.mggan_launch_log(1 if on else 0)
+
+    def read_launches(self):
+        """[(kernel symbol as tools/ and profiles/ spell it, threads)] of the launches since the last read."""
+        from .ksym import parse_launch_log
+
+        buf = self._logbuf
+        self._c.mggan_launch_log_read(buf, len(buf))
+        return parse_launch_log(buf.value.decode())
 
     def __getattr__(self, name):
         w = self._w.get(name)
@@ -80,10 +94,11 @@ class _Lib:
                 tr, mk = self.trace, self.marks
                 if mk is not None and _name in mk["names"] and 16 * (len(mk["calls"]) + 1) <= mk["buf"].numel() * 8:
                     slot = mk["buf"].data_ptr() + 16 * len(mk["calls"])
+                    self._c.mggan_launch_log(1)  # (empties the log: the unmarked calls before this one were not read)
                     self._c.mggan_timestamp(slot, args[-1])
                     rc = _fn(*args)
                     self._c.mggan_timestamp(slot + 8, args[-1])
-                    mk["calls"].append((_name, args))
+                    mk["calls"].append((_name, args, self.read_launches()))
                     if rc != 0:
                         raise HipError("{} failed ({}): {}".format(_name, rc, last_error().decode()))
                     return
@@ -92,10 +107,13 @@ class _Lib:
 
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
+                    self._c.mggan_launch_log(1)  # (launches of value-returning / untraced helpers since the last read)
                 rc = _fn(*args)
                 if tr is not None:
                     e1.record()
-                    tr.append((_name, args, e0, e1))
+                    tr.append((_name, args, e0, e1, self.read_launches()))
+                elif self.sink is not None:
+                    self.sink.append((_name, self.read_launches()))
                 if rc != 0:
                     raise HipError("{} failed ({}): {}".format(_name, rc, last_error().decode()))
 
@@ -129,21 +147,42 @@ class _LazyLib:
 def start_trace():
     """Bracket every C-ABI call with HIP events on the current stream (all launches go to torch's current
     stream, so torch.cuda.Event sees them)."""
-    load().trace = []
+    l = load()
+    l.launch_log(True)
+    l.trace = []
 
 
 def stop_trace():
-    """-> {entry: (calls, [ms per call], [args per call])}"""
+    """-> {entry: (calls, [ms per call], [args per call], [launches per call])}; launches = [(kernel symbol, threads)]
+    from the library's launch log (mggan/hip/ksym.py spells the symbols as the rocprofv3 tables under profiles/ do)."""
     import torch
 
     l = load()
     tr, l.trace = l.trace, None
+    l.launch_log(False)
     torch.cuda.synchronize()
     out = {}
-    for name, args, e0, e1 in tr or []:
-        c, t, a = out.get(name, (0, [], []))
-        out[name] = (c + 1, t + [e0.elapsed_time(e1)], a + [args])
+    for name, args, e0, e1, launches in tr or []:
+        c, t, a, k = out.get(name, (0, [], [], []))
+        out[name] = (c + 1, t + [e0.elapsed_time(e1)], a + [args], k + [launches])
     return out
+
+
+class launches_of:
+    """with launches_of() as seen: ...   ->  seen = [(entry, [(kernel symbol, threads)])] of every C-ABI call inside the
+    block, eager or under stream capture (the log is taken at launch time on the host)."""
+
+    def __enter__(self):
+        l = load()
+        l.launch_log(True)
+        l.sink = []
+        return l.sink
+
+    def __exit__(self, *exc):
+        l = load()
+        l.sink = None
+        l.launch_log(False)
+        return False
 
 
 lib = _LazyLib()

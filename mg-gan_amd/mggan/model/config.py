@@ -4,9 +4,35 @@ Additions: dataset choice 'synthetic' (+ its shape flags) and --rng."""
 import argparse
 
 
+BUILT_WIDTHS = {"h_dim": (32,), "decoder_h_dim": (32,)}
+
+
+def check_widths(config):
+    """The kernels of libmggan_hip.so are instantiated for the reference's DEFAULT widths (config.py:70-71 there:
+    --h_dim 32 -> generator encoder / social features 32, discriminator encoder 64; --decoder_h_dim 32 -> rollout LSTM 32,
+    step embedding 16) and for noise vectors whose length is a multiple of 4.  Anything else is refused HERE -- at parse
+    time and again in construct_model -- with a ValueError, before a module is built or a kernel launched."""
+    bad = []
+    for flag, ok in BUILT_WIDTHS.items():
+        v = getattr(config, flag, ok[0])
+        if int(v) not in ok:
+            bad.append("--{} {} (built: {})".format(flag, v, " / ".join(str(o) for o in ok)))
+    z = int(getattr(config, "noise_dim", 8))
+    if z < 4 or z % 4:
+        bad.append("--noise_dim {} (built: positive multiples of 4)".format(z))
+    if bad:
+        raise ValueError("not built on the HIP path: " + "; ".join(bad) + ".  libmggan_hip.so instantiates its LSTM, social-"
+                         "attention and rollout kernels for the reference's default widths only (DESIGN.md section 9).")
+    return config
+
+
 class _Parser(argparse.ArgumentParser):
     def opt_list(self, *args, options=None, tunable=None, **kwargs):
         return self.add_argument(*args, **kwargs)
+
+    def parse_known_args(self, args=None, namespace=None):  # (parse_args goes through here too)
+        ns, rest = super().parse_known_args(args, namespace)
+        return check_widths(ns), rest
 
 
 def get_parser():
@@ -76,6 +102,7 @@ def get_parser():
                         help="train(): replay the iteration as a captured HIP graph per batch shape (needs --rng device; "
                              "auto = on whenever the configuration allows it), eager launches otherwise")
     parser.add_argument("--graph_shapes", type=int, default=8, help="batch shapes the graph cache of train() keeps")
+    parser.add_argument("--graph_buckets", type=int, default=64, help="shape buckets of padded (ragged) batches the cache keeps")
     parser.add_argument("--graph_pad", type=str, choices=["auto", "on", "off"], default="auto",
                         help="train(): pad RAGGED batches (the reference loader's: a new tuple of scene sizes almost every "
                              "batch) to shape buckets with inert phantom pedestrians, so that one captured graph per bucket "

@@ -5,6 +5,9 @@ from mggan.model.modules.discriminators import MultiDiscriminatorTrajectory
 
 
 def construct_model(config):
+    from mggan.model.config import check_widths
+
+    check_widths(config)  # ValueError for widths the kernels are not instantiated for (a hand-built namespace lands here)
     unbound_output = config.gan_obj in ["W", "LS"]
     num_discs = 5 if config.gan_type == "probgan" else 1
     config.use_pinet = config.weighting_target != "none" and not config.unconditional

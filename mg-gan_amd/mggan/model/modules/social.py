@@ -28,6 +28,9 @@ class EmbedSocialFeatures(nn.Module):
 class SocialAttention(FlatModule):
     def __init__(self, social_feat_size, hidden_size):
         super().__init__()
+        if hidden_size not in (32, 64) or social_feat_size < 1:
+            raise ValueError("HIP SocialAttention: hidden_size {} not built (32 or 64; csrc/social_rows.hip "
+                             "social_rows_*_kernel<H>, csrc/social.hip)".format(hidden_size))
         self.feature_embedder = EmbedSocialFeatures(3, social_feat_size)
         self.attention = AttentionPooling(hidden_size, social_feat_size)
 

@@ -38,7 +38,7 @@ def _canned():
             "c1_shaped": {"note": "z" * 500}, "train_loop": {"ms_per_step_by_epoch": [1.5] * 6},
             "cpu_baseline": {"value": 567.0123456, "unit": "trajectories/s", "cores": 16, "kind": "port", "mode": "block",
                              "sample": "s" * 600},
-            "gpu_over_cpu": 1534.7,
+            "gpu_over_cpu_port": 1534.7,
             "collective_transports": [{"config": "c2", "peer-mapped": {"ms_per_step": 1.5, "value": 1.0, "launch": "x" * 80},
                                        "rccl-segments": {"ms_per_step": 1.9, "value": 0.8, "launch": "y" * 80}}]}
 
@@ -62,6 +62,7 @@ def test_compact_line_is_small_strict_json():
     assert [c["workload"] for c in line["configs"]] == ["c2", "c3"]
     assert line["configs"][0].get("iteration_frac_of_f32_peak") is None  # NaN never reaches the line
     assert "roofline_top_kernels" not in line and "breakdown" not in line and "c1_shaped" not in line
+    assert not [k for k in line if k.startswith("gpu_over_cpu")]  # the ratio against the port stays in the detail file
 
 
 def test_emit_writes_detail_file(tmp_path, monkeypatch):

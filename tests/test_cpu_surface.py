@@ -300,3 +300,35 @@ def test_static_scene_tables_layout():
         tb.fill([[0, 20], [20, 49]])  # more pedestrians than the bucket holds
     with pytest.raises(ValueError):
         tb.fill([[i, i + 1] for i in range(13)])  # more scenes than slots
+
+
+def test_widths_the_kernels_are_not_built_for_raise_before_any_launch():
+    """--h_dim / --decoder_h_dim (reference config.py:70-71): libmggan_hip.so instantiates the default widths only.
+    The parser, construct_model and the module constructors refuse anything else with a ValueError (nothing is built,
+    nothing is launched -- this runs without a GPU)."""
+    import argparse
+
+    import pytest
+    from mggan.model.config import check_widths, get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.model.modules.common_modules import RelativeDecoder, TrajectoryEncoder
+    from mggan.model.modules.social import SocialAttention
+
+    for flags in (["--h_dim", "64"], ["--h_dim", "16"], ["--decoder_h_dim", "64"], ["--decoder_h_dim", "8"],
+                  ["--noise_dim", "6"], ["--h_dim", "8", "--decoder_h_dim", "8", "--noise_dim", "4"]):
+        with pytest.raises(ValueError, match="not built on the HIP path"):
+            get_parser().parse_args(flags)
+    cfg = get_parser().parse_args(["--num_gens", "2", "--noise_dim", "12"])  # the defaults (and any multiple of 4) parse
+    assert (cfg.h_dim, cfg.decoder_h_dim, cfg.noise_dim) == (32, 32, 12)
+    ns = argparse.Namespace(**vars(get_parser().parse_args([])))
+    ns.h_dim = 64  # a namespace that never went through the parser
+    with pytest.raises(ValueError, match="--h_dim 64"):
+        construct_model(ns)
+    with pytest.raises(ValueError):
+        check_widths(argparse.Namespace(h_dim=32, decoder_h_dim=16, noise_dim=8))
+    with pytest.raises(ValueError, match="hidden_size 128"):
+        TrajectoryEncoder(hidden_size=128, embedding_dim=16)
+    with pytest.raises(ValueError, match="h_dim 64"):
+        RelativeDecoder(pred_len=12, embedding_dim=32, h_dim=64, inp_format="rel", z_size=8, social_feat_size=32)
+    with pytest.raises(ValueError, match="hidden_size 16"):
+        SocialAttention(16, 16)

@@ -101,6 +101,24 @@ def _worker(rank, world, port, q):
     f._flat_grad = torch.cat([p.grad.flatten() for p in params])
     ctx.all_reduce_grads(f)
     assert torch.allclose(f._flat_grad, ref, rtol=1e-4, atol=1e-6), float((f._flat_grad - ref).abs().max())
+    # ---- the epoch-end metric flush of train()'s graph cache: ONE exchange issued by every rank, whatever it replayed
+    # (rank 0 replayed three iterations of one bucket, the others none: before, they skipped the collective and rank 0 hung)
+    from mggan.abstract_train import IterationGraphs
+
+    class StubTrainer:
+        dist = ctx
+
+    ig = IterationGraphs(StubTrainer())
+    if rank == 0:
+        ig._acc[17] = [torch.zeros(4), torch.tensor([3.0, 6.0, 9.0, 0.0]), 3, {(("loss/a", 0), ("loss/b", (1, 2)))}]
+        ig.replays = 3
+    m = defaultdict(list)
+    ig.flush(m)
+    if rank == 0:
+        assert m["loss/a"] == [1.0 * world] * 3 and m["loss/b"] == [5.0 * world] * 3, dict(m)
+        assert ig._acc[17][2] == 0 and float(ig._acc[17][1].abs().sum()) == 0.0 and ig.history == [(3, 0, 0)]
+    else:
+        assert not m
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))

@@ -75,6 +75,7 @@ def test_ragged_batches_replay_one_graph_per_bucket(bucket, shapes, graphs):
     assert total == 32 and len(ig.entries) == graphs and ig.padded == total and ie.padded == total
     assert ig.replays == total - graphs and ig.replays >= 0.9 * total and ig.eager == graphs
     assert ie.replays == 0 and ie.eager == total
+    assert len(ig.history) == 4 and ig.history[-1] == (ig.replays, ig.eager, graphs)  # the replay rate, logged per epoch
     for k, v in m_e.items():
         assert np.isfinite(v) and np.isfinite(m_g[k]), k
         np.testing.assert_allclose(m_g[k], v, rtol=1e-5, atol=1e-7, err_msg=k)

@@ -20,6 +20,6 @@ for mode in ("nograd", "grad", "nograd", "grad"):
     with ctx:
         out = tr.G(batch["in_xy"], batch["in_dxdy"], sse, noise=None, all_gen_out=False, img=batch["features"], num_samples=20)
     t = stop_trace()
-    c, ms, a = t["mggan_decoder_rollout_fwd"]
+    c, ms, a, _ = t["mggan_decoder_rollout_fwd"]
     print(mode, "decoder_rollout_fwd ms:", [round(x, 4) for x in ms], "rows", a[0][0], flush=True)
     del out

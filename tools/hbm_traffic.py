@@ -8,7 +8,7 @@ Units / corrections (MI355X_MICROARCH.md, "HBM"): both counters are in KiB; on g
 the 128-byte requests of wide coalesced reads at 64 bytes, so it is doubled; WRITE_SIZE is taken as is
 (uncalibrated).  bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the launches."""
 import json
-import re
+import os
 import sqlite3
 import sys
 
@@ -17,22 +17,8 @@ Q = """select s.kernel_name, sum(e.value), count(distinct d.id) from rocpd_pmc_e
  join rocpd_info_kernel_symbol s on d.kernel_id = s.id where p.name = ? group by s.kernel_name"""
 
 
-def short(sym):
-    """_Z23decoder_bwd_mfma_kernel12DecFusedArgs.kd -> decoder_bwd_mfma_kernel (template flags kept)."""
-    m = re.match(r"_Z(\d+)", sym)
-    if not m:
-        return sym
-    n = int(m.group(1))
-    base = sym[m.end():m.end() + n]
-    rest = sym[m.end() + n:]
-    t = re.match(r"ILb([01])ELb([01])(?:ELb([01]))?E", rest)
-    if t:
-        flags = ["true" if f == "1" else "false" for f in t.groups() if f is not None]
-        return "{}<{}>".format(base, ",".join(flags))
-    t = re.match(r"ILi(\d+)", rest)
-    if t:
-        return "{}<{}>".format(base, t.group(1))
-    return base
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mg-gan_amd", "mggan", "hip"))
+from ksym import short  # noqa: E402  (name<every template argument>: the spelling bench.py's roofline block uses)
 
 
 def main(fetch_db, write_db):

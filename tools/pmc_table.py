@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Per-kernel averages of the counters of one rocprofv3 --pmc pass:  python tools/pmc_table.py <results.db> [filter]"""
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mg-gan_amd", "mggan", "hip"))
+from ksym import short  # noqa: E402
 
 
 def main(path, flt=""):
@@ -13,6 +17,7 @@ def main(path, flt=""):
     for k, n, v, cnt in c.execute(q):
         if flt and flt not in k:
             continue
+        k = short(k)
         tab.setdefault(k, {})[n] = v / cnt
         tab[k]["_launches"] = cnt
         if n not in names:
