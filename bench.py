@@ -378,9 +378,15 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
     use_graph = graph and rng == "device" and not args.no_graph
     sharded = tr.dist.enabled
     replay = None
+    verbose = os.environ.get("MGGAN_BENCH_VERBOSE", "0") == "1"
+    if verbose:
+        print("[bench] {}: use_graph={} sharded={} devcomm={}".format(tag, use_graph, sharded, tr.dist.devcomm is not None),
+              file=sys.stderr, flush=True)
     if use_graph:
         try:
             replay = tr.capture_iteration(batch)
+            if verbose:
+                print("[bench] captured: {}".format(getattr(tr, "launch_mode", "?")), file=sys.stderr, flush=True)
         except Exception as exc:  # noqa: BLE001
             if not sharded:
                 raise
@@ -403,6 +409,9 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
 
     for i in range(args.warmup):
         run_step(i == args.warmup - 1)
+        if verbose:
+            torch.cuda.synchronize()
+            print("[bench] warm-up step {} done".format(i), file=sys.stderr, flush=True)
     tr.flush_metrics()
     barrier()
     if sharded and tr.dist.devcomm is not None:
@@ -672,7 +681,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-floor", action="store_true", help="skip the C1-shaped eager / host-RNG / graph floor timings")
     ap.add_argument("--cpu-iters", type=int, default=5)
-    ap.add_argument("--no-transport-ab", action="store_true", help="N>1: skip the second pass on the other collective transport")
+    ap.add_argument("--transport-ab", action="store_true",
+                    help="N>1: repeat both workloads on the OTHER collective transport (RCCL between graph segments when the "
+                         "default is the peer-mapped kernels) into `collective_transports`.  Opt-in: the N>1 line the "
+                         "driver parses must not depend on a second trainer and a second communicator coming up")
+    ap.add_argument("--no-transport-ab", action="store_true", help=argparse.SUPPRESS)  # (round-4 command lines)
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -729,7 +742,7 @@ def main():
         c = CONFIGS[tag]
         others.append(measure(tag, c["scenes"], c["peds"], c["num_gens"], args, world, rank, dev))
     transports = None
-    if world > 1 and not args.no_transport_ab:
+    if world > 1 and args.transport_ab and not args.no_transport_ab:
         # the same workloads on the other transport (north_star names RCCL; the default keeps the iteration ONE graph
         # with the exchange points as peer-mapped kernels): both numbers in the line, same timing protocol
         other = "rccl" if head.get("collective") == "peer-mapped" else "peer-mapped"

@@ -223,13 +223,16 @@ int mggan_segment_max_bwd(int P, int B, const int* pair_o, const int* ped_prow, 
  * end (the reference loader's ragged batches, /root/reference/mggan/data_utils/trajectories_scene.py:40-78, replayed as one
  * captured graph per bucket): the image loops stop at n_real, the element counts of the statistics shrink with it, and
  * the attention head writes zero features for the phantom rows.  The launch geometry stays that of B. */
+/* mggan_conv1_pool, gram != NULL (sharded training; ticket must be NULL): the BatchNorm-1 statistics are those of the batch
+ * whose Gram matrix of image patches is `gram` -- the GLOBAL batch's, all-reduced once per iteration -- and are written by
+ * the launch itself (see mggan_bn1_from_gram below); no exchange at this point. */
 int mggan_cnn_grid(int B);      /* workgroups (= partial rows) of conv1_pool / conv2_fwd2 / image_gram / conv1_wgrad */
 int mggan_cnn_bwd_grid(int B);  /* workgroups (= partial rows) of conv2_bwd */
 int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float* bias, float* xsel,
                      unsigned char* code, double* part, unsigned int* ticket, double count, const float* gamma,
                      const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
-                     float eps, int updates, float* scale, float* shift, float* stat, const int* dims,
-                     mggan_stream_t stream);
+                     float eps, int updates, float* scale, float* shift, float* stat, const double* gram,
+                     const int* dims, mggan_stream_t stream);
 int mggan_conv2_fwd2(const float* xsel, int B, int C, const float* scale1, const float* shift1,
                      const float* W, const float* bias, float* y2, double* part, unsigned int* ticket, double count,
                      const float* gamma, const float* beta, float* run_mean, float* run_var,
@@ -287,6 +290,22 @@ int mggan_image_gram(const float* img, int B, double* gram, double* workspace, s
 int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const unsigned char* code1, const double* gram,
                       const float* W, const float* bias, const double* coefd, float* dW, double* workspace,
                       size_t workspace_bytes, const int* dims, mggan_stream_t stream);
+/* Sharded training (scene sharding over the GPUs of a node), layer 1 of the scene CNNs without an exchange of
+ * its own: with the batch's GLOBAL Gram matrix (mggan_image_gram, all-reduced once per batch) the BatchNorm-1 FORWARD
+ * statistics of any conv1 weights follow without a collective (mggan_bn1_from_gram: scale / shift / stat and the
+ * running-statistics update, as mggan_bn_finalize), and what the layer-1 ADJOINT needs of the other ranks is folded into an
+ * f64 tail [A (C x 36) | S1 (C) | S2 (C)] (mggan_conv1_tail_fold; wrows = the partial rows mggan_conv1_wgrad leaves when
+ * dW == NULL, part1 = those of mggan_conv2_bwd) that travels with the step's gradient all-reduce (mggan_comm_allreduce2);
+ * mggan_conv1_tail_finalize then adds dW1 / dgamma1 / dbeta1 of the GLOBAL batch, identically on every rank. */
+int mggan_bn1_from_gram(const double* gram, int C, const float* W, const float* bias, const float* gamma,
+                        const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
+                        float eps, int updates, float* scale, float* shift, float* stat, mggan_stream_t stream);
+int mggan_conv1_tail_floats(int C);
+int mggan_conv1_tail_fold(const double* wrows, int rows, const double* part1, int rows1, int C, double* tail,
+                          int riders /* doubles behind the sums that are set to zero */, mggan_stream_t stream);
+int mggan_conv1_tail_finalize(const double* tail, const double* gram, int C, const float* W, const float* bias,
+                              const float* gamma, const float* stat, float* dW, float* dgamma, float* dbeta,
+                              mggan_stream_t stream);
 
 /* ---- both discriminator heads over many rows, weight-stationary (csrc/dheads.hip) -------------------------------
  * reference: discriminators.py:76-85,197-204 (discs[0]) and :97-108,211-219 (gen_id_reconstructor) on the K*b rows of
@@ -362,6 +381,9 @@ int mggan_comm_ipc_open(const void* handle, void** out);
 int mggan_comm_ipc_close(void* p);
 int mggan_comm_allreduce(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
                          mggan_stream_t stream);
+/* ... with an f64 tail (data2, n2 doubles) summed in the same collective (same flags, same sequence number) */
+int mggan_comm_allreduce2(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
+                          double* data2, long n2, mggan_stream_t stream);
 int mggan_comm_error(const void* arena, unsigned int* out);
 int mggan_comm_set_timeout(double seconds);
 int mggan_comm_host_error(unsigned int** out);
@@ -482,6 +504,14 @@ int mggan_colmean(const float* x, int rows, int g, float scale, float* out, mgga
 int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count, const int* dims, int bmod,
                      mggan_stream_t stream);
 int mggan_inv_counts(const int* counts, int g, float* inv_count, mggan_stream_t stream);
+/* Sharded training: the generator step's 1/count weights (train.py:94-96 of the reference: counts over the GLOBAL batch)
+ * without a collective of their own -- mggan_sample_counts computes, ahead of the sampling launch, how often every generator
+ * will be picked on these logits and uniforms (out: 16 doubles, the same CDF arithmetic as mggan_sample_categorical); the
+ * doubles ride in the f64 tail of an earlier exchange (mggan_comm_allreduce2) and mggan_inv_counts_f64 turns the sums into
+ * the weights. */
+int mggan_sample_counts(int b, int K, int g, const float* logits, const float* u, int* scratch /* 17 ints, zero */,
+                        double* out, mggan_stream_t stream);
+int mggan_inv_counts_f64(const double* counts, int g, float* inv_count, mggan_stream_t stream);
 /* flat parameter buffer + segment table: elem_seg[i] = segment of element i (-1 = padding),
  * active[s] = segment takes part in this step (grad not None), seg_step[s] = Adam step count.
  * zero_grad != 0: the consumed gradients are left at 0 instead of their clipped values (saves the caller's

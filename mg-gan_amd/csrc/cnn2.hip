@@ -188,6 +188,32 @@ __device__ __forceinline__ void bn_bwd_finalize_lane(const BnBwdFin& f, int C, c
   f.dgamma[c] += (float)sums[C + c];
 }
 
+// BatchNorm-1 statistics of conv1(W, bias) over the batch whose Gram matrix of image patches is `gram` (sharded training:
+// the GLOBAL batch's):  sum x_c = W_c . B + n b_c,  sum x_c^2 = W_c P W_c^T + 2 b_c W_c . B + n b_c^2
+// (B = row 36 of P, n = P[36][36]).  f64 throughout: the variance is a difference of two such sums.  Every thread of the
+// workgroup calls it; sums: 2C doubles of LDS.
+__device__ __forceinline__ void bn1_from_gram_block(const double* __restrict__ gram, int C, const float* __restrict__ W,
+                                                    const float* __restrict__ bias, BnFin fin, double* sums) {
+  const int c = threadIdx.x;
+  const double n = gram[36 * NTAP + 36];
+  if (c < C) {
+    double s = 0.0, q = 0.0;
+    for (int t = 0; t < 36; ++t) {
+      const double wt = (double)W[c * 36 + t];
+      s += wt * gram[36 * NTAP + t];
+      double r = 0.0;
+      for (int u = 0; u < 36; ++u) r += (double)W[c * 36 + u] * gram[u * NTAP + t];
+      q += wt * r;
+    }
+    const double b = (double)bias[c];
+    sums[c] = s + n * b;
+    sums[C + c] = q + 2.0 * b * s + n * b * b;
+  }
+  __syncthreads();
+  fin.count = n;
+  bn_finalize_lane(fin, C, sums);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // conv1 + statistics + pooling decision.  Implicit GEMM on v_mfma_f32_16x16x4_f32: a tile is FOUR pooling windows,
 // row i = 4*window + element of the A operand, so that the D fragment of a lane (4 rows of one output channel) is
@@ -197,7 +223,8 @@ template <int C>
 __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __restrict__ img, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const float* __restrict__ gamma,
                                                          float* __restrict__ xsel, unsigned char* __restrict__ code,
-                                                         double* part, BnFin fin, const int* dims) {
+                                                         double* part, BnFin fin, const double* __restrict__ gram,
+                                                         const int* dims) {
   MG_REAL_IMAGES_COUNT(B, dims, fin)
   __shared__ __attribute__((aligned(16))) float imgp[ILDS];
   __shared__ double redd[4][2][16];
@@ -305,6 +332,12 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __r
     const int which = tid / C, c = tid - which * C;
     store_part(part + (size_t)blockIdx.x * 2 * C + tid,
                (redd[0][which][c] + redd[1][which][c]) + (redd[2][which][c] + redd[3][which][c]));
+  }
+  if (gram) {
+    // sharded training: the GLOBAL statistics of this layer follow from the global Gram matrix and the weights alone
+    // (nothing this launch computed enters them): workgroup 0 writes scale / shift / running statistics on its way out
+    if (blockIdx.x == 0) bn1_from_gram_block(gram, C, W, bias, fin, colsum);
+    return;
   }
   if (!fin.ticket) return;
   if (!last_block(fin.ticket, &flag)) return;
@@ -786,6 +819,78 @@ __global__ __launch_bounds__(256) void conv1_wgrad_finalize_kernel(const double*
   dW[c * 36 + t] += (float)(cs * (A - (S1 / n) * Bt - (S2 / n) * chat));
 }
 
+// ---- sharded training, layer 1 without an exchange of its own ---------------------------------------
+// Forward: the statistics of the conv1 output follow from the batch's Gram matrix of image patches and the weights --
+//   sum x_c = W_c . B + n b_c,   sum x_c^2 = W_c P W_c^T + 2 b_c W_c . B + n b_c^2   (B = row 36 of P, n = P[36][36]) --
+// so with the GLOBAL Gram matrix (all-reduced once per batch) every conv1 forward pass of the iteration, of either CNN, has
+// its global-batch statistics without talking to anybody.  f64 throughout: the variance is a difference of two such sums.
+__global__ __launch_bounds__(64) void bn1_from_gram_kernel(const double* __restrict__ gram, int C,
+                                                           const float* __restrict__ W, const float* __restrict__ bias,
+                                                           BnFin fin) {
+  __shared__ double sums[64];
+  bn1_from_gram_block(gram, C, W, bias, fin, sums);
+}
+
+// Backward: what the layer-1 adjoint needs of the other ranks -- the BatchNorm-1 adjoint sums S1 = sum g, S2 = sum g xhat and
+// the raw conv1 weight-gradient sums A -- is needed by NOTHING before the weight gradient itself, so this rank's share
+// [A (C x 36) | S1 (C) | S2 (C)] is folded into one f64 tail here, travels with the gradient all-reduce of the step
+// (csrc/comm.hip: the tail of mggan_comm_allreduce2), and the finalize below runs behind it, identically on every rank.
+__global__ __launch_bounds__(256) void conv1_tail_fold_kernel(const double* wrows, int rows, const double* part1, int rows1,
+                                                              int C, double* tail, int riders) {
+  __shared__ double red[7][36];
+  __shared__ double colsum[32], cred[8 * 32];
+  const int c = blockIdx.x;
+  if (c == C) {
+    colsum_rows(part1, rows1, 2 * C, colsum, cred);
+    if ((int)threadIdx.x < 2 * C) tail[C * 36 + threadIdx.x] = colsum[threadIdx.x];
+    // the rider slots behind the CNN's sums start at zero (whoever rides along writes behind this launch)
+    if ((int)threadIdx.x < riders) tail[C * 36 + 2 * C + threadIdx.x] = 0.0;
+    return;
+  }
+  const int t = threadIdx.x % 36, rg = threadIdx.x / 36;
+  if (rg < 7) {
+    double s = 0.0;
+    const double* p = wrows + c * 36 + t;
+    const size_t ld = (size_t)C * 36;
+    int r = rg;
+    for (; r + 7 * 7 < rows; r += 8 * 7) {  // 8 loads in flight per lane, fixed order (as conv1_wgrad_finalize_kernel)
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + u * 7) * ld];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < rows; r += 7) s += p[(size_t)r * ld];
+    red[rg][t] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 36) return;
+  double A = 0.0;
+  for (int i = 0; i < 7; ++i) A += red[i][t];
+  tail[c * 36 + t] = A;
+}
+
+// dW1 += (gamma/sigma) (A - (S1/n) B - (S2/n) Chat),  dgamma1 += S2,  dbeta1 += S1  from the GLOBAL tail and Gram matrix
+// (n = P[36][36]); one workgroup per output channel.  Every rank computes the same numbers: the slots of these three
+// parameters hold zeros during the gradient all-reduce and receive the global-batch gradient here.
+__global__ __launch_bounds__(64) void conv1_tail_finalize_kernel(const double* __restrict__ tail,
+                                                                 const double* __restrict__ gram, int C,
+                                                                 const float* __restrict__ W, const float* __restrict__ bias,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ stat, float* dW, float* dgamma,
+                                                                 float* dbeta) {
+  const int c = blockIdx.x, t = threadIdx.x;
+  const double S1 = tail[C * 36 + c], S2 = tail[C * 36 + C + c], n = gram[36 * NTAP + 36];
+  if (t == 36) dbeta[c] += (float)S1;
+  if (t == 37) dgamma[c] += (float)S2;
+  if (t >= 36) return;
+  const double mean = (double)stat[c], inv = (double)stat[C + c], cs = (double)gamma[c] * inv;
+  const double Bt = gram[36 * NTAP + t];
+  double wp = 0.0;
+  for (int s = 0; s < 36; ++s) wp += (double)W[c * 36 + s] * gram[s * NTAP + t];
+  const double chat = (wp + ((double)bias[c] - mean) * Bt) * inv;
+  dW[c * 36 + t] += (float)(cs * (tail[c * 36 + t] - (S1 / n) * Bt - (S2 / n) * chat));
+}
+
 // persistent grid: at most `cap` workgroups (three per CU), and every workgroup walks the same number of images
 // (the last one may fall short): 1,280 images -> 640 workgroups x 2, 8,192 -> 745 x 11
 static int grid_for(int B, int cap) {
@@ -817,17 +922,19 @@ static BnFin make_fin(unsigned* ticket, double count, const float* gamma, const 
 int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float* bias, float* xsel,
                      unsigned char* code, double* part, unsigned* ticket, double count, const float* gamma,
                      const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
-                     float eps, int updates, float* scale, float* shift, float* stat, const int* dims, hipStream_t stream) {
+                     float eps, int updates, float* scale, float* shift, float* stat, const double* gram,
+                     const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv1_pool: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(img && W && bias && gamma && xsel && code && part, "conv1_pool: null pointer");
-  MG_CHECK_ARG(!ticket || (beta && run_mean && run_var && num_batches_tracked && scale && shift && stat),
+  MG_CHECK_ARG(!(ticket || gram) || (beta && run_mean && run_var && num_batches_tracked && scale && shift && stat),
                "conv1_pool: the fused finalize needs the BatchNorm tensors");
+  MG_CHECK_ARG(!(ticket && gram), "conv1_pool: statistics either from this launch (ticket) or from the Gram matrix");
   const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
                              scale, shift, stat);
   const int grid = grid_for(B, 768);
-  if (C == 16) MG_LAUNCH((conv1_pool_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, dims);
-  else MG_LAUNCH((conv1_pool_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, dims);
+  if (C == 16) MG_LAUNCH((conv1_pool_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, gram, dims);
+  else MG_LAUNCH((conv1_pool_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, gram, dims);
   MG_LAUNCH_CHECK("conv1_pool");
   return MGGAN_OK;
 }
@@ -919,6 +1026,40 @@ int mggan_bn_bwd_sync_finalize(void* const* arenas, int rank, int world, long ma
   return MGGAN_OK;
 }
 
+int mggan_bn1_from_gram(const double* gram, int C, const float* W, const float* bias, const float* gamma,
+                        const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
+                        float eps, int updates, float* scale, float* shift, float* stat, hipStream_t stream) {
+  MG_CHECK_ARG(gram && W && bias && gamma && beta && run_mean && run_var && num_batches_tracked && scale && shift && stat &&
+                   (C == 8 || C == 16),
+               "bn1_from_gram: bad arguments");
+  MG_LAUNCH(bn1_from_gram_kernel, dim3(1), dim3(64), 0, stream, gram, C, W, bias,
+            make_fin(nullptr, 0.0, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates, scale, shift,
+                     stat));
+  MG_LAUNCH_CHECK("bn1_from_gram");
+  return MGGAN_OK;
+}
+
+int mggan_conv1_tail_floats(int C) { return C * 36 + 2 * C; }
+
+int mggan_conv1_tail_fold(const double* wrows, int rows, const double* part1, int rows1, int C, double* tail, int riders,
+                          hipStream_t stream) {
+  MG_CHECK_ARG(wrows && part1 && tail && rows >= 0 && rows1 >= 0 && (C == 8 || C == 16) && riders >= 0 && riders <= 64,
+               "conv1_tail_fold: bad arguments");
+  MG_LAUNCH(conv1_tail_fold_kernel, dim3(C + 1), dim3(256), 0, stream, wrows, rows, part1, rows1, C, tail, riders);
+  MG_LAUNCH_CHECK("conv1_tail_fold");
+  return MGGAN_OK;
+}
+
+int mggan_conv1_tail_finalize(const double* tail, const double* gram, int C, const float* W, const float* bias,
+                              const float* gamma, const float* stat, float* dW, float* dgamma, float* dbeta,
+                              hipStream_t stream) {
+  MG_CHECK_ARG(tail && gram && W && bias && gamma && stat && dW && dgamma && dbeta && (C == 8 || C == 16),
+               "conv1_tail_finalize: bad arguments");
+  MG_LAUNCH(conv1_tail_finalize_kernel, dim3(C), dim3(64), 0, stream, tail, gram, C, W, bias, gamma, stat, dW, dgamma, dbeta);
+  MG_LAUNCH_CHECK("conv1_tail_finalize");
+  return MGGAN_OK;
+}
+
 /* workspace: mggan_cnn_grid(B) * 1536 doubles */
 int mggan_image_gram(const float* img, int B, double* gram, double* workspace, size_t workspace_bytes,
                      const int* dims, hipStream_t stream) {
@@ -937,12 +1078,14 @@ int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const un
                       size_t workspace_bytes, const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv1_wgrad: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
-  MG_CHECK_ARG(img && G1c && code1 && gram && W && bias && coefd && dW && workspace, "conv1_wgrad: null pointer");
+  MG_CHECK_ARG(img && G1c && code1 && workspace, "conv1_wgrad: null pointer");
+  MG_CHECK_ARG(!dW || (gram && W && bias && coefd), "conv1_wgrad: the finalize needs gram / W / bias / coefd");
   const int grid = grid_for(B, 768);
   MG_CHECK_ARG(workspace_bytes >= (size_t)grid * C * 36 * sizeof(double), "conv1_wgrad: workspace too small");
   if (C == 16) MG_LAUNCH((conv1_wgrad_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
   else MG_LAUNCH((conv1_wgrad_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
-  MG_LAUNCH(conv1_wgrad_finalize_kernel, dim3(C), dim3(256), 0, stream, workspace, grid, C, gram, W, bias, coefd, dW);
+  // dW == NULL: the partial rows stay in `workspace` (sharded training: mggan_conv1_tail_fold / _finalize take over)
+  if (dW) MG_LAUNCH(conv1_wgrad_finalize_kernel, dim3(C), dim3(256), 0, stream, workspace, grid, C, gram, W, bias, coefd, dW);
   MG_LAUNCH_CHECK("conv1_wgrad");
   return MGGAN_OK;
 }

@@ -24,22 +24,21 @@ static unsigned* g_host_error = nullptr;
 long long comm_timeout_ticks() { return g_timeout_ticks; }
 unsigned* comm_host_error() { return g_host_error; }
 
+// One chunk of one vector: `k` = the chunk's flag index within the collective, `e0`/`cnt` = its elements of `data`,
+// `off` = byte offset of the vector inside a slot.
 template <typename T>
-__global__ __launch_bounds__(256) void comm_allreduce_kernel(CommArgs a) {
-  __shared__ int lost_s;
+__device__ __forceinline__ void comm_chunk(const CommArgs& a, T* data, long e0, long cnt, size_t off, int k, unsigned seq,
+                                           CommHeader* hdr, int* lost_s) {
   char* mine = (char*)a.arena[a.rank];
-  CommHeader* hdr = (CommHeader*)mine;
-  const unsigned seq = __hip_atomic_load(&hdr->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-  const int buf = seq & 1, k = blockIdx.x, W = a.world, r = a.rank;
-  const long e0 = (long)k * COMM_CHUNK, cnt = min((long)COMM_CHUNK, a.n - e0);
+  const int buf = seq & 1, W = a.world, r = a.rank;
   const size_t slot_bytes = (size_t)a.max_elems * 8, doff = comm_data_off(a.max_blocks);
-  T* src = (T*)a.data + e0;
+  T* src = data + e0;
   // (a) my chunk into slot r of every rank
   for (int j = 0; j < W; ++j) {
-    T* dst = (T*)((char*)a.arena[j] + doff + ((size_t)buf * COMM_MAX_RANKS + r) * slot_bytes) + e0;
+    T* dst = (T*)((char*)a.arena[j] + doff + ((size_t)buf * COMM_MAX_RANKS + r) * slot_bytes + off) + e0;
     for (long i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
   }
-  if (threadIdx.x == 0) lost_s = 0;
+  if (threadIdx.x == 0) *lost_s = 0;
   __threadfence_system();
   __syncthreads();
   // (b) stamp, (c) wait
@@ -47,18 +46,38 @@ __global__ __launch_bounds__(256) void comm_allreduce_kernel(CommArgs a) {
     unsigned* pf = (unsigned*)((char*)a.arena[threadIdx.x] + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + r) * a.max_blocks + k;
     __hip_atomic_store(pf, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     unsigned* wf = (unsigned*)(mine + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + threadIdx.x) * a.max_blocks + k;
-    if (!comm_wait_flag(wf, seq, hdr, a)) lost_s = 1;
+    if (!comm_wait_flag(wf, seq, hdr, a)) *lost_s = 1;
   }
   __syncthreads();
   // (d) fixed-order sum of the W slots of my own arena -- or, when a peer never arrived, poison: a failed exchange must
   // be visible in the weights (NaN), not look like a gradient
-  const bool lost = lost_s != 0;
-  const T* base = (const T*)(mine + doff + (size_t)buf * COMM_MAX_RANKS * slot_bytes) + e0;
+  const bool lost = *lost_s != 0;
+  const T* base = (const T*)(mine + doff + (size_t)buf * COMM_MAX_RANKS * slot_bytes + off) + e0;
   const size_t stride = slot_bytes / sizeof(T);
   for (long i = threadIdx.x; i < cnt; i += 256) {
     T s = __builtin_nontemporal_load(base + i);
     for (int j = 1; j < W; ++j) s += __builtin_nontemporal_load(base + (size_t)j * stride + i);
     src[i] = lost ? comm_poison<T>() : s;
+  }
+}
+
+// Vector 1 (`data`, n elements of T) in chunks 0 .. nb1-1; an optional f64 TAIL (`data2`, n2 doubles, behind vector 1 in the
+// slot at the next 256-byte boundary) in the chunks that follow: the per-rank f64 sums that must travel with a gradient
+// buffer (the layer-1 BatchNorm adjoint sums and the raw conv1 weight-gradient sums of the sharded scene CNN) ride in the
+// same collective instead of being one of their own.
+template <typename T>
+__global__ __launch_bounds__(256) void comm_allreduce_kernel(CommArgs a) {
+  __shared__ int lost_s;
+  CommHeader* hdr = (CommHeader*)a.arena[a.rank];
+  const unsigned seq = __hip_atomic_load(&hdr->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const int k = blockIdx.x, nb1 = (int)((a.n + COMM_CHUNK - 1) / COMM_CHUNK);
+  if (k < nb1) {
+    const long e0 = (long)k * COMM_CHUNK;
+    comm_chunk<T>(a, (T*)a.data, e0, min((long)COMM_CHUNK, a.n - e0), 0, k, seq, hdr, &lost_s);
+  } else {
+    const long e0 = (long)(k - nb1) * COMM_CHUNK;
+    const size_t off = ((size_t)a.n * sizeof(T) + 255) / 256 * 256;
+    comm_chunk<double>(a, (double*)a.data2, e0, min((long)COMM_CHUNK, a.n2 - e0), off, k, seq, hdr, &lost_s);
   }
   // the last workgroup closes the collective
   __syncthreads();
@@ -132,24 +151,41 @@ int mggan_comm_ipc_close(void* p) {
 }
 
 /* arenas: `world` pointers (arena of rank j mapped into this process); data: n elements reduced in place */
-int mggan_comm_allreduce(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
-                         hipStream_t stream) {
-  MG_CHECK_ARG(arenas && data && world >= 1 && world <= COMM_MAX_RANKS && rank >= 0 && rank < world, "comm_allreduce: bad ranks");
+static int comm_allreduce_launch(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
+                                 double* data2, long n2, hipStream_t stream) {
+  MG_CHECK_ARG(arenas && (data || n == 0) && world >= 1 && world <= COMM_MAX_RANKS && rank >= 0 && rank < world,
+               "comm_allreduce: bad ranks");
   MG_CHECK_ARG(dtype >= 0 && dtype <= 2, "comm_allreduce: dtype %d (0 f32, 1 f64, 2 i32)", dtype);
-  const long cap = dtype == 1 ? max_elems : 2 * max_elems;
-  MG_CHECK_ARG(n >= 0 && n <= cap, "comm_allreduce: %ld elements exceed the arena slot (%ld)", n, cap);
-  if (n == 0) return MGGAN_OK;
+  MG_CHECK_ARG(n >= 0 && n2 >= 0 && (data2 || n2 == 0), "comm_allreduce: bad vector lengths");
+  const size_t esz = dtype == 1 ? 8 : 4;
+  const size_t off2 = ((size_t)n * esz + 255) / 256 * 256;
+  MG_CHECK_ARG((n2 ? off2 + (size_t)n2 * 8 : (size_t)n * esz) <= (size_t)max_elems * 8,
+               "comm_allreduce: %ld + %ld elements exceed the arena slot (%ld bytes)", n, n2, max_elems * 8);
+  if (n == 0 && n2 == 0) return MGGAN_OK;
   CommArgs a;
   for (int j = 0; j < COMM_MAX_RANKS; ++j) a.arena[j] = j < world ? arenas[j] : nullptr;
   a.data = data; a.n = n; a.max_elems = max_elems; a.rank = rank; a.world = world;
   a.max_blocks = cdiv(max_elems * 2, COMM_CHUNK); a.dtype = dtype;
+  a.data2 = data2; a.n2 = n2;
   a.timeout_ticks = g_timeout_ticks; a.host_error = g_host_error;
-  const int grid = cdiv(n, COMM_CHUNK);
+  const int grid = cdiv(n, COMM_CHUNK) + cdiv(n2, COMM_CHUNK);
+  MG_CHECK_ARG(grid <= a.max_blocks, "comm_allreduce: %d chunks exceed the arena's flags (%d)", grid, a.max_blocks);
   if (dtype == 0) MG_LAUNCH(comm_allreduce_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
   else if (dtype == 1) MG_LAUNCH(comm_allreduce_kernel<double>, dim3(grid), dim3(256), 0, stream, a);
   else MG_LAUNCH(comm_allreduce_kernel<int>, dim3(grid), dim3(256), 0, stream, a);
   MG_LAUNCH_CHECK("comm_allreduce");
   return MGGAN_OK;
+}
+
+int mggan_comm_allreduce(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
+                         hipStream_t stream) {
+  return comm_allreduce_launch(arenas, rank, world, max_elems, data, n, dtype, nullptr, 0, stream);
+}
+
+/* ... with an f64 tail (n2 doubles) summed in the same collective */
+int mggan_comm_allreduce2(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
+                          double* data2, long n2, hipStream_t stream) {
+  return comm_allreduce_launch(arenas, rank, world, max_elems, data, n, dtype, data2, n2, stream);
 }
 
 /* bound of every wait inside a collective, in seconds (> 0); applies to launches and captures made afterwards */

@@ -21,6 +21,8 @@ struct CommArgs {
   void* arena[COMM_MAX_RANKS];  // arena of rank j for this channel, mapped into this process (arena[rank] = own)
   void* data;                   // vector to reduce in place
   long n;
+  double* data2;                // optional f64 tail reduced in the same collective (csrc/comm.hip), n2 elements
+  long n2;
   long max_elems;               // capacity of one slot in elements of the widest type (8 bytes)
   int rank, world, max_blocks, dtype;  // dtype 0: f32, 1: f64, 2: i32
   long long timeout_ticks;             // bound of every wait
@@ -98,7 +100,7 @@ __device__ __forceinline__ void comm_allreduce_small(const CommArgs& a, double* 
 static inline CommArgs comm_make_args(void* const* arenas, int rank, int world, long max_elems) {
   CommArgs a;
   for (int j = 0; j < COMM_MAX_RANKS; ++j) a.arena[j] = j < world ? arenas[j] : nullptr;
-  a.data = nullptr; a.n = 0; a.max_elems = max_elems; a.rank = rank; a.world = world;
+  a.data = nullptr; a.n = 0; a.data2 = nullptr; a.n2 = 0; a.max_elems = max_elems; a.rank = rank; a.world = world;
   a.max_blocks = cdiv(max_elems * 2, COMM_CHUNK); a.dtype = 1;
   a.timeout_ticks = comm_timeout_ticks(); a.host_error = comm_host_error();
   return a;

@@ -810,6 +810,52 @@ __global__ void sample_categorical_kernel(int b, int K, int g, const float* __re
   idx[i] = sb_pick(cdf, g, u[i] * run);
 }
 
+// How often every generator WILL be picked by a sampling launch (mggan_sample_categorical / mggan_sample_bucket_rows) on
+// these logits and uniforms -- the same CDF, the same comparison -- without bucketing anything: sharded training computes
+// the generator step's counts ahead of time, so that they travel as f64 riders of an earlier exchange (the discriminator
+// step's gradient all-reduce) instead of being a collective of their own.  One workgroup, integer LDS
+// atomics (exact, order independent); out[0 .. BR_MAXG) = counts as doubles (zero beyond g).
+__global__ __launch_bounds__(256) void sample_counts_kernel(int b, int K, int g, const float* __restrict__ logits,
+                                                            const float* __restrict__ u, int* scratch /*[BR_MAXG + 1]*/,
+                                                            double* out) {
+  __shared__ int hist[BR_MAXG];
+  __shared__ int last;
+  if (threadIdx.x < BR_MAXG) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int ped = blockIdx.x * 256 + threadIdx.x;  // a lane is a pedestrian: its CDF once, its K picks in sample order
+  if (ped < b) {
+    float cdf[BR_MAXG], run;
+    sb_build(logits + (size_t)ped * g, g, cdf, run);
+    unsigned long long packed[2] = {0ull, 0ull};  // 16 byte counters (K <= 255)
+    for (int k = 0; k < K; ++k) {
+      const int pick = sb_pick(cdf, g, u[(size_t)ped * K + k] * run);
+      packed[pick >> 3] += 1ull << (8 * (pick & 7));
+    }
+#pragma unroll
+    for (int c = 0; c < BR_MAXG; ++c) {
+      const int n = (int)((packed[c >> 3] >> (8 * (c & 7))) & 0xffull);
+      if (n) atomicAdd(&hist[c], n);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < BR_MAXG && hist[threadIdx.x]) atomicAdd(&scratch[threadIdx.x], hist[threadIdx.x]);
+  // the last workgroup hands the totals over as doubles and re-arms the scratch words (integer sums: order independent)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&scratch[BR_MAXG], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x < BR_MAXG) {
+    out[threadIdx.x] = (double)__hip_atomic_load(&scratch[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&scratch[threadIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&scratch[BR_MAXG], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void inv_count_f64_kernel(const double* __restrict__ counts, int g, float* inv) {
+  const int i = threadIdx.x;
+  if (i < g) inv[i] = counts[i] > 0.5 ? 1.f / (float)counts[i] : 0.f;
+}
+
 // ---- sampling + bucketing in one launch for small row counts ------------------------------------------------------
 // (Beyond a few thousand rows the fusion does not pay: a two-launch form - one workgroup per (sample, 1024-pedestrian
 // chunk) re-drawing the earlier samples of its lanes for the occurrence offsets, block counts scanned by the last
@@ -1221,6 +1267,25 @@ int mggan_gen_counts(const int* idx, int n, int g, int* counts, float* inv_count
   }
   MG_LAUNCH(inv_count_kernel, dim3(1), dim3(256), 0, stream, counts, g, inv_count);
   MG_LAUNCH_CHECK("gen_counts");
+  return MGGAN_OK;
+}
+
+/* out: 16 doubles -- how often each generator is picked by a sampling launch on (logits (b, g), u (b*K)); scratch: 17 ints,
+   zero before the first call (the launch leaves them zero) */
+int mggan_sample_counts(int b, int K, int g, const float* logits, const float* u, int* scratch, double* out,
+                        hipStream_t stream) {
+  MG_CHECK_ARG(out && scratch && b >= 1 && logits && u && g >= 1 && g <= BR_MAXG && K >= 0 && K <= 255,
+               "sample_counts: bad arguments (1..16 generators, up to 255 samples)");
+  MG_LAUNCH(sample_counts_kernel, dim3(cdiv(b, 256)), dim3(256), 0, stream, b, K, g, logits, u, scratch, out);
+  MG_LAUNCH_CHECK("sample_counts");
+  return MGGAN_OK;
+}
+
+/* inv_count[i] = 1 / counts[i] (0 for an empty generator) from counts held as doubles (summed over the ranks) */
+int mggan_inv_counts_f64(const double* counts, int g, float* inv_count, hipStream_t stream) {
+  MG_CHECK_ARG(counts && inv_count && g >= 1 && g <= 256, "inv_counts_f64: bad arguments");
+  MG_LAUNCH(inv_count_f64_kernel, dim3(1), dim3(256), 0, stream, counts, g, inv_count);
+  MG_LAUNCH_CHECK("inv_counts_f64");
   return MGGAN_OK;
 }
 

@@ -107,6 +107,11 @@ class MultiGeneratorGAN(abc.ABC):
             HF.auto_branches(b)
         cfg = self.config
         run_d = self.total_iterations % max(int(cfg.num_gen_steps), 1) == 0 or self.epoch >= cfg.keep_gen_steps
+        # sharded training with global-batch BatchNorm: the Gram matrix of the image patches comes FIRST and is all-reduced
+        # -- the one exchange that serves every conv1 forward pass (statistics) and weight gradient of the iteration
+        bn_sync = self.dist if (self.dist.enabled and getattr(cfg, "bn_sync", "global") == "global") else None
+        if bn_sync is not None:
+            HF.begin_images(img, sync=bn_sync)
         shared = None
         if getattr(self, "share_trunk", False) and loss_mask is None and cfg.num_unrolling_steps == 0 and run_d:
             # G is not updated between the no-grad generator call of the D step and the G step: one trunk
@@ -117,7 +122,8 @@ class MultiGeneratorGAN(abc.ABC):
         # its history context -- scene CNN and LSTM -- and the fake trajectories are queued; beside those it stretched all
         # of them: conv1_pool<8> 100 us instead of 30 at configs[1], the PM-network's 8 us chain 343 us at configs[2]);
         # its first reader is the scene CNN's adjoint of that step
-        HF.begin_images(img, defer=os.environ.get("MGGAN_GRAM_EARLY", "0") != "1")
+        if bn_sync is None:
+            HF.begin_images(img, defer=os.environ.get("MGGAN_GRAM_EARLY", "0") != "1")
         # abstract_train.py:136-150: the discriminator step runs when total_iterations % num_gen_steps == 0 or
         # epoch >= keep_gen_steps, and num_unrolling_steps + 1 times.  The reference's unrolling "backup" is
         # `self.D.state_dict()` -- references to the live parameters, not copies -- so its load_state_dict(backup)

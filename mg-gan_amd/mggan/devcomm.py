@@ -24,7 +24,8 @@ class DeviceComm:
     # ordered with it by fork/join -- the capture stream, the autograd-backward stream), 1 + i = branch stream i of
     # mggan.hip.functions.  A process that trains eagerly and then captures, or captures several times, keeps using the
     # same arenas; all ranks run the same program, so they agree on the roles.
-    CHANNELS = 1 + 4
+    # ... and one for the Gram side stream (its launch and exchange run beside the first scene-CNN pass of an iteration).
+    CHANNELS = 1 + 4 + 1
 
     def __init__(self, group, device, max_elems=None):
         """Collective: every rank of `group` calls it.  Raises on EVERY rank if any rank fails (the phases end with an
@@ -119,9 +120,11 @@ class DeviceComm:
         from mggan.hip import functions as HF
 
         cur = torch.cuda.current_stream(self.device)
+        if HF._GRAM.get("stream") is not None and cur == HF._GRAM["stream"]:
+            return self.CHANNELS - 1
         for which, st in HF._BR["streams"].items():
             if cur == st:
-                if not 0 <= int(which) < self.CHANNELS - 1:
+                if not 0 <= int(which) < self.CHANNELS - 2:
                     raise RuntimeError("device all-reduce: branch stream {} has no channel".format(which))
                 return 1 + int(which)
         return 0
@@ -131,14 +134,27 @@ class DeviceComm:
         (mggan_bn_sync_finalize)."""
         return self._arenas[self._channel()], self.rank, self.world, self.MAX_ELEMS
 
-    def supports(self, t):
-        cap = self.MAX_ELEMS * (1 if t.dtype == torch.float64 else 2)
-        return t.is_cuda and t.is_contiguous() and t.dtype in _DTYPES and t.numel() <= cap
+    def supports(self, t, tail=None):
+        """Does `t` (and an f64 tail behind it, at the next 256-byte boundary of the slot) fit an arena slot?"""
+        if not (t.is_cuda and t.is_contiguous() and t.dtype in _DTYPES):
+            return False
+        nbytes = t.numel() * t.element_size()
+        if tail is not None:
+            if tail.dtype != torch.float64 or not tail.is_contiguous():
+                return False
+            nbytes = (nbytes + 255) // 256 * 256 + tail.numel() * 8
+        return nbytes <= self.MAX_ELEMS * 8
 
-    def all_reduce_(self, t):
-        """Sum over the ranks, in place, on the current stream (capturable)."""
-        lib.mggan_comm_allreduce(self._arenas[self._channel()], self.rank, self.world, self.MAX_ELEMS, t.data_ptr(),
-                                 t.numel(), _DTYPES[t.dtype], torch.cuda.current_stream(self.device).cuda_stream)
+    def all_reduce_(self, t, tail=None):
+        """Sum over the ranks, in place, on the current stream (capturable); `tail`: an f64 vector summed in the same
+        exchange (csrc/comm.hip: mggan_comm_allreduce2)."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        if tail is None:
+            lib.mggan_comm_allreduce(self._arenas[self._channel()], self.rank, self.world, self.MAX_ELEMS, t.data_ptr(),
+                                     t.numel(), _DTYPES[t.dtype], st)
+        else:
+            lib.mggan_comm_allreduce2(self._arenas[self._channel()], self.rank, self.world, self.MAX_ELEMS, t.data_ptr(),
+                                      t.numel(), _DTYPES[t.dtype], tail.data_ptr(), tail.numel(), st)
         return t
 
     def failed(self):

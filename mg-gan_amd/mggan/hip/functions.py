@@ -1457,19 +1457,91 @@ def _gram_launch(img, dims=None):
     return gram, ws
 
 
-def begin_images(img, side=True, defer=False):
+def begin_images(img, side=True, defer=False, sync=None):
     """Announce this batch's image crops (B,4,33,33); their Gram matrix is started on a side stream now, or -- defer=True
     -- at the point of the iteration where launch_images() is called (the trainer picks a latency-bound stretch: next to
-    the discriminator's convolutions and LSTM it only stretches all three)."""
+    the discriminator's convolutions and LSTM it only stretches all three).
+    sync (a DistContext, sharded training with global-batch BatchNorm): the Gram matrix is computed NOW on the caller's
+    stream and all-reduced -- the ONE exchange that gives every conv1 forward pass of the iteration its global statistics
+    and every conv1 weight gradient its image-only part (global_gram)."""
     _GRAM["reg"].clear()
     _GRAM["pending"] = None
+    _GRAM["global"] = None
     if img is None or not img.is_cuda or img.shape[0] == 0:
         return
     img = img.contiguous()
+    _GRAM["pending_global"] = None
+    if sync is not None:
+        if GRAM_SCHEDULE == "late" and side and _BR["on"] and getattr(sync, "devcomm", None) is not None:
+            _GRAM["pending_global"] = (img, sync)  # started by launch_images()
+        else:
+            global_gram(img, sync, side=side and GRAM_SCHEDULE != "first")
+        return
     if defer and side and _BR["on"]:
         _GRAM["pending"] = img
         return
     _start_gram(img, side)
+
+
+def global_gram(img, sync, side=False):
+    """-> the 37 x 37 Gram matrix of the image patches of the GLOBAL batch (this rank's, all-reduced; the element
+    [36][36] is the global number of conv1 output positions).  One collective per batch, cached per iteration.
+    side=True (the trainer, peer-mapped collectives, branch streams on): launch and exchange go to the Gram side stream --
+    on a channel of their own, csrc/comm.hip arenas are per stream role -- and readers wait for its event."""
+    hit = _GRAM.get("global")
+    if hit is not None and hit[1] == img.data_ptr() and hit[2] == tuple(img.shape):
+        if hit[4] is not None:
+            _cur().wait_event(hit[4])
+            hit[0].record_stream(_cur())
+        return hit[0]
+    _GRAM["pending_global"] = None  # (announced for later, needed now: e.g. an iteration without a discriminator step)
+    ev = None
+    if side and _BR["on"] and getattr(sync, "devcomm", None) is not None:
+        if _GRAM["stream"] is None:
+            _GRAM["stream"] = role_stream("gram")
+        st = _GRAM["stream"]
+        st.wait_stream(_cur())
+        with torch.cuda.stream(st):
+            gram, ws = _gram_launch(img)
+            sync.all_reduce_(gram, what="gram")
+            ev = torch.cuda.Event()
+            ev.record(st)
+    else:
+        gram, ws = _gram_launch(img)
+        sync.all_reduce_(gram, what="gram")
+    _GRAM["global"] = (gram, img.data_ptr(), tuple(img.shape), ws, ev)
+    _GRAM["passes"] = 0
+    # (end_images joins the side stream through this entry; nobody looks the matrix up here in sharded mode)
+    _GRAM["reg"][img.data_ptr()] = (gram, ws, ev, img)
+    return gram
+
+
+# WHEN the global Gram matrix is computed and exchanged (MGGAN_GRAM_SCHEDULE; measured on one rank with the collective hooks
+# forced on, DESIGN section 6):
+#   late  (default) -- where the single-GPU path computes it: on the side stream beside the discriminator step's row pass.
+#                      The scene-CNN passes issued before that point (the shared trunk, the discriminator's context of the
+#                      discriminator step) exchange their own 2C sums: 13 exchanges per iteration.
+#   side            -- on the side stream from the start of the iteration; only the FIRST pass exchanges its own sums (12),
+#                      but the launch runs beside the trunk's conv1 (+270 us at 256 x 32: both fill the chip).
+#   first           -- on the caller's stream before anything else: every pass uses it (11), the iteration waits for it.
+GRAM_SCHEDULE = os.environ.get("MGGAN_GRAM_SCHEDULE", "late")
+
+
+def gram_for_pass(img, sync):
+    """The global Gram matrix for the BatchNorm-1 statistics of a scene-CNN forward pass, or None = this pass exchanges its
+    own sums (the matrix has not been started yet, or -- schedule `side` -- it is the first pass of the iteration and would
+    wait for it).  A host-side decision: every rank runs the same program, they all decide alike."""
+    hit = _GRAM.get("global")
+    if hit is None or hit[1] != img.data_ptr() or hit[2] != tuple(img.shape):
+        pend = _GRAM.get("pending_global")
+        if pend is not None and pend[0].data_ptr() == img.data_ptr():
+            return None  # announced, not started yet
+        return global_gram(img, sync)  # a stand-alone module call: computed (and exchanged) on the spot
+    n = _GRAM.get("passes", 0)
+    _GRAM["passes"] = n + 1
+    if n == 0 and hit[4] is not None and GRAM_SCHEDULE == "side":
+        return None
+    return global_gram(img, sync)
 
 
 def _start_gram(img, side=True, after_branches=()):
@@ -1497,6 +1569,9 @@ def launch_images(after_branches=()):
     img, _GRAM["pending"] = _GRAM.get("pending"), None
     if img is not None:
         _start_gram(img, True, after_branches)
+    pend, _GRAM["pending_global"] = _GRAM.get("pending_global"), None
+    if pend is not None:
+        global_gram(pend[0], pend[1], side=True)
 
 
 def end_images():
@@ -1506,6 +1581,8 @@ def end_images():
         _cur().wait_stream(st)
     _GRAM["reg"].clear()
     _GRAM["pending"] = None
+    _GRAM["global"] = None
+    _GRAM["pending_global"] = None
 
 
 def _image_gram(img, dims=None):
@@ -1517,6 +1594,9 @@ def _image_gram(img, dims=None):
             hit[0].record_stream(_cur())
         return hit[0]
     return _gram_launch(img, dims)[0]
+
+
+TAIL_RIDERS = 16  # spare doubles at the end of a gradient tail (mggan/parallel.py: DistContext.all_reduce_grads)
 
 
 def _cnn_tickets(owner, dev):
@@ -1556,6 +1636,7 @@ class SceneAttentionFn(Function):
             """eval mode (running statistics) or sharded training (sums exchanged between the ranks first)"""
             dc = getattr(sync, "devcomm", None) if training else None
             if dc is not None:  # fold + peer-mapped exchange + finalize: ONE launch per exchange point
+                sync.count_collective("bn2.forward" if hw == 16 * 16 else "bn1.forward")
                 lib.mggan_bn_sync_finalize(*dc.channel_args(), _p(part), grid if B else 0, float(B) * hw, C, _p(gamma),
                                            _p(beta), _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked),
                                            float(bn.momentum), float(bn.eps), stat_updates, _p(out3[0]), _p(out3[1]),
@@ -1576,9 +1657,17 @@ class SceneAttentionFn(Function):
         if dims is not None and not fused:
             raise RuntimeError("padded batches need the fused BatchNorm finalize (train mode, one GPU)")
         pd = _pad_ptr(dims)
+        # sharded, global-batch statistics: layer 1's follow from the batch's GLOBAL Gram matrix and these weights -- no
+        # exchange of their own (csrc/cnn2.hip: bn1_from_gram_block, run by conv1_pool's workgroup 0 on its way out).  The
+        # Gram matrix is computed and all-reduced on a side stream from the start of the iteration; the FIRST scene-CNN pass
+        # of the iteration would wait ~a conv1_pool for it and exchanges its own 2C sums instead (gram_for_pass).
+        gram_g = gram_for_pass(img, sync) if (training and sync is not None) else None
         lib.mggan_conv1_pool(_p(img), B, C, _p(c1w), _p(c1b), _p(xsel), _p(code), _p(part),
-                             *bn_args(bn1, g1, be1, 33 * 33, 0, b1), pd, st)
-        cnt1 = float(B) * 33 * 33 if fused else finalize_unfused(bn1, g1, be1, 33 * 33, b1)
+                             *bn_args(bn1, g1, be1, 33 * 33, 0, b1), _p(gram_g), pd, st)
+        if gram_g is not None:
+            cnt1 = float("nan")
+        else:
+            cnt1 = float(B) * 33 * 33 if fused else finalize_unfused(bn1, g1, be1, 33 * 33, b1)
         sc1, sh1, stat1 = b1
         y2 = _empty(B, C, 16, 16, like=img)
         b2 = mk()
@@ -1642,6 +1731,7 @@ class SceneAttentionFn(Function):
         def bn_bwd_sharded(part, nrows, gamma, beta, stat, cnt, coef, coefd, hw):
             dc = getattr(sync, "devcomm", None)
             if dc is not None:
+                sync.count_collective("bn2.backward" if hw == 16 * 16 else "bn1.backward")
                 lib.mggan_bn_bwd_sync_finalize(*dc.channel_args(), _p(part), nrows if B else 0, float(B) * hw, C, _p(gamma),
                                                _p(stat), _p(coef), _p(coefd), root.grad_ptr(gamma), root.grad_ptr(beta), st)
                 return
@@ -1671,17 +1761,35 @@ class SceneAttentionFn(Function):
             wl = C * C * 9 + C
             _queue_reduce(ws.data_ptr(), pw, 0, 1, C * C * 9, 0, C * C * 9, grid, 1, wl, keep=(ws,))
             _queue_reduce(ws.data_ptr() + 4 * C * C * 9, pb, 0, 1, C, 0, C, grid, 1, wl)
-        if not fused:
-            bn_bwd_sharded(part1, grid, g1, be1, stat1, cnt1, coef1, coefd1, 33 * 33)
         # conv1: the image needs no gradient; dW1 from the sparse routed gradients and the batch's Gram matrix (f64);
         # db1 is identically zero in front of a train-mode BatchNorm (the slot is attached: the reference's set of
         # touched parameters includes it)
         root.grad_ptr(c1b)
-        gram = _image_gram(img, ctx.dims)
         nbw = max(lib.mggan_cnn_grid(B), 1) * C * 36 * 8
         wsw = torch.empty(nbw // 8, dtype=torch.float64, device=dev)
-        lib.mggan_conv1_wgrad(_p(img), B, C, _p(G1c), _p(code), _p(gram), _p(c1w), _p(c1b), _p(coefd1), root.grad_ptr(c1w),
-                              _p(wsw), nbw, pd, st)
+        if fused:
+            gram = _image_gram(img, ctx.dims)
+            lib.mggan_conv1_wgrad(_p(img), B, C, _p(G1c), _p(code), _p(gram), _p(c1w), _p(c1b), _p(coefd1),
+                                  root.grad_ptr(c1w), _p(wsw), nbw, pd, st)
+            return (None,) * 21
+        # sharded: layer 1 has no exchange of its own.  This rank's raw sums -- conv1 weight gradient A, BatchNorm-1 adjoint
+        # S1 / S2 -- are folded into one f64 tail that travels with the step's gradient all-reduce
+        # (DistContext.all_reduce_grads); the finalize runs behind it with the global sums and the global Gram matrix
+        gram = global_gram(img, sync)
+        lib.mggan_conv1_wgrad(_p(img), B, C, _p(G1c), _p(code), 0, 0, 0, 0, 0, _p(wsw), nbw, pd, st)
+        # (+ TAIL_RIDERS spare doubles behind the CNN's sums: small per-rank sums of the trainer that ride along, e.g. the
+        #  generator counts of the next step -- zero unless somebody writes them)
+        tf = lib.mggan_conv1_tail_floats(C)
+        tail = torch.empty(tf + TAIL_RIDERS, dtype=torch.float64, device=dev)
+        lib.mggan_conv1_tail_fold(_p(wsw), max(lib.mggan_cnn_grid(B), 1) if B else 0, _p(part1), grid if B else 0, C,
+                                  _p(tail), TAIL_RIDERS, st)
+        ptrs = (root.grad_ptr(c1w), root.grad_ptr(g1), root.grad_ptr(be1))
+
+        def finalize(tail=tail, gram=gram, keep=(wsw, part1)):
+            lib.mggan_conv1_tail_finalize(_p(tail), _p(gram), C, _p(c1w), _p(c1b), _p(g1), _p(stat1), ptrs[0], ptrs[1],
+                                          ptrs[2], _s())
+
+        root.__dict__.setdefault("_grad_tails", []).append((tail, finalize, tf))
         return (None,) * 21
 
 

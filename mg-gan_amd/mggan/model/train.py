@@ -128,6 +128,31 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         """Row count over all ranks (loss normalisers are means over the GLOBAL batch)."""
         return self.dist.global_count(n) if self.dist.enabled else n
 
+    def _ride_generator_counts(self, shared, b):
+        """Sharded training: the generator step weights its rows by 1 / count(generator) over the GLOBAL batch
+        (train.py:94-96 of the reference) -- an exchange of its own per iteration.  Its picks are already determined when
+        the discriminator step ends (PM-network logits of the shared trunk, uniforms drawn at the start of the iteration),
+        so this rank's counts are computed now and travel as riders in the f64 tail of the discriminator's gradient
+        all-reduce; _gen_weights finds the global counts there."""
+        self._rider_counts = None
+        if not (self.dist.enabled and shared is not None and shared.get("g_logits") is not None
+                and getattr(self.rng, "on_device", False) and hasattr(self.rng, "peek_uniforms")
+                and os.environ.get("MGGAN_COUNT_RIDER", "1") != "0"):
+            return
+        tails = self.D.__dict__.get("_grad_tails") or []
+        logits = shared["g_logits"]
+        K, g = int(self.config.num_samples), self.G.n_gs
+        u = self.rng.peek_uniforms(b * K, logits.device)
+        if len(tails) != 1 or u is None or g > HF.TAIL_RIDERS or logits.shape != (b, g) or not logits.is_contiguous():
+            return
+        tail, tf = tails[0][0], tails[0][2]
+        riders = tail[tf:tf + HF.TAIL_RIDERS]
+        scratch = self.__dict__.get("_count_scratch")
+        if scratch is None or scratch.device != logits.device:
+            scratch = self._count_scratch = torch.zeros(17, dtype=torch.int32, device=logits.device)
+        lib.mggan_sample_counts(b, K, g, logits.data_ptr(), u.data_ptr(), scratch.data_ptr(), riders.data_ptr(), HF._s())
+        self._rider_counts = (riders, u.data_ptr(), b * K)
+
     def _gen_weights(self, gen_idxs):
         """Batch-global 1/count(generator) weights (train.py:94-96) + int32 row targets in (k*b+ped) order."""
         g = self.G.n_gs
@@ -139,11 +164,21 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         counts = torch.empty(g, dtype=torch.int32, device=self.device)
         inv = torch.empty(g, dtype=torch.float32, device=self.device)
         st = HF._s()
+        rider, self._rider_counts = getattr(self, "_rider_counts", None), None
+        check = os.environ.get("MGGAN_CHECK_RIDERS", "0") == "1"  # (tests: a host sync and an exchange of its own)
+        if self.dist.enabled and rider is not None and rider[2] == row_gen.numel():
+            # the global counts came with the discriminator step's gradient exchange (_ride_generator_counts)
+            if check:
+                lib.mggan_gen_counts(row_gen.data_ptr(), row_gen.numel(), g, counts.data_ptr(), inv.data_ptr(), 0, 0, st)
+                self.dist.all_reduce_(counts, what="count (check)")
+                assert torch.equal(counts.double().cpu(), rider[0][:g].cpu()), (counts.cpu(), rider[0][:g].cpu())
+            lib.mggan_inv_counts_f64(rider[0].data_ptr(), g, inv.data_ptr(), st)
+            return row_gen, inv
         # (padded batch: the rows of phantom pedestrians -- row % b_pad >= n_real -- are not counted)
         lib.mggan_gen_counts(row_gen.data_ptr(), row_gen.numel(), g, counts.data_ptr(), inv.data_ptr(), HF._pad_ptr(),
                              HF._PAD["b"], st)
         if self.dist.enabled:
-            self.dist.all_reduce_(counts)
+            self.dist.all_reduce_(counts, what="count")
             lib.mggan_inv_counts(counts.data_ptr(), g, inv.data_ptr(), st)
         return row_gen, inv
 
@@ -264,6 +299,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self.optimizerD.zero_grad()
         self._backward(losses, [self._one] * len(losses))
         HF.mark("D.bwd.end")
+        self._ride_generator_counts(shared, in_xy.size(1))
         self.dist.all_reduce_grads(self.D)
         self.optimizerD.step(self.config.clipping_threshold_d, zero_grad=self.zero_grads_in_step)
         HF.mark("D.opt.end")

@@ -61,28 +61,51 @@ class DistContext:
 
     recorder = None  # a SegmentRecorder while an iteration is being captured into HIP graphs
     devcomm = None   # mggan.devcomm.DeviceComm: the collectives as plain kernels over peer-mapped memory
+    n_collectives = 0  # exchanges ISSUED by this rank since reset_count() (whatever the transport; tests assert the
+    collective_log = None  # schedule: DESIGN section 6) -- and, when a list, their names in issue order
 
-    def _collective(self, t):
-        """Sum `t` over the ranks in place.  Preferred: the peer-mapped kernel (mggan/devcomm.py) -- an ordinary
-        launch on the current stream, capturable, so the sharded iteration stays ONE graph.  Otherwise
-        torch.distributed: while an iteration is being captured that collective CUTS the graph (the kernels queued so
-        far become one graph segment, the collective stays an eager call replayed between the segments)."""
-        if self.devcomm is not None and self.devcomm.supports(t):
-            self.devcomm.all_reduce_(t)
+    def count_collective(self, what):
+        self.n_collectives += 1
+        if self.collective_log is not None:
+            self.collective_log.append(what)
+
+    def reset_count(self, log=False):
+        self.n_collectives = 0
+        self.collective_log = [] if log else None
+
+    def _collective(self, t, tail=None, what="all_reduce"):
+        """Sum `t` over the ranks in place -- and, in the SAME exchange, an optional f64 `tail` (the per-rank sums that ride
+        with a gradient buffer).  Preferred: the peer-mapped kernel (mggan/devcomm.py) -- an ordinary launch on the
+        current stream, capturable, so the sharded iteration stays ONE graph.  Otherwise torch.distributed: while an
+        iteration is being captured that collective CUTS the graph (the kernels queued so far become one graph segment,
+        the collective stays an eager call replayed between the segments); vector and tail then travel as one f64
+        buffer."""
+        self.count_collective(what)
+        if self.devcomm is not None and self.devcomm.supports(t, tail):
+            self.devcomm.all_reduce_(t, tail)
             return
         group = self.group
 
-        def run():
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        def exchange():
+            if tail is None:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                return
+            n = t.numel()
+            buf = torch.cat([t.reshape(-1).double(), tail.reshape(-1)])
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            t.reshape(-1).copy_(buf[:n])
+            tail.reshape(-1).copy_(buf[n:])
+
+        run = exchange
 
         if self.recorder is not None:
             self.recorder.cut(run)
         else:
             run()
 
-    def all_reduce_(self, t):
+    def all_reduce_(self, t, what="all_reduce"):
         if self.enabled:
-            self._collective(t)
+            self._collective(t, what=what)
         return t
 
     def all_reduce_stats(self, sums, n_local):
@@ -90,12 +113,13 @@ class DistContext:
         if not self.enabled:
             return n_local
         if self.equal_shards:  # every rank holds n_local images: no count exchange, no host read-back
-            self._collective(sums)
+            self._collective(sums, what="bn.stats")
             return float(n_local) * self.world_size
         if self.recorder is not None or (sums.is_cuda and torch.cuda.is_current_stream_capturing()):
             raise RuntimeError("graph capture of a sharded iteration needs equal shards (the global image count of "
                                "unequal shards is read back to the host)")
         buf = torch.cat([sums, sums.new_tensor([float(n_local)])])
+        self.count_collective("bn.stats")
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         sums.copy_(buf[:-1])
         return float(buf[-1].item())
@@ -108,6 +132,7 @@ class DistContext:
         if self.recorder is not None:
             raise RuntimeError("graph capture of a sharded iteration needs equal shards")
         t = torch.tensor([float(n_local)], dtype=torch.float64, device=self._dev)
+        self.count_collective("count")
         dist.all_reduce(t, group=self.group)
         return float(t.item())
 
@@ -116,12 +141,23 @@ class DistContext:
     _dev = "cpu"
 
     def all_reduce_grads(self, root):
-        """C1: one collective over the whole flat gradient buffer."""
+        """C1: one collective over the whole flat gradient buffer -- and, riding in it, the f64 tail a sharded scene-CNN
+        backward pass of this step left on the root (mggan/hip/functions.py, SceneAttentionFn.backward: this rank's raw
+        conv1 weight-gradient and BatchNorm-1 adjoint sums); its finalize runs right behind the exchange, identically on
+        every rank, and adds the global-batch dW1 / dgamma1 / dbeta1 into slots that held zeros during the exchange."""
         if self.enabled:
             from mggan.hip.functions import join_side_stream
 
             join_side_stream()
-            self._collective(root._flat_grad)
+            tails = root.__dict__.pop("_grad_tails", [])
+            if len(tails) > 1:
+                raise RuntimeError("one scene-CNN backward pass per root and optimizer step ({} tails)".format(len(tails)))
+            if tails:
+                tail, finalize = tails[0][0], tails[0][1]
+                self._collective(root._flat_grad, tail, what="gradients+conv1.tail")
+                finalize()
+            else:
+                self._collective(root._flat_grad, what="gradients")
 
     def close(self):
         """Unmap / free the peer-mapped arenas (a process that builds several trainers in a row)."""
@@ -143,7 +179,8 @@ class DistContext:
 
             # slot capacity from the largest vector this trainer reduces (the flat gradient buffers; f32 = half an
             # 8-byte element each), rounded up to a power of two; every rank builds the same models
-            need = max([(r._flat_grad.numel() + 1) // 2 for r in roots if getattr(r, "_flat_grad", None) is not None] + [1])
+            # (+ 1,024 doubles: the f64 tail that rides with a gradient buffer, 608 at C = 16, behind a 256-byte boundary)
+            need = max([(r._flat_grad.numel() + 1) // 2 + 1024 for r in roots if getattr(r, "_flat_grad", None) is not None] + [1])
             cap = 1 << 16
             while cap < need:
                 cap <<= 1
@@ -155,7 +192,8 @@ class DistContext:
         otherwise capture_iteration uses graph segments with the collectives between them."""
         if self.devcomm is None or not self.equal_shards:
             return False
-        return all(r._flat_grad is None or self.devcomm.supports(r._flat_grad) for r in roots)
+        return all(r._flat_grad is None or self.devcomm.supports(r._flat_grad, torch.empty(608, dtype=torch.float64))
+                   for r in roots)
 
     def check(self, sync=False):
         """Raise if a peer-mapped collective has timed out (sync=False: a host read, free; the training loop calls it every

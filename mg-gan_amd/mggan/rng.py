@@ -139,6 +139,13 @@ class DeviceRNG:
     def randn(self, *shape):
         return torch.randn(*shape, device="cuda")
 
+    def peek_uniforms(self, n, device):
+        """The uniforms the NEXT sampling call of n picks will consume (not advanced), or None when that call would draw
+        afresh -- sharded training counts the generator step's picks ahead of time (mggan_sample_counts)."""
+        if self._unif is not None and self._unif.device == torch.device(device) and self._unif_used + n <= self._nu:
+            return self._unif[self._unif_used:self._unif_used + n]
+        return None
+
     def sample_generators(self, logits, num_samples):
         """Inverse-CDF categorical sampling in one HIP launch (torch.multinomial costs ~12 tiny kernels)."""
         from mggan.hip import functions as HF

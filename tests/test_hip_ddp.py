@@ -14,6 +14,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MAX_COLLECTIVES = 13  # exchanges per sharded iteration with global-batch BatchNorm (round 4: 18)
 
 
 def _free_port():
@@ -141,10 +142,21 @@ def _run_graph(rank, world, port, sizes, q, device_comm, backend="gloo", own_dev
     flat = torch.cat([tr.G._flat.cpu(), tr.D._flat.cpu()])
     steps = int(tr.optimizerD.seg_step.max().cpu())
     one_graph = isinstance(replay.graph, torch.cuda.CUDAGraph)
+    # the exchange schedule of one iteration, counted on an eager iteration behind the replays
+    tr.dist.reset_count(log=True)
+    tr.train_iteration(batch, defaultdict(list))
+    torch.cuda.synchronize()
+    schedule = list(tr.dist.collective_log)
+    # ... and the generator counts that rode with the discriminator step's gradients are the counts of the picks
+    os.environ["MGGAN_CHECK_RIDERS"] = "1"
+    tr.train_iteration(batch, defaultdict(list))
+    torch.cuda.synchronize()
+    os.environ["MGGAN_CHECK_RIDERS"] = "0"
+    assert "count (check)" in tr.dist.collective_log, tr.dist.collective_log
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, flat.numpy(), 1 if one_graph else replay.graph.n_graphs, steps,
-           {k: v for k, v in m.items() if "probs" not in k}, tr.dist.devcomm is not None, sync, tr.launch_mode))
+           {k: v for k, v in m.items() if "probs" not in k}, tr.dist.devcomm is not None, sync, tr.launch_mode, schedule))
 
 
 def _launch_graph(world, sizes, device_comm, backend="gloo", own_device=False):
@@ -163,9 +175,19 @@ def _launch_graph(world, sizes, device_comm, backend="gloo", own_device=False):
 
 
 def _check_replicas(res, replays=3):
-    (_, f0, n0, s0, m0, _, sync0, _) = res[0]
+    (_, f0, n0, s0, m0, _, sync0, _, sched0) = res[0]
+    # <= 13 exchanges per iteration (round 4: 18): ONE Gram all-reduce serves the layer-1 forward statistics of the passes
+    # issued behind it (default schedule `late`: two passes come before it and exchange their own sums; MGGAN_GRAM_SCHEDULE
+    # =first: none, 11 exchanges, the iteration waits for the matrix); the three layer-1 adjoints and the generator counts
+    # ride with the three gradient all-reduces; layer 2 keeps its 4 + 3 synchronisation points (the floor with
+    # global-batch BatchNorm is 10: DESIGN section 6)
+    assert len(sched0) <= MAX_COLLECTIVES, sched0
+    assert sum("gradients" in w for w in sched0) == 3 and sum(w.startswith("bn1") for w in sched0) <= 2, sched0
+    assert "count" not in sched0 and sched0.count("gram") == 1, sched0
+    assert not [w for w in sched0 if w == "bn1.backward"], sched0
     assert np.isfinite(f0).all() and 0.2 < m0["train/discr_loss"][-1] < 3.0
-    for (_, f1, n1, s1, m1, _, sync1, _) in res[1:]:
+    for (_, f1, n1, s1, m1, _, sync1, _, sched1) in res[1:]:
+        assert sched1 == sched0  # every rank issues the same exchanges in the same order
         assert n0 == n1 and sync0 and sync1
         assert s0 == s1 == 2 + replays         # 2 eager warm-up iterations + the replays (capturing executes nothing)
         assert np.array_equal(f0, f1)          # replicas stay bit-identical through the replays
@@ -291,7 +313,7 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
-                          "--config", "c1", "--also", "", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                          "--config", "c1", "--also", "", "--no-cpu-baseline", "--transport-ab"], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

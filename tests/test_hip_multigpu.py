@@ -50,7 +50,7 @@ def test_sharded_iteration_rccl_segments_across_devices(world):
 def test_bench_self_launch_across_devices():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
-                          "--also", "", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                          "--also", "", "--no-cpu-baseline", "--transport-ab"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0
