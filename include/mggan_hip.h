@@ -516,7 +516,10 @@ int mggan_inv_counts_f64(const double* counts, int g, float* inv_count, mggan_st
  * active[s] = segment takes part in this step (grad not None), seg_step[s] = Adam step count.
  * zero_grad != 0: the consumed gradients are left at 0 instead of their clipped values (saves the caller's
  * memset before the next backward pass).  lr_dev != NULL: the learning rate is read from that device word instead of
- * `lr` (a captured HIP graph then follows the per-epoch schedule without being captured again). */
+ * `lr` (a captured HIP graph then follows the per-epoch schedule without being captured again).
+ * ONE launch (gradient norm, clipping, update): workspace = 258 doubles that are ZERO before the first call (partial sums
+ * and the two counters of the launch's grid barrier; every launch leaves them ready for the next).  One workspace per
+ * optimizer; launches that share one must be ordered by their stream. */
 int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, const int* elem_seg, int nseg,
                      const unsigned char* active, int* seg_step, float max_norm, double lr, const double* lr_dev,
                      double beta1, double beta2, double eps, double weight_decay, int zero_grad, double* workspace,

@@ -907,13 +907,17 @@ int mggan_bn_finalize(const double* sums, double count, int C, int training, con
   return MGGAN_OK;
 }
 
-// persistent: a workgroup walks images b, b + grid, ... (its waves' weight fragments are loaded once); every workgroup
-// gets the same number of images (+-1), at most 1,024 workgroups (MGGAN_ATTN_GRID: exactly that many, A/B measurements)
+// persistent: a workgroup walks images b, b + grid, ... (its waves' weight fragments are loaded once): FOUR images per
+// workgroup up to 2,048 workgroups, beyond that equal shares.  Measured (iteration, one box, MGGAN_ATTN_GRID = exactly that
+// many): 1,280 images -- 160: 1.411, 320: 1.405, 428: 1.419, 640: 1.416-1.438, 1,280: 1.482 ms (a workgroup's partial block,
+// ticket and weight fragments cost more than its second, third, fourth image); 8,192 images -- 1,024: 4.86, 2,048: 4.74,
+// 4,096: 4.91, 8,192: 5.11 ms.
 static int attn_grid(int B) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("MGGAN_ATTN_GRID"); forced = e ? atoi(e) : 0; }
   if (forced > 0) return forced < B ? forced : B;
-  return cdiv(B, cdiv(B, 1024));
+  const int per = cdiv(B, 2048) > 4 ? cdiv(B, 2048) : 4;
+  return cdiv(B, per);
 }
 
 int mggan_scene_attention_grid(int B) { return B > 0 ? attn_grid(B) : 0; }

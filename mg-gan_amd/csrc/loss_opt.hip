@@ -537,18 +537,34 @@ __global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ 
 }
 
 // ---- clip_grad_norm_ + AdamW over a flat parameter buffer with a segment table ---------------
-#define NORM_BLOCKS 256
-__global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float* __restrict__ grad, long n,
-                                                               const int* __restrict__ elem_seg,
-                                                               const unsigned char* __restrict__ active,
-                                                               double* partial, int nseg, int* seg_step) {
+// ONE launch (round 5; before: a 256-workgroup norm pass and the update pass, 5 + 8-12 us with the gap between them on the
+// serial tail of all three optimizer steps of an iteration).  A workgroup first sums the squares of the very gradient
+// elements it is going to update, publishes the partial, and waits -- a grid barrier on a per-optimizer counter that only
+// ever grows: the grid is at most CA_MAX_BLOCKS workgroups of 256 threads, all resident at once, and a waiting workgroup
+// holds up nobody it waits for -- until every partial is there; then every workgroup adds the partials in index order (the
+// same total everywhere, bit for bit, run after run) and updates its elements.
+#define CA_MAX_BLOCKS 256
+__device__ __forceinline__ void ca_store(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ca_load(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+// workspace: [CA_MAX_BLOCKS partial sums | arrival counter | finished counter (64-bit integers)], zero before the first launch
+__global__ __launch_bounds__(256) void clip_adamw_kernel(float* param, float* grad, float* m, float* v, long n,
+                                                         const int* __restrict__ elem_seg,
+                                                         const unsigned char* __restrict__ active, int nseg,
+                                                         int* seg_step, double* workspace, float max_norm, double lr_arg,
+                                                         const double* __restrict__ lr_dev, double beta1, double beta2,
+                                                         double eps_d, double wd, int zero_grad, float* norm_out) {
   __shared__ double red[256];
-  // Adam step counters of the touched tensors advance here (the update kernel that follows reads them)
-  if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < nseg; i += 256)
-      if (active[i]) seg_step[i] += 1;
+  const double lr = lr_dev ? *lr_dev : lr_arg;  // device-resident: a captured graph follows the schedule
+  const long stride = (long)gridDim.x * 256, i0 = (long)blockIdx.x * 256 + threadIdx.x;
+  // ---- phase 1: this workgroup's share of the squared norm (f64) ----
   double acc = 0.0;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)NORM_BLOCKS * 256) {
+  for (long i = i0; i < n; i += stride) {
     const int sg = elem_seg[i];
     if (sg >= 0 && active[sg]) acc += (double)grad[i] * (double)grad[i];
   }
@@ -558,19 +574,19 @@ __global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float* __re
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-}
-
-__global__ __launch_bounds__(256) void adamw_kernel(float* param, float* grad, float* m, float* v, long n,
-                                                    const int* __restrict__ elem_seg,
-                                                    const unsigned char* __restrict__ active,
-                                                    const int* __restrict__ seg_step, const double* __restrict__ partial,
-                                                    float max_norm, double lr_arg, const double* __restrict__ lr_dev,
-                                                    double beta1, double beta2, double eps_d, double wd, int zero_grad,
-                                                    float* norm_out) {
-  __shared__ double red[256];
-  const double lr = lr_dev ? *lr_dev : lr_arg;  // device-resident: a captured graph follows the schedule
-  red[threadIdx.x] = threadIdx.x < NORM_BLOCKS ? partial[threadIdx.x] : 0.0;
+  unsigned long long* counter = (unsigned long long*)(workspace + CA_MAX_BLOCKS);
+  if (threadIdx.x == 0) {
+    ca_store(workspace + blockIdx.x, red[0]);
+    __threadfence();
+    const unsigned long long mine = atomicAdd(counter, 1ull);
+    // this launch's arrivals are (mine - mine % grid) .. + grid - 1: launches of one optimizer are ordered by their stream
+    const unsigned long long target = mine - mine % gridDim.x + gridDim.x;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __threadfence();
+  }
+  __syncthreads();
+  // ---- every workgroup: the same fixed-order sum of all partials ----
+  red[threadIdx.x] = threadIdx.x < gridDim.x ? ca_load(workspace + threadIdx.x) : 0.0;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
@@ -580,10 +596,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, float* grad, f
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+  // ---- phase 2: clip + AdamW on the same elements; the Adam step counter of a touched tensor is its old value + 1 (the
+  // counters themselves are advanced by the LAST workgroup to finish its elements: nobody reads them after that)
+  for (long i = i0; i < n; i += stride) {
     const int sg = elem_seg[i];
     if (sg < 0 || !active[sg]) continue;
-    const int t = seg_step[sg];  // already advanced by gradnorm_partial_kernel
+    const int t = seg_step[sg] + 1;
     const float g = grad[i] * coef;
     grad[i] = zero_grad ? 0.f : g;  // clip_grad_norm_ scales .grad in place; or leave it zeroed for the next step
     // torch.optim.AdamW single-tensor path: scalar factors in double, tensor math in f32
@@ -597,6 +615,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* param, float* grad, f
     p -= (float)(lr / bc1) * (mi / denom);
     param[i] = p;
   }
+  __shared__ int last;
+  __syncthreads();
+  unsigned long long* done = counter + 1;
+  if (threadIdx.x == 0) {
+    const unsigned long long d = atomicAdd(done, 1ull);
+    last = d == gridDim.x - 1;
+    if (last) __hip_atomic_store(done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (last)
+    for (int i = threadIdx.x; i < nseg; i += 256)
+      if (active[i]) seg_step[i] += 1;
 }
 
 __global__ void adam_inc_kernel(int nseg, const unsigned char* __restrict__ active, int* seg_step) {
@@ -1296,19 +1326,18 @@ int mggan_inv_counts(const int* counts, int g, float* inv_count, hipStream_t str
   return MGGAN_OK;
 }
 
-/* workspace: 256 doubles */
+/* workspace: 258 doubles, ZERO before the first call (partial sums + the grid barrier's two counters; left ready for the next) */
 int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, const int* elem_seg, int nseg,
                      const unsigned char* active, int* seg_step, float max_norm, double lr, const double* lr_dev,
                      double beta1, double beta2, double eps, double weight_decay, int zero_grad, double* workspace,
                      float* norm_out, hipStream_t stream) {
   MG_CHECK_ARG(param && grad && m && v && elem_seg && active && seg_step && workspace, "clip_adamw: null pointer");
   if (n == 0) return MGGAN_OK;
-  MG_LAUNCH(gradnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, grad, n, elem_seg, active,
-                     workspace, nseg, seg_step);
+  // workspace: 258 doubles (mggan_clip_adamw_workspace), zeroed once by the caller
   int blocks = cdiv(n, 256 * 4);
-  if (blocks > 1024) blocks = 1024;
-  MG_LAUNCH(adamw_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, m, v, n, elem_seg, active, seg_step,
-                     workspace, max_norm, lr, lr_dev, beta1, beta2, eps, weight_decay, zero_grad, norm_out);
+  if (blocks > CA_MAX_BLOCKS) blocks = CA_MAX_BLOCKS;
+  MG_LAUNCH(clip_adamw_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, m, v, n, elem_seg, active, nseg, seg_step,
+            workspace, max_norm, lr, lr_dev, beta1, beta2, eps, weight_decay, zero_grad, norm_out);
   MG_LAUNCH_CHECK("clip_adamw");
   return MGGAN_OK;
 }

@@ -19,7 +19,8 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros_like(f)
         self.nseg = len(root._flat_items)
         self.seg_step = torch.zeros(self.nseg, dtype=torch.int32, device=f.device)
-        self._ws = torch.zeros(256, dtype=torch.float64, device=f.device)
+        # (mggan_clip_adamw: 256 partial sums + the two counters of its grid barrier; zero once, the launches keep it ready)
+        self._ws = torch.zeros(264, dtype=torch.float64, device=f.device)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=f.device)
         self._flat_id = f.data_ptr()
         # the learning rate the kernel reads lives on the device: a captured iteration follows the schedule
