@@ -881,6 +881,9 @@ static int persistent_grid(int B) {
   // so with 1,280 images the first 256 workgroups get three and the other 256 two -- five per CU if the dispatcher
   // deals workgroups round-robin -- where ceil(B / 3) = 427 equal workgroups left a third of the CUs with one
   // workgroup and the rest with two (six images)
+  static int knob = -1;  // MGGAN_CNN_BWD_GRID: measurement knob -- exactly this many workgroups
+  if (knob < 0) { const char* e = getenv("MGGAN_CNN_BWD_GRID"); knob = e ? atoi(e) : 0; }
+  if (knob > 0) return B < knob ? B : knob;
   return B <= 512 ? B : 512;
 }
 

@@ -6,6 +6,7 @@ tensors are storage only.  Parameter gradients are accumulated by the kernels
 into the root module's flat gradient buffer (hip/flat.py), so backward returns
 None for parameter inputs.
 """
+import contextlib
 import ctypes
 import json
 import os
@@ -2234,6 +2235,20 @@ def d_rows_lean_ok(D, in_enc, scene, pred, K, soc_blocks, row0):
     return pred.shape[0] == 12 and tuple(pe[0].weight.shape) == (64, 24) and tuple(pe[2].weight.shape) == (32, 64)
 
 
+# Blocks 1 .. K-1 of the frozen discriminator's row pass beside block 0's chain of small launches (branch stream 3), forward
+# and backward: -12 us per iteration at 25,600 rows (three alternating pairs on one box: 1.450-1.455 vs 1.463-1.466 ms), +15 us
+# at 163,840 rows, where the big launch fills the chip by itself (5.129-5.138 vs 5.108-5.124 ms).  MGGAN_DROWS_BRANCH=0 / 1
+# forces it off / on.
+_DROWS_KNOB = os.environ.get("MGGAN_DROWS_BRANCH", "")
+DROWS_BRANCH_MAX_ROWS = 65536
+
+
+def _drows_branch(R):
+    if _DROWS_KNOB in ("0", "1"):
+        return _DROWS_KNOB == "1"
+    return R <= DROWS_BRANCH_MAX_ROWS
+
+
 class DRowsLeanFn(Function):
     """The K-sample row pass of a FROZEN discriminator (the generator step, the evaluation passes) in its lean form
     (discriminators.py:113-219, pool_type 'sways', unmasked):
@@ -2257,34 +2272,40 @@ class DRowsLeanFn(Function):
         fc, Wat = D.social.feature_embedder.fc, D.social.attention.W
         W, c_in, c_pe, c_sc = 192, 64, 96, 128
         g, act = r[2].weight.shape[0], D._out_act()
-        # ---- block 0 ----
+        # Block 0 (the b rows with social features: pred_encoder -> social attention -> heads, six small launches in a row)
+        # and blocks 1 .. K-1 (one launch) meet only in the outputs: what the big launch needs -- P, the per-pedestrian part of
+        # the heads' first layers, from the in_enc and scene columns of X -- is produced first, then the big launch goes to
+        # branch stream 3 beside block 0's chain (configs[1]: 25 us of the 160 us between the rollout and its adjoint).
         X = _empty(b, W, like=in_enc)
         Wpe, bpe = (pe[0].weight, pe[2].weight), (pe[0].bias, pe[2].bias)
+        wa = (d0[0].weight, d0[0].bias, d0[2].weight, d0[2].bias)
+        wb = (r[0].weight, r[0].bias, r[2].weight, r[2].bias)
+        lib.mggan_d_rows_fill(b, 1, 1, c_in, c_in, c_pe - c_in, c_sc, 0, _p(in_enc), ld_in, 0, 0, _p(X), W, st)
+        join_branch(scene)  # the scene CNN's branch has to be there now
+        lib.mggan_d_rows_fill(b, 1, 1, 0, 0, 0, c_sc, W - c_sc, 0, 0, _p(scene), ld_sc, _p(X), W, st)
+        P = _empty(b, W, like=X)
+        lib.mggan_dheads_shared(_p(X), W, b, c_in, c_sc, _p(wa[0]), _p(wa[1]), _p(wb[0]), _p(wb[1]), _p(P), st)
+        ya, yb = _empty(R, 1, like=X), _empty(R, g, like=X)
+        # ---- blocks 1 .. K-1 (rows b .. R-1 of ya / yb) ----
+        mask = torch.empty(-(-(R - b) // 16) * 64, dtype=torch.int64, device=X.device) if save else None
+        with branch(3) if _drows_branch(R) else contextlib.nullcontext():
+            lib.mggan_d_rows_lean_fwd(_p(pred), T, b, R, b, g, act, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(P), c_pe,
+                                      _p(wa[0]), _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[2]), _p(wb[3]), _p(mask), _p(ya), _p(yb),
+                                      _s())
+        # ---- block 0 (rows 0 .. b-1) ----
         x0 = _empty(b, 2 * T, like=in_enc) if save else None
         h_pe0 = _empty(b, 64, like=in_enc) if save else None
         lib.mggan_pred_encoder_fwd(_p(pred), 0, T, R, b, b, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(X), W, c_pe,
                                    _p(h_pe0), _p(x0), st)
         outs_pe = [h_pe0, None]
-        lib.mggan_d_rows_fill(b, 1, 1, c_in, c_in, c_pe - c_in, c_sc, 0, _p(in_enc), ld_in, 0, 0, _p(X), W, st)
         xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
         sw = (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, Wat.weight, Wat.bias)
         soc_saved = _social_fwd(xy_last, dxdy_last, _p(X) + 4 * c_in, W, b, c_sc - c_in, tb, *sw, _p(X), W, save, 0, X)
-        join_branch(scene)  # the scene CNN's branch only has to be there now
-        lib.mggan_d_rows_fill(b, 1, 1, 0, 0, 0, c_sc, W - c_sc, 0, 0, _p(scene), ld_sc, _p(X), W, st)
-        wa = (d0[0].weight, d0[0].bias, d0[2].weight, d0[2].bias)
-        wb = (r[0].weight, r[0].bias, r[2].weight, r[2].bias)
-        P = _empty(b, W, like=X)
-        lib.mggan_dheads_shared(_p(X), W, b, c_in, c_sc, _p(wa[0]), _p(wa[1]), _p(wb[0]), _p(wb[1]), _p(P), st)
         ha = _empty(b, 96, like=X) if save else None
         hb = _empty(b, 96, like=X) if save else None
-        ya, yb = _empty(R, 1, like=X), _empty(R, g, like=X)
         lib.mggan_dheads_fwd(_p(X), W, b, g, act, _p(wa[0]), _p(wa[1]), _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[1]),
                              _p(wb[2]), _p(wb[3]), _p(ha), _p(hb), _p(ya), _p(yb), st)
-        # ---- blocks 1 .. K-1 ----
-        mask = torch.empty(-(-(R - b) // 16) * 64, dtype=torch.int64, device=X.device) if save else None
-        lib.mggan_d_rows_lean_fwd(_p(pred), T, b, R, b, g, act, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(P), c_pe,
-                                  _p(wa[0]), _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[2]), _p(wb[3]), _p(mask), _p(ya), _p(yb),
-                                  st)
+        join_branch(ya, yb, mask, P, which=3)
         if save:
             ctx.cfg = (D, tb, K, b, T, pshape, g, act)
             ctx.save_for_backward(X, x0, outs_pe[0], xy_last, dxdy_last, ha, ya, hb, mask, *soc_saved)
@@ -2304,8 +2325,11 @@ class DRowsLeanFn(Function):
         dya = torch.zeros(R, 1, dtype=F32, device=ya.device) if dya is None else dya.reshape(R, 1).contiguous()
         dyb = torch.zeros(R, g, dtype=F32, device=ya.device) if dyb is None else dyb.reshape(R, g).contiguous()
         dpred = _empty(T, R, 2, like=ya)
-        lib.mggan_d_rows_lean_bwd(_p(dya), _p(dyb), _p(ya), _p(mask), T, b, R, g, act, _p(pe[0].weight), _p(pe[2].weight),
-                                  c_pe, _p(d0[0].weight), _p(d0[2].weight), _p(r[0].weight), _p(r[2].weight), _p(dpred), st)
+        # blocks 1 .. K-1 (rows b .. R-1 of dpred) on branch stream 3 beside block 0's chain (rows 0 .. b-1)
+        with branch(3) if _drows_branch(R) else contextlib.nullcontext():
+            lib.mggan_d_rows_lean_bwd(_p(dya), _p(dyb), _p(ya), _p(mask), T, b, R, g, act, _p(pe[0].weight), _p(pe[2].weight),
+                                      c_pe, _p(d0[0].weight), _p(d0[2].weight), _p(r[0].weight), _p(r[2].weight), _p(dpred),
+                                      _s())
         # block 0: heads -> social attention (dh added into the in_enc | pred_enc columns) -> pred_encoder
         dX = _empty(b, W, like=ya)
         lib.mggan_dheads_bwd_data(_p(dya), _p(dyb), _p(ya), _p(ha), _p(hb), b, g, act, _p(d0[0].weight), _p(d0[2].weight),
@@ -2317,6 +2341,7 @@ class DRowsLeanFn(Function):
         dx0 = _chain_bwd(alias_cols(dX, c_pe, c_sc), W, x0, 2 * T, b, (h_pe, alias_cols(X, c_pe, c_sc)), spec_pe,
                          (pe[0].weight, pe[2].weight), (pe[0].bias, pe[2].bias), True, False, pe[0], ld_last=W)
         lib.mggan_rows_to_steps_n(_p(dx0), 2 * T, T, b, R, _p(dpred), st)
+        join_branch(dpred, which=3)
         return (None, None, dpred.view(pshape)) + (None,) * 6
 
 
