@@ -665,10 +665,14 @@ size_t mggan_wgrad_workspace_bytes(int rows, int K, int N, int n_groups) {
 // partials for 73 MB of operands), and there are at most 256 slabs per problem (a wave of the reduction then walks at most
 // 32 rows; the problems of a batch fill the chip together, not each on its own); never less than 128 rows.
 static int stream_slab_rows(int rows, int K, int N) {
+  static int factor = -1;  // MGGAN_WGRAD_SLAB_FACTOR: partial block <= 1/factor of the operands (measurement knob)
+  if (factor < 0) { const char* e = getenv("MGGAN_WGRAD_SLAB_FACTOR"); factor = e ? atoi(e) : 8; if (factor < 1) factor = 1; }
   int s = cdiv(cdiv(rows, 256), 64) * 64;
-  const int by_output = cdiv(cdiv(8L * N * (K + 1), K + N), 64) * 64;
+  const int by_output = cdiv(cdiv((long)factor * N * (K + 1), K + N), 64) * 64;
   if (by_output > s) s = by_output;
-  return s < 128 ? 128 : s;
+  static int floor_rows = -1;  // MGGAN_WGRAD_SLAB_MIN
+  if (floor_rows < 0) { const char* e = getenv("MGGAN_WGRAD_SLAB_MIN"); floor_rows = e ? atoi(e) : 128; if (floor_rows < 64) floor_rows = 64; }
+  return s < floor_rows ? floor_rows : s;
 }
 
 static StreamProb stream_problem(const float* dZ, const float* X, float* workspace, int rows, int K, int N, int lddz,

@@ -1322,7 +1322,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // waves per SIMD (the compiler parked them in scratch and fetched them back every step)
   __shared__ __attribute__((aligned(16))) float ahs[2][64][36];
   extern __shared__ __attribute__((aligned(16))) float tailw[];  // W_e2d[:, :EIN] (H x e2ld, dEnc only) | W1[:, H:] (Hh x 36)
-  const int gi = blockIdx.x / p.NW, wi = blockIdx.x % p.NW;
+  // Workgroups b and b + 256 share a CU (512 workgroups dealt round-robin over 256 CUs), i.e. generator gi and gi + n/2.  A
+  // generator's tiles beyond its first round go to its FIRST workgroups; the upper half of the generators walks its
+  // workgroups backwards, so that the second-round tiles of two generators that share CUs land on different ones (configs[1]:
+  // 1,600 tiles on 1,024 slots -- 72 CUs of a generator pair carried four second-round tiles and 56 none).
+  const int gi = blockIdx.x / p.NW, n_g = gridDim.x / p.NW;
+  const int wi = (2 * gi >= n_g && n_g > 1) ? p.NW - 1 - (int)(blockIdx.x % p.NW) : (int)(blockIdx.x % p.NW);
   // (the wave index in a scalar register: slot, tile and the tile's record bases are then scalars and the per-lane part of
   // every saved-state address is a 32-bit offset -- as 64-bit per-lane pointers they did not fit)
   const int lane = threadIdx.x & 63, w = mg_wave(), fi = lane & 15, fk = lane >> 4;
