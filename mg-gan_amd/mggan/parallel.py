@@ -78,23 +78,22 @@ class DistContext:
         with a gradient buffer).  Preferred: the peer-mapped kernel (mggan/devcomm.py) -- an ordinary launch on the
         current stream, capturable, so the sharded iteration stays ONE graph.  Otherwise torch.distributed: while an
         iteration is being captured that collective CUTS the graph (the kernels queued so far become one graph segment,
-        the collective stays an eager call replayed between the segments); vector and tail then travel as one f64
-        buffer."""
+        the collective stays an eager call replayed between the segments); the tail is then a second call (counted)."""
         self.count_collective(what)
+        if tail is not None and not (self.devcomm is not None and self.devcomm.supports(t, tail)):
+            self.count_collective(what + " (tail: second call)")
         if self.devcomm is not None and self.devcomm.supports(t, tail):
             self.devcomm.all_reduce_(t, tail)
             return
         group = self.group
 
         def exchange():
-            if tail is None:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-                return
-            n = t.numel()
-            buf = torch.cat([t.reshape(-1).double(), tail.reshape(-1)])
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            t.reshape(-1).copy_(buf[:n])
-            tail.reshape(-1).copy_(buf[n:])
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            if tail is not None:
+                # (a second call: packing vector and tail into one f64 buffer needs allocations between the replays of the
+                #  graph segments, and those made the segment replay fault at 8,192 pedestrians -- "write access to a
+                #  read-only page", every run; the calls below touch only memory that existed when the capture ended)
+                dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group)
 
         run = exchange
 

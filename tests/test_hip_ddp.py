@@ -175,7 +175,10 @@ def _launch_graph(world, sizes, device_comm, backend="gloo", own_device=False):
 
 
 def _check_replicas(res, replays=3):
-    (_, f0, n0, s0, m0, _, sync0, _, sched0) = res[0]
+    (_, f0, n0, s0, m0, peer_mapped, sync0, _, sched0) = res[0]
+    if not peer_mapped:  # torch.distributed between graph segments: the f64 tail of a gradient exchange is a second call
+        assert sum("second call" in w for w in sched0) == 3, sched0
+        sched0 = [w for w in sched0 if "second call" not in w]
     # <= 13 exchanges per iteration (round 4: 18): ONE Gram all-reduce serves the layer-1 forward statistics of the passes
     # issued behind it (default schedule `late`: two passes come before it and exchange their own sums; MGGAN_GRAM_SCHEDULE
     # =first: none, 11 exchanges, the iteration waits for the matrix); the three layer-1 adjoints and the generator counts
@@ -187,7 +190,7 @@ def _check_replicas(res, replays=3):
     assert not [w for w in sched0 if w == "bn1.backward"], sched0
     assert np.isfinite(f0).all() and 0.2 < m0["train/discr_loss"][-1] < 3.0
     for (_, f1, n1, s1, m1, _, sync1, _, sched1) in res[1:]:
-        assert sched1 == sched0  # every rank issues the same exchanges in the same order
+        assert [w for w in sched1 if "second call" not in w] == sched0  # the same exchanges in the same order on every rank
         assert n0 == n1 and sync0 and sync1
         assert s0 == s1 == 2 + replays         # 2 eager warm-up iterations + the replays (capturing executes nothing)
         assert np.array_equal(f0, f1)          # replicas stay bit-identical through the replays
