@@ -210,3 +210,47 @@ def test_folded_weights_are_cached_per_weight_version():
     f_off, w_off = run(False)
     assert (f_on, f_off) == (4, 7), (f_on, f_off)
     assert bool(torch.isfinite(w_on).all()) and torch.equal(w_on, w_off)
+
+
+def test_replay_after_an_external_weight_write_refolds_the_lstm_weights():
+    """A steady-state graph folds a module's LSTM weights only behind the optimizer step that changed them and reads, at its
+    start, what the previous iteration left in the folded buffers.  Weights written between two replays
+    behind the trainer's back -- load_state_dict here -- must reach the next replay: the trainer sees the write in its
+    host-side fingerprint and re-folds first.  Reference run: the same sequence with eager launches."""
+    import bench
+    from mggan.data_utils import synthetic
+
+    dev = torch.device("cuda", 0)
+
+    def run(graph):
+        tr = bench.build_trainer(3, "device", dev)
+        torch.cuda.manual_seed(4321)
+        batch = tr.to_device(synthetic.make_batch(synthetic.scene_sizes(10, 5), seed=3))
+        batch["loss_mask"] = None
+        tr.defer_metrics = True
+        tr.zero_grads_in_step = True
+        m = defaultdict(list)
+        g0 = {k: v.detach().clone() for k, v in tr.G.state_dict().items()}
+        d0 = {k: v.detach().clone() for k, v in tr.D.state_dict().items()}
+        if graph:
+            replay = tr.capture_iteration(batch, warmup=1)
+            step = lambda: replay(m, False)
+        else:
+            tr.train_iteration(batch, m)
+            step = lambda: tr.train_iteration(batch, m)
+        step()
+        step()
+        # back to the initial weights (BatchNorm statistics included), Adam moments kept: only a re-fold makes the encoders /
+        # decoders of the next replay see them
+        tr.G.load_state_dict(g0)
+        tr.D.load_state_dict(d0)
+        step()
+        step()
+        tr.flush_metrics()
+        torch.cuda.synchronize()
+        return torch.cat([tr.G._flat.clone(), tr.D._flat.clone()]).cpu()
+
+    ref = run(False)
+    got = run(True)
+    assert bool(torch.isfinite(ref).all())
+    assert torch.equal(got, ref)
