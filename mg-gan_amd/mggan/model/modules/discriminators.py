@@ -66,7 +66,7 @@ class MultiDiscriminatorTrajectory(FlatModule):
             pred_enc = pad.index_copy(0, mask.repeat(n_samples).nonzero().flatten(), pred_enc)
         return torch.cat([in_enc.repeat(n_samples, 1), pred_enc], dim=1)
 
-    def history_context(self, in_dxdy, img, passes=1, lstm_branch=None):
+    def history_context(self, in_dxdy, img, passes=1, lstm_branch=None, lstm_first=False, defer_cnn=None):
         """(in_enc (b,h/2), scene (b,64)): everything that depends only on the observed history and the
         image crop.  The real and the fake pass of one discriminator step share it (identical inputs and
         weights), autograd sums their cotangents, so the history LSTM and the scene CNN run forward and
@@ -75,15 +75,39 @@ class MultiDiscriminatorTrajectory(FlatModule):
         stream `lstm_branch` (the caller joins both before it uses the results)."""
         self.ensure_flat()
         fc = self.in_encoder_fc
-        with HF.branch():  # scene CNN || history LSTM; joined by forward() right before the classifier input
-            HF.mark("Dctx.cnn.begin")
-            scene = self.scene_encoder(img, stat_updates=passes)
-            HF.mark("Dctx.cnn.end")
-        with HF.branch(lstm_branch) if lstm_branch is not None else contextlib.nullcontext():
-            HF.mark("Dctx.lstm.begin")
-            h = self.in_encoder(in_dxdy)
-            in_enc = HF.mlp(h, [(fc[0], HF.ACT_LEAKY, 0.2), (fc[2], HF.ACT_NONE, 0.0)])
-            HF.mark("Dctx.lstm.end")
+        def cnn():
+            with HF.branch():  # scene CNN || history LSTM; joined by forward() right before the classifier input
+                HF.mark("Dctx.cnn.begin")
+                out = self.scene_encoder(img, stat_updates=passes)
+                HF.mark("Dctx.cnn.end")
+            return out
+
+        def lstm():
+            with HF.branch(lstm_branch) if lstm_branch is not None else contextlib.nullcontext():
+                HF.mark("Dctx.lstm.begin")
+                h = self.in_encoder(in_dxdy)
+                out = HF.mlp(h, [(fc[0], HF.ACT_LEAKY, 0.2), (fc[2], HF.ACT_NONE, 0.0)])
+                HF.mark("Dctx.lstm.end")
+            return out
+
+        if defer_cnn is not None:
+            # the LSTM chain now; the scene CNN when the caller's hook fires (defer_cnn(callable): e.g. behind the generator's
+            # sampling launches) -- the result arrives through the returned list
+            in_enc = lstm()
+            box = [in_enc, None]
+
+            def late():
+                with torch.no_grad():
+                    box[1] = cnn()
+
+            defer_cnn(late)
+            return box
+        if lstm_first:  # (both on one stream: the three small launches of the LSTM chain ahead of the CNN's persistent grids)
+            in_enc = lstm()
+            scene = cnn()
+        else:
+            scene = cnn()
+            in_enc = lstm()
         return in_enc, scene
 
     def _encode_parts(self, in_dxdy, pred_dxdy, context=None):

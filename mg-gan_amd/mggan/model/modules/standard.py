@@ -180,6 +180,12 @@ class MultiGenerator(FlatModule):
                 net_chooser_out = logits if logits is not None else self._chooser(enc_h) if self.use_pinet else \
                     self.net_prior.expand(enc_h.size(0), -1)
                 sampled_gen_idxs, rows = self.rng.sample_rows(net_chooser_out, num_samples)  # picks + row tables, one launch
+                # (a caller's hook: work that should start behind the sampling launches but beside the rollouts, e.g. the
+                #  discriminator's scene CNN in the generator step -- its persistent grids, started first, keep the few
+                #  workgroups of the sampling kernels waiting for a CU slot)
+                cb, self._after_sampling = getattr(self, "_after_sampling", None), None
+                if cb is not None:
+                    cb()
             else:
                 net_chooser_out, sampled_gen_idxs = self.get_samples(enc_h, num_samples, logits=logits)
         if rows is not None:

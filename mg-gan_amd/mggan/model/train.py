@@ -55,6 +55,16 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         # branch stream of D's history LSTM in the generator step: 0 = behind D's scene CNN on the same stream,
         # 2 = a third stream (measured slower: the rollout forward next to it loses more than the LSTM gains)
         self.g_step_lstm_branch = int(os.environ.get("MGGAN_G_LSTM_BRANCH", "0"))
+        # ... and, on the same stream, in front of the CNN (1) or behind it (0)
+        # (round 5, three alternating pairs on one box: LSTM chain first 1.380 vs 1.385 ms at 64 x 20, 4.66 vs 4.73 ms at
+        #  256 x 32 -- three small launches get their CU slots before the CNN's persistent grids fill the register files)
+        self.g_step_lstm_first = os.environ.get("MGGAN_G_LSTM_FIRST", "1") == "1"
+        # the same order in the discriminator step (LSTM on the main stream, the CNN forked behind it): 1.408 vs 1.388 ms and
+        # 4.77 vs 4.72 ms -- there the CNN is the longer chain and starts late
+        self.d_step_lstm_first = os.environ.get("MGGAN_D_LSTM_FIRST", "0") == "1"
+        # ... and D's scene CNN of the generator step forked behind the generator's sampling launches (beside the rollouts
+        # only): 1.408 vs 1.395 ms, 4.75 vs 4.69 ms -- lost; kept as a knob
+        self.g_step_cnn_after_sampling = os.environ.get("MGGAN_G_CNN_AFTER_SAMPLING", "0") == "1"
         self.share_trunk = True
         # weight-gradient GEMMs on a side stream during backward, joined in optimizer.step
         self.overlap_wgrad = os.environ.get("MGGAN_OVERLAP_WGRAD", "0") == "1"  # measured: no gain inside a hipGraph (5.5 vs 5.3 ms)
@@ -241,7 +251,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             rows_d = getattr(self.G, "last_rows", None)
             HF.mark("D.fake.end")
         # history LSTM + scene CNN of D are identical in the real and the fake pass: run them once
-        ctx = self.D.history_context(in_dxdy, img, passes=2) if (loss_mask is None and self.share_context) else None
+        ctx = self.D.history_context(in_dxdy, img, passes=2, lstm_first=self.d_step_lstm_first) \
+            if (loss_mask is None and self.share_context) else None
         # the Gram matrix of the image crops starts behind the history LSTM on this stream (by then D's scene CNN on its
         # branch stream is nearly through as well): beside the latency-bound row pass.  (Forked from this stream only: a
         # side stream with two parents inside a capture makes hipStreamEndCapture crash.)
@@ -321,13 +332,22 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                 # D's history LSTM + scene CNN depend on neither G nor (in this step) any gradient: they run on
                 # branch streams (CNN on 0, LSTM on 2) next to the generator's forward pass
                 with torch.no_grad():
-                    ctx_d = self.D.history_context(in_dxdy, img, passes=1, lstm_branch=self.g_step_lstm_branch)
+                    defer = None
+                    if self.g_step_cnn_after_sampling and getattr(self.rng, "on_device", False) and HF._BR["on"]:
+                        defer = lambda fn: setattr(self.G, "_after_sampling", fn)
+                    ctx_d = self.D.history_context(in_dxdy, img, passes=1, lstm_branch=self.g_step_lstm_branch,
+                                                   lstm_first=self.g_step_lstm_first, defer_cnn=defer)
             noise = self.rng.noise(cfg.num_samples, cfg.noise_dim, sub_batches, self.device)
             gen_out, _, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
                                           mask=loss_mask, num_samples=cfg.num_samples,
                                           trunk=None if shared is None else shared.get("g_trunk"),
                                           logits=None if shared is None else shared.get("g_logits"))
             HF.mark("G.gen.end")
+            if isinstance(ctx_d, list):
+                late, self.G._after_sampling = getattr(self.G, "_after_sampling", None), None
+                if late is not None:  # (the generator took a path without the device sampler: the hook never fired)
+                    late()
+                ctx_d = tuple(ctx_d)
             losses, grads, items = [], [], []
             if cfg.l2_loss_type != "none":
                 # min-over-samples L2 (three small launches) beside the discriminator pass on the predictions; autograd
