@@ -31,6 +31,9 @@ from mggan.utils import (expected_sample_idxs, get_selection_indices, thresholde
 M_REAL, M_FAKE, M_CE_D, M_L2, M_ADV, M_CLF, M_PM, M_PROBS = 0, 1, 2, 3, 4, 5, 6, 8
 
 
+_GRAM_LATE = os.environ.get("MGGAN_GRAM_LATE", "0") == "1"
+
+
 class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
     def __init__(self, generator, discriminator, config, writer):
         super().__init__(generator, discriminator, config, writer)
@@ -256,7 +259,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         # the Gram matrix of the image crops starts behind the history LSTM on this stream (by then D's scene CNN on its
         # branch stream is nearly through as well): beside the latency-bound row pass.  (Forked from this stream only: a
         # side stream with two parents inside a capture makes hipStreamEndCapture crash.)
-        HF.launch_images()
+        if not _GRAM_LATE:
+            HF.launch_images()
         pair = ctx is not None and getattr(self, "pair_passes", True)
         kind = 1 if self.config.gan_obj == "LS" else 0  # phi_1 / phi_2: squared error for 'LS', BCE for 'NS' and 'MM'
         join_fake = lambda: HF.join_branch(gen_out.abs, gen_out.rel, gen_labels_gt, g_logits,
@@ -308,6 +312,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
 
         HF.mark("D.loss.end")
         self.optimizerD.zero_grad()
+        if _GRAM_LATE:
+            HF.launch_images()  # (A/B knob: the Gram matrix beside the backward pass instead of the row pass)
         self._backward(losses, [self._one] * len(losses))
         HF.mark("D.bwd.end")
         self._ride_generator_counts(shared, in_xy.size(1))
