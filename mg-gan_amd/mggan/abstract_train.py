@@ -5,6 +5,7 @@ import abc
 import ctypes
 import math
 import os
+import sys
 import time
 from argparse import Namespace
 from collections import defaultdict
@@ -352,8 +353,9 @@ class MultiGeneratorGAN(abc.ABC):
                 graphs.flush(metrics)  # the epoch's replayed iterations: one D2H of their summed metric snapshots
                 if graphs.history and self.dist.rank == 0:
                     r1, e1, n_g = graphs.history[-1]
+                    # (stderr: a caller such as bench.py owns stdout -- its one JSON line must stay the only thing there)
                     print("[mggan] epoch {}: {} of {} iterations replayed from {} graph(s)".format(
-                        self.epoch, r1 - r0, (r1 - r0) + (e1 - e0), n_g))
+                        self.epoch, r1 - r0, (r1 - r0) + (e1 - e0), n_g), file=sys.stderr)
             torch.cuda.synchronize()
             self.epoch_seconds.append(time.perf_counter() - t_epoch)
             self.epoch_iterations.append(n_it)
