@@ -102,3 +102,22 @@ def test_graph_on_needs_the_device_rng():
     tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
     with pytest.raises(ValueError):
         tr.train()
+
+
+def test_bench_stdout_is_exactly_one_json_line():
+    """The driver parses the ONE line bench.py prints: nothing else may reach stdout -- not the model summary of
+    construct_model, not train()'s per-epoch lines (the floors and the train() legs run inside this command too)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--config", "c1",
+                          "--also", "", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:5]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and not line["roofline"]["kernel"].startswith("mggan_")
