@@ -289,7 +289,8 @@ int mggan_image_gram(const float* img, int B, double* gram, double* workspace, s
  * gradient is identically zero in front of a train-mode BatchNorm.  workspace: mggan_cnn_grid(B) * C * 36 doubles. */
 int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const unsigned char* code1, const double* gram,
                       const float* W, const float* bias, const double* coefd, float* dW, double* workspace,
-                      size_t workspace_bytes, const int* dims, mggan_stream_t stream);
+                      size_t workspace_bytes, unsigned int* ticket /* two zeroed words: the finalize rides in the launch */,
+                      const int* dims, mggan_stream_t stream);
 /* Sharded training (scene sharding over the GPUs of a node), layer 1 of the scene CNNs without an exchange of
  * its own: with the batch's GLOBAL Gram matrix (mggan_image_gram, all-reduced once per batch) the BatchNorm-1 FORWARD
  * statistics of any conv1 weights follow without a collective (mggan_bn1_from_gram: scale / shift / stat and the

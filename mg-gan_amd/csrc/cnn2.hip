@@ -700,10 +700,28 @@ __global__ __launch_bounds__(256) void image_gram_finalize_kernel(const double* 
 // of a half-wave sit 16 image columns apart, i.e. on disjoint banks.
 #define GS_LD 257   // row stride of the staged gradients (floats): channel c on bank c + cell
 #define CS_LD 260   // row stride of the staged codes (bytes)
+// The finalize (fold the partial rows, the f64 formula, dW +=) rides in the launch (round 5): the LAST C workgroups to finish
+// wait until every row is there -- a workgroup only gets one of the last C tickets when at most C - 1 others are still at
+// work, and those are running or find free slots: no deadlock -- and take one output channel each.
+struct C1Fin {
+  unsigned* ticket;  // [arrivals, finished finalizers], zero before the first launch, left zero; NULL: no finalize
+  const double* gram;
+  const float* W;
+  const float* bias;
+  const double* coefd;
+  float* dW;
+};
+template <bool ATOMIC>
+__device__ __forceinline__ void conv1_wgrad_finalize_channel(const double* part, int rows, int C, int c,
+                                                             const double* __restrict__ gram, const float* __restrict__ W,
+                                                             const float* __restrict__ bias,
+                                                             const double* __restrict__ coefd, float* dW,
+                                                             double (*red)[36]);
+
 template <int C>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int B, const float* __restrict__ img, const float* __restrict__ G1c,
                                                           const unsigned char* __restrict__ code1, double* part /*[grid][C*36]*/,
-                                                          const int* dims) {
+                                                          C1Fin fin, const int* dims) {
   MG_REAL_IMAGES(B, dims)
   __shared__ __attribute__((aligned(16))) float imgp[GLDS];
   __shared__ float gs[16 * GS_LD];
@@ -780,18 +798,46 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int B, const float* __
       fold[w][lane] = acc[q][r];
       __syncthreads();
       const int c = 4 * fk + r, t = 16 * q + fi;
-      if (w == 0 && c < C && t < 36) out[c * 36 + t] = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
+      if (w == 0 && c < C && t < 36) {
+        const double v = (fold[0][lane] + fold[1][lane]) + (fold[2][lane] + fold[3][lane]);
+        if (fin.ticket) store_part(out + c * 36 + t, v);  // (read by another workgroup of this launch)
+        else out[c * 36 + t] = v;
+      }
     }
+  if (!fin.ticket) return;
+  __shared__ int my_c;
+  __shared__ double red[7][36];
+  const int nfin = (int)gridDim.x < C ? (int)gridDim.x : C;
+  __syncthreads();  // every lane's store_part has completed (each waited for its own)
+  if (tid == 0) {
+    const int t = (int)atomicAdd(&fin.ticket[0], 1u);
+    my_c = t - ((int)gridDim.x - nfin);
+    if (my_c >= 0)
+      while (__hip_atomic_load(&fin.ticket[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+  if (my_c < 0) return;
+  for (int c = my_c; c < C; c += nfin)
+    conv1_wgrad_finalize_channel<true>(part, gridDim.x, C, c, fin.gram, fin.W, fin.bias, fin.coefd, fin.dW, red);
+  if (tid == 0) {
+    const unsigned d = atomicAdd(&fin.ticket[1], 1u);
+    if ((int)d == nfin - 1) {  // the last finalizer re-arms both words
+      __hip_atomic_store(&fin.ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&fin.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // dW[c][t] += cs_c * (A[c][t] - m1_c * Bt[t] - m2_c * Chat[c][t])   (one workgroup per output channel, f64)
 // coefd = [cs | S1 | S2 | mean | invstd] (C each) + count, written by the BatchNorm-1 backward finalize
-__global__ __launch_bounds__(256) void conv1_wgrad_finalize_kernel(const double* part, int rows, int C,
-                                                                   const double* __restrict__ gram,
-                                                                   const float* __restrict__ W, const float* __restrict__ bias,
-                                                                   const double* __restrict__ coefd, float* dW) {
-  __shared__ double red[7][36];
-  const int c = blockIdx.x, t = threadIdx.x % 36, rg = threadIdx.x / 36;
+// ATOMIC: the rows were written by OTHER workgroups of the same launch (agent-scope stores): read them past the L1.
+template <bool ATOMIC>
+__device__ __forceinline__ void conv1_wgrad_finalize_channel(const double* part, int rows, int C, int c,
+                                                             const double* __restrict__ gram, const float* __restrict__ W,
+                                                             const float* __restrict__ bias,
+                                                             const double* __restrict__ coefd, float* dW,
+                                                             double (*red)[36]) {
+  const int t = threadIdx.x % 36, rg = threadIdx.x / 36;
   if (rg < 7) {
     double s = 0.0;
     const double* p = part + c * 36 + t;
@@ -800,23 +846,33 @@ __global__ __launch_bounds__(256) void conv1_wgrad_finalize_kernel(const double*
     for (; r + 7 * 7 < rows; r += 8 * 7) {  // 8 loads in flight per lane, fixed order
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + u * 7) * ld];
+      for (int u = 0; u < 8; ++u) v[u] = ATOMIC ? load_part(p + (size_t)(r + u * 7) * ld) : p[(size_t)(r + u * 7) * ld];
       s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
-    for (; r < rows; r += 7) s += p[(size_t)r * ld];
+    for (; r < rows; r += 7) s += ATOMIC ? load_part(p + (size_t)r * ld) : p[(size_t)r * ld];
     red[rg][t] = s;
   }
   __syncthreads();
-  if (threadIdx.x >= 36) return;
-  double A = 0.0;
-  for (int i = 0; i < 7; ++i) A += red[i][t];
-  const double cs = coefd[c], S1 = coefd[C + c], S2 = coefd[2 * C + c], mean = coefd[3 * C + c], inv = coefd[4 * C + c];
-  const double n = coefd[5 * C];
-  const double Bt = gram[36 * NTAP + t];
-  double wp = 0.0;
-  for (int s = 0; s < 36; ++s) wp += (double)W[c * 36 + s] * gram[s * NTAP + t];
-  const double chat = (wp + ((double)bias[c] - mean) * Bt) * inv;
-  dW[c * 36 + t] += (float)(cs * (A - (S1 / n) * Bt - (S2 / n) * chat));
+  if (threadIdx.x < 36) {
+    double A = 0.0;
+    for (int i = 0; i < 7; ++i) A += red[i][t];
+    const double cs = coefd[c], S1 = coefd[C + c], S2 = coefd[2 * C + c], mean = coefd[3 * C + c], inv = coefd[4 * C + c];
+    const double n = coefd[5 * C];
+    const double Bt = gram[36 * NTAP + t];
+    double wp = 0.0;
+    for (int s = 0; s < 36; ++s) wp += (double)W[c * 36 + s] * gram[s * NTAP + t];
+    const double chat = (wp + ((double)bias[c] - mean) * Bt) * inv;
+    dW[c * 36 + t] += (float)(cs * (A - (S1 / n) * Bt - (S2 / n) * chat));
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void conv1_wgrad_finalize_kernel(const double* part, int rows, int C,
+                                                                   const double* __restrict__ gram,
+                                                                   const float* __restrict__ W, const float* __restrict__ bias,
+                                                                   const double* __restrict__ coefd, float* dW) {
+  __shared__ double red[7][36];
+  conv1_wgrad_finalize_channel<false>(part, rows, C, blockIdx.x, gram, W, bias, coefd, dW, red);
 }
 
 // ---- sharded training, layer 1 without an exchange of its own ---------------------------------------
@@ -1075,17 +1131,21 @@ int mggan_image_gram(const float* img, int B, double* gram, double* workspace, s
 /* workspace: mggan_cnn_grid(B) * C * 36 doubles; dW (C,4,3,3) is ACCUMULATED into */
 int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const unsigned char* code1, const double* gram,
                       const float* W, const float* bias, const double* coefd, float* dW, double* workspace,
-                      size_t workspace_bytes, const int* dims, hipStream_t stream) {
+                      size_t workspace_bytes, unsigned* ticket, const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv1_wgrad: channels %d not built (8 or 16)", C);
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(img && G1c && code1 && workspace, "conv1_wgrad: null pointer");
   MG_CHECK_ARG(!dW || (gram && W && bias && coefd), "conv1_wgrad: the finalize needs gram / W / bias / coefd");
   const int grid = grid_for(B, 768);
   MG_CHECK_ARG(workspace_bytes >= (size_t)grid * C * 36 * sizeof(double), "conv1_wgrad: workspace too small");
-  if (C == 16) MG_LAUNCH((conv1_wgrad_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
-  else MG_LAUNCH((conv1_wgrad_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
-  // dW == NULL: the partial rows stay in `workspace` (sharded training: mggan_conv1_tail_fold / _finalize take over)
-  if (dW) MG_LAUNCH(conv1_wgrad_finalize_kernel, dim3(C), dim3(256), 0, stream, workspace, grid, C, gram, W, bias, coefd, dW);
+  // ticket (two zeroed words, left zero) && dW: the finalize rides in the launch -- its last C workgroups fold the rows and add
+  // dW; without a ticket it is a second launch; dW == NULL: the partial rows stay in `workspace` (sharded training:
+  // mggan_conv1_tail_fold / _finalize take over)
+  const C1Fin fin = {dW ? ticket : nullptr, gram, W, bias, coefd, dW};
+  if (C == 16) MG_LAUNCH((conv1_wgrad_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, fin, dims);
+  else MG_LAUNCH((conv1_wgrad_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, fin, dims);
+  if (dW && !ticket)
+    MG_LAUNCH(conv1_wgrad_finalize_kernel, dim3(C), dim3(256), 0, stream, workspace, grid, C, gram, W, bias, coefd, dW);
   MG_LAUNCH_CHECK("conv1_wgrad");
   return MGGAN_OK;
 }

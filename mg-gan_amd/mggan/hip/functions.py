@@ -1597,6 +1597,10 @@ def _image_gram(img, dims=None):
     return _gram_launch(img, dims)[0]
 
 
+# conv1's weight-gradient finalize INSIDE its launch (the last C workgroups to finish fold the partial rows; csrc/cnn2.hip):
+# measured and not used -- 1.400 vs 1.393 ms at 64 x 20 (three alternating pairs on one box), 4.77 = 4.76 ms at 256 x 32: the
+# write-through stores of 576 doubles per workgroup and the wait cost more than the 8 us launch they replace.
+C1_TICKET = os.environ.get("MGGAN_CONV1_TICKET", "0") == "1"
 TAIL_RIDERS = 16  # spare doubles at the end of a gradient tail (mggan/parallel.py: DistContext.all_reduce_grads)
 
 
@@ -1771,13 +1775,13 @@ class SceneAttentionFn(Function):
         if fused:
             gram = _image_gram(img, ctx.dims)
             lib.mggan_conv1_wgrad(_p(img), B, C, _p(G1c), _p(code), _p(gram), _p(c1w), _p(c1b), _p(coefd1),
-                                  root.grad_ptr(c1w), _p(wsw), nbw, pd, st)
+                                  root.grad_ptr(c1w), _p(wsw), nbw, tk.data_ptr() + 16 if C1_TICKET else 0, pd, st)
             return (None,) * 21
         # sharded: layer 1 has no exchange of its own.  This rank's raw sums -- conv1 weight gradient A, BatchNorm-1 adjoint
         # S1 / S2 -- are folded into one f64 tail that travels with the step's gradient all-reduce
         # (DistContext.all_reduce_grads); the finalize runs behind it with the global sums and the global Gram matrix
         gram = global_gram(img, sync)
-        lib.mggan_conv1_wgrad(_p(img), B, C, _p(G1c), _p(code), 0, 0, 0, 0, 0, _p(wsw), nbw, pd, st)
+        lib.mggan_conv1_wgrad(_p(img), B, C, _p(G1c), _p(code), 0, 0, 0, 0, 0, _p(wsw), nbw, 0, pd, st)
         # (+ TAIL_RIDERS spare doubles behind the CNN's sums: small per-rank sums of the trainer that ride along, e.g. the
         #  generator counts of the next step -- zero unless somebody writes them)
         tf = lib.mggan_conv1_tail_floats(C)
