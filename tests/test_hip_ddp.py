@@ -167,7 +167,7 @@ def _launch_graph(world, sizes, device_comm, backend="gloo", own_device=False):
              for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=200) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=200 + 40 * world) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -216,6 +216,18 @@ def test_two_ranks_one_graph_with_device_allreduce():
     # same arithmetic as the segmented replay with eager gloo collectives (other reduction order across ranks: 1e-5)
     rel = np.linalg.norm(res[0][1] - seg[0][1]) / np.linalg.norm(seg[0][1])
     assert rel <= 1e-4, rel
+
+
+def test_eight_ranks_one_graph_like_the_eight_gpu_configs():
+    """BASELINE configs[3] / configs[4] shard the batch over EIGHT ranks.  No 8-GPU node here: eight processes share the one
+    GPU, map each other's arenas (8 slots, 8 flags per chunk, rank-ordered sums over 8 terms) and replay ONE graph each --
+    replicas bit-identical after two eager iterations and three replays, finite losses that are the same global means on every
+    rank, the 13-exchange schedule in the same order on every rank.  (Not compared with another world size: the device RNG
+    mixes the rank into its Philox key, so 8 ranks draw other noise than 2.)"""
+    sizes = [3] * 16  # two scenes of three pedestrians per rank
+    res = _launch_graph(8, sizes, device_comm=True)
+    _check_replicas(res)
+    assert all(r[5] and r[2] == 1 and "peer-mapped" in r[7] for r in res), [(r[0], r[5], r[2]) for r in res]
 
 
 def test_one_rank_forced_collectives_stay_in_one_graph():
