@@ -281,7 +281,10 @@ int mggan_conv2_bwd(const float* xsel, int B, int C, const float* scale1,
                     const int* dims, mggan_stream_t stream);
 /* Gram matrix of the 3x3 patches of a batch of images, gram[s][t] (37 x 37 doubles; tap t = 9*ci + 3*ky + kx,
  * tap 36 = the constant 1): the image-only part of every conv1 weight gradient of the batch (both CNNs, every
- * backward pass).  workspace: mggan_cnn_grid(B) * 1536 doubles. */
+ * backward pass).  Computed from the images' autocorrelation (10 channel pairs x 25 offsets, edge rows / columns
+ * taken out at assembly; MGGAN_GRAM_KERNEL=mfma: tap by tap on the matrix cores).  workspace:
+ * mggan_image_gram_workspace(B) bytes. */
+size_t mggan_image_gram_workspace(int B);
 int mggan_image_gram(const float* img, int B, double* gram, double* workspace, size_t workspace_bytes,
                      const int* dims, mggan_stream_t stream);
 /* conv1 weight gradient (the images need no input gradient): dW (C,4,3,3) += (gamma/sigma) * (A - mean(g) * B -

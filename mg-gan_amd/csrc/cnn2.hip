@@ -11,9 +11,11 @@
 //                       re-read three times per pass, the raw (B,C,33,36) output (76 KB per image), never exists;
 //                       20 KB per image are kept instead.
 //   conv2_fwd2_kernel   a1 = ReLU(scale1*x_sel+shift1) -> conv2 -> raw (B,C,16,16) + statistics.
-//   image_gram_kernel   P[s][t] = sum over images and positions of patch[s]*patch[t] (37x37, tap 36 = the constant 1):
+//   image_gram_*        P[s][t] = sum over images and positions of patch[s]*patch[t] (37x37, tap 36 = the constant 1):
 //                       the only DENSE quantity the conv1 weight gradient needs -- and it depends on the images alone,
 //                       so ONE launch per batch serves every backward pass of both CNNs (three per iteration).
+//                       image_gram_ac_kernel (default) takes it from the images' autocorrelation on the vector ALU
+//                       (272 k products per image); image_gram_kernel is the tap-by-tap MFMA form (2.1 M).
 //   conv1_wgrad_kernel  A[c][t] = sum_pos dy_sparse[c][pos]*patch[pos][t] on the matrix cores (the gradient that
 //                       reaches a pooled cell sits on one of the four window positions).
 //   conv1_wgrad_finalize  dW = (gamma/sigma) * (A - m1*B - m2*Chat), Chat[c][t] = (sum_s W[c][s] P[s][t] + (bias-mean) B[t]) / sigma
@@ -692,6 +694,268 @@ __global__ __launch_bounds__(256) void image_gram_finalize_kernel(const double* 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same Gram matrix from the images' AUTOCORRELATION: patch[pos][(i,k)] = X_i(pos + k) (zero outside the image), so
+//   P[(i,k)][(j,l)] = sum over u of X_i(u) X_j(u + l - k), u restricted to the positions pos + k the tap k can reach
+// -- a 5x5 table of offsets d = l - k per channel pair, minus the image's first / last row and column where a tap
+// looks off the edge.  10 channel pairs (i <= j; the other half by symmetry) x 25 offsets x 1,089 positions = 272 k
+// products per image instead of the 37 x 37 x 1,089 = 1.49 M the tap-by-tap product spends (the MFMA kernel above:
+// 2.1 M with its padding) -- on the vector ALU, whose f32 rate equals the matrix pipe's.
+// A WALKER (one lane) moves along one line of X_i against the five lines around it of X_j with a sliding 5x5 register
+// window and keeps 25 sums -- for TWO lines at once, one per half of a packed-f32 FMA: the image sits in LDS as
+// float2 (row q, row q + 17), so one ds_read_b64 fetches both halves' operand and the window shift of the fully
+// unrolled walk is register renaming (no moves).  Waves 0-2: 10 pairs x 17 double rows walk along x (S per offset and
+// row).  Wave 3: 10 pairs x 2 edge columns walk DOWN column 0 / 32 (17 steps of the same float2: rows 0-16 | 17-33):
+// the products at an edge column, E0 / E32, summed over the rows.  The four corner products per offset are taken
+// directly.  Per workgroup and offset: {all rows, row 0, row 32} of S, E0, E32 -- what the assembly needs to take the
+// edge terms out.  f32 within a run of <= 8 images (<= 264 products per sum, the run length of the MFMA kernel's
+// accumulators), f64 across runs, workgroups and ranks.
+#define AC_LD 37                         // float2 per line (columns -2 .. 34)
+#define AC_PLANE (21 * AC_LD)            // float2 per channel: rows q = -2 .. 18 | q + 17
+#define AC_LDS2 (4 * AC_PLANE)
+#define AC_THREADS 256
+#define AC_MAINW 170                     // walkers along x: 10 pairs x 17 double rows (waves 0-2)
+#define AC_EDGE0 192                     // walkers down the edge columns: lanes 192 .. 211 (wave 3)
+#define AC_RED2 (AC_MAINW * 25)          // reduce buffer (floats; aliases the planes between runs): [main walkers][25]
+#define AC_RED3 (AC_RED2 + 20 * 25)      // [edge walkers][25]; then [main walkers][3] (the tap-36 column)
+#define AC_MAIN (3 * 10 * 25 * 3)        // [S | E0 | E32][pair][offset][all rows | row 0 | row 32]
+#define AC_ROW 2304                      // doubles per workgroup: AC_MAIN + 36 (the tap-36 column) padded to 36 x 64
+#define AC_RUN 8
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int ac_pair_i(int p) { return p < 4 ? 0 : (p < 7 ? 1 : (p < 9 ? 2 : 3)); }
+__device__ __forceinline__ int ac_pair_j(int p) { return p < 4 ? p : (p < 7 ? p - 3 : (p < 9 ? p - 5 : 3)); }
+// X(y, x) of one channel from the double-row planes (y, x in -2 .. 34)
+__device__ __forceinline__ float ac_at(const f32x2* plane, int y, int x) {
+  return y <= 18 ? plane[(y + 2) * AC_LD + x + 2].x : plane[(y - 15) * AC_LD + x + 2].y;
+}
+// one walk: STEPS positions LINE float2 apart, the window's other axis PERP apart; acc[perp * 5 + along]
+template <int STEPS, int LINE, int PERP>
+__device__ __forceinline__ void ac_walk(const f32x2* pa, const f32x2* pw, f32x2 acc[25], f32x2 on[3]) {
+  f32x2 w[5][5];
+#pragma unroll
+  for (int v = 0; v < 5; ++v)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) w[v][c] = pw[(v - 2) * PERP + (c - 2) * LINE];
+#pragma unroll
+  for (int x = 0; x < STEPS; ++x) {
+    const f32x2 a = pa[x * LINE];
+    on[0] += a;
+    if (x == 0) on[1] += a;
+    if (x == STEPS - 1) on[2] += a;
+#pragma unroll
+    for (int v = 0; v < 5; ++v)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) acc[v * 5 + c] = __builtin_elementwise_fma(a, w[v][c], acc[v * 5 + c]);
+    if (x < STEPS - 1) {
+#pragma unroll
+      for (int v = 0; v < 5; ++v) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[v][c] = w[v][c + 1];
+        w[v][4] = pw[(v - 2) * PERP + (x + 3) * LINE];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(AC_THREADS, 2) void image_gram_ac_kernel(int B, const float* __restrict__ img,
+                                                                      double* part /*[grid][AC_ROW]*/, const int* dims) {
+  MG_REAL_IMAGES(B, dims)
+  __shared__ f32x2 lds2[AC_LDS2];
+  float* lds = (float*)lds2;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < AC_LDS2; i += AC_THREADS) lds2[i] = f32x2{0.f, 0.f};
+  const bool mainw = tid < AC_MAINW, edgew = tid >= AC_EDGE0 && tid < AC_EDGE0 + 20;
+  const int p = mainw ? tid / 17 : (edgew ? (tid - AC_EDGE0) >> 1 : 0), q = mainw ? tid - p * 17 : 0;
+  const int wbase = mainw ? (q + 2) * AC_LD + 2 : 2 * AC_LD + 2 + (((tid - AC_EDGE0) & 1) ? IH - 1 : 0);
+  const f32x2* pa = lds2 + wbase + ac_pair_i(p) * AC_PLANE;
+  const f32x2* pw = lds2 + wbase + ac_pair_j(p) * AC_PLANE;
+  // loader lane (column lx, line lk of 7): rows q = lk + 7u - 2 (u < 3) | q + 17 of every channel, as float2
+  const bool loader = tid < 7 * IH;
+  const int lk = loader ? tid / IH : 0, lx = loader ? tid - lk * IH : 0;
+  const bool lo_ok = lk >= 2 /* u = 0: rows -2, -1 are halo */, hi_ok = lk <= 3 /* u = 2: rows above 32 are halo */;
+  const int src_lo0 = (lk >= 2 ? lk - 2 : 0) * IH + lx;          // half 0, u = 0 (clamped)
+  const int src_lo = (lk + 5) * IH + lx;                          // half 0, u = 1 (u = 2: + 7 rows)
+  const int src_hi = (lk + 15) * IH + lx;                         // half 1, u = 0 (u = 1: + 7 rows)
+  const int src_hi2 = (lk <= 3 ? lk + 29 : IH - 1) * IH + lx;     // half 1, u = 2 (clamped)
+  f32x2* dst0 = lds2 + lk * AC_LD + lx + 2;
+  // reducer (pair, offset) = lanes 0-249; lanes 0-11 also the tap-36 column (channel, which)
+  const bool reducer = tid < 250, reducer1 = tid < 12;
+  const int rp = reducer ? tid / 25 : 0, rd = reducer ? tid - rp * 25 : 0, rdT = (rd % 5) * 5 + rd / 5;
+  const int o1c = reducer1 ? tid / 3 : 0, o1p = o1c == 0 ? 0 : (o1c == 1 ? 4 : (o1c == 2 ? 7 : 9));
+  double* out = part + (size_t)blockIdx.x * AC_ROW;
+  bool first = true;
+  f32x2 acc[25], on[3];
+  float cacc[4];
+  auto clear = [&]() {
+#pragma unroll
+    for (int d = 0; d < 25; ++d) acc[d] = f32x2{0.f, 0.f};
+    on[0] = on[1] = on[2] = f32x2{0.f, 0.f};
+    cacc[0] = cacc[1] = cacc[2] = cacc[3] = 0.f;
+  };
+  // the run's f32 sums -> the workgroup's f64 row (its own, in global memory: read-modify-write by the lane that owns the
+  // entry), image rows added in index order; the planes are dead here and hold the reduce buffer
+  auto flush = [&]() {
+    auto add_out = [&](double* o, double v, bool assign) { *o = assign ? v : *o + v; };
+    double sall = 0.0, s1all = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // half 0: image rows 0-16; half 1: rows 17-33
+      __syncthreads();
+      if (mainw || edgew) {
+        float* o = lds + (mainw ? tid * 25 : AC_RED2 + (tid - AC_EDGE0) * 25);
+#pragma unroll
+        for (int d = 0; d < 25; ++d) o[d] = h ? acc[d].y : acc[d].x;
+        if (mainw) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) lds[AC_RED3 + tid * 3 + k] = h ? on[k].y : on[k].x;
+        }
+      }
+      __syncthreads();
+      if (reducer) {
+        const float* o = lds + rp * 17 * 25 + rd;
+        for (int y = 0; y < (h ? 16 : 17); ++y) sall += (double)o[y * 25];  // (row 33 = walker 16, half 1, is the zero halo)
+        double* dst = out + (rp * 25 + rd) * 3;
+        if (h == 0) add_out(dst + 1, (double)o[0], first);
+        else {
+          add_out(dst, sall, first);
+          add_out(dst + 2, (double)o[15 * 25], first);
+        }
+        add_out(dst + 750, (double)lds[AC_RED2 + (rp * 2 + 0) * 25 + rdT], first && h == 0);
+        add_out(dst + 1500, (double)lds[AC_RED2 + (rp * 2 + 1) * 25 + rdT], first && h == 0);
+      }
+      if (reducer1) {
+        const float* o = lds + AC_RED3 + o1p * 17 * 3 + tid % 3;
+        for (int y = 0; y < (h ? 16 : 17); ++y) s1all += (double)o[y * 3];
+        double* dst = out + AC_MAIN + tid * 3;
+        if (h == 0) add_out(dst + 1, (double)o[0], first);
+        else {
+          add_out(dst, s1all, first);
+          add_out(dst + 2, (double)o[15 * 3], first);
+        }
+      }
+    }
+    if (reducer) {
+      double* dst = out + (rp * 25 + rd) * 3;
+      add_out(dst + 750 + 1, (double)cacc[0], first);   // E0: (row 0, column 0), (row 32, column 0)
+      add_out(dst + 750 + 2, (double)cacc[2], first);
+      add_out(dst + 1500 + 1, (double)cacc[1], first);  // E32: (row 0, column 32), (row 32, column 32)
+      add_out(dst + 1500 + 2, (double)cacc[3], first);
+    }
+    first = false;
+    __syncthreads();
+    for (int i = tid; i < AC_LDS2; i += AC_THREADS) lds2[i] = f32x2{0.f, 0.f};  // (the halo again; the next commit follows a barrier)
+    clear();
+  };
+  clear();
+  f32x2 pre[4][3];
+  auto fetch = [&](int b) {
+    const float* src = img + (size_t)b * 4 * IPIX;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      const float* s = src + ch * IPIX;
+      const float a0 = s[src_lo0], a1 = s[src_lo], a2 = s[src_lo + 7 * IH];
+      const float b0 = s[src_hi], b1 = s[src_hi + 7 * IH], b2 = s[src_hi2];
+      pre[ch][0] = f32x2{lo_ok ? a0 : 0.f, b0};
+      pre[ch][1] = f32x2{a1, b1};
+      pre[ch][2] = f32x2{a2, hi_ok ? b2 : 0.f};
+    }
+  };
+  if ((int)blockIdx.x < B && loader) fetch(blockIdx.x);
+  int run = 0;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    if (loader) {
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) dst0[ch * AC_PLANE + 7 * u * AC_LD] = pre[ch][u];
+    }
+    __syncthreads();
+    if (b + (int)gridDim.x < B && loader) fetch(b + gridDim.x);
+    if (tid < AC_EDGE0) {
+      if (mainw) ac_walk<IH, 1, AC_LD>(pa, pw, acc, on);
+    } else if (edgew) {
+      ac_walk<17, AC_LD, 1>(pa, pw, acc, on);
+    }
+    if (reducer) {  // the corner products: (row 0, col 0), (row 0, col 32), (row 32, col 0), (row 32, col 32)
+      const f32x2* xi = lds2 + ac_pair_i(rp) * AC_PLANE;
+      const f32x2* xj = lds2 + ac_pair_j(rp) * AC_PLANE;
+      const int dy = rd / 5 - 2, dx = rd % 5 - 2;
+      cacc[0] = fmaf(ac_at(xi, 0, 0), ac_at(xj, dy, dx), cacc[0]);
+      cacc[1] = fmaf(ac_at(xi, 0, IH - 1), ac_at(xj, dy, IH - 1 + dx), cacc[1]);
+      cacc[2] = fmaf(ac_at(xi, IH - 1, 0), ac_at(xj, IH - 1 + dy, dx), cacc[2]);
+      cacc[3] = fmaf(ac_at(xi, IH - 1, IH - 1), ac_at(xj, IH - 1 + dy, IH - 1 + dx), cacc[3]);
+    }
+    if (++run == AC_RUN) {
+      flush();
+      run = 0;
+    }
+  }
+  if (run || first) flush();
+  if (tid >= 12 && tid < 12 + AC_ROW - AC_MAIN - 36) out[AC_MAIN + 36 + tid - 12] = 0.0;  // (padding columns)
+}
+
+// column sums of the per-workgroup rows (f64, fixed order): 16 columns x 16 row groups per workgroup, 8 loads in flight
+__global__ __launch_bounds__(256) void image_gram_ac_fold_kernel(const double* part, int rows, double* folded /*[AC_ROW]*/) {
+  __shared__ double red[16][16];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
+  double t = 0.0;
+  int r = rg;
+  for (; r + 7 * 16 < rows; r += 8 * 16) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(r + u * 16) * AC_ROW + col];
+    t += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  for (; r < rows; r += 16) t += part[(size_t)r * AC_ROW + col];
+  red[rg][threadIdx.x & 15] = t;
+  __syncthreads();
+  if (threadIdx.x >= 16) return;
+  t = 0.0;
+  for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+  folded[col] = t;
+}
+
+// rows a tap with vertical offset ky reaches, from {all rows, row 0, row 32}
+__device__ __forceinline__ double ac_rows(const double* v, int ky) {
+  return v[0] - (ky == 1 ? v[1] : 0.0) - (ky == -1 ? v[2] : 0.0);
+}
+__device__ __forceinline__ double ac_entry(const double* f, int p, int ky, int kx, int dy, int dx) {
+  const int d = (dy + 2) * 5 + dx + 2;
+  double v = ac_rows(f + ((0 * 10 + p) * 25 + d) * 3, ky);
+  if (kx == 1) v -= ac_rows(f + ((1 * 10 + p) * 25 + d) * 3, ky);
+  if (kx == -1) v -= ac_rows(f + ((2 * 10 + p) * 25 + d) * 3, ky);
+  return v;
+}
+__global__ __launch_bounds__(256) void image_gram_ac_assemble_kernel(const double* folded, int B, double* gram, const int* dims) {
+  MG_REAL_IMAGES(B, dims)
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= NTAP * NTAP) return;
+  int s = e / NTAP, t = e - s * NTAP;
+  if (s > t) {  // (both triangles from the same expression: the matrix is symmetric to the bit)
+    const int u = s;
+    s = t;
+    t = u;
+  }
+  double v;
+  if (s == 36 && t == 36) {
+    v = (double)IPIX * (double)B;
+  } else if (s == 36 || t == 36) {
+    const int u = s == 36 ? t : s, i = u / 9, ky = (u % 9) / 3 - 1, kx = u % 3 - 1;
+    const double* o = folded + AC_MAIN + i * 9;
+    v = ac_rows(o, ky);
+    if (kx == 1) v -= ac_rows(o + 3, ky);
+    if (kx == -1) v -= ac_rows(o + 6, ky);
+  } else {
+    const int i = s / 9, ky = (s % 9) / 3 - 1, kx = s % 3 - 1;
+    const int j = t / 9, ly = (t % 9) / 3 - 1, lx = t % 3 - 1;
+    const int lo = i <= j ? i : j, hi = i <= j ? j : i;
+    const int p = (lo == 0 ? 0 : (lo == 1 ? 4 : (lo == 2 ? 7 : 9))) + hi - lo;
+    v = i <= j ? ac_entry(folded, p, ky, kx, ly - ky, lx - kx) : ac_entry(folded, p, ly, lx, ky - ly, kx - lx);
+  }
+  gram[e] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // conv1 weight gradient, sparse part: A[c][t] = sum over images and pooled cells of G1c[c][cell] * patch[pos(code)][t].
 // MFMA with M = channel, N = tap (three tiles), K = four pooled cells that share ONE window element e: the A operand of
 // lane (c = fi, k = fk) is the gradient of cell k if the saved argmax position of (c, cell) equals e, else 0
@@ -1117,13 +1381,41 @@ int mggan_conv1_tail_finalize(const double* tail, const double* gram, int C, con
 }
 
 /* workspace: mggan_cnn_grid(B) * 1536 doubles */
+// MGGAN_GRAM_KERNEL=mfma selects the tap-by-tap MFMA kernel (the default until round 5); anything else the autocorrelation form
+static bool gram_ac() {
+  static const bool ac = [] {
+    const char* e = getenv("MGGAN_GRAM_KERNEL");
+    return !(e && e[0] == 'm');
+  }();
+  return ac;
+}
+// two workgroups of the autocorrelation kernel fit a CU (registers): 512 resident, every one with the same number of images
+static int gram_ac_grid(int B) {
+  static const int cap = [] {
+    const char* e = getenv("MGGAN_GRAM_GRID");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 512;
+  }();
+  return B < cap ? B : cap;
+}
+size_t mggan_image_gram_workspace(int B) {
+  const size_t grid = (size_t)(grid_for(B, 768) > 0 ? grid_for(B, 768) : 1), ac = (size_t)(B > 0 ? gram_ac_grid(B) : 1);
+  return (gram_ac() ? (ac + 1) * AC_ROW : grid * 6 * 256) * sizeof(double);
+}
 int mggan_image_gram(const float* img, int B, double* gram, double* workspace, size_t workspace_bytes,
                      const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(gram && workspace && (img || B == 0), "image_gram: null pointer");
-  const int grid = grid_for(B, 768);
-  MG_CHECK_ARG(workspace_bytes >= (size_t)(grid > 0 ? grid : 1) * 6 * 256 * sizeof(double), "image_gram: workspace too small");
-  if (grid > 0) MG_LAUNCH(image_gram_kernel, dim3(grid), dim3(256), 0, stream, B, img, workspace, dims);
-  MG_LAUNCH(image_gram_finalize_kernel, dim3(96), dim3(256), 0, stream, workspace, grid, gram);
+  const int grid = gram_ac() ? gram_ac_grid(B) : grid_for(B, 768);
+  MG_CHECK_ARG(workspace_bytes >= mggan_image_gram_workspace(B), "image_gram: workspace too small");
+  if (gram_ac()) {
+    double* folded = workspace + (size_t)(grid > 0 ? grid : 1) * AC_ROW;
+    if (grid > 0) MG_LAUNCH(image_gram_ac_kernel, dim3(grid), dim3(AC_THREADS), 0, stream, B, img, workspace, dims);
+    MG_LAUNCH(image_gram_ac_fold_kernel, dim3(AC_ROW / 16), dim3(256), 0, stream, workspace, grid, folded);
+    MG_LAUNCH(image_gram_ac_assemble_kernel, dim3((NTAP * NTAP + 255) / 256), dim3(256), 0, stream, folded, B, gram, dims);
+  } else {
+    if (grid > 0) MG_LAUNCH(image_gram_kernel, dim3(grid), dim3(256), 0, stream, B, img, workspace, dims);
+    MG_LAUNCH(image_gram_finalize_kernel, dim3(96), dim3(256), 0, stream, workspace, grid, gram);
+  }
   MG_LAUNCH_CHECK("image_gram");
   return MGGAN_OK;
 }

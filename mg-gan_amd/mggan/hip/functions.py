@@ -1452,7 +1452,7 @@ def _gram_launch(img, dims=None):
     B = img.shape[0]
     dims = _PAD["dims"] if dims is None else dims
     gram = torch.empty(37 * 37, dtype=torch.float64, device=img.device)
-    nb = max(lib.mggan_cnn_grid(B), 1) * 1536 * 8
+    nb = lib.mggan_image_gram_workspace(B)
     ws = torch.empty(nb // 8, dtype=torch.float64, device=img.device)
     lib.mggan_image_gram(_p(img), B, _p(gram), _p(ws), nb, _pad_ptr(dims) if dims is not None else 0, _s())
     return gram, ws

@@ -569,3 +569,36 @@ def test_rollout_ped_adjoint_matches_the_three_launches(b, K, EIN, S, Z):
     torch.cuda.synchronize()
     assert torch.equal(dQe1, dQe0)  # the same four-way sums in the same order
     torch.testing.assert_close(dEnc1, dEnc0, rtol=1e-5, atol=1e-5)
+
+
+def _patch_gram_f64(img):
+    """P[s][t] = sum over images and positions of patch[s] * patch[t]; tap t = 9*ci + 3*ky + kx, tap 36 = 1 (f64, torch)."""
+    x = img.double()
+    pat = torch.nn.functional.unfold(x, kernel_size=3, padding=1)  # (B, 36, 1089), rows ordered (ci, ky, kx)
+    pat = torch.cat([pat, torch.ones(x.shape[0], 1, pat.shape[2], dtype=torch.float64)], 1)
+    return torch.einsum("bsp,btp->st", pat, pat)
+
+
+@pytest.mark.parametrize("B,real", [(1, None), (3, None), (50, None), (777, None), (1500, None), (40, 29), (16, 0)])
+def test_image_gram_matches_the_patch_product(B, real):
+    """Both Gram kernels (autocorrelation form = the default, MFMA tap-by-tap = MGGAN_GRAM_KERNEL=mfma, exercised by
+    tools/ab_gram.py) against the f64 patch product; a padded batch counts its real images only."""
+    lib, dev = _lib(), _dev()
+    g = torch.Generator().manual_seed(B)
+    img = torch.randn(B, 4, 33, 33, generator=g) * 0.7 + 0.2
+    img[:, 3] = (img[:, 3] > 0.5).float()  # a sparse plane, like the rasterised pedestrians
+    imgd = img.to(dev)
+    gram = torch.full((37 * 37,), float("nan"), dtype=torch.float64, device=dev)
+    nb = lib.mggan_image_gram_workspace(B)
+    ws = torch.empty(nb // 8, dtype=torch.float64, device=dev)
+    dims = 0
+    if real is not None:
+        dimst = torch.tensor([real, 1, 0, 0], dtype=torch.int32, device=dev)
+        dims = dimst.data_ptr()
+    lib.mggan_image_gram(imgd.data_ptr(), B, gram.data_ptr(), ws.data_ptr(), nb, dims, st())
+    ref = _patch_gram_f64(img[:B if real is None else real]) if (real is None or real > 0) else torch.zeros(37, 37, dtype=torch.float64)
+    got = gram.cpu().view(37, 37)
+    assert torch.isfinite(got).all()
+    scale = ref.abs().max().clamp_min(1.0)
+    assert (got - ref).abs().max() / scale < 2e-6
+    assert torch.equal(got, got.t())
