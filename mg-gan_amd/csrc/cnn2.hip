@@ -1092,6 +1092,116 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(int B, const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same sums A[c][t] by GATHER on the vector ALU.  A pooled cell passes its gradient to ONE of its four window
+// positions, a different one per channel: the matrix form above multiplies every cell against all four (the A operand is
+// zero for three of them) and pads 36 taps to 48 -- 5.3 matrix slots per useful product, 0.10 of the f32 rate.  Here a
+// lane owns one channel and walks cells: g * (the 36 patch values around the cell's selected position), 36 FMAs on 36
+// ds_read_b32 at a lane-private address -- bound by the LDS (one float per FMA), which is still 2.4x less time than the
+// matrix pipe's wasted slots.  The reads are conflict-free by construction: the 32 lanes of an LDS pass are 8
+// neighbouring cells of one row x 4 channels; with a row stride of 48 floats (== 16 mod 32) the position (ey, ex) of
+// cell px lands on bank 2 px + ex + 16 (ey ^ ky & 1) + const -- 32 different banks for the 32 possible (cell, position)
+// pairs, and lanes that picked the same pair read the same address (a broadcast).  Wave w owns four channels (C = 16:
+// 4w .. 4w+3, all 16 rows of cells; C = 8: 4 (w & 1) .., every other row).  f32 over a run of four images (64 products
+// per sum and lane), then the 16 lanes of a channel meet and the run goes into f64 (LDS); one row per workgroup as above.
+#define WG_LD 48
+#define WG_PLANE (35 * WG_LD)
+#define WG_LDS (4 * WG_PLANE)
+#define WG_GLD 264  // channel stride of the staged gradients (floats) and codes (bytes): four channels of a pass 8 banks apart
+#define WG_RUN 4
+template <int C>
+__global__ __launch_bounds__(256, 3) void conv1_wgrad_gather_kernel(int B, const float* __restrict__ img,
+                                                                    const float* __restrict__ G1c,
+                                                                    const unsigned char* __restrict__ code1,
+                                                                    double* part /*[grid][C*36]*/, const int* dims) {
+  MG_REAL_IMAGES(B, dims)
+  constexpr int NI = C == 16 ? 16 : 8;  // cells per lane and image
+  __shared__ __attribute__((aligned(16))) float imgp[WG_LDS];
+  __shared__ float gs[C * WG_GLD];
+  __shared__ __attribute__((aligned(16))) unsigned char cs[C * WG_GLD];
+  __shared__ double dsum[4][4][36];  // [wave][channel of the wave's four][tap]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < WG_LDS; i += 256) imgp[i] = 0.f;
+  for (int i = tid; i < 4 * 4 * 36; i += 256) (&dsum[0][0][0])[i] = 0.0;
+  const int px = (lane & 7) + 8 * (lane >> 5), cq = (lane >> 3) & 3;
+  const int c = 4 * (C == 16 ? w : (w & 1)) + cq;
+  const int py0 = C == 16 ? 0 : (w >> 1), pystep = C == 16 ? 1 : 2;
+  float acc[36];
+#pragma unroll
+  for (int t = 0; t < 36; ++t) acc[t] = 0.f;
+  float pre[IMG_PER], pg_[C];
+  unsigned pc_[C / 4];
+  auto fetch = [&](int b) {
+    fetch_image(img + (size_t)b * 4 * IPIX, pre);
+#pragma unroll
+    for (int u = 0; u < C; ++u) pg_[u] = G1c[(size_t)b * C * 256 + u * 256 + tid];
+#pragma unroll
+    for (int u = 0; u < C / 4; ++u) pc_[u] = reinterpret_cast<const unsigned*>(code1 + (size_t)b * C * 256)[u * 256 + tid];
+  };
+  // the run's sums: the 16 lanes of a channel (lane bits 0-2 and 5) meet, lane 0 of them adds into the wave's f64 row
+  auto flush = [&]() {
+#pragma unroll
+    for (int t = 0; t < 36; ++t) {
+      float v = acc[t];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 32, 64);
+      if ((lane & 0x27) == 0) dsum[w][cq][t] += (double)v;
+      acc[t] = 0.f;
+    }
+  };
+  if ((int)blockIdx.x < B) fetch(blockIdx.x);
+  __syncthreads();
+  int run = 0;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    commit_image<WG_LD, WG_PLANE>(pre, imgp);
+#pragma unroll
+    for (int u = 0; u < C; ++u) gs[u * WG_GLD + tid] = pg_[u];
+#pragma unroll
+    for (int u = 0; u < C / 4; ++u) {  // word u*256 + tid of the (C,256) code bytes: channel = word / 64
+      const int word = u * 256 + tid;
+      reinterpret_cast<unsigned*>(cs)[(word >> 6) * (WG_GLD / 4) + (word & 63)] = pc_[u];
+    }
+    __syncthreads();
+    if (b + (int)gridDim.x < B) fetch(b + gridDim.x);
+#pragma unroll 2
+    for (int i = 0; i < NI; ++i) {
+      const int py = py0 + pystep * i, cell = py * 16 + px;
+      const float g = gs[c * WG_GLD + cell];
+      const int e = cs[c * WG_GLD + cell];
+      const float* p = imgp + (2 * py + (e >> 1)) * WG_LD + 2 * px + (e & 1);
+      // all 36 reads, THEN the 36 FMAs (scheduling barriers: left alone, the compiler sinks every read to its FMA and waits
+      // for each one -- 409 waits per image; 171 -> 147 us at 8,192 images, C = 16).  Three workgroups per CU cover the
+      // latency of a cell's reads; a software pipeline in half cells (reads of one half under the FMAs of the other) needs
+      // 168 registers + spills and is slower (166 us).
+      float v[36];
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) v[ci * 9 + ky * 3 + kx] = p[ci * WG_PLANE + ky * WG_LD + kx];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 36; ++t) acc[t] = fmaf(g, v[t], acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++run == WG_RUN) {
+      flush();
+      run = 0;
+    }
+  }
+  if (run) flush();
+  __syncthreads();
+  double* out = part + (size_t)blockIdx.x * C * 36;
+  for (int i = tid; i < C * 36; i += 256) {
+    const int ch = i / 36, t = i - ch * 36;
+    out[i] = C == 16 ? dsum[ch >> 2][ch & 3][t] : dsum[ch >> 2][ch & 3][t] + dsum[(ch >> 2) + 2][ch & 3][t];
+  }
+}
+
 // dW[c][t] += cs_c * (A[c][t] - m1_c * Bt[t] - m2_c * Chat[c][t])   (one workgroup per output channel, f64)
 // coefd = [cs | S1 | S2 | mean | invstd] (C each) + count, written by the BatchNorm-1 backward finalize
 // ATOMIC: the rows were written by OTHER workgroups of the same launch (agent-scope stores): read them past the L1.
@@ -1434,7 +1544,15 @@ int mggan_conv1_wgrad(const float* img, int B, int C, const float* G1c, const un
   // dW; without a ticket it is a second launch; dW == NULL: the partial rows stay in `workspace` (sharded training:
   // mggan_conv1_tail_fold / _finalize take over)
   const C1Fin fin = {dW ? ticket : nullptr, gram, W, bias, coefd, dW};
-  if (C == 16) MG_LAUNCH((conv1_wgrad_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, fin, dims);
+  // MGGAN_C1WGRAD=mfma: the one-hot matrix form (rounds 2-5) instead of the gather on the vector ALU
+  static const bool gather = [] {
+    const char* e = getenv("MGGAN_C1WGRAD");
+    return !(e && e[0] == 'm');
+  }();
+  if (gather && !fin.ticket) {
+    if (C == 16) MG_LAUNCH((conv1_wgrad_gather_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
+    else MG_LAUNCH((conv1_wgrad_gather_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, dims);
+  } else if (C == 16) MG_LAUNCH((conv1_wgrad_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, fin, dims);
   else MG_LAUNCH((conv1_wgrad_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, G1c, code1, workspace, fin, dims);
   if (dW && !ticket)
     MG_LAUNCH(conv1_wgrad_finalize_kernel, dim3(C), dim3(256), 0, stream, workspace, grid, C, gram, W, bias, coefd, dW);

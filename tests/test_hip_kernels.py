@@ -602,3 +602,37 @@ def test_image_gram_matches_the_patch_product(B, real):
     scale = ref.abs().max().clamp_min(1.0)
     assert (got - ref).abs().max() / scale < 2e-6
     assert torch.equal(got, got.t())
+
+
+@pytest.mark.parametrize("C,B,real", [(16, 1, None), (16, 37, None), (8, 37, None), (8, 300, None), (16, 300, 211), (8, 5, 0)])
+def test_conv1_wgrad_rows_match_the_sparse_patch_product(C, B, real):
+    """The sparse part of the conv1 weight gradient, A[c][t] = sum over images and pooled cells of g[c][cell] * patch[position the
+    cell's code selects][t] (mggan_conv1_wgrad with dW = NULL: one f64 row per workgroup; the default kernel gathers on the vector
+    ALU, MGGAN_C1WGRAD=mfma is the one-hot matrix form -- tools/ab_c1wgrad.py runs both), against torch f64."""
+    lib, dev = _lib(), _dev()
+    g = torch.Generator().manual_seed(100 * C + B)
+    img = torch.randn(B, 4, 33, 33, generator=g) * 0.7 + 0.2
+    G1c = torch.randn(B, C, 16, 16, generator=g)
+    code = torch.randint(0, 4, (B, C, 16, 16), generator=g, dtype=torch.uint8)
+    rows = max(lib.mggan_cnn_grid(B), 1)
+    ws = torch.full((rows * C * 36,), float("nan"), dtype=torch.float64, device=dev)
+    imgd, Gd, cd = img.to(dev), G1c.to(dev), code.to(dev)
+    dims = 0
+    if real is not None:
+        dimst = torch.tensor([real, 1, 0, 0], dtype=torch.int32, device=dev)
+        dims = dimst.data_ptr()
+    lib.mggan_conv1_wgrad(imgd.data_ptr(), B, C, Gd.data_ptr(), cd.data_ptr(), 0, 0, 0, 0, 0, ws.data_ptr(), ws.numel() * 8, 0,
+                          dims, st())
+    got = ws.view(rows, C * 36).sum(0).view(C, 36).cpu()
+    n = B if real is None else real
+    ref = torch.zeros(C, 36, dtype=torch.float64)
+    if n > 0:
+        dy = torch.zeros(n, C, 34, 34, dtype=torch.float64)
+        c64 = code[:n].long()
+        yy = 2 * torch.arange(16).view(1, 1, 16, 1) + (c64 >> 1)
+        xx = 2 * torch.arange(16).view(1, 1, 1, 16) + (c64 & 1)
+        dy.view(n, C, -1).scatter_(2, (yy * 34 + xx).view(n, C, -1), G1c[:n].double().view(n, C, -1))
+        pat = torch.nn.functional.unfold(img[:n].double(), kernel_size=3, padding=1).view(n, 36, 33, 33)
+        ref = torch.einsum("bcyx,btyx->ct", dy[:, :, :33, :33], pat)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= 2e-6 * ref.abs().max().clamp_min(1.0)
