@@ -212,7 +212,7 @@ def join_side_stream():
 # Measured in between (branches on / off): 2,560 pedestrians 2.59 / 2.74 ms, 4,096: 3.73 / 3.81, 6,144: 5.07 / 5.18.
 # Re-measured after the round-3 kernels (each of which leaves more of the chip free): 8,192 pedestrians 5.29 / 5.37 ms,
 # 12,288: 7.70 / 7.59, 16,384: 9.92 / 9.64 -- the crossover moved up, the default threshold with it (6,144 -> 8,192).
-_BR = {"on": os.environ.get("MGGAN_BRANCH", "auto") != "0", "streams": {}, "dirty": set(), "raw": {},
+_BR = {"on": os.environ.get("MGGAN_BRANCH", "auto") != "0", "streams": {}, "dirty": set(), "raw": {}, "hold": set(),
        "auto": os.environ.get("MGGAN_BRANCH", "auto") == "auto", "max_b": int(os.environ.get("MGGAN_BRANCH_MAX_B", "8192"))}
 
 
@@ -267,6 +267,28 @@ class branch:
         return False
 
 
+class HandoffFn(Function):
+    """Identity on tensors computed on another stream: a node of the CONSUMING stream.  Autograd runs a node's adjoint on the
+    stream of its forward; gradients that reach a value from several streams (the min-L2 branch and the discriminator pass on
+    the generator's predictions) then meet HERE, on the consumer's stream, and travel on to the producer's stream as one --
+    a captured stream that waits for two foreign streams at one point crashes hipStreamEndCapture (ROCm 7.0)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        return tuple(x.view_as(x) for x in xs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return gs
+
+
+def hold_branch(which, on=True):
+    """A held branch is skipped by the join-everything calls at the end of a backward pass / a step: work forked in one step
+    and consumed in the next (the generator step's forward pass beside the discriminator step's backward pass) stays in
+    flight until join_branch(..., which=<it>) names it."""
+    (_BR["hold"].add if on else _BR["hold"].discard)(which)
+
+
 def join_branch(*tensors, which=None, force=False):
     """The current stream waits for branch stream `which` (None: all of them); `tensors` (branch results consumed
     from here on) are registered with the consuming stream so the allocator keeps them until it is done."""
@@ -274,6 +296,8 @@ def join_branch(*tensors, which=None, force=False):
     for w, side in list(_BR["streams"].items()):
         if which is not None and w != which:
             continue
+        if which is None and w in _BR["hold"]:
+            continue  # (a branch that outlives the step it was forked in: joined by name only, hold_branch)
         if not (w in _BR["dirty"] or force):
             continue
         if cur is None:

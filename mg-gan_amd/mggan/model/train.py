@@ -32,6 +32,16 @@ M_REAL, M_FAKE, M_CE_D, M_L2, M_ADV, M_CLF, M_PM, M_PROBS = 0, 1, 2, 3, 4, 5, 6,
 
 
 _GRAM_LATE = os.environ.get("MGGAN_GRAM_LATE", "0") == "1"
+# The generator step's forward pass (sampling, row bucketing, the K-sample rollout with its saved state) reads nothing the
+# discriminator step's update writes -- G's weights, the shared trunk, the PM-network logits, this iteration's random numbers --
+# so it is issued on a branch stream of its own BEFORE the discriminator step's backward pass and runs beside it (MGGAN_G_EARLY=0:
+# inside the generator step, beside the discriminator's history context).  Same arithmetic, same order of random draws.
+# Measured (one box, alternating; ms per iteration, off -> on): 1,280 pedestrians 1.362 -> 1.390 (the rollout takes CUs from
+# two balanced latency-bound chains), 2,560: 2.027 -> 1.989, 4,096: 2.840 -> 2.779, 6,144: 3.755 -> 3.642, 8,192: 4.578 -> 4.500
+# (it fills the tail where only the discriminator's half-empty C = 8 convolution adjoints run): on from MGGAN_G_EARLY_MIN_B.
+_G_EARLY = os.environ.get("MGGAN_G_EARLY", "1") == "1"
+_G_EARLY_MIN_B = int(os.environ.get("MGGAN_G_EARLY_MIN_B", "2048"))
+_EARLY_BRANCH = 5
 
 
 class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
@@ -314,6 +324,13 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self.optimizerD.zero_grad()
         if _GRAM_LATE:
             HF.launch_images()  # (A/B knob: the Gram matrix beside the backward pass instead of the row pass)
+        if (_G_EARLY and in_xy.size(1) >= _G_EARLY_MIN_B and shared is not None and shared.get("g_trunk") is not None
+                and shared.get("g_logits") is not None and HF._BR["on"] and not HF._on_branch() and loss_mask is None
+                and not self.dist.enabled):
+            # (sharded training keeps the in-step order: the generator counts ride in the discriminator's gradient exchange
+            #  on uniforms PEEKED after this point -- _ride_generator_counts --, and between graph segments nothing may stay
+            #  in flight; one rank with the hooks forced on: 4.851 -> 4.815 ms at 8,192 pedestrians, not worth a 14th exchange)
+            self._early_generator_forward(in_xy, in_dxdy, sub_batches, img, shared)
         self._backward(losses, [self._one] * len(losses))
         HF.mark("D.bwd.end")
         self._ride_generator_counts(shared, in_xy.size(1))
@@ -322,10 +339,23 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         HF.mark("D.opt.end")
         self._emit(train_metrics, items)
 
+    def _early_generator_forward(self, in_xy, in_dxdy, sub_batches, img, shared):
+        """The generator step's G(...) call, queued on its own (held) branch stream from the discriminator step."""
+        cfg = self.config
+        HF.hold_branch(_EARLY_BRANCH)
+        with HF.branch(_EARLY_BRANCH):  # (the branches G.forward would fork are no-ops on a branch: one chain)
+            noise = self.rng.noise(cfg.num_samples, cfg.noise_dim, sub_batches, self.device)
+            gen_out, _, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img, mask=None,
+                                          num_samples=cfg.num_samples, trunk=shared.get("g_trunk"),
+                                          logits=shared.get("g_logits"))
+            HF.mark("G.gen.end")
+        shared["g_early"] = (gen_out, gen_idxs, getattr(self.G, "last_rows", None))
+
     def generator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None,
                        shared=None):
         m, cfg = self._m, self.config
         b = in_xy.size(1)
+        early = None if shared is None else shared.pop("g_early", None)
         # adversarial pass: D's weights get no gradient here (the reference discards them: D.zero_grad()
         # precedes backward and the next discriminator step zeroes them again, train.py:128,207)
         d_params = list(self.D.parameters())
@@ -343,12 +373,23 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                         defer = lambda fn: setattr(self.G, "_after_sampling", fn)
                     ctx_d = self.D.history_context(in_dxdy, img, passes=1, lstm_branch=self.g_step_lstm_branch,
                                                    lstm_first=self.g_step_lstm_first, defer_cnn=defer)
-            noise = self.rng.noise(cfg.num_samples, cfg.noise_dim, sub_batches, self.device)
-            gen_out, _, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
-                                          mask=loss_mask, num_samples=cfg.num_samples,
-                                          trunk=None if shared is None else shared.get("g_trunk"),
-                                          logits=None if shared is None else shared.get("g_logits"))
-            HF.mark("G.gen.end")
+            if early is not None:
+                # issued from the discriminator step: this stream takes its results over (and autograd will run their
+                # adjoints on the branch stream they were computed on)
+                gen_out, gen_idxs, rows_early = early
+                HF.hold_branch(_EARLY_BRANCH, False)
+                HF.join_branch(gen_out.abs, gen_out.rel, gen_idxs,
+                               *([v for v in vars(rows_early).values() if torch.is_tensor(v)] if rows_early is not None else []),
+                               which=_EARLY_BRANCH)
+                self.G.last_rows = rows_early
+                gen_out = type(gen_out)(*HF.HandoffFn.apply(*gen_out))
+            else:
+                noise = self.rng.noise(cfg.num_samples, cfg.noise_dim, sub_batches, self.device)
+                gen_out, _, gen_idxs = self.G(in_xy, in_dxdy, sub_batches, noise=noise, all_gen_out=False, img=img,
+                                              mask=loss_mask, num_samples=cfg.num_samples,
+                                              trunk=None if shared is None else shared.get("g_trunk"),
+                                              logits=None if shared is None else shared.get("g_logits"))
+                HF.mark("G.gen.end")
             if isinstance(ctx_d, list):
                 late, self.G._after_sampling = getattr(self.G, "_after_sampling", None), None
                 if late is not None:  # (the generator took a path without the device sampler: the hook never fired)

@@ -161,6 +161,50 @@ def test_branch_streams_and_graph_replay_are_bit_identical():
         assert torch.equal(run(branches, graph), ref), (branches, graph)
 
 
+def test_generator_forward_beside_the_discriminator_backward_is_bit_identical(monkeypatch):
+    """From 2,048 pedestrians on the trainer issues the generator step's forward pass on a held branch stream before the
+    discriminator step's backward pass (mggan/model/train.py: _early_generator_forward).  Same arithmetic, same random draws:
+    with the threshold forced to 0 the weights after several iterations equal those of the in-step order bit for bit, eagerly
+    and as a replayed graph -- and the early path is the one that ran."""
+    import bench
+    from mggan.data_utils import synthetic
+    from mggan.model import train as T
+
+    dev = torch.device("cuda", 0)
+
+    def run(min_b, graph, iters=4):
+        monkeypatch.setattr(T, "_G_EARLY_MIN_B", min_b)
+        calls = []
+        real = T.PiNetMultiGeneratorGAN._early_generator_forward
+        monkeypatch.setattr(T.PiNetMultiGeneratorGAN, "_early_generator_forward",
+                            lambda self, *a: (calls.append(1), real(self, *a))[1])
+        tr = bench.build_trainer(3, "device", dev)
+        torch.cuda.manual_seed(777)
+        batch = tr.to_device(synthetic.make_batch(synthetic.scene_sizes(24, 6), seed=0))
+        batch["loss_mask"] = None
+        tr.defer_metrics = True
+        tr.zero_grads_in_step = True
+        m = defaultdict(list)
+        if graph:
+            replay = tr.capture_iteration(batch, warmup=1)
+            for _ in range(iters - 1):
+                replay(m, False)
+        else:
+            for _ in range(iters):
+                tr.train_iteration(batch, m)
+        tr.flush_metrics()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(T.PiNetMultiGeneratorGAN, "_early_generator_forward", real)
+        return torch.cat([tr.G._flat.clone(), tr.D._flat.clone()]).cpu(), len(calls)
+
+    ref, n = run(1 << 30, False)
+    assert n == 0 and bool(torch.isfinite(ref).all())
+    for graph in (False, True):
+        got, n = run(0, graph)
+        assert n >= 2, "the early path did not run"
+        assert torch.equal(got, ref), graph
+
+
 def test_folded_weights_are_cached_per_weight_version():
     """Inside the trainer's iteration the folded LSTM weights are launched once per weight version: four mggan_lstm_fold
     calls per steady-state iteration instead of seven, and the weights after eager iterations, a capture, replays and
