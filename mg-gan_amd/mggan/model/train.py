@@ -39,6 +39,8 @@ _GRAM_LATE = os.environ.get("MGGAN_GRAM_LATE", "0") == "1"
 # Measured (one box, alternating; ms per iteration, off -> on): 1,280 pedestrians 1.362 -> 1.390 (the rollout takes CUs from
 # two balanced latency-bound chains), 2,560: 2.027 -> 1.989, 4,096: 2.840 -> 2.779, 6,144: 3.755 -> 3.642, 8,192: 4.578 -> 4.500
 # (it fills the tail where only the discriminator's half-empty C = 8 convolution adjoints run): on from MGGAN_G_EARLY_MIN_B.
+# (At 1,280 pedestrians forking it BEHIND the main chain's adjoints instead -- beside the branch's tail and the optimizer -- is
+#  worse still, 1.371 -> 1.453: the rollout's 1,600 tiles hold every CU while the tail's small launches wait for a slot.)
 _G_EARLY = os.environ.get("MGGAN_G_EARLY", "1") == "1"
 _G_EARLY_MIN_B = int(os.environ.get("MGGAN_G_EARLY_MIN_B", "2048"))
 _EARLY_BRANCH = 5
