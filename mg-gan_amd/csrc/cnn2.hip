@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(64) void conv1_tail_finalize_kernel(const double* _
 }
 
 // persistent grid: at most `cap` workgroups (three per CU), and every workgroup walks the same number of images
-// (the last one may fall short): 1,280 images -> 640 workgroups x 2, 8,192 -> 745 x 11
+// (the last one may fall short): 1,280 images -> 512 workgroups x 2-3, 8,192 -> 512 x 16, 12,288 -> 768 x 16
 static int grid_for(int B, int cap) {
   static int knob = -1;  // MGGAN_CNN_GRID: measurement knob -- exactly this many workgroups (unequal image counts)
   if (knob < 0) { const char* e = getenv("MGGAN_CNN_GRID"); knob = e ? atoi(e) : 0; }
@@ -1333,8 +1333,12 @@ static int grid_for(int B, int cap) {
   // from 8,192 images on the three-per-CU rule below wins: 4.74-4.77 vs 4.84-4.87 ms)
   if (B > 512 && B <= 2048) return 512;
   if (B <= cap) return B;
-  const int per = (B + cap - 1) / cap;
-  return (B + per - 1) / per;
+  // every workgroup the same number of images, two or three workgroups per CU -- whichever leaves a CU with fewer images:
+  // 8,192 images as 512 x 16 are 32 per CU, as 745 x 11 some CUs walk 33 (configs[2], one box, three alternating pairs:
+  // 4.515 -> 4.455 ms; 4,096 images 2.805 -> 2.744; 6,144 a tie either way; 448 or 576 workgroups lose 0.1-0.2 ms)
+  const int per3 = (B + cap - 1) / cap, per2 = (B + 511) / 512;
+  if (cap == 768 && 2 * per2 < 3 * per3) return (B + per2 - 1) / per2;
+  return (B + per3 - 1) / per3;
 }
 
 extern "C" {
