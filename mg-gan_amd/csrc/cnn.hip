@@ -919,7 +919,12 @@ static int attn_grid(int B) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("MGGAN_ATTN_GRID"); forced = e ? atoi(e) : 0; }
   if (forced > 0) return forced < B ? forced : B;
-  const int per = cdiv(B, 2048) > 4 ? cdiv(B, 2048) : 4;
+  // at least four images per workgroup, at most 2,048 workgroups -- and from 1,024 images on a multiple of the 256 CUs with
+  // equal image counts: 1,280 images as 256 x 5 instead of 320 x 4 (64 CUs held two workgroups: 1.367 -> 1.360 ms per
+  // configs[1] iteration, three alternating pairs; 512 workgroups: 1.375), 8,192 as 2,048 x 4 as before
+  int k = B / 1024;
+  k = k > 8 ? 8 : k;
+  const int per = k >= 1 ? cdiv(B, 256 * k) : 4;
   return cdiv(B, per);
 }
 
