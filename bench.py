@@ -292,6 +292,41 @@ def cpu_baseline(sizes, num_gens, iters, mode="block", tag="same workload"):
                       "{} mode, {} pinned threads".format(iters, tag, len(sizes), b, num_gens, mode, w["threads"])}
 
 
+def sharded_one_rank_leg(args, single_ms):
+    """What the sharded launch mode costs on ONE rank, before a byte crosses xGMI: this command again with the collective
+    hooks forced on (MGGAN_FORCE_DIST=1, world size 1) on each in-graph transport, against the single-GPU graphs of this
+    run.  single_ms: {config tag: ms_per_step}.  One child process per transport (the process group is per process)."""
+    import socket
+    import subprocess
+
+    out = {"note": "world size 1: every exchange kernel / RCCL call of the sharded iteration is issued, nothing waits for a "
+                   "peer (RCCL's in-place all-reduce over one rank launches no kernel at all, so its column is the cost of "
+                   "the unfused BatchNorm folds and tails around the calls, not of RCCL's kernels)"}
+    for name, env_add in (("peer-mapped", {"MGGAN_DEVICE_COMM": "1"}),
+                          ("rccl-graph", {"MGGAN_DEVICE_COMM": "0", "MGGAN_RCCL_GRAPH": "1"})):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MGGAN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                   LOCAL_RANK="0", MGGAN_BENCH_NO_DETAIL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_add)
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--also", args.also, "--no-floor",
+               "--no-cpu-baseline", "--no-profile", "--steps", str(max(args.steps, 20)), "--warmup", str(max(args.warmup, 5))]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as exc:  # noqa: BLE001
+            out[name] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:200])}
+            continue
+        rows = []
+        for c in line["configs"]:  # (the compact line spells the config tag "workload")
+            base = single_ms.get(c["workload"])
+            rows.append({"config": c["workload"], "ms_per_step": c["ms_per_step"], "single_graph_ms_per_step": base,
+                         "overhead": round(c["ms_per_step"] / base - 1.0, 4) if base else None,
+                         "collective": c.get("collective"), "exchanges_per_step": c.get("exchanges_per_step")})
+        out[name] = rows
+    return out
+
+
 def train_loop_leg(tag, args, dev, batches=25, epochs=6):
     """MultiGeneratorGAN.train() itself (the reference's loop, abstract_train.py:114-168) on the synthetic loader at the
     headline shape: device-resident batches, --rng device, the loop's own graph cache.  Epoch 1 produces the data and runs
@@ -357,15 +392,17 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
     """Build a trainer for one workload, time exactly args.steps iterations between barriers, then (profile) time
     every C-ABI entry with HIP events over three eager iterations.  -> dict (rank 0 keeps it).
     transport (sharded runs): None = the default (peer-mapped all-reduce kernels inside the one graph when every rank
-    could map its peers, else RCCL between graph segments), "rccl" = torch.distributed (backend nccl == RCCL) collectives
-    between graph segments, "peer-mapped" = the kernels of csrc/comm.hip."""
+    could map its peers, else ncclAllReduce issued by the library inside the one graph, else RCCL between graph segments),
+    "peer-mapped" = the kernels of csrc/comm.hip, "rccl-graph" = csrc/rccl.hip (RCCL inside the one graph),
+    "rccl" / "rccl-segments" = torch.distributed (backend nccl == RCCL) collectives between graph segments."""
     import torch.distributed as dist
     from mggan.data_utils import synthetic
     from mggan.hip.lib import start_trace, stop_trace
 
     rng = rng or args.rng
-    if transport is not None:  # read by mggan.devcomm.create when the trainer attaches its DistContext
-        os.environ["MGGAN_DEVICE_COMM"] = "0" if transport == "rccl" else "1"
+    if transport is not None:  # read by mggan.devcomm.create / create_rccl when the trainer attaches its DistContext
+        os.environ["MGGAN_DEVICE_COMM"] = "1" if transport == "peer-mapped" else "0"
+        os.environ["MGGAN_RCCL_GRAPH"] = "0" if transport in ("rccl", "rccl-segments") else "1"
     tr = build_trainer(num_gens, rng, dev, seed=rank)
     tr.dist.equal_shards = True  # every rank holds the same number of scenes/pedestrians
     sizes = synthetic.scene_sizes(scenes, peds)
@@ -380,7 +417,7 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
     replay = None
     verbose = os.environ.get("MGGAN_BENCH_VERBOSE", "0") == "1"
     if verbose:
-        print("[bench] {}: use_graph={} sharded={} devcomm={}".format(tag, use_graph, sharded, tr.dist.devcomm is not None),
+        print("[bench] {}: use_graph={} sharded={} transport={}".format(tag, use_graph, sharded, tr.dist.transport),
               file=sys.stderr, flush=True)
     if use_graph:
         try:
@@ -414,14 +451,16 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
             print("[bench] warm-up step {} done".format(i), file=sys.stderr, flush=True)
     tr.flush_metrics()
     barrier()
-    if sharded and tr.dist.devcomm is not None:
-        # the peer-mapped all-reduce has never met this node before: the replicas must still hold identical weights
-        # and no wait may have timed out; otherwise every rank falls back to torch.distributed collectives together
+    if sharded and tr.dist.stream_safe:
+        # the in-graph all-reduce has never met this node before: the replicas must still hold identical weights
+        # and no wait may have timed out; otherwise every rank falls back to the next transport together
+        # (peer-mapped kernels -> RCCL inside the graph -> torch.distributed between graph segments)
         from mggan.parallel import replicas_in_sync
 
+        was = tr.dist.transport
         ok = 1.0
         try:
-            tr.dist.devcomm.check()
+            tr.dist.check(sync=True)
             ok = 1.0 if replicas_in_sync(tr.G, tr.D) else 0.0
         except Exception as exc:  # noqa: BLE001
             print("[bench] rank {}: {}".format(rank, exc), file=sys.stderr)
@@ -429,13 +468,14 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
         v = torch.tensor([ok], device=dev)
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         if float(v.item()) < 0.5:
-            print("[bench] rank {}: peer-mapped all-reduce rejected; re-measuring with torch.distributed collectives".format(
-                rank), file=sys.stderr)
+            nxt = "rccl-graph" if was == "peer-mapped" else "rccl-segments"
+            print("[bench] rank {}: {} all-reduce rejected; re-measuring with {}".format(rank, was, nxt), file=sys.stderr)
             tr.dist.close()
             del tr, replay
             torch.cuda.empty_cache()
-            res = measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile, graph, rng, transport="rccl")
-            res["collective_note"] = "peer-mapped all-reduce rejected by the post-warm-up check; fell back to RCCL"
+            res = measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile, graph, rng, transport=nxt)
+            res["collective_note"] = "{} all-reduce rejected by the post-warm-up check; fell back to {}".format(
+                was, res.get("collective"))
             return res
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -454,11 +494,18 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
            "b_per_gpu": b, "ms_per_step": round(dt / args.steps * 1e3, 4),
            "value": round(world * b * args.steps / dt, 2), "unit": "trajectories/s", "rng": rng, "launch": launch,
            "bn_sync": tr.config.bn_sync,
-           "collective": (None if not sharded else "peer-mapped" if tr.dist.devcomm is not None else
-                          "rccl-segments" if use_graph else "rccl-eager"),
+           "collective": (None if not sharded else tr.dist.transport if (tr.dist.stream_safe or use_graph) else "rccl-eager"),
            "last_losses": {k: round(v[-1], 6) for k, v in sorted(metrics.items()) if "probs" not in k}}
-    if sharded and tr.dist.devcomm is not None:
-        tr.dist.devcomm.check()  # a timed-out wait inside a peer-mapped all-reduce would have flagged the arena
+    if sharded:
+        tr.dist.check(sync=True)  # a timed-out wait inside a peer-mapped all-reduce would have flagged the arena
+        # the exchange schedule of one iteration, counted on an eager iteration behind the timed region
+        tr.dist.reset_count(log=True)
+        tr.train_iteration(batch, defaultdict(list))
+        tr.flush_metrics()
+        torch.cuda.synchronize()
+        res["exchanges_per_step"] = len([w for w in tr.dist.collective_log if "second call" not in w])
+        res["exchange_schedule"] = list(tr.dist.collective_log)
+        tr.dist.reset_count()
     if not profile:
         tr.dist.close()
         del tr, replay
@@ -605,6 +652,8 @@ def compact_line(full):
             e.update(kernel=r["roofline"].get("kernel"), frac=r["roofline"].get("frac"), bound=r["roofline"].get("bound"))
         if r.get("iteration_frac_of_f32_peak") is not None:
             e["iteration_frac_of_f32_peak"] = r["iteration_frac_of_f32_peak"]
+        if r.get("exchanges_per_step") is not None:  # sharded runs: transport and exchanges per iteration
+            e.update(collective=r.get("collective"), exchanges_per_step=r["exchanges_per_step"])
         confs.append(e)
     if confs:
         line["configs"] = confs
@@ -633,7 +682,7 @@ def emit(full):
     return the compact line."""
     text = compact_line(full)
     blob = json.dumps(_clean(full), allow_nan=False, indent=1)
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+    for d in () if os.environ.get("MGGAN_BENCH_NO_DETAIL") == "1" else (ROOT, os.path.join(ROOT, "gpurun_out")):
         try:
             os.makedirs(d, exist_ok=True)
             with open(os.path.join(d, "bench_detail.json"), "w") as fh:
@@ -680,6 +729,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-floor", action="store_true", help="skip the C1-shaped eager / host-RNG / graph floor timings")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-entry timing behind the timed region (no roofline block)")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="skip the forced-one-rank sharded-mode legs of the N=1 run")
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--transport-ab", action="store_true",
                     help="N>1: repeat both workloads on the OTHER collective transport (RCCL between graph segments when the "
@@ -736,32 +787,39 @@ def main():
     from mggan.hip import lib as hiplib_mod  # noqa: F401
 
     head_cfg = CONFIGS[args.config]
-    head = measure(args.config, head_cfg["scenes"], head_cfg["peds"], head_cfg["num_gens"], args, world, rank, dev)
+    prof = not args.no_profile
+    head = measure(args.config, head_cfg["scenes"], head_cfg["peds"], head_cfg["num_gens"], args, world, rank, dev, profile=prof)
     others = []
     for tag in [t for t in args.also.split(",") if t and t != args.config]:
         c = CONFIGS[tag]
-        others.append(measure(tag, c["scenes"], c["peds"], c["num_gens"], args, world, rank, dev))
+        others.append(measure(tag, c["scenes"], c["peds"], c["num_gens"], args, world, rank, dev, profile=prof))
     transports = None
     if world > 1 and args.transport_ab and not args.no_transport_ab:
         # the same workloads on the other transport (north_star names RCCL; the default keeps the iteration ONE graph
         # with the exchange points as peer-mapped kernels): both numbers in the line, same timing protocol
-        other = "rccl" if head.get("collective") == "peer-mapped" else "peer-mapped"
         transports = []
         for tag in [args.config] + [t for t in args.also.split(",") if t and t != args.config]:
             c = CONFIGS[tag]
-            alt = measure(tag, c["scenes"], c["peds"], c["num_gens"], args, world, rank, dev, profile=False, transport=other)
             base = head if tag == args.config else [o for o in others if o["config"] == tag][0]
-            transports.append({"config": tag, base["collective"]: {"ms_per_step": base["ms_per_step"], "value": base["value"],
-                                                                    "launch": base["launch"]},
-                               alt["collective"]: {"ms_per_step": alt["ms_per_step"], "value": alt["value"],
-                                                   "launch": alt["launch"]}})
+            row = {"config": tag, base["collective"]: {"ms_per_step": base["ms_per_step"], "value": base["value"],
+                                                       "launch": base["launch"]}}
+            for other in ("peer-mapped", "rccl-graph", "rccl-segments"):
+                if other in row:
+                    continue
+                alt = measure(tag, c["scenes"], c["peds"], c["num_gens"], args, world, rank, dev, profile=False,
+                              transport=other)
+                row.setdefault(alt["collective"], {"ms_per_step": alt["ms_per_step"], "value": alt["value"],
+                                                   "launch": alt["launch"]})
+            transports.append(row)
         os.environ.pop("MGGAN_DEVICE_COMM", None)
+        os.environ.pop("MGGAN_RCCL_GRAPH", None)
 
     out = None
     if rank == 0:
         keep = ("config", "workload", "b_per_gpu", "ms_per_step", "value", "unit", "launch", "collective", "roofline",
                 "roofline_top_kernels", "iteration_flops_algorithmic_g", "iteration_flops_executed_g", "iteration_tflops",
-                "iteration_frac_of_f32_peak", "launches_per_step", "breakdown")
+                "iteration_frac_of_f32_peak", "launches_per_step", "breakdown", "exchanges_per_step", "exchange_schedule",
+                "collective_note")
         out = {
             "metric": "train-step trajectories/sec", "value": head["value"], "unit": "trajectories/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
@@ -769,18 +827,22 @@ def main():
             "config": {"workload": head["workload"], "b_per_gpu": head["b_per_gpu"], "parallelism": "dp{}".format(world),
                        "rng": head["rng"], "bn_sync": head["bn_sync"], "launch": head["launch"],
                        "collective": head.get("collective"), "last_losses": head["last_losses"]},
-            "roofline": head["roofline"], "roofline_top_kernels": head["roofline_top_kernels"],
-            "iteration_flops_algorithmic_g": head["iteration_flops_algorithmic_g"],
-            "iteration_flops_executed_g": head["iteration_flops_executed_g"],
-            "iteration_tflops": head["iteration_tflops"],
-            "iteration_frac_of_f32_peak": head["iteration_frac_of_f32_peak"],
-            "gpu_ms_per_step_sum_of_entries": head["gpu_ms_per_step_sum_of_entries"],
-            "launches_per_step": head["launches_per_step"], "breakdown": head["breakdown"],
+            "roofline": head.get("roofline"), "roofline_top_kernels": head.get("roofline_top_kernels"),
+            "iteration_flops_algorithmic_g": head.get("iteration_flops_algorithmic_g"),
+            "iteration_flops_executed_g": head.get("iteration_flops_executed_g"),
+            "iteration_tflops": head.get("iteration_tflops"),
+            "iteration_frac_of_f32_peak": head.get("iteration_frac_of_f32_peak"),
+            "gpu_ms_per_step_sum_of_entries": head.get("gpu_ms_per_step_sum_of_entries"),
+            "launches_per_step": head.get("launches_per_step"), "breakdown": head.get("breakdown"),
             # every measured workload, the headline first (same timing protocol: warmup, barrier, K steps, barrier)
             "configs": [{k: r[k] for k in keep if k in r} for r in [head] + others],
         }
         if transports is not None:
             out["collective_transports"] = transports
+        if world == 1 and os.environ.get("MGGAN_FORCE_DIST", "0") != "1" and not args.no_floor and not args.no_sharded_leg:
+            # (detail file) the sharded launch mode on one rank, both in-graph transports: the part of the N > 1 points that
+            # is measurable here -- exchanges per step, the schedule, the overhead over this run's single-GPU graphs
+            out["sharded_mode_one_rank"] = sharded_one_rank_leg(args, {r["config"]: r["ms_per_step"] for r in [head] + others})
     if world == 1 and os.environ.get("MGGAN_FORCE_DIST", "0") != "1" and not args.no_floor:
         # what a user of train() gets on ragged ETH-shaped batches (configs[0] shape): the graph floor, eager launches
         # with the device RNG, and eager launches with the seed-comparable host RNG (one D2H + host multinomial per G call)

@@ -403,6 +403,23 @@ int mggan_bn_bwd_sync_finalize(void* const* arenas, int rank, int world, long ma
                                double local_count, int C, const float* gamma, const float* stat, float* coef,
                                double* coefd, float* dgamma, float* dbeta, mggan_stream_t stream);
 
+/* ---- RCCL all-reduce inside the iteration graph (csrc/rccl.hip; scene-sharded training) --------------
+ * No reference counterpart.  The north-star transport ("RCCL all-reduce of discriminator/PM gradients over xGMI") as a
+ * launch of THIS library: ncclAllReduce bound from librccl.so (dlopen; the copy torch has mapped) on the caller's
+ * stream, so it is captured into the one iteration graph like every other entry -- torch.distributed's collectives cut
+ * the capture into segments.  The communicator is the library's own: rank 0 draws a 128-byte id
+ * (mggan_rccl_unique_id), the host side hands it to every rank (mggan/devcomm.py: RcclComm), every rank calls
+ * mggan_rccl_comm_init on its device.  mggan_rccl_allreduce sums `data` (n elements; dtype 0 f32, 1 f64, 2 i32) in
+ * place and, in the same RCCL group (one launch), an optional f64 tail `data2` (n2 doubles) -- the RCCL form of
+ * mggan_comm_allreduce2.  mggan_rccl_available: 1 when librccl.so resolves, else 0 (the reason: mggan_last_error after
+ * a failed call). */
+int mggan_rccl_available(void);
+int mggan_rccl_unique_id(void* id);
+int mggan_rccl_comm_init(const void* id, int rank, int world, void** comm);
+int mggan_rccl_comm_destroy(void* comm);
+int mggan_rccl_allreduce(void* comm, void* data, long n, int dtype, double* data2, long n2, mggan_stream_t stream);
+int mggan_rccl_async_error(void* comm, int* out);
+
 /* ---- losses (+ gradients), clipping, AdamW ----------------------------------------------
  * reference: abstract_train.py:62-67, utils.py:18-25, train.py:58-75,92-113,181-200,626-639,
  *            train.py:131-135,209-213,656-658, abstract_train.py:45-50 */

@@ -61,7 +61,7 @@ class MultiGeneratorGAN(abc.ABC):
         self.G.rng = self.rng
         self.dist = DistContext()
         self.dist.attach(self.G, self.D, bn_sync=getattr(config, "bn_sync", "global"))
-        if self.dist.enabled and self.dist.devcomm is None and os.environ.get("MGGAN_BRANCH_SHARDED", "0") != "1":
+        if self.dist.enabled and not self.dist.stream_safe and os.environ.get("MGGAN_BRANCH_SHARDED", "0") != "1":
             # sharded runs are replayed as ~19 short graph segments (one per collective); forks that have to be
             # joined at every cut measured slower than one stream (3.49 vs 3.24 ms per iteration with dummy
             # collectives on one MI355X), so the branch streams stay off unless asked for
@@ -104,7 +104,7 @@ class MultiGeneratorGAN(abc.ABC):
             self.rng.begin_iteration(sub_batches, b, self.config.noise_dim, self.device)
         from mggan.hip import functions as HF
 
-        if not (self.dist.enabled and self.dist.devcomm is None):  # (segmented sharded replay: the trainer set them off)
+        if not (self.dist.enabled and not self.dist.stream_safe):  # (segmented sharded replay: the trainer set them off)
             HF.auto_branches(b)
         cfg = self.config
         run_d = self.total_iterations % max(int(cfg.num_gen_steps), 1) == 0 or self.epoch >= cfg.keep_gen_steps
@@ -174,9 +174,9 @@ class MultiGeneratorGAN(abc.ABC):
             in_graph = self.dist.graph_safe(self.G, self.D)
             if not in_graph and not self.dist.equal_shards:
                 raise RuntimeError("graph capture of a sharded iteration needs equal shards (dist.equal_shards)")
-            if not in_graph and self.dist.devcomm is not None:
+            if not in_graph and self.dist.stream_safe:
                 # the decision is per trainer, not per collective: a torch.distributed call inside the single-graph
-                # capture would fail, so the peer-mapped kernels are set aside for this trainer's captures
+                # capture would fail, so the in-graph transports are set aside for this trainer's captures
                 self.dist.close()
             HF.enable_branches(in_graph or os.environ.get("MGGAN_BRANCH_SHARDED", "0") == "1")
         self.graph_collectives = in_graph
@@ -290,7 +290,8 @@ class MultiGeneratorGAN(abc.ABC):
                 graph.debug_dump(dot)
             run = graph.replay
             self.launch_mode = "hipGraph replay of the whole iteration" + (
-                ", peer-mapped all-reduce kernels inside it" if in_graph else "")
+                (", peer-mapped all-reduce kernels inside it" if self.dist.devcomm is not None else
+                 ", RCCL all-reduce (ncclAllReduce on the capturing stream) inside it") if in_graph else "")
         return run, graph, captured
 
     def graph_mode(self):

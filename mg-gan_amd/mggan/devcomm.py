@@ -18,6 +18,25 @@ from mggan.hip.lib import lib
 _DTYPES = {torch.float32: 0, torch.float64: 1, torch.int32: 2}
 
 
+CHANNELS = 1 + 4 + 1
+
+
+def current_channel(device):
+    """The channel (stream ROLE) of torch's current stream: 0 = the main chain, 1 + i = branch stream i of
+    mggan.hip.functions, CHANNELS - 1 = the Gram side stream.  All ranks run the same program: they agree on the roles."""
+    from mggan.hip import functions as HF
+
+    cur = torch.cuda.current_stream(device)
+    if HF._GRAM.get("stream") is not None and cur == HF._GRAM["stream"]:
+        return CHANNELS - 1
+    for which, st in HF._BR["streams"].items():
+        if cur == st:
+            if not 0 <= int(which) < CHANNELS - 2:
+                raise RuntimeError("device all-reduce: branch stream {} has no channel".format(which))
+            return 1 + int(which)
+    return 0
+
+
 class DeviceComm:
     MAX_ELEMS = 1 << 16  # 8-byte elements per slot: 512 KB (the flat gradient buffers are 211-360 KB at the default widths)
     # A channel is a logical ROLE, not a raw stream: 0 = the main chain (the caller's stream and every stream that is
@@ -25,7 +44,7 @@ class DeviceComm:
     # mggan.hip.functions.  A process that trains eagerly and then captures, or captures several times, keeps using the
     # same arenas; all ranks run the same program, so they agree on the roles.
     # ... and one for the Gram side stream (its launch and exchange run beside the first scene-CNN pass of an iteration).
-    CHANNELS = 1 + 4 + 1
+    CHANNELS = CHANNELS
 
     def __init__(self, group, device, max_elems=None):
         """Collective: every rank of `group` calls it.  Raises on EVERY rank if any rank fails (the phases end with an
@@ -117,17 +136,7 @@ class DeviceComm:
         return ok
 
     def _channel(self):
-        from mggan.hip import functions as HF
-
-        cur = torch.cuda.current_stream(self.device)
-        if HF._GRAM.get("stream") is not None and cur == HF._GRAM["stream"]:
-            return self.CHANNELS - 1
-        for which, st in HF._BR["streams"].items():
-            if cur == st:
-                if not 0 <= int(which) < self.CHANNELS - 2:
-                    raise RuntimeError("device all-reduce: branch stream {} has no channel".format(which))
-                return 1 + int(which)
-        return 0
+        return current_channel(self.device)
 
     def channel_args(self):
         """(arenas, rank, world, max_elems) of the current stream's channel, for kernels that embed the small exchange
@@ -197,5 +206,137 @@ def create(group, device, max_elems=None):
         return DeviceComm(group, device, max_elems)  # raises on every rank together
     except Exception as exc:  # noqa: BLE001
         print("[mggan] device all-reduce unavailable ({}: {}); torch.distributed collectives between graph segments "
+              "instead".format(type(exc).__name__, exc))
+        return None
+
+
+def _device_identity(device):
+    """Something that tells two physical GPUs of one host apart whatever the ranks' device numbering is."""
+    props = torch.cuda.get_device_properties(device)
+    for attr in ("uuid", "pci_bus_id"):
+        v = getattr(props, attr, None)
+        if v is not None:
+            return "{}:{}".format(attr, v)
+    return "index:{}:{}".format(os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")),
+                                torch.device(device).index)
+
+
+class RcclComm:
+    """RCCL all-reduce INSIDE the iteration graph (csrc/rccl.hip): ncclAllReduce bound from librccl.so by this package's
+    own library and issued on torch's current stream -- an ordinary capturable launch, unlike torch.distributed's
+    collectives, which cut the capture into graph segments.  The transport north_star names; the peer-mapped kernels
+    (DeviceComm) stay the default on one node because every message of an iteration is latency bound (<= 360 KB).
+
+    One communicator per CHANNEL (stream role, as DeviceComm's arenas): collectives of one communicator are ordered by
+    their stream, two streams never share one -- no cross-stream ordering inside a capture.  Rank 0 draws the ids once,
+    every rank initialises a channel's communicator at its first collective there (all ranks run the same program; the
+    eager warm-up iterations in front of a capture touch every channel the iteration uses)."""
+
+    def __init__(self, group, device):
+        """Collective.  Raises on every rank together when RCCL is unusable (library missing, two ranks on one device)."""
+        self.group, self.device = group, torch.device(device)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._comms = {}
+        ids = None
+        try:
+            if not lib.mggan_rccl_available():
+                raise RuntimeError("librccl.so does not resolve in this process")
+            if self.rank == 0:
+                ids = []
+                for _ in range(CHANNELS):
+                    b = ctypes.create_string_buffer(128)
+                    lib.mggan_rccl_unique_id(b)
+                    ids.append(b.raw)
+            mine = (socket.gethostname(), _device_identity(self.device), ids)
+        except Exception as exc:  # noqa: BLE001
+            print("[mggan] in-graph RCCL, rank {}: {}: {}".format(self.rank, type(exc).__name__, exc))
+            mine = None
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=group)
+        if any(e is None for e in everyone):
+            raise RuntimeError("RCCL unavailable on rank(s) {}".format([j for j, e in enumerate(everyone) if e is None]))
+        if len({(h, d) for h, d, _ in everyone}) != self.world:
+            raise RuntimeError("several ranks share one device (RCCL wants one GPU per rank)")
+        self._ids = everyone[0][2]
+        ok = None
+        try:
+            ok = True if self.self_test() else None
+        except Exception as exc:  # noqa: BLE001
+            print("[mggan] in-graph RCCL, rank {}: {}: {}".format(self.rank, type(exc).__name__, exc))
+        dist.all_gather_object(everyone, ok, group=group)
+        if any(e is None for e in everyone):
+            self.close()
+            raise RuntimeError("RCCL self test failed on rank(s) {}".format([j for j, e in enumerate(everyone) if e is None]))
+
+    def _comm(self, ch):
+        c = self._comms.get(ch)
+        if c is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("in-graph RCCL: channel {} meets its first collective inside a capture (run an eager "
+                                   "iteration first)".format(ch))
+            c = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                lib.mggan_rccl_comm_init(self._ids[ch], self.rank, self.world, ctypes.byref(c))
+            self._comms[ch] = c
+        return c
+
+    def self_test(self):
+        w = self.world
+        want = float(w * (w + 1) // 2)
+        ok = True
+        with torch.cuda.device(self.device):
+            for dt, n in ((torch.float32, 3000), (torch.float64, 33), (torch.int32, 9)):
+                x = torch.full((n,), self.rank + 1, dtype=dt, device=self.device)
+                tail = torch.full((7,), self.rank + 1, dtype=torch.float64, device=self.device) if dt == torch.float32 else None
+                self.all_reduce_(x, tail)
+                torch.cuda.synchronize(self.device)
+                ok = ok and bool((x == want).all()) and (tail is None or bool((tail == want).all()))
+        return ok
+
+    def supports(self, t, tail=None):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype in _DTYPES):
+            return False
+        return tail is None or (tail.is_cuda and tail.dtype == torch.float64 and tail.is_contiguous())
+
+    def all_reduce_(self, t, tail=None):
+        """Sum over the ranks, in place, on the current stream (capturable); `tail`: an f64 vector summed in the same RCCL
+        group (one launch)."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        lib.mggan_rccl_allreduce(self._comm(current_channel(self.device)), t.data_ptr(), t.numel(), _DTYPES[t.dtype],
+                                 tail.data_ptr() if tail is not None else 0, tail.numel() if tail is not None else 0, st)
+        return t
+
+    def failed(self):
+        for c in self._comms.values():
+            e = ctypes.c_int()
+            lib.mggan_rccl_async_error(c, ctypes.byref(e))
+            if e.value:
+                return True
+        return False
+
+    def check(self, sync=True):
+        if sync:
+            torch.cuda.synchronize(self.device)
+        if self.failed():
+            raise RuntimeError("in-graph RCCL: asynchronous error on rank {}".format(self.rank))
+
+    def close(self):
+        comms, self._comms = getattr(self, "_comms", {}), {}
+        for c in comms.values():
+            try:
+                lib.mggan_rccl_comm_destroy(c)
+            except Exception:  # noqa: BLE001
+                pass
+
+
+def create_rccl(group, device):
+    """-> RcclComm or None (MGGAN_RCCL_GRAPH=0, librccl missing, ranks sharing a device: every rank falls back to
+    torch.distributed between graph segments together)."""
+    if os.environ.get("MGGAN_RCCL_GRAPH", "1") == "0":
+        return None
+    try:
+        return RcclComm(group, device)
+    except Exception as exc:  # noqa: BLE001
+        print("[mggan] in-graph RCCL unavailable ({}: {}); torch.distributed collectives between graph segments "
               "instead".format(type(exc).__name__, exc))
         return None

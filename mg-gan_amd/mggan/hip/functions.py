@@ -1492,12 +1492,14 @@ def begin_images(img, side=True, defer=False, sync=None):
     _GRAM["reg"].clear()
     _GRAM["pending"] = None
     _GRAM["global"] = None
-    if img is None or not img.is_cuda or img.shape[0] == 0:
+    _GRAM["pending_global"] = None
+    if img is None or not img.is_cuda or (img.shape[0] == 0 and sync is None):
         return
     img = img.contiguous()
-    _GRAM["pending_global"] = None
     if sync is not None:
-        if GRAM_SCHEDULE == "late" and side and _BR["on"] and getattr(sync, "devcomm", None) is not None:
+        # (a rank whose shard holds no pedestrian announces its empty batch like any other: the Gram kernel copes with
+        #  B = 0, and every rank must issue the same collectives on the same channels)
+        if GRAM_SCHEDULE == "late" and side and _BR["on"] and getattr(sync, "stream_safe", False):
             _GRAM["pending_global"] = (img, sync)  # started by launch_images()
         else:
             global_gram(img, sync, side=side and GRAM_SCHEDULE != "first")
@@ -1521,7 +1523,7 @@ def global_gram(img, sync, side=False):
         return hit[0]
     _GRAM["pending_global"] = None  # (announced for later, needed now: e.g. an iteration without a discriminator step)
     ev = None
-    if side and _BR["on"] and getattr(sync, "devcomm", None) is not None:
+    if side and _BR["on"] and getattr(sync, "stream_safe", False):
         if _GRAM["stream"] is None:
             _GRAM["stream"] = role_stream("gram")
         st = _GRAM["stream"]

@@ -42,7 +42,7 @@ def parse_header(path=HEADER_PATH):
 # functions whose int return value is data, not a status code
 _VALUE_RETURNING = {"mggan_version", "mggan_launch_log", "mggan_launch_log_read", "mggan_wgrad_splits", "mggan_lstm_prep_size", "mggan_cnn_bwd_grid", "mggan_cnn_grid", "mggan_comm_arena_bytes", "mggan_social_rows_grid", "mggan_social_rows_splits",
                     "mggan_scene_attention_grid", "mggan_conv1_tail_floats", "mggan_scene_attention_partial_floats",
-                    "mggan_social_rows_partial_floats"}
+                    "mggan_social_rows_partial_floats", "mggan_rccl_available"}
 
 _lib = None
 

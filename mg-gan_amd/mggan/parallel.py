@@ -61,6 +61,18 @@ class DistContext:
 
     recorder = None  # a SegmentRecorder while an iteration is being captured into HIP graphs
     devcomm = None   # mggan.devcomm.DeviceComm: the collectives as plain kernels over peer-mapped memory
+    rccl = None      # mggan.devcomm.RcclComm: ncclAllReduce issued by this package's library on the caller's stream
+    #                  (capturable: the sharded iteration stays one graph); used where the peer-mapped kernels are not
+
+    @property
+    def stream_safe(self):
+        """True when the collectives are launches on the CALLER's stream (peer-mapped kernels or in-graph RCCL): they may
+        be issued from branch streams and captured into one graph.  False: torch.distributed between graph segments."""
+        return self.devcomm is not None or self.rccl is not None
+
+    @property
+    def transport(self):
+        return "peer-mapped" if self.devcomm is not None else "rccl-graph" if self.rccl is not None else "rccl-segments"
     n_collectives = 0  # exchanges ISSUED by this rank since reset_count() (whatever the transport; tests assert the
     collective_log = None  # schedule: DESIGN section 6) -- and, when a list, their names in issue order
 
@@ -80,11 +92,12 @@ class DistContext:
         iteration is being captured that collective CUTS the graph (the kernels queued so far become one graph segment,
         the collective stays an eager call replayed between the segments); the tail is then a second call (counted)."""
         self.count_collective(what)
-        if tail is not None and not (self.devcomm is not None and self.devcomm.supports(t, tail)):
+        for comm in (self.devcomm, self.rccl):
+            if comm is not None and comm.supports(t, tail):
+                comm.all_reduce_(t, tail)
+                return
+        if tail is not None:
             self.count_collective(what + " (tail: second call)")
-        if self.devcomm is not None and self.devcomm.supports(t, tail):
-            self.devcomm.all_reduce_(t, tail)
-            return
         group = self.group
 
         def exchange():
@@ -149,20 +162,27 @@ class DistContext:
 
             join_side_stream()
             tails = root.__dict__.pop("_grad_tails", [])
-            if len(tails) > 1:
-                raise RuntimeError("one scene-CNN backward pass per root and optimizer step ({} tails)".format(len(tails)))
             if tails:
-                tail, finalize = tails[0][0], tails[0][1]
-                self._collective(root._flat_grad, tail, what="gradients+conv1.tail")
-                finalize()
+                self._collective(root._flat_grad, tails[0][0], what="gradients+conv1.tail")
+                # a step with several scene-CNN backward passes on one root (the masked discriminator step runs the
+                # encoder once for the real and once for the fake pass): the first tail rides with the gradients, every
+                # further one is an exchange of its own; each finalize ADDS its global-batch dW1 / dgamma1 / dbeta1
+                for extra in tails[1:]:
+                    self._collective(extra[0], what="conv1.tail (extra pass)")
+                for t in tails:
+                    t[1]()
             else:
                 self._collective(root._flat_grad, what="gradients")
 
-    def close(self):
-        """Unmap / free the peer-mapped arenas (a process that builds several trainers in a row)."""
+    def close(self, rccl=True):
+        """Unmap / free the peer-mapped arenas (a process that builds several trainers in a row); rccl: the in-graph RCCL
+        communicators too."""
         if self.devcomm is not None:
             self.devcomm.close()
             self.devcomm = None
+        if rccl and self.rccl is not None:
+            self.rccl.close()
+            self.rccl = None
 
     def attach(self, *roots, bn_sync="global"):
         """bn_sync 'global': the scene CNNs' BatchNorm statistics are all-reduced (14 of the ~18 collectives of an
@@ -184,21 +204,34 @@ class DistContext:
             while cap < need:
                 cap <<= 1
             self.devcomm = devcomm.create(self.group, self._dev, cap)
+        if self.enabled and self.rccl is None and torch.device(self._dev).type == "cuda" and (
+                self.devcomm is None or os.environ.get("MGGAN_RCCL_GRAPH", "1") == "2"):
+            # no peer-mapped arenas (several nodes, IPC refused, MGGAN_DEVICE_COMM=0): RCCL, issued by this package's
+            # library on the caller's stream -- still ONE graph per iteration.  (MGGAN_RCCL_GRAPH=2: build it beside the
+            # peer-mapped kernels as well, as the fallback of a trainer whose gradient buffers outgrow an arena slot.)
+            from mggan import devcomm
+
+            self.rccl = devcomm.create_rccl(self.group, self._dev)
 
     def graph_safe(self, *roots):
         """Can every collective of an iteration run INSIDE one captured graph?  Needs the peer-mapped kernels, equal
         shards (unequal ones read the global row count back to the host) and slots that hold the flat gradient buffers;
         otherwise capture_iteration uses graph segments with the collectives between them."""
-        if self.devcomm is None or not self.equal_shards:
+        if not self.stream_safe or not self.equal_shards:
             return False
-        return all(r._flat_grad is None or self.devcomm.supports(r._flat_grad, torch.empty(608, dtype=torch.float64))
-                   for r in roots)
+        if self.devcomm is None:
+            return True  # in-graph RCCL takes any length
+        tail = torch.empty(608, dtype=torch.float64, device=self._dev)
+        return all(r._flat_grad is None or self.devcomm.supports(r._flat_grad, tail) or
+                   (self.rccl is not None and self.rccl.supports(r._flat_grad, tail)) for r in roots)
 
     def check(self, sync=False):
         """Raise if a peer-mapped collective has timed out (sync=False: a host read, free; the training loop calls it every
         iteration -- a lost peer leaves NaN in the reduced buffers and must stop the run, not train on)."""
         if self.devcomm is not None:
             self.devcomm.check(sync=sync)
+        if self.rccl is not None:
+            self.rccl.check(sync=sync)
 
     def host_barrier(self):
         """Line the ranks up on the host (after per-rank host phases -- data-loader construction, validation, checkpoint

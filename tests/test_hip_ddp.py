@@ -35,7 +35,7 @@ def _draws(sizes, g, K, seed):
     return out
 
 
-def _run(rank, world, port, sizes, q):
+def _run(rank, world, port, sizes, q, nan_peds=()):
     import sys
 
     for p in (os.path.join(ROOT, "mg-gan_amd"), ROOT):
@@ -57,12 +57,18 @@ def _run(rank, world, port, sizes, q):
     full = synthetic.make_batch(sizes, seed=9)
     dr = _draws(sizes, g, K, 5)
     _, p0, p1, _ = shard_scenes(full["seq_start_end"], rank, world)
+    valid = torch.ones(sum(sizes), dtype=torch.bool)
+    if len(nan_peds):  # pedestrians without ground truth: train_iteration computes the loss mask from the NaNs
+        valid[list(nan_peds)] = False
+        full["gt_xy"][:, ~valid] = float("nan")
+        full["gt_dxdy"][:, ~valid] = float("nan")
     batch = tr.to_device(shard_batch(full, rank, world))
-    batch["loss_mask"] = None
+    if not len(nan_peds):
+        batch["loss_mask"] = None
     m = defaultdict(list)
     for it in range(2):
         tr.rng = tr.G.rng = ReplayRNG(labels=list(dr["labels"]), noise=[n[:, p0:p1] for n in dr["noise"]],
-                                      gen_idxs=[i[p0:p1] for i in dr["idx"]])
+                                      gen_idxs=[i[p0:p1][valid[p0:p1]] for i in dr["idx"]])
         tr.train_iteration(batch, m)
     flat = torch.cat([tr.G._flat.cpu(), tr.D._flat.cpu()])
     bn = float(tr.G.scene_encoder.CNN.encoder.ConvBlock_1.Block.BN_1.running_var.sum().cpu())
@@ -72,11 +78,11 @@ def _run(rank, world, port, sizes, q):
     q.put((rank, flat.numpy(), bn, {k: v for k, v in m.items() if "probs" not in k}))
 
 
-def _launch(world, sizes):
+def _launch(world, sizes, nan_peds=()):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, sizes, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, sizes, q, nan_peds)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
@@ -99,7 +105,24 @@ def test_two_ranks_match_single_process():
     assert np.array_equal(two[0][1], two[1][1])    # bit-identical replicas
 
 
-def _run_graph(rank, world, port, sizes, q, device_comm, backend="gloo", own_device=False):
+def test_two_ranks_match_single_process_on_a_masked_batch():
+    """Pedestrians with NaN ground truth: the masked discriminator step runs D's scene encoder once for the real and once
+    for the fake pass (no shared context), so a root carries TWO conv1 gradient tails per optimizer step -- the first rides
+    with the gradient all-reduce, the second is an exchange of its own (mggan/parallel.py: all_reduce_grads)."""
+    sizes = [3, 2, 4, 1, 3, 5]
+    nan_peds = (1, 7, 12)  # one on rank 0, one in the middle, one on rank 1
+    single = _launch(1, sizes, nan_peds)[0]
+    two = _launch(2, sizes, nan_peds)
+    for r in two:
+        rel = np.linalg.norm(r[1] - single[1]) / np.linalg.norm(single[1])
+        assert rel <= 1e-3, rel
+        assert abs(r[2] - single[2]) <= 1e-3 * abs(single[2])
+        for k, v in single[3].items():
+            np.testing.assert_allclose(r[3][k], v, rtol=2e-3, atol=1e-6, err_msg=k)
+    assert np.array_equal(two[0][1], two[1][1])
+
+
+def _run_graph(rank, world, port, sizes, q, device_comm, backend="gloo", own_device=False, rccl_graph=True, eager=False):
     """Sharded iteration captured on `world` ranks (sharing the box's one GPU, handles exchanged over gloo -- or, with
     own_device, one GPU per rank and any backend: tests/test_hip_multigpu.py):
     device_comm=True: peer-mapped all-reduce kernels inside ONE graph; False: graph segments around eager collectives."""
@@ -108,7 +131,7 @@ def _run_graph(rank, world, port, sizes, q, device_comm, backend="gloo", own_dev
     for p in (os.path.join(ROOT, "mg-gan_amd"), ROOT):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                      MGGAN_DEVICE_COMM="1" if device_comm else "0")
+                      MGGAN_DEVICE_COMM="1" if device_comm else "0", MGGAN_RCCL_GRAPH="1" if rccl_graph else "0")
     if world == 1:
         os.environ["MGGAN_FORCE_DIST"] = "1"
     import torch.distributed as dist
@@ -132,12 +155,21 @@ def _run_graph(rank, world, port, sizes, q, device_comm, backend="gloo", own_dev
     batch["loss_mask"] = None
     tr.defer_metrics = True
     m = defaultdict(list)
+    if eager:  # the same five iterations as eager launches (same Philox state: the device RNG counts iterations)
+        for i in range(5):
+            tr.train_iteration(batch, m)
+        tr.flush_metrics()
+        torch.cuda.synchronize()
+        flat = torch.cat([tr.G._flat.cpu(), tr.D._flat.cpu()])
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, flat.numpy(), 0, 5, {}, tr.dist.devcomm is not None, True, "eager", [], tr.dist.transport))
+        return
     replay = tr.capture_iteration(batch, warmup=2)
     for i in range(3):
         replay(m, True)
     torch.cuda.synchronize()
-    if tr.dist.devcomm is not None:
-        tr.dist.devcomm.check()
+    tr.dist.check(sync=True)
     sync = replicas_in_sync(tr.G, tr.D)
     flat = torch.cat([tr.G._flat.cpu(), tr.D._flat.cpu()])
     steps = int(tr.optimizerD.seg_step.max().cpu())
@@ -156,14 +188,15 @@ def _run_graph(rank, world, port, sizes, q, device_comm, backend="gloo", own_dev
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, flat.numpy(), 1 if one_graph else replay.graph.n_graphs, steps,
-           {k: v for k, v in m.items() if "probs" not in k}, tr.dist.devcomm is not None, sync, tr.launch_mode, schedule))
+           {k: v for k, v in m.items() if "probs" not in k}, tr.dist.devcomm is not None, sync, tr.launch_mode, schedule,
+           tr.dist.transport))
 
 
-def _launch_graph(world, sizes, device_comm, backend="gloo", own_device=False):
+def _launch_graph(world, sizes, device_comm, backend="gloo", own_device=False, rccl_graph=True, eager=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_graph, args=(r, world, port, sizes, q, device_comm, backend, own_device))
+    procs = [ctx.Process(target=_run_graph, args=(r, world, port, sizes, q, device_comm, backend, own_device, rccl_graph, eager))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -175,8 +208,8 @@ def _launch_graph(world, sizes, device_comm, backend="gloo", own_device=False):
 
 
 def _check_replicas(res, replays=3):
-    (_, f0, n0, s0, m0, peer_mapped, sync0, _, sched0) = res[0]
-    if not peer_mapped:  # torch.distributed between graph segments: the f64 tail of a gradient exchange is a second call
+    (_, f0, n0, s0, m0, peer_mapped, sync0, _, sched0, transport0) = res[0]
+    if transport0 == "rccl-segments":  # torch.distributed between graph segments: the f64 tail of a gradient exchange is a second call
         assert sum("second call" in w for w in sched0) == 3, sched0
         sched0 = [w for w in sched0 if "second call" not in w]
     # <= 13 exchanges per iteration (round 4: 18): ONE Gram all-reduce serves the layer-1 forward statistics of the passes
@@ -189,7 +222,7 @@ def _check_replicas(res, replays=3):
     assert "count" not in sched0 and sched0.count("gram") == 1, sched0
     assert not [w for w in sched0 if w == "bn1.backward"], sched0
     assert np.isfinite(f0).all() and 0.2 < m0["train/discr_loss"][-1] < 3.0
-    for (_, f1, n1, s1, m1, _, sync1, _, sched1) in res[1:]:
+    for (_, f1, n1, s1, m1, _, sync1, _, sched1, _) in res[1:]:
         assert [w for w in sched1 if "second call" not in w] == sched0  # the same exchanges in the same order on every rank
         assert n0 == n1 and sync0 and sync1
         assert s0 == s1 == 2 + replays         # 2 eager warm-up iterations + the replays (capturing executes nothing)
@@ -235,6 +268,71 @@ def test_one_rank_forced_collectives_stay_in_one_graph():
     on a one-GPU box (bench.py); here: it is one graph and trains."""
     (r,) = _launch_graph(1, [3, 3, 3, 3], device_comm=True)
     assert r[5] and r[2] == 1 and r[6] and np.isfinite(r[1]).all()
+
+
+def test_one_rank_rccl_inside_the_one_graph_is_bit_identical_to_eager_launches():
+    """The north-star transport as a launch of this library (csrc/rccl.hip: ncclAllReduce bound from librccl.so, issued on
+    the capturing stream): with the peer-mapped kernels switched off the sharded iteration is still ONE graph -- no
+    segments --, and 2 eager + 3 replayed iterations leave the weights 5 eager iterations leave, to the bit.  (One rank:
+    RCCL wants a GPU per rank, the box has one; tests/test_hip_multigpu.py repeats it across devices.)"""
+    sizes = [3, 3, 3, 3]
+    (r,) = _launch_graph(1, sizes, device_comm=False, backend="nccl")
+    assert r[9] == "rccl-graph" and r[2] == 1 and "RCCL all-reduce" in r[7], (r[9], r[2], r[7])
+    assert r[6] and np.isfinite(r[1]).all()
+    sched = [w for w in r[8] if "second call" not in w]
+    assert len(sched) == len(r[8]) and len(sched) <= MAX_COLLECTIVES, r[8]  # the f64 tail rides in the gradients' RCCL group
+    (e,) = _launch_graph(1, sizes, device_comm=False, backend="nccl", eager=True)
+    assert e[9] == "rccl-graph"
+    assert np.array_equal(r[1], e[1])
+    # ... and the segmented replay (torch.distributed between graph segments) is still there when asked for
+    (sg,) = _launch_graph(1, sizes, device_comm=False, backend="nccl", rccl_graph=False)
+    assert sg[9] == "rccl-segments" and sg[2] > 5
+    assert np.array_equal(r[1], sg[1])
+
+
+def test_rccl_binding_sums_a_vector_and_its_tail_eager_and_captured():
+    """csrc/rccl.hip on its own (world size 1: the sum is the identity): every dtype, with and without the f64 tail, eager
+    and replayed from a graph; the entry refuses a null communicator."""
+    import ctypes
+
+    import torch.distributed as dist
+
+    from mggan import devcomm
+    from mggan.hip.lib import HipError, lib
+
+    assert lib.mggan_rccl_available() == 1
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        comm = devcomm.RcclComm(None, dev)
+        for dt, n in ((torch.float32, 90001), (torch.float64, 33), (torch.int32, 8)):
+            x = (torch.arange(n, device=dev) % 97).to(dt)
+            tail = torch.arange(17, dtype=torch.float64, device=dev) if dt == torch.float32 else None
+            want, want_t = x.clone(), None if tail is None else tail.clone()
+            comm.all_reduce_(x, tail)
+            torch.cuda.synchronize()
+            assert torch.equal(x, want) and (tail is None or torch.equal(tail, want_t))
+        x = torch.full((1000,), 3.0, device=dev)
+        tail = torch.full((9,), 2.0, dtype=torch.float64, device=dev)
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            comm.all_reduce_(x, tail)
+            with torch.cuda.graph(g, stream=s):
+                comm.all_reduce_(x, tail)
+                x.mul_(2.0)
+        for k in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert bool((x == 24.0).all()) and bool((tail == 2.0).all())
+        comm.check()
+        with pytest.raises(HipError):
+            lib.mggan_rccl_allreduce(0, x.data_ptr(), 4, 0, 0, 0, 0)
+        comm.close()
+    finally:
+        dist.destroy_process_group()
 
 
 def _run_allreduce(rank, world, port, q, backend="gloo", own_device=False):
@@ -334,7 +432,7 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
     kinds = set().union(*[set(t) - {"config"} for t in line["collective_transports"]])
-    assert kinds == {"peer-mapped", "rccl-segments"}, kinds
+    assert kinds == {"peer-mapped", "rccl-segments"}, kinds  # (two ranks on one device: RCCL inside the graph is refused)
 
 
 def _run_lost_peer(rank, world, port, q):

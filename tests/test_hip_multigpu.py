@@ -39,12 +39,25 @@ def test_sharded_iteration_one_graph_across_devices(world):
 @pytest.mark.parametrize("world", WORLDS)
 def test_sharded_iteration_rccl_segments_across_devices(world):
     sizes = [3] * (2 * world)
-    res = _launch_graph(world, sizes, device_comm=False, backend="nccl", own_device=True)
+    res = _launch_graph(world, sizes, device_comm=False, backend="nccl", own_device=True, rccl_graph=False)
     _check_replicas(res)
-    assert res[0][2] > 10 and not res[0][5]  # RCCL collectives between graph segments
+    assert res[0][2] > 10 and not res[0][5] and res[0][9] == "rccl-segments"  # RCCL collectives between graph segments
     peer = _launch_graph(world, sizes, device_comm=True, backend="nccl", own_device=True)
     rel = np.linalg.norm(res[0][1] - peer[0][1]) / np.linalg.norm(peer[0][1])
     assert rel <= 1e-4, rel  # both transports train the same model (other summation order across the ranks)
+
+
+@pytest.mark.parametrize("world", WORLDS)
+def test_sharded_iteration_rccl_inside_one_graph_across_devices(world):
+    """ncclAllReduce issued by the library on the capturing stream (csrc/rccl.hip): one graph per rank, replicas
+    bit-identical, the same model as the peer-mapped kernels train."""
+    sizes = [3] * (2 * world)
+    res = _launch_graph(world, sizes, device_comm=False, backend="nccl", own_device=True)
+    _check_replicas(res)
+    assert all(r[9] == "rccl-graph" and r[2] == 1 and "RCCL all-reduce" in r[7] for r in res), [(r[9], r[2]) for r in res]
+    peer = _launch_graph(world, sizes, device_comm=True, backend="nccl", own_device=True)
+    rel = np.linalg.norm(res[0][1] - peer[0][1]) / np.linalg.norm(peer[0][1])
+    assert rel <= 1e-4, rel
 
 
 def test_bench_self_launch_across_devices():
@@ -54,4 +67,4 @@ def test_bench_self_launch_across_devices():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0
-    assert {"peer-mapped", "rccl-segments"} <= set().union(*[set(t) for t in line["collective_transports"]])
+    assert {"peer-mapped", "rccl-graph", "rccl-segments"} <= set().union(*[set(t) for t in line["collective_transports"]])
