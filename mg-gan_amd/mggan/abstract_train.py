@@ -84,6 +84,14 @@ class MultiGeneratorGAN(abc.ABC):
             HF.set_pad_dims(*pad_was)
 
     def _train_iteration(self, batch, metrics):
+        from mggan.hip import functions as HF
+
+        try:
+            self._train_iteration_body(batch, metrics, HF)
+        finally:
+            HF.force_masked(False)
+
+    def _train_iteration_body(self, batch, metrics, HF):
         in_xy, in_dxdy = batch["in_xy"], batch["in_dxdy"]
         b = in_xy.size(1)
         sub_batches = batch["seq_start_end"] if "seq_start_end" in batch else list(zip(range(b), range(1, b + 1)))
@@ -92,8 +100,19 @@ class MultiGeneratorGAN(abc.ABC):
             loss_mask = batch["loss_mask"]
         else:
             loss_mask = ~gt_xy.isnan().any(2).any(0)
-            if bool(loss_mask.all()):
+            all_valid = bool(loss_mask.all())
+            if self.dist.enabled and self.dist.world_size > 1:
+                # the masked steps issue other collectives than the unmasked ones (no shared discriminator context: two
+                # scene-CNN passes per step): every rank takes the masked path as soon as ANY rank holds a NaN
+                import torch.distributed as dist
+
+                flag = torch.tensor([0.0 if all_valid else 1.0], device=gt_xy.device)
+                self.dist.count_collective("mask.any")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.dist.group)
+                all_valid = float(flag.item()) == 0.0
+            if all_valid:
                 loss_mask = None
+            HF.force_masked(loss_mask is not None and self.dist.enabled and self.dist.world_size > 1)
         if loss_mask is not None:
             gt_dxdy, gt_xy = gt_dxdy[:, loss_mask], gt_xy[:, loss_mask]
         img = batch["features"] if "features" in batch else None

@@ -1465,6 +1465,24 @@ class PoolHiddenFn(Function):
         return (None, dh) + (None,) * 10
 
 
+# Sharded training: the masked steps issue other collectives than the unmasked ones (no shared discriminator context, a
+# scene-CNN pass on img[mask] per call), so once ANY rank holds a pedestrian without ground truth every rank walks the
+# masked path -- also a rank whose own mask is all True (mggan/abstract_train.py sets this around the iteration).
+_MASK = {"force": False}
+
+
+def force_masked(on=None):
+    was = _MASK["force"]
+    if on is not None:
+        _MASK["force"] = bool(on)
+    return was
+
+
+def is_masked(mask):
+    """Does `mask` select the masked code path?  (None == every pedestrian valid: no device sync.)"""
+    return mask is not None and (_MASK["force"] or not bool(mask.all()))
+
+
 # Gram matrices of the image patches (csrc/cnn2.hip: image_gram_kernel): the image-only part of every conv1 weight
 # gradient of a batch.  The trainer announces the batch's images at the start of an iteration (begin_images): ONE launch
 # on a side stream serves the backward passes of both scene CNNs; a backward pass that finds no announced Gram matrix

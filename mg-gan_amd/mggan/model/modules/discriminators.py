@@ -186,7 +186,7 @@ class MultiDiscriminatorTrajectory(FlatModule):
             pred_xy, pred_dxdy = pred_xy.unsqueeze(1), pred_dxdy.unsqueeze(1)
         pred_len, n_samples, b, _ = pred_xy.shape
         full_b = in_xy.size(1)
-        masked = mask is not None and not bool(mask.all())  # pass mask=None (all valid) to avoid the sync
+        masked = HF.is_masked(mask)  # pass mask=None (all valid) to avoid the sync
 
         if context is not None and masked:
             raise ValueError("a shared history context needs mask=None (all pedestrians valid)")

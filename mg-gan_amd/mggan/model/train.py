@@ -478,7 +478,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             # singleton axis (see PmMganFn) the only trace D's forward leaves is one more update of the BatchNorm
             # running statistics of its scene encoder
             with torch.no_grad():
-                self.D.scene_encoder(img if mask is None or bool(mask.all()) else img[mask])
+                self.D.scene_encoder(img[mask] if HF.is_masked(mask) else img)
             loss = HF.PmMganFn.apply(net_chooser_weights, 0.9 ** self.epoch, m[M_PM:M_PM + 1], m[M_PROBS:M_PROBS + g], n_pm)
         else:  # 'l2' / 'endpoint' (train.py:616-624,641-647): cross entropy against the closest generator
             T_, E_, _, b_, _ = gen_out.abs.shape
