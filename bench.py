@@ -501,10 +501,11 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
         # the exchange schedule of one iteration, counted on an eager iteration behind the timed region
         tr.dist.reset_count(log=True)
         tr.train_iteration(batch, defaultdict(list))
+        log = list(tr.dist.collective_log)  # (the read-back of the logged losses behind it is not part of the iteration)
         tr.flush_metrics()
         torch.cuda.synchronize()
-        res["exchanges_per_step"] = len([w for w in tr.dist.collective_log if "second call" not in w])
-        res["exchange_schedule"] = list(tr.dist.collective_log)
+        res["exchanges_per_step"] = len([w for w in log if "second call" not in w])
+        res["exchange_schedule"] = log
         tr.dist.reset_count()
     if not profile:
         tr.dist.close()

@@ -226,18 +226,24 @@ int mggan_segment_max_bwd(int P, int B, const int* pair_o, const int* ped_prow, 
 /* mggan_conv1_pool, gram != NULL (sharded training; ticket must be NULL): the BatchNorm-1 statistics are those of the batch
  * whose Gram matrix of image patches is `gram` -- the GLOBAL batch's, all-reduced once per iteration -- and are written by
  * the launch itself (see mggan_bn1_from_gram below); no exchange at this point. */
+/* `comm` (mggan_conv1_pool, mggan_conv2_fwd2, mggan_scene_attention_bwd; may be NULL; needs ticket != NULL): sharded training
+ * over peer-mapped arenas -- a device pointer from mggan_comm_channel_create for the calling stream's channel.  The last
+ * workgroup to finish folds the partial rows, exchanges the 2C sums and `count` (THIS rank's element count) with the other
+ * ranks and finalizes with the GLOBAL statistics: the BatchNorm exchange point costs no launch of its own (round 5: fold +
+ * exchange + finalize were one extra launch, mggan_bn_sync_finalize).  A rank with B == 0 still takes part (one
+ * single-workgroup launch).  Backward: coef from the global sums, dgamma / dbeta take this rank's share. */
 int mggan_cnn_grid(int B);      /* workgroups (= partial rows) of conv1_pool / conv2_fwd2 / image_gram / conv1_wgrad */
 int mggan_cnn_bwd_grid(int B);  /* workgroups (= partial rows) of conv2_bwd */
 int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float* bias, float* xsel,
                      unsigned char* code, double* part, unsigned int* ticket, double count, const float* gamma,
                      const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
                      float eps, int updates, float* scale, float* shift, float* stat, const double* gram,
-                     const int* dims, mggan_stream_t stream);
+                     const void* comm, const int* dims, mggan_stream_t stream);
 int mggan_conv2_fwd2(const float* xsel, int B, int C, const float* scale1, const float* shift1,
                      const float* W, const float* bias, float* y2, double* part, unsigned int* ticket, double count,
                      const float* gamma, const float* beta, float* run_mean, float* run_var,
                      long long* num_batches_tracked, float momentum, float eps, int updates, float* scale, float* shift,
-                     float* stat, const int* dims, mggan_stream_t stream);
+                     float* stat, const void* comm, const int* dims, mggan_stream_t stream);
 int mggan_bn_reduce_rows(const double* part, int rows, int W, double* sums, mggan_stream_t stream);
 /* training: 0 = eval (running statistics), n >= 1 = batch statistics and n momentum updates of the running ones */
 int mggan_bn_finalize(const double* sums, double count, int C, int training, const float* gamma, const float* beta,
@@ -267,7 +273,7 @@ int mggan_scene_attention_bwd(const float* ysel, const unsigned char* ycode, int
                               const float* shift2, const float* stat2, const float* Wa, const float* ba, const float* Wb,
                               const float* bb, const float* dout, int ld_dout, float* g2sel, float* wpart, double* part,
                               unsigned int* ticket, double count, const float* gamma2, float* coef2, float* dgamma2,
-                              float* dbeta2, const int* dims, mggan_stream_t stream);
+                              float* dbeta2, const void* comm, const int* dims, mggan_stream_t stream);
 /* conv2 adjoint (BatchNorm-2 backward on the fly, dW2 / db2 as per-workgroup partial rows in `workspace`, input
  * gradient routed through ReLU / max-pool of block 1 -> G1c (B,C,16,16)); part1:
  * mggan_cnn_bwd_grid(B) rows; coefd1 = [gamma*invstd | S1 | S2 | mean | invstd] (C each) + count, f64, for
@@ -306,7 +312,8 @@ int mggan_bn1_from_gram(const double* gram, int C, const float* W, const float* 
                         float eps, int updates, float* scale, float* shift, float* stat, mggan_stream_t stream);
 int mggan_conv1_tail_floats(int C);
 int mggan_conv1_tail_fold(const double* wrows, int rows, const double* part1, int rows1, int C, double* tail,
-                          int riders /* doubles behind the sums that are set to zero */, mggan_stream_t stream);
+                          int riders /* doubles behind the sums: copied from rider_src, or set to zero (NULL) */,
+                          const double* rider_src, mggan_stream_t stream);
 int mggan_conv1_tail_finalize(const double* tail, const double* gram, int C, const float* W, const float* bias,
                               const float* gamma, const float* stat, float* dW, float* dgamma, float* dbeta,
                               mggan_stream_t stream);
@@ -388,6 +395,10 @@ int mggan_comm_allreduce(void* const* arenas, int rank, int world, long max_elem
 /* ... with an f64 tail (data2, n2 doubles) summed in the same collective (same flags, same sequence number) */
 int mggan_comm_allreduce2(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
                           double* data2, long n2, mggan_stream_t stream);
+/* A channel's arguments in device memory (*out), for the scene-CNN kernels that fold their BatchNorm exchange into their
+ * last workgroup (the `comm` argument of mggan_conv1_pool, mggan_conv2_fwd2, mggan_scene_attention_bwd). */
+int mggan_comm_channel_create(void* const* arenas, int rank, int world, long max_elems, void** out);
+int mggan_comm_channel_free(void* p);
 int mggan_comm_error(const void* arena, unsigned int* out);
 int mggan_comm_set_timeout(double seconds);
 int mggan_comm_host_error(unsigned int** out);
@@ -538,13 +549,34 @@ int mggan_inv_counts_f64(const double* counts, int g, float* inv_count, mggan_st
  * zero_grad != 0: the consumed gradients are left at 0 instead of their clipped values (saves the caller's
  * memset before the next backward pass).  lr_dev != NULL: the learning rate is read from that device word instead of
  * `lr` (a captured HIP graph then follows the per-epoch schedule without being captured again).
- * ONE launch (gradient norm, clipping, update): workspace = 258 doubles that are ZERO before the first call (partial sums
- * and the two counters of the launch's grid barrier; every launch leaves them ready for the next).  One workspace per
+ * ONE launch (gradient norm, clipping, update): workspace = 600 doubles that are ZERO before the first call (partial sums,
+ * the two counters of the launch's grid barrier, the tail flag, the finalized tail block; every launch leaves them ready for
+ * the next).  One workspace per
  * optimizer; launches that share one must be ordered by their stream. */
+/* comm (may be NULL): sharded training over peer-mapped arenas -- a device pointer from mggan_comm_channel_create for the
+ * calling stream's channel: the gradient all-reduce (sum over the ranks, rank order) runs INSIDE this launch, chunk by chunk
+ * by the workgroup that updates the chunk (round 5: mggan_comm_allreduce2 in front of it); every rank must make the call.
+ * tail (may be NULL): the f64 tail that rides with the gradients (mggan_conv1_tail_fold) and what its finalize needs; with
+ * comm it is exchanged in the same launch, and its finalize (mggan_conv1_tail_finalize: global-batch dW1 / dgamma1 / dbeta1
+ * added into their slots of `grad`) happens in this launch too -- with comm == NULL the tail must already hold the global
+ * sums (e.g. mggan_rccl_allreduce in front of this call).  The chunk count of `n` floats + 1 must fit the arena's flags. */
+typedef struct {
+  double* tail;        /* [A (C x 36) | S1 (C) | S2 (C) | riders], n2 doubles */
+  long n2;
+  const double* gram;  /* 37 x 37 Gram matrix of the GLOBAL batch's image patches */
+  const float* W;      /* conv1 weight (C,4,3,3) */
+  const float* bias;
+  const float* gamma;  /* BatchNorm-1 weight */
+  const float* stat;   /* [mean | invstd] of the forward pass */
+  float* dW;           /* slots inside `grad` */
+  float* dgamma;
+  float* dbeta;
+  int C;
+} mggan_grad_tail_t;
 int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, const int* elem_seg, int nseg,
                      const unsigned char* active, int* seg_step, float max_norm, double lr, const double* lr_dev,
                      double beta1, double beta2, double eps, double weight_decay, int zero_grad, double* workspace,
-                     float* norm_out, mggan_stream_t stream);
+                     float* norm_out, const void* comm, const mggan_grad_tail_t* tail, mggan_stream_t stream);
 
 /* Fused decoder backward: BPTT + in-kernel per-generator weight gradients (dW_hh and dW1[:, :H] on MFMA).
  * n_gens*NW persistent workgroups; workgroup (g, w) leaves one partial block of `wlen` floats at

@@ -10,6 +10,7 @@
 // NEXT kernel applies scale/shift + ReLU (+ 2x2 max-pool) in its prologue while staging its input tile into LDS.
 #include <stdlib.h>
 #include "common.h"
+#include "comm_dev.h"
 #include "../../include/mggan_hip.h"
 
 #define IH 33
@@ -26,6 +27,7 @@ struct BnBwdFin {  // fused BatchNorm-backward finalize (same layout as in cnn2.
   double* coefd;       // [gamma*invstd | S1 | S2 | mean | invstd] + count (f64; may be NULL)
   float* dgamma;
   float* dbeta;
+  const CommArgs* comm;  // sharded training: the last workgroup exchanges the folded sums before it finalizes (cnn2.hip)
 };
 
 __device__ __forceinline__ void load6(const float* p, float r[6]) {
@@ -99,6 +101,34 @@ __device__ __forceinline__ void bn_bwd_finalize_lane(const BnBwdFin& f, int C, c
   }
   f.dbeta[c] += (float)sums[c];
   f.dgamma[c] += (float)sums[C + c];
+}
+
+// The last workgroup's finalize with the exchange of sharded training folded in (cnn2.hip: bn_bwd_finalize_block): the
+// coefficients come from the GLOBAL sums, dgamma / dbeta take this rank's share.  sums: >= 2C + 1 doubles, local: 2C.
+__device__ __forceinline__ void bn_bwd_finalize_block(BnBwdFin fin, int C, double* sums, double* local) {
+  if (!fin.comm) {
+    bn_bwd_finalize_lane(fin, C, sums);
+    return;
+  }
+  if ((int)threadIdx.x < 2 * C) local[threadIdx.x] = sums[threadIdx.x];
+  if (threadIdx.x == 0) sums[2 * C] = fin.count;
+  comm_allreduce_small(*fin.comm, sums, 2 * C + 1);
+  fin.count = sums[2 * C];
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const float keep_b = fin.dbeta[c], keep_g = fin.dgamma[c];
+  bn_bwd_finalize_lane(fin, C, sums);
+  fin.dbeta[c] = keep_b + (float)local[c];
+  fin.dgamma[c] = keep_g + (float)local[C + c];
+}
+
+// Sharded training, a rank WITHOUT images: it launched no attention adjoint, but its peers' last workgroups wait for its
+// share of the exchange.
+__global__ __launch_bounds__(256) void bn_bwd_sync_empty_kernel(int C, BnBwdFin fin) {
+  __shared__ double sums[64], local[32];
+  if ((int)threadIdx.x < 64) sums[threadIdx.x] = 0.0;
+  __syncthreads();
+  bn_bwd_finalize_block(fin, C, sums, local);
 }
 
 // train: batch statistics -> scale/shift (+ running-stat update, cnn.py BN_1 momentum 0.1, eps 1e-5)
@@ -219,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
   constexpr int SMF = BWD ? (4 * AT_TILE_FLOATS > 4 * WGF ? 4 * AT_TILE_FLOATS : 4 * WGF) : 1;
   __shared__ __attribute__((aligned(16))) float smem[SMF];
   __shared__ double sred[BWD ? 4 * 2 * C : 1];
-  __shared__ double colsum[32], cred[BWD ? 8 * 32 : 1];
+  __shared__ double colsum[40], cred[BWD ? 8 * 32 : 1];
   __shared__ int flag;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, pp = lane & 15, kq = lane >> 4;
   const bool chq = 4 * kq < C;  // this lane's channel quarter exists
@@ -482,7 +512,7 @@ __global__ __launch_bounds__(256) void attn_kernel(int B, const float* __restric
   if (!fin.ticket) return;
   if (!last_block(fin.ticket, &flag)) return;
   colsum_rows(part, gridDim.x, 2 * C, colsum, cred);
-  bn_bwd_finalize_lane(fin, C, colsum);
+  bn_bwd_finalize_block(fin, C, colsum, sred);  // (sred: 8C doubles, free by now)
 }
 
 // ---------------- conv2 backward: BN2 bwd + weight grad + input grad routed through pool1/ReLU ----------------
@@ -888,8 +918,9 @@ static int persistent_grid(int B) {
 }
 
 static BnBwdFin make_bfin(unsigned* ticket, double count, const float* gamma, const float* stat, float* coef, double* coefd,
-                          float* dgamma, float* dbeta) {
+                          float* dgamma, float* dbeta, const void* comm = nullptr) {
   BnBwdFin f;
+  f.comm = (const CommArgs*)comm;
   f.ticket = ticket; f.count = count; f.gamma = gamma; f.stat = stat; f.coef = coef; f.coefd = coefd; f.dgamma = dgamma;
   f.dbeta = dbeta;
   return f;
@@ -957,13 +988,22 @@ int mggan_scene_attention_bwd(const float* ysel, const unsigned char* ycode, int
                               const float* shift2, const float* stat2, const float* Wa, const float* ba, const float* Wb,
                               const float* bb, const float* dout, int ld_dout, float* g2sel, float* wpart, double* part,
                               unsigned* ticket, double count, const float* gamma2, float* coef2, float* dgamma2,
-                              float* dbeta2, const int* dims, hipStream_t stream) {
+                              float* dbeta2, const void* comm, const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "scene_attention_bwd: channels %d not built (8 or 16)", C);
+  MG_CHECK_ARG(!comm || (ticket && !dims), "scene_attention_bwd: the in-launch exchange needs the fused finalize (ticket) and an "
+                                          "unpadded batch");
+  if (B == 0 && comm) {
+    MG_CHECK_ARG(stat2 && gamma2 && coef2 && dgamma2 && dbeta2, "scene_attention_bwd: null pointer");
+    MG_LAUNCH(bn_bwd_sync_empty_kernel, dim3(1), dim3(256), 0, stream, C,
+              make_bfin(ticket, count, gamma2, stat2, coef2, nullptr, dgamma2, dbeta2, comm));
+    MG_LAUNCH_CHECK("scene_attention_bwd");
+    return MGGAN_OK;
+  }
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(ysel && ycode && scale2 && shift2 && stat2 && Wa && ba && Wb && bb && dout && g2sel && wpart && part,
                "scene_attention_bwd: null pointer");
   MG_CHECK_ARG(!ticket || (gamma2 && coef2 && dgamma2 && dbeta2), "scene_attention_bwd: the fused finalize needs gamma / coef / grads");
-  const BnBwdFin fin = make_bfin(ticket, count, gamma2, stat2, coef2, nullptr, dgamma2, dbeta2);
+  const BnBwdFin fin = make_bfin(ticket, count, gamma2, stat2, coef2, nullptr, dgamma2, dbeta2, comm);
   if (C == 16)
     MG_LAUNCH((attn_kernel<16, true>), dim3(attn_grid(B)), dim3(256), 0, stream, B, nullptr, scale2, shift2, Wa, ba, Wb,
               bb, nullptr, 0, nullptr, nullptr, ysel, ycode, dout, ld_dout, stat2, g2sel, wpart, part, fin, dims);

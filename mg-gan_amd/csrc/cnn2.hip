@@ -55,6 +55,9 @@ struct BnFin {  // fused BatchNorm finalize (ticket == NULL: the caller reduces 
   float* scale;
   float* shift;
   float* stat;
+  const CommArgs* comm;  // sharded training: the last workgroup also exchanges the folded sums (+ its element count) with
+                         // the other ranks through the peer-mapped arenas of this channel (device copy of the CommArgs,
+                         // mggan_comm_channel_create) before it finalizes -- NULL: this rank's statistics
 };
 
 struct BnBwdFin {  // fused BatchNorm-backward finalize
@@ -66,6 +69,7 @@ struct BnBwdFin {  // fused BatchNorm-backward finalize
   double* coefd;       // [gamma*invstd | S1 | S2 | mean | invstd] + count  (f64, for conv1_wgrad_finalize); may be NULL
   float* dgamma;
   float* dbeta;
+  const CommArgs* comm;  // as in BnFin: coefficients from the GLOBAL sums, dgamma / dbeta take this rank's share
 };
 
 // (4,33,33) image -> interior of the zero-haloed planes (the halo is cleared once per workgroup), in two halves: the
@@ -190,6 +194,35 @@ __device__ __forceinline__ void bn_bwd_finalize_lane(const BnBwdFin& f, int C, c
   f.dgamma[c] += (float)sums[C + c];
 }
 
+// The fused finalize of a launch's LAST workgroup, with the exchange of sharded training folded in (every thread of the
+// workgroup calls it; sums: >= 2C + 1 doubles of LDS holding the folded column sums).  One launch less per BatchNorm
+// exchange point than fold -> mggan_bn_sync_finalize -> consumer, and the wait for the peers' flags happens where the
+// producer's grid has already drained.
+__device__ __forceinline__ void bn_finalize_block(BnFin fin, int C, double* sums) {
+  if (fin.comm) {
+    if (threadIdx.x == 0) sums[2 * C] = fin.count;
+    comm_allreduce_small(*fin.comm, sums, 2 * C + 1);
+    fin.count = sums[2 * C];
+  }
+  bn_finalize_lane(fin, C, sums);
+}
+__device__ __forceinline__ void bn_bwd_finalize_block(BnBwdFin fin, int C, double* sums, double* local /* 2C doubles of LDS */) {
+  if (!fin.comm) {
+    bn_bwd_finalize_lane(fin, C, sums);
+    return;
+  }
+  if ((int)threadIdx.x < 2 * C) local[threadIdx.x] = sums[threadIdx.x];
+  if (threadIdx.x == 0) sums[2 * C] = fin.count;
+  comm_allreduce_small(*fin.comm, sums, 2 * C + 1);
+  fin.count = sums[2 * C];
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const float keep_b = fin.dbeta[c], keep_g = fin.dgamma[c];
+  bn_bwd_finalize_lane(fin, C, sums);
+  fin.dbeta[c] = keep_b + (float)local[c];
+  fin.dgamma[c] = keep_g + (float)local[C + c];
+}
+
 // BatchNorm-1 statistics of conv1(W, bias) over the batch whose Gram matrix of image patches is `gram` (sharded training:
 // the GLOBAL batch's):  sum x_c = W_c . B + n b_c,  sum x_c^2 = W_c P W_c^T + 2 b_c W_c . B + n b_c^2
 // (B = row 36 of P, n = P[36][36]).  f64 throughout: the variance is a difference of two such sums.  Every thread of the
@@ -230,7 +263,7 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __r
   MG_REAL_IMAGES_COUNT(B, dims, fin)
   __shared__ __attribute__((aligned(16))) float imgp[ILDS];
   __shared__ double redd[4][2][16];
-  __shared__ double colsum[32], cred[8 * 32];
+  __shared__ double colsum[40], cred[8 * 32];
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fi = lane & 15, fk = lane >> 4;
   for (int i = tid; i < ILDS; i += 256) imgp[i] = 0.f;
@@ -344,7 +377,7 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __r
   if (!fin.ticket) return;
   if (!last_block(fin.ticket, &flag)) return;
   colsum_rows(part, gridDim.x, 2 * C, colsum, cred);
-  bn_finalize_lane(fin, C, colsum);
+  bn_finalize_block(fin, C, colsum);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -358,7 +391,7 @@ __global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __r
   MG_REAL_IMAGES_COUNT(B, dims, fin)
   constexpr int COT = C / 4;
   __shared__ __attribute__((aligned(16))) float a1p[C * A1_PLANE];
-  __shared__ double colsum[32], cred[8 * 32];
+  __shared__ double colsum[40], cred[8 * 32];
   __shared__ int flag;
   for (int i = threadIdx.x; i < C * A1_PLANE; i += 256) a1p[i] = 0.f;
   const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pg = threadIdx.x & 63;
@@ -430,7 +463,7 @@ __global__ __launch_bounds__(256) void conv2_fwd2_kernel(int B, const float* __r
   if (!fin.ticket) return;
   if (!last_block(fin.ticket, &flag)) return;
   colsum_rows(part, gridDim.x, 2 * C, colsum, cred);
-  bn_finalize_lane(fin, C, colsum);
+  bn_finalize_block(fin, C, colsum);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -455,7 +488,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   constexpr int PLANE = C == 16 ? 386 : 388, KS = C / 4;
   __shared__ __attribute__((aligned(16))) float a1p[C * PLANE];
   __shared__ double redd[4][2][16];
-  __shared__ double colsum[32], cred[8 * 32];
+  __shared__ double colsum[40], cred[8 * 32];
   __shared__ int flag;
   for (int i = threadIdx.x; i < C * PLANE; i += 256) a1p[i] = 0.f;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, fk = lane >> 4;
@@ -525,7 +558,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (!fin.ticket) return;
   if (!last_block(fin.ticket, &flag)) return;
   colsum_rows(part, gridDim.x, 2 * C, colsum, cred);
-  bn_finalize_lane(fin, C, colsum);
+  bn_finalize_block(fin, C, colsum);
 }
 
 // sums[col] = sum over rows of part[row][col]  (f64; the sharded path all-reduces `sums` before finalizing)
@@ -581,6 +614,14 @@ __global__ __launch_bounds__(256) void bn_bwd_sync_finalize_kernel(CommArgs ca, 
   bn_bwd_finalize_lane(fin, C, colsum);
   fin.dbeta[c] = keep_b + (float)local[c];
   fin.dgamma[c] = keep_g + (float)local[C + c];
+}
+
+// ... and from the device copy of a channel's CommArgs: what a rank WITHOUT images launches in place of the producer (its
+// peers' last workgroups wait for its flags)
+__global__ __launch_bounds__(256) void bn_sync_finalize_dev_kernel(const double* part, int rows, int C, BnFin fin) {
+  __shared__ double colsum[64], cred[8 * 32];
+  colsum_rows(part, rows, 2 * C, colsum, cred);
+  bn_finalize_block(fin, C, colsum);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1266,15 +1307,16 @@ __global__ __launch_bounds__(64) void bn1_from_gram_kernel(const double* __restr
 // [A (C x 36) | S1 (C) | S2 (C)] is folded into one f64 tail here, travels with the gradient all-reduce of the step
 // (csrc/comm.hip: the tail of mggan_comm_allreduce2), and the finalize below runs behind it, identically on every rank.
 __global__ __launch_bounds__(256) void conv1_tail_fold_kernel(const double* wrows, int rows, const double* part1, int rows1,
-                                                              int C, double* tail, int riders) {
+                                                              int C, double* tail, int riders, const double* rider_src) {
   __shared__ double red[7][36];
   __shared__ double colsum[32], cred[8 * 32];
   const int c = blockIdx.x;
   if (c == C) {
     colsum_rows(part1, rows1, 2 * C, colsum, cred);
     if ((int)threadIdx.x < 2 * C) tail[C * 36 + threadIdx.x] = colsum[threadIdx.x];
-    // the rider slots behind the CNN's sums start at zero (whoever rides along writes behind this launch)
-    if ((int)threadIdx.x < riders) tail[C * 36 + 2 * C + threadIdx.x] = 0.0;
+    // the rider slots behind the CNN's sums: what the caller prepared (rider_src), or zero (whoever rides along writes
+    // behind this launch)
+    if ((int)threadIdx.x < riders) tail[C * 36 + 2 * C + threadIdx.x] = rider_src ? rider_src[threadIdx.x] : 0.0;
     return;
   }
   const int t = threadIdx.x % 36, rg = threadIdx.x / 36;
@@ -1346,8 +1388,10 @@ extern "C" {
 int mggan_cnn_grid(int B) { return grid_for(B, 768); }
 
 static BnFin make_fin(unsigned* ticket, double count, const float* gamma, const float* beta, float* run_mean, float* run_var,
-                      long long* nbt, float momentum, float eps, int updates, float* scale, float* shift, float* stat) {
+                      long long* nbt, float momentum, float eps, int updates, float* scale, float* shift, float* stat,
+                      const void* comm = nullptr) {
   BnFin f;
+  f.comm = (const CommArgs*)comm;
   f.ticket = ticket; f.count = count; f.gamma = gamma; f.beta = beta; f.run_mean = run_mean; f.run_var = run_var;
   f.nbt = nbt; f.momentum = momentum; f.eps = eps; f.updates = updates; f.scale = scale; f.shift = shift; f.stat = stat;
   return f;
@@ -1357,15 +1401,23 @@ int mggan_conv1_pool(const float* img, int B, int C, const float* W, const float
                      unsigned char* code, double* part, unsigned* ticket, double count, const float* gamma,
                      const float* beta, float* run_mean, float* run_var, long long* num_batches_tracked, float momentum,
                      float eps, int updates, float* scale, float* shift, float* stat, const double* gram,
-                     const int* dims, hipStream_t stream) {
+                     const void* comm, const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv1_pool: channels %d not built (8 or 16)", C);
+  MG_CHECK_ARG(!comm || (ticket && !gram && !dims), "conv1_pool: the in-launch exchange needs the fused finalize (ticket), no Gram "
+                                                   "matrix and an unpadded batch");
+  const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
+                             scale, shift, stat, comm);
+  if (B == 0 && comm) {  // a rank without images still takes part in the exchange its peers' last workgroups run
+    MG_CHECK_ARG(part && gamma && beta && run_mean && run_var && num_batches_tracked && scale && shift && stat, "conv1_pool: null pointer");
+    MG_LAUNCH(bn_sync_finalize_dev_kernel, dim3(1), dim3(256), 0, stream, part, 0, C, fin);
+    MG_LAUNCH_CHECK("conv1_pool");
+    return MGGAN_OK;
+  }
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(img && W && bias && gamma && xsel && code && part, "conv1_pool: null pointer");
   MG_CHECK_ARG(!(ticket || gram) || (beta && run_mean && run_var && num_batches_tracked && scale && shift && stat),
                "conv1_pool: the fused finalize needs the BatchNorm tensors");
   MG_CHECK_ARG(!(ticket && gram), "conv1_pool: statistics either from this launch (ticket) or from the Gram matrix");
-  const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
-                             scale, shift, stat);
   const int grid = grid_for(B, 768);
   if (C == 16) MG_LAUNCH((conv1_pool_kernel<16>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, gram, dims);
   else MG_LAUNCH((conv1_pool_kernel<8>), dim3(grid), dim3(256), 0, stream, B, img, W, bias, gamma, xsel, code, part, fin, gram, dims);
@@ -1377,14 +1429,21 @@ int mggan_conv2_fwd2(const float* xsel, int B, int C, const float* scale1, const
                      const float* W, const float* bias, float* y2, double* part, unsigned* ticket, double count,
                      const float* gamma, const float* beta, float* run_mean, float* run_var,
                      long long* num_batches_tracked, float momentum, float eps, int updates, float* scale, float* shift,
-                     float* stat, const int* dims, hipStream_t stream) {
+                     float* stat, const void* comm, const int* dims, hipStream_t stream) {
   MG_CHECK_ARG(C == 8 || C == 16, "conv2_fwd2: channels %d not built (8 or 16)", C);
+  MG_CHECK_ARG(!comm || (ticket && !dims), "conv2_fwd2: the in-launch exchange needs the fused finalize (ticket) and an unpadded batch");
+  const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
+                             scale, shift, stat, comm);
+  if (B == 0 && comm) {
+    MG_CHECK_ARG(part && gamma && beta && run_mean && run_var && num_batches_tracked && scale && shift && stat, "conv2_fwd2: null pointer");
+    MG_LAUNCH(bn_sync_finalize_dev_kernel, dim3(1), dim3(256), 0, stream, part, 0, C, fin);
+    MG_LAUNCH_CHECK("conv2_fwd2");
+    return MGGAN_OK;
+  }
   if (B == 0) return MGGAN_OK;
   MG_CHECK_ARG(xsel && scale1 && shift1 && W && bias && y2 && part, "conv2_fwd2: null pointer");
   MG_CHECK_ARG(!ticket || (gamma && beta && run_mean && run_var && num_batches_tracked && scale && shift && stat),
                "conv2_fwd2: the fused finalize needs the BatchNorm tensors");
-  const BnFin fin = make_fin(ticket, count, gamma, beta, run_mean, run_var, num_batches_tracked, momentum, eps, updates,
-                             scale, shift, stat);
   const int grid = grid_for(B, 768);
   static int valu = -1;  // MGGAN_CONV2_VALU=1: the register-tiled VALU kernel (A/B measurements)
   if (valu < 0) { const char* e = getenv("MGGAN_CONV2_VALU"); valu = e && e[0] == '1'; }
@@ -1407,8 +1466,9 @@ int mggan_bn_reduce_rows(const double* part, int rows, int W, double* sums, hipS
 }
 
 static BnBwdFin make_bfin(unsigned* ticket, double count, const float* gamma, const float* stat, float* coef, double* coefd,
-                          float* dgamma, float* dbeta) {
+                          float* dgamma, float* dbeta, const void* comm = nullptr) {
   BnBwdFin f;
+  f.comm = (const CommArgs*)comm;
   f.ticket = ticket; f.count = count; f.gamma = gamma; f.stat = stat; f.coef = coef; f.coefd = coefd; f.dgamma = dgamma;
   f.dbeta = dbeta;
   return f;
@@ -1476,10 +1536,10 @@ int mggan_bn1_from_gram(const double* gram, int C, const float* W, const float* 
 int mggan_conv1_tail_floats(int C) { return C * 36 + 2 * C; }
 
 int mggan_conv1_tail_fold(const double* wrows, int rows, const double* part1, int rows1, int C, double* tail, int riders,
-                          hipStream_t stream) {
+                          const double* rider_src, hipStream_t stream) {
   MG_CHECK_ARG(wrows && part1 && tail && rows >= 0 && rows1 >= 0 && (C == 8 || C == 16) && riders >= 0 && riders <= 64,
                "conv1_tail_fold: bad arguments");
-  MG_LAUNCH(conv1_tail_fold_kernel, dim3(C + 1), dim3(256), 0, stream, wrows, rows, part1, rows1, C, tail, riders);
+  MG_LAUNCH(conv1_tail_fold_kernel, dim3(C + 1), dim3(256), 0, stream, wrows, rows, part1, rows1, C, tail, riders, rider_src);
   MG_LAUNCH_CHECK("conv1_tail_fold");
   return MGGAN_OK;
 }

@@ -24,43 +24,6 @@ static unsigned* g_host_error = nullptr;
 long long comm_timeout_ticks() { return g_timeout_ticks; }
 unsigned* comm_host_error() { return g_host_error; }
 
-// One chunk of one vector: `k` = the chunk's flag index within the collective, `e0`/`cnt` = its elements of `data`,
-// `off` = byte offset of the vector inside a slot.
-template <typename T>
-__device__ __forceinline__ void comm_chunk(const CommArgs& a, T* data, long e0, long cnt, size_t off, int k, unsigned seq,
-                                           CommHeader* hdr, int* lost_s) {
-  char* mine = (char*)a.arena[a.rank];
-  const int buf = seq & 1, W = a.world, r = a.rank;
-  const size_t slot_bytes = (size_t)a.max_elems * 8, doff = comm_data_off(a.max_blocks);
-  T* src = data + e0;
-  // (a) my chunk into slot r of every rank
-  for (int j = 0; j < W; ++j) {
-    T* dst = (T*)((char*)a.arena[j] + doff + ((size_t)buf * COMM_MAX_RANKS + r) * slot_bytes + off) + e0;
-    for (long i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
-  }
-  if (threadIdx.x == 0) *lost_s = 0;
-  __threadfence_system();
-  __syncthreads();
-  // (b) stamp, (c) wait
-  if ((int)threadIdx.x < W) {
-    unsigned* pf = (unsigned*)((char*)a.arena[threadIdx.x] + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + r) * a.max_blocks + k;
-    __hip_atomic_store(pf, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    unsigned* wf = (unsigned*)(mine + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + threadIdx.x) * a.max_blocks + k;
-    if (!comm_wait_flag(wf, seq, hdr, a)) *lost_s = 1;
-  }
-  __syncthreads();
-  // (d) fixed-order sum of the W slots of my own arena -- or, when a peer never arrived, poison: a failed exchange must
-  // be visible in the weights (NaN), not look like a gradient
-  const bool lost = *lost_s != 0;
-  const T* base = (const T*)(mine + doff + (size_t)buf * COMM_MAX_RANKS * slot_bytes + off) + e0;
-  const size_t stride = slot_bytes / sizeof(T);
-  for (long i = threadIdx.x; i < cnt; i += 256) {
-    T s = __builtin_nontemporal_load(base + i);
-    for (int j = 1; j < W; ++j) s += __builtin_nontemporal_load(base + (size_t)j * stride + i);
-    src[i] = lost ? comm_poison<T>() : s;
-  }
-}
-
 // Vector 1 (`data`, n elements of T) in chunks 0 .. nb1-1; an optional f64 TAIL (`data2`, n2 doubles, behind vector 1 in the
 // slot at the next 256-byte boundary) in the chunks that follow: the per-rank f64 sums that must travel with a gradient
 // buffer (the layer-1 BatchNorm adjoint sums and the raw conv1 weight-gradient sums of the sharded scene CNN) ride in the
@@ -186,6 +149,30 @@ int mggan_comm_allreduce(void* const* arenas, int rank, int world, long max_elem
 int mggan_comm_allreduce2(void* const* arenas, int rank, int world, long max_elems, void* data, long n, int dtype,
                           double* data2, long n2, hipStream_t stream) {
   return comm_allreduce_launch(arenas, rank, world, max_elems, data, n, dtype, data2, n2, stream);
+}
+
+/* A channel's CommArgs in DEVICE memory, for the kernels that fold a small exchange into their last workgroup
+   (mggan_conv1_pool / mggan_conv2_fwd2 / mggan_scene_attention_bwd: `comm`); carries the wait bound and the host error
+   word in force when it is created.  *out: device pointer, released with mggan_comm_channel_free. */
+int mggan_comm_channel_create(void* const* arenas, int rank, int world, long max_elems, void** out) {
+  MG_CHECK_ARG(arenas && out && world >= 1 && world <= COMM_MAX_RANKS && rank >= 0 && rank < world && max_elems > 0,
+               "comm_channel_create: bad arguments");
+  const CommArgs a = comm_make_args(arenas, rank, world, max_elems);
+  void* p = nullptr;
+  MG_CHECK_HIP(hipMalloc(&p, sizeof(CommArgs)), "comm_channel_create: hipMalloc");
+  hipError_t e = hipMemcpy(p, &a, sizeof(CommArgs), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    mggan_set_error("comm_channel_create: hipMemcpy failed: %s", hipGetErrorString(e));
+    return MGGAN_ERR_LAUNCH;
+  }
+  *out = p;
+  return MGGAN_OK;
+}
+
+int mggan_comm_channel_free(void* p) {
+  if (p && hipFree(p) != hipSuccess) return MGGAN_ERR_LAUNCH;
+  return MGGAN_OK;
 }
 
 /* bound of every wait inside a collective, in seconds (> 0); applies to launches and captures made afterwards */

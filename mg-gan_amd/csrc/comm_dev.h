@@ -5,7 +5,7 @@
 #include "common.h"
 
 #define COMM_MAX_RANKS 8
-#define COMM_CHUNK 2048                 // elements per workgroup (8 per lane)
+#define COMM_CHUNK 1024                 // elements per workgroup (4 per lane)
 #define COMM_TICKS_PER_S 100000000ll     // wall_clock64 ticks (100 MHz)
 #define COMM_TIMEOUT_DEFAULT_S 30.0      // ranks drift apart for seconds in ordinary runs (per-rank data loading, validation,
                                          // checkpoints): the bound is for a LOST peer, not a late one (mggan_comm_set_timeout)
@@ -95,6 +95,43 @@ __device__ __forceinline__ void comm_allreduce_small(const CommArgs& a, double* 
   }
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One chunk of one vector: `k` = the chunk's flag index within the collective, `e0`/`cnt` = its elements of `data`,
+// `off` = byte offset of the vector inside a slot.
+template <typename T>
+__device__ __forceinline__ void comm_chunk(const CommArgs& a, T* data, long e0, long cnt, size_t off, int k, unsigned seq,
+                                           CommHeader* hdr, int* lost_s) {
+  char* mine = (char*)a.arena[a.rank];
+  const int buf = seq & 1, W = a.world, r = a.rank;
+  const size_t slot_bytes = (size_t)a.max_elems * 8, doff = comm_data_off(a.max_blocks);
+  T* src = data + e0;
+  // (a) my chunk into slot r of every rank
+  for (int j = 0; j < W; ++j) {
+    T* dst = (T*)((char*)a.arena[j] + doff + ((size_t)buf * COMM_MAX_RANKS + r) * slot_bytes + off) + e0;
+    for (long i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
+  }
+  if (threadIdx.x == 0) *lost_s = 0;
+  __threadfence_system();
+  __syncthreads();
+  // (b) stamp, (c) wait
+  if ((int)threadIdx.x < W) {
+    unsigned* pf = (unsigned*)((char*)a.arena[threadIdx.x] + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + r) * a.max_blocks + k;
+    __hip_atomic_store(pf, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned* wf = (unsigned*)(mine + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + threadIdx.x) * a.max_blocks + k;
+    if (!comm_wait_flag(wf, seq, hdr, a)) *lost_s = 1;
+  }
+  __syncthreads();
+  // (d) fixed-order sum of the W slots of my own arena -- or, when a peer never arrived, poison: a failed exchange must
+  // be visible in the weights (NaN), not look like a gradient
+  const bool lost = *lost_s != 0;
+  const T* base = (const T*)(mine + doff + (size_t)buf * COMM_MAX_RANKS * slot_bytes + off) + e0;
+  const size_t stride = slot_bytes / sizeof(T);
+  for (long i = threadIdx.x; i < cnt; i += blockDim.x) {
+    T s = __builtin_nontemporal_load(base + i);
+    for (int j = 1; j < W; ++j) s += __builtin_nontemporal_load(base + (size_t)j * stride + i);
+    src[i] = lost ? comm_poison<T>() : s;
+  }
 }
 
 static inline CommArgs comm_make_args(void* const* arenas, int rank, int world, long max_elems) {

@@ -9,7 +9,9 @@
 //   clip_grad_norm_ + AdamW               model/train.py:131-135,209-213,656-658; abstract_train.py:45-50
 // All reductions are fixed-order (deterministic); every loss kernel also emits the gradient
 // w.r.t. its input so logits never round-trip through autograd.
+#include <string.h>
 #include "common.h"
+#include "comm_dev.h"
 #include "../../include/mggan_hip.h"
 
 // ---- BCE on the discriminator output ---------------------------------------------------
@@ -536,14 +538,28 @@ __global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) out[c] = scale * (float)(red[0] / rows);
 }
 
-// ---- clip_grad_norm_ + AdamW over a flat parameter buffer with a segment table ---------------
-// ONE launch (round 5; before: a 256-workgroup norm pass and the update pass, 5 + 8-12 us with the gap between them on the
-// serial tail of all three optimizer steps of an iteration).  A workgroup first sums the squares of the very gradient
-// elements it is going to update, publishes the partial, and waits -- a grid barrier on a per-optimizer counter that only
-// ever grows: the grid is at most CA_MAX_BLOCKS workgroups of 256 threads, all resident at once, and a waiting workgroup
-// holds up nobody it waits for -- until every partial is there; then every workgroup adds the partials in index order (the
-// same total everywhere, bit for bit, run after run) and updates its elements.
+// ---- (all-reduce +) clip_grad_norm_ + AdamW over a flat parameter buffer with a segment table ---------------
+// ONE launch per optimizer step.  A workgroup owns whole 1,024-element chunks of the flat buffer (chunk b, b + grid, ...)
+// through every phase, so nothing but the norm couples the workgroups:
+//   phase 0 (sharded training over peer-mapped arenas, `comm`): the gradient all-reduce itself -- the chunk protocol of
+//            csrc/comm.hip (own chunk into slot r of every rank, flag, wait for the W flags, rank-ordered sum), chunk by chunk
+//            by the workgroup that will update those elements; round 5 ran it as a launch of its own in front of this one.
+//            The f64 tail that rides with the gradients (this rank's raw conv1 weight-gradient / BatchNorm-1 adjoint sums,
+//            csrc/cnn2.hip) is one more chunk, and its finalize -- the global-batch dW1 / dgamma1 / dbeta1 from the
+//            summed tail and the global Gram matrix -- happens right there instead of in a third launch: the tail has the
+//            launch's last workgroup to itself (its exchange runs beside those of the gradient chunks), the finalized
+//            block goes to a side buffer behind the counters, and the workgroups whose chunks hold slots of those three
+//            parameters (zero until then, also in the sum) wait for its flag and add it -- the same numbers on every rank.
+//            Without `comm` but with a tail (RCCL inside the graph: the exchange ran in front of this launch) the finalize
+//            alone happens here.
+//   phase 1: the squared norm of the elements a workgroup owns (f64), published; a grid barrier on a per-optimizer counter
+//            that only ever grows (the grid is at most CA_MAX_BLOCKS workgroups of 256 threads: all resident); then every
+//            workgroup adds the partials in index order (the same total everywhere, bit for bit, run after run).
+//   phase 2: clip + AdamW on the same elements.
+// Every wait is bounded (the collective's bound, or CA_WAIT_TICKS without one): a launch that gives up leaves NaN weights.
 #define CA_MAX_BLOCKS 256
+#define CA_CHUNK COMM_CHUNK
+#define CA_WAIT_TICKS (20ll * COMM_TICKS_PER_S)
 __device__ __forceinline__ void ca_store(double* p, double v) {
   __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
@@ -552,20 +568,45 @@ __device__ __forceinline__ double ca_load(const double* p) {
   return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT));
 }
-// workspace: [CA_MAX_BLOCKS partial sums | arrival counter | finished counter (64-bit integers)], zero before the first launch
+struct GradTail {          // the f64 tail of a step's gradient exchange and its finalize (mggan_grad_tail_t)
+  double* tail;            // [A (C x 36) | S1 (C) | S2 (C) | riders]; NULL: none
+  long n2;
+  const double* gram;      // 37 x 37, the GLOBAL batch's
+  const float* W;          // conv1 weight (C,4,3,3), bias, BatchNorm-1 gamma, stat1 = [mean | invstd]
+  const float* bias;
+  const float* gamma;
+  const float* stat;
+  float* dW;               // slots INSIDE the flat gradient buffer: += the global-batch gradient
+  float* dgamma;
+  float* dbeta;
+  int C;
+};
+// workspace: [CA_MAX_BLOCKS partial sums | arrival counter | finished counter | tail-finalize flag (64-bit words)], zero
+// before the first launch; every launch leaves it ready for the next
 #define CA_SEG_TABLE 512
+#define CA_WS_DOUBLES 264        // partials + counters; the finalize block (38 C <= 608 floats) follows
+__device__ __forceinline__ bool ca_wait_ge(unsigned long long* p, unsigned long long target, long long bound) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (wall_clock64() - t0 > bound) return false;
+  }
+  return true;
+}
 __global__ __launch_bounds__(256) void clip_adamw_kernel(float* param, float* grad, float* m, float* v, long n,
                                                          const int* __restrict__ elem_seg,
                                                          const unsigned char* __restrict__ active, int nseg,
                                                          int* seg_step, double* workspace, float max_norm, double lr_arg,
                                                          const double* __restrict__ lr_dev, double beta1, double beta2,
-                                                         double eps_d, double wd, int zero_grad, float* norm_out) {
+                                                         double eps_d, double wd, int zero_grad, float* norm_out,
+                                                         const CommArgs* __restrict__ comm, GradTail gt) {
   __shared__ double red[256];
   __shared__ float s_sq2[CA_SEG_TABLE], s_lr1[CA_SEG_TABLE];
+  __shared__ int lost_s, gave_up;
   const double lr = lr_dev ? *lr_dev : lr_arg;  // device-resident: a captured graph follows the schedule
-  const long stride = (long)gridDim.x * 256, i0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const int nchunks = (int)((n + CA_CHUNK - 1) / CA_CHUNK);
   // the bias corrections depend on the tensor (its step count), not on the element: two f64 pow() per TENSOR and workgroup
-  // instead of per element (four elements per lane: eight of them in a row on the optimizer's critical path)
+  // instead of per element
   const bool table = nseg <= CA_SEG_TABLE;
   if (table)
     for (int sg = threadIdx.x; sg < nseg; sg += 256) {
@@ -574,11 +615,74 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* param, float* gr
       s_sq2[sg] = (float)sqrt(bc2);
       s_lr1[sg] = (float)(lr / bc1);
     }
-  // ---- phase 1: this workgroup's share of the squared norm (f64) ----
+  if (threadIdx.x == 0) gave_up = 0;
+  unsigned long long* counter = (unsigned long long*)(workspace + CA_MAX_BLOCKS);
+  unsigned long long* fin_flag = counter + 2;
+  const long long bound = comm ? comm->timeout_ticks : CA_WAIT_TICKS;
+  // ---- phase 0: the exchange (and the tail's finalize) ----
+  CommHeader* hdr = comm ? (CommHeader*)comm->arena[comm->rank] : nullptr;
+  const unsigned seq = comm ? __hip_atomic_load(&hdr->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
+  float* fin_out = (float*)(workspace + CA_WS_DOUBLES);  // 38 C floats behind the counters
+  // the tail has a workgroup of its own (the last one): nobody exchanges two things in a row
+  const int nwork = gridDim.x - (gt.tail ? 1 : 0);
+  if (gt.tail && (int)blockIdx.x == nwork) {
+    if (comm) {
+      const size_t off = ((size_t)n * sizeof(float) + 255) / 256 * 256;
+      comm_chunk<double>(*comm, gt.tail, 0, gt.n2, off, nchunks, seq, hdr, &lost_s);
+      __syncthreads();
+    }
+    {
+      // dW1 = (gamma/sigma) (A - (S1/n) B - (S2/n) Chat),  dgamma1 = S2,  dbeta1 = S1  (csrc/cnn2.hip:
+      // conv1_tail_finalize_kernel, one 64-lane group per output channel) -> fin_out = [dW1 (C x 36) | dbeta1 (C) | dgamma1 (C)]
+      const int C = gt.C, t = threadIdx.x & 63;
+      const double nn = gt.gram[36 * 37 + 36];
+      for (int c = threadIdx.x >> 6; c < C; c += 4) {
+        const double S1 = gt.tail[C * 36 + c], S2 = gt.tail[C * 36 + C + c];
+        if (t == 36) fin_out[C * 36 + c] = (float)S1;
+        if (t == 37) fin_out[C * 37 + c] = (float)S2;
+        if (t < 36) {
+          const double mean = (double)gt.stat[c], inv = (double)gt.stat[C + c], cs = (double)gt.gamma[c] * inv;
+          const double Bt = gt.gram[36 * 37 + t];
+          double wp = 0.0;
+          for (int s = 0; s < 36; ++s) wp += (double)gt.W[c * 36 + s] * gt.gram[s * 37 + t];
+          const double chat = (wp + ((double)gt.bias[c] - mean) * Bt) * inv;
+          fin_out[c * 36 + t] = (float)(cs * (gt.tail[c * 36 + t] - (S1 / nn) * Bt - (S2 / nn) * chat));
+        }
+      }
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(fin_flag, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
   double acc = 0.0;
-  for (long i = i0; i < n; i += stride) {
-    const int sg = elem_seg[i];
-    if (sg >= 0 && active[sg]) acc += (double)grad[i] * (double)grad[i];
+  const long dW0 = gt.tail ? (long)(gt.dW - grad) : 0, dG0 = gt.tail ? (long)(gt.dgamma - grad) : 0,
+             dB0 = gt.tail ? (long)(gt.dbeta - grad) : 0;
+  for (int k = blockIdx.x; k < nchunks && (int)blockIdx.x < nwork; k += nwork) {
+    const long e0 = (long)k * CA_CHUNK, cnt = min((long)CA_CHUNK, n - e0), e1 = e0 + cnt;
+    if (comm) {
+      comm_chunk<float>(*comm, grad, e0, cnt, 0, k, seq, hdr, &lost_s);
+      __syncthreads();
+    }
+    if (gt.tail && ((dW0 < e1 && dW0 + gt.C * 36 > e0) || (dG0 < e1 && dG0 + gt.C > e0) || (dB0 < e1 && dB0 + gt.C > e0))) {
+      // this chunk holds slots of dW1 / dgamma1 / dbeta1 (zero so far, also in the sum): the tail workgroup's finalize
+      // goes in now -- the same numbers on every rank
+      if (threadIdx.x == 0 && !ca_wait_ge(fin_flag, 1ull, bound)) gave_up = 1;
+      __syncthreads();
+      __threadfence();
+      for (long i = e0 + threadIdx.x; i < e1; i += 256) {
+        float add = 0.f;
+        if (i >= dW0 && i < dW0 + gt.C * 36) add = __builtin_nontemporal_load(fin_out + (i - dW0));
+        else if (i >= dB0 && i < dB0 + gt.C) add = __builtin_nontemporal_load(fin_out + gt.C * 36 + (i - dB0));
+        else if (i >= dG0 && i < dG0 + gt.C) add = __builtin_nontemporal_load(fin_out + gt.C * 37 + (i - dG0));
+        if (add != 0.f) grad[i] += add;
+      }
+    }
+    // ---- phase 1: this chunk's share of the squared norm (f64) ----
+    for (long i = e0 + threadIdx.x; i < e1; i += 256) {
+      const int sg = elem_seg[i];
+      if (sg >= 0 && active[sg]) acc += (double)grad[i] * (double)grad[i];
+    }
   }
   red[threadIdx.x] = acc;
   __syncthreads();
@@ -586,14 +690,13 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* param, float* gr
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  unsigned long long* counter = (unsigned long long*)(workspace + CA_MAX_BLOCKS);
   if (threadIdx.x == 0) {
     ca_store(workspace + blockIdx.x, red[0]);
     __threadfence();
     const unsigned long long mine = atomicAdd(counter, 1ull);
     // this launch's arrivals are (mine - mine % grid) .. + grid - 1: launches of one optimizer are ordered by their stream
     const unsigned long long target = mine - mine % gridDim.x + gridDim.x;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    if (!ca_wait_ge(counter, target, bound)) gave_up = 1;
     __threadfence();
   }
   __syncthreads();
@@ -607,33 +710,37 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* param, float* gr
   const float total = (float)sqrt(red[0]);
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.f);
+  if (gave_up) coef = __builtin_nanf("");  // a wait ran out: visible in the weights, never a half-exchanged update
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
   // ---- phase 2: clip + AdamW on the same elements; the Adam step counter of a touched tensor is its old value + 1 (the
   // counters themselves are advanced by the LAST workgroup to finish its elements: nobody reads them after that)
-  for (long i = i0; i < n; i += stride) {
-    const int sg = elem_seg[i];
-    if (sg < 0 || !active[sg]) continue;
-    const float g = grad[i] * coef;
-    grad[i] = zero_grad ? 0.f : g;  // clip_grad_norm_ scales .grad in place; or leave it zeroed for the next step
-    // torch.optim.AdamW single-tensor path: scalar factors in double, tensor math in f32
-    float p = param[i] * (float)(1.0 - lr * wd);
-    const float mi = m[i] + (g - m[i]) * (float)(1.0 - beta1);          // exp_avg.lerp_(grad, 1-beta1)
-    const float vi = v[i] * (float)beta2 + g * g * (float)(1.0 - beta2);  // mul_(beta2).addcmul_
-    m[i] = mi;
-    v[i] = vi;
-    float sq2, lr1;
-    if (table) {
-      sq2 = s_sq2[sg];
-      lr1 = s_lr1[sg];
-    } else {
-      const int t = seg_step[sg] + 1;
-      const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
-      sq2 = (float)sqrt(bc2);
-      lr1 = (float)(lr / bc1);
+  for (int k = blockIdx.x; k < nchunks && (int)blockIdx.x < nwork; k += nwork) {
+    const long e0 = (long)k * CA_CHUNK, e1 = min(n, e0 + CA_CHUNK);
+    for (long i = e0 + threadIdx.x; i < e1; i += 256) {
+      const int sg = elem_seg[i];
+      if (sg < 0 || !active[sg]) continue;
+      const float g = grad[i] * coef;
+      grad[i] = zero_grad ? 0.f : g;  // clip_grad_norm_ scales .grad in place; or leave it zeroed for the next step
+      // torch.optim.AdamW single-tensor path: scalar factors in double, tensor math in f32
+      float p = param[i] * (float)(1.0 - lr * wd);
+      const float mi = m[i] + (g - m[i]) * (float)(1.0 - beta1);          // exp_avg.lerp_(grad, 1-beta1)
+      const float vi = v[i] * (float)beta2 + g * g * (float)(1.0 - beta2);  // mul_(beta2).addcmul_
+      m[i] = mi;
+      v[i] = vi;
+      float sq2, lr1;
+      if (table) {
+        sq2 = s_sq2[sg];
+        lr1 = s_lr1[sg];
+      } else {
+        const int t = seg_step[sg] + 1;
+        const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+        sq2 = (float)sqrt(bc2);
+        lr1 = (float)(lr / bc1);
+      }
+      const float denom = sqrtf(vi) / sq2 + (float)eps_d;
+      p -= lr1 * (mi / denom);
+      param[i] = p;
     }
-    const float denom = sqrtf(vi) / sq2 + (float)eps_d;
-    p -= lr1 * (mi / denom);
-    param[i] = p;
   }
   __shared__ int last;
   __syncthreads();
@@ -641,7 +748,11 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* param, float* gr
   if (threadIdx.x == 0) {
     const unsigned long long d = atomicAdd(done, 1ull);
     last = d == gridDim.x - 1;
-    if (last) __hip_atomic_store(done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last) {
+      __hip_atomic_store(done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(fin_flag, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+      if (comm) __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the collective is closed
+    }
   }
   __syncthreads();
   if (last)
@@ -1346,18 +1457,31 @@ int mggan_inv_counts(const int* counts, int g, float* inv_count, hipStream_t str
   return MGGAN_OK;
 }
 
-/* workspace: 258 doubles, ZERO before the first call (partial sums + the grid barrier's two counters; left ready for the next) */
+/* workspace: 600 doubles, ZERO before the first call (partial sums + the grid barrier's counters + the tail flag + the
+   finalized tail block; left ready for the next).  comm (device CommArgs of the calling stream's channel, mggan_comm_channel_create) and tail: see the header. */
 int mggan_clip_adamw(float* param, float* grad, float* m, float* v, long n, const int* elem_seg, int nseg,
                      const unsigned char* active, int* seg_step, float max_norm, double lr, const double* lr_dev,
                      double beta1, double beta2, double eps, double weight_decay, int zero_grad, double* workspace,
-                     float* norm_out, hipStream_t stream) {
+                     float* norm_out, const void* comm, const mggan_grad_tail_t* tail, hipStream_t stream) {
   MG_CHECK_ARG(param && grad && m && v && elem_seg && active && seg_step && workspace, "clip_adamw: null pointer");
   if (n == 0) return MGGAN_OK;
-  // workspace: 258 doubles (mggan_clip_adamw_workspace), zeroed once by the caller
-  int blocks = cdiv(n, 256 * 4);
-  if (blocks > CA_MAX_BLOCKS) blocks = CA_MAX_BLOCKS;
+  GradTail gt;
+  memset(&gt, 0, sizeof(gt));
+  if (tail && tail->tail) {
+    MG_CHECK_ARG(tail->gram && tail->W && tail->bias && tail->gamma && tail->stat && tail->dW && tail->dgamma && tail->dbeta &&
+                     (tail->C == 8 || tail->C == 16) && tail->n2 >= (long)tail->C * 38 && tail->n2 <= COMM_CHUNK,
+                 "clip_adamw: incomplete gradient tail");
+    MG_CHECK_ARG(tail->dW >= grad && tail->dW + tail->C * 36 <= grad + n && tail->dgamma >= grad && tail->dgamma + tail->C <= grad + n &&
+                     tail->dbeta >= grad && tail->dbeta + tail->C <= grad + n,
+                 "clip_adamw: the tail's gradient slots lie outside the flat gradient buffer");
+    gt.tail = tail->tail; gt.n2 = tail->n2; gt.gram = tail->gram; gt.W = tail->W; gt.bias = tail->bias; gt.gamma = tail->gamma;
+    gt.stat = tail->stat; gt.dW = tail->dW; gt.dgamma = tail->dgamma; gt.dbeta = tail->dbeta; gt.C = tail->C;
+  }
+  int blocks = cdiv(n, CA_CHUNK);
+  if (blocks > CA_MAX_BLOCKS - 1) blocks = CA_MAX_BLOCKS - 1;
+  if (gt.tail) blocks += 1;  // the tail's own workgroup
   MG_LAUNCH(clip_adamw_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, m, v, n, elem_seg, active, nseg, seg_step,
-            workspace, max_norm, lr, lr_dev, beta1, beta2, eps, weight_decay, zero_grad, norm_out);
+            workspace, max_norm, lr, lr_dev, beta1, beta2, eps, weight_decay, zero_grad, norm_out, (const CommArgs*)comm, gt);
   MG_LAUNCH_CHECK("clip_adamw");
   return MGGAN_OK;
 }

@@ -52,7 +52,7 @@ class DeviceComm:
         elements (sized by the caller from the largest vector it will reduce; the same on every rank)."""
         self.group, self.device = group, torch.device(device)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self._local, self._opened, self._arenas = [], [], []
+        self._local, self._opened, self._arenas, self._chan_dev = [], [], [], {}
         if max_elems is not None:
             self.MAX_ELEMS = max(int(max_elems), 1 << 10)
         lib.mggan_comm_set_timeout(float(os.environ.get("MGGAN_COMM_TIMEOUT_S", "30")))
@@ -143,6 +143,25 @@ class DeviceComm:
         (mggan_bn_sync_finalize)."""
         return self._arenas[self._channel()], self.rank, self.world, self.MAX_ELEMS
 
+    def channel_dev(self):
+        """Device copy of the current stream's channel arguments (include/mggan_hip.h: the `comm` argument of the scene-CNN
+        entries that fold their BatchNorm exchange into their last workgroup); created at the channel's first use."""
+        ch = self._channel()
+        p = self._chan_dev.get(ch)
+        if p is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("device all-reduce: channel {} meets its first in-launch exchange inside a capture (run "
+                                   "an eager iteration first)".format(ch))
+            q = ctypes.c_void_p()
+            lib.mggan_comm_channel_create(self._arenas[ch], self.rank, self.world, self.MAX_ELEMS, ctypes.byref(q))
+            p = self._chan_dev[ch] = q
+        return p
+
+    def chunks_fit(self, n_f32):
+        """Can the optimizer's launch run the exchange of n_f32 floats + a tail chunk itself (one flag per 1,024-element
+        chunk, csrc/loss_opt.hip)?"""
+        return (n_f32 + 1023) // 1024 + 1 <= (self.MAX_ELEMS * 2 + 1023) // 1024
+
     def supports(self, t, tail=None):
         """Does `t` (and an f64 tail behind it, at the next 256-byte boundary of the slot) fit an arena slot?"""
         if not (t.is_cuda and t.is_contiguous() and t.dtype in _DTYPES):
@@ -190,6 +209,9 @@ class DeviceComm:
             raise RuntimeError("device all-reduce: timed-out wait on channel(s) {} of rank {}".format(bad, self.rank))
 
     def close(self):
+        for q in getattr(self, "_chan_dev", {}).values():
+            lib.mggan_comm_channel_free(q)
+        self._chan_dev = {}
         for q in getattr(self, "_opened", []):
             lib.mggan_comm_ipc_close(q)
         for p in getattr(self, "_local", []):

@@ -1515,6 +1515,7 @@ def begin_images(img, side=True, defer=False, sync=None):
         return
     img = img.contiguous()
     if sync is not None:
+        choose_gram_schedule(img.shape[0], sync)
         # (a rank whose shard holds no pedestrian announces its empty batch like any other: the Gram kernel copes with
         #  B = 0, and every rank must issue the same collectives on the same channels)
         if GRAM_SCHEDULE == "late" and side and _BR["on"] and getattr(sync, "stream_safe", False):
@@ -1569,7 +1570,22 @@ def global_gram(img, sync, side=False):
 #   side            -- on the side stream from the start of the iteration; only the FIRST pass exchanges its own sums (12),
 #                      but the launch runs beside the trunk's conv1 (+270 us at 256 x 32: both fill the chip).
 #   first           -- on the caller's stream before anything else: every pass uses it (11), the iteration waits for it.
-GRAM_SCHEDULE = os.environ.get("MGGAN_GRAM_SCHEDULE", "late")
+#   auto  (default) -- decided per batch from the shard's image count: `first` from GRAM_FIRST_MIN_B images per rank on (the
+#                      Gram launch is a few per cent of such an iteration and saves two exchanges), `late` below.  A host-side
+#                      decision every rank must take alike: only shards known to be equal (DistContext.equal_shards, what a
+#                      captured iteration needs anyway) go by their size, unequal ones stay `late`.
+_GRAM_SCHEDULE_ENV = os.environ.get("MGGAN_GRAM_SCHEDULE", "auto")
+GRAM_FIRST_MIN_B = int(os.environ.get("MGGAN_GRAM_FIRST_MIN_B", "4096"))
+GRAM_SCHEDULE = "late" if _GRAM_SCHEDULE_ENV == "auto" else _GRAM_SCHEDULE_ENV
+
+
+def choose_gram_schedule(n_images, sync):
+    """Set the schedule of this iteration (begin_images calls it before anything is announced)."""
+    global GRAM_SCHEDULE
+    if _GRAM_SCHEDULE_ENV != "auto":
+        return GRAM_SCHEDULE
+    GRAM_SCHEDULE = "first" if (getattr(sync, "equal_shards", False) and n_images >= GRAM_FIRST_MIN_B) else "late"
+    return GRAM_SCHEDULE
 
 
 def gram_for_pass(img, sync):
@@ -1645,7 +1661,18 @@ def _image_gram(img, dims=None):
 # measured and not used -- 1.400 vs 1.393 ms at 64 x 20 (three alternating pairs on one box), 4.77 = 4.76 ms at 256 x 32: the
 # write-through stores of 576 doubles per workgroup and the wait cost more than the 8 us launch they replace.
 C1_TICKET = os.environ.get("MGGAN_CONV1_TICKET", "0") == "1"
+BN_EXCHANGE_IN_LAUNCH = os.environ.get("MGGAN_BN_EXCHANGE", "fused") != "launch"
 TAIL_RIDERS = 16  # spare doubles at the end of a gradient tail (mggan/parallel.py: DistContext.all_reduce_grads)
+_RIDER_SRC = {}   # id(root) -> f64 tensor (TAIL_RIDERS) whose contents the root's next gradient tail carries as riders
+
+
+def set_rider_src(root, src):
+    """The next scene-CNN backward pass of `root` (sharded) copies `src` (TAIL_RIDERS doubles, written on a stream that
+    backward pass is ordered behind) into the rider slots of its gradient tail."""
+    if src is None:
+        _RIDER_SRC.pop(id(root), None)
+    else:
+        _RIDER_SRC[id(root)] = src
 
 
 def _cnn_tickets(owner, dev):
@@ -1653,6 +1680,13 @@ def _cnn_tickets(owner, dev):
     if t is None or t.device != dev:
         t = owner.__dict__["_cnn_tickets"] = torch.zeros(8, dtype=torch.int32, device=dev)
     return t
+
+
+class GradTailDesc(ctypes.Structure):
+    """include/mggan_hip.h: mggan_grad_tail_t"""
+    _fields_ = [("tail", ctypes.c_void_p), ("n2", ctypes.c_long), ("gram", ctypes.c_void_p), ("W", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("stat", ctypes.c_void_p), ("dW", ctypes.c_void_p),
+                ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p), ("C", ctypes.c_int)]
 
 
 class SceneAttentionFn(Function):
@@ -1676,10 +1710,17 @@ class SceneAttentionFn(Function):
         fused = training and sync is None  # single GPU: the kernel's last workgroup finalizes BatchNorm itself
         mk = lambda: (_empty(C, like=img), _empty(C, like=img), _empty(2 * C, like=img))
 
-        def bn_args(bn, gamma, beta, hw, k, out3):
-            return (tk.data_ptr() + 4 * k if fused else 0, float(B) * hw, _p(gamma), _p(beta), _p(bn.running_mean),
-                    _p(bn.running_var), _p(bn.num_batches_tracked), float(bn.momentum), float(bn.eps), stat_updates,
-                    _p(out3[0]), _p(out3[1]), _p(out3[2]))
+        # sharded over peer-mapped arenas: the exchange of a BatchNorm point rides in the producing launch's last
+        # workgroup (csrc/cnn2.hip: bn_finalize_block) -- no launch of its own (MGGAN_BN_EXCHANGE=launch: round 5's
+        # fold + exchange + finalize kernel behind the producer)
+        dc = getattr(sync, "devcomm", None) if (training and sync is not None) else None
+        inl = dc is not None and BN_EXCHANGE_IN_LAUNCH
+        comm_dev = dc.channel_dev() if inl else 0
+
+        def bn_args(bn, gamma, beta, hw, k, out3, in_launch=False):
+            return (tk.data_ptr() + 4 * k if (fused or in_launch) else 0, float(B) * hw, _p(gamma), _p(beta),
+                    _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), float(bn.momentum), float(bn.eps),
+                    stat_updates, _p(out3[0]), _p(out3[1]), _p(out3[2]))
 
         def finalize_unfused(bn, gamma, beta, hw, out3):
             """eval mode (running statistics) or sharded training (sums exchanged between the ranks first)"""
@@ -1711,9 +1752,13 @@ class SceneAttentionFn(Function):
         # Gram matrix is computed and all-reduced on a side stream from the start of the iteration; the FIRST scene-CNN pass
         # of the iteration would wait ~a conv1_pool for it and exchanges its own 2C sums instead (gram_for_pass).
         gram_g = gram_for_pass(img, sync) if (training and sync is not None) else None
+        inl1 = inl and gram_g is None
         lib.mggan_conv1_pool(_p(img), B, C, _p(c1w), _p(c1b), _p(xsel), _p(code), _p(part),
-                             *bn_args(bn1, g1, be1, 33 * 33, 0, b1), _p(gram_g), pd, st)
+                             *bn_args(bn1, g1, be1, 33 * 33, 0, b1, inl1), _p(gram_g), comm_dev if inl1 else 0, pd, st)
         if gram_g is not None:
+            cnt1 = float("nan")
+        elif inl1:
+            sync.count_collective("bn1.forward")
             cnt1 = float("nan")
         else:
             cnt1 = float(B) * 33 * 33 if fused else finalize_unfused(bn1, g1, be1, 33 * 33, b1)
@@ -1721,8 +1766,12 @@ class SceneAttentionFn(Function):
         y2 = _empty(B, C, 16, 16, like=img)
         b2 = mk()
         lib.mggan_conv2_fwd2(_p(xsel), B, C, _p(sc1), _p(sh1), _p(c2w), _p(c2b), _p(y2), _p(part),
-                             *bn_args(bn2, g2, be2, 16 * 16, 1, b2), pd, st)
-        cnt2 = float(B) * 16 * 16 if fused else finalize_unfused(bn2, g2, be2, 16 * 16, b2)
+                             *bn_args(bn2, g2, be2, 16 * 16, 1, b2, inl), comm_dev, pd, st)
+        if inl:
+            sync.count_collective("bn2.forward")
+            cnt2 = float("nan")
+        else:
+            cnt2 = float(B) * 16 * 16 if fused else finalize_unfused(bn2, g2, be2, 16 * 16, b2)
         sc2, sh2, stat2 = b2
         out, ld_o = _out(out_slot, B, 64, img)
         # what the adjoint needs of the conv2 output per pooled cell: the raw value that won the 2x2 window and its position
@@ -1760,9 +1809,14 @@ class SceneAttentionFn(Function):
         # the attention head's weight gradients come out of the same launch: one partial block per workgroup
         pf = lib.mggan_scene_attention_partial_floats(C)
         wpart = _empty(rows2 * pf, like=img)
+        dc = getattr(sync, "devcomm", None)
+        inl = dc is not None and BN_EXCHANGE_IN_LAUNCH  # the BatchNorm-2 adjoint exchange inside this launch's last workgroup
+        if inl:
+            sync.count_collective("bn2.backward")
         lib.mggan_scene_attention_bwd(_p(ysel), _p(ycode), B, C, _p(sc2), _p(sh2), _p(stat2), _p(wa), _p(ba), _p(wb), _p(bb), _p(dout),
-                                      ld, _p(G2), _p(wpart), _p(part2), tk.data_ptr() + 8 if fused else 0, cnt2, _p(g2),
-                                      _p(coef2), root.grad_ptr(g2), root.grad_ptr(be2), pd, st)
+                                      ld, _p(G2), _p(wpart), _p(part2), tk.data_ptr() + 8 if (fused or inl) else 0,
+                                      float(B) * 16 * 16 if inl else cnt2, _p(g2), _p(coef2), root.grad_ptr(g2),
+                                      root.grad_ptr(be2), dc.channel_dev() if inl else 0, pd, st)
         if B:
             p0 = wpart.data_ptr()
             adescs = ((p0, root.grad_ptr(wa), root.grad_ptr(ba), 32, C + 1, C),
@@ -1791,7 +1845,7 @@ class SceneAttentionFn(Function):
             lib.mggan_bn_bwd_coef(_p(sums), _p(local), cnt, C, _p(gamma), _p(stat), _p(coef), _p(coefd),
                                   root.grad_ptr(gamma), root.grad_ptr(beta), st)
 
-        if not fused:
+        if not fused and not inl:
             bn_bwd_sharded(part2, rows2, g2, be2, stat2, cnt2, coef2, None, 16 * 16)
         G1c = _empty(B, C, 16, 16, like=img)
         grid = lib.mggan_cnn_bwd_grid(B)
@@ -1830,15 +1884,22 @@ class SceneAttentionFn(Function):
         #  generator counts of the next step -- zero unless somebody writes them)
         tf = lib.mggan_conv1_tail_floats(C)
         tail = torch.empty(tf + TAIL_RIDERS, dtype=torch.float64, device=dev)
+        # riders prepared ahead of the backward pass (the trainer's generator counts, set_rider_src) are copied in by the
+        # fold itself; the root remembers that its tail carries them
+        src = _RIDER_SRC.pop(id(root), None)
+        root.__dict__["_rider_in_tail"] = src is not None
         lib.mggan_conv1_tail_fold(_p(wsw), max(lib.mggan_cnn_grid(B), 1) if B else 0, _p(part1), grid if B else 0, C,
-                                  _p(tail), TAIL_RIDERS, st)
+                                  _p(tail), TAIL_RIDERS, _p(src), st)
         ptrs = (root.grad_ptr(c1w), root.grad_ptr(g1), root.grad_ptr(be1))
 
         def finalize(tail=tail, gram=gram, keep=(wsw, part1)):
             lib.mggan_conv1_tail_finalize(_p(tail), _p(gram), C, _p(c1w), _p(c1b), _p(g1), _p(stat1), ptrs[0], ptrs[1],
                                           ptrs[2], _s())
 
-        root.__dict__.setdefault("_grad_tails", []).append((tail, finalize, tf))
+        # (4th entry: what the optimizer launch needs to run exchange + finalize itself, include/mggan_hip.h:
+        #  mggan_grad_tail_t -- and the tensors that have to outlive it)
+        desc = GradTailDesc(_p(tail), tail.numel(), _p(gram), _p(c1w), _p(c1b), _p(g1), _p(stat1), ptrs[0], ptrs[1], ptrs[2], C)
+        root.__dict__.setdefault("_grad_tails", []).append((tail, finalize, tf, desc, (tail, gram, wsw, part1, stat1)))
         return (None,) * 21
 
 

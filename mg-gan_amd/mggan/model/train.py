@@ -153,30 +153,40 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         """Row count over all ranks (loss normalisers are means over the GLOBAL batch)."""
         return self.dist.global_count(n) if self.dist.enabled else n
 
-    def _ride_generator_counts(self, shared, b):
+    def _early_rider_counts(self, logits, b):
         """Sharded training: the generator step weights its rows by 1 / count(generator) over the GLOBAL batch
         (train.py:94-96 of the reference) -- an exchange of its own per iteration.  Its picks are already determined when
-        the discriminator step ends (PM-network logits of the shared trunk, uniforms drawn at the start of the iteration),
-        so this rank's counts are computed now and travel as riders in the f64 tail of the discriminator's gradient
-        all-reduce; _gen_weights finds the global counts there."""
-        self._rider_counts = None
-        if not (self.dist.enabled and shared is not None and shared.get("g_logits") is not None
-                and getattr(self.rng, "on_device", False) and hasattr(self.rng, "peek_uniforms")
+        the PM-network logits of the shared trunk exist (the uniforms were drawn at the start of the iteration), so this
+        rank's counts are computed right there -- on the discriminator step's fake-trajectory branch, which has slack --
+        and travel as riders in the f64 tail of the discriminator's gradient exchange (the tail fold copies them in,
+        HF.set_rider_src); _gen_weights finds the global counts there."""
+        self._rider_counts, self._rider_early = None, None
+        HF.set_rider_src(self.D, None)
+        if not (self.dist.enabled and logits is not None and getattr(self.rng, "on_device", False)
+                and hasattr(self.rng, "peek_uniforms") and getattr(self.config, "bn_sync", "global") == "global"
                 and os.environ.get("MGGAN_COUNT_RIDER", "1") != "0"):
             return
-        tails = self.D.__dict__.get("_grad_tails") or []
-        logits = shared["g_logits"]
         K, g = int(self.config.num_samples), self.G.n_gs
         u = self.rng.peek_uniforms(b * K, logits.device)
-        if len(tails) != 1 or u is None or g > HF.TAIL_RIDERS or logits.shape != (b, g) or not logits.is_contiguous():
+        if u is None or g > HF.TAIL_RIDERS or logits.shape != (b, g) or not logits.is_contiguous():
+            return
+        buf = self.__dict__.get("_rider_buf")
+        if buf is None or buf.device != logits.device:
+            buf = self._rider_buf = torch.zeros(HF.TAIL_RIDERS, dtype=torch.float64, device=logits.device)
+            self._count_scratch = torch.zeros(17, dtype=torch.int32, device=logits.device)
+        lib.mggan_sample_counts(b, K, g, logits.data_ptr(), u.data_ptr(), self._count_scratch.data_ptr(), buf.data_ptr(), HF._s())
+        HF.set_rider_src(self.D, buf)
+        self._rider_early = (u.data_ptr(), b * K)
+
+    def _ride_generator_counts(self):
+        """Behind the discriminator step's backward pass: did its gradient tail take the counts along?"""
+        early, self._rider_early = getattr(self, "_rider_early", None), None
+        HF.set_rider_src(self.D, None)
+        tails = self.D.__dict__.get("_grad_tails") or []
+        if early is None or len(tails) != 1 or not self.D.__dict__.get("_rider_in_tail", False):
             return
         tail, tf = tails[0][0], tails[0][2]
-        riders = tail[tf:tf + HF.TAIL_RIDERS]
-        scratch = self.__dict__.get("_count_scratch")
-        if scratch is None or scratch.device != logits.device:
-            scratch = self._count_scratch = torch.zeros(17, dtype=torch.int32, device=logits.device)
-        lib.mggan_sample_counts(b, K, g, logits.data_ptr(), u.data_ptr(), scratch.data_ptr(), riders.data_ptr(), HF._s())
-        self._rider_counts = (riders, u.data_ptr(), b * K)
+        self._rider_counts = (tail[tf:tf + HF.TAIL_RIDERS], early[0], early[1])
 
     def _gen_weights(self, gen_idxs):
         """Batch-global 1/count(generator) weights (train.py:94-96) + int32 row targets in (k*b+ped) order."""
@@ -191,7 +201,10 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         st = HF._s()
         rider, self._rider_counts = getattr(self, "_rider_counts", None), None
         check = os.environ.get("MGGAN_CHECK_RIDERS", "0") == "1"  # (tests: a host sync and an exchange of its own)
-        if self.dist.enabled and rider is not None and rider[2] == row_gen.numel():
+        # (the riders are the counts of THIS step's picks only if its sampling read the uniforms they were counted on: a
+        #  re-drawn pool or an unplanned call in between falls back to the counted exchange)
+        if self.dist.enabled and rider is not None and rider[2] == row_gen.numel() \
+                and getattr(self.rng, "last_sample_u", None) == (rider[1], rider[2]):
             # the global counts came with the discriminator step's gradient exchange (_ride_generator_counts)
             if check:
                 lib.mggan_gen_counts(row_gen.data_ptr(), row_gen.numel(), g, counts.data_ptr(), inv.data_ptr(), 0, 0, st)
@@ -263,6 +276,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                                                       trunk=None if g_trunk is None else tuple(t.detach() for t in g_trunk))
             if shared is not None and g_trunk is not None:
                 shared["g_logits"] = g_logits  # same trunk, same weights in the generator step: not recomputed there
+                self._early_rider_counts(g_logits, in_xy.size(1))
             rows_d = getattr(self.G, "last_rows", None)
             HF.mark("D.fake.end")
         # history LSTM + scene CNN of D are identical in the real and the fake pass: run them once
@@ -328,16 +342,17 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             HF.launch_images()  # (A/B knob: the Gram matrix beside the backward pass instead of the row pass)
         if (_G_EARLY and in_xy.size(1) >= _G_EARLY_MIN_B and shared is not None and shared.get("g_trunk") is not None
                 and shared.get("g_logits") is not None and HF._BR["on"] and not HF._on_branch() and loss_mask is None
-                and not self.dist.enabled):
-            # (sharded training keeps the in-step order: the generator counts ride in the discriminator's gradient exchange
-            #  on uniforms PEEKED after this point -- _ride_generator_counts --, and between graph segments nothing may stay
-            #  in flight; one rank with the hooks forced on: 4.851 -> 4.815 ms at 8,192 pedestrians, not worth a 14th exchange)
+                and (not self.dist.enabled or self.dist.stream_safe)):
+            # (sharded training over an in-graph transport too: the generator counts that ride in the discriminator's
+            #  gradient exchange were counted on the fake-trajectory branch, on uniforms peeked BEFORE this call consumes them
+            #  -- _early_rider_counts; between graph segments nothing may stay in flight, so the segmented replay keeps the
+            #  in-step order)
             self._early_generator_forward(in_xy, in_dxdy, sub_batches, img, shared)
         self._backward(losses, [self._one] * len(losses))
         HF.mark("D.bwd.end")
-        self._ride_generator_counts(shared, in_xy.size(1))
-        self.dist.all_reduce_grads(self.D)
-        self.optimizerD.step(self.config.clipping_threshold_d, zero_grad=self.zero_grads_in_step)
+        self._ride_generator_counts()
+        ex = self.dist.all_reduce_grads(self.D, defer=True)
+        self.optimizerD.step(self.config.clipping_threshold_d, zero_grad=self.zero_grads_in_step, exchange=ex)
         HF.mark("D.opt.end")
         self._emit(train_metrics, items)
 
@@ -455,8 +470,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self.optimizerG.zero_grad()
         self._backward(losses, grads)
         HF.mark("G.bwd.end")
-        self.dist.all_reduce_grads(self.G)
-        self.optimizerG.step(cfg.clipping_threshold_g, zero_grad=self.zero_grads_in_step)
+        ex = self.dist.all_reduce_grads(self.G, defer=True)
+        self.optimizerG.step(cfg.clipping_threshold_g, zero_grad=self.zero_grads_in_step, exchange=ex)
         HF.mark("G.opt.end")
         self._emit(train_metrics, items)
 
@@ -494,8 +509,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self.optimizerG.zero_grad()
         self._backward([loss], [self._w["pi"]])
         HF.mark("PM.bwd.end")
-        self.dist.all_reduce_grads(self.G)
-        self.optimizerG.step(0.0, zero_grad=self.zero_grads_in_step)
+        ex = self.dist.all_reduce_grads(self.G, defer=True)
+        self.optimizerG.step(0.0, zero_grad=self.zero_grads_in_step, exchange=ex)
         HF.mark("PM.opt.end")
         items = [("probs/Gen {} probability".format(i), M_PROBS + i) for i in range(g)]
         self._emit(metrics, items + [("train/net_chooser_loss", M_PM)])

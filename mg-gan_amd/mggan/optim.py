@@ -2,6 +2,7 @@
 (reference: torch.optim.AdamW(lr, betas=(beta1, 0.999)) + nn.utils.clip_grad_norm_,
 /root/reference/mggan/abstract_train.py:45-50, model/train.py:131-135,209-213,656-658)
 and the per-epoch cosine schedule (abstract_train.py:52-57,199-200)."""
+import ctypes
 import math
 
 import torch
@@ -20,7 +21,7 @@ class FlatAdamW:
         self.nseg = len(root._flat_items)
         self.seg_step = torch.zeros(self.nseg, dtype=torch.int32, device=f.device)
         # (mggan_clip_adamw: 256 partial sums + the two counters of its grid barrier; zero once, the launches keep it ready)
-        self._ws = torch.zeros(264, dtype=torch.float64, device=f.device)
+        self._ws = torch.zeros(600, dtype=torch.float64, device=f.device)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=f.device)
         self._flat_id = f.data_ptr()
         # the learning rate the kernel reads lives on the device: a captured iteration follows the schedule
@@ -38,11 +39,14 @@ class FlatAdamW:
     def zero_grad(self):
         self.root.zero_grad_flat()
 
-    def step(self, max_norm=0.0, zero_grad=False):
+    def step(self, max_norm=0.0, zero_grad=False, exchange=None):
         """Clip the gradients of the touched parameters to `max_norm` (0 = no clipping), then AdamW-update them.
         Parameters that received no gradient since zero_grad() are skipped, like `p.grad is None` in torch.
         zero_grad=True leaves the consumed gradients at zero (instead of their clipped values), which turns the
-        next zero_grad() into bookkeeping only."""
+        next zero_grad() into bookkeeping only.
+        exchange (sharded training, DistContext.all_reduce_grads(defer=True)): (comm, tail descriptor, keep-alive) -- the
+        gradient all-reduce over the peer-mapped arenas and / or the finalize of the conv1 gradient tail run inside this
+        launch."""
         r = self.root
         if r._flat.data_ptr() != self._flat_id:
             raise RuntimeError("the module's flat parameter buffer was rebuilt after the optimizer was created")
@@ -62,7 +66,11 @@ class FlatAdamW:
                              self.exp_avg_sq.data_ptr(), r._flat.numel(), r._elem_seg.data_ptr(), self.nseg,
                              mask.data_ptr(), self.seg_step.data_ptr(), float(max_norm), float(self.lr),
                              self._lr_dev.data_ptr(), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                             1 if zero_grad else 0, self._ws.data_ptr(), self.grad_norm.data_ptr(), st)
+                             1 if zero_grad else 0, self._ws.data_ptr(), self.grad_norm.data_ptr(),
+                             exchange[0] if exchange else 0,
+                             ctypes.addressof(exchange[1]) if (exchange and exchange[1] is not None) else 0, st)
+        if exchange and exchange[2] is not None and torch.cuda.is_current_stream_capturing():
+            self._keep = exchange[2]  # (graph memory: the tail's tensors are read by every replay)
         from mggan.hip.functions import bump_weight_version
 
         bump_weight_version(r, tuple(r._touched))  # folded LSTM weights of the updated parameters are stale from here on

@@ -16,6 +16,11 @@ import torch
 import torch.distributed as dist
 
 
+# the gradient exchange and the conv1 tail's finalize inside the optimizer's launch (csrc/loss_opt.hip: clip_adamw_kernel);
+# MGGAN_FUSED_STEP=0: round 5's three launches (all-reduce, finalize, optimizer)
+FUSED_STEP = os.environ.get("MGGAN_FUSED_STEP", "1") != "0"
+
+
 def shard_scenes(seq_start_end, rank, world_size):
     """Contiguous scene range for `rank`, balanced by pedestrian count.
     Returns (scene_slice, ped_start, ped_end, local_seq_start_end)."""
@@ -152,27 +157,39 @@ class DistContext:
 
     _dev = "cpu"
 
-    def all_reduce_grads(self, root):
+    def all_reduce_grads(self, root, defer=False):
         """C1: one collective over the whole flat gradient buffer -- and, riding in it, the f64 tail a sharded scene-CNN
         backward pass of this step left on the root (mggan/hip/functions.py, SceneAttentionFn.backward: this rank's raw
         conv1 weight-gradient and BatchNorm-1 adjoint sums); its finalize runs right behind the exchange, identically on
-        every rank, and adds the global-batch dW1 / dgamma1 / dbeta1 into slots that held zeros during the exchange."""
-        if self.enabled:
-            from mggan.hip.functions import join_side_stream
+        every rank, and adds the global-batch dW1 / dgamma1 / dbeta1 into slots that held zeros during the exchange.
+        defer=True (the trainer): -> (comm, tail descriptor, keep-alive) for FlatAdamW.step(exchange=...) when exchange and
+        finalize can run INSIDE the optimizer's launch (peer-mapped arenas: both; RCCL inside the graph: the finalize) --
+        one launch per optimizer step instead of three; None when everything has been done here."""
+        if not self.enabled:
+            return None
+        from mggan.hip.functions import join_side_stream
 
-            join_side_stream()
-            tails = root.__dict__.pop("_grad_tails", [])
-            if tails:
-                self._collective(root._flat_grad, tails[0][0], what="gradients+conv1.tail")
-                # a step with several scene-CNN backward passes on one root (the masked discriminator step runs the
-                # encoder once for the real and once for the fake pass): the first tail rides with the gradients, every
-                # further one is an exchange of its own; each finalize ADDS its global-batch dW1 / dgamma1 / dbeta1
-                for extra in tails[1:]:
-                    self._collective(extra[0], what="conv1.tail (extra pass)")
-                for t in tails:
-                    t[1]()
-            else:
-                self._collective(root._flat_grad, what="gradients")
+        join_side_stream()
+        tails = root.__dict__.pop("_grad_tails", [])
+        fuse = defer and FUSED_STEP and len(tails) <= 1 and (not tails or len(tails[0]) >= 5)
+        if fuse and self.devcomm is not None and self.devcomm.supports(root._flat_grad, tails[0][0] if tails else None) \
+                and self.devcomm.chunks_fit(root._flat_grad.numel()):
+            self.count_collective("gradients+conv1.tail" if tails else "gradients")
+            return (self.devcomm.channel_dev(), tails[0][3] if tails else None, tails[0][4] if tails else None)
+        if tails:
+            self._collective(root._flat_grad, tails[0][0], what="gradients+conv1.tail")
+            # a step with several scene-CNN backward passes on one root (the masked discriminator step runs the
+            # encoder once for the real and once for the fake pass): the first tail rides with the gradients, every
+            # further one is an exchange of its own; each finalize ADDS its global-batch dW1 / dgamma1 / dbeta1
+            for extra in tails[1:]:
+                self._collective(extra[0], what="conv1.tail (extra pass)")
+            if fuse and self.stream_safe:  # (the sums are global now: the optimizer's launch finalizes)
+                return (0, tails[0][3], tails[0][4])
+            for t in tails:
+                t[1]()
+        else:
+            self._collective(root._flat_grad, what="gradients")
+        return None
 
     def close(self, rccl=True):
         """Unmap / free the peer-mapped arenas (a process that builds several trainers in a row); rccl: the in-graph RCCL

@@ -162,6 +162,7 @@ class DeviceRNG:
             u = torch.empty(n, dtype=torch.float32, device=lg.device)
             lib.mggan_draw_iteration(self._state.data_ptr(), self._ticket.data_ptr(), 0, 0, 0, 0, 0, 0, 0, n, u.data_ptr(),
                                      HF._s())
+        self.last_sample_u = (u.data_ptr(), n)
         idx = torch.empty(b, num_samples, dtype=torch.int64, device=lg.device)
         lib.mggan_sample_categorical(b, num_samples, g, lg.data_ptr(), u.data_ptr(), idx.data_ptr(),
                                      HF._s())
@@ -185,6 +186,7 @@ class DeviceRNG:
             u = torch.empty(n, dtype=torch.float32, device=lg.device)
             lib.mggan_draw_iteration(self._state.data_ptr(), self._ticket.data_ptr(), 0, 0, 0, 0, 0, 0, 0, n, u.data_ptr(),
                                      HF._s())
+        self.last_sample_u = (u.data_ptr(), n)  # (the trainer's pre-counted generator picks must have read these very uniforms)
         idx = torch.empty(b, num_samples, dtype=torch.int64, device=lg.device)
         rows, blk = HF.empty_rollout_rows(b, num_samples, g, lg.device)
         lib.mggan_sample_bucket_rows(b, num_samples, g, lg.data_ptr(), u.data_ptr(), idx.data_ptr(), rows.row_gen.data_ptr(),

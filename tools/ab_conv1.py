@@ -23,7 +23,7 @@ for B in (1536, 8192):
     s = torch.cuda.current_stream().cuda_stream
     run = lambda: lib.mggan_conv1_pool(img.data_ptr(), B, C, W.data_ptr(), bias.data_ptr(), xsel.data_ptr(), code.data_ptr(),
                                        part.data_ptr(), 0, float(B) * 1089, gamma.data_ptr(), 0, 0, 0, 0, 0.1, 1e-5, 1, 0, 0, 0,
-                                       0, 0, s)
+                                       0, 0, 0, s)
     for _ in range(5):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
