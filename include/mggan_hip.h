@@ -606,6 +606,11 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
  * get their constant content: 0, and -- position tensors -- element 0 of the inner axis = pedestrian % period (distinct
  * positions inside a phantom scene).  One launch. */
 int mggan_pad_batch(const void* descs, int n, int b, int b_pad, int period, mggan_stream_t stream);
+/* n (<= 8) small buffers copied in ONE launch: `descs` = n records { const void* src; void* dst; long bytes; } (<= 64 KB each).
+ * Snapshot / roll-back of the discriminator's BatchNorm running statistics (nn.BatchNorm2d buffers, reference
+ * /root/reference/mggan/model/modules/cnn.py:140-141) around the next iteration's discriminator context when it is issued
+ * ahead of time (mggan/model/train.py: _issue_d_context / drain_pipeline). */
+int mggan_copy_small(const void* descs, int n, mggan_stream_t stream);
 /* ---- input pipeline: per-pedestrian scene crops cut on the GPU -----------------------------
  * Replaces the per-pedestrian PIL crop loop of BaseTrajectories.py:254-288 / trajectories_scene.py:349-356.
  * atlas = the u8 RGB "small" scene images (H,W,3) packed back to back in device memory; pedestrian p reads the

@@ -62,7 +62,39 @@ __global__ __launch_bounds__(256) void pad_batch_kernel(PadBatch a) {
   }
 }
 
+// A handful of small buffers copied in ONE launch (BatchNorm running statistics: 8-64 bytes each): snapshot / roll-back of
+// module buffers around work that is issued speculatively (mggan/model/train.py: the next iteration's discriminator context).
+#define MG_COPY_MAX 8
+struct CopySmall {
+  const unsigned char* src[MG_COPY_MAX];
+  unsigned char* dst[MG_COPY_MAX];
+  int bytes[MG_COPY_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void copy_small_kernel(CopySmall a) {
+  for (int k = 0; k < a.n; ++k)
+    for (int i = threadIdx.x; i < a.bytes[k]; i += 256) a.dst[k][i] = a.src[k][i];
+}
+
 extern "C" {
+
+int mggan_copy_small(const void* descs, int n, hipStream_t stream) {
+  struct Desc { const void* src; void* dst; long bytes; };
+  MG_CHECK_ARG(descs && n > 0 && n <= MG_COPY_MAX, "copy_small: 1..%d buffers", MG_COPY_MAX);
+  const Desc* d = (const Desc*)descs;
+  CopySmall a;
+  a.n = n;
+  for (int i = 0; i < MG_COPY_MAX; ++i) {
+    const bool on = i < n;
+    MG_CHECK_ARG(!on || (d[i].src && d[i].dst && d[i].bytes > 0 && d[i].bytes <= 65536), "copy_small: bad buffer %d", i);
+    a.src[i] = on ? (const unsigned char*)d[i].src : nullptr;
+    a.dst[i] = on ? (unsigned char*)d[i].dst : nullptr;
+    a.bytes[i] = on ? (int)d[i].bytes : 0;
+  }
+  MG_LAUNCH(copy_small_kernel, dim3(1), dim3(256), 0, stream, a);
+  MG_LAUNCH_CHECK("copy_small");
+  return MGGAN_OK;
+}
 
 int mggan_pad_batch(const void* descs, int n, int b, int b_pad, int period, hipStream_t stream) {
   struct Desc { const float* src; float* dst; long inner; int outer, position; };

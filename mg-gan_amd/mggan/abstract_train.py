@@ -152,6 +152,16 @@ class MultiGeneratorGAN(abc.ABC):
         if hasattr(self, "_open_iteration"):
             self._open_iteration()
         prep_was = HF.prep_cache(True)  # folded LSTM weights are kept per weight version inside the iteration
+        # cross-iteration pipelining: the caller names the batch of the NEXT iteration (batch["next"]: its in_dxdy / features,
+        # already on the device; capture_iteration(pipeline=True) names the static batch itself); its discriminator context is
+        # issued beside this iteration's PM-network step (mggan/model/train.py: _issue_d_context)
+        pipe = getattr(self, "_pipe", None)
+        if pipe is not None:
+            nxt = batch.get("next")
+            ok = nxt is not None and run_d and self.pipeline_ok(loss_mask)
+            pipe["next"] = (nxt["in_dxdy"], nxt["features"]) if ok else None
+            if not ok and pipe["ctx"] is not None and not (run_d and loss_mask is None):
+                self.drain_pipeline()
         try:
             if run_d:
                 for _ in range(cfg.num_unrolling_steps + 1):
@@ -159,6 +169,14 @@ class MultiGeneratorGAN(abc.ABC):
             HF.launch_images()  # (no discriminator step in this iteration, or one that did not start it)
             self.generator_step(*args, shared=shared)
             self.net_chooser_step(*args)
+            if pipe is not None and pipe["next"] is not None:  # (no PM-network step: --weighting_target none)
+                pipe["next"] = None
+            if pipe is not None and pipe["ctx"] is not None and torch.cuda.is_current_stream_capturing():
+                # a capture ends with every fork joined: the held stream meets the main chain at the END of the iteration
+                # (eager iterations leave it in flight until the next discriminator step takes the context)
+                from mggan.model.train import _PIPE_BRANCH
+
+                HF.join_branch(which=_PIPE_BRANCH, force=True)
         finally:
             HF.prep_cache(prep_was)
             HF.end_images()
@@ -167,7 +185,7 @@ class MultiGeneratorGAN(abc.ABC):
         self.total_iterations += 1
         self.dist.check()
 
-    def capture_iteration(self, batch, warmup=3, pool=None):
+    def capture_iteration(self, batch, warmup=3, pool=None, pipeline=None):
         """Capture one full D+G+PM iteration on `batch` into a HIP graph (needs --rng device: no host
         sync anywhere in the iteration).  Returns replay(metrics) which re-runs the iteration on the
         same static batch tensors (copy new data into them to change the input).  `warmup` eager iterations run
@@ -183,6 +201,14 @@ class MultiGeneratorGAN(abc.ABC):
 
         batch = dict(batch)
         batch["loss_mask"] = None
+        # pipeline (None: MGGAN_PIPELINE): the captured iteration reads its discriminator context from where the previous
+        # replay left it and ends with the context of the next one -- the static batch's own: replays feed the same buffers
+        pipe = getattr(self, "_pipe", None)
+        if pipe is not None:
+            if pipeline is not None:
+                pipe["on"] = bool(pipeline)
+            if pipe["on"] and not self.dist.enabled and "features" in batch:
+                batch["next"] = {"in_dxdy": batch["in_dxdy"], "features": batch["features"]}
         in_graph = False
         if self.dist.enabled:
 
@@ -256,6 +282,13 @@ class MultiGeneratorGAN(abc.ABC):
                 self.train_iteration(batch, scratch)
         HF._cur().wait_stream(side)
         self.flush_metrics()
+        if getattr(self, "_pipe", None) is not None and self._pipe["ctx"] is not None:
+            # the context the last warm-up iteration issued is eager work on its held stream: the capture must find it done
+            # (a captured stream cannot wait for work outside the capture)
+            from mggan.model.train import _PIPE_BRANCH
+
+            HF.join_branch(which=_PIPE_BRANCH, force=True)
+            HF._BR["dirty"].discard(_PIPE_BRANCH)
         captured = defaultdict(list)
         it0 = self.total_iterations  # the captured iteration executes nothing: it does not count (the replays do)
         # no cyclic garbage collection while a stream is capturing: a collection that finalises an older trainer's graphs

@@ -102,6 +102,98 @@ def role_stream(role):
     return st
 
 
+class ReplayAlloc:
+    """with ReplayAlloc(store): the FIRST time (empty store) every tensor torch.empty / zeros / full / ones / empty_like /
+    zeros_like hands out inside the block is recorded; every later time the same tensors are handed out again, in call
+    order.  A forward pass that runs under it therefore writes its outputs and everything it saves for its backward pass to
+    the same device addresses every time -- what lets work that a captured graph reads at its START be produced at the END
+    of the previous replay (the next iteration's discriminator context, mggan/model/train.py) while Python still builds a
+    fresh autograd graph over those tensors in every eager iteration.  A sequence that diverges from the recorded one
+    (another shape, dtype or count) raises: the caller falls back to the in-order schedule."""
+    NAMES = ("empty", "zeros", "full", "ones", "empty_like", "zeros_like")
+
+    def __init__(self, store):
+        self.store = store  # {"tensors": [...], "specs": [...], "done": bool}
+
+    def __enter__(self):
+        st = self.store
+        st.setdefault("tensors", [])
+        st.setdefault("specs", [])
+        self.pos, self.replay = 0, bool(st.get("done"))
+        self.saved = {n: getattr(torch, n) for n in self.NAMES}
+
+        def wrap(name, fn):
+            def alloc(*a, **k):
+                if self.replay:
+                    if self.pos >= len(st["tensors"]):
+                        raise RuntimeError("ReplayAlloc: more allocations than recorded ({})".format(len(st["tensors"])))
+                    t, spec = st["tensors"][self.pos], st["specs"][self.pos]
+                    self.pos += 1
+                    now = (name,) + _alloc_spec(name, a, k)
+                    if spec != now:
+                        raise RuntimeError("ReplayAlloc: allocation {} is {} now, recorded {}".format(self.pos - 1, now, spec))
+                    if name in ("zeros", "zeros_like"):
+                        t.zero_()
+                    elif name == "ones":
+                        t.fill_(1)
+                    elif name == "full":
+                        t.fill_(a[1] if len(a) > 1 else k["fill_value"])
+                    return t
+                with _Unpatched(self):
+                    t = fn(*a, **k)
+                st["tensors"].append(t)
+                st["specs"].append((name, tuple(t.shape), t.dtype))
+                return t
+
+            return alloc
+
+        for n, fn in self.saved.items():
+            setattr(torch, n, wrap(n, fn))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        for n, fn in self.saved.items():
+            setattr(torch, n, fn)
+        if et is None:
+            if self.replay and self.pos != len(self.store["tensors"]):
+                raise RuntimeError("ReplayAlloc: {} allocations now, {} recorded".format(self.pos, len(self.store["tensors"])))
+            self.store["done"] = True
+        return False
+
+
+def _alloc_spec(name, a, k):
+    """(shape, dtype) a torch allocation call asks for, from its arguments."""
+    if name in ("empty_like", "zeros_like"):
+        return tuple(a[0].shape), k.get("dtype", a[0].dtype)
+    sh = a[0] if name == "full" else (a[0] if (len(a) == 1 and isinstance(a[0], (tuple, list, torch.Size))) else a)
+    return tuple(int(x) for x in sh), k.get("dtype", torch.float32)
+
+
+class _Unpatched:
+    def __init__(self, ra):
+        self.ra = ra
+
+    def __enter__(self):
+        self.cur = {n: getattr(torch, n) for n in self.ra.NAMES}
+        for n, fn in self.ra.saved.items():
+            setattr(torch, n, fn)
+
+    def __exit__(self, *exc):
+        for n, fn in self.cur.items():
+            setattr(torch, n, fn)
+        return False
+
+
+class _CopyDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_long)]
+
+
+def copy_small(pairs):
+    """[(src tensor, dst tensor)] (<= 8, contiguous, equal byte sizes) copied in ONE launch on the current stream."""
+    arr = (_CopyDesc * len(pairs))(*[_CopyDesc(a.data_ptr(), b.data_ptr(), a.numel() * a.element_size()) for a, b in pairs])
+    lib.mggan_copy_small(ctypes.addressof(arr), len(pairs), _s())
+
+
 def poison_scratch(on=True):
     _DEBUG["poison"] = bool(on)
 

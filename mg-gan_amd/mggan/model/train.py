@@ -44,6 +44,20 @@ _GRAM_LATE = os.environ.get("MGGAN_GRAM_LATE", "0") == "1"
 _G_EARLY = os.environ.get("MGGAN_G_EARLY", "1") == "1"
 _G_EARLY_MIN_B = int(os.environ.get("MGGAN_G_EARLY_MIN_B", "2048"))
 _EARLY_BRANCH = 5
+# Cross-iteration pipelining (MGGAN_PIPELINE=1, capture_iteration(pipeline=True)): the NEXT iteration's discriminator context --
+# history LSTM + scene CNN of D on the next batch, with the weights D holds since this iteration's discriminator update -- is
+# issued on a held branch stream beside the PM-network step, whose tail (the generator's scene-CNN adjoint) runs alone on the
+# chip; the next discriminator step finds it done.  Same arithmetic in the same order (BatchNorm running statistics included:
+# nothing else touches D's between the two points), so the weights are bit-identical to the in-order schedule; an issued
+# context that is never consumed is rolled back (drain_pipeline).
+# MEASURED (round 6, one box, three alternating pairs, ms per iteration in-order -> pipelined): 64 x 20: 1.358 -> 1.435-1.48
+# (issued at PM.begin), 1.46-1.50 (before the PM step's backward pass), 1.50-1.53 (before the generator step's), 1.53 (behind the
+# PM step's main backward chain); 256 x 32: 4.48 -> 4.60-4.64 / 4.61-4.65 / 4.96 / 4.68.  It LOSES everywhere: in the
+# discriminator step the context already runs beside the fake-trajectory branch and is exposed for ~40 us only (64 x 20), while
+# beside the PM step its persistent CNN grids and the generator's share the CUs (a sum, not a maximum) -- and what does not fit
+# extends the iteration.  Off by default; the mechanism (ReplayAlloc, roll-back of the running statistics) is kept and tested.
+_PIPE_BRANCH = 6
+_PIPE_AT = os.environ.get("MGGAN_PIPE_AT", "pm_begin")  # pm_begin | pm_bwd | g_bwd
 
 
 class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
@@ -88,6 +102,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         self.zero_grads_in_step = False
         self._pending = []
         self._bwd_stream = None
+        self._pipe = {"on": os.environ.get("MGGAN_PIPELINE", "0") == "1", "stores": {}, "ctx": None, "key": None, "snap": None,
+                      "next": None}
 
     def padding_ok(self):
         """Can train() pad ragged batches to shape buckets (abstract_train.IterationGraphs)?  The kernels that mix rows
@@ -220,7 +236,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             lib.mggan_inv_counts(counts.data_ptr(), g, inv.data_ptr(), st)
         return row_gen, inv
 
-    def _backward(self, losses, grads):
+    def _backward(self, losses, grads, at_main_end=None):
         # (autograd's device worker thread is switched off for the pass: every node here is a Python function, and handing
         #  each one to another thread through the GIL cost 35 % of an eager iteration's host time -- 7.9 vs 5.1 ms on the
         #  configs[0] shape; stream semantics are unchanged: a node still runs on the stream of its forward)
@@ -246,6 +262,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             HF.defer_grad_reduce(False)
         HF.join_side_stream()
         HF.mark("bwd.main.end")
+        if at_main_end is not None:
+            at_main_end()  # (work forked here runs beside the tail only: the scene CNN's adjoint on its branch, the reductions)
         HF.flush_wgrad_gemms()  # beside what is left of the branch streams' backward (the scene CNN's convolutions)
         HF.mark("bwd.gemms.end")
         if HF._MARKS["on"] and 0 in HF._BR["streams"]:
@@ -258,6 +276,70 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         if HF._BR["on"]:
             HF._cur().wait_stream(self._bwd_stream)
         HF.join_branch(force=True)  # backward nodes ran on the streams of their forwards
+
+    # ---- the next iteration's discriminator context, ahead of time ----------------------------
+    def _d_bn_buffers(self):
+        bufs = []
+        for mod in self.D.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                bufs += [mod.running_mean, mod.running_var, mod.num_batches_tracked]
+        return bufs
+
+    def pipeline_ok(self, loss_mask=None):
+        cfg = self.config
+        return (self._pipe["on"] and loss_mask is None and self.share_context and int(cfg.num_unrolling_steps) == 0
+                and int(cfg.num_gen_steps) == 1 and not self.dist.enabled and HF._BR["on"] and HF.pad_dims() is None)
+
+    def _issue_d_context(self, where):
+        """At point `where` of the iteration: issue D.history_context for the batch announced as next (self._pipe['next'])."""
+        nxt = self._pipe["next"]
+        if nxt is None or where != _PIPE_AT or self._pipe["ctx"] is not None:
+            return
+        in_dxdy, img = nxt
+        self._pipe["next"] = None
+        key = (in_dxdy.data_ptr(), tuple(in_dxdy.shape), img.data_ptr(), tuple(img.shape))
+        store = self._pipe["stores"].setdefault((key[1], key[3]), {})
+        bufs = self._d_bn_buffers()
+        if self._pipe["snap"] is None:
+            self._pipe["snap"] = [torch.empty_like(t) for t in bufs]
+        HF.hold_branch(_PIPE_BRANCH)
+        try:
+            with HF.branch(_PIPE_BRANCH):
+                HF.mark("pipe.ctx.begin")
+                HF.copy_small(list(zip(bufs, self._pipe["snap"])))  # (what drain_pipeline restores if nobody takes the context)
+                with HF.ReplayAlloc(store):
+                    ctx = self.D.history_context(in_dxdy, img, passes=2, lstm_first=True)
+                HF.mark("pipe.ctx.end")
+        except RuntimeError as exc:
+            # the pass allocated differently than the recorded one: not a pass a captured graph could have re-run in place
+            HF.hold_branch(_PIPE_BRANCH, False)
+            self._pipe["on"] = False
+            raise RuntimeError("cross-iteration pipelining switched off: {}".format(exc)) from exc
+        self._pipe["ctx"], self._pipe["key"] = ctx, key
+
+    def _take_d_context(self, in_dxdy, img):
+        """-> the context issued for exactly this batch by the previous iteration, or None."""
+        ctx, key = self._pipe["ctx"], self._pipe["key"]
+        if ctx is None:
+            return None
+        if key != (in_dxdy.data_ptr(), tuple(in_dxdy.shape), img.data_ptr(), tuple(img.shape)) or not self.D.training:
+            self.drain_pipeline()
+            return None
+        self._pipe["ctx"] = self._pipe["key"] = None
+        HF.hold_branch(_PIPE_BRANCH, False)
+        HF.join_branch(ctx[0], ctx[1], which=_PIPE_BRANCH)
+        return ctx
+
+    def drain_pipeline(self):
+        """Forget a context that was issued ahead of time and not consumed: D's BatchNorm running statistics go back to what
+        they were before it (its two momentum updates belong to a discriminator step that is not going to happen).  Called
+        before anything outside the steady loop looks at D (validation, a checkpoint, another batch shape)."""
+        if self._pipe["ctx"] is None:
+            return
+        self._pipe["ctx"] = self._pipe["key"] = None
+        HF.hold_branch(_PIPE_BRANCH, False)
+        HF.join_branch(which=_PIPE_BRANCH, force=True)
+        HF.copy_small(list(zip(self._pipe["snap"], self._d_bn_buffers())))
 
     # ---- the three steps -----------------------------------------------------------------
     def discriminator_step(self, in_xy, in_dxdy, gt_xy, gt_dxdy, sub_batches, train_metrics, loss_mask, img=None,
@@ -280,8 +362,11 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             rows_d = getattr(self.G, "last_rows", None)
             HF.mark("D.fake.end")
         # history LSTM + scene CNN of D are identical in the real and the fake pass: run them once
-        ctx = self.D.history_context(in_dxdy, img, passes=2, lstm_first=self.d_step_lstm_first) \
-            if (loss_mask is None and self.share_context) else None
+        ctx = None
+        if loss_mask is None and self.share_context:
+            ctx = self._take_d_context(in_dxdy, img)  # issued by the previous iteration (cross-iteration pipelining)?
+            if ctx is None:
+                ctx = self.D.history_context(in_dxdy, img, passes=2, lstm_first=self.d_step_lstm_first)
         # the Gram matrix of the image crops starts behind the history LSTM on this stream (by then D's scene CNN on its
         # branch stream is nearly through as well): beside the latency-bound row pass.  (Forked from this stream only: a
         # side stream with two parents inside a capture makes hipStreamEndCapture crash.)
@@ -388,7 +473,11 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                     defer = None
                     if self.g_step_cnn_after_sampling and getattr(self.rng, "on_device", False) and HF._BR["on"]:
                         defer = lambda fn: setattr(self.G, "_after_sampling", fn)
-                    ctx_d = self.D.history_context(in_dxdy, img, passes=1, lstm_branch=self.g_step_lstm_branch,
+                    # (with the generator's forward pass already issued from the discriminator step -- large batches -- the
+                    #  chip is empty here: history LSTM and scene CNN side by side, 4.494 -> 4.466 ms at 256 x 32, three
+                    #  alternating pairs; beside the rollout forward -- small batches -- the third stream loses 20 us)
+                    lstm_branch = 2 if (early is not None and "MGGAN_G_LSTM_BRANCH" not in os.environ) else self.g_step_lstm_branch
+                    ctx_d = self.D.history_context(in_dxdy, img, passes=1, lstm_branch=lstm_branch,
                                                    lstm_first=self.g_step_lstm_first, defer_cnn=defer)
             if early is not None:
                 # issued from the discriminator step: this stream takes its results over (and autograd will run their
@@ -433,7 +522,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
 
             if ctx_d is not None:
                 HF.join_branch(ctx_d[1], which=0)
-                HF.join_branch(ctx_d[0], which=self.g_step_lstm_branch)
+                HF.join_branch(ctx_d[0], which=lstm_branch)
             HF.mark("G.dpass.begin")
             disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask,
                               context=ctx_d)
@@ -468,6 +557,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
 
         HF.mark("G.loss.end")
         self.optimizerG.zero_grad()
+        self._issue_d_context("g_bwd")
         self._backward(losses, grads)
         HF.mark("G.bwd.end")
         ex = self.dist.all_reduce_grads(self.G, defer=True)
@@ -481,6 +571,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             return
         m, g = self._m, self.G.n_gs
         HF.mark("PM.begin")
+        self._issue_d_context("pm_begin")
         gen_out, net_chooser_weights, _ = self.G(in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=img,
                                                  num_samples=cfg.num_expectation_samples, mask=mask, need_samples=False)
         n_pm = self._global(net_chooser_weights.shape[0])
@@ -507,7 +598,8 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             loss = HF.CeMeanFn.apply(net_chooser_weights, target, None, m[M_PM:M_PM + 1], n_pm)
         HF.mark("PM.loss.end")
         self.optimizerG.zero_grad()
-        self._backward([loss], [self._w["pi"]])
+        self._issue_d_context("pm_bwd")
+        self._backward([loss], [self._w["pi"]], at_main_end=lambda: self._issue_d_context("pm_tail"))
         HF.mark("PM.bwd.end")
         ex = self.dist.all_reduce_grads(self.G, defer=True)
         self.optimizerG.step(0.0, zero_grad=self.zero_grads_in_step, exchange=ex)

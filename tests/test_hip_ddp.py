@@ -137,7 +137,8 @@ def test_two_ranks_match_single_process_on_a_masked_batch():
     assert np.array_equal(two[0][1], two[1][1])
 
 
-def _run_graph(rank, world, port, sizes, q, device_comm, backend="gloo", own_device=False, rccl_graph=True, eager=False):
+def _run_graph(rank, world, port, sizes, q, device_comm, backend="gloo", own_device=False, rccl_graph=True, eager=False,
+               env=None):
     """Sharded iteration captured on `world` ranks (sharing the box's one GPU, handles exchanged over gloo -- or, with
     own_device, one GPU per rank and any backend: tests/test_hip_multigpu.py):
     device_comm=True: peer-mapped all-reduce kernels inside ONE graph; False: graph segments around eager collectives."""
@@ -149,6 +150,7 @@ def _run_graph(rank, world, port, sizes, q, device_comm, backend="gloo", own_dev
                       MGGAN_DEVICE_COMM="1" if device_comm else "0", MGGAN_RCCL_GRAPH="1" if rccl_graph else "0")
     if world == 1:
         os.environ["MGGAN_FORCE_DIST"] = "1"
+    os.environ.update(env or {})
     import torch.distributed as dist
 
     import bench
@@ -207,12 +209,12 @@ def _run_graph(rank, world, port, sizes, q, device_comm, backend="gloo", own_dev
            tr.dist.transport))
 
 
-def _launch_graph(world, sizes, device_comm, backend="gloo", own_device=False, rccl_graph=True, eager=False):
+def _launch_graph(world, sizes, device_comm, backend="gloo", own_device=False, rccl_graph=True, eager=False, env=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_graph, args=(r, world, port, sizes, q, device_comm, backend, own_device, rccl_graph, eager))
-             for r in range(world)]
+    procs = [ctx.Process(target=_run_graph, args=(r, world, port, sizes, q, device_comm, backend, own_device, rccl_graph, eager,
+                                                  env)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=200 + 40 * world) for _ in range(world)], key=lambda t: t[0])
@@ -264,6 +266,23 @@ def test_two_ranks_one_graph_with_device_allreduce():
     # same arithmetic as the segmented replay with eager gloo collectives (other reduction order across ranks: 1e-5)
     rel = np.linalg.norm(res[0][1] - seg[0][1]) / np.linalg.norm(seg[0][1])
     assert rel <= 1e-4, rel
+
+
+def test_large_shards_put_the_gram_matrix_first_eleven_exchanges():
+    """From MGGAN_GRAM_FIRST_MIN_B images per rank on (4,096; forced down to 1 here) the iteration starts with the Gram matrix
+    of the image patches and its ONE all-reduce: every conv1 pass takes its BatchNorm statistics from it, no pass exchanges
+    layer-1 sums of its own -- 11 exchanges: Gram + 4 layer-2 forward + 3 layer-2 backward + 3 gradient buffers (each with
+    its conv1 tail and, in the discriminator step's, the generator counts).  The decision is taken from the shard's image
+    count, which equal shards share: every rank decides alike (why the two discriminator-step layer-2
+    forward exchanges are not merged into one)."""
+    res = _launch_graph(2, [3, 3, 3, 3], device_comm=True, env={"MGGAN_GRAM_FIRST_MIN_B": "1"})
+    _check_replicas(res)
+    sched = res[0][8]
+    assert sched[0] == "gram" and len(sched) == 11, sched
+    assert sorted(sched) == sorted(["gram"] + ["bn2.forward"] * 4 + ["bn2.backward"] * 3 + ["gradients+conv1.tail"] * 3), sched
+    # every step ends with its gradient exchange, its layer-2 adjoint exchange right before it
+    ends = [i for i, w in enumerate(sched) if w.startswith("gradients")]
+    assert ends[-1] == len(sched) - 1 and all(sched[i - 1] == "bn2.backward" for i in ends), sched
 
 
 def test_eight_ranks_one_graph_like_the_eight_gpu_configs():

@@ -298,3 +298,56 @@ def test_replay_after_an_external_weight_write_refolds_the_lstm_weights():
     got = run(True)
     assert bool(torch.isfinite(ref).all())
     assert torch.equal(got, ref)
+
+
+def test_next_discriminator_context_ahead_of_time_is_bit_identical(monkeypatch):
+    """Cross-iteration pipelining (mggan/model/train.py: _issue_d_context, off by default -- measured slower, kept as a knob):
+    the next iteration's discriminator context is issued beside the PM-network step into fixed buffers (HF.ReplayAlloc), the
+    next discriminator step takes it.  Same arithmetic in the same order: weights AND D's BatchNorm running statistics after
+    five iterations (the last context rolled back, drain_pipeline) equal the in-order schedule's bit for bit -- eagerly and
+    with a captured graph that reads the context the previous replay left; the taken path is the one that ran."""
+    import bench
+    from mggan.data_utils import synthetic
+    from mggan.model import train as T
+
+    dev = torch.device("cuda", 0)
+
+    def run(pipeline, graph, where="pm_begin", iters=5):
+        monkeypatch.setattr(T, "_PIPE_AT", where)
+        taken = []
+        real = T.PiNetMultiGeneratorGAN._take_d_context
+
+        def spy(self, *a):
+            out = real(self, *a)
+            taken.append(out is not None)
+            return out
+
+        monkeypatch.setattr(T.PiNetMultiGeneratorGAN, "_take_d_context", spy)
+        tr = bench.build_trainer(3, "device", dev)
+        torch.cuda.manual_seed(4321)
+        batch = tr.to_device(synthetic.make_batch(synthetic.scene_sizes(20, 5), seed=2))
+        batch["loss_mask"] = None
+        tr.defer_metrics = True
+        tr._pipe["on"] = pipeline
+        m = defaultdict(list)
+        if graph:
+            replay = tr.capture_iteration(batch, warmup=2, pipeline=pipeline)
+            for _ in range(iters - 2):
+                replay(m, False)
+        else:
+            b = dict(batch, next={"in_dxdy": batch["in_dxdy"], "features": batch["features"]}) if pipeline else batch
+            for _ in range(iters):
+                tr.train_iteration(b, m)
+        tr.drain_pipeline()
+        tr.flush_metrics()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(T.PiNetMultiGeneratorGAN, "_take_d_context", real)
+        bn = torch.cat([t.detach().double().flatten() for t in tr._d_bn_buffers()]).cpu()
+        return torch.cat([tr.G._flat.clone(), tr.D._flat.clone()]).cpu(), bn, sum(taken)
+
+    ref, bn_ref, n = run(False, False)
+    assert n == 0 and bool(torch.isfinite(ref).all())
+    for graph, where in ((False, "pm_begin"), (True, "pm_begin"), (True, "pm_tail")):
+        got, bn, n = run(True, graph, where)
+        assert n >= 1, "no issued context was taken"
+        assert torch.equal(got, ref) and torch.equal(bn, bn_ref), (graph, where)
