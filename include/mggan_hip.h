@@ -606,6 +606,17 @@ int mggan_decoder_rollout_bwd_fused(int n_gens, int NW, int T, int H, int EIN, i
  * get their constant content: 0, and -- position tensors -- element 0 of the inner axis = pedestrian % period (distinct
  * positions inside a phantom scene).  One launch. */
 int mggan_pad_batch(const void* descs, int n, int b, int b_pad, int period, mggan_stream_t stream);
+/* Crops of the AUGMENTED scene image (training; /root/reference/mggan/data_utils/trajectories_scene.py:276-357: flip ->
+ * img.rotate(alpha / pi * 180, expand=True) -> img.resize(..., ANTIALIAS) -> one crop per pedestrian), computed directly from
+ * the un-augmented scaled images resident in `atlas` -- bit-identical to Pillow's result.  items: one record of 26 int32 per
+ * batch item { int64 img_off; int w, h, flip, rot, nw, nh, sw, sh; int a[6]; int ksh, ksv; int64 kh, bh, kv, bv; } (the
+ * 16.16 inverse affine map of Pillow's nearest-neighbour rotation and the offsets of the item's Lanczos tables -- rows of ksh /
+ * ksv 22-bit coefficients and (first source index, taps) pairs per output column / row -- in `tables`; built by
+ * mggan/data_utils/aug_geometry.py); ped_item[p] = item of pedestrian p, centers (n, 2) = crop centre (x, y) in the resized
+ * image; out (n, 4, 2 margin + 1, 2 margin + 1): RGB as -1 + v * 2 / 256 and the one-hot centre channel.  Limits: window <= 33,
+ * <= 128 taps per pass (downscale <= 21), staged source rows <= 800 pixels (checked on the host side). */
+int mggan_crop_patches_aug(const unsigned char* atlas, const void* items, const int* tables, const int* ped_item,
+                           const int* centers, int n, int margin, float* out, mggan_stream_t stream);
 /* n (<= 8) small buffers copied in ONE launch: `descs` = n records { const void* src; void* dst; long bytes; } (<= 64 KB each).
  * Snapshot / roll-back of the discriminator's BatchNorm running statistics (nn.BatchNorm2d buffers, reference
  * /root/reference/mggan/model/modules/cnn.py:140-141) around the next iteration's discriminator context when it is issued

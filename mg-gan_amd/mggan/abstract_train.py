@@ -367,6 +367,8 @@ class MultiGeneratorGAN(abc.ABC):
         kw = dict(synthetic_scenes=getattr(cfg, "synthetic_scenes", 64), synthetic_peds=getattr(cfg, "synthetic_peds", 0))
         if getattr(cfg, "cache_device", 0):
             kw["cache_device"] = self.device
+        if cfg.dataset != "synthetic" and getattr(cfg, "crop_device", "auto") != "off":
+            kw["crop_device"] = self.device  # scene crops on the GPU (the loader then runs in this process: workers = 0)
         pad = getattr(cfg, "graph_pad", "auto")
         graphs = self.iteration_graphs = IterationGraphs(
             self, getattr(cfg, "graph_shapes", 8), pad=pad, bucket=getattr(cfg, "graph_bucket", "quarter"),

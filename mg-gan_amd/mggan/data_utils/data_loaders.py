@@ -35,8 +35,9 @@ class SyntheticScenes(torch.utils.data.Dataset):
 
 def get_dataloader(dataset, phase, augment=False, batch_size=8, workers=0, shuffle=False, synthetic_scenes=64,
                    synthetic_peds=0, crop_device=None, cache_device=None):
-    """crop_device: a HIP device -> the image crops of un-augmented on-disk datasets are cut on the GPU from scene
-    images resident in HBM (mggan/data_utils/device_crops.py); `features` then arrives on that device."""
+    """crop_device: a HIP device -> the image crops of on-disk datasets are cut on the GPU from scene images resident in HBM
+    (mggan/data_utils/device_crops.py; augmented training items included: the flip / rotation / Lanczos resize of the
+    reference's Pillow path is computed per crop, bit-identically); `features` then arrives on that device."""
     assert phase in ("train", "val", "test")
     if dataset != "synthetic":
         from mggan.data_utils.trajectories_scene import TrajectoryDatasetEval, seq_collate_scene
@@ -54,7 +55,7 @@ def get_dataloader(dataset, phase, augment=False, batch_size=8, workers=0, shuff
                                       "'synthetic')".format(dataset))
         ds = TrajectoryDatasetEval(dataset_name=name, phase=phase, margin_in=16, margin_out=16, load_occupancy=False,
                                    scaling_small=small, data_augmentation=int(augment))
-        if crop_device is not None and not (augment and phase == "train"):
+        if crop_device is not None:
             from mggan.data_utils.device_crops import DeviceCropDataset
 
             dds = DeviceCropDataset(ds, crop_device)

@@ -111,6 +111,10 @@ def get_parser():
     parser.add_argument("--graph_bucket", type=str, choices=["quarter", "pow2"], default="quarter",
                         help="bucket sizes of --graph_pad: four per octave (at most a quarter of a bucket is padding) or "
                              "powers of two (fewer graphs, up to half)")
+    parser.add_argument("--crop_device", type=str, choices=["auto", "on", "off"], default="auto",
+                        help="on-disk datasets: cut the per-pedestrian scene crops on the GPU from scene images resident in HBM "
+                             "(training augmentation included, bit-identical to the host's Pillow path) instead of on the "
+                             "host.  auto = on")
     parser.add_argument("--cache_device", type=int, default=0,
                         help="synthetic dataset: keep the produced batches resident in HBM after their first use")
     parser.add_argument("--synthetic_scenes", type=int, default=64, help="scenes per synthetic epoch")

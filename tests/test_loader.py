@@ -75,3 +75,25 @@ def test_device_crops_match_host_crops(loader_golden, name):
     g = loader_golden["{}/test/batch/features".format(name)]
     n = min(len(g), dev["features"].shape[0])
     np.testing.assert_array_equal(dev["features"].cpu().numpy()[:n], g[:n])  # and == the reference's crops
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["eth", "gofp", "stanford"])
+def test_device_crops_match_host_crops_with_training_augmentation(loader_golden, name):
+    """phase="train", --augment 1 (the reference's default, trajectories_scene.py:276-357): the scene image is flipped,
+    rotated (expand, nearest) and Lanczos-resized per item by Pillow on the host; mggan_crop_patches_aug computes every
+    pedestrian's crop of that image directly from the resident un-augmented image -- the same bytes, and the reference's own."""
+    from mggan.data_utils.data_loaders import get_dataloader
+
+    np.random.seed(123)  # the augmentation draws (rotation angle, flip code) come from numpy's global generator
+    host = next(iter(get_dataloader(name, "train", augment=True, batch_size=3)))
+    np.random.seed(123)
+    dev = next(iter(get_dataloader(name, "train", augment=True, batch_size=3, crop_device="cuda")))
+    assert dev["features"].is_cuda and dev["features"].shape == host["features"].shape
+    np.testing.assert_array_equal(dev["features"].cpu().numpy(), host["features"].numpy())
+    for k in ("in_xy", "gt_xy", "in_dxdy", "gt_dxdy"):
+        np.testing.assert_array_equal(dev[k].numpy(), host[k].numpy())
+    assert dev["seq_start_end"] == host["seq_start_end"]
+    g = loader_golden["{}/train/batch/features".format(name)]
+    assert len(g) == dev["features"].shape[0]
+    np.testing.assert_array_equal(dev["features"].cpu().numpy(), g)  # == what the reference's loader produced

@@ -19,9 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mg-gan_amd"))
 
 
-def make_dataset(root, frames=120, peds=40, w=640, h=480):
+def make_dataset(root, frames=120, peds=40, w=640, h=480, phase="test"):
     r = np.random.RandomState(0)
-    d = Path(root) / "eth" / "test"
+    d = Path(root) / "eth" / phase
     d.mkdir(parents=True)
     yy, xx = np.mgrid[0:h, 0:w]
     img = np.clip(np.stack([127 + 100 * np.sin(xx / 17.0), 127 + 100 * np.cos(yy / 11.0), (xx * 3 + yy * 5) % 256], -1) +
@@ -63,6 +63,18 @@ def main():
     if torch.cuda.is_available():
         dev = run(get_dataloader("eth", "test", batch_size=a.scenes_per_batch, crop_device="cuda"), a.batches, True)
         print("device crops (scene images in HBM, one launch per batch):     {:9.0f} pedestrians/s  ({:.1f}x)".format(dev, dev / host))
+    # training with --augment 1 (the reference's default): flip + rotate(expand) + Lanczos resize of the scene image per item
+    make_dataset(tmp, phase="train")
+    np.random.seed(0)
+    host_a = run(get_dataloader("eth", "train", augment=True, batch_size=a.scenes_per_batch), a.batches, False)
+    print("host crops, augmented   (Pillow rotate + 2 resizes per item):   {:9.0f} pedestrians/s".format(host_a))
+    if torch.cuda.is_available():
+        np.random.seed(0)
+        ld = get_dataloader("eth", "train", augment=True, batch_size=a.scenes_per_batch, crop_device="cuda")
+        run(ld, a.batches, True)  # (first pass: the Lanczos tables of the sizes it meets are built and cached)
+        dev_a = run(ld, max(a.batches, 2), True)
+        print("device crops, augmented (per-crop taps from the resident image): {:9.0f} pedestrians/s  ({:.1f}x)".format(
+            dev_a, dev_a / host_a))
 
 
 if __name__ == "__main__":
