@@ -327,6 +327,61 @@ def sharded_one_rank_leg(args, single_ms):
     return out
 
 
+def train_loop_disk_leg(args, dev, head_ms, frames=980, peds=40, scenes_per_batch=32, epochs=6):
+    """train() as the README runs it on an ON-DISK dataset in the reference's format (one 640 x 480 scene image, `frames`
+    frames x `peds` pedestrians written as an ETH-style text file), --augment 1 (the reference's default), no --cache_device:
+    every batch goes through the loader -- trajectories on the host, the augmented scene crops on the GPU
+    (mggan/data_utils/device_crops.py) -- and the trainer's graph cache.  32 scenes x 40 pedestrians = the headline's 1,280
+    pedestrians per batch.  The figure is the median over the later epochs of (epoch wall time) / iterations."""
+    import contextlib
+    import io
+    import tempfile
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_loader as BL
+
+    from mggan.logging import Experiment
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.model.train import PiNetMultiGeneratorGAN
+
+    tmp = tempfile.mkdtemp(prefix="mggan_disk_")
+    was = os.environ.get("MGGAN_DATA_ROOT")
+    os.environ["MGGAN_DATA_ROOT"] = tmp
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            BL.make_dataset(tmp, frames=frames, peds=peds, phase="train")
+            BL.make_dataset(tmp, frames=40, peds=peds, phase="val")
+            cfg = get_parser().parse_args([
+                "--num_gens", str(CONFIGS["c2"]["num_gens"]), "--rng", "device", "--graph", "auto", "--dataset", "eth",
+                "--augment", "1", "--epochs", str(epochs), "--batch_size", str(scenes_per_batch), "--val_every", "1000000",
+                "--save_every", "1000000"])
+            torch.manual_seed(145325)
+            np.random.seed(435346)
+            G, D = construct_model(cfg)
+            tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+            torch.cuda.manual_seed(1234)
+            tr.zero_grads_in_step = True
+            last = tr.train()
+    finally:
+        if was is None:
+            os.environ.pop("MGGAN_DATA_ROOT", None)
+        else:
+            os.environ["MGGAN_DATA_ROOT"] = was
+    ig = tr.iteration_graphs
+    per_it = sorted(s / n for s, n in list(zip(tr.epoch_seconds, tr.epoch_iterations))[2:])
+    ms = per_it[len(per_it) // 2] * 1e3
+    tr.dist.close()
+    return {"workload": "train() on an on-disk dataset (reference format: {} frames x {} pedestrians, one 640x480 scene image), "
+                        "--augment 1, batches of {} scenes, num_gens={}, {} epochs; crops on the GPU, no device cache".format(
+                            frames, peds, scenes_per_batch, CONFIGS["c2"]["num_gens"], epochs),
+            "ms_per_step": round(ms, 4), "vs_captured_iteration": round(ms / head_ms, 3),
+            "iterations_per_epoch": tr.epoch_iterations[-1], "replayed_iterations": ig.replays if ig else 0,
+            "eager_iterations": (ig.eager if ig else sum(tr.epoch_iterations)), "graphs": len(ig.entries) if ig else 0,
+            "ms_per_step_by_epoch": [round(s / n * 1e3, 4) for s, n in zip(tr.epoch_seconds, tr.epoch_iterations)],
+            "last_losses": {k: round(v, 6) for k, v in sorted(last.items()) if "probs" not in k}}
+
+
 def train_loop_leg(tag, args, dev, batches=25, epochs=6):
     """MultiGeneratorGAN.train() itself (the reference's loop, abstract_train.py:114-168) on the synthetic loader at the
     headline shape: device-resident batches, --rng device, the loop's own graph cache.  Epoch 1 produces the data and runs
@@ -867,6 +922,11 @@ def main():
             tl = train_loop_leg(args.config, args, dev)
             tl["vs_graph_headline"] = round(tl["value"] / out["value"], 3)
             out["train_loop"] = tl
+        if args.config == "c2":
+            try:
+                out["train_loop_disk"] = train_loop_disk_leg(args, dev, head["ms_per_step"])
+            except Exception as exc:  # noqa: BLE001  (a detail leg must not cost the line)
+                out["train_loop_disk"] = {"error": "{}: {}".format(type(exc).__name__, str(exc)[:300])}
         # train() on RAGGED batches of the configs[0] shape (32 scenes of 1-6 pedestrians, a new tuple of sizes every batch,
         # like the reference loader's): padded to shape buckets, one captured graph per bucket replays them all
         tr_ = train_loop_leg("c1", args, dev)

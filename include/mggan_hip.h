@@ -614,9 +614,11 @@ int mggan_pad_batch(const void* descs, int n, int b, int b_pad, int period, mgga
  * ksv 22-bit coefficients and (first source index, taps) pairs per output column / row -- in `tables`; built by
  * mggan/data_utils/aug_geometry.py); ped_item[p] = item of pedestrian p, centers (n, 2) = crop centre (x, y) in the resized
  * image; out (n, 4, 2 margin + 1, 2 margin + 1): RGB as -1 + v * 2 / 256 and the one-hot centre channel.  Limits: window <= 33,
- * <= 128 taps per pass (downscale <= 21), staged source rows <= 800 pixels (checked on the host side). */
+ * <= 128 taps per pass (downscale <= 21), staged source rows <= 800 pixels (checked on the host side); `atlas` must be
+ * readable 4 bytes past its last pixel (a pixel is fetched as one dword). */
 int mggan_crop_patches_aug(const unsigned char* atlas, const void* items, const int* tables, const int* ped_item,
-                           const int* centers, int n, int margin, float* out, mggan_stream_t stream);
+                           const int* centers, int n, int margin, int max_taps /* largest ksh of the batch's items */,
+                           float* out, mggan_stream_t stream);
 /* n (<= 8) small buffers copied in ONE launch: `descs` = n records { const void* src; void* dst; long bytes; } (<= 64 KB each).
  * Snapshot / roll-back of the discriminator's BatchNorm running statistics (nn.BatchNorm2d buffers, reference
  * /root/reference/mggan/model/modules/cnn.py:140-141) around the next iteration's discriminator context when it is issued

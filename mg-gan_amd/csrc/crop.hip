@@ -41,9 +41,15 @@ __global__ __launch_bounds__(256) void crop_patches_kernel(const unsigned char* 
 //     vertical pass: thread (Y, X, c) sums its taps over the intermediate rows -> u8 -> -1 + v * 2 / 256 (f64, rounded once).
 // Integer arithmetic throughout (int32 accumulators like Pillow's); HBM traffic is the gathered source window, read once per strip.
 #define AUG_SIDE_MAX 33
+#define AUG_L (AUG_SIDE_MAX * 3)  // (X, channel) pairs of a window row
 #define AUG_KS_MAX 128     // taps per output pixel and pass: Lanczos support 3 x scale, scale <= 21
-#define AUG_ROWS 320       // intermediate rows held per strip
+#define AUG_ROWS 192       // intermediate rows held per strip
+#define AUG_TPAD (AUG_ROWS + AUG_KS_MAX + 12)  // bytes per (X, channel) line of the intermediate image (+ slack: a thread reads whole
+                                              // words); 83 words: neighbouring lines start on different LDS banks
 #define AUG_SPAN_MAX 800   // source columns of a staged row: 32 x scale + taps
+#define AUG_STAGE 9600     // bytes of staged canvas rows per colour plane ...
+#define AUG_PLANE (AUG_STAGE + 44)  // ... planes 2,411 words apart: the three channels of a column sit on different banks
+#define AUG_BIAS (1 << 22) // coefficients are stored biased (>= 0, < 2^24) as three byte limbs for v_dot4_u32_u8
 struct AugItem {           // one per batch item (scene instance); mggan/data_utils/device_crops.py packs it as 26 int32
   long long img_off;       // byte offset of the scene's scaled image (h, w, 3) u8 in the atlas
   int w, h, flip, rot;     // flip 0 / 1 (left-right) / 2 (top-bottom); rot 0: alpha == 0 (the canvas is the flipped image)
@@ -56,20 +62,48 @@ __device__ __forceinline__ int aug_clip8(int v) {
   v >>= 22;
   return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
+// sum_t byte_t(px) * k_t over four taps, k biased and split into byte limbs: three v_dot4_u32_u8 (full rate; a 32-bit integer
+// multiply is quarter rate and would need a bit-field extract per tap) + one for the bias.  All sums are exact modulo 2^32 and
+// the true value fits an int32 (Pillow accumulates in int), so the wrap-around cancels.
+struct AugAcc {
+  unsigned lo, mid, hi, sum;
+  __device__ __forceinline__ void clear() { lo = mid = hi = sum = 0u; }
+  __device__ __forceinline__ void taps(unsigned px, unsigned k0, unsigned k1, unsigned k2) {
+    lo = __builtin_amdgcn_udot4(px, k0, lo, false);
+    mid = __builtin_amdgcn_udot4(px, k1, mid, false);
+    hi = __builtin_amdgcn_udot4(px, k2, hi, false);
+    sum = __builtin_amdgcn_udot4(px, 0x01010101u, sum, false);
+  }
+  __device__ __forceinline__ int value() const { return (int)((1u << 21) + lo + (mid << 8) + (hi << 16) - (sum << 22)); }
+};
+__device__ __forceinline__ void aug_pack_limbs(const int k[4], unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = p1 = p2 = 0u;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned kb = (unsigned)(k[u] + AUG_BIAS);
+    p0 |= (kb & 0xffu) << (8 * u);
+    p1 |= ((kb >> 8) & 0xffu) << (8 * u);
+    p2 |= ((kb >> 16) & 0xffu) << (8 * u);
+  }
+}
+// KS: the taps of a horizontal coefficient row, rounded up to a multiple of 32 -- they live in REGISTERS (3 KS / 4 packed limb
+// words) of the thread that owns output column X and channel c for the whole launch; taps beyond an item's own count are zero
+// (stored as the bias: they cancel).
+template <int KS>
 __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned char* __restrict__ atlas,
                                                                const AugItem* __restrict__ items, const int* __restrict__ tables,
                                                                const int* __restrict__ ped_item, const int* __restrict__ centers,
                                                                int margin, float* __restrict__ out) {
-  __shared__ int khs[AUG_SIDE_MAX * AUG_KS_MAX];
-  __shared__ unsigned char tmp[AUG_ROWS * AUG_SIDE_MAX * 3 + 4];
-  __shared__ unsigned char rowbuf[4][AUG_SPAN_MAX * 3 + 8];
-  const int p = blockIdx.x, side = 2 * margin + 1, plane = side * side;
+  __shared__ __attribute__((aligned(16))) unsigned char stage[3 * AUG_PLANE + 16];  // a block of canvas rows, one plane per colour
+  __shared__ __attribute__((aligned(16))) unsigned char tmpT[AUG_L * AUG_TPAD];      // the horizontally resized strip, line (X, c) major
+  __shared__ int sbv[2 * AUG_SIDE_MAX];
+  const int p = blockIdx.x, side = 2 * margin + 1, plane = side * side, tid = threadIdx.x;
   const AugItem it = items[ped_item[p]];
   float* o = out + (size_t)p * 4 * plane;
   const int X0 = centers[2 * p] - margin, Y0 = centers[2 * p + 1] - margin;
   // the window's part inside the small image; everything else reads 0 like Image.crop
   const int Xa = max(X0, 0), Xb = min(X0 + side, it.sw), Ya = max(Y0, 0), Yb = min(Y0 + side, it.sh);
-  for (int i = threadIdx.x; i < 4 * plane; i += 256) {
+  for (int i = tid; i < 4 * plane; i += 256) {
     const int c = i / plane, r = i % plane;
     o[i] = c == 3 ? ((r == margin * side + margin) ? 1.f : 0.f) : -1.f;
   }
@@ -78,16 +112,35 @@ __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned ch
   const int* kh = tables + it.kh;
   const int* bh = tables + it.bh;
   const int* kv = tables + it.kv;
-  const int* bv = tables + it.bv;
-  for (int i = threadIdx.x; i < nX * it.ksh; i += 256) khs[i] = kh[(size_t)(Xa + i / it.ksh) * it.ksh + i % it.ksh];
-  const int xlo = bh[2 * Xa], xhi = bh[2 * (Xb - 1)] + bh[2 * (Xb - 1) + 1], span = xhi - xlo;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int Xi = lane / 3, ch = lane % 3;
-  const int hx0 = lane < nL ? bh[2 * (Xa + Xi)] - xlo : 0, hn = lane < nL ? bh[2 * (Xa + Xi) + 1] : 0;
-  const int Xi2 = (lane + 64) / 3, ch2 = (lane + 64) % 3;  // lanes 64..98 of the 99 (X, c) pairs: second pass of the wave
-  const int hx1 = lane + 64 < nL ? bh[2 * (Xa + Xi2)] - xlo : 0, hn1 = lane + 64 < nL ? bh[2 * (Xa + Xi2) + 1] : 0;
-  const unsigned char* img = atlas + it.img_off;
+  // (first source row, taps) of the window's output rows: read once (the strip loop and the vertical pass walk them)
+  if (tid < 2 * (Yb - Ya)) sbv[tid] = tables[it.bv + 2 * Ya + tid];
+  for (int i = tid; i < AUG_L * AUG_TPAD / 4; i += 256) reinterpret_cast<unsigned*>(tmpT)[i] = 0u;  // (slack bytes: finite)
   __syncthreads();
+  const int* bv = sbv - 2 * Ya;
+  const int xlo = bh[2 * Xa], xhi = bh[2 * (Xb - 1)] + bh[2 * (Xb - 1) + 1], span = xhi - xlo;
+  const int span_pad = (span + KS + 7) & ~3;          // a thread reads KS (+4) bytes from its first tap on: slack behind the row
+  const int R = min(16, AUG_STAGE / span_pad);          // canvas rows staged per block
+  // horizontal pass: thread (l, half) = output column / channel l of the rows half, half + 2, ... of a staged block
+  const int l = tid % AUG_L, half = tid / AUG_L;
+  const bool hthread = tid < 2 * AUG_L && l < nL;
+  const int Xi = l / 3, ch = l % 3;
+  unsigned k0[KS / 4], k1[KS / 4], k2[KS / 4];
+  {
+    const int* krow = kh + (size_t)(Xa + (hthread ? Xi : 0)) * it.ksh;
+#pragma unroll
+    for (int q = 0; q < KS / 4; ++q) {
+      int k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) k[u] = (hthread && 4 * q + u < it.ksh) ? krow[4 * q + u] : 0;
+      aug_pack_limbs(k, k0[q], k1[q], k2[q]);
+    }
+  }
+  const int hx0 = hthread ? bh[2 * (Xa + Xi)] - xlo : 0;
+  const unsigned char* img = atlas + it.img_off;
+  // the affine map in 32-bit two's complement like Pillow's `int xx, yy` (Geometry.c checks that every coordinate of the
+  // canvas stays below 32,768 pixels = 2^31 in 16.16; partial sums may wrap, the result does not)
+  const unsigned ua0 = (unsigned)it.a[0], ua1 = (unsigned)it.a[1], ua2 = (unsigned)it.a[2], ua3 = (unsigned)it.a[3],
+                 ua4 = (unsigned)it.a[4], ua5 = (unsigned)it.a[5];
   int Ys = Ya;
   while (Ys < Yb) {
     // strip [Ys, Ye): as many output rows as keep the source rows within AUG_ROWS
@@ -95,50 +148,96 @@ __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned ch
     int Ye = Ys + 1;
     while (Ye < Yb && bv[2 * Ye] + bv[2 * Ye + 1] - ylo <= AUG_ROWS) ++Ye;
     const int yhi = bv[2 * (Ye - 1)] + bv[2 * (Ye - 1) + 1];
-    // ---- horizontal pass: source rows ylo .. yhi-1 of the rotated canvas -> tmp ----
-    for (int y = ylo + wv; y < yhi; y += 4) {
-      unsigned char* rb = rowbuf[wv];
-      for (int j = lane; j < span; j += 64) {
-        const int xr = xlo + j;
-        int xin = xr, yin = y;
-        if (it.rot) {
-          xin = (int)(((long long)it.a[2] + (long long)y * it.a[1] + (long long)xr * it.a[0]) >> 16);
-          yin = (int)(((long long)it.a[5] + (long long)y * it.a[4] + (long long)xr * it.a[3]) >> 16);
+    for (int yb = ylo; yb < yhi; yb += R) {
+      const int nr = min(R, yhi - yb);
+      // ---- stage nr canvas rows (gathered through the affine map, flipped on the way).  A thread owns FOUR neighbouring
+      // canvas columns of eight rows (threads 0..127: rows 0-7, 128..255: rows 8-15): 32 dword loads in flight before the
+      // first LDS store -- the pass is bound by the latency of the gather, not by its bytes -- and one 4-byte LDS store per
+      // row and colour plane (byte stores of neighbouring lanes into one LDS word serialise) ----
+      {
+        const int rh = (tid >> 7) * 8;  // this thread's first row of the block
+        const unsigned bx = ua2 + (unsigned)(yb + rh) * ua1, by = ua5 + (unsigned)(yb + rh) * ua4;
+        for (int j4 = (tid & 127) * 4; j4 < span; j4 += 4 * 128) {
+          unsigned v[8][4];
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) {
+            const int xr = xlo + j4 + c4;
+            unsigned cx = bx + (unsigned)xr * ua0, cy = by + (unsigned)xr * ua3;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              v[r][c4] = 0u;
+              if (rh + r < nr && j4 + c4 < span) {
+                const int xin = it.rot ? ((int)cx >> 16) : xr, yin = it.rot ? ((int)cy >> 16) : yb + rh + r;
+                if (xin >= 0 && xin < it.w && yin >= 0 && yin < it.h) {
+                  const int xs = it.flip == 1 ? it.w - 1 - xin : xin, ys = it.flip == 2 ? it.h - 1 - yin : yin;
+                  const unsigned at = (unsigned)(__mul24(ys, it.w) + xs) * 3u;  // (< 2^15 each; the image holds < 2^31 bytes)
+                  __builtin_memcpy(&v[r][c4], img + at, 4);  // one (unaligned) dword; the atlas ends in spare bytes
+                }
+              }
+              cx += ua1;
+              cy += ua4;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (rh + r < nr) {
+              unsigned* at = reinterpret_cast<unsigned*>(stage + (rh + r) * span_pad + j4);  // (span_pad and j4 are multiples of 4)
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+                at[c * (AUG_PLANE / 4)] = ((v[r][0] >> (8 * c)) & 0xffu) | (((v[r][1] >> (8 * c)) & 0xffu) << 8) |
+                                          (((v[r][2] >> (8 * c)) & 0xffu) << 16) | (((v[r][3] >> (8 * c)) & 0xffu) << 24);
+            }
         }
-        unsigned char r = 0, g = 0, b = 0;
-        if (xin >= 0 && xin < it.w && yin >= 0 && yin < it.h) {
-          const int xs = it.flip == 1 ? it.w - 1 - xin : xin, ys = it.flip == 2 ? it.h - 1 - yin : yin;
-          const unsigned char* q = img + ((size_t)ys * it.w + xs) * 3;
-          r = q[0]; g = q[1]; b = q[2];
+      }
+      __syncthreads();
+      // ---- horizontal pass over the staged rows: aligned words, re-aligned to the thread's first tap, four taps per dot4 ----
+      if (hthread) {
+        for (int r = half; r < nr; r += 2) {
+          const unsigned char* row = stage + ch * AUG_PLANE + r * span_pad + hx0;
+          const int phase = (int)((size_t)row & 3);
+          const unsigned* wp = reinterpret_cast<const unsigned*>(row - phase);
+          AugAcc acc;
+          acc.clear();
+          unsigned w0 = wp[0];
+#pragma unroll
+          for (int q = 0; q < KS / 4; ++q) {
+            const unsigned w1 = wp[q + 1];
+            acc.taps(__builtin_amdgcn_alignbyte(w1, w0, phase), k0[q], k1[q], k2[q]);
+            w0 = w1;
+          }
+          tmpT[l * AUG_TPAD + (yb + r - ylo)] = (unsigned char)aug_clip8(acc.value());
         }
-        rb[3 * j] = r; rb[3 * j + 1] = g; rb[3 * j + 2] = b;
       }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane < nL) {
-        int sacc = 1 << 21;
-        const int* k = khs + Xi * it.ksh;
-        for (int t = 0; t < hn; ++t) sacc += (int)rb[3 * (hx0 + t) + ch] * k[t];
-        tmp[(y - ylo) * (AUG_SIDE_MAX * 3) + lane] = (unsigned char)aug_clip8(sacc);
-      }
-      if (lane + 64 < nL) {
-        int sacc = 1 << 21;
-        const int* k = khs + Xi2 * it.ksh;
-        for (int t = 0; t < hn1; ++t) sacc += (int)rb[3 * (hx1 + t) + ch2] * k[t];
-        tmp[(y - ylo) * (AUG_SIDE_MAX * 3) + lane + 64] = (unsigned char)aug_clip8(sacc);
-      }
-      __builtin_amdgcn_wave_barrier();
+      __syncthreads();
+    }
+    // ---- vertical pass: output rows Ys .. Ye-1; their coefficient rows first go to LDS as packed limbs (the staging area is
+    // free now): kvp[(Y - Ys)][q][3] ----
+    unsigned* kvp = reinterpret_cast<unsigned*>(stage);
+    const int qv = (it.ksv + 3) / 4;
+    for (int i = tid; i < (Ye - Ys) * qv; i += 256) {
+      const int Yi = i / qv, q = i % qv;
+      int k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) k[u] = 4 * q + u < it.ksv ? kv[(size_t)(Ys + Yi) * it.ksv + 4 * q + u] : 0;
+      aug_pack_limbs(k, kvp[3 * i], kvp[3 * i + 1], kvp[3 * i + 2]);
     }
     __syncthreads();
-    // ---- vertical pass: output rows Ys .. Ye-1 ----
-    for (int i = threadIdx.x; i < (Ye - Ys) * nL; i += 256) {
-      const int Y = Ys + i / nL, l = i % nL;
-      const int y0 = bv[2 * Y] - ylo, n = bv[2 * Y + 1];
-      const int* k = kv + (size_t)Y * it.ksv;
-      int sacc = 1 << 21;
-      for (int t = 0; t < n; ++t) sacc += (int)tmp[(y0 + t) * (AUG_SIDE_MAX * 3) + l] * k[t];
-      const int v = aug_clip8(sacc);
-      o[(l % 3) * plane + (Y - Y0) * side + (Xa + l / 3 - X0)] = (float)(-1.0 + (double)v * 2.0 / 256.0);
+    for (int i = tid; i < (Ye - Ys) * nL; i += 256) {
+      const int Y = Ys + i / nL, ll = i % nL;
+      const unsigned char* col = tmpT + ll * AUG_TPAD + (bv[2 * Y] - ylo);
+      const int phase = (int)((size_t)col & 3);
+      const unsigned* wp = reinterpret_cast<const unsigned*>(col - phase);
+      const unsigned* kq = kvp + 3 * (Y - Ys) * qv;
+      AugAcc acc;
+      acc.clear();
+      unsigned w0 = wp[0];
+      for (int q = 0; q < qv; ++q) {
+        const unsigned w1 = wp[q + 1];
+        acc.taps(__builtin_amdgcn_alignbyte(w1, w0, phase), kq[3 * q], kq[3 * q + 1], kq[3 * q + 2]);
+        w0 = w1;
+      }
+      const int v = aug_clip8(acc.value());
+      o[(ll % 3) * plane + (Y - Y0) * side + (Xa + ll / 3 - X0)] = (float)(-1.0 + (double)v * 2.0 / 256.0);
     }
     __syncthreads();
     Ys = Ye;
@@ -247,14 +346,19 @@ int mggan_crop_patches(const unsigned char* atlas, const long long* img_off, con
 }
 
 int mggan_crop_patches_aug(const unsigned char* atlas, const void* items, const int* tables, const int* ped_item,
-                           const int* centers, int n, int margin, float* out, hipStream_t stream) {
+                           const int* centers, int n, int margin, int max_taps, float* out, hipStream_t stream) {
   MG_CHECK_ARG(n >= 0 && margin >= 0 && 2 * margin + 1 <= AUG_SIDE_MAX, "crop_patches_aug: window of %d pixels (<= %d)", 2 * margin + 1,
                AUG_SIDE_MAX);
+  MG_CHECK_ARG(max_taps >= 1 && max_taps <= AUG_KS_MAX, "crop_patches_aug: %d taps per pixel (<= %d)", max_taps, AUG_KS_MAX);
   if (n == 0) return MGGAN_OK;
   MG_CHECK_ARG(atlas && items && tables && ped_item && centers && out, "crop_patches_aug: null pointer");
   static_assert(sizeof(AugItem) == 26 * 4, "AugItem is 26 int32 words");
-  MG_LAUNCH(crop_patches_aug_kernel, dim3(n), dim3(256), 0, stream, atlas, (const AugItem*)items, tables, ped_item, centers, margin,
-            out);
+  const AugItem* it = (const AugItem*)items;
+  // (the coefficient row of an output column lives in registers: instantiated per tap count, rounded up)
+  if (max_taps <= 32) MG_LAUNCH((crop_patches_aug_kernel<32>), dim3(n), dim3(256), 0, stream, atlas, it, tables, ped_item, centers, margin, out);
+  else if (max_taps <= 64) MG_LAUNCH((crop_patches_aug_kernel<64>), dim3(n), dim3(256), 0, stream, atlas, it, tables, ped_item, centers, margin, out);
+  else if (max_taps <= 96) MG_LAUNCH((crop_patches_aug_kernel<96>), dim3(n), dim3(256), 0, stream, atlas, it, tables, ped_item, centers, margin, out);
+  else MG_LAUNCH((crop_patches_aug_kernel<128>), dim3(n), dim3(256), 0, stream, atlas, it, tables, ped_item, centers, margin, out);
   MG_LAUNCH_CHECK("crop_patches_aug");
   return MGGAN_OK;
 }

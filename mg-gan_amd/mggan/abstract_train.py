@@ -96,11 +96,17 @@ class MultiGeneratorGAN(abc.ABC):
         b = in_xy.size(1)
         sub_batches = batch["seq_start_end"] if "seq_start_end" in batch else list(zip(range(b), range(1, b + 1)))
         gt_xy, gt_dxdy = batch["gt_xy"], batch["gt_dxdy"]
-        if "loss_mask" in batch:  # None == every pedestrian valid (no device sync, HIP-graph capturable)
+        if "loss_mask" in batch and not batch.get("_local_mask"):  # None == every pedestrian valid (no device sync, capturable)
             loss_mask = batch["loss_mask"]
         else:
-            loss_mask = ~gt_xy.isnan().any(2).any(0)
-            all_valid = bool(loss_mask.all())
+            if "loss_mask" in batch:  # this rank's verdict, taken by the loader on the host copy (device_crops.py)
+                loss_mask = batch["loss_mask"]
+                all_valid = loss_mask is None
+                if all_valid:
+                    loss_mask = torch.ones(b, dtype=torch.bool, device=gt_xy.device)
+            else:
+                loss_mask = ~gt_xy.isnan().any(2).any(0)
+                all_valid = bool(loss_mask.all())
             if self.dist.enabled and self.dist.world_size > 1:
                 # the masked steps issue other collectives than the unmasked ones (no shared discriminator context: two
                 # scene-CNN passes per step): every rank takes the masked path as soon as ANY rank holds a NaN
@@ -201,6 +207,7 @@ class MultiGeneratorGAN(abc.ABC):
 
         batch = dict(batch)
         batch["loss_mask"] = None
+        batch.pop("_local_mask", None)
         # pipeline (None: MGGAN_PIPELINE): the captured iteration reads its discriminator context from where the previous
         # replay left it and ends with the context of the next one -- the static batch's own: replays feed the same buffers
         pipe = getattr(self, "_pipe", None)
@@ -367,17 +374,23 @@ class MultiGeneratorGAN(abc.ABC):
         kw = dict(synthetic_scenes=getattr(cfg, "synthetic_scenes", 64), synthetic_peds=getattr(cfg, "synthetic_peds", 0))
         if getattr(cfg, "cache_device", 0):
             kw["cache_device"] = self.device
+        workers = cfg.workers
         if cfg.dataset != "synthetic" and getattr(cfg, "crop_device", "auto") != "off":
-            kw["crop_device"] = self.device  # scene crops on the GPU (the loader then runs in this process: workers = 0)
+            # scene crops on the GPU; the host half of a batch (trajectory transforms, the augmentation's geometry: ~55 us
+            # per item of Python) runs where --workers says -- in this process by default, like the reference's loader and
+            # with its numpy draw order (loader workers were measured SLOWER here: 4.5 vs 3.4 ms per 1,280-pedestrian batch,
+            # the batches cross the process boundary as a dozen small tensors each)
+            kw["crop_device"] = self.device
+            workers = int(os.environ.get("MGGAN_LOADER_WORKERS", str(workers)))
         pad = getattr(cfg, "graph_pad", "auto")
         graphs = self.iteration_graphs = IterationGraphs(
             self, getattr(cfg, "graph_shapes", 8), pad=pad, bucket=getattr(cfg, "graph_bucket", "quarter"),
             capture=self.graph_mode(), bucket_limit=getattr(cfg, "graph_buckets", 64)) if (self.graph_mode() or pad == "on") else None
         self.epoch_seconds, self.epoch_iterations = [], []  # wall time of the training loop of every epoch (bench.py)
         train_loader = get_dataloader(dataset=cfg.dataset, phase="train", augment=cfg.augment,
-                                      batch_size=cfg.batch_size, workers=cfg.workers, shuffle=True, **kw)
+                                      batch_size=cfg.batch_size, workers=workers, shuffle=True, **kw)
         val_loader = get_dataloader(dataset=cfg.dataset, phase="val", augment=False, batch_size=cfg.batch_size,
-                                    workers=cfg.workers, shuffle=False, **kw)
+                                    workers=0 if "crop_device" in kw else workers, shuffle=False, **kw)
         track_metric = "val/ADE k=20"
         min_track_metric = math.inf
         self.total_iterations = 0  # a local of train() in the reference (abstract_train.py:104): every call starts at 0
@@ -652,6 +665,8 @@ class IterationGraphs:
             valid = (not gt.is_cuda) and not bool(torch.isnan(gt).any())  # (a device batch would need a sync to tell)
         if not valid:
             return False
+        if "_local_mask" in batch:  # (the loader's verdict has been used; the static copies are valid by construction)
+            batch = {k: v for k, v in batch.items() if k != "_local_mask"}
         bucket = self.bucket_of(batch)
         if bucket is None and not self.capture:
             return False

@@ -58,9 +58,9 @@ def get_dataloader(dataset, phase, augment=False, batch_size=8, workers=0, shuff
         if crop_device is not None:
             from mggan.data_utils.device_crops import DeviceCropDataset
 
-            dds = DeviceCropDataset(ds, crop_device)
-            return torch.utils.data.DataLoader(dds, batch_size=batch_size, shuffle=shuffle, num_workers=0,
-                                               collate_fn=dds.collate, drop_last=False)
+            from mggan.data_utils.device_crops import DeviceCropLoader
+
+            return DeviceCropLoader(DeviceCropDataset(ds, crop_device), batch_size, shuffle, workers)
         return torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=shuffle, num_workers=workers,
                                            collate_fn=seq_collate_scene, drop_last=False)
     n_batches = max(1, synthetic_scenes // max(batch_size, 1))

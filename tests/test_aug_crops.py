@@ -92,7 +92,7 @@ def test_device_kernel_matches_pillow_crops(w, h, f):
     ct = torch.tensor(ctr, dtype=torch.int32, device=dev)
     out = torch.full((len(ped_item), 4, 33, 33), float("nan"), device=dev)
     lib.mggan_crop_patches_aug(dds.atlas.data_ptr(), it.data_ptr(), pool.data_ptr(), pi.data_ptr(), ct.data_ptr(), len(ped_item), 16,
-                               out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                               int(np.stack(items)[:, 16].max()), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     ref = np.stack(want).astype(np.float64)

@@ -70,7 +70,7 @@ def test_device_crops_match_host_crops(loader_golden, name):
     assert dev["features"].is_cuda and dev["features"].shape == host["features"].shape
     assert torch.equal(dev["features"].cpu(), host["features"])
     for k in ("in_xy", "gt_xy", "in_dxdy", "gt_dxdy"):
-        np.testing.assert_array_equal(dev[k].numpy(), host[k].numpy())
+        np.testing.assert_array_equal(dev[k].cpu().numpy(), host[k].numpy())  # (the whole batch arrives on the device)
     assert dev["seq_start_end"] == host["seq_start_end"]
     g = loader_golden["{}/test/batch/features".format(name)]
     n = min(len(g), dev["features"].shape[0])
@@ -92,7 +92,7 @@ def test_device_crops_match_host_crops_with_training_augmentation(loader_golden,
     assert dev["features"].is_cuda and dev["features"].shape == host["features"].shape
     np.testing.assert_array_equal(dev["features"].cpu().numpy(), host["features"].numpy())
     for k in ("in_xy", "gt_xy", "in_dxdy", "gt_dxdy"):
-        np.testing.assert_array_equal(dev[k].numpy(), host[k].numpy())
+        np.testing.assert_array_equal(dev[k].cpu().numpy(), host[k].numpy())
     assert dev["seq_start_end"] == host["seq_start_end"]
     g = loader_golden["{}/train/batch/features".format(name)]
     assert len(g) == dev["features"].shape[0]
