@@ -630,7 +630,12 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
                   "launches_per_step": round(calls, 2), "avg_launch_ms": round(per_launch_s * 1e3, 4),
                   "timed": "graph replay (device-clock marks)" if symbol in replay_ms else "eager (HIP events)",
                   "standalone_ms": round(ms_alone / max(calls, 1), 4),
-                  "tflops": round(tf, 3), "algorithmic_gbs": round(gbs, 1)}
+                  "tflops": round(tf, 3), "algorithmic_gbs": round(gbs, 1),
+                  # BOTH fractions, whatever `bound` says: where they are close the single label hides the other roof
+                  "frac_mfma": round(tf / F32_PEAK_TFLOPS, 5), "frac_hbm": round(gbs / HBM_PEAK_GBS, 5)}
+        tb = common["traffic"]
+        if tb and per_launch_s > 0:  # ... and the fraction of the HBM roof by MEASURED bytes (re-reads included)
+            common["frac_hbm_measured"] = round(tb / per_launch_s / 1e9 / HBM_PEAK_GBS, 5)
         # the binding roof is the one the kernel sits closer to
         if gbs / HBM_PEAK_GBS > tf / F32_PEAK_TFLOPS:
             return dict(common, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -638,6 +643,14 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
         return dict(common, bound="mfma", achieved=round(tf, 3), peak=F32_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(tf / F32_PEAK_TFLOPS, 5))
 
+    hbm_step = None
+    if traffic_tab:  # measured bytes per launch (committed PMC table) x this run's launches per iteration, kernel by kernel
+        tot = 0.0
+        for _, _, calls, _, sym, _ in rows:
+            e = traffic_tab.get(sym)
+            if isinstance(e, dict) and e.get("bytes_per_launch") is not None:
+                tot += float(e["bytes_per_launch"]) * calls
+        hbm_step = round(tot) if tot > 0 else None
     # the dominant kernel = the one with the largest share of the step's GPU time (summed over its launches), in the
     # regime of the timed region when the marked replay is available
     rows.sort(key=lambda r: replay_ms.get(r[4], r[0] if not replay_ms else 0.0), reverse=True)
@@ -656,6 +669,10 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
         "iteration_flops_executed_g": round(executed_flops / 1e9, 2),
         "iteration_tflops": round(total_flops / (dt / args.steps) / 1e12, 3),
         "iteration_frac_of_f32_peak": round(total_flops / (dt / args.steps) / 1e12 / F32_PEAK_TFLOPS, 4),
+        # HBM bytes of one iteration: the sum over the committed per-kernel PMC table (profiles/hbm_traffic_<cfg>.json:
+        # bytes per launch x launches per iteration), and what that is of the 8 TB/s roof at this run's iteration time
+        "hbm_bytes_per_step": hbm_step,
+        "iteration_frac_of_hbm_peak": round(hbm_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if hbm_step else None,
         "gpu_ms_per_step_sum_of_entries": round(gpu_ms, 3),
         "launches_per_step": round(sum(r[2] for r in rows), 1),
         "breakdown": [{"entry": n, "kernel": sym, "ms_per_step": round(ms, 4), "calls": round(c, 2), "gflop": round(fl / 1e9, 3),
@@ -668,7 +685,8 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
 
 LINE_LIMIT = 4096  # the driver keeps the last 8 KB of stdout: the one JSON line must fit with room to spare
 
-ROOFLINE_KEYS = ("kernel", "entry", "bound", "achieved", "peak", "unit", "frac", "traffic", "mfma_util", "avg_launch_ms")
+ROOFLINE_KEYS = ("kernel", "entry", "bound", "achieved", "peak", "unit", "frac", "traffic", "mfma_util", "avg_launch_ms",
+                 "frac_mfma", "frac_hbm", "frac_hbm_measured")
 
 
 def _clean(x):
@@ -713,7 +731,7 @@ def compact_line(full):
         confs.append(e)
     if confs:
         line["configs"] = confs
-    for k in ("iteration_frac_of_f32_peak", "launches_per_step"):
+    for k in ("iteration_frac_of_f32_peak", "hbm_bytes_per_step", "iteration_frac_of_hbm_peak", "launches_per_step"):
         if full.get(k) is not None:
             line[k] = full[k]
     if full.get("collective_transports"):
@@ -874,7 +892,8 @@ def main():
     if rank == 0:
         keep = ("config", "workload", "b_per_gpu", "ms_per_step", "value", "unit", "launch", "collective", "roofline",
                 "roofline_top_kernels", "iteration_flops_algorithmic_g", "iteration_flops_executed_g", "iteration_tflops",
-                "iteration_frac_of_f32_peak", "launches_per_step", "breakdown", "exchanges_per_step", "exchange_schedule",
+                "iteration_frac_of_f32_peak", "hbm_bytes_per_step", "iteration_frac_of_hbm_peak", "launches_per_step", "breakdown",
+                "exchanges_per_step", "exchange_schedule",
                 "collective_note")
         out = {
             "metric": "train-step trajectories/sec", "value": head["value"], "unit": "trajectories/s", "n_gpus": world,
@@ -888,6 +907,8 @@ def main():
             "iteration_flops_executed_g": head.get("iteration_flops_executed_g"),
             "iteration_tflops": head.get("iteration_tflops"),
             "iteration_frac_of_f32_peak": head.get("iteration_frac_of_f32_peak"),
+            "hbm_bytes_per_step": head.get("hbm_bytes_per_step"),
+            "iteration_frac_of_hbm_peak": head.get("iteration_frac_of_hbm_peak"),
             "gpu_ms_per_step_sum_of_entries": head.get("gpu_ms_per_step_sum_of_entries"),
             "launches_per_step": head.get("launches_per_step"), "breakdown": head.get("breakdown"),
             # every measured workload, the headline first (same timing protocol: warmup, barrier, K steps, barrier)
