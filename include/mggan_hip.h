@@ -619,6 +619,13 @@ int mggan_pad_batch(const void* descs, int n, int b, int b_pad, int period, mgga
 int mggan_crop_patches_aug(const unsigned char* atlas, const void* items, const int* tables, const int* ped_item,
                            const int* centers, int n, int margin, int max_taps /* largest ksh of the batch's items */,
                            float* out, mggan_stream_t stream);
+/* ... or, when the pedestrians of an item are many (their windows overlap: a 33 x 33 window of a 64 x 48 image), the WHOLE resized
+ * image of every item first -- tile p of n_tiles is the 33 x 33 block around tile_center[2p..] (x, y) of item tile_item[p]'s
+ * resized image, written as u8 RGB (sh, sw, 3) at small + small_off[item] -- and the crops as windows of those images
+ * (mggan_crop_patches with atlas = small).  Same arithmetic, same bits; the host side picks the cheaper form per batch. */
+int mggan_aug_small_images(const unsigned char* atlas, const void* items, const int* tables, const int* tile_item,
+                           const int* tile_center, int n_tiles, int max_taps, const long long* small_off, unsigned char* small,
+                           mggan_stream_t stream);
 /* n (<= 8) small buffers copied in ONE launch: `descs` = n records { const void* src; void* dst; long bytes; } (<= 64 KB each).
  * Snapshot / roll-back of the discriminator's BatchNorm running statistics (nn.BatchNorm2d buffers, reference
  * /root/reference/mggan/model/modules/cnn.py:140-141) around the next iteration's discriminator context when it is issued

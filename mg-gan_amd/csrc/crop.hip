@@ -93,20 +93,28 @@ template <int KS>
 __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned char* __restrict__ atlas,
                                                                const AugItem* __restrict__ items, const int* __restrict__ tables,
                                                                const int* __restrict__ ped_item, const int* __restrict__ centers,
-                                                               int margin, float* __restrict__ out) {
+                                                               int margin, float* __restrict__ out,
+                                                               const long long* __restrict__ small_off,
+                                                               unsigned char* __restrict__ small) {
+  // TILE MODE (small != NULL): the workgroup computes one 33 x 33 TILE of an item's whole resized image -- ped_item[p] is the
+  // tile's item, centers[2p..] its centre -- as u8 RGB into small + small_off[item]; the crops are then windows of those
+  // images (crop_patches_kernel).  Pedestrians of one item share its canvas and their windows overlap (a 33 x 33 window of a
+  // 64 x 48 image): from a few pedestrians per item on, the whole image costs less than their windows one by one.
   __shared__ __attribute__((aligned(16))) unsigned char stage[3 * AUG_PLANE + 16];  // a block of canvas rows, one plane per colour
   __shared__ __attribute__((aligned(16))) unsigned char tmpT[AUG_L * AUG_TPAD];      // the horizontally resized strip, line (X, c) major
   __shared__ int sbv[2 * AUG_SIDE_MAX];
   const int p = blockIdx.x, side = 2 * margin + 1, plane = side * side, tid = threadIdx.x;
   const AugItem it = items[ped_item[p]];
-  float* o = out + (size_t)p * 4 * plane;
+  float* o = small ? nullptr : out + (size_t)p * 4 * plane;
+  unsigned char* so = small ? small + small_off[ped_item[p]] : nullptr;
   const int X0 = centers[2 * p] - margin, Y0 = centers[2 * p + 1] - margin;
   // the window's part inside the small image; everything else reads 0 like Image.crop
   const int Xa = max(X0, 0), Xb = min(X0 + side, it.sw), Ya = max(Y0, 0), Yb = min(Y0 + side, it.sh);
-  for (int i = tid; i < 4 * plane; i += 256) {
-    const int c = i / plane, r = i % plane;
-    o[i] = c == 3 ? ((r == margin * side + margin) ? 1.f : 0.f) : -1.f;
-  }
+  if (o)
+    for (int i = tid; i < 4 * plane; i += 256) {
+      const int c = i / plane, r = i % plane;
+      o[i] = c == 3 ? ((r == margin * side + margin) ? 1.f : 0.f) : -1.f;
+    }
   if (Xa >= Xb || Ya >= Yb) return;
   const int nX = Xb - Xa, nL = nX * 3;
   const int* kh = tables + it.kh;
@@ -237,7 +245,8 @@ __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned ch
         w0 = w1;
       }
       const int v = aug_clip8(acc.value());
-      o[(ll % 3) * plane + (Y - Y0) * side + (Xa + ll / 3 - X0)] = (float)(-1.0 + (double)v * 2.0 / 256.0);
+      if (o) o[(ll % 3) * plane + (Y - Y0) * side + (Xa + ll / 3 - X0)] = (float)(-1.0 + (double)v * 2.0 / 256.0);
+      else so[((size_t)Y * it.sw + Xa + ll / 3) * 3 + ll % 3] = (unsigned char)v;
     }
     __syncthreads();
     Ys = Ye;
@@ -345,6 +354,21 @@ int mggan_crop_patches(const unsigned char* atlas, const long long* img_off, con
   return MGGAN_OK;
 }
 
+static int crop_aug_launch(const unsigned char* atlas, const void* items, const int* tables, const int* ped_item, const int* centers,
+                           int n, int margin, int max_taps, float* out, const long long* small_off, unsigned char* small,
+                           hipStream_t stream) {
+  const AugItem* it = (const AugItem*)items;
+  // (the coefficient row of an output column lives in registers: instantiated per tap count, rounded up)
+#define AUG_LAUNCH(KS) MG_LAUNCH((crop_patches_aug_kernel<KS>), dim3(n), dim3(256), 0, stream, atlas, it, tables, ped_item, centers, \
+                                 margin, out, small_off, small)
+  if (max_taps <= 32) AUG_LAUNCH(32);
+  else if (max_taps <= 64) AUG_LAUNCH(64);
+  else if (max_taps <= 96) AUG_LAUNCH(96);
+  else AUG_LAUNCH(128);
+#undef AUG_LAUNCH
+  return MGGAN_OK;
+}
+
 int mggan_crop_patches_aug(const unsigned char* atlas, const void* items, const int* tables, const int* ped_item,
                            const int* centers, int n, int margin, int max_taps, float* out, hipStream_t stream) {
   MG_CHECK_ARG(n >= 0 && margin >= 0 && 2 * margin + 1 <= AUG_SIDE_MAX, "crop_patches_aug: window of %d pixels (<= %d)", 2 * margin + 1,
@@ -353,13 +377,22 @@ int mggan_crop_patches_aug(const unsigned char* atlas, const void* items, const 
   if (n == 0) return MGGAN_OK;
   MG_CHECK_ARG(atlas && items && tables && ped_item && centers && out, "crop_patches_aug: null pointer");
   static_assert(sizeof(AugItem) == 26 * 4, "AugItem is 26 int32 words");
-  const AugItem* it = (const AugItem*)items;
-  // (the coefficient row of an output column lives in registers: instantiated per tap count, rounded up)
-  if (max_taps <= 32) MG_LAUNCH((crop_patches_aug_kernel<32>), dim3(n), dim3(256), 0, stream, atlas, it, tables, ped_item, centers, margin, out);
-  else if (max_taps <= 64) MG_LAUNCH((crop_patches_aug_kernel<64>), dim3(n), dim3(256), 0, stream, atlas, it, tables, ped_item, centers, margin, out);
-  else if (max_taps <= 96) MG_LAUNCH((crop_patches_aug_kernel<96>), dim3(n), dim3(256), 0, stream, atlas, it, tables, ped_item, centers, margin, out);
-  else MG_LAUNCH((crop_patches_aug_kernel<128>), dim3(n), dim3(256), 0, stream, atlas, it, tables, ped_item, centers, margin, out);
+  crop_aug_launch(atlas, items, tables, ped_item, centers, n, margin, max_taps, out, nullptr, nullptr, stream);
   MG_LAUNCH_CHECK("crop_patches_aug");
+  return MGGAN_OK;
+}
+
+/* The whole resized image of every item, tile by tile: tile p (of n_tiles) belongs to item tile_item[p] and is the 33 x 33 block
+   around tile_center[2p..] of that item's resized image; u8 RGB (sh, sw, 3) at small + small_off[item]. */
+int mggan_aug_small_images(const unsigned char* atlas, const void* items, const int* tables, const int* tile_item,
+                           const int* tile_center, int n_tiles, int max_taps, const long long* small_off, unsigned char* small,
+                           hipStream_t stream) {
+  MG_CHECK_ARG(n_tiles >= 0 && max_taps >= 1 && max_taps <= AUG_KS_MAX, "aug_small_images: bad arguments");
+  if (n_tiles == 0) return MGGAN_OK;
+  MG_CHECK_ARG(atlas && items && tables && tile_item && tile_center && small_off && small, "aug_small_images: null pointer");
+  const int n = n_tiles;
+  crop_aug_launch(atlas, items, tables, tile_item, tile_center, n, (AUG_SIDE_MAX - 1) / 2, max_taps, nullptr, small_off, small, stream);
+  MG_LAUNCH_CHECK("aug_small_images");
   return MGGAN_OK;
 }
 

@@ -16,7 +16,20 @@ from torch.utils.data import Dataset
 from mggan.data_utils import aug_geometry as AG
 from mggan.data_utils.trajectories_scene import seq_collate_scene
 
+import os
+
 KS_MAX, SPAN_MAX = 128, 800  # csrc/crop.hip: AUG_KS_MAX, AUG_SPAN_MAX
+TILE_MODE = os.environ.get("MGGAN_CROP_TILES", "1") != "0"  # whole resized images first when that is less work (A/B knob)
+PREFETCH_THREAD = os.environ.get("MGGAN_LOADER_THREAD", "0") == "1"  # one batch ahead on a thread of the loader's own: measured
+#   SLOWER (2.34 vs 2.17-2.26 ms per 1,280-pedestrian iteration of train(); the loader alone 565 k vs 725 k pedestrians/s): both
+#   threads are Python and share the GIL; off
+
+
+class _PreBatched:
+    """What DeviceCropDataset.__getitems__ returns: a batch that needs no collation any more."""
+
+    def __init__(self, batch):
+        self.batch = batch
 
 
 class DeviceCropDataset(Dataset):
@@ -40,6 +53,7 @@ class DeviceCropDataset(Dataset):
         # device copy is refreshed when the pool has grown
         self._pool, self._pool_idx, self._pool_dev, self._pool_len = [], {}, None, 0
         self._stream = None
+        self._rings, self._pending_events = {}, []
         self.f_small = ds.img_scaling / ds.scaling_small
         if self.aug:
             self._prewarm()
@@ -60,6 +74,20 @@ class DeviceCropDataset(Dataset):
                     self._tables(n, out)
                 except NotImplementedError:
                     return
+
+    def _staging(self, numel, dtype):
+        """A pinned host buffer of `numel` elements from a ring of eight per dtype: the async copy out of a slot has long
+        finished when the ring comes round (its event is waited for anyway)."""
+        ring = self._rings.setdefault(dtype, {"bufs": [None] * 8, "events": [None] * 8, "i": 0})
+        i = ring["i"] = (ring["i"] + 1) % 8
+        buf = ring["bufs"][i]
+        if ring["events"][i] is not None:
+            ring["events"][i].synchronize()
+        if buf is None or buf.numel() < numel:
+            buf = ring["bufs"][i] = torch.empty(max(numel, 1024), dtype=dtype).pin_memory()
+        ev = ring["events"][i] = torch.cuda.Event()
+        self._pending_events.append(ev)
+        return buf[:numel]
 
     def _tables(self, in_size, out_size):
         """-> (offset of the coefficient rows, offset of the (first index, taps) pairs, taps per row) in the table pool."""
@@ -120,9 +148,82 @@ class DeviceCropDataset(Dataset):
         return [obs, xy[:, ds.obs_len:], dxdy[:, :ds.obs_len - 1], dxdy[:, ds.obs_len - 1:], (end - start) * [scene], meta,
                 torch.empty(1)]
 
+    def __getitems__(self, indices):
+        """A whole batch in one pass (torch's DataLoader hands over the batch's indices when a dataset defines this): the
+        per-item work of __getitem__ with its numpy / torch calls made once per BATCH -- the host half of a 32-scene batch
+        costs ~1 ms instead of 2.2 (55 us of Python per item).  Same arithmetic, element by element, and the augmentation
+        draws in item order from numpy's global generator: the batches are bit-identical to the per-item path
+        (tests/test_loader.py compares both with the reference's fixtures)."""
+        ds = self.ds
+        if ds.format not in ("pixel", "meter"):
+            raise AssertionError(" Not valid format '{}': 'meters' or 'pixel'".format(ds.format))
+        I = len(indices)
+        draws = [ds.augmentation() for _ in indices]  # (rotation angle, flip code) per item, in order
+        se = [ds.seq_start_end[i] for i in indices]
+        n = np.array([e - s for s, e in se], np.int64)
+        scenes = [ds.scene_list[i] for i in indices]
+        wh = np.array([ds.images[sc]["scaled_image"].size for sc in scenes], np.float64)  # (w, h) per item
+        to_orig = np.array([1 / ds.images[sc]["scale_factor"] for sc in scenes], np.float64) if ds.format == "pixel" \
+            else np.full(I, float(ds.img_scaling))
+        alpha = np.array([d[0] for d in draws], np.float64)
+        flip = np.array([d[1] for d in draws], np.int64)
+        c = np.array([np.cos(a) for a, _ in draws], np.float64)  # (scalar calls, like rotate(): the vector loop of np.cos
+        sn = np.array([np.sin(a) for a, _ in draws], np.float64)  #  is not promised to round like its scalar one)
+        center = wh / 2.0
+        # the expanded canvas starts at the minimum of the rotated corners -- which trajectories_scene.rotate writes into an
+        # INTEGER array (the corners are ints): truncation toward zero, reproduced here
+        corners = np.stack([np.zeros_like(wh), np.stack([np.zeros(I), wh[:, 1]], 1), wh, np.stack([wh[:, 0], np.zeros(I)], 1)], 1)
+        d = corners - center[:, None, :]
+        cr = np.stack([d[..., 0] * c[:, None] + d[..., 1] * sn[:, None] + center[:, None, 0],
+                       -d[..., 0] * sn[:, None] + d[..., 1] * c[:, None] + center[:, None, 1]], -1)
+        offset = np.trunc(cr).min(axis=1)  # (I, 2)
+        xy = np.concatenate([ds.trajectory[s:e] for s, e in se]).copy()  # (N, 20, 2) f64
+        rep = lambda a: np.repeat(a, n, axis=0)
+        f, w_o, h_o = rep(flip), rep(wh[:, 0] * to_orig), rep(wh[:, 1] * to_orig)
+        m1, m2 = f == 1, f == 2
+        xy[m1, :, 0] = w_o[m1, None] - xy[m1, :, 0]
+        xy[m2, :, 1] = h_o[m2, None] - xy[m2, :, 1]
+        cen = rep(center * to_orig[:, None])[:, None, :]  # rotation centre in trajectory units
+        cc, ss = rep(c)[:, None], rep(sn)[:, None]
+        dd = xy - cen
+        out = np.empty_like(xy)
+        out[..., 0] = dd[..., 0] * cc + dd[..., 1] * ss + cen[..., 0]
+        out[..., 1] = -dd[..., 0] * ss + dd[..., 1] * cc + cen[..., 1]
+        out -= rep(offset * to_orig[:, None])[:, None, :]
+        # (everything below in numpy, float32 like the per-item path's torch ops -- IEEE elementwise, the same bits: a torch
+        #  op on a 50k-element CPU tensor wakes the whole OpenMP pool, milliseconds on a 256-core host)
+        xy32 = out.astype(np.float32)
+        dxdy = xy32[:, 1:] - xy32[:, :-1]
+        centers = ds.crop_center(xy32[:, ds.obs_len - 1]).astype(np.int32)
+        bounds = np.concatenate([[0], np.cumsum(n)]).tolist()
+        gt_np = xy32[:, ds.obs_len:]
+        # the four time-major tensors as slices of ONE array (T_in + T_gt + (T_in - 1) + T_gt, N, 2): one upload in finish()
+        parts = (xy32[:, :ds.obs_len], gt_np, dxdy[:, :ds.obs_len - 1], dxdy[:, ds.obs_len - 1:])
+        base = torch.from_numpy(np.concatenate([a.transpose(1, 0, 2) for a in parts], 0))
+        cuts = np.cumsum([0] + [a.shape[1] for a in parts])
+        sl = lambda i: base[int(cuts[i]):int(cuts[i + 1])]
+        batch = {"in_xy": sl(0), "gt_xy": sl(1), "in_dxdy": sl(2), "gt_dxdy": sl(3), "_traj_base": base,
+                 "size": torch.LongTensor([xy32.shape[0]]),
+                 "scene_img": tuple(sc for sc, k in zip(scenes, n) for _ in range(int(k))), "features": torch.empty(1),
+                 "occupancy": tuple(torch.empty(1) for _ in indices),
+                 "seq_start_end": [[a, b] for a, b in zip(bounds, bounds[1:])]}
+        valid = ~np.isnan(gt_np).any(axis=(1, 2))
+        batch["loss_mask"] = None if bool(valid.all()) else torch.from_numpy(valid)
+        batch["_local_mask"] = True
+        ped_item = np.repeat(np.arange(I, dtype=np.int32), n)
+        if self.aug:
+            recs = np.stack([self._aug_item(sc, a, fl, resolve=False) for sc, (a, fl) in zip(scenes, draws)])
+            batch["_crop_meta"] = ("aug", recs, ped_item, centers)
+        else:
+            rec = np.array([self.scene_rec[sc] for sc in scenes], np.int64)  # (off, h, w)
+            batch["_crop_meta"] = ("plain", rec[ped_item, 0], rec[ped_item, 1:].astype(np.int32), centers)
+        return [_PreBatched(batch)]
+
     def collate_host(self, data):
         """The host half of a batch (runs in loader workers too): the reference's collate of the trajectories, plus what the
         device half needs -- no HIP call."""
+        if len(data) == 1 and isinstance(data[0], _PreBatched):
+            return data[0].batch  # (__getitems__ built the batch already)
         metas = [d[5] for d in data]
         batch = seq_collate_scene([d[:5] + [torch.empty(0)] + d[6:] for d in data])
         # the validity scan of the training loop (abstract_train.py:127-132 of the reference: pedestrians without ground truth)
@@ -139,16 +240,33 @@ class DeviceCropDataset(Dataset):
                                    np.concatenate([m[2] for m in metas]))
         return batch
 
-    def finish(self, batch):
-        """The device half, in the process that owns the GPU: one launch cuts every crop of the batch."""
+    def finish(self, batch, join=True):
+        """The device half, in the process that owns the GPU: one launch cuts every crop of the batch.  join=False (a
+        prefetching thread): the consumer orders its stream behind the loader's itself (join_stream)."""
         from mggan.hip.lib import lib
 
         meta = batch.pop("_crop_meta")
         m = self.ds.margin_in
-        # through pinned memory: a copy from pageable memory makes the host wait for the stream -- i.e. for the training
-        # iterations queued ahead of it
-        up = lambda t: t.pin_memory().to(self.device, non_blocking=True)
-        to = lambda a: up(torch.from_numpy(np.ascontiguousarray(a)))
+        # through pinned memory (a copy from pageable memory makes the host wait for the stream -- i.e. for the training
+        # iterations queued ahead of it), and as few copies as possible: every int32 array of the batch rides in ONE upload
+        # (pack), the four trajectory tensors in another
+        def pack(arrays):
+            """[int32 / int64 arrays] -> device views of one uploaded buffer (8-byte aligned pieces)."""
+            flat = [np.ascontiguousarray(a).reshape(-1).view(np.int32) for a in arrays]
+            offs = np.cumsum([0] + [(f.size + 1) // 2 * 2 for f in flat])
+            stage = self._staging(int(offs[-1]), torch.int32)
+            buf = stage.numpy()
+            for f, o in zip(flat, offs):
+                buf[o:o + f.size] = f
+            dev = stage.to(self.device, non_blocking=True)
+            return [dev[int(o):int(o) + f.size] for f, o in zip(flat, offs)], dev
+
+        def up(t):
+            """A host tensor through this loader's pinned staging ring (filled with numpy: torch's own copy of a 100k-element
+            CPU tensor wakes its whole thread pool -- milliseconds on a 256-core host)."""
+            stage = self._staging(t.numel(), t.dtype)
+            np.copyto(stage.numpy().reshape(tuple(t.shape)), t.numpy())
+            return stage.view(t.shape).to(self.device, non_blocking=True)
         # on a stream of the loader's own: the crops of batch i + 1 are cut while the training iteration of batch i (queued on
         # the caller's stream just before) still runs -- at 1,280 pedestrians that iteration is a chain of latency-bound
         # launches that leaves most of the chip idle; the caller's stream waits for the loader's below
@@ -156,6 +274,12 @@ class DeviceCropDataset(Dataset):
             self._stream = torch.cuda.Stream(self.device)
         caller = torch.cuda.current_stream(self.device)
         with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
+            base = batch.pop("_traj_base", None)
+            if base is not None:  # (__getitems__ laid the four trajectory tensors out in one array: one copy)
+                both, t0 = up(base), 0
+                for k in ("in_xy", "gt_xy", "in_dxdy", "gt_dxdy"):
+                    batch[k] = both[t0:t0 + batch[k].shape[0]]
+                    t0 += batch[k].shape[0]
             for k, v in list(batch.items()):
                 if torch.is_tensor(v) and not v.is_cuda:
                     batch[k] = up(v)
@@ -164,23 +288,61 @@ class DeviceCropDataset(Dataset):
                 recs = np.stack([self._resolve_tables(r.copy()) for r in meta[1]])
                 if self._pool_dev is None or self._pool_dev.numel() != self._pool_len:
                     self._pool_dev = torch.from_numpy(np.concatenate(self._pool)).to(self.device)
-                items, ped_item, ctr = to(recs), to(meta[2]), to(meta[3])
-                n = ped_item.numel()
+                n = int(meta[2].shape[0])
                 out = torch.empty(n, 4, 2 * m + 1, 2 * m + 1, dtype=torch.float32, device=self.device)
-                lib.mggan_crop_patches_aug(self.atlas.data_ptr(), items.data_ptr(), self._pool_dev.data_ptr(), ped_item.data_ptr(),
-                                           ctr.data_ptr(), n, m, int(recs[:, 16].max()), out.data_ptr(), st)
-                self._keep = (items, ped_item, ctr, self._pool_dev)  # alive until the next batch (the launch is asynchronous)
+                # the pedestrians of an item share its canvas, and their windows overlap: when the 33 x 33 tiles of the items'
+                # whole resized images are fewer than the windows, the images are computed once (tile by tile, the same
+                # kernel) and the crops are cut from them like un-augmented ones
+                sw, sh = recs[:, 8].astype(np.int64), recs[:, 9].astype(np.int64)
+                tx, ty = (sw + 32) // 33, (sh + 32) // 33
+                if m == 16 and int((tx * ty).sum()) < n and TILE_MODE:
+                    small_off = np.concatenate([[0], np.cumsum(sw * sh * 3)[:-1]]).astype(np.int64)
+                    t_item = np.repeat(np.arange(len(recs), dtype=np.int32), tx * ty)
+                    t_ctr = np.concatenate([np.stack([16 + 33 * (np.arange(a * b) % a), 16 + 33 * (np.arange(a * b) // a)], 1)
+                                            for a, b in zip(tx, ty)]).astype(np.int32)
+                    small = torch.empty(int((sw * sh * 3).sum()) + 8, dtype=torch.uint8, device=self.device)
+                    pi = meta[2]
+                    (items, d_ti, d_tc, d_so, off, hw, ctr), dev = pack([
+                        recs, t_item, t_ctr, small_off, small_off[pi], np.stack([sh[pi], sw[pi]], 1).astype(np.int32), meta[3]])
+                    lib.mggan_aug_small_images(self.atlas.data_ptr(), items.data_ptr(), self._pool_dev.data_ptr(), d_ti.data_ptr(),
+                                               d_tc.data_ptr(), int(t_item.shape[0]), int(recs[:, 16].max()), d_so.data_ptr(),
+                                               small.data_ptr(), st)
+                    lib.mggan_crop_patches(small.data_ptr(), off.data_ptr(), hw.data_ptr(), ctr.data_ptr(), n, m, out.data_ptr(), st)
+                    self._keep = (dev, small, self._pool_dev)
+                else:
+                    (items, ped_item, ctr), dev = pack([recs, meta[2], meta[3]])
+                    lib.mggan_crop_patches_aug(self.atlas.data_ptr(), items.data_ptr(), self._pool_dev.data_ptr(),
+                                               ped_item.data_ptr(), ctr.data_ptr(), n, m, int(recs[:, 16].max()), out.data_ptr(), st)
+                    self._keep = (dev, self._pool_dev)  # alive until the next batch (the launch is asynchronous)
             else:
-                off, hw, ctr = to(meta[1]), to(meta[2]), to(meta[3])
-                n = off.numel()
+                (off, hw, ctr), dev = pack([meta[1], meta[2], meta[3]])
+                n = int(meta[1].shape[0])
                 out = torch.empty(n, 4, 2 * m + 1, 2 * m + 1, dtype=torch.float32, device=self.device)
                 lib.mggan_crop_patches(self.atlas.data_ptr(), off.data_ptr(), hw.data_ptr(), ctr.data_ptr(), n, m, out.data_ptr(), st)
-                self._keep = (off, hw, ctr)
-        caller.wait_stream(self._stream)
-        for v in list(batch.values()) + [out]:
+                self._keep = (dev,)
+        batch["features"] = out
+        for ev in self._pending_events:  # (the staging slots used by this batch are free once the loader stream gets here)
+            ev.record(self._stream)
+        self._pending_events = []
+        if join:
+            self.join_stream(batch, caller)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+            batch["_ready"] = ev
+        return batch
+
+    def join_stream(self, batch, caller=None):
+        """The consuming stream waits for the loader stream's work on this batch."""
+        caller = caller or torch.cuda.current_stream(self.device)
+        ev = batch.pop("_ready", None)
+        if ev is not None:
+            caller.wait_event(ev)
+        else:
+            caller.wait_stream(self._stream)
+        for v in batch.values():
             if torch.is_tensor(v) and v.is_cuda:
                 v.record_stream(caller)
-        batch["features"] = out
         return batch
 
     def collate(self, data):
@@ -209,5 +371,50 @@ class DeviceCropLoader:
         return len(self.loader)
 
     def __iter__(self):
-        for batch in self.loader:
-            yield self.dds.finish(batch)
+        if not PREFETCH_THREAD or self.loader.num_workers:
+            for batch in self.loader:
+                yield self.dds.finish(batch)
+            return
+        # one batch ahead on a thread of the loader's own: its ~1.6 ms of Python / numpy per 32-scene batch run while the
+        # training thread launches the previous iteration (which needs the GIL for a fraction of that); the draws stay in
+        # order (one producer), the consumer orders its stream behind the loader's
+        import queue
+        import threading
+
+        q, stop, end = queue.Queue(maxsize=2), threading.Event(), object()
+
+        def produce():
+            try:
+                with torch.cuda.device(self.dds.device):
+                    for batch in self.loader:
+                        item = self.dds.finish(batch, join=False)
+                        while not stop.is_set():
+                            try:
+                                q.put(item, timeout=0.1)
+                                break
+                            except queue.Full:
+                                pass
+                        if stop.is_set():
+                            return
+                item = end
+            except BaseException as exc:  # noqa: BLE001  (re-raised in the consumer)
+                item = exc
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return
+                except queue.Full:
+                    pass
+
+        th = threading.Thread(target=produce, daemon=True, name="mggan-loader")
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is end:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield self.dds.join_stream(item)
+        finally:
+            stop.set()

@@ -100,3 +100,46 @@ def test_device_kernel_matches_pillow_crops(w, h, f):
     centre = np.zeros((33, 33), np.float32)
     centre[16, 16] = 1
     assert all(np.array_equal(got[p, 3], centre) for p in range(len(ped_item)))
+
+
+@pytest.mark.gpu
+def test_whole_image_tiles_equal_per_crop_windows(monkeypatch):
+    """With many pedestrians per item the loader computes each item's whole resized image once (33 x 33 tiles,
+    mggan_aug_small_images) and cuts plain windows from it; with few it computes the windows directly.  Same bits both ways, and
+    Pillow's."""
+    import torch
+
+    from mggan.data_utils import device_crops as DC
+
+    img = _image(420, 300, 9)
+    rng = np.random.default_rng(3)
+    dev = torch.device("cuda", 0)
+
+    class _DS:
+        data_augmentation, phase, images = 1, "train", {"s": {"scaled_image": Image.fromarray(img)}}
+        img_scaling, scaling_small, margin_in = 0.1, 1.0, 16
+
+    dds = DC.DeviceCropDataset(_DS, dev)
+    recs, ped_item, ctr, want = [], [], [], []
+    for i in range(2):
+        alpha, code = float(rng.random() * 2 * np.pi), int(rng.integers(0, 3))
+        recs.append(dds._aug_item("s", alpha, code, resolve=False))
+        pil = Image.fromarray(img)
+        pil = pil.transpose(Image.FLIP_LEFT_RIGHT) if code == 1 else pil.transpose(Image.FLIP_TOP_BOTTOM) if code == 2 else pil
+        pil = pil.rotate(alpha / np.pi * 180, expand=True)
+        small = pil.resize(AG.small_size(pil.width, pil.height, 0.1), Image.LANCZOS)
+        for _ in range(30):
+            xc, yc = int(rng.integers(-10, small.width + 10)), int(rng.integers(-10, small.height + 10))
+            ped_item.append(i)
+            ctr.append((xc, yc))
+            want.append(np.asarray(small.crop((xc - 16, yc - 16, xc + 17, yc + 17))))
+    meta = ("aug", np.stack(recs), np.array(ped_item, np.int32), np.array(ctr, np.int32))
+    outs = {}
+    for tiles in (True, False):
+        monkeypatch.setattr(DC, "TILE_MODE", tiles)
+        b = dds.finish({"_crop_meta": meta, "seq_start_end": [[0, 30], [30, 60]]})
+        torch.cuda.synchronize()
+        outs[tiles] = b["features"].cpu().numpy()
+    assert np.array_equal(outs[True], outs[False])
+    ref = np.stack(want).astype(np.float64)
+    np.testing.assert_array_equal(outs[True][:, :3], (-1 + ref * 2.0 / 256).astype(np.float32).transpose(0, 3, 1, 2))
