@@ -13,6 +13,7 @@
 // (mggan_comm_host_error: readable without a device sync) instead of hanging the GPU, and the collective then leaves NaN
 // (INT_MIN) behind -- never a sum over stale slots.
 // No reference counterpart (the reference is single-process); replaces torch.distributed.all_reduce on this path.
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 #include "../../include/mggan_hip.h"
@@ -21,6 +22,13 @@
 
 static long long g_timeout_ticks = (long long)(COMM_TIMEOUT_DEFAULT_S * COMM_TICKS_PER_S);
 static unsigned* g_host_error = nullptr;
+int comm_light() {
+  static const int v = [] {
+    const char* e = getenv("MGGAN_COMM_FENCES");
+    return (e && e[0] == 'l') ? 1 : 0;
+  }();
+  return v;
+}
 long long comm_timeout_ticks() { return g_timeout_ticks; }
 unsigned* comm_host_error() { return g_host_error; }
 
@@ -130,7 +138,7 @@ static int comm_allreduce_launch(void* const* arenas, int rank, int world, long 
   a.data = data; a.n = n; a.max_elems = max_elems; a.rank = rank; a.world = world;
   a.max_blocks = cdiv(max_elems * 2, COMM_CHUNK); a.dtype = dtype;
   a.data2 = data2; a.n2 = n2;
-  a.timeout_ticks = g_timeout_ticks; a.host_error = g_host_error;
+  a.timeout_ticks = g_timeout_ticks; a.host_error = g_host_error; a.light = comm_light();
   const int grid = cdiv(n, COMM_CHUNK) + cdiv(n2, COMM_CHUNK);
   MG_CHECK_ARG(grid <= a.max_blocks, "comm_allreduce: %d chunks exceed the arena's flags (%d)", grid, a.max_blocks);
   if (dtype == 0) MG_LAUNCH(comm_allreduce_kernel<float>, dim3(grid), dim3(256), 0, stream, a);

@@ -27,10 +27,27 @@ struct CommArgs {
   int rank, world, max_blocks, dtype;  // dtype 0: f32, 1: f64, 2: i32
   long long timeout_ticks;             // bound of every wait
   unsigned* host_error;                // host-mapped word, set (with the arena's) when a wait timed out; may be null
+  int light;                           // MGGAN_COMM_FENCES=light: no system-scope fence / release / acquire around the flags (below)
 };
+
+// The arenas are UNCACHED (fine-grained) memory: a store to them is written through and a load bypasses the caches, and the
+// workgroup barrier between the data stores and the flag store already waits for every wave's stores to be acknowledged
+// (s_waitcnt vmcnt(0)).  The formal protocol (default, `light == 0`) still brackets the flags with a system-scope fence, a
+// release store and acquire loads -- each a write-back / invalidate of the caches this kernel's OTHER traffic dirtied, 1-3 us
+// apiece on the chains of the small shard.  `light` drops them: flags and data are ordered by the barrier and by the
+// point-to-point link's write ordering alone.  Measured on one rank only; the default stays strict until
+// the protocol has met a second device.
+__device__ __forceinline__ void comm_publish_fence(const CommArgs& a) {
+  if (!a.light) __threadfence_system();
+}
+__device__ __forceinline__ void comm_store_flag(const CommArgs& a, unsigned* pf, unsigned seq) {
+  if (a.light) __hip_atomic_store(pf, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else __hip_atomic_store(pf, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 long long comm_timeout_ticks();  // csrc/comm.hip
 unsigned* comm_host_error();
+int comm_light();
 
 // What a timed-out collective leaves behind: never a sum over stale slots.
 template <typename T> __device__ __forceinline__ T comm_poison();
@@ -43,7 +60,8 @@ template <> __device__ __forceinline__ int comm_poison<int>() { return (int)0x80
 __device__ __forceinline__ bool comm_wait_flag(unsigned* wf, unsigned seq, CommHeader* hdr, const CommArgs& a) {
   const long long t0 = wall_clock64();
   const bool dead = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-  while (__hip_atomic_load(wf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+  while ((a.light ? __hip_atomic_load(wf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                  : __hip_atomic_load(wf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) != seq) {
     __builtin_amdgcn_s_sleep(2);
     if (dead || wall_clock64() - t0 > a.timeout_ticks) {
       __hip_atomic_store(&hdr->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -76,11 +94,11 @@ __device__ __forceinline__ void comm_allreduce_small(const CommArgs& a, double* 
   }
   __shared__ int comm_lost;
   if (threadIdx.x == 0) comm_lost = 0;
-  __threadfence_system();
+  comm_publish_fence(a);
   __syncthreads();
   if ((int)threadIdx.x < W) {
     unsigned* pf = (unsigned*)((char*)a.arena[threadIdx.x] + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + r) * a.max_blocks;
-    __hip_atomic_store(pf, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    comm_store_flag(a, pf, seq);
     unsigned* wf = (unsigned*)(mine + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + threadIdx.x) * a.max_blocks;
     if (!comm_wait_flag(wf, seq, hdr, a)) comm_lost = 1;
   }
@@ -112,12 +130,12 @@ __device__ __forceinline__ void comm_chunk(const CommArgs& a, T* data, long e0, 
     for (long i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
   }
   if (threadIdx.x == 0) *lost_s = 0;
-  __threadfence_system();
+  comm_publish_fence(a);
   __syncthreads();
   // (b) stamp, (c) wait
   if ((int)threadIdx.x < W) {
     unsigned* pf = (unsigned*)((char*)a.arena[threadIdx.x] + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + r) * a.max_blocks + k;
-    __hip_atomic_store(pf, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    comm_store_flag(a, pf, seq);
     unsigned* wf = (unsigned*)(mine + comm_flags_off()) + ((size_t)buf * COMM_MAX_RANKS + threadIdx.x) * a.max_blocks + k;
     if (!comm_wait_flag(wf, seq, hdr, a)) *lost_s = 1;
   }
@@ -139,6 +157,6 @@ static inline CommArgs comm_make_args(void* const* arenas, int rank, int world, 
   for (int j = 0; j < COMM_MAX_RANKS; ++j) a.arena[j] = j < world ? arenas[j] : nullptr;
   a.data = nullptr; a.n = 0; a.data2 = nullptr; a.n2 = 0; a.max_elems = max_elems; a.rank = rank; a.world = world;
   a.max_blocks = cdiv(max_elems * 2, COMM_CHUNK); a.dtype = 1;
-  a.timeout_ticks = comm_timeout_ticks(); a.host_error = comm_host_error();
+  a.timeout_ticks = comm_timeout_ticks(); a.host_error = comm_host_error(); a.light = comm_light();
   return a;
 }

@@ -878,7 +878,12 @@ def weights_fingerprint(root):
     """What the host can see of writes to the weights of `root`: the kernel-side version counter (optimizer steps, graph
     replays: bump_weight_version) and torch's own version counters (load_state_dict, a parameter broadcast, any in-place
     torch op)."""
-    return (getattr(root, "_kernel_version", 0),) + tuple(p._version for p in root.parameters())
+    ps = root.__dict__.get("_fp_params")
+    if ps is None or root.__dict__.get("_fp_flat") is not getattr(root, "_flat", None):
+        # (the parameter list is walked once per flat buffer: a replay takes this fingerprint twice per root)
+        ps = root.__dict__["_fp_params"] = tuple(root.parameters())
+        root.__dict__["_fp_flat"] = getattr(root, "_flat", None)
+    return (getattr(root, "_kernel_version", 0),) + tuple(p._version for p in ps)
 
 
 def refold_root(root):
@@ -2482,6 +2487,17 @@ class DRowsLeanFn(Function):
         wa = (d0[0].weight, d0[0].bias, d0[2].weight, d0[2].bias)
         wb = (r[0].weight, r[0].bias, r[2].weight, r[2].bias)
         lib.mggan_d_rows_fill(b, 1, 1, c_in, c_in, c_pe - c_in, c_sc, 0, _p(in_enc), ld_in, 0, 0, _p(X), W, st)
+        # ---- block 0 (rows 0 .. b-1), first half: pred_encoder and the social attention need the history encoding and the
+        # predictions only -- they go out BEFORE this stream waits for the scene CNN's branch (round 6: the generator step no
+        # longer joins that branch ahead of the discriminator pass; 64 x 20: the loss launch moves ~35 us earlier) ----
+        x0 = _empty(b, 2 * T, like=in_enc) if save else None
+        h_pe0 = _empty(b, 64, like=in_enc) if save else None
+        lib.mggan_pred_encoder_fwd(_p(pred), 0, T, R, b, b, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(X), W, c_pe,
+                                   _p(h_pe0), _p(x0), st)
+        outs_pe = [h_pe0, None]
+        xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
+        sw = (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, Wat.weight, Wat.bias)
+        soc_saved = _social_fwd(xy_last, dxdy_last, _p(X) + 4 * c_in, W, b, c_sc - c_in, tb, *sw, _p(X), W, save, 0, X)
         join_branch(scene)  # the scene CNN's branch has to be there now
         lib.mggan_d_rows_fill(b, 1, 1, 0, 0, 0, c_sc, W - c_sc, 0, 0, _p(scene), ld_sc, _p(X), W, st)
         P = _empty(b, W, like=X)
@@ -2493,15 +2509,7 @@ class DRowsLeanFn(Function):
             lib.mggan_d_rows_lean_fwd(_p(pred), T, b, R, b, g, act, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(P), c_pe,
                                       _p(wa[0]), _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[2]), _p(wb[3]), _p(mask), _p(ya), _p(yb),
                                       _s())
-        # ---- block 0 (rows 0 .. b-1) ----
-        x0 = _empty(b, 2 * T, like=in_enc) if save else None
-        h_pe0 = _empty(b, 64, like=in_enc) if save else None
-        lib.mggan_pred_encoder_fwd(_p(pred), 0, T, R, b, b, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(X), W, c_pe,
-                                   _p(h_pe0), _p(x0), st)
-        outs_pe = [h_pe0, None]
-        xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
-        sw = (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, Wat.weight, Wat.bias)
-        soc_saved = _social_fwd(xy_last, dxdy_last, _p(X) + 4 * c_in, W, b, c_sc - c_in, tb, *sw, _p(X), W, save, 0, X)
+        # ---- block 0, second half: both heads (the scene columns are in place) ----
         ha = _empty(b, 96, like=X) if save else None
         hb = _empty(b, 96, like=X) if save else None
         lib.mggan_dheads_fwd(_p(X), W, b, g, act, _p(wa[0]), _p(wa[1]), _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[1]),

@@ -98,7 +98,8 @@ class _Lib:
                     self._c.mggan_timestamp(slot, args[-1])
                     rc = _fn(*args)
                     self._c.mggan_timestamp(slot + 8, args[-1])
-                    mk["calls"].append((_name, args, self.read_launches()))
+                    # (the two marks go through the logged launch macro too: they are not launches of the entry)
+                    mk["calls"].append((_name, args, [k for k in self.read_launches() if not k[0].startswith("timestamp_kernel")]))
                     if rc != 0:
                         raise HipError("{} failed ({}): {}".format(_name, rc, last_error().decode()))
                     return

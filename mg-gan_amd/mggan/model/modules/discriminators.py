@@ -88,6 +88,12 @@ class MultiDiscriminatorTrajectory(FlatModule):
                 h = self.in_encoder(in_dxdy)
                 out = HF.mlp(h, [(fc[0], HF.ACT_LEAKY, 0.2), (fc[2], HF.ACT_NONE, 0.0)])
                 HF.mark("Dctx.lstm.end")
+                if HF._on_branch():
+                    # (a consumer that needs the history encoding only waits for THIS point of the branch stream, not for
+                    #  the scene CNN queued behind it on the same stream: generator_step)
+                    ev = torch.cuda.Event()
+                    ev.record(HF._cur())
+                    out._mggan_ready = ev
             return out
 
         if defer_cnn is not None:

@@ -44,6 +44,7 @@ _GRAM_LATE = os.environ.get("MGGAN_GRAM_LATE", "0") == "1"
 _G_EARLY = os.environ.get("MGGAN_G_EARLY", "1") == "1"
 _G_EARLY_MIN_B = int(os.environ.get("MGGAN_G_EARLY_MIN_B", "2048"))
 _EARLY_BRANCH = 5
+_G_SCENE_JOIN_EARLY = os.environ.get("MGGAN_G_SCENE_JOIN", "late") == "early"
 # Cross-iteration pipelining (MGGAN_PIPELINE=1, capture_iteration(pipeline=True)): the NEXT iteration's discriminator context --
 # history LSTM + scene CNN of D on the next batch, with the weights D holds since this iteration's discriminator update -- is
 # issued on a held branch stream beside the PM-network step, whose tail (the generator's scene-CNN adjoint) runs alone on the
@@ -521,8 +522,16 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                     HF.mark("G.l2.end")
 
             if ctx_d is not None:
-                HF.join_branch(ctx_d[1], which=0)
-                HF.join_branch(ctx_d[0], which=lstm_branch)
+                # (only the history encoding is needed at once; the discriminator's row pass waits for the scene CNN's
+                #  branch where it first reads the scene features -- MGGAN_G_SCENE_JOIN=early: before the pass, as until round 5)
+                ev = getattr(ctx_d[0], "_mggan_ready", None)
+                if _G_SCENE_JOIN_EARLY or ev is None:
+                    HF.join_branch(ctx_d[1], which=0)
+                    HF.join_branch(ctx_d[0], which=lstm_branch)
+                else:
+                    HF._cur().wait_event(ev)
+                    ctx_d[0].record_stream(HF._cur())
+                    ctx_d[1].record_stream(HF._cur())
             HF.mark("G.dpass.begin")
             disc_out = self.D(in_xy, in_dxdy, gen_out.abs, gen_out.rel, sub_batches, img=img, mask=loss_mask,
                               context=ctx_d)
