@@ -97,3 +97,35 @@ def test_device_crops_match_host_crops_with_training_augmentation(loader_golden,
     g = loader_golden["{}/train/batch/features".format(name)]
     assert len(g) == dev["features"].shape[0]
     np.testing.assert_array_equal(dev["features"].cpu().numpy(), g)  # == what the reference's loader produced
+
+
+@pytest.mark.parametrize("name,small", [("eth", 0.5), ("gofp", 0.5), ("stanford", 0.7)])
+@pytest.mark.parametrize("phase,aug", [("test", 0), ("train", 1)])
+def test_batched_host_half_equals_per_item_path(loader_golden, name, small, phase, aug):
+    """DeviceCropDataset.__getitems__ (the whole batch in one numpy pass: what the DataLoader calls) against its per-item
+    __getitem__ + collate: the same trajectory tensors, crop centres and augmentation records to the bit, with the
+    augmentation draws consumed in the same order -- and the trajectories are the reference loader's (CPU only: the device
+    half is not touched)."""
+    from mggan.data_utils.device_crops import DeviceCropDataset
+    from mggan.data_utils.trajectories_scene import TrajectoryDatasetEval
+
+    ds = TrajectoryDatasetEval(dataset_name=name, phase=phase, margin_in=16, margin_out=16, load_occupancy=False,
+                               scaling_small=small, data_augmentation=aug)
+    dds = DeviceCropDataset(ds, "cpu")
+    idx = list(range(min(3, len(ds))))
+    np.random.seed(123)
+    a = dds.collate_host([dds[i] for i in idx])
+    state_a = np.random.get_state()[2]
+    np.random.seed(123)
+    b = dds.collate_host(dds.__getitems__(idx))
+    assert np.random.get_state()[2] == state_a  # as many draws from numpy's global generator
+    g = loader_golden
+    p = "{}/{}/".format(name, phase)
+    for k in ("in_xy", "gt_xy", "in_dxdy", "gt_dxdy"):
+        np.testing.assert_array_equal(a[k].numpy(), b[k].numpy(), err_msg=k)  # (NaN == NaN here: pedestrians without ground truth)
+        np.testing.assert_allclose(b[k].numpy(), g[p + "batch/" + k], rtol=1e-6, atol=1e-6, equal_nan=True, err_msg=k)
+    assert a["seq_start_end"] == b["seq_start_end"] == g[p + "batch/seq_start_end"].tolist()
+    assert a["scene_img"] == b["scene_img"] and (a["loss_mask"] is None) == (b["loss_mask"] is None)
+    assert a["_crop_meta"][0] == b["_crop_meta"][0]
+    for x, y in zip(a["_crop_meta"][1:], b["_crop_meta"][1:]):
+        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
