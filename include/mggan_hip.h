@@ -462,8 +462,10 @@ int mggan_pm_target(int b, int T, int E, int g, int mode, const float* gen_abs, 
                     mggan_stream_t stream);
 /* PM-network target 'mgan' as the reference computes it (train.py:606-614; the target softmax runs over a singleton
  * axis): loss_r = scale * (-target_weight * sum_j log p_j + reg * sum_j p_j log p_j), p = softmax(logits (b,g)) */
-int mggan_pm_mgan_loss(int b, int g, const float* logits, float target_weight, float reg, float scale, float* loss_rows,
-                       float* dlogits, float* probs, mggan_stream_t stream);
+/* reg_dev != NULL: `reg` (the reference's 0.9 ** epoch) is read from that device word instead -- a captured iteration then
+ * follows the epochs without being captured again */
+int mggan_pm_mgan_loss(int b, int g, const float* logits, float target_weight, float reg, const float* reg_dev, float scale,
+                       float* loss_rows, float* dlogits, float* probs, mggan_stream_t stream);
 /* Categorical(logits=...).sample((K,)).T on the device (standard.py:217-225): inverse CDF from uniforms u (b,K) */
 /* ---- device RNG: every draw of one training iteration in ONE launch (csrc/rng.hip, Philox4x32-10) ---------
  * reference draws being replaced on the `--rng device` path: utils.py:18-25 (label uniforms),

@@ -373,10 +373,11 @@ __global__ void pm_target_kernel(int b, int T, int E, int g, int mode, const flo
 // every target is 1 and the product broadcasts over the batch: loss = -(1/g) sum_{r,j} log p_rj - reg * mean_r H(p_r),
 // reg = 0.9^epoch, p = softmax(logits).  Per row: loss_r = -tw sum_j log p_j + reg sum_j p_j log p_j with tw = b/g;
 // dlogits_k = scale * [ tw (g p_k - 1) + reg p_k (log p_k - sum_j p_j log p_j) ].
-__global__ void pm_mgan_kernel(int b, int g, const float* __restrict__ logits, float tw, float reg, float scale,
-                               float* loss_rows, float* dlogits, float* probs) {
+__global__ void pm_mgan_kernel(int b, int g, const float* __restrict__ logits, float tw, float reg_arg,
+                               const float* __restrict__ reg_dev, float scale, float* loss_rows, float* dlogits, float* probs) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= b) return;
+  const float reg = reg_dev ? *reg_dev : reg_arg;  // device-resident: a captured graph follows the epoch (0.9 ** epoch)
   const float* z = logits + (size_t)r * g;
   float mx = -INFINITY;
   for (int j = 0; j < g; ++j) mx = fmaxf(mx, z[j]);
@@ -1385,11 +1386,11 @@ int mggan_pm_ml_loss_mean(int b, int T, int E, int g, const float* gen_abs, cons
   return MGGAN_OK;
 }
 
-int mggan_pm_mgan_loss(int b, int g, const float* logits, float target_weight, float reg, float scale, float* loss_rows,
-                       float* dlogits, float* probs, hipStream_t stream) {
+int mggan_pm_mgan_loss(int b, int g, const float* logits, float target_weight, float reg, const float* reg_dev, float scale,
+                       float* loss_rows, float* dlogits, float* probs, hipStream_t stream) {
   if (b == 0) return MGGAN_OK;
   MG_CHECK_ARG(logits && loss_rows && dlogits && g > 0, "pm_mgan_loss: bad arguments");
-  MG_LAUNCH(pm_mgan_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, g, logits, target_weight, reg, scale,
+  MG_LAUNCH(pm_mgan_kernel, dim3(cdiv(b, 128)), dim3(128), 0, stream, b, g, logits, target_weight, reg, reg_dev, scale,
                      loss_rows, dlogits, probs);
   MG_LAUNCH_CHECK("pm_mgan_loss");
   return MGGAN_OK;

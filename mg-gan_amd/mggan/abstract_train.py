@@ -200,9 +200,8 @@ class MultiGeneratorGAN(abc.ABC):
         if not getattr(self.rng, "on_device", False):
             raise RuntimeError("graph capture needs the device RNG (--rng device): the host RNG path reads the "
                                "PM-network logits back to the CPU")
-        if int(self.config.num_gen_steps) != 1:
-            raise RuntimeError("graph capture replays ONE fixed iteration: --num_gen_steps must be 1 (the discriminator "
-                               "step would otherwise run in some iterations only)")
+        # (--num_gen_steps k: the discriminator step runs in some iterations only; the captured iteration is the one of
+        #  self.total_iterations as it stands -- train()'s graph cache keeps one graph per (shape, with / without the step))
         from mggan.hip import functions as HF
 
         batch = dict(batch)
@@ -355,14 +354,15 @@ class MultiGeneratorGAN(abc.ABC):
 
     def graph_mode(self):
         """Does train() replay captured iterations?  --graph on | off | auto (auto: whenever the configuration allows it).
-        A captured iteration cannot contain a host synchronisation (so: the device RNG) nor host decisions that change
-        from one iteration to the next (--num_gen_steps gating, the epoch-dependent target of --weighting_target mgan);
-        the learning rate is read from device memory, so the cosine schedule needs no re-capture."""
+        A captured iteration cannot contain a host synchronisation (so: the device RNG).  What changes from one iteration to
+        the next lives in device memory (the learning rate of the cosine schedule, the 0.9 ** epoch of --weighting_target
+        mgan) or in the graph cache's key (--num_gen_steps k / --keep_gen_steps: iterations with and without the
+        discriminator step are two graphs per shape)."""
         cfg = self.config
         mode = getattr(cfg, "graph", "auto")
-        ok = (getattr(self.rng, "on_device", False) and int(cfg.num_gen_steps) == 1 and cfg.weighting_target != "mgan")
+        ok = bool(getattr(self.rng, "on_device", False))
         if mode == "on" and not ok:
-            raise ValueError("--graph on needs --rng device, --num_gen_steps 1 and a --weighting_target other than 'mgan'")
+            raise ValueError("--graph on needs --rng device")
         if self.dist.enabled and not self.dist.equal_shards:
             # a sharded iteration is only capturable with equal shards (unequal ones read the global row count back to
             # the host): without them train() launches eagerly instead of trying -- and failing -- a capture per shape
@@ -396,6 +396,8 @@ class MultiGeneratorGAN(abc.ABC):
         self.total_iterations = 0  # a local of train() in the reference (abstract_train.py:104): every call starts at 0
         for epoch in range(cfg.epochs):
             self.epoch += 1
+            if hasattr(self, "_pm_reg"):
+                self._pm_reg()  # (the device word of 0.9 ** epoch: before the epoch's first replay)
             self.D.train()
             self.G.train()
             metrics = defaultdict(list)
@@ -671,6 +673,10 @@ class IterationGraphs:
         if bucket is None and not self.capture:
             return False
         key = bucket[0] if bucket is not None else self.key_of(batch)
+        cfg = tr.config
+        if int(cfg.num_gen_steps) != 1:  # (abstract_train.py:136-150 of the reference: does this iteration hold a D step?)
+            run_d = tr.total_iterations % max(int(cfg.num_gen_steps), 1) == 0 or tr.epoch >= cfg.keep_gen_steps
+            key = (key, bool(run_d))
         ent = self.entries.get(key)
         if ent is None:
             n_pad = sum(1 for e in self.entries.values() if e.tables is not None)

@@ -2895,11 +2895,14 @@ class PmMganFn(Function):
 
     @staticmethod
     def forward(ctx, logits, reg, out, probs_out, norm=None):
+        """reg: a Python number, or a 0-dim device tensor (read by the kernel at run time: graph replays follow the epoch)"""
         logits = logits.contiguous()
         b, g = logits.shape
         n = float(norm or b)
         loss_rows, dl, probs = _empty(b, like=logits), _empty(b, g, like=logits), _empty(b, g, like=logits)
-        lib.mggan_pm_mgan_loss(b, g, _p(logits), n / g, float(reg), 1.0 / n, _p(loss_rows), _p(dl), _p(probs), _s())
+        on_dev = torch.is_tensor(reg)
+        lib.mggan_pm_mgan_loss(b, g, _p(logits), n / g, 0.0 if on_dev else float(reg), _p(reg) if on_dev else 0, 1.0 / n,
+                               _p(loss_rows), _p(dl), _p(probs), _s())
         lib.mggan_sum(_p(loss_rows), b, 1.0, _p(out), 0, _s())
         if probs_out is not None:
             lib.mggan_colmean(_p(probs), b, g, float(b) / n, _p(probs_out), _s())

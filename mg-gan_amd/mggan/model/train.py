@@ -117,6 +117,19 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                 and int(cfg.num_unrolling_steps) == 0 and not self.dist.enabled
                 and getattr(self.rng, "on_device", False))
 
+    def _pm_reg(self):
+        """0.9 ** epoch (train.py:612 of the reference: the entropy term of the 'mgan' PM-network target) as a device word that
+        the loss kernel reads at run time; refreshed here whenever the epoch has moved on -- never inside a capture (train()
+        refreshes it at the start of every epoch, before the first replay)."""
+        t = self.__dict__.get("_pm_reg_dev")
+        if t is None:
+            t = self._pm_reg_dev = torch.zeros((), dtype=torch.float32, device=self.device)
+            self._pm_reg_epoch = None
+        if self._pm_reg_epoch != self.epoch and not torch.cuda.is_current_stream_capturing():
+            t.fill_(0.9 ** self.epoch)
+            self._pm_reg_epoch = self.epoch
+        return t
+
     def _set_l2_weight(self, value):
         """self.l2_weight decays per epoch (abstract_train.py:197); the backward pass reads it from device memory."""
         if self._w["l2"] is not self._one:
@@ -594,7 +607,7 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
             # running statistics of its scene encoder
             with torch.no_grad():
                 self.D.scene_encoder(img[mask] if HF.is_masked(mask) else img)
-            loss = HF.PmMganFn.apply(net_chooser_weights, 0.9 ** self.epoch, m[M_PM:M_PM + 1], m[M_PROBS:M_PROBS + g], n_pm)
+            loss = HF.PmMganFn.apply(net_chooser_weights, self._pm_reg(), m[M_PM:M_PM + 1], m[M_PROBS:M_PROBS + g], n_pm)
         else:  # 'l2' / 'endpoint' (train.py:616-624,641-647): cross entropy against the closest generator
             T_, E_, _, b_, _ = gen_out.abs.shape
             target = torch.empty(b_, dtype=torch.int32, device=self.device)

@@ -90,6 +90,28 @@ def test_graph_follows_the_learning_rate_schedule():
     assert tr.optimizerG.lr < tr.optimizerG.base_lr and float(tr.optimizerG._lr_dev.cpu()) == tr.optimizerG.lr
 
 
+def test_mgan_pm_target_and_gated_discriminator_steps_replay_like_eager():
+    """Two configurations that used to launch eagerly: `--weighting_target mgan` (its 0.9 ** epoch is a device word now: a
+    captured iteration follows the epochs) and `--num_gen_steps 2` (the discriminator step runs in every second iteration: the
+    graph cache keeps one graph per shape with and one without it).  `--graph on` replays both, bit-identical to `--graph off`
+    over three epochs."""
+    # (--keep_gen_steps: the gating of abstract_train.py:136-150 only acts while epoch < keep_gen_steps, 0 by default)
+    for extra in (["--weighting_target", "mgan"], ["--num_gen_steps", "2", "--keep_gen_steps", "100"]):
+        ex = ["--graph_pad", "off"] + extra
+        tr_g, m_g = _train("on", 3, extra=ex)
+        tr_e, m_e = _train("off", 3, extra=ex)
+        ig = tr_g.iteration_graphs
+        n_graphs = 2 if "--num_gen_steps" in extra else 1
+        assert ig is not None and len(ig.entries) == n_graphs and ig.eager == n_graphs and ig.replays == 12 - n_graphs, (
+            extra, len(ig.entries), ig.eager, ig.replays)
+        for k, v in m_e.items():
+            np.testing.assert_allclose(m_g[k], v, rtol=1e-5, atol=1e-7, err_msg=k)
+        for a, b in ((tr_g.G, tr_e.G), (tr_g.D, tr_e.D)):
+            assert torch.equal(a._flat, b._flat), extra
+        if "--weighting_target" in extra:
+            assert abs(float(tr_g._pm_reg_dev.cpu()) - 0.9 ** 3) < 1e-7
+
+
 def test_graph_on_needs_the_device_rng():
     from mggan.logging import Experiment
     from mggan.model.config import get_parser
