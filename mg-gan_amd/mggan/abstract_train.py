@@ -130,7 +130,8 @@ class MultiGeneratorGAN(abc.ABC):
         from mggan.hip import functions as HF
 
         if not (self.dist.enabled and not self.dist.stream_safe):  # (segmented sharded replay: the trainer set them off)
-            HF.auto_branches(b)
+            HF.auto_branches(b, for_graph=torch.cuda.is_current_stream_capturing() or getattr(self, "_warming_up", False)
+                             or self.dist.enabled)
         cfg = self.config
         run_d = self.total_iterations % max(int(cfg.num_gen_steps), 1) == 0 or self.epoch >= cfg.keep_gen_steps
         # sharded training with global-batch BatchNorm: the Gram matrix of the image patches comes FIRST and is all-reduced
@@ -284,8 +285,12 @@ class MultiGeneratorGAN(abc.ABC):
         side = HF.role_stream("capture")  # (one per process: torch's stream pool wraps around after 32 objects)
         side.wait_stream(HF._cur())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.train_iteration(batch, scratch)
+            self._warming_up = True  # (the warm-up creates what the capture will use: streams, per-role tables -- same shape)
+            try:
+                for _ in range(warmup):
+                    self.train_iteration(batch, scratch)
+            finally:
+                self._warming_up = False
         HF._cur().wait_stream(side)
         self.flush_metrics()
         if getattr(self, "_pipe", None) is not None and self._pipe["ctx"] is not None:

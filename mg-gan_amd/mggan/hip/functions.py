@@ -308,10 +308,21 @@ _BR = {"on": os.environ.get("MGGAN_BRANCH", "auto") != "0", "streams": {}, "dirt
        "auto": os.environ.get("MGGAN_BRANCH", "auto") == "auto", "max_b": int(os.environ.get("MGGAN_BRANCH_MAX_B", "8192"))}
 
 
-def auto_branches(b):
-    """Called by the trainer at the start of an iteration over b pedestrians (every branch is joined there)."""
+# Eager iterations are bound by the HOST (3.5-5 ms of Python per iteration against 0.8-4.5 ms of kernels), and every fork / join
+# of a branch stream is host work (an event record and a wait, ~13 us each, ~70 per iteration): eager launches on ONE stream
+# are faster at every size (round 6, ms per iteration with branches -> without: 32 ragged scenes 4.50 -> 3.54, --rng host 7.09
+# -> 6.21; 64 x 20: 4.76 -> 3.85; 256 x 32: 5.60 -> 4.99).  The branch streams pay inside a captured graph, where they are edges
+# and cost nothing to issue: auto = on for captures (and the warm-up iterations in front of one), off for eager iterations.
+# Same kernels, fixed-order reductions: the results do not depend on it (tests/test_hip_graph.py).  MGGAN_BRANCH_EAGER=1: as
+# until round 5.
+_BRANCH_EAGER = os.environ.get("MGGAN_BRANCH_EAGER", "0") == "1"
+
+
+def auto_branches(b, for_graph=True):
+    """Called by the trainer at the start of an iteration over b pedestrians (every branch is joined there); for_graph:
+    the iteration is being captured, warms a capture up, or is a sharded one (whose channels are per stream role)."""
     if _BR["auto"]:
-        want = b <= _BR["max_b"]
+        want = b <= _BR["max_b"] and (for_graph or _BRANCH_EAGER)
         if want != _BR["on"]:
             enable_branches(want)
 

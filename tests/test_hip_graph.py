@@ -172,6 +172,10 @@ def test_generator_forward_beside_the_discriminator_backward_is_bit_identical(mo
 
     dev = torch.device("cuda", 0)
 
+    from mggan.hip import functions as HF
+
+    monkeypatch.setattr(HF, "_BRANCH_EAGER", True)  # (eager iterations run on one stream by default: here they fork too)
+
     def run(min_b, graph, iters=4):
         monkeypatch.setattr(T, "_G_EARLY_MIN_B", min_b)
         calls = []
@@ -311,6 +315,10 @@ def test_next_discriminator_context_ahead_of_time_is_bit_identical(monkeypatch):
     from mggan.model import train as T
 
     dev = torch.device("cuda", 0)
+
+    from mggan.hip import functions as HF
+
+    monkeypatch.setattr(HF, "_BRANCH_EAGER", True)  # (the eager variant needs the branch streams an eager iteration no longer uses)
 
     def run(pipeline, graph, where="pm_begin", iters=5):
         monkeypatch.setattr(T, "_PIPE_AT", where)
