@@ -42,7 +42,20 @@ class FlatModule(nn.Module):
         if f is None:
             return False
         base = f.data_ptr()
-        named = list(self.parameters())
+        # nn.Module.parameters() re-walks the module tree through named_modules(): 150 us per call at ~60 modules, three
+        # optimizer steps per iteration.  The module list is walked once per flat buffer (and again every 64th call: a
+        # REPLACED submodule is the one thing its cached form cannot see); the parameters are read from the modules' own
+        # dictionaries every time, so a re-seated or replaced nn.Parameter is still caught at the very next step
+        mods = self.__dict__.get("_flat_mods")
+        n = self.__dict__["_flat_checks"] = self.__dict__.get("_flat_checks", 0) + 1
+        if mods is None or mods[0] is not f or n % 64 == 0:
+            mods = self.__dict__["_flat_mods"] = (f, list(self.modules()))
+        seen, named = set(), []
+        for m in mods[1]:
+            for p in m._parameters.values():
+                if p is not None and id(p) not in seen:
+                    seen.add(id(p))
+                    named.append(p)
         if len(named) != len(self._flat_items):
             return False
         return all(p is q and q.data_ptr() == base + 4 * off for p, (q, off) in zip(named, self._flat_items))

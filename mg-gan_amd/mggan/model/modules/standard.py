@@ -73,7 +73,11 @@ class MultiGenerator(FlatModule):
 
     # -- helpers ---------------------------------------------------------------------------
     def generator_parameters(self):
-        return [p for g in self.gs for p in g.parameters()]
+        hit = self.__dict__.get("_gen_params")
+        if hit is None or hit[0] is not self._flat or self._flat is None:
+            hit = (self._flat, [p for g in self.gs for p in g.parameters()])
+            self.__dict__["_gen_params"] = hit
+        return hit[1]
 
     def _gen_stride(self):
         if self.n_gs == 1:

@@ -474,7 +474,10 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         early = None if shared is None else shared.pop("g_early", None)
         # adversarial pass: D's weights get no gradient here (the reference discards them: D.zero_grad()
         # precedes backward and the next discriminator step zeroes them again, train.py:128,207)
-        d_params = list(self.D.parameters())
+        d_params = self.__dict__.get("_d_params")
+        if d_params is None or d_params[0] is not self.D._flat:
+            d_params = self._d_params = (self.D._flat, list(self.D.parameters()))  # (walked once per flat buffer)
+        d_params = d_params[1]
         flags = [p.requires_grad for p in d_params]
         for p in d_params:
             p.requires_grad_(False)
