@@ -488,7 +488,7 @@ int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, i
  * step), the separate launches beyond: idx receives the picks, the row tables are those of mggan_bucket_rows;
  * ticket: reserved (one word, untouched) */
 int mggan_sample_bucket_rows(int b, int K, int g, const float* logits, const float* u, long long* idx, int* row_gen,
-                             int* row_ped, int* row_slot, int* row_pos, int* inv, int* seg, int* row_gen_pos, int* blk_cnt,
+                             int* row_ped, int* row_slot, int* row_pos, int* inv, int* seg, int* row_gen_pos, int* blk_cnt, int blk_self_reset,
                              unsigned int* ticket, mggan_stream_t stream);
 int mggan_scale(float* x, long n, const float* scalar, mggan_stream_t stream);
 /* classifier input of the discriminator (discriminators.py:141,185,196): rows k*b+ped =

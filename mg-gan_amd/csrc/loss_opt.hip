@@ -851,9 +851,9 @@ __global__ __launch_bounds__(64) void bucket_scan_kernel(int nblk, int g, int* b
 // pass 4: stable scatter.  Rank of a position among the same-generator positions of its block: wave ballot +
 // prefix over the block's waves.
 __global__ __launch_bounds__(BR_BLOCK) void bucket_scatter_kernel(const int* __restrict__ row_gen_pos, int R, int b, int g,
-                                                                  const int* __restrict__ blk_cnt,
-                                                                  const int* __restrict__ seg, int* row_gen,
-                                                                  int* row_ped, int* row_slot, int* row_pos, int* inv) {
+                                                                  int* blk_cnt, const int* __restrict__ seg, int* row_gen,
+                                                                  int* row_ped, int* row_slot, int* row_pos, int* inv,
+                                                                  int self_reset) {
   __shared__ int wcnt[BR_BLOCK / 64][BR_MAXG];
   const int pos = blockIdx.x * BR_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool ok = pos < R;
@@ -871,6 +871,12 @@ __global__ __launch_bounds__(BR_BLOCK) void bucket_scatter_kernel(const int* __r
     const int r = seg[gi] + blk_cnt[blockIdx.x * BR_MAXG + gi] + before + rank;
     const int slot = inv[pos];
     row_gen[r] = gi; row_ped[r] = pos % b; row_slot[r] = slot; row_pos[r] = pos; inv[pos] = r;
+  }
+  if (self_reset) {
+    // a workgroup is the only reader of its row of block offsets: it leaves the row zeroed for the next call's counting
+    // pass (a caller-owned, persistent buffer: no memset node in front of every call)
+    __syncthreads();
+    if (threadIdx.x < BR_MAXG) blk_cnt[blockIdx.x * BR_MAXG + threadIdx.x] = 0;
   }
 }
 
@@ -1183,7 +1189,7 @@ __global__ __launch_bounds__(256) void sample_slots_scan_kernel(int b, int K, in
 
 int mggan_sample_bucket_rows(int b, int K, int g, const float* logits, const float* u, long long* idx, int* row_gen,
                              int* row_ped, int* row_slot, int* row_pos, int* inv, int* seg, int* row_gen_pos, int* blk_cnt,
-                             unsigned int* ticket, hipStream_t stream) {
+                             int blk_self_reset, unsigned int* ticket, hipStream_t stream) {
   MG_CHECK_ARG(g >= 1 && g <= BR_MAXG && K >= 0 && K < 65536, "sample_bucket_rows: num_gens %d not in 1..%d (samples %d)", g, BR_MAXG, K);
   const long Rl = (long)b * K;
   if (Rl == 0) return MGGAN_OK;
@@ -1198,22 +1204,25 @@ int mggan_sample_bucket_rows(int b, int K, int g, const float* logits, const flo
   }
   static int merged = -1;  // MGGAN_SB_MERGED=0: the five-launch path (A/B measurements)
   if (merged < 0) { const char* e = getenv("MGGAN_SB_MERGED"); merged = !(e && e[0] == '0'); }
-  if (!merged) {
+  // (the multi-launch forms leave their block counts behind: a self-resetting buffer is cleared behind them)
+  auto multi = [&]() -> int {
     if (int rc = mggan_sample_categorical(b, K, g, logits, u, idx, stream)) return rc;
-    return mggan_bucket_rows(idx, b, K, g, row_gen, row_ped, row_slot, row_pos, inv, seg, row_gen_pos, blk_cnt, stream);
-  }
+    if (int rc = mggan_bucket_rows(idx, b, K, g, row_gen, row_ped, row_slot, row_pos, inv, seg, row_gen_pos, blk_cnt, stream)) return rc;
+    if (blk_self_reset)
+      MG_CHECK_HIP(hipMemsetAsync(blk_cnt, 0, sizeof(int) * (size_t)cdiv(R, BR_BLOCK) * BR_MAXG, stream), "sample_bucket_rows: memset");
+    return MGGAN_OK;
+  };
+  if (!merged) return multi();
   const int nblk = cdiv(R, BR_BLOCK);
   // the scan kernel keeps the block counts in dynamic LDS (nblk * BR_MAXG ints) beside a few static words: above what fits
   // into 64 KB the five-launch path takes over (decided BEFORE anything is written)
-  if ((size_t)nblk * BR_MAXG * sizeof(int) > 64 * 1024 - 256) {
-    if (int rc = mggan_sample_categorical(b, K, g, logits, u, idx, stream)) return rc;
-    return mggan_bucket_rows(idx, b, K, g, row_gen, row_ped, row_slot, row_pos, inv, seg, row_gen_pos, blk_cnt, stream);
-  }
-  MG_CHECK_HIP(hipMemsetAsync(blk_cnt, 0, sizeof(int) * (size_t)nblk * BR_MAXG, stream), "sample_bucket_rows: memset");
+  if ((size_t)nblk * BR_MAXG * sizeof(int) > 64 * 1024 - 256) return multi();
+  if (!blk_self_reset)
+    MG_CHECK_HIP(hipMemsetAsync(blk_cnt, 0, sizeof(int) * (size_t)nblk * BR_MAXG, stream), "sample_bucket_rows: memset");
   MG_LAUNCH(sample_slots_scan_kernel, dim3(cdiv(b, 256)), dim3(256), sizeof(int) * (size_t)nblk * BR_MAXG, stream, b, K, g,
                      logits, u, idx, row_gen_pos, inv, blk_cnt, nblk, seg, ticket);
   MG_LAUNCH(bucket_scatter_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, b, g, blk_cnt, seg, row_gen,
-                     row_ped, row_slot, row_pos, inv);
+                     row_ped, row_slot, row_pos, inv, blk_self_reset);
   MG_LAUNCH_CHECK("sample_bucket_rows");
   return MGGAN_OK;
 }
@@ -1235,7 +1244,7 @@ int mggan_bucket_rows(const long long* idx, int b, int K, int g, int* row_gen, i
   MG_LAUNCH(bucket_count_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, g, blk_cnt);
   MG_LAUNCH(bucket_scan_kernel, dim3(1), dim3(64), 0, stream, nblk, g, blk_cnt, seg);
   MG_LAUNCH(bucket_scatter_kernel, dim3(nblk), dim3(BR_BLOCK), 0, stream, row_gen_pos, R, b, g, blk_cnt, seg,
-                     row_gen, row_ped, row_slot, row_pos, inv);
+                     row_gen, row_ped, row_slot, row_pos, inv, 0);
   MG_LAUNCH_CHECK("bucket_rows");
   return MGGAN_OK;
 }

@@ -188,10 +188,18 @@ class DeviceRNG:
                                      HF._s())
         self.last_sample_u = (u.data_ptr(), n)  # (the trainer's pre-counted generator picks must have read these very uniforms)
         idx = torch.empty(b, num_samples, dtype=torch.int64, device=lg.device)
-        rows, blk = HF.empty_rollout_rows(b, num_samples, g, lg.device)
+        rows, _ = HF.empty_rollout_rows(b, num_samples, g, lg.device)
+        # the block counters of the bucketing pass: ONE zeroed buffer per sampler, left zero by every call (the scatter
+        # kernel clears what it read) -- no memset node in front of every call, inside a captured graph either
+        need = 16 * ((n + 1023) // 1024)
+        blk = self.__dict__.get("_blk")
+        if blk is None or blk.device != lg.device or blk.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the sampler's block counters must exist before a capture (run an eager iteration first)")
+            blk = self._blk = torch.zeros(max(need, 4096), dtype=torch.int32, device=lg.device)
         lib.mggan_sample_bucket_rows(b, num_samples, g, lg.data_ptr(), u.data_ptr(), idx.data_ptr(), rows.row_gen.data_ptr(),
                                      rows.row_ped.data_ptr(), rows.row_slot.data_ptr(), rows.row_pos.data_ptr(),
-                                     rows.inv.data_ptr(), rows.seg.data_ptr(), rows.row_gen_pos.data_ptr(), blk.data_ptr(),
+                                     rows.inv.data_ptr(), rows.seg.data_ptr(), rows.row_gen_pos.data_ptr(), blk.data_ptr(), 1,
                                      self._bticket.data_ptr(), HF._s())
         return idx, rows
 

@@ -106,17 +106,22 @@ def test_fused_sampling_and_bucketing_match_the_separate_launches(b, K, g):
     ld = (torch.randn(b, g, generator=gen) * 2).cuda()
     st = torch.cuda.current_stream().cuda_stream
     ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
-    for rep in range(2):
+    keep = torch.zeros(16 * ((b * K + 1023) // 1024) + 16, dtype=torch.int32, device="cuda")  # the self-resetting counters
+    for rep in range(3):
         ud = torch.rand(b, K, generator=gen).cuda()
         idx = torch.empty(b, K, dtype=torch.int64, device="cuda")
         lib.mggan_sample_categorical(b, K, g, ld.data_ptr(), ud.data_ptr(), idx.data_ptr(), st)
         ref = device_rollout_rows(idx, g)
         idx2 = torch.full((b, K), -1, dtype=torch.int64, device="cuda")
         rows, blk = empty_rollout_rows(b, K, g, ld.device)
+        # rep 0: a fresh buffer behind a memset node; rep 1, 2: the caller-owned buffer every call leaves zeroed
+        own = rep > 0
         lib.mggan_sample_bucket_rows(b, K, g, ld.data_ptr(), ud.data_ptr(), idx2.data_ptr(), rows.row_gen.data_ptr(),
                                      rows.row_ped.data_ptr(), rows.row_slot.data_ptr(), rows.row_pos.data_ptr(),
-                                     rows.inv.data_ptr(), rows.seg.data_ptr(), rows.row_gen_pos.data_ptr(), blk.data_ptr(),
-                                     ticket.data_ptr(), st)
+                                     rows.inv.data_ptr(), rows.seg.data_ptr(), rows.row_gen_pos.data_ptr(),
+                                     (keep if own else blk).data_ptr(), 1 if own else 0, ticket.data_ptr(), st)
+        if own:
+            assert int(keep.abs().sum()) == 0
         assert torch.equal(idx, idx2), (b, K, g, rep)
         for name in ("row_gen", "row_ped", "row_slot", "row_pos", "inv", "seg", "row_gen_pos"):
             assert torch.equal(getattr(rows, name), getattr(ref, name)), (name, b, K, g, rep)
