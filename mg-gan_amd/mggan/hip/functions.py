@@ -2466,6 +2466,9 @@ def _drows_branch(R):
     return R <= DROWS_BRANCH_MAX_ROWS
 
 
+_DROWS_B0_BRANCH = os.environ.get("MGGAN_DROWS_B0", "branch") != "main"  # (A/B knob: block 0's first half on this stream)
+
+
 class DRowsLeanFn(Function):
     """The K-sample row pass of a FROZEN discriminator (the generator step, the evaluation passes) in its lean form
     (discriminators.py:113-219, pool_type 'sways', unmasked):
@@ -2499,33 +2502,35 @@ class DRowsLeanFn(Function):
         wb = (r[0].weight, r[0].bias, r[2].weight, r[2].bias)
         lib.mggan_d_rows_fill(b, 1, 1, c_in, c_in, c_pe - c_in, c_sc, 0, _p(in_enc), ld_in, 0, 0, _p(X), W, st)
         # ---- block 0 (rows 0 .. b-1), first half: pred_encoder and the social attention need the history encoding and the
-        # predictions only -- they go out BEFORE this stream waits for the scene CNN's branch (round 6: the generator step no
-        # longer joins that branch ahead of the discriminator pass; 64 x 20: the loss launch moves ~35 us earlier) ----
+        # predictions only -- they go to branch stream 3, BEFORE this stream waits for the scene CNN's branch (round 6: the
+        # generator step no longer joins that branch ahead of the discriminator pass), and run beside the per-pedestrian part
+        # of the heads and the one big launch of blocks 1 .. K-1 on this stream (they write the pred_enc / soc columns of X,
+        # this stream the scene columns and P) ----
         x0 = _empty(b, 2 * T, like=in_enc) if save else None
         h_pe0 = _empty(b, 64, like=in_enc) if save else None
-        lib.mggan_pred_encoder_fwd(_p(pred), 0, T, R, b, b, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(X), W, c_pe,
-                                   _p(h_pe0), _p(x0), st)
-        outs_pe = [h_pe0, None]
         xy_last, dxdy_last = xy_last.contiguous(), dxdy_last.contiguous()
         sw = (fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, fc[4].weight, fc[4].bias, Wat.weight, Wat.bias)
-        soc_saved = _social_fwd(xy_last, dxdy_last, _p(X) + 4 * c_in, W, b, c_sc - c_in, tb, *sw, _p(X), W, save, 0, X)
-        join_branch(scene)  # the scene CNN's branch has to be there now
+        with branch(3) if (_drows_branch(R) and _DROWS_B0_BRANCH) else contextlib.nullcontext():
+            lib.mggan_pred_encoder_fwd(_p(pred), 0, T, R, b, b, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(X), W, c_pe,
+                                       _p(h_pe0), _p(x0), _s())
+            soc_saved = _social_fwd(xy_last, dxdy_last, _p(X) + 4 * c_in, W, b, c_sc - c_in, tb, *sw, _p(X), W, save, 0, X)
+        outs_pe = [h_pe0, None]
+        join_branch(scene, which=0)  # the scene CNN's branch has to be there now
         lib.mggan_d_rows_fill(b, 1, 1, 0, 0, 0, c_sc, W - c_sc, 0, 0, _p(scene), ld_sc, _p(X), W, st)
         P = _empty(b, W, like=X)
         lib.mggan_dheads_shared(_p(X), W, b, c_in, c_sc, _p(wa[0]), _p(wa[1]), _p(wb[0]), _p(wb[1]), _p(P), st)
         ya, yb = _empty(R, 1, like=X), _empty(R, g, like=X)
-        # ---- blocks 1 .. K-1 (rows b .. R-1 of ya / yb) ----
+        # ---- blocks 1 .. K-1 (rows b .. R-1 of ya / yb): one launch ----
         mask = torch.empty(-(-(R - b) // 16) * 64, dtype=torch.int64, device=X.device) if save else None
-        with branch(3) if _drows_branch(R) else contextlib.nullcontext():
-            lib.mggan_d_rows_lean_fwd(_p(pred), T, b, R, b, g, act, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(P), c_pe,
-                                      _p(wa[0]), _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[2]), _p(wb[3]), _p(mask), _p(ya), _p(yb),
-                                      _s())
+        lib.mggan_d_rows_lean_fwd(_p(pred), T, b, R, b, g, act, _p(Wpe[0]), _p(bpe[0]), _p(Wpe[1]), _p(bpe[1]), _p(P), c_pe,
+                                  _p(wa[0]), _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[2]), _p(wb[3]), _p(mask), _p(ya), _p(yb),
+                                  st)
+        join_branch(X, x0, h_pe0, *[t for t in soc_saved if torch.is_tensor(t)], which=3)
         # ---- block 0, second half: both heads (the scene columns are in place) ----
         ha = _empty(b, 96, like=X) if save else None
         hb = _empty(b, 96, like=X) if save else None
         lib.mggan_dheads_fwd(_p(X), W, b, g, act, _p(wa[0]), _p(wa[1]), _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[1]),
                              _p(wb[2]), _p(wb[3]), _p(ha), _p(hb), _p(ya), _p(yb), st)
-        join_branch(ya, yb, mask, P, which=3)
         if save:
             ctx.cfg = (D, tb, K, b, T, pshape, g, act)
             ctx.save_for_backward(X, x0, outs_pe[0], xy_last, dxdy_last, ha, ya, hb, mask, *soc_saved)
