@@ -949,13 +949,38 @@ def _prep_for(owner, tensors, psz_total, like, fold):
         if ent[0] != key:
             fold(ent[1])
             ent[0] = key
-        ent[2] = fold  # (the closure of the latest use: same weights, same buffer, the current stream at call time)
+        elif ent[4] is not None:  # folded ahead of time on another stream (prefold): this stream waits for that launch
+            _cur().wait_event(ent[4])
+        ent[4] = None
+        ent[2], ent[3] = fold, tensors  # (the closure of the latest use: same weights, same buffer, the current stream at call time)
         return ent[1]
     prep = torch.empty(psz_total, dtype=F32, device=like.device)
     fold(prep)
-    object.__setattr__(owner, "_mggan_prep", [key, prep, fold])
+    object.__setattr__(owner, "_mggan_prep", [key, prep, fold, tensors, None])
     _PREP["owners"].add(owner)
     return prep
+
+
+def prefold(owner):
+    """Fold `owner`'s weights NOW, on the current stream, if an optimizer step has written them since its buffer was folded
+    -- ahead of the module's first use in a step, off that step's critical chain (the trainer calls it on a branch stream:
+    the rollout of the PM-network step found its fold, 6 us + a queue hop, between the trunk and the rollout).  The
+    module's next use waits for this launch through an event.  No-op for a module that has never been used."""
+    ent = getattr(owner, "_mggan_prep", None)
+    if ent is None or not (_PREP["on"] and _PREP["enabled"]) or ent[3] is None:
+        return False
+    root = getattr(owner, "_flat_root", owner)
+    at = getattr(root, "_written_at", None) or {}
+    written = max([getattr(root, "_all_written_at", 0)] + [at.get(id(t), 0) for t in ent[3]])
+    key = (written,) + tuple((t.data_ptr(), t._version) for t in ent[3])
+    if ent[0] == key:
+        return False
+    ent[2](ent[1])
+    ent[0] = key
+    ev = torch.cuda.Event()
+    ev.record(_cur())
+    ent[4] = ev
+    return True
 
 
 class LstmEncoderFn(Function):

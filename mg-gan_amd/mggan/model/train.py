@@ -45,6 +45,8 @@ _G_EARLY = os.environ.get("MGGAN_G_EARLY", "1") == "1"
 _G_EARLY_MIN_B = int(os.environ.get("MGGAN_G_EARLY_MIN_B", "2048"))
 _EARLY_BRANCH = 5
 _G_SCENE_JOIN_EARLY = os.environ.get("MGGAN_G_SCENE_JOIN", "late") == "early"
+_PM_PREFOLD = os.environ.get("MGGAN_PM_PREFOLD", "0") == "1"  # measured (round 6): 1.3226 -> 1.3292 ms at 64 x 20 -- the fork and the
+#   event cost more than the 6 us fold they take off the chain (the lesson of DESIGN section 4 again); off
 # Cross-iteration pipelining (MGGAN_PIPELINE=1, capture_iteration(pipeline=True)): the NEXT iteration's discriminator context --
 # history LSTM + scene CNN of D on the next batch, with the weights D holds since this iteration's discriminator update -- is
 # issued on a held branch stream beside the PM-network step, whose tail (the generator's scene-CNN adjoint) runs alone on the
@@ -597,6 +599,12 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
         m, g = self._m, self.G.n_gs
         HF.mark("PM.begin")
         self._issue_d_context("pm_begin")
+        if _PM_PREFOLD and HF._BR["on"] and not HF._on_branch():
+            # the generator step has just updated the decoders: their folded weights are due before this step's rollout, whose
+            # first launch would otherwise find the fold (6 us and a queue hop) between the trunk and itself; here it runs on a
+            # branch stream beside the trunk (the rollout waits for its event)
+            with HF.branch(2):
+                HF.prefold(self.G)
         gen_out, net_chooser_weights, _ = self.G(in_xy, in_dxdy, sub_batches, noise=None, all_gen_out=True, img=img,
                                                  num_samples=cfg.num_expectation_samples, mask=mask, need_samples=False)
         n_pm = self._global(net_chooser_weights.shape[0])
