@@ -2521,7 +2521,13 @@ class DRowsLeanFn(Function):
         # and blocks 1 .. K-1 (one launch) meet only in the outputs: what the big launch needs -- P, the per-pedestrian part of
         # the heads' first layers, from the in_enc and scene columns of X -- is produced first, then the big launch goes to
         # branch stream 3 beside block 0's chain (configs[1]: 25 us of the 160 us between the rollout and its adjoint).
-        X = _empty(b, W, like=in_enc)
+        # (the caller may have had the scene CNN write its features into the scene columns of a classifier-input buffer of its
+        #  own -- discriminators.history_context(scene_out=...): that buffer is X, and the broadcast launch below is skipped)
+        X = getattr(scene, "_mggan_X", None)
+        scene_in_place = (X is not None and tuple(X.shape) == (b, W) and X.stride(0) == W
+                          and scene.data_ptr() == X.data_ptr() + 4 * c_sc and ld_sc == W)
+        if not scene_in_place:
+            X = _empty(b, W, like=in_enc)
         Wpe, bpe = (pe[0].weight, pe[2].weight), (pe[0].bias, pe[2].bias)
         wa = (d0[0].weight, d0[0].bias, d0[2].weight, d0[2].bias)
         wb = (r[0].weight, r[0].bias, r[2].weight, r[2].bias)
@@ -2541,7 +2547,8 @@ class DRowsLeanFn(Function):
             soc_saved = _social_fwd(xy_last, dxdy_last, _p(X) + 4 * c_in, W, b, c_sc - c_in, tb, *sw, _p(X), W, save, 0, X)
         outs_pe = [h_pe0, None]
         join_branch(scene, which=0)  # the scene CNN's branch has to be there now
-        lib.mggan_d_rows_fill(b, 1, 1, 0, 0, 0, c_sc, W - c_sc, 0, 0, _p(scene), ld_sc, _p(X), W, st)
+        if not scene_in_place:
+            lib.mggan_d_rows_fill(b, 1, 1, 0, 0, 0, c_sc, W - c_sc, 0, 0, _p(scene), ld_sc, _p(X), W, st)
         P = _empty(b, W, like=X)
         lib.mggan_dheads_shared(_p(X), W, b, c_in, c_sc, _p(wa[0]), _p(wa[1]), _p(wb[0]), _p(wb[1]), _p(P), st)
         ya, yb = _empty(R, 1, like=X), _empty(R, g, like=X)

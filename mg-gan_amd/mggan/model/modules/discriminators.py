@@ -66,7 +66,7 @@ class MultiDiscriminatorTrajectory(FlatModule):
             pred_enc = pad.index_copy(0, mask.repeat(n_samples).nonzero().flatten(), pred_enc)
         return torch.cat([in_enc.repeat(n_samples, 1), pred_enc], dim=1)
 
-    def history_context(self, in_dxdy, img, passes=1, lstm_branch=None, lstm_first=False, defer_cnn=None):
+    def history_context(self, in_dxdy, img, passes=1, lstm_branch=None, lstm_first=False, defer_cnn=None, scene_out=None):
         """(in_enc (b,h/2), scene (b,64)): everything that depends only on the observed history and the
         image crop.  The real and the fake pass of one discriminator step share it (identical inputs and
         weights), autograd sums their cotangents, so the history LSTM and the scene CNN run forward and
@@ -78,7 +78,11 @@ class MultiDiscriminatorTrajectory(FlatModule):
         def cnn():
             with HF.branch():  # scene CNN || history LSTM; joined by forward() right before the classifier input
                 HF.mark("Dctx.cnn.begin")
-                out = self.scene_encoder(img, stat_updates=passes)
+                # (scene_out: an HF.OutSlot -- the attention head writes the features straight into the scene columns of the
+                #  classifier input the caller has allocated, no broadcast launch behind the branch join)
+                out = self.scene_encoder(img, stat_updates=passes, out=scene_out)
+                if scene_out is not None:
+                    out._mggan_X = scene_out.buf
                 HF.mark("Dctx.cnn.end")
             return out
 

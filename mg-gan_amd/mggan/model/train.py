@@ -45,6 +45,7 @@ _G_EARLY = os.environ.get("MGGAN_G_EARLY", "1") == "1"
 _G_EARLY_MIN_B = int(os.environ.get("MGGAN_G_EARLY_MIN_B", "2048"))
 _EARLY_BRANCH = 5
 _G_SCENE_JOIN_EARLY = os.environ.get("MGGAN_G_SCENE_JOIN", "late") == "early"
+_G_SCENE_IN_PLACE = os.environ.get("MGGAN_G_SCENE_IN_PLACE", "1") != "0"
 _PM_PREFOLD = os.environ.get("MGGAN_PM_PREFOLD", "0") == "1"  # measured (round 6): 1.3226 -> 1.3292 ms at 64 x 20 -- the fork and the
 #   event cost more than the 6 us fold they take off the chain (the lesson of DESIGN section 4 again); off
 # Cross-iteration pipelining (MGGAN_PIPELINE=1, capture_iteration(pipeline=True)): the NEXT iteration's discriminator context --
@@ -496,8 +497,13 @@ class PiNetMultiGeneratorGAN(MultiGeneratorGAN):
                     #  chip is empty here: history LSTM and scene CNN side by side, 4.494 -> 4.466 ms at 256 x 32, three
                     #  alternating pairs; beside the rollout forward -- small batches -- the third stream loses 20 us)
                     lstm_branch = 2 if (early is not None and "MGGAN_G_LSTM_BRANCH" not in os.environ) else self.g_step_lstm_branch
+                    # the lean row pass reads the scene features from the scene columns of its (b, 192) classifier input: the
+                    # attention head writes them there itself (no broadcast launch behind the branch join)
+                    slot = None
+                    if _G_SCENE_IN_PLACE and defer is None and cfg.pool_type == "sways" and self.gan_type == "mgan":
+                        slot = HF.OutSlot(torch.empty(b, 192, dtype=torch.float32, device=self.device), 128, 192)
                     ctx_d = self.D.history_context(in_dxdy, img, passes=1, lstm_branch=lstm_branch,
-                                                   lstm_first=self.g_step_lstm_first, defer_cnn=defer)
+                                                   lstm_first=self.g_step_lstm_first, defer_cnn=defer, scene_out=slot)
             if early is not None:
                 # issued from the discriminator step: this stream takes its results over (and autograd will run their
                 # adjoints on the branch stream they were computed on)
