@@ -364,3 +364,36 @@ def test_next_discriminator_context_ahead_of_time_is_bit_identical(monkeypatch):
         got, bn, n = run(True, graph, where)
         assert n >= 1, "no issued context was taken"
         assert torch.equal(got, ref) and torch.equal(bn, bn_ref), (graph, where)
+
+
+def test_decoder_prefold_on_a_branch_is_bit_identical(monkeypatch):
+    """HF.prefold (MGGAN_PM_PREFOLD, off by default -- measured slower): the decoders' folded weights of the PM-network step
+    produced ahead of time on a branch stream, handed to the rollout through an event.  Same weights after four iterations."""
+    import bench
+    from mggan.data_utils import synthetic
+    from mggan.hip import functions as HF
+    from mggan.model import train as T
+
+    dev = torch.device("cuda", 0)
+
+    def run(prefold):
+        monkeypatch.setattr(T, "_PM_PREFOLD", prefold)
+        n = []
+        real = HF.prefold
+        monkeypatch.setattr(HF, "prefold", lambda owner: (n.append(real(owner)), n[-1])[1])
+        tr = bench.build_trainer(3, "device", dev)
+        torch.cuda.manual_seed(99)
+        batch = tr.to_device(synthetic.make_batch(synthetic.scene_sizes(12, 5), seed=1))
+        batch["loss_mask"] = None
+        tr.defer_metrics = True
+        replay = tr.capture_iteration(batch, warmup=2)
+        for _ in range(2):
+            replay(defaultdict(list), False)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(HF, "prefold", real)
+        return torch.cat([tr.G._flat.clone(), tr.D._flat.clone()]).cpu(), sum(bool(x) for x in n)
+
+    ref, n0 = run(False)
+    got, n1 = run(True)
+    assert n0 == 0 and n1 >= 2, (n0, n1)  # (the fold really ran ahead of time)
+    assert torch.equal(got, ref)
