@@ -4,25 +4,36 @@ Additions: dataset choice 'synthetic' (+ its shape flags) and --rng."""
 import argparse
 
 
-BUILT_WIDTHS = {"h_dim": (32,), "decoder_h_dim": (32,)}
+BUILT_WIDTHS = {"h_dim": 32, "decoder_h_dim": 32}
 
 
 def check_widths(config):
     """The kernels of libmggan_hip.so are instantiated for the reference's DEFAULT widths (config.py:70-71 there:
     --h_dim 32 -> generator encoder / social features 32, discriminator encoder 64; --decoder_h_dim 32 -> rollout LSTM 32,
-    step embedding 16) and for noise vectors whose length is a multiple of 4.  Anything else is refused HERE -- at parse
-    time and again in construct_model -- with a ValueError, before a module is built or a kernel launched."""
+    step embedding 16) and for noise vectors whose length is a multiple of 4.  NARROWER models (2 <= width <= 32) run on the
+    same kernels zero-padded (mggan/model/widths.py; attention pooling and the multi-generator model only); wider ones are
+    refused HERE -- at parse time and again in construct_model -- with a ValueError, before a module is built or a kernel
+    launched."""
     bad = []
-    for flag, ok in BUILT_WIDTHS.items():
-        v = getattr(config, flag, ok[0])
-        if int(v) not in ok:
-            bad.append("--{} {} (built: {})".format(flag, v, " / ".join(str(o) for o in ok)))
+    narrow = False
+    for flag, built in BUILT_WIDTHS.items():
+        v = int(getattr(config, flag, built))
+        if not 2 <= v <= built:
+            bad.append("--{} {} (built: {}, narrower widths run zero-padded)".format(flag, v, built))
+        narrow |= v != built
     z = int(getattr(config, "noise_dim", 8))
     if z < 4 or z % 4:
         bad.append("--noise_dim {} (built: positive multiples of 4)".format(z))
+    if narrow and not bad:
+        if getattr(config, "pool_type", "sways") != "sways":
+            bad.append("--pool_type sgan at a narrower width (the padded layout is defined for the attention pooling)")
+        if getattr(config, "experiment", "multi_generator") != "multi_generator":
+            bad.append("--experiment discrete at a narrower width")
+        if int(getattr(config, "n_social_modules", 1)) <= 0:
+            bad.append("--n_social_modules 0 at a narrower width")
     if bad:
         raise ValueError("not built on the HIP path: " + "; ".join(bad) + ".  libmggan_hip.so instantiates its LSTM, social-"
-                         "attention and rollout kernels for the reference's default widths only (DESIGN.md section 9).")
+                         "attention and rollout kernels for the reference's default widths (DESIGN.md section 9).")
     return config
 
 

@@ -9,6 +9,7 @@ from torch import nn
 from mggan.utils import make_mlp
 from mggan.hip.flat import FlatModule
 from mggan.hip import functions as HF
+from mggan.model.widths import holders_only
 
 GeneratorOutput = namedtuple("generator_out", ["rel", "abs"])
 
@@ -31,7 +32,7 @@ class TrajectoryEncoder(FlatModule):
         if inp_size != 2 or num_layers != 1 or embedding_dim is None or return_hc:
             raise ValueError("HIP TrajectoryEncoder supports inp_size=2 (inp_format 'rel'/'abs'), one layer, "
                              "an embedding and return_hc=False (the configurations of the reference hot path)")
-        if hidden_size not in (32, 64):
+        if hidden_size not in (32, 64) and not holders_only():
             raise ValueError("HIP TrajectoryEncoder: hidden_size {} not built (32: generator, 64: discriminator; "
                              "csrc/lstm.hip lstm_*_kernel<H>)".format(hidden_size))
         self.embedding_dim = embedding_dim
@@ -57,7 +58,7 @@ class RelativeDecoder(FlatModule):
         super().__init__()
         if inp_format != "rel" or num_layers != 1 or dropout != 0.0:
             raise ValueError("HIP RelativeDecoder supports inp_format='rel', one layer, no dropout")
-        if h_dim != 32 or not 0 < social_feat_size <= 32 or z_size < 4 or z_size % 4:
+        if (h_dim != 32 or not 0 < social_feat_size <= 32 or z_size < 4 or z_size % 4) and not holders_only():
             raise ValueError("HIP RelativeDecoder: h_dim {} / social_feat_size {} / z_size {} not built (32, 1..32, a "
                              "multiple of 4; csrc/lstm.hip decoder_*_kernel)".format(h_dim, social_feat_size, z_size))
         self.pred_len = pred_len

@@ -6,6 +6,7 @@ from torch import nn
 
 from mggan.hip.flat import FlatModule
 from mggan.hip import functions as HF
+from mggan.model.widths import holders_only
 
 
 class AttentionPooling(nn.Module):
@@ -28,7 +29,7 @@ class EmbedSocialFeatures(nn.Module):
 class SocialAttention(FlatModule):
     def __init__(self, social_feat_size, hidden_size):
         super().__init__()
-        if hidden_size not in (32, 64) or social_feat_size < 1:
+        if (hidden_size not in (32, 64) or social_feat_size < 1) and not holders_only():
             raise ValueError("HIP SocialAttention: hidden_size {} not built (32 or 64; csrc/social_rows.hip "
                              "social_rows_*_kernel<H>, csrc/social.hip)".format(hidden_size))
         self.feature_embedder = EmbedSocialFeatures(3, social_feat_size)

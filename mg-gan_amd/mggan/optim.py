@@ -81,23 +81,32 @@ class FlatAdamW:
     def state_dict(self):
         state = {}
         steps = self.seg_step.cpu()
+        wm = getattr(self.root, "_width_map", None)  # narrower model on padded kernels: the reference's shapes (model/widths.py)
         for i, (p, o) in enumerate(self.root._flat_items):
             if int(steps[i]) == 0:
                 continue
             n = p.numel()
-            state[i] = {"step": torch.tensor(float(steps[i])), "exp_avg": self.exp_avg[o:o + n].view(p.shape).clone(),
-                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+            m, v = self.exp_avg[o:o + n].view(p.shape).clone(), self.exp_avg_sq[o:o + n].view(p.shape).clone()
+            if wm is not None:
+                name = self.root._flat_names[i]
+                m, v = wm.to_logical(name, m), wm.to_logical(name, v)
+            state[i] = {"step": torch.tensor(float(steps[i])), "exp_avg": m, "exp_avg_sq": v}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
                  "amsgrad": False, "params": list(range(self.nseg))}
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
         steps = torch.zeros(self.nseg, dtype=torch.int32)
+        wm = getattr(self.root, "_width_map", None)
         for i, st in sd["state"].items():
             p, o = self.root._flat_items[int(i)]
             n = p.numel()
-            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            m, v = st["exp_avg"], st["exp_avg_sq"]
+            if wm is not None:
+                name = self.root._flat_names[int(i)]
+                m, v = wm.to_physical(name, m, p.shape), wm.to_physical(name, v, p.shape)
+            self.exp_avg[o:o + n].copy_(m.reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(v.reshape(-1))
             steps[int(i)] = int(st["step"])
         self.seg_step.copy_(steps)
         self.lr = sd["param_groups"][0]["lr"]

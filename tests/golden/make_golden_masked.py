@@ -132,3 +132,6 @@ if __name__ == "__main__":
         main("masked_sgan_g2", ["--pool_type", "sgan"], nan=True, keep_init=False)
     if "sgan" in which:  # Social-GAN pooling in G and D (social_gan.py:157-229) instead of the attention
         main("pool_sgan_g2", ["--pool_type", "sgan"], nan=False, keep_init=False)
+    if "narrow" in which:  # widths below the built ones (config.py:70-71): the HIP path runs them zero-padded (mggan/model/widths.py)
+        main("narrow_h16_g2", ["--h_dim", "16", "--decoder_h_dim", "16"], nan=False, keep_init=True)
+        main("narrow_h24_d8_g2", ["--h_dim", "24", "--decoder_h_dim", "8", "--noise_dim", "4"], nan=True, keep_init=True)

@@ -12,7 +12,8 @@ from conftest import GOLDEN
 from test_masked import STEPS, _batch, _check
 
 VARIANTS = ["obj_ls_g2", "obj_mm_g2", "wt_l2_g2", "wt_endpoint_g2", "wt_mgan_g2", "pool_sgan_g2", "discrete_g2",
-            "masked_sgan_g2"]
+            "masked_sgan_g2", "narrow_h16_g2", "narrow_h24_d8_g2"]
+NARROW = [v for v in VARIANTS if v.startswith("narrow")]
 
 
 def _load(tag):
@@ -33,7 +34,8 @@ def test_oracle_variant_iteration(tag):
     np.random.seed(int(g["meta/seed"]) + 1)
     o = _opts(args)
     G, D = O.construct_oracle(int(g["meta/num_gens"]), gan_obj=o.get("gan_obj", "NS"), pool_type=o.get("pool_type", "sways"),
-                               experiment=o.get("experiment", "multi_generator"))
+                               experiment=o.get("experiment", "multi_generator"), h_dim=int(o.get("h_dim", 32)),
+                               decoder_h_dim=int(o.get("decoder_h_dim", 32)), noise_dim=int(o.get("noise_dim", 8)))
     G.train()
     D.train()
     tr = O.OracleTrainer(G, D, mode="block", gan_obj=o.get("gan_obj", "NS"), weighting_target=o.get("weighting_target", "ml"))
@@ -74,9 +76,13 @@ def test_hip_variant_iteration(tag):
     m = defaultdict(list)
     tr.train_iteration(bt, m)
     _check(g, m, tr.G, tr.D)
+    if tag in NARROW:  # the padding of the wider kernels' parameters stayed exactly zero through D, G and PM updates
+        from mggan.model import widths
+
+        assert widths.padding_is_zero(tr.G) and widths.padding_is_zero(tr.D)
 
 
-@pytest.mark.parametrize("tag", ["pool_sgan_g2", "discrete_g2"])
+@pytest.mark.parametrize("tag", ["pool_sgan_g2", "discrete_g2"] + NARROW)
 def test_variant_state_dict_surface(tag):
     """CPU: the variant models expose the reference's state_dict keys and shapes (checkpoint compatibility)."""
     from mggan.model.config import get_parser
@@ -135,3 +141,58 @@ def test_variants_graph_replay_and_prediction_strategies(extra):
                                            num=6)
         p = p[0] if isinstance(p, tuple) else p
         assert tuple(p.shape) == (12, 6, b, 2) and bool(torch.isfinite(p).all()), strat
+
+
+@pytest.mark.gpu
+def test_narrow_model_graph_replay_and_checkpoint_round_trip():
+    """--h_dim 16 --decoder_h_dim 24 on the padded kernels (mggan/model/widths.py): eager iteration, HIP-graph replays, the
+    padding stays exactly zero, and model + optimizer state round-trip through the reference-shaped state_dicts."""
+    import contextlib
+    import io
+
+    from mggan.data_utils import synthetic
+    from mggan.logging import Experiment
+    from mggan.model import widths
+    from mggan.model.config import get_parser
+    from mggan.model.model_factory import construct_model
+    from mggan.model.train import PiNetMultiGeneratorGAN
+
+    def make(seed):
+        cfg = get_parser().parse_args(["--num_gens", "3", "--rng", "device", "--h_dim", "16", "--decoder_h_dim", "24"])
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            G, D = construct_model(cfg)
+        tr = PiNetMultiGeneratorGAN(G, D, cfg, Experiment(debug=True))
+        tr.G.train()
+        tr.D.train()
+        tr.defer_metrics = True
+        return tr
+
+    tr = make(1)
+    batch = tr.to_device(synthetic.make_batch(synthetic.scene_sizes(12, None, seed=3), seed=5))
+    batch["loss_mask"] = None
+    m = defaultdict(list)
+    tr.train_iteration(batch, m)
+    replay = tr.capture_iteration(batch, warmup=1)
+    for _ in range(3):
+        replay(m, True)
+    torch.cuda.synchronize()
+    for k, v in m.items():
+        assert np.isfinite(v).all(), k
+    assert widths.padding_is_zero(tr.G) and widths.padding_is_zero(tr.D)
+    sd = {"G": tr.G.state_dict(), "D": tr.D.state_dict(), "oG": tr.optimizerG.state_dict(), "oD": tr.optimizerD.state_dict()}
+    assert tuple(sd["G"]["encoder.encoder.weight_hh_l0"].shape) == (64, 16)
+    assert tuple(sd["G"]["gs.0.hidden2pos.0.weight"].shape) == (12, 24 + 16)
+    assert tuple(sd["D"]["discs.0.0.weight"].shape) == (64, 128)
+    tr2 = make(2)
+    tr2.train_iteration(batch, defaultdict(list))  # (moments exist before they are overwritten)
+    tr2.G.load_state_dict(sd["G"])
+    tr2.D.load_state_dict(sd["D"])
+    tr2.optimizerG.load_state_dict(sd["oG"])
+    tr2.optimizerD.load_state_dict(sd["oD"])
+    for a, b in ((tr.G, tr2.G), (tr.D, tr2.D)):
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            assert torch.equal(p, q), k
+    for a, b in ((tr.optimizerG, tr2.optimizerG), (tr.optimizerD, tr2.optimizerD)):
+        assert torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+        assert torch.equal(a.seg_step.cpu(), b.seg_step.cpu())
