@@ -327,7 +327,7 @@ def sharded_one_rank_leg(args, single_ms):
     return out
 
 
-def train_loop_disk_leg(args, dev, head_ms, frames=980, peds=40, scenes_per_batch=32, epochs=6):
+def train_loop_disk_leg(args, dev, head_ms, frames=3219, peds=40, scenes_per_batch=32, epochs=5, workers=2):
     """train() as the README runs it on an ON-DISK dataset in the reference's format (one 640 x 480 scene image, `frames`
     frames x `peds` pedestrians written as an ETH-style text file), --augment 1 (the reference's default), no --cache_device:
     every batch goes through the loader -- trajectories on the host, the augmented scene crops on the GPU
@@ -355,7 +355,7 @@ def train_loop_disk_leg(args, dev, head_ms, frames=980, peds=40, scenes_per_batc
             cfg = get_parser().parse_args([
                 "--num_gens", str(CONFIGS["c2"]["num_gens"]), "--rng", "device", "--graph", "auto", "--dataset", "eth",
                 "--augment", "1", "--epochs", str(epochs), "--batch_size", str(scenes_per_batch), "--val_every", "1000000",
-                "--save_every", "1000000"])
+                "--save_every", "1000000", "--workers", str(workers)])
             torch.manual_seed(145325)
             np.random.seed(435346)
             G, D = construct_model(cfg)
@@ -373,8 +373,9 @@ def train_loop_disk_leg(args, dev, head_ms, frames=980, peds=40, scenes_per_batc
     ms = per_it[len(per_it) // 2] * 1e3
     tr.dist.close()
     return {"workload": "train() on an on-disk dataset (reference format: {} frames x {} pedestrians, one 640x480 scene image), "
-                        "--augment 1, batches of {} scenes, num_gens={}, {} epochs; crops on the GPU, no device cache".format(
-                            frames, peds, scenes_per_batch, CONFIGS["c2"]["num_gens"], epochs),
+                        "--augment 1, --workers {} (the reference's flag: loader processes for the host half of a batch), batches of {} scenes, "
+                        "num_gens={}, {} epochs; crops on the GPU, no device cache".format(
+                            frames, peds, workers, scenes_per_batch, CONFIGS["c2"]["num_gens"], epochs),
             "ms_per_step": round(ms, 4), "vs_captured_iteration": round(ms / head_ms, 3),
             "iterations_per_epoch": tr.epoch_iterations[-1], "replayed_iterations": ig.replays if ig else 0,
             "eager_iterations": (ig.eager if ig else sum(tr.epoch_iterations)), "graphs": len(ig.entries) if ig else 0,

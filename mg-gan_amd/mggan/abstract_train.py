@@ -381,10 +381,10 @@ class MultiGeneratorGAN(abc.ABC):
             kw["cache_device"] = self.device
         workers = cfg.workers
         if cfg.dataset != "synthetic" and getattr(cfg, "crop_device", "auto") != "off":
-            # scene crops on the GPU; the host half of a batch (trajectory transforms, the augmentation's geometry: ~55 us
-            # per item of Python) runs where --workers says -- in this process by default, like the reference's loader and
-            # with its numpy draw order (loader workers were measured SLOWER here: 4.5 vs 3.4 ms per 1,280-pedestrian batch,
-            # the batches cross the process boundary as a dozen small tensors each)
+            # scene crops on the GPU; the host half of a batch (trajectory transforms, the augmentation's geometry) runs where
+            # --workers says -- in this process by default, like the reference's loader and with its numpy draw order; with
+            # --workers N in N forked processes that hand their batches over through shared-memory slots
+            # (mggan/data_utils/device_crops.py: DeviceCropLoader)
             kw["crop_device"] = self.device
             workers = int(os.environ.get("MGGAN_LOADER_WORKERS", str(workers)))
         pad = getattr(cfg, "graph_pad", "auto")
@@ -634,16 +634,24 @@ class IterationGraphs:
     def _load(self, ent, batch):
         """Copy a batch into an entry's static buffers (padded entries: the real pedestrians in front, the phantom
         pedestrians restored behind them where the previous batch was longer, the scene tables re-filled)."""
-        if ent.tables is None:
-            for k, v in batch.items():
-                if torch.is_tensor(v):
-                    ent.static[k].copy_(v, non_blocking=True)
-            return
         from mggan.hip import functions as HF
         from mggan.hip.lib import lib
 
         b = batch["in_xy"].shape[1]
-        keys = [k for k, v in batch.items() if torch.is_tensor(v)]
+        if ent.tables is None:
+            # an exact-shape entry: the float32 tensors with a pedestrian axis in ONE launch too (mggan_pad_batch with nothing
+            # to pad: six copy launches of a device batch otherwise, in series in front of every replay)
+            keys = []
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    if v.is_cuda and v.dtype == torch.float32 and k in self.PED_AXIS and v.numel():
+                        keys.append(k)
+                    else:
+                        ent.static[k].copy_(v, non_blocking=True)
+            if not keys:
+                return
+        else:
+            keys = [k for k, v in batch.items() if torch.is_tensor(v)]
         descs = (_PadDesc * len(keys))()
         keep = []
         for d, k in zip(descs, keys):
@@ -657,8 +665,10 @@ class IterationGraphs:
             d.position = 1 if k in ("in_xy", "gt_xy") else 0
         # ONE launch: the real pedestrians in front, the phantom pedestrians (constant positions x = slot within a phantom
         # scene, zero steps, black crops) behind them
-        lib.mggan_pad_batch(ctypes.addressof(descs), len(keys), b, ent.tables.b, HF.StaticSceneTables.PHANTOM_SCENE, HF._s())
-        ent.tables.fill(batch["seq_start_end"])
+        lib.mggan_pad_batch(ctypes.addressof(descs), len(keys), b, ent.tables.b if ent.tables is not None else b,
+                            HF.StaticSceneTables.PHANTOM_SCENE, HF._s())
+        if ent.tables is not None:
+            ent.tables.fill(batch["seq_start_end"])
 
     def step(self, batch, metrics):
         """-> True when the batch was consumed here (eagerly on its static buffers, or as a replay)."""
@@ -720,14 +730,17 @@ class IterationGraphs:
         ent.replay(None, False)
         tr.total_iterations += 1
         self.replays += 1
-        seen = set()
+        seen, totals, snaps = set(), [], []
         for _, items, snap in ent.replay.pending:  # the replay refreshed its snapshot buffers: add them up on the device
             acc = self._acc.setdefault(id(snap), [snap, torch.zeros_like(snap), 0, set()])
             acc[3].add(tuple(items))
             if id(snap) not in seen:
                 seen.add(id(snap))
-                acc[1] += snap
+                totals.append(acc[1])
+                snaps.append(snap)
                 acc[2] += 1
+        if totals:
+            torch._foreach_add_(totals, snaps)  # (one launch for the snapshots of all three steps)
         return True
 
     def flush(self, metrics):

@@ -20,9 +20,14 @@ import os
 
 KS_MAX, SPAN_MAX = 128, 800  # csrc/crop.hip: AUG_KS_MAX, AUG_SPAN_MAX
 TILE_MODE = os.environ.get("MGGAN_CROP_TILES", "1") != "0"  # whole resized images first when that is less work (A/B knob)
+LOADER_STREAM_PRIORITY = int(os.environ.get("MGGAN_LOADER_STREAM_PRIORITY", "0"))
 PREFETCH_THREAD = os.environ.get("MGGAN_LOADER_THREAD", "0") == "1"  # one batch ahead on a thread of the loader's own: measured
 #   SLOWER (2.34 vs 2.17-2.26 ms per 1,280-pedestrian iteration of train(); the loader alone 565 k vs 725 k pedestrians/s): both
 #   threads are Python and share the GIL; off
+
+
+class _PoolMiss(Exception):
+    pass
 
 
 class _PreBatched:
@@ -93,6 +98,8 @@ class DeviceCropDataset(Dataset):
         """-> (offset of the coefficient rows, offset of the (first index, taps) pairs, taps per row) in the table pool."""
         hit = self._pool_idx.get((in_size, out_size))
         if hit is None:
+            if getattr(self, "_frozen", False):  # (a slot worker: its pool is a copy made at fork time, the device copy is the
+                raise _PoolMiss()                #  parent's -- a table the parent does not have yet is left to the parent)
             bounds, kk, ks = AG.resample_coeffs(in_size, out_size)
             if ks > KS_MAX:
                 raise NotImplementedError("downscale {} -> {}: {} taps per pixel (the device kernel holds {})".format(
@@ -240,12 +247,40 @@ class DeviceCropDataset(Dataset):
                                    np.concatenate([m[2] for m in metas]))
         return batch
 
+    def plan(self, meta):
+        """The host arithmetic of the device half (numpy only; slot workers run it too): which launches the batch needs and
+        the int32 arrays they read -> {"kind", "arrays": [...], scalars}."""
+        m = self.ds.margin_in
+        if meta[0] != "aug":
+            return {"kind": "plain", "arrays": [meta[1], meta[2], meta[3]], "n": int(meta[1].shape[0])}
+        recs = np.stack([self._resolve_tables(r.copy()) for r in meta[1]])
+        n = int(meta[2].shape[0])
+        # the pedestrians of an item share its canvas, and their windows overlap: when the 33 x 33 tiles of the items'
+        # whole resized images are fewer than the windows, the images are computed once (tile by tile, the same
+        # kernel) and the crops are cut from them like un-augmented ones
+        sw, sh = recs[:, 8].astype(np.int64), recs[:, 9].astype(np.int64)
+        tx, ty = (sw + 32) // 33, (sh + 32) // 33
+        if m == 16 and int((tx * ty).sum()) < n and TILE_MODE:
+            small_off = np.concatenate([[0], np.cumsum(sw * sh * 3)[:-1]]).astype(np.int64)
+            t_item = np.repeat(np.arange(len(recs), dtype=np.int32), tx * ty)
+            t_ctr = np.concatenate([np.stack([16 + 33 * (np.arange(a * b) % a), 16 + 33 * (np.arange(a * b) // a)], 1)
+                                    for a, b in zip(tx, ty)]).astype(np.int32)
+            pi = meta[2]
+            return {"kind": "tiles", "n": n, "tiles": int(t_item.shape[0]), "max_taps": int(recs[:, 16].max()),
+                    "small_bytes": int((sw * sh * 3).sum()) + 8,
+                    "arrays": [recs, t_item, t_ctr, small_off, small_off[pi], np.stack([sh[pi], sw[pi]], 1).astype(np.int32),
+                               meta[3]]}
+        return {"kind": "windows", "n": n, "max_taps": int(recs[:, 16].max()), "arrays": [recs, meta[2], meta[3]]}
+
     def finish(self, batch, join=True):
         """The device half, in the process that owns the GPU: one launch cuts every crop of the batch.  join=False (a
         prefetching thread): the consumer orders its stream behind the loader's itself (join_stream)."""
         from mggan.hip.lib import lib
 
-        meta = batch.pop("_crop_meta")
+        plan = batch.pop("_crop_plan", None)
+        meta = batch.pop("_crop_meta", None)
+        if plan is None:
+            plan = self.plan(meta)
         m = self.ds.margin_in
         # through pinned memory (a copy from pageable memory makes the host wait for the stream -- i.e. for the training
         # iterations queued ahead of it), and as few copies as possible: every int32 array of the batch rides in ONE upload
@@ -271,7 +306,7 @@ class DeviceCropDataset(Dataset):
         # the caller's stream just before) still runs -- at 1,280 pedestrians that iteration is a chain of latency-bound
         # launches that leaves most of the chip idle; the caller's stream waits for the loader's below
         if self._stream is None:
-            self._stream = torch.cuda.Stream(self.device)
+            self._stream = torch.cuda.Stream(self.device, priority=LOADER_STREAM_PRIORITY)
         caller = torch.cuda.current_stream(self.device)
         with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
             base = batch.pop("_traj_base", None)
@@ -284,40 +319,24 @@ class DeviceCropDataset(Dataset):
                 if torch.is_tensor(v) and not v.is_cuda:
                     batch[k] = up(v)
             st = torch.cuda.current_stream().cuda_stream
-            if meta[0] == "aug":
-                recs = np.stack([self._resolve_tables(r.copy()) for r in meta[1]])
-                if self._pool_dev is None or self._pool_dev.numel() != self._pool_len:
-                    self._pool_dev = torch.from_numpy(np.concatenate(self._pool)).to(self.device)
-                n = int(meta[2].shape[0])
-                out = torch.empty(n, 4, 2 * m + 1, 2 * m + 1, dtype=torch.float32, device=self.device)
-                # the pedestrians of an item share its canvas, and their windows overlap: when the 33 x 33 tiles of the items'
-                # whole resized images are fewer than the windows, the images are computed once (tile by tile, the same
-                # kernel) and the crops are cut from them like un-augmented ones
-                sw, sh = recs[:, 8].astype(np.int64), recs[:, 9].astype(np.int64)
-                tx, ty = (sw + 32) // 33, (sh + 32) // 33
-                if m == 16 and int((tx * ty).sum()) < n and TILE_MODE:
-                    small_off = np.concatenate([[0], np.cumsum(sw * sh * 3)[:-1]]).astype(np.int64)
-                    t_item = np.repeat(np.arange(len(recs), dtype=np.int32), tx * ty)
-                    t_ctr = np.concatenate([np.stack([16 + 33 * (np.arange(a * b) % a), 16 + 33 * (np.arange(a * b) // a)], 1)
-                                            for a, b in zip(tx, ty)]).astype(np.int32)
-                    small = torch.empty(int((sw * sh * 3).sum()) + 8, dtype=torch.uint8, device=self.device)
-                    pi = meta[2]
-                    (items, d_ti, d_tc, d_so, off, hw, ctr), dev = pack([
-                        recs, t_item, t_ctr, small_off, small_off[pi], np.stack([sh[pi], sw[pi]], 1).astype(np.int32), meta[3]])
-                    lib.mggan_aug_small_images(self.atlas.data_ptr(), items.data_ptr(), self._pool_dev.data_ptr(), d_ti.data_ptr(),
-                                               d_tc.data_ptr(), int(t_item.shape[0]), int(recs[:, 16].max()), d_so.data_ptr(),
-                                               small.data_ptr(), st)
-                    lib.mggan_crop_patches(small.data_ptr(), off.data_ptr(), hw.data_ptr(), ctr.data_ptr(), n, m, out.data_ptr(), st)
-                    self._keep = (dev, small, self._pool_dev)
-                else:
-                    (items, ped_item, ctr), dev = pack([recs, meta[2], meta[3]])
-                    lib.mggan_crop_patches_aug(self.atlas.data_ptr(), items.data_ptr(), self._pool_dev.data_ptr(),
-                                               ped_item.data_ptr(), ctr.data_ptr(), n, m, int(recs[:, 16].max()), out.data_ptr(), st)
-                    self._keep = (dev, self._pool_dev)  # alive until the next batch (the launch is asynchronous)
+            n = plan["n"]
+            out = torch.empty(n, 4, 2 * m + 1, 2 * m + 1, dtype=torch.float32, device=self.device)
+            if plan["kind"] != "plain" and (self._pool_dev is None or self._pool_dev.numel() != self._pool_len):
+                self._pool_dev = torch.from_numpy(np.concatenate(self._pool)).to(self.device)
+            if plan["kind"] == "tiles":
+                small = torch.empty(plan["small_bytes"], dtype=torch.uint8, device=self.device)
+                (items, d_ti, d_tc, d_so, off, hw, ctr), dev = pack(plan["arrays"])
+                lib.mggan_aug_small_images(self.atlas.data_ptr(), items.data_ptr(), self._pool_dev.data_ptr(), d_ti.data_ptr(),
+                                           d_tc.data_ptr(), plan["tiles"], plan["max_taps"], d_so.data_ptr(), small.data_ptr(), st)
+                lib.mggan_crop_patches(small.data_ptr(), off.data_ptr(), hw.data_ptr(), ctr.data_ptr(), n, m, out.data_ptr(), st)
+                self._keep = (dev, small, self._pool_dev)
+            elif plan["kind"] == "windows":
+                (items, ped_item, ctr), dev = pack(plan["arrays"])
+                lib.mggan_crop_patches_aug(self.atlas.data_ptr(), items.data_ptr(), self._pool_dev.data_ptr(),
+                                           ped_item.data_ptr(), ctr.data_ptr(), n, m, plan["max_taps"], out.data_ptr(), st)
+                self._keep = (dev, self._pool_dev)  # alive until the next batch (the launch is asynchronous)
             else:
-                (off, hw, ctr), dev = pack([meta[1], meta[2], meta[3]])
-                n = int(meta[1].shape[0])
-                out = torch.empty(n, 4, 2 * m + 1, 2 * m + 1, dtype=torch.float32, device=self.device)
+                (off, hw, ctr), dev = pack(plan["arrays"])
                 lib.mggan_crop_patches(self.atlas.data_ptr(), off.data_ptr(), hw.data_ptr(), ctr.data_ptr(), n, m, out.data_ptr(), st)
                 self._keep = (dev,)
         batch["features"] = out
@@ -330,6 +349,74 @@ class DeviceCropDataset(Dataset):
             ev = torch.cuda.Event()
             ev.record(self._stream)
             batch["_ready"] = ev
+        return batch
+
+    # -- slot workers (--workers N): the host half in other processes, handed over through shared memory -------------------
+    def to_slot(self, batch, slot):
+        """(worker) Write the arrays of a host batch into the shared slot (a uint8 numpy view); -> the picklable skeleton
+        (array descriptors instead of arrays) the parent rebuilds the batch from, or None when the slot is too small."""
+        meta = batch.pop("_crop_meta")
+        try:
+            plan = self.plan(meta)
+        except _PoolMiss:
+            plan = None
+        pos = [0]
+
+        def put(a):
+            a = np.ascontiguousarray(a)
+            o = (pos[0] + 7) // 8 * 8
+            if o + a.nbytes > slot.size:
+                raise MemoryError
+            slot[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+            pos[0] = o + a.nbytes
+            return ("__arr__", o, a.shape, a.dtype.str)
+
+        skel = {}
+        try:
+            for k, v in batch.items():
+                if k in ("in_xy", "gt_xy", "in_dxdy", "gt_dxdy"):
+                    skel[k] = ("__rows__", int(v.shape[0]))  # (slices of _traj_base, re-cut by the parent)
+                elif torch.is_tensor(v):
+                    skel[k] = ("__tensor__",) + put(v.numpy())[1:]
+                elif k == "occupancy":
+                    skel[k] = ("__empties__", len(v))
+                else:
+                    skel[k] = v
+            if plan is not None:
+                skel["_crop_plan"] = dict(plan, arrays=[put(a) for a in plan["arrays"]])
+            else:
+                skel["_crop_meta"] = tuple(put(a) if isinstance(a, np.ndarray) else a for a in meta)
+        except MemoryError:
+            return None
+        return skel
+
+    @staticmethod
+    def from_slot(skel, slot):
+        """(parent) The batch of a skeleton; its arrays are views of the slot (finish copies them out at once)."""
+        def arr(d):
+            _, o, shape, dt = d
+            dt = np.dtype(dt)
+            n = int(np.prod(shape)) * dt.itemsize
+            return slot[o:o + n].view(dt).reshape(shape)
+
+        is_arr = lambda v: isinstance(v, tuple) and len(v) == 4 and v[0] in ("__arr__", "__tensor__")
+        batch = {}
+        for k, v in skel.items():
+            if is_arr(v):
+                batch[k] = torch.from_numpy(arr(v)) if v[0] == "__tensor__" else arr(v)
+            elif isinstance(v, tuple) and v and v[0] == "__empties__":
+                batch[k] = tuple(torch.empty(1) for _ in range(v[1]))
+            else:
+                batch[k] = v
+        base, t0 = batch["_traj_base"], 0
+        for k in ("in_xy", "gt_xy", "in_dxdy", "gt_dxdy"):
+            rows = skel[k][1]
+            batch[k] = base[t0:t0 + rows]
+            t0 += rows
+        if "_crop_plan" in batch:
+            batch["_crop_plan"] = dict(batch["_crop_plan"], arrays=[arr(d) for d in batch["_crop_plan"]["arrays"]])
+        else:
+            batch["_crop_meta"] = tuple(arr(a) if is_arr(a) else a for a in batch["_crop_meta"])
         return batch
 
     def join_stream(self, batch, caller=None):
@@ -349,29 +436,151 @@ class DeviceCropDataset(Dataset):
         return self.finish(self.collate_host(data))
 
 
-def _seed_numpy_in_worker(_):
-    """torch seeds its own and Python's generator per loader worker, not numpy's -- and the augmentation draws come from
-    numpy's global generator (trajectories_scene.py:276-278): without this every worker would repeat the parent's draws."""
-    np.random.seed(torch.initial_seed() % (1 << 32))
+SLOT_BYTES = int(os.environ.get("MGGAN_LOADER_SLOT_MB", "8")) << 20
+SLOTS_PER_WORKER = 2
+NEXT_EPOCH_AHEAD = os.environ.get("MGGAN_LOADER_NEXT_EPOCH", "1") != "0"
+
+
+def _slot_worker(dds, conn, slots, seed):
+    """A loader worker process: the host half of the batches it is sent (indices -> trajectories, crop centres, the
+    augmentation's geometry, the launch plan), written into a shared-memory slot; only a small skeleton travels through the
+    pipe.  It never touches the GPU."""
+    try:
+        np.random.seed(seed)
+        torch.set_num_threads(1)
+        dds._frozen = True
+        views = [t.numpy() for t in slots]
+        while True:
+            try:
+                msg = conn.recv()
+            except (EOFError, KeyboardInterrupt):
+                break
+            if msg is None:
+                break
+            slot_id, indices = msg
+            try:
+                out = dds.to_slot(dds.__getitems__(indices)[0].batch, views[slot_id])
+            except BaseException as exc:  # noqa: BLE001  (re-raised in the parent)
+                out = exc
+            conn.send((slot_id, out))
+    finally:
+        os._exit(0)  # (no interpreter teardown: the fork inherited handles of the parent's device tensors and must not free them)
 
 
 class DeviceCropLoader:
-    """DataLoader whose workers do the host half of every batch (trajectory transforms, crop centres, the augmentation's
-    geometry) and whose consumer -- the process that owns the GPU -- does the device half (DeviceCropDataset.finish).
-    workers == 0: both halves in this process, the reference's draw order from numpy's global generator."""
+    """Loader of device-cropped batches.  workers == 0 (the reference's default): both halves of a batch in this process,
+    the augmentation draws in the reference's order from numpy's global generator.  workers > 0 (--workers N): the host half
+    (~1.6 ms of Python / numpy per 1,280-pedestrian batch) runs in N forked processes that write the batch into shared-
+    memory slots; this process -- the one that owns the GPU -- copies a slot into pinned memory, uploads it and launches the
+    crop kernel (~0.3 ms).  (torch's DataLoader workers pickle every tensor through a pipe: measured SLOWER than no workers.)
+    Batches arrive in sampler order; each worker draws its augmentations from a numpy generator seeded from the parent's."""
 
     def __init__(self, dds, batch_size, shuffle, workers):
         self.dataset, self.dds = dds, dds
-        kw = dict(num_workers=workers, worker_init_fn=_seed_numpy_in_worker, persistent_workers=True, prefetch_factor=4) if workers else {}
         self.loader = torch.utils.data.DataLoader(dds, batch_size=batch_size, shuffle=shuffle, collate_fn=dds.collate_host,
-                                                  drop_last=False, **kw)
+                                                  drop_last=False)
         self.batch_size = batch_size
+        self.n_workers = int(workers)
+        self._procs, self._ahead, self._rr = None, None, 0
+
+    def _start_workers(self):
+        import atexit
+        import multiprocessing as mp
+
+        ctx = mp.get_context("fork")
+        self._procs = []
+        for _ in range(self.n_workers):
+            slots = [torch.empty(SLOT_BYTES, dtype=torch.uint8).share_memory_() for _ in range(SLOTS_PER_WORKER)]
+            parent, child = ctx.Pipe()
+            pr = ctx.Process(target=_slot_worker, args=(self.dds, child, slots, int(np.random.randint(0, 2 ** 31 - 1))),
+                             daemon=True, name="mggan-loader-worker")
+            pr.start()
+            child.close()
+            self._procs.append({"proc": pr, "conn": parent, "slots": slots, "views": [t.numpy() for t in slots], "free":
+                                list(range(SLOTS_PER_WORKER))})
+        atexit.register(self.close)
+
+    def close(self):
+        for w in self._procs or []:
+            try:
+                w["conn"].send(None)
+                w["conn"].close()
+            except (OSError, BrokenPipeError):
+                pass
+        for w in self._procs or []:
+            w["proc"].join(timeout=2)
+            if w["proc"].is_alive():
+                w["proc"].terminate()
+        self._procs, self._ahead = None, None
+
+    def _iter_workers(self):
+        from collections import deque
+
+        if self._procs is None:
+            self._start_workers()
+        # (sampler iterator, requests in flight) of the epoch being produced; the FOLLOWING epoch's first requests go out as
+        # soon as this epoch's sampler is exhausted, so that an epoch does not start with the workers' latency (~2 ms)
+        batches, pending = self._ahead or (iter(self.loader.batch_sampler), deque())
+        self._ahead = None
+        nxt = None
+
+        def fill(it, pend):
+            """Send requests while the next worker in turn has a free slot; -> False once `it` is exhausted."""
+            while self._procs[self._rr]["free"]:
+                try:
+                    idx = next(it)
+                except StopIteration:
+                    return False
+                w = self._procs[self._rr]
+                sid = w["free"].pop()
+                w["conn"].send((sid, list(idx)))
+                pend.append((self._rr, sid, idx))
+                self._rr = (self._rr + 1) % len(self._procs)
+            return True
+
+        done = False
+        try:
+            while True:
+                if not done:
+                    done = not fill(batches, pending)
+                if done and NEXT_EPOCH_AHEAD:
+                    if nxt is None:
+                        nxt = (iter(self.loader.batch_sampler), deque())
+                    fill(*nxt)
+                if not pending:
+                    self._ahead, nxt = nxt, None
+                    return
+                wi, sid, idx = pending.popleft()
+                w = self._procs[wi]
+                got_sid, skel = w["conn"].recv()
+                assert got_sid == sid
+                if isinstance(skel, BaseException):
+                    w["free"].append(sid)
+                    raise skel
+                if skel is None:  # the batch does not fit a slot: its host half here, in this process
+                    batch = self.dds.finish(self.dds.collate_host(self.dds.__getitems__(list(idx))))
+                else:
+                    batch = self.dds.finish(self.dds.from_slot(skel, w["views"][sid]))  # (copies the slot out: it is free again)
+                w["free"].append(sid)
+                yield batch
+        finally:
+            # an abandoned epoch: drain what the workers still owe so that the next one starts clean
+            for pend in (pending, nxt[1] if nxt is not None else ()):
+                for wi, sid, _ in pend:
+                    try:
+                        self._procs[wi]["conn"].recv()
+                        self._procs[wi]["free"].append(sid)
+                    except (EOFError, OSError, TypeError):
+                        pass
 
     def __len__(self):
         return len(self.loader)
 
     def __iter__(self):
-        if not PREFETCH_THREAD or self.loader.num_workers:
+        if self.n_workers > 0:
+            yield from self._iter_workers()
+            return
+        if not PREFETCH_THREAD:
             for batch in self.loader:
                 yield self.dds.finish(batch)
             return

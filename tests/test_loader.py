@@ -129,3 +129,63 @@ def test_batched_host_half_equals_per_item_path(loader_golden, name, small, phas
     assert a["_crop_meta"][0] == b["_crop_meta"][0]
     for x, y in zip(a["_crop_meta"][1:], b["_crop_meta"][1:]):
         np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+
+
+@pytest.mark.parametrize("phase,aug", [("test", 0), ("train", 1)])
+def test_slot_round_trip_of_a_worker_batch(loader_golden, phase, aug):
+    """--workers N: a worker writes the host half of a batch (and its launch plan) into a shared-memory slot and sends a
+    skeleton; the parent's rebuilt batch equals the in-process one, array for array (CPU only)."""
+    import pickle
+
+    from mggan.data_utils.device_crops import DeviceCropDataset
+    from mggan.data_utils.trajectories_scene import TrajectoryDatasetEval
+
+    ds = TrajectoryDatasetEval(dataset_name="eth", phase=phase, margin_in=16, margin_out=16, load_occupancy=False,
+                               scaling_small=0.5, data_augmentation=aug)
+    dds = DeviceCropDataset(ds, "cpu")
+    idx = list(range(min(4, len(ds))))
+    np.random.seed(5)
+    ref = dds.__getitems__(idx)[0].batch
+    plan = dds.plan(ref["_crop_meta"])
+    np.random.seed(5)
+    slot = np.zeros(1 << 20, np.uint8)
+    skel = pickle.loads(pickle.dumps(dds.to_slot(dds.__getitems__(idx)[0].batch, slot)))  # (what crosses the pipe)
+    assert len(pickle.dumps(skel)) < 64 << 10
+    got = DeviceCropDataset.from_slot(skel, slot)
+    for k in ("in_xy", "gt_xy", "in_dxdy", "gt_dxdy", "size", "_traj_base"):
+        np.testing.assert_array_equal(got[k].numpy(), ref[k].numpy(), err_msg=k)
+    assert got["seq_start_end"] == ref["seq_start_end"] and got["scene_img"] == ref["scene_img"]
+    assert (got["loss_mask"] is None) == (ref["loss_mask"] is None) and len(got["occupancy"]) == len(ref["occupancy"])
+    gp = got["_crop_plan"]
+    assert {k: v for k, v in gp.items() if k != "arrays"} == {k: v for k, v in plan.items() if k != "arrays"}
+    for x, y in zip(gp["arrays"], plan["arrays"]):
+        assert x.dtype == y.dtype
+        np.testing.assert_array_equal(x, y)
+    assert dds.to_slot(dds.__getitems__(idx)[0].batch, np.zeros(64, np.uint8)) is None  # too small a slot: the parent's job
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("phase,aug", [("test", False), ("train", True)])
+def test_loader_workers_hand_over_the_same_batches(loader_golden, phase, aug, monkeypatch):
+    """get_dataloader(..., workers=2, crop_device=...): two forked processes do the host halves, the batches arrive in
+    sampler order and equal the in-process loader's (the augmentation draws are pinned to one rotation + flip so that the
+    processes' own generators do not matter), over two epochs (the workers persist)."""
+    from mggan.data_utils import trajectories_scene as TS
+    from mggan.data_utils.data_loaders import get_dataloader
+
+    if aug:
+        monkeypatch.setattr(TS.TrajectoryDatasetEval, "augmentation", lambda self: (0.7, 1))
+    one = get_dataloader("eth", phase, augment=aug, batch_size=2, crop_device="cuda")
+    two = get_dataloader("eth", phase, augment=aug, batch_size=2, crop_device="cuda", workers=2)
+    try:
+        for _ in range(2):
+            n = 0
+            for a, b in zip(one, two):
+                n += 1
+                for k in ("in_xy", "gt_xy", "in_dxdy", "gt_dxdy", "features"):
+                    assert b[k].is_cuda
+                    np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), err_msg=k)
+                assert a["seq_start_end"] == b["seq_start_end"] and a["scene_img"] == b["scene_img"]
+            assert n == len(one) == len(two) and n >= 2
+    finally:
+        two.close()
