@@ -626,8 +626,9 @@ int mggan_crop_patches_aug(const unsigned char* atlas, const void* items, const 
  * resized image, written as u8 RGB (sh, sw, 3) at small + small_off[item] -- and the crops as windows of those images
  * (mggan_crop_patches with atlas = small).  Same arithmetic, same bits; the host side picks the cheaper form per batch. */
 int mggan_aug_small_images(const unsigned char* atlas, const void* items, const int* tables, const int* tile_item,
-                           const int* tile_center, int n_tiles, int max_taps, const long long* small_off, unsigned char* small,
-                           mggan_stream_t stream);
+                           const int* tile_center, const int* tile_rows /* (n_tiles, 2) or NULL: rows [first, end) of the resized
+                           image this entry computes -- the host splits tiles into row bands when a batch has few */,
+                           int n_tiles, int max_taps, const long long* small_off, unsigned char* small, mggan_stream_t stream);
 /* n (<= 8) small buffers copied in ONE launch: `descs` = n records { const void* src; void* dst; long bytes; } (<= 64 KB each).
  * Snapshot / roll-back of the discriminator's BatchNorm running statistics (nn.BatchNorm2d buffers, reference
  * /root/reference/mggan/model/modules/cnn.py:140-141) around the next iteration's discriminator context when it is issued

@@ -4,6 +4,8 @@
 // the "small" scene image around the last observed position, RGB mapped to -1 + v*2/256, plus a one-hot centre
 // channel; pixels outside the image read 0 like PIL's crop.  HBM-bound byte work: one lane per output float,
 // consecutive lanes walk consecutive x (coalesced 4-byte stores, 3-byte-strided u8 loads served by L1/L2).
+#include <cstring>
+#include <cstdlib>
 #include "common.h"
 #include "../../include/mggan_hip.h"
 
@@ -95,13 +97,18 @@ __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned ch
                                                                const int* __restrict__ ped_item, const int* __restrict__ centers,
                                                                int margin, float* __restrict__ out,
                                                                const long long* __restrict__ small_off,
-                                                               unsigned char* __restrict__ small) {
+                                                               unsigned char* __restrict__ small, int plane_b, int tpad,
+                                                               int rows_cap, const int* __restrict__ bands) {
   // TILE MODE (small != NULL): the workgroup computes one 33 x 33 TILE of an item's whole resized image -- ped_item[p] is the
   // tile's item, centers[2p..] its centre -- as u8 RGB into small + small_off[item]; the crops are then windows of those
   // images (crop_patches_kernel).  Pedestrians of one item share its canvas and their windows overlap (a 33 x 33 window of a
   // 64 x 48 image): from a few pedestrians per item on, the whole image costs less than their windows one by one.
-  __shared__ __attribute__((aligned(16))) unsigned char stage[3 * AUG_PLANE + 16];  // a block of canvas rows, one plane per colour
-  __shared__ __attribute__((aligned(16))) unsigned char tmpT[AUG_L * AUG_TPAD];      // the horizontally resized strip, line (X, c) major
+  // dynamic LDS, sized by the launch from the batch's largest tap count (crop_aug_launch): at the usual 2-4x downscale a
+  // workgroup needs ~35 KB instead of the 62 KB of the largest case, and a CU holds four of them instead of two -- the staging
+  // gather is bound by latency, i.e. by the waves in flight
+  extern __shared__ __attribute__((aligned(16))) unsigned char aug_lds[];
+  unsigned char* stage = aug_lds;                  // a block of canvas rows, one plane (plane_b bytes) per colour
+  unsigned char* tmpT = aug_lds + 3 * plane_b + 16;  // the horizontally resized strip, line (X, c) major, tpad bytes per line
   __shared__ int sbv[2 * AUG_SIDE_MAX];
   const int p = blockIdx.x, side = 2 * margin + 1, plane = side * side, tid = threadIdx.x;
   const AugItem it = items[ped_item[p]];
@@ -109,7 +116,10 @@ __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned ch
   unsigned char* so = small ? small + small_off[ped_item[p]] : nullptr;
   const int X0 = centers[2 * p] - margin, Y0 = centers[2 * p + 1] - margin;
   // the window's part inside the small image; everything else reads 0 like Image.crop
-  const int Xa = max(X0, 0), Xb = min(X0 + side, it.sw), Ya = max(Y0, 0), Yb = min(Y0 + side, it.sh);
+  // (bands, tile mode: the workgroup computes rows [bands[2p], bands[2p + 1]) of its tile only -- a batch of few tiles is
+  //  split into row bands so that the launch fills the chip)
+  const int Xa = max(X0, 0), Xb = min(X0 + side, it.sw);
+  const int Ya = max(max(Y0, 0), bands ? bands[2 * p] : 0), Yb = min(min(Y0 + side, it.sh), bands ? bands[2 * p + 1] : it.sh);
   if (o)
     for (int i = tid; i < 4 * plane; i += 256) {
       const int c = i / plane, r = i % plane;
@@ -122,12 +132,12 @@ __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned ch
   const int* kv = tables + it.kv;
   // (first source row, taps) of the window's output rows: read once (the strip loop and the vertical pass walk them)
   if (tid < 2 * (Yb - Ya)) sbv[tid] = tables[it.bv + 2 * Ya + tid];
-  for (int i = tid; i < AUG_L * AUG_TPAD / 4; i += 256) reinterpret_cast<unsigned*>(tmpT)[i] = 0u;  // (slack bytes: finite)
+  for (int i = tid; i < AUG_L * tpad / 4; i += 256) reinterpret_cast<unsigned*>(tmpT)[i] = 0u;  // (slack bytes: finite)
   __syncthreads();
   const int* bv = sbv - 2 * Ya;
   const int xlo = bh[2 * Xa], xhi = bh[2 * (Xb - 1)] + bh[2 * (Xb - 1) + 1], span = xhi - xlo;
   const int span_pad = (span + KS + 7) & ~3;          // a thread reads KS (+4) bytes from its first tap on: slack behind the row
-  const int R = min(16, AUG_STAGE / span_pad);          // canvas rows staged per block
+  const int R = min(16, (plane_b - 44) / span_pad);          // canvas rows staged per block
   // horizontal pass: thread (l, half) = output column / channel l of the rows half, half + 2, ... of a staged block
   const int l = tid % AUG_L, half = tid / AUG_L;
   const bool hthread = tid < 2 * AUG_L && l < nL;
@@ -151,10 +161,10 @@ __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned ch
                  ua4 = (unsigned)it.a[4], ua5 = (unsigned)it.a[5];
   int Ys = Ya;
   while (Ys < Yb) {
-    // strip [Ys, Ye): as many output rows as keep the source rows within AUG_ROWS
+    // strip [Ys, Ye): as many output rows as keep the source rows within rows_cap
     const int ylo = bv[2 * Ys];
     int Ye = Ys + 1;
-    while (Ye < Yb && bv[2 * Ye] + bv[2 * Ye + 1] - ylo <= AUG_ROWS) ++Ye;
+    while (Ye < Yb && bv[2 * Ye] + bv[2 * Ye + 1] - ylo <= rows_cap) ++Ye;
     const int yhi = bv[2 * (Ye - 1)] + bv[2 * (Ye - 1) + 1];
     for (int yb = ylo; yb < yhi; yb += R) {
       const int nr = min(R, yhi - yb);
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned ch
               unsigned* at = reinterpret_cast<unsigned*>(stage + (rh + r) * span_pad + j4);  // (span_pad and j4 are multiples of 4)
 #pragma unroll
               for (int c = 0; c < 3; ++c)
-                at[c * (AUG_PLANE / 4)] = ((v[r][0] >> (8 * c)) & 0xffu) | (((v[r][1] >> (8 * c)) & 0xffu) << 8) |
+                at[c * (plane_b / 4)] = ((v[r][0] >> (8 * c)) & 0xffu) | (((v[r][1] >> (8 * c)) & 0xffu) << 8) |
                                           (((v[r][2] >> (8 * c)) & 0xffu) << 16) | (((v[r][3] >> (8 * c)) & 0xffu) << 24);
             }
         }
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned ch
       // ---- horizontal pass over the staged rows: aligned words, re-aligned to the thread's first tap, four taps per dot4 ----
       if (hthread) {
         for (int r = half; r < nr; r += 2) {
-          const unsigned char* row = stage + ch * AUG_PLANE + r * span_pad + hx0;
+          const unsigned char* row = stage + ch * plane_b + r * span_pad + hx0;
           const int phase = (int)((size_t)row & 3);
           const unsigned* wp = reinterpret_cast<const unsigned*>(row - phase);
           AugAcc acc;
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned ch
             acc.taps(__builtin_amdgcn_alignbyte(w1, w0, phase), k0[q], k1[q], k2[q]);
             w0 = w1;
           }
-          tmpT[l * AUG_TPAD + (yb + r - ylo)] = (unsigned char)aug_clip8(acc.value());
+          tmpT[l * tpad + (yb + r - ylo)] = (unsigned char)aug_clip8(acc.value());
         }
       }
       __syncthreads();
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256) void crop_patches_aug_kernel(const unsigned ch
     __syncthreads();
     for (int i = tid; i < (Ye - Ys) * nL; i += 256) {
       const int Y = Ys + i / nL, ll = i % nL;
-      const unsigned char* col = tmpT + ll * AUG_TPAD + (bv[2 * Y] - ylo);
+      const unsigned char* col = tmpT + ll * tpad + (bv[2 * Y] - ylo);
       const int phase = (int)((size_t)col & 3);
       const unsigned* wp = reinterpret_cast<const unsigned*>(col - phase);
       const unsigned* kq = kvp + 3 * (Y - Ys) * qv;
@@ -356,14 +366,33 @@ int mggan_crop_patches(const unsigned char* atlas, const long long* img_off, con
 
 static int crop_aug_launch(const unsigned char* atlas, const void* items, const int* tables, const int* ped_item, const int* centers,
                            int n, int margin, int max_taps, float* out, const long long* small_off, unsigned char* small,
-                           hipStream_t stream) {
+                           const int* bands, hipStream_t stream) {
   const AugItem* it = (const AugItem*)items;
+  // LDS of a workgroup from the batch's largest tap count: Lanczos taps = 2 * ceil(3 * scale) + 1, so scale <= taps / 6; a
+  // window of 33 output pixels spans <= 33 * scale + taps source pixels in either direction
+  const int ks = max_taps <= 32 ? 32 : max_taps <= 64 ? 64 : max_taps <= 96 ? 96 : 128, taps_in = max_taps;
+  static const bool lds_max = [] { const char* e = getenv("MGGAN_CROP_LDS"); return e && !strcmp(e, "max"); }();  // (A/B knob)
+  if (lds_max) max_taps = AUG_KS_MAX;
+  const int reach = (int)(33.0 * (max_taps > 6 ? max_taps / 6.0 : 1.0)) + 1 + max_taps;
+  int rows_cap = reach + 8 + 32;
+  if (rows_cap > AUG_ROWS) rows_cap = AUG_ROWS;
+  int tpad = rows_cap + ks + 12;
+  tpad = (tpad + 3) / 4;
+  if (!(tpad & 1)) ++tpad;  // (an odd number of words per line: the lines of neighbouring (X, c) start on different banks)
+  tpad *= 4;
+  long plane_b = 16L * (reach + ks + 16) + 44;   // sixteen staged rows; also >= the packed vertical coefficients of a strip
+  if (3 * plane_b < 33L * (ks / 4) * 12 + 64) plane_b = (33L * (ks / 4) * 12 + 64) / 3 + 4;
+  if (plane_b > AUG_PLANE) plane_b = AUG_PLANE;
+  long words = (plane_b + 3) / 4;
+  words += (11 - words % 32 + 32) % 32;          // planes 11 banks apart: the three channels of a column on different banks
+  plane_b = words * 4;
+  const size_t dyn = (size_t)3 * plane_b + 16 + (size_t)AUG_L * tpad;
   // (the coefficient row of an output column lives in registers: instantiated per tap count, rounded up)
-#define AUG_LAUNCH(KS) MG_LAUNCH((crop_patches_aug_kernel<KS>), dim3(n), dim3(256), 0, stream, atlas, it, tables, ped_item, centers, \
-                                 margin, out, small_off, small)
-  if (max_taps <= 32) AUG_LAUNCH(32);
-  else if (max_taps <= 64) AUG_LAUNCH(64);
-  else if (max_taps <= 96) AUG_LAUNCH(96);
+#define AUG_LAUNCH(KS) MG_LAUNCH((crop_patches_aug_kernel<KS>), dim3(n), dim3(256), dyn, stream, atlas, it, tables, ped_item, centers, \
+                                 margin, out, small_off, small, (int)plane_b, tpad, rows_cap, bands)
+  if (taps_in <= 32) AUG_LAUNCH(32);
+  else if (taps_in <= 64) AUG_LAUNCH(64);
+  else if (taps_in <= 96) AUG_LAUNCH(96);
   else AUG_LAUNCH(128);
 #undef AUG_LAUNCH
   return MGGAN_OK;
@@ -377,7 +406,7 @@ int mggan_crop_patches_aug(const unsigned char* atlas, const void* items, const 
   if (n == 0) return MGGAN_OK;
   MG_CHECK_ARG(atlas && items && tables && ped_item && centers && out, "crop_patches_aug: null pointer");
   static_assert(sizeof(AugItem) == 26 * 4, "AugItem is 26 int32 words");
-  crop_aug_launch(atlas, items, tables, ped_item, centers, n, margin, max_taps, out, nullptr, nullptr, stream);
+  crop_aug_launch(atlas, items, tables, ped_item, centers, n, margin, max_taps, out, nullptr, nullptr, nullptr, stream);
   MG_LAUNCH_CHECK("crop_patches_aug");
   return MGGAN_OK;
 }
@@ -385,13 +414,14 @@ int mggan_crop_patches_aug(const unsigned char* atlas, const void* items, const 
 /* The whole resized image of every item, tile by tile: tile p (of n_tiles) belongs to item tile_item[p] and is the 33 x 33 block
    around tile_center[2p..] of that item's resized image; u8 RGB (sh, sw, 3) at small + small_off[item]. */
 int mggan_aug_small_images(const unsigned char* atlas, const void* items, const int* tables, const int* tile_item,
-                           const int* tile_center, int n_tiles, int max_taps, const long long* small_off, unsigned char* small,
-                           hipStream_t stream) {
+                           const int* tile_center, const int* tile_rows, int n_tiles, int max_taps, const long long* small_off,
+                           unsigned char* small, hipStream_t stream) {
   MG_CHECK_ARG(n_tiles >= 0 && max_taps >= 1 && max_taps <= AUG_KS_MAX, "aug_small_images: bad arguments");
   if (n_tiles == 0) return MGGAN_OK;
   MG_CHECK_ARG(atlas && items && tables && tile_item && tile_center && small_off && small, "aug_small_images: null pointer");
   const int n = n_tiles;
-  crop_aug_launch(atlas, items, tables, tile_item, tile_center, n, (AUG_SIDE_MAX - 1) / 2, max_taps, nullptr, small_off, small, stream);
+  crop_aug_launch(atlas, items, tables, tile_item, tile_center, n, (AUG_SIDE_MAX - 1) / 2, max_taps, nullptr, small_off, small,
+                  tile_rows, stream);
   MG_LAUNCH_CHECK("aug_small_images");
   return MGGAN_OK;
 }

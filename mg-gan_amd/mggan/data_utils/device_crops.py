@@ -20,6 +20,8 @@ import os
 
 KS_MAX, SPAN_MAX = 128, 800  # csrc/crop.hip: AUG_KS_MAX, AUG_SPAN_MAX
 TILE_MODE = os.environ.get("MGGAN_CROP_TILES", "1") != "0"  # whole resized images first when that is less work (A/B knob)
+TILE_BANDS_MAX = int(os.environ.get("MGGAN_CROP_BANDS", "4"))  # row bands per tile at most (1: whole tiles)
+TILE_WGS = 900  # ... aimed at about this many workgroups per launch (256 CUs x 3-4 resident)
 LOADER_STREAM_PRIORITY = int(os.environ.get("MGGAN_LOADER_STREAM_PRIORITY", "0"))
 PREFETCH_THREAD = os.environ.get("MGGAN_LOADER_THREAD", "0") == "1"  # one batch ahead on a thread of the loader's own: measured
 #   SLOWER (2.34 vs 2.17-2.26 ms per 1,280-pedestrian iteration of train(); the loader alone 565 k vs 725 k pedestrians/s): both
@@ -266,9 +268,17 @@ class DeviceCropDataset(Dataset):
             t_ctr = np.concatenate([np.stack([16 + 33 * (np.arange(a * b) % a), 16 + 33 * (np.arange(a * b) // a)], 1)
                                     for a, b in zip(tx, ty)]).astype(np.int32)
             pi = meta[2]
+            # few tiles (a strong downscale: each is a long serial job): split them into row bands until the launch has a few
+            # workgroups per CU -- a band recomputes the source rows its taps share with its neighbours (+30 % work at three
+            # bands and scale 10), the launch is 2x shorter
+            nb = int(min(TILE_BANDS_MAX, max(1, TILE_WGS // max(len(t_item), 1))))
+            rows = 33 // nb
+            lo = t_ctr[:, 1] - 16
+            t_rows = np.stack([np.stack([lo + k * rows, (lo + (k + 1) * rows) if k < nb - 1 else lo + 33], 1) for k in range(nb)], 1)
+            t_item, t_ctr, t_rows = np.repeat(t_item, nb), np.repeat(t_ctr, nb, axis=0), t_rows.reshape(-1, 2).astype(np.int32)
             return {"kind": "tiles", "n": n, "tiles": int(t_item.shape[0]), "max_taps": int(recs[:, 16].max()),
                     "small_bytes": int((sw * sh * 3).sum()) + 8,
-                    "arrays": [recs, t_item, t_ctr, small_off, small_off[pi], np.stack([sh[pi], sw[pi]], 1).astype(np.int32),
+                    "arrays": [recs, t_item, t_ctr, t_rows, small_off, small_off[pi], np.stack([sh[pi], sw[pi]], 1).astype(np.int32),
                                meta[3]]}
         return {"kind": "windows", "n": n, "max_taps": int(recs[:, 16].max()), "arrays": [recs, meta[2], meta[3]]}
 
@@ -325,9 +335,10 @@ class DeviceCropDataset(Dataset):
                 self._pool_dev = torch.from_numpy(np.concatenate(self._pool)).to(self.device)
             if plan["kind"] == "tiles":
                 small = torch.empty(plan["small_bytes"], dtype=torch.uint8, device=self.device)
-                (items, d_ti, d_tc, d_so, off, hw, ctr), dev = pack(plan["arrays"])
+                (items, d_ti, d_tc, d_tr, d_so, off, hw, ctr), dev = pack(plan["arrays"])
                 lib.mggan_aug_small_images(self.atlas.data_ptr(), items.data_ptr(), self._pool_dev.data_ptr(), d_ti.data_ptr(),
-                                           d_tc.data_ptr(), plan["tiles"], plan["max_taps"], d_so.data_ptr(), small.data_ptr(), st)
+                                           d_tc.data_ptr(), d_tr.data_ptr(), plan["tiles"], plan["max_taps"], d_so.data_ptr(),
+                                           small.data_ptr(), st)
                 lib.mggan_crop_patches(small.data_ptr(), off.data_ptr(), hw.data_ptr(), ctr.data_ptr(), n, m, out.data_ptr(), st)
                 self._keep = (dev, small, self._pool_dev)
             elif plan["kind"] == "windows":
