@@ -142,7 +142,13 @@ class _LazyLib:
     def __getattr__(self, name):
         if name.startswith("__"):
             raise AttributeError(name)
-        return getattr(load(), name)
+        v = getattr(load(), name)
+        if callable(v) and name.startswith("mggan_"):
+            # an entry's wrapper is fixed for the life of the process (tracing / marks are read inside it): from the second
+            # use on `lib.mggan_x` is a plain instance attribute -- ~130 C-ABI calls per eager iteration came through two
+            # Python-level __getattr__ each
+            self.__dict__[name] = v
+        return v
 
 
 def start_trace():

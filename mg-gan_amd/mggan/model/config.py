@@ -11,7 +11,7 @@ def check_widths(config):
     """The kernels of libmggan_hip.so are instantiated for the reference's DEFAULT widths (config.py:70-71 there:
     --h_dim 32 -> generator encoder / social features 32, discriminator encoder 64; --decoder_h_dim 32 -> rollout LSTM 32,
     step embedding 16) and for noise vectors whose length is a multiple of 4.  NARROWER models (2 <= width <= 32) run on the
-    same kernels zero-padded (mggan/model/widths.py; attention pooling and the multi-generator model only); wider ones are
+    same kernels zero-padded (mggan/model/widths.py); wider ones are
     refused HERE -- at parse time and again in construct_model -- with a ValueError, before a module is built or a kernel
     launched."""
     bad = []
@@ -24,13 +24,8 @@ def check_widths(config):
     z = int(getattr(config, "noise_dim", 8))
     if z < 4 or z % 4:
         bad.append("--noise_dim {} (built: positive multiples of 4)".format(z))
-    if narrow and not bad:
-        if getattr(config, "pool_type", "sways") != "sways":
-            bad.append("--pool_type sgan at a narrower width (the padded layout is defined for the attention pooling)")
-        if getattr(config, "experiment", "multi_generator") != "multi_generator":
-            bad.append("--experiment discrete at a narrower width")
-        if int(getattr(config, "n_social_modules", 1)) <= 0:
-            bad.append("--n_social_modules 0 at a narrower width")
+    if narrow and not bad and int(getattr(config, "n_social_modules", 1)) <= 0:
+        bad.append("--n_social_modules 0 at a narrower width")
     if bad:
         raise ValueError("not built on the HIP path: " + "; ".join(bad) + ".  libmggan_hip.so instantiates its LSTM, social-"
                          "attention and rollout kernels for the reference's default widths (DESIGN.md section 9).")

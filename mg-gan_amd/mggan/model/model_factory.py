@@ -46,8 +46,8 @@ def construct_model(config):
         rng_state = torch.get_rng_state()
         G, D = _build(config, widths.BUILT_H, widths.BUILT_DH, num_discs, unbound_output)
         torch.set_rng_state(rng_state)
-        widths.attach(G, widths.generator_rules(h, dh, int(config.noise_dim)))
-        widths.attach(D, widths.discriminator_rules(h))
+        widths.attach(G, widths.generator_rules(h, dh, int(config.noise_dim), config.pool_type, config.experiment == "discrete"))
+        widths.attach(D, widths.discriminator_rules(h, config.pool_type))
         G.load_state_dict(Gl.state_dict())
         D.load_state_dict(Dl.state_dict())
         assert widths.padding_is_zero(G) and widths.padding_is_zero(D)

@@ -44,17 +44,31 @@ def _gates(pw, lw):
     return [(pw, lw)] * 4
 
 
-def generator_rules(h, dh, z):
-    e, hm, dm = dh // 2, h // 2, dh // 2
-    dec = r"(?:gs\.\d+|G_\d+)\."
-    return [
+def generator_rules(h, dh, z, pool_type="sways", discrete=False):
+    """MultiGenerator (standard.py:17-109) or DiscreteLatentGenerator (standard_discrete.py:18-106: ONE decoder, embeddings of
+    16 whatever --decoder_h_dim says, the encoded generator id between enc_h and the noise)."""
+    e = 16 if discrete else dh // 2
+    hm, dm = h // 2, dh // 2
+    dec = r"decoder\." if discrete else r"(?:gs\.\d+|G_\d+)\."
+    if pool_type == "sways":
+        social = [
+            (r"social\.feature_embedder\.fc\.4\.(weight|bias)", _p(32, h), None),
+            (r"social\.attention\.W\.weight", _p(32, h), _p(32, h)),
+            (r"social\.attention\.W\.bias", _p(32, h), None),
+        ]
+    else:  # PoolHiddenNet (social_gan.py:157-229): [position embedding | hidden] -> h -> bottleneck = h, max over the scene
+        social = [
+            (r"social\.spatial_embedding\.(weight|bias)", _p(16, e), None),
+            (r"social\.mlp_pre_pool\.0\.weight", _p(32, h), [(16, e), (32, h)]),
+            (r"social\.mlp_pre_pool\.0\.bias", _p(32, h), None),
+            (r"social\.mlp_pre_pool\.2\.weight", _p(32, h), _p(32, h)),
+            (r"social\.mlp_pre_pool\.2\.bias", _p(32, h), None),
+        ]
+    return social + [
         (r"encoder\.embedding\.(weight|bias)", _p(16, e), None),
         (r"encoder\.encoder\.weight_ih_l0", _gates(32, h), _p(16, e)),
         (r"encoder\.encoder\.weight_hh_l0", _gates(32, h), _p(32, h)),
         (r"encoder\.encoder\.bias_[ih]h_l0", _gates(32, h), None),
-        (r"social\.feature_embedder\.fc\.4\.(weight|bias)", _p(32, h), None),
-        (r"social\.attention\.W\.weight", _p(32, h), _p(32, h)),
-        (r"social\.attention\.W\.bias", _p(32, h), None),
         (dec + r"decoder\.weight_ih_l0", _gates(32, dh), _p(16, e)),
         (dec + r"decoder\.weight_hh_l0", _gates(32, dh), _p(32, dh)),
         (dec + r"decoder\.bias_[ih]h_l0", _gates(32, dh), None),
@@ -62,7 +76,7 @@ def generator_rules(h, dh, z):
         (dec + r"hidden2pos\.0\.weight", _p(16, dm), [(32, dh), (32, h)]),
         (dec + r"hidden2pos\.0\.bias", _p(16, dm), None),
         (dec + r"hidden2pos\.2\.weight", None, _p(16, dm)),
-        (r"enc_h_to_dec_h\.0\.weight", _p(32, dh), [(32, h), (64, 64), (32, h), (z, z)]),
+        (r"enc_h_to_dec_h\.0\.weight", _p(32, dh), [(32, h), (64, 64), (32, h), (z, z)] + ([(z, z)] if discrete else [])),
         (r"enc_h_to_dec_h\.0\.bias", _p(32, dh), None),
         (r"net_chooser\.0\.weight", _p(16, hm), [(32, h), (64, 64), (32, h)]),
         (r"net_chooser\.0\.bias", _p(16, hm), None),
@@ -72,12 +86,27 @@ def generator_rules(h, dh, z):
     ]
 
 
-def discriminator_rules(h):
+def discriminator_rules(h, pool_type="sways"):
     H, Q = 2 * h, h           # discriminators.py: h_dim = 2 * --h_dim; h_dim // 2
     M = (2 * H + 64) // 2     # hidden width of the classifier heads (:77-80)
-    cls_in = [(32, Q), (32, Q), (32, Q), (32, Q), (64, 64)]  # [soc(in | pred) | in | pred | scene]
+    enc = [(32, Q), (32, Q)]  # [in | pred]: the layout of `enc` and of everything that is a weighted sum of its rows
     head = r"(?:discs\.\d+|gen_id_reconstructor)\."
-    return [
+    if pool_type == "sways":
+        soc = enc             # attention pooling: soc = attention @ enc
+        social = [
+            (r"social\.feature_embedder\.fc\.4\.(weight|bias)", _p(64, H), None),
+            (r"social\.attention\.W\.weight", _p(64, H), enc),
+            (r"social\.attention\.W\.bias", _p(64, H), None),
+        ]
+    else:                     # PoolHiddenNet(embedding_dim=16, h_dim=H, bottleneck_dim=H) (discriminators.py:62-67)
+        soc = _p(64, H)
+        social = [
+            (r"social\.mlp_pre_pool\.0\.weight", _p(64, H), [(16, 16)] + enc),
+            (r"social\.mlp_pre_pool\.0\.bias", _p(64, H), None),
+            (r"social\.mlp_pre_pool\.2\.weight", _p(64, H), _p(64, H)),
+            (r"social\.mlp_pre_pool\.2\.bias", _p(64, H), None),
+        ]
+    return social + [
         (r"in_encoder\.embedding\.(weight|bias)", _p(64, H), None),
         (r"in_encoder\.encoder\.weight_[ih]h_l0", _gates(64, H), _p(64, H)),
         (r"in_encoder\.encoder\.bias_[ih]h_l0", _gates(64, H), None),
@@ -88,10 +117,7 @@ def discriminator_rules(h):
         (r"pred_encoder\.0\.(weight|bias)", _p(64, H), None),
         (r"pred_encoder\.2\.weight", _p(32, Q), _p(64, H)),
         (r"pred_encoder\.2\.bias", _p(32, Q), None),
-        (r"social\.feature_embedder\.fc\.4\.(weight|bias)", _p(64, H), None),
-        (r"social\.attention\.W\.weight", _p(64, H), [(32, Q), (32, Q)]),
-        (r"social\.attention\.W\.bias", _p(64, H), None),
-        (head + r"0\.weight", _p(96, M), cls_in),
+        (head + r"0\.weight", _p(96, M), soc + enc + [(64, 64)]),  # [soc | in | pred | scene]
         (head + r"0\.bias", _p(96, M), None),
         (head + r"2\.weight", None, _p(96, M)),
     ]

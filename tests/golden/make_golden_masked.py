@@ -135,3 +135,5 @@ if __name__ == "__main__":
     if "narrow" in which:  # widths below the built ones (config.py:70-71): the HIP path runs them zero-padded (mggan/model/widths.py)
         main("narrow_h16_g2", ["--h_dim", "16", "--decoder_h_dim", "16"], nan=False, keep_init=True)
         main("narrow_h24_d8_g2", ["--h_dim", "24", "--decoder_h_dim", "8", "--noise_dim", "4"], nan=True, keep_init=True)
+        main("narrow_sgan_g2", ["--pool_type", "sgan", "--h_dim", "16", "--decoder_h_dim", "24"], nan=False, keep_init=True)
+        main("narrow_discrete_g2", ["--experiment", "discrete", "--h_dim", "24", "--decoder_h_dim", "16"], nan=False, keep_init=True)

@@ -304,8 +304,7 @@ def test_static_scene_tables_layout():
 
 def test_widths_the_kernels_are_not_built_for_raise_before_any_launch():
     """--h_dim / --decoder_h_dim (reference config.py:70-71): libmggan_hip.so instantiates the default widths; narrower
-    models run on them zero-padded (mggan/model/widths.py, tests/test_variants.py), WIDER ones -- and narrower ones with the
-    variants the padded layout is not defined for -- are refused by the parser, construct_model and the module
+    models run on them zero-padded (mggan/model/widths.py, tests/test_variants.py), WIDER ones are refused by the parser, construct_model and the module
     constructors with a ValueError (nothing is built, nothing is launched -- this runs without a GPU)."""
     import argparse
 
@@ -316,7 +315,7 @@ def test_widths_the_kernels_are_not_built_for_raise_before_any_launch():
     from mggan.model.modules.social import SocialAttention
 
     for flags in (["--h_dim", "64"], ["--h_dim", "1"], ["--decoder_h_dim", "64"], ["--decoder_h_dim", "33"],
-                  ["--noise_dim", "6"], ["--h_dim", "16", "--pool_type", "sgan"], ["--decoder_h_dim", "8", "--experiment", "discrete"]):
+                  ["--noise_dim", "6"], ["--h_dim", "16", "--n_social_modules", "0"]):
         with pytest.raises(ValueError, match="not built on the HIP path"):
             get_parser().parse_args(flags)
     cfg = get_parser().parse_args(["--num_gens", "2", "--noise_dim", "12"])  # the defaults (and any multiple of 4) parse

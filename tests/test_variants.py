@@ -12,7 +12,7 @@ from conftest import GOLDEN
 from test_masked import STEPS, _batch, _check
 
 VARIANTS = ["obj_ls_g2", "obj_mm_g2", "wt_l2_g2", "wt_endpoint_g2", "wt_mgan_g2", "pool_sgan_g2", "discrete_g2",
-            "masked_sgan_g2", "narrow_h16_g2", "narrow_h24_d8_g2"]
+            "masked_sgan_g2", "narrow_h16_g2", "narrow_h24_d8_g2", "narrow_sgan_g2", "narrow_discrete_g2"]
 NARROW = [v for v in VARIANTS if v.startswith("narrow")]
 
 
