@@ -384,8 +384,11 @@ class MultiGeneratorGAN(abc.ABC):
             # scene crops on the GPU; the host half of a batch (trajectory transforms, the augmentation's geometry) runs where
             # --workers says -- in this process by default, like the reference's loader and with its numpy draw order; with
             # --workers N in N forked processes that hand their batches over through shared-memory slots
-            # (mggan/data_utils/device_crops.py: DeviceCropLoader)
+            # (mggan/data_utils/device_crops.py: DeviceCropLoader).  --rng device without --workers: two such processes
+            # (MGGAN_LOADER_WORKERS=0 keeps the host half in this process)
             kw["crop_device"] = self.device
+            if workers == 0 and getattr(cfg, "rng", "host") == "device" and (os.cpu_count() or 1) >= 8:
+                workers = 2  # (--rng device is not seed-identical with the reference anyway: take the loader processes)
             workers = int(os.environ.get("MGGAN_LOADER_WORKERS", str(workers)))
         pad = getattr(cfg, "graph_pad", "auto")
         graphs = self.iteration_graphs = IterationGraphs(
