@@ -652,9 +652,11 @@ def measure(tag, scenes, peds, num_gens, args, world, rank, dev, profile=True, g
             if isinstance(e, dict) and e.get("bytes_per_launch") is not None:
                 tot += float(e["bytes_per_launch"]) * calls
         hbm_step = round(tot) if tot > 0 else None
-    # the dominant kernel = the one with the largest share of the step's GPU time (summed over its launches), in the
-    # regime of the timed region when the marked replay is available
-    rows.sort(key=lambda r: replay_ms.get(r[4], r[0] if not replay_ms else 0.0), reverse=True)
+    # the dominant kernel = the one with the largest share of the step's GPU WORK: its launches' time when each runs alone
+    # on the GPU (rows[.][0]).  Its duration for `achieved` is the one inside graph replay (roof()); ranking by that duration
+    # instead made the block flip from run to run between the rollout adjoint and whichever small CNN kernel the replay had
+    # stretched most by running others beside it (conv1_pool_kernel<8>: 35 us alone, 60-100 us in the graph)
+    rows.sort(key=lambda r: r[0], reverse=True)
     roofline = roof(rows[0])
     roofline["note"] = ("f32 (exact) -- mfma: peak is the dense f32 vector/MFMA rate, achieved = algorithmic FLOPs per launch "
                         "(SURVEY App. D shapes) / average duration of a launch of this kernel INSIDE graph replay (device-clock "

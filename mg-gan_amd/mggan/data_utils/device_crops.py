@@ -91,7 +91,9 @@ class DeviceCropDataset(Dataset):
         if ring["events"][i] is not None:
             ring["events"][i].synchronize()
         if buf is None or buf.numel() < numel:
-            buf = ring["bufs"][i] = torch.empty(max(numel, 1024), dtype=dtype).pin_memory()
+            # (generously: a slot that met a one-element tensor first and the trajectories later would be pinned twice -- and
+            #  pinning costs milliseconds)
+            buf = ring["bufs"][i] = torch.empty(max(2 * numel, 1 << 18), dtype=dtype).pin_memory()
         ev = ring["events"][i] = torch.cuda.Event()
         self._pending_events.append(ev)
         return buf[:numel]
