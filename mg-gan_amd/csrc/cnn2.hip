@@ -228,17 +228,26 @@ __device__ __forceinline__ void bn_bwd_finalize_block(BnBwdFin fin, int C, doubl
 // (B = row 36 of P, n = P[36][36]).  f64 throughout: the variance is a difference of two such sums.  Every thread of the
 // workgroup calls it; sums: 2C doubles of LDS.
 __device__ __forceinline__ void bn1_from_gram_block(const double* __restrict__ gram, int C, const float* __restrict__ W,
-                                                    const float* __restrict__ bias, BnFin fin, double* sums) {
+                                                    const float* __restrict__ bias, BnFin fin, double* sums,
+                                                    double* rs /* C * 36 doubles of LDS */) {
   const int c = threadIdx.x;
   const double n = gram[36 * NTAP + 36];
+  // (W_c P)_t for every (channel, tap) on all threads first -- as ONE thread per channel walking its 36 x 36 products this was
+  // 25 us at the end of the launch's first workgroup (conv1_pool_kernel<8>: 45 -> 73 us in sharded training); the sums over
+  // the taps stay sequential per channel, in the same order: the same bits
+  for (int i = threadIdx.x; i < C * 36; i += blockDim.x) {
+    const int ch = i / 36, t = i - ch * 36;
+    double r = 0.0;
+    for (int u = 0; u < 36; ++u) r += (double)W[ch * 36 + u] * gram[u * NTAP + t];
+    rs[i] = r;
+  }
+  __syncthreads();
   if (c < C) {
     double s = 0.0, q = 0.0;
     for (int t = 0; t < 36; ++t) {
       const double wt = (double)W[c * 36 + t];
       s += wt * gram[36 * NTAP + t];
-      double r = 0.0;
-      for (int u = 0; u < 36; ++u) r += (double)W[c * 36 + u] * gram[u * NTAP + t];
-      q += wt * r;
+      q += wt * rs[c * 36 + t];
     }
     const double b = (double)bias[c];
     sums[c] = s + n * b;
@@ -371,7 +380,8 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(int B, const float* __r
   if (gram) {
     // sharded training: the GLOBAL statistics of this layer follow from the global Gram matrix and the weights alone
     // (nothing this launch computed enters them): workgroup 0 writes scale / shift / running statistics on its way out
-    if (blockIdx.x == 0) bn1_from_gram_block(gram, C, W, bias, fin, colsum);
+    if (blockIdx.x == 0) bn1_from_gram_block(gram, C, W, bias, fin, colsum, reinterpret_cast<double*>(imgp));  // (the image
+    //                                                                       tile is free: every wave is behind the barrier above)
     return;
   }
   if (!fin.ticket) return;
@@ -1299,7 +1309,8 @@ __global__ __launch_bounds__(64) void bn1_from_gram_kernel(const double* __restr
                                                            const float* __restrict__ W, const float* __restrict__ bias,
                                                            BnFin fin) {
   __shared__ double sums[64];
-  bn1_from_gram_block(gram, C, W, bias, fin, sums);
+  __shared__ double rs[16 * 36];
+  bn1_from_gram_block(gram, C, W, bias, fin, sums, rs);
 }
 
 // Backward: what the layer-1 adjoint needs of the other ranks -- the BatchNorm-1 adjoint sums S1 = sum g, S2 = sum g xhat and

@@ -990,21 +990,33 @@ __global__ __launch_bounds__(256) void sample_counts_kernel(int b, int K, int g,
   __shared__ int last;
   if (threadIdx.x < BR_MAXG) hist[threadIdx.x] = 0;
   __syncthreads();
-  const int ped = blockIdx.x * 256 + threadIdx.x;  // a lane is a pedestrian: its CDF once, its K picks in sample order
-  if (ped < b) {
-    float cdf[BR_MAXG], run;
-    sb_build(logits + (size_t)ped * g, g, cdf, run);
-    unsigned long long packed[2] = {0ull, 0ull};  // 16 byte counters (K <= 255)
-    for (int k = 0; k < K; ++k) {
-      const int pick = sb_pick(cdf, g, u[(size_t)ped * K + k] * run);
-      packed[pick >> 3] += 1ull << (8 * (pick & 7));
+  // a lane is ONE draw (pedestrian i / K, sample i % K): coalesced reads of the uniforms and b * K / 256 workgroups -- as a
+  // lane per pedestrian walking its K draws (a stride-K read each) this was 21-37 us on the discriminator step's chain at
+  // 1,280 pedestrians x 20 samples; the CDF is rebuilt per draw (g exponentials) with the same calls: the same picks
+  // (a handful of workgroups walking the draws grid-strided: every workgroup ends with g atomics on the same g words, and
+  //  a hundred workgroups queued 20 us of them)
+  // ... and the picks of a wave are counted with ballots (64 lanes adding to the same g LDS words one after the other were
+  //  most of what was left): lane c < g keeps the wave's count of generator c
+  int mine = 0;
+  const long total = (long)b * K;
+  for (long i0 = (long)blockIdx.x * 256; i0 < total; i0 += (long)gridDim.x * 256) {  // (uniform trip count per workgroup)
+    const long i = i0 + threadIdx.x;
+    int pick = -1;
+    if (i < total) {
+      const int ped = (int)(i / K);
+      float cdf[BR_MAXG], run;
+      sb_build(logits + (size_t)ped * g, g, cdf, run);
+      pick = sb_pick(cdf, g, u[i] * run);
     }
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int c = 0; c < BR_MAXG; ++c) {
-      const int n = (int)((packed[c >> 3] >> (8 * (c & 7))) & 0xffull);
-      if (n) atomicAdd(&hist[c], n);
-    }
+    for (int c = 0; c < BR_MAXG; ++c)
+      if (c < g) {
+        const int n = __popcll(__ballot(pick == c));
+        if (lane == c) mine += n;
+      }
   }
+  if ((threadIdx.x & 63) < g && mine) atomicAdd(&hist[threadIdx.x & 63], mine);
   __syncthreads();
   if (threadIdx.x < BR_MAXG && hist[threadIdx.x]) atomicAdd(&scratch[threadIdx.x], hist[threadIdx.x]);
   // the last workgroup hands the totals over as doubles and re-arms the scratch words (integer sums: order independent)
@@ -1447,7 +1459,13 @@ int mggan_sample_counts(int b, int K, int g, const float* logits, const float* u
                         hipStream_t stream) {
   MG_CHECK_ARG(out && scratch && b >= 1 && logits && u && g >= 1 && g <= BR_MAXG && K >= 0 && K <= 255,
                "sample_counts: bad arguments (1..16 generators, up to 255 samples)");
-  MG_LAUNCH(sample_counts_kernel, dim3(cdiv(b, 256)), dim3(256), 0, stream, b, K, g, logits, u, scratch, out);
+  if (K == 0) {
+    MG_CHECK_HIP(hipMemsetAsync(out, 0, BR_MAXG * sizeof(double), stream), "sample_counts: memset");
+    return MGGAN_OK;
+  }
+  long wgs = cdiv((long)b * K, 256);  // one draw per lane up to 256 workgroups (a round trip per draw: walking eight draws
+  if (wgs > 256) wgs = 256;           //  per lane in 13 workgroups took as long as the launch this replaced)
+  MG_LAUNCH(sample_counts_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, b, K, g, logits, u, scratch, out);
   MG_LAUNCH_CHECK("sample_counts");
   return MGGAN_OK;
 }

@@ -39,7 +39,19 @@ def main(scenes=64, peds=20, num_gens=4):
     if os.environ.get("MGGAN_MARKS_NODES") == "1":
         mark_every_backward_node()
     dev = torch.device("cuda", 0)
+    if os.environ.get("MGGAN_FORCE_DIST", "0") == "1":  # the sharded launch mode on one rank (as bench.py sets it up)
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group(os.environ.get("MGGAN_DIST_BACKEND", "nccl"), rank=0, world_size=1, device_id=dev)
     tr = bench.build_trainer(num_gens, "device", dev)
+    if tr.dist.enabled:
+        tr.dist.equal_shards = True  # (every rank holds the same number of images: no count exchange, capturable)
     batch = tr.to_device(synthetic.make_batch(synthetic.scene_sizes(scenes, peds), seed=0))
     batch["loss_mask"] = None
     tr.defer_metrics = True
