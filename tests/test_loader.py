@@ -189,3 +189,28 @@ def test_loader_workers_hand_over_the_same_batches(loader_golden, phase, aug, mo
             assert n == len(one) == len(two) and n >= 2
     finally:
         two.close()
+
+
+def test_slot_worker_without_the_tables_leaves_the_plan_to_the_parent(loader_golden):
+    """A loader worker whose copy of the Lanczos table pool lacks a size (datasets with too many scene sizes to build every
+    table ahead of time) sends the crop records unresolved; the parent resolves them against ITS pool: the same plan."""
+    from mggan.data_utils.device_crops import DeviceCropDataset
+    from mggan.data_utils.trajectories_scene import TrajectoryDatasetEval
+
+    ds = TrajectoryDatasetEval(dataset_name="eth", phase="train", margin_in=16, margin_out=16, load_occupancy=False,
+                               scaling_small=0.5, data_augmentation=1)
+    parent = DeviceCropDataset(ds, "cpu")
+    worker = DeviceCropDataset(ds, "cpu")
+    worker._pool, worker._pool_idx, worker._pool_len, worker._frozen = [], {}, 0, True  # (forked before any table existed)
+    idx = list(range(min(3, len(ds))))
+    np.random.seed(9)
+    want = parent.plan(parent.__getitems__(idx)[0].batch["_crop_meta"])
+    np.random.seed(9)
+    slot = np.zeros(1 << 20, np.uint8)
+    skel = worker.to_slot(worker.__getitems__(idx)[0].batch, slot)
+    assert "_crop_plan" not in skel and "_crop_meta" in skel
+    got = DeviceCropDataset.from_slot(skel, slot)
+    plan = parent.plan(got["_crop_meta"])
+    assert {k: v for k, v in plan.items() if k != "arrays"} == {k: v for k, v in want.items() if k != "arrays"}
+    for x, y in zip(plan["arrays"], want["arrays"]):
+        np.testing.assert_array_equal(x, y)
