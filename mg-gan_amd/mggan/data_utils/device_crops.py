@@ -565,6 +565,9 @@ class DeviceCropLoader:
                     return
                 wi, sid, idx = pending.popleft()
                 w = self._procs[wi]
+                while not w["conn"].poll(1.0):  # (a worker that died -- killed for memory, say -- must not hang the loop)
+                    if not w["proc"].is_alive():
+                        raise RuntimeError("loader worker {} exited with code {}".format(wi, w["proc"].exitcode))
                 got_sid, skel = w["conn"].recv()
                 assert got_sid == sid
                 if isinstance(skel, BaseException):
